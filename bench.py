@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- NLTGV2 primal-dual iterations/sec on a 640x480 Delaunay graph (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic input: `--iters` (200) x
+step(params, graph) on one 640x480-derived Delaunay graph per GPU (BASELINE.json configs[1]; with
+--gpus N each rank owns an independent frame = configs[3], results gathered with RCCL).  Inputs are
+resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+  python bench.py                         # 1 GPU, defaults finish in about a minute
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+
+Extra keys beyond the driver contract: "roofline" (dominant kernel vs the 8 TB/s HBM peak, from the
+algorithmic byte count 64*V+40*E per step), "cpu_baseline" (the CPU checker in the reference's
+node-based layout, 1 thread, timed here on the box's host cores), "parity" (this run's result vs the
+checker), "batched" (aggregate rate with many frames resident on one GPU), "other_configs".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=200, help="primal-dual iterations per step (BASELINE: 200)")
+    ap.add_argument("--config", default="640x480")
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU in the extra 'batched' measurement (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip batched / other-config measurements")
+    ap.add_argument("--cpu-iters", type=int, default=8000)
+    return ap.parse_args()
+
+
+def measure(reg, params, iters, steps, warmup, sync, barrier, after_step=None):
+    """warmup, then EXACTLY `steps` steps bracketed by barrier+synchronize.  Returns (wall seconds,
+    device ms summed over the steps' HIP-event regions)."""
+    for _ in range(warmup):
+        reg.run(params, iters)
+        if after_step:
+            after_step()
+    barrier()
+    sync()
+    ev_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ev_ms += reg.run_timed(params, iters)
+        if after_step:
+            after_step()
+    sync()
+    barrier()
+    t1 = time.perf_counter()
+    return t1 - t0, ev_ms
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import numpy as np
+    import torch  # first: one HIP runtime per process
+
+    import flame_amd
+    from flame_amd import synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def sync():
+        torch.cuda.synchronize()
+
+    params = flame_amd.Params()
+    # one independent frame per rank (BASELINE configs[3]); seeds differ so the frames differ
+    g = synth.make_graph(a.config, seed=1234 + rank)
+    reg = flame_amd.Regularizer(local_rank)
+    reg.upload_graph(g)
+    info = reg.info()
+
+    after_step = None
+    if dist is not None:
+        # result gather: x*graph_scale of every frame, padded to a common length, RCCL all_gather
+        vmax_t = torch.tensor([g["V"]], device="cuda", dtype=torch.int64)
+        dist.all_reduce(vmax_t, op=dist.ReduceOp.MAX)
+        vmax = int(vmax_t.item())
+        mine = torch.zeros(vmax, dtype=torch.float32, device="cuda")
+        gathered = torch.empty(world * vmax, dtype=torch.float32, device="cuda")
+
+        def after_step():
+            reg.export_idepth_device(mine.data_ptr(), 1.0)
+            dist.all_gather_into_tensor(gathered, mine)
+
+    wall, ev_ms = measure(reg, params, a.iters, a.steps, a.warmup, sync, barrier, after_step)
+    if dist is not None:
+        t = torch.tensor([wall], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    total_iters = world * a.steps * a.iters
+    value = total_iters / wall
+
+    out = None
+    if rank == 0:
+        B_iter = info["algorithmic_bytes_per_iter"]
+        # dominant kernel: k_fused_step, one launch per iteration.  Its own duration (no launch gaps),
+        # from HIP events bracketing single launches on the solver's stream:
+        kern_us = reg_profile_kernel(reg, params)
+        per_iter_us = ev_ms * 1e3 / (a.steps * a.iters)
+        achieved = B_iter / (kern_us * 1e-6) / 1e9
+        roofline = {
+            "bound": "hbm", "kernel": "k_fused_step", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": B_iter, "avg_launch_us": round(kern_us, 3),
+            "per_iteration_us_incl_gaps": round(per_iter_us, 3),
+            "frac_incl_gaps": round(B_iter / (per_iter_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+            "note": "single 640x480 graph is launch/latency bound (working set 1.6 MB lives in L2); see 'batched'",
+        }
+        out = {
+            "metric": "NLTGV2 primal-dual iters/sec on 640x480 Delaunay graph; depth RMS vs CPU",
+            "value": round(value, 1), "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(wall * 1e3 / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.config} Delaunay graph, V={g['V']} E={g['E']}, {a.iters} primal-dual iters per step, "
+                                   f"one frame per GPU", "iters_per_step": a.iters, "V": g["V"], "E": g["E"],
+                       "parallelism": f"frames x{world}" if world > 1 else "single frame"},
+            "roofline": roofline,
+            "device": {"name": info["device_name"], "arch": info["gcn_arch"], "cus": info["compute_units"]},
+        }
+        # ---- parity of THIS run's input against the CPU checker (same seeded input, same iteration count)
+        from oracle import capi as oracle
+
+        chk = flame_amd.Regularizer(local_rank)
+        chk.upload_graph(g)
+        chk.run(params, a.iters)
+        got = chk.download_state(("x", "w1", "w2"))
+        chk.close()
+        ref = synth.copy_graph(g)
+        oracle.run(ref, a.iters)
+        d = got["x"].astype(np.float64) - ref["x"].astype(np.float64)
+        out["parity"] = {"depth_rms_vs_cpu": float(np.sqrt(np.mean(d * d))), "max_abs": float(np.abs(d).max()),
+                         "bit_identical": bool(all(np.array_equal(got[k], ref[k]) for k in got)),
+                         "iters": a.iters, "tolerance_rms": 1e-4}
+        # ---- CPU baseline on this box's host cores: reference-layout restatement, 1 thread (the
+        # reference runs its solver on exactly one thread, flame.cc:99-112)
+        if not a.no_cpu_baseline:
+            secs = oracle.reflayout_run_timed(synth.copy_graph(g), a.cpu_iters)
+            flat = oracle.run_timed(synth.copy_graph(g), max(200, a.cpu_iters // 4))
+            out["cpu_baseline"] = {
+                "value": round(a.cpu_iters / secs, 1), "unit": "iters/s", "cores": 1, "kind": "port",
+                "sample": f"{a.cpu_iters} iterations of the same {a.config} graph (V={g['V']} E={g['E']}), "
+                          f"node-based (BGL-like) layout, 1 thread, {secs:.1f} s",
+                "flat_soa_1thread_iters_per_s": round(max(200, a.cpu_iters // 4) / flat, 1),
+                "host_cores": os.cpu_count(),
+            }
+            out["speedup_vs_cpu_baseline"] = round(value / world / out["cpu_baseline"]["value"], 1)
+    if not a.no_extras and world == 1:
+        extras(a, reg, params, out, flame_amd, synth, sync)
+    reg.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def reg_profile_kernel(reg, params, n=400):
+    """Mean duration (us) of ONE k_fused_step launch: eager launches, hipGraph off, each `run(1)`
+    bracketed by HIP events on the solver's stream (flame_nltgv2_run_timed)."""
+    from flame_amd.regularizer import OPT_USE_HIPGRAPH
+
+    reg.set_option(OPT_USE_HIPGRAPH, 0)
+    for _ in range(20):
+        reg.run_timed(params, 1)
+    ts = sorted(reg.run_timed(params, 1) for _ in range(n))
+    reg.set_option(OPT_USE_HIPGRAPH, 1)
+    core = ts[n // 10: n - n // 10]  # trimmed mean: drops the occasional host hiccup
+    return 1e3 * sum(core) / len(core)
+
+
+def extras(a, reg, params, out, flame_amd, synth, sync):
+    """Rank-0-only extra measurements (not part of `value`)."""
+    # (1) batched mode: B independent 640x480 frames resident on one GPU as a disjoint union
+    if a.batch > 0:
+        frames = [synth.make_graph(a.config, seed=5000 + i) for i in range(a.batch)]
+        union = synth.concat_graphs(frames)
+        b = flame_amd.Regularizer(0)
+        b.upload_graph(union)
+        bi = b.info()
+        iters = 50
+        b.run(params, iters)
+        ms = min(b.run_timed(params, iters) for _ in range(5))
+        kern_us = reg_profile_kernel(b, params, n=100)
+        per_iter_us = ms * 1e3 / iters
+        out["batched"] = {
+            "frames": a.batch, "V": bi["V"], "E": bi["E"],
+            "frame_iters_per_s": round(a.batch * iters / (ms * 1e-3), 1),
+            "per_iteration_us": round(per_iter_us, 2), "kernel_us": round(kern_us, 2),
+            "achieved_GBps": round(bi["algorithmic_bytes_per_iter"] / (kern_us * 1e-6) / 1e9, 1),
+            "frac": round(bi["algorithmic_bytes_per_iter"] / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+            "frac_incl_gaps": round(bi["algorithmic_bytes_per_iter"] / (per_iter_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+        }
+        b.close()
+    # (2) the other single-GPU BASELINE configs, 200 iterations each
+    oc = {}
+    for cfg in ("1280x720", "1920x1080"):
+        g = synth.make_graph(cfg, seed=1234)
+        r = flame_amd.Regularizer(0)
+        r.upload_graph(g)
+        r.run(params, 200)
+        ms = min(r.run_timed(params, 200) for _ in range(5))
+        kern_us = reg_profile_kernel(r, params, n=100)
+        bi = r.info()
+        oc[cfg] = {"V": g["V"], "E": g["E"], "iters_per_s": round(200 / (ms * 1e-3), 1), "kernel_us": round(kern_us, 3),
+                   "frac": round(bi["algorithmic_bytes_per_iter"] / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                   "frac_incl_gaps": round(bi["algorithmic_bytes_per_iter"] * 200 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+        r.close()
+    out["other_configs"] = oc
+
+
+if __name__ == "__main__":
+    main()

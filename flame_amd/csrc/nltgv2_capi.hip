@@ -1,0 +1,699 @@
+// nltgv2_capi.hip -- solver context and the C-ABI declared in include/flame_nltgv2.h.
+//
+// Host side of the drop-in boundary for flame::optimizers::nltgv2_l1_graph_regularizer
+// (/root/reference/src/flame/optimizers/nltgv2_l1_graph_regularizer.h:134-168).  The context owns
+// the device image of one reference Graph (h:107-112) in two forms:
+//   canonical  SoA arrays in the caller's vertex/edge order  (upload/download, the individually
+//              callable dual/primal/extragradient sweeps, costs)
+//   packed     SELL-64 layout of the fused one-kernel-per-step sweep (run)
+// and converts between them on the device only when the other form is asked for.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "flame_nltgv2.h"
+#include "nltgv2_kernels.h"
+#include "nltgv2_pack.hpp"
+
+using namespace flame_hip;
+
+namespace {
+
+constexpr int kGraphChunk = 256;      // steps per captured hipGraph (even: keeps ping-pong parity)
+constexpr int kCostPartials = 256;
+constexpr int kMaxCachedGraphs = 6;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct CachedGraph {
+  hipGraphExec_t exec = nullptr;
+  int n = 0, parity = 0, unroll = 0, wpb = 0;
+  uint64_t topo = 0;
+  flame_nltgv2_params params{};
+  uint64_t stamp = 0;
+};
+
+}  // namespace
+
+struct flame_nltgv2_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int last_error = 0;
+  int last_hip = 0;
+  hipDeviceProp_t prop{};
+
+  bool have_graph = false;
+  bool canon_valid = false, fused_valid = false, have_prev = false;
+  int parity = 0;
+  uint64_t topo = 0, stamp = 0;
+  bool pointers_changed = false;
+
+  int opt_solver = 0, opt_use_graph = 1, opt_block_waves = 0, opt_unroll = 0;
+
+  PackedLayout L;
+  CanonArgs c;
+  FusedArgs f;
+  std::vector<DevBuf*> all;
+  // canonical
+  DevBuf pos, x, w1, w2, xb, w1b, w2b, xp, w1p, w2p, data, weight, src, dst, alpha, beta, q1, q2, q3, row_ptr, half;
+  // packed
+  DevBuf slice_row, perm, pdeg, rec_nbr, rec_edge, edge_src_slot, hrec, hq, vstate, vaux, bar0, bar1, vprev;
+  // misc
+  DevBuf err, cost_pe, cost_pv, cost_out;
+  int* h_err = nullptr;    // pinned
+  float* h_cost = nullptr; // pinned
+  std::vector<CachedGraph> graphs;
+  size_t device_bytes = 0;
+};
+
+namespace {
+
+#define HIPCHK(ctx, expr)                              \
+  do {                                                 \
+    hipError_t _e = (expr);                            \
+    if (_e != hipSuccess) {                            \
+      (ctx)->last_hip = (int)_e;                       \
+      (ctx)->last_error = FLAME_NLTGV2_ERR_HIP;        \
+      return FLAME_NLTGV2_ERR_HIP;                     \
+    }                                                  \
+  } while (0)
+
+#define LAUNCHCHK(ctx, expr)                           \
+  do {                                                 \
+    int _e = (expr);                                   \
+    if (_e != 0) {                                     \
+      (ctx)->last_hip = _e;                            \
+      (ctx)->last_error = FLAME_NLTGV2_ERR_HIP;        \
+      return FLAME_NLTGV2_ERR_HIP;                     \
+    }                                                  \
+  } while (0)
+
+int fail(flame_nltgv2_ctx* ctx, int status) {
+  if (ctx) ctx->last_error = status;
+  return status;
+}
+
+int ensure(flame_nltgv2_ctx* ctx, DevBuf& b, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  if (b.cap >= bytes) return 0;
+  size_t want = bytes + bytes / 2;  // geometric growth, reused across frames
+  want = (want + 255) & ~size_t(255);
+  if (b.p) {
+    HIPCHK(ctx, hipFree(b.p));
+    ctx->device_bytes -= b.cap;
+    b.p = nullptr, b.cap = 0;
+  }
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    ctx->last_hip = (int)e;
+    b.p = nullptr;
+    return fail(ctx, e == hipErrorOutOfMemory ? FLAME_NLTGV2_ERR_OOM : FLAME_NLTGV2_ERR_HIP);
+  }
+  b.cap = want;
+  ctx->device_bytes += want;
+  ctx->pointers_changed = true;
+  return 0;
+}
+
+void drop_graphs(flame_nltgv2_ctx* ctx) {
+  for (auto& g : ctx->graphs)
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  ctx->graphs.clear();
+}
+
+SolverParams to_sp(const flame_nltgv2_params* p) {
+  return SolverParams{p->data_factor, p->step_x, p->step_q, p->theta, p->x_min, p->x_max};
+}
+
+int enter(flame_nltgv2_ctx* ctx) {
+  if (!ctx) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return 0;
+}
+
+void refresh_args(flame_nltgv2_ctx* ctx) {
+  CanonArgs& c = ctx->c;
+  c.V = ctx->L.V, c.E = ctx->L.E;
+  c.pos = (float2*)ctx->pos.p;
+  c.x = (float*)ctx->x.p, c.w1 = (float*)ctx->w1.p, c.w2 = (float*)ctx->w2.p;
+  c.xb = (float*)ctx->xb.p, c.w1b = (float*)ctx->w1b.p, c.w2b = (float*)ctx->w2b.p;
+  c.xp = (float*)ctx->xp.p, c.w1p = (float*)ctx->w1p.p, c.w2p = (float*)ctx->w2p.p;
+  c.data = (float*)ctx->data.p, c.weight = (float*)ctx->weight.p;
+  c.src = (int32_t*)ctx->src.p, c.dst = (int32_t*)ctx->dst.p;
+  c.alpha = (float*)ctx->alpha.p, c.beta = (float*)ctx->beta.p;
+  c.q1 = (float*)ctx->q1.p, c.q2 = (float*)ctx->q2.p, c.q3 = (float*)ctx->q3.p;
+  c.row_ptr = (int32_t*)ctx->row_ptr.p, c.half = (uint32_t*)ctx->half.p;
+  c.err = (int*)ctx->err.p;
+  FusedArgs& f = ctx->f;
+  f.n_slices = ctx->L.n_slices;
+  f.n_slots = (ctx->L.rows + kRowPad) * kWave;
+  f.slice_row = (int32_t*)ctx->slice_row.p, f.perm = (int32_t*)ctx->perm.p, f.pdeg = (int32_t*)ctx->pdeg.p;
+  f.rec_nbr = (uint32_t*)ctx->rec_nbr.p, f.rec_edge = (int32_t*)ctx->rec_edge.p;
+  f.edge_src_slot = (int32_t*)ctx->edge_src_slot.p;
+  f.hrec = (int4*)ctx->hrec.p, f.hq = (float4*)ctx->hq.p;
+  f.vstate = (float4*)ctx->vstate.p, f.vaux = (float2*)ctx->vaux.p;
+  f.bar[0] = (float4*)ctx->bar0.p, f.bar[1] = (float4*)ctx->bar1.p;
+  f.vprev = (float4*)ctx->vprev.p;
+  f.err = (int*)ctx->err.p;
+}
+
+int h2d(flame_nltgv2_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
+  if (bytes == 0) return 0;
+  HIPCHK(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return 0;
+}
+
+int ensure_canon(flame_nltgv2_ctx* ctx) {
+  if (ctx->canon_valid) return 0;
+  LAUNCHCHK(ctx, launch_unpack_state(ctx->c, ctx->f, ctx->parity, ctx->have_prev, ctx->stream));
+  ctx->canon_valid = true;
+  return 0;
+}
+
+int ensure_fused(flame_nltgv2_ctx* ctx) {
+  if (ctx->fused_valid) return 0;
+  LAUNCHCHK(ctx, launch_pack_state(ctx->c, ctx->f, ctx->parity, ctx->stream));
+  ctx->fused_valid = true;
+  ctx->have_prev = false;
+  return 0;
+}
+
+void pick_config(const flame_nltgv2_ctx* ctx, int* unroll, int* wpb) {
+  // Small graphs are latency bound: one wave per workgroup spreads the slices over as many CUs as
+  // possible and a deep chunk (all slots of a slice in one round of loads) shortens the dependent
+  // chain.  Large graphs / batches are bandwidth bound: 4-wave workgroups, shallow chunks keep the
+  // register footprint (and thus occupancy) reasonable.
+  const bool small = ctx->L.n_slices <= 8 * ctx->prop.multiProcessorCount;
+  *unroll = ctx->opt_unroll ? ctx->opt_unroll : (small ? 8 : 4);
+  *wpb = ctx->opt_block_waves ? ctx->opt_block_waves : (small ? 1 : 4);
+}
+
+bool same_params(const flame_nltgv2_params& a, const flame_nltgv2_params& b) {
+  return std::memcmp(&a, &b, sizeof(a)) == 0;
+}
+
+int enqueue_fused_eager(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n, int parity, int unroll,
+                        int wpb, bool prev_on_last) {
+  const SolverParams sp = to_sp(p);
+  for (int it = 0; it < n; ++it) {
+    LAUNCHCHK(ctx, launch_fused_step(ctx->f, sp, parity ^ (it & 1), prev_on_last && it == n - 1, unroll, wpb,
+                                     ctx->stream));
+  }
+  return 0;
+}
+
+int get_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n, int parity, int unroll, int wpb,
+              hipGraphExec_t* out) {
+  for (auto& g : ctx->graphs) {
+    if (g.n == n && g.parity == parity && g.unroll == unroll && g.wpb == wpb && g.topo == ctx->topo &&
+        same_params(g.params, *p)) {
+      g.stamp = ++ctx->stamp;
+      *out = g.exec;
+      return 0;
+    }
+  }
+  hipGraph_t graph = nullptr;
+  HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+  int rc = enqueue_fused_eager(ctx, p, n, parity, unroll, wpb, true);
+  hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+  if (rc != 0) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
+  }
+  HIPCHK(ctx, e);
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  HIPCHK(ctx, e);
+  if ((int)ctx->graphs.size() >= kMaxCachedGraphs) {
+    size_t victim = 0;
+    for (size_t i = 1; i < ctx->graphs.size(); ++i)
+      if (ctx->graphs[i].stamp < ctx->graphs[victim].stamp) victim = i;
+    (void)hipGraphExecDestroy(ctx->graphs[victim].exec);
+    ctx->graphs.erase(ctx->graphs.begin() + (long)victim);
+  }
+  CachedGraph cg;
+  cg.exec = exec, cg.n = n, cg.parity = parity, cg.unroll = unroll, cg.wpb = wpb, cg.topo = ctx->topo;
+  cg.params = *p, cg.stamp = ++ctx->stamp;
+  ctx->graphs.push_back(cg);
+  *out = exec;
+  return 0;
+}
+
+// Builds (if needed) every hipGraph a run of n steps will replay, without running anything: keeps
+// graph instantiation out of timed regions.
+int prepare_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
+  if (ctx->opt_solver != 0 || !ctx->opt_use_graph) return 0;
+  int unroll, wpb;
+  pick_config(ctx, &unroll, &wpb);
+  int parity = ctx->parity;
+  hipGraphExec_t exec;
+  if (n >= kGraphChunk) {
+    int rc = get_graph(ctx, p, kGraphChunk, parity, unroll, wpb, &exec);
+    if (rc) return rc;
+  }
+  const int rem = n % kGraphChunk;
+  if (rem >= 4) {
+    int rc = get_graph(ctx, p, rem, parity, unroll, wpb, &exec);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
+  if (n <= 0) return 0;
+  if (ctx->opt_solver == 1) {  // canonical 4-sweep path
+    int rc = ensure_canon(ctx);
+    if (rc) return rc;
+    const SolverParams sp = to_sp(p);
+    for (int it = 0; it < n; ++it) {
+      LAUNCHCHK(ctx, launch_save_prev(ctx->c, ctx->stream));
+      LAUNCHCHK(ctx, launch_dual(ctx->c, sp, ctx->stream));
+      LAUNCHCHK(ctx, launch_primal(ctx->c, sp, ctx->stream));
+      LAUNCHCHK(ctx, launch_extragradient(ctx->c, sp, ctx->stream));
+    }
+    ctx->fused_valid = false;
+    return 0;
+  }
+  int rc = ensure_fused(ctx);
+  if (rc) return rc;
+  int unroll, wpb;
+  pick_config(ctx, &unroll, &wpb);
+  int left = n;
+  while (left > 0) {
+    const int chunk = left >= kGraphChunk ? kGraphChunk : left;
+    if (ctx->opt_use_graph && chunk >= 4) {
+      hipGraphExec_t exec = nullptr;
+      rc = get_graph(ctx, p, chunk, ctx->parity, unroll, wpb, &exec);
+      if (rc) return rc;
+      HIPCHK(ctx, hipGraphLaunch(exec, ctx->stream));
+    } else {
+      rc = enqueue_fused_eager(ctx, p, chunk, ctx->parity, unroll, wpb, true);
+      if (rc) return rc;
+    }
+    ctx->parity ^= (chunk & 1);
+    left -= chunk;
+  }
+  ctx->have_prev = true;
+  ctx->canon_valid = false;
+  return 0;
+}
+
+int finish(flame_nltgv2_ctx* ctx) {
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_err, ctx->err.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (*ctx->h_err != 0) return fail(ctx, FLAME_NLTGV2_ERR_NAN);
+  return 0;
+}
+
+bool params_ok(const flame_nltgv2_params* p) { return p != nullptr; }
+
+}  // namespace
+
+extern "C" {
+
+int flame_nltgv2_abi_version(void) { return FLAME_NLTGV2_ABI_VERSION; }
+
+void flame_nltgv2_default_params(flame_nltgv2_params* p) {
+  if (!p) return;
+  p->data_factor = 0.1f, p->step_x = 0.001f, p->step_q = 125.0f;
+  p->theta = 0.25f, p->x_min = 0.0f, p->x_max = 10.0f;
+}
+
+const char* flame_nltgv2_status_string(int status) {
+  switch (status) {
+    case FLAME_NLTGV2_OK: return "ok";
+    case FLAME_NLTGV2_ERR_INVALID_ARG: return "invalid argument";
+    case FLAME_NLTGV2_ERR_NO_DEVICE: return "no usable HIP device";
+    case FLAME_NLTGV2_ERR_HIP: return "HIP runtime error";
+    case FLAME_NLTGV2_ERR_NO_GRAPH: return "no graph uploaded";
+    case FLAME_NLTGV2_ERR_NAN: return "dual variable became NaN/Inf (reference FLAME_ASSERT, h:174)";
+    case FLAME_NLTGV2_ERR_OOM: return "out of device memory";
+    default: return "unknown status";
+  }
+}
+
+int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
+  if (!out) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return FLAME_NLTGV2_ERR_NO_DEVICE;
+  if (device < 0 || device >= count) return FLAME_NLTGV2_ERR_NO_DEVICE;
+  flame_nltgv2_ctx* ctx = new (std::nothrow) flame_nltgv2_ctx();
+  if (!ctx) return FLAME_NLTGV2_ERR_OOM;
+  ctx->device = device;
+  bool ok = hipSetDevice(device) == hipSuccess;
+  ok = ok && hipGetDeviceProperties(&ctx->prop, device) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&ctx->h_err, sizeof(int), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&ctx->h_cost, 2 * sizeof(float), hipHostMallocDefault) == hipSuccess;
+  if (!ok) {
+    flame_nltgv2_destroy(ctx);
+    return FLAME_NLTGV2_ERR_HIP;
+  }
+  ctx->stream = ctx->own_stream;
+  *ctx->h_err = 0;
+  ctx->all = {&ctx->pos, &ctx->x, &ctx->w1, &ctx->w2, &ctx->xb, &ctx->w1b, &ctx->w2b, &ctx->xp, &ctx->w1p,
+              &ctx->w2p, &ctx->data, &ctx->weight, &ctx->src, &ctx->dst, &ctx->alpha, &ctx->beta, &ctx->q1,
+              &ctx->q2, &ctx->q3, &ctx->row_ptr, &ctx->half, &ctx->slice_row, &ctx->perm, &ctx->pdeg,
+              &ctx->rec_nbr, &ctx->rec_edge, &ctx->edge_src_slot, &ctx->hrec, &ctx->hq, &ctx->vstate,
+              &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->err, &ctx->cost_pe, &ctx->cost_pv,
+              &ctx->cost_out};
+  *out = ctx;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_destroy(flame_nltgv2_ctx* ctx) {
+  if (!ctx) return FLAME_NLTGV2_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  drop_graphs(ctx);
+  for (DevBuf* b : ctx->all)
+    if (b->p) (void)hipFree(b->p);
+  if (ctx->h_err) (void)hipHostFree(ctx->h_err);
+  if (ctx->h_cost) (void)hipHostFree(ctx->h_cost);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_set_stream(flame_nltgv2_ctx* ctx, void* hip_stream) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
+  if (!ctx) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  switch (option) {
+    case FLAME_NLTGV2_OPT_SOLVER:
+      if (value != 0 && value != 1) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_solver = value;
+      return 0;
+    case FLAME_NLTGV2_OPT_USE_HIPGRAPH:
+      ctx->opt_use_graph = value ? 1 : 0;
+      return 0;
+    case FLAME_NLTGV2_OPT_BLOCK_WAVES:
+      if (value != 0 && value != 1 && value != 2 && value != 4) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_block_waves = value;
+      return 0;
+    case FLAME_NLTGV2_OPT_UNROLL:
+      if (value != 0 && value != 4 && value != 8 && value != 16) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_unroll = value;
+      return 0;
+    default:
+      return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  }
+}
+
+int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!g) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  const int32_t V = g->V, E = g->E;
+  if (V < 0 || E < 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  if (V > 0 && (!g->pos || !g->x || !g->w1 || !g->w2 || !g->x_bar || !g->w1_bar || !g->w2_bar ||
+                !g->data_term || !g->data_weight))
+    return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  if (E > 0 && (!g->src || !g->dst || !g->alpha || !g->beta || !g->q1 || !g->q2 || !g->q3))
+    return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  ctx->have_graph = false;
+  rc = build_layout(g, &ctx->L);
+  if (rc) return fail(ctx, rc);
+  const PackedLayout& L = ctx->L;
+  const size_t n_slots = (size_t)(L.rows + kRowPad) * kWave;
+  if (n_slots > (size_t)0x7fffffff) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  const size_t n_packed = (size_t)L.n_slices * kWave;
+
+  // Make sure nothing in flight still uses buffers we may reallocate.
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->pointers_changed = false;
+  const size_t fV = sizeof(float) * (size_t)V, fE = sizeof(float) * (size_t)E;
+  struct { DevBuf* b; size_t bytes; } req[] = {
+      {&ctx->pos, 2 * fV}, {&ctx->x, fV}, {&ctx->w1, fV}, {&ctx->w2, fV}, {&ctx->xb, fV}, {&ctx->w1b, fV},
+      {&ctx->w2b, fV}, {&ctx->xp, fV}, {&ctx->w1p, fV}, {&ctx->w2p, fV}, {&ctx->data, fV}, {&ctx->weight, fV},
+      {&ctx->src, fE}, {&ctx->dst, fE}, {&ctx->alpha, fE}, {&ctx->beta, fE}, {&ctx->q1, fE}, {&ctx->q2, fE},
+      {&ctx->q3, fE}, {&ctx->row_ptr, sizeof(int32_t) * ((size_t)V + 1)}, {&ctx->half, 2 * fE},
+      {&ctx->slice_row, sizeof(int32_t) * ((size_t)L.n_slices + 1)}, {&ctx->perm, sizeof(int32_t) * n_packed},
+      {&ctx->pdeg, sizeof(int32_t) * n_packed}, {&ctx->rec_nbr, sizeof(uint32_t) * n_slots},
+      {&ctx->rec_edge, sizeof(int32_t) * n_slots}, {&ctx->edge_src_slot, fE},
+      {&ctx->hrec, sizeof(int4) * n_slots}, {&ctx->hq, sizeof(float4) * n_slots},
+      {&ctx->vstate, sizeof(float4) * n_packed}, {&ctx->vaux, sizeof(float2) * n_packed},
+      {&ctx->bar0, sizeof(float4) * n_packed}, {&ctx->bar1, sizeof(float4) * n_packed},
+      {&ctx->vprev, sizeof(float4) * n_packed}, {&ctx->err, sizeof(int)},
+      {&ctx->cost_pe, sizeof(double) * kCostPartials}, {&ctx->cost_pv, sizeof(double) * kCostPartials},
+      {&ctx->cost_out, 2 * sizeof(float)}};
+  for (auto& r : req) {
+    rc = ensure(ctx, *r.b, r.bytes);
+    if (rc) return rc;
+  }
+  ctx->topo++;
+  drop_graphs(ctx);
+  refresh_args(ctx);
+
+  rc = h2d(ctx, ctx->pos, g->pos, 2 * fV);
+  const struct { DevBuf* b; const void* src; size_t bytes; } cp[] = {
+      {&ctx->x, g->x, fV}, {&ctx->w1, g->w1, fV}, {&ctx->w2, g->w2, fV}, {&ctx->xb, g->x_bar, fV},
+      {&ctx->w1b, g->w1_bar, fV}, {&ctx->w2b, g->w2_bar, fV},
+      {&ctx->xp, g->x_prev ? g->x_prev : g->x, fV}, {&ctx->w1p, g->w1_prev ? g->w1_prev : g->w1, fV},
+      {&ctx->w2p, g->w2_prev ? g->w2_prev : g->w2, fV}, {&ctx->data, g->data_term, fV},
+      {&ctx->weight, g->data_weight, fV}, {&ctx->src, g->src, fE}, {&ctx->dst, g->dst, fE},
+      {&ctx->alpha, g->alpha, fE}, {&ctx->beta, g->beta, fE}, {&ctx->q1, g->q1, fE}, {&ctx->q2, g->q2, fE},
+      {&ctx->q3, g->q3, fE}, {&ctx->row_ptr, L.row_ptr.data(), sizeof(int32_t) * ((size_t)V + 1)},
+      {&ctx->half, L.half.data(), 2 * fE},
+      {&ctx->slice_row, L.slice_row.data(), sizeof(int32_t) * ((size_t)L.n_slices + 1)},
+      {&ctx->perm, L.perm.data(), sizeof(int32_t) * n_packed}, {&ctx->pdeg, L.pdeg.data(), sizeof(int32_t) * n_packed},
+      {&ctx->rec_nbr, L.rec_nbr.data(), sizeof(uint32_t) * n_slots},
+      {&ctx->rec_edge, L.rec_edge.data(), sizeof(int32_t) * n_slots},
+      {&ctx->edge_src_slot, L.edge_src_slot.data(), fE}};
+  for (auto& c : cp) {
+    if (rc) return rc;
+    rc = h2d(ctx, *c.b, c.src, c.bytes);
+  }
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, sizeof(int), ctx->stream));
+  LAUNCHCHK(ctx, launch_pack_static(ctx->c, ctx->f, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors / caller arrays may go away
+  ctx->canon_valid = true;
+  ctx->fused_valid = false;
+  ctx->have_prev = false;
+  ctx->parity = 0;
+  ctx->have_graph = true;
+  ctx->last_error = 0;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_update_data(flame_nltgv2_ctx* ctx, const float* data_term, const float* data_weight) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (ctx->L.V > 0 && (!data_term || !data_weight)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  rc = ensure_canon(ctx);
+  if (rc) return rc;
+  const size_t fV = sizeof(float) * (size_t)ctx->L.V;
+  rc = h2d(ctx, ctx->data, data_term, fV);
+  if (!rc) rc = h2d(ctx, ctx->weight, data_weight, fV);
+  if (rc) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->fused_valid = false;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_upload_state(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* s) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!s) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  rc = ensure_canon(ctx);
+  if (rc) return rc;
+  const size_t fV = sizeof(float) * (size_t)ctx->L.V, fE = sizeof(float) * (size_t)ctx->L.E;
+  const struct { DevBuf* b; const float* src; size_t bytes; } cp[] = {
+      {&ctx->x, s->x, fV}, {&ctx->w1, s->w1, fV}, {&ctx->w2, s->w2, fV}, {&ctx->xb, s->x_bar, fV},
+      {&ctx->w1b, s->w1_bar, fV}, {&ctx->w2b, s->w2_bar, fV}, {&ctx->xp, s->x_prev, fV},
+      {&ctx->w1p, s->w1_prev, fV}, {&ctx->w2p, s->w2_prev, fV}, {&ctx->q1, s->q1, fE}, {&ctx->q2, s->q2, fE},
+      {&ctx->q3, s->q3, fE}};
+  for (auto& c : cp) {
+    if (!c.src) continue;
+    rc = h2d(ctx, *c.b, c.src, c.bytes);
+    if (rc) return rc;
+  }
+  HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, sizeof(int), ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->fused_valid = false;
+  ctx->last_error = 0;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_run_async(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n_iters) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!params_ok(p) || n_iters < 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  return enqueue_run(ctx, p, n_iters);
+}
+
+int flame_nltgv2_sync(flame_nltgv2_ctx* ctx) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+  }
+  return finish(ctx);
+}
+
+int flame_nltgv2_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n_iters) {
+  int rc = flame_nltgv2_run_async(ctx, p, n_iters);
+  if (rc) return rc;
+  return finish(ctx);
+}
+
+int flame_nltgv2_run_timed(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n_iters, float* elapsed_ms) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!params_ok(p) || n_iters < 0 || !elapsed_ms) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  // layout conversion and graph instantiation are not part of the steady-state step
+  if (ctx->opt_solver == 0) rc = ensure_fused(ctx); else rc = ensure_canon(ctx);
+  if (rc) return rc;
+  rc = prepare_run(ctx, p, n_iters);
+  if (rc) return rc;
+  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  rc = enqueue_run(ctx, p, n_iters);
+  if (rc) return rc;
+  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  rc = finish(ctx);
+  float ms = 0.f;
+  HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *elapsed_ms = ms;
+  return rc;
+}
+
+int flame_nltgv2_step(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p) { return flame_nltgv2_run(ctx, p, 1); }
+
+#define CANON_OP(NAME, LAUNCH)                                                  \
+  int NAME(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p) {               \
+    int rc = enter(ctx);                                                        \
+    if (rc) return rc;                                                          \
+    if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);          \
+    if (!params_ok(p)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);          \
+    rc = ensure_canon(ctx);                                                     \
+    if (rc) return rc;                                                          \
+    const SolverParams sp = to_sp(p);                                           \
+    LAUNCHCHK(ctx, LAUNCH(ctx->c, sp, ctx->stream));                            \
+    ctx->fused_valid = false;                                                   \
+    return finish(ctx);                                                         \
+  }
+CANON_OP(flame_nltgv2_dual_step, launch_dual)
+CANON_OP(flame_nltgv2_primal_step, launch_primal)
+CANON_OP(flame_nltgv2_extragradient_step, launch_extragradient)
+#undef CANON_OP
+
+int flame_nltgv2_save_prev(flame_nltgv2_ctx* ctx) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  rc = ensure_canon(ctx);
+  if (rc) return rc;
+  LAUNCHCHK(ctx, launch_save_prev(ctx->c, ctx->stream));
+  ctx->fused_valid = false;
+  return finish(ctx);
+}
+
+int flame_nltgv2_costs(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, float* smoothness, float* data) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!params_ok(p)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  rc = ensure_canon(ctx);
+  if (rc) return rc;
+  LAUNCHCHK(ctx, launch_costs(ctx->c, to_sp(p), (double*)ctx->cost_pe.p, (double*)ctx->cost_pv.p, kCostPartials,
+                              (float*)ctx->cost_out.p, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_cost, ctx->cost_out.p, 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (smoothness) *smoothness = ctx->h_cost[0];
+  if (data) *data = ctx->h_cost[1];
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_download_state(flame_nltgv2_ctx* ctx, flame_nltgv2_graph* out) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!out) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  rc = ensure_canon(ctx);
+  if (rc) return rc;
+  const size_t fV = sizeof(float) * (size_t)ctx->L.V, fE = sizeof(float) * (size_t)ctx->L.E;
+  const struct { float* dst; DevBuf* b; size_t bytes; } cp[] = {
+      {out->x, &ctx->x, fV}, {out->w1, &ctx->w1, fV}, {out->w2, &ctx->w2, fV}, {out->x_bar, &ctx->xb, fV},
+      {out->w1_bar, &ctx->w1b, fV}, {out->w2_bar, &ctx->w2b, fV}, {out->x_prev, &ctx->xp, fV},
+      {out->w1_prev, &ctx->w1p, fV}, {out->w2_prev, &ctx->w2p, fV}, {out->q1, &ctx->q1, fE},
+      {out->q2, &ctx->q2, fE}, {out->q3, &ctx->q3, fE}};
+  for (auto& c : cp) {
+    if (!c.dst || c.bytes == 0) continue;
+    HIPCHK(ctx, hipMemcpyAsync(c.dst, c.b->p, c.bytes, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  out->V = ctx->L.V, out->E = ctx->L.E;
+  return finish(ctx);
+}
+
+int flame_nltgv2_export_idepth_device(flame_nltgv2_ctx* ctx, void* dst_device, float scale) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!dst_device && ctx->L.V > 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  const bool packed = !ctx->canon_valid;
+  LAUNCHCHK(ctx, launch_export(ctx->c, ctx->f, packed, scale, (float*)dst_device, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info) {
+  if (!ctx || !info) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  std::memset(info, 0, sizeof(*info));
+  info->abi_version = FLAME_NLTGV2_ABI_VERSION;
+  info->device = ctx->device;
+  info->V = ctx->L.V, info->E = ctx->L.E;
+  info->n_slices = ctx->L.n_slices;
+  info->max_degree = ctx->L.max_degree;
+  info->padded_half_edges = ctx->L.rows * kWave;
+  info->device_bytes = (int64_t)ctx->device_bytes;
+  info->algorithmic_bytes_per_iter = 64ll * ctx->L.V + 40ll * ctx->L.E;
+  info->compute_units = ctx->prop.multiProcessorCount;
+  std::snprintf(info->device_name, sizeof(info->device_name), "%s", ctx->prop.name);
+  std::snprintf(info->gcn_arch, sizeof(info->gcn_arch), "%s", ctx->prop.gcnArchName);
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_last_error(flame_nltgv2_ctx* ctx) { return ctx ? ctx->last_error : FLAME_NLTGV2_ERR_INVALID_ARG; }
+int flame_nltgv2_last_hip_error(flame_nltgv2_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
+
+int flame_nltgv2_pack_probe(const flame_nltgv2_graph* g, int32_t* perm, int32_t* slice_row, int32_t* rec_nbr,
+                            int32_t* rec_edge, int64_t capacity_rows, int64_t* rows_out) {
+  PackedLayout L;
+  int rc = build_layout(g, &L);
+  if (rc) return rc;
+  if (rows_out) *rows_out = L.rows;
+  if (perm) std::memcpy(perm, L.perm.data(), sizeof(int32_t) * L.perm.size());
+  if (slice_row) std::memcpy(slice_row, L.slice_row.data(), sizeof(int32_t) * L.slice_row.size());
+  if ((rec_nbr || rec_edge) && capacity_rows < L.rows) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  const size_t n = (size_t)L.rows * kWave;
+  if (rec_nbr) std::memcpy(rec_nbr, L.rec_nbr.data(), sizeof(int32_t) * n);
+  if (rec_edge) std::memcpy(rec_edge, L.rec_edge.data(), sizeof(int32_t) * n);
+  return L.n_slices;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// nltgv2_kernels.h -- argument bundles and launch wrappers shared by nltgv2_kernels.hip (device
+// code) and nltgv2_capi.hip (context + C-ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace flame_hip {
+
+// == flame_nltgv2_params == Params, nltgv2_l1_graph_regularizer.h:121-129
+struct SolverParams {
+  float data_factor, step_x, step_q, theta, x_min, x_max;
+};
+
+// Canonical SoA state in the caller's vertex / edge order (device pointers).
+struct CanonArgs {
+  int V = 0, E = 0;
+  float2* pos = nullptr;
+  float *x = nullptr, *w1 = nullptr, *w2 = nullptr;
+  float *xb = nullptr, *w1b = nullptr, *w2b = nullptr;
+  float *xp = nullptr, *w1p = nullptr, *w2p = nullptr;
+  float *data = nullptr, *weight = nullptr;
+  int32_t *src = nullptr, *dst = nullptr;
+  float *alpha = nullptr, *beta = nullptr;
+  float *q1 = nullptr, *q2 = nullptr, *q3 = nullptr;
+  int32_t* row_ptr = nullptr;  // [V+1]
+  uint32_t* half = nullptr;    // [2E] edge id | role bit
+  int* err = nullptr;
+};
+
+// Packed SELL-64 layout of the fused sweep (device pointers).
+struct FusedArgs {
+  int n_slices = 0;
+  int64_t n_slots = 0;  // (rows + kRowPad) * 64
+  int32_t* slice_row = nullptr;
+  int32_t* perm = nullptr;  // [n_slices*64]
+  int32_t* pdeg = nullptr;
+  uint32_t* rec_nbr = nullptr;  // [n_slots]
+  int32_t* rec_edge = nullptr;  // [n_slots]
+  int32_t* edge_src_slot = nullptr;  // [E]
+  int4* hrec = nullptr;     // [n_slots] {nbr|role, alpha, dx, dy}
+  float4* hq = nullptr;     // [n_slots] {q1,q2,q3,beta}
+  float4* vstate = nullptr; // [n_slices*64] {x,w1,w2,data}
+  float2* vaux = nullptr;   // [n_slices*64] {data_weight, degree bits}
+  float4* bar[2] = {nullptr, nullptr};  // ping-pong {x_bar,w1_bar,w2_bar,-}
+  float4* vprev = nullptr;  // {x_prev,w1_prev,w2_prev,-} written by the last step of a run
+  int* err = nullptr;
+};
+
+int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, bool write_prev, int unroll,
+                      int waves_per_block, hipStream_t stream);
+int launch_save_prev(const CanonArgs& c, hipStream_t s);
+int launch_dual(const CanonArgs& c, const SolverParams& p, hipStream_t s);
+int launch_primal(const CanonArgs& c, const SolverParams& p, hipStream_t s);
+int launch_extragradient(const CanonArgs& c, const SolverParams& p, hipStream_t s);
+int launch_pack_static(const CanonArgs& c, const FusedArgs& a, hipStream_t s);
+int launch_pack_state(const CanonArgs& c, const FusedArgs& a, int parity, hipStream_t s);
+int launch_unpack_state(const CanonArgs& c, const FusedArgs& a, int parity, bool have_prev, hipStream_t s);
+int launch_export(const CanonArgs& c, const FusedArgs& a, bool packed_current, float scale, float* dst,
+                  hipStream_t s);
+int launch_costs(const CanonArgs& c, const SolverParams& p, double* partial_e, double* partial_v,
+                 int n_partials, float* out2, hipStream_t s);
+
+}  // namespace flame_hip

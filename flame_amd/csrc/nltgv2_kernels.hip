@@ -1,0 +1,562 @@
+// nltgv2_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the NLTGV2-L1 primal-dual solver.
+//
+// Reference arithmetic: /root/reference/src/flame/optimizers/nltgv2_l1_graph_regularizer.{h,cc}
+// (cited per kernel).  The whole file is compiled with -ffp-contract=off: the reference build is
+// plain x86-64 (no FMA, CMakeLists.txt:24), every expression below keeps the reference's
+// left-to-right float evaluation order, and each vertex accumulates its incident-edge updates
+// sequentially in ascending edge id -- the order of the reference's edge scatter -- so the results
+// are bit-identical to the reference's sequential loops, not merely within tolerance.
+//
+// This is a sparse-graph stencil at ~0.3 flop/B: no MFMA.  What matters on CDNA4 here is
+// (1) 16-byte-per-lane coalesced streams (one vertex per lane of a 64-wide wavefront, SELL-64
+// slot-major half-edge arrays), (2) as few dependent global round trips per step as possible
+// (one fused kernel per step, loads of a whole slot chunk issued back to back), (3) XCD-aware
+// slice placement so a slice's neighbours were written by the same XCD's L2 one step earlier.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nltgv2_kernels.h"
+
+namespace flame_hip {
+
+namespace {
+
+constexpr uint32_t kRole = 0x80000000u;
+
+// proxNLTGV2Conj, h:171-176:  q / max(1,|q|).  For finite q this is exactly clamp(q,-1,1):
+// |q|<=1 -> q/1 == q, |q|>1 -> q/|q| == +-1 exactly (IEEE x/x == 1).  For NaN/Inf the reference
+// produces NaN and FLAME_ASSERTs (h:174); we report that through `ok` instead of exiting.
+__device__ __forceinline__ float prox_conj(float q, bool& ok) {
+  ok = ok && (__builtin_fabsf(q) <= 3.402823466e+38f);
+  return __builtin_fminf(__builtin_fmaxf(q, -1.0f), 1.0f);
+}
+
+// proxL1, h:179-197 (thresh = step_x * (data_factor * data_weight), call site cc:149-150).
+__device__ __forceinline__ float prox_l1(float x_min, float x_max, float step_x, float data_weight,
+                                         float x, float data) {
+  const float diff = x - data;
+  const float thresh = step_x * data_weight;
+  float new_x;
+  if (diff > thresh) {
+    new_x = x - thresh;
+  } else if (diff < -thresh) {
+    new_x = x + thresh;
+  } else {
+    new_x = data;
+  }
+  new_x = (new_x < x_min) ? x_min : new_x;
+  new_x = (new_x > x_max) ? x_max : new_x;
+  return new_x;
+}
+
+// One edge seen from one endpoint: dual update of (q1,q2,q3) (cc:99-110) followed by this
+// endpoint's share of the primal scatter (cc:126-141).  (xi..) = source vertex, (xj..) = target.
+struct EdgeOut {
+  float q1, q2, q3;
+};
+
+__device__ __forceinline__ EdgeOut edge_dual(const SolverParams& p, float alpha, float beta, float dx,
+                                             float dy, float q1, float q2, float q3, float xbi,
+                                             float w1bi, float w2bi, float xbj, float w1bj,
+                                             float w2bj, bool& ok) {
+  float K1x = alpha * (xbi - xbj);
+  K1x -= alpha * dx * w1bi;
+  K1x -= alpha * dy * w2bi;
+  EdgeOut o;
+  o.q1 = prox_conj(q1 + p.step_q * K1x, ok);
+  const float K2x = beta * (w1bi - w1bj);
+  o.q2 = prox_conj(q2 + p.step_q * K2x, ok);
+  const float K3x = beta * (w2bi - w2bj);
+  o.q3 = prox_conj(q3 + p.step_q * K3x, ok);
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused step: one launch == one reference step() (cc:33-49) on the SELL-64 layout.
+//
+//   wave <-> slice of 64 packed vertices, lane <-> vertex.  Slot k of the lane's vertex is its k-th
+//   incident half-edge in ascending edge id.  Every half-edge keeps a PRIVATE copy of (q1,q2,q3):
+//   both endpoints recompute the edge's dual update from identical inputs with identical
+//   instructions, so the two copies stay bit-identical and no cross-lane exchange of q is needed
+//   -- this removes the dual->primal global dependency, leaving ONE grid-wide dependency per step
+//   (x_bar/w_bar of step t feed step t+1), carried by the kernel boundary through the
+//   ping-ponged `bar` arrays.
+//
+//   U = slots processed per chunk: 2U streaming loads + U gathers are issued back to back, so a
+//   slice pays ~2 dependent memory round trips per chunk, not per slot.
+// ------------------------------------------------------------------------------------------------
+template <int U, bool WRITE_PREV>
+__global__ void __launch_bounds__(256)
+k_fused_step(const int n_slices, const int slices_per_xcd, const int32_t* __restrict__ slice_row,
+             const int4* __restrict__ hrec, float4* __restrict__ hq, float4* __restrict__ vstate,
+             const float2* __restrict__ vaux, const float4* __restrict__ bar_in,
+             float4* __restrict__ bar_out, float4* __restrict__ vprev, const SolverParams p,
+             int* __restrict__ err) {
+  const int lane = threadIdx.x & 63;
+  const int waves_per_block = blockDim.x >> 6;
+  // XCD-aware placement: workgroup b is dispatched to XCD b % 8 (observed, used for speed only);
+  // give each XCD one contiguous range of slices so that a slice's gathers hit lines its own
+  // XCD's L2 wrote in the previous step.
+  const int b = blockIdx.x;
+  const int xcd = b & 7;
+  const int wave_in_xcd = (b >> 3) * waves_per_block + (threadIdx.x >> 6);
+  if (wave_in_xcd >= slices_per_xcd) return;
+  const int slice = xcd * slices_per_xcd + wave_in_xcd;
+  if (slice >= n_slices) return;
+
+  const int v = slice * 64 + lane;
+  const int row0 = slice_row[slice];
+  const int D = slice_row[slice + 1] - row0;
+
+  const float4 st = vstate[v];
+  const float2 aux = vaux[v];
+  const float4 bs = bar_in[v];
+  const int deg = __float_as_int(aux.y);
+
+  float x = st.x, w1 = st.y, w2 = st.z;
+  const float x_prev = x, w1_prev = w1, w2_prev = w2;  // step()'s prev copy, cc:37-42
+  bool ok = true;
+
+  size_t slot = (size_t)row0 * 64 + lane;
+  for (int k0 = 0; k0 < D; k0 += U) {
+    int4 rec[U];
+    float4 q[U];
+    float4 bn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {  // spare rows keep these in bounds past the slice end
+      rec[u] = hrec[slot + (size_t)u * 64];
+      q[u] = hq[slot + (size_t)u * 64];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) bn[u] = bar_in[rec[u].x & 0x7fffffff];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool act = (k0 + u) < deg;
+      const bool is_target = rec[u].x < 0;
+      const float alpha = __int_as_float(rec[u].y);
+      const float dx = __int_as_float(rec[u].z);  // pos_i - pos_j of the EDGE (source minus target)
+      const float dy = __int_as_float(rec[u].w);
+      const float beta = q[u].w;
+      // (i) = source, (j) = target
+      const float xbi = is_target ? bn[u].x : bs.x, xbj = is_target ? bs.x : bn[u].x;
+      const float w1bi = is_target ? bn[u].y : bs.y, w1bj = is_target ? bs.y : bn[u].y;
+      const float w2bi = is_target ? bn[u].z : bs.z, w2bj = is_target ? bs.z : bn[u].z;
+      bool okq = true;
+      const EdgeOut o = edge_dual(p, alpha, beta, dx, dy, q[u].x, q[u].y, q[u].z, xbi, w1bi, w2bi,
+                                  xbj, w1bj, w2bj, okq);
+      // primal scatter, this endpoint's share, cc:126-141
+      const float t1 = o.q1 * p.step_x * alpha;
+      const float t2 = o.q2 * p.step_x * beta;
+      const float t3 = o.q3 * p.step_x * beta;
+      float nx, nw1, nw2;
+      if (is_target) {
+        nx = x + t1;
+        nw1 = w1 + t2;
+        nw2 = w2 + t3;
+      } else {
+        nx = x - t1;
+        nw1 = w1 + t1 * dx;
+        nw2 = w2 + t1 * dy;
+        nw1 = nw1 - t2;
+        nw2 = nw2 - t3;
+      }
+      if (act) {
+        x = nx, w1 = nw1, w2 = nw2;
+        ok = ok && okq;
+        hq[slot + (size_t)u * 64] = make_float4(o.q1, o.q2, o.q3, beta);
+      }
+    }
+    slot += (size_t)U * 64;
+  }
+
+  // proxL1 per vertex, cc:147-151
+  x = prox_l1(p.x_min, p.x_max, p.step_x, p.data_factor * aux.x, x, st.w);
+  // extraGradientStep, cc:160-171
+  float xb = x + p.theta * (x - x_prev);
+  xb = (xb < p.x_min) ? p.x_min : xb;
+  xb = (xb > p.x_max) ? p.x_max : xb;
+  const float w1b = w1 + p.theta * (w1 - w1_prev);
+  const float w2b = w2 + p.theta * (w2 - w2_prev);
+
+  vstate[v] = make_float4(x, w1, w2, st.w);
+  bar_out[v] = make_float4(xb, w1b, w2b, 0.0f);
+  if (WRITE_PREV) vprev[v] = make_float4(x_prev, w1_prev, w2_prev, 0.0f);
+  if (!ok) atomicOr(err, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Canonical (original order, SoA) sweeps: the individually callable pieces of a step.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_save_prev(int V, const float* __restrict__ x, const float* __restrict__ w1,
+            const float* __restrict__ w2, float* __restrict__ xp, float* __restrict__ w1p,
+            float* __restrict__ w2p) {  // cc:35-42
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  xp[v] = x[v];
+  w1p[v] = w1[v];
+  w2p[v] = w2[v];
+}
+
+// internal::dualStep, cc:89-114: one lane per edge.
+__global__ void __launch_bounds__(256)
+k_dual_edge_sweep(int E, const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                  const float* __restrict__ alpha, const float* __restrict__ beta,
+                  const float2* __restrict__ pos, const float* __restrict__ xb,
+                  const float* __restrict__ w1b, const float* __restrict__ w2b,
+                  float* __restrict__ q1, float* __restrict__ q2, float* __restrict__ q3,
+                  const SolverParams p, int* __restrict__ err) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int i = src[e], j = dst[e];
+  const float2 pi = pos[i], pj = pos[j];
+  bool ok = true;
+  const EdgeOut o = edge_dual(p, alpha[e], beta[e], pi.x - pj.x, pi.y - pj.y, q1[e], q2[e], q3[e],
+                              xb[i], w1b[i], w2b[i], xb[j], w1b[j], w2b[j], ok);
+  q1[e] = o.q1;
+  q2[e] = o.q2;
+  q3[e] = o.q3;
+  if (!ok) atomicOr(err, 1);
+}
+
+// internal::primalStep, cc:116-154, as a per-vertex gather over the canonical CSR (ascending edge
+// id == the reference's scatter order for that vertex), then proxL1.
+__global__ void __launch_bounds__(256)
+k_primal_vertex_gather(int V, const int32_t* __restrict__ row_ptr, const uint32_t* __restrict__ half,
+                       const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                       const float* __restrict__ alpha, const float* __restrict__ beta,
+                       const float2* __restrict__ pos, const float* __restrict__ q1,
+                       const float* __restrict__ q2, const float* __restrict__ q3,
+                       const float* __restrict__ data, const float* __restrict__ weight,
+                       float* __restrict__ x, float* __restrict__ w1, float* __restrict__ w2,
+                       const SolverParams p) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  float xv = x[v], w1v = w1[v], w2v = w2[v];
+  const int r1 = row_ptr[v + 1];
+  for (int r = row_ptr[v]; r < r1; ++r) {
+    const uint32_t h = half[r];
+    const int e = (int)(h & ~kRole);
+    const float a = alpha[e], b = beta[e];
+    const float t1 = q1[e] * p.step_x * a;
+    const float t2 = q2[e] * p.step_x * b;
+    const float t3 = q3[e] * p.step_x * b;
+    if (h & kRole) {
+      xv = xv + t1;
+      w1v = w1v + t2;
+      w2v = w2v + t3;
+    } else {
+      const float2 pi = pos[v], pj = pos[dst[e]];
+      xv = xv - t1;
+      w1v = w1v + t1 * (pi.x - pj.x);
+      w2v = w2v + t1 * (pi.y - pj.y);
+      w1v = w1v - t2;
+      w2v = w2v - t3;
+    }
+  }
+  x[v] = prox_l1(p.x_min, p.x_max, p.step_x, p.data_factor * weight[v], xv, data[v]);
+  w1[v] = w1v;
+  w2[v] = w2v;
+}
+
+// internal::extraGradientStep, cc:156-174.
+__global__ void __launch_bounds__(256)
+k_extragradient(int V, const float* __restrict__ x, const float* __restrict__ w1,
+                const float* __restrict__ w2, const float* __restrict__ xp,
+                const float* __restrict__ w1p, const float* __restrict__ w2p,
+                float* __restrict__ xb, float* __restrict__ w1b, float* __restrict__ w2b,
+                const SolverParams p) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  float nb = x[v] + p.theta * (x[v] - xp[v]);
+  nb = (nb < p.x_min) ? p.x_min : nb;
+  nb = (nb > p.x_max) ? p.x_max : nb;
+  xb[v] = nb;
+  w1b[v] = w1[v] + p.theta * (w1[v] - w1p[v]);
+  w2b[v] = w2[v] + p.theta * (w2[v] - w2p[v]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// canonical <-> packed conversions
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_pack_static(int64_t n_slots, const int32_t* __restrict__ rec_edge, const uint32_t* __restrict__ rec_nbr,
+              const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+              const float* __restrict__ alpha, const float2* __restrict__ pos, int4* __restrict__ hrec) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  const int e = rec_edge[s];
+  int4 r;
+  r.x = (int)rec_nbr[s];
+  if (e >= 0) {
+    const float2 pi = pos[src[e]], pj = pos[dst[e]];
+    r.y = __float_as_int(alpha[e]);
+    r.z = __float_as_int(pi.x - pj.x);
+    r.w = __float_as_int(pi.y - pj.y);
+  } else {
+    r.y = r.z = r.w = 0;
+  }
+  hrec[s] = r;
+}
+
+__global__ void __launch_bounds__(256)
+k_pack_edge_state(int64_t n_slots, const int32_t* __restrict__ rec_edge, const float* __restrict__ q1,
+                  const float* __restrict__ q2, const float* __restrict__ q3,
+                  const float* __restrict__ beta, float4* __restrict__ hq) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  const int e = rec_edge[s];
+  hq[s] = (e >= 0) ? make_float4(q1[e], q2[e], q3[e], beta[e]) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__global__ void __launch_bounds__(256)
+k_pack_vertex_state(int n_packed, const int32_t* __restrict__ perm, const int32_t* __restrict__ pdeg,
+                    const float* __restrict__ x, const float* __restrict__ w1,
+                    const float* __restrict__ w2, const float* __restrict__ xb,
+                    const float* __restrict__ w1b, const float* __restrict__ w2b,
+                    const float* __restrict__ data, const float* __restrict__ weight,
+                    float4* __restrict__ vstate, float2* __restrict__ vaux, float4* __restrict__ bar) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_packed) return;
+  const int o = perm[s];
+  if (o >= 0) {
+    vstate[s] = make_float4(x[o], w1[o], w2[o], data[o]);
+    vaux[s] = make_float2(weight[o], __int_as_float(pdeg[s]));
+    bar[s] = make_float4(xb[o], w1b[o], w2b[o], 0.f);
+  } else {
+    vstate[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    vaux[s] = make_float2(0.f, __int_as_float(0));
+    bar[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_unpack_vertex_state(int n_packed, const int32_t* __restrict__ perm, const float4* __restrict__ vstate,
+                      const float4* __restrict__ bar, const float4* __restrict__ vprev, int have_prev,
+                      float* __restrict__ x, float* __restrict__ w1, float* __restrict__ w2,
+                      float* __restrict__ xb, float* __restrict__ w1b, float* __restrict__ w2b,
+                      float* __restrict__ xp, float* __restrict__ w1p, float* __restrict__ w2p) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_packed) return;
+  const int o = perm[s];
+  if (o < 0) return;
+  const float4 st = vstate[s], b = bar[s];
+  x[o] = st.x, w1[o] = st.y, w2[o] = st.z;
+  xb[o] = b.x, w1b[o] = b.y, w2b[o] = b.z;
+  if (have_prev) {
+    const float4 pv = vprev[s];
+    xp[o] = pv.x, w1p[o] = pv.y, w2p[o] = pv.z;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_unpack_edge_state(int E, const int32_t* __restrict__ edge_src_slot, const float4* __restrict__ hq,
+                    float* __restrict__ q1, float* __restrict__ q2, float* __restrict__ q3) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const float4 q = hq[edge_src_slot[e]];
+  q1[e] = q.x, q2[e] = q.y, q3[e] = q.z;
+}
+
+// x * graph_scale in original order (flame.cc:377), from whichever layout is current.
+__global__ void __launch_bounds__(256)
+k_export_packed(int n_packed, const int32_t* __restrict__ perm, const float4* __restrict__ vstate,
+                float scale, float* __restrict__ out) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_packed) return;
+  const int o = perm[s];
+  if (o >= 0) out[o] = vstate[s].x * scale;
+}
+
+__global__ void __launch_bounds__(256)
+k_export_canonical(int V, const float* __restrict__ x, float scale, float* __restrict__ out) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < V) out[v] = x[v] * scale;
+}
+
+// ------------------------------------------------------------------------------------------------
+// costs: smoothnessCost cc:51-71 and dataCost cc:73-85.  Summed in double, fixed tree.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ void block_sum_store(double v, double* __restrict__ partial) {
+  __shared__ double sm[4];
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ void __launch_bounds__(256)
+k_cost_edges(int E, const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+             const float* __restrict__ alpha, const float* __restrict__ beta,
+             const float2* __restrict__ pos, const float* __restrict__ x, const float* __restrict__ w1,
+             const float* __restrict__ w2, double* __restrict__ partial) {
+  double acc = 0.0;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+    const int i = src[e], j = dst[e];
+    const float2 pi = pos[i], pj = pos[j];
+    const float dx = pi.x - pj.x, dy = pi.y - pj.y;
+    float a = x[i] - x[j] - w1[i] * dx - w2[i] * dy;
+    a = (a >= 0) ? a : -a;
+    float b = w1[i] - w1[j];
+    b = (b >= 0) ? b : -b;
+    float c = w2[i] - w2[j];
+    c = (c >= 0) ? c : -c;
+    acc += (double)(alpha[e] * a);
+    acc += (double)(beta[e] * b + beta[e] * c);
+  }
+  block_sum_store(acc, partial);
+}
+
+__global__ void __launch_bounds__(256)
+k_cost_vertices(int V, const float* __restrict__ x, const float* __restrict__ data,
+                const float* __restrict__ weight, double* __restrict__ partial) {
+  double acc = 0.0;
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < V; v += gridDim.x * blockDim.x) {
+    float diff = (x[v] - data[v]) * weight[v];
+    diff = (diff > 0) ? diff : -diff;
+    acc += (double)diff;
+  }
+  block_sum_store(acc, partial);
+}
+
+__global__ void __launch_bounds__(256)
+k_cost_final(int n_edge_partials, int n_vertex_partials, const double* __restrict__ pe,
+             const double* __restrict__ pv, float data_factor, float* __restrict__ out) {
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < n_edge_partials; i += blockDim.x) a += pe[i];
+  for (int i = threadIdx.x; i < n_vertex_partials; i += blockDim.x) b += pv[i];
+  __shared__ double sa[4], sb[4];
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sa[w] = a, sb[w] = b;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = data_factor * (float)(sa[0] + sa[1] + sa[2] + sa[3]);
+    out[1] = (float)(sb[0] + sb[1] + sb[2] + sb[3]);
+  }
+}
+
+inline dim3 grid1d(int64_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers (all asynchronous on `stream`; return the hipError_t of the launch)
+// ------------------------------------------------------------------------------------------------
+int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, bool write_prev, int unroll,
+                      int waves_per_block, hipStream_t stream) {
+  if (a.n_slices <= 0) return (int)hipSuccess;
+  const int spx = (a.n_slices + 7) / 8;                          // slices per XCD
+  const int bpx = (spx + waves_per_block - 1) / waves_per_block;  // blocks per XCD
+  const dim3 grid((unsigned)(bpx * 8)), block((unsigned)(64 * waves_per_block));
+  const float4* bin = a.bar[parity];
+  float4* bout = a.bar[parity ^ 1];
+#define FLAME_LAUNCH(UU, WP)                                                                         \
+  hipLaunchKernelGGL((k_fused_step<UU, WP>), grid, block, 0, stream, a.n_slices, spx, a.slice_row,   \
+                     a.hrec, a.hq, a.vstate, a.vaux, bin, bout, a.vprev, p, a.err)
+  if (unroll >= 16) {
+    if (write_prev) FLAME_LAUNCH(16, true); else FLAME_LAUNCH(16, false);
+  } else if (unroll >= 8) {
+    if (write_prev) FLAME_LAUNCH(8, true); else FLAME_LAUNCH(8, false);
+  } else {
+    if (write_prev) FLAME_LAUNCH(4, true); else FLAME_LAUNCH(4, false);
+  }
+#undef FLAME_LAUNCH
+  return (int)hipGetLastError();
+}
+
+int launch_save_prev(const CanonArgs& c, hipStream_t s) {
+  if (c.V <= 0) return 0;
+  hipLaunchKernelGGL(k_save_prev, grid1d(c.V), dim3(256), 0, s, c.V, c.x, c.w1, c.w2, c.xp, c.w1p, c.w2p);
+  return (int)hipGetLastError();
+}
+
+int launch_dual(const CanonArgs& c, const SolverParams& p, hipStream_t s) {
+  if (c.E <= 0) return 0;
+  hipLaunchKernelGGL(k_dual_edge_sweep, grid1d(c.E), dim3(256), 0, s, c.E, c.src, c.dst, c.alpha, c.beta,
+                     c.pos, c.xb, c.w1b, c.w2b, c.q1, c.q2, c.q3, p, c.err);
+  return (int)hipGetLastError();
+}
+
+int launch_primal(const CanonArgs& c, const SolverParams& p, hipStream_t s) {
+  if (c.V <= 0) return 0;
+  hipLaunchKernelGGL(k_primal_vertex_gather, grid1d(c.V), dim3(256), 0, s, c.V, c.row_ptr, c.half, c.src,
+                     c.dst, c.alpha, c.beta, c.pos, c.q1, c.q2, c.q3, c.data, c.weight, c.x, c.w1, c.w2, p);
+  return (int)hipGetLastError();
+}
+
+int launch_extragradient(const CanonArgs& c, const SolverParams& p, hipStream_t s) {
+  if (c.V <= 0) return 0;
+  hipLaunchKernelGGL(k_extragradient, grid1d(c.V), dim3(256), 0, s, c.V, c.x, c.w1, c.w2, c.xp, c.w1p,
+                     c.w2p, c.xb, c.w1b, c.w2b, p);
+  return (int)hipGetLastError();
+}
+
+int launch_pack_static(const CanonArgs& c, const FusedArgs& a, hipStream_t s) {
+  if (a.n_slots <= 0) return 0;
+  hipLaunchKernelGGL(k_pack_static, grid1d(a.n_slots), dim3(256), 0, s, a.n_slots, a.rec_edge, a.rec_nbr,
+                     c.src, c.dst, c.alpha, c.pos, a.hrec);
+  return (int)hipGetLastError();
+}
+
+int launch_pack_state(const CanonArgs& c, const FusedArgs& a, int parity, hipStream_t s) {
+  if (a.n_slots > 0) {
+    hipLaunchKernelGGL(k_pack_edge_state, grid1d(a.n_slots), dim3(256), 0, s, a.n_slots, a.rec_edge, c.q1,
+                       c.q2, c.q3, c.beta, a.hq);
+  }
+  const int n_packed = a.n_slices * 64;
+  if (n_packed > 0) {
+    hipLaunchKernelGGL(k_pack_vertex_state, grid1d(n_packed), dim3(256), 0, s, n_packed, a.perm, a.pdeg,
+                       c.x, c.w1, c.w2, c.xb, c.w1b, c.w2b, c.data, c.weight, a.vstate, a.vaux,
+                       a.bar[parity]);
+    // the other ping-pong half must hold valid (zero) values in padding lanes too
+    (void)hipMemsetAsync(a.bar[parity ^ 1], 0, sizeof(float4) * (size_t)n_packed, s);
+  }
+  return (int)hipGetLastError();
+}
+
+int launch_unpack_state(const CanonArgs& c, const FusedArgs& a, int parity, bool have_prev, hipStream_t s) {
+  const int n_packed = a.n_slices * 64;
+  if (n_packed > 0) {
+    hipLaunchKernelGGL(k_unpack_vertex_state, grid1d(n_packed), dim3(256), 0, s, n_packed, a.perm, a.vstate,
+                       a.bar[parity], a.vprev, have_prev ? 1 : 0, c.x, c.w1, c.w2, c.xb, c.w1b, c.w2b,
+                       c.xp, c.w1p, c.w2p);
+  }
+  if (c.E > 0) {
+    hipLaunchKernelGGL(k_unpack_edge_state, grid1d(c.E), dim3(256), 0, s, c.E, a.edge_src_slot, a.hq, c.q1,
+                       c.q2, c.q3);
+  }
+  return (int)hipGetLastError();
+}
+
+int launch_export(const CanonArgs& c, const FusedArgs& a, bool packed_current, float scale, float* dst,
+                  hipStream_t s) {
+  if (c.V <= 0) return 0;
+  if (packed_current) {
+    const int n_packed = a.n_slices * 64;
+    hipLaunchKernelGGL(k_export_packed, grid1d(n_packed), dim3(256), 0, s, n_packed, a.perm, a.vstate, scale, dst);
+  } else {
+    hipLaunchKernelGGL(k_export_canonical, grid1d(c.V), dim3(256), 0, s, c.V, c.x, scale, dst);
+  }
+  return (int)hipGetLastError();
+}
+
+int launch_costs(const CanonArgs& c, const SolverParams& p, double* partial_e, double* partial_v,
+                 int n_partials, float* out2, hipStream_t s) {
+  hipLaunchKernelGGL(k_cost_edges, dim3(n_partials), dim3(256), 0, s, c.E, c.src, c.dst, c.alpha, c.beta,
+                     c.pos, c.x, c.w1, c.w2, partial_e);
+  hipLaunchKernelGGL(k_cost_vertices, dim3(n_partials), dim3(256), 0, s, c.V, c.x, c.data, c.weight, partial_v);
+  hipLaunchKernelGGL(k_cost_final, dim3(1), dim3(256), 0, s, n_partials, n_partials, partial_e, partial_v,
+                     p.data_factor, out2);
+  return (int)hipGetLastError();
+}
+
+}  // namespace flame_hip

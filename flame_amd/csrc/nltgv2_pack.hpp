@@ -1,0 +1,187 @@
+// nltgv2_pack.hpp -- host-side packing of a flat reference Graph image into the device layouts.
+//
+// Two layouts are derived from the caller's edge list (src[k] -> dst[k], k = boost::edges() order,
+// /root/reference/src/flame/optimizers/nltgv2_l1_graph_regularizer.cc:91-96):
+//
+//  (A) canonical CSR of incident half-edges, per ORIGINAL vertex, ascending edge id.  Ascending
+//      edge id is the order in which the reference's primalStep edge scatter (cc:120-142) touches a
+//      given vertex, so a sequential per-vertex gather over this list reproduces the reference's
+//      float accumulation order exactly.
+//
+//  (B) SELL-64 ("sliced ELLPACK, 64 = one gfx950 wavefront") layout for the fused sweep:
+//      vertices are renumbered (connected component, then Morton order of pos for locality, then
+//      by degree inside windows of 512 to equalise slice widths) and cut into slices of 64; slice s
+//      owns rows [slice_row[s], slice_row[s+1]) of 64-lane-wide half-edge arrays, row k holding the
+//      k-th incident half-edge (again ascending edge id) of each of its 64 vertices.  Lane l of a
+//      wave therefore streams rec[(row+k)*64 + l]: fully coalesced, one vertex per lane.
+//
+// Pure C++17, no HIP: also used by flame_nltgv2_pack_probe for the CPU test-suite.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <numeric>
+#include <vector>
+
+#include "flame_nltgv2.h"
+
+namespace flame_hip {
+
+constexpr int kWave = 64;           // gfx950 wavefront
+constexpr int kDegreeWindow = 512;  // vertices per degree-sorting window (8 slices)
+constexpr int kRowPad = 16;         // spare rows at the end of the half-edge arrays (largest unroll)
+constexpr uint32_t kRoleBit = 0x80000000u;  // set: the owning vertex is the TARGET (jj) of the edge
+
+struct PackedLayout {
+  int32_t V = 0, E = 0, n_slices = 0, max_degree = 0;
+  int64_t rows = 0;                    // 64-wide rows actually used (excluding kRowPad)
+  std::vector<int32_t> perm;           // [n_slices*64] packed slot -> original vertex (-1 padding)
+  std::vector<int32_t> iperm;          // [V] original vertex -> packed slot
+  std::vector<int32_t> pdeg;           // [n_slices*64] degree of packed vertex
+  std::vector<int32_t> slice_row;      // [n_slices+1]
+  std::vector<uint32_t> rec_nbr;       // [(rows+pad)*64] packed neighbour | role bit; empty: self
+  std::vector<int32_t> rec_edge;       // [(rows+pad)*64] edge id, -1 empty
+  std::vector<int32_t> edge_src_slot;  // [E] slot of the source-side copy of edge e
+  std::vector<int32_t> row_ptr;        // [V+1]  (A)
+  std::vector<uint32_t> half;          // [2E]   (A) edge id | role bit, ascending edge id per vertex
+};
+
+inline uint32_t morton_spread16(uint32_t v) {
+  v &= 0xFFFFu;
+  v = (v | (v << 8)) & 0x00FF00FFu;
+  v = (v | (v << 4)) & 0x0F0F0F0Fu;
+  v = (v | (v << 2)) & 0x33333333u;
+  v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+
+// Returns FLAME_NLTGV2_OK or FLAME_NLTGV2_ERR_INVALID_ARG.
+inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
+  if (!g || g->V < 0 || g->E < 0) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  const int32_t V = g->V, E = g->E;
+  if (V > 0 && !g->pos) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  if (E > 0 && (!g->src || !g->dst)) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  if (V >= (1 << 30)) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  L->V = V;
+  L->E = E;
+
+  // ---- (A) canonical CSR, ascending edge id -------------------------------------------------
+  L->row_ptr.assign(static_cast<size_t>(V) + 1, 0);
+  for (int32_t k = 0; k < E; ++k) {
+    const int32_t i = g->src[k], j = g->dst[k];
+    if (i < 0 || i >= V || j < 0 || j >= V || i == j) return FLAME_NLTGV2_ERR_INVALID_ARG;
+    L->row_ptr[i + 1]++;
+    L->row_ptr[j + 1]++;
+  }
+  for (int32_t v = 0; v < V; ++v) L->row_ptr[v + 1] += L->row_ptr[v];
+  L->half.assign(static_cast<size_t>(2) * E, 0);
+  {
+    std::vector<int32_t> cur(L->row_ptr.begin(), L->row_ptr.end() - 1);
+    for (int32_t k = 0; k < E; ++k) {
+      L->half[cur[g->src[k]]++] = static_cast<uint32_t>(k);
+      L->half[cur[g->dst[k]]++] = static_cast<uint32_t>(k) | kRoleBit;
+    }
+  }
+  int32_t maxdeg = 0;
+  for (int32_t v = 0; v < V; ++v) maxdeg = std::max(maxdeg, L->row_ptr[v + 1] - L->row_ptr[v]);
+  L->max_degree = maxdeg;
+
+  // ---- vertex renumbering ---------------------------------------------------------------------
+  // connected components (union-find): a batch of independent frames is a disjoint union and the
+  // frames overlap in image coordinates, so Morton order alone would interleave them.
+  std::vector<int32_t> parent(V);
+  std::iota(parent.begin(), parent.end(), 0);
+  auto find = [&](int32_t a) {
+    while (parent[a] != a) {
+      parent[a] = parent[parent[a]];
+      a = parent[a];
+    }
+    return a;
+  };
+  for (int32_t k = 0; k < E; ++k) {
+    int32_t a = find(g->src[k]), b = find(g->dst[k]);
+    if (a != b) parent[std::max(a, b)] = std::min(a, b);  // root = smallest id of the component
+  }
+  float minx = 0, miny = 0, maxx = 1, maxy = 1;
+  if (V > 0) {
+    minx = maxx = g->pos[0];
+    miny = maxy = g->pos[1];
+    for (int32_t v = 0; v < V; ++v) {
+      const float px = g->pos[2 * v], py = g->pos[2 * v + 1];
+      if (!std::isfinite(px) || !std::isfinite(py)) return FLAME_NLTGV2_ERR_INVALID_ARG;
+      minx = std::min(minx, px), maxx = std::max(maxx, px);
+      miny = std::min(miny, py), maxy = std::max(maxy, py);
+    }
+  }
+  const float sx = (maxx > minx) ? 65535.0f / (maxx - minx) : 0.0f;
+  const float sy = (maxy > miny) ? 65535.0f / (maxy - miny) : 0.0f;
+  std::vector<uint64_t> key(V);
+  for (int32_t v = 0; v < V; ++v) {
+    const uint32_t qx = static_cast<uint32_t>((g->pos[2 * v] - minx) * sx);
+    const uint32_t qy = static_cast<uint32_t>((g->pos[2 * v + 1] - miny) * sy);
+    const uint32_t m = morton_spread16(qx) | (morton_spread16(qy) << 1);
+    key[v] = (static_cast<uint64_t>(static_cast<uint32_t>(find(v))) << 32) | m;
+  }
+  std::vector<int32_t> order(V);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+  auto degree = [&](int32_t v) { return L->row_ptr[v + 1] - L->row_ptr[v]; };
+  for (int32_t w0 = 0; w0 < V; w0 += kDegreeWindow) {
+    const int32_t w1 = std::min<int32_t>(V, w0 + kDegreeWindow);
+    std::stable_sort(order.begin() + w0, order.begin() + w1,
+                     [&](int32_t a, int32_t b) { return degree(a) > degree(b); });
+  }
+
+  // ---- (B) SELL-64 ----------------------------------------------------------------------------
+  const int32_t n_slices = (V + kWave - 1) / kWave;
+  L->n_slices = n_slices;
+  const size_t n_packed = static_cast<size_t>(n_slices) * kWave;
+  L->perm.assign(n_packed, -1);
+  L->pdeg.assign(n_packed, 0);
+  L->iperm.assign(V, -1);
+  for (int32_t s = 0; s < V; ++s) {
+    L->perm[s] = order[s];
+    L->iperm[order[s]] = s;
+    L->pdeg[s] = degree(order[s]);
+  }
+  L->slice_row.assign(static_cast<size_t>(n_slices) + 1, 0);
+  for (int32_t s = 0; s < n_slices; ++s) {
+    int32_t width = 0;
+    for (int l = 0; l < kWave; ++l) width = std::max(width, L->pdeg[static_cast<size_t>(s) * kWave + l]);
+    L->slice_row[s + 1] = L->slice_row[s] + width;
+  }
+  L->rows = L->slice_row[n_slices];
+  const size_t n_slots = static_cast<size_t>(L->rows + kRowPad) * kWave;
+  L->rec_edge.assign(n_slots, -1);
+  L->rec_nbr.assign(n_slots, 0);
+  // empty slots point at a harmless, in-range vertex: the lane's own packed index where there is
+  // one, else 0 (spare rows).
+  for (int32_t s = 0; s < n_slices; ++s) {
+    for (int64_t r = L->slice_row[s]; r < L->slice_row[s + 1]; ++r) {
+      for (int l = 0; l < kWave; ++l) {
+        L->rec_nbr[static_cast<size_t>(r) * kWave + l] = static_cast<uint32_t>(s * kWave + l);
+      }
+    }
+  }
+  L->edge_src_slot.assign(E, -1);
+  for (size_t p = 0; p < n_packed; ++p) {
+    const int32_t o = L->perm[p];
+    if (o < 0) continue;
+    const int32_t s = static_cast<int32_t>(p / kWave), l = static_cast<int32_t>(p % kWave);
+    const int64_t row0 = L->slice_row[s];
+    for (int32_t k = 0; k < degree(o); ++k) {
+      const uint32_t h = L->half[L->row_ptr[o] + k];
+      const int32_t e = static_cast<int32_t>(h & ~kRoleBit);
+      const bool is_target = (h & kRoleBit) != 0;
+      const int32_t other = is_target ? g->src[e] : g->dst[e];
+      const size_t slot = static_cast<size_t>(row0 + k) * kWave + l;
+      L->rec_edge[slot] = e;
+      L->rec_nbr[slot] = static_cast<uint32_t>(L->iperm[other]) | (is_target ? kRoleBit : 0u);
+      if (!is_target) L->edge_src_slot[e] = static_cast<int32_t>(slot);
+    }
+  }
+  return FLAME_NLTGV2_OK;
+}
+
+}  // namespace flame_hip

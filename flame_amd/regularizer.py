@@ -1,0 +1,314 @@
+"""ctypes mirror of flame::optimizers::nltgv2_l1_graph_regularizer over the C-ABI
+(include/flame_nltgv2.h -> libflame_nltgv2_hip.so).
+
+Reference surface (/root/reference/src/flame/optimizers/nltgv2_l1_graph_regularizer.h):
+  struct Params h:121-129            -> Params
+  step(params, graph) h:134          -> Regularizer.step / .run(n)
+  smoothnessCost / dataCost / cost   -> Regularizer.smoothness_cost / data_cost / cost  (h:139-151)
+  internal::dualStep / primalStep / extraGradientStep h:158-168
+                                     -> Regularizer.dual_step / primal_step / extragradient_step
+Graph (h:107-112) is represented by a dict of flat numpy arrays (see flame_amd.synth.assemble_graph):
+the order of `src/dst` is boost::edges() order and (src,dst) = (boost::source, boost::target).
+
+This module never computes on the CPU: if the HIP library is missing or no GPU is present the calls
+raise NLTGV2Error.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_FP = C.POINTER(C.c_float)
+_IP = C.POINTER(C.c_int32)
+
+OPT_SOLVER, OPT_USE_HIPGRAPH, OPT_BLOCK_WAVES, OPT_UNROLL = 1, 2, 3, 4
+ERR_NAN = -5
+
+VERTEX_STATE = ("x", "w1", "w2", "x_bar", "w1_bar", "w2_bar", "x_prev", "w1_prev", "w2_prev")
+EDGE_STATE = ("q1", "q2", "q3")
+
+
+class NLTGV2Error(RuntimeError):
+    def __init__(self, status: int, what: str):
+        super().__init__(f"{what}: status {status} ({status_string(status)})")
+        self.status = status
+
+
+class Params(C.Structure):
+    """== struct Params, nltgv2_l1_graph_regularizer.h:121-129 (same defaults)."""
+
+    _fields_ = [(n, C.c_float) for n in ("data_factor", "step_x", "step_q", "theta", "x_min", "x_max")]
+
+    def __init__(self, data_factor=0.1, step_x=0.001, step_q=125.0, theta=0.25, x_min=0.0, x_max=10.0):
+        super().__init__(data_factor, step_x, step_q, theta, x_min, x_max)
+
+
+class _Graph(C.Structure):
+    _fields_ = (
+        [("V", C.c_int32), ("E", C.c_int32), ("pos", _FP)]
+        + [(n, _FP) for n in VERTEX_STATE + ("data_term", "data_weight")]
+        + [("src", _IP), ("dst", _IP)]
+        + [(n, _FP) for n in ("alpha", "beta") + EDGE_STATE]
+    )
+
+
+class _Info(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("device", C.c_int32), ("V", C.c_int32), ("E", C.c_int32),
+        ("n_slices", C.c_int32), ("max_degree", C.c_int32), ("padded_half_edges", C.c_int64),
+        ("device_bytes", C.c_int64), ("algorithmic_bytes_per_iter", C.c_int64), ("compute_units", C.c_int32),
+        ("device_name", C.c_char * 64), ("gcn_arch", C.c_char * 32),
+    ]
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "libflame_nltgv2_hip.so")
+
+
+# every symbol include/flame_nltgv2.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = (
+    "flame_nltgv2_default_params", "flame_nltgv2_create", "flame_nltgv2_destroy", "flame_nltgv2_set_stream",
+    "flame_nltgv2_upload_graph", "flame_nltgv2_update_data", "flame_nltgv2_upload_state", "flame_nltgv2_run",
+    "flame_nltgv2_run_async", "flame_nltgv2_sync", "flame_nltgv2_run_timed", "flame_nltgv2_save_prev",
+    "flame_nltgv2_dual_step", "flame_nltgv2_primal_step", "flame_nltgv2_extragradient_step", "flame_nltgv2_step",
+    "flame_nltgv2_costs", "flame_nltgv2_download_state", "flame_nltgv2_export_idepth_device",
+    "flame_nltgv2_set_option", "flame_nltgv2_get_info", "flame_nltgv2_last_error", "flame_nltgv2_last_hip_error",
+    "flame_nltgv2_status_string", "flame_nltgv2_abi_version", "flame_nltgv2_pack_probe",
+)
+
+
+def load_library():
+    """Loads libflame_nltgv2_hip.so (built in-tree by __graft_entry__.build()).  Raises if absent:
+    there is no fallback implementation."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise NLTGV2Error(-2, f"HIP library not built: {path} (run __graft_entry__.build())")
+    L = C.CDLL(path)
+    ctx = C.c_void_p
+    PP, GP = C.POINTER(Params), C.POINTER(_Graph)
+    sig = {
+        "flame_nltgv2_default_params": (None, [PP]),
+        "flame_nltgv2_create": (C.c_int, [C.POINTER(ctx), C.c_int]),
+        "flame_nltgv2_destroy": (C.c_int, [ctx]),
+        "flame_nltgv2_set_stream": (C.c_int, [ctx, C.c_void_p]),
+        "flame_nltgv2_upload_graph": (C.c_int, [ctx, GP]),
+        "flame_nltgv2_update_data": (C.c_int, [ctx, _FP, _FP]),
+        "flame_nltgv2_upload_state": (C.c_int, [ctx, GP]),
+        "flame_nltgv2_run": (C.c_int, [ctx, PP, C.c_int]),
+        "flame_nltgv2_run_async": (C.c_int, [ctx, PP, C.c_int]),
+        "flame_nltgv2_sync": (C.c_int, [ctx]),
+        "flame_nltgv2_run_timed": (C.c_int, [ctx, PP, C.c_int, _FP]),
+        "flame_nltgv2_save_prev": (C.c_int, [ctx]),
+        "flame_nltgv2_dual_step": (C.c_int, [ctx, PP]),
+        "flame_nltgv2_primal_step": (C.c_int, [ctx, PP]),
+        "flame_nltgv2_extragradient_step": (C.c_int, [ctx, PP]),
+        "flame_nltgv2_step": (C.c_int, [ctx, PP]),
+        "flame_nltgv2_costs": (C.c_int, [ctx, PP, _FP, _FP]),
+        "flame_nltgv2_download_state": (C.c_int, [ctx, GP]),
+        "flame_nltgv2_export_idepth_device": (C.c_int, [ctx, C.c_void_p, C.c_float]),
+        "flame_nltgv2_set_option": (C.c_int, [ctx, C.c_int, C.c_int]),
+        "flame_nltgv2_get_info": (C.c_int, [ctx, C.POINTER(_Info)]),
+        "flame_nltgv2_last_error": (C.c_int, [ctx]),
+        "flame_nltgv2_last_hip_error": (C.c_int, [ctx]),
+        "flame_nltgv2_status_string": (C.c_char_p, [C.c_int]),
+        "flame_nltgv2_abi_version": (C.c_int, []),
+        "flame_nltgv2_pack_probe": (C.c_int, [GP, _IP, _IP, _IP, _IP, C.c_int64, C.POINTER(C.c_int64)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    _LIB = L
+    return L
+
+
+def status_string(status: int) -> str:
+    try:
+        return load_library().flame_nltgv2_status_string(int(status)).decode()
+    except Exception:  # library missing
+        return "?"
+
+
+def _as(arr, dtype, n, name):
+    a = np.ascontiguousarray(arr, dtype=dtype)
+    if a.size != n:
+        raise ValueError(f"{name}: expected {n} elements, got {a.size}")
+    return a
+
+
+def _graph_view(g: dict, keep: list, need_all=True) -> _Graph:
+    V, E = int(g["V"]), int(g["E"])
+    cg = _Graph()
+    cg.V, cg.E = V, E
+    sizes = {"pos": 2 * V, "data_term": V, "data_weight": V, "src": E, "dst": E, "alpha": E, "beta": E}
+    sizes.update({k: V for k in VERTEX_STATE})
+    sizes.update({k: E for k in EDGE_STATE})
+    for name, ctype in _Graph._fields_[2:]:
+        if name not in g or g[name] is None:
+            if need_all and not name.endswith("_prev"):
+                raise KeyError(name)
+            continue
+        dt = np.int32 if ctype is _IP else np.float32
+        a = _as(g[name], dt, sizes[name], name)
+        keep.append(a)
+        setattr(cg, name, a.ctypes.data_as(ctype))
+    return cg
+
+
+def pack_probe(g: dict):
+    """Host-only view of the SELL-64 layout the fused sweep uses (no GPU needed)."""
+    L = load_library()
+    keep = []
+    cg = _graph_view(g, keep, need_all=False)
+    rows = C.c_int64(0)
+    n_slices = L.flame_nltgv2_pack_probe(C.byref(cg), None, None, None, None, 0, C.byref(rows))
+    if n_slices < 0:
+        raise NLTGV2Error(n_slices, "pack_probe")
+    perm = np.empty(n_slices * 64, np.int32)
+    slice_row = np.empty(n_slices + 1, np.int32)
+    rec_nbr = np.empty(rows.value * 64, np.int32)
+    rec_edge = np.empty(rows.value * 64, np.int32)
+    rc = L.flame_nltgv2_pack_probe(C.byref(cg), perm.ctypes.data_as(_IP), slice_row.ctypes.data_as(_IP),
+                                   rec_nbr.ctypes.data_as(_IP), rec_edge.ctypes.data_as(_IP), rows.value,
+                                   C.byref(rows))
+    if rc < 0:
+        raise NLTGV2Error(rc, "pack_probe")
+    return dict(n_slices=n_slices, rows=rows.value, perm=perm, slice_row=slice_row,
+                rec_nbr=rec_nbr.view(np.uint32), rec_edge=rec_edge)
+
+
+class Regularizer:
+    """One solver context on one GPU; holds the device image of one Graph."""
+
+    def __init__(self, device: int = 0):
+        self._L = load_library()
+        self._ctx = C.c_void_p()
+        rc = self._L.flame_nltgv2_create(C.byref(self._ctx), int(device))
+        if rc != 0:
+            self._ctx = None
+            raise NLTGV2Error(rc, "flame_nltgv2_create")
+        self.V = self.E = 0
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.flame_nltgv2_destroy(self._ctx)
+            self._ctx = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise NLTGV2Error(rc, what)
+
+    # ---- graph in / out -------------------------------------------------------------------------
+    def upload_graph(self, g: dict):
+        keep = []
+        cg = _graph_view(g, keep)
+        self._chk(self._L.flame_nltgv2_upload_graph(self._ctx, C.byref(cg)), "upload_graph")
+        self.V, self.E = int(g["V"]), int(g["E"])
+
+    def update_data(self, data_term, data_weight):
+        d = _as(data_term, np.float32, self.V, "data_term")
+        w = _as(data_weight, np.float32, self.V, "data_weight")
+        self._chk(self._L.flame_nltgv2_update_data(self._ctx, d.ctypes.data_as(_FP), w.ctypes.data_as(_FP)),
+                  "update_data")
+
+    def upload_state(self, state: dict):
+        keep = []
+        s = dict(state)
+        s.setdefault("V", self.V)
+        s.setdefault("E", self.E)
+        cg = _graph_view(s, keep, need_all=False)
+        self._chk(self._L.flame_nltgv2_upload_state(self._ctx, C.byref(cg)), "upload_state")
+
+    def download_state(self, keys=VERTEX_STATE + EDGE_STATE) -> dict:
+        out = {}
+        cg = _Graph()
+        for k in keys:
+            n = self.V if k in VERTEX_STATE else self.E
+            out[k] = np.empty(n, np.float32)
+            setattr(cg, k, out[k].ctypes.data_as(_FP))
+        self._chk(self._L.flame_nltgv2_download_state(self._ctx, C.byref(cg)), "download_state")
+        return out
+
+    # ---- the reference call surface -------------------------------------------------------------
+    def run(self, params: Params, n_iters: int):
+        """n_iters x step(params, graph), nltgv2...cc:33-49."""
+        self._chk(self._L.flame_nltgv2_run(self._ctx, C.byref(params), int(n_iters)), "run")
+
+    def step(self, params: Params):
+        self._chk(self._L.flame_nltgv2_step(self._ctx, C.byref(params)), "step")
+
+    def run_async(self, params: Params, n_iters: int):
+        self._chk(self._L.flame_nltgv2_run_async(self._ctx, C.byref(params), int(n_iters)), "run_async")
+
+    def sync(self):
+        self._chk(self._L.flame_nltgv2_sync(self._ctx), "sync")
+
+    def run_timed(self, params: Params, n_iters: int) -> float:
+        """Returns device milliseconds (HIP events on the solver's stream)."""
+        ms = C.c_float(0)
+        self._chk(self._L.flame_nltgv2_run_timed(self._ctx, C.byref(params), int(n_iters), C.byref(ms)), "run_timed")
+        return float(ms.value)
+
+    def save_prev(self):
+        self._chk(self._L.flame_nltgv2_save_prev(self._ctx), "save_prev")
+
+    def dual_step(self, params: Params):
+        self._chk(self._L.flame_nltgv2_dual_step(self._ctx, C.byref(params)), "dual_step")
+
+    def primal_step(self, params: Params):
+        self._chk(self._L.flame_nltgv2_primal_step(self._ctx, C.byref(params)), "primal_step")
+
+    def extragradient_step(self, params: Params):
+        self._chk(self._L.flame_nltgv2_extragradient_step(self._ctx, C.byref(params)), "extragradient_step")
+
+    def costs(self, params: Params):
+        s, d = C.c_float(0), C.c_float(0)
+        self._chk(self._L.flame_nltgv2_costs(self._ctx, C.byref(params), C.byref(s), C.byref(d)), "costs")
+        return float(s.value), float(d.value)
+
+    def smoothness_cost(self, params: Params) -> float:
+        return self.costs(params)[0]
+
+    def data_cost(self, params: Params) -> float:
+        return self.costs(params)[1]
+
+    def cost(self, params: Params) -> float:
+        s, d = self.costs(params)
+        return float(np.float32(s) + np.float32(d))
+
+    # ---- plumbing -------------------------------------------------------------------------------
+    def set_stream(self, hip_stream_ptr: int | None):
+        self._chk(self._L.flame_nltgv2_set_stream(self._ctx, C.c_void_p(hip_stream_ptr or 0)), "set_stream")
+
+    def set_option(self, option: int, value: int):
+        self._chk(self._L.flame_nltgv2_set_option(self._ctx, int(option), int(value)), "set_option")
+
+    def export_idepth_device(self, device_ptr: int, scale: float = 1.0):
+        self._chk(self._L.flame_nltgv2_export_idepth_device(self._ctx, C.c_void_p(device_ptr), C.c_float(scale)),
+                  "export_idepth_device")
+
+    def info(self) -> dict:
+        i = _Info()
+        self._chk(self._L.flame_nltgv2_get_info(self._ctx, C.byref(i)), "get_info")
+        d = {n: getattr(i, n) for n, _ in _Info._fields_}
+        d["device_name"] = d["device_name"].decode(errors="replace")
+        d["gcn_arch"] = d["gcn_arch"].decode(errors="replace")
+        return d
+
+    def last_error(self) -> int:
+        return int(self._L.flame_nltgv2_last_error(self._ctx))

@@ -1,0 +1,177 @@
+/*
+ * flame_nltgv2.h -- C-ABI of libflame_nltgv2_hip.so: the MI355X (gfx950) implementation of FLaME's
+ * NLTGV2-L1 primal-dual graph regularizer.
+ *
+ * This is the drop-in boundary for ONE path of robustrobotics/flame:
+ *   src/flame/optimizers/nltgv2_l1_graph_regularizer.{h,cc}   (namespace
+ *   flame::optimizers::nltgv2_l1_graph_regularizer), called from src/flame/flame.cc:104 (solver
+ *   thread) and flame.cc:2172-2173 (cost statistics).
+ * Every entry point below names the reference interface it replaces.  Plain pointers and sizes
+ * only; no C++/torch types.  All pointers are HOST memory unless the name says "device".
+ *
+ * Conventions
+ *   - All functions return 0 (FLAME_NLTGV2_OK) on success or a negative flame_nltgv2_status.
+ *     Nothing here aborts or throws (the reference's FLAME_ASSERT calls exit(1), assert.h:111).
+ *   - A context is NOT thread-safe; use one per solver thread.  The caller provides the
+ *     graph_mtx_-equivalent (flame.h:539; lock sites flame.cc:103, 302, 309, 329, 365).
+ *   - Edge k is directed src[k] -> dst[k] == (boost::source, boost::target) of the k-th edge of
+ *     boost::edges(graph) (nltgv2...cc:91-96).  Orientation is semantic (the operator uses the
+ *     SOURCE vertex's w_bar only, cc:100-101,129-133); edge order fixes the floating-point
+ *     accumulation order of primalStep (cc:120-142) and is honoured exactly.
+ *   - There is no CPU fallback: every compute entry point fails with
+ *     FLAME_NLTGV2_ERR_NO_DEVICE / _HIP when no gfx950 device is usable.
+ */
+#ifndef FLAME_NLTGV2_H_
+#define FLAME_NLTGV2_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLAME_NLTGV2_ABI_VERSION 1
+
+typedef struct flame_nltgv2_ctx flame_nltgv2_ctx;
+
+typedef enum flame_nltgv2_status {
+  FLAME_NLTGV2_OK = 0,
+  FLAME_NLTGV2_ERR_INVALID_ARG = -1, /* NULL pointer, negative size, index out of range, self loop */
+  FLAME_NLTGV2_ERR_NO_DEVICE = -2,   /* no HIP device / wrong device ordinal */
+  FLAME_NLTGV2_ERR_HIP = -3,         /* a HIP runtime call failed (see flame_nltgv2_last_hip_error) */
+  FLAME_NLTGV2_ERR_NO_GRAPH = -4,    /* compute call before flame_nltgv2_upload_graph */
+  FLAME_NLTGV2_ERR_NAN = -5,         /* a dual variable became NaN/Inf: the condition on which the
+                                        reference's FLAME_ASSERT(!std::isnan(new_q)) fires
+                                        (nltgv2...h:174).  Sticky until the next upload. */
+  FLAME_NLTGV2_ERR_OOM = -6
+} flame_nltgv2_status;
+
+/* == struct Params, nltgv2_l1_graph_regularizer.h:121-129 (same fields, order and defaults). */
+typedef struct flame_nltgv2_params {
+  float data_factor; /* 0.1   lambda */
+  float step_x;      /* 0.001 primal step tau */
+  float step_q;      /* 125   dual step sigma */
+  float theta;       /* 0.25  extra-gradient step */
+  float x_min;       /* 0     feasible set */
+  float x_max;       /* 10 */
+} flame_nltgv2_params;
+
+/* Flat (structure-of-arrays) image of a reference Graph (h:107-112): VertexData (h:74-90) and
+ * EdgeData (h:95-102; `valid` is syncGraph bookkeeping, flame.cc:2080-2118, and has no image here).
+ * Used read-only by upload and write-only by download; in a download any pointer may be NULL to
+ * skip that array. */
+typedef struct flame_nltgv2_graph {
+  int32_t V, E;
+  float* pos; /* 2*V floats, (x,y) interleaved: VertexData::pos */
+  float *x, *w1, *w2;
+  float *x_bar, *w1_bar, *w2_bar;
+  float *x_prev, *w1_prev, *w2_prev; /* upload: may be NULL (step() overwrites them, cc:35-42) */
+  float *data_term, *data_weight;
+  int32_t *src, *dst;
+  float *alpha, *beta;
+  float *q1, *q2, *q3;
+} flame_nltgv2_graph;
+
+void flame_nltgv2_default_params(flame_nltgv2_params* p);
+
+/* Context lifetime.  `device` is the HIP device ordinal (one process / one context per GPU).
+ * Replaces: the Graph object owned by Flame (flame.h:536) as the holder of solver state. */
+int flame_nltgv2_create(flame_nltgv2_ctx** out, int device);
+int flame_nltgv2_destroy(flame_nltgv2_ctx* ctx);
+
+/* Run all subsequent work of this context on the caller's hipStream_t (pass NULL to return to the
+ * context's own stream).  Lets a host framework time / order the solver with its own events. */
+int flame_nltgv2_set_stream(flame_nltgv2_ctx* ctx, void* hip_stream);
+
+/* Topology + weights + state -> device.  Replaces the graph (re)construction of
+ * Flame::syncGraph (flame.cc:2030-2121: add_vertex / add_edge / remove_*), after which the packed
+ * device layout is rebuilt.  Buffers are reused and grown geometrically across calls. */
+int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g);
+
+/* Per-frame refresh of data_term/data_weight for an unchanged topology (flame.cc:1985-2018). */
+int flame_nltgv2_update_data(flame_nltgv2_ctx* ctx, const float* data_term, const float* data_weight);
+
+/* State only (x,w,x_bar,w_bar,q; NULL members are left untouched) for an unchanged topology,
+ * e.g. after projectGraph re-projected x (flame.cc:1898-1900) or rescale_data (flame.cc:328-351). */
+int flame_nltgv2_upload_state(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* state);
+
+/* n_iters x step(params, graph) (nltgv2...cc:33-49), state resident on the device; returns after
+ * the work has completed.  Replaces the body of the solver thread loop, flame.cc:101-107. */
+int flame_nltgv2_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n_iters);
+/* Same, but only enqueues; flame_nltgv2_sync waits and reports the NaN flag. */
+int flame_nltgv2_run_async(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n_iters);
+int flame_nltgv2_sync(flame_nltgv2_ctx* ctx);
+/* Same as run, additionally returns the device time of the n_iters steps measured with HIP events
+ * on the stream the kernels run on (what bench.py reports). */
+int flame_nltgv2_run_timed(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n_iters, float* elapsed_ms);
+
+/* The individually callable pieces of a step, each one kernel sweep over the canonical SoA state:
+ *   save_prev           step()'s x_prev/w_prev copy                 cc:35-42
+ *   dual_step           internal::dualStep                          cc:89-114
+ *   primal_step         internal::primalStep (+ proxL1)             cc:116-154
+ *   extragradient_step  internal::extraGradientStep                 cc:156-174
+ * step == save_prev; dual; primal; extragradient == flame_nltgv2_run(ctx,p,1). */
+int flame_nltgv2_save_prev(flame_nltgv2_ctx* ctx);
+int flame_nltgv2_dual_step(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p);
+int flame_nltgv2_primal_step(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p);
+int flame_nltgv2_extragradient_step(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p);
+int flame_nltgv2_step(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p);
+
+/* smoothnessCost (cc:51-71) and dataCost (cc:73-85); cost() (h:149-151) is their sum.  Summed in
+ * double with a fixed reduction tree (the reference sums sequentially in float). */
+int flame_nltgv2_costs(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, float* smoothness, float* data);
+
+/* Device -> host copy of the solver state in the caller's original vertex/edge order.  Replaces
+ * the read-back loop flame.cc:372-380 (and is the checkpoint format). */
+int flame_nltgv2_download_state(flame_nltgv2_ctx* ctx, flame_nltgv2_graph* out);
+
+/* Writes scale * x[v] (original vertex order, V floats) into DEVICE memory `dst_device`, on the
+ * context's stream: the `vtx.x * graph_scale_` of flame.cc:377, kept on the GPU so that a
+ * multi-GPU host can hand the buffer straight to an RCCL gather. */
+int flame_nltgv2_export_idepth_device(flame_nltgv2_ctx* ctx, void* dst_device, float scale);
+
+/* Options (flame_nltgv2_set_option). */
+enum {
+  FLAME_NLTGV2_OPT_SOLVER = 1,       /* 0 = fused one-kernel-per-step sweep (default), 1 = 4-kernel
+                                        canonical sweeps (save_prev/dual/primal/extragradient) */
+  FLAME_NLTGV2_OPT_USE_HIPGRAPH = 2, /* 1 (default) = capture the n_iters launches in a hipGraph */
+  FLAME_NLTGV2_OPT_BLOCK_WAVES = 3,  /* waves per workgroup of the fused sweep: 0 = auto, 1,2,4 */
+  FLAME_NLTGV2_OPT_UNROLL = 4        /* half-edge slots per load chunk of the fused sweep: 0 = auto, 4,8,16 */
+};
+int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value);
+
+typedef struct flame_nltgv2_info {
+  int32_t abi_version;
+  int32_t device;
+  int32_t V, E;
+  int32_t n_slices;        /* 64-vertex slices of the packed (SELL-64) layout */
+  int32_t max_degree;
+  int64_t padded_half_edges; /* slots in the packed half-edge arrays (>= 2*E) */
+  int64_t device_bytes;    /* device memory held by the context */
+  int64_t algorithmic_bytes_per_iter; /* 64*V + 40*E, SURVEY.md section 8(d) */
+  int32_t compute_units;
+  char device_name[64];
+  char gcn_arch[32];
+} flame_nltgv2_info;
+int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info);
+
+/* Error reporting. */
+int flame_nltgv2_last_error(flame_nltgv2_ctx* ctx);     /* last non-OK status of this context */
+int flame_nltgv2_last_hip_error(flame_nltgv2_ctx* ctx); /* raw hipError_t of the last HIP failure */
+const char* flame_nltgv2_status_string(int status);
+int flame_nltgv2_abi_version(void);
+
+/* Host-only packing probe (no device needed; used by the CPU test-suite): builds the packed
+ * SELL-64 layout the fused sweep runs on and copies it out.  Any output pointer may be NULL.
+ *   perm[n_slices*64]       packed slot -> original vertex id (-1 = padding lane)
+ *   slice_row[n_slices+1]   first 64-wide row of each slice in the half-edge arrays
+ *   rec_nbr[rows*64]        packed neighbour index | role<<31 (role 1: this vertex is the TARGET)
+ *   rec_edge[rows*64]       original edge id of the slot (-1 = empty)
+ * Returns n_slices (>= 0) or a negative status; *rows_out receives the number of 64-wide rows. */
+int flame_nltgv2_pack_probe(const flame_nltgv2_graph* g, int32_t* perm, int32_t* slice_row,
+                            int32_t* rec_nbr, int32_t* rec_edge, int64_t capacity_rows, int64_t* rows_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLAME_NLTGV2_H_ */

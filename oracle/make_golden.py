@@ -1,0 +1,69 @@
+"""Generates tests/golden/*.npz (run in the build container: needs oracle/_ref/libref_triangle.so,
+i.e. /root/reference).  Usage:  python -m oracle.make_golden
+
+What the fixtures are -- and are not:
+  * INPUTS: synthetic vertices (flame_amd.synth) triangulated by the REFERENCE's vendored Triangle
+    with the reference's switches, so edge order and (source,target) orientation are exactly what
+    flame.cc:2085-2096 would feed boost::add_edge.
+  * OUTPUTS: solver state after N steps computed by oracle/nltgv2_oracle.c, cross-checked bit-exact
+    against oracle/nltgv2_numpy.py.  They are NOT outputs of the reference binary (unbuildable here,
+    see nltgv2_oracle.c header) -> PARITY UNPINNED; they freeze the restatement so that the on-box
+    GPU run is checked against numbers that were produced and reviewed in the build container.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from flame_amd import synth
+from oracle import capi, nltgv2_numpy, ref_triangle
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+INPUT_KEYS = ("pos", "data_term", "data_weight", "src", "dst", "alpha", "beta")
+
+
+def make(config: str, seed: int, iters, full_at, weights: str = "ones"):
+    g = synth.make_graph(config, seed, delaunay=ref_triangle.delaunay_edges)
+    if weights == "varied":  # adaptive_data_weights-like (flame.cc:2043-2044) + non-unit beta
+        g["data_weight"] = (np.float32(0.25) + np.float32(3.0) * synth.uniform01(seed, g["V"], stream=9)).astype(np.float32)
+        g["beta"] = (np.float32(0.5) + synth.uniform01(seed, g["E"], stream=10)).astype(np.float32)
+    out = {k: g[k] for k in INPUT_KEYS}
+    out["config"] = np.array(config)
+    out["seed"] = np.array(seed)
+    out["iters"] = np.array(sorted(iters))
+    a = synth.copy_graph(g)
+    b = synth.copy_graph(g)
+    done = 0
+    for n in sorted(iters):
+        capi.run(a, n - done)
+        nltgv2_numpy.run(b, n - done, capi.DEFAULT_PARAMS)
+        done = n
+        for k in synth.STATE_KEYS:
+            assert np.array_equal(a[k], b[k]), (config, n, k)
+        keys = synth.STATE_KEYS if n in full_at else ("x", "w1", "w2")
+        for k in keys:
+            if k.endswith("_prev"):
+                continue
+            out[f"n{n}_{k}"] = a[k].copy()
+        sm, dc = capi.costs(a)
+        out[f"n{n}_cost"] = np.array([sm, dc], dtype=np.float32)
+    return out
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    jobs = [
+        ("cfg1_320x240_s1234", dict(config="320x240", seed=1234, iters=(1, 2, 50, 200), full_at=(1, 2, 50, 200))),
+        ("cfg1_320x240_s77_varied", dict(config="320x240", seed=77, iters=(1, 50), full_at=(50,), weights="varied")),
+        ("cfg2_640x480_s1234", dict(config="640x480", seed=1234, iters=(1, 50, 200), full_at=(200,))),
+    ]
+    for name, kw in jobs:
+        d = make(**kw)
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **d)
+        print(name, "V", d["pos"].shape[0], "E", d["src"].shape[0], os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
