@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip batched / other-config measurements")
     ap.add_argument("--cpu-iters", type=int, default=8000)
+    ap.add_argument("--persistent", type=int, default=1, help="0: one launch per step; 1: persistent single launch")
     return ap.parse_args()
 
 
@@ -100,23 +101,24 @@ def main():
     # one independent frame per rank (BASELINE configs[3]); seeds differ so the frames differ
     g = synth.make_graph(a.config, seed=1234 + rank)
     reg = flame_amd.Regularizer(local_rank)
+    reg.set_option(flame_amd.regularizer.OPT_PERSISTENT, a.persistent)
     reg.upload_graph(g)
     info = reg.info()
 
     after_step = None
     if dist is not None:
-        # result gather: x*graph_scale of every frame, padded to a common length, RCCL all_gather
-        vmax_t = torch.tensor([g["V"]], device="cuda", dtype=torch.int64)
-        dist.all_reduce(vmax_t, op=dist.ReduceOp.MAX)
-        vmax = int(vmax_t.item())
-        mine = torch.zeros(vmax, dtype=torch.float32, device="cuda")
-        gathered = torch.empty(world * vmax, dtype=torch.float32, device="cuda")
+        # result gather (configs[3]): x*graph_scale of every rank's frame to all ranks, one RCCL
+        # all_gather per step; no collective on the solve path
+        from flame_amd.frames import IdepthGather
+
+        ig = IdepthGather(dist, [g["V"]], world, torch.device("cuda", local_rank))
 
         def after_step():
-            reg.export_idepth_device(mine.data_ptr(), 1.0)
-            dist.all_gather_into_tensor(gathered, mine)
+            reg.export_idepth_device(ig.local_row(0).data_ptr(), 1.0)
+            ig.gather()
 
     wall, ev_ms = measure(reg, params, a.iters, a.steps, a.warmup, sync, barrier, after_step)
+    run_path = flame_amd.regularizer.RUN_PATHS.get(reg.info()["last_run_path"], "?")
     if dist is not None:
         t = torch.tensor([wall], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -150,6 +152,7 @@ def main():
                        "parallelism": f"frames x{world}" if world > 1 else "single frame"},
             "roofline": roofline,
             "device": {"name": info["device_name"], "arch": info["gcn_arch"], "cus": info["compute_units"]},
+            "run_path": run_path,
         }
         # ---- parity of THIS run's input against the CPU checker (same seeded input, same iteration count)
         from oracle import capi as oracle

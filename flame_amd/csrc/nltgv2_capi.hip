@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -25,6 +26,7 @@ namespace {
 constexpr int kGraphChunk = 256;      // steps per captured hipGraph (even: keeps ping-pong parity)
 constexpr int kCostPartials = 256;
 constexpr int kMaxCachedGraphs = 6;
+constexpr unsigned kMaxSpins = 1u << 20;  // bound of every neighbour wait in the persistent run (~1 s)
 
 struct DevBuf {
   void* p = nullptr;
@@ -56,7 +58,10 @@ struct flame_nltgv2_ctx {
   uint64_t topo = 0, stamp = 0;
   bool pointers_changed = false;
 
-  int opt_solver = 0, opt_use_graph = 1, opt_block_waves = 0, opt_unroll = 0;
+  int opt_solver = 0, opt_use_graph = 1, opt_block_waves = 0, opt_unroll = 0, opt_persistent = 1;
+  uint32_t tag_next = 1;  // persistent run: tag of the current bar values (monotonic)
+  bool state_lost = false;
+  int last_run_path = 0;
 
   PackedLayout L;
   CanonArgs c;
@@ -66,6 +71,7 @@ struct flame_nltgv2_ctx {
   DevBuf pos, x, w1, w2, xb, w1b, w2b, xp, w1p, w2p, data, weight, src, dst, alpha, beta, q1, q2, q3, row_ptr, half;
   // packed
   DevBuf slice_row, perm, pdeg, rec_nbr, rec_edge, edge_src_slot, hrec, hq, vstate, vaux, bar0, bar1, vprev;
+  DevBuf gran0, gran1, abort_flag, he_slot, he_vid, he_meta, he_wave_chain;
   // misc
   DevBuf err, cost_pe, cost_pv, cost_out;
   int* h_err = nullptr;    // pinned
@@ -162,6 +168,11 @@ void refresh_args(flame_nltgv2_ctx* ctx) {
   f.vstate = (float4*)ctx->vstate.p, f.vaux = (float2*)ctx->vaux.p;
   f.bar[0] = (float4*)ctx->bar0.p, f.bar[1] = (float4*)ctx->bar1.p;
   f.vprev = (float4*)ctx->vprev.p;
+  f.gran[0] = ctx->gran0.p, f.gran[1] = ctx->gran1.p;
+  f.he_waves = ctx->L.he_ok ? ctx->L.he_waves : 0;
+  f.he_slot = (int32_t*)ctx->he_slot.p, f.he_vid = (int32_t*)ctx->he_vid.p;
+  f.he_meta = (uint32_t*)ctx->he_meta.p, f.he_wave_chain = (int32_t*)ctx->he_wave_chain.p;
+  f.abort_flag = (int*)ctx->abort_flag.p;
   f.err = (int*)ctx->err.p;
 }
 
@@ -194,6 +205,13 @@ void pick_config(const flame_nltgv2_ctx* ctx, int* unroll, int* wpb) {
   const bool small = ctx->L.n_slices <= 8 * ctx->prop.multiProcessorCount;
   *unroll = ctx->opt_unroll ? ctx->opt_unroll : (small ? 8 : 4);
   *wpb = ctx->opt_block_waves ? ctx->opt_block_waves : (small ? 1 : 4);
+}
+
+bool persistent_eligible(const flame_nltgv2_ctx* ctx, int n) {
+  // one lane per half-edge, all waves resident: <= 24 waves per CU (the kernel needs < 64 VGPRs, so
+  // the hardware admits 32); the cooperative launch re-checks and we fall back if it refuses.
+  return ctx->opt_persistent && n >= 4 && n <= (1 << 24) && ctx->L.he_ok && ctx->L.he_waves > 0 &&
+         ctx->L.he_waves <= 24 * ctx->prop.multiProcessorCount && ctx->prop.cooperativeLaunch;
 }
 
 bool same_params(const flame_nltgv2_params& a, const flame_nltgv2_params& b) {
@@ -251,7 +269,7 @@ int get_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n, int pa
 // Builds (if needed) every hipGraph a run of n steps will replay, without running anything: keeps
 // graph instantiation out of timed regions.
 int prepare_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
-  if (ctx->opt_solver != 0 || !ctx->opt_use_graph) return 0;
+  if (ctx->opt_solver != 0 || !ctx->opt_use_graph || persistent_eligible(ctx, n)) return 0;
   int unroll, wpb;
   pick_config(ctx, &unroll, &wpb);
   int parity = ctx->parity;
@@ -281,12 +299,37 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       LAUNCHCHK(ctx, launch_extragradient(ctx->c, sp, ctx->stream));
     }
     ctx->fused_valid = false;
+    ctx->last_run_path = 4;
     return 0;
   }
   int rc = ensure_fused(ctx);
   if (rc) return rc;
   int unroll, wpb;
   pick_config(ctx, &unroll, &wpb);
+  if (persistent_eligible(ctx, n)) {
+    // tags must stay unique: clear the granule buffers long before the 32-bit counter could wrap
+    if ((uint64_t)ctx->tag_next + (uint64_t)n >= 0x7fff0000ull) {
+      const size_t bytes = 16 * (size_t)ctx->L.n_slices * kWave;
+      HIPCHK(ctx, hipMemsetAsync(ctx->gran0.p, 0, bytes, ctx->stream));
+      HIPCHK(ctx, hipMemsetAsync(ctx->gran1.p, 0, bytes, ctx->stream));
+      ctx->tag_next = 1;
+    }
+    const int pw = ctx->L.he_waves <= 4 * ctx->prop.multiProcessorCount ? 1 : 4;  // waves per workgroup
+    // a fresh first tag per launch: records left by earlier runs (whose state may since have been
+    // changed by per-step launches or host uploads) can never satisfy a wait of this launch
+    const uint32_t tag0 = ctx->tag_next + 2;
+    int e = launch_persistent_run(ctx->f, to_sp(p), ctx->parity, tag0, n, pw, std::getenv("FLAME_NLTGV2_DEBUG_NOWAIT") ? 0xfffffffeu : kMaxSpins, ctx->stream);
+    if (e == 0) {
+      ctx->tag_next = tag0 + (uint32_t)n;
+      ctx->last_run_path = 1;
+      ctx->parity ^= (n & 1);
+      ctx->have_prev = true;
+      ctx->canon_valid = false;
+      return 0;
+    }
+    (void)hipGetLastError();  // e.g. cooperative launch too large: fall through to per-step launches
+    ctx->opt_persistent = 0;
+  }
   int left = n;
   while (left > 0) {
     const int chunk = left >= kGraphChunk ? kGraphChunk : left;
@@ -295,9 +338,11 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       rc = get_graph(ctx, p, chunk, ctx->parity, unroll, wpb, &exec);
       if (rc) return rc;
       HIPCHK(ctx, hipGraphLaunch(exec, ctx->stream));
+      ctx->last_run_path = 2;
     } else {
       rc = enqueue_fused_eager(ctx, p, chunk, ctx->parity, unroll, wpb, true);
       if (rc) return rc;
+      ctx->last_run_path = 3;
     }
     ctx->parity ^= (chunk & 1);
     left -= chunk;
@@ -310,6 +355,10 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
 int finish(flame_nltgv2_ctx* ctx) {
   HIPCHK(ctx, hipMemcpyAsync(ctx->h_err, ctx->err.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (*ctx->h_err & 2) {
+    ctx->have_graph = false;  // some slices wrote their state back, others did not
+    return fail(ctx, FLAME_NLTGV2_ERR_TIMEOUT);
+  }
   if (*ctx->h_err != 0) return fail(ctx, FLAME_NLTGV2_ERR_NAN);
   return 0;
 }
@@ -337,6 +386,7 @@ const char* flame_nltgv2_status_string(int status) {
     case FLAME_NLTGV2_ERR_NO_GRAPH: return "no graph uploaded";
     case FLAME_NLTGV2_ERR_NAN: return "dual variable became NaN/Inf (reference FLAME_ASSERT, h:174)";
     case FLAME_NLTGV2_ERR_OOM: return "out of device memory";
+    case FLAME_NLTGV2_ERR_TIMEOUT: return "persistent run: neighbour wait timed out";
     default: return "unknown status";
   }
 }
@@ -366,7 +416,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
               &ctx->w2p, &ctx->data, &ctx->weight, &ctx->src, &ctx->dst, &ctx->alpha, &ctx->beta, &ctx->q1,
               &ctx->q2, &ctx->q3, &ctx->row_ptr, &ctx->half, &ctx->slice_row, &ctx->perm, &ctx->pdeg,
               &ctx->rec_nbr, &ctx->rec_edge, &ctx->edge_src_slot, &ctx->hrec, &ctx->hq, &ctx->vstate,
-              &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->err, &ctx->cost_pe, &ctx->cost_pv,
+              &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->gran0, &ctx->gran1, &ctx->abort_flag, &ctx->he_slot, &ctx->he_vid, &ctx->he_meta, &ctx->he_wave_chain, &ctx->err, &ctx->cost_pe, &ctx->cost_pv,
               &ctx->cost_out};
   *out = ctx;
   return FLAME_NLTGV2_OK;
@@ -409,6 +459,9 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
     case FLAME_NLTGV2_OPT_BLOCK_WAVES:
       if (value != 0 && value != 1 && value != 2 && value != 4) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_block_waves = value;
+      return 0;
+    case FLAME_NLTGV2_OPT_PERSISTENT:
+      ctx->opt_persistent = value ? 1 : 0;
       return 0;
     case FLAME_NLTGV2_OPT_UNROLL:
       if (value != 0 && value != 4 && value != 8 && value != 16) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
@@ -453,7 +506,10 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
       {&ctx->hrec, sizeof(int4) * n_slots}, {&ctx->hq, sizeof(float4) * n_slots},
       {&ctx->vstate, sizeof(float4) * n_packed}, {&ctx->vaux, sizeof(float2) * n_packed},
       {&ctx->bar0, sizeof(float4) * n_packed}, {&ctx->bar1, sizeof(float4) * n_packed},
-      {&ctx->vprev, sizeof(float4) * n_packed}, {&ctx->err, sizeof(int)},
+      {&ctx->vprev, sizeof(float4) * n_packed}, {&ctx->gran0, 16 * n_packed}, {&ctx->gran1, 16 * n_packed},
+      {&ctx->abort_flag, sizeof(int)}, {&ctx->he_slot, sizeof(int32_t) * L.he_slot.size()},
+      {&ctx->he_vid, sizeof(int32_t) * L.he_vid.size()}, {&ctx->he_meta, sizeof(uint32_t) * L.he_meta.size()},
+      {&ctx->he_wave_chain, sizeof(int32_t) * L.he_wave_chain.size()}, {&ctx->err, sizeof(int)},
       {&ctx->cost_pe, sizeof(double) * kCostPartials}, {&ctx->cost_pv, sizeof(double) * kCostPartials},
       {&ctx->cost_out, 2 * sizeof(float)}};
   for (auto& r : req) {
@@ -478,13 +534,22 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
       {&ctx->perm, L.perm.data(), sizeof(int32_t) * n_packed}, {&ctx->pdeg, L.pdeg.data(), sizeof(int32_t) * n_packed},
       {&ctx->rec_nbr, L.rec_nbr.data(), sizeof(uint32_t) * n_slots},
       {&ctx->rec_edge, L.rec_edge.data(), sizeof(int32_t) * n_slots},
-      {&ctx->edge_src_slot, L.edge_src_slot.data(), fE}};
+      {&ctx->edge_src_slot, L.edge_src_slot.data(), fE},
+      {&ctx->he_slot, L.he_slot.data(), sizeof(int32_t) * L.he_slot.size()},
+      {&ctx->he_vid, L.he_vid.data(), sizeof(int32_t) * L.he_vid.size()},
+      {&ctx->he_meta, L.he_meta.data(), sizeof(uint32_t) * L.he_meta.size()},
+      {&ctx->he_wave_chain, L.he_wave_chain.data(), sizeof(int32_t) * L.he_wave_chain.size()}};
   for (auto& c : cp) {
     if (rc) return rc;
     rc = h2d(ctx, *c.b, c.src, c.bytes);
   }
   if (rc) return rc;
   HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, sizeof(int), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->abort_flag.p, 0, sizeof(int), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->gran0.p, 0, 16 * n_packed + 16, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->gran1.p, 0, 16 * n_packed + 16, ctx->stream));
+  ctx->tag_next = 1;
+  ctx->state_lost = false;
   LAUNCHCHK(ctx, launch_pack_static(ctx->c, ctx->f, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors / caller arrays may go away
   ctx->canon_valid = true;
@@ -675,6 +740,7 @@ int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info) {
   info->compute_units = ctx->prop.multiProcessorCount;
   std::snprintf(info->device_name, sizeof(info->device_name), "%s", ctx->prop.name);
   std::snprintf(info->gcn_arch, sizeof(info->gcn_arch), "%s", ctx->prop.gcnArchName);
+  info->last_run_path = ctx->last_run_path;
   return FLAME_NLTGV2_OK;
 }
 

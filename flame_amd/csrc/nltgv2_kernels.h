@@ -44,11 +44,20 @@ struct FusedArgs {
   float2* vaux = nullptr;   // [n_slices*64] {data_weight, degree bits}
   float4* bar[2] = {nullptr, nullptr};  // ping-pong {x_bar,w1_bar,w2_bar,-}
   float4* vprev = nullptr;  // {x_prev,w1_prev,w2_prev,-} written by the last step of a run
+  void* gran[2] = {nullptr, nullptr};  // persistent run: [n_slices*64] 16-byte {x_bar,w1_bar,w2_bar,tag} records
+  int he_waves = 0;                    // persistent run: wave-aligned half-edge rows (nltgv2_pack.hpp (C))
+  int32_t* he_slot = nullptr;
+  int32_t* he_vid = nullptr;
+  uint32_t* he_meta = nullptr;
+  int32_t* he_wave_chain = nullptr;
+  int* abort_flag = nullptr;
   int* err = nullptr;
 };
 
 int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, bool write_prev, int unroll,
                       int waves_per_block, hipStream_t stream);
+int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int parity_in, unsigned tag0, int n_iters,
+                          int waves_per_block, unsigned max_spins, hipStream_t stream);
 int launch_save_prev(const CanonArgs& c, hipStream_t s);
 int launch_dual(const CanonArgs& c, const SolverParams& p, hipStream_t s);
 int launch_primal(const CanonArgs& c, const SolverParams& p, hipStream_t s);

@@ -185,6 +185,216 @@ k_fused_step(const int n_slices, const int slices_per_xcd, const int32_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// Persistent run: ONE launch == n_iters reference step()s, for graphs whose half-edges all fit on
+// the chip at once (one LANE per half-edge, <= 32 waves per CU).
+//
+// Why: a dependent kernel boundary costs ~3.5 us on this part (measured: trivial dependent kernels
+// replay at that period) while one step of a 640x480 graph is < 1 us of work, so one-launch-per-step
+// is launch bound.  Inside one launch the only thing a step needs from other waves is the
+// (x_bar,w1_bar,w2_bar) of graph neighbours, and a 16-byte write-through record crosses the chip
+// in ~0.45-0.55 us (tools/hop_bench.hip) -- so the steps are run as pure DATAFLOW:
+//
+//   * lane <-> half-edge; the lanes of a vertex are contiguous (ascending edge id) inside one wave
+//     and its last lane ("tail") owns the vertex.  Records, weights and the private (q1,q2,q3) copy
+//     of every half-edge stay in REGISTERS for the whole run (loaded once from the SELL arrays).
+//   * every vertex publishes ONE naturally aligned 16-byte record {x_bar, w1_bar, w2_bar, tag =
+//     step number} with ONE write-through (sc1) dwordx4 store; every half-edge lane re-reads its
+//     neighbour's record (L1-bypassing sc1 dwordx4 load) until the tag equals the step it needs.
+//     The data is its own flag: no fences, no flag words, no grid barrier.  (A lane's aligned
+//     16-byte access is a single request inside one cache line; tearing between value and tag has
+//     not been observed on gfx950 and would show up as a bit mismatch in the parity tests, which
+//     compare every run of this kernel with the CPU checker exactly.)
+//   * two record buffers alternate by step parity: a vertex can only overwrite its step-s record
+//     with step s+2 after ALL its neighbours published s+1, i.e. after they consumed s.  Tags grow
+//     monotonically over the context's lifetime and every launch starts from a fresh tag, so stale
+//     records never match.
+//   * the primal accumulation of a vertex must follow the reference's edge order exactly, so the
+//     per-half-edge contributions are combined by an ORDERED segmented chain: step j moves the
+//     running sums one lane up (DPP wave_shr:1, no LDS) and the lane at position j adds its
+//     contribution; after max-degree steps the tail lane holds bit-exactly what the reference's
+//     sequential scatter (cc:120-142) produces.  Identity contributions are -0.0f (x + -0.0f == x
+//     for every x, including both zeros).
+//
+// All waves must be resident (cooperative launch: the runtime checks the grid); every wait is
+// bounded and reports FLAME_NLTGV2_ERR_TIMEOUT through `err`.
+// ------------------------------------------------------------------------------------------------
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+constexpr int kAuxSc1 = 16;  // cache-policy bits of the raw buffer builtins: bit 4 = sc1
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+}
+
+__device__ __forceinline__ float shr1(float v) {  // lane l <- lane l-1 (whole wave), lane 0 keeps v
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+
+constexpr unsigned kHeTailBit = 1u << 12, kHeActiveBit = 1u << 13, kHeValidBit = 1u << 14;
+
+__global__ void __launch_bounds__(256)
+k_persistent_he(const int n_waves, const int waves_per_xcd, const int32_t* __restrict__ he_slot,
+                const int32_t* __restrict__ he_vid, const uint32_t* __restrict__ he_meta,
+                const int32_t* __restrict__ he_wave_chain, const int4* hrec, float4* hq, float4* vstate,
+                const float2* vaux, const float4* bar_in, float4* bar_out, float4* vprev, void* gran0,
+                void* gran1, const unsigned tag0, const int n_iters, const unsigned max_spins,
+                const SolverParams p, int* __restrict__ err, int* __restrict__ abort_flag) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int b = blockIdx.x;
+  const int xcd = b & 7;
+  const int idx = (b >> 3) * wpb + (threadIdx.x >> 6);
+  if (idx >= waves_per_xcd) return;
+  const int w = xcd * waves_per_xcd + idx;
+  if (w >= n_waves) return;
+
+  const size_t hl = (size_t)w * 64 + lane;
+  const unsigned meta = he_meta[hl];
+  const int slot = he_slot[hl];
+  const int pv = he_vid[hl];
+  const int chain = __builtin_amdgcn_readfirstlane(he_wave_chain[w]);
+  const int pos = (int)(meta & 63u);
+  const int tail_lane = (int)((meta >> 6) & 63u);
+  const bool is_tail = (meta & kHeTailBit) != 0u;
+  const bool active = (meta & kHeActiveBit) != 0u;
+  const bool valid = (meta & kHeValidBit) != 0u;
+
+  int4 rec = make_int4(0, 0, 0, 0);
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active) {
+    rec = hrec[slot];
+    q = hq[slot];
+  }
+  const bool is_target = rec.x < 0;
+  const int nbr_off = (int)(((unsigned)rec.x & 0x07ffffffu) << 4);
+  const float alpha = __int_as_float(rec.y), dx = __int_as_float(rec.z), dy = __int_as_float(rec.w);
+  const float beta = q.w;
+  float q1 = q.x, q2 = q.y, q3 = q.z;
+
+  float4 st = make_float4(0.f, 0.f, 0.f, 0.f), bs = make_float4(0.f, 0.f, 0.f, 0.f);
+  float2 aux = make_float2(0.f, 0.f);
+  if (valid) {  // every lane of a vertex reads the same words (broadcast load)
+    st = vstate[pv];
+    aux = vaux[pv];
+    bs = bar_in[pv];
+  }
+  const float data = st.w;
+  const float lam_w = p.data_factor * aux.x;
+  float x = st.x, w1 = st.y, w2 = st.z;         // invariant: every lane holds its vertex's state
+  float xb = bs.x, w1b = bs.y, w2b = bs.z;
+  float x_prev = x, w1_prev = w1, w2_prev = w2;
+  bool ok = true;
+  bool timed_out = false;
+
+  const __amdgpu_buffer_rsrc_t r0 = make_rsrc(gran0), r1 = make_rsrc(gran1);
+  const int my_off = pv << 4;
+
+  if (is_tail) {  // publish bar(tag0); tag0 is fresh, leftovers of earlier runs cannot match
+    v4i_t o;
+    o.x = __float_as_int(xb), o.y = __float_as_int(w1b), o.z = __float_as_int(w2b), o.w = (int)tag0;
+    __builtin_amdgcn_raw_buffer_store_b128(o, (tag0 & 1u) ? r1 : r0, my_off, 0, kAuxSc1);
+  }
+
+  for (int it = 0; it < n_iters; ++it) {
+    const unsigned s = tag0 + (unsigned)it;
+    const __amdgpu_buffer_rsrc_t rin = (s & 1u) ? r1 : r0;
+    // ---- wait for the neighbour's bar(s) ---------------------------------------------------------
+    v4i_t g = {0, 0, 0, 0};
+    bool pend = active;
+    unsigned spins = 0;
+    const bool dbg_nowait = (max_spins == 0xfffffffeu);  // timing experiment only
+    for (;;) {
+      if (pend) {
+        int o = nbr_off;
+        asm volatile("" : "+v"(o)::"memory");  // opaque: the load must be re-issued on every spin
+        g = __builtin_amdgcn_raw_buffer_load_b128(rin, o, 0, kAuxSc1);
+        pend = ((unsigned)g.w != s) && !dbg_nowait;
+      }
+      if (!__any(pend)) break;
+      ++spins;
+      if ((spins & 63u) == 0u) {
+        const int ab = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ab != 0 || spins > max_spins) {
+          timed_out = true;
+          break;
+        }
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (timed_out) break;
+
+    // ---- dual update of this half-edge's private q copy (cc:99-110) ------------------------------
+    const float nxb = __int_as_float(g.x), nw1b = __int_as_float(g.y), nw2b = __int_as_float(g.z);
+    const float xbi = is_target ? nxb : xb, xbj = is_target ? xb : nxb;
+    const float w1bi = is_target ? nw1b : w1b, w1bj = is_target ? w1b : nw1b;
+    const float w2bi = is_target ? nw2b : w2b, w2bj = is_target ? w2b : nw2b;
+    bool okq = true;
+    const EdgeOut e = edge_dual(p, alpha, beta, dx, dy, q1, q2, q3, xbi, w1bi, w2bi, xbj, w1bj, w2bj, okq);
+    // ---- this endpoint's share of the primal scatter (cc:126-141) as ordered contributions -------
+    const float t1 = e.q1 * p.step_x * alpha;
+    const float t2 = e.q2 * p.step_x * beta;
+    const float t3 = e.q3 * p.step_x * beta;
+    float cx = is_target ? t1 : -t1;                 // x_j += t1        | x_i -= t1
+    float a1 = is_target ? t2 : t1 * dx;             // w1_j += t2       | w1_i += t1*dx
+    float b1 = is_target ? -0.0f : -t2;              //                  | w1_i -= t2
+    float a2 = is_target ? t3 : t1 * dy;
+    float b2 = is_target ? -0.0f : -t3;
+    if (active) {
+      q1 = e.q1, q2 = e.q2, q3 = e.q3;
+      ok = ok && okq;
+    } else {
+      cx = a1 = b1 = a2 = b2 = -0.0f;
+    }
+    // ---- ordered segmented chain: after `chain` steps the tail lane holds the vertex sums --------
+    float X = x, W1 = w1, W2 = w2;
+    {
+      const float Xn = X + cx, W1n = (W1 + a1) + b1, W2n = (W2 + a2) + b2;
+      if (pos == 0) X = Xn, W1 = W1n, W2 = W2n;
+    }
+    for (int j = 1; j < chain; ++j) {
+      const float Xs = shr1(X), W1s = shr1(W1), W2s = shr1(W2);
+      const float Xn = Xs + cx, W1n = (W1s + a1) + b1, W2n = (W2s + a2) + b2;
+      if (pos == j) X = Xn, W1 = W1n, W2 = W2n;
+    }
+    // ---- vertex update at the tail lane: proxL1 (cc:147-151), extragradient (cc:160-171) ---------
+    const float xn = prox_l1(p.x_min, p.x_max, p.step_x, lam_w, X, data);
+    float nb = xn + p.theta * (xn - x);
+    nb = (nb < p.x_min) ? p.x_min : nb;
+    nb = (nb > p.x_max) ? p.x_max : nb;
+    const float w1bn = W1 + p.theta * (W1 - w1);
+    const float w2bn = W2 + p.theta * (W2 - w2);
+    if (is_tail) {
+      v4i_t o;
+      o.x = __float_as_int(nb), o.y = __float_as_int(w1bn), o.z = __float_as_int(w2bn), o.w = (int)(s + 1u);
+      __builtin_amdgcn_raw_buffer_store_b128(o, ((s + 1u) & 1u) ? r1 : r0, my_off, 0, kAuxSc1);
+    }
+    // ---- hand the vertex's new state back to all of its lanes -------------------------------------
+    x_prev = x, w1_prev = w1, w2_prev = w2;  // step()'s prev copy, cc:37-42
+    x = __shfl(xn, tail_lane, 64);
+    w1 = __shfl(W1, tail_lane, 64);
+    w2 = __shfl(W2, tail_lane, 64);
+    xb = __shfl(nb, tail_lane, 64);
+    w1b = __shfl(w1bn, tail_lane, 64);
+    w2b = __shfl(w2bn, tail_lane, 64);
+  }
+
+  if (timed_out) {
+    if (lane == 0) {
+      __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicOr(err, 2);
+    }
+    return;  // the run is reported as failed; the host invalidates the state
+  }
+
+  if (is_tail) {
+    vstate[pv] = make_float4(x, w1, w2, data);
+    bar_out[pv] = make_float4(xb, w1b, w2b, 0.0f);
+    vprev[pv] = make_float4(x_prev, w1_prev, w2_prev, 0.0f);
+  }
+  if (active) hq[slot] = make_float4(q1, q2, q3, beta);
+  if (!ok) atomicOr(err, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Canonical (original order, SoA) sweeps: the individually callable pieces of a step.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -471,6 +681,36 @@ int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, boo
   }
 #undef FLAME_LAUNCH
   return (int)hipGetLastError();
+}
+
+// Persistent run (single cooperative launch).  Returns the hipError_t unchanged (e.g.
+// hipErrorCooperativeLaunchTooLarge) so the caller can fall back to per-step launches.
+int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int parity_in, unsigned tag0, int n_iters,
+                          int waves_per_block, unsigned max_spins, hipStream_t stream) {
+  if (a.he_waves <= 0 || n_iters <= 0) return (int)hipSuccess;
+  int n_waves = a.he_waves;
+  int wpx = (a.he_waves + 7) / 8;
+  const int bpx = (wpx + waves_per_block - 1) / waves_per_block;
+  const dim3 grid((unsigned)(bpx * 8)), block((unsigned)(64 * waves_per_block));
+  const int32_t* he_slot = a.he_slot;
+  const int32_t* he_vid = a.he_vid;
+  const uint32_t* he_meta = a.he_meta;
+  const int32_t* he_wave_chain = a.he_wave_chain;
+  const int4* hrec = a.hrec;
+  float4* hq = a.hq;
+  float4* vstate = a.vstate;
+  const float2* vaux = a.vaux;
+  const float4* bin = a.bar[parity_in];
+  float4* bout = a.bar[parity_in ^ (n_iters & 1)];
+  float4* vprev = a.vprev;
+  void* g0 = a.gran[0];
+  void* g1 = a.gran[1];
+  SolverParams pp = p;
+  int* err = a.err;
+  int* abort_flag = a.abort_flag;
+  void* args[] = {&n_waves, &wpx, &he_slot, &he_vid, &he_meta, &he_wave_chain, &hrec, &hq, &vstate, &vaux, &bin,
+                  &bout, &vprev, &g0, &g1, &tag0, &n_iters, &max_spins, &pp, &err, &abort_flag};
+  return (int)hipLaunchCooperativeKernel((const void*)k_persistent_he, grid, block, args, 0, stream);
 }
 
 int launch_save_prev(const CanonArgs& c, hipStream_t s) {

@@ -45,7 +45,18 @@ struct PackedLayout {
   std::vector<int32_t> edge_src_slot;  // [E] slot of the source-side copy of edge e
   std::vector<int32_t> row_ptr;        // [V+1]  (A)
   std::vector<uint32_t> half;          // [2E]   (A) edge id | role bit, ascending edge id per vertex
+  // (C) wave-aligned half-edge rows of the persistent run: one LANE per half-edge, the lanes of a
+  // vertex contiguous (ascending edge id) inside ONE wave; isolated vertices get one idle lane.
+  bool he_ok = false;                  // false: some vertex has more than 64 incident edges
+  int32_t he_waves = 0;
+  int32_t he_max_chain = 0;            // longest per-wave chain (= max degree)
+  std::vector<int32_t> he_slot;        // [he_waves*64] slot of this half-edge in the SELL arrays, -1 idle
+  std::vector<int32_t> he_vid;         // [he_waves*64] packed vertex owning the lane, -1 unused lane
+  std::vector<uint32_t> he_meta;       // [he_waves*64] pos | tail_lane<<6 | is_tail<<12 | active<<13 | valid<<14
+  std::vector<int32_t> he_wave_chain;  // [he_waves] max(1, max degree) of the wave's vertices
 };
+
+constexpr uint32_t kHeTail = 1u << 12, kHeActive = 1u << 13, kHeValid = 1u << 14;
 
 inline uint32_t morton_spread16(uint32_t v) {
   v &= 0xFFFFu;
@@ -127,10 +138,16 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
   auto degree = [&](int32_t v) { return L->row_ptr[v + 1] - L->row_ptr[v]; };
-  for (int32_t w0 = 0; w0 < V; w0 += kDegreeWindow) {
-    const int32_t w1 = std::min<int32_t>(V, w0 + kDegreeWindow);
-    std::stable_sort(order.begin() + w0, order.begin() + w1,
-                     [&](int32_t a, int32_t b) { return degree(a) > degree(b); });
+  // degree-sort inside windows that never straddle two components (frames of a batch)
+  for (int32_t c0 = 0; c0 < V;) {
+    int32_t c1 = c0 + 1;
+    while (c1 < V && (key[order[c1]] >> 32) == (key[order[c0]] >> 32)) ++c1;
+    for (int32_t w0 = c0; w0 < c1; w0 += kDegreeWindow) {
+      const int32_t w1 = std::min<int32_t>(c1, w0 + kDegreeWindow);
+      std::stable_sort(order.begin() + w0, order.begin() + w1,
+                       [&](int32_t a, int32_t b) { return degree(a) > degree(b); });
+    }
+    c0 = c1;
   }
 
   // ---- (B) SELL-64 ----------------------------------------------------------------------------
@@ -179,6 +196,43 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
       L->rec_edge[slot] = e;
       L->rec_nbr[slot] = static_cast<uint32_t>(L->iperm[other]) | (is_target ? kRoleBit : 0u);
       if (!is_target) L->edge_src_slot[e] = static_cast<int32_t>(slot);
+    }
+  }
+
+  // ---- (C) wave-aligned half-edge rows -------------------------------------------------------------
+  L->he_ok = (maxdeg <= kWave);
+  L->he_waves = 0;
+  L->he_max_chain = 0;
+  L->he_slot.clear(), L->he_vid.clear(), L->he_meta.clear(), L->he_wave_chain.clear();
+  if (L->he_ok && V > 0) {
+    int32_t fill = kWave;  // forces a new wave for the first vertex
+    for (int32_t s = 0; s < V; ++s) {
+      const int32_t d = L->pdeg[s];
+      const int32_t need = std::max(d, 1);
+      if (fill + need > kWave) {
+        L->he_slot.resize(L->he_slot.size() + kWave, -1);
+        L->he_vid.resize(L->he_vid.size() + kWave, -1);
+        L->he_meta.resize(L->he_meta.size() + kWave, 0u);
+        L->he_wave_chain.push_back(1);
+        L->he_waves++;
+        fill = 0;
+      }
+      const size_t base = static_cast<size_t>(L->he_waves - 1) * kWave + fill;
+      const int32_t tail_lane = fill + need - 1;
+      const int64_t row0 = L->slice_row[s / kWave];
+      for (int32_t k = 0; k < need; ++k) {
+        uint32_t m = static_cast<uint32_t>(k) | (static_cast<uint32_t>(tail_lane) << 6) | kHeValid;
+        if (k == need - 1) m |= kHeTail;
+        if (k < d) {
+          m |= kHeActive;
+          L->he_slot[base + k] = static_cast<int32_t>((row0 + k) * kWave + (s % kWave));
+        }
+        L->he_vid[base + k] = s;
+        L->he_meta[base + k] = m;
+      }
+      L->he_wave_chain.back() = std::max(L->he_wave_chain.back(), need);
+      L->he_max_chain = std::max(L->he_max_chain, need);
+      fill += need;
     }
   }
   return FLAME_NLTGV2_OK;

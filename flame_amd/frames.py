@@ -1,0 +1,74 @@
+"""Frame-level data parallelism: independent frames (one Delaunay graph each) are sharded across
+ranks -- one process per GPU -- with NO collective on the solve path; the only exchange is the result
+gather of `x * graph_scale` (what Flame::update reads back, /root/reference/src/flame/flame.cc:372-380),
+done with torch.distributed (backend "nccl" = RCCL over xGMI on the GPU node, "gloo" in CPU tests).
+
+A single graph is never split across GPUs: at <= 11 MB per step and two neighbour exchanges per step
+the xGMI latency would dominate (DESIGN.md "Multi-GPU").
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import torch
+
+
+def shard_frames(n_frames: int, world: int, rank: int) -> List[int]:
+    """Frame ids owned by `rank`: contiguous blocks, sizes differing by at most one."""
+    if world <= 0 or not (0 <= rank < world) or n_frames < 0:
+        raise ValueError("bad sharding arguments")
+    base, extra = divmod(n_frames, world)
+    start = rank * base + min(rank, extra)
+    return list(range(start, start + base + (1 if rank < extra else 0)))
+
+
+def frames_per_rank(n_frames: int, world: int) -> List[int]:
+    return [len(shard_frames(n_frames, world, r)) for r in range(world)]
+
+
+class IdepthGather:
+    """Gathers every rank's per-frame inverse-depth vectors (ragged: V differs per frame) to all ranks.
+
+    Layout: each rank contributes a [slots, vmax] float32 block (slots = max frames per rank, vmax =
+    max vertex count over all frames, zero padded), so ONE all_gather_into_tensor of a fixed shape moves
+    everything -- at ~34 KB per 640x480 frame this is a pure-latency collective, one call per step.
+    """
+
+    def __init__(self, dist, sizes_local: Sequence[int], n_frames: int, device):
+        self.dist = dist
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.n_frames = n_frames
+        self.slots = max(frames_per_rank(n_frames, self.world)) if n_frames else 0
+        self.my_frames = shard_frames(n_frames, self.world, self.rank)
+        if len(sizes_local) != len(self.my_frames):
+            raise ValueError("one size per local frame expected")
+        # agree on vmax and publish every frame's true length
+        sizes = torch.zeros(self.world * max(self.slots, 1), dtype=torch.int64, device=device)
+        mine = torch.zeros(max(self.slots, 1), dtype=torch.int64, device=device)
+        for i, v in enumerate(sizes_local):
+            mine[i] = int(v)
+        dist.all_gather_into_tensor(sizes, mine)
+        self.sizes = sizes.cpu().view(self.world, max(self.slots, 1))
+        self.vmax = int(self.sizes.max().item()) if n_frames else 0
+        self.local = torch.zeros(max(self.slots, 1), max(self.vmax, 1), dtype=torch.float32, device=device)
+        self.gathered = torch.empty(self.world * max(self.slots, 1), max(self.vmax, 1), dtype=torch.float32,
+                                    device=device)
+
+    def local_row(self, i: int) -> torch.Tensor:
+        """Device row the solver of local frame i writes its x*scale into (first V entries)."""
+        return self.local[i]
+
+    def gather(self) -> None:
+        self.dist.all_gather_into_tensor(self.gathered, self.local)
+
+    def frame(self, frame_id: int) -> torch.Tensor:
+        """x*scale of global frame `frame_id` (valid after gather())."""
+        counts = frames_per_rank(self.n_frames, self.world)
+        r, acc = 0, 0
+        while frame_id >= acc + counts[r]:
+            acc += counts[r]
+            r += 1
+        i = frame_id - acc
+        n = int(self.sizes[r, i].item())
+        return self.gathered[r * max(self.slots, 1) + i, :n]

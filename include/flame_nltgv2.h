@@ -43,7 +43,9 @@ typedef enum flame_nltgv2_status {
   FLAME_NLTGV2_ERR_NAN = -5,         /* a dual variable became NaN/Inf: the condition on which the
                                         reference's FLAME_ASSERT(!std::isnan(new_q)) fires
                                         (nltgv2...h:174).  Sticky until the next upload. */
-  FLAME_NLTGV2_ERR_OOM = -6
+  FLAME_NLTGV2_ERR_OOM = -6,
+  FLAME_NLTGV2_ERR_TIMEOUT = -7      /* persistent run: a bounded neighbour wait expired (should not
+                                        happen; state is invalid, upload the graph again) */
 } flame_nltgv2_status;
 
 /* == struct Params, nltgv2_l1_graph_regularizer.h:121-129 (same fields, order and defaults). */
@@ -136,7 +138,10 @@ enum {
                                         canonical sweeps (save_prev/dual/primal/extragradient) */
   FLAME_NLTGV2_OPT_USE_HIPGRAPH = 2, /* 1 (default) = capture the n_iters launches in a hipGraph */
   FLAME_NLTGV2_OPT_BLOCK_WAVES = 3,  /* waves per workgroup of the fused sweep: 0 = auto, 1,2,4 */
-  FLAME_NLTGV2_OPT_UNROLL = 4        /* half-edge slots per load chunk of the fused sweep: 0 = auto, 4,8,16 */
+  FLAME_NLTGV2_OPT_UNROLL = 4,       /* half-edge slots per load chunk of the fused sweep: 0 = auto, 4,8,16 */
+  FLAME_NLTGV2_OPT_PERSISTENT = 5    /* 1 (default) = run() uses ONE persistent launch for all n_iters steps
+                                        when the graph fits on the chip (one lane per half-edge, <= 24 waves/CU, degree <= 64);
+                                        0 = always one launch per step */
 };
 int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value);
 
@@ -152,6 +157,8 @@ typedef struct flame_nltgv2_info {
   int32_t compute_units;
   char device_name[64];
   char gcn_arch[32];
+  int32_t last_run_path; /* 0 none, 1 persistent single launch, 2 one launch per step (hipGraph),
+                            3 one launch per step (eager), 4 four canonical sweeps per step */
 } flame_nltgv2_info;
 int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info);
 

@@ -1,0 +1,78 @@
+"""The C-ABI library loads here (no GPU) and exports every symbol include/flame_nltgv2.h declares;
+without a device every compute entry point fails loudly (no CPU fallback in the product path)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from tests.conftest import HAS_GPU, ROOT
+
+HEADER = os.path.join(ROOT, "include", "flame_nltgv2.h")
+
+
+def declared_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(flame_nltgv2_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_header_symbols_are_exported(built):
+    import flame_amd
+    from flame_amd.regularizer import ABI_SYMBOLS
+
+    decl = declared_symbols()
+    assert len(decl) >= 25
+    assert set(decl) == set(ABI_SYMBOLS), set(decl) ^ set(ABI_SYMBOLS)
+    lib = C.CDLL(flame_amd.library_path())
+    for name in decl:
+        assert hasattr(lib, name), name
+    nm = subprocess.check_output(["nm", "-D", "--defined-only", flame_amd.library_path()], text=True)
+    exported = set(re.findall(r" T (flame_nltgv2_[a-z_0-9]+)", nm))
+    assert set(decl) <= exported
+
+
+def test_header_is_plain_c(built, tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 and as C++."""
+    src = tmp_path / "t.c"
+    src.write_text('#include "flame_nltgv2.h"\nint main(void){flame_nltgv2_params p; (void)p; return FLAME_NLTGV2_ABI_VERSION - 1;}\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                           "-o", str(tmp_path / "t.o")])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-x", "c++", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                           "-o", str(tmp_path / "t2.o")])
+
+
+def test_defaults_and_status_strings(built):
+    import flame_amd
+
+    lib = flame_amd.load_library()
+    assert lib.flame_nltgv2_abi_version() == 1
+    p = flame_amd.Params(0, 0, 0, 0, 0, 0)
+    lib.flame_nltgv2_default_params(C.byref(p))
+    # == nltgv2_l1_graph_regularizer.h:121-129
+    assert [round(v, 6) for v in (p.data_factor, p.step_x, p.step_q, p.theta, p.x_min, p.x_max)] == \
+        [0.1, 0.001, 125.0, 0.25, 0.0, 10.0]
+    for st in range(0, -8, -1):
+        assert lib.flame_nltgv2_status_string(st)
+    assert b"unknown" in lib.flame_nltgv2_status_string(-99)
+
+
+@pytest.mark.skipif(HAS_GPU, reason="checks the no-device behaviour")
+def test_no_device_fails_loudly(built):
+    import flame_amd
+
+    with pytest.raises(flame_amd.NLTGV2Error) as ei:
+        flame_amd.Regularizer(0)
+    assert ei.value.status == -2  # FLAME_NLTGV2_ERR_NO_DEVICE: no silent CPU path
+
+
+def test_product_package_never_imports_the_checker():
+    """oracle/ is test infrastructure: nothing under flame_amd/ may import or load it."""
+    pkg = os.path.join(ROOT, "flame_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dirpath, f)
+                assert "liboracle" not in txt and "nltgv2_oracle" not in txt, os.path.join(dirpath, f)

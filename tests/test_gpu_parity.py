@@ -27,12 +27,14 @@ def env(built):
     return flame_amd, oracle
 
 
-def gpu_run(flame_amd, g, n, params=None, options=()):
+def gpu_run(flame_amd, g, n, params=None, options=(), expect_path=None):
     with flame_amd.Regularizer(0) as reg:
         for k, v in options:
             reg.set_option(k, v)
         reg.upload_graph(g)
         reg.run(params or flame_amd.Params(), n)
+        if expect_path is not None:
+            assert reg.info()["last_run_path"] == expect_path
         return reg.download_state()
 
 
@@ -71,17 +73,20 @@ def test_config_parity(env, config, n):
     g = synth.make_graph(config, seed=4242)
     ref, bad = cpu_run(oracle, g, n)
     assert bad == 0
-    out = gpu_run(flame_amd, g, n)
-    assert rms(out["x"], ref["x"]) <= TOL_RMS
-    assert_state_equal(out, ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=config)
+    for persistent in (1, 0):
+        out = gpu_run(flame_amd, g, n, options=[(5, persistent)], expect_path=None if persistent else 2)
+        assert rms(out["x"], ref["x"]) <= TOL_RMS
+        assert_state_equal(out, ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"{config} p={persistent}")
 
 
 def test_four_kernel_path_matches_fused_and_checker(env):
     flame_amd, oracle = env
     g = synth.make_graph("320x240", seed=11)
     ref, _ = cpu_run(oracle, g, 37)
-    fused = gpu_run(flame_amd, g, 37)
-    canon = gpu_run(flame_amd, g, 37, options=[(flame_amd.regularizer.OPT_SOLVER, 1)])
+    persistent = gpu_run(flame_amd, g, 37, expect_path=1)
+    fused = gpu_run(flame_amd, g, 37, options=[(5, 0)], expect_path=2)
+    canon = gpu_run(flame_amd, g, 37, options=[(flame_amd.regularizer.OPT_SOLVER, 1)], expect_path=4)
+    assert_state_equal(persistent, ref, what="persistent")
     assert_state_equal(fused, ref, what="fused")
     assert_state_equal(canon, ref, what="4-kernel")
 
@@ -114,11 +119,12 @@ def test_internal_steps_individually(env):
 
 
 @pytest.mark.parametrize("opts", [
-    [(3, 1), (4, 4)], [(3, 1), (4, 8)], [(3, 1), (4, 16)], [(3, 2), (4, 8)], [(3, 4), (4, 4)], [(3, 4), (4, 16)],
-    [(2, 0)],
+    [(5, 0), (3, 1), (4, 4)], [(5, 0), (3, 1), (4, 8)], [(5, 0), (3, 1), (4, 16)], [(5, 0), (3, 2), (4, 8)],
+    [(5, 0), (3, 4), (4, 4)], [(5, 0), (3, 4), (4, 16)], [(5, 0), (2, 0)], [(5, 1)],
 ])
 def test_launch_configurations_are_bit_identical(env, opts):
-    """waves per workgroup (opt 3), slot chunk (opt 4), hipGraph on/off (opt 2) never change a bit."""
+    """waves per workgroup (opt 3), slot chunk (opt 4), hipGraph on/off (opt 2), persistent single
+    launch vs one launch per step (opt 5) never change a bit."""
     flame_amd, oracle = env
     g = synth.make_graph("320x240", seed=3)
     ref, _ = cpu_run(oracle, g, 21)
@@ -186,8 +192,8 @@ def test_star_graph_high_degree(env):
     g = synth.assemble_graph(pos, data, np.array(e, np.int32))
     ref, bad = cpu_run(oracle, g, 25)
     assert bad == 0
-    for unroll in (4, 16):
-        out = gpu_run(flame_amd, g, 25, options=[(4, unroll)])
+    for unroll in (4, 16):  # degree 999 > 16: not eligible for the persistent run -> per-step launches
+        out = gpu_run(flame_amd, g, 25, options=[(4, unroll)], expect_path=2)
         assert_state_equal(out, ref, what=f"star U={unroll}")
 
 

@@ -1,0 +1,163 @@
+"""CPU tests of the checker itself (oracle/): the C restatement against the independently written
+numpy restatement, against the committed golden fixtures, and against algebraic properties of the
+algorithm.  PARITY UNPINNED (see oracle/nltgv2_oracle.c): no reference-produced vectors exist for
+this path, so these tests pin the restatement to itself, to a second restatement and to the maths."""
+import numpy as np
+import pytest
+from hypothesis import given, settings
+from hypothesis import strategies as st
+
+from flame_amd import synth
+from oracle import capi as oracle
+from oracle import nltgv2_numpy
+from tests.helpers import OUT_KEYS, assert_state_equal, load_golden, random_graph, rms
+
+GOLDEN = ["cfg1_320x240_s1234", "cfg1_320x240_s77_varied", "cfg2_640x480_s1234"]
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_c_restatement_reproduces_golden(name):
+    g, z = load_golden(name)
+    done = 0
+    for n in [int(i) for i in z["iters"]]:
+        assert oracle.run(g, n - done) == 0
+        done = n
+        for k in OUT_KEYS:
+            key = f"n{n}_{k}"
+            if key in z.files:
+                assert np.array_equal(g[k], z[key]), key
+        np.testing.assert_array_equal(np.array(oracle.costs(g), np.float32), z[f"n{n}_cost"])
+
+
+def test_numpy_restatement_is_bit_identical_to_c():
+    for seed, (V, E) in enumerate([(50, 120), (300, 1000), (1000, 2900)]):
+        g = random_graph(V, E, seed=seed)
+        a, b = synth.copy_graph(g), synth.copy_graph(g)
+        kw = dict(data_factor=0.2, step_x=0.002, step_q=60.0, theta=0.5, x_min=0.1, x_max=2.0)
+        oracle.run(a, 25, oracle.make_params(**kw))
+        nltgv2_numpy.run(b, 25, kw)
+        assert_state_equal(a, b, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"seed {seed}")
+
+
+def test_reference_layout_variant_is_bit_identical():
+    """The node-based (BGL-like) timing stand-in computes exactly what the flat oracle computes."""
+    g = synth.make_graph("320x240", seed=3)
+    a, b = synth.copy_graph(g), synth.copy_graph(g)
+    oracle.run(a, 40)
+    secs = oracle.reflayout_run_timed(b, 40, export=True)
+    assert secs > 0
+    assert_state_equal(a, b, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"))
+
+
+def test_step_is_composition_of_its_parts():
+    """step == prev-save; dualStep; primalStep; extraGradientStep (cc:33-49)."""
+    g = synth.make_graph("320x240", seed=4)
+    a, b = synth.copy_graph(g), synth.copy_graph(g)
+    for _ in range(5):
+        oracle.run(a, 1)
+        for k in ("x", "w1", "w2"):
+            b[k + "_prev"][:] = b[k]
+        oracle.dual_step(b)
+        oracle.primal_step(b)
+        oracle.extragradient_step(b)
+    assert_state_equal(a, b, keys=OUT_KEYS + ("x_prev",))
+
+
+def test_invariants_after_steps():
+    g = synth.make_graph("320x240", seed=5)
+    p = dict(oracle.DEFAULT_PARAMS)
+    oracle.run(g, 120)
+    for k in ("q1", "q2", "q3"):  # proxNLTGV2Conj projects onto [-1,1] (h:171-176)
+        assert np.all(np.abs(g[k]) <= 1.0)
+    for k in ("x", "x_bar"):  # feasible set (h:193-195, cc:165-166)
+        assert g[k].min() >= p["x_min"] and g[k].max() <= p["x_max"]
+    # extragradient identity for the unclamped w (cc:169-170)
+    th = np.float32(p["theta"])
+    assert np.array_equal(g["w1_bar"], g["w1"] + th * (g["w1"] - g["w1_prev"]))
+
+
+def test_edge_order_is_rounding_level_orientation_is_semantic():
+    """shuffling edge ORDER perturbs the 200-step result at 1e-7 RMS level,
+    flipping every ORIENTATION changes it by ~1e-3 (the operator uses the source's w_bar only)."""
+    g = synth.make_graph("320x240", seed=6)
+    base = synth.copy_graph(g)
+    oracle.run(base, 200)
+    perm = np.random.default_rng(0).permutation(g["E"])
+    s = synth.copy_graph(g)
+    for k in ("src", "dst", "alpha", "beta"):
+        s[k] = np.ascontiguousarray(g[k][perm])
+    oracle.run(s, 200)
+    f = synth.copy_graph(g)
+    f["src"], f["dst"] = g["dst"].copy(), g["src"].copy()
+    oracle.run(f, 200)
+    assert rms(s["x"], base["x"]) < 2e-6
+    assert rms(f["x"], base["x"]) > 1e-4
+    assert rms(f["x"], base["x"]) > 50 * rms(s["x"], base["x"])
+
+
+def test_constant_data_is_a_fixed_point():
+    """If the data term is one plane-free constant and the state starts there, nothing moves:
+    K1=K2=K3=0, q stays 0, prox snaps x to data."""
+    g = synth.make_graph("320x240", seed=7)
+    for k in ("data_term", "x", "x_bar", "x_prev"):
+        g[k][:] = np.float32(1.25)
+    before = synth.copy_graph(g)
+    oracle.run(g, 30)
+    assert_state_equal(g, before)
+
+
+def test_affine_data_is_reproduced_by_the_tgv_plane_model():
+    """NLTGV2 does not penalise affine inverse depth: with data = a + b*x + c*y, x = data and
+    w = (b, c) at every vertex, K1 = alpha*((x_i - x_j) - dx*b - dy*c) vanishes up to rounding, so the
+    iterate stays at the data (|x - data| tiny) and the dual stays ~0."""
+    g = synth.make_graph("320x240", seed=8)
+    bx, cy = np.float32(0.002), np.float32(-0.001)
+    plane = (np.float32(0.8) + bx * g["pos"][:, 0] + cy * g["pos"][:, 1]).astype(np.float32)
+    for k in ("data_term", "x", "x_bar", "x_prev"):
+        g[k][:] = plane
+    for k, v in (("w1", bx), ("w2", cy)):
+        g[k][:] = v
+        g[k + "_bar"][:] = v
+        g[k + "_prev"][:] = v
+    oracle.run(g, 100)
+    assert np.abs(g["x"] - plane).max() < 1e-4
+    assert np.abs(g["q2"]).max() < 1e-3 and np.abs(g["q3"]).max() < 1e-3
+
+
+def test_solver_denoises_towards_the_planes():
+    """End-to-end sanity: on the two-plane scene the regularised x is closer to the noise-free planes
+    than the noisy data is."""
+    g = synth.make_graph("640x480", seed=9)
+    w, h, _ = synth.CONFIGS["640x480"]
+    xh = g["pos"][:, 0].astype(np.float64) / w
+    yh = g["pos"][:, 1].astype(np.float64) / h
+    clean = np.where(xh < 0.5, 0.5 + 0.8 * xh + 0.2 * yh, 1.6 - 0.5 * xh + 0.3 * yh)
+    oracle.run(g, 2000)
+    err_data = np.median(np.abs(g["data_term"] - clean))
+    err_x = np.median(np.abs(g["x"] - clean))
+    assert err_x < 0.6 * err_data
+
+
+def test_nan_flag():
+    g = synth.make_graph("320x240", seed=10)
+    g["x_bar"][3] = np.nan
+    assert oracle.run(g, 1) != 0
+
+
+@settings(max_examples=300, deadline=None)
+@given(st.floats(width=32, allow_nan=False, allow_infinity=False))
+def test_prox_conj_is_exactly_a_clamp_for_finite_q(q):
+    """The identity the GPU kernels rely on: q / max(1,|q|) == clamp(q,-1,1) bit for bit (h:171-176)."""
+    q = np.float32(q)
+    absq = q if q > 0 else -q
+    ref = np.float32(q / (absq if absq > 1 else np.float32(1)))
+    clamp = np.float32(min(max(q, np.float32(-1)), np.float32(1)))
+    assert ref.tobytes() == clamp.tobytes() or (ref == 0 and clamp == 0 and np.signbit(ref) == np.signbit(clamp))
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.floats(width=32, allow_nan=False, allow_infinity=False))
+def test_negative_zero_is_the_exact_additive_identity(a):
+    """The persistent kernel pads its ordered accumulation with -0.0f contributions."""
+    a = np.float32(a)
+    assert (a + np.float32(-0.0)).tobytes() == a.tobytes()
