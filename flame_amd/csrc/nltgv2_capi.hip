@@ -26,7 +26,8 @@ namespace {
 constexpr int kGraphChunk = 256;      // steps per captured hipGraph (even: keeps ping-pong parity)
 constexpr int kCostPartials = 256;
 constexpr int kMaxCachedGraphs = 6;
-constexpr unsigned kMaxSpins = 1u << 20;  // bound of every neighbour wait in the persistent run (~1 s)
+constexpr int kPreSleep = 12;  // initial x64-cycle sleep between publishing and the first neighbour poll (adapts)
+constexpr unsigned kMaxSpins = 1u << 20;  // bound of every neighbour wait in the persistent run (~1 s of polling bursts)
 
 struct DevBuf {
   void* p = nullptr;
@@ -62,6 +63,7 @@ struct flame_nltgv2_ctx {
   uint32_t tag_next = 1;  // persistent run: tag of the current bar values (monotonic)
   bool state_lost = false;
   int last_run_path = 0;
+  uint64_t coop_checked_topo = 0;  // topology whose persistent grid the runtime has verified as resident
 
   PackedLayout L;
   CanonArgs c;
@@ -318,8 +320,11 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
     // a fresh first tag per launch: records left by earlier runs (whose state may since have been
     // changed by per-step launches or host uploads) can never satisfy a wait of this launch
     const uint32_t tag0 = ctx->tag_next + 2;
-    int e = launch_persistent_run(ctx->f, to_sp(p), ctx->parity, tag0, n, pw, std::getenv("FLAME_NLTGV2_DEBUG_NOWAIT") ? 0xfffffffeu : kMaxSpins, ctx->stream);
+    int e = launch_persistent_run(ctx->f, to_sp(p), ctx->parity, tag0, n, pw, std::getenv("FLAME_NLTGV2_DEBUG_NOWAIT") ? 0xfffffffeu : kMaxSpins,
+                                  std::getenv("FLAME_NLTGV2_PRESLEEP") ? std::atoi(std::getenv("FLAME_NLTGV2_PRESLEEP")) : kPreSleep,
+                                  ctx->coop_checked_topo != ctx->topo, ctx->stream);
     if (e == 0) {
+      ctx->coop_checked_topo = ctx->topo;
       ctx->tag_next = tag0 + (uint32_t)n;
       ctx->last_run_path = 1;
       ctx->parity ^= (n & 1);

@@ -237,7 +237,7 @@ k_persistent_he(const int n_waves, const int waves_per_xcd, const int32_t* __res
                 const int32_t* __restrict__ he_wave_chain, const int4* hrec, float4* hq, float4* vstate,
                 const float2* vaux, const float4* bar_in, float4* bar_out, float4* vprev, void* gran0,
                 void* gran1, const unsigned tag0, const int n_iters, const unsigned max_spins,
-                const SolverParams p, int* __restrict__ err, int* __restrict__ abort_flag) {
+                const int presleep, const SolverParams p, int* __restrict__ err, int* __restrict__ abort_flag) {
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
   const int b = blockIdx.x;
@@ -284,6 +284,7 @@ k_persistent_he(const int n_waves, const int waves_per_xcd, const int32_t* __res
   float x_prev = x, w1_prev = w1, w2_prev = w2;
   bool ok = true;
   bool timed_out = false;
+  int ps = presleep >= 0 ? presleep : -presleep;  // presleep < 0: fixed |presleep|, no adaptation
 
   const __amdgpu_buffer_rsrc_t r0 = make_rsrc(gran0), r1 = make_rsrc(gran1);
   const int my_off = pv << 4;
@@ -296,16 +297,24 @@ k_persistent_he(const int n_waves, const int waves_per_xcd, const int32_t* __res
 
   for (int it = 0; it < n_iters; ++it) {
     const unsigned s = tag0 + (unsigned)it;
-    const __amdgpu_buffer_rsrc_t rin = (s & 1u) ? r1 : r0;
     // ---- wait for the neighbour's bar(s) ---------------------------------------------------------
+    // ONE poll in flight per wave, and none before the record can plausibly be there: polling is
+    // not free on this chip -- every sc1 load of a written-through line is a trip to the memory side,
+    // and thousands of them in flight slow down the very stores they are waiting for (measured: a
+    // 4-deep poll ring made the step 45 % slower).  So: sleep `ps` x 64 cycles after publishing (the
+    // neighbours publish at about the same time; their records need ~0.45 us to become visible),
+    // then poll, pausing 64 cycles between misses; `ps` adapts per wave (below).  The offset goes through an opaque copy
+    // so the compiler re-issues the load (it would otherwise hoist it out of the spin).
     v4i_t g = {0, 0, 0, 0};
     bool pend = active;
     unsigned spins = 0;
     const bool dbg_nowait = (max_spins == 0xfffffffeu);  // timing experiment only
+    const __amdgpu_buffer_rsrc_t rin = (s & 1u) ? r1 : r0;
+    for (int z = 0; z < ps; ++z) __builtin_amdgcn_s_sleep(1);
     for (;;) {
       if (pend) {
         int o = nbr_off;
-        asm volatile("" : "+v"(o)::"memory");  // opaque: the load must be re-issued on every spin
+        asm volatile("" : "+v"(o)::"memory");
         g = __builtin_amdgcn_raw_buffer_load_b128(rin, o, 0, kAuxSc1);
         pend = ((unsigned)g.w != s) && !dbg_nowait;
       }
@@ -321,6 +330,12 @@ k_persistent_he(const int n_waves, const int waves_per_xcd, const int32_t* __res
       __builtin_amdgcn_s_sleep(1);
     }
     if (timed_out) break;
+    // adapt the pre-poll sleep (wave-uniform): a miss costs a whole memory round trip, sleeping a
+    // little too long costs only the excess -> lengthen on a miss, probe shorter every 4th clean step
+    if (presleep >= 0) {
+      if (spins != 0u) ps = (ps < 48) ? ps + 1 : ps;
+      else if ((it & 3) == 3 && ps > 0) ps -= 1;
+    }
 
     // ---- dual update of this half-edge's private q copy (cc:99-110) ------------------------------
     const float nxb = __int_as_float(g.x), nw1b = __int_as_float(g.y), nw2b = __int_as_float(g.z);
@@ -686,7 +701,8 @@ int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, boo
 // Persistent run (single cooperative launch).  Returns the hipError_t unchanged (e.g.
 // hipErrorCooperativeLaunchTooLarge) so the caller can fall back to per-step launches.
 int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int parity_in, unsigned tag0, int n_iters,
-                          int waves_per_block, unsigned max_spins, hipStream_t stream) {
+                          int waves_per_block, unsigned max_spins, int presleep, bool cooperative,
+                          hipStream_t stream) {
   if (a.he_waves <= 0 || n_iters <= 0) return (int)hipSuccess;
   int n_waves = a.he_waves;
   int wpx = (a.he_waves + 7) / 8;
@@ -709,8 +725,12 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int parity_
   int* err = a.err;
   int* abort_flag = a.abort_flag;
   void* args[] = {&n_waves, &wpx, &he_slot, &he_vid, &he_meta, &he_wave_chain, &hrec, &hq, &vstate, &vaux, &bin,
-                  &bout, &vprev, &g0, &g1, &tag0, &n_iters, &max_spins, &pp, &err, &abort_flag};
-  return (int)hipLaunchCooperativeKernel((const void*)k_persistent_he, grid, block, args, 0, stream);
+                  &bout, &vprev, &g0, &g1, &tag0, &n_iters, &max_spins, &presleep, &pp, &err, &abort_flag};
+  // The first launch of a topology is cooperative: the runtime verifies that the whole grid is
+  // resident (hipErrorCooperativeLaunchTooLarge otherwise).  The same grid is then launched plainly
+  // (identical residency, ~15 us less launch overhead per call).
+  if (cooperative) return (int)hipLaunchCooperativeKernel((const void*)k_persistent_he, grid, block, args, 0, stream);
+  return (int)hipLaunchKernel((const void*)k_persistent_he, grid, block, args, 0, stream);
 }
 
 int launch_save_prev(const CanonArgs& c, hipStream_t s) {

@@ -1,0 +1,263 @@
+// flame_hip/nltgv2_l1_graph_regularizer.hpp -- C++11 facade over the C-ABI (flame_nltgv2.h) that
+// keeps the reference's call surface:
+//
+//   reference  /root/reference/src/flame/optimizers/nltgv2_l1_graph_regularizer.h
+//     namespace flame::optimizers::nltgv2_l1_graph_regularizer
+//       struct Params                                   h:121-129
+//       void  step(const Params&, Graph*)               h:134
+//       float smoothnessCost / dataCost / cost          h:139-151
+//       internal::dualStep / primalStep / extraGradientStep   h:158-168
+//
+//   here       namespace flame::optimizers::nltgv2_l1_graph_regularizer::hip  -- same names, same
+//              argument meaning, same Params fields and defaults.  A maintainer switches a call site
+//              by adding `::hip` (or a namespace alias).
+//
+// Host side stays ordinary C++: the facade is header-only, needs no HIP headers and works with any
+// graph container for which flame_hip::GraphAccess<Graph> is specialised:
+//   * flame_hip/bgl_adaptor.hpp      the reference's boost::adjacency_list Graph (needs Boost)
+//   * flame_hip::FlatGraph (below)   a dependency-free container with the reference's field names
+//
+// Errors: the reference aborts the process (FLAME_ASSERT -> exit(1), assert.h:111); the facade throws
+// flame_hip::Error carrying the C-ABI status instead.  Nothing is ever computed on the CPU here.
+#ifndef FLAME_HIP_NLTGV2_L1_GRAPH_REGULARIZER_HPP_
+#define FLAME_HIP_NLTGV2_L1_GRAPH_REGULARIZER_HPP_
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "flame_nltgv2.h"
+
+namespace flame_hip {
+
+struct Error : std::runtime_error {
+  int status;
+  Error(int s, const std::string& what)
+      : std::runtime_error(what + ": " + flame_nltgv2_status_string(s)), status(s) {}
+};
+
+// Flat image of a Graph in boost::vertices()/boost::edges() order; what upload/download move.
+struct FlatArrays {
+  std::vector<float> pos, x, w1, w2, x_bar, w1_bar, w2_bar, x_prev, w1_prev, w2_prev, data_term, data_weight;
+  std::vector<int32_t> src, dst;
+  std::vector<float> alpha, beta, q1, q2, q3;
+  void resize(size_t V, size_t E) {
+    pos.resize(2 * V);
+    for (auto* a : {&x, &w1, &w2, &x_bar, &w1_bar, &w2_bar, &x_prev, &w1_prev, &w2_prev, &data_term, &data_weight})
+      a->resize(V);
+    src.resize(E), dst.resize(E);
+    for (auto* a : {&alpha, &beta, &q1, &q2, &q3}) a->resize(E);
+  }
+  flame_nltgv2_graph view() {
+    flame_nltgv2_graph g;
+    g.V = static_cast<int32_t>(x.size()), g.E = static_cast<int32_t>(src.size());
+    g.pos = pos.data();
+    g.x = x.data(), g.w1 = w1.data(), g.w2 = w2.data();
+    g.x_bar = x_bar.data(), g.w1_bar = w1_bar.data(), g.w2_bar = w2_bar.data();
+    g.x_prev = x_prev.data(), g.w1_prev = w1_prev.data(), g.w2_prev = w2_prev.data();
+    g.data_term = data_term.data(), g.data_weight = data_weight.data();
+    g.src = src.data(), g.dst = dst.data();
+    g.alpha = alpha.data(), g.beta = beta.data();
+    g.q1 = q1.data(), g.q2 = q2.data(), g.q3 = q3.data();
+    return g;
+  }
+};
+
+// Specialise for a graph container:
+//   static void pack(const Graph&, FlatArrays*)      vertices()/edges() order; (src,dst) = (source,target)
+//   static void unpack(const FlatArrays&, Graph*)    writes x,w,x_bar,w_bar,x_prev,w_prev,q back
+template <class Graph>
+struct GraphAccess;
+
+// Dependency-free graph container with the reference's VertexData/EdgeData field names (h:74-102).
+struct VertexData {
+  float pos_x = 0.0f, pos_y = 0.0f;  // cv::Point2f pos
+  float x = 0.0f, w1 = 0.0f, w2 = 0.0f;
+  float x_bar = 0.0f, w1_bar = 0.0f, w2_bar = 0.0f;
+  float x_prev = 0.0f, w1_prev = 0.0f, w2_prev = 0.0f;
+  float data_term = 0.0f, data_weight = 1.0f;
+};
+struct EdgeData {
+  int32_t source = 0, target = 0;  // boost::source / boost::target
+  float alpha = 1.0f, beta = 1.0f;
+  float q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
+  bool valid = true;
+};
+struct FlatGraph {
+  std::vector<VertexData> vertices;
+  std::vector<EdgeData> edges;
+};
+
+template <>
+struct GraphAccess<FlatGraph> {
+  static void pack(const FlatGraph& g, FlatArrays* f) {
+    f->resize(g.vertices.size(), g.edges.size());
+    for (size_t v = 0; v < g.vertices.size(); ++v) {
+      const VertexData& d = g.vertices[v];
+      f->pos[2 * v] = d.pos_x, f->pos[2 * v + 1] = d.pos_y;
+      f->x[v] = d.x, f->w1[v] = d.w1, f->w2[v] = d.w2;
+      f->x_bar[v] = d.x_bar, f->w1_bar[v] = d.w1_bar, f->w2_bar[v] = d.w2_bar;
+      f->x_prev[v] = d.x_prev, f->w1_prev[v] = d.w1_prev, f->w2_prev[v] = d.w2_prev;
+      f->data_term[v] = d.data_term, f->data_weight[v] = d.data_weight;
+    }
+    for (size_t e = 0; e < g.edges.size(); ++e) {
+      const EdgeData& d = g.edges[e];
+      f->src[e] = d.source, f->dst[e] = d.target;
+      f->alpha[e] = d.alpha, f->beta[e] = d.beta;
+      f->q1[e] = d.q1, f->q2[e] = d.q2, f->q3[e] = d.q3;
+    }
+  }
+  static void unpack(const FlatArrays& f, FlatGraph* g) {
+    for (size_t v = 0; v < g->vertices.size(); ++v) {
+      VertexData& d = g->vertices[v];
+      d.x = f.x[v], d.w1 = f.w1[v], d.w2 = f.w2[v];
+      d.x_bar = f.x_bar[v], d.w1_bar = f.w1_bar[v], d.w2_bar = f.w2_bar[v];
+      d.x_prev = f.x_prev[v], d.w1_prev = f.w1_prev[v], d.w2_prev = f.w2_prev[v];
+    }
+    for (size_t e = 0; e < g->edges.size(); ++e) {
+      EdgeData& d = g->edges[e];
+      d.q1 = f.q1[e], d.q2 = f.q2[e], d.q3 = f.q3[e];
+    }
+  }
+};
+
+}  // namespace flame_hip
+
+namespace flame {
+namespace optimizers {
+namespace nltgv2_l1_graph_regularizer {
+namespace hip {
+
+// == struct Params h:121-129: layout-identical to flame_nltgv2_params, same defaults.
+struct Params {
+  float data_factor = 0.1f;  // lambda in the TV literature.
+  float step_x = 0.001f;     // Primal step size.
+  float step_q = 125.0f;     // Dual step size.
+  float theta = 0.25f;       // Extra gradient step size.
+  float x_min = 0.0f;        // Feasible set.
+  float x_max = 10.0f;
+};
+static_assert(sizeof(Params) == sizeof(flame_nltgv2_params), "Params must mirror the C-ABI struct");
+
+inline flame_nltgv2_params to_c(const Params& p) {
+  flame_nltgv2_params c;
+  c.data_factor = p.data_factor, c.step_x = p.step_x, c.step_q = p.step_q;
+  c.theta = p.theta, c.x_min = p.x_min, c.x_max = p.x_max;
+  return c;
+}
+
+// Device image of ONE Graph: what the pipeline keeps next to `Graph graph_` (flame.h:536).  Not
+// thread-safe -- hold graph_mtx_ (flame.h:539) around every call exactly as the reference does around
+// step() and the graph edits (flame.cc:103, 302, 309, 329, 365).
+class DeviceGraph {
+ public:
+  explicit DeviceGraph(int device = 0) : ctx_(nullptr) {
+    const int rc = flame_nltgv2_create(&ctx_, device);
+    if (rc != 0) throw flame_hip::Error(rc, "flame_nltgv2_create");
+  }
+  ~DeviceGraph() { flame_nltgv2_destroy(ctx_); }
+  DeviceGraph(const DeviceGraph&) = delete;
+  DeviceGraph& operator=(const DeviceGraph&) = delete;
+
+  // After Flame::syncGraph changed vertices / edges / data (flame.cc:1940-2188).
+  template <class Graph>
+  void upload(const Graph& graph) {
+    flame_hip::GraphAccess<Graph>::pack(graph, &flat_);
+    flame_nltgv2_graph v = flat_.view();
+    check(flame_nltgv2_upload_graph(ctx_, &v), "upload_graph");
+  }
+  // Before Flame::update reads x, w1, w2 (flame.cc:372-380) or edits the graph.
+  template <class Graph>
+  void download(Graph* graph) {
+    flame_nltgv2_graph v = flat_.view();
+    check(flame_nltgv2_download_state(ctx_, &v), "download_state");
+    flame_hip::GraphAccess<Graph>::unpack(flat_, graph);
+  }
+
+  void step(const Params& p) { run(p, 1); }
+  void run(const Params& p, int n_iters) {
+    const flame_nltgv2_params c = to_c(p);
+    check(flame_nltgv2_run(ctx_, &c, n_iters), "run");
+  }
+  void dualStep(const Params& p) { const flame_nltgv2_params c = to_c(p); check(flame_nltgv2_dual_step(ctx_, &c), "dualStep"); }
+  void primalStep(const Params& p) { const flame_nltgv2_params c = to_c(p); check(flame_nltgv2_primal_step(ctx_, &c), "primalStep"); }
+  void extraGradientStep(const Params& p) {
+    const flame_nltgv2_params c = to_c(p);
+    check(flame_nltgv2_extragradient_step(ctx_, &c), "extraGradientStep");
+  }
+  void savePrev() { check(flame_nltgv2_save_prev(ctx_), "savePrev"); }
+  float smoothnessCost(const Params& p) { float s = 0, d = 0; costs(p, &s, &d); return s; }
+  float dataCost(const Params& p) { float s = 0, d = 0; costs(p, &s, &d); return d; }
+  float cost(const Params& p) { float s = 0, d = 0; costs(p, &s, &d); return s + d; }
+  void costs(const Params& p, float* smooth, float* data) {
+    const flame_nltgv2_params c = to_c(p);
+    check(flame_nltgv2_costs(ctx_, &c, smooth, data), "costs");
+  }
+  flame_nltgv2_ctx* handle() { return ctx_; }
+
+ private:
+  void check(int rc, const char* what) {
+    if (rc != 0) throw flame_hip::Error(rc, what);
+  }
+  flame_nltgv2_ctx* ctx_;
+  flame_hip::FlatArrays flat_;
+};
+
+// ---- the reference's free functions, same signatures (h:134-168) -----------------------------------
+// Stateless convenience forms: upload + compute + download on every call.  Exact, but they pay the
+// transfer each time; a pipeline should own a DeviceGraph instead.
+template <class Graph>
+inline void step(const Params& params, Graph* graph) {
+  DeviceGraph d;
+  d.upload(*graph);
+  d.step(params);
+  d.download(graph);
+}
+template <class Graph>
+inline float smoothnessCost(const Params& params, const Graph& graph) {
+  DeviceGraph d;
+  d.upload(graph);
+  return d.smoothnessCost(params);
+}
+template <class Graph>
+inline float dataCost(const Params& params, const Graph& graph) {
+  DeviceGraph d;
+  d.upload(graph);
+  return d.dataCost(params);
+}
+template <class Graph>
+inline float cost(const Params& params, const Graph& graph) {
+  return smoothnessCost(params, graph) + dataCost(params, graph);
+}
+
+namespace internal {
+template <class Graph>
+inline void dualStep(const Params& params, Graph* graph) {
+  DeviceGraph d;
+  d.upload(*graph);
+  d.dualStep(params);
+  d.download(graph);
+}
+template <class Graph>
+inline void primalStep(const Params& params, Graph* graph) {
+  DeviceGraph d;
+  d.upload(*graph);
+  d.primalStep(params);
+  d.download(graph);
+}
+template <class Graph>
+inline void extraGradientStep(const Params& params, Graph* graph) {
+  DeviceGraph d;
+  d.upload(*graph);
+  d.extraGradientStep(params);
+  d.download(graph);
+}
+}  // namespace internal
+
+}  // namespace hip
+}  // namespace nltgv2_l1_graph_regularizer
+}  // namespace optimizers
+}  // namespace flame
+
+#endif  // FLAME_HIP_NLTGV2_L1_GRAPH_REGULARIZER_HPP_
