@@ -272,6 +272,32 @@ def extras(a, reg, params, out, flame_amd, synth, sync):
                    "achieved_GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4)}
         r.close()
     out["other_configs"] = oc
+    # (3) what the boundary costs when the host hands over fresh buffers every frame (PCIe-inclusive;
+    #     never part of `value`): upload = host pack + H2D + device pack, download = unpack + D2H
+    import time as _t
+
+    g = synth.make_graph(a.config, seed=4321)
+    r = flame_amd.Regularizer(0)
+    r.upload_graph(g)
+    r.run(params, a.iters)
+    t0 = _t.perf_counter()
+    for _ in range(10):
+        r.upload_graph(g)
+    t1 = _t.perf_counter()
+    for _ in range(10):
+        r.run(params, 1)
+        r.download_state()
+    t2 = _t.perf_counter()
+    for _ in range(10):
+        r.run(params, 1)
+    t3 = _t.perf_counter()
+    up_ms, down_ms = (t1 - t0) * 100, ((t2 - t1) - (t3 - t2)) * 100
+    r.run(params, a.iters)
+    ms = min(r.run_timed(params, a.iters) for _ in range(5))
+    out["host_boundary"] = {"upload_graph_ms": round(up_ms, 3), "download_state_ms": round(down_ms, 3),
+                            "pcie_inclusive_iters_per_s": round(a.iters / ((ms + up_ms + down_ms) * 1e-3), 1),
+                            "note": "upload+200 iters+download per frame; never reported as value"}
+    r.close()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,22 @@
+#!/bin/bash
+# tools/profile.sh ROUND -- rocprofv3 evidence for bench.py's numbers (run on the GPU box via gpurun).
+# Kernel trace/stats and the PMC counters are collected in SEPARATE runs (counters never together with
+# tracing), as /opt/skills/guides prescribe.  Output: gpurun_out/prof_<ROUND>/ ; summarise with
+# tools/summarize_profile.py and commit the summaries under profiles/.
+set -u
+R=${1:-r01}
+cd /tmp && export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+OUT=gpurun_out/prof_$R
+mkdir -p $OUT
+B="python bench.py --steps 20 --warmup 2 --no-extras --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- $B > $OUT/kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- $B > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- $B > $OUT/write.log 2>&1
+rocprofv3 --pmc SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/sq -o s --output-format csv -- $B > $OUT/sq.log 2>&1
+# the one-launch-per-step path, for comparison
+B2="$B --persistent 0"
+rocprofv3 --kernel-trace --stats -d $OUT/kt_step -o kt --output-format csv -- $B2 > $OUT/kt_step.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch_step -o f --output-format csv -- $B2 > $OUT/fetch_step.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/write_step -o w --output-format csv -- $B2 > $OUT/write_step.log 2>&1
+grep -h '"metric"' $OUT/kt.log $OUT/kt_step.log | cut -c1-400
