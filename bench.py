@@ -85,7 +85,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("FLAME_BENCH_FORCE_DIST"):
+        # launched by torch.distributed.run (also with a single rank: exercises the RCCL path)
         import torch.distributed as dist
 
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))

@@ -225,10 +225,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(void* base) {
   return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
 }
 
-__device__ __forceinline__ float shr1(float v) {  // lane l <- lane l-1 (whole wave), lane 0 keeps v
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
-}
-
 constexpr unsigned kHeTailBit = 1u << 12, kHeActiveBit = 1u << 13, kHeValidBit = 1u << 14;
 
 __global__ void __launch_bounds__(256)
@@ -366,8 +362,21 @@ k_persistent_he(const int n_waves, const int waves_per_xcd, const int32_t* __res
       if (pos == 0) X = Xn, W1 = W1n, W2 = W2n;
     }
     for (int j = 1; j < chain; ++j) {
-      const float Xs = shr1(X), W1s = shr1(W1), W2s = shr1(W2);
-      const float Xn = Xs + cx, W1n = (W1s + a1) + b1, W2n = (W2s + a2) + b2;
+      // Xn = X[lane-1] + cx etc. with the lane shift folded into the add (v_add_f32_dpp wave_shr:1).
+      // Hand-written because hipcc emits v_mov + v_mov_dpp + v_pk_add here (17 instructions per
+      // chain step instead of 12).  s_nop 4: VALU-write -> DPP-read (2) and EXEC-write -> DPP (5)
+      // wait states, which the compiler cannot see into an asm statement.  Lane 0 has no source
+      // lane and keeps an undefined Xn: it is always at position 0 and never selects it.
+      float Xn, W1n, W2n;
+      asm volatile(
+          "s_nop 4\n\t"
+          "v_add_f32_dpp %0, %3, %6 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+          "v_add_f32_dpp %1, %4, %7 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+          "v_add_f32_dpp %2, %5, %8 wave_shr:1 row_mask:0xf bank_mask:0xf"
+          : "=&v"(Xn), "=&v"(W1n), "=&v"(W2n)
+          : "v"(X), "v"(W1), "v"(W2), "v"(cx), "v"(a1), "v"(a2));
+      W1n = W1n + b1;
+      W2n = W2n + b2;
       if (pos == j) X = Xn, W1 = W1n, W2 = W2n;
     }
     // ---- vertex update at the tail lane: proxL1 (cc:147-151), extragradient (cc:160-171) ---------
