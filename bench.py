@@ -191,7 +191,7 @@ def main():
             }
             out["speedup_vs_cpu_baseline"] = round(value / world / out["cpu_baseline"]["value"], 1)
     if not a.no_extras and world == 1:
-        extras(a, reg, params, out, flame_amd, synth, sync)
+        extras(a, reg, params, out, flame_amd, synth, sync, info)
     reg.close()
     if rank == 0:
         print(json.dumps(out))
@@ -227,19 +227,15 @@ def reg_profile_kernel(reg, params, n=400):
     return 1e3 * sum(core) / len(core)
 
 
-def extras(a, reg, params, out, flame_amd, synth, sync):
+def extras(a, reg, params, out, flame_amd, synth, sync, info):
     """Rank-0-only extra measurements (not part of `value`)."""
     # (1) batched mode: B independent frames resident on one GPU as a disjoint union.
-    #     "resident": as many frames as fit the persistent kernel (all half-edges on chip, <= 24 waves/CU)
+    #     "resident": as many frames as the vertex-per-lane persistent kernel keeps in registers
     #     "streaming": a.batch frames through the one-launch-per-step sweep (HBM/MALL streaming)
-    cap = 24 * 256 * 64  # lanes
-    per_frame = None
     out["batched"] = {}
     for label, nf, iters in (("resident", None, 200), ("streaming", a.batch, 50)):
-        if label == "resident":
-            probe = synth.make_graph(a.config, seed=5000)
-            per_frame = 2 * probe["E"] * 1.04
-            nf = max(1, int(cap // per_frame))
+        if label == "resident":  # as many frames as the register-resident persistent kernel holds
+            nf = max(1, info["tv_wave_capacity"] // max(1, info["tv_waves"]))
         if not nf:
             continue
         frames = [synth.make_graph(a.config, seed=5000 + i) for i in range(nf)]

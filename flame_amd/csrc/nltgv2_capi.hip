@@ -26,6 +26,8 @@ namespace {
 constexpr int kGraphChunk = 256;      // steps per captured hipGraph (even: keeps ping-pong parity)
 constexpr int kCostPartials = 256;
 constexpr int kMaxCachedGraphs = 6;
+constexpr int kTvWavesPerCu = 8;       // residency of k_persistent_tv (<= 256 VGPRs -> 2 waves per SIMD)
+constexpr int kHeWavesPerCuSweet = 8;  // above this many lane-per-half-edge waves per CU the vertex-per-lane form wins
 constexpr int kPreSleep = 12;  // initial x64-cycle sleep between publishing and the first neighbour poll (adapts)
 constexpr unsigned kMaxSpins = 1u << 20;  // bound of every neighbour wait in the persistent run (~1 s of polling bursts)
 
@@ -63,7 +65,7 @@ struct flame_nltgv2_ctx {
   uint32_t tag_next = 1;  // persistent run: tag of the current bar values (monotonic)
   bool state_lost = false;
   int last_run_path = 0;
-  uint64_t coop_checked_topo = 0;  // topology whose persistent grid the runtime has verified as resident
+  uint64_t coop_checked_key = 0;  // (topology, form) whose persistent grid the runtime has verified as resident
 
   PackedLayout L;
   CanonArgs c;
@@ -73,7 +75,7 @@ struct flame_nltgv2_ctx {
   DevBuf pos, x, w1, w2, xb, w1b, w2b, xp, w1p, w2p, data, weight, src, dst, alpha, beta, q1, q2, q3, row_ptr, half;
   // packed
   DevBuf slice_row, perm, pdeg, rec_nbr, rec_edge, edge_src_slot, hrec, hq, vstate, vaux, bar0, bar1, vprev;
-  DevBuf gran0, gran1, abort_flag, he_slot, he_vid, he_meta, he_wave_chain;
+  DevBuf gran0, gran1, abort_flag, he_slot, he_vid, he_meta, he_wave_chain, tv_slot, tv_vid, tv_meta, tv_wave;
   // misc
   DevBuf err, cost_pe, cost_pv, cost_out;
   int* h_err = nullptr;    // pinned
@@ -174,6 +176,9 @@ void refresh_args(flame_nltgv2_ctx* ctx) {
   f.he_waves = ctx->L.he_ok ? ctx->L.he_waves : 0;
   f.he_slot = (int32_t*)ctx->he_slot.p, f.he_vid = (int32_t*)ctx->he_vid.p;
   f.he_meta = (uint32_t*)ctx->he_meta.p, f.he_wave_chain = (int32_t*)ctx->he_wave_chain.p;
+  f.tv_waves = ctx->L.tv_ok ? ctx->L.tv_waves : 0;
+  f.tv_slot = (int32_t*)ctx->tv_slot.p, f.tv_vid = (int32_t*)ctx->tv_vid.p;
+  f.tv_meta = (uint32_t*)ctx->tv_meta.p, f.tv_wave = (uint32_t*)ctx->tv_wave.p;
   f.abort_flag = (int*)ctx->abort_flag.p;
   f.err = (int*)ctx->err.p;
 }
@@ -209,12 +214,21 @@ void pick_config(const flame_nltgv2_ctx* ctx, int* unroll, int* wpb) {
   *wpb = ctx->opt_block_waves ? ctx->opt_block_waves : (small ? 1 : 4);
 }
 
-bool persistent_eligible(const flame_nltgv2_ctx* ctx, int n) {
-  // one lane per half-edge, all waves resident: <= 24 waves per CU (the kernel needs < 64 VGPRs, so
-  // the hardware admits 32); the cooperative launch re-checks and we fall back if it refuses.
-  return ctx->opt_persistent && n >= 4 && n <= (1 << 24) && ctx->L.he_ok && ctx->L.he_waves > 0 &&
-         ctx->L.he_waves <= 24 * ctx->prop.multiProcessorCount && ctx->prop.cooperativeLaunch;
+// Which persistent form (if any) runs n steps: 0 none (per-step launches), 1 lane-per-half-edge
+// (lowest latency while the chip is not issue bound), 2 vertex-per-lane (fewest instructions; wins
+// once more than ~kHeWavesPerCuSweet waves of form 1 would share a CU).
+int persistent_form(const flame_nltgv2_ctx* ctx, int n) {
+  if (!ctx->opt_persistent || n < 4 || n > (1 << 24) || !ctx->prop.cooperativeLaunch) return 0;
+  const int cus = ctx->prop.multiProcessorCount;
+  const bool he_fits = ctx->L.he_ok && ctx->L.he_waves > 0 && ctx->L.he_waves <= 24 * cus;
+  const bool tv_fits = ctx->L.tv_ok && ctx->L.tv_waves > 0 && ctx->L.tv_waves <= kTvWavesPerCu * cus;
+  if (ctx->opt_persistent == 2) return he_fits ? 1 : 0;
+  if (ctx->opt_persistent == 3) return tv_fits ? 2 : 0;
+  if (he_fits && ctx->L.he_waves <= kHeWavesPerCuSweet * cus) return 1;
+  if (tv_fits) return 2;
+  return he_fits ? 1 : 0;
 }
+bool persistent_eligible(const flame_nltgv2_ctx* ctx, int n) { return persistent_form(ctx, n) != 0; }
 
 bool same_params(const flame_nltgv2_params& a, const flame_nltgv2_params& b) {
   return std::memcmp(&a, &b, sizeof(a)) == 0;
@@ -308,7 +322,8 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   if (rc) return rc;
   int unroll, wpb;
   pick_config(ctx, &unroll, &wpb);
-  if (persistent_eligible(ctx, n)) {
+  const int form = persistent_form(ctx, n);
+  if (form != 0) {
     // tags must stay unique: clear the granule buffers long before the 32-bit counter could wrap
     if ((uint64_t)ctx->tag_next + (uint64_t)n >= 0x7fff0000ull) {
       const size_t bytes = 16 * (size_t)ctx->L.n_slices * kWave;
@@ -316,24 +331,25 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       HIPCHK(ctx, hipMemsetAsync(ctx->gran1.p, 0, bytes, ctx->stream));
       ctx->tag_next = 1;
     }
-    const int pw = ctx->L.he_waves <= 4 * ctx->prop.multiProcessorCount ? 1 : 4;  // waves per workgroup
+    const int nw = form == 2 ? ctx->L.tv_waves : ctx->L.he_waves;
+    const int pw = nw <= 4 * ctx->prop.multiProcessorCount ? 1 : 4;  // waves per workgroup
     // a fresh first tag per launch: records left by earlier runs (whose state may since have been
     // changed by per-step launches or host uploads) can never satisfy a wait of this launch
     const uint32_t tag0 = ctx->tag_next + 2;
-    int e = launch_persistent_run(ctx->f, to_sp(p), ctx->parity, tag0, n, pw, std::getenv("FLAME_NLTGV2_DEBUG_NOWAIT") ? 0xfffffffeu : kMaxSpins,
+    int e = launch_persistent_run(ctx->f, to_sp(p), form, ctx->parity, tag0, n, pw, std::getenv("FLAME_NLTGV2_DEBUG_NOWAIT") ? 0xfffffffeu : kMaxSpins,
                                   std::getenv("FLAME_NLTGV2_PRESLEEP") ? std::atoi(std::getenv("FLAME_NLTGV2_PRESLEEP")) : kPreSleep,
-                                  ctx->coop_checked_topo != ctx->topo, ctx->stream);
+                                  ctx->coop_checked_key != (ctx->topo * 4 + (uint64_t)form), ctx->stream);
     if (e == 0) {
-      ctx->coop_checked_topo = ctx->topo;
+      ctx->coop_checked_key = ctx->topo * 4 + (uint64_t)form;
       ctx->tag_next = tag0 + (uint32_t)n;
-      ctx->last_run_path = 1;
+      ctx->last_run_path = form == 2 ? 5 : 1;
       ctx->parity ^= (n & 1);
       ctx->have_prev = true;
       ctx->canon_valid = false;
       return 0;
     }
     (void)hipGetLastError();  // e.g. cooperative launch too large: fall through to per-step launches
-    ctx->opt_persistent = 0;
+    if (ctx->opt_persistent == 1 || ctx->opt_persistent == form + 1) ctx->opt_persistent = 0;
   }
   int left = n;
   while (left > 0) {
@@ -421,7 +437,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
               &ctx->w2p, &ctx->data, &ctx->weight, &ctx->src, &ctx->dst, &ctx->alpha, &ctx->beta, &ctx->q1,
               &ctx->q2, &ctx->q3, &ctx->row_ptr, &ctx->half, &ctx->slice_row, &ctx->perm, &ctx->pdeg,
               &ctx->rec_nbr, &ctx->rec_edge, &ctx->edge_src_slot, &ctx->hrec, &ctx->hq, &ctx->vstate,
-              &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->gran0, &ctx->gran1, &ctx->abort_flag, &ctx->he_slot, &ctx->he_vid, &ctx->he_meta, &ctx->he_wave_chain, &ctx->err, &ctx->cost_pe, &ctx->cost_pv,
+              &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->gran0, &ctx->gran1, &ctx->abort_flag, &ctx->he_slot, &ctx->he_vid, &ctx->he_meta, &ctx->he_wave_chain, &ctx->tv_slot, &ctx->tv_vid, &ctx->tv_meta, &ctx->tv_wave, &ctx->err, &ctx->cost_pe, &ctx->cost_pv,
               &ctx->cost_out};
   *out = ctx;
   return FLAME_NLTGV2_OK;
@@ -466,7 +482,8 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
       ctx->opt_block_waves = value;
       return 0;
     case FLAME_NLTGV2_OPT_PERSISTENT:
-      ctx->opt_persistent = value ? 1 : 0;
+      if (value < 0 || value > 3) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_persistent = value;
       return 0;
     case FLAME_NLTGV2_OPT_UNROLL:
       if (value != 0 && value != 4 && value != 8 && value != 16) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
@@ -514,7 +531,10 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
       {&ctx->vprev, sizeof(float4) * n_packed}, {&ctx->gran0, 16 * n_packed}, {&ctx->gran1, 16 * n_packed},
       {&ctx->abort_flag, sizeof(int)}, {&ctx->he_slot, sizeof(int32_t) * L.he_slot.size()},
       {&ctx->he_vid, sizeof(int32_t) * L.he_vid.size()}, {&ctx->he_meta, sizeof(uint32_t) * L.he_meta.size()},
-      {&ctx->he_wave_chain, sizeof(int32_t) * L.he_wave_chain.size()}, {&ctx->err, sizeof(int)},
+      {&ctx->he_wave_chain, sizeof(int32_t) * L.he_wave_chain.size()},
+      {&ctx->tv_slot, sizeof(int32_t) * L.tv_slot.size()}, {&ctx->tv_vid, sizeof(int32_t) * L.tv_vid.size()},
+      {&ctx->tv_meta, sizeof(uint32_t) * L.tv_meta.size()}, {&ctx->tv_wave, sizeof(uint32_t) * L.tv_wave.size()},
+      {&ctx->err, sizeof(int)},
       {&ctx->cost_pe, sizeof(double) * kCostPartials}, {&ctx->cost_pv, sizeof(double) * kCostPartials},
       {&ctx->cost_out, 2 * sizeof(float)}};
   for (auto& r : req) {
@@ -543,7 +563,11 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
       {&ctx->he_slot, L.he_slot.data(), sizeof(int32_t) * L.he_slot.size()},
       {&ctx->he_vid, L.he_vid.data(), sizeof(int32_t) * L.he_vid.size()},
       {&ctx->he_meta, L.he_meta.data(), sizeof(uint32_t) * L.he_meta.size()},
-      {&ctx->he_wave_chain, L.he_wave_chain.data(), sizeof(int32_t) * L.he_wave_chain.size()}};
+      {&ctx->he_wave_chain, L.he_wave_chain.data(), sizeof(int32_t) * L.he_wave_chain.size()},
+      {&ctx->tv_slot, L.tv_slot.data(), sizeof(int32_t) * L.tv_slot.size()},
+      {&ctx->tv_vid, L.tv_vid.data(), sizeof(int32_t) * L.tv_vid.size()},
+      {&ctx->tv_meta, L.tv_meta.data(), sizeof(uint32_t) * L.tv_meta.size()},
+      {&ctx->tv_wave, L.tv_wave.data(), sizeof(uint32_t) * L.tv_wave.size()}};
   for (auto& c : cp) {
     if (rc) return rc;
     rc = h2d(ctx, *c.b, c.src, c.bytes);
@@ -746,6 +770,9 @@ int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info) {
   std::snprintf(info->device_name, sizeof(info->device_name), "%s", ctx->prop.name);
   std::snprintf(info->gcn_arch, sizeof(info->gcn_arch), "%s", ctx->prop.gcnArchName);
   info->last_run_path = ctx->last_run_path;
+  info->he_waves = ctx->L.he_ok ? ctx->L.he_waves : 0;
+  info->tv_waves = ctx->L.tv_ok ? ctx->L.tv_waves : 0;
+  info->tv_wave_capacity = kTvWavesPerCu * ctx->prop.multiProcessorCount;
   return FLAME_NLTGV2_OK;
 }
 

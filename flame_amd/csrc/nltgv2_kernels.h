@@ -50,14 +50,19 @@ struct FusedArgs {
   int32_t* he_vid = nullptr;
   uint32_t* he_meta = nullptr;
   int32_t* he_wave_chain = nullptr;
+  int tv_waves = 0;                    // persistent run, vertex-per-lane rows (nltgv2_pack.hpp (D))
+  int32_t* tv_slot = nullptr;
+  int32_t* tv_vid = nullptr;
+  uint32_t* tv_meta = nullptr;
+  uint32_t* tv_wave = nullptr;
   int* abort_flag = nullptr;
   int* err = nullptr;
 };
 
 int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, bool write_prev, int unroll,
                       int waves_per_block, hipStream_t stream);
-int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int parity_in, unsigned tag0, int n_iters,
-                          int waves_per_block, unsigned max_spins, int presleep, bool cooperative,
+int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, int parity_in, unsigned tag0,
+                          int n_iters, int waves_per_block, unsigned max_spins, int presleep, bool cooperative,
                           hipStream_t stream);
 int launch_save_prev(const CanonArgs& c, hipStream_t s);
 int launch_dual(const CanonArgs& c, const SolverParams& p, hipStream_t s);

@@ -419,6 +419,217 @@ k_persistent_he(const int n_waves, const int waves_per_xcd, const int32_t* __res
 }
 
 // ------------------------------------------------------------------------------------------------
+// Persistent run, throughput form: same dataflow protocol as k_persistent_he (tagged 16-byte bar
+// records, two parity buffers, bounded waits), but one VERTEX per lane with up to 8 half-edge slots
+// held in registers -- ~5x fewer instructions per half-edge than the lane-per-half-edge form, at the
+// price of a longer serial chain per wave.  It is the better choice when many waves share a CU
+// (batches of frames, 1080p graphs), where the lane-per-half-edge kernel becomes issue bound.
+//
+// A vertex of degree > 8 occupies ceil(deg/8) ADJACENT lanes of one wave; pass p processes the lanes
+// with chain index p, which first take over the running sums of lane-1 (DPP wave_shr:1), so the
+// accumulation still follows ascending edge id exactly.  The last lane of a chain owns the vertex:
+// it applies proxL1 / extragradient, publishes the record and hands the state back to its chain.
+// ------------------------------------------------------------------------------------------------
+constexpr int kTvS = 8;
+constexpr unsigned kTvOwnerBit = 1u << 16, kTvValidBit = 1u << 17;
+
+__device__ __forceinline__ float dpp_shr1(float v) {  // lane l <- lane l-1; lane 0 keeps its value
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+
+__global__ void __launch_bounds__(256)
+k_persistent_tv(const int n_waves, const int waves_per_xcd, const int32_t* __restrict__ tv_slot,
+                const int32_t* __restrict__ tv_vid, const uint32_t* __restrict__ tv_meta,
+                const uint32_t* __restrict__ tv_wave, const int4* hrec, float4* hq, float4* vstate,
+                const float2* vaux, const float4* bar_in, float4* bar_out, float4* vprev, void* gran0,
+                void* gran1, const unsigned tag0, const int n_iters, const unsigned max_spins,
+                const int presleep, const SolverParams p, int* __restrict__ err, int* __restrict__ abort_flag) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int b = blockIdx.x;
+  const int xcd = b & 7;
+  const int idx = (b >> 3) * wpb + (threadIdx.x >> 6);
+  if (idx >= waves_per_xcd) return;
+  const int w = xcd * waves_per_xcd + idx;
+  if (w >= n_waves) return;
+
+  const unsigned meta = tv_meta[(size_t)w * 64 + lane];
+  const int pv = tv_vid[(size_t)w * 64 + lane];
+  const unsigned winfo = (unsigned)__builtin_amdgcn_readfirstlane((int)tv_wave[w]);
+  const int passes = (int)(winfo & 0xffu);
+  const bool has_chain = (winfo & 0x100u) != 0u;
+  const int nslots = (int)(meta & 15u);
+  const int cidx = (int)((meta >> 4) & 63u);
+  const int owner_lane = (int)((meta >> 10) & 63u);
+  const bool is_owner = (meta & kTvOwnerBit) != 0u;
+  const bool valid = (meta & kTvValidBit) != 0u;
+
+  int nbr[kTvS];
+  float alpha[kTvS], dx[kTvS], dy[kTvS], beta[kTvS], q1[kTvS], q2[kTvS], q3[kTvS];
+#pragma unroll
+  for (int k = 0; k < kTvS; ++k) {
+    const int sl = tv_slot[((size_t)w * kTvS + k) * 64 + lane];
+    int4 r = make_int4(0, 0, 0, 0);
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sl >= 0) {
+      r = hrec[sl];
+      q = hq[sl];
+    }
+    nbr[k] = (int)(((unsigned)r.x & 0x80000000u) | (((unsigned)r.x & 0x07ffffffu) << 4));
+    alpha[k] = __int_as_float(r.y), dx[k] = __int_as_float(r.z), dy[k] = __int_as_float(r.w);
+    q1[k] = q.x, q2[k] = q.y, q3[k] = q.z, beta[k] = q.w;
+  }
+
+  float4 st = make_float4(0.f, 0.f, 0.f, 0.f), bs = make_float4(0.f, 0.f, 0.f, 0.f);
+  float2 aux = make_float2(0.f, 0.f);
+  if (valid) {
+    st = vstate[pv];
+    aux = vaux[pv];
+    bs = bar_in[pv];
+  }
+  const float data = st.w;
+  const float lam_w = p.data_factor * aux.x;
+  float x = st.x, w1 = st.y, w2 = st.z;  // invariant: every lane of a chain holds the vertex state
+  float xb = bs.x, w1b = bs.y, w2b = bs.z;
+  float x_prev = x, w1_prev = w1, w2_prev = w2;
+  bool ok = true;
+  bool timed_out = false;
+  int ps = presleep >= 0 ? presleep : -presleep;
+
+  const __amdgpu_buffer_rsrc_t r0 = make_rsrc(gran0), r1 = make_rsrc(gran1);
+  const int my_off = pv << 4;
+  const unsigned all_mask = (1u << nslots) - 1u;
+
+  if (is_owner) {
+    v4i_t o;
+    o.x = __float_as_int(xb), o.y = __float_as_int(w1b), o.z = __float_as_int(w2b), o.w = (int)tag0;
+    __builtin_amdgcn_raw_buffer_store_b128(o, (tag0 & 1u) ? r1 : r0, my_off, 0, kAuxSc1);
+  }
+
+  for (int it = 0; it < n_iters; ++it) {
+    const unsigned s = tag0 + (unsigned)it;
+    const __amdgpu_buffer_rsrc_t rin = (s & 1u) ? r1 : r0;
+    // ---- wait for all neighbours' bar(s): one round of loads in flight, only pending slots re-polled
+    v4i_t g[kTvS];
+    unsigned pending = all_mask;
+    unsigned spins = 0;
+    const bool dbg_nowait = (max_spins == 0xfffffffeu);
+    for (int z = 0; z < ps; ++z) __builtin_amdgcn_s_sleep(1);
+    for (;;) {
+#pragma unroll
+      for (int k = 0; k < kTvS; ++k) {
+        if ((pending >> k) & 1u) {
+          int o = nbr[k] & 0x7fffffff;
+          asm volatile("" : "+v"(o)::"memory");  // opaque: re-issue on every spin
+          g[k] = __builtin_amdgcn_raw_buffer_load_b128(rin, o, 0, kAuxSc1);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kTvS; ++k) {
+        if (((pending >> k) & 1u) && ((unsigned)g[k].w == s || dbg_nowait)) pending &= ~(1u << k);
+      }
+      if (!__any(pending != 0u)) break;
+      ++spins;
+      if ((spins & 63u) == 0u) {
+        const int ab = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ab != 0 || spins > max_spins) {
+          timed_out = true;
+          break;
+        }
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (timed_out) break;
+    if (presleep >= 0) {
+      if (spins != 0u) ps = (ps < 48) ? ps + 1 : ps;
+      else if ((it & 3) == 3 && ps > 0) ps -= 1;
+    }
+
+    float X = x, W1 = w1, W2 = w2;
+    for (int pass = 0; pass < passes; ++pass) {
+      if (pass > 0) {  // chain continuation: take over the running sums of the previous lane
+        const float Xs = dpp_shr1(X), W1s = dpp_shr1(W1), W2s = dpp_shr1(W2);
+        if (cidx == pass) X = Xs, W1 = W1s, W2 = W2s;
+      }
+      const bool live = (cidx == pass);
+#pragma unroll
+      for (int k = 0; k < kTvS; ++k) {
+        const bool act = live && (k < nslots);
+        const bool is_target = nbr[k] < 0;
+        const float nxb = __int_as_float(g[k].x), nw1b = __int_as_float(g[k].y), nw2b = __int_as_float(g[k].z);
+        const float xbi = is_target ? nxb : xb, xbj = is_target ? xb : nxb;
+        const float w1bi = is_target ? nw1b : w1b, w1bj = is_target ? w1b : nw1b;
+        const float w2bi = is_target ? nw2b : w2b, w2bj = is_target ? w2b : nw2b;
+        bool okq = true;
+        const EdgeOut e = edge_dual(p, alpha[k], beta[k], dx[k], dy[k], q1[k], q2[k], q3[k], xbi, w1bi, w2bi,
+                                    xbj, w1bj, w2bj, okq);
+        const float t1 = e.q1 * p.step_x * alpha[k];
+        const float t2 = e.q2 * p.step_x * beta[k];
+        const float t3 = e.q3 * p.step_x * beta[k];
+        float nx, nw1, nw2;
+        if (is_target) {
+          nx = X + t1;
+          nw1 = W1 + t2;
+          nw2 = W2 + t3;
+        } else {
+          nx = X - t1;
+          nw1 = W1 + t1 * dx[k];
+          nw2 = W2 + t1 * dy[k];
+          nw1 = nw1 - t2;
+          nw2 = nw2 - t3;
+        }
+        if (act) {
+          X = nx, W1 = nw1, W2 = nw2;
+          q1[k] = e.q1, q2[k] = e.q2, q3[k] = e.q3;
+          ok = ok && okq;
+        }
+      }
+    }
+    // ---- vertex update at the owner lane ----------------------------------------------------------
+    const float xn = prox_l1(p.x_min, p.x_max, p.step_x, lam_w, X, data);
+    float nb = xn + p.theta * (xn - x);
+    nb = (nb < p.x_min) ? p.x_min : nb;
+    nb = (nb > p.x_max) ? p.x_max : nb;
+    const float w1bn = W1 + p.theta * (W1 - w1);
+    const float w2bn = W2 + p.theta * (W2 - w2);
+    if (is_owner) {
+      v4i_t o;
+      o.x = __float_as_int(nb), o.y = __float_as_int(w1bn), o.z = __float_as_int(w2bn), o.w = (int)(s + 1u);
+      __builtin_amdgcn_raw_buffer_store_b128(o, ((s + 1u) & 1u) ? r1 : r0, my_off, 0, kAuxSc1);
+    }
+    x_prev = x, w1_prev = w1, w2_prev = w2;
+    if (has_chain) {  // wave-uniform: hand the owner's new state back to every lane of its chain
+      x = __shfl(xn, owner_lane, 64);
+      w1 = __shfl(W1, owner_lane, 64);
+      w2 = __shfl(W2, owner_lane, 64);
+      xb = __shfl(nb, owner_lane, 64);
+      w1b = __shfl(w1bn, owner_lane, 64);
+      w2b = __shfl(w2bn, owner_lane, 64);
+    } else {
+      x = xn, w1 = W1, w2 = W2, xb = nb, w1b = w1bn, w2b = w2bn;
+    }
+  }
+
+  if (timed_out) {
+    if (lane == 0) {
+      __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicOr(err, 2);
+    }
+    return;
+  }
+  if (is_owner) {
+    vstate[pv] = make_float4(x, w1, w2, data);
+    bar_out[pv] = make_float4(xb, w1b, w2b, 0.0f);
+    vprev[pv] = make_float4(x_prev, w1_prev, w2_prev, 0.0f);
+  }
+#pragma unroll
+  for (int k = 0; k < kTvS; ++k) {
+    if (k < nslots) hq[tv_slot[((size_t)w * kTvS + k) * 64 + lane]] = make_float4(q1[k], q2[k], q3[k], beta[k]);
+  }
+  if (!ok) atomicOr(err, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Canonical (original order, SoA) sweeps: the individually callable pieces of a step.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -707,20 +918,21 @@ int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, boo
   return (int)hipGetLastError();
 }
 
-// Persistent run (single cooperative launch).  Returns the hipError_t unchanged (e.g.
-// hipErrorCooperativeLaunchTooLarge) so the caller can fall back to per-step launches.
-int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int parity_in, unsigned tag0, int n_iters,
-                          int waves_per_block, unsigned max_spins, int presleep, bool cooperative,
+// Persistent run (single launch).  form 1 = lane per half-edge (k_persistent_he), form 2 = vertex per
+// lane (k_persistent_tv).  Returns the hipError_t unchanged (e.g. hipErrorCooperativeLaunchTooLarge)
+// so the caller can fall back to per-step launches.
+int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, int parity_in, unsigned tag0,
+                          int n_iters, int waves_per_block, unsigned max_spins, int presleep, bool cooperative,
                           hipStream_t stream) {
-  if (a.he_waves <= 0 || n_iters <= 0) return (int)hipSuccess;
-  int n_waves = a.he_waves;
-  int wpx = (a.he_waves + 7) / 8;
+  int n_waves = (form == 2) ? a.tv_waves : a.he_waves;
+  if (n_waves <= 0 || n_iters <= 0) return (int)hipSuccess;
+  int wpx = (n_waves + 7) / 8;
   const int bpx = (wpx + waves_per_block - 1) / waves_per_block;
   const dim3 grid((unsigned)(bpx * 8)), block((unsigned)(64 * waves_per_block));
-  const int32_t* he_slot = a.he_slot;
-  const int32_t* he_vid = a.he_vid;
-  const uint32_t* he_meta = a.he_meta;
-  const int32_t* he_wave_chain = a.he_wave_chain;
+  const int32_t* i0 = (form == 2) ? a.tv_slot : a.he_slot;
+  const int32_t* i1 = (form == 2) ? a.tv_vid : a.he_vid;
+  const uint32_t* i2 = (form == 2) ? a.tv_meta : a.he_meta;
+  const void* i3 = (form == 2) ? (const void*)a.tv_wave : (const void*)a.he_wave_chain;
   const int4* hrec = a.hrec;
   float4* hq = a.hq;
   float4* vstate = a.vstate;
@@ -733,13 +945,14 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int parity_
   SolverParams pp = p;
   int* err = a.err;
   int* abort_flag = a.abort_flag;
-  void* args[] = {&n_waves, &wpx, &he_slot, &he_vid, &he_meta, &he_wave_chain, &hrec, &hq, &vstate, &vaux, &bin,
+  void* args[] = {&n_waves, &wpx, &i0, &i1, &i2, &i3, &hrec, &hq, &vstate, &vaux, &bin,
                   &bout, &vprev, &g0, &g1, &tag0, &n_iters, &max_spins, &presleep, &pp, &err, &abort_flag};
+  const void* fn = (form == 2) ? (const void*)k_persistent_tv : (const void*)k_persistent_he;
   // The first launch of a topology is cooperative: the runtime verifies that the whole grid is
   // resident (hipErrorCooperativeLaunchTooLarge otherwise).  The same grid is then launched plainly
   // (identical residency, ~15 us less launch overhead per call).
-  if (cooperative) return (int)hipLaunchCooperativeKernel((const void*)k_persistent_he, grid, block, args, 0, stream);
-  return (int)hipLaunchKernel((const void*)k_persistent_he, grid, block, args, 0, stream);
+  if (cooperative) return (int)hipLaunchCooperativeKernel(fn, grid, block, args, 0, stream);
+  return (int)hipLaunchKernel(fn, grid, block, args, 0, stream);
 }
 
 int launch_save_prev(const CanonArgs& c, hipStream_t s) {

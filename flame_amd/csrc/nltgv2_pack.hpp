@@ -54,7 +54,18 @@ struct PackedLayout {
   std::vector<int32_t> he_vid;         // [he_waves*64] packed vertex owning the lane, -1 unused lane
   std::vector<uint32_t> he_meta;       // [he_waves*64] pos | tail_lane<<6 | is_tail<<12 | active<<13 | valid<<14
   std::vector<int32_t> he_wave_chain;  // [he_waves] max(1, max degree) of the wave's vertices
+  // (D) one-vertex-per-lane rows of the register-resident persistent run (throughput form): a lane
+  // holds up to kTvSlots half-edges; a vertex of higher degree occupies ceil(deg/kTvSlots) ADJACENT
+  // lanes of one wave ("chain"), the last of which owns the vertex.
+  bool tv_ok = false;
+  int32_t tv_waves = 0;
+  std::vector<int32_t> tv_slot;   // [tv_waves*kTvSlots*64] (wave, k, lane) -> SELL slot, -1 none
+  std::vector<int32_t> tv_vid;    // [tv_waves*64] packed vertex the lane belongs to, -1 unused
+  std::vector<uint32_t> tv_meta;  // [tv_waves*64] nslots | chain_idx<<4 | owner_lane<<10 | owner<<16 | valid<<17
+  std::vector<uint32_t> tv_wave;  // [tv_waves] passes | has_chain<<8 | slots used in pass 0 <<16 | in later passes <<20
 };
+constexpr int kTvSlots = 8;
+constexpr uint32_t kTvOwner = 1u << 16, kTvValid = 1u << 17;
 
 constexpr uint32_t kHeTail = 1u << 12, kHeActive = 1u << 13, kHeValid = 1u << 14;
 
@@ -233,6 +244,50 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
       L->he_wave_chain.back() = std::max(L->he_wave_chain.back(), need);
       L->he_max_chain = std::max(L->he_max_chain, need);
       fill += need;
+    }
+  }
+
+  // ---- (D) one-vertex-per-lane rows, kTvSlots register slots per lane ------------------------------
+  L->tv_ok = (maxdeg <= kTvSlots * kWave);
+  L->tv_waves = 0;
+  L->tv_slot.clear(), L->tv_vid.clear(), L->tv_meta.clear(), L->tv_wave.clear();
+  if (L->tv_ok && V > 0) {
+    int32_t fill = kWave;
+    for (int32_t s = 0; s < V; ++s) {
+      const int32_t d = L->pdeg[s];
+      const int32_t lanes = std::max(1, (d + kTvSlots - 1) / kTvSlots);
+      if (fill + lanes > kWave) {
+        L->tv_slot.resize(L->tv_slot.size() + static_cast<size_t>(kTvSlots) * kWave, -1);
+        L->tv_vid.resize(L->tv_vid.size() + kWave, -1);
+        L->tv_meta.resize(L->tv_meta.size() + kWave, 0u);
+        L->tv_wave.push_back(1u);
+        L->tv_waves++;
+        fill = 0;
+      }
+      const size_t w = static_cast<size_t>(L->tv_waves - 1);
+      const int64_t row0 = L->slice_row[s / kWave];
+      const int32_t owner_lane = fill + lanes - 1;
+      for (int32_t c = 0; c < lanes; ++c) {
+        const int32_t lane = fill + c;
+        const int32_t k0 = c * kTvSlots;
+        const int32_t ns = std::max(0, std::min(kTvSlots, d - k0));
+        uint32_t m = static_cast<uint32_t>(ns) | (static_cast<uint32_t>(c) << 4) |
+                     (static_cast<uint32_t>(owner_lane) << 10) | kTvValid;
+        if (c == lanes - 1) m |= kTvOwner;
+        L->tv_meta[w * kWave + lane] = m;
+        L->tv_vid[w * kWave + lane] = s;
+        for (int32_t k = 0; k < ns; ++k) {
+          L->tv_slot[(w * kTvSlots + k) * kWave + lane] =
+              static_cast<int32_t>((row0 + k0 + k) * kWave + (s % kWave));
+        }
+      }
+      uint32_t& wi = L->tv_wave[w];
+      const uint32_t passes = std::max<uint32_t>(wi & 0xffu, static_cast<uint32_t>(lanes));
+      uint32_t k_first = (wi >> 16) & 15u, k_later = (wi >> 20) & 15u;
+      k_first = std::max<uint32_t>(k_first, static_cast<uint32_t>(std::min(d, kTvSlots)));
+      if (lanes > 1) k_later = std::max<uint32_t>(k_later, lanes > 2 ? kTvSlots : static_cast<uint32_t>(d - kTvSlots));
+      wi = passes | ((passes > 1u || (wi & 0x100u)) ? 0x100u : 0u) | (k_first << 16) | (k_later << 20);
+      fill += lanes;
     }
   }
   return FLAME_NLTGV2_OK;

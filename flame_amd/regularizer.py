@@ -27,7 +27,8 @@ _FP = C.POINTER(C.c_float)
 _IP = C.POINTER(C.c_int32)
 
 OPT_SOLVER, OPT_USE_HIPGRAPH, OPT_BLOCK_WAVES, OPT_UNROLL, OPT_PERSISTENT = 1, 2, 3, 4, 5
-RUN_PATHS = {0: "none", 1: "persistent", 2: "per-step hipGraph", 3: "per-step eager", 4: "canonical 4-sweep"}
+RUN_PATHS = {0: "none", 1: "persistent", 2: "per-step hipGraph", 3: "per-step eager", 4: "canonical 4-sweep",
+             5: "persistent-tv"}
 ERR_NAN = -5
 
 VERTEX_STATE = ("x", "w1", "w2", "x_bar", "w1_bar", "w2_bar", "x_prev", "w1_prev", "w2_prev")
@@ -63,7 +64,8 @@ class _Info(C.Structure):
         ("abi_version", C.c_int32), ("device", C.c_int32), ("V", C.c_int32), ("E", C.c_int32),
         ("n_slices", C.c_int32), ("max_degree", C.c_int32), ("padded_half_edges", C.c_int64),
         ("device_bytes", C.c_int64), ("algorithmic_bytes_per_iter", C.c_int64), ("compute_units", C.c_int32),
-        ("device_name", C.c_char * 64), ("gcn_arch", C.c_char * 32), ("last_run_path", C.c_int32),
+        ("device_name", C.c_char * 64), ("gcn_arch", C.c_char * 32), ("last_run_path", C.c_int32), ("he_waves", C.c_int32), ("tv_waves", C.c_int32),
+        ("tv_wave_capacity", C.c_int32),
     ]
 
 

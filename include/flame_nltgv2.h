@@ -140,8 +140,9 @@ enum {
   FLAME_NLTGV2_OPT_BLOCK_WAVES = 3,  /* waves per workgroup of the fused sweep: 0 = auto, 1,2,4 */
   FLAME_NLTGV2_OPT_UNROLL = 4,       /* half-edge slots per load chunk of the fused sweep: 0 = auto, 4,8,16 */
   FLAME_NLTGV2_OPT_PERSISTENT = 5    /* 1 (default) = run() uses ONE persistent launch for all n_iters steps
-                                        when the graph fits on the chip (one lane per half-edge, <= 24 waves/CU, degree <= 64);
-                                        0 = always one launch per step */
+                                        when the graph fits on the chip, picking the form by occupancy;
+                                        2 = force the lane-per-half-edge form, 3 = force the vertex-per-lane
+                                        form (each only if it fits); 0 = always one launch per step */
 };
 int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value);
 
@@ -157,8 +158,12 @@ typedef struct flame_nltgv2_info {
   int32_t compute_units;
   char device_name[64];
   char gcn_arch[32];
-  int32_t last_run_path; /* 0 none, 1 persistent single launch, 2 one launch per step (hipGraph),
-                            3 one launch per step (eager), 4 four canonical sweeps per step */
+  int32_t last_run_path; /* 0 none, 1 persistent launch (lane per half-edge), 2 one launch per step
+                            (hipGraph), 3 one launch per step (eager), 4 four canonical sweeps per step,
+                            5 persistent launch (vertex per lane) */
+  int32_t he_waves;      /* waves of the lane-per-half-edge persistent form (0: not applicable) */
+  int32_t tv_waves;      /* waves of the vertex-per-lane persistent form (0: not applicable) */
+  int32_t tv_wave_capacity; /* vertex-per-lane waves the device keeps resident */
 } flame_nltgv2_info;
 int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info);
 

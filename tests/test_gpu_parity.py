@@ -73,7 +73,7 @@ def test_config_parity(env, config, n):
     g = synth.make_graph(config, seed=4242)
     ref, bad = cpu_run(oracle, g, n)
     assert bad == 0
-    for persistent in (1, 0):
+    for persistent in (1, 2, 3, 0):  # auto, lane-per-half-edge, vertex-per-lane, one launch per step
         out = gpu_run(flame_amd, g, n, options=[(5, persistent)], expect_path=None if persistent else 2)
         assert rms(out["x"], ref["x"]) <= TOL_RMS
         assert_state_equal(out, ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"{config} p={persistent}")
@@ -84,6 +84,8 @@ def test_four_kernel_path_matches_fused_and_checker(env):
     g = synth.make_graph("320x240", seed=11)
     ref, _ = cpu_run(oracle, g, 37)
     persistent = gpu_run(flame_amd, g, 37, expect_path=1)
+    persistent_tv = gpu_run(flame_amd, g, 37, options=[(5, 3)], expect_path=5)
+    assert_state_equal(persistent_tv, ref, what="persistent vertex-per-lane")
     fused = gpu_run(flame_amd, g, 37, options=[(5, 0)], expect_path=2)
     canon = gpu_run(flame_amd, g, 37, options=[(flame_amd.regularizer.OPT_SOLVER, 1)], expect_path=4)
     assert_state_equal(persistent, ref, what="persistent")
@@ -120,7 +122,7 @@ def test_internal_steps_individually(env):
 
 @pytest.mark.parametrize("opts", [
     [(5, 0), (3, 1), (4, 4)], [(5, 0), (3, 1), (4, 8)], [(5, 0), (3, 1), (4, 16)], [(5, 0), (3, 2), (4, 8)],
-    [(5, 0), (3, 4), (4, 4)], [(5, 0), (3, 4), (4, 16)], [(5, 0), (2, 0)], [(5, 1)],
+    [(5, 0), (3, 4), (4, 4)], [(5, 0), (3, 4), (4, 16)], [(5, 0), (2, 0)], [(5, 1)], [(5, 2)], [(5, 3)],
 ])
 def test_launch_configurations_are_bit_identical(env, opts):
     """waves per workgroup (opt 3), slot chunk (opt 4), hipGraph on/off (opt 2), persistent single
@@ -192,9 +194,21 @@ def test_star_graph_high_degree(env):
     g = synth.assemble_graph(pos, data, np.array(e, np.int32))
     ref, bad = cpu_run(oracle, g, 25)
     assert bad == 0
-    for unroll in (4, 16):  # degree 999 > 16: not eligible for the persistent run -> per-step launches
-        out = gpu_run(flame_amd, g, 25, options=[(4, unroll)], expect_path=2)
+    for unroll in (4, 16):  # one launch per step
+        out = gpu_run(flame_amd, g, 25, options=[(5, 0), (4, unroll)], expect_path=2)
         assert_state_equal(out, ref, what=f"star U={unroll}")
+    # degree 999 > 64 lanes: the lane-per-half-edge form cannot hold it, the vertex-per-lane form
+    # cannot either (999 > 8*64) -> automatic fall back to per-step launches
+    out = gpu_run(flame_amd, g, 25, expect_path=2)
+    assert_state_equal(out, ref, what="star auto")
+    # a hub of degree 300: 38 chained lanes in the vertex-per-lane form
+    V2 = 400
+    e2 = [(0, i) if i % 3 else (i, 0) for i in range(1, 301)] + [(i, i + 1) for i in range(1, V2 - 1)]
+    g2 = synth.assemble_graph(pos[:V2], data[:V2], np.array(e2, np.int32))
+    ref2, _ = cpu_run(oracle, g2, 25)
+    for form, path in ((3, 5), (1, 5)):  # forced, and picked automatically (degree 300 > 64 lanes)
+        out = gpu_run(flame_amd, g2, 25, options=[(5, form)], expect_path=path)
+        assert_state_equal(out, ref2, what=f"hub of degree 300, persistent option {form}")
 
 
 def test_edge_order_and_orientation_semantics(env):
