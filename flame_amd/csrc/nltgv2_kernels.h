@@ -44,7 +44,7 @@ struct FusedArgs {
   float2* vaux = nullptr;   // [n_slices*64] {data_weight, degree bits}
   float4* bar[2] = {nullptr, nullptr};  // ping-pong {x_bar,w1_bar,w2_bar,-}
   float4* vprev = nullptr;  // {x_prev,w1_prev,w2_prev,-} written by the last step of a run
-  void* gran[2] = {nullptr, nullptr};  // persistent run: [n_slices*64] 16-byte {x_bar,w1_bar,w2_bar,tag} records
+  void* xbuf = nullptr;  // persistent run: [R0|L0|R1|L1|XCC] exchange buffer, see nltgv2_kernels.hip
   int he_waves = 0;                    // persistent run: wave-aligned half-edge rows (nltgv2_pack.hpp (C))
   int32_t* he_slot = nullptr;
   int32_t* he_vid = nullptr;
@@ -62,8 +62,8 @@ struct FusedArgs {
 int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, bool write_prev, int unroll,
                       int waves_per_block, hipStream_t stream);
 int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, int parity_in, unsigned tag0,
-                          int n_iters, int waves_per_block, unsigned max_spins, int presleep, bool cooperative,
-                          hipStream_t stream);
+                          int n_iters, int waves_per_block, unsigned max_spins, int presleep, int dual,
+                          bool cooperative, hipStream_t stream);
 int launch_save_prev(const CanonArgs& c, hipStream_t s);
 int launch_dual(const CanonArgs& c, const SolverParams& p, hipStream_t s);
 int launch_primal(const CanonArgs& c, const SolverParams& p, hipStream_t s);

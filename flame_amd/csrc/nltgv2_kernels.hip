@@ -221,6 +221,21 @@ k_fused_step(const int n_slices, const int slices_per_xcd, const int32_t* __rest
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 
 constexpr int kAuxSc1 = 16;  // cache-policy bits of the raw buffer builtins: bit 4 = sc1
+// Exchange buffer of a persistent run, ONE allocation addressed through one buffer descriptor:
+//   [ R0 | L0 | R1 | L1 | XCC ]   R/L = remote/local records of step parity 0/1, S = 16*n_packed bytes
+//   each, XCC = one dword per vertex.
+// "remote" records are written through (sc1) and can be read from any XCD (one-way ~0.45-0.55 us,
+// every read is a trip to the memory side).  "local" records are written with a PLAIN store, i.e.
+// they stay in the writer's XCD L2, where a reader on the SAME XCD finds them with an sc1 load in
+// ~0.26 us without any memory-side traffic -- but a reader on another XCD would never see them
+// (tools/hop_bench.hip measured both).  Which copy a lane polls is decided from the TRUE XCC ids of
+// both waves (HW_REG_XCC_ID, exchanged once per launch through the XCC table), never from an
+// assumed workgroup->XCD placement.
+__device__ __forceinline__ unsigned read_xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 15u;
+}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(void* base) {
   return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
 }
@@ -231,9 +246,10 @@ __global__ void __launch_bounds__(256)
 k_persistent_he(const int n_waves, const int waves_per_xcd, const int32_t* __restrict__ he_slot,
                 const int32_t* __restrict__ he_vid, const uint32_t* __restrict__ he_meta,
                 const int32_t* __restrict__ he_wave_chain, const int4* hrec, float4* hq, float4* vstate,
-                const float2* vaux, const float4* bar_in, float4* bar_out, float4* vprev, void* gran0,
-                void* gran1, const unsigned tag0, const int n_iters, const unsigned max_spins,
-                const int presleep, const SolverParams p, int* __restrict__ err, int* __restrict__ abort_flag) {
+                const float2* vaux, const float4* bar_in, float4* bar_out, float4* vprev, void* xbuf,
+                const int rec_bytes, const int dual, const unsigned tag0, const int n_iters,
+                const unsigned max_spins, const int presleep, const SolverParams p, int* __restrict__ err,
+                int* __restrict__ abort_flag) {
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
   const int b = blockIdx.x;
@@ -282,16 +298,44 @@ k_persistent_he(const int n_waves, const int waves_per_xcd, const int32_t* __res
   bool timed_out = false;
   int ps = presleep >= 0 ? presleep : -presleep;  // presleep < 0: fixed |presleep|, no adaptation
 
-  const __amdgpu_buffer_rsrc_t r0 = make_rsrc(gran0), r1 = make_rsrc(gran1);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(xbuf);
   const int my_off = pv << 4;
+  const int S = rec_bytes, par = 2 * rec_bytes;
+  int poll_off = nbr_off;  // remote copy by default
 
-  if (is_tail) {  // publish bar(tag0); tag0 is fresh, leftovers of earlier runs cannot match
-    v4i_t o;
-    o.x = __float_as_int(xb), o.y = __float_as_int(w1b), o.z = __float_as_int(w2b), o.w = (int)tag0;
-    __builtin_amdgcn_raw_buffer_store_b128(o, (tag0 & 1u) ? r1 : r0, my_off, 0, kAuxSc1);
+  if (dual) {  // one-time XCC exchange: which neighbours run on my XCD?
+    const unsigned my_xcc = read_xcc_id();
+    const unsigned want = (tag0 & 0x0fffffffu) << 4;
+    if (is_tail) __builtin_amdgcn_raw_buffer_store_b32((int)(want | my_xcc), rx, 4 * S + (pv << 2), 0, kAuxSc1);
+    bool pend = active;
+    unsigned spins = 0;
+    unsigned got = 0;
+    for (;;) {
+      if (pend) {
+        int o = 4 * S + (nbr_off >> 2);
+        asm volatile("" : "+v"(o)::"memory");
+        got = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, kAuxSc1);
+        pend = ((got & ~15u) != want);
+      }
+      if (!__any(pend)) break;
+      if (++spins > max_spins) {
+        timed_out = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (active && !timed_out && (got & 15u) == my_xcc) poll_off = nbr_off + S;
   }
 
-  for (int it = 0; it < n_iters; ++it) {
+  if (is_tail && !timed_out) {  // publish bar(tag0); tag0 is fresh, leftovers of earlier runs cannot match
+    v4i_t o;
+    o.x = __float_as_int(xb), o.y = __float_as_int(w1b), o.z = __float_as_int(w2b), o.w = (int)tag0;
+    const int so = (tag0 & 1u) ? par : 0;
+    __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
+    if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
+  }
+
+  for (int it = 0; it < n_iters && !timed_out; ++it) {
     const unsigned s = tag0 + (unsigned)it;
     // ---- wait for the neighbour's bar(s) ---------------------------------------------------------
     // ONE poll in flight per wave, and none before the record can plausibly be there: polling is
@@ -305,13 +349,13 @@ k_persistent_he(const int n_waves, const int waves_per_xcd, const int32_t* __res
     bool pend = active;
     unsigned spins = 0;
     const bool dbg_nowait = (max_spins == 0xfffffffeu);  // timing experiment only
-    const __amdgpu_buffer_rsrc_t rin = (s & 1u) ? r1 : r0;
+    const int so_in = (s & 1u) ? par : 0;
     for (int z = 0; z < ps; ++z) __builtin_amdgcn_s_sleep(1);
     for (;;) {
       if (pend) {
-        int o = nbr_off;
+        int o = poll_off;
         asm volatile("" : "+v"(o)::"memory");
-        g = __builtin_amdgcn_raw_buffer_load_b128(rin, o, 0, kAuxSc1);
+        g = __builtin_amdgcn_raw_buffer_load_b128(rx, o, so_in, kAuxSc1);
         pend = ((unsigned)g.w != s) && !dbg_nowait;
       }
       if (!__any(pend)) break;
@@ -389,7 +433,9 @@ k_persistent_he(const int n_waves, const int waves_per_xcd, const int32_t* __res
     if (is_tail) {
       v4i_t o;
       o.x = __float_as_int(nb), o.y = __float_as_int(w1bn), o.z = __float_as_int(w2bn), o.w = (int)(s + 1u);
-      __builtin_amdgcn_raw_buffer_store_b128(o, ((s + 1u) & 1u) ? r1 : r0, my_off, 0, kAuxSc1);
+      const int so = ((s + 1u) & 1u) ? par : 0;
+      __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
+      if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
     }
     // ---- hand the vertex's new state back to all of its lanes -------------------------------------
     x_prev = x, w1_prev = w1, w2_prev = w2;  // step()'s prev copy, cc:37-42
@@ -441,9 +487,10 @@ __global__ void __launch_bounds__(256)
 k_persistent_tv(const int n_waves, const int waves_per_xcd, const int32_t* __restrict__ tv_slot,
                 const int32_t* __restrict__ tv_vid, const uint32_t* __restrict__ tv_meta,
                 const uint32_t* __restrict__ tv_wave, const int4* hrec, float4* hq, float4* vstate,
-                const float2* vaux, const float4* bar_in, float4* bar_out, float4* vprev, void* gran0,
-                void* gran1, const unsigned tag0, const int n_iters, const unsigned max_spins,
-                const int presleep, const SolverParams p, int* __restrict__ err, int* __restrict__ abort_flag) {
+                const float2* vaux, const float4* bar_in, float4* bar_out, float4* vprev, void* xbuf,
+                const int rec_bytes, const int dual, const unsigned tag0, const int n_iters,
+                const unsigned max_spins, const int presleep, const SolverParams p, int* __restrict__ err,
+                int* __restrict__ abort_flag) {
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
   const int b = blockIdx.x;
@@ -496,19 +543,54 @@ k_persistent_tv(const int n_waves, const int waves_per_xcd, const int32_t* __res
   bool timed_out = false;
   int ps = presleep >= 0 ? presleep : -presleep;
 
-  const __amdgpu_buffer_rsrc_t r0 = make_rsrc(gran0), r1 = make_rsrc(gran1);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(xbuf);
   const int my_off = pv << 4;
+  const int S = rec_bytes, par = 2 * rec_bytes;
   const unsigned all_mask = (1u << nslots) - 1u;
 
-  if (is_owner) {
-    v4i_t o;
-    o.x = __float_as_int(xb), o.y = __float_as_int(w1b), o.z = __float_as_int(w2b), o.w = (int)tag0;
-    __builtin_amdgcn_raw_buffer_store_b128(o, (tag0 & 1u) ? r1 : r0, my_off, 0, kAuxSc1);
+  if (dual) {  // one-time XCC exchange: which neighbours run on my XCD?  (bit 30 of nbr[k] := same XCD)
+    const unsigned my_xcc = read_xcc_id();
+    const unsigned want = (tag0 & 0x0fffffffu) << 4;
+    if (is_owner) __builtin_amdgcn_raw_buffer_store_b32((int)(want | my_xcc), rx, 4 * S + (pv << 2), 0, kAuxSc1);
+    unsigned pending = all_mask;
+    unsigned spins = 0;
+    unsigned got[kTvS];
+    for (;;) {
+#pragma unroll
+      for (int k = 0; k < kTvS; ++k) {
+        if ((pending >> k) & 1u) {
+          int o = 4 * S + ((nbr[k] & 0x7fffffff) >> 2);
+          asm volatile("" : "+v"(o)::"memory");
+          got[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, kAuxSc1);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kTvS; ++k) {
+        if (((pending >> k) & 1u) && (got[k] & ~15u) == want) {
+          pending &= ~(1u << k);
+          if ((got[k] & 15u) == my_xcc) nbr[k] += S;  // poll the local copy (S < 2^31: role bit untouched)
+        }
+      }
+      if (!__any(pending != 0u)) break;
+      if (++spins > max_spins) {
+        timed_out = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
   }
 
-  for (int it = 0; it < n_iters; ++it) {
+  if (is_owner && !timed_out) {
+    v4i_t o;
+    o.x = __float_as_int(xb), o.y = __float_as_int(w1b), o.z = __float_as_int(w2b), o.w = (int)tag0;
+    const int so = (tag0 & 1u) ? par : 0;
+    __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
+    if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
+  }
+
+  for (int it = 0; it < n_iters && !timed_out; ++it) {
     const unsigned s = tag0 + (unsigned)it;
-    const __amdgpu_buffer_rsrc_t rin = (s & 1u) ? r1 : r0;
+    const int so_in = (s & 1u) ? par : 0;
     // ---- wait for all neighbours' bar(s): one round of loads in flight, only pending slots re-polled
     v4i_t g[kTvS];
     unsigned pending = all_mask;
@@ -521,7 +603,7 @@ k_persistent_tv(const int n_waves, const int waves_per_xcd, const int32_t* __res
         if ((pending >> k) & 1u) {
           int o = nbr[k] & 0x7fffffff;
           asm volatile("" : "+v"(o)::"memory");  // opaque: re-issue on every spin
-          g[k] = __builtin_amdgcn_raw_buffer_load_b128(rin, o, 0, kAuxSc1);
+          g[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, o, so_in, kAuxSc1);
         }
       }
 #pragma unroll
@@ -595,7 +677,9 @@ k_persistent_tv(const int n_waves, const int waves_per_xcd, const int32_t* __res
     if (is_owner) {
       v4i_t o;
       o.x = __float_as_int(nb), o.y = __float_as_int(w1bn), o.z = __float_as_int(w2bn), o.w = (int)(s + 1u);
-      __builtin_amdgcn_raw_buffer_store_b128(o, ((s + 1u) & 1u) ? r1 : r0, my_off, 0, kAuxSc1);
+      const int so = ((s + 1u) & 1u) ? par : 0;
+      __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
+      if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
     }
     x_prev = x, w1_prev = w1, w2_prev = w2;
     if (has_chain) {  // wave-uniform: hand the owner's new state back to every lane of its chain
@@ -922,8 +1006,8 @@ int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, boo
 // lane (k_persistent_tv).  Returns the hipError_t unchanged (e.g. hipErrorCooperativeLaunchTooLarge)
 // so the caller can fall back to per-step launches.
 int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, int parity_in, unsigned tag0,
-                          int n_iters, int waves_per_block, unsigned max_spins, int presleep, bool cooperative,
-                          hipStream_t stream) {
+                          int n_iters, int waves_per_block, unsigned max_spins, int presleep, int dual,
+                          bool cooperative, hipStream_t stream) {
   int n_waves = (form == 2) ? a.tv_waves : a.he_waves;
   if (n_waves <= 0 || n_iters <= 0) return (int)hipSuccess;
   int wpx = (n_waves + 7) / 8;
@@ -940,13 +1024,14 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
   const float4* bin = a.bar[parity_in];
   float4* bout = a.bar[parity_in ^ (n_iters & 1)];
   float4* vprev = a.vprev;
-  void* g0 = a.gran[0];
-  void* g1 = a.gran[1];
+  void* xbuf = a.xbuf;
+  int rec_bytes = a.n_slices * 64 * 16;
   SolverParams pp = p;
   int* err = a.err;
   int* abort_flag = a.abort_flag;
   void* args[] = {&n_waves, &wpx, &i0, &i1, &i2, &i3, &hrec, &hq, &vstate, &vaux, &bin,
-                  &bout, &vprev, &g0, &g1, &tag0, &n_iters, &max_spins, &presleep, &pp, &err, &abort_flag};
+                  &bout, &vprev, &xbuf, &rec_bytes, &dual, &tag0, &n_iters, &max_spins, &presleep, &pp, &err,
+                  &abort_flag};
   const void* fn = (form == 2) ? (const void*)k_persistent_tv : (const void*)k_persistent_he;
   // The first launch of a topology is cooperative: the runtime verifies that the whole grid is
   // resident (hipErrorCooperativeLaunchTooLarge otherwise).  The same grid is then launched plainly

@@ -139,10 +139,14 @@ enum {
   FLAME_NLTGV2_OPT_USE_HIPGRAPH = 2, /* 1 (default) = capture the n_iters launches in a hipGraph */
   FLAME_NLTGV2_OPT_BLOCK_WAVES = 3,  /* waves per workgroup of the fused sweep: 0 = auto, 1,2,4 */
   FLAME_NLTGV2_OPT_UNROLL = 4,       /* half-edge slots per load chunk of the fused sweep: 0 = auto, 4,8,16 */
-  FLAME_NLTGV2_OPT_PERSISTENT = 5    /* 1 (default) = run() uses ONE persistent launch for all n_iters steps
+  FLAME_NLTGV2_OPT_PERSISTENT = 5,   /* 1 (default) = run() uses ONE persistent launch for all n_iters steps
                                         when the graph fits on the chip, picking the form by occupancy;
                                         2 = force the lane-per-half-edge form, 3 = force the vertex-per-lane
                                         form (each only if it fits); 0 = always one launch per step */
+  FLAME_NLTGV2_OPT_DUAL_PUBLISH = 6  /* persistent run: neighbours on the same XCD exchange through that XCD's
+                                        L2 (plain store + local record copy), others through write-through
+                                        records: 2 = always, 1 (default) = when many waves share a CU,
+                                        0 = write-through records only */
 };
 int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value);
 
