@@ -27,8 +27,8 @@ constexpr int kGraphChunk = 256;      // steps per captured hipGraph (even: keep
 constexpr int kCostPartials = 256;
 constexpr int kMaxCachedGraphs = 6;
 constexpr int kTvWavesPerCu = 8;       // residency of k_persistent_tv (<= 256 VGPRs -> 2 waves per SIMD)
-constexpr int kDualMinWavesPerCu = 6;  // auto: exchange through the XCD's L2 when more waves than this share a CU
-constexpr int kHeWavesPerCuSweet = 8;  // above this many lane-per-half-edge waves per CU the vertex-per-lane form wins
+constexpr int kDualMinWavesPerCu = 5;  // auto: exchange through the XCD's L2 when more waves than this share a CU
+constexpr int kHeWavesPerCuSweet = 24; // lane-per-half-edge form whenever it is resident (measured faster up to 22 waves per CU)
 constexpr int kPreSleep = 12;  // initial x64-cycle sleep between publishing and the first neighbour poll (adapts)
 constexpr unsigned kMaxSpins = 1u << 20;  // bound of every neighbour wait in the persistent run (~1 s of polling bursts)
 
@@ -333,8 +333,9 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
     }
     const int nw = form == 2 ? ctx->L.tv_waves : ctx->L.he_waves;
     const int pw = nw <= 4 * ctx->prop.multiProcessorCount ? 1 : 4;  // waves per workgroup
-    // same-XCD exchange through L2 pays once the memory side is busy (measured: 1080p graph -18 %,
-    // 15-frame batch -19 % per step; a lone 640x480 frame at 3 waves per CU +6 %)
+    // same-XCD exchange through L2 pays once the memory side is busy (measured per step: 1080p graph
+    // -18 %, 7-frame batch -20 %, 15-frame batch -19 %, 1280x720 -5 %; a lone 640x480 frame at 3 waves
+    // per CU +6 %)
     const int dual = ctx->opt_dual == 2 || (ctx->opt_dual == 1 && nw > kDualMinWavesPerCu * ctx->prop.multiProcessorCount);
     // a fresh first tag per launch: records left by earlier runs (whose state may since have been
     // changed by per-step launches or host uploads) can never satisfy a wait of this launch
