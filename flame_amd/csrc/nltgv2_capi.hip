@@ -78,7 +78,8 @@ struct flame_nltgv2_ctx {
   DevBuf slice_row, perm, pdeg, rec_nbr, rec_edge, edge_src_slot, hrec, hq, vstate, vaux, bar0, bar1, vprev;
   DevBuf xbuf, abort_flag, he_slot, he_vid, he_meta, he_wave_chain, tv_slot, tv_vid, tv_meta, tv_wave;
   // misc
-  DevBuf err, cost_pe, cost_pv, cost_out;
+  DevBuf err, cost_pe, cost_pv, cost_out, img_ref, img_cmp, photo_err;
+  int img_rows = 0, img_cols = 0, img_step = 0;
   int* h_err = nullptr;    // pinned
   float* h_cost = nullptr; // pinned
   std::vector<CachedGraph> graphs;
@@ -442,7 +443,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
               &ctx->q2, &ctx->q3, &ctx->row_ptr, &ctx->half, &ctx->slice_row, &ctx->perm, &ctx->pdeg,
               &ctx->rec_nbr, &ctx->rec_edge, &ctx->edge_src_slot, &ctx->hrec, &ctx->hq, &ctx->vstate,
               &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->xbuf, &ctx->abort_flag, &ctx->he_slot, &ctx->he_vid, &ctx->he_meta, &ctx->he_wave_chain, &ctx->tv_slot, &ctx->tv_vid, &ctx->tv_meta, &ctx->tv_wave, &ctx->err, &ctx->cost_pe, &ctx->cost_pv,
-              &ctx->cost_out};
+              &ctx->cost_out, &ctx->img_ref, &ctx->img_cmp, &ctx->photo_err};
   *out = ctx;
   return FLAME_NLTGV2_OK;
 }
@@ -758,6 +759,45 @@ int flame_nltgv2_export_idepth_device(flame_nltgv2_ctx* ctx, void* dst_device, f
   if (!dst_device && ctx->L.V > 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
   const bool packed = !ctx->canon_valid;
   LAUNCHCHK(ctx, launch_export(ctx->c, ctx->f, packed, scale, (float*)dst_device, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_photo_set_images(flame_nltgv2_ctx* ctx, const uint8_t* ref, const uint8_t* cmp, int rows, int cols,
+                                  int step_bytes) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ref || !cmp || rows < 2 || cols < 2 || step_bytes < cols) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  const size_t bytes = (size_t)rows * (size_t)step_bytes;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  rc = ensure(ctx, ctx->img_ref, bytes + 16);
+  if (!rc) rc = ensure(ctx, ctx->img_cmp, bytes + 16);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->img_ref.p, ref, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->img_cmp.p, cmp, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->img_rows = rows, ctx->img_cols = cols, ctx->img_step = step_bytes;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_photo_residual(flame_nltgv2_ctx* ctx, const float* KRKinv, const float* Kt, float graph_scale,
+                                int border, float* err_out) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!KRKinv || !Kt || !err_out || border < 1 || ctx->img_rows == 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  rc = ensure_canon(ctx);
+  if (rc) return rc;
+  const size_t fV = sizeof(float) * (size_t)ctx->L.V;
+  rc = ensure(ctx, ctx->photo_err, fV);
+  if (rc) return rc;
+  PhotoGeometry geo;
+  std::memcpy(geo.KRKinv, KRKinv, sizeof(geo.KRKinv));
+  std::memcpy(geo.Kt, Kt, sizeof(geo.Kt));
+  LAUNCHCHK(ctx, launch_photo_residual(ctx->c, graph_scale, geo, (const uint8_t*)ctx->img_ref.p,
+                                       (const uint8_t*)ctx->img_cmp.p, ctx->img_rows, ctx->img_cols, ctx->img_step,
+                                       border, (float*)ctx->photo_err.p, ctx->stream));
+  if (fV) HIPCHK(ctx, hipMemcpyAsync(err_out, ctx->photo_err.p, fV, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return FLAME_NLTGV2_OK;
 }

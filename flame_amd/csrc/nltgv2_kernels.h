@@ -12,6 +12,12 @@ struct SolverParams {
   float data_factor, step_x, step_q, theta, x_min, x_max;
 };
 
+// K*R*Kinv (row-major) and K*t of EpipolarGeometry::loadGeometry (stereo/epipolar_geometry.h:88-93)
+struct PhotoGeometry {
+  float KRKinv[9];
+  float Kt[3];
+};
+
 // Canonical SoA state in the caller's vertex / edge order (device pointers).
 struct CanonArgs {
   int V = 0, E = 0;
@@ -73,6 +79,8 @@ int launch_pack_state(const CanonArgs& c, const FusedArgs& a, int parity, hipStr
 int launch_unpack_state(const CanonArgs& c, const FusedArgs& a, int parity, bool have_prev, hipStream_t s);
 int launch_export(const CanonArgs& c, const FusedArgs& a, bool packed_current, float scale, float* dst,
                   hipStream_t s);
+int launch_photo_residual(const CanonArgs& c, float graph_scale, const PhotoGeometry& geo, const uint8_t* ref,
+                          const uint8_t* cmp, int rows, int cols, int step, int border, float* err, hipStream_t s);
 int launch_costs(const CanonArgs& c, const SolverParams& p, double* partial_e, double* partial_v,
                  int n_partials, float* out2, hipStream_t s);
 

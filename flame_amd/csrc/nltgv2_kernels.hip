@@ -973,6 +973,61 @@ k_cost_final(int n_edge_partials, int n_vertex_partials, const double* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Per-vertex photometric residual (BASELINE config 5).  No live reference
+// code (only the commented-out block flame.cc:854-893); built from the live, test-pinned pieces
+// EpipolarGeometry::project (stereo/epipolar_geometry.h:127-143, 191-201) and
+// utils::bilinearInterp<uint8_t,float> (utils/image_utils.h:199-214, 230-255).  An epilogue sweep:
+// it reads x, never writes it.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bilinear_u8(const uint8_t* __restrict__ data, int step, float x, float y) {
+  const int xf = (int)x, yf = (int)y;
+  const float dx = x - xf, dy = y - yf;
+  const float w11 = dx * dy;
+  const float w01 = dx - w11;
+  const float w10 = dy - w11;
+  const float w00 = 1.0f - dx - dy + w11;
+  const uint8_t* p = data + (long)yf * step + xf;
+  return w00 * p[0] + w01 * p[1] + w10 * p[step] + w11 * p[1 + step];
+}
+
+__device__ __forceinline__ bool inside_region(float x, float y, int rows, int cols, int border) {
+  return x >= (float)border && y >= (float)border && x < (float)(cols - border) && y < (float)(rows - border);
+}
+
+__global__ void __launch_bounds__(256)
+k_photo_residual(int V, const float2* __restrict__ pos, const float* __restrict__ x, float graph_scale,
+                 PhotoGeometry geo, const uint8_t* __restrict__ ref, const uint8_t* __restrict__ cmp, int rows,
+                 int cols, int step, int border, float* __restrict__ err) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  float out = __builtin_nanf("");
+  const float idepth = x[v] * graph_scale;
+  const float2 u = pos[v];
+  if (!(idepth != idepth) && !(idepth < 0.0f) && inside_region(u.x, u.y, rows, cols, border)) {
+    float h0, h1, h2;
+    const float* K = geo.KRKinv;
+    if (idepth == 0.0f) {  // maxDepthProjection
+      h0 = (K[0] * u.x + K[1] * u.y) + K[2] * 1.0f;
+      h1 = (K[3] * u.x + K[4] * u.y) + K[5] * 1.0f;
+      h2 = (K[6] * u.x + K[7] * u.y) + K[8] * 1.0f;
+    } else {
+      const float depth = 1.0f / idepth;
+      const float a = u.x * depth, b = u.y * depth, c = depth;
+      h0 = ((K[0] * a + K[1] * b) + K[2] * c) + geo.Kt[0];
+      h1 = ((K[3] * a + K[4] * b) + K[5] * c) + geo.Kt[1];
+      h2 = ((K[6] * a + K[7] * b) + K[8] * c) + geo.Kt[2];
+    }
+    const float inv = 1.0f / h2;
+    const float cx = h0 * inv, cy = h1 * inv;
+    if (cx == cx && cy == cy && inside_region(cx, cy, rows, cols, border)) {
+      const float d = bilinear_u8(cmp, step, cx, cy) - bilinear_u8(ref, step, u.x, u.y);
+      out = (d > 0) ? d : -d;
+    }
+  }
+  err[v] = out;
+}
+
 inline dim3 grid1d(int64_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
 }  // namespace
@@ -1113,6 +1168,14 @@ int launch_export(const CanonArgs& c, const FusedArgs& a, bool packed_current, f
   } else {
     hipLaunchKernelGGL(k_export_canonical, grid1d(c.V), dim3(256), 0, s, c.V, c.x, scale, dst);
   }
+  return (int)hipGetLastError();
+}
+
+int launch_photo_residual(const CanonArgs& c, float graph_scale, const PhotoGeometry& geo, const uint8_t* ref,
+                          const uint8_t* cmp, int rows, int cols, int step, int border, float* err, hipStream_t s) {
+  if (c.V <= 0) return 0;
+  hipLaunchKernelGGL(k_photo_residual, grid1d(c.V), dim3(256), 0, s, c.V, c.pos, c.x, graph_scale, geo, ref, cmp,
+                     rows, cols, step, border, err);
   return (int)hipGetLastError();
 }
 

@@ -82,6 +82,7 @@ ABI_SYMBOLS = (
     "flame_nltgv2_costs", "flame_nltgv2_download_state", "flame_nltgv2_export_idepth_device",
     "flame_nltgv2_set_option", "flame_nltgv2_get_info", "flame_nltgv2_last_error", "flame_nltgv2_last_hip_error",
     "flame_nltgv2_status_string", "flame_nltgv2_abi_version", "flame_nltgv2_pack_probe",
+    "flame_nltgv2_photo_set_images", "flame_nltgv2_photo_residual",
 )
 
 
@@ -124,6 +125,8 @@ def load_library():
         "flame_nltgv2_status_string": (C.c_char_p, [C.c_int]),
         "flame_nltgv2_abi_version": (C.c_int, []),
         "flame_nltgv2_pack_probe": (C.c_int, [GP, _IP, _IP, _IP, _IP, C.c_int64, C.POINTER(C.c_int64)]),
+        "flame_nltgv2_photo_set_images": (C.c_int, [ctx, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int]),
+        "flame_nltgv2_photo_residual": (C.c_int, [ctx, _FP, _FP, C.c_float, C.c_int, _FP]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -293,6 +296,25 @@ class Regularizer:
     def cost(self, params: Params) -> float:
         s, d = self.costs(params)
         return float(np.float32(s) + np.float32(d))
+
+    # ---- config-5 epilogue ----------------------------------------------------------------------
+    def photo_set_images(self, ref, cmp):
+        ref = np.ascontiguousarray(ref, np.uint8)
+        cmp = np.ascontiguousarray(cmp, np.uint8)
+        if ref.shape != cmp.shape or ref.ndim != 2:
+            raise ValueError("two equally sized single-channel u8 images expected")
+        U8 = C.POINTER(C.c_uint8)
+        self._chk(self._L.flame_nltgv2_photo_set_images(self._ctx, ref.ctypes.data_as(U8), cmp.ctypes.data_as(U8),
+                                                         ref.shape[0], ref.shape[1], ref.strides[0]), "photo_set_images")
+
+    def photo_residual(self, KRKinv, Kt, graph_scale=1.0, border=3):
+        k = np.ascontiguousarray(KRKinv, np.float32).reshape(9)
+        t = np.ascontiguousarray(Kt, np.float32).reshape(3)
+        err = np.empty(self.V, np.float32)
+        self._chk(self._L.flame_nltgv2_photo_residual(self._ctx, k.ctypes.data_as(_FP), t.ctypes.data_as(_FP),
+                                                       C.c_float(graph_scale), int(border), err.ctypes.data_as(_FP)),
+                  "photo_residual")
+        return err
 
     # ---- plumbing -------------------------------------------------------------------------------
     def set_stream(self, hip_stream_ptr: int | None):

@@ -132,6 +132,17 @@ int flame_nltgv2_download_state(flame_nltgv2_ctx* ctx, flame_nltgv2_graph* out);
  * multi-GPU host can hand the buffer straight to an RCCL gather. */
 int flame_nltgv2_export_idepth_device(flame_nltgv2_ctx* ctx, void* dst_device, float scale);
 
+/* Per-vertex photometric residual (BASELINE config 5).  No live reference counterpart: the only
+ * occurrence is the commented-out block flame.cc:854-893; built from the live pieces
+ * EpipolarGeometry::project (stereo/epipolar_geometry.h:127-143) and utils::bilinearInterp<uint8_t,float>
+ * (utils/image_utils.h:230-255).  err[v] = |I_cmp(project(pos_v, x_v*graph_scale)) - I_ref(pos_v)|, NaN
+ * where either pixel is outside [border, size-border).  An epilogue: it never modifies x.
+ * KRKinv: 9 floats row-major, Kt: 3 floats (EpipolarGeometry::loadGeometry, h:88-93). */
+int flame_nltgv2_photo_set_images(flame_nltgv2_ctx* ctx, const uint8_t* ref, const uint8_t* cmp, int rows, int cols,
+                                  int step_bytes);
+int flame_nltgv2_photo_residual(flame_nltgv2_ctx* ctx, const float* KRKinv, const float* Kt, float graph_scale,
+                                int border, float* err_out);
+
 /* Options (flame_nltgv2_set_option). */
 enum {
   FLAME_NLTGV2_OPT_SOLVER = 1,       /* 0 = fused one-kernel-per-step sweep (default), 1 = 4-kernel

@@ -44,7 +44,9 @@ def lib():
     if _LIB is None:
         path = os.path.join(_HERE, "liboracle_nltgv2.so")
         src = os.path.join(_HERE, "nltgv2_oracle.c")
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        src2 = os.path.join(_HERE, "photometric_oracle.c")
+        if (not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src)
+                or os.path.getmtime(path) < os.path.getmtime(src2)):
             build()
         L = C.CDLL(path)
         PP, GP = C.POINTER(Params), C.POINTER(Graph)
@@ -71,6 +73,13 @@ def lib():
         L.nltgv2_reflayout_run_timed.restype = C.c_double
         L.nltgv2_reflayout_export.argtypes = [C.c_void_p, GP]
         L.nltgv2_reflayout_export.restype = None
+        U8 = C.POINTER(C.c_uint8)
+        L.photo_project.argtypes = [_FP, _FP, C.c_float, C.c_float, C.c_float, _FP, _FP]
+        L.photo_project.restype = None
+        L.photo_bilinear_u8.argtypes = [U8, C.c_int, C.c_float, C.c_float]
+        L.photo_bilinear_u8.restype = C.c_float
+        L.photo_residual.argtypes = [C.c_int, _FP, _FP, C.c_float, _FP, _FP, U8, U8, C.c_int, C.c_int, C.c_int, C.c_int, _FP]
+        L.photo_residual.restype = None
         _LIB = L
     return _LIB
 
@@ -139,3 +148,33 @@ def reflayout_run_timed(g: dict, n_iters: int, params=None, export: bool = False
     finally:
         L.nltgv2_reflayout_destroy(h)
     return secs
+
+
+# ---- photometric residual (config 5), oracle/photometric_oracle.c -------------------------------------
+def photo_project(KRKinv, Kt, ux, uy, idepth):
+    k = np.ascontiguousarray(KRKinv, np.float32).reshape(9)
+    t = np.ascontiguousarray(Kt, np.float32).reshape(3)
+    cx, cy = C.c_float(0), C.c_float(0)
+    lib().photo_project(k.ctypes.data_as(_FP), t.ctypes.data_as(_FP), ux, uy, idepth, C.byref(cx), C.byref(cy))
+    return float(cx.value), float(cy.value)
+
+
+def photo_bilinear_u8(img, x, y):
+    a = np.ascontiguousarray(img, np.uint8)
+    return float(lib().photo_bilinear_u8(a.ctypes.data_as(C.POINTER(C.c_uint8)), a.strides[0], x, y))
+
+
+def photo_residual(pos, x, graph_scale, KRKinv, Kt, ref, cmp, border):
+    pos = np.ascontiguousarray(pos, np.float32)
+    x = np.ascontiguousarray(x, np.float32)
+    k = np.ascontiguousarray(KRKinv, np.float32).reshape(9)
+    t = np.ascontiguousarray(Kt, np.float32).reshape(3)
+    ref = np.ascontiguousarray(ref, np.uint8)
+    cmp = np.ascontiguousarray(cmp, np.uint8)
+    assert ref.shape == cmp.shape and ref.strides == cmp.strides
+    err = np.empty(x.shape[0], np.float32)
+    U8 = C.POINTER(C.c_uint8)
+    lib().photo_residual(x.shape[0], pos.ctypes.data_as(_FP), x.ctypes.data_as(_FP), graph_scale, k.ctypes.data_as(_FP),
+                         t.ctypes.data_as(_FP), ref.ctypes.data_as(U8), cmp.ctypes.data_as(U8), ref.shape[0],
+                         ref.shape[1], ref.strides[0], border, err.ctypes.data_as(_FP))
+    return err
