@@ -291,6 +291,28 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
     up_ms, down_ms = (t1 - t0) * 100, ((t2 - t1) - (t3 - t2)) * 100
     r.run(params, a.iters)
     ms = min(r.run_timed(params, a.iters) for _ in range(5))
+    # per-frame warm-start synchronisation (syncGraph's graph edits): ~8 % vertex churn, new triangulation
+    import numpy as _np
+
+    rng = _np.random.default_rng(3)
+    keep = rng.random(g["V"]) > 0.08
+    fid = _np.nonzero(keep)[0].astype(_np.int32)
+    pos2 = (g["pos"][keep] + rng.normal(0, 0.3, (len(fid), 2))).astype(_np.float32)
+    n_new = g["V"] - len(fid)
+    w_, h_, _c = synth.CONFIGS[a.config]
+    pos2 = _np.concatenate([pos2, _np.stack([rng.random(n_new) * (w_ - 8) + 4, rng.random(n_new) * (h_ - 8) + 4], 1)
+                            .astype(_np.float32)])
+    fid = _np.concatenate([fid, _np.arange(g["V"], g["V"] + n_new, dtype=_np.int32)])
+    data2 = _np.concatenate([g["data_term"][keep], _np.ones(n_new, _np.float32)])
+    edges2 = synth.delaunay_edges_scipy(pos2)
+    r.upload_graph(g)
+    r.run(params, 50)
+    t4 = _t.perf_counter()
+    r.sync_graph(fid, pos2, data2, _np.ones(len(fid), _np.float32), edges2)
+    t5 = _t.perf_counter()
+    r.run(params, 50)
+    out["frame_sync"] = {"sync_graph_ms": round((t5 - t4) * 1e3, 3), "churn": "8 % of vertices replaced, re-triangulated",
+                         "V": int(len(fid)), "E": int(r.info()["E"])}
     out["host_boundary"] = {"upload_graph_ms": round(up_ms, 3), "download_state_ms": round(down_ms, 3),
                             "pcie_inclusive_iters_per_s": round(a.iters / ((ms + up_ms + down_ms) * 1e-3), 1),
                             "note": "upload+200 iters+download per frame; never reported as value"}

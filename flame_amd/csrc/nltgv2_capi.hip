@@ -12,7 +12,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <cmath>
 #include <new>
+#include <unordered_map>
 #include <vector>
 
 #include "flame_nltgv2.h"
@@ -69,6 +72,7 @@ struct flame_nltgv2_ctx {
   uint64_t coop_checked_key = 0;  // (topology, form) whose persistent grid the runtime has verified as resident
 
   PackedLayout L;
+  std::vector<int32_t> h_src, h_dst, h_feat;  // host image of the current topology (for sync_graph)
   CanonArgs c;
   FusedArgs f;
   std::vector<DevBuf*> all;
@@ -589,12 +593,160 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
   ctx->state_lost = false;
   LAUNCHCHK(ctx, launch_pack_static(ctx->c, ctx->f, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors / caller arrays may go away
+  ctx->h_src.assign(g->src, g->src + E);
+  ctx->h_dst.assign(g->dst, g->dst + E);
+  ctx->h_feat.resize((size_t)V);
+  for (int32_t v = 0; v < V; ++v) ctx->h_feat[(size_t)v] = v;  // default feature id = vertex index
   ctx->canon_valid = true;
   ctx->fused_valid = false;
   ctx->have_prev = false;
   ctx->parity = 0;
   ctx->have_graph = true;
   ctx->last_error = 0;
+  return FLAME_NLTGV2_OK;
+}
+
+// ---- per-frame graph synchronisation: the graph-edit part of Flame::syncGraph / projectGraph --------
+// (flame.cc:1985-2121 and 1862-1938), on explicit orders instead of BGL's hash-set iteration order:
+//   * a vertex whose feature id was in the previous graph keeps x,w1,w2,x_bar,w_bar,x_prev,w_prev
+//     (warm start); pos / data_term / data_weight are replaced (flame.cc:1996-2001); with
+//     check_sticky_obstacles, x is reset to data_term where x - data_term > threshold (flame.cc:2011-2014);
+//     vertices absent from the new list disappear together with their edges (flame.cc:2020-2028,
+//     1923-1931);
+//   * a new vertex starts at x = x_bar = x_prev = init_x (or data_term), w = 0 (flame.cc:2035-2048,
+//     2160-2162);
+//   * an edge of the new triangulation that already connected the same two features keeps its dual
+//     (q1,q2,q3) AND its old (source,target) orientation -- boost::edge(u,v) finds it either way
+//     (flame.cc:2094-2100); other old edges are dropped (flame.cc:2108-2119); new edges get q = 0 and the
+//     orientation (edges[2k], edges[2k+1]) = add_edge(v[e0], v[e1]) (flame.cc:2085-2096);
+//   * every edge gets alpha = 1/||pos_a - pos_b|| from the NEW positions and beta = 1 (flame.cc:2087-2103);
+//   * resulting edge order = surviving edges in their previous relative order, then the new edges in
+//     triangulator order (boost::edges() walks a std::list: erase keeps order, add_edge appends).
+int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!in || in->V < 0 || in->E < 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  const int32_t V = in->V, E = in->E;
+  if (V > 0 && (!in->feat_id || !in->pos || !in->data_term || !in->data_weight)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  if (E > 0 && !in->edges) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+
+  // previous state -> host
+  const int32_t Vo = ctx->L.V, Eo = ctx->L.E;
+  std::vector<float> ox(Vo), ow1(Vo), ow2(Vo), oxb(Vo), ow1b(Vo), ow2b(Vo), oxp(Vo), ow1p(Vo), ow2p(Vo), oq1(Eo), oq2(Eo), oq3(Eo);
+  flame_nltgv2_graph old{};
+  old.x = ox.data(), old.w1 = ow1.data(), old.w2 = ow2.data();
+  old.x_bar = oxb.data(), old.w1_bar = ow1b.data(), old.w2_bar = ow2b.data();
+  old.x_prev = oxp.data(), old.w1_prev = ow1p.data(), old.w2_prev = ow2p.data();
+  old.q1 = oq1.data(), old.q2 = oq2.data(), old.q3 = oq3.data();
+  rc = flame_nltgv2_download_state(ctx, &old);
+  if (rc) return rc;
+
+  std::unordered_map<int32_t, int32_t> old_of_feat;
+  old_of_feat.reserve((size_t)Vo * 2);
+  for (int32_t v = 0; v < Vo; ++v) old_of_feat[ctx->h_feat[(size_t)v]] = v;
+  std::unordered_map<uint64_t, int32_t> old_edge;  // (min feat, max feat) -> old edge index
+  old_edge.reserve((size_t)Eo * 2);
+  auto key = [](int32_t a, int32_t b) {
+    const uint32_t lo = (uint32_t)std::min(a, b), hi = (uint32_t)std::max(a, b);
+    return ((uint64_t)hi << 32) | lo;
+  };
+  for (int32_t e = 0; e < Eo; ++e)
+    old_edge[key(ctx->h_feat[(size_t)ctx->h_src[(size_t)e]], ctx->h_feat[(size_t)ctx->h_dst[(size_t)e]])] = e;
+
+  // vertices
+  std::vector<float> x(V), w1(V, 0.f), w2(V, 0.f), xb(V), w1b(V, 0.f), w2b(V, 0.f), xp(V), w1p(V, 0.f), w2p(V, 0.f);
+  std::unordered_map<int32_t, int32_t> seen;
+  seen.reserve((size_t)V * 2);
+  for (int32_t v = 0; v < V; ++v) {
+    if (!seen.emplace(in->feat_id[v], v).second) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // duplicate id
+    auto it = old_of_feat.find(in->feat_id[v]);
+    if (it != old_of_feat.end()) {
+      const int32_t o = it->second;
+      x[v] = ox[o], w1[v] = ow1[o], w2[v] = ow2[o];
+      xb[v] = oxb[o], w1b[v] = ow1b[o], w2b[v] = ow2b[o];
+      xp[v] = oxp[o], w1p[v] = ow1p[o], w2p[v] = ow2p[o];
+      if (in->check_sticky_obstacles && (x[v] - in->data_term[v] > in->sticky_threshold)) x[v] = in->data_term[v];
+    } else {
+      const float xi = in->init_x ? in->init_x[v] : in->data_term[v];
+      x[v] = xb[v] = xp[v] = xi;
+    }
+  }
+  // edges
+  struct Keep { int32_t old_idx, a, b; };
+  std::vector<Keep> keep;
+  std::vector<std::pair<int32_t, int32_t>> fresh;
+  keep.reserve((size_t)E), fresh.reserve((size_t)E);
+  std::unordered_map<uint64_t, char> dup;
+  dup.reserve((size_t)E * 2);
+  for (int32_t k = 0; k < E; ++k) {
+    const int32_t a = in->edges[2 * k], b = in->edges[2 * k + 1];
+    if (a < 0 || a >= V || b < 0 || b >= V || a == b) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+    const uint64_t kk = key(in->feat_id[a], in->feat_id[b]);
+    if (!dup.emplace(kk, 1).second) continue;  // boost::edge() finds the one just added: no parallel edges
+    auto it = old_edge.find(kk);
+    if (it != old_edge.end()) {
+      const int32_t e = it->second;
+      const bool same = ctx->h_feat[(size_t)ctx->h_src[(size_t)e]] == in->feat_id[a];
+      keep.push_back(Keep{e, same ? a : b, same ? b : a});
+    } else {
+      fresh.emplace_back(a, b);
+    }
+  }
+  std::sort(keep.begin(), keep.end(), [](const Keep& p, const Keep& q) { return p.old_idx < q.old_idx; });
+  const int32_t En = (int32_t)(keep.size() + fresh.size());
+  std::vector<int32_t> src(En), dst(En);
+  std::vector<float> alpha(En), beta(En, 1.0f), q1(En, 0.f), q2(En, 0.f), q3(En, 0.f);
+  int32_t e = 0;
+  for (const Keep& kp : keep) {
+    src[e] = kp.a, dst[e] = kp.b;
+    q1[e] = oq1[kp.old_idx], q2[e] = oq2[kp.old_idx], q3[e] = oq3[kp.old_idx];
+    ++e;
+  }
+  for (const auto& f : fresh) {
+    src[e] = f.first, dst[e] = f.second;
+    ++e;
+  }
+  for (int32_t k = 0; k < En; ++k) {  // flame.cc:2087-2103 (diff = u_ii - u_jj of the triangulator edge;
+    const float dx = in->pos[2 * src[k]] - in->pos[2 * dst[k]];  //  the squares make the sign irrelevant)
+    const float dy = in->pos[2 * src[k] + 1] - in->pos[2 * dst[k] + 1];
+    alpha[k] = 1.0f / std::sqrt(dx * dx + dy * dy);
+  }
+
+  flame_nltgv2_graph g{};
+  g.V = V, g.E = En;
+  g.pos = const_cast<float*>(in->pos);
+  g.x = x.data(), g.w1 = w1.data(), g.w2 = w2.data();
+  g.x_bar = xb.data(), g.w1_bar = w1b.data(), g.w2_bar = w2b.data();
+  g.x_prev = xp.data(), g.w1_prev = w1p.data(), g.w2_prev = w2p.data();
+  g.data_term = const_cast<float*>(in->data_term), g.data_weight = const_cast<float*>(in->data_weight);
+  g.src = src.data(), g.dst = dst.data();
+  g.alpha = alpha.data(), g.beta = beta.data();
+  g.q1 = q1.data(), g.q2 = q2.data(), g.q3 = q3.data();
+  rc = flame_nltgv2_upload_graph(ctx, &g);
+  if (rc) return rc;
+  ctx->h_feat.assign(in->feat_id, in->feat_id + V);
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_set_feature_ids(flame_nltgv2_ctx* ctx, const int32_t* feat_id) {
+  if (!ctx) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!feat_id && ctx->L.V > 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  std::unordered_map<int32_t, int32_t> seen;
+  seen.reserve((size_t)ctx->L.V * 2);
+  for (int32_t v = 0; v < ctx->L.V; ++v)
+    if (!seen.emplace(feat_id[v], v).second) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  ctx->h_feat.assign(feat_id, feat_id + ctx->L.V);
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_get_topology(flame_nltgv2_ctx* ctx, int32_t* src, int32_t* dst, int32_t* feat_id) {
+  if (!ctx) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (src) std::copy(ctx->h_src.begin(), ctx->h_src.end(), src);
+  if (dst) std::copy(ctx->h_dst.begin(), ctx->h_dst.end(), dst);
+  if (feat_id) std::copy(ctx->h_feat.begin(), ctx->h_feat.end(), feat_id);
   return FLAME_NLTGV2_OK;
 }
 

@@ -59,6 +59,12 @@ class _Graph(C.Structure):
     )
 
 
+class _SyncInput(C.Structure):
+    _fields_ = [("V", C.c_int32), ("feat_id", _IP), ("pos", _FP), ("data_term", _FP), ("data_weight", _FP),
+                ("init_x", _FP), ("E", C.c_int32), ("edges", _IP), ("check_sticky_obstacles", C.c_int32),
+                ("sticky_threshold", C.c_float)]
+
+
 class _Info(C.Structure):
     _fields_ = [
         ("abi_version", C.c_int32), ("device", C.c_int32), ("V", C.c_int32), ("E", C.c_int32),
@@ -82,7 +88,8 @@ ABI_SYMBOLS = (
     "flame_nltgv2_costs", "flame_nltgv2_download_state", "flame_nltgv2_export_idepth_device",
     "flame_nltgv2_set_option", "flame_nltgv2_get_info", "flame_nltgv2_last_error", "flame_nltgv2_last_hip_error",
     "flame_nltgv2_status_string", "flame_nltgv2_abi_version", "flame_nltgv2_pack_probe",
-    "flame_nltgv2_photo_set_images", "flame_nltgv2_photo_residual",
+    "flame_nltgv2_photo_set_images", "flame_nltgv2_photo_residual", "flame_nltgv2_sync_graph",
+    "flame_nltgv2_get_topology", "flame_nltgv2_set_feature_ids",
 )
 
 
@@ -127,6 +134,9 @@ def load_library():
         "flame_nltgv2_pack_probe": (C.c_int, [GP, _IP, _IP, _IP, _IP, C.c_int64, C.POINTER(C.c_int64)]),
         "flame_nltgv2_photo_set_images": (C.c_int, [ctx, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int]),
         "flame_nltgv2_photo_residual": (C.c_int, [ctx, _FP, _FP, C.c_float, C.c_int, _FP]),
+        "flame_nltgv2_sync_graph": (C.c_int, [ctx, C.POINTER(_SyncInput)]),
+        "flame_nltgv2_get_topology": (C.c_int, [ctx, _IP, _IP, _IP]),
+        "flame_nltgv2_set_feature_ids": (C.c_int, [ctx, _IP]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -225,6 +235,42 @@ class Regularizer:
         cg = _graph_view(g, keep)
         self._chk(self._L.flame_nltgv2_upload_graph(self._ctx, C.byref(cg)), "upload_graph")
         self.V, self.E = int(g["V"]), int(g["E"])
+
+    def sync_graph(self, feat_id, pos, data_term, data_weight, edges, init_x=None, check_sticky_obstacles=False,
+                   sticky_threshold=0.25):
+        """Per-frame warm-start synchronisation (Flame::syncGraph's graph edits, flame.cc:1985-2121)."""
+        V = int(len(feat_id))
+        fid = _as(feat_id, np.int32, V, "feat_id")
+        p = _as(pos, np.float32, 2 * V, "pos")
+        d = _as(data_term, np.float32, V, "data_term")
+        w = _as(data_weight, np.float32, V, "data_weight")
+        ed = np.ascontiguousarray(edges, np.int32).reshape(-1, 2)
+        si = _SyncInput()
+        si.V, si.E = V, int(ed.shape[0])
+        si.feat_id, si.pos = fid.ctypes.data_as(_IP), p.ctypes.data_as(_FP)
+        si.data_term, si.data_weight = d.ctypes.data_as(_FP), w.ctypes.data_as(_FP)
+        ix = None
+        if init_x is not None:
+            ix = _as(init_x, np.float32, V, "init_x")
+            si.init_x = ix.ctypes.data_as(_FP)
+        si.edges = ed.ctypes.data_as(_IP)
+        si.check_sticky_obstacles = 1 if check_sticky_obstacles else 0
+        si.sticky_threshold = sticky_threshold
+        self._chk(self._L.flame_nltgv2_sync_graph(self._ctx, C.byref(si)), "sync_graph")
+        info = self.info()
+        self.V, self.E = info["V"], info["E"]
+
+    def set_feature_ids(self, feat_id):
+        fid = _as(feat_id, np.int32, self.V, "feat_id")
+        self._chk(self._L.flame_nltgv2_set_feature_ids(self._ctx, fid.ctypes.data_as(_IP)), "set_feature_ids")
+
+    def topology(self):
+        src = np.empty(self.E, np.int32)
+        dst = np.empty(self.E, np.int32)
+        fid = np.empty(self.V, np.int32)
+        self._chk(self._L.flame_nltgv2_get_topology(self._ctx, src.ctypes.data_as(_IP), dst.ctypes.data_as(_IP),
+                                                     fid.ctypes.data_as(_IP)), "get_topology")
+        return src, dst, fid
 
     def update_data(self, data_term, data_weight):
         d = _as(data_term, np.float32, self.V, "data_term")

@@ -175,6 +175,23 @@ class DeviceGraph {
     flame_hip::GraphAccess<Graph>::unpack(flat_, graph);
   }
 
+  // Per-frame warm-start synchronisation: Flame::syncGraph's graph edits (flame.cc:1985-2121) applied to the
+  // device image; see flame_nltgv2_sync_graph.  `edges` = triangulator->edges() as index pairs.
+  void sync(const std::vector<int32_t>& feat_id, const std::vector<float>& pos_xy, const std::vector<float>& data_term,
+            const std::vector<float>& data_weight, const std::vector<int32_t>& edges, bool check_sticky_obstacles = false,
+            const float* init_x = nullptr) {
+    flame_nltgv2_sync_input in;
+    in.V = static_cast<int32_t>(feat_id.size());
+    in.feat_id = feat_id.data(), in.pos = pos_xy.data();
+    in.data_term = data_term.data(), in.data_weight = data_weight.data();
+    in.init_x = init_x;
+    in.E = static_cast<int32_t>(edges.size() / 2);
+    in.edges = edges.data();
+    in.check_sticky_obstacles = check_sticky_obstacles ? 1 : 0;
+    in.sticky_threshold = 0.25f;  // flame.cc:2011
+    check(flame_nltgv2_sync_graph(ctx_, &in), "sync_graph");
+  }
+
   void step(const Params& p) { run(p, 1); }
   void run(const Params& p, int n_iters) {
     const flame_nltgv2_params c = to_c(p);

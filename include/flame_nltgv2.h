@@ -90,6 +90,34 @@ int flame_nltgv2_set_stream(flame_nltgv2_ctx* ctx, void* hip_stream);
  * device layout is rebuilt.  Buffers are reused and grown geometrically across calls. */
 int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g);
 
+/* Per-frame graph synchronisation with WARM START: the graph-edit part of Flame::syncGraph
+ * (flame.cc:1985-2121) and the vertex removal of Flame::projectGraph (flame.cc:1923-1931).  The caller
+ * passes the vertex set of the new frame (stable feature ids, positions, data terms) and the edges of its
+ * new triangulation; vertices/edges that survive keep their primal/dual state (an edge also keeps its old
+ * orientation, as boost::edge(u,v) finds it either way, flame.cc:2094-2100), new ones start as the
+ * reference initialises them.  Order of the resulting edge list: surviving edges in their previous
+ * relative order, then new edges in triangulator order -- what boost::edges() yields after the
+ * reference's erase/add_edge sequence.  (The reference's VERTEX order is BGL hash order and therefore
+ * unspecified; here it is the caller's.)  Feature ids default to the vertex index after upload_graph. */
+typedef struct flame_nltgv2_sync_input {
+  int32_t V;
+  const int32_t* feat_id;   /* [V] unique, stable across frames (Flame::feat_to_vtx_, flame.h:542-543) */
+  const float* pos;         /* [2V] positions in the new frame (after projectGraph re-projection) */
+  const float* data_term;   /* [V] feat.idepth_mu / graph_scale */
+  const float* data_weight; /* [V] */
+  const float* init_x;      /* [V] x of NEW vertices (flame.cc:2160-2162); NULL = data_term */
+  int32_t E;
+  const int32_t* edges;     /* [2E] triangulator->edges(): pairs of indices into the new vertex list */
+  int32_t check_sticky_obstacles; /* params.check_sticky_obstacles, flame.cc:2011 */
+  float sticky_threshold;         /* 0.25f in the reference */
+} flame_nltgv2_sync_input;
+int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in);
+/* Declares the feature ids of the vertices of a graph brought in with flame_nltgv2_upload_graph (V ints,
+ * unique): Flame::vtx_to_feat_ (flame.h:542-543). */
+int flame_nltgv2_set_feature_ids(flame_nltgv2_ctx* ctx, const int32_t* feat_id);
+/* Current edge list / feature ids (E, E, V ints; any pointer may be NULL). */
+int flame_nltgv2_get_topology(flame_nltgv2_ctx* ctx, int32_t* src, int32_t* dst, int32_t* feat_id);
+
 /* Per-frame refresh of data_term/data_weight for an unchanged topology (flame.cc:1985-2018). */
 int flame_nltgv2_update_data(flame_nltgv2_ctx* ctx, const float* data_term, const float* data_weight);
 

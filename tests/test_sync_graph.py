@@ -1,0 +1,90 @@
+"""Per-frame warm-start graph synchronisation: flame_nltgv2_sync_graph against the
+restatement of Flame::syncGraph's graph edits (oracle/sync_oracle.py) over a sequence of frames with
+vertex churn, re-projection, re-triangulation and the sticky-obstacle reset -- every state array and the
+resulting edge list must match exactly, frame after frame."""
+import numpy as np
+import pytest
+
+from flame_amd import synth
+from oracle import capi as oracle
+from oracle import sync_oracle
+from tests.helpers import OUT_KEYS, assert_state_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def next_frame(rng, feat_id, pos, data, next_id, width, height):
+    """Drops ~8 % of the features, jitters the survivors (projectGraph), adds ~8 % new ones."""
+    keep = rng.random(len(feat_id)) > 0.08
+    feat_id, pos, data = feat_id[keep], pos[keep].copy(), data[keep].copy()
+    pos += rng.normal(0, 0.4, pos.shape).astype(np.float32)
+    data = (data * np.float32(1.0) + rng.normal(0, 0.01, data.shape)).astype(np.float32)
+    n_new = int(0.08 * len(keep))
+    new_pos = np.stack([rng.random(n_new) * (width - 8) + 4, rng.random(n_new) * (height - 8) + 4], 1).astype(np.float32)
+    new_data = (0.5 + rng.random(n_new)).astype(np.float32)
+    new_id = np.arange(next_id, next_id + n_new)
+    order = rng.permutation(len(feat_id) + n_new)  # the caller's vertex order changes freely
+    feat_id = np.concatenate([feat_id, new_id])[order]
+    pos = np.concatenate([pos, new_pos])[order]
+    data = np.concatenate([data, new_data])[order]
+    return feat_id.astype(np.int32), np.ascontiguousarray(pos), np.ascontiguousarray(data), next_id + n_new
+
+
+def test_frame_sequence_matches_syncgraph_restatement(built):
+    import torch  # noqa: F401
+
+    import flame_amd
+
+    rng = np.random.default_rng(7)
+    g0 = synth.make_graph("320x240", seed=12)
+    feat_id = np.arange(g0["V"], dtype=np.int32) * 3 + 5  # arbitrary stable ids
+    pos, data = g0["pos"].copy(), g0["data_term"].copy()
+    next_id = int(feat_id.max()) + 1
+    params = flame_amd.Params()
+
+    ref = sync_oracle.RefGraph.from_flat(g0, feat_id)
+    with flame_amd.Regularizer(0) as reg:
+        reg.upload_graph(g0)
+        reg.set_feature_ids(feat_id)
+        for frame in range(5):
+            # solve a little on both sides
+            flat = sync_oracle.flatten(ref, feat_id)
+            src, dst, fid = reg.topology()
+            assert np.array_equal(fid, feat_id)
+            assert np.array_equal(src, flat["src"]) and np.array_equal(dst, flat["dst"]), f"frame {frame}: edge list"
+            n = 25 + 3 * frame
+            reg.run(params, n)
+            assert oracle.run(flat, n) == 0
+            out = reg.download_state()
+            assert_state_equal(out, flat, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"frame {frame}")
+            sync_oracle.absorb(ref, flat, feat_id)
+            # next frame: churn, re-projection, new triangulation
+            feat_id, pos, data, next_id = next_frame(rng, feat_id, pos, data, next_id, 320, 240)
+            weight = (0.5 + rng.random(len(feat_id))).astype(np.float32)
+            edges = synth.delaunay_edges_scipy(pos)
+            if frame % 2:
+                edges = edges[:, ::-1].copy()  # the triangulator's orientation is arbitrary; survivors keep theirs
+            init_x = (data * np.float32(1.02)).astype(np.float32)
+            sticky = frame >= 2
+            reg.sync_graph(feat_id, pos, data, weight, edges, init_x=init_x, check_sticky_obstacles=sticky,
+                           sticky_threshold=0.02)
+            sync_oracle.sync(ref, feat_id, pos, data, weight, edges, init_x=init_x, check_sticky=sticky, thr=0.02)
+        flat = sync_oracle.flatten(ref, feat_id)
+        assert_state_equal(reg.download_state(), flat, keys=OUT_KEYS + ("x_prev",), what="after last sync")
+
+
+def test_sync_rejects_bad_input(built):
+    import torch  # noqa: F401
+
+    import flame_amd
+
+    g = synth.make_graph("320x240", seed=1)
+    with flame_amd.Regularizer(0) as reg:
+        reg.upload_graph(g)
+        fid = np.arange(g["V"], dtype=np.int32)
+        fid[3] = fid[2]  # duplicate feature id
+        with pytest.raises(flame_amd.NLTGV2Error):
+            reg.sync_graph(fid, g["pos"], g["data_term"], g["data_weight"], np.stack([g["src"], g["dst"]], 1))
+        with pytest.raises(flame_amd.NLTGV2Error):
+            reg.sync_graph(np.arange(g["V"], dtype=np.int32), g["pos"], g["data_term"], g["data_weight"],
+                           np.array([[0, g["V"]]], np.int32))
