@@ -307,12 +307,31 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
     edges2 = synth.delaunay_edges_scipy(pos2)
     r.upload_graph(g)
     r.run(params, 50)
+    r.sync_graph(_np.arange(g["V"], dtype=_np.int32), g["pos"], g["data_term"], g["data_weight"],
+                 _np.stack([g["src"], g["dst"]], 1))  # warm-up of the sync path (allocations, hash tables)
+    r.run(params, 50)
     t4 = _t.perf_counter()
     r.sync_graph(fid, pos2, data2, _np.ones(len(fid), _np.float32), edges2)
     t5 = _t.perf_counter()
     r.run(params, 50)
     out["frame_sync"] = {"sync_graph_ms": round((t5 - t4) * 1e3, 3), "churn": "8 % of vertices replaced, re-triangulated",
                          "V": int(len(fid)), "E": int(r.info()["E"])}
+    # mesh -> dense idepthmap (utils::interpolateMesh, next row 8(f)-2), incl. the D2H copy of the map
+    tris = synth.delaunay_triangles_scipy(pos2)
+    r.interpolate_mesh(tris, h_, w_)
+    t6 = _t.perf_counter()
+    for _ in range(10):
+        img, cov = r.interpolate_mesh(tris, h_, w_)
+    t7 = _t.perf_counter()
+    out["rasterize"] = {"interpolate_mesh_ms": round((t7 - t6) * 100, 3), "triangles": int(len(tris)),
+                        "image": f"{w_}x{h_}", "coverage": round(cov / (w_ * h_), 4)}
+    if not a.no_cpu_baseline:
+        from oracle import capi as _oracle
+
+        xs = r.download_state(("x",))["x"]
+        t8 = _t.perf_counter()
+        _oracle.raster_interpolate_mesh(tris, pos2, xs, h_, w_)
+        out["rasterize"]["cpu_checker_ms"] = round((_t.perf_counter() - t8) * 1e3, 3)
     out["host_boundary"] = {"upload_graph_ms": round(up_ms, 3), "download_state_ms": round(down_ms, 3),
                             "pcie_inclusive_iters_per_s": round(a.iters / ((ms + up_ms + down_ms) * 1e-3), 1),
                             "note": "upload+200 iters+download per frame; never reported as value"}

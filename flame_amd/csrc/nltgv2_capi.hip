@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <new>
 #include <unordered_map>
@@ -82,7 +83,7 @@ struct flame_nltgv2_ctx {
   DevBuf slice_row, perm, pdeg, rec_nbr, rec_edge, edge_src_slot, hrec, hq, vstate, vaux, bar0, bar1, vprev;
   DevBuf xbuf, abort_flag, he_slot, he_vid, he_meta, he_wave_chain, tv_slot, tv_vid, tv_meta, tv_wave;
   // misc
-  DevBuf err, cost_pe, cost_pv, cost_out, img_ref, img_cmp, photo_err;
+  DevBuf err, cost_pe, cost_pv, cost_out, img_ref, img_cmp, photo_err, r_tris, r_valid, r_keys, r_img, r_cov, r_vtx, r_val;
   int img_rows = 0, img_cols = 0, img_step = 0;
   int* h_err = nullptr;    // pinned
   float* h_cost = nullptr; // pinned
@@ -447,7 +448,8 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
               &ctx->q2, &ctx->q3, &ctx->row_ptr, &ctx->half, &ctx->slice_row, &ctx->perm, &ctx->pdeg,
               &ctx->rec_nbr, &ctx->rec_edge, &ctx->edge_src_slot, &ctx->hrec, &ctx->hq, &ctx->vstate,
               &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->xbuf, &ctx->abort_flag, &ctx->he_slot, &ctx->he_vid, &ctx->he_meta, &ctx->he_wave_chain, &ctx->tv_slot, &ctx->tv_vid, &ctx->tv_meta, &ctx->tv_wave, &ctx->err, &ctx->cost_pe, &ctx->cost_pv,
-              &ctx->cost_out, &ctx->img_ref, &ctx->img_cmp, &ctx->photo_err};
+              &ctx->cost_out, &ctx->img_ref, &ctx->img_cmp, &ctx->photo_err, &ctx->r_tris, &ctx->r_valid, &ctx->r_keys,
+              &ctx->r_img, &ctx->r_cov, &ctx->r_vtx, &ctx->r_val};
   *out = ctx;
   return FLAME_NLTGV2_OK;
 }
@@ -519,8 +521,11 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
   if (E > 0 && (!g->src || !g->dst || !g->alpha || !g->beta || !g->q1 || !g->q2 || !g->q3))
     return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
   ctx->have_graph = false;
+  const bool trace = std::getenv("FLAME_NLTGV2_TRACE") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
   rc = build_layout(g, &ctx->L);
   if (rc) return fail(ctx, rc);
+  const auto t_packed = std::chrono::steady_clock::now();
   const PackedLayout& L = ctx->L;
   const size_t n_slots = (size_t)(L.rows + kRowPad) * kWave;
   if (n_slots > (size_t)0x7fffffff) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
@@ -593,6 +598,12 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
   ctx->state_lost = false;
   LAUNCHCHK(ctx, launch_pack_static(ctx->c, ctx->f, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors / caller arrays may go away
+  if (trace) {
+    const auto t_end = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[flame_nltgv2] upload_graph V=%d E=%d: host pack %.3f ms, alloc+copy+device pack %.3f ms\n", V, E,
+                 std::chrono::duration<double, std::milli>(t_packed - t_begin).count(),
+                 std::chrono::duration<double, std::milli>(t_end - t_packed).count());
+  }
   ctx->h_src.assign(g->src, g->src + E);
   ctx->h_dst.assign(g->dst, g->dst + E);
   ctx->h_feat.resize((size_t)V);
@@ -913,6 +924,71 @@ int flame_nltgv2_export_idepth_device(flame_nltgv2_ctx* ctx, void* dst_device, f
   LAUNCHCHK(ctx, launch_export(ctx->c, ctx->f, packed, scale, (float*)dst_device, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return FLAME_NLTGV2_OK;
+}
+
+// Shared tail of the two interpolate_mesh entry points: triangles/validity -> device, rasterise, copy back.
+static int interpolate_common(flame_nltgv2_ctx* ctx, const int32_t* triangles, int32_t T, int32_t V,
+                              const uint8_t* vtx_valid, const uint8_t* tri_valid, const float2* d_vtx,
+                              const float* d_val, float value_scale, int rows, int cols, float* out, int32_t* coverage) {
+  if (T < 0 || rows <= 0 || cols <= 0 || !out || (T > 0 && !triangles)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  for (int32_t t = 0; t < 3 * T; ++t)
+    if (triangles[t] < 0 || triangles[t] >= V) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  const size_t n = (size_t)rows * (size_t)cols;
+  int rc = ensure(ctx, ctx->r_tris, sizeof(int32_t) * 3 * (size_t)T);
+  if (!rc) rc = ensure(ctx, ctx->r_valid, (size_t)T + (size_t)V + 16);
+  if (!rc) rc = ensure(ctx, ctx->r_keys, sizeof(unsigned long long) * n);
+  if (!rc) rc = ensure(ctx, ctx->r_img, sizeof(float) * n);
+  if (!rc) rc = ensure(ctx, ctx->r_cov, sizeof(int));
+  if (rc) return rc;
+  if (T > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->r_tris.p, triangles, sizeof(int32_t) * 3 * (size_t)T, hipMemcpyHostToDevice, ctx->stream));
+  uint8_t* d_tv = nullptr;
+  uint8_t* d_vv = nullptr;
+  if (tri_valid && T > 0) {
+    d_tv = (uint8_t*)ctx->r_valid.p;
+    HIPCHK(ctx, hipMemcpyAsync(d_tv, tri_valid, (size_t)T, hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (vtx_valid && V > 0) {
+    d_vv = (uint8_t*)ctx->r_valid.p + (size_t)T;
+    HIPCHK(ctx, hipMemcpyAsync(d_vv, vtx_valid, (size_t)V, hipMemcpyHostToDevice, ctx->stream));
+  }
+  LAUNCHCHK(ctx, launch_interpolate_mesh(T, (const int32_t*)ctx->r_tris.p, d_vtx, d_val, value_scale, d_vv, d_tv,
+                                         (unsigned long long*)ctx->r_keys.p, (float*)ctx->r_img.p, (int*)ctx->r_cov.p,
+                                         rows, cols, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(out, ctx->r_img.p, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
+  int cov = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&cov, ctx->r_cov.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (coverage) *coverage = cov;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_interpolate_mesh(flame_nltgv2_ctx* ctx, const int32_t* triangles, int32_t T, const uint8_t* tri_valid,
+                                  int rows, int cols, float graph_scale, float* idepthmap_out, int32_t* coverage_out) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  rc = ensure_canon(ctx);
+  if (rc) return rc;
+  return interpolate_common(ctx, triangles, T, ctx->L.V, nullptr, tri_valid, ctx->c.pos, ctx->c.x, graph_scale, rows,
+                            cols, idepthmap_out, coverage_out);
+}
+
+int flame_nltgv2_interpolate_mesh_arrays(flame_nltgv2_ctx* ctx, const int32_t* triangles, int32_t T, const float* vertices_xy,
+                                         const float* values, int32_t V, const uint8_t* vtx_valid,
+                                         const uint8_t* tri_valid, int rows, int cols, float* img_out,
+                                         int32_t* coverage_out) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (V < 0 || (V > 0 && (!vertices_xy || !values))) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  rc = ensure(ctx, ctx->r_vtx, sizeof(float) * 2 * (size_t)V);
+  if (!rc) rc = ensure(ctx, ctx->r_val, sizeof(float) * (size_t)V);
+  if (rc) return rc;
+  if (V > 0) {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->r_vtx.p, vertices_xy, sizeof(float) * 2 * (size_t)V, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->r_val.p, values, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, ctx->stream));
+  }
+  return interpolate_common(ctx, triangles, T, V, vtx_valid, tri_valid, (const float2*)ctx->r_vtx.p,
+                            (const float*)ctx->r_val.p, 1.0f, rows, cols, img_out, coverage_out);
 }
 
 int flame_nltgv2_photo_set_images(flame_nltgv2_ctx* ctx, const uint8_t* ref, const uint8_t* cmp, int rows, int cols,

@@ -79,6 +79,9 @@ int launch_pack_state(const CanonArgs& c, const FusedArgs& a, int parity, hipStr
 int launch_unpack_state(const CanonArgs& c, const FusedArgs& a, int parity, bool have_prev, hipStream_t s);
 int launch_export(const CanonArgs& c, const FusedArgs& a, bool packed_current, float scale, float* dst,
                   hipStream_t s);
+int launch_interpolate_mesh(int T, const int32_t* tris, const float2* vtx, const float* values, float value_scale,
+                            const uint8_t* vtx_valid, const uint8_t* tri_valid, unsigned long long* keys, float* img,
+                            int* coverage, int rows, int cols, hipStream_t s);
 int launch_photo_residual(const CanonArgs& c, float graph_scale, const PhotoGeometry& geo, const uint8_t* ref,
                           const uint8_t* cmp, int rows, int cols, int step, int border, float* err, hipStream_t s);
 int launch_costs(const CanonArgs& c, const SolverParams& p, double* partial_e, double* partial_v,

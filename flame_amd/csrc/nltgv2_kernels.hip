@@ -1028,6 +1028,78 @@ k_photo_residual(int V, const float2* __restrict__ pos, const float* __restrict_
   err[v] = out;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Mesh -> dense inverse-depth map (the step right after the solver, flame.cc:409-437):
+//   utils::interpolateMesh (utils/image_utils.cc:373-396) drawing every triangle with
+//   utils::DrawShadedTriangleBarycentric (utils/rasterization.cc:164-246, Edge::init
+//   rasterization.h:120-154).  The reference draws the triangles one after the other, so where two
+//   triangles share pixels (the inclusive w >= 0 rule puts shared edges in both) the LATER triangle
+//   wins.  Here every triangle is rasterised concurrently by one wavefront and the order is restored
+//   with a 64-bit atomicMax on {triangle index + 1, value bits}: the surviving value is exactly the
+//   one the sequential loop leaves behind.  Edge values are integers held in floats (exact below
+//   2^24), evaluated per pixel; value = (v1*w1 + (v2*w2 + v3*w3)) / (w1 + (w2 + w3)) as in the SSE
+//   code.  Pixel keys live in a rows*cols u64 scratch image, resolved to floats (NaN = uncovered)
+//   together with the coverage count of flame.cc:428-437.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float edge_eval(int v0x, int v0y, int v1x, int v1y, int px, int py) {
+  const float A = (float)(v1y - v0y);
+  const float B = (float)(v0x - v1x);
+  const float C = (float)(v1x * v0y - v0x * v1y);
+  return (A * (float)px + B * (float)py) + C;
+}
+
+__global__ void __launch_bounds__(64)
+k_raster_triangles(int T, const int32_t* __restrict__ tris, const float2* __restrict__ vtx,
+                   const float* __restrict__ values, float value_scale, const uint8_t* __restrict__ vtx_valid,
+                   const uint8_t* __restrict__ tri_valid, unsigned long long* __restrict__ keys, int rows,
+                   int cols) {
+  const int t = blockIdx.x;
+  if (t >= T) return;
+  const int a = tris[3 * t], b = tris[3 * t + 1], c = tris[3 * t + 2];
+  if (tri_valid && !tri_valid[t]) return;
+  if (vtx_valid && !(vtx_valid[a] && vtx_valid[b] && vtx_valid[c])) return;
+  // (2,1,0): "Triangle spits out points in clockwise order, but drawing function expects CCW"
+  const float2 f1 = vtx[c], f2 = vtx[b], f3 = vtx[a];
+  // cv::Point2f -> cv::Point is saturate_cast<int> == cvRound == round half to even
+  const int p1x = __float2int_rn(f1.x), p1y = __float2int_rn(f1.y);
+  const int p2x = __float2int_rn(f2.x), p2y = __float2int_rn(f2.y);
+  const int p3x = __float2int_rn(f3.x), p3y = __float2int_rn(f3.y);
+  const float v1 = values[c] * value_scale, v2 = values[b] * value_scale, v3 = values[a] * value_scale;
+  const int xmin = min(p1x, min(p2x, p3x)), ymin = min(p1y, min(p2y, p3y));
+  const int xmax = max(p1x, max(p2x, p3x)), ymax = max(p1y, max(p2y, p3y));
+  const int w = ((xmax - xmin) / 4) * 4 + 4;  // the reference walks x in blocks of 4 pixels
+  const int h = ymax - ymin + 1;
+  const long n = (long)w * h;
+  const unsigned long long hi = (unsigned long long)(t + 1) << 32;
+  for (long i = threadIdx.x; i < n; i += 64) {
+    const int x = xmin + (int)(i % w), y = ymin + (int)(i / w);
+    const float w1 = edge_eval(p2x, p2y, p3x, p3y, x, y);
+    const float w2 = edge_eval(p3x, p3y, p1x, p1y, x, y);
+    const float w3 = edge_eval(p1x, p1y, p2x, p2y, x, y);
+    if (w1 >= 0.0f && w2 >= 0.0f && w3 >= 0.0f && x >= 0 && y >= 0 && x < cols && y < rows) {
+      const float norm = w1 + (w2 + w3);
+      const float val = (v1 * w1 + (v2 * w2 + v3 * w3)) / norm;
+      atomicMax(&keys[(long)y * cols + x], hi | (unsigned long long)__float_as_uint(val));
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_raster_resolve(long n, const unsigned long long* __restrict__ keys, float* __restrict__ img,
+                 int* __restrict__ coverage) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool covered = false;
+  if (i < n) {
+    const unsigned long long k = keys[i];
+    covered = (k >> 32) != 0ull;
+    const float v = __uint_as_float((unsigned)k);
+    img[i] = covered ? v : __builtin_nanf("");
+    covered = covered && !(v != v);  // flame.cc:431: counts !isnan
+  }
+  const unsigned long long m = __ballot(covered);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(coverage, __popcll(m));
+}
+
 inline dim3 grid1d(int64_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
 }  // namespace
@@ -1168,6 +1240,21 @@ int launch_export(const CanonArgs& c, const FusedArgs& a, bool packed_current, f
   } else {
     hipLaunchKernelGGL(k_export_canonical, grid1d(c.V), dim3(256), 0, s, c.V, c.x, scale, dst);
   }
+  return (int)hipGetLastError();
+}
+
+int launch_interpolate_mesh(int T, const int32_t* tris, const float2* vtx, const float* values, float value_scale,
+                            const uint8_t* vtx_valid, const uint8_t* tri_valid, unsigned long long* keys, float* img,
+                            int* coverage, int rows, int cols, hipStream_t s) {
+  const long n = (long)rows * cols;
+  if (n <= 0) return 0;
+  (void)hipMemsetAsync(keys, 0, sizeof(unsigned long long) * (size_t)n, s);
+  (void)hipMemsetAsync(coverage, 0, sizeof(int), s);
+  if (T > 0) {
+    hipLaunchKernelGGL(k_raster_triangles, dim3((unsigned)T), dim3(64), 0, s, T, tris, vtx, values, value_scale,
+                       vtx_valid, tri_valid, keys, rows, cols);
+  }
+  hipLaunchKernelGGL(k_raster_resolve, grid1d(n), dim3(256), 0, s, n, keys, img, coverage);
   return (int)hipGetLastError();
 }
 

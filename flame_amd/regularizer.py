@@ -89,7 +89,8 @@ ABI_SYMBOLS = (
     "flame_nltgv2_set_option", "flame_nltgv2_get_info", "flame_nltgv2_last_error", "flame_nltgv2_last_hip_error",
     "flame_nltgv2_status_string", "flame_nltgv2_abi_version", "flame_nltgv2_pack_probe",
     "flame_nltgv2_photo_set_images", "flame_nltgv2_photo_residual", "flame_nltgv2_sync_graph",
-    "flame_nltgv2_get_topology", "flame_nltgv2_set_feature_ids",
+    "flame_nltgv2_get_topology", "flame_nltgv2_set_feature_ids", "flame_nltgv2_interpolate_mesh",
+    "flame_nltgv2_interpolate_mesh_arrays",
 )
 
 
@@ -137,6 +138,10 @@ def load_library():
         "flame_nltgv2_sync_graph": (C.c_int, [ctx, C.POINTER(_SyncInput)]),
         "flame_nltgv2_get_topology": (C.c_int, [ctx, _IP, _IP, _IP]),
         "flame_nltgv2_set_feature_ids": (C.c_int, [ctx, _IP]),
+        "flame_nltgv2_interpolate_mesh": (C.c_int, [ctx, _IP, C.c_int32, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_float,
+                                                    _FP, _IP]),
+        "flame_nltgv2_interpolate_mesh_arrays": (C.c_int, [ctx, _IP, C.c_int32, _FP, _FP, C.c_int32, C.POINTER(C.c_uint8),
+                                                           C.POINTER(C.c_uint8), C.c_int, C.c_int, _FP, _IP]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -342,6 +347,35 @@ class Regularizer:
     def cost(self, params: Params) -> float:
         s, d = self.costs(params)
         return float(np.float32(s) + np.float32(d))
+
+    # ---- mesh -> dense inverse-depth map (utils::interpolateMesh) -----------------------------------
+    def interpolate_mesh(self, triangles, rows, cols, graph_scale=1.0, tri_valid=None):
+        """Rasterises the solver's current x*graph_scale over `triangles`; returns (idepthmap, coverage)."""
+        tr = np.ascontiguousarray(triangles, np.int32).reshape(-1, 3)
+        img = np.empty((rows, cols), np.float32)
+        cov = C.c_int32(0)
+        U8 = C.POINTER(C.c_uint8)
+        tv = None if tri_valid is None else np.ascontiguousarray(tri_valid, np.uint8)
+        self._chk(self._L.flame_nltgv2_interpolate_mesh(self._ctx, tr.ctypes.data_as(_IP), tr.shape[0],
+                                                        None if tv is None else tv.ctypes.data_as(U8), rows, cols,
+                                                        C.c_float(graph_scale), img.ctypes.data_as(_FP), C.byref(cov)),
+                  "interpolate_mesh")
+        return img, int(cov.value)
+
+    def interpolate_mesh_arrays(self, triangles, vertices, values, rows, cols, vtx_valid=None, tri_valid=None):
+        tr = np.ascontiguousarray(triangles, np.int32).reshape(-1, 3)
+        xy = np.ascontiguousarray(vertices, np.float32).reshape(-1, 2)
+        val = _as(values, np.float32, xy.shape[0], "values")
+        img = np.empty((rows, cols), np.float32)
+        cov = C.c_int32(0)
+        U8 = C.POINTER(C.c_uint8)
+        tv = None if tri_valid is None else np.ascontiguousarray(tri_valid, np.uint8)
+        vv = None if vtx_valid is None else np.ascontiguousarray(vtx_valid, np.uint8)
+        self._chk(self._L.flame_nltgv2_interpolate_mesh_arrays(
+            self._ctx, tr.ctypes.data_as(_IP), tr.shape[0], xy.ctypes.data_as(_FP), val.ctypes.data_as(_FP), xy.shape[0],
+            None if vv is None else vv.ctypes.data_as(U8), None if tv is None else tv.ctypes.data_as(U8), rows, cols,
+            img.ctypes.data_as(_FP), C.byref(cov)), "interpolate_mesh_arrays")
+        return img, int(cov.value)
 
     # ---- config-5 epilogue ----------------------------------------------------------------------
     def photo_set_images(self, ref, cmp):

@@ -95,6 +95,20 @@ def delaunay_edges_scipy(pos: np.ndarray) -> np.ndarray:
     return cand[first].astype(np.int32)
 
 
+def delaunay_triangles_scipy(pos: np.ndarray) -> np.ndarray:
+    """Delaunay triangles as (T,3) int32 with the winding of the reference's triangulator (Shewchuk
+    Triangle: counter-clockwise in x-right / y-up coordinates, i.e. positive signed area)."""
+    from scipy.spatial import Delaunay
+
+    tri = Delaunay(pos.astype(np.float64)).simplices.astype(np.int32)
+    p = pos.astype(np.float64)
+    a, b, c = p[tri[:, 0]], p[tri[:, 1]], p[tri[:, 2]]
+    area2 = (b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (c[:, 0] - a[:, 0]) * (b[:, 1] - a[:, 1])
+    flip = area2 < 0
+    tri[flip] = tri[flip][:, [0, 2, 1]]
+    return np.ascontiguousarray(tri)
+
+
 def edge_weights(pos: np.ndarray, edges: np.ndarray):
     """alpha = 1/||pos_i - pos_j|| in float32 (flame.cc:2087-2102), beta = 1 (flame.cc:2103)."""
     d = pos[edges[:, 0]] - pos[edges[:, 1]]

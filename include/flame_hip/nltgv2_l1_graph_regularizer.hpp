@@ -192,6 +192,18 @@ class DeviceGraph {
     check(flame_nltgv2_sync_graph(ctx_, &in), "sync_graph");
   }
 
+  // utils::interpolateMesh (utils/image_utils.cc:373-396) at its call site flame.cc:409-415: rasterises
+  // x*graph_scale of the device state over `triangles` (triangulator->triangles(), 3 ints each) into a
+  // rows*cols float image (NaN = uncovered); returns the coverage count of flame.cc:428-437.
+  int interpolateMesh(const std::vector<int32_t>& triangles, int rows, int cols, float graph_scale, float* idepthmap,
+                      const uint8_t* tri_validity = nullptr) {
+    int32_t coverage = 0;
+    check(flame_nltgv2_interpolate_mesh(ctx_, triangles.data(), static_cast<int32_t>(triangles.size() / 3), tri_validity,
+                                        rows, cols, graph_scale, idepthmap, &coverage),
+          "interpolate_mesh");
+    return coverage;
+  }
+
   void step(const Params& p) { run(p, 1); }
   void run(const Params& p, int n_iters) {
     const flame_nltgv2_params c = to_c(p);

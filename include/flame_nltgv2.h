@@ -160,6 +160,22 @@ int flame_nltgv2_download_state(flame_nltgv2_ctx* ctx, flame_nltgv2_graph* out);
  * multi-GPU host can hand the buffer straight to an RCCL gather. */
 int flame_nltgv2_export_idepth_device(flame_nltgv2_ctx* ctx, void* dst_device, float scale);
 
+/* Mesh -> dense inverse-depth map, the step right after the solver each frame:
+ * utils::interpolateMesh (utils/image_utils.cc:373-396) over utils::DrawShadedTriangleBarycentric
+ * (utils/rasterization.cc:164-246), as called at flame.cc:409-415, plus the coverage count of
+ * flame.cc:428-437.  `triangles`: T index triples in the reference triangulator's order and winding
+ * (utils::Delaunay::triangles()); later triangles win on shared pixels, exactly like the reference's
+ * sequential loop.  Output: rows*cols floats, NaN where no triangle covers the pixel.
+ *   interpolate_mesh         vertices = the context's graph: pos and x*graph_scale straight from the device
+ *                            state (flame.cc:372-380 without the host round trip)
+ *   interpolate_mesh_arrays  the reference signature: explicit vertices / values / validity arrays */
+int flame_nltgv2_interpolate_mesh(flame_nltgv2_ctx* ctx, const int32_t* triangles, int32_t T, const uint8_t* tri_valid,
+                                  int rows, int cols, float graph_scale, float* idepthmap_out, int32_t* coverage_out);
+int flame_nltgv2_interpolate_mesh_arrays(flame_nltgv2_ctx* ctx, const int32_t* triangles, int32_t T,
+                                         const float* vertices_xy, const float* values, int32_t V,
+                                         const uint8_t* vtx_valid, const uint8_t* tri_valid, int rows, int cols,
+                                         float* img_out, int32_t* coverage_out);
+
 /* Per-vertex photometric residual (BASELINE config 5).  No live reference counterpart: the only
  * occurrence is the commented-out block flame.cc:854-893; built from the live pieces
  * EpipolarGeometry::project (stereo/epipolar_geometry.h:127-143) and utils::bilinearInterp<uint8_t,float>

@@ -44,9 +44,9 @@ def lib():
     if _LIB is None:
         path = os.path.join(_HERE, "liboracle_nltgv2.so")
         src = os.path.join(_HERE, "nltgv2_oracle.c")
-        src2 = os.path.join(_HERE, "photometric_oracle.c")
+        others = [os.path.join(_HERE, f) for f in ("photometric_oracle.c", "raster_oracle.c")]
         if (not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src)
-                or os.path.getmtime(path) < os.path.getmtime(src2)):
+                or any(os.path.getmtime(path) < os.path.getmtime(o) for o in others)):
             build()
         L = C.CDLL(path)
         PP, GP = C.POINTER(Params), C.POINTER(Graph)
@@ -80,6 +80,12 @@ def lib():
         L.photo_bilinear_u8.restype = C.c_float
         L.photo_residual.argtypes = [C.c_int, _FP, _FP, C.c_float, _FP, _FP, U8, U8, C.c_int, C.c_int, C.c_int, C.c_int, _FP]
         L.photo_residual.restype = None
+        L.raster_triangle_barycentric.argtypes = [C.c_int] * 6 + [C.c_float] * 3 + [_FP, C.c_int, C.c_int]
+        L.raster_triangle_barycentric.restype = None
+        L.raster_interpolate_mesh.argtypes = [C.c_int, _IP, _FP, _FP, U8, U8, _FP, C.c_int, C.c_int]
+        L.raster_interpolate_mesh.restype = None
+        L.raster_coverage.argtypes = [_FP, C.c_int, C.c_int]
+        L.raster_coverage.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -178,3 +184,28 @@ def photo_residual(pos, x, graph_scale, KRKinv, Kt, ref, cmp, border):
                          t.ctypes.data_as(_FP), ref.ctypes.data_as(U8), cmp.ctypes.data_as(U8), ref.shape[0],
                          ref.shape[1], ref.strides[0], border, err.ctypes.data_as(_FP))
     return err
+
+
+# ---- mesh -> dense inverse-depth rasterisation, oracle/raster_oracle.c -----------------------------------
+def raster_triangle(img, p1, p2, p3, v1, v2, v3):
+    assert img.dtype == np.float32 and img.flags["C_CONTIGUOUS"]
+    lib().raster_triangle_barycentric(int(p1[0]), int(p1[1]), int(p2[0]), int(p2[1]), int(p3[0]), int(p3[1]), v1, v2,
+                                      v3, img.ctypes.data_as(_FP), img.shape[0], img.shape[1])
+
+
+def raster_interpolate_mesh(tris, vtx_xy, values, rows, cols, tri_valid=None, vtx_valid=None):
+    tris = np.ascontiguousarray(tris, np.int32).reshape(-1, 3)
+    xy = np.ascontiguousarray(vtx_xy, np.float32)
+    val = np.ascontiguousarray(values, np.float32)
+    img = np.full((rows, cols), np.nan, np.float32)
+    U8 = C.POINTER(C.c_uint8)
+    tv = None if tri_valid is None else np.ascontiguousarray(tri_valid, np.uint8)
+    vv = None if vtx_valid is None else np.ascontiguousarray(vtx_valid, np.uint8)
+    lib().raster_interpolate_mesh(tris.shape[0], tris.ctypes.data_as(_IP), xy.ctypes.data_as(_FP), val.ctypes.data_as(_FP),
+                                  None if vv is None else vv.ctypes.data_as(U8), None if tv is None else tv.ctypes.data_as(U8),
+                                  img.ctypes.data_as(_FP), rows, cols)
+    return img
+
+
+def raster_coverage(img):
+    return int(lib().raster_coverage(img.ctypes.data_as(_FP), img.shape[0], img.shape[1]))
