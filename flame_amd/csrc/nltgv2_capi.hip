@@ -16,7 +16,6 @@
 #include <chrono>
 #include <cmath>
 #include <new>
-#include <unordered_map>
 #include <vector>
 
 #include "flame_nltgv2.h"
@@ -346,8 +345,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
     // a fresh first tag per launch: records left by earlier runs (whose state may since have been
     // changed by per-step launches or host uploads) can never satisfy a wait of this launch
     const uint32_t tag0 = ctx->tag_next + 2;
-    int e = launch_persistent_run(ctx->f, to_sp(p), form, ctx->parity, tag0, n, pw, std::getenv("FLAME_NLTGV2_DEBUG_NOWAIT") ? 0xfffffffeu : kMaxSpins,
-                                  std::getenv("FLAME_NLTGV2_PRESLEEP") ? std::atoi(std::getenv("FLAME_NLTGV2_PRESLEEP")) : kPreSleep,
+    int e = launch_persistent_run(ctx->f, to_sp(p), form, ctx->parity, tag0, n, pw, kMaxSpins, kPreSleep,
                                   dual, ctx->coop_checked_key != (ctx->topo * 4 + (uint64_t)form), ctx->stream);
     if (e == 0) {
       ctx->coop_checked_key = ctx->topo * 4 + (uint64_t)form;
@@ -395,6 +393,50 @@ int finish(flame_nltgv2_ctx* ctx) {
 }
 
 bool params_ok(const flame_nltgv2_params* p) { return p != nullptr; }
+
+// Open-addressing hash map u64 -> i32 (linear probing, power-of-two capacity, no erase): the per-frame
+// bookkeeping of sync_graph looks up ~V feature ids and ~E feature pairs; std::unordered_map made that the
+// most expensive part of a frame (2.0-2.5 ms at 640x480), this table does it in a fraction.
+class FlatMap {
+ public:
+  explicit FlatMap(size_t n) {
+    size_t cap = 16;
+    while (cap < 2 * n + 2) cap <<= 1;
+    mask_ = cap - 1;
+    keys_.assign(cap, kEmpty);
+    vals_.resize(cap);
+  }
+  // inserts (k,v) if k is absent; returns the slot's value pointer and whether it was inserted
+  std::pair<int32_t*, bool> emplace(uint64_t k, int32_t v) {
+    size_t i = hash(k) & mask_;
+    for (;; i = (i + 1) & mask_) {
+      if (keys_[i] == kEmpty) {
+        keys_[i] = k;
+        vals_[i] = v;
+        return {&vals_[i], true};
+      }
+      if (keys_[i] == k) return {&vals_[i], false};
+    }
+  }
+  const int32_t* find(uint64_t k) const {
+    size_t i = hash(k) & mask_;
+    for (;; i = (i + 1) & mask_) {
+      if (keys_[i] == kEmpty) return nullptr;
+      if (keys_[i] == k) return &vals_[i];
+    }
+  }
+
+ private:
+  static constexpr uint64_t kEmpty = ~0ull;  // feature ids are non-negative int32: never a real key
+  static size_t hash(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return (size_t)(z ^ (z >> 31));
+  }
+  size_t mask_;
+  std::vector<uint64_t> keys_;
+  std::vector<int32_t> vals_;
+};
 
 }  // namespace
 
@@ -642,6 +684,8 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
   if (V > 0 && (!in->feat_id || !in->pos || !in->data_term || !in->data_weight)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
   if (E > 0 && !in->edges) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
 
+  const bool trace = std::getenv("FLAME_NLTGV2_TRACE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   // previous state -> host
   const int32_t Vo = ctx->L.V, Eo = ctx->L.E;
   std::vector<float> ox(Vo), ow1(Vo), ow2(Vo), oxb(Vo), ow1b(Vo), ow2b(Vo), oxp(Vo), ow1p(Vo), ow2p(Vo), oq1(Eo), oq2(Eo), oq3(Eo);
@@ -652,28 +696,28 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
   old.q1 = oq1.data(), old.q2 = oq2.data(), old.q3 = oq3.data();
   rc = flame_nltgv2_download_state(ctx, &old);
   if (rc) return rc;
+  const auto t1 = std::chrono::steady_clock::now();
 
-  std::unordered_map<int32_t, int32_t> old_of_feat;
-  old_of_feat.reserve((size_t)Vo * 2);
-  for (int32_t v = 0; v < Vo; ++v) old_of_feat[ctx->h_feat[(size_t)v]] = v;
-  std::unordered_map<uint64_t, int32_t> old_edge;  // (min feat, max feat) -> old edge index
-  old_edge.reserve((size_t)Eo * 2);
+  for (int32_t v = 0; v < V; ++v)
+    if (in->feat_id[v] < 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  FlatMap old_of_feat((size_t)Vo);
+  for (int32_t v = 0; v < Vo; ++v) old_of_feat.emplace((uint64_t)(uint32_t)ctx->h_feat[(size_t)v], v);
+  FlatMap old_edge((size_t)Eo);  // (min feat, max feat) -> old edge index
   auto key = [](int32_t a, int32_t b) {
     const uint32_t lo = (uint32_t)std::min(a, b), hi = (uint32_t)std::max(a, b);
     return ((uint64_t)hi << 32) | lo;
   };
   for (int32_t e = 0; e < Eo; ++e)
-    old_edge[key(ctx->h_feat[(size_t)ctx->h_src[(size_t)e]], ctx->h_feat[(size_t)ctx->h_dst[(size_t)e]])] = e;
+    old_edge.emplace(key(ctx->h_feat[(size_t)ctx->h_src[(size_t)e]], ctx->h_feat[(size_t)ctx->h_dst[(size_t)e]]), e);
 
   // vertices
   std::vector<float> x(V), w1(V, 0.f), w2(V, 0.f), xb(V), w1b(V, 0.f), w2b(V, 0.f), xp(V), w1p(V, 0.f), w2p(V, 0.f);
-  std::unordered_map<int32_t, int32_t> seen;
-  seen.reserve((size_t)V * 2);
+  FlatMap seen((size_t)V);
   for (int32_t v = 0; v < V; ++v) {
-    if (!seen.emplace(in->feat_id[v], v).second) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // duplicate id
-    auto it = old_of_feat.find(in->feat_id[v]);
-    if (it != old_of_feat.end()) {
-      const int32_t o = it->second;
+    if (!seen.emplace((uint64_t)(uint32_t)in->feat_id[v], v).second) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // duplicate id
+    const int32_t* it = old_of_feat.find((uint64_t)(uint32_t)in->feat_id[v]);
+    if (it) {
+      const int32_t o = *it;
       x[v] = ox[o], w1[v] = ow1[o], w2[v] = ow2[o];
       xb[v] = oxb[o], w1b[v] = ow1b[o], w2b[v] = ow2b[o];
       xp[v] = oxp[o], w1p[v] = ow1p[o], w2p[v] = ow2p[o];
@@ -688,16 +732,15 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
   std::vector<Keep> keep;
   std::vector<std::pair<int32_t, int32_t>> fresh;
   keep.reserve((size_t)E), fresh.reserve((size_t)E);
-  std::unordered_map<uint64_t, char> dup;
-  dup.reserve((size_t)E * 2);
+  FlatMap dup((size_t)E);
   for (int32_t k = 0; k < E; ++k) {
     const int32_t a = in->edges[2 * k], b = in->edges[2 * k + 1];
     if (a < 0 || a >= V || b < 0 || b >= V || a == b) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
     const uint64_t kk = key(in->feat_id[a], in->feat_id[b]);
     if (!dup.emplace(kk, 1).second) continue;  // boost::edge() finds the one just added: no parallel edges
-    auto it = old_edge.find(kk);
-    if (it != old_edge.end()) {
-      const int32_t e = it->second;
+    const int32_t* it = old_edge.find(kk);
+    if (it) {
+      const int32_t e = *it;
       const bool same = ctx->h_feat[(size_t)ctx->h_src[(size_t)e]] == in->feat_id[a];
       keep.push_back(Keep{e, same ? a : b, same ? b : a});
     } else {
@@ -724,6 +767,7 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
     alpha[k] = 1.0f / std::sqrt(dx * dx + dy * dy);
   }
 
+  const auto t2 = std::chrono::steady_clock::now();
   flame_nltgv2_graph g{};
   g.V = V, g.E = En;
   g.pos = const_cast<float*>(in->pos);
@@ -736,6 +780,12 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
   g.q1 = q1.data(), g.q2 = q2.data(), g.q3 = q3.data();
   rc = flame_nltgv2_upload_graph(ctx, &g);
   if (rc) return rc;
+  if (trace) {
+    const auto t3 = std::chrono::steady_clock::now();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::fprintf(stderr, "[flame_nltgv2] sync_graph: download %.3f ms, remap %.3f ms, upload %.3f ms\n", ms(t0, t1), ms(t1, t2),
+                 ms(t2, t3));
+  }
   ctx->h_feat.assign(in->feat_id, in->feat_id + V);
   return FLAME_NLTGV2_OK;
 }
@@ -744,10 +794,9 @@ int flame_nltgv2_set_feature_ids(flame_nltgv2_ctx* ctx, const int32_t* feat_id) 
   if (!ctx) return FLAME_NLTGV2_ERR_INVALID_ARG;
   if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
   if (!feat_id && ctx->L.V > 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-  std::unordered_map<int32_t, int32_t> seen;
-  seen.reserve((size_t)ctx->L.V * 2);
+  FlatMap seen((size_t)ctx->L.V);
   for (int32_t v = 0; v < ctx->L.V; ++v)
-    if (!seen.emplace(feat_id[v], v).second) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+    if (feat_id[v] < 0 || !seen.emplace((uint64_t)(uint32_t)feat_id[v], v).second) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
   ctx->h_feat.assign(feat_id, feat_id + ctx->L.V);
   return FLAME_NLTGV2_OK;
 }

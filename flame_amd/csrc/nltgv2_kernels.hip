@@ -348,7 +348,6 @@ k_persistent_he(const int n_waves, const int waves_per_xcd, const int32_t* __res
     v4i_t g = {0, 0, 0, 0};
     bool pend = active;
     unsigned spins = 0;
-    const bool dbg_nowait = (max_spins == 0xfffffffeu);  // timing experiment only
     const int so_in = (s & 1u) ? par : 0;
     for (int z = 0; z < ps; ++z) __builtin_amdgcn_s_sleep(1);
     for (;;) {
@@ -356,7 +355,7 @@ k_persistent_he(const int n_waves, const int waves_per_xcd, const int32_t* __res
         int o = poll_off;
         asm volatile("" : "+v"(o)::"memory");
         g = __builtin_amdgcn_raw_buffer_load_b128(rx, o, so_in, kAuxSc1);
-        pend = ((unsigned)g.w != s) && !dbg_nowait;
+        pend = ((unsigned)g.w != s);
       }
       if (!__any(pend)) break;
       ++spins;
@@ -595,7 +594,6 @@ k_persistent_tv(const int n_waves, const int waves_per_xcd, const int32_t* __res
     v4i_t g[kTvS];
     unsigned pending = all_mask;
     unsigned spins = 0;
-    const bool dbg_nowait = (max_spins == 0xfffffffeu);
     for (int z = 0; z < ps; ++z) __builtin_amdgcn_s_sleep(1);
     for (;;) {
 #pragma unroll
@@ -608,7 +606,7 @@ k_persistent_tv(const int n_waves, const int waves_per_xcd, const int32_t* __res
       }
 #pragma unroll
       for (int k = 0; k < kTvS; ++k) {
-        if (((pending >> k) & 1u) && ((unsigned)g[k].w == s || dbg_nowait)) pending &= ~(1u << k);
+        if (((pending >> k) & 1u) && (unsigned)g[k].w == s) pending &= ~(1u << k);
       }
       if (!__any(pending != 0u)) break;
       ++spins;

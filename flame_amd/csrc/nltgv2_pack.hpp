@@ -26,6 +26,16 @@
 
 #include "flame_nltgv2.h"
 
+#ifdef FLAME_PACK_PROFILE
+#include <chrono>
+double g_prof[8];
+#define PROF_T(i) do { auto _n = std::chrono::steady_clock::now(); g_prof[i] += std::chrono::duration<double, std::milli>(_n - _t).count(); _t = _n; } while (0)
+#define PROF_BEGIN auto _t = std::chrono::steady_clock::now();
+#else
+#define PROF_T(i)
+#define PROF_BEGIN
+#endif
+
 namespace flame_hip {
 
 constexpr int kWave = 64;           // gfx950 wavefront
@@ -87,6 +97,7 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
   if (V >= (1 << 30)) return FLAME_NLTGV2_ERR_INVALID_ARG;
   L->V = V;
   L->E = E;
+  PROF_BEGIN
 
   // ---- (A) canonical CSR, ascending edge id -------------------------------------------------
   L->row_ptr.assign(static_cast<size_t>(V) + 1, 0);
@@ -109,6 +120,7 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
   for (int32_t v = 0; v < V; ++v) maxdeg = std::max(maxdeg, L->row_ptr[v + 1] - L->row_ptr[v]);
   L->max_degree = maxdeg;
 
+  PROF_T(0);
   // ---- vertex renumbering ---------------------------------------------------------------------
   // connected components (union-find): a batch of independent frames is a disjoint union and the
   // frames overlap in image coordinates, so Morton order alone would interleave them.
@@ -145,6 +157,7 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
     const uint32_t m = morton_spread16(qx) | (morton_spread16(qy) << 1);
     key[v] = (static_cast<uint64_t>(static_cast<uint32_t>(find(v))) << 32) | m;
   }
+  PROF_T(1);
   std::vector<int32_t> order(V);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
@@ -161,6 +174,7 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
     c0 = c1;
   }
 
+  PROF_T(2);
   // ---- (B) SELL-64 ----------------------------------------------------------------------------
   const int32_t n_slices = (V + kWave - 1) / kWave;
   L->n_slices = n_slices;
@@ -210,6 +224,7 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
     }
   }
 
+  PROF_T(3);
   // ---- (C) wave-aligned half-edge rows -------------------------------------------------------------
   L->he_ok = (maxdeg <= kWave);
   L->he_waves = 0;
@@ -247,6 +262,7 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
     }
   }
 
+  PROF_T(4);
   // ---- (D) one-vertex-per-lane rows, kTvSlots register slots per lane ------------------------------
   L->tv_ok = (maxdeg <= kTvSlots * kWave);
   L->tv_waves = 0;
@@ -290,6 +306,7 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
       fill += lanes;
     }
   }
+  PROF_T(5);
   return FLAME_NLTGV2_OK;
 }
 

@@ -101,7 +101,7 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
  * unspecified; here it is the caller's.)  Feature ids default to the vertex index after upload_graph. */
 typedef struct flame_nltgv2_sync_input {
   int32_t V;
-  const int32_t* feat_id;   /* [V] unique, stable across frames (Flame::feat_to_vtx_, flame.h:542-543) */
+  const int32_t* feat_id;   /* [V] unique, >= 0, stable across frames (Flame::feat_to_vtx_, flame.h:542-543) */
   const float* pos;         /* [2V] positions in the new frame (after projectGraph re-projection) */
   const float* data_term;   /* [V] feat.idepth_mu / graph_scale */
   const float* data_weight; /* [V] */
