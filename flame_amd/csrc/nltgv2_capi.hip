@@ -69,6 +69,7 @@ struct flame_nltgv2_ctx {
   uint32_t tag_next = 1;  // persistent run: tag of the current bar values (monotonic)
   bool state_lost = false;
   int last_run_path = 0;
+  bool static_stale = false;  // pos changed on the device (project_graph): packed alpha/dx/dy need a re-pack
   uint64_t coop_checked_key = 0;  // (topology, form) whose persistent grid the runtime has verified as resident
 
   PackedLayout L;
@@ -204,6 +205,10 @@ int ensure_canon(flame_nltgv2_ctx* ctx) {
 
 int ensure_fused(flame_nltgv2_ctx* ctx) {
   if (ctx->fused_valid) return 0;
+  if (ctx->static_stale) {  // positions moved: dx, dy of the packed records follow (alpha stays the caller's)
+    LAUNCHCHK(ctx, launch_pack_static(ctx->c, ctx->f, ctx->stream));
+    ctx->static_stale = false;
+  }
   LAUNCHCHK(ctx, launch_pack_state(ctx->c, ctx->f, ctx->parity, ctx->stream));
   ctx->fused_valid = true;
   ctx->have_prev = false;
@@ -638,6 +643,7 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
   HIPCHK(ctx, hipMemsetAsync(ctx->xbuf.p, 0, 68 * n_packed + 64, ctx->stream));
   ctx->tag_next = 1;
   ctx->state_lost = false;
+  ctx->static_stale = false;
   LAUNCHCHK(ctx, launch_pack_static(ctx->c, ctx->f, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors / caller arrays may go away
   if (trace) {
@@ -787,6 +793,51 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
                  ms(t2, t3));
   }
   ctx->h_feat.assign(in->feat_id, in->feat_id + V);
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_project_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_projection* pr, float graph_scale,
+                               uint8_t* keep_out, float* pos_out) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!pr || !(graph_scale > 0.0f) || (ctx->L.V > 0 && !keep_out)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  rc = ensure_canon(ctx);
+  if (rc) return rc;
+  const size_t V = (size_t)ctx->L.V;
+  rc = ensure(ctx, ctx->r_valid, V + 16);
+  if (rc) return rc;
+  ProjectGeometry geo;
+  std::memcpy(geo.K, pr->K, sizeof(geo.K));
+  std::memcpy(geo.Kinv, pr->Kinv, sizeof(geo.Kinv));
+  std::memcpy(geo.KRKinv, pr->KRKinv, sizeof(geo.KRKinv));
+  std::memcpy(geo.q, pr->q_ref_to_cmp, sizeof(geo.q));
+  std::memcpy(geo.t, pr->t_ref_to_cmp, sizeof(geo.t));
+  geo.rx = pr->region_x, geo.ry = pr->region_y, geo.rw = pr->region_w, geo.rh = pr->region_h;
+  LAUNCHCHK(ctx, launch_project_graph(ctx->c, graph_scale, geo, (uint8_t*)ctx->r_valid.p, ctx->stream));
+  if (V) HIPCHK(ctx, hipMemcpyAsync(keep_out, ctx->r_valid.p, V, hipMemcpyDeviceToHost, ctx->stream));
+  if (V && pos_out) HIPCHK(ctx, hipMemcpyAsync(pos_out, ctx->pos.p, sizeof(float) * 2 * V, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->fused_valid = false;  // x changed; pos changed: alpha/dx/dy of the packed records are stale until the next
+                             // sync_graph / upload_graph re-derives them (the reference re-triangulates right after)
+  ctx->static_stale = true;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_rescale_data(flame_nltgv2_ctx* ctx, float graph_scale, float* new_graph_scale, flame_nltgv2_params* p) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!new_graph_scale || !p || ctx->L.V <= 0 || !(graph_scale > 0.0f)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  rc = ensure_canon(ctx);
+  if (rc) return rc;
+  LAUNCHCHK(ctx, launch_rescale(ctx->c, graph_scale, (float*)ctx->cost_out.p, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_cost, ctx->cost_out.p, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const float ns = ctx->h_cost[0];
+  p->data_factor *= ns / graph_scale;  // flame.cc:349
+  *new_graph_scale = ns;
+  ctx->fused_valid = false;
   return FLAME_NLTGV2_OK;
 }
 

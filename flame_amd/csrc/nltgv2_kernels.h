@@ -18,6 +18,15 @@ struct PhotoGeometry {
   float Kt[3];
 };
 
+// Everything EpipolarGeometry::project(u, idepth, &u_new, &idepth_new) reads (stereo/epipolar_geometry.h:152-180)
+// plus the valid region of Flame::projectGraph (flame.cc:1881-1884).
+struct ProjectGeometry {
+  float K[9], Kinv[9], KRKinv[9];
+  float q[4];  // q_ref_to_cmp as (w, x, y, z)
+  float t[3];
+  float rx, ry, rw, rh;
+};
+
 // Canonical SoA state in the caller's vertex / edge order (device pointers).
 struct CanonArgs {
   int V = 0, E = 0;
@@ -79,6 +88,8 @@ int launch_pack_state(const CanonArgs& c, const FusedArgs& a, int parity, hipStr
 int launch_unpack_state(const CanonArgs& c, const FusedArgs& a, int parity, bool have_prev, hipStream_t s);
 int launch_export(const CanonArgs& c, const FusedArgs& a, bool packed_current, float scale, float* dst,
                   hipStream_t s);
+int launch_project_graph(const CanonArgs& c, float graph_scale, const ProjectGeometry& geo, uint8_t* keep, hipStream_t s);
+int launch_rescale(const CanonArgs& c, float graph_scale, float* new_scale_dev, hipStream_t s);
 int launch_interpolate_mesh(int T, const int32_t* tris, const float2* vtx, const float* values, float value_scale,
                             const uint8_t* vtx_valid, const uint8_t* tri_valid, unsigned long long* keys, float* img,
                             int* coverage, int rows, int cols, hipStream_t s);

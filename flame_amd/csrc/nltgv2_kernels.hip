@@ -1098,6 +1098,76 @@ k_raster_resolve(long n, const unsigned long long* __restrict__ keys, float* __r
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(coverage, __popcll(m));
 }
 
+// ------------------------------------------------------------------------------------------------
+// Graph maintenance sweeps of the per-frame path, on the canonical state:
+//   k_project_graph   Flame::projectGraph, flame.cc:1888-1905: re-project every vertex into the new
+//                     frame with EpipolarGeometry::project(u, idepth, &u_new, &idepth_new)
+//                     (stereo/epipolar_geometry.h:152-180; the rotation is Eigen's quaternion *
+//                     vector: uv = q.vec x v; uv += uv; v + w*uv + q.vec x uv), write pos and
+//                     x = idepth_new / scale back, and report which vertices stay
+//                     (cv::Rect_<float>::contains, idepth_new >= 0).
+//   k_rescale_*       the rescale_data block, flame.cc:328-351; the mean of data_term*scale is summed
+//                     sequentially in vertex order by one lane (the reference's order is BGL hash order).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_project_graph(int V, float2* __restrict__ pos, float* __restrict__ x, float graph_scale, ProjectGeometry geo,
+                uint8_t* __restrict__ keep) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const float2 u = pos[v];
+  const float idepth = x[v] * graph_scale;
+  float nx, ny, nid;
+  if (idepth == 0.0f) {
+    const float* M = geo.KRKinv;
+    const float h0 = (M[0] * u.x + M[1] * u.y) + M[2] * 1.0f;
+    const float h1 = (M[3] * u.x + M[4] * u.y) + M[5] * 1.0f;
+    const float h2 = (M[6] * u.x + M[7] * u.y) + M[8] * 1.0f;
+    const float inv = 1.0f / h2;
+    nx = h0 * inv, ny = h1 * inv, nid = 0.0f;
+  } else {
+    const float depth = 1.0f / idepth;
+    float p0 = geo.Kinv[0] * u.x + geo.Kinv[2], p1 = geo.Kinv[4] * u.y + geo.Kinv[5], p2 = 1.0f;
+    p0 *= depth, p1 *= depth, p2 *= depth;
+    const float w = geo.q[0], ux = geo.q[1], uy = geo.q[2], uz = geo.q[3];
+    float uvx = uy * p2 - uz * p1;
+    float uvy = uz * p0 - ux * p2;
+    float uvz = ux * p1 - uy * p0;
+    uvx += uvx, uvy += uvy, uvz += uvz;
+    const float cx = uy * uvz - uz * uvy;
+    const float cy = uz * uvx - ux * uvz;
+    const float cz = ux * uvy - uy * uvx;
+    const float pc0 = ((p0 + w * uvx) + cx) + geo.t[0];
+    const float pc1 = ((p1 + w * uvy) + cy) + geo.t[1];
+    const float pc2 = ((p2 + w * uvz) + cz) + geo.t[2];
+    const float u0 = geo.K[0] * pc0 + geo.K[2] * pc2, u1 = geo.K[4] * pc1 + geo.K[5] * pc2;
+    nid = 1.0f / pc2;
+    nx = u0 * nid, ny = u1 * nid;
+  }
+  pos[v] = make_float2(nx, ny);
+  x[v] = nid / graph_scale;
+  const bool inside = geo.rx <= nx && nx < geo.rx + geo.rw && geo.ry <= ny && ny < geo.ry + geo.rh;
+  keep[v] = (inside && !(nid < 0.0f)) ? 1 : 0;
+}
+
+__global__ void k_rescale_mean(int V, const float* __restrict__ data, float graph_scale, float* __restrict__ out2) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  float sum = 0.0f;
+  for (int v = 0; v < V; ++v) sum += data[v] * graph_scale;
+  out2[0] = sum / V;  // new_scale
+}
+
+__global__ void __launch_bounds__(256)
+k_rescale_apply(int V, float* __restrict__ x, float* __restrict__ xb, float* __restrict__ xp, float* __restrict__ data,
+                float graph_scale, const float* __restrict__ new_scale_p) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const float ns = new_scale_p[0];
+  x[v] = x[v] * graph_scale / ns;
+  xb[v] = xb[v] * graph_scale / ns;
+  xp[v] = xp[v] * graph_scale / ns;
+  data[v] = data[v] * graph_scale / ns;
+}
+
 inline dim3 grid1d(int64_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
 }  // namespace
@@ -1238,6 +1308,20 @@ int launch_export(const CanonArgs& c, const FusedArgs& a, bool packed_current, f
   } else {
     hipLaunchKernelGGL(k_export_canonical, grid1d(c.V), dim3(256), 0, s, c.V, c.x, scale, dst);
   }
+  return (int)hipGetLastError();
+}
+
+int launch_project_graph(const CanonArgs& c, float graph_scale, const ProjectGeometry& geo, uint8_t* keep, hipStream_t s) {
+  if (c.V <= 0) return 0;
+  hipLaunchKernelGGL(k_project_graph, grid1d(c.V), dim3(256), 0, s, c.V, c.pos, c.x, graph_scale, geo, keep);
+  return (int)hipGetLastError();
+}
+
+int launch_rescale(const CanonArgs& c, float graph_scale, float* new_scale_dev, hipStream_t s) {
+  if (c.V <= 0) return 0;
+  hipLaunchKernelGGL(k_rescale_mean, dim3(1), dim3(64), 0, s, c.V, c.data, graph_scale, new_scale_dev);
+  hipLaunchKernelGGL(k_rescale_apply, grid1d(c.V), dim3(256), 0, s, c.V, c.x, c.xb, c.xp, c.data, graph_scale,
+                     new_scale_dev);
   return (int)hipGetLastError();
 }
 

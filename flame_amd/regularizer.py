@@ -65,6 +65,12 @@ class _SyncInput(C.Structure):
                 ("sticky_threshold", C.c_float)]
 
 
+class _Projection(C.Structure):
+    _fields_ = [("K", C.c_float * 9), ("Kinv", C.c_float * 9), ("KRKinv", C.c_float * 9), ("q_ref_to_cmp", C.c_float * 4),
+                ("t_ref_to_cmp", C.c_float * 3), ("region_x", C.c_float), ("region_y", C.c_float), ("region_w", C.c_float),
+                ("region_h", C.c_float)]
+
+
 class _Info(C.Structure):
     _fields_ = [
         ("abi_version", C.c_int32), ("device", C.c_int32), ("V", C.c_int32), ("E", C.c_int32),
@@ -90,7 +96,7 @@ ABI_SYMBOLS = (
     "flame_nltgv2_status_string", "flame_nltgv2_abi_version", "flame_nltgv2_pack_probe",
     "flame_nltgv2_photo_set_images", "flame_nltgv2_photo_residual", "flame_nltgv2_sync_graph",
     "flame_nltgv2_get_topology", "flame_nltgv2_set_feature_ids", "flame_nltgv2_interpolate_mesh",
-    "flame_nltgv2_interpolate_mesh_arrays",
+    "flame_nltgv2_interpolate_mesh_arrays", "flame_nltgv2_project_graph", "flame_nltgv2_rescale_data",
 )
 
 
@@ -138,6 +144,8 @@ def load_library():
         "flame_nltgv2_sync_graph": (C.c_int, [ctx, C.POINTER(_SyncInput)]),
         "flame_nltgv2_get_topology": (C.c_int, [ctx, _IP, _IP, _IP]),
         "flame_nltgv2_set_feature_ids": (C.c_int, [ctx, _IP]),
+        "flame_nltgv2_project_graph": (C.c_int, [ctx, C.POINTER(_Projection), C.c_float, C.POINTER(C.c_uint8), _FP]),
+        "flame_nltgv2_rescale_data": (C.c_int, [ctx, C.c_float, _FP, PP]),
         "flame_nltgv2_interpolate_mesh": (C.c_int, [ctx, _IP, C.c_int32, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_float,
                                                     _FP, _IP]),
         "flame_nltgv2_interpolate_mesh_arrays": (C.c_int, [ctx, _IP, C.c_int32, _FP, _FP, C.c_int32, C.POINTER(C.c_uint8),
@@ -276,6 +284,27 @@ class Regularizer:
         self._chk(self._L.flame_nltgv2_get_topology(self._ctx, src.ctypes.data_as(_IP), dst.ctypes.data_as(_IP),
                                                      fid.ctypes.data_as(_IP)), "get_topology")
         return src, dst, fid
+
+    def project_graph(self, K, Kinv, KRKinv, q, t, region, graph_scale=1.0):
+        """Flame::projectGraph on the device state; returns (keep mask, new positions)."""
+        pr = _Projection()
+        for name, a, n in (("K", K, 9), ("Kinv", Kinv, 9), ("KRKinv", KRKinv, 9), ("q_ref_to_cmp", q, 4), ("t_ref_to_cmp", t, 3)):
+            arr = np.ascontiguousarray(a, np.float32).reshape(n)
+            setattr(pr, name, (C.c_float * n)(*arr.tolist()))
+        pr.region_x, pr.region_y, pr.region_w, pr.region_h = [float(r) for r in region]
+        keep = np.zeros(self.V, np.uint8)
+        pos = np.empty((self.V, 2), np.float32)
+        self._chk(self._L.flame_nltgv2_project_graph(self._ctx, C.byref(pr), C.c_float(graph_scale),
+                                                     keep.ctypes.data_as(C.POINTER(C.c_uint8)), pos.ctypes.data_as(_FP)),
+                  "project_graph")
+        return keep, pos
+
+    def rescale_data(self, graph_scale, params: Params):
+        """The rescale_data block (flame.cc:328-351); updates params.data_factor; returns the new graph scale."""
+        ns = C.c_float(0)
+        self._chk(self._L.flame_nltgv2_rescale_data(self._ctx, C.c_float(graph_scale), C.byref(ns), C.byref(params)),
+                  "rescale_data")
+        return float(ns.value)
 
     def update_data(self, data_term, data_weight):
         d = _as(data_term, np.float32, self.V, "data_term")

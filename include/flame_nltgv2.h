@@ -118,6 +118,26 @@ int flame_nltgv2_set_feature_ids(flame_nltgv2_ctx* ctx, const int32_t* feat_id);
 /* Current edge list / feature ids (E, E, V ints; any pointer may be NULL). */
 int flame_nltgv2_get_topology(flame_nltgv2_ctx* ctx, int32_t* src, int32_t* dst, int32_t* feat_id);
 
+/* Flame::projectGraph (flame.cc:1888-1905) on the device state: every vertex is re-projected into the new
+ * frame with EpipolarGeometry::project(pos, x*graph_scale, &u_new, &idepth_new)
+ * (stereo/epipolar_geometry.h:152-180); pos and x = idepth_new/graph_scale are written back; keep_out[v] = 0
+ * where the reference would remove the vertex (outside the valid region, cv::Rect_<float>::contains, or
+ * idepth_new < 0; flame.cc:1902-1906).  pos_out (2V floats, may be NULL) receives the new positions for the
+ * host's re-triangulation.  Removal itself happens in the following flame_nltgv2_sync_graph, as in the
+ * reference (projectGraph is always followed by syncGraph, flame.cc:301-318).
+ * All matrices row-major 3x3 as EpipolarGeometry holds them; q = (w,x,y,z). */
+typedef struct flame_nltgv2_projection {
+  float K[9], Kinv[9], KRKinv[9];
+  float q_ref_to_cmp[4];
+  float t_ref_to_cmp[3];
+  float region_x, region_y, region_w, region_h; /* valid_region, flame.cc:1881-1884 */
+} flame_nltgv2_projection;
+int flame_nltgv2_project_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_projection* pr, float graph_scale,
+                               uint8_t* keep_out, float* pos_out);
+/* The rescale_data block of Flame::update (flame.cc:328-351): new_scale = mean(data_term*graph_scale);
+ * x, x_bar, x_prev, data_term *= graph_scale/new_scale; params->data_factor *= new_scale/graph_scale. */
+int flame_nltgv2_rescale_data(flame_nltgv2_ctx* ctx, float graph_scale, float* new_graph_scale, flame_nltgv2_params* params);
+
 /* Per-frame refresh of data_term/data_weight for an unchanged topology (flame.cc:1985-2018). */
 int flame_nltgv2_update_data(flame_nltgv2_ctx* ctx, const float* data_term, const float* data_weight);
 

@@ -80,6 +80,10 @@ def lib():
         L.photo_bilinear_u8.restype = C.c_float
         L.photo_residual.argtypes = [C.c_int, _FP, _FP, C.c_float, _FP, _FP, U8, U8, C.c_int, C.c_int, C.c_int, C.c_int, _FP]
         L.photo_residual.restype = None
+        L.graph_project.argtypes = [C.c_int, _FP, _FP, C.c_float, _FP, _FP, _FP, _FP, _FP] + [C.c_float] * 4 + [U8]
+        L.graph_project.restype = None
+        L.graph_rescale.argtypes = [C.c_int, _FP, _FP, _FP, _FP, C.c_float, _FP]
+        L.graph_rescale.restype = C.c_float
         L.raster_triangle_barycentric.argtypes = [C.c_int] * 6 + [C.c_float] * 3 + [_FP, C.c_int, C.c_int]
         L.raster_triangle_barycentric.restype = None
         L.raster_interpolate_mesh.argtypes = [C.c_int, _IP, _FP, _FP, U8, U8, _FP, C.c_int, C.c_int]
@@ -209,3 +213,24 @@ def raster_interpolate_mesh(tris, vtx_xy, values, rows, cols, tri_valid=None, vt
 
 def raster_coverage(img):
     return int(lib().raster_coverage(img.ctypes.data_as(_FP), img.shape[0], img.shape[1]))
+
+
+# ---- graph maintenance (projectGraph / rescale_data), oracle/photometric_oracle.c -----------------------
+def graph_project(pos, x, graph_scale, K, Kinv, q, t, KRKinv, region):
+    """In place on pos (V,2) and x; returns the keep mask."""
+    f = lambda a, n: np.ascontiguousarray(a, np.float32).reshape(n)  # noqa: E731
+    assert pos.dtype == np.float32 and x.dtype == np.float32 and pos.flags["C_CONTIGUOUS"]
+    keep = np.zeros(x.shape[0], np.uint8)
+    k, ki, qq, tt, kr = f(K, 9), f(Kinv, 9), f(q, 4), f(t, 3), f(KRKinv, 9)
+    lib().graph_project(x.shape[0], pos.ctypes.data_as(_FP), x.ctypes.data_as(_FP), graph_scale, k.ctypes.data_as(_FP),
+                        ki.ctypes.data_as(_FP), qq.ctypes.data_as(_FP), tt.ctypes.data_as(_FP), kr.ctypes.data_as(_FP),
+                        region[0], region[1], region[2], region[3], keep.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return keep
+
+
+def graph_rescale(g, graph_scale, data_factor):
+    df = C.c_float(data_factor)
+    new_scale = lib().graph_rescale(int(g["V"]), g["x"].ctypes.data_as(_FP), g["x_bar"].ctypes.data_as(_FP),
+                                    g["x_prev"].ctypes.data_as(_FP), g["data_term"].ctypes.data_as(_FP), graph_scale,
+                                    C.byref(df))
+    return float(new_scale), float(df.value)

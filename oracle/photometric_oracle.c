@@ -76,3 +76,74 @@ void photo_residual(int V, const float* pos, const float* x, float graph_scale, 
     err[v] = (d > 0) ? d : -d; /* utils::fast_abs */
   }
 }
+
+/* ------------------------------------------------------------------------------------------------------
+ * Graph maintenance pieces of SURVEY.md 8(f) rank 1 (test infrastructure; UNPINNED: Eigen is not
+ * available to check the quaternion product against, and the reference has no test for these):
+ *   Flame::projectGraph            /root/reference/src/flame/flame.cc:1862-1938 (re-projection + the
+ *                                   keep/remove decision; do_grad_check_after_projection = false)
+ *   EpipolarGeometry::project(u_ref, idepth, &u_cmp, &new_idepth)   stereo/epipolar_geometry.h:152-180
+ *   Eigen::Quaternion * Vector3 (_transformVector): uv = q.vec x v; uv += uv; v + q.w*uv + q.vec x uv
+ *   rescale_data block             flame.cc:328-351
+ * q = (w, x, y, z) of q_ref_to_cmp; K, Kinv row-major 3x3 (only the entries the reference reads are used).
+ * ------------------------------------------------------------------------------------------------------ */
+static void quat_rotate(const float* q, const float* v, float* out) {
+  const float w = q[0], ux = q[1], uy = q[2], uz = q[3];
+  float uvx = uy * v[2] - uz * v[1];
+  float uvy = uz * v[0] - ux * v[2];
+  float uvz = ux * v[1] - uy * v[0];
+  uvx += uvx, uvy += uvy, uvz += uvz;
+  const float cx = uy * uvz - uz * uvy;
+  const float cy = uz * uvx - ux * uvz;
+  const float cz = ux * uvy - uy * uvx;
+  out[0] = (v[0] + w * uvx) + cx;
+  out[1] = (v[1] + w * uvy) + cy;
+  out[2] = (v[2] + w * uvz) + cz;
+}
+
+void graph_project(int V, float* pos, float* x, float graph_scale, const float* K, const float* Kinv, const float* q,
+                   const float* t, const float* KRKinv, float rx, float ry, float rw, float rh, uint8_t* keep) {
+  for (int v = 0; v < V; ++v) {
+    const float ux = pos[2 * v], uy = pos[2 * v + 1];
+    const float idepth = x[v] * graph_scale;
+    float nx, ny, nid;
+    if (idepth == 0.0f) { /* h:155-161: maxDepthProjection */
+      const float h0 = (KRKinv[0] * ux + KRKinv[1] * uy) + KRKinv[2] * 1.0f;
+      const float h1 = (KRKinv[3] * ux + KRKinv[4] * uy) + KRKinv[5] * 1.0f;
+      const float h2 = (KRKinv[6] * ux + KRKinv[7] * uy) + KRKinv[8] * 1.0f;
+      const float inv = 1.0f / h2;
+      nx = h0 * inv, ny = h1 * inv, nid = 0.0f;
+    } else {
+      const float depth = 1.0f / idepth;
+      float p_ref[3] = {Kinv[0] * ux + Kinv[2], Kinv[4] * uy + Kinv[5], 1.0f};
+      p_ref[0] *= depth, p_ref[1] *= depth, p_ref[2] *= depth;
+      float r[3];
+      quat_rotate(q, p_ref, r);
+      const float pc0 = r[0] + t[0], pc1 = r[1] + t[1], pc2 = r[2] + t[2];
+      const float u0 = K[0] * pc0 + K[2] * pc2, u1 = K[4] * pc1 + K[5] * pc2;
+      nid = 1.0f / pc2;
+      nx = u0 * nid, ny = u1 * nid;
+    }
+    pos[2 * v] = nx, pos[2 * v + 1] = ny;
+    x[v] = nid / graph_scale; /* flame.cc:1899-1900 */
+    /* cv::Rect_<float>::contains: x <= pt.x < x + width, same for y (flame.cc:1902) */
+    const int inside = rx <= nx && nx < rx + rw && ry <= ny && ny < ry + rh;
+    keep[v] = (uint8_t)(inside && !(nid < 0.0f));
+  }
+}
+
+/* flame.cc:328-351; the sum runs in the caller's vertex order (the reference's is BGL hash order). */
+float graph_rescale(int V, float* x, float* x_bar, float* x_prev, float* data_term, float graph_scale,
+                    float* data_factor) {
+  float idepth_sum = 0.0f;
+  for (int v = 0; v < V; ++v) idepth_sum += data_term[v] * graph_scale;
+  const float new_scale = idepth_sum / V;
+  for (int v = 0; v < V; ++v) {
+    x[v] = x[v] * graph_scale / new_scale;
+    x_bar[v] = x_bar[v] * graph_scale / new_scale;
+    x_prev[v] = x_prev[v] * graph_scale / new_scale;
+    data_term[v] = data_term[v] * graph_scale / new_scale;
+  }
+  *data_factor *= new_scale / graph_scale;
+  return new_scale;
+}
