@@ -63,12 +63,11 @@ struct flame_nltgv2_ctx {
   bool canon_valid = false, fused_valid = false, have_prev = false;
   int parity = 0;
   uint64_t topo = 0, stamp = 0;
-  bool pointers_changed = false;
 
   int opt_solver = 0, opt_use_graph = 1, opt_block_waves = 0, opt_unroll = 0, opt_persistent = 1, opt_dual = 1;
   uint32_t tag_next = 1;  // persistent run: tag of the current bar values (monotonic)
-  bool state_lost = false;
   int last_run_path = 0;
+  uint64_t persist_refused_topo = ~0ull;  // topology for which the runtime refused the persistent grid
   bool static_stale = false;  // pos changed on the device (project_graph): packed alpha/dx/dy need a re-pack
   uint64_t coop_checked_key = 0;  // (topology, form) whose persistent grid the runtime has verified as resident
 
@@ -136,7 +135,6 @@ int ensure(flame_nltgv2_ctx* ctx, DevBuf& b, size_t bytes) {
   }
   b.cap = want;
   ctx->device_bytes += want;
-  ctx->pointers_changed = true;
   return 0;
 }
 
@@ -230,6 +228,7 @@ void pick_config(const flame_nltgv2_ctx* ctx, int* unroll, int* wpb) {
 // once more than ~kHeWavesPerCuSweet waves of form 1 would share a CU).
 int persistent_form(const flame_nltgv2_ctx* ctx, int n) {
   if (!ctx->opt_persistent || n < 4 || n > (1 << 24) || !ctx->prop.cooperativeLaunch) return 0;
+  if (ctx->persist_refused_topo == ctx->topo) return 0;
   const int cus = ctx->prop.multiProcessorCount;
   const bool he_fits = ctx->L.he_ok && ctx->L.he_waves > 0 && ctx->L.he_waves <= 24 * cus;
   const bool tv_fits = ctx->L.tv_ok && ctx->L.tv_waves > 0 && ctx->L.tv_waves <= kTvWavesPerCu * cus;
@@ -361,8 +360,8 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       ctx->canon_valid = false;
       return 0;
     }
-    (void)hipGetLastError();  // e.g. cooperative launch too large: fall through to per-step launches
-    if (ctx->opt_persistent == 1 || ctx->opt_persistent == form + 1) ctx->opt_persistent = 0;
+    (void)hipGetLastError();  // e.g. cooperative launch too large: fall through to per-step launches,
+    ctx->persist_refused_topo = ctx->topo;  // and do not try again for this topology
   }
   int left = n;
   while (left > 0) {
@@ -580,7 +579,6 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
 
   // Make sure nothing in flight still uses buffers we may reallocate.
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->pointers_changed = false;
   const size_t fV = sizeof(float) * (size_t)V, fE = sizeof(float) * (size_t)E;
   struct { DevBuf* b; size_t bytes; } req[] = {
       {&ctx->pos, 2 * fV}, {&ctx->x, fV}, {&ctx->w1, fV}, {&ctx->w2, fV}, {&ctx->xb, fV}, {&ctx->w1b, fV},
@@ -642,7 +640,6 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
   HIPCHK(ctx, hipMemsetAsync(ctx->abort_flag.p, 0, sizeof(int), ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->xbuf.p, 0, 68 * n_packed + 64, ctx->stream));
   ctx->tag_next = 1;
-  ctx->state_lost = false;
   ctx->static_stale = false;
   LAUNCHCHK(ctx, launch_pack_static(ctx->c, ctx->f, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors / caller arrays may go away

@@ -51,19 +51,45 @@ class IdepthGather:
         dist.all_gather_into_tensor(sizes, mine)
         self.sizes = sizes.cpu().view(self.world, max(self.slots, 1))
         self.vmax = int(self.sizes.max().item()) if n_frames else 0
-        self.local = torch.zeros(max(self.slots, 1), max(self.vmax, 1), dtype=torch.float32, device=device)
-        self.gathered = torch.empty(self.world * max(self.slots, 1), max(self.vmax, 1), dtype=torch.float32,
-                                    device=device)
+        # double buffered: the gather of step k runs (on the collective's stream) while the solver already
+        # works on step k+1 and exports into the other buffer
+        shape_l = (max(self.slots, 1), max(self.vmax, 1))
+        shape_g = (self.world * max(self.slots, 1), max(self.vmax, 1))
+        self._local = [torch.zeros(shape_l, dtype=torch.float32, device=device) for _ in range(2)]
+        self._gathered = [torch.empty(shape_g, dtype=torch.float32, device=device) for _ in range(2)]
+        self._work = [None, None]
+        self._cur = 0
+        self.local = self._local[0]
+        self.gathered = self._gathered[0]
 
     def local_row(self, i: int) -> torch.Tensor:
-        """Device row the solver of local frame i writes its x*scale into (first V entries)."""
-        return self.local[i]
+        """Device row the solver of local frame i writes its x*scale into (first V entries).  Valid until
+        the next gather(); waits for the collective that last read this buffer."""
+        if self._work[self._cur] is not None:
+            self._work[self._cur].wait()
+            self._work[self._cur] = None
+        return self._local[self._cur][i]
 
-    def gather(self) -> None:
-        self.dist.all_gather_into_tensor(self.gathered, self.local)
+    def gather(self, async_op: bool = False) -> None:
+        """all_gather of the current local buffer.  async_op=True returns at once; frame() / wait() or the
+        next reuse of the buffer completes it."""
+        k = self._cur
+        w = self.dist.all_gather_into_tensor(self._gathered[k], self._local[k], async_op=async_op)
+        self._work[k] = w if async_op else None
+        self.gathered = self._gathered[k]
+        self._last = k
+        self._cur = 1 - k
+        self.local = self._local[self._cur]
+
+    def wait(self) -> None:
+        for k in (0, 1):
+            if self._work[k] is not None:
+                self._work[k].wait()
+                self._work[k] = None
 
     def frame(self, frame_id: int) -> torch.Tensor:
-        """x*scale of global frame `frame_id` (valid after gather())."""
+        """x*scale of global frame `frame_id` from the most recent gather()."""
+        self.wait()
         counts = frames_per_rank(self.n_frames, self.world)
         r, acc = 0, 0
         while frame_id >= acc + counts[r]:
