@@ -113,10 +113,15 @@ def main():
         from flame_amd.frames import IdepthGather
 
         ig = IdepthGather(dist, [g["V"]], world, torch.device("cuda", local_rank))
+        # the solver runs on a torch stream so that export -> all_gather is ordered on the device, without
+        # a host round trip between them
+        solver_stream = torch.cuda.Stream(device=local_rank)
+        reg.set_stream(solver_stream.cuda_stream)
 
         def after_step():
-            reg.export_idepth_device(ig.local_row(0).data_ptr(), 1.0)
-            ig.gather(async_op=True)  # overlaps the next step's solve; completed before the buffer is reused
+            reg.export_idepth_device(ig.local_row(0).data_ptr(), 1.0, wait=False)
+            with torch.cuda.stream(solver_stream):
+                ig.gather(async_op=True)  # overlaps the next step's solve; completed before the buffer is reused
 
     wall, ev_ms = measure(reg, params, a.iters, a.steps, a.warmup, sync, barrier, after_step)
     if dist is not None:

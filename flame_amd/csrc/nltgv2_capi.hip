@@ -1012,15 +1012,23 @@ int flame_nltgv2_download_state(flame_nltgv2_ctx* ctx, flame_nltgv2_graph* out) 
   return finish(ctx);
 }
 
-int flame_nltgv2_export_idepth_device(flame_nltgv2_ctx* ctx, void* dst_device, float scale) {
+static int export_idepth(flame_nltgv2_ctx* ctx, void* dst_device, float scale, bool wait) {
   int rc = enter(ctx);
   if (rc) return rc;
   if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
   if (!dst_device && ctx->L.V > 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
   const bool packed = !ctx->canon_valid;
   LAUNCHCHK(ctx, launch_export(ctx->c, ctx->f, packed, scale, (float*)dst_device, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (wait) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_export_idepth_device(flame_nltgv2_ctx* ctx, void* dst_device, float scale) {
+  return export_idepth(ctx, dst_device, scale, true);
+}
+
+int flame_nltgv2_export_idepth_device_async(flame_nltgv2_ctx* ctx, void* dst_device, float scale) {
+  return export_idepth(ctx, dst_device, scale, false);
 }
 
 // Shared tail of the two interpolate_mesh entry points: triangles/validity -> device, rasterise, copy back.

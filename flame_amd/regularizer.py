@@ -92,6 +92,7 @@ ABI_SYMBOLS = (
     "flame_nltgv2_run_async", "flame_nltgv2_sync", "flame_nltgv2_run_timed", "flame_nltgv2_save_prev",
     "flame_nltgv2_dual_step", "flame_nltgv2_primal_step", "flame_nltgv2_extragradient_step", "flame_nltgv2_step",
     "flame_nltgv2_costs", "flame_nltgv2_download_state", "flame_nltgv2_export_idepth_device",
+    "flame_nltgv2_export_idepth_device_async",
     "flame_nltgv2_set_option", "flame_nltgv2_get_info", "flame_nltgv2_last_error", "flame_nltgv2_last_hip_error",
     "flame_nltgv2_status_string", "flame_nltgv2_abi_version", "flame_nltgv2_pack_probe",
     "flame_nltgv2_photo_set_images", "flame_nltgv2_photo_residual", "flame_nltgv2_sync_graph",
@@ -132,6 +133,7 @@ def load_library():
         "flame_nltgv2_costs": (C.c_int, [ctx, PP, _FP, _FP]),
         "flame_nltgv2_download_state": (C.c_int, [ctx, GP]),
         "flame_nltgv2_export_idepth_device": (C.c_int, [ctx, C.c_void_p, C.c_float]),
+        "flame_nltgv2_export_idepth_device_async": (C.c_int, [ctx, C.c_void_p, C.c_float]),
         "flame_nltgv2_set_option": (C.c_int, [ctx, C.c_int, C.c_int]),
         "flame_nltgv2_get_info": (C.c_int, [ctx, C.POINTER(_Info)]),
         "flame_nltgv2_last_error": (C.c_int, [ctx]),
@@ -432,9 +434,9 @@ class Regularizer:
     def set_option(self, option: int, value: int):
         self._chk(self._L.flame_nltgv2_set_option(self._ctx, int(option), int(value)), "set_option")
 
-    def export_idepth_device(self, device_ptr: int, scale: float = 1.0):
-        self._chk(self._L.flame_nltgv2_export_idepth_device(self._ctx, C.c_void_p(device_ptr), C.c_float(scale)),
-                  "export_idepth_device")
+    def export_idepth_device(self, device_ptr: int, scale: float = 1.0, wait: bool = True):
+        fn = self._L.flame_nltgv2_export_idepth_device if wait else self._L.flame_nltgv2_export_idepth_device_async
+        self._chk(fn(self._ctx, C.c_void_p(device_ptr), C.c_float(scale)), "export_idepth_device")
 
     def info(self) -> dict:
         i = _Info()

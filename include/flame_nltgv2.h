@@ -179,6 +179,9 @@ int flame_nltgv2_download_state(flame_nltgv2_ctx* ctx, flame_nltgv2_graph* out);
  * context's stream: the `vtx.x * graph_scale_` of flame.cc:377, kept on the GPU so that a
  * multi-GPU host can hand the buffer straight to an RCCL gather. */
 int flame_nltgv2_export_idepth_device(flame_nltgv2_ctx* ctx, void* dst_device, float scale);
+/* Same, enqueue only: ordered on the context's stream (see flame_nltgv2_set_stream), no host wait -- a
+ * collective enqueued on the same stream afterwards reads the finished buffer. */
+int flame_nltgv2_export_idepth_device_async(flame_nltgv2_ctx* ctx, void* dst_device, float scale);
 
 /* Mesh -> dense inverse-depth map, the step right after the solver each frame:
  * utils::interpolateMesh (utils/image_utils.cc:373-396) over utils::DrawShadedTriangleBarycentric
