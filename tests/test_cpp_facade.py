@@ -20,6 +20,29 @@ def build_program(tmp_path):
     return exe
 
 
+def build_bgl_program(tmp_path):
+    exe = str(tmp_path / "bgl_adaptor_test")
+    lib_dir = os.path.join(ROOT, "flame_amd")
+    subprocess.check_call([
+        "g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "tests", "cpp", "mock_boost"),
+        "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "bgl_adaptor_test.cc"), "-o", exe,
+        "-L", lib_dir, "-lflame_nltgv2_hip", "-L", os.path.join(ROOT, "oracle"), "-loracle_nltgv2",
+        f"-Wl,-rpath,{lib_dir}", f"-Wl,-rpath,{os.path.join(ROOT, 'oracle')}", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_bgl_adaptor_compiles_against_the_bgl_api(built, tmp_path):
+    """include/flame_hip/bgl_adaptor.hpp against a test-only mock of the Boost.Graph calls it makes."""
+    assert os.path.exists(build_bgl_program(tmp_path))
+
+
+@pytest.mark.gpu
+def test_bgl_adaptor_end_to_end(built, tmp_path):
+    r = subprocess.run([build_bgl_program(tmp_path)], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_facade_compiles_as_cxx11_and_links(built, tmp_path):
     assert os.path.exists(build_program(tmp_path))
 
