@@ -29,9 +29,9 @@ namespace {
 constexpr int kGraphChunk = 256;      // steps per captured hipGraph (even: keeps ping-pong parity)
 constexpr int kCostPartials = 256;
 constexpr int kMaxCachedGraphs = 6;
+constexpr int kHeWavesPerCu = 24;      // residency cap of k_persistent_he (<= 64 VGPRs: the hardware admits 32)
 constexpr int kTvWavesPerCu = 8;       // residency of k_persistent_tv (<= 256 VGPRs -> 2 waves per SIMD)
 constexpr int kDualMinWavesPerCu = 5;  // auto: exchange through the XCD's L2 when more waves than this share a CU
-constexpr int kHeWavesPerCuSweet = 24; // lane-per-half-edge form whenever it is resident (measured faster up to 22 waves per CU)
 constexpr int kPreSleep = 12;  // initial x64-cycle sleep between publishing and the first neighbour poll (adapts)
 constexpr unsigned kMaxSpins = 1u << 20;  // bound of every neighbour wait in the persistent run (~1 s of polling bursts)
 
@@ -66,7 +66,7 @@ struct flame_nltgv2_ctx {
 
   int opt_solver = 0, opt_use_graph = 1, opt_block_waves = 0, opt_unroll = 0, opt_persistent = 1, opt_dual = 1;
   uint32_t tag_next = 1;  // persistent run: tag of the current bar values (monotonic)
-  int last_run_path = 0;
+  int last_run_path = 0, last_run_groups = 0;
   uint64_t persist_refused_topo = ~0ull;  // topology for which the runtime refused the persistent grid
   bool static_stale = false;  // pos changed on the device (project_graph): packed alpha/dx/dy need a re-pack
   uint64_t coop_checked_key = 0;  // (topology, form) whose persistent grid the runtime has verified as resident
@@ -223,22 +223,61 @@ void pick_config(const flame_nltgv2_ctx* ctx, int* unroll, int* wpb) {
   *wpb = ctx->opt_block_waves ? ctx->opt_block_waves : (small ? 1 : 4);
 }
 
-// Which persistent form (if any) runs n steps: 0 none (per-step launches), 1 lane-per-half-edge
-// (lowest latency while the chip is not issue bound), 2 vertex-per-lane (fewest instructions; wins
-// once more than ~kHeWavesPerCuSweet waves of form 1 would share a CU).
-int persistent_form(const flame_nltgv2_ctx* ctx, int n) {
+// A persistent launch covers a contiguous range of waves of one form.
+struct WaveGroup {
+  int begin, count;
+};
+
+// Which persistent form (if any) runs n steps -- 0 none (one launch per step), 1 lane-per-half-edge
+// (lowest latency), 2 vertex-per-lane (fewest instructions) -- and over which wave groups.  A graph that
+// is resident as a whole is one group.  A disjoint union too large for that (a big batch of frames) is run
+// group of connected components by group, each group resident on its own: the components are independent,
+// so running them one after the other for all n steps is exactly the same computation.
+int plan_persistent(const flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups) {
+  groups->clear();
   if (!ctx->opt_persistent || n < 4 || n > (1 << 24) || !ctx->prop.cooperativeLaunch) return 0;
   if (ctx->persist_refused_topo == ctx->topo) return 0;
+  const PackedLayout& L = ctx->L;
   const int cus = ctx->prop.multiProcessorCount;
-  const bool he_fits = ctx->L.he_ok && ctx->L.he_waves > 0 && ctx->L.he_waves <= 24 * cus;
-  const bool tv_fits = ctx->L.tv_ok && ctx->L.tv_waves > 0 && ctx->L.tv_waves <= kTvWavesPerCu * cus;
-  if (ctx->opt_persistent == 2) return he_fits ? 1 : 0;
-  if (ctx->opt_persistent == 3) return tv_fits ? 2 : 0;
-  if (he_fits && ctx->L.he_waves <= kHeWavesPerCuSweet * cus) return 1;
-  if (tv_fits) return 2;
-  return he_fits ? 1 : 0;
+  const int he_cap = kHeWavesPerCu * cus, tv_cap = kTvWavesPerCu * cus;
+  const bool he_fits = L.he_ok && L.he_waves > 0 && L.he_waves <= he_cap;
+  const bool tv_fits = L.tv_ok && L.tv_waves > 0 && L.tv_waves <= tv_cap;
+  if (ctx->opt_persistent == 2 && !L.he_ok) return 0;
+  if (ctx->opt_persistent == 3 && !L.tv_ok) return 0;
+  int form = 0;
+  if (ctx->opt_persistent == 2) form = 1;
+  else if (ctx->opt_persistent == 3) form = 2;
+  else if (he_fits) form = 1;
+  else if (tv_fits) form = 2;
+  else form = L.tv_ok ? 2 : (L.he_ok ? 1 : 0);  // too big for one launch: vertex-per-lane groups
+  if (form == 0) return 0;
+  const int total = form == 2 ? L.tv_waves : L.he_waves;
+  const int cap = form == 2 ? tv_cap : he_cap;
+  if (total <= 0) return 0;
+  if (total <= cap) {
+    groups->push_back(WaveGroup{0, total});
+    return form;
+  }
+  const std::vector<int32_t>& cw = form == 2 ? L.comp_tv_wave : L.comp_he_wave;
+  if (cw.size() < 3) return 0;  // one component that does not fit: stream it
+  int begin = cw[0];
+  for (size_t c = 0; c + 1 < cw.size(); ++c) {
+    if (cw[c + 1] - cw[c] > cap) {  // a single component larger than the chip
+      groups->clear();
+      return 0;
+    }
+    if (cw[c + 1] - begin > cap) {
+      groups->push_back(WaveGroup{begin, cw[c] - begin});
+      begin = cw[c];
+    }
+  }
+  groups->push_back(WaveGroup{begin, cw.back() - begin});
+  return form;
 }
-bool persistent_eligible(const flame_nltgv2_ctx* ctx, int n) { return persistent_form(ctx, n) != 0; }
+bool persistent_eligible(const flame_nltgv2_ctx* ctx, int n) {
+  std::vector<WaveGroup> g;
+  return plan_persistent(ctx, n, &g) != 0;
+}
 
 bool same_params(const flame_nltgv2_params& a, const flame_nltgv2_params& b) {
   return std::memcmp(&a, &b, sizeof(a)) == 0;
@@ -332,36 +371,47 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   if (rc) return rc;
   int unroll, wpb;
   pick_config(ctx, &unroll, &wpb);
-  const int form = persistent_form(ctx, n);
+  std::vector<WaveGroup> groups;
+  const int form = plan_persistent(ctx, n, &groups);
   if (form != 0) {
-    // tags must stay unique: clear the granule buffers long before the 32-bit counter could wrap
-    if ((uint64_t)ctx->tag_next + (uint64_t)n >= 0x07ff0000ull) {  // 28-bit tags in the XCC table
+    // tags must stay unique: clear the record buffers long before the 28-bit tag of the XCC table wraps
+    if ((uint64_t)ctx->tag_next + (uint64_t)n >= 0x07ff0000ull) {
       const size_t bytes = 68 * (size_t)ctx->L.n_slices * kWave;
       HIPCHK(ctx, hipMemsetAsync(ctx->xbuf.p, 0, bytes, ctx->stream));
       ctx->tag_next = 1;
     }
-    const int nw = form == 2 ? ctx->L.tv_waves : ctx->L.he_waves;
-    const int pw = nw <= 4 * ctx->prop.multiProcessorCount ? 1 : 4;  // waves per workgroup
-    // same-XCD exchange through L2 pays once the memory side is busy (measured per step: 1080p graph
-    // -18 %, 7-frame batch -20 %, 15-frame batch -19 %, 1280x720 -5 %; a lone 640x480 frame at 3 waves
-    // per CU +6 %)
-    const int dual = ctx->opt_dual == 2 || (ctx->opt_dual == 1 && nw > kDualMinWavesPerCu * ctx->prop.multiProcessorCount);
-    // a fresh first tag per launch: records left by earlier runs (whose state may since have been
-    // changed by per-step launches or host uploads) can never satisfy a wait of this launch
+    // a fresh first tag per run: records left by earlier runs (whose state may since have been changed
+    // by per-step launches or host uploads) can never satisfy a wait of this one
     const uint32_t tag0 = ctx->tag_next + 2;
-    int e = launch_persistent_run(ctx->f, to_sp(p), form, ctx->parity, tag0, n, pw, kMaxSpins, kPreSleep,
-                                  dual, ctx->coop_checked_key != (ctx->topo * 4 + (uint64_t)form), ctx->stream);
+    const uint64_t key = ctx->topo * 4 + (uint64_t)form;
+    int e = 0;
+    for (const WaveGroup& gr : groups) {
+      const int pw = gr.count <= 4 * ctx->prop.multiProcessorCount ? 1 : 4;  // waves per workgroup
+      // same-XCD exchange through L2 pays once the memory side is busy (measured per step: 1080p graph
+      // -18 %, 7-frame batch -20 %, 15-frame batch -19 %, 1280x720 -5 %; a lone 640x480 frame at 3 waves
+      // per CU +6 %)
+      const int dual = ctx->opt_dual == 2 || (ctx->opt_dual == 1 && gr.count > kDualMinWavesPerCu * ctx->prop.multiProcessorCount);
+      e = launch_persistent_run(ctx->f, to_sp(p), form, gr.begin, gr.count, ctx->parity, tag0, n, pw, kMaxSpins,
+                                kPreSleep, dual, ctx->coop_checked_key != key, ctx->stream);
+      if (e != 0) break;
+    }
     if (e == 0) {
-      ctx->coop_checked_key = ctx->topo * 4 + (uint64_t)form;
+      ctx->coop_checked_key = key;
       ctx->tag_next = tag0 + (uint32_t)n;
       ctx->last_run_path = form == 2 ? 5 : 1;
+      ctx->last_run_groups = (int)groups.size();
       ctx->parity ^= (n & 1);
       ctx->have_prev = true;
       ctx->canon_valid = false;
       return 0;
     }
-    (void)hipGetLastError();  // e.g. cooperative launch too large: fall through to per-step launches,
-    ctx->persist_refused_topo = ctx->topo;  // and do not try again for this topology
+    (void)hipGetLastError();  // e.g. cooperative launch too large
+    ctx->persist_refused_topo = ctx->topo;  // do not try again for this topology
+    if (groups.size() > 1) {
+      // some groups may already have advanced n steps: the state is inconsistent
+      ctx->have_graph = false;
+      return fail(ctx, FLAME_NLTGV2_ERR_HIP);
+    }
   }
   int left = n;
   while (left > 0) {
@@ -1153,6 +1203,7 @@ int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info) {
   info->he_waves = ctx->L.he_ok ? ctx->L.he_waves : 0;
   info->tv_waves = ctx->L.tv_ok ? ctx->L.tv_waves : 0;
   info->tv_wave_capacity = kTvWavesPerCu * ctx->prop.multiProcessorCount;
+  info->last_run_groups = ctx->last_run_groups;
   return FLAME_NLTGV2_OK;
 }
 

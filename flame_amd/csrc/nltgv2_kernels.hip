@@ -243,7 +243,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(void* base) {
 constexpr unsigned kHeTailBit = 1u << 12, kHeActiveBit = 1u << 13, kHeValidBit = 1u << 14;
 
 __global__ void __launch_bounds__(256)
-k_persistent_he(const int n_waves, const int waves_per_xcd, const int32_t* __restrict__ he_slot,
+k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd, const int32_t* __restrict__ he_slot,
                 const int32_t* __restrict__ he_vid, const uint32_t* __restrict__ he_meta,
                 const int32_t* __restrict__ he_wave_chain, const int4* hrec, float4* hq, float4* vstate,
                 const float2* vaux, const float4* bar_in, float4* bar_out, float4* vprev, void* xbuf,
@@ -256,8 +256,8 @@ k_persistent_he(const int n_waves, const int waves_per_xcd, const int32_t* __res
   const int xcd = b & 7;
   const int idx = (b >> 3) * wpb + (threadIdx.x >> 6);
   if (idx >= waves_per_xcd) return;
-  const int w = xcd * waves_per_xcd + idx;
-  if (w >= n_waves) return;
+  if (xcd * waves_per_xcd + idx >= n_waves) return;
+  const int w = wave_begin + xcd * waves_per_xcd + idx;  // this launch covers waves [wave_begin, +n_waves)
 
   const size_t hl = (size_t)w * 64 + lane;
   const unsigned meta = he_meta[hl];
@@ -483,7 +483,7 @@ __device__ __forceinline__ float dpp_shr1(float v) {  // lane l <- lane l-1; lan
 }
 
 __global__ void __launch_bounds__(256)
-k_persistent_tv(const int n_waves, const int waves_per_xcd, const int32_t* __restrict__ tv_slot,
+k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd, const int32_t* __restrict__ tv_slot,
                 const int32_t* __restrict__ tv_vid, const uint32_t* __restrict__ tv_meta,
                 const uint32_t* __restrict__ tv_wave, const int4* hrec, float4* hq, float4* vstate,
                 const float2* vaux, const float4* bar_in, float4* bar_out, float4* vprev, void* xbuf,
@@ -496,8 +496,8 @@ k_persistent_tv(const int n_waves, const int waves_per_xcd, const int32_t* __res
   const int xcd = b & 7;
   const int idx = (b >> 3) * wpb + (threadIdx.x >> 6);
   if (idx >= waves_per_xcd) return;
-  const int w = xcd * waves_per_xcd + idx;
-  if (w >= n_waves) return;
+  if (xcd * waves_per_xcd + idx >= n_waves) return;
+  const int w = wave_begin + xcd * waves_per_xcd + idx;  // this launch covers waves [wave_begin, +n_waves)
 
   const unsigned meta = tv_meta[(size_t)w * 64 + lane];
   const int pv = tv_vid[(size_t)w * 64 + lane];
@@ -1200,10 +1200,9 @@ int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, boo
 // Persistent run (single launch).  form 1 = lane per half-edge (k_persistent_he), form 2 = vertex per
 // lane (k_persistent_tv).  Returns the hipError_t unchanged (e.g. hipErrorCooperativeLaunchTooLarge)
 // so the caller can fall back to per-step launches.
-int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, int parity_in, unsigned tag0,
-                          int n_iters, int waves_per_block, unsigned max_spins, int presleep, int dual,
-                          bool cooperative, hipStream_t stream) {
-  int n_waves = (form == 2) ? a.tv_waves : a.he_waves;
+int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, int wave_begin, int n_waves,
+                          int parity_in, unsigned tag0, int n_iters, int waves_per_block, unsigned max_spins,
+                          int presleep, int dual, bool cooperative, hipStream_t stream) {
   if (n_waves <= 0 || n_iters <= 0) return (int)hipSuccess;
   int wpx = (n_waves + 7) / 8;
   const int bpx = (wpx + waves_per_block - 1) / waves_per_block;
@@ -1224,7 +1223,7 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
   SolverParams pp = p;
   int* err = a.err;
   int* abort_flag = a.abort_flag;
-  void* args[] = {&n_waves, &wpx, &i0, &i1, &i2, &i3, &hrec, &hq, &vstate, &vaux, &bin,
+  void* args[] = {&wave_begin, &n_waves, &wpx, &i0, &i1, &i2, &i3, &hrec, &hq, &vstate, &vaux, &bin,
                   &bout, &vprev, &xbuf, &rec_bytes, &dual, &tag0, &n_iters, &max_spins, &presleep, &pp, &err,
                   &abort_flag};
   const void* fn = (form == 2) ? (const void*)k_persistent_tv : (const void*)k_persistent_he;

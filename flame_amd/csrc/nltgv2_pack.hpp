@@ -73,6 +73,11 @@ struct PackedLayout {
   std::vector<int32_t> tv_vid;    // [tv_waves*64] packed vertex the lane belongs to, -1 unused
   std::vector<uint32_t> tv_meta;  // [tv_waves*64] nslots | chain_idx<<4 | owner_lane<<10 | owner<<16 | valid<<17
   std::vector<uint32_t> tv_wave;  // [tv_waves] passes | has_chain<<8 | slots used in pass 0 <<16 | in later passes <<20
+  // connected components (= frames of a batch) are contiguous in packed order and never share a wave of
+  // (C)/(D): a batch too large to be resident at once is run group of components by group
+  std::vector<int32_t> comp_start;     // [n_comp+1] first packed vertex of each component
+  std::vector<int32_t> comp_he_wave;   // [n_comp+1] first (C) wave of each component
+  std::vector<int32_t> comp_tv_wave;   // [n_comp+1] first (D) wave of each component
 };
 constexpr int kTvSlots = 8;
 constexpr uint32_t kTvOwner = 1u << 16, kTvValid = 1u << 17;
@@ -175,6 +180,10 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
   }
 
   PROF_T(2);
+  L->comp_start.clear();
+  for (int32_t s = 0; s < V; ++s)
+    if (s == 0 || (key[order[s]] >> 32) != (key[order[s - 1]] >> 32)) L->comp_start.push_back(s);
+  L->comp_start.push_back(V);
   // ---- (B) SELL-64 ----------------------------------------------------------------------------
   const int32_t n_slices = (V + kWave - 1) / kWave;
   L->n_slices = n_slices;
@@ -230,12 +239,19 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
   L->he_waves = 0;
   L->he_max_chain = 0;
   L->he_slot.clear(), L->he_vid.clear(), L->he_meta.clear(), L->he_wave_chain.clear();
+  L->comp_he_wave.clear(), L->comp_tv_wave.clear();
   if (L->he_ok && V > 0) {
     int32_t fill = kWave;  // forces a new wave for the first vertex
+    size_t next_comp = 0;
     for (int32_t s = 0; s < V; ++s) {
       const int32_t d = L->pdeg[s];
       const int32_t need = std::max(d, 1);
-      if (fill + need > kWave) {
+      const bool comp_begin = next_comp < L->comp_start.size() && L->comp_start[next_comp] == s;
+      if (comp_begin) {
+        L->comp_he_wave.push_back(L->he_waves);
+        ++next_comp;
+      }
+      if (fill + need > kWave || comp_begin) {
         L->he_slot.resize(L->he_slot.size() + kWave, -1);
         L->he_vid.resize(L->he_vid.size() + kWave, -1);
         L->he_meta.resize(L->he_meta.size() + kWave, 0u);
@@ -260,6 +276,7 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
       L->he_max_chain = std::max(L->he_max_chain, need);
       fill += need;
     }
+    L->comp_he_wave.push_back(L->he_waves);
   }
 
   PROF_T(4);
@@ -269,10 +286,16 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
   L->tv_slot.clear(), L->tv_vid.clear(), L->tv_meta.clear(), L->tv_wave.clear();
   if (L->tv_ok && V > 0) {
     int32_t fill = kWave;
+    size_t next_comp = 0;
     for (int32_t s = 0; s < V; ++s) {
       const int32_t d = L->pdeg[s];
       const int32_t lanes = std::max(1, (d + kTvSlots - 1) / kTvSlots);
-      if (fill + lanes > kWave) {
+      const bool comp_begin = next_comp < L->comp_start.size() && L->comp_start[next_comp] == s;
+      if (comp_begin) {
+        L->comp_tv_wave.push_back(L->tv_waves);
+        ++next_comp;
+      }
+      if (fill + lanes > kWave || comp_begin) {
         L->tv_slot.resize(L->tv_slot.size() + static_cast<size_t>(kTvSlots) * kWave, -1);
         L->tv_vid.resize(L->tv_vid.size() + kWave, -1);
         L->tv_meta.resize(L->tv_meta.size() + kWave, 0u);
@@ -305,6 +328,7 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
       wi = passes | ((passes > 1u || (wi & 0x100u)) ? 0x100u : 0u) | (k_first << 16) | (k_later << 20);
       fill += lanes;
     }
+    L->comp_tv_wave.push_back(L->tv_waves);
   }
   PROF_T(5);
   return FLAME_NLTGV2_OK;

@@ -77,7 +77,7 @@ class _Info(C.Structure):
         ("n_slices", C.c_int32), ("max_degree", C.c_int32), ("padded_half_edges", C.c_int64),
         ("device_bytes", C.c_int64), ("algorithmic_bytes_per_iter", C.c_int64), ("compute_units", C.c_int32),
         ("device_name", C.c_char * 64), ("gcn_arch", C.c_char * 32), ("last_run_path", C.c_int32), ("he_waves", C.c_int32), ("tv_waves", C.c_int32),
-        ("tv_wave_capacity", C.c_int32),
+        ("tv_wave_capacity", C.c_int32), ("last_run_groups", C.c_int32),
     ]
 
 

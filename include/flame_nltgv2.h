@@ -246,6 +246,7 @@ typedef struct flame_nltgv2_info {
   int32_t he_waves;      /* waves of the lane-per-half-edge persistent form (0: not applicable) */
   int32_t tv_waves;      /* waves of the vertex-per-lane persistent form (0: not applicable) */
   int32_t tv_wave_capacity; /* vertex-per-lane waves the device keeps resident */
+  int32_t last_run_groups;  /* persistent launches the last run was split into (groups of whole components) */
 } flame_nltgv2_info;
 int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info);
 

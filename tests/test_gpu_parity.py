@@ -251,6 +251,29 @@ def test_batch_of_frames_equals_individual_frames(env):
         eo += f["E"]
 
 
+def test_large_batch_runs_as_groups_of_resident_frames(env):
+    """40 frames do not fit the chip at once: the persistent run is split into groups of whole frames
+    (connected components), which is the same computation because frames are independent."""
+    flame_amd, oracle = env
+    frames = [synth.make_graph("640x480", seed=300 + i) for i in range(40)]
+    union = synth.concat_graphs(frames)
+    with flame_amd.Regularizer(0) as reg:
+        reg.upload_graph(union)
+        reg.run(flame_amd.Params(), 30)
+        info = reg.info()
+        out = reg.download_state(("x", "w2", "x_bar", "q1"))
+    assert info["last_run_path"] == 5 and info["last_run_groups"] >= 2
+    vo = eo = 0
+    for i, f in enumerate(frames):
+        if i % 7 == 0 or i == len(frames) - 1:
+            ref, _ = cpu_run(oracle, f, 30)
+            for k in ("x", "w2", "x_bar"):
+                assert np.array_equal(out[k][vo:vo + f["V"]], ref[k]), (i, k)
+            assert np.array_equal(out["q1"][eo:eo + f["E"]], ref["q1"]), i
+        vo += f["V"]
+        eo += f["E"]
+
+
 def test_update_data_and_upload_state(env):
     """Per-frame path with unchanged topology: refresh data term (flam.cc:1985-2018), warm start kept;
     then a host-side rescale of x (flame.cc:328-351) pushed with upload_state."""
