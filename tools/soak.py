@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""tools/soak.py -- long-run exactness soak of the persistent dataflow kernels (GPU box).
+
+Every record hand-off of the persistent kernels is a 16-byte {value,tag} access; a torn or stale read
+would change some bit of the result.  This runs many more steps than the test-suite does, in every
+persistent configuration, and compares ALL state arrays with the CPU checker bit for bit."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch  # noqa
+import flame_amd
+from flame_amd import synth
+from flame_amd.regularizer import OPT_DUAL_PUBLISH, OPT_PERSISTENT
+from oracle import capi as oracle
+
+ITERS = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+LOAD = len(sys.argv) > 2 and sys.argv[2] == "load"  # run a competing HBM-streaming workload on another stream
+KEYS = ("x", "w1", "w2", "x_bar", "w1_bar", "w2_bar", "x_prev", "q1", "q2", "q3")
+results = []
+t_start = time.time()
+stop = False
+if LOAD:
+    import threading
+
+    def hog():
+        st = torch.cuda.Stream()
+        a = torch.empty(64 << 20, dtype=torch.float32, device="cuda")  # 256 MB: past the Infinity Cache
+        b = torch.empty_like(a)
+        with torch.cuda.stream(st):
+            while not stop:
+                for _ in range(8):
+                    b.copy_(a)
+                    a.add_(b, alpha=0.5)
+                st.synchronize()
+                time.sleep(0.002)  # uneven: bursts of streaming traffic with gaps
+
+    th = threading.Thread(target=hog, daemon=True)
+    th.start()
+cases = [("640x480", 1), ("1280x720", 2), ("320x240", 3)]
+for cfg, seed in cases:
+    g = synth.make_graph(cfg, seed=seed)
+    ref = synth.copy_graph(g)
+    t0 = time.time()
+    oracle.run(ref, ITERS)
+    cpu_s = time.time() - t0
+    for form, dual in ((2, 0), (2, 2), (3, 0), (3, 2)):
+        with flame_amd.Regularizer(0) as reg:
+            reg.set_option(OPT_PERSISTENT, form)
+            reg.set_option(OPT_DUAL_PUBLISH, dual)
+            reg.upload_graph(g)
+            done = 0
+            rng = np.random.default_rng(form * 10 + dual)
+            launches = 0
+            while done < ITERS:  # uneven launch lengths: many launches, fresh tags, both parities
+                n = int(min(ITERS - done, rng.integers(5, 3000)))
+                reg.run(flame_amd.Params(), n)
+                done += n
+                launches += 1
+            out = reg.download_state(KEYS)
+            path = reg.info()["last_run_path"]
+        ok = all(np.array_equal(out[k], ref[k]) for k in KEYS)
+        results.append(dict(config=cfg, V=g["V"], E=g["E"], iters=ITERS, launches=launches, form=form, dual=dual,
+                            run_path=path, bit_identical=bool(ok)))
+        print(results[-1], flush=True)
+stop = True
+if LOAD:
+    th.join(timeout=10)
+print(json.dumps(dict(under_load=LOAD, all_ok=all(r["bit_identical"] for r in results), seconds=round(time.time() - t_start, 1),
+                      results=results)))
