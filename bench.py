@@ -312,7 +312,11 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
                             .astype(_np.float32)])
     fid = _np.concatenate([fid, _np.arange(g["V"], g["V"] + n_new, dtype=_np.int32)])
     data2 = _np.concatenate([g["data_term"][keep], _np.ones(n_new, _np.float32)])
-    edges2 = synth.delaunay_edges_scipy(pos2)
+    t_d0 = _t.perf_counter()
+    tris2, edges2 = synth.delaunay_native(pos2)
+    t_d1 = _t.perf_counter()
+    out["delaunay"] = {"triangulate_ms": round((t_d1 - t_d0) * 1e3, 3), "points": int(len(pos2)), "triangles": int(len(tris2)),
+                       "note": "host code (the reference's Triangle is host code too), exact predicates"}
     r.upload_graph(g)
     r.run(params, 50)
     r.sync_graph(_np.arange(g["V"], dtype=_np.int32), g["pos"], g["data_term"], g["data_weight"],
@@ -325,7 +329,7 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
     out["frame_sync"] = {"sync_graph_ms": round((t5 - t4) * 1e3, 3), "churn": "8 % of vertices replaced, re-triangulated",
                          "V": int(len(fid)), "E": int(r.info()["E"])}
     # mesh -> dense idepthmap (utils::interpolateMesh, next row 8(f)-2), incl. the D2H copy of the map
-    tris = synth.delaunay_triangles_scipy(pos2)
+    tris = tris2
     r.interpolate_mesh(tris, h_, w_)
     t6 = _t.perf_counter()
     for _ in range(10):

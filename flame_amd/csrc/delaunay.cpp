@@ -1,0 +1,396 @@
+// delaunay.cpp -- 2-D Delaunay triangulation of float32 points (host code, like the reference's):
+// the counterpart of utils::Delaunay (/root/reference/src/flame/utils/delaunay.{h,cc}), which wraps the
+// vendored Shewchuk Triangle with switches "zneQB" (delaunay.cc:66-68) and hands Flame::syncGraph the edge
+// list the solver's graph is built from (flame.cc:2073-2104) and the triangles interpolateMesh draws
+// (flame.cc:409-415).  SURVEY.md section 8(f) rank 3.
+//
+// Own implementation, not a port: incremental Bowyer-Watson with ghost triangles (no super-triangle, so
+// the convex hull is exact), points inserted along a Morton curve and located by a visibility walk from
+// the previous insertion.  Predicates are EXACT: every float32 coordinate is an integer multiple of a
+// common power of two, so coordinates are rescaled to int64 once; orient2d is then exact in __int128 and
+// incircle in 256-bit integer arithmetic, behind a double-precision filter with a forward error bound.
+// A point set in general position has ONE Delaunay triangulation, so the result equals Triangle's as a
+// set of triangles (pinned in tests/test_delaunay.py against triangulations produced by the reference's
+// Triangle, oracle/_ref); order and rotation of the output triangles / edges are this implementation's
+// own, which is fine because the solver consumes explicit edge lists.
+//
+// Output conventions (matching Triangle's): triangles counter-clockwise in x-right / y-up coordinates;
+// edges unique and undirected, listed as first met walking the triangles (v0,v1),(v1,v2),(v2,v0).
+// Exact duplicates of an earlier point are skipped (Triangle ignores them as well).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "flame_nltgv2.h"
+
+namespace {
+
+typedef __int128 i128;
+
+// ---- 256-bit signed accumulation of products of two i128 (incircle needs |value| < 2^240) --------------
+struct I256 {
+  uint64_t w[4];  // little endian, two's complement
+};
+
+inline I256 from_product(i128 a, i128 b) {
+  const bool neg = (a < 0) != (b < 0);
+  unsigned __int128 ua = a < 0 ? (unsigned __int128)(-a) : (unsigned __int128)a;
+  unsigned __int128 ub = b < 0 ? (unsigned __int128)(-b) : (unsigned __int128)b;
+  const uint64_t a0 = (uint64_t)ua, a1 = (uint64_t)(ua >> 64), b0 = (uint64_t)ub, b1 = (uint64_t)(ub >> 64);
+  unsigned __int128 p00 = (unsigned __int128)a0 * b0, p01 = (unsigned __int128)a0 * b1;
+  unsigned __int128 p10 = (unsigned __int128)a1 * b0, p11 = (unsigned __int128)a1 * b1;
+  I256 r;
+  r.w[0] = (uint64_t)p00;
+  unsigned __int128 mid = (p00 >> 64) + (uint64_t)p01 + (uint64_t)p10;
+  r.w[1] = (uint64_t)mid;
+  unsigned __int128 hi = (mid >> 64) + (p01 >> 64) + (p10 >> 64) + (uint64_t)p11;
+  r.w[2] = (uint64_t)hi;
+  r.w[3] = (uint64_t)((hi >> 64) + (p11 >> 64));
+  if (neg) {  // two's complement negate
+    unsigned __int128 c = 1;
+    for (int i = 0; i < 4; ++i) {
+      c += (uint64_t)~r.w[i];
+      r.w[i] = (uint64_t)c;
+      c >>= 64;
+    }
+  }
+  return r;
+}
+
+inline void add_to(I256& a, const I256& b) {
+  unsigned __int128 c = 0;
+  for (int i = 0; i < 4; ++i) {
+    c += (unsigned __int128)a.w[i] + b.w[i];
+    a.w[i] = (uint64_t)c;
+    c >>= 64;
+  }
+}
+
+inline int sign_of(const I256& a) {
+  if (a.w[3] >> 63) return -1;
+  return (a.w[0] | a.w[1] | a.w[2] | a.w[3]) ? 1 : 0;
+}
+
+struct Pt {
+  int64_t x, y;  // exact integer image of the float32 coordinates (common power-of-two scale)
+  double fx, fy; // the same values as doubles, for the incircle filter
+};
+
+const int GHOST = -1;
+
+struct Tri {
+  int v[3];
+  int n[3];  // neighbour across the edge opposite v[i]
+  bool alive;
+};
+
+class Triangulator {
+ public:
+  std::vector<Pt> p;
+  std::vector<Tri> t;
+  std::vector<int> cavity, stack_;
+  std::vector<char> in_cavity;  // per triangle, reset after each insertion
+  bool filter_ok = false;       // differences of coordinates are exact in double
+
+  int orient(int a, int b, int c) const {  // > 0: c to the left of a->b (counter-clockwise), exact
+    const i128 d = (i128)(p[b].x - p[a].x) * (p[c].y - p[a].y) - (i128)(p[b].y - p[a].y) * (p[c].x - p[a].x);
+    return d > 0 ? 1 : (d < 0 ? -1 : 0);
+  }
+
+  int incircle(int a, int b, int c, int d) const {  // > 0: d strictly inside the circle through ccw a,b,c
+    if (filter_ok) {
+      const double adx = p[a].fx - p[d].fx, ady = p[a].fy - p[d].fy;
+      const double bdx = p[b].fx - p[d].fx, bdy = p[b].fy - p[d].fy;
+      const double cdx = p[c].fx - p[d].fx, cdy = p[c].fy - p[d].fy;
+      const double bdxcdy = bdx * cdy, cdxbdy = cdx * bdy, cdxady = cdx * ady, adxcdy = adx * cdy;
+      const double adxbdy = adx * bdy, bdxady = bdx * ady;
+      const double alift = adx * adx + ady * ady, blift = bdx * bdx + bdy * bdy, clift = cdx * cdx + cdy * cdy;
+      const double det = alift * (bdxcdy - cdxbdy) + blift * (cdxady - adxcdy) + clift * (adxbdy - bdxady);
+      const double permanent = (std::fabs(bdxcdy) + std::fabs(cdxbdy)) * alift +
+                               (std::fabs(cdxady) + std::fabs(adxcdy)) * blift +
+                               (std::fabs(adxbdy) + std::fabs(bdxady)) * clift;
+      const double errbound = 1.2e-15 * permanent;  // > (10 + 96 eps) eps, Shewchuk's iccerrboundA
+      if (det > errbound) return 1;
+      if (det < -errbound) return -1;
+    }
+    const i128 adx = (i128)p[a].x - p[d].x, ady = (i128)p[a].y - p[d].y;
+    const i128 bdx = (i128)p[b].x - p[d].x, bdy = (i128)p[b].y - p[d].y;
+    const i128 cdx = (i128)p[c].x - p[d].x, cdy = (i128)p[c].y - p[d].y;
+    I256 s = from_product(adx * adx + ady * ady, bdx * cdy - cdx * bdy);
+    add_to(s, from_product(bdx * bdx + bdy * bdy, cdx * ady - adx * cdy));
+    add_to(s, from_product(cdx * cdx + cdy * cdy, adx * bdy - bdx * ady));
+    return sign_of(s);
+  }
+
+  // Bowyer-Watson membership: is point d inside the (open) circumdisk of triangle ti?  For a ghost triangle
+  // (a, b, GHOST) the "disk" is the open half-plane to the left of a->b plus the open segment ab.
+  bool in_disk(int ti, int d) const {
+    const Tri& T = t[ti];
+    for (int i = 0; i < 3; ++i) {
+      if (T.v[i] == GHOST) {
+        const int a = T.v[(i + 1) % 3], b = T.v[(i + 2) % 3];
+        const int o = orient(a, b, d);
+        if (o > 0) return true;
+        if (o < 0) return false;
+        // collinear: inside iff strictly between a and b
+        const i128 dot1 = (i128)(p[d].x - p[a].x) * (p[b].x - p[a].x) + (i128)(p[d].y - p[a].y) * (p[b].y - p[a].y);
+        const i128 dot2 = (i128)(p[d].x - p[b].x) * (p[a].x - p[b].x) + (i128)(p[d].y - p[b].y) * (p[a].y - p[b].y);
+        return dot1 > 0 && dot2 > 0;
+      }
+    }
+    return incircle(T.v[0], T.v[1], T.v[2], d) > 0;
+  }
+
+  int new_tri(int a, int b, int c) {
+    Tri T;
+    T.v[0] = a, T.v[1] = b, T.v[2] = c;
+    T.n[0] = T.n[1] = T.n[2] = -1;
+    T.alive = true;
+    t.push_back(T);
+    in_cavity.push_back(0);
+    return (int)t.size() - 1;
+  }
+
+  static bool is_ghost(const Tri& T) { return T.v[0] == GHOST || T.v[1] == GHOST || T.v[2] == GHOST; }
+
+  // Visibility walk from a real triangle; returns a triangle (real or ghost) whose disk contains d, or -1
+  // when d coincides with an existing vertex.
+  int locate(int start, int d) const {
+    int cur = start;
+    if (is_ghost(t[cur])) {
+      for (int i = 0; i < 3; ++i)
+        if (t[cur].v[i] == GHOST) cur = t[cur].n[i];
+    }
+    for (size_t guard = 0; guard < t.size() + 8; ++guard) {
+      const Tri& T = t[cur];
+      bool moved = false;
+      for (int i = 0; i < 3; ++i) {
+        const int a = T.v[(i + 1) % 3], b = T.v[(i + 2) % 3];
+        if (orient(a, b, d) < 0) {
+          const int nb = T.n[i];
+          if (is_ghost(t[nb])) return nb;
+          cur = nb;
+          moved = true;
+          break;
+        }
+      }
+      if (!moved) return cur;
+    }
+    return cur;
+  }
+
+  // Inserts point d; `seed` is a triangle whose disk contains d.  Returns one of the new real triangles.
+  int insert(int seed, int d) {
+    cavity.clear();
+    stack_.clear();
+    stack_.push_back(seed);
+    in_cavity[seed] = 1;
+    while (!stack_.empty()) {
+      const int ti = stack_.back();
+      stack_.pop_back();
+      cavity.push_back(ti);
+      for (int i = 0; i < 3; ++i) {
+        const int nb = t[ti].n[i];
+        if (nb >= 0 && !in_cavity[nb] && in_disk(nb, d)) {
+          in_cavity[nb] = 1;
+          stack_.push_back(nb);
+        }
+      }
+    }
+    // boundary edges (a -> b as seen from inside the cavity, cavity on the left) and their outer neighbours
+    struct BE { int a, b, outer, tri; };
+    std::vector<BE> be;
+    for (int ti : cavity) {
+      for (int i = 0; i < 3; ++i) {
+        const int nb = t[ti].n[i];
+        if (nb < 0 || !in_cavity[nb]) be.push_back(BE{t[ti].v[(i + 1) % 3], t[ti].v[(i + 2) % 3], nb, -1});
+      }
+    }
+    for (BE& e : be) {
+      e.tri = new_tri(e.a, e.b, d);  // orientation inherited from the removed triangle: (a, b, apex) ccw
+      Tri& T = t[e.tri];
+      T.n[2] = e.outer;  // across a-b (opposite d)
+      if (e.outer >= 0) {
+        Tri& O = t[e.outer];
+        for (int i = 0; i < 3; ++i) {
+          const int oa = O.v[(i + 1) % 3], ob = O.v[(i + 2) % 3];
+          if (oa == e.b && ob == e.a) O.n[i] = e.tri;
+        }
+      }
+    }
+    // link the fan: triangle (a, b, d) meets, across edge b-d (opposite a, index 0), the triangle whose a == b;
+    // across edge d-a (opposite b, index 1), the triangle whose b == a.
+    // Vertex ids include GHOST (-1): index by id + 1.
+    if (fan_next.size() < p.size() + 1) fan_next.assign(p.size() + 1, -1);
+    for (const BE& e : be) fan_next[e.a + 1] = e.tri;
+    for (const BE& e : be) {
+      const int nxt = fan_next[e.b + 1];  // triangle starting at b
+      t[e.tri].n[0] = nxt;
+      t[nxt].n[1] = e.tri;
+    }
+    for (const BE& e : be) fan_next[e.a + 1] = -1;
+    for (int ti : cavity) {
+      t[ti].alive = false;
+      in_cavity[ti] = 0;
+    }
+    for (const BE& e : be)
+      if (!is_ghost(t[e.tri])) return e.tri;
+    return be.empty() ? seed : be[0].tri;
+  }
+
+  std::vector<int> fan_next;
+};
+
+inline uint32_t spread16(uint32_t v) {
+  v &= 0xFFFFu;
+  v = (v | (v << 8)) & 0x00FF00FFu;
+  v = (v | (v << 4)) & 0x0F0F0F0Fu;
+  v = (v | (v << 2)) & 0x33333333u;
+  v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+
+}  // namespace
+
+extern "C" int flame_delaunay_triangulate(const float* xy, int32_t n, int32_t* triangles, int32_t tri_capacity,
+                                          int32_t* n_triangles, int32_t* edges, int32_t edge_capacity,
+                                          int32_t* n_edges) {
+  if (n < 0 || (n > 0 && !xy) || !n_triangles || !n_edges) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  *n_triangles = 0;
+  *n_edges = 0;
+  if (n < 3) return FLAME_NLTGV2_OK;
+
+  // ---- exact integer image of the coordinates --------------------------------------------------------
+  int emin = 1000, emax = -1000;
+  for (int32_t i = 0; i < 2 * n; ++i) {
+    const float v = xy[i];
+    if (!std::isfinite(v)) return FLAME_NLTGV2_ERR_INVALID_ARG;
+    if (v == 0.0f) continue;
+    int e;
+    std::frexp(v, &e);  // |v| in [2^(e-1), 2^e); ulp(v) = 2^(e-24)
+    emin = std::min(emin, e - 24);
+    emax = std::max(emax, e);
+  }
+  if (emin == 1000) return FLAME_NLTGV2_OK;  // all points at the origin
+  if (emax - emin > 58) return FLAME_NLTGV2_ERR_INVALID_ARG;  // dynamic range beyond the exact predicates
+  Triangulator T;
+  T.filter_ok = (emax - emin) <= 50;  // differences exact in double, products well inside the error bound
+  T.p.resize((size_t)n);
+  float minx = xy[0], maxx = xy[0], miny = xy[1], maxy = xy[1];
+  for (int32_t i = 0; i < n; ++i) {
+    T.p[(size_t)i].x = (int64_t)std::ldexp((double)xy[2 * i], -emin);
+    T.p[(size_t)i].y = (int64_t)std::ldexp((double)xy[2 * i + 1], -emin);
+    T.p[(size_t)i].fx = (double)xy[2 * i];
+    T.p[(size_t)i].fy = (double)xy[2 * i + 1];
+    minx = std::min(minx, xy[2 * i]), maxx = std::max(maxx, xy[2 * i]);
+    miny = std::min(miny, xy[2 * i + 1]), maxy = std::max(maxy, xy[2 * i + 1]);
+  }
+
+  // ---- insertion order: Morton curve (consecutive points are close: short walks) ----------------------
+  std::vector<int> order((size_t)n);
+  std::iota(order.begin(), order.end(), 0);
+  {
+    const double sx = maxx > minx ? 65535.0 / ((double)maxx - minx) : 0.0, sy = maxy > miny ? 65535.0 / ((double)maxy - miny) : 0.0;
+    std::vector<uint32_t> key((size_t)n);
+    for (int32_t i = 0; i < n; ++i) {
+      const uint32_t qx = (uint32_t)(((double)xy[2 * i] - minx) * sx), qy = (uint32_t)(((double)xy[2 * i + 1] - miny) * sy);
+      key[(size_t)i] = spread16(qx) | (spread16(qy) << 1);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[(size_t)a] < key[(size_t)b]; });
+  }
+
+  // ---- first non-degenerate triangle --------------------------------------------------------------------
+  const int a = order[0];
+  size_t ib = 1;
+  while (ib < order.size() && T.p[(size_t)order[ib]].x == T.p[(size_t)a].x && T.p[(size_t)order[ib]].y == T.p[(size_t)a].y) ++ib;
+  if (ib >= order.size()) return FLAME_NLTGV2_OK;  // all points identical
+  const int b = order[ib];
+  size_t ic = ib + 1;
+  while (ic < order.size() && T.orient(a, b, order[ic]) == 0) ++ic;
+  if (ic >= order.size()) return FLAME_NLTGV2_OK;  // all points collinear: no triangles
+  int c = order[ic];
+  int v0 = a, v1 = b, v2 = c;
+  if (T.orient(v0, v1, v2) < 0) std::swap(v1, v2);
+  T.t.reserve((size_t)n * 4 + 16);
+  T.in_cavity.reserve((size_t)n * 4 + 16);
+  const int t0 = T.new_tri(v0, v1, v2);
+  // ghosts: across edge opposite v[i] of t0, i.e. edge (v[i+1], v[i+2]); the ghost holds it reversed
+  int g[3];
+  for (int i = 0; i < 3; ++i) g[i] = T.new_tri(T.t[t0].v[(i + 2) % 3], T.t[t0].v[(i + 1) % 3], GHOST);
+  for (int i = 0; i < 3; ++i) {
+    T.t[t0].n[i] = g[i];
+    T.t[g[i]].n[2] = t0;  // across its real edge (opposite GHOST)
+  }
+  // ghost i = (u, w, G) with u = v[i+2], w = v[i+1]: edge w-G (opposite u, index 0) is shared with the ghost
+  // that starts at w, i.e. ghost (i+2) = (v[i+1], v[i], G); edge G-u (opposite w, index 1) with ghost (i+1).
+  for (int i = 0; i < 3; ++i) {
+    T.t[g[i]].n[0] = g[(i + 2) % 3];
+    T.t[g[i]].n[1] = g[(i + 1) % 3];
+  }
+
+  std::vector<char> used((size_t)n, 0);
+  used[(size_t)v0] = used[(size_t)v1] = used[(size_t)v2] = 1;
+  int last = t0;
+  for (size_t k = 0; k < order.size(); ++k) {
+    const int d = order[k];
+    if (used[(size_t)d]) continue;
+    used[(size_t)d] = 1;
+    int seed = T.locate(last, d);
+    // duplicate of an existing vertex: the located triangle has it as a corner
+    bool dup = false;
+    for (int i = 0; i < 3; ++i) {
+      const int v = T.t[seed].v[i];
+      if (v != GHOST && T.p[(size_t)v].x == T.p[(size_t)d].x && T.p[(size_t)v].y == T.p[(size_t)d].y) dup = true;
+    }
+    if (dup) continue;
+    if (!T.in_disk(seed, d)) {
+      // d lies on the boundary of the located triangle's disk only when it is ON an edge / hull line:
+      // one of the neighbours then contains it in its open disk
+      int alt = -1;
+      for (int i = 0; i < 3 && alt < 0; ++i) {
+        const int nb = T.t[seed].n[i];
+        if (nb >= 0 && T.in_disk(nb, d)) alt = nb;
+      }
+      if (alt < 0) continue;  // cannot happen for a point not equal to a vertex; skip defensively
+      seed = alt;
+    }
+    last = T.insert(seed, d);
+  }
+
+  // ---- output ---------------------------------------------------------------------------------------------
+  int32_t nt = 0;
+  for (const Tri& tr : T.t)
+    if (tr.alive && !Triangulator::is_ghost(tr)) ++nt;
+  *n_triangles = nt;
+  if (triangles) {
+    if (tri_capacity < nt) return FLAME_NLTGV2_ERR_INVALID_ARG;
+    int32_t k = 0;
+    for (const Tri& tr : T.t)
+      if (tr.alive && !Triangulator::is_ghost(tr)) {
+        triangles[3 * k] = tr.v[0], triangles[3 * k + 1] = tr.v[1], triangles[3 * k + 2] = tr.v[2];
+        ++k;
+      }
+  }
+  // edges: every real triangle contributes the edges whose opposite neighbour is a ghost or has a larger
+  // index (each undirected edge exactly once), in triangle order
+  int32_t ne = 0;
+  for (size_t ti = 0; ti < T.t.size(); ++ti) {
+    const Tri& tr = T.t[ti];
+    if (!tr.alive || Triangulator::is_ghost(tr)) continue;
+    for (int i = 0; i < 3; ++i) {
+      const int nb = tr.n[(i + 2) % 3];  // neighbour across edge (v[i], v[i+1]) = opposite v[i+2]
+      if (nb < 0 || Triangulator::is_ghost(T.t[(size_t)nb]) || (size_t)nb > ti) {
+        if (edges) {
+          if (ne >= edge_capacity) return FLAME_NLTGV2_ERR_INVALID_ARG;
+          edges[2 * ne] = tr.v[i], edges[2 * ne + 1] = tr.v[(i + 1) % 3];
+        }
+        ++ne;
+      }
+    }
+  }
+  *n_edges = ne;
+  return FLAME_NLTGV2_OK;
+}

@@ -98,6 +98,7 @@ ABI_SYMBOLS = (
     "flame_nltgv2_photo_set_images", "flame_nltgv2_photo_residual", "flame_nltgv2_sync_graph",
     "flame_nltgv2_get_topology", "flame_nltgv2_set_feature_ids", "flame_nltgv2_interpolate_mesh",
     "flame_nltgv2_interpolate_mesh_arrays", "flame_nltgv2_project_graph", "flame_nltgv2_rescale_data",
+    "flame_delaunay_triangulate",
 )
 
 
@@ -146,6 +147,7 @@ def load_library():
         "flame_nltgv2_sync_graph": (C.c_int, [ctx, C.POINTER(_SyncInput)]),
         "flame_nltgv2_get_topology": (C.c_int, [ctx, _IP, _IP, _IP]),
         "flame_nltgv2_set_feature_ids": (C.c_int, [ctx, _IP]),
+        "flame_delaunay_triangulate": (C.c_int, [_FP, C.c_int32, _IP, C.c_int32, _IP, _IP, C.c_int32, _IP]),
         "flame_nltgv2_project_graph": (C.c_int, [ctx, C.POINTER(_Projection), C.c_float, C.POINTER(C.c_uint8), _FP]),
         "flame_nltgv2_rescale_data": (C.c_int, [ctx, C.c_float, _FP, PP]),
         "flame_nltgv2_interpolate_mesh": (C.c_int, [ctx, _IP, C.c_int32, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_float,
@@ -191,6 +193,22 @@ def _graph_view(g: dict, keep: list, need_all=True) -> _Graph:
         keep.append(a)
         setattr(cg, name, a.ctypes.data_as(ctype))
     return cg
+
+
+def delaunay(pos):
+    """Delaunay triangulation of float32 points with the library's own triangulator (host code, exact
+    predicates).  Returns (triangles (T,3) int32 counter-clockwise, edges (E,2) int32)."""
+    L = load_library()
+    p = np.ascontiguousarray(pos, np.float32).reshape(-1, 2)
+    n = p.shape[0]
+    nt, ne = C.c_int32(0), C.c_int32(0)
+    tri = np.empty((max(2 * n, 1), 3), np.int32)
+    edg = np.empty((max(3 * n, 1), 2), np.int32)
+    rc = L.flame_delaunay_triangulate(p.ctypes.data_as(_FP), n, tri.ctypes.data_as(_IP), tri.shape[0], C.byref(nt),
+                                      edg.ctypes.data_as(_IP), edg.shape[0], C.byref(ne))
+    if rc != 0:
+        raise NLTGV2Error(rc, "flame_delaunay_triangulate")
+    return tri[: nt.value].copy(), edg[: ne.value].copy()
 
 
 def pack_probe(g: dict):

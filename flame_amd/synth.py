@@ -11,9 +11,10 @@ reference's graph builder:
     (flame.cc:2087-2104, nltgv2_l1_graph_regularizer.h:96-100)
 
 The RNG is a counter-based splitmix64 defined here so inputs are reproducible across hosts.
-Delaunay on this side uses scipy (Qhull); fixtures under tests/golden/ instead carry edge lists from
-the reference's own vendored Triangle (see oracle/make_golden.py).  The solver takes explicit edge
-lists, so either source is valid input.
+Delaunay on this side is the library's own triangulator (flame_delaunay_triangulate; scipy/Qhull variants
+are kept for cross-checks); fixtures under tests/golden/ instead carry edge lists from the reference's own
+vendored Triangle (see oracle/make_golden.py).  The solver takes explicit edge lists, so any source is
+valid input.
 """
 from __future__ import annotations
 
@@ -95,6 +96,18 @@ def delaunay_edges_scipy(pos: np.ndarray) -> np.ndarray:
     return cand[first].astype(np.int32)
 
 
+def delaunay_native(pos: np.ndarray):
+    """(triangles, edges) from the library's own triangulator (flame_delaunay_triangulate: host code, exact
+    predicates; same set of triangles as the reference's Triangle / Qhull for points in general position)."""
+    from .regularizer import delaunay
+
+    return delaunay(pos)
+
+
+def delaunay_edges_native(pos: np.ndarray) -> np.ndarray:
+    return delaunay_native(pos)[1]
+
+
 def delaunay_triangles_scipy(pos: np.ndarray) -> np.ndarray:
     """Delaunay triangles as (T,3) int32 with the winding of the reference's triangulator (Shewchuk
     Triangle: counter-clockwise in x-right / y-up coordinates, i.e. positive signed area)."""
@@ -139,7 +152,7 @@ def assemble_graph(pos: np.ndarray, data: np.ndarray, edges: np.ndarray, weight=
     return g
 
 
-def make_graph(config: str = "640x480", seed: int = 1234, delaunay=delaunay_edges_scipy) -> dict:
+def make_graph(config: str = "640x480", seed: int = 1234, delaunay=delaunay_edges_native) -> dict:
     width, height, cell = CONFIGS[config]
     pos = make_points(width, height, cell, seed)
     data = make_data_term(pos, width, height, seed)

@@ -122,6 +122,20 @@ struct GraphAccess<FlatGraph> {
   }
 };
 
+// utils::Delaunay counterpart (src/flame/utils/delaunay.{h,cc}): triangles()/edges() of the Delaunay
+// triangulation of `vertices_xy` (x0,y0,x1,y1,...), exact predicates, host code.
+inline void delaunayTriangulate(const std::vector<float>& vertices_xy, std::vector<int32_t>* triangles,
+                                std::vector<int32_t>* edges) {
+  const int32_t n = static_cast<int32_t>(vertices_xy.size() / 2);
+  int32_t nt = 0, ne = 0;
+  std::vector<int32_t> t(static_cast<size_t>(n > 0 ? 6 * n : 3)), e(static_cast<size_t>(n > 0 ? 6 * n : 2));
+  const int rc = flame_delaunay_triangulate(vertices_xy.data(), n, t.data(), static_cast<int32_t>(t.size() / 3), &nt,
+                                            e.data(), static_cast<int32_t>(e.size() / 2), &ne);
+  if (rc != 0) throw Error(rc, "flame_delaunay_triangulate");
+  if (triangles) triangles->assign(t.begin(), t.begin() + 3 * nt);
+  if (edges) edges->assign(e.begin(), e.begin() + 2 * ne);
+}
+
 }  // namespace flame_hip
 
 namespace flame {

@@ -199,6 +199,16 @@ int flame_nltgv2_interpolate_mesh_arrays(flame_nltgv2_ctx* ctx, const int32_t* t
                                          const uint8_t* vtx_valid, const uint8_t* tri_valid, int rows, int cols,
                                          float* img_out, int32_t* coverage_out);
 
+/* 2-D Delaunay triangulation of float32 points: the counterpart of utils::Delaunay
+ * (src/flame/utils/delaunay.{h,cc}, a wrapper of the vendored Shewchuk Triangle called with "zneQB",
+ * delaunay.cc:66-68) that feeds Flame::syncGraph its edge list (flame.cc:2073-2104) and interpolateMesh its
+ * triangles.  HOST code, like the reference's; exact predicates, so a point set in
+ * general position yields the same set of triangles as Triangle.  Triangles are counter-clockwise in
+ * x-right / y-up coordinates (Triangle's convention); edges are unique undirected pairs.  Pass NULL for
+ * `triangles` / `edges` to query the counts (Euler: T <= 2n - 5, E <= 3n - 6).  Needs no context, no GPU. */
+int flame_delaunay_triangulate(const float* xy, int32_t n, int32_t* triangles, int32_t tri_capacity,
+                               int32_t* n_triangles, int32_t* edges, int32_t edge_capacity, int32_t* n_edges);
+
 /* Per-vertex photometric residual (BASELINE config 5).  No live reference counterpart: the only
  * occurrence is the commented-out block flame.cc:854-893; built from the live pieces
  * EpipolarGeometry::project (stereo/epipolar_geometry.h:127-143) and utils::bilinearInterp<uint8_t,float>

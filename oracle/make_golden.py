@@ -51,8 +51,31 @@ def make(config: str, seed: int, iters, full_at, weights: str = "ones"):
     return out
 
 
+def make_delaunay_fixture():
+    """Point sets + the triangulations the REFERENCE's vendored Triangle produces for them (oracle/_ref):
+    reference-run outputs that pin flame_delaunay_triangulate (tests/test_delaunay.py)."""
+    rng = np.random.default_rng(2024)
+    sets = {
+        "jittered_320x240": synth.make_points(320, 240, 6, 99),
+        "uniform_1500": (rng.random((1500, 2)) * [640, 480]).astype(np.float32),
+        "clustered_900": np.concatenate([rng.normal(c, 9.0, (300, 2)) for c in ((100, 100), (300, 200), (500, 380))]).astype(np.float32),
+        "tiny_7": (rng.random((7, 2)) * 50).astype(np.float32),
+    }
+    out = {}
+    for name, pts in sets.items():
+        out[name + "_points"] = pts
+        out[name + "_triangles"] = ref_triangle.delaunay_triangles(pts)
+        out[name + "_edges"] = ref_triangle.delaunay_edges(pts)
+    path = os.path.join(OUT, "delaunay_ref_triangle.npz")
+    np.savez_compressed(path, **out)
+    print("delaunay_ref_triangle", {k: v.shape for k, v in out.items() if k.endswith("triangles")}, os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    make_delaunay_fixture()
+    if os.environ.get("GOLDEN_ONLY_DELAUNAY"):
+        return
     jobs = [
         ("cfg1_320x240_s1234", dict(config="320x240", seed=1234, iters=(1, 2, 50, 200), full_at=(1, 2, 50, 200))),
         ("cfg1_320x240_s77_varied", dict(config="320x240", seed=77, iters=(1, 50), full_at=(50,), weights="varied")),

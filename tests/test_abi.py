@@ -15,7 +15,7 @@ HEADER = os.path.join(ROOT, "include", "flame_nltgv2.h")
 def declared_symbols():
     txt = open(HEADER).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(flame_nltgv2_[a-z_0-9]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(flame_(?:nltgv2|delaunay)_[a-z_0-9]+)\s*\(", txt)))
 
 
 def test_header_symbols_are_exported(built):
@@ -29,7 +29,7 @@ def test_header_symbols_are_exported(built):
     for name in decl:
         assert hasattr(lib, name), name
     nm = subprocess.check_output(["nm", "-D", "--defined-only", flame_amd.library_path()], text=True)
-    exported = set(re.findall(r" T (flame_nltgv2_[a-z_0-9]+)", nm))
+    exported = set(re.findall(r" T (flame_(?:nltgv2|delaunay)_[a-z_0-9]+)", nm))
     assert set(decl) <= exported
 
 

@@ -1,0 +1,125 @@
+"""flame_delaunay_triangulate (host code, like the reference's utils::Delaunay).
+
+PINNED by reference-run outputs: tests/golden/delaunay_ref_triangle.npz holds point sets together with the
+triangulations the reference's own vendored Triangle ("zneQB", delaunay.cc:66-68) produced for them in the
+build container (oracle/make_golden.py, oracle/_ref).  A point set in general position has exactly one
+Delaunay triangulation, so the triangle SETS must be equal; output order / rotation are the implementation's
+own.  Also: agreement with Qhull (scipy) at every BASELINE size, exact empty-circumcircle verification with
+Python integers on degenerate (co-circular) input, and the degenerate / error cases."""
+import os
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+from flame_amd import regularizer, synth
+from tests.helpers import GOLDEN
+
+
+def tri_set(t):
+    return set(tuple(sorted(int(v) for v in x)) for x in np.asarray(t).reshape(-1, 3))
+
+
+def edge_set(e):
+    return set(tuple(sorted(int(v) for v in x)) for x in np.asarray(e).reshape(-1, 2))
+
+
+def signed_area2(p, t):
+    a, b, c = p[t[:, 0]].astype(np.float64), p[t[:, 1]].astype(np.float64), p[t[:, 2]].astype(np.float64)
+    return (b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (c[:, 0] - a[:, 0]) * (b[:, 1] - a[:, 1])
+
+
+@pytest.mark.parametrize("name", ["jittered_320x240", "uniform_1500", "clustered_900", "tiny_7"])
+def test_equals_reference_triangle_run(built, name):
+    z = np.load(os.path.join(GOLDEN, "delaunay_ref_triangle.npz"))
+    pts = z[name + "_points"]
+    tri, edg = regularizer.delaunay(pts)
+    assert tri_set(tri) == tri_set(z[name + "_triangles"])
+    assert edge_set(edg) == edge_set(z[name + "_edges"])
+    assert len(edg) == len(edge_set(edg))  # unique
+    assert np.all(signed_area2(pts, tri) > 0)  # counter-clockwise, Triangle's convention
+    assert np.all(signed_area2(pts, z[name + "_triangles"]) > 0)
+
+
+@pytest.mark.parametrize("config", ["320x240", "640x480", "1280x720", "1920x1080"])
+def test_equals_qhull_at_baseline_sizes(built, config):
+    from scipy.spatial import Delaunay
+
+    w, h, c = synth.CONFIGS[config]
+    pts = synth.make_points(w, h, c, 31)
+    tri, edg = regularizer.delaunay(pts)
+    assert tri_set(tri) == tri_set(Delaunay(pts.astype(np.float64)).simplices)
+    assert edge_set(edg) == edge_set(synth.delaunay_edges_scipy(pts))
+    n = len(pts)
+    assert len(edg) == len(tri) + n - 1  # Euler: V - E + T = 1 for a triangulated disk
+
+
+def exact_incircle(pa, pb, pc, pd):
+    f = lambda v: Fraction(float(v))  # noqa: E731
+    adx, ady = f(pa[0]) - f(pd[0]), f(pa[1]) - f(pd[1])
+    bdx, bdy = f(pb[0]) - f(pd[0]), f(pb[1]) - f(pd[1])
+    cdx, cdy = f(pc[0]) - f(pd[0]), f(pc[1]) - f(pd[1])
+    return ((adx * adx + ady * ady) * (bdx * cdy - cdx * bdy) + (bdx * bdx + bdy * bdy) * (cdx * ady - adx * cdy)
+            + (cdx * cdx + cdy * cdy) * (adx * bdy - bdx * ady))
+
+
+def test_cocircular_grid_is_a_valid_delaunay_triangulation(built):
+    """An exact grid is maximally degenerate (every cell is co-circular): the triangulation is not unique,
+    so it is verified instead -- exact empty-circumcircle test of every triangle against the opposite vertex
+    of every neighbour (rational arithmetic), full coverage, consistent winding."""
+    xs, ys = np.meshgrid(np.arange(0, 13, dtype=np.float32) * 7.5, np.arange(0, 9, dtype=np.float32) * 7.5)
+    pts = np.stack([xs.ravel(), ys.ravel()], 1)
+    tri, edg = regularizer.delaunay(pts)
+    n = len(pts)
+    hull = 2 * (13 + 9) - 4
+    assert len(tri) == 2 * n - 2 - hull and len(edg) == 3 * n - 3 - hull
+    assert np.all(signed_area2(pts, tri) > 0)
+    assert abs(0.5 * signed_area2(pts, tri).sum() - (12 * 7.5) * (8 * 7.5)) < 1e-6
+    by_edge = {}
+    for t in tri:
+        for i in range(3):
+            by_edge.setdefault(tuple(sorted((int(t[i]), int(t[(i + 1) % 3])))), []).append(t)
+    for (u, v), ts in by_edge.items():
+        assert len(ts) <= 2
+        if len(ts) == 2:
+            for a, b in ((ts[0], ts[1]), (ts[1], ts[0])):
+                opp = [int(w) for w in b if int(w) not in (u, v)][0]
+                assert exact_incircle(pts[a[0]], pts[a[1]], pts[a[2]], pts[opp]) <= 0  # not strictly inside
+
+
+def test_points_on_edges_and_hull(built):
+    """Points exactly ON an existing edge and exactly on the hull line (collinear) are inserted correctly."""
+    pts = np.array([[0, 0], [10, 0], [0, 10], [10, 10], [5, 5], [5, 0], [2.5, 2.5], [20, 0], [7.5, 7.5]], np.float32)
+    tri, edg = regularizer.delaunay(pts)
+    assert np.all(signed_area2(pts, tri) > 0)
+    assert abs(0.5 * signed_area2(pts, tri).sum() - 150.0) < 1e-9  # area of the hull (0,0),(20,0),(10,10),(0,10)
+    assert set(np.unique(tri)) == set(range(len(pts)))
+    from scipy.spatial import Delaunay
+
+    assert len(tri) == len(Delaunay(pts.astype(np.float64)).simplices)
+
+
+def test_degenerate_and_invalid_inputs(built):
+    for pts in (np.zeros((0, 2), np.float32), np.array([[1, 1]], np.float32), np.array([[0, 0], [1, 1]], np.float32),
+                np.array([[0, 0], [1, 1], [2, 2], [3, 3]], np.float32),  # collinear
+                np.array([[3, 4]] * 5, np.float32)):  # all identical
+        tri, edg = regularizer.delaunay(pts)
+        assert len(tri) == 0 and len(edg) == 0
+    pts = np.array([[0, 0], [4, 0], [0, 4], [4, 0], [0, 0], [1, 1]], np.float32)  # exact duplicates are skipped
+    tri, edg = regularizer.delaunay(pts)
+    assert tri_set(tri) == {(0, 1, 5), (0, 2, 5), (1, 2, 5)}
+    bad = np.array([[0, 0], [1, 0], [np.nan, 1]], np.float32)
+    with pytest.raises(regularizer.NLTGV2Error):
+        regularizer.delaunay(bad)
+    huge = np.array([[0, 0], [1e-30, 0], [1e30, 1]], np.float32)  # dynamic range beyond the exact predicates
+    with pytest.raises(regularizer.NLTGV2Error):
+        regularizer.delaunay(huge)
+
+
+def test_result_feeds_the_solver_graph(built):
+    """The triangulator's edges are a valid solver topology (what syncGraph does with them, flame.cc:2085-2104)."""
+    pts = synth.make_points(320, 240, 6, 5)
+    _, edg = regularizer.delaunay(pts)
+    g = synth.assemble_graph(pts, synth.make_data_term(pts, 320, 240, 5), edg)
+    pr = regularizer.pack_probe(g)
+    assert pr["n_slices"] == (g["V"] + 63) // 64
