@@ -163,20 +163,43 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
     key[v] = (static_cast<uint64_t>(static_cast<uint32_t>(find(v))) << 32) | m;
   }
   PROF_T(1);
-  std::vector<int32_t> order(V);
+  // stable LSD radix sort of the vertices by key (6 passes of 11 bits, constant digits skipped): O(V)
+  std::vector<int32_t> order(V), tmp(V);
   std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
-  auto degree = [&](int32_t v) { return L->row_ptr[v + 1] - L->row_ptr[v]; };
-  // degree-sort inside windows that never straddle two components (frames of a batch)
-  for (int32_t c0 = 0; c0 < V;) {
-    int32_t c1 = c0 + 1;
-    while (c1 < V && (key[order[c1]] >> 32) == (key[order[c0]] >> 32)) ++c1;
-    for (int32_t w0 = c0; w0 < c1; w0 += kDegreeWindow) {
-      const int32_t w1 = std::min<int32_t>(c1, w0 + kDegreeWindow);
-      std::stable_sort(order.begin() + w0, order.begin() + w1,
-                       [&](int32_t a, int32_t b) { return degree(a) > degree(b); });
+  {
+    constexpr int kBits = 11, kBuckets = 1 << kBits;
+    std::vector<uint32_t> count(kBuckets + 1);
+    for (int pass = 0; pass * kBits < 64; ++pass) {
+      const int shift = kBits * pass;
+      bool trivial = true;  // skip a pass whose digit is the same for all keys
+      const uint32_t d0 = V ? static_cast<uint32_t>((key[0] >> shift) & (kBuckets - 1)) : 0u;
+      for (int32_t v = 0; v < V && trivial; ++v) trivial = static_cast<uint32_t>((key[v] >> shift) & (kBuckets - 1)) == d0;
+      if (trivial) continue;
+      std::fill(count.begin(), count.end(), 0u);
+      for (int32_t i = 0; i < V; ++i) count[((key[order[i]] >> shift) & (kBuckets - 1)) + 1]++;
+      for (int d = 0; d < kBuckets; ++d) count[d + 1] += count[d];
+      for (int32_t i = 0; i < V; ++i) tmp[count[(key[order[i]] >> shift) & (kBuckets - 1)]++] = order[i];
+      order.swap(tmp);
     }
-    c0 = c1;
+  }
+  auto degree = [&](int32_t v) { return L->row_ptr[v + 1] - L->row_ptr[v]; };
+  // stable counting sort by descending degree inside windows that never straddle two components
+  // (frames of a batch)
+  {
+    std::vector<int32_t> bucket(static_cast<size_t>(maxdeg) + 2);
+    for (int32_t c0 = 0; c0 < V;) {
+      int32_t c1 = c0 + 1;
+      while (c1 < V && (key[order[c1]] >> 32) == (key[order[c0]] >> 32)) ++c1;
+      for (int32_t w0 = c0; w0 < c1; w0 += kDegreeWindow) {
+        const int32_t w1 = std::min<int32_t>(c1, w0 + kDegreeWindow);
+        std::fill(bucket.begin(), bucket.end(), 0);
+        for (int32_t i = w0; i < w1; ++i) bucket[maxdeg - degree(order[i]) + 1]++;  // slot 0 = highest degree
+        for (int32_t d = 0; d <= maxdeg; ++d) bucket[d + 1] += bucket[d];
+        for (int32_t i = w0; i < w1; ++i) tmp[w0 + bucket[maxdeg - degree(order[i])]++] = order[i];
+        std::copy(tmp.begin() + w0, tmp.begin() + w1, order.begin() + w0);
+      }
+      c0 = c1;
+    }
   }
 
   PROF_T(2);
