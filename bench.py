@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU in the extra 'batched' measurement (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip batched / other-config measurements")
-    ap.add_argument("--cpu-iters", type=int, default=8000)
+    ap.add_argument("--cpu-iters", type=int, default=20000)
     ap.add_argument("--persistent", type=int, default=1, help="0: one launch per step; 1: persistent single launch")
     return ap.parse_args()
 
