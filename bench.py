@@ -243,7 +243,7 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
     out["batched"] = {}
     for label, nf, iters in (("resident", None, 200), ("large", a.batch, 100)):
         if label == "resident":  # as many frames as the register-resident persistent kernel holds
-            nf = max(1, info["tv_wave_capacity"] // max(1, info["tv_waves"]))
+            nf = max(1, info["tv_wave_capacity"] // max(1, info["tv_waves"] + 1))
         if not nf:
             continue
         frames = [synth.make_graph(a.config, seed=5000 + i) for i in range(nf)]

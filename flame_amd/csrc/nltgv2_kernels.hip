@@ -482,7 +482,11 @@ __device__ __forceinline__ float dpp_shr1(float v) {  // lane l <- lane l-1; lan
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
 }
 
-__global__ void __launch_bounds__(256)
+// LDS_STATIC: the per-slot constants (neighbour offset, alpha, dx, dy, beta: 40 dwords per lane) live in LDS
+// (10 KB per wave) instead of registers, which halves the VGPR footprint and doubles the residency (16 waves per
+// CU): bigger resident batches and 4K-sized single graphs.  The duals stay in registers.
+template <bool LDS_STATIC>
+__global__ void __launch_bounds__(256, LDS_STATIC ? 3 : 2)
 k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd, const int32_t* __restrict__ tv_slot,
                 const int32_t* __restrict__ tv_vid, const uint32_t* __restrict__ tv_meta,
                 const uint32_t* __restrict__ tv_wave, const int4* hrec, float4* hq, float4* vstate,
@@ -510,8 +514,17 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
   const bool is_owner = (meta & kTvOwnerBit) != 0u;
   const bool valid = (meta & kTvValidBit) != 0u;
 
-  int nbr[kTvS];
-  float alpha[kTvS], dx[kTvS], dy[kTvS], beta[kTvS], q1[kTvS], q2[kTvS], q3[kTvS];
+  extern __shared__ __attribute__((aligned(16))) int tv_smem[];
+  int* const s_base = tv_smem + (threadIdx.x >> 6) * (5 * kTvS * 64) + lane;  // [field][slot][lane] per wave
+  int r_nbr[LDS_STATIC ? 1 : kTvS];
+  float r_alpha[LDS_STATIC ? 1 : kTvS], r_dx[LDS_STATIC ? 1 : kTvS], r_dy[LDS_STATIC ? 1 : kTvS], r_beta[LDS_STATIC ? 1 : kTvS];
+#define TV_I(field, k) s_base[((field) * kTvS + (k)) * 64]
+#define NBR(k) (*(LDS_STATIC ? &TV_I(0, k) : &r_nbr[LDS_STATIC ? 0 : (k)]))
+#define ALPHA(k) (*(LDS_STATIC ? (float*)&TV_I(1, k) : &r_alpha[LDS_STATIC ? 0 : (k)]))
+#define DX(k) (*(LDS_STATIC ? (float*)&TV_I(2, k) : &r_dx[LDS_STATIC ? 0 : (k)]))
+#define DY(k) (*(LDS_STATIC ? (float*)&TV_I(3, k) : &r_dy[LDS_STATIC ? 0 : (k)]))
+#define BETA(k) (*(LDS_STATIC ? (float*)&TV_I(4, k) : &r_beta[LDS_STATIC ? 0 : (k)]))
+  float q1[kTvS], q2[kTvS], q3[kTvS];
 #pragma unroll
   for (int k = 0; k < kTvS; ++k) {
     const int sl = tv_slot[((size_t)w * kTvS + k) * 64 + lane];
@@ -521,9 +534,9 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
       r = hrec[sl];
       q = hq[sl];
     }
-    nbr[k] = (int)(((unsigned)r.x & 0x80000000u) | (((unsigned)r.x & 0x07ffffffu) << 4));
-    alpha[k] = __int_as_float(r.y), dx[k] = __int_as_float(r.z), dy[k] = __int_as_float(r.w);
-    q1[k] = q.x, q2[k] = q.y, q3[k] = q.z, beta[k] = q.w;
+    NBR(k) = (int)(((unsigned)r.x & 0x80000000u) | (((unsigned)r.x & 0x07ffffffu) << 4));
+    ALPHA(k) = __int_as_float(r.y), DX(k) = __int_as_float(r.z), DY(k) = __int_as_float(r.w);
+    q1[k] = q.x, q2[k] = q.y, q3[k] = q.z, BETA(k) = q.w;
   }
 
   float4 st = make_float4(0.f, 0.f, 0.f, 0.f), bs = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -558,7 +571,7 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
 #pragma unroll
       for (int k = 0; k < kTvS; ++k) {
         if ((pending >> k) & 1u) {
-          int o = 4 * S + ((nbr[k] & 0x7fffffff) >> 2);
+          int o = 4 * S + ((NBR(k) & 0x7fffffff) >> 2);
           asm volatile("" : "+v"(o)::"memory");
           got[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, kAuxSc1);
         }
@@ -567,7 +580,7 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
       for (int k = 0; k < kTvS; ++k) {
         if (((pending >> k) & 1u) && (got[k] & ~15u) == want) {
           pending &= ~(1u << k);
-          if ((got[k] & 15u) == my_xcc) nbr[k] += S;  // poll the local copy (S < 2^31: role bit untouched)
+          if ((got[k] & 15u) == my_xcc) NBR(k) += S;  // poll the local copy (S < 2^31: role bit untouched)
         }
       }
       if (!__any(pending != 0u)) break;
@@ -599,7 +612,7 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
 #pragma unroll
       for (int k = 0; k < kTvS; ++k) {
         if ((pending >> k) & 1u) {
-          int o = nbr[k] & 0x7fffffff;
+          int o = NBR(k) & 0x7fffffff;
           asm volatile("" : "+v"(o)::"memory");  // opaque: re-issue on every spin
           g[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, o, so_in, kAuxSc1);
         }
@@ -635,17 +648,18 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
 #pragma unroll
       for (int k = 0; k < kTvS; ++k) {
         const bool act = live && (k < nslots);
-        const bool is_target = nbr[k] < 0;
+        const bool is_target = NBR(k) < 0;
+        const float alpha_k = ALPHA(k), beta_k = BETA(k), dx_k = DX(k), dy_k = DY(k);
         const float nxb = __int_as_float(g[k].x), nw1b = __int_as_float(g[k].y), nw2b = __int_as_float(g[k].z);
         const float xbi = is_target ? nxb : xb, xbj = is_target ? xb : nxb;
         const float w1bi = is_target ? nw1b : w1b, w1bj = is_target ? w1b : nw1b;
         const float w2bi = is_target ? nw2b : w2b, w2bj = is_target ? w2b : nw2b;
         bool okq = true;
-        const EdgeOut e = edge_dual(p, alpha[k], beta[k], dx[k], dy[k], q1[k], q2[k], q3[k], xbi, w1bi, w2bi,
+        const EdgeOut e = edge_dual(p, alpha_k, beta_k, dx_k, dy_k, q1[k], q2[k], q3[k], xbi, w1bi, w2bi,
                                     xbj, w1bj, w2bj, okq);
-        const float t1 = e.q1 * p.step_x * alpha[k];
-        const float t2 = e.q2 * p.step_x * beta[k];
-        const float t3 = e.q3 * p.step_x * beta[k];
+        const float t1 = e.q1 * p.step_x * alpha_k;
+        const float t2 = e.q2 * p.step_x * beta_k;
+        const float t3 = e.q3 * p.step_x * beta_k;
         float nx, nw1, nw2;
         if (is_target) {
           nx = X + t1;
@@ -653,8 +667,8 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
           nw2 = W2 + t3;
         } else {
           nx = X - t1;
-          nw1 = W1 + t1 * dx[k];
-          nw2 = W2 + t1 * dy[k];
+          nw1 = W1 + t1 * dx_k;
+          nw2 = W2 + t1 * dy_k;
           nw1 = nw1 - t2;
           nw2 = nw2 - t3;
         }
@@ -706,9 +720,15 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
   }
 #pragma unroll
   for (int k = 0; k < kTvS; ++k) {
-    if (k < nslots) hq[tv_slot[((size_t)w * kTvS + k) * 64 + lane]] = make_float4(q1[k], q2[k], q3[k], beta[k]);
+    if (k < nslots) hq[tv_slot[((size_t)w * kTvS + k) * 64 + lane]] = make_float4(q1[k], q2[k], q3[k], BETA(k));
   }
   if (!ok) atomicOr(err, 1);
+#undef NBR
+#undef ALPHA
+#undef DX
+#undef DY
+#undef BETA
+#undef TV_I
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1202,7 +1222,7 @@ int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, boo
 // so the caller can fall back to per-step launches.
 int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, int wave_begin, int n_waves,
                           int parity_in, unsigned tag0, int n_iters, int waves_per_block, unsigned max_spins,
-                          int presleep, int dual, bool cooperative, hipStream_t stream) {
+                          int presleep, int dual, int tv_static_in_lds, bool cooperative, hipStream_t stream) {
   if (n_waves <= 0 || n_iters <= 0) return (int)hipSuccess;
   int wpx = (n_waves + 7) / 8;
   const int bpx = (wpx + waves_per_block - 1) / waves_per_block;
@@ -1226,12 +1246,15 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
   void* args[] = {&wave_begin, &n_waves, &wpx, &i0, &i1, &i2, &i3, &hrec, &hq, &vstate, &vaux, &bin,
                   &bout, &vprev, &xbuf, &rec_bytes, &dual, &tag0, &n_iters, &max_spins, &presleep, &pp, &err,
                   &abort_flag};
-  const void* fn = (form == 2) ? (const void*)k_persistent_tv : (const void*)k_persistent_he;
+  const bool tv_lds = form == 2 && (tv_static_in_lds != 0);
+  const void* fn = (form == 2) ? (tv_lds ? (const void*)k_persistent_tv<true> : (const void*)k_persistent_tv<false>)
+                               : (const void*)k_persistent_he;
+  const unsigned lds_bytes = tv_lds ? (unsigned)(waves_per_block * 5 * kTvS * 64 * sizeof(int)) : 0u;
   // The first launch of a topology is cooperative: the runtime verifies that the whole grid is
   // resident (hipErrorCooperativeLaunchTooLarge otherwise).  The same grid is then launched plainly
   // (identical residency, ~15 us less launch overhead per call).
-  if (cooperative) return (int)hipLaunchCooperativeKernel(fn, grid, block, args, 0, stream);
-  return (int)hipLaunchKernel(fn, grid, block, args, 0, stream);
+  if (cooperative) return (int)hipLaunchCooperativeKernel(fn, grid, block, args, lds_bytes, stream);
+  return (int)hipLaunchKernel(fn, grid, block, args, lds_bytes, stream);
 }
 
 int launch_save_prev(const CanonArgs& c, hipStream_t s) {

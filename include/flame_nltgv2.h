@@ -231,10 +231,13 @@ enum {
                                         when the graph fits on the chip, picking the form by occupancy;
                                         2 = force the lane-per-half-edge form, 3 = force the vertex-per-lane
                                         form (each only if it fits); 0 = always one launch per step */
-  FLAME_NLTGV2_OPT_DUAL_PUBLISH = 6  /* persistent run: neighbours on the same XCD exchange through that XCD's
+  FLAME_NLTGV2_OPT_DUAL_PUBLISH = 6, /* persistent run: neighbours on the same XCD exchange through that XCD's
                                         L2 (plain store + local record copy), others through write-through
                                         records: 2 = always, 1 (default) = when many waves share a CU,
                                         0 = write-through records only */
+  FLAME_NLTGV2_OPT_TV_LDS = 7      /* vertex-per-lane persistent form: per-slot constants in LDS instead of registers
+                                        (12 instead of 8 waves per CU resident): 2 = always, 1 (default) = when the
+                                        register form is not resident in one launch, 0 = never */
 };
 int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value);
 

@@ -6,6 +6,7 @@ import torch  # noqa
 import flame_amd
 from flame_amd import synth
 from flame_amd.regularizer import OPT_PERSISTENT, OPT_DUAL_PUBLISH, RUN_PATHS
+OPT_TV_LDS = 7
 
 params = flame_amd.Params()
 cases = [("640x480", 1), ("1280x720", 1), ("1920x1080", 1), ("640x480", 4), ("640x480", 7), ("640x480", 12), ("640x480", 15), ("640x480", 30)]
@@ -15,10 +16,11 @@ for cfg, nf in cases:
     frames = [synth.make_graph(cfg, seed=5000 + i) for i in range(nf)]
     g = synth.concat_graphs(frames) if nf > 1 else frames[0]
     row = {}
-    for form, dual in ((2, 2), (2, 0), (3, 2), (3, 0), (0, 0)):
+    for form, dual, lds in ((2, 2, 0), (3, 2, 0), (3, 2, 2), (0, 0, 0)):
         r = flame_amd.Regularizer(0)
         r.set_option(OPT_PERSISTENT, form)
         r.set_option(OPT_DUAL_PUBLISH, dual)
+        r.set_option(OPT_TV_LDS, lds)
         r.upload_graph(g)
         iters = 200 if form else 50
         try:
@@ -28,8 +30,8 @@ for cfg, nf in cases:
             path = RUN_PATHS[info["last_run_path"]]
             us = ms * 1e3 / iters
             gbps = info["algorithmic_bytes_per_iter"] / (us * 1e-6) / 1e9
-            row[path + ("+L2" if dual else "")] = f"{us:7.2f} us/it {nf / (us * 1e-6) / 1e6:6.2f} Mfi/s frac {gbps / 8000:5.3f}"
+            row[path + ("+L2" if dual else "") + ("+lds" if lds else "")] = f"{us:7.2f} us/it {nf / (us * 1e-6) / 1e6:6.2f} Mfi/s frac {gbps / 8000:5.3f}"
         except Exception as e:
-            row[f"form{form}"] = f"ERR {e}"
+            row[f"form{form}{lds}"] = f"ERR {e}"
         r.close()
     print(cfg, "x", nf, "V", g["V"], json.dumps(row))
