@@ -186,7 +186,7 @@ def main():
                          "iters": a.iters, "tolerance_rms": 1e-4}
         # ---- CPU baseline on this box's host cores: reference-layout restatement, 1 thread (the
         # reference runs its solver on exactly one thread, flame.cc:99-112)
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N=1 only
             secs = oracle.reflayout_run_timed(synth.copy_graph(g), a.cpu_iters)
             flat = oracle.run_timed(synth.copy_graph(g), max(200, a.cpu_iters // 4))
             out["cpu_baseline"] = {
