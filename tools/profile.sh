@@ -19,4 +19,10 @@ B2="$B --persistent 0"
 rocprofv3 --kernel-trace --stats -d $OUT/kt_step -o kt --output-format csv -- $B2 > $OUT/kt_step.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch_step -o f --output-format csv -- $B2 > $OUT/fetch_step.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/write_step -o w --output-format csv -- $B2 > $OUT/write_step.log 2>&1
+# the HBM-streaming regime: 64 frames through k_fused_step (persistent forms off)
+S="python tools/stream_case.py 64"
+rocprofv3 --kernel-trace --stats -d $OUT/kt_stream -o kt --output-format csv -- $S > $OUT/kt_stream.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch_stream -o f --output-format csv -- $S > $OUT/fetch_stream.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/write_stream -o w --output-format csv -- $S > $OUT/write_stream.log 2>&1
 grep -h '"metric"' $OUT/kt.log $OUT/kt_step.log | cut -c1-400
+tail -1 $OUT/kt_stream.log

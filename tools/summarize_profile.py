@@ -42,7 +42,8 @@ def kstat(path, kernel):
 out = {}
 traffic = {}
 for tag, sub, kernel, path_name in (("persistent", "", "k_persistent_he", "persistent"),
-                                    ("per_step", "_step", "k_fused_step", "per-step hipGraph")):
+                                    ("per_step", "_step", "k_fused_step", "per-step hipGraph"),
+                                    ("stream_64_frames", "_stream", "k_fused_step", None)):
     kt = os.path.join(SRC, "kt" + sub, "kt_kernel_stats.csv")
     if not os.path.exists(kt):
         continue
@@ -59,8 +60,11 @@ for tag, sub, kernel, path_name in (("persistent", "", "k_persistent_he", "persi
         hbm = (2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024.0
         entry["hbm_bytes_per_launch"] = hbm
         entry["hbm_formula"] = "(2*FETCH_SIZE + WRITE_SIZE)*1024  [KiB counters; x2 = gfx950 FETCH_SIZE correction]"
-        traffic[f"640x480:{path_name}"] = {"hbm_bytes_per_launch": round(hbm), "kernel": kernel,
-                                            "source": f"profiles/{R}_counters.json"}
+        if path_name:
+            traffic[f"640x480:{path_name}"] = {"hbm_bytes_per_launch": round(hbm), "kernel": kernel,
+                                                "source": f"profiles/{R}_counters.json"}
+        if entry["kernel_stats"]:
+            entry["measured_hbm_GBps"] = round(hbm / (entry["kernel_stats"]["avg_ns"] * 1e-9) / 1e9, 1)
     out[tag] = entry
 json.dump(out, open(os.path.join(DST, f"{R}_counters.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
