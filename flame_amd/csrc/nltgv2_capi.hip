@@ -32,7 +32,7 @@ constexpr int kMaxCachedGraphs = 6;
 constexpr int kHeWavesPerCu = 24;      // residency cap of k_persistent_he (<= 64 VGPRs: the hardware admits 32)
 constexpr int kTvLdsWavesPerCu = 12;   // ... with the slot constants in LDS (167 VGPRs -> 3 waves per SIMD, 10 KB LDS per wave)
 constexpr int kTvWavesPerCu = 8;       // residency of k_persistent_tv (<= 256 VGPRs -> 2 waves per SIMD)
-constexpr int kDualMinWavesPerCu = 5;  // auto: exchange through the XCD's L2 when more waves than this share a CU
+constexpr int kDualMinWavesPerCu = 0;  // auto: exchange through the XCD's L2 when more waves than this share a CU
 constexpr int kPreSleep = 12;  // initial x64-cycle sleep between publishing and the first neighbour poll (adapts)
 constexpr unsigned kMaxSpins = 1u << 20;  // bound of every neighbour wait in the persistent run (~1 s of polling bursts)
 
@@ -395,9 +395,8 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
     int e = 0;
     for (const WaveGroup& gr : groups) {
       const int pw = gr.count <= 4 * ctx->prop.multiProcessorCount ? 1 : 4;  // waves per workgroup
-      // same-XCD exchange through L2 pays once the memory side is busy (measured per step: 1080p graph
-      // -18 %, 7-frame batch -20 %, 15-frame batch -19 %, 1280x720 -5 %; a lone 640x480 frame at 3 waves
-      // per CU +6 %)
+      // same-XCD exchange through L2: with the waves laid out along the Morton curve it wins at every size
+      // (measured per step: 640x480 -16 %, 1280x720 -23 %, 1080p -18 %, 7-frame batch -20 %, 15 frames -19 %)
       const int dual = ctx->opt_dual == 2 || (ctx->opt_dual == 1 && gr.count > kDualMinWavesPerCu * ctx->prop.multiProcessorCount);
       e = launch_persistent_run(ctx->f, to_sp(p), form, gr.begin, gr.count, ctx->parity, tag0, n, pw, kMaxSpins,
                                 kPreSleep, dual, tv_lds, ctx->coop_checked_key != key, ctx->stream);

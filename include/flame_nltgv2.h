@@ -233,8 +233,7 @@ enum {
                                         form (each only if it fits); 0 = always one launch per step */
   FLAME_NLTGV2_OPT_DUAL_PUBLISH = 6, /* persistent run: neighbours on the same XCD exchange through that XCD's
                                         L2 (plain store + local record copy), others through write-through
-                                        records: 2 = always, 1 (default) = when many waves share a CU,
-                                        0 = write-through records only */
+                                        records: 1 (default) and 2 = on, 0 = write-through records only */
   FLAME_NLTGV2_OPT_TV_LDS = 7      /* vertex-per-lane persistent form: per-slot constants in LDS instead of registers
                                         (12 instead of 8 waves per CU resident): 2 = always, 1 (default) = when the
                                         register form is not resident in one launch, 0 = never */
