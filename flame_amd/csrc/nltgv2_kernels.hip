@@ -296,7 +296,7 @@ k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd
   float x_prev = x, w1_prev = w1, w2_prev = w2;
   bool ok = true;
   bool timed_out = false;
-  int ps = presleep >= 0 ? presleep : -presleep;  // presleep < 0: fixed |presleep|, no adaptation
+  const int ps = presleep;  // x64 cycles between publishing and the first poll (fixed per launch)
 
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(xbuf);
   const int my_off = pv << 4;
@@ -343,7 +343,9 @@ k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd
     // and thousands of them in flight slow down the very stores they are waiting for (measured: a
     // 4-deep poll ring made the step 45 % slower).  So: sleep `ps` x 64 cycles after publishing (the
     // neighbours publish at about the same time; their records need ~0.45 us to become visible),
-    // then poll, pausing 64 cycles between misses; `ps` adapts per wave (below).  The offset goes through an opaque copy
+    // then poll, pausing 64 cycles between misses.  `ps` is fixed per launch (the host picks it from the
+    // number of waves per CU; a per-wave adaptive rule -- lengthen on a miss, shorten on a clean step --
+    // drifted late and measured 3-17 % slower than the best fixed value).  The offset goes through an opaque copy
     // so the compiler re-issues the load (it would otherwise hoist it out of the spin).
     v4i_t g = {0, 0, 0, 0};
     bool pend = active;
@@ -369,12 +371,6 @@ k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd
       __builtin_amdgcn_s_sleep(1);
     }
     if (timed_out) break;
-    // adapt the pre-poll sleep (wave-uniform): a miss costs a whole memory round trip, sleeping a
-    // little too long costs only the excess -> lengthen on a miss, probe shorter every 4th clean step
-    if (presleep >= 0) {
-      if (spins != 0u) ps = (ps < 48) ? ps + 1 : ps;
-      else if ((it & 3) == 3 && ps > 0) ps -= 1;
-    }
 
     // ---- dual update of this half-edge's private q copy (cc:99-110) ------------------------------
     const float nxb = __int_as_float(g.x), nw1b = __int_as_float(g.y), nw2b = __int_as_float(g.z);
@@ -553,7 +549,7 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
   float x_prev = x, w1_prev = w1, w2_prev = w2;
   bool ok = true;
   bool timed_out = false;
-  int ps = presleep >= 0 ? presleep : -presleep;
+  const int ps = presleep;
 
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(xbuf);
   const int my_off = pv << 4;
@@ -633,10 +629,6 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
       __builtin_amdgcn_s_sleep(1);
     }
     if (timed_out) break;
-    if (presleep >= 0) {
-      if (spins != 0u) ps = (ps < 48) ? ps + 1 : ps;
-      else if ((it & 3) == 3 && ps > 0) ps -= 1;
-    }
 
     float X = x, W1 = w1, W2 = w2;
     for (int pass = 0; pass < passes; ++pass) {

@@ -234,9 +234,12 @@ enum {
   FLAME_NLTGV2_OPT_DUAL_PUBLISH = 6, /* persistent run: neighbours on the same XCD exchange through that XCD's
                                         L2 (plain store + local record copy), others through write-through
                                         records: 1 (default) and 2 = on, 0 = write-through records only */
-  FLAME_NLTGV2_OPT_TV_LDS = 7      /* vertex-per-lane persistent form: per-slot constants in LDS instead of registers
+  FLAME_NLTGV2_OPT_TV_LDS = 7,       /* vertex-per-lane persistent form: per-slot constants in LDS instead of registers
                                         (12 instead of 8 waves per CU resident): 2 = always, 1 (default) = when the
                                         register form is not resident in one launch, 0 = never */
+  FLAME_NLTGV2_OPT_PRESLEEP = 8      /* persistent run, sleep between publishing a step's record and the first
+                                        neighbour poll: 0 (default) = chosen from the waves per CU;
+                                        n in 1..64 = (n-1) x 64 cycles */
 };
 int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value);
 
