@@ -527,6 +527,7 @@ const char* flame_nltgv2_status_string(int status) {
     case FLAME_NLTGV2_ERR_NAN: return "dual variable became NaN/Inf (reference FLAME_ASSERT, h:174)";
     case FLAME_NLTGV2_ERR_OOM: return "out of device memory";
     case FLAME_NLTGV2_ERR_TIMEOUT: return "persistent run: neighbour wait timed out";
+    case FLAME_NLTGV2_ERR_ASSERT: return "input on which the reference asserts (FLAME_ASSERT)";
     default: return "unknown status";
   }
 }

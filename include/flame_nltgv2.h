@@ -44,8 +44,10 @@ typedef enum flame_nltgv2_status {
                                         reference's FLAME_ASSERT(!std::isnan(new_q)) fires
                                         (nltgv2...h:174).  Sticky until the next upload. */
   FLAME_NLTGV2_ERR_OOM = -6,
-  FLAME_NLTGV2_ERR_TIMEOUT = -7      /* persistent run: a bounded neighbour wait expired (should not
+  FLAME_NLTGV2_ERR_TIMEOUT = -7,     /* persistent run: a bounded neighbour wait expired (should not
                                         happen; state is invalid, upload the graph again) */
+  FLAME_NLTGV2_ERR_ASSERT = -8       /* flame_stereo.h: an input on which the reference's FLAME_ASSERT would
+                                        exit(1) (assert.h:111) */
 } flame_nltgv2_status;
 
 /* == struct Params, nltgv2_l1_graph_regularizer.h:121-129 (same fields, order and defaults). */

@@ -44,7 +44,7 @@ def lib():
     if _LIB is None:
         path = os.path.join(_HERE, "liboracle_nltgv2.so")
         src = os.path.join(_HERE, "nltgv2_oracle.c")
-        others = [os.path.join(_HERE, f) for f in ("photometric_oracle.c", "raster_oracle.c")]
+        others = [os.path.join(_HERE, f) for f in ("photometric_oracle.c", "raster_oracle.c", "stereo_oracle.c")]
         if (not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src)
                 or any(os.path.getmtime(path) < os.path.getmtime(o) for o in others)):
             build()

@@ -1,4 +1,4 @@
-"""The C-ABI library loads here (no GPU) and exports every symbol include/flame_nltgv2.h declares;
+"""The C-ABI library loads here (no GPU) and exports every symbol include/*.h declares;
 without a device every compute entry point fails loudly (no CPU fallback in the product path)."""
 import ctypes as C
 import os
@@ -9,34 +9,39 @@ import pytest
 
 from tests.conftest import HAS_GPU, ROOT
 
-HEADER = os.path.join(ROOT, "include", "flame_nltgv2.h")
+HEADERS = [os.path.join(ROOT, "include", h) for h in ("flame_nltgv2.h", "flame_stereo.h")]
 
 
 def declared_symbols():
-    txt = open(HEADER).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(flame_(?:nltgv2|delaunay)_[a-z_0-9]+)\s*\(", txt)))
+    out = set()
+    for h in HEADERS:
+        txt = open(h).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        out |= set(re.findall(r"\b(flame_(?:nltgv2|delaunay|stereo)_[a-z_0-9]+)\s*\(", txt))
+    return sorted(out)
 
 
 def test_header_symbols_are_exported(built):
     import flame_amd
     from flame_amd.regularizer import ABI_SYMBOLS
+    from flame_amd.stereo import STEREO_ABI_SYMBOLS
 
     decl = declared_symbols()
-    assert len(decl) >= 25
-    assert set(decl) == set(ABI_SYMBOLS), set(decl) ^ set(ABI_SYMBOLS)
+    assert len(decl) >= 38
+    assert set(decl) == set(ABI_SYMBOLS) | set(STEREO_ABI_SYMBOLS), set(decl) ^ (set(ABI_SYMBOLS) | set(STEREO_ABI_SYMBOLS))
     lib = C.CDLL(flame_amd.library_path())
     for name in decl:
         assert hasattr(lib, name), name
     nm = subprocess.check_output(["nm", "-D", "--defined-only", flame_amd.library_path()], text=True)
-    exported = set(re.findall(r" T (flame_(?:nltgv2|delaunay)_[a-z_0-9]+)", nm))
+    exported = set(re.findall(r" T (flame_(?:nltgv2|delaunay|stereo)_[a-z_0-9]+)", nm))
     assert set(decl) <= exported
 
 
 def test_header_is_plain_c(built, tmp_path):
     """The boundary is a C ABI: the header must compile as C99 and as C++."""
     src = tmp_path / "t.c"
-    src.write_text('#include "flame_nltgv2.h"\nint main(void){flame_nltgv2_params p; (void)p; return FLAME_NLTGV2_ABI_VERSION - 1;}\n')
+    src.write_text('#include "flame_nltgv2.h"\n#include "flame_stereo.h"\nint main(void){flame_nltgv2_params p; flame_stereo_feature f; (void)p; (void)f;'
+                   ' return FLAME_NLTGV2_ABI_VERSION - 1 + (int)sizeof(flame_stereo_feature) - 40;}\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-c", str(src),
                            "-o", str(tmp_path / "t.o")])
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-x", "c++", "-I", os.path.join(ROOT, "include"), "-c", str(src),
@@ -53,7 +58,7 @@ def test_defaults_and_status_strings(built):
     # == nltgv2_l1_graph_regularizer.h:121-129
     assert [round(v, 6) for v in (p.data_factor, p.step_x, p.step_q, p.theta, p.x_min, p.x_max)] == \
         [0.1, 0.001, 125.0, 0.25, 0.0, 10.0]
-    for st in range(0, -8, -1):
+    for st in range(0, -9, -1):
         assert lib.flame_nltgv2_status_string(st)
     assert b"unknown" in lib.flame_nltgv2_status_string(-99)
 
@@ -65,6 +70,11 @@ def test_no_device_fails_loudly(built):
     with pytest.raises(flame_amd.NLTGV2Error) as ei:
         flame_amd.Regularizer(0)
     assert ei.value.status == -2  # FLAME_NLTGV2_ERR_NO_DEVICE: no silent CPU path
+    from flame_amd.stereo import FeatureTracker
+
+    with pytest.raises(flame_amd.NLTGV2Error) as ei:
+        FeatureTracker([525, 0, 320, 0, 525, 240, 0, 0, 1], [1, 0, 0, 0, 1, 0, 0, 0, 1], 640, 480)
+    assert ei.value.status == -2
 
 
 def test_product_package_never_imports_the_checker():
