@@ -31,6 +31,34 @@ def build_bgl_program(tmp_path):
     return exe
 
 
+def build_tracker_program(tmp_path):
+    exe = str(tmp_path / "feature_tracker_test")
+    lib_dir = os.path.join(ROOT, "flame_amd")
+    subprocess.check_call([
+        "g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-Werror", "-Wno-invalid-offsetof", "-I", os.path.join(ROOT, "include"),
+        os.path.join(ROOT, "tests", "cpp", "feature_tracker_test.cc"), "-o", exe,
+        "-L", lib_dir, "-lflame_nltgv2_hip", "-L", os.path.join(ROOT, "oracle"), "-loracle_nltgv2",
+        f"-Wl,-rpath,{lib_dir}", f"-Wl,-rpath,{os.path.join(ROOT, 'oracle')}", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_feature_tracker_binding_compiles_and_fails_loudly_without_a_device(built, tmp_path):
+    """include/flame_hip/feature_tracker.hpp with look-alikes of the reference's Params/Frame/SE3/FeatureWithIDepth."""
+    exe = build_tracker_program(tmp_path)
+    from tests.conftest import HAS_GPU
+
+    if not HAS_GPU:
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 77 and "no usable HIP device" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_feature_tracker_binding_end_to_end(built, tmp_path):
+    r = subprocess.run([build_tracker_program(tmp_path)], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and r.stdout.count(" ok") >= 3, r.stdout + r.stderr
+
+
 def test_bgl_adaptor_compiles_against_the_bgl_api(built, tmp_path):
     """include/flame_hip/bgl_adaptor.hpp against a test-only mock of the Boost.Graph calls it makes."""
     assert os.path.exists(build_bgl_program(tmp_path))

@@ -1,0 +1,43 @@
+"""Times the per-feature epipolar update: kernel (HIP events), host-array call, frame creation, CPU checker."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import torch  # noqa: F401  (one HIP runtime per process)
+
+from flame_amd import synth_stereo as ss
+from flame_amd.stereo import FEATURE_DTYPE, FeatureTracker, StereoParams
+from oracle import stereo_capi as so
+
+for (w, h, n) in ((640, 480, 4240), (1280, 720, 9282), (1920, 1080, 28800)):
+    sc = ss.standard_scene(w, h)
+    imgs = {c: sc.render(c) for c in (10, 11, 12)}
+    feats = ss.make_features(sc, FEATURE_DTYPE, [10, 11], n, 3)
+    poses = ss.poses_for(sc, [10, 11], 12, 11)
+    P = StereoParams()
+    with FeatureTracker(sc.K32, sc.Kinv32, w, h) as tr:
+        t0 = time.perf_counter()
+        for c, img in imgs.items():
+            tr.add_frame(c, img)
+        t_frames = (time.perf_counter() - t0) / 3
+        t0 = time.perf_counter(); tr.add_frame(12, imgs[12]); t_frame = time.perf_counter() - t0
+        best_k, best_c = 1e9, 1e9
+        for _ in range(10):
+            f = feats.copy()
+            t0 = time.perf_counter()
+            rc, st = tr.update_feature_idepths(P, 12, 11, poses, f)
+            best_c = min(best_c, time.perf_counter() - t0)
+            best_k = min(best_k, tr.last_kernel_ms())
+    frames = [dict(p, img_pad=so.make_frame(imgs[p["id"]], 5)[0]) for p in poses]
+    newf = so.make_frame(imgs[12], 5)
+    best_o = 1e9
+    for _ in range(5):
+        f = feats.copy().view(so.FEATURE_DTYPE)
+        t0 = time.perf_counter()
+        so.update_feature_idepths(so.Params(), sc.K32, sc.Kinv32, w, h, 5, frames, newf, 11, f)
+        best_o = min(best_o, time.perf_counter() - t0)
+    t0 = time.perf_counter(); so.make_frame(imgs[12], 5); t_of = time.perf_counter() - t0
+    print("%dx%d feats %d updates %d | kernel %.1f us  host call %.1f us  add_frame %.1f us | cpu checker %.1f us  cpu frame %.1f us"
+          % (w, h, feats.shape[0], st["num_idepth_updates"], best_k * 1e3, best_c * 1e6, t_frame * 1e6, best_o * 1e6, t_of * 1e6), flush=True)
