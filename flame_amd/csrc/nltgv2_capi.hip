@@ -35,7 +35,7 @@ constexpr int kTvWavesPerCu = 8;       // residency of k_persistent_tv (<= 256 V
 constexpr int kDualMinWavesPerCu = 0;  // auto: exchange through the XCD's L2 when more waves than this share a CU
 // x64-cycle sleep between publishing and the first neighbour poll (measured optimum, r01 sweep: he 6 at
 // <= 12 waves/CU, 10 above; tv is insensitive, shortest wins)
-constexpr int kPreSleepHe = 6, kPreSleepHeDense = 10, kPreSleepTv = 2;
+constexpr int kPreSleepHe = 6, kPreSleepHeDense = 10, kPreSleepHeOneXcd = 4, kPreSleepTv = 2;
 constexpr unsigned kMaxSpins = 1u << 20;  // bound of every neighbour wait in the persistent run (~1 s of polling bursts)
 
 struct DevBuf {
@@ -68,6 +68,7 @@ struct flame_nltgv2_ctx {
   uint64_t topo = 0, stamp = 0;
 
   int opt_solver = 0, opt_use_graph = 1, opt_block_waves = 0, opt_unroll = 0, opt_persistent = 1, opt_dual = 1;
+  int opt_xcds = 0;      // XCDs a persistent launch spreads over: 0 = auto, 1..8
   int opt_presleep = 0;  // 0: auto (kPreSleep*); n > 0: (n - 1) x 64 cycles
   int opt_tv_lds = 1;  // 0 registers, 1 auto (LDS when the register form is not resident in one launch), 2 LDS
   uint32_t tag_next = 1;  // persistent run: tag of the current bar values (monotonic)
@@ -401,11 +402,18 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       // same-XCD exchange through L2: with the waves laid out along the Morton curve it wins at every size
       // (measured per step: 640x480 -16 %, 1280x720 -23 %, 1080p -18 %, 7-frame batch -20 %, 15 frames -19 %)
       const int dual = ctx->opt_dual == 2 || (ctx->opt_dual == 1 && gr.count > kDualMinWavesPerCu * ctx->prop.multiProcessorCount);
+      // A graph of <= 8 lane-per-half-edge waves per CU of ONE XCD (32 CUs) runs there entirely: every exchange
+      // stays in that XCD's L2 (measured 320x240: 1.23 instead of 1.47 us per step; at 640x480 the 26 waves per CU
+      // this would need cost more than the shorter hop saves).
+      const int cus_per_xcd = ctx->prop.multiProcessorCount / 8;
+      const int xcds = ctx->opt_xcds > 0 ? ctx->opt_xcds : (form == 1 && gr.count <= 8 * cus_per_xcd) ? 1 : 8;
       const int presleep = ctx->opt_presleep > 0 ? ctx->opt_presleep - 1
                            : form == 2                ? kPreSleepTv
+                           : xcds == 1                ? kPreSleepHeOneXcd
                            : gr.count > 12 * ctx->prop.multiProcessorCount ? kPreSleepHeDense
                                                                             : kPreSleepHe;
-      e = launch_persistent_run(ctx->f, to_sp(p), form, gr.begin, gr.count, ctx->parity, tag0, n, pw, kMaxSpins, presleep, dual, tv_lds, ctx->coop_checked_key != key, ctx->stream);
+      e = launch_persistent_run(ctx->f, to_sp(p), form, gr.begin, gr.count, ctx->parity, tag0, n, pw, kMaxSpins, presleep, dual,
+                                tv_lds, xcds, ctx->coop_checked_key != key, ctx->stream);
       if (e != 0) break;
     }
     if (e == 0) {
@@ -609,6 +617,11 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
     case FLAME_NLTGV2_OPT_DUAL_PUBLISH:
       if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_dual = value;
+      return 0;
+    case FLAME_NLTGV2_OPT_XCDS:
+      if (value < 0 || value > 8) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_xcds = value;
+      ctx->coop_checked_key = ~0ull;
       return 0;
     case FLAME_NLTGV2_OPT_PRESLEEP:
       if (value < 0 || value > 64) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);

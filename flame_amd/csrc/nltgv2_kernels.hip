@@ -1214,9 +1214,12 @@ int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, boo
 // so the caller can fall back to per-step launches.
 int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, int wave_begin, int n_waves,
                           int parity_in, unsigned tag0, int n_iters, int waves_per_block, unsigned max_spins,
-                          int presleep, int dual, int tv_static_in_lds, bool cooperative, hipStream_t stream) {
+                          int presleep, int dual, int tv_static_in_lds, int xcds, bool cooperative, hipStream_t stream) {
   if (n_waves <= 0 || n_iters <= 0) return (int)hipSuccess;
-  int wpx = (n_waves + 7) / 8;
+  // Workgroup b runs on XCD b & 7.  With xcds < 8 only the first `xcds` XCDs get waves (the workgroups of the
+  // others find no work and exit), which keeps a small graph's whole exchange inside fewer L2s.
+  if (xcds < 1 || xcds > 8) xcds = 8;
+  int wpx = (n_waves + xcds - 1) / xcds;
   const int bpx = (wpx + waves_per_block - 1) / waves_per_block;
   const dim3 grid((unsigned)(bpx * 8)), block((unsigned)(64 * waves_per_block));
   const int32_t* i0 = (form == 2) ? a.tv_slot : a.he_slot;

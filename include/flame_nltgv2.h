@@ -239,9 +239,11 @@ enum {
   FLAME_NLTGV2_OPT_TV_LDS = 7,       /* vertex-per-lane persistent form: per-slot constants in LDS instead of registers
                                         (12 instead of 8 waves per CU resident): 2 = always, 1 (default) = when the
                                         register form is not resident in one launch, 0 = never */
-  FLAME_NLTGV2_OPT_PRESLEEP = 8      /* persistent run, sleep between publishing a step's record and the first
+  FLAME_NLTGV2_OPT_PRESLEEP = 8,     /* persistent run, sleep between publishing a step's record and the first
                                         neighbour poll: 0 (default) = chosen from the waves per CU;
                                         n in 1..64 = (n-1) x 64 cycles */
+  FLAME_NLTGV2_OPT_XCDS = 9          /* persistent run: number of XCDs (of 8) the waves are spread over: 0 (default) =
+                                        one XCD for graphs small enough to run there, else all eight; 1..8 */
 };
 int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value);
 
