@@ -392,6 +392,14 @@ def test_gpu_update_matches_oracle(built, size):
 
 
 @gpu
+def test_gpu_update_matches_oracle_1080p(built):
+    """BASELINE's largest image size: 57 k features anchored in two pose-frames."""
+    sc, imgs, feats, poses = _scene_case(1920, 1080, 28800, seed=12)
+    st, out = _assert_same(sc, imgs, feats, poses)
+    assert feats.shape[0] > 50000 and st[0] > 0.5 * feats.shape[0]
+
+
+@gpu
 def test_gpu_frame_create_matches_oracle(built):
     from flame_amd.stereo import FeatureTracker
 
