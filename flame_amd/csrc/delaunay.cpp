@@ -96,6 +96,12 @@ class Triangulator {
   bool filter_ok = false;       // differences of coordinates are exact in double
 
   int orient(int a, int b, int c) const {  // > 0: c to the left of a->b (counter-clockwise), exact
+    if (filter_ok) {  // the differences are exact in double; only the two products and their difference round
+      const double l = (p[b].fx - p[a].fx) * (p[c].fy - p[a].fy), r = (p[b].fy - p[a].fy) * (p[c].fx - p[a].fx);
+      const double det = l - r, bound = 4.0e-16 * (std::fabs(l) + std::fabs(r));  // > (3 + 16 eps) eps, Shewchuk's ccwerrboundA
+      if (det > bound) return 1;
+      if (det < -bound) return -1;
+    }
     const i128 d = (i128)(p[b].x - p[a].x) * (p[c].y - p[a].y) - (i128)(p[b].y - p[a].y) * (p[c].x - p[a].x);
     return d > 0 ? 1 : (d < 0 ? -1 : 0);
   }
@@ -149,6 +155,12 @@ class Triangulator {
     T.v[0] = a, T.v[1] = b, T.v[2] = c;
     T.n[0] = T.n[1] = T.n[2] = -1;
     T.alive = true;
+    if (!free_.empty()) {  // reuse the slot of a removed triangle: the working set stays ~2n triangles
+      const int i = free_.back();
+      free_.pop_back();
+      t[(size_t)i] = T;
+      return i;
+    }
     t.push_back(T);
     in_cavity.push_back(0);
     return (int)t.size() - 1;
@@ -201,13 +213,17 @@ class Triangulator {
       }
     }
     // boundary edges (a -> b as seen from inside the cavity, cavity on the left) and their outer neighbours
-    struct BE { int a, b, outer, tri; };
-    std::vector<BE> be;
+    be.clear();
     for (int ti : cavity) {
       for (int i = 0; i < 3; ++i) {
         const int nb = t[ti].n[i];
         if (nb < 0 || !in_cavity[nb]) be.push_back(BE{t[ti].v[(i + 1) % 3], t[ti].v[(i + 2) % 3], nb, -1});
       }
+    }
+    for (int ti : cavity) {  // retire the cavity (their slots are reused by the fan below)
+      t[ti].alive = false;
+      in_cavity[ti] = 0;
+      free_.push_back(ti);
     }
     for (BE& e : be) {
       e.tri = new_tri(e.a, e.b, d);  // orientation inherited from the removed triangle: (a, b, apex) ccw
@@ -232,16 +248,14 @@ class Triangulator {
       t[nxt].n[1] = e.tri;
     }
     for (const BE& e : be) fan_next[e.a + 1] = -1;
-    for (int ti : cavity) {
-      t[ti].alive = false;
-      in_cavity[ti] = 0;
-    }
     for (const BE& e : be)
       if (!is_ghost(t[e.tri])) return e.tri;
     return be.empty() ? seed : be[0].tri;
   }
 
-  std::vector<int> fan_next;
+  struct BE { int a, b, outer, tri; };
+  std::vector<BE> be;
+  std::vector<int> fan_next, free_;
 };
 
 inline uint32_t spread16(uint32_t v) {
@@ -270,7 +284,11 @@ extern "C" int flame_delaunay_triangulate(const float* xy, int32_t n, int32_t* t
     if (!std::isfinite(v)) return FLAME_NLTGV2_ERR_INVALID_ARG;
     if (v == 0.0f) continue;
     int e;
-    std::frexp(v, &e);  // |v| in [2^(e-1), 2^e); ulp(v) = 2^(e-24)
+    uint32_t bits;
+    std::memcpy(&bits, &v, sizeof bits);
+    const int biased = (int)((bits >> 23) & 0xffu);
+    if (biased != 0) e = biased - 126;  // normal number: v = m * 2^e with m in [0.5, 1)
+    else std::frexp(v, &e);             // |v| in [2^(e-1), 2^e); ulp(v) = 2^(e-24)
     emin = std::min(emin, e - 24);
     emax = std::max(emax, e);
   }
@@ -280,9 +298,10 @@ extern "C" int flame_delaunay_triangulate(const float* xy, int32_t n, int32_t* t
   T.filter_ok = (emax - emin) <= 50;  // differences exact in double, products well inside the error bound
   T.p.resize((size_t)n);
   float minx = xy[0], maxx = xy[0], miny = xy[1], maxy = xy[1];
+  const double to_int = std::ldexp(1.0, -emin);
   for (int32_t i = 0; i < n; ++i) {
-    T.p[(size_t)i].x = (int64_t)std::ldexp((double)xy[2 * i], -emin);
-    T.p[(size_t)i].y = (int64_t)std::ldexp((double)xy[2 * i + 1], -emin);
+    T.p[(size_t)i].x = (int64_t)((double)xy[2 * i] * to_int);  // exact: a power-of-two scale, |result| < 2^58
+    T.p[(size_t)i].y = (int64_t)((double)xy[2 * i + 1] * to_int);
     T.p[(size_t)i].fx = (double)xy[2 * i];
     T.p[(size_t)i].fy = (double)xy[2 * i + 1];
     minx = std::min(minx, xy[2 * i]), maxx = std::max(maxx, xy[2 * i]);
@@ -299,7 +318,10 @@ extern "C" int flame_delaunay_triangulate(const float* xy, int32_t n, int32_t* t
       const uint32_t qx = (uint32_t)(((double)xy[2 * i] - minx) * sx), qy = (uint32_t)(((double)xy[2 * i + 1] - miny) * sy);
       key[(size_t)i] = spread16(qx) | (spread16(qy) << 1);
     }
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[(size_t)a] < key[(size_t)b]; });
+    std::vector<uint64_t> packed((size_t)n);  // (key, index): ties keep index order, as a stable sort would
+    for (int32_t i = 0; i < n; ++i) packed[(size_t)i] = ((uint64_t)key[(size_t)i] << 32) | (uint32_t)i;
+    std::sort(packed.begin(), packed.end());
+    for (int32_t i = 0; i < n; ++i) order[(size_t)i] = (int)(uint32_t)packed[(size_t)i];
   }
 
   // ---- first non-degenerate triangle --------------------------------------------------------------------

@@ -816,10 +816,14 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
     }
   }
   // edges
-  struct Keep { int32_t old_idx, a, b; };
-  std::vector<Keep> keep;
+  // Survivors must come out in their PREVIOUS relative order (boost::edges() walks a std::list: erase keeps the
+  // order of the rest).  They are met in triangulator order, so they are parked in a table indexed by the old edge
+  // id and read back in one pass -- no sort.
+  struct Keep { int32_t a, b; };
+  std::vector<Keep> keep_of_old((size_t)Eo, Keep{-1, -1});
   std::vector<std::pair<int32_t, int32_t>> fresh;
-  keep.reserve((size_t)E), fresh.reserve((size_t)E);
+  fresh.reserve((size_t)E);
+  int32_t n_keep = 0;
   FlatMap dup((size_t)E);
   for (int32_t k = 0; k < E; ++k) {
     const int32_t a = in->edges[2 * k], b = in->edges[2 * k + 1];
@@ -830,19 +834,21 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
     if (it) {
       const int32_t e = *it;
       const bool same = ctx->h_feat[(size_t)ctx->h_src[(size_t)e]] == in->feat_id[a];
-      keep.push_back(Keep{e, same ? a : b, same ? b : a});
+      keep_of_old[(size_t)e] = Keep{same ? a : b, same ? b : a};
+      ++n_keep;
     } else {
       fresh.emplace_back(a, b);
     }
   }
-  std::sort(keep.begin(), keep.end(), [](const Keep& p, const Keep& q) { return p.old_idx < q.old_idx; });
-  const int32_t En = (int32_t)(keep.size() + fresh.size());
+  const int32_t En = (int32_t)((size_t)n_keep + fresh.size());
   std::vector<int32_t> src(En), dst(En);
   std::vector<float> alpha(En), beta(En, 1.0f), q1(En, 0.f), q2(En, 0.f), q3(En, 0.f);
   int32_t e = 0;
-  for (const Keep& kp : keep) {
+  for (int32_t o = 0; o < Eo; ++o) {
+    const Keep& kp = keep_of_old[(size_t)o];
+    if (kp.a < 0) continue;
     src[e] = kp.a, dst[e] = kp.b;
-    q1[e] = oq1[kp.old_idx], q2[e] = oq2[kp.old_idx], q3[e] = oq3[kp.old_idx];
+    q1[e] = oq1[o], q2[e] = oq2[o], q3[e] = oq3[o];
     ++e;
   }
   for (const auto& f : fresh) {
