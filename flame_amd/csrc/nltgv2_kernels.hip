@@ -630,9 +630,35 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
     }
     if (timed_out) break;
 
+    // ---- phase A, every lane at once: dual update of each slot's private q copy (cc:99-110) and the three
+    // step-scaled values its primal scatter needs (cc:126-141).  They overwrite the neighbour record of the slot
+    // (dead from here on), so the ordered accumulation below costs no registers.
+#pragma unroll
+    for (int k = 0; k < kTvS; ++k) {
+      const bool is_target = NBR(k) < 0;
+      const float alpha_k = ALPHA(k), beta_k = BETA(k), dx_k = DX(k), dy_k = DY(k);
+      const float nxb = __int_as_float(g[k].x), nw1b = __int_as_float(g[k].y), nw2b = __int_as_float(g[k].z);
+      const float xbi = is_target ? nxb : xb, xbj = is_target ? xb : nxb;
+      const float w1bi = is_target ? nw1b : w1b, w1bj = is_target ? w1b : nw1b;
+      const float w2bi = is_target ? nw2b : w2b, w2bj = is_target ? w2b : nw2b;
+      bool okq = true;
+      const EdgeOut e = edge_dual(p, alpha_k, beta_k, dx_k, dy_k, q1[k], q2[k], q3[k], xbi, w1bi, w2bi,
+                                  xbj, w1bj, w2bj, okq);
+      g[k].x = __float_as_int(e.q1 * p.step_x * alpha_k);
+      g[k].y = __float_as_int(e.q2 * p.step_x * beta_k);
+      g[k].z = __float_as_int(e.q3 * p.step_x * beta_k);
+      if (k < nslots) {
+        q1[k] = e.q1, q2[k] = e.q2, q3[k] = e.q3;
+        ok = ok && okq;
+      }
+    }
+    // ---- phase B, ordered accumulation in ascending edge id: pass 0 for the first lane of every vertex, pass c
+    // for the c-th continuation lane of vertices with more than eight edges (it first takes over the running sums
+    // of the lane before it).  A Delaunay wave contains such a vertex more often than not; with the duals already
+    // done a further pass is 13 instead of ~60 instructions per slot.
     float X = x, W1 = w1, W2 = w2;
     for (int pass = 0; pass < passes; ++pass) {
-      if (pass > 0) {  // chain continuation: take over the running sums of the previous lane
+      if (pass > 0) {
         const float Xs = dpp_shr1(X), W1s = dpp_shr1(W1), W2s = dpp_shr1(W2);
         if (cidx == pass) X = Xs, W1 = W1s, W2 = W2s;
       }
@@ -641,17 +667,7 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
       for (int k = 0; k < kTvS; ++k) {
         const bool act = live && (k < nslots);
         const bool is_target = NBR(k) < 0;
-        const float alpha_k = ALPHA(k), beta_k = BETA(k), dx_k = DX(k), dy_k = DY(k);
-        const float nxb = __int_as_float(g[k].x), nw1b = __int_as_float(g[k].y), nw2b = __int_as_float(g[k].z);
-        const float xbi = is_target ? nxb : xb, xbj = is_target ? xb : nxb;
-        const float w1bi = is_target ? nw1b : w1b, w1bj = is_target ? w1b : nw1b;
-        const float w2bi = is_target ? nw2b : w2b, w2bj = is_target ? w2b : nw2b;
-        bool okq = true;
-        const EdgeOut e = edge_dual(p, alpha_k, beta_k, dx_k, dy_k, q1[k], q2[k], q3[k], xbi, w1bi, w2bi,
-                                    xbj, w1bj, w2bj, okq);
-        const float t1 = e.q1 * p.step_x * alpha_k;
-        const float t2 = e.q2 * p.step_x * beta_k;
-        const float t3 = e.q3 * p.step_x * beta_k;
+        const float t1 = __int_as_float(g[k].x), t2 = __int_as_float(g[k].y), t3 = __int_as_float(g[k].z);
         float nx, nw1, nw2;
         if (is_target) {
           nx = X + t1;
@@ -659,16 +675,12 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
           nw2 = W2 + t3;
         } else {
           nx = X - t1;
-          nw1 = W1 + t1 * dx_k;
-          nw2 = W2 + t1 * dy_k;
+          nw1 = W1 + t1 * DX(k);
+          nw2 = W2 + t1 * DY(k);
           nw1 = nw1 - t2;
           nw2 = nw2 - t3;
         }
-        if (act) {
-          X = nx, W1 = nw1, W2 = nw2;
-          q1[k] = e.q1, q2[k] = e.q2, q3[k] = e.q3;
-          ok = ok && okq;
-        }
+        if (act) X = nx, W1 = nw1, W2 = nw2;
       }
     }
     // ---- vertex update at the owner lane ----------------------------------------------------------
