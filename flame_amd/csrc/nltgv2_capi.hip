@@ -30,7 +30,7 @@ constexpr int kGraphChunk = 256;      // steps per captured hipGraph (even: keep
 constexpr int kCostPartials = 256;
 constexpr int kMaxCachedGraphs = 6;
 constexpr int kHeWavesPerCu = 24;      // residency cap of k_persistent_he (<= 64 VGPRs: the hardware admits 32)
-constexpr int kTvLdsWavesPerCu = 12;   // ... with the slot constants in LDS (167 VGPRs -> 3 waves per SIMD, 10 KB LDS per wave)
+constexpr int kTvLdsWavesPerCu = 16;   // ... with the slot constants in LDS (<= 128 VGPRs -> 4 waves per SIMD; 10 KB LDS per wave = all 160 KB)
 constexpr int kTvWavesPerCu = 8;       // residency of k_persistent_tv (<= 256 VGPRs -> 2 waves per SIMD)
 constexpr int kDualMinWavesPerCu = 0;  // auto: exchange through the XCD's L2 when more waves than this share a CU
 // x64-cycle sleep between publishing and the first neighbour poll (measured optimum, r01 sweep: he 6 at
@@ -247,7 +247,7 @@ int plan_persistent(const flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* 
   const PackedLayout& L = ctx->L;
   const int cus = ctx->prop.multiProcessorCount;
   // vertex-per-lane form: slot constants in registers (8 waves/CU, fastest per wave) while the graph is resident
-  // that way, else in LDS (12 waves/CU: +18 % frame-steps/s on big batches, -9 % per wave)
+  // that way, else in LDS (16 waves/CU: 30 frames of 640x480 resident in one launch)
   const bool tv_lds = ctx->opt_tv_lds == 2 || (ctx->opt_tv_lds == 1 && L.tv_waves > kTvWavesPerCu * cus);
   const int he_cap = kHeWavesPerCu * cus, tv_cap = (tv_lds ? kTvLdsWavesPerCu : kTvWavesPerCu) * cus;
   if (use_tv_lds) *use_tv_lds = tv_lds ? 1 : 0;

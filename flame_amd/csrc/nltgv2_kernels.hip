@@ -479,10 +479,10 @@ __device__ __forceinline__ float dpp_shr1(float v) {  // lane l <- lane l-1; lan
 }
 
 // LDS_STATIC: the per-slot constants (neighbour offset, alpha, dx, dy, beta: 40 dwords per lane) live in LDS
-// (10 KB per wave) instead of registers, which halves the VGPR footprint and doubles the residency (16 waves per
-// CU): bigger resident batches and 4K-sized single graphs.  The duals stay in registers.
+// (10 KB per wave) instead of registers: <= 128 VGPRs, four waves per SIMD (16 per CU, which is also all of the
+// CU's 160 KB of LDS): bigger resident batches and 4K-sized single graphs.  The duals stay in registers.
 template <bool LDS_STATIC>
-__global__ void __launch_bounds__(256, LDS_STATIC ? 3 : 2)
+__global__ void __launch_bounds__(256, LDS_STATIC ? 4 : 2)
 k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd, const int32_t* __restrict__ tv_slot,
                 const int32_t* __restrict__ tv_vid, const uint32_t* __restrict__ tv_meta,
                 const uint32_t* __restrict__ tv_wave, const int4* hrec, float4* hq, float4* vstate,

@@ -7,12 +7,10 @@ R.library_path = lambda: os.path.join(os.getcwd(), "build", "ab", lib)
 import flame_amd
 from flame_amd import synth
 p = flame_amd.Params()
-cases = [("22x640x480", synth.concat_graphs([synth.make_graph("640x480", 100+i) for i in range(22)])),
-         ("64x640x480", synth.concat_graphs([synth.make_graph("640x480", 100+i) for i in range(64)])),
-         ("1920x1080", synth.make_graph("1920x1080", 1234))]
-for name, g in cases:
-    for tvlds in (0, 2):
-        r = flame_amd.Regularizer(0); r.set_option(5, 3); r.set_option(7, tvlds); r.upload_graph(g); r.run(p, 200)
-        ms = min(r.run_timed(p, 200) for _ in range(6))
-        i = r.info()
-        print(lib, name, "tv lds", tvlds, "us/it %.3f" % (ms*1e3/200), "groups", i["last_run_groups"], flush=True); r.close()
+gs = [synth.make_graph("640x480", 100+i) for i in range(64)]
+for nf in (16, 22, 30, 44, 64):
+    g = synth.concat_graphs(gs[:nf])
+    r = flame_amd.Regularizer(0); r.upload_graph(g); r.run(p, 200)
+    ms = min(r.run_timed(p, 200) for _ in range(6))
+    i = r.info()
+    print(lib, nf, "frames: us/it %.3f" % (ms*1e3/200), "path", i["last_run_path"], "groups", i["last_run_groups"], "frame-iters/s %.2fM" % (nf/(ms*1e-3/200)/1e6), "frac %.3f" % (i["algorithmic_bytes_per_iter"]/(ms*1e-3/200)/8e12), flush=True); r.close()
