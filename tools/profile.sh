@@ -24,5 +24,11 @@ S="python tools/stream_case.py 64"
 rocprofv3 --kernel-trace --stats -d $OUT/kt_stream -o kt --output-format csv -- $S > $OUT/kt_stream.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch_stream -o f --output-format csv -- $S > $OUT/fetch_stream.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/write_stream -o w --output-format csv -- $S > $OUT/write_stream.log 2>&1
+# the resident batch (k_persistent_tv, 30 frames in one launch) and the per-feature epipolar update
+rocprofv3 --kernel-trace --stats -d $OUT/kt_batch -o kt --output-format csv -- python tools/stream_case.py 30 resident > $OUT/kt_batch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch_batch -o f --output-format csv -- python tools/stream_case.py 30 resident > $OUT/fetch_batch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/write_batch -o w --output-format csv -- python tools/stream_case.py 30 resident > $OUT/write_batch.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/kt_stereo -o kt --output-format csv -- python tools/stereo_bench.py > $OUT/kt_stereo.log 2>&1
+tail -1 $OUT/kt_batch.log; tail -3 $OUT/kt_stereo.log
 grep -h '"metric"' $OUT/kt.log $OUT/kt_step.log | cut -c1-400
 tail -1 $OUT/kt_stream.log

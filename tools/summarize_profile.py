@@ -43,7 +43,9 @@ out = {}
 traffic = {}
 for tag, sub, kernel, path_name in (("persistent", "", "k_persistent_he", "persistent"),
                                     ("per_step", "_step", "k_fused_step", "per-step hipGraph"),
-                                    ("stream_64_frames", "_stream", "k_fused_step", None)):
+                                    ("stream_64_frames", "_stream", "k_fused_step", None),
+                                    ("resident_30_frames", "_batch", "k_persistent_tv", None),
+                                    ("feature_update", "_stereo", "k_update_feature_idepths", None)):
     kt = os.path.join(SRC, "kt" + sub, "kt_kernel_stats.csv")
     if not os.path.exists(kt):
         continue
