@@ -123,10 +123,13 @@ def test_internal_steps_individually(env):
 @pytest.mark.parametrize("opts", [
     [(5, 0), (3, 1), (4, 4)], [(5, 0), (3, 1), (4, 8)], [(5, 0), (3, 1), (4, 16)], [(5, 0), (3, 2), (4, 8)],
     [(5, 0), (3, 4), (4, 4)], [(5, 0), (3, 4), (4, 16)], [(5, 0), (2, 0)], [(5, 1)], [(5, 2)], [(5, 3)], [(5, 2), (6, 0)], [(5, 3), (6, 0)], [(5, 2), (6, 2)], [(5, 3), (6, 2)], [(5, 3), (7, 2)], [(5, 3), (6, 2), (7, 2)], [(5, 3), (7, 0)],
+    [(5, 2), (9, 1)], [(5, 2), (9, 2)], [(5, 2), (9, 4)], [(5, 2), (9, 8)], [(5, 3), (9, 1)], [(5, 2), (8, 1)], [(5, 2), (8, 21)],
+    [(5, 3), (8, 9)], [(5, 2), (9, 1), (6, 0)],
 ])
 def test_launch_configurations_are_bit_identical(env, opts):
     """waves per workgroup (opt 3), slot chunk (opt 4), hipGraph on/off (opt 2), persistent single
-    launch vs one launch per step (opt 5), same-XCD L2 exchange on/off (opt 6), slot constants in LDS (opt 7) never change a bit."""
+    launch vs one launch per step (opt 5), same-XCD L2 exchange on/off (opt 6), slot constants in LDS (opt 7), the pre-poll sleep (opt 8) and the number of
+    XCDs a persistent launch is spread over (opt 9) never change a bit."""
     flame_amd, oracle = env
     g = synth.make_graph("320x240", seed=3)
     ref, _ = cpu_run(oracle, g, 21)
