@@ -790,22 +790,21 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
     if (in->feat_id[v] < 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
   FlatMap old_of_feat((size_t)Vo);
   for (int32_t v = 0; v < Vo; ++v) old_of_feat.emplace((uint64_t)(uint32_t)ctx->h_feat[(size_t)v], v);
-  FlatMap old_edge((size_t)Eo);  // (min feat, max feat) -> old edge index
   auto key = [](int32_t a, int32_t b) {
     const uint32_t lo = (uint32_t)std::min(a, b), hi = (uint32_t)std::max(a, b);
     return ((uint64_t)hi << 32) | lo;
   };
-  for (int32_t e = 0; e < Eo; ++e)
-    old_edge.emplace(key(ctx->h_feat[(size_t)ctx->h_src[(size_t)e]], ctx->h_feat[(size_t)ctx->h_dst[(size_t)e]]), e);
 
   // vertices
   std::vector<float> x(V), w1(V, 0.f), w2(V, 0.f), xb(V), w1b(V, 0.f), w2b(V, 0.f), xp(V), w1p(V, 0.f), w2p(V, 0.f);
+  std::vector<int32_t> old_of_new((size_t)V, -1);  // new vertex -> its index in the previous graph
   FlatMap seen((size_t)V);
   for (int32_t v = 0; v < V; ++v) {
     if (!seen.emplace((uint64_t)(uint32_t)in->feat_id[v], v).second) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // duplicate id
     const int32_t* it = old_of_feat.find((uint64_t)(uint32_t)in->feat_id[v]);
     if (it) {
       const int32_t o = *it;
+      old_of_new[(size_t)v] = o;
       x[v] = ox[o], w1[v] = ow1[o], w2[v] = ow2[o];
       xb[v] = oxb[o], w1b[v] = ow1b[o], w2b[v] = ow2b[o];
       xp[v] = oxp[o], w1p[v] = ow1p[o], w2p[v] = ow2p[o];
@@ -815,30 +814,48 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
       x[v] = xb[v] = xp[v] = xi;
     }
   }
-  // edges
-  // Survivors must come out in their PREVIOUS relative order (boost::edges() walks a std::list: erase keeps the
-  // order of the rest).  They are met in triangulator order, so they are parked in a table indexed by the old edge
-  // id and read back in one pass -- no sort.
+  // edges.  A surviving edge joins two surviving vertices: it is looked up in the previous graph's adjacency (the
+  // host copy of the packed layout: ~6 incident edges per vertex, one cache line) instead of a hash table over all
+  // edges.  Survivors must come out in their PREVIOUS relative order (boost::edges() walks a std::list: erase keeps
+  // the order of the rest): they are met in triangulator order, so they are parked in a table indexed by the old
+  // edge id and read back in one pass -- no sort.
   struct Keep { int32_t a, b; };
   std::vector<Keep> keep_of_old((size_t)Eo, Keep{-1, -1});
   std::vector<std::pair<int32_t, int32_t>> fresh;
-  fresh.reserve((size_t)E);
+  fresh.reserve((size_t)E / 4 + 16);
   int32_t n_keep = 0;
-  FlatMap dup((size_t)E);
+  const std::vector<int32_t>& orow = ctx->L.row_ptr;
+  const std::vector<uint32_t>& ohalf = ctx->L.half;
   for (int32_t k = 0; k < E; ++k) {
     const int32_t a = in->edges[2 * k], b = in->edges[2 * k + 1];
     if (a < 0 || a >= V || b < 0 || b >= V || a == b) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-    const uint64_t kk = key(in->feat_id[a], in->feat_id[b]);
-    if (!dup.emplace(kk, 1).second) continue;  // boost::edge() finds the one just added: no parallel edges
-    const int32_t* it = old_edge.find(kk);
-    if (it) {
-      const int32_t e = *it;
-      const bool same = ctx->h_feat[(size_t)ctx->h_src[(size_t)e]] == in->feat_id[a];
+    const int32_t oa = old_of_new[(size_t)a], ob = old_of_new[(size_t)b];
+    int32_t e = -1;
+    if (oa >= 0 && ob >= 0) {
+      for (int32_t h = orow[(size_t)oa]; h < orow[(size_t)oa + 1]; ++h) {
+        const int32_t cand = (int32_t)(ohalf[(size_t)h] & ~kRoleBit);
+        const int32_t other = ctx->h_src[(size_t)cand] == oa ? ctx->h_dst[(size_t)cand] : ctx->h_src[(size_t)cand];
+        if (other == ob) {
+          e = cand;  // the first (lowest id) of possible parallel edges, as boost::edge() on the list would find
+          break;
+        }
+      }
+    }
+    if (e >= 0) {
+      if (keep_of_old[(size_t)e].a >= 0) continue;  // the same pair again: boost::edge() finds the edge, nothing is added
+      const bool same = ctx->h_src[(size_t)e] == oa;
       keep_of_old[(size_t)e] = Keep{same ? a : b, same ? b : a};
       ++n_keep;
     } else {
       fresh.emplace_back(a, b);
     }
+  }
+  if (!fresh.empty()) {  // no parallel edges among the new ones either (boost::edge() finds the one just added)
+    FlatMap dup(fresh.size());
+    size_t n = 0;
+    for (const auto& f : fresh)
+      if (dup.emplace(key(in->feat_id[f.first], in->feat_id[f.second]), 1).second) fresh[n++] = f;
+    fresh.resize(n);
   }
   const int32_t En = (int32_t)((size_t)n_keep + fresh.size());
   std::vector<int32_t> src(En), dst(En);
