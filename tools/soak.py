@@ -10,7 +10,7 @@ import numpy as np
 import torch  # noqa
 import flame_amd
 from flame_amd import synth
-from flame_amd.regularizer import OPT_DUAL_PUBLISH, OPT_PERSISTENT
+from flame_amd.regularizer import OPT_DUAL_PUBLISH, OPT_PERSISTENT, OPT_TV_LDS
 from oracle import capi as oracle
 
 ITERS = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
@@ -43,10 +43,11 @@ for cfg, seed in cases:
     t0 = time.time()
     oracle.run(ref, ITERS)
     cpu_s = time.time() - t0
-    for form, dual in ((2, 0), (2, 2), (3, 0), (3, 2)):
+    for form, dual, lds in ((2, 0, 0), (2, 2, 0), (3, 0, 0), (3, 2, 0), (3, 2, 2)):
         with flame_amd.Regularizer(0) as reg:
             reg.set_option(OPT_PERSISTENT, form)
             reg.set_option(OPT_DUAL_PUBLISH, dual)
+            reg.set_option(OPT_TV_LDS, lds)
             reg.upload_graph(g)
             done = 0
             rng = np.random.default_rng(form * 10 + dual)
@@ -59,7 +60,7 @@ for cfg, seed in cases:
             out = reg.download_state(KEYS)
             path = reg.info()["last_run_path"]
         ok = all(np.array_equal(out[k], ref[k]) for k in KEYS)
-        results.append(dict(config=cfg, V=g["V"], E=g["E"], iters=ITERS, launches=launches, form=form, dual=dual,
+        results.append(dict(config=cfg, V=g["V"], E=g["E"], iters=ITERS, launches=launches, form=form, dual=dual, tv_lds=lds,
                             run_path=path, bit_identical=bool(ok)))
         print(results[-1], flush=True)
 stop = True
