@@ -16,7 +16,8 @@
  *
  * PINNING.  The EpipolarGeometry functions are pinned by the reference's own known-answer tests
  * (test/stereo/epipolar_geometry_test.cc, 21 tests) -- tests/test_stereo.py replays them against this
- * file; bilinearInterp by test/utils/image_utils_test.cc:150-166.  Everything else here (predict, search
+ * file; bilinearInterp by test/utils/image_utils_test.cc:150-166, clipLineLiangBarsky by :644-752 (5 tests),
+ * getCentralGradient by :171-326 (ramp images).  Everything else here (predict, search
  * region, line search, measurement model, fusion, the per-feature driver) has NO reference test and the
  * reference translation units cannot be built in this image (Eigen, Sophus and OpenCV are absent and
  * stand-in headers are not allowed): PARITY UNPINNED for those parts.

@@ -241,6 +241,41 @@ def test_reference_epiline_points_from_near_to_far():
     assert abs(abs(d[0] * ex + d[1] * ey) - 1) < 1e-4
 
 
+@pytest.mark.parametrize("case", [  # test/utils/image_utils_test.cc:644-752 (LiangBarky*): window, expected clip or None
+    ((0, 3, 0, 3), (1.0, 1.0, 2.0, 2.0), (1.0, 1.0, 2.0, 2.0)),
+    ((1.1, 3, 1.2, 3), (1.0, 1.0, 2.0, 2.0), (1.2, 1.2, 2.0, 2.0)),
+    ((1, 1.5, 1, 1.25), (1.0, 1.0, 2.0, 2.0), (1.0, 1.0, 1.25, 1.25)),
+    ((1.1, 1.5, 1.15, 1.25), (1.0, 1.0, 2.0, 2.0), (1.15, 1.15, 1.25, 1.25)),
+    ((2 + 1e-3 + 1, 640 - 2 - 1e-3 - 2, 2 + 1e-3 + 1, 480 - 2 - 1e-3 - 2), (-3.40414, 1.95745, -3.26889, 2.17682), None),
+])
+def test_kat_liang_barsky(case):
+    win, seg, want = case
+    ok, got = so.clip_liang_barsky(*[np.float32(v) for v in win], *[np.float32(v) for v in seg])
+    if want is None:
+        assert not ok
+    else:
+        assert ok and all(abs(float(g) - w) < 1e-6 for g, w in zip(got, want)), (got, want)
+
+
+@pytest.mark.parametrize("vertical", [False, True])
+def test_kat_central_gradient_ramps(vertical):
+    """test/utils/image_utils_test.cc:171-326 (getCentralGradientHorizontal/Vertical): a 640x480 ramp image, the
+    reference's expectations (central differences inside, one-sided at the borders, tolerance 1e-6)."""
+    w, h = 640, 480
+    if vertical:
+        col = np.floor(np.float32(255.0 / h) * np.arange(h, dtype=np.float32) + np.float32(0.5)).astype(np.uint8)
+        img = np.repeat(col[:, None], w, axis=1)
+    else:
+        row = np.floor(np.float32(255.0 / w) * np.arange(w, dtype=np.float32) + np.float32(0.5)).astype(np.uint8)
+        img = np.repeat(row[None, :], h, axis=0)
+    _, gx, gy = so.make_frame(np.ascontiguousarray(img), 0)
+    f = img.astype(np.float32)
+    assert np.abs(gx[:, 1:-1] - 0.5 * (f[:, 2:] - f[:, :-2])).max() < 1e-6
+    assert np.abs(gx[:, 0] - (f[:, 1] - f[:, 0])).max() < 1e-6 and np.abs(gx[:, -1] - (f[:, -1] - f[:, -2])).max() < 1e-6
+    assert np.abs(gy[1:-1] - 0.5 * (f[2:] - f[:-2])).max() < 1e-6
+    assert np.abs(gy[0] - (f[1] - f[0])).max() < 1e-6 and np.abs(gy[-1] - (f[-1] - f[-2])).max() < 1e-6
+
+
 def test_liang_barsky():
     ok, (a, b, c, d) = so.clip_liang_barsky(1, 639, 1, 479, -10, 100, 700, 100)
     assert ok and (a, b, c, d) == (1, 100, 639, 100)
