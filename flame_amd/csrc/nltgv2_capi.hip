@@ -45,7 +45,7 @@ struct DevBuf {
 
 struct CachedGraph {
   hipGraphExec_t exec = nullptr;
-  int n = 0, parity = 0, unroll = 0, wpb = 0;
+  int n = 0, parity = 0, unroll = 0, wpb = 0, gen = 0;
   uint64_t topo = 0;
   flame_nltgv2_params params{};
   uint64_t stamp = 0;
@@ -69,6 +69,7 @@ struct flame_nltgv2_ctx {
 
   int opt_solver = 0, opt_use_graph = 1, opt_block_waves = 0, opt_unroll = 0, opt_persistent = 1, opt_dual = 1;
   int opt_xcds = 0;      // XCDs a persistent launch spreads over: 0 = auto, 1..8
+  int opt_fault = 0;     // test hook: > 0 = the next persistent runs time out after this many spins
   int opt_presleep = 0;  // 0: auto (kPreSleep*); n > 0: (n - 1) x 64 cycles
   int opt_tv_lds = 1;  // 0 registers, 1 auto (LDS when the register form is not resident in one launch), 2 LDS
   uint32_t tag_next = 1;  // persistent run: tag of the current bar values (monotonic)
@@ -76,6 +77,16 @@ struct flame_nltgv2_ctx {
   uint64_t persist_refused_topo = ~0ull;  // topology for which the runtime refused the persistent grid
   bool static_stale = false;  // pos changed on the device (project_graph): packed alpha/dx/dy need a re-pack
   uint64_t coop_checked_key = 0;  // (topology, form) whose persistent grid the runtime has verified as resident
+  int buf_gen = 0;                // which of the two (hq, vstate) copies is current; part of the hipGraph cache key
+  int timeouts_recovered = 0;     // persistent runs that timed out and were redone on the per-step path
+  // The persistent run in flight, until finish() has seen its error word: what is needed to take it back
+  struct PendingRun {
+    bool active = false;
+    bool chained = false;  // a further run was enqueued before this one was checked: no longer possible to take back
+    int n = 0, parity_before = 0;
+    bool have_prev_before = false;
+    flame_nltgv2_params params{};
+  } pending;
 
   PackedLayout L;
   std::vector<int32_t> h_src, h_dst, h_feat;  // host image of the current topology (for sync_graph)
@@ -86,6 +97,7 @@ struct flame_nltgv2_ctx {
   DevBuf pos, x, w1, w2, xb, w1b, w2b, xp, w1p, w2p, data, weight, src, dst, alpha, beta, q1, q2, q3, row_ptr, half;
   // packed
   DevBuf slice_row, perm, pdeg, rec_nbr, rec_edge, edge_src_slot, hrec, hq, vstate, vaux, bar0, bar1, vprev;
+  DevBuf hq_alt, vstate_alt;  // the other copies of hq / vstate: a persistent run writes there, success swaps the roles
   DevBuf xbuf, abort_flag, he_slot, he_vid, he_meta, he_wave_chain, tv_slot, tv_vid, tv_meta, tv_wave;
   // misc
   DevBuf err, cost_pe, cost_pv, cost_out, img_ref, img_cmp, photo_err, r_tris, r_valid, r_keys, r_img, r_cov, r_vtx, r_val;
@@ -181,6 +193,7 @@ void refresh_args(flame_nltgv2_ctx* ctx) {
   f.edge_src_slot = (int32_t*)ctx->edge_src_slot.p;
   f.hrec = (int4*)ctx->hrec.p, f.hq = (float4*)ctx->hq.p;
   f.vstate = (float4*)ctx->vstate.p, f.vaux = (float2*)ctx->vaux.p;
+  f.hq_out = (float4*)ctx->hq_alt.p, f.vstate_out = (float4*)ctx->vstate_alt.p;
   f.bar[0] = (float4*)ctx->bar0.p, f.bar[1] = (float4*)ctx->bar1.p;
   f.vprev = (float4*)ctx->vprev.p;
   f.xbuf = ctx->xbuf.p;
@@ -200,7 +213,13 @@ int h2d(flame_nltgv2_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
   return 0;
 }
 
+int finish(flame_nltgv2_ctx* ctx);
+
 int ensure_canon(flame_nltgv2_ctx* ctx) {
+  if (ctx->pending.active) {  // a persistent run is still unchecked: settle it before anything reads or edits the state
+    const int rc = finish(ctx);
+    if (rc) return rc;
+  }
   if (ctx->canon_valid) return 0;
   LAUNCHCHK(ctx, launch_unpack_state(ctx->c, ctx->f, ctx->parity, ctx->have_prev, ctx->stream));
   ctx->canon_valid = true;
@@ -308,7 +327,7 @@ int get_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n, int pa
               hipGraphExec_t* out) {
   for (auto& g : ctx->graphs) {
     if (g.n == n && g.parity == parity && g.unroll == unroll && g.wpb == wpb && g.topo == ctx->topo &&
-        same_params(g.params, *p)) {
+        g.gen == ctx->buf_gen && same_params(g.params, *p)) {
       g.stamp = ++ctx->stamp;
       *out = g.exec;
       return 0;
@@ -336,6 +355,7 @@ int get_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n, int pa
   }
   CachedGraph cg;
   cg.exec = exec, cg.n = n, cg.parity = parity, cg.unroll = unroll, cg.wpb = wpb, cg.topo = ctx->topo;
+  cg.gen = ctx->buf_gen;
   cg.params = *p, cg.stamp = ++ctx->stamp;
   ctx->graphs.push_back(cg);
   *out = exec;
@@ -365,7 +385,7 @@ int prepare_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
 int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   if (n <= 0) return 0;
   if (ctx->opt_solver == 1) {  // canonical 4-sweep path
-    int rc = ensure_canon(ctx);
+    int rc = ensure_canon(ctx);  // (settles a pending persistent run first)
     if (rc) return rc;
     const SolverParams sp = to_sp(p);
     for (int it = 0; it < n; ++it) {
@@ -412,28 +432,40 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
                            : xcds == 1                ? kPreSleepHeOneXcd
                            : gr.count > 12 * ctx->prop.multiProcessorCount ? kPreSleepHeDense
                                                                             : kPreSleepHe;
-      e = launch_persistent_run(ctx->f, to_sp(p), form, gr.begin, gr.count, ctx->parity, tag0, n, pw, kMaxSpins, presleep, dual,
+      const unsigned spins_arg = ctx->opt_fault > 0 ? (0x80000000u | (unsigned)ctx->opt_fault) : kMaxSpins;
+      e = launch_persistent_run(ctx->f, to_sp(p), form, gr.begin, gr.count, ctx->parity, tag0, n, pw, spins_arg, presleep, dual,
                                 tv_lds, xcds, ctx->coop_checked_key != key, ctx->stream);
       if (e != 0) break;
     }
+    ctx->tag_next = tag0 + (uint32_t)n;
     if (e == 0) {
+      // The kernels wrote (will write) hq / vstate / bar into the other copies: make those current.  finish() takes
+      // this back if the run reports a timeout.
+      if (ctx->pending.active) {
+        ctx->pending.chained = true;
+      } else {
+        ctx->pending.active = true, ctx->pending.chained = false;
+        ctx->pending.n = n, ctx->pending.params = *p;
+        ctx->pending.parity_before = ctx->parity, ctx->pending.have_prev_before = ctx->have_prev;
+      }
+      std::swap(ctx->hq, ctx->hq_alt);
+      std::swap(ctx->vstate, ctx->vstate_alt);
+      ctx->buf_gen ^= 1;
+      refresh_args(ctx);
       ctx->coop_checked_key = key;
-      ctx->tag_next = tag0 + (uint32_t)n;
       ctx->last_run_path = form == 2 ? 5 : 1;
       ctx->last_run_groups = (int)groups.size();
-      ctx->parity ^= (n & 1);
+      ctx->parity ^= 1;
       ctx->have_prev = true;
       ctx->canon_valid = false;
       return 0;
     }
-    (void)hipGetLastError();  // e.g. cooperative launch too large
+    // e.g. cooperative launch too large.  Groups already enqueued write into the other copies only: the current
+    // state is intact, the steps are done on the one-launch-per-step path below.
+    (void)hipGetLastError();
     ctx->persist_refused_topo = ctx->topo;  // do not try again for this topology
-    if (groups.size() > 1) {
-      // some groups may already have advanced n steps: the state is inconsistent
-      ctx->have_graph = false;
-      return fail(ctx, FLAME_NLTGV2_ERR_HIP);
-    }
   }
+  if (ctx->pending.active) ctx->pending.chained = true;
   int left = n;
   while (left > 0) {
     const int chunk = left >= kGraphChunk ? kGraphChunk : left;
@@ -459,9 +491,29 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
 int finish(flame_nltgv2_ctx* ctx) {
   HIPCHK(ctx, hipMemcpyAsync(ctx->h_err, ctx->err.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const flame_nltgv2_ctx::PendingRun run = ctx->pending;
+  ctx->pending.active = false;
   if (*ctx->h_err & 2) {
-    ctx->have_graph = false;  // some slices wrote their state back, others did not
-    return fail(ctx, FLAME_NLTGV2_ERR_TIMEOUT);
+    // A neighbour wait of the persistent run expired (its waves were not all resident: the GPU is shared with
+    // something that keeps CUs full).  Its results went to the other copies of the state; take the swap back, and
+    // do the same steps on the one-launch-per-step path, which needs no co-residency.
+    if (!run.active || run.chained) {  // several runs were chained without a sync in between: state lost
+      ctx->have_graph = false;
+      return fail(ctx, FLAME_NLTGV2_ERR_TIMEOUT);
+    }
+    std::swap(ctx->hq, ctx->hq_alt);
+    std::swap(ctx->vstate, ctx->vstate_alt);
+    ctx->buf_gen ^= 1;
+    refresh_args(ctx);
+    ctx->parity = run.parity_before;
+    ctx->have_prev = run.have_prev_before;
+    ctx->persist_refused_topo = ctx->topo;
+    ctx->timeouts_recovered++;
+    HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, sizeof(int), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->abort_flag.p, 0, sizeof(int), ctx->stream));
+    int rc = enqueue_run(ctx, &run.params, run.n);
+    if (rc) return rc;
+    return finish(ctx);
   }
   if (*ctx->h_err != 0) return fail(ctx, FLAME_NLTGV2_ERR_NAN);
   return 0;
@@ -564,7 +616,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
   ctx->all = {&ctx->pos, &ctx->x, &ctx->w1, &ctx->w2, &ctx->xb, &ctx->w1b, &ctx->w2b, &ctx->xp, &ctx->w1p,
               &ctx->w2p, &ctx->data, &ctx->weight, &ctx->src, &ctx->dst, &ctx->alpha, &ctx->beta, &ctx->q1,
               &ctx->q2, &ctx->q3, &ctx->row_ptr, &ctx->half, &ctx->slice_row, &ctx->perm, &ctx->pdeg,
-              &ctx->rec_nbr, &ctx->rec_edge, &ctx->edge_src_slot, &ctx->hrec, &ctx->hq, &ctx->vstate,
+              &ctx->rec_nbr, &ctx->rec_edge, &ctx->edge_src_slot, &ctx->hrec, &ctx->hq, &ctx->vstate, &ctx->hq_alt, &ctx->vstate_alt,
               &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->xbuf, &ctx->abort_flag, &ctx->he_slot, &ctx->he_vid, &ctx->he_meta, &ctx->he_wave_chain, &ctx->tv_slot, &ctx->tv_vid, &ctx->tv_meta, &ctx->tv_wave, &ctx->err, &ctx->cost_pe, &ctx->cost_pv,
               &ctx->cost_out, &ctx->img_ref, &ctx->img_cmp, &ctx->photo_err, &ctx->r_tris, &ctx->r_valid, &ctx->r_keys,
               &ctx->r_img, &ctx->r_cov, &ctx->r_vtx, &ctx->r_val};
@@ -617,6 +669,11 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
     case FLAME_NLTGV2_OPT_DUAL_PUBLISH:
       if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_dual = value;
+      return 0;
+    case FLAME_NLTGV2_OPT_FAULT_INJECT:
+      if (value < 0 || value > (1 << 24)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_fault = value;
+      if (value == 0) ctx->persist_refused_topo = ~0ull;  // let the persistent path be tried again
       return 0;
     case FLAME_NLTGV2_OPT_XCDS:
       if (value < 0 || value > 8) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
@@ -675,6 +732,7 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
       {&ctx->rec_edge, sizeof(int32_t) * n_slots}, {&ctx->edge_src_slot, fE},
       {&ctx->hrec, sizeof(int4) * n_slots}, {&ctx->hq, sizeof(float4) * n_slots},
       {&ctx->vstate, sizeof(float4) * n_packed}, {&ctx->vaux, sizeof(float2) * n_packed},
+      {&ctx->hq_alt, sizeof(float4) * n_slots}, {&ctx->vstate_alt, sizeof(float4) * n_packed},
       {&ctx->bar0, sizeof(float4) * n_packed}, {&ctx->bar1, sizeof(float4) * n_packed},
       {&ctx->vprev, sizeof(float4) * n_packed}, {&ctx->xbuf, 68 * n_packed + 64},
       {&ctx->abort_flag, sizeof(int)}, {&ctx->he_slot, sizeof(int32_t) * L.he_slot.size()},
@@ -724,6 +782,10 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
   HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, sizeof(int), ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->abort_flag.p, 0, sizeof(int), ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->xbuf.p, 0, 68 * n_packed + 64, ctx->stream));
+  // empty slots / padding vertices of the second copies: zero, as the packing kernels write them in the first
+  HIPCHK(ctx, hipMemsetAsync(ctx->hq_alt.p, 0, sizeof(float4) * n_slots, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->vstate_alt.p, 0, sizeof(float4) * n_packed, ctx->stream));
+  ctx->pending.active = false;
   ctx->tag_next = 1;
   ctx->static_stale = false;
   LAUNCHCHK(ctx, launch_pack_static(ctx->c, ctx->f, ctx->stream));
@@ -1262,6 +1324,7 @@ int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info) {
   info->tv_waves = ctx->L.tv_ok ? ctx->L.tv_waves : 0;
   info->tv_wave_capacity = (ctx->opt_tv_lds ? kTvLdsWavesPerCu : kTvWavesPerCu) * ctx->prop.multiProcessorCount;
   info->last_run_groups = ctx->last_run_groups;
+  info->timeouts_recovered = ctx->timeouts_recovered;
   return FLAME_NLTGV2_OK;
 }
 

@@ -56,6 +56,8 @@ struct FusedArgs {
   int4* hrec = nullptr;     // [n_slots] {nbr|role, alpha, dx, dy}
   float4* hq = nullptr;     // [n_slots] {q1,q2,q3,beta}
   float4* vstate = nullptr; // [n_slices*64] {x,w1,w2,data}
+  float4* hq_out = nullptr;     // the other copies: a persistent run writes its results there and the host swaps
+  float4* vstate_out = nullptr; // the roles once the run is known to have succeeded
   float2* vaux = nullptr;   // [n_slices*64] {data_weight, degree bits}
   float4* bar[2] = {nullptr, nullptr};  // ping-pong {x_bar,w1_bar,w2_bar,-}
   float4* vprev = nullptr;  // {x_prev,w1_prev,w2_prev,-} written by the last step of a run

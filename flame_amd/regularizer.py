@@ -26,7 +26,7 @@ _LIB = None
 _FP = C.POINTER(C.c_float)
 _IP = C.POINTER(C.c_int32)
 
-OPT_SOLVER, OPT_USE_HIPGRAPH, OPT_BLOCK_WAVES, OPT_UNROLL, OPT_PERSISTENT, OPT_DUAL_PUBLISH, OPT_TV_LDS, OPT_PRESLEEP, OPT_XCDS = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OPT_SOLVER, OPT_USE_HIPGRAPH, OPT_BLOCK_WAVES, OPT_UNROLL, OPT_PERSISTENT, OPT_DUAL_PUBLISH, OPT_TV_LDS, OPT_PRESLEEP, OPT_XCDS, OPT_FAULT_INJECT = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 RUN_PATHS = {0: "none", 1: "persistent", 2: "per-step hipGraph", 3: "per-step eager", 4: "canonical 4-sweep",
              5: "persistent-tv"}
 ERR_NAN = -5
@@ -77,7 +77,7 @@ class _Info(C.Structure):
         ("n_slices", C.c_int32), ("max_degree", C.c_int32), ("padded_half_edges", C.c_int64),
         ("device_bytes", C.c_int64), ("algorithmic_bytes_per_iter", C.c_int64), ("compute_units", C.c_int32),
         ("device_name", C.c_char * 64), ("gcn_arch", C.c_char * 32), ("last_run_path", C.c_int32), ("he_waves", C.c_int32), ("tv_waves", C.c_int32),
-        ("tv_wave_capacity", C.c_int32), ("last_run_groups", C.c_int32),
+        ("tv_wave_capacity", C.c_int32), ("last_run_groups", C.c_int32), ("timeouts_recovered", C.c_int32),
     ]
 
 

@@ -44,8 +44,11 @@ typedef enum flame_nltgv2_status {
                                         reference's FLAME_ASSERT(!std::isnan(new_q)) fires
                                         (nltgv2...h:174).  Sticky until the next upload. */
   FLAME_NLTGV2_ERR_OOM = -6,
-  FLAME_NLTGV2_ERR_TIMEOUT = -7,     /* persistent run: a bounded neighbour wait expired (should not
-                                        happen; state is invalid, upload the graph again) */
+  FLAME_NLTGV2_ERR_TIMEOUT = -7,     /* persistent run: a bounded neighbour wait expired.  run()/sync() normally hide
+                                        this: the run's results go to second copies of the state, so the state is
+                                        rolled back and the steps are redone with one launch per step (get_info:
+                                        timeouts_recovered).  Returned only when several runs were chained with
+                                        run_async() and no sync() in between: then the state is lost, upload again */
   FLAME_NLTGV2_ERR_ASSERT = -8       /* flame_stereo.h: an input on which the reference's FLAME_ASSERT would
                                         exit(1) (assert.h:111) */
 } flame_nltgv2_status;
@@ -242,8 +245,11 @@ enum {
   FLAME_NLTGV2_OPT_PRESLEEP = 8,     /* persistent run, sleep between publishing a step's record and the first
                                         neighbour poll: 0 (default) = chosen from the waves per CU;
                                         n in 1..64 = (n-1) x 64 cycles */
-  FLAME_NLTGV2_OPT_XCDS = 9          /* persistent run: number of XCDs (of 8) the waves are spread over: 0 (default) =
+  FLAME_NLTGV2_OPT_XCDS = 9,         /* persistent run: number of XCDs (of 8) the waves are spread over: 0 (default) =
                                         one XCD for graphs small enough to run there, else all eight; 1..8 */
+  FLAME_NLTGV2_OPT_FAULT_INJECT = 10 /* test hook: n > 0 = one wave of every persistent run withholds its first record, so
+                                        the run times out after n polls and the recovery path (state rolled back, steps
+                                        redone with one launch per step) is exercised; 0 (default) = off */
 };
 int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value);
 
@@ -266,6 +272,7 @@ typedef struct flame_nltgv2_info {
   int32_t tv_waves;      /* waves of the vertex-per-lane persistent form (0: not applicable) */
   int32_t tv_wave_capacity; /* vertex-per-lane waves the device keeps resident */
   int32_t last_run_groups;  /* persistent launches the last run was split into (groups of whole components) */
+  int32_t timeouts_recovered; /* persistent runs whose wait expired: state rolled back, steps redone one launch per step */
 } flame_nltgv2_info;
 int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info);
 

@@ -341,6 +341,43 @@ def test_nan_is_reported_not_fatal(env):
             reg.run(flame_amd.Params(), 1)
 
 
+@pytest.mark.parametrize("form", [2, 3])
+def test_persistent_timeout_is_rolled_back_and_redone(env, form):
+    """A persistent run whose neighbour wait expires (fault injection: one wave withholds its first record) must
+    leave the state it started from untouched; run() then does the same steps with one launch per step."""
+    flame_amd, oracle = env
+    g = synth.make_graph("320x240", seed=9)
+    p = flame_amd.Params()
+    ref = synth.copy_graph(g)
+    with flame_amd.Regularizer(0) as reg:
+        reg.set_option(5, form)
+        reg.upload_graph(g)
+        reg.run(p, 30)                       # a normal persistent run first (odd/even parity both follow)
+        oracle.run(ref, 30)
+        assert reg.info()["last_run_path"] in (1, 5)
+        reg.set_option(10, 200)              # FLAME_NLTGV2_OPT_FAULT_INJECT
+        reg.run(p, 41)                       # times out inside, recovered
+        oracle.run(ref, 41)
+        info = reg.info()
+        assert info["timeouts_recovered"] == 1 and info["last_run_path"] in (2, 3)
+        assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="after recovery")
+        reg.run(p, 10)                       # the topology stays on the per-step path while the fault is on
+        oracle.run(ref, 10)
+        assert reg.info()["timeouts_recovered"] == 1
+        reg.set_option(10, 0)                # fault off: persistent runs again
+        reg.run(p, 25)
+        oracle.run(ref, 25)
+        assert reg.info()["last_run_path"] in (1, 5)
+        assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="after the fault")
+        # chained asynchronous runs cannot be taken back: reported, not hidden
+        reg.set_option(10, 200)
+        reg.run_async(p, 8)
+        reg.run_async(p, 8)
+        with pytest.raises(flame_amd.NLTGV2Error) as ei:
+            reg.sync()
+        assert ei.value.status == -7
+
+
 def test_invalid_arguments(env):
     flame_amd, _ = env
     g = synth.make_graph("320x240", seed=9)
