@@ -27,7 +27,6 @@ using namespace flame_hip;
 namespace {
 
 constexpr int kGraphChunk = 256;      // steps per captured hipGraph (even: keeps ping-pong parity)
-constexpr int kCostPartials = 256;
 constexpr int kMaxCachedGraphs = 6;
 constexpr int kHeWavesPerCu = 24;      // residency cap of k_persistent_he (<= 64 VGPRs: the hardware admits 32)
 constexpr int kTvLdsWavesPerCu = 16;   // ... with the slot constants in LDS (<= 128 VGPRs -> 4 waves per SIMD; 10 KB LDS per wave = all 160 KB)
@@ -97,10 +96,12 @@ struct flame_nltgv2_ctx {
   DevBuf pos, x, w1, w2, xb, w1b, w2b, xp, w1p, w2p, data, weight, src, dst, alpha, beta, q1, q2, q3, row_ptr, half;
   // packed
   DevBuf slice_row, perm, pdeg, rec_nbr, rec_edge, edge_src_slot, hrec, hq, vstate, vaux, bar0, bar1, vprev;
+  DevBuf cost_terms;          // addends of smoothnessCost / dataCost
+  std::vector<float> h_terms;
   DevBuf hq_alt, vstate_alt;  // the other copies of hq / vstate: a persistent run writes there, success swaps the roles
   DevBuf xbuf, abort_flag, he_slot, he_vid, he_meta, he_wave_chain, tv_slot, tv_vid, tv_meta, tv_wave;
   // misc
-  DevBuf err, cost_pe, cost_pv, cost_out, img_ref, img_cmp, photo_err, r_tris, r_valid, r_keys, r_img, r_cov, r_vtx, r_val;
+  DevBuf err, cost_out, img_ref, img_cmp, photo_err, r_tris, r_valid, r_keys, r_img, r_cov, r_vtx, r_val;
   int img_rows = 0, img_cols = 0, img_step = 0;
   int* h_err = nullptr;    // pinned
   float* h_cost = nullptr; // pinned
@@ -616,8 +617,8 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
   ctx->all = {&ctx->pos, &ctx->x, &ctx->w1, &ctx->w2, &ctx->xb, &ctx->w1b, &ctx->w2b, &ctx->xp, &ctx->w1p,
               &ctx->w2p, &ctx->data, &ctx->weight, &ctx->src, &ctx->dst, &ctx->alpha, &ctx->beta, &ctx->q1,
               &ctx->q2, &ctx->q3, &ctx->row_ptr, &ctx->half, &ctx->slice_row, &ctx->perm, &ctx->pdeg,
-              &ctx->rec_nbr, &ctx->rec_edge, &ctx->edge_src_slot, &ctx->hrec, &ctx->hq, &ctx->vstate, &ctx->hq_alt, &ctx->vstate_alt,
-              &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->xbuf, &ctx->abort_flag, &ctx->he_slot, &ctx->he_vid, &ctx->he_meta, &ctx->he_wave_chain, &ctx->tv_slot, &ctx->tv_vid, &ctx->tv_meta, &ctx->tv_wave, &ctx->err, &ctx->cost_pe, &ctx->cost_pv,
+              &ctx->rec_nbr, &ctx->rec_edge, &ctx->edge_src_slot, &ctx->hrec, &ctx->hq, &ctx->vstate, &ctx->hq_alt, &ctx->vstate_alt, &ctx->cost_terms,
+              &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->xbuf, &ctx->abort_flag, &ctx->he_slot, &ctx->he_vid, &ctx->he_meta, &ctx->he_wave_chain, &ctx->tv_slot, &ctx->tv_vid, &ctx->tv_meta, &ctx->tv_wave, &ctx->err,
               &ctx->cost_out, &ctx->img_ref, &ctx->img_cmp, &ctx->photo_err, &ctx->r_tris, &ctx->r_valid, &ctx->r_keys,
               &ctx->r_img, &ctx->r_cov, &ctx->r_vtx, &ctx->r_val};
   *out = ctx;
@@ -741,7 +742,6 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
       {&ctx->tv_slot, sizeof(int32_t) * L.tv_slot.size()}, {&ctx->tv_vid, sizeof(int32_t) * L.tv_vid.size()},
       {&ctx->tv_meta, sizeof(uint32_t) * L.tv_meta.size()}, {&ctx->tv_wave, sizeof(uint32_t) * L.tv_wave.size()},
       {&ctx->err, sizeof(int)},
-      {&ctx->cost_pe, sizeof(double) * kCostPartials}, {&ctx->cost_pv, sizeof(double) * kCostPartials},
       {&ctx->cost_out, 2 * sizeof(float)}};
   for (auto& r : req) {
     rc = ensure(ctx, *r.b, r.bytes);
@@ -1152,12 +1152,22 @@ int flame_nltgv2_costs(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, floa
   if (!params_ok(p)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
   rc = ensure_canon(ctx);
   if (rc) return rc;
-  LAUNCHCHK(ctx, launch_costs(ctx->c, to_sp(p), (double*)ctx->cost_pe.p, (double*)ctx->cost_pv.p, kCostPartials,
-                              (float*)ctx->cost_out.p, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(ctx->h_cost, ctx->cost_out.p, 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  // The reference adds the terms up sequentially in float (edge order, then vertex order): the device forms the
+  // addends, the host adds them in that order -- the result is the reference's to the last bit.  (A statistics call,
+  // flame.cc:2172-2173: 2E + V dependent additions, ~60 us at 640x480.)
+  const size_t E = (size_t)ctx->L.E, V = (size_t)ctx->L.V, n = 2 * E + V;
+  rc = ensure(ctx, ctx->cost_terms, sizeof(float) * n);
+  if (rc) return rc;
+  ctx->h_terms.resize(n);
+  LAUNCHCHK(ctx, launch_cost_terms(ctx->c, (float*)ctx->cost_terms.p, ctx->stream));
+  if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->h_terms.data(), ctx->cost_terms.p, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  if (smoothness) *smoothness = ctx->h_cost[0];
-  if (data) *data = ctx->h_cost[1];
+  float cost = 0.0f;
+  for (size_t k = 0; k < 2 * E; ++k) cost += ctx->h_terms[k];
+  float dcost = 0.0f;
+  for (size_t k = 0; k < V; ++k) dcost += ctx->h_terms[2 * E + k];
+  if (smoothness) *smoothness = p->data_factor * cost;
+  if (data) *data = dcost;
   return FLAME_NLTGV2_OK;
 }
 

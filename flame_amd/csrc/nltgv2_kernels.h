@@ -97,7 +97,6 @@ int launch_interpolate_mesh(int T, const int32_t* tris, const float2* vtx, const
                             int* coverage, int rows, int cols, hipStream_t s);
 int launch_photo_residual(const CanonArgs& c, float graph_scale, const PhotoGeometry& geo, const uint8_t* ref,
                           const uint8_t* cmp, int rows, int cols, int step, int border, float* err, hipStream_t s);
-int launch_costs(const CanonArgs& c, const SolverParams& p, double* partial_e, double* partial_v,
-                 int n_partials, float* out2, hipStream_t s);
+int launch_cost_terms(const CanonArgs& c, float* terms, hipStream_t s);
 
 }  // namespace flame_hip

@@ -934,76 +934,6 @@ k_export_canonical(int V, const float* __restrict__ x, float scale, float* __res
 }
 
 // ------------------------------------------------------------------------------------------------
-// costs: smoothnessCost cc:51-71 and dataCost cc:73-85.  Summed in double, fixed tree.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-
-__device__ __forceinline__ void block_sum_store(double v, double* __restrict__ partial) {
-  __shared__ double sm[4];
-  v = wave_sum(v);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (lane == 0) sm[w] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) partial[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
-}
-
-__global__ void __launch_bounds__(256)
-k_cost_edges(int E, const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
-             const float* __restrict__ alpha, const float* __restrict__ beta,
-             const float2* __restrict__ pos, const float* __restrict__ x, const float* __restrict__ w1,
-             const float* __restrict__ w2, double* __restrict__ partial) {
-  double acc = 0.0;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
-    const int i = src[e], j = dst[e];
-    const float2 pi = pos[i], pj = pos[j];
-    const float dx = pi.x - pj.x, dy = pi.y - pj.y;
-    float a = x[i] - x[j] - w1[i] * dx - w2[i] * dy;
-    a = (a >= 0) ? a : -a;
-    float b = w1[i] - w1[j];
-    b = (b >= 0) ? b : -b;
-    float c = w2[i] - w2[j];
-    c = (c >= 0) ? c : -c;
-    acc += (double)(alpha[e] * a);
-    acc += (double)(beta[e] * b + beta[e] * c);
-  }
-  block_sum_store(acc, partial);
-}
-
-__global__ void __launch_bounds__(256)
-k_cost_vertices(int V, const float* __restrict__ x, const float* __restrict__ data,
-                const float* __restrict__ weight, double* __restrict__ partial) {
-  double acc = 0.0;
-  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < V; v += gridDim.x * blockDim.x) {
-    float diff = (x[v] - data[v]) * weight[v];
-    diff = (diff > 0) ? diff : -diff;
-    acc += (double)diff;
-  }
-  block_sum_store(acc, partial);
-}
-
-__global__ void __launch_bounds__(256)
-k_cost_final(int n_edge_partials, int n_vertex_partials, const double* __restrict__ pe,
-             const double* __restrict__ pv, float data_factor, float* __restrict__ out) {
-  double a = 0.0, b = 0.0;
-  for (int i = threadIdx.x; i < n_edge_partials; i += blockDim.x) a += pe[i];
-  for (int i = threadIdx.x; i < n_vertex_partials; i += blockDim.x) b += pv[i];
-  __shared__ double sa[4], sb[4];
-  a = wave_sum(a);
-  b = wave_sum(b);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (lane == 0) sa[w] = a, sb[w] = b;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    out[0] = data_factor * (float)(sa[0] + sa[1] + sa[2] + sa[3]);
-    out[1] = (float)(sb[0] + sb[1] + sb[2] + sb[3]);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Per-vertex photometric residual (BASELINE config 5).  No live reference
 // code (only the commented-out block flame.cc:854-893); built from the live, test-pinned pieces
 // EpipolarGeometry::project (stereo/epipolar_geometry.h:127-143, 191-201) and
@@ -1387,14 +1317,41 @@ int launch_photo_residual(const CanonArgs& c, float graph_scale, const PhotoGeom
   return (int)hipGetLastError();
 }
 
-int launch_costs(const CanonArgs& c, const SolverParams& p, double* partial_e, double* partial_v,
-                 int n_partials, float* out2, hipStream_t s) {
-  hipLaunchKernelGGL(k_cost_edges, dim3(n_partials), dim3(256), 0, s, c.E, c.src, c.dst, c.alpha, c.beta,
-                     c.pos, c.x, c.w1, c.w2, partial_e);
-  hipLaunchKernelGGL(k_cost_vertices, dim3(n_partials), dim3(256), 0, s, c.V, c.x, c.data, c.weight, partial_v);
-  hipLaunchKernelGGL(k_cost_final, dim3(1), dim3(256), 0, s, n_partials, n_partials, partial_e, partial_v,
-                     p.data_factor, out2);
+// The addends of smoothnessCost (cc:51-71: two per edge, alpha*|..| and beta*|..| + beta*|..|) and of dataCost
+// (cc:73-85: one per vertex), each exactly as the reference forms it.  The host adds them up in order.
+__global__ void __launch_bounds__(256)
+k_cost_terms(int E, int V, const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+             const float* __restrict__ alpha, const float* __restrict__ beta, const float2* __restrict__ pos,
+             const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ w2,
+             const float* __restrict__ data, const float* __restrict__ weight, float* __restrict__ terms) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < E) {
+    const int i = src[t], j = dst[t];
+    const float2 pi = pos[i], pj = pos[j];
+    const float dx = pi.x - pj.x, dy = pi.y - pj.y;
+    float a = x[i] - x[j] - w1[i] * dx - w2[i] * dy;
+    a = (a >= 0) ? a : -a;
+    float b = w1[i] - w1[j];
+    b = (b >= 0) ? b : -b;
+    float c = w2[i] - w2[j];
+    c = (c >= 0) ? c : -c;
+    terms[2 * (size_t)t] = alpha[t] * a;
+    terms[2 * (size_t)t + 1] = beta[t] * b + beta[t] * c;
+  } else if (t < E + V) {
+    const int v = t - E;
+    float diff = (x[v] - data[v]) * weight[v];
+    diff = (diff > 0) ? diff : -diff;
+    terms[2 * (size_t)E + v] = diff;
+  }
+}
+
+int launch_cost_terms(const CanonArgs& c, float* terms, hipStream_t s) {
+  const int n = c.E + c.V;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_cost_terms, grid1d(n), dim3(256), 0, s, c.E, c.V, c.src, c.dst, c.alpha, c.beta, c.pos, c.x, c.w1,
+                     c.w2, c.data, c.weight, terms);
   return (int)hipGetLastError();
 }
+
 
 }  // namespace flame_hip

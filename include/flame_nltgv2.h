@@ -172,8 +172,9 @@ int flame_nltgv2_primal_step(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p
 int flame_nltgv2_extragradient_step(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p);
 int flame_nltgv2_step(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p);
 
-/* smoothnessCost (cc:51-71) and dataCost (cc:73-85); cost() (h:149-151) is their sum.  Summed in
- * double with a fixed reduction tree (the reference sums sequentially in float). */
+/* smoothnessCost (cc:51-71) and dataCost (cc:73-85); cost() (h:149-151) is their sum.  The device forms the
+ * addends exactly as the reference does, the host adds them sequentially in float in edge / vertex order: the
+ * results equal the reference's to the last bit (for the caller's vertex order; the reference's is BGL hash order). */
 int flame_nltgv2_costs(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, float* smoothness, float* data);
 
 /* Device -> host copy of the solver state in the caller's original vertex/edge order.  Replaces
