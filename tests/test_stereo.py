@@ -609,3 +609,51 @@ def test_gpu_device_resident_features(built):
         assert tr.last_kernel_ms() > 0
     assert st["num_idepth_updates"] == st_o[0]
     assert dev.cpu().numpy().tobytes() == out_o.tobytes()
+
+
+@gpu
+@pytest.mark.parametrize("trial", range(24))
+def test_gpu_randomized_differential(built, trial):
+    """Random camera motions, plane slants, priors and parameter blocks: the HIP path and the checker must agree on
+    every record and counter -- or on the index of the first feature the reference would assert on."""
+    from flame_amd import synth_stereo as ss
+
+    rng = np.random.default_rng(1000 + trial)
+    w, h = (160, 120) if trial % 3 else (208, 144)
+    sc = ss.PlaneScene(w, h, seed=50 + trial, normal=(rng.uniform(-0.4, 0.4), rng.uniform(-0.3, 0.3), 1.0),
+                       distance=float(rng.uniform(0.8, 4.0)), margin=96)
+    sc.add_camera(10, np.eye(3), [0, 0, 0])
+    sc.add_camera(11, ss.rot(rng.normal(size=3), rng.uniform(0, 0.02)), rng.normal(size=3) * 0.03)
+    tz = [0.0, rng.uniform(0.02, 0.3), -rng.uniform(0.02, 0.3)][trial % 3]
+    t_new = np.array([rng.normal() * 0.08, rng.normal() * 0.04, tz])
+    R_new = np.eye(3) if trial % 3 == 0 else ss.rot(rng.normal(size=3), rng.uniform(0, 0.04))
+    sc.add_camera(12, R_new, t_new)
+    imgs = {c: sc.render(c) for c in (10, 11, 12)}
+    feats = ss.make_features(sc, so.FEATURE_DTYPE, [10, 11], 300, 70 + trial, mu_noise=float(rng.uniform(0.02, 0.6)),
+                             var=float(rng.choice([1e-4, 0.01, 0.05, 0.2])), border=int(rng.integers(4, 14)))
+    n = feats.shape[0]
+    # sprinkle awkward priors
+    idx = rng.permutation(n)
+    feats["idepth_mu"][idx[:10]] = 0.0
+    feats["idepth_mu"][idx[10:20]] *= rng.uniform(2.0, 6.0, 10).astype(np.float32)
+    feats["idepth_var"][idx[20:30]] = rng.uniform(0.2, 0.26, 10).astype(np.float32)
+    feats["num_dropouts"][idx[30:40]] = rng.integers(3, 7, 10).astype(np.uint32)
+    feats["search_status"][idx[40:50]] = rng.integers(0, 4, 10).astype(np.int32)
+    feats["valid"][idx[50:60]] = 0
+    pkw = dict(search_sigma=float(rng.uniform(1.0, 4.0)), min_grad_mag=float(rng.uniform(1.0, 10.0)),
+               epilength_min=float(rng.uniform(1.0, 6.0)), epilength_max=float(rng.uniform(8.0, 40.0)),
+               max_cost=float(rng.uniform(200.0, 2000.0)), second_best_factor=float(rng.uniform(1.0, 2.5)),
+               sample_dist=float(rng.choice([0.5, 1.0, 1.5])), do_subpixel=int(rng.integers(0, 2)),
+               do_meas_fusion=int(rng.integers(0, 2)), do_letterbox=int(trial % 5 == 0),
+               outlier_sigma_thresh=float(rng.uniform(1.0, 4.0)), idepth_max=float(rng.uniform(1.0, 3.0)),
+               rescale_factor_min=float(rng.uniform(0.5, 0.9)), rescale_factor_max=float(rng.uniform(1.1, 1.6)),
+               pixel_var=float(rng.uniform(4.0, 32.0)), epipolar_line_var=float(rng.uniform(0.5, 2.0)))
+    poses = ss.poses_for(sc, [10, 11], 12, 11)
+    rc_o, st_o, out_o = _oracle_update(sc, imgs, feats, poses, so.Params(**pkw))
+    rc_g, st_g, out_g = _gpu_update(sc, imgs, feats, poses, pkw, raise_on_error=False)
+    if rc_o < 0:
+        assert rc_g == -8 and st_g["error_feature"] == -rc_o - 1, (rc_o, rc_g, st_g)
+    else:
+        assert rc_o == 0 and rc_g == 0, (rc_o, rc_g, st_g)
+        assert out_g.tobytes() == out_o.tobytes()
+        assert st_g["num_idepth_updates"] == st_o[0] and st_g["num_fail_max_cost"] == st_o[5]
