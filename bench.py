@@ -44,25 +44,31 @@ def parse():
     return ap.parse_args()
 
 
-def measure(reg, params, iters, steps, warmup, sync, barrier, after_step=None):
-    """warmup, then EXACTLY `steps` steps bracketed by barrier+synchronize.  Returns (wall seconds,
-    device ms summed over the steps' HIP-event regions)."""
+def measure(reg, params, iters, steps, warmup, sync, barrier, stream, after_step=None):
+    """warmup, then EXACTLY `steps` steps bracketed by barrier+synchronize.  The steps are enqueued back to back
+    (no host round trip between them; run_async), each launch bracketed by a HIP event pair recorded on the
+    solver's stream.  Returns (wall seconds, device ms summed over the steps' event regions)."""
+    import torch
+
     for _ in range(warmup):
         reg.run(params, iters)
         if after_step:
             after_step()
     barrier()
     sync()
-    ev_ms = 0.0
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
-    for _ in range(steps):
-        ev_ms += reg.run_timed(params, iters)
+    for e0, e1 in ev:
+        e0.record(stream)
+        reg.run_async(params, iters)
+        e1.record(stream)
         if after_step:
             after_step()
+    reg.sync()  # also checks the solver's error word
     sync()
     barrier()
     t1 = time.perf_counter()
-    return t1 - t0, ev_ms
+    return t1 - t0, sum(e0.elapsed_time(e1) for e0, e1 in ev)
 
 
 def main():
@@ -106,6 +112,10 @@ def main():
     reg.upload_graph(g)
     info = reg.info()
 
+    # the solver runs on a torch stream: torch's HIP events can then bracket its launches, and (N > 1) export ->
+    # all_gather is ordered on the device without a host round trip between them
+    solver_stream = torch.cuda.Stream(device=local_rank)
+    reg.set_stream(solver_stream.cuda_stream)
     after_step = None
     if dist is not None:
         # result gather (configs[3]): x*graph_scale of every rank's frame to all ranks, one RCCL
@@ -113,17 +123,13 @@ def main():
         from flame_amd.frames import IdepthGather
 
         ig = IdepthGather(dist, [g["V"]], world, torch.device("cuda", local_rank))
-        # the solver runs on a torch stream so that export -> all_gather is ordered on the device, without
-        # a host round trip between them
-        solver_stream = torch.cuda.Stream(device=local_rank)
-        reg.set_stream(solver_stream.cuda_stream)
 
         def after_step():
             reg.export_idepth_device(ig.local_row(0).data_ptr(), 1.0, wait=False)
             with torch.cuda.stream(solver_stream):
                 ig.gather(async_op=True)  # overlaps the next step's solve; completed before the buffer is reused
 
-    wall, ev_ms = measure(reg, params, a.iters, a.steps, a.warmup, sync, barrier, after_step)
+    wall, ev_ms = measure(reg, params, a.iters, a.steps, a.warmup, sync, barrier, solver_stream, after_step)
     if dist is not None:
         ig.wait()
     run_path = flame_amd.regularizer.RUN_PATHS.get(reg.info()["last_run_path"], "?")
