@@ -44,13 +44,15 @@ def parse():
     return ap.parse_args()
 
 
-def measure(reg, params, iters, steps, warmup, sync, barrier, stream, after_step=None):
+def measure(reg, params, iters, steps, warmup, sync, barrier, stream, before_step=None, after_step=None):
     """warmup, then EXACTLY `steps` steps bracketed by barrier+synchronize.  The steps are enqueued back to back
     (no host round trip between them; run_async), each launch bracketed by a HIP event pair recorded on the
     solver's stream.  Returns (wall seconds, device ms summed over the steps' event regions)."""
     import torch
 
     for _ in range(warmup):
+        if before_step:
+            before_step()
         reg.run(params, iters)
         if after_step:
             after_step()
@@ -59,6 +61,8 @@ def measure(reg, params, iters, steps, warmup, sync, barrier, stream, after_step
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
     for e0, e1 in ev:
+        if before_step:
+            before_step()
         e0.record(stream)
         reg.run_async(params, iters)
         e1.record(stream)
@@ -116,7 +120,7 @@ def main():
     # all_gather is ordered on the device without a host round trip between them
     solver_stream = torch.cuda.Stream(device=local_rank)
     reg.set_stream(solver_stream.cuda_stream)
-    after_step = None
+    before_step = after_step = None
     if dist is not None:
         # result gather (configs[3]): x*graph_scale of every rank's frame to all ranks, one RCCL
         # all_gather per step; no collective on the solve path
@@ -124,12 +128,15 @@ def main():
 
         ig = IdepthGather(dist, [g["V"]], world, torch.device("cuda", local_rank))
 
+
+        def before_step():  # the solver leaves x * graph_scale in the gather's (double-buffered) send row itself
+            reg.set_export_target(ig.local_row(0).data_ptr(), 1.0)
+
         def after_step():
-            reg.export_idepth_device(ig.local_row(0).data_ptr(), 1.0, wait=False)
             with torch.cuda.stream(solver_stream):
                 ig.gather(async_op=True)  # overlaps the next step's solve; completed before the buffer is reused
 
-    wall, ev_ms = measure(reg, params, a.iters, a.steps, a.warmup, sync, barrier, solver_stream, after_step)
+    wall, ev_ms = measure(reg, params, a.iters, a.steps, a.warmup, sync, barrier, solver_stream, before_step, after_step)
     if dist is not None:
         ig.wait()
     run_path = flame_amd.regularizer.RUN_PATHS.get(reg.info()["last_run_path"], "?")

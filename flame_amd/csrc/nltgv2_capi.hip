@@ -68,6 +68,8 @@ struct flame_nltgv2_ctx {
 
   int opt_solver = 0, opt_use_graph = 1, opt_block_waves = 0, opt_unroll = 0, opt_persistent = 1, opt_dual = 1;
   int opt_xcds = 0;      // XCDs a persistent launch spreads over: 0 = auto, 1..8
+  float* export_ptr = nullptr;  // flame_nltgv2_set_export_target: every run also leaves x * scale there
+  float export_scale = 1.0f;
   int opt_fault = 0;     // test hook: > 0 = the next persistent runs time out after this many spins
   int opt_presleep = 0;  // 0: auto (kPreSleep*); n > 0: (n - 1) x 64 cycles
   int opt_tv_lds = 1;  // 0 registers, 1 auto (LDS when the register form is not resident in one launch), 2 LDS
@@ -397,6 +399,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
     }
     ctx->fused_valid = false;
     ctx->last_run_path = 4;
+    if (ctx->export_ptr) LAUNCHCHK(ctx, launch_export(ctx->c, ctx->f, false, ctx->export_scale, ctx->export_ptr, ctx->stream));
     return 0;
   }
   int rc = ensure_fused(ctx);
@@ -435,7 +438,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
                                                                             : kPreSleepHe;
       const unsigned spins_arg = ctx->opt_fault > 0 ? (0x80000000u | (unsigned)ctx->opt_fault) : kMaxSpins;
       e = launch_persistent_run(ctx->f, to_sp(p), form, gr.begin, gr.count, ctx->parity, tag0, n, pw, spins_arg, presleep, dual,
-                                tv_lds, xcds, ctx->coop_checked_key != key, ctx->stream);
+                                tv_lds, xcds, ctx->export_ptr, ctx->export_scale, ctx->coop_checked_key != key, ctx->stream);
       if (e != 0) break;
     }
     ctx->tag_next = tag0 + (uint32_t)n;
@@ -486,6 +489,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   }
   ctx->have_prev = true;
   ctx->canon_valid = false;
+  if (ctx->export_ptr) LAUNCHCHK(ctx, launch_export(ctx->c, ctx->f, true, ctx->export_scale, ctx->export_ptr, ctx->stream));
   return 0;
 }
 
@@ -1200,6 +1204,13 @@ static int export_idepth(flame_nltgv2_ctx* ctx, void* dst_device, float scale, b
   const bool packed = !ctx->canon_valid;
   LAUNCHCHK(ctx, launch_export(ctx->c, ctx->f, packed, scale, (float*)dst_device, ctx->stream));
   if (wait) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_set_export_target(flame_nltgv2_ctx* ctx, void* dst_device, float scale) {
+  if (!ctx) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  ctx->export_ptr = (float*)dst_device;
+  ctx->export_scale = scale;
   return FLAME_NLTGV2_OK;
 }
 

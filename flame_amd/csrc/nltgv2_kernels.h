@@ -80,7 +80,8 @@ int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, boo
                       int waves_per_block, hipStream_t stream);
 int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, int wave_begin, int n_waves,
                           int parity_in, unsigned tag0, int n_iters, int waves_per_block, unsigned max_spins,
-                          int presleep, int dual, int tv_static_in_lds, int xcds, bool cooperative, hipStream_t stream);
+                          int presleep, int dual, int tv_static_in_lds, int xcds, float* export_out, float export_scale,
+                          bool cooperative, hipStream_t stream);
 int launch_save_prev(const CanonArgs& c, hipStream_t s);
 int launch_dual(const CanonArgs& c, const SolverParams& p, hipStream_t s);
 int launch_primal(const CanonArgs& c, const SolverParams& p, hipStream_t s);

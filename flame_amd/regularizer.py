@@ -92,7 +92,7 @@ ABI_SYMBOLS = (
     "flame_nltgv2_run_async", "flame_nltgv2_sync", "flame_nltgv2_run_timed", "flame_nltgv2_save_prev",
     "flame_nltgv2_dual_step", "flame_nltgv2_primal_step", "flame_nltgv2_extragradient_step", "flame_nltgv2_step",
     "flame_nltgv2_costs", "flame_nltgv2_download_state", "flame_nltgv2_export_idepth_device",
-    "flame_nltgv2_export_idepth_device_async",
+    "flame_nltgv2_export_idepth_device_async", "flame_nltgv2_set_export_target",
     "flame_nltgv2_set_option", "flame_nltgv2_get_info", "flame_nltgv2_last_error", "flame_nltgv2_last_hip_error",
     "flame_nltgv2_status_string", "flame_nltgv2_abi_version", "flame_nltgv2_pack_probe",
     "flame_nltgv2_photo_set_images", "flame_nltgv2_photo_residual", "flame_nltgv2_sync_graph",
@@ -135,6 +135,7 @@ def load_library():
         "flame_nltgv2_download_state": (C.c_int, [ctx, GP]),
         "flame_nltgv2_export_idepth_device": (C.c_int, [ctx, C.c_void_p, C.c_float]),
         "flame_nltgv2_export_idepth_device_async": (C.c_int, [ctx, C.c_void_p, C.c_float]),
+        "flame_nltgv2_set_export_target": (C.c_int, [ctx, C.c_void_p, C.c_float]),
         "flame_nltgv2_set_option": (C.c_int, [ctx, C.c_int, C.c_int]),
         "flame_nltgv2_get_info": (C.c_int, [ctx, C.POINTER(_Info)]),
         "flame_nltgv2_last_error": (C.c_int, [ctx]),
@@ -455,6 +456,11 @@ class Regularizer:
     def export_idepth_device(self, device_ptr: int, scale: float = 1.0, wait: bool = True):
         fn = self._L.flame_nltgv2_export_idepth_device if wait else self._L.flame_nltgv2_export_idepth_device_async
         self._chk(fn(self._ctx, C.c_void_p(device_ptr), C.c_float(scale)), "export_idepth_device")
+
+    def set_export_target(self, device_ptr: int | None, scale: float = 1.0):
+        """While set, every run also leaves scale * x (original vertex order) in this device buffer."""
+        self._chk(self._L.flame_nltgv2_set_export_target(self._ctx, C.c_void_p(device_ptr or 0), C.c_float(scale)),
+                  "set_export_target")
 
     def info(self) -> dict:
         i = _Info()

@@ -188,6 +188,10 @@ int flame_nltgv2_export_idepth_device(flame_nltgv2_ctx* ctx, void* dst_device, f
 /* Same, enqueue only: ordered on the context's stream (see flame_nltgv2_set_stream), no host wait -- a
  * collective enqueued on the same stream afterwards reads the finished buffer. */
 int flame_nltgv2_export_idepth_device_async(flame_nltgv2_ctx* ctx, void* dst_device, float scale);
+/* Standing export target: while `dst_device` is set (NULL = off), every run()/run_async() also leaves
+ * scale * x[v] there (V floats, original vertex order) as part of the same launch -- the persistent kernels write
+ * it in their epilogue, so a per-step result gather needs no extra kernel between two runs. */
+int flame_nltgv2_set_export_target(flame_nltgv2_ctx* ctx, void* dst_device, float scale);
 
 /* Mesh -> dense inverse-depth map, the step right after the solver each frame:
  * utils::interpolateMesh (utils/image_utils.cc:373-396) over utils::DrawShadedTriangleBarycentric

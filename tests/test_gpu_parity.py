@@ -439,6 +439,32 @@ def test_export_idepth_device_and_stream(env):
         reg.set_stream(None)
 
 
+@pytest.mark.parametrize("form", [0, 2, 3])
+def test_standing_export_target(env, form):
+    """flame_nltgv2_set_export_target: every run leaves scale * x in the caller's vertex order, on all paths."""
+    import torch
+
+    flame_amd, oracle = env
+    g = synth.make_graph("320x240", seed=21)
+    ref = synth.copy_graph(g)
+    p = flame_amd.Params()
+    buf = torch.full((g["V"],), -7.0, dtype=torch.float32, device="cuda")
+    with flame_amd.Regularizer(0) as reg:
+        reg.set_option(5, form)
+        reg.upload_graph(g)
+        reg.set_export_target(buf.data_ptr(), 1.5)
+        for n in (17, 4, 30):
+            reg.run(p, n)
+            oracle.run(ref, n)
+            torch.cuda.synchronize()
+            assert np.array_equal(buf.cpu().numpy(), ref["x"] * np.float32(1.5)), (form, n)
+        reg.set_export_target(None)
+        buf.fill_(-7.0)
+        reg.run(p, 5)
+        torch.cuda.synchronize()
+        assert float(buf.max()) == -7.0
+
+
 def test_run_timed_and_info(env):
     flame_amd, _ = env
     g = synth.make_graph("640x480", seed=1)
