@@ -186,7 +186,7 @@ k_fused_step(const int n_slices, const int slices_per_xcd, const int32_t* __rest
 
 // ------------------------------------------------------------------------------------------------
 // Persistent run: ONE launch == n_iters reference step()s, for graphs whose half-edges all fit on
-// the chip at once (one LANE per half-edge, <= 32 waves per CU).
+// the chip at once (one LANE per half-edge, the host admits <= 24 waves per CU).
 //
 // Why: a dependent kernel boundary costs ~3.5 us on this part (measured: trivial dependent kernels
 // replay at that period) while one step of a 640x480 graph is < 1 us of work, so one-launch-per-step
@@ -216,7 +216,8 @@ k_fused_step(const int n_slices, const int slices_per_xcd, const int32_t* __rest
 //     for every x, including both zeros).
 //
 // All waves must be resident (cooperative launch: the runtime checks the grid); every wait is
-// bounded and reports FLAME_NLTGV2_ERR_TIMEOUT through `err`.
+// bounded and reports through `err`.  The run is transactional: it reads hq/vstate/bar_in and writes hq_out/
+// vstate_out/bar_out (the other copies), so the host can take a timed-out run back and redo it per step.
 // ------------------------------------------------------------------------------------------------
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 
