@@ -211,7 +211,10 @@ def main():
             }
             out["speedup_vs_cpu_baseline"] = round(value / world / out["cpu_baseline"]["value"], 1)
     if not a.no_extras and world == 1:
-        extras(a, reg, params, out, flame_amd, synth, sync, info)
+        try:  # labelled side measurements: never allowed to take the contract line down with them
+            extras(a, reg, params, out, flame_amd, synth, sync, info)
+        except Exception as e:  # noqa: BLE001
+            out["extras_error"] = f"{type(e).__name__}: {e}"
     reg.close()
     if rank == 0:
         print(json.dumps(out))
