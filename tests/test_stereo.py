@@ -609,6 +609,19 @@ def test_gpu_device_resident_features(built):
         assert tr.last_kernel_ms() > 0
     assert st["num_idepth_updates"] == st_o[0]
     assert dev.cpu().numpy().tobytes() == out_o.tobytes()
+    # the same on a caller-owned stream, enqueue only (no stats): ordered with the caller's other work on that stream
+    dev2 = torch.from_numpy(feats.view(np.uint8).reshape(-1, 40).copy()).cuda()
+    stream = torch.cuda.Stream()
+    with FeatureTracker(sc.K32, sc.Kinv32, sc.width, sc.height) as tr:
+        tr.set_stream(stream.cuda_stream)
+        for fid, img in imgs.items():
+            tr.add_frame(fid, img)
+        torch.cuda.synchronize()
+        assert tr.update_feature_idepths_device(_product_params(), 12, 11, poses, feats.shape[0], dev2.data_ptr(), wait=False) is None
+        with torch.cuda.stream(stream):
+            host = dev2.to("cpu", non_blocking=False)
+        tr.set_stream(None)
+    assert host.numpy().tobytes() == out_o.tobytes()
 
 
 @gpu
