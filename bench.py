@@ -210,6 +210,21 @@ def main():
                 "host_cores": os.cpu_count(),
             }
             out["speedup_vs_cpu_baseline"] = round(value / world / out["cpu_baseline"]["value"], 1)
+            # the strongest fair CPU number: OpenMP two-phase form over the host cores, bit-identical
+            # to the sequential restatement; the reference itself runs the solver on one thread
+            best = None
+            for t in (8, 16, 32, 64, 128):
+                if t > (os.cpu_count() or 1):
+                    break
+                s_omp = oracle.omp_run_timed(synth.copy_graph(g), 2000, t)
+                if best is None or 2000 / s_omp > best[0]:
+                    best = (2000 / s_omp, t)
+            if best:
+                out["cpu_baseline"]["openmp_all_cores"] = {
+                    "value": round(best[0], 1), "unit": "iters/s", "threads": best[1],
+                    "sample": "2000 iterations per thread count in (8,16,32,64,128), best reported; flat SoA arrays, "
+                              "edge-parallel dual + vertex-gather primal",
+                    "gpu_over_this": round(value / world / best[0], 1)}
     if not a.no_extras and world == 1:
         try:  # labelled side measurements: never allowed to take the contract line down with them
             extras(a, reg, params, out, flame_amd, synth, sync, info)

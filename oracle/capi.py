@@ -44,7 +44,7 @@ def lib():
     if _LIB is None:
         path = os.path.join(_HERE, "liboracle_nltgv2.so")
         src = os.path.join(_HERE, "nltgv2_oracle.c")
-        others = [os.path.join(_HERE, f) for f in ("photometric_oracle.c", "raster_oracle.c", "stereo_oracle.c")]
+        others = [os.path.join(_HERE, f) for f in ("photometric_oracle.c", "raster_oracle.c", "stereo_oracle.c", "nltgv2_omp.c")]
         if (not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src)
                 or any(os.path.getmtime(path) < os.path.getmtime(o) for o in others)):
             build()
@@ -142,6 +142,25 @@ def costs(g, params=None):
     v = _view(g)
     return (float(lib().nltgv2_oracle_smoothness_cost(C.byref(p), C.byref(v))),
             float(lib().nltgv2_oracle_data_cost(C.byref(p), C.byref(v))))
+
+
+def omp_run(g: dict, n_iters: int, threads: int, params: Params | None = None) -> int:
+    """OpenMP two-phase form (oracle/nltgv2_omp.c); bit-identical to run() for any thread count."""
+    L = lib()
+    L.nltgv2_omp_run.argtypes = [C.POINTER(Params), C.POINTER(Graph), C.c_int, C.c_int]
+    L.nltgv2_omp_run.restype = C.c_int
+    p = params or make_params()
+    gv = _view(g)
+    return int(L.nltgv2_omp_run(C.byref(p), C.byref(gv), int(n_iters), int(threads)))
+
+
+def omp_run_timed(g: dict, n_iters: int, threads: int, params: Params | None = None) -> float:
+    import time
+
+    omp_run(g, 20, threads, params)  # thread pool up, caches warm
+    t0 = time.perf_counter()
+    omp_run(g, n_iters, threads, params)
+    return time.perf_counter() - t0
 
 
 def reflayout_run_timed(g: dict, n_iters: int, params=None, export: bool = False) -> float:

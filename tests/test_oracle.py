@@ -49,6 +49,19 @@ def test_reference_layout_variant_is_bit_identical():
     assert_state_equal(a, b, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"))
 
 
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_openmp_two_phase_variant_is_bit_identical(threads):
+    """oracle/nltgv2_omp.c (the multi-core CPU figure of bench.py): per-vertex gather in ascending edge id == the
+    reference's sequential scatter, for any thread count."""
+    for seed, cfg in ((4, "320x240"), (5, "640x480")):
+        g = synth.make_graph(cfg, seed=seed)
+        a, b = synth.copy_graph(g), synth.copy_graph(g)
+        assert oracle.run(a, 40) == 0
+        assert oracle.omp_run(b, 40, threads) == 0
+        for k in synth.STATE_KEYS:
+            assert np.array_equal(a[k], b[k]), (cfg, threads, k)
+
+
 def test_step_is_composition_of_its_parts():
     """step == prev-save; dualStep; primalStep; extraGradientStep (cc:33-49)."""
     g = synth.make_graph("320x240", seed=4)
