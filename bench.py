@@ -137,8 +137,17 @@ def main():
                 ig.gather(async_op=True)  # overlaps the next step's solve; completed before the buffer is reused
 
     wall, ev_ms = measure(reg, params, a.iters, a.steps, a.warmup, sync, barrier, solver_stream, before_step, after_step)
+    gather_us = None
     if dist is not None:
         ig.wait()
+        # latency of the result gather on its own (configs[3]: "RCCL gather over xGMI"), outside the timed region
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            ig.local_row(0)
+            ig.gather(async_op=False)
+            torch.cuda.synchronize()
+        gather_us = (time.perf_counter() - t0) / 20 * 1e6
     run_path = flame_amd.regularizer.RUN_PATHS.get(reg.info()["last_run_path"], "?")
     if dist is not None:
         t = torch.tensor([wall], device="cuda", dtype=torch.float64)
@@ -183,6 +192,10 @@ def main():
             "device": {"name": info["device_name"], "arch": info["gcn_arch"], "cus": info["compute_units"]},
             "run_path": run_path,
         }
+        if gather_us is not None:
+            out["result_gather"] = {"all_gather_us": round(gather_us, 1), "bytes_per_rank": int(g["V"]) * 4, "ranks": world,
+                                    "note": "blocking all_gather_into_tensor of x*graph_scale incl. host launch + sync; in the "
+                                            "step loop it is asynchronous and overlaps the next solve"}
         # ---- parity of THIS run's input against the CPU checker (same seeded input, same iteration count)
         from oracle import capi as oracle
 
