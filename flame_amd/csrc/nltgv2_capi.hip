@@ -293,18 +293,40 @@ int plan_persistent(const flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* 
   }
   const std::vector<int32_t>& cw = form == 2 ? L.comp_tv_wave : L.comp_he_wave;
   if (cw.size() < 3) return 0;  // one component that does not fit: stream it
-  int begin = cw[0];
-  for (size_t c = 0; c + 1 < cw.size(); ++c) {
-    if (cw[c + 1] - cw[c] > cap) {  // a single component larger than the chip
-      groups->clear();
-      return 0;
+  // Groups of about equal size (the per-step time of a group grows with its waves, and a small last group would run
+  // at low occupancy): cut at the component boundaries nearest to k * total / n_groups, never beyond what the chip
+  // holds; if the components are too uneven for that, fall back to filling each group greedily.
+  for (size_t c = 0; c + 1 < cw.size(); ++c)
+    if (cw[c + 1] - cw[c] > cap) return 0;  // a single component larger than the chip
+  const int n_groups = (total + cap - 1) / cap;
+  bool ok = true;
+  {
+    size_t c = 0;
+    int begin = cw[0];
+    for (int gi = 1; gi <= n_groups && ok; ++gi) {
+      const long ideal = cw[0] + (long)gi * total / n_groups;
+      size_t e = c + 1;  // at least one component per group
+      while (e + 1 < cw.size() && cw[e] < ideal) ++e;
+      if (gi == n_groups) e = cw.size() - 1;
+      while (e > c + 1 && cw[e] - begin > cap) --e;
+      if (cw[e] - begin > cap) ok = false;
+      groups->push_back(WaveGroup{begin, cw[e] - begin});
+      begin = cw[e], c = e;
+      if (c + 1 >= cw.size() && gi < n_groups) break;
     }
-    if (cw[c + 1] - begin > cap) {
-      groups->push_back(WaveGroup{begin, cw[c] - begin});
-      begin = cw[c];
-    }
+    if (ok && begin != cw.back()) ok = false;  // balanced cuts did not cover everything within n_groups groups
   }
-  groups->push_back(WaveGroup{begin, cw.back() - begin});
+  if (!ok) {
+    groups->clear();
+    int begin = cw[0];
+    for (size_t c = 0; c + 1 < cw.size(); ++c) {
+      if (cw[c + 1] - begin > cap) {
+        groups->push_back(WaveGroup{begin, cw[c] - begin});
+        begin = cw[c];
+      }
+    }
+    groups->push_back(WaveGroup{begin, cw.back() - begin});
+  }
   return form;
 }
 bool persistent_eligible(const flame_nltgv2_ctx* ctx, int n) {
