@@ -312,6 +312,20 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
         g = synth.make_graph(cfg, seed=1234)
         r = flame_amd.Regularizer(0)
         r.upload_graph(g)
+        fused = cfg == "1920x1080"
+        if fused:  # BASELINE config 5: the photometric residual of the final x comes out of the solver's own launch
+            import numpy as _np2
+
+            from flame_amd import synth_stereo as _ss
+
+            wv, hv, _ = synth.CONFIGS[cfg]
+            tex = _ss.texture(wv, hv, 77, margin=0)
+            ref_img = _np2.clip(_np2.rint(tex), 0, 255).astype(_np2.uint8)
+            cmp_img = _np2.roll(ref_img, 3, axis=1)
+            Kc = _np2.array([[0.52 * wv, 0, wv / 2.0], [0, 0.52 * wv, hv / 2.0], [0, 0, 1]])
+            Kt = (Kc @ _np2.array([0.04, -0.01, 0.003])).astype(_np2.float32)
+            r.photo_set_images(ref_img, cmp_img)
+            r.photo_fuse(_np2.eye(3, dtype=_np2.float32), Kt, graph_scale=1.0, border=4)
         r.run(params, 200)
         ms = min(r.run_timed(params, 200) for _ in range(5))
         bi = r.info()
@@ -319,6 +333,10 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
         oc[cfg] = {"V": g["V"], "E": g["E"], "iters_per_s": round(200 / (ms * 1e-3), 1),
                    "run_path": flame_amd.regularizer.RUN_PATHS.get(bi["last_run_path"], "?"),
                    "achieved_GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4)}
+        if fused:
+            res = r.photo_residual_last()
+            oc[cfg]["photometric_residual"] = {"fused_into_the_solver_launch": True,
+                                               "defined_on_fraction_of_vertices": round(float(_np2.isfinite(res).mean()), 3)}
         r.close()
     out["other_configs"] = oc
     # (3) what the boundary costs when the host hands over fresh buffers every frame (PCIe-inclusive;

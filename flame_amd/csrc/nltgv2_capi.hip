@@ -68,6 +68,10 @@ struct flame_nltgv2_ctx {
 
   int opt_solver = 0, opt_use_graph = 1, opt_block_waves = 0, opt_unroll = 0, opt_persistent = 1, opt_dual = 1;
   int opt_xcds = 0;      // XCDs a persistent launch spreads over: 0 = auto, 1..8
+  bool photo_fused = false;     // flame_nltgv2_photo_fuse: every run also leaves the photometric residual in photo_err
+  PhotoGeometry photo_geo{};
+  float photo_scale = 1.0f;
+  int photo_border = 3;
   float* export_ptr = nullptr;  // flame_nltgv2_set_export_target: every run also leaves x * scale there
   float export_scale = 1.0f;
   int opt_fault = 0;     // test hook: > 0 = the next persistent runs time out after this many spins
@@ -407,6 +411,31 @@ int prepare_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   return 0;
 }
 
+PhotoFuse photo_target(const flame_nltgv2_ctx* ctx) {
+  PhotoFuse f;
+  if (!ctx->photo_fused || ctx->img_rows == 0) return f;
+  f.pos = (const float2*)ctx->pos.p;
+  f.ref = (const uint8_t*)ctx->img_ref.p, f.cmp = (const uint8_t*)ctx->img_cmp.p;
+  f.err = (float*)ctx->photo_err.p;
+  f.geo = ctx->photo_geo;
+  f.graph_scale = ctx->photo_scale;
+  f.rows = ctx->img_rows, f.cols = ctx->img_cols, f.step = ctx->img_step, f.border = ctx->photo_border;
+  return f;
+}
+
+// after a run on a path whose kernels have no photometric epilogue
+int enqueue_photo_sweep(flame_nltgv2_ctx* ctx, bool packed_current) {
+  const PhotoFuse f = photo_target(ctx);
+  if (!f.err) return 0;
+  if (packed_current) {
+    LAUNCHCHK(ctx, launch_photo_residual_packed(ctx->f, f, ctx->stream));
+  } else {
+    LAUNCHCHK(ctx, launch_photo_residual(ctx->c, f.graph_scale, f.geo, f.ref, f.cmp, f.rows, f.cols, f.step, f.border, f.err,
+                                         ctx->stream));
+  }
+  return 0;
+}
+
 int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   if (n <= 0) return 0;
   if (ctx->opt_solver == 1) {  // canonical 4-sweep path
@@ -422,7 +451,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
     ctx->fused_valid = false;
     ctx->last_run_path = 4;
     if (ctx->export_ptr) LAUNCHCHK(ctx, launch_export(ctx->c, ctx->f, false, ctx->export_scale, ctx->export_ptr, ctx->stream));
-    return 0;
+    return enqueue_photo_sweep(ctx, false);
   }
   int rc = ensure_fused(ctx);
   if (rc) return rc;
@@ -460,7 +489,8 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
                                                                             : kPreSleepHe;
       const unsigned spins_arg = ctx->opt_fault > 0 ? (0x80000000u | (unsigned)ctx->opt_fault) : kMaxSpins;
       e = launch_persistent_run(ctx->f, to_sp(p), form, gr.begin, gr.count, ctx->parity, tag0, n, pw, spins_arg, presleep, dual,
-                                tv_lds, xcds, ctx->export_ptr, ctx->export_scale, ctx->coop_checked_key != key, ctx->stream);
+                                tv_lds, xcds, ctx->export_ptr, ctx->export_scale, photo_target(ctx), ctx->coop_checked_key != key,
+                                ctx->stream);
       if (e != 0) break;
     }
     ctx->tag_next = tag0 + (uint32_t)n;
@@ -512,7 +542,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   ctx->have_prev = true;
   ctx->canon_valid = false;
   if (ctx->export_ptr) LAUNCHCHK(ctx, launch_export(ctx->c, ctx->f, true, ctx->export_scale, ctx->export_ptr, ctx->stream));
-  return 0;
+  return enqueue_photo_sweep(ctx, true);
 }
 
 int finish(flame_nltgv2_ctx* ctx) {
@@ -759,7 +789,7 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
       {&ctx->rec_edge, sizeof(int32_t) * n_slots}, {&ctx->edge_src_slot, fE},
       {&ctx->hrec, sizeof(int4) * n_slots}, {&ctx->hq, sizeof(float4) * n_slots},
       {&ctx->vstate, sizeof(float4) * n_packed}, {&ctx->vaux, sizeof(float2) * n_packed},
-      {&ctx->hq_alt, sizeof(float4) * n_slots}, {&ctx->vstate_alt, sizeof(float4) * n_packed},
+      {&ctx->hq_alt, sizeof(float4) * n_slots}, {&ctx->vstate_alt, sizeof(float4) * n_packed}, {&ctx->photo_err, fV},
       {&ctx->bar0, sizeof(float4) * n_packed}, {&ctx->bar1, sizeof(float4) * n_packed},
       {&ctx->vprev, sizeof(float4) * n_packed}, {&ctx->xbuf, 68 * n_packed + 64},
       {&ctx->abort_flag, sizeof(int)}, {&ctx->he_slot, sizeof(int32_t) * L.he_slot.size()},
@@ -1343,6 +1373,41 @@ int flame_nltgv2_photo_residual(flame_nltgv2_ctx* ctx, const float* KRKinv, cons
   LAUNCHCHK(ctx, launch_photo_residual(ctx->c, graph_scale, geo, (const uint8_t*)ctx->img_ref.p,
                                        (const uint8_t*)ctx->img_cmp.p, ctx->img_rows, ctx->img_cols, ctx->img_step,
                                        border, (float*)ctx->photo_err.p, ctx->stream));
+  if (fV) HIPCHK(ctx, hipMemcpyAsync(err_out, ctx->photo_err.p, fV, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_photo_fuse(flame_nltgv2_ctx* ctx, const float* KRKinv, const float* Kt, float graph_scale, int border,
+                            int enable) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!enable) {
+    ctx->photo_fused = false;
+    return FLAME_NLTGV2_OK;
+  }
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!KRKinv || !Kt || border < 1 || ctx->img_rows == 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  rc = ensure(ctx, ctx->photo_err, sizeof(float) * (size_t)ctx->L.V);
+  if (rc) return rc;
+  std::memcpy(ctx->photo_geo.KRKinv, KRKinv, sizeof(ctx->photo_geo.KRKinv));
+  std::memcpy(ctx->photo_geo.Kt, Kt, sizeof(ctx->photo_geo.Kt));
+  ctx->photo_scale = graph_scale, ctx->photo_border = border;
+  ctx->photo_fused = true;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_photo_residual_last(flame_nltgv2_ctx* ctx, float* err_out) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!ctx->photo_fused || !err_out) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  if (ctx->pending.active) {
+    rc = finish(ctx);
+    if (rc) return rc;
+  }
+  const size_t fV = sizeof(float) * (size_t)ctx->L.V;
   if (fV) HIPCHK(ctx, hipMemcpyAsync(err_out, ctx->photo_err.p, fV, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return FLAME_NLTGV2_OK;

@@ -18,6 +18,17 @@ struct PhotoGeometry {
   float Kt[3];
 };
 
+// Standing photometric target of the persistent runs (flame_nltgv2_photo_fuse): err == nullptr means off.
+struct PhotoFuse {
+  const float2* pos = nullptr;  // canonical positions, caller's vertex order
+  const uint8_t* ref = nullptr;
+  const uint8_t* cmp = nullptr;
+  float* err = nullptr;         // [V], caller's vertex order
+  PhotoGeometry geo{};
+  float graph_scale = 1.0f;
+  int rows = 0, cols = 0, step = 0, border = 0;
+};
+
 // Everything EpipolarGeometry::project(u, idepth, &u_new, &idepth_new) reads (stereo/epipolar_geometry.h:152-180)
 // plus the valid region of Flame::projectGraph (flame.cc:1881-1884).
 struct ProjectGeometry {
@@ -81,7 +92,7 @@ int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, boo
 int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, int wave_begin, int n_waves,
                           int parity_in, unsigned tag0, int n_iters, int waves_per_block, unsigned max_spins,
                           int presleep, int dual, int tv_static_in_lds, int xcds, float* export_out, float export_scale,
-                          bool cooperative, hipStream_t stream);
+                          const PhotoFuse& photo, bool cooperative, hipStream_t stream);
 int launch_save_prev(const CanonArgs& c, hipStream_t s);
 int launch_dual(const CanonArgs& c, const SolverParams& p, hipStream_t s);
 int launch_primal(const CanonArgs& c, const SolverParams& p, hipStream_t s);
@@ -98,6 +109,7 @@ int launch_interpolate_mesh(int T, const int32_t* tris, const float2* vtx, const
                             int* coverage, int rows, int cols, hipStream_t s);
 int launch_photo_residual(const CanonArgs& c, float graph_scale, const PhotoGeometry& geo, const uint8_t* ref,
                           const uint8_t* cmp, int rows, int cols, int step, int border, float* err, hipStream_t s);
+int launch_photo_residual_packed(const FusedArgs& a, const PhotoFuse& photo, hipStream_t s);
 int launch_cost_terms(const CanonArgs& c, float* terms, hipStream_t s);
 
 }  // namespace flame_hip

@@ -72,6 +72,57 @@ __device__ __forceinline__ EdgeOut edge_dual(const SolverParams& p, float alpha,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Per-vertex photometric residual (BASELINE config 5): |I_cmp(project(u, idepth)) - I_ref(u)|,
+// NaN where it is undefined.  No live reference code (only the commented-out block flame.cc:854-893); built from the
+// live, test-pinned pieces EpipolarGeometry::project (stereo/epipolar_geometry.h:127-143, 191-201) and
+// utils::bilinearInterp<uint8_t,float> (utils/image_utils.h:199-214, 230-255).  It reads x, never writes it.  Used by
+// the stand-alone sweep k_photo_residual and, when a standing target is set, by the epilogue of the persistent runs
+// (the residual of the run's final x as part of the solver's own launch).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float photo_bilinear_u8(const uint8_t* __restrict__ data, int step, float x, float y) {
+  const int xf = (int)x, yf = (int)y;
+  const float dx = x - xf, dy = y - yf;
+  const float w11 = dx * dy;
+  const float w01 = dx - w11;
+  const float w10 = dy - w11;
+  const float w00 = 1.0f - dx - dy + w11;
+  const uint8_t* p = data + (size_t)yf * step + xf;
+  return w00 * p[0] + w01 * p[1] + w10 * p[step] + w11 * p[1 + step];
+}
+
+__device__ __forceinline__ bool photo_inside(float x, float y, int rows, int cols, int border) {
+  return x >= (float)border && y >= (float)border && x < (float)(cols - border) && y < (float)(rows - border);
+}
+
+__device__ __forceinline__ float photo_residual_at(float2 u, float idepth, const PhotoGeometry& geo,
+                                                   const uint8_t* __restrict__ ref, const uint8_t* __restrict__ cmp, int rows,
+                                                   int cols, int step, int border) {
+  float out = __builtin_nanf("");
+  if (!(idepth != idepth) && !(idepth < 0.0f) && photo_inside(u.x, u.y, rows, cols, border)) {
+    float h0, h1, h2;
+    const float* K = geo.KRKinv;
+    if (idepth == 0.0f) {  // maxDepthProjection
+      h0 = (K[0] * u.x + K[1] * u.y) + K[2] * 1.0f;
+      h1 = (K[3] * u.x + K[4] * u.y) + K[5] * 1.0f;
+      h2 = (K[6] * u.x + K[7] * u.y) + K[8] * 1.0f;
+    } else {
+      const float depth = 1.0f / idepth;
+      const float a = u.x * depth, b = u.y * depth, c = depth;
+      h0 = ((K[0] * a + K[1] * b) + K[2] * c) + geo.Kt[0];
+      h1 = ((K[3] * a + K[4] * b) + K[5] * c) + geo.Kt[1];
+      h2 = ((K[6] * a + K[7] * b) + K[8] * c) + geo.Kt[2];
+    }
+    const float inv = 1.0f / h2;
+    const float cx = h0 * inv, cy = h1 * inv;
+    if (cx == cx && cy == cy && photo_inside(cx, cy, rows, cols, border)) {
+      const float d = photo_bilinear_u8(cmp, step, cx, cy) - photo_bilinear_u8(ref, step, u.x, u.y);
+      out = (d > 0) ? d : -d;
+    }
+  }
+  return out;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused step: one launch == one reference step() (cc:33-49) on the SELL-64 layout.
 //
 //   wave <-> slice of 64 packed vertices, lane <-> vertex.  Slot k of the lane's vertex is its k-th
@@ -251,7 +302,7 @@ k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd
                 float4* vprev, void* xbuf, const int rec_bytes, const int dual, const unsigned tag0, const int n_iters,
                 const unsigned max_spins_arg, const int presleep, const SolverParams p, int* __restrict__ err,
                 int* __restrict__ abort_flag, const int32_t* __restrict__ perm, float* __restrict__ export_out,
-                const float export_scale) {
+                const float export_scale, const PhotoFuse photo) {
   const unsigned max_spins = max_spins_arg & 0x7fffffffu;
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
@@ -462,9 +513,14 @@ k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd
     vstate_out[pv] = make_float4(x, w1, w2, data);
     bar_out[pv] = make_float4(xb, w1b, w2b, 0.0f);
     vprev[pv] = make_float4(x_prev, w1_prev, w2_prev, 0.0f);
-    if (export_out) {  // flame_nltgv2_set_export_target: x * graph_scale in the caller's vertex order (flame.cc:372-380)
-      const int o = perm[pv];
-      if (o >= 0) export_out[o] = x * export_scale;
+    if (export_out || photo.err) {
+      const int o = perm[pv];  // the caller's vertex index
+      // flame_nltgv2_set_export_target: x * graph_scale in the caller's vertex order (flame.cc:372-380)
+      if (o >= 0 && export_out) export_out[o] = x * export_scale;
+      // flame_nltgv2_photo_fuse: the photometric residual of the final x, in the same launch (config 5)
+      if (o >= 0 && photo.err)
+        photo.err[o] = photo_residual_at(photo.pos[o], x * photo.graph_scale, photo.geo, photo.ref, photo.cmp, photo.rows,
+                                         photo.cols, photo.step, photo.border);
     }
   }
   if (active) hq_out[slot] = make_float4(q1, q2, q3, beta);
@@ -502,7 +558,7 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
                 float4* vprev, void* xbuf, const int rec_bytes, const int dual, const unsigned tag0, const int n_iters,
                 const unsigned max_spins_arg, const int presleep, const SolverParams p, int* __restrict__ err,
                 int* __restrict__ abort_flag, const int32_t* __restrict__ perm, float* __restrict__ export_out,
-                const float export_scale) {
+                const float export_scale, const PhotoFuse photo) {
   const unsigned max_spins = max_spins_arg & 0x7fffffffu;
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
@@ -736,9 +792,12 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
     vstate_out[pv] = make_float4(x, w1, w2, data);
     bar_out[pv] = make_float4(xb, w1b, w2b, 0.0f);
     vprev[pv] = make_float4(x_prev, w1_prev, w2_prev, 0.0f);
-    if (export_out) {
+    if (export_out || photo.err) {
       const int o = perm[pv];
-      if (o >= 0) export_out[o] = x * export_scale;
+      if (o >= 0 && export_out) export_out[o] = x * export_scale;
+      if (o >= 0 && photo.err)
+        photo.err[o] = photo_residual_at(photo.pos[o], x * photo.graph_scale, photo.geo, photo.ref, photo.cmp, photo.rows,
+                                         photo.cols, photo.step, photo.border);
     }
   }
 #pragma unroll
@@ -944,59 +1003,25 @@ k_export_canonical(int V, const float* __restrict__ x, float scale, float* __res
   if (v < V) out[v] = x[v] * scale;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Per-vertex photometric residual (BASELINE config 5).  No live reference
-// code (only the commented-out block flame.cc:854-893); built from the live, test-pinned pieces
-// EpipolarGeometry::project (stereo/epipolar_geometry.h:127-143, 191-201) and
-// utils::bilinearInterp<uint8_t,float> (utils/image_utils.h:199-214, 230-255).  An epilogue sweep:
-// it reads x, never writes it.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float bilinear_u8(const uint8_t* __restrict__ data, int step, float x, float y) {
-  const int xf = (int)x, yf = (int)y;
-  const float dx = x - xf, dy = y - yf;
-  const float w11 = dx * dy;
-  const float w01 = dx - w11;
-  const float w10 = dy - w11;
-  const float w00 = 1.0f - dx - dy + w11;
-  const uint8_t* p = data + (long)yf * step + xf;
-  return w00 * p[0] + w01 * p[1] + w10 * p[step] + w11 * p[1 + step];
-}
-
-__device__ __forceinline__ bool inside_region(float x, float y, int rows, int cols, int border) {
-  return x >= (float)border && y >= (float)border && x < (float)(cols - border) && y < (float)(rows - border);
-}
-
+// The stand-alone residual sweep (photo_residual_at is defined next to the persistent kernels, which use it too).
 __global__ void __launch_bounds__(256)
 k_photo_residual(int V, const float2* __restrict__ pos, const float* __restrict__ x, float graph_scale,
                  PhotoGeometry geo, const uint8_t* __restrict__ ref, const uint8_t* __restrict__ cmp, int rows,
                  int cols, int step, int border, float* __restrict__ err) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
-  float out = __builtin_nanf("");
-  const float idepth = x[v] * graph_scale;
-  const float2 u = pos[v];
-  if (!(idepth != idepth) && !(idepth < 0.0f) && inside_region(u.x, u.y, rows, cols, border)) {
-    float h0, h1, h2;
-    const float* K = geo.KRKinv;
-    if (idepth == 0.0f) {  // maxDepthProjection
-      h0 = (K[0] * u.x + K[1] * u.y) + K[2] * 1.0f;
-      h1 = (K[3] * u.x + K[4] * u.y) + K[5] * 1.0f;
-      h2 = (K[6] * u.x + K[7] * u.y) + K[8] * 1.0f;
-    } else {
-      const float depth = 1.0f / idepth;
-      const float a = u.x * depth, b = u.y * depth, c = depth;
-      h0 = ((K[0] * a + K[1] * b) + K[2] * c) + geo.Kt[0];
-      h1 = ((K[3] * a + K[4] * b) + K[5] * c) + geo.Kt[1];
-      h2 = ((K[6] * a + K[7] * b) + K[8] * c) + geo.Kt[2];
-    }
-    const float inv = 1.0f / h2;
-    const float cx = h0 * inv, cy = h1 * inv;
-    if (cx == cx && cy == cy && inside_region(cx, cy, rows, cols, border)) {
-      const float d = bilinear_u8(cmp, step, cx, cy) - bilinear_u8(ref, step, u.x, u.y);
-      out = (d > 0) ? d : -d;
-    }
-  }
-  err[v] = out;
+  err[v] = photo_residual_at(pos[v], x[v] * graph_scale, geo, ref, cmp, rows, cols, step, border);
+}
+
+// ... and the same on the packed state (after a run on the one-launch-per-step path, which has no such epilogue)
+__global__ void __launch_bounds__(256)
+k_photo_residual_packed(int n_packed, const int32_t* __restrict__ perm, const float4* __restrict__ vstate, PhotoFuse photo) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_packed) return;
+  const int o = perm[s];
+  if (o >= 0)
+    photo.err[o] = photo_residual_at(photo.pos[o], vstate[s].x * photo.graph_scale, photo.geo, photo.ref, photo.cmp,
+                                     photo.rows, photo.cols, photo.step, photo.border);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1176,7 +1201,7 @@ int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, boo
 int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, int wave_begin, int n_waves,
                           int parity_in, unsigned tag0, int n_iters, int waves_per_block, unsigned max_spins,
                           int presleep, int dual, int tv_static_in_lds, int xcds, float* export_out, float export_scale,
-                          bool cooperative, hipStream_t stream) {
+                          const PhotoFuse& photo_in, bool cooperative, hipStream_t stream) {
   if (n_waves <= 0 || n_iters <= 0) return (int)hipSuccess;
   // Workgroup b runs on XCD b & 7.  With xcds < 8 only the first `xcds` XCDs get waves (the workgroups of the
   // others find no work and exit), which keeps a small graph's whole exchange inside fewer L2s.
@@ -1203,9 +1228,10 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
   int* err = a.err;
   int* abort_flag = a.abort_flag;
   const int32_t* perm = a.perm;
+  PhotoFuse photo = photo_in;
   void* args[] = {&wave_begin, &n_waves, &wpx, &i0, &i1, &i2, &i3, &hrec, &hq, &vstate, &hq_out, &vstate_out, &vaux,
                   &bin, &bout, &vprev, &xbuf, &rec_bytes, &dual, &tag0, &n_iters, &max_spins, &presleep, &pp, &err,
-                  &abort_flag, &perm, &export_out, &export_scale};
+                  &abort_flag, &perm, &export_out, &export_scale, &photo};
   const bool tv_lds = form == 2 && (tv_static_in_lds != 0);
   const void* fn = (form == 2) ? (tv_lds ? (const void*)k_persistent_tv<true> : (const void*)k_persistent_tv<false>)
                                : (const void*)k_persistent_he;
@@ -1327,6 +1353,13 @@ int launch_photo_residual(const CanonArgs& c, float graph_scale, const PhotoGeom
   if (c.V <= 0) return 0;
   hipLaunchKernelGGL(k_photo_residual, grid1d(c.V), dim3(256), 0, s, c.V, c.pos, c.x, graph_scale, geo, ref, cmp,
                      rows, cols, step, border, err);
+  return (int)hipGetLastError();
+}
+
+int launch_photo_residual_packed(const FusedArgs& a, const PhotoFuse& photo, hipStream_t s) {
+  const int n_packed = a.n_slices * 64;
+  if (n_packed <= 0 || !photo.err) return 0;
+  hipLaunchKernelGGL(k_photo_residual_packed, grid1d(n_packed), dim3(256), 0, s, n_packed, a.perm, a.vstate, photo);
   return (int)hipGetLastError();
 }
 

@@ -95,7 +95,8 @@ ABI_SYMBOLS = (
     "flame_nltgv2_export_idepth_device_async", "flame_nltgv2_set_export_target",
     "flame_nltgv2_set_option", "flame_nltgv2_get_info", "flame_nltgv2_last_error", "flame_nltgv2_last_hip_error",
     "flame_nltgv2_status_string", "flame_nltgv2_abi_version", "flame_nltgv2_pack_probe",
-    "flame_nltgv2_photo_set_images", "flame_nltgv2_photo_residual", "flame_nltgv2_sync_graph",
+    "flame_nltgv2_photo_set_images", "flame_nltgv2_photo_residual", "flame_nltgv2_photo_fuse",
+    "flame_nltgv2_photo_residual_last", "flame_nltgv2_sync_graph",
     "flame_nltgv2_get_topology", "flame_nltgv2_set_feature_ids", "flame_nltgv2_interpolate_mesh",
     "flame_nltgv2_interpolate_mesh_arrays", "flame_nltgv2_project_graph", "flame_nltgv2_rescale_data",
     "flame_delaunay_triangulate",
@@ -145,6 +146,8 @@ def load_library():
         "flame_nltgv2_pack_probe": (C.c_int, [GP, _IP, _IP, _IP, _IP, C.c_int64, C.POINTER(C.c_int64)]),
         "flame_nltgv2_photo_set_images": (C.c_int, [ctx, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int]),
         "flame_nltgv2_photo_residual": (C.c_int, [ctx, _FP, _FP, C.c_float, C.c_int, _FP]),
+        "flame_nltgv2_photo_fuse": (C.c_int, [ctx, _FP, _FP, C.c_float, C.c_int, C.c_int]),
+        "flame_nltgv2_photo_residual_last": (C.c_int, [ctx, _FP]),
         "flame_nltgv2_sync_graph": (C.c_int, [ctx, C.POINTER(_SyncInput)]),
         "flame_nltgv2_get_topology": (C.c_int, [ctx, _IP, _IP, _IP]),
         "flame_nltgv2_set_feature_ids": (C.c_int, [ctx, _IP]),
@@ -447,6 +450,21 @@ class Regularizer:
         return err
 
     # ---- plumbing -------------------------------------------------------------------------------
+    def photo_fuse(self, KRKinv=None, Kt=None, graph_scale=1.0, border=3, enable=True):
+        """While enabled, every run also leaves the photometric residual of its final x on the device (config 5)."""
+        if not enable:
+            self._chk(self._L.flame_nltgv2_photo_fuse(self._ctx, None, None, C.c_float(1.0), 3, 0), "photo_fuse")
+            return
+        k = np.ascontiguousarray(KRKinv, np.float32).reshape(9)
+        t = np.ascontiguousarray(Kt, np.float32).reshape(3)
+        self._chk(self._L.flame_nltgv2_photo_fuse(self._ctx, k.ctypes.data_as(_FP), t.ctypes.data_as(_FP),
+                                                  C.c_float(graph_scale), int(border), 1), "photo_fuse")
+
+    def photo_residual_last(self) -> np.ndarray:
+        err = np.empty(self.V, np.float32)
+        self._chk(self._L.flame_nltgv2_photo_residual_last(self._ctx, err.ctypes.data_as(_FP)), "photo_residual_last")
+        return err
+
     def set_stream(self, hip_stream_ptr: int | None):
         self._chk(self._L.flame_nltgv2_set_stream(self._ctx, C.c_void_p(hip_stream_ptr or 0)), "set_stream")
 

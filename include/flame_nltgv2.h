@@ -229,6 +229,15 @@ int flame_nltgv2_photo_set_images(flame_nltgv2_ctx* ctx, const uint8_t* ref, con
                                   int step_bytes);
 int flame_nltgv2_photo_residual(flame_nltgv2_ctx* ctx, const float* KRKinv, const float* Kt, float graph_scale,
                                 int border, float* err_out);
+/* Standing form of the same residual, computed as part of the solver's own launch (BASELINE config 5: "photometric
+ * data-term residual fused into the primal step"): while enabled, every run()/run_async() leaves the residual of its
+ * final x in a device buffer -- the persistent kernels evaluate it in their epilogue, right after the last primal
+ * step, from the registers that hold x; the one-launch-per-step path appends one sweep.  It never feeds back into x.
+ * flame_nltgv2_photo_residual_last copies that buffer out (V floats, caller's vertex order; no kernel is launched).
+ * The images are those of flame_nltgv2_photo_set_images; enable = 0 switches it off. */
+int flame_nltgv2_photo_fuse(flame_nltgv2_ctx* ctx, const float* KRKinv, const float* Kt, float graph_scale, int border,
+                            int enable);
+int flame_nltgv2_photo_residual_last(flame_nltgv2_ctx* ctx, float* err_out);
 
 /* Options (flame_nltgv2_set_option). */
 enum {

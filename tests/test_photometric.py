@@ -95,3 +95,39 @@ def test_gpu_residual_matches_checker_on_1080p(built):
     assert np.array_equal(np.isnan(got), np.isnan(want))
     assert np.isfinite(want).sum() > 0.9 * g["V"]
     assert np.array_equal(got[np.isfinite(want)], want[np.isfinite(want)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,form", [("1920x1080", 1), ("1920x1080", 3), ("640x480", 2), ("640x480", 0)])
+def test_gpu_residual_fused_into_the_run(built, config, form):
+    """BASELINE config 5: the residual of the run's final x produced by the solver's own launch (epilogue of the
+    persistent kernels; one appended sweep on the per-step path) equals the stand-alone sweep and the checker."""
+    import torch  # noqa: F401
+
+    import flame_amd
+
+    g = synth.make_graph(config, seed=56)
+    cols, rows, _ = synth.CONFIGS[config]
+    ref, cmp = smooth_texture(rows, cols, 4), smooth_texture(rows, cols, 5)
+    K = np.array([[0.52 * cols, 0, cols / 2.0], [0, 0.52 * cols, rows / 2.0], [0, 0, 1]], np.float64)
+    KRKinv, Kt = geometry(K, _rot_y(0.008), np.array([0.04, -0.01, 0.003]))
+    p = flame_amd.Params()
+    with flame_amd.Regularizer(0) as reg:
+        reg.set_option(5, form)
+        reg.upload_graph(g)
+        reg.photo_set_images(ref, cmp)
+        reg.photo_fuse(KRKinv, Kt, graph_scale=1.1, border=4)
+        for n in (40, 7):
+            reg.run(p, n)
+            fused = reg.photo_residual_last()
+            x = reg.download_state(("x",))["x"]
+            want = oracle.photo_residual(g["pos"], x, 1.1, KRKinv, Kt, ref, cmp, 4)
+            assert np.array_equal(np.isnan(fused), np.isnan(want)) and np.isfinite(want).sum() > 0.9 * g["V"]
+            assert np.array_equal(fused[np.isfinite(want)], want[np.isfinite(want)]), (config, form, n)
+            sweep = reg.photo_residual(KRKinv, Kt, graph_scale=1.1, border=4)
+            assert np.array_equal(np.nan_to_num(sweep, nan=-1.0), np.nan_to_num(fused, nan=-1.0))
+        path = reg.info()["last_run_path"]
+        assert (path in (1, 5)) == (form != 0)
+        reg.photo_fuse(enable=False)
+        with pytest.raises(flame_amd.NLTGV2Error):
+            reg.photo_residual_last()
