@@ -378,6 +378,29 @@ def test_oracle_unknown_frame_and_assert_paths():
     assert rc == -(1 + 5)
 
 
+# ---- golden fixture (freezes the checker; generator: oracle/make_golden_stereo.py) -----------------------------------
+
+
+def _load_golden():
+    import os
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stereo_160x120_s31.npz"))
+    poses = [dict(id=int(i), q_to_new=z["q_to_new"][k], t_to_new=z["t_to_new"][k], q_to_pf=z["q_to_pf"][k], t_to_pf=z["t_to_pf"][k])
+             for k, i in enumerate(z["pose_ids"])]
+    imgs = {10: z["img10"], 11: z["img11"], 12: z["img12"]}
+    return z, poses, imgs
+
+
+def test_checker_reproduces_the_golden_fixture():
+    z, poses, imgs = _load_golden()
+    w, h, pad = int(z["width"]), int(z["height"]), int(z["pad"])
+    feats = np.ascontiguousarray(z["feats_in"]).view(so.FEATURE_DTYPE).reshape(-1).copy()
+    frames = [dict(p, img_pad=so.make_frame(imgs[p["id"]], pad)[0]) for p in poses]
+    rc, stats = so.update_feature_idepths(so.Params(), z["K"], z["Kinv"], w, h, pad, frames, so.make_frame(imgs[12], pad), 11, feats)
+    assert rc == 0 and np.array_equal(stats, z["stats"])
+    assert feats.view(np.uint8).reshape(-1, 40).tobytes() == z["feats_out"].tobytes()
+
+
 # ---- GPU parity: the HIP path through the C-ABI against the oracle, bit for bit ---------------------------------
 
 gpu = pytest.mark.gpu
@@ -416,6 +439,21 @@ def _assert_same(sc, imgs, feats, poses, **pkw):
                 raise AssertionError("%s differs on %d features, first %d: gpu %r oracle %r (input %r)"
                                      % (name, bad.size, i, a[i], b[i], feats[i]))
     return st_o, out_o
+
+
+@gpu
+def test_gpu_reproduces_the_golden_fixture(built):
+    from flame_amd.stereo import FEATURE_DTYPE, FeatureTracker
+
+    z, poses, imgs = _load_golden()
+    w, h, pad = int(z["width"]), int(z["height"]), int(z["pad"])
+    feats = np.ascontiguousarray(z["feats_in"]).view(FEATURE_DTYPE).reshape(-1).copy()
+    with FeatureTracker(z["K"], z["Kinv"], w, h, border=pad) as tr:
+        for fid, img in imgs.items():
+            tr.add_frame(fid, img)
+        rc, st = tr.update_feature_idepths(_product_params(), 12, 11, poses, feats)
+    assert rc == 0 and st["num_idepth_updates"] == int(z["stats"][0]) and st["num_fail_max_cost"] == int(z["stats"][5])
+    assert feats.view(np.uint8).reshape(-1, 40).tobytes() == z["feats_out"].tobytes()
 
 
 @gpu
