@@ -476,3 +476,47 @@ def test_run_timed_and_info(env):
     assert info["V"] == g["V"] and info["E"] == g["E"]
     assert info["algorithmic_bytes_per_iter"] == 64 * g["V"] + 40 * g["E"]
     assert "gfx950" in info["gcn_arch"]
+
+
+@pytest.mark.parametrize("trial", range(8))
+def test_randomized_run_sequences(env, trial):
+    """Random graphs, parameters, run lengths and option changes between runs (persistent forms, per-step path,
+    canonical sweeps, state edits in between): the device state must track the checker bit for bit throughout."""
+    import torch
+
+    flame_amd, oracle = env
+    rng = np.random.default_rng(400 + trial)
+    if trial % 2:
+        g = synth.make_graph(["320x240", "640x480"][trial % 4 // 2], seed=900 + trial)
+    else:
+        g = random_graph(int(rng.integers(50, 3000)), int(rng.integers(100, 9000)), seed=900 + trial)
+    ref = synth.copy_graph(g)
+    kw = dict(data_factor=float(rng.uniform(0.02, 0.5)), step_x=float(rng.uniform(2e-4, 5e-3)), step_q=float(rng.uniform(20, 300)),
+              theta=float(rng.uniform(0.0, 1.0)), x_min=0.0, x_max=float(rng.uniform(2.0, 10.0)))
+    p, rp = flame_amd.Params(**kw), oracle.make_params(**kw)
+    buf = torch.zeros(g["V"], dtype=torch.float32, device="cuda")
+    with flame_amd.Regularizer(0) as reg:
+        reg.upload_graph(g)
+        reg.set_export_target(buf.data_ptr(), 2.0)
+        for step in range(12):
+            form = int(rng.choice([0, 1, 2, 3]))
+            reg.set_option(5, form)
+            reg.set_option(1, int(rng.random() < 0.15))      # canonical four-sweep path now and then
+            reg.set_option(6, int(rng.choice([0, 1, 2])))
+            reg.set_option(7, int(rng.choice([0, 1, 2])))
+            n = int(rng.choice([1, 2, 3, 5, 8, 13, 40, 120]))
+            reg.run(p, n)
+            assert oracle.run(ref, n, rp) == 0
+            if rng.random() < 0.3:                            # the caller edits the data term between runs
+                ref["data_term"] = (ref["data_term"] * np.float32(rng.uniform(0.95, 1.05))).astype(np.float32)
+                ref["data_weight"] = (0.5 + rng.random(g["V"])).astype(np.float32)
+                reg.update_data(ref["data_term"], ref["data_weight"])
+            if step % 4 == 3:
+                assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"trial {trial} step {step}")
+                torch.cuda.synchronize()
+        assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"trial {trial} end")
+        torch.cuda.synchronize()
+        assert np.array_equal(buf.cpu().numpy(), ref["x"] * np.float32(2.0))  # the standing export target followed every path
+        sm, dc = reg.costs(p)
+        rs, rd = oracle.costs(ref, rp)
+        assert np.float32(sm) == np.float32(rs) and np.float32(dc) == np.float32(rd)
