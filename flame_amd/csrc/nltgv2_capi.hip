@@ -103,6 +103,9 @@ struct flame_nltgv2_ctx {
   // packed
   DevBuf slice_row, perm, pdeg, rec_nbr, rec_edge, edge_src_slot, hrec, hq, vstate, vaux, bar0, bar1, vprev;
   DevBuf cost_terms;          // addends of smoothnessCost / dataCost
+  DevBuf run_tail;            // RunTail of the persistent kernels (standing export / photometric targets)
+  RunTail tail_sent{};        // what run_tail currently holds
+  bool tail_valid = false;
   std::vector<float> h_terms;
   DevBuf hq_alt, vstate_alt;  // the other copies of hq / vstate: a persistent run writes there, success swaps the roles
   DevBuf xbuf, abort_flag, he_slot, he_vid, he_meta, he_wave_chain, tv_slot, tv_vid, tv_meta, tv_wave;
@@ -413,6 +416,8 @@ int prepare_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
 
 PhotoFuse photo_target(const flame_nltgv2_ctx* ctx) {
   PhotoFuse f;
+  std::memset(static_cast<void*>(&f), 0, sizeof f);  // padding too: the block is compared bytewise before it is re-sent
+  f.graph_scale = 1.0f;
   if (!ctx->photo_fused || ctx->img_rows == 0) return f;
   f.pos = (const float2*)ctx->pos.p;
   f.ref = (const uint8_t*)ctx->img_ref.p, f.cmp = (const uint8_t*)ctx->img_cmp.p;
@@ -471,6 +476,21 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
     // by per-step launches or host uploads) can never satisfy a wait of this one
     const uint32_t tag0 = ctx->tag_next + 2;
     const uint64_t key = ctx->topo * 8 + (uint64_t)form * 2 + (uint64_t)tv_lds;
+    {  // standing outputs: (re)send the small block the kernels read in their epilogue when it changed
+      RunTail want;
+      std::memset(static_cast<void*>(&want), 0, sizeof want);
+      want.export_out = ctx->export_ptr, want.export_scale = ctx->export_scale;
+      const PhotoFuse pf = photo_target(ctx);
+      std::memcpy(static_cast<void*>(&want.photo), &pf, sizeof pf);
+      rc = ensure(ctx, ctx->run_tail, sizeof(RunTail));
+      if (rc) return rc;
+      if (!ctx->tail_valid || std::memcmp(&want, &ctx->tail_sent, sizeof(RunTail)) != 0) {
+        // pageable source: the runtime stages it during the call, so `want` may go out of scope
+        HIPCHK(ctx, hipMemcpyAsync(ctx->run_tail.p, &want, sizeof(RunTail), hipMemcpyHostToDevice, ctx->stream));
+        ctx->tail_sent = want;
+        ctx->tail_valid = true;
+      }
+    }
     int e = 0;
     for (const WaveGroup& gr : groups) {
       const int pw = gr.count <= 4 * ctx->prop.multiProcessorCount ? 1 : 4;  // waves per workgroup
@@ -489,8 +509,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
                                                                             : kPreSleepHe;
       const unsigned spins_arg = ctx->opt_fault > 0 ? (0x80000000u | (unsigned)ctx->opt_fault) : kMaxSpins;
       e = launch_persistent_run(ctx->f, to_sp(p), form, gr.begin, gr.count, ctx->parity, tag0, n, pw, spins_arg, presleep, dual,
-                                tv_lds, xcds, ctx->export_ptr, ctx->export_scale, photo_target(ctx), ctx->coop_checked_key != key,
-                                ctx->stream);
+                                tv_lds, xcds, (const RunTail*)ctx->run_tail.p, ctx->coop_checked_key != key, ctx->stream);
       if (e != 0) break;
     }
     ctx->tag_next = tag0 + (uint32_t)n;
@@ -673,7 +692,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
   ctx->all = {&ctx->pos, &ctx->x, &ctx->w1, &ctx->w2, &ctx->xb, &ctx->w1b, &ctx->w2b, &ctx->xp, &ctx->w1p,
               &ctx->w2p, &ctx->data, &ctx->weight, &ctx->src, &ctx->dst, &ctx->alpha, &ctx->beta, &ctx->q1,
               &ctx->q2, &ctx->q3, &ctx->row_ptr, &ctx->half, &ctx->slice_row, &ctx->perm, &ctx->pdeg,
-              &ctx->rec_nbr, &ctx->rec_edge, &ctx->edge_src_slot, &ctx->hrec, &ctx->hq, &ctx->vstate, &ctx->hq_alt, &ctx->vstate_alt, &ctx->cost_terms,
+              &ctx->rec_nbr, &ctx->rec_edge, &ctx->edge_src_slot, &ctx->hrec, &ctx->hq, &ctx->vstate, &ctx->hq_alt, &ctx->vstate_alt, &ctx->cost_terms, &ctx->run_tail,
               &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->xbuf, &ctx->abort_flag, &ctx->he_slot, &ctx->he_vid, &ctx->he_meta, &ctx->he_wave_chain, &ctx->tv_slot, &ctx->tv_vid, &ctx->tv_meta, &ctx->tv_wave, &ctx->err,
               &ctx->cost_out, &ctx->img_ref, &ctx->img_cmp, &ctx->photo_err, &ctx->r_tris, &ctx->r_valid, &ctx->r_keys,
               &ctx->r_img, &ctx->r_cov, &ctx->r_vtx, &ctx->r_val};

@@ -29,6 +29,14 @@ struct PhotoFuse {
   int rows = 0, cols = 0, step = 0, border = 0;
 };
 
+// Standing outputs of a persistent run, read once in the kernels' epilogue from device memory.
+struct RunTail {
+  float* export_out = nullptr;  // flame_nltgv2_set_export_target (nullptr: off)
+  float export_scale = 1.0f;
+  int reserved_ = 0;
+  PhotoFuse photo;              // flame_nltgv2_photo_fuse (photo.err == nullptr: off)
+};
+
 // Everything EpipolarGeometry::project(u, idepth, &u_new, &idepth_new) reads (stereo/epipolar_geometry.h:152-180)
 // plus the valid region of Flame::projectGraph (flame.cc:1881-1884).
 struct ProjectGeometry {
@@ -91,8 +99,8 @@ int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, boo
                       int waves_per_block, hipStream_t stream);
 int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, int wave_begin, int n_waves,
                           int parity_in, unsigned tag0, int n_iters, int waves_per_block, unsigned max_spins,
-                          int presleep, int dual, int tv_static_in_lds, int xcds, float* export_out, float export_scale,
-                          const PhotoFuse& photo, bool cooperative, hipStream_t stream);
+                          int presleep, int dual, int tv_static_in_lds, int xcds, const RunTail* tail, bool cooperative,
+                          hipStream_t stream);
 int launch_save_prev(const CanonArgs& c, hipStream_t s);
 int launch_dual(const CanonArgs& c, const SolverParams& p, hipStream_t s);
 int launch_primal(const CanonArgs& c, const SolverParams& p, hipStream_t s);

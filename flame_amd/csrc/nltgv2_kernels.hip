@@ -301,8 +301,7 @@ k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd
                 float4* hq_out, float4* vstate_out, const float2* vaux, const float4* bar_in, float4* bar_out,
                 float4* vprev, void* xbuf, const int rec_bytes, const int dual, const unsigned tag0, const int n_iters,
                 const unsigned max_spins_arg, const int presleep, const SolverParams p, int* __restrict__ err,
-                int* __restrict__ abort_flag, const int32_t* __restrict__ perm, float* __restrict__ export_out,
-                const float export_scale, const PhotoFuse photo) {
+                int* __restrict__ abort_flag, const int32_t* __restrict__ perm, const RunTail* __restrict__ tail) {
   const unsigned max_spins = max_spins_arg & 0x7fffffffu;
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
@@ -513,14 +512,19 @@ k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd
     vstate_out[pv] = make_float4(x, w1, w2, data);
     bar_out[pv] = make_float4(xb, w1b, w2b, 0.0f);
     vprev[pv] = make_float4(x_prev, w1_prev, w2_prev, 0.0f);
-    if (export_out || photo.err) {
+    // Standing outputs of a run (kept in device memory rather than in the argument list: they are read once, here).
+    float* const export_out = tail->export_out;
+    float* const photo_err = tail->photo.err;
+    if (export_out || photo_err) {
       const int o = perm[pv];  // the caller's vertex index
       // flame_nltgv2_set_export_target: x * graph_scale in the caller's vertex order (flame.cc:372-380)
-      if (o >= 0 && export_out) export_out[o] = x * export_scale;
+      if (o >= 0 && export_out) export_out[o] = x * tail->export_scale;
       // flame_nltgv2_photo_fuse: the photometric residual of the final x, in the same launch (config 5)
-      if (o >= 0 && photo.err)
-        photo.err[o] = photo_residual_at(photo.pos[o], x * photo.graph_scale, photo.geo, photo.ref, photo.cmp, photo.rows,
+      if (o >= 0 && photo_err) {
+        const PhotoFuse& photo = tail->photo;
+        photo_err[o] = photo_residual_at(photo.pos[o], x * photo.graph_scale, photo.geo, photo.ref, photo.cmp, photo.rows,
                                          photo.cols, photo.step, photo.border);
+      }
     }
   }
   if (active) hq_out[slot] = make_float4(q1, q2, q3, beta);
@@ -557,8 +561,7 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
                 float4* hq_out, float4* vstate_out, const float2* vaux, const float4* bar_in, float4* bar_out,
                 float4* vprev, void* xbuf, const int rec_bytes, const int dual, const unsigned tag0, const int n_iters,
                 const unsigned max_spins_arg, const int presleep, const SolverParams p, int* __restrict__ err,
-                int* __restrict__ abort_flag, const int32_t* __restrict__ perm, float* __restrict__ export_out,
-                const float export_scale, const PhotoFuse photo) {
+                int* __restrict__ abort_flag, const int32_t* __restrict__ perm, const RunTail* __restrict__ tail) {
   const unsigned max_spins = max_spins_arg & 0x7fffffffu;
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
@@ -792,12 +795,16 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
     vstate_out[pv] = make_float4(x, w1, w2, data);
     bar_out[pv] = make_float4(xb, w1b, w2b, 0.0f);
     vprev[pv] = make_float4(x_prev, w1_prev, w2_prev, 0.0f);
-    if (export_out || photo.err) {
+    float* const export_out = tail->export_out;
+    float* const photo_err = tail->photo.err;
+    if (export_out || photo_err) {
       const int o = perm[pv];
-      if (o >= 0 && export_out) export_out[o] = x * export_scale;
-      if (o >= 0 && photo.err)
-        photo.err[o] = photo_residual_at(photo.pos[o], x * photo.graph_scale, photo.geo, photo.ref, photo.cmp, photo.rows,
+      if (o >= 0 && export_out) export_out[o] = x * tail->export_scale;
+      if (o >= 0 && photo_err) {
+        const PhotoFuse& photo = tail->photo;
+        photo_err[o] = photo_residual_at(photo.pos[o], x * photo.graph_scale, photo.geo, photo.ref, photo.cmp, photo.rows,
                                          photo.cols, photo.step, photo.border);
+      }
     }
   }
 #pragma unroll
@@ -1200,8 +1207,8 @@ int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, boo
 // so the caller can fall back to per-step launches.
 int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, int wave_begin, int n_waves,
                           int parity_in, unsigned tag0, int n_iters, int waves_per_block, unsigned max_spins,
-                          int presleep, int dual, int tv_static_in_lds, int xcds, float* export_out, float export_scale,
-                          const PhotoFuse& photo_in, bool cooperative, hipStream_t stream) {
+                          int presleep, int dual, int tv_static_in_lds, int xcds, const RunTail* tail, bool cooperative,
+                          hipStream_t stream) {
   if (n_waves <= 0 || n_iters <= 0) return (int)hipSuccess;
   // Workgroup b runs on XCD b & 7.  With xcds < 8 only the first `xcds` XCDs get waves (the workgroups of the
   // others find no work and exit), which keeps a small graph's whole exchange inside fewer L2s.
@@ -1228,10 +1235,9 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
   int* err = a.err;
   int* abort_flag = a.abort_flag;
   const int32_t* perm = a.perm;
-  PhotoFuse photo = photo_in;
   void* args[] = {&wave_begin, &n_waves, &wpx, &i0, &i1, &i2, &i3, &hrec, &hq, &vstate, &hq_out, &vstate_out, &vaux,
                   &bin, &bout, &vprev, &xbuf, &rec_bytes, &dual, &tag0, &n_iters, &max_spins, &presleep, &pp, &err,
-                  &abort_flag, &perm, &export_out, &export_scale, &photo};
+                  &abort_flag, &perm, &tail};
   const bool tv_lds = form == 2 && (tv_static_in_lds != 0);
   const void* fn = (form == 2) ? (tv_lds ? (const void*)k_persistent_tv<true> : (const void*)k_persistent_tv<false>)
                                : (const void*)k_persistent_he;
