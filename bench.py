@@ -443,8 +443,8 @@ def feature_update(a, w_, h_):
     res = {"features": n, "image": f"{w_}x{h_}", "updated": st["num_idepth_updates"], "kernel_us": round(k_ms * 1e3, 2),
            "host_call_us": round(c_s * 1e6, 1), "frame_create_us": round(t_frame * 1e6, 1),
            "features_per_s_kernel": round(n / (k_ms * 1e-3), 0),
-           "note": "latency-bound: one lane per feature walks ~40 dependent 4-byte bilinear samples of L2-resident "
-                   "images; 80 B of HBM traffic per feature"}
+           "note": "bound by the serial instruction chain of a lane (one lane per feature, ~2800 dependent instructions; "
+                   "images L2-resident, 80 B of HBM traffic per feature)"}
     if not a.no_cpu_baseline:
         from oracle import stereo_capi as so
 
