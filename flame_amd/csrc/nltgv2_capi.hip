@@ -30,6 +30,7 @@ constexpr int kGraphChunk = 256;      // steps per captured hipGraph (even: keep
 constexpr int kMaxCachedGraphs = 6;
 constexpr int kHeWavesPerCu = 24;      // residency cap of k_persistent_he (<= 64 VGPRs: the hardware admits 32)
 constexpr int kTvLdsWavesPerCu = 16;   // ... with the slot constants in LDS (<= 128 VGPRs -> 4 waves per SIMD; 10 KB LDS per wave = all 160 KB)
+constexpr int kWgWavesPerCu = 24;      // residency cap of k_persistent_wg (<= 64 VGPRs; its LDS use is a few KB per workgroup)
 constexpr int kTvWavesPerCu = 8;       // residency of k_persistent_tv (<= 256 VGPRs -> 2 waves per SIMD)
 constexpr int kDualMinWavesPerCu = 0;  // auto: exchange through the XCD's L2 when more waves than this share a CU
 // x64-cycle sleep between publishing and the first neighbour poll (measured optimum, r01 sweep: he 6 at
@@ -76,6 +77,9 @@ struct flame_nltgv2_ctx {
   float export_scale = 1.0f;
   int opt_fault = 0;     // test hook: > 0 = the next persistent runs time out after this many spins
   int opt_presleep = 0;  // 0: auto (kPreSleep*); n > 0: (n - 1) x 64 cycles
+  int opt_wg_waves = 4;  // waves per workgroup of the patch-per-workgroup form (layout (E); applies at the next upload)
+  int opt_probe = 0;     // > 0: k_persistent_wg records a per-wave, per-step cycle probe (flame_nltgv2_read_probe)
+  size_t probe_words = 0;
   int opt_tv_lds = 1;  // 0 registers, 1 auto (LDS when the register form is not resident in one launch), 2 LDS
   uint32_t tag_next = 1;  // persistent run: tag of the current bar values (monotonic)
   int last_run_path = 0, last_run_groups = 0;
@@ -109,6 +113,7 @@ struct flame_nltgv2_ctx {
   std::vector<float> h_terms;
   DevBuf hq_alt, vstate_alt;  // the other copies of hq / vstate: a persistent run writes there, success swaps the roles
   DevBuf xbuf, abort_flag, he_slot, he_vid, he_meta, he_wave_chain, tv_slot, tv_vid, tv_meta, tv_wave;
+  DevBuf wg_slot, wg_vid, wg_meta, wg_nbr, wg_fetch, wg_info, wg_wave_chain, probe;
   // misc
   DevBuf err, cost_out, img_ref, img_cmp, photo_err, r_tris, r_valid, r_keys, r_img, r_cov, r_vtx, r_val;
   int img_rows = 0, img_cols = 0, img_step = 0;
@@ -213,6 +218,11 @@ void refresh_args(flame_nltgv2_ctx* ctx) {
   f.tv_waves = ctx->L.tv_ok ? ctx->L.tv_waves : 0;
   f.tv_slot = (int32_t*)ctx->tv_slot.p, f.tv_vid = (int32_t*)ctx->tv_vid.p;
   f.tv_meta = (uint32_t*)ctx->tv_meta.p, f.tv_wave = (uint32_t*)ctx->tv_wave.p;
+  f.wg_count = ctx->L.wg_ok ? ctx->L.wg_count : 0;
+  f.wg_waves = ctx->L.wg_waves, f.wg_lcap = ctx->L.wg_lcap, f.wg_rcap = ctx->L.wg_rcap;
+  f.wg_slot = (int32_t*)ctx->wg_slot.p, f.wg_vid = (int32_t*)ctx->wg_vid.p, f.wg_meta = (uint32_t*)ctx->wg_meta.p;
+  f.wg_nbr = (int32_t*)ctx->wg_nbr.p, f.wg_fetch = (int32_t*)ctx->wg_fetch.p, f.wg_info = (int32_t*)ctx->wg_info.p;
+  f.wg_wave_chain = (int32_t*)ctx->wg_wave_chain.p;
   f.abort_flag = (int*)ctx->abort_flag.p;
   f.err = (int*)ctx->err.p;
 }
@@ -280,25 +290,28 @@ int plan_persistent(const flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* 
   const bool tv_lds = ctx->opt_tv_lds == 2 || (ctx->opt_tv_lds == 1 && L.tv_waves > kTvWavesPerCu * cus);
   const int he_cap = kHeWavesPerCu * cus, tv_cap = (tv_lds ? kTvLdsWavesPerCu : kTvWavesPerCu) * cus;
   if (use_tv_lds) *use_tv_lds = tv_lds ? 1 : 0;
+  const int wg_cap = (kWgWavesPerCu / std::max(1, L.wg_waves)) * cus;  // in workgroups
   const bool he_fits = L.he_ok && L.he_waves > 0 && L.he_waves <= he_cap;
   const bool tv_fits = L.tv_ok && L.tv_waves > 0 && L.tv_waves <= tv_cap;
   if (ctx->opt_persistent == 2 && !L.he_ok) return 0;
   if (ctx->opt_persistent == 3 && !L.tv_ok) return 0;
+  if (ctx->opt_persistent == 4 && !L.wg_ok) return 0;
   int form = 0;
-  if (ctx->opt_persistent == 2) form = 1;
+  if (ctx->opt_persistent == 4) form = 3;
+  else if (ctx->opt_persistent == 2) form = 1;
   else if (ctx->opt_persistent == 3) form = 2;
   else if (he_fits) form = 1;
   else if (tv_fits) form = 2;
   else form = L.tv_ok ? 2 : (L.he_ok ? 1 : 0);  // too big for one launch: vertex-per-lane groups
   if (form == 0) return 0;
-  const int total = form == 2 ? L.tv_waves : L.he_waves;
-  const int cap = form == 2 ? tv_cap : he_cap;
+  const int total = form == 3 ? L.wg_count : form == 2 ? L.tv_waves : L.he_waves;
+  const int cap = form == 3 ? wg_cap : form == 2 ? tv_cap : he_cap;
   if (total <= 0) return 0;
   if (total <= cap) {
     groups->push_back(WaveGroup{0, total});
     return form;
   }
-  const std::vector<int32_t>& cw = form == 2 ? L.comp_tv_wave : L.comp_he_wave;
+  const std::vector<int32_t>& cw = form == 3 ? L.comp_wg : form == 2 ? L.comp_tv_wave : L.comp_he_wave;
   if (cw.size() < 3) return 0;  // one component that does not fit: stream it
   // Groups of about equal size (the per-step time of a group grows with its waves, and a small last group would run
   // at low occupancy): cut at the component boundaries nearest to k * total / n_groups, never beyond what the chip
@@ -501,13 +514,24 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       // stays in that XCD's L2 (measured 320x240: 1.23 instead of 1.47 us per step; at 640x480 the 26 waves per CU
       // this would need cost more than the shorter hop saves).
       const int cus_per_xcd = ctx->prop.multiProcessorCount / 8;
-      const int xcds = ctx->opt_xcds > 0 ? ctx->opt_xcds : (form == 1 && gr.count <= 8 * cus_per_xcd) ? 1 : 8;
+      const int unit = form == 3 ? ctx->L.wg_waves : 1;  // waves per launch unit
+      const int xcds = ctx->opt_xcds > 0 ? ctx->opt_xcds : (form != 2 && gr.count * unit <= 8 * cus_per_xcd) ? 1 : 8;
       const int presleep = ctx->opt_presleep > 0 ? ctx->opt_presleep - 1
                            : form == 2                ? kPreSleepTv
                            : xcds == 1                ? kPreSleepHeOneXcd
-                           : gr.count > 12 * ctx->prop.multiProcessorCount ? kPreSleepHeDense
+                           : gr.count * unit > 12 * ctx->prop.multiProcessorCount ? kPreSleepHeDense
                                                                             : kPreSleepHe;
       const unsigned spins_arg = ctx->opt_fault > 0 ? (0x80000000u | (unsigned)ctx->opt_fault) : kMaxSpins;
+      if (form == 3) {
+        ctx->f.probe = nullptr;
+        if (ctx->opt_probe) {
+          const size_t words = (size_t)ctx->L.wg_count * ctx->L.wg_waves * (size_t)n * 8;
+          rc = ensure(ctx, ctx->probe, words * sizeof(unsigned));
+          if (rc) return rc;
+          ctx->f.probe = (unsigned*)ctx->probe.p;
+          ctx->probe_words = words;
+        }
+      }
       e = launch_persistent_run(ctx->f, to_sp(p), form, gr.begin, gr.count, ctx->parity, tag0, n, pw, spins_arg, presleep, dual,
                                 tv_lds, xcds, (const RunTail*)ctx->run_tail.p, ctx->coop_checked_key != key, ctx->stream);
       if (e != 0) break;
@@ -528,7 +552,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       ctx->buf_gen ^= 1;
       refresh_args(ctx);
       ctx->coop_checked_key = key;
-      ctx->last_run_path = form == 2 ? 5 : 1;
+      ctx->last_run_path = form == 3 ? 6 : form == 2 ? 5 : 1;
       ctx->last_run_groups = (int)groups.size();
       ctx->parity ^= 1;
       ctx->have_prev = true;
@@ -739,8 +763,15 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
       ctx->opt_block_waves = value;
       return 0;
     case FLAME_NLTGV2_OPT_PERSISTENT:
-      if (value < 0 || value > 3) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      if (value < 0 || value > 4) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_persistent = value;
+      return 0;
+    case FLAME_NLTGV2_OPT_WG_WAVES:
+      if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_wg_waves = value;
+      return 0;
+    case FLAME_NLTGV2_OPT_PROBE:
+      ctx->opt_probe = value ? 1 : 0;
       return 0;
     case FLAME_NLTGV2_OPT_DUAL_PUBLISH:
       if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
@@ -787,7 +818,7 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
   ctx->have_graph = false;
   const bool trace = std::getenv("FLAME_NLTGV2_TRACE") != nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
-  rc = build_layout(g, &ctx->L);
+  rc = build_layout(g, &ctx->L, ctx->opt_wg_waves);
   if (rc) return fail(ctx, rc);
   const auto t_packed = std::chrono::steady_clock::now();
   const PackedLayout& L = ctx->L;
@@ -816,6 +847,10 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
       {&ctx->he_wave_chain, sizeof(int32_t) * L.he_wave_chain.size()},
       {&ctx->tv_slot, sizeof(int32_t) * L.tv_slot.size()}, {&ctx->tv_vid, sizeof(int32_t) * L.tv_vid.size()},
       {&ctx->tv_meta, sizeof(uint32_t) * L.tv_meta.size()}, {&ctx->tv_wave, sizeof(uint32_t) * L.tv_wave.size()},
+      {&ctx->wg_slot, sizeof(int32_t) * L.wg_slot.size()}, {&ctx->wg_vid, sizeof(int32_t) * L.wg_vid.size()},
+      {&ctx->wg_meta, sizeof(uint32_t) * L.wg_meta.size()}, {&ctx->wg_nbr, sizeof(int32_t) * L.wg_nbr.size()},
+      {&ctx->wg_fetch, sizeof(int32_t) * L.wg_fetch.size()}, {&ctx->wg_info, sizeof(int32_t) * L.wg_info.size()},
+      {&ctx->wg_wave_chain, sizeof(int32_t) * L.wg_wave_chain.size()},
       {&ctx->err, sizeof(int)},
       {&ctx->cost_out, 2 * sizeof(float)}};
   for (auto& r : req) {
@@ -848,7 +883,14 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
       {&ctx->tv_slot, L.tv_slot.data(), sizeof(int32_t) * L.tv_slot.size()},
       {&ctx->tv_vid, L.tv_vid.data(), sizeof(int32_t) * L.tv_vid.size()},
       {&ctx->tv_meta, L.tv_meta.data(), sizeof(uint32_t) * L.tv_meta.size()},
-      {&ctx->tv_wave, L.tv_wave.data(), sizeof(uint32_t) * L.tv_wave.size()}};
+      {&ctx->tv_wave, L.tv_wave.data(), sizeof(uint32_t) * L.tv_wave.size()},
+      {&ctx->wg_slot, L.wg_slot.data(), sizeof(int32_t) * L.wg_slot.size()},
+      {&ctx->wg_vid, L.wg_vid.data(), sizeof(int32_t) * L.wg_vid.size()},
+      {&ctx->wg_meta, L.wg_meta.data(), sizeof(uint32_t) * L.wg_meta.size()},
+      {&ctx->wg_nbr, L.wg_nbr.data(), sizeof(int32_t) * L.wg_nbr.size()},
+      {&ctx->wg_fetch, L.wg_fetch.data(), sizeof(int32_t) * L.wg_fetch.size()},
+      {&ctx->wg_info, L.wg_info.data(), sizeof(int32_t) * L.wg_info.size()},
+      {&ctx->wg_wave_chain, L.wg_wave_chain.data(), sizeof(int32_t) * L.wg_wave_chain.size()}};
   for (auto& c : cp) {
     if (rc) return rc;
     rc = h2d(ctx, *c.b, c.src, c.bytes);
@@ -1457,6 +1499,23 @@ int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info) {
 
 int flame_nltgv2_last_error(flame_nltgv2_ctx* ctx) { return ctx ? ctx->last_error : FLAME_NLTGV2_ERR_INVALID_ARG; }
 int flame_nltgv2_last_hip_error(flame_nltgv2_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
+
+int flame_nltgv2_read_probe(flame_nltgv2_ctx* ctx, uint32_t* out, int64_t max_words, int64_t* n_words) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (ctx->pending.active) {
+    rc = finish(ctx);
+    if (rc) return rc;
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const int64_t have = (int64_t)ctx->probe_words;
+  if (n_words) *n_words = have;
+  if (out && ctx->probe.p) {
+    const int64_t n = std::min(have, max_words);
+    if (n > 0) HIPCHK(ctx, hipMemcpy(out, ctx->probe.p, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
+  }
+  return FLAME_NLTGV2_OK;
+}
 
 int flame_nltgv2_pack_probe(const flame_nltgv2_graph* g, int32_t* perm, int32_t* slice_row, int32_t* rec_nbr,
                             int32_t* rec_edge, int64_t capacity_rows, int64_t* rows_out) {

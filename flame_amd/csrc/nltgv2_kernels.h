@@ -91,6 +91,15 @@ struct FusedArgs {
   int32_t* tv_vid = nullptr;
   uint32_t* tv_meta = nullptr;
   uint32_t* tv_wave = nullptr;
+  int wg_count = 0, wg_waves = 0, wg_lcap = 0, wg_rcap = 0;  // persistent run, patch-per-workgroup rows (nltgv2_pack.hpp (E))
+  int32_t* wg_slot = nullptr;
+  int32_t* wg_vid = nullptr;
+  uint32_t* wg_meta = nullptr;
+  int32_t* wg_nbr = nullptr;
+  int32_t* wg_fetch = nullptr;
+  int32_t* wg_info = nullptr;
+  int32_t* wg_wave_chain = nullptr;
+  unsigned* probe = nullptr;           // optional per-wave, per-step cycle probe of k_persistent_wg (tools/probe_wg.py)
   int* abort_flag = nullptr;
   int* err = nullptr;
 };

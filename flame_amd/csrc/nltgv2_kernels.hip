@@ -532,6 +532,316 @@ k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd
 }
 
 // ------------------------------------------------------------------------------------------------
+// Persistent run, patch-per-workgroup form ("wg"): the lane-per-half-edge arithmetic of k_persistent_he, but the
+// exchange is organised around what bounds a step on this chip -- the NUMBER of memory-side requests per step and the
+// length of the dependent chain between a record arriving and the next one leaving:
+//
+//   * a workgroup (blockDim/64 waves on one CU) owns a compact Morton patch of vertices.  Neighbours inside the patch
+//     exchange their records through LDS (two parity areas, one workgroup barrier per step); a vertex is published to
+//     memory only if it has a neighbour in another patch.
+//   * every DISTINCT foreign record a patch needs is fetched by exactly one polling lane (sorted by record id, records
+//     numbered in walk order, so a producer's records share cache lines) and handed to the half-edge lanes through
+//     LDS: a 640x480 graph issues ~7 k polls per step instead of one per half-edge (~51 k).
+//   * the ordered accumulation (cc:120-142: ascending edge id) is done by EVERY lane of the vertex from the
+//     contributions its lanes left in LDS -- (W + a) + b in exactly the reference's order -- so there is no DPP ripple
+//     and no hand-back: all lanes of a vertex hold bit-identical state at all times.
+//
+// Protocol (tags, two parity buffers, remote/local copies, XCC table, bounded waits, transactional outputs) is that of
+// k_persistent_he.  LDS: [rec par0: lcap local + rcap fetched | rec par1 | contributions (T+kWgPad) x {cx,a1,a2,b1} |
+// (T+kWgPad) x b2]; the pad lets the batched contribution reads run past a vertex's last lane without a bounds test.
+// ------------------------------------------------------------------------------------------------
+constexpr int kWgPad = 80;
+constexpr unsigned kWgTailBit = 1u << 24, kWgActiveBit = 1u << 25, kWgValidBit = 1u << 26, kWgPublishBit = 1u << 27;
+
+__device__ __forceinline__ void lds_wave_sync() {  // LDS operations of one wave are processed in issue order
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void lds_wg_barrier() {  // no vmcnt wait: a step's publish stores stay in flight
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <bool PROBE>
+__global__ void __launch_bounds__(1024)
+k_persistent_wg(const int wg_begin, const int n_wgs, const int wgs_per_xcd, const int lcap, const int rcap,
+                const int32_t* __restrict__ wg_slot, const int32_t* __restrict__ wg_vid,
+                const uint32_t* __restrict__ wg_meta, const int32_t* __restrict__ wg_nbr,
+                const int32_t* __restrict__ wg_fetch, const int32_t* __restrict__ wg_info,
+                const int32_t* __restrict__ wg_wave_chain, const int4* hrec, const float4* hq, const float4* vstate,
+                float4* hq_out, float4* vstate_out, const float2* vaux, const float4* bar_in, float4* bar_out, float4* vprev,
+                void* xbuf, const int rec_bytes, const int dual, const unsigned tag0, const int n_iters,
+                const unsigned max_spins_arg, const int presleep, const SolverParams p, int* __restrict__ err,
+                int* __restrict__ abort_flag, const int32_t* __restrict__ perm, const RunTail* __restrict__ tail,
+                unsigned* __restrict__ probe) {
+  extern __shared__ float4 lds[];
+  __shared__ int wg_flag;  // != 0: a wait of this workgroup expired (set before, read after the step's barrier)
+  const unsigned max_spins = max_spins_arg & 0x7fffffffu;
+  const int T = (int)blockDim.x, tid = (int)threadIdx.x, wv = tid >> 6, W = T >> 6;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, idx = b >> 3;
+  if (idx >= wgs_per_xcd) return;
+  if (xcd * wgs_per_xcd + idx >= n_wgs) return;
+  const int wg = wg_begin + xcd * wgs_per_xcd + idx;  // this launch covers workgroups [wg_begin, +n_wgs)
+
+  const int rid_base = wg_info[4 * wg], n_fetch = wg_info[4 * wg + 1];
+  const int chain = __builtin_amdgcn_readfirstlane(wg_wave_chain[wg * W + wv]);
+  const size_t hl = (size_t)wg * T + tid;
+  const unsigned meta = wg_meta[hl];
+  const int slot = wg_slot[hl];
+  const int pv = wg_vid[hl];
+  const int nbr_code = wg_nbr[hl];
+  const int frid = wg_fetch[hl];
+  const int first = (int)(meta & 63u), deg = (int)((meta >> 6) & 127u), loc = (int)((meta >> 13) & 2047u);
+  const bool is_tail = (meta & kWgTailBit) != 0u, active = (meta & kWgActiveBit) != 0u;
+  const bool valid = (meta & kWgValidBit) != 0u, publishes = (meta & kWgPublishBit) != 0u;
+  const bool is_fetch = frid >= 0;
+  const bool wave_fetches = (wv << 6) < n_fetch;  // wave-uniform
+  // LDS map, in float4 units
+  const int rec_stride = lcap + rcap;
+  const int o_ctr4 = 2 * rec_stride, o_ctr1 = o_ctr4 + T + kWgPad;
+  float* const ldsf = reinterpret_cast<float*>(lds);
+  const int nbr_idx = (nbr_code < 0) ? lcap + (nbr_code & 0x7fffffff) : nbr_code;
+  const int vbase = (wv << 6) + first;  // LDS index of the vertex's first lane (its contributions: vbase .. vbase+deg-1)
+
+  int4 rec = make_int4(0, 0, 0, 0);
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active) {
+    rec = hrec[slot];
+    q = hq[slot];
+  }
+  const bool is_target = rec.x < 0;
+  const float alpha = __int_as_float(rec.y), dx = __int_as_float(rec.z), dy = __int_as_float(rec.w);
+  const float beta = q.w;
+  float q1 = q.x, q2 = q.y, q3 = q.z;
+
+  float4 st = make_float4(0.f, 0.f, 0.f, 0.f), bs = make_float4(0.f, 0.f, 0.f, 0.f);
+  float2 aux = make_float2(0.f, 0.f);
+  if (valid) {  // every lane of a vertex reads the same words (broadcast load)
+    st = vstate[pv];
+    aux = vaux[pv];
+    bs = bar_in[pv];
+  }
+  const float data = st.w;
+  const float lam_w = p.data_factor * aux.x;
+  float x = st.x, w1 = st.y, w2 = st.z;  // invariant: every lane of a vertex holds the vertex's state
+  float xb = bs.x, w1b = bs.y, w2b = bs.z;
+  float x_prev = x, w1_prev = w1, w2_prev = w2;
+  bool ok = true;
+  bool timed_out = false;
+
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(xbuf);
+  const int my_off = (rid_base + loc) << 4;
+  const int S = rec_bytes, par = 2 * rec_bytes;
+  int poll_off = is_fetch ? (frid << 4) : 0;  // remote copy by default
+
+  if (tid == 0) wg_flag = 0;
+  lds_wg_barrier();
+  if (dual) {  // one-time XCC exchange: which producers run on my XCD?
+    const unsigned my_xcc = read_xcc_id();
+    const unsigned want = (tag0 & 0x0fffffffu) << 4;
+    if (is_tail && publishes)
+      __builtin_amdgcn_raw_buffer_store_b32((int)(want | my_xcc), rx, 4 * S + (my_off >> 2), 0, kAuxSc1);
+    if (wave_fetches) {
+      bool pend = is_fetch;
+      unsigned spins = 0;
+      unsigned got = 0;
+      for (;;) {
+        if (pend) {
+          int o = 4 * S + (frid << 2);
+          asm volatile("" : "+v"(o)::"memory");
+          got = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, kAuxSc1);
+          pend = ((got & ~15u) != want);
+        }
+        if (!__any(pend)) break;
+        if (++spins > max_spins) {
+          wg_flag = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (is_fetch && (got & 15u) == my_xcc && (got & ~15u) == want) poll_off += S;
+    }
+  }
+
+  // test hook (FLAME_NLTGV2_OPT_FAULT_INJECT): the first workgroup of the launch never publishes its first records
+  const bool mute = (max_spins_arg >> 31) != 0u && wg == wg_begin;
+  if (is_tail) {  // bar(tag0): into the patch's LDS area, and to memory where another patch reads it
+    v4i_t o;
+    o.x = __float_as_int(xb), o.y = __float_as_int(w1b), o.z = __float_as_int(w2b), o.w = (int)tag0;
+    lds[((tag0 & 1u) ? rec_stride : 0) + loc] = make_float4(xb, w1b, w2b, 0.0f);
+    if (publishes && !mute) {
+      const int so = (tag0 & 1u) ? par : 0;
+      __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
+      if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
+    }
+  }
+  unsigned pr_t0 = 0, pr_polls = 0;
+  if (PROBE) pr_t0 = (unsigned)clock64();
+
+  for (int it = 0; it < n_iters; ++it) {
+    const unsigned s = tag0 + (unsigned)it;
+    const int rbase = (s & 1u) ? rec_stride : 0;       // this step's record area
+    const int wbase = (s & 1u) ? 0 : rec_stride;       // next step's
+    // ---- fetch: one polling lane per distinct foreign record, result into LDS ----------------------------------
+    unsigned pr_t1 = 0, pr_t2 = 0;
+    if (wave_fetches) {
+      bool pend = is_fetch;
+      unsigned spins = 0;
+      const int so_in = (s & 1u) ? par : 0;
+      for (int z = 0; z < presleep; ++z) __builtin_amdgcn_s_sleep(1);
+      if (PROBE) pr_t1 = (unsigned)clock64();
+      for (;;) {
+        if (pend) {
+          int o = poll_off;
+          asm volatile("" : "+v"(o)::"memory");
+          const v4i_t g = __builtin_amdgcn_raw_buffer_load_b128(rx, o, so_in, kAuxSc1);
+          if ((unsigned)g.w == s) {
+            lds[rbase + lcap + tid] = make_float4(__int_as_float(g.x), __int_as_float(g.y), __int_as_float(g.z), 0.0f);
+            pend = false;
+          }
+        }
+        if (PROBE) ++pr_polls;
+        if (!__any(pend)) break;
+        ++spins;
+        if ((spins & 63u) == 0u) {
+          const int ab = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (ab != 0 || spins > max_spins) {
+            wg_flag = 1;
+            break;
+          }
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (PROBE) pr_t2 = (unsigned)clock64();
+    }
+    lds_wg_barrier();
+    unsigned pr_t3 = 0;
+    if (PROBE) pr_t3 = (unsigned)clock64();
+    // ---- neighbour record from LDS; workgroup-uniform abort flag -----------------------------------------------
+    float4 nb4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) nb4 = lds[rbase + nbr_idx];
+    if (wg_flag != 0) {
+      timed_out = true;
+      break;
+    }
+    // ---- dual update of this half-edge's private q copy (cc:99-110) ------------------------------
+    const float nxb = nb4.x, nw1b = nb4.y, nw2b = nb4.z;
+    const float xbi = is_target ? nxb : xb, xbj = is_target ? xb : nxb;
+    const float w1bi = is_target ? nw1b : w1b, w1bj = is_target ? w1b : nw1b;
+    const float w2bi = is_target ? nw2b : w2b, w2bj = is_target ? w2b : nw2b;
+    bool okq = true;
+    const EdgeOut e = edge_dual(p, alpha, beta, dx, dy, q1, q2, q3, xbi, w1bi, w2bi, xbj, w1bj, w2bj, okq);
+    // ---- this endpoint's share of the primal scatter (cc:126-141) as ordered contributions -------
+    const float t1 = e.q1 * p.step_x * alpha;
+    const float t2 = e.q2 * p.step_x * beta;
+    const float t3 = e.q3 * p.step_x * beta;
+    float cx = is_target ? t1 : -t1;      // x_j += t1        | x_i -= t1
+    float a1 = is_target ? t2 : t1 * dx;  // w1_j += t2       | w1_i += t1*dx
+    float b1 = is_target ? -0.0f : -t2;   //                  | w1_i -= t2
+    float a2 = is_target ? t3 : t1 * dy;
+    float b2 = is_target ? -0.0f : -t3;
+    if (active) {
+      q1 = e.q1, q2 = e.q2, q3 = e.q3;
+      ok = ok && okq;
+      lds[o_ctr4 + tid] = make_float4(cx, a1, a2, b1);
+      ldsf[4 * o_ctr1 + tid] = b2;
+    }
+    lds_wave_sync();  // a vertex's lanes are lanes of this wave
+    // ---- ordered accumulation, by every lane of the vertex (ascending edge id = ascending lane) --------------
+    // Reads are issued in batches of up to 8 (two LDS round trips cover degree 16); entries past the vertex's last
+    // lane are read (the pad keeps them in bounds) and not used.
+    float X = x, W1 = w1, W2 = w2;
+    for (int k0 = 0; k0 < chain; k0 += 8) {
+      float4 c[8];
+      float cb[8];
+      const bool more = (k0 + 4) < chain;  // wave-uniform
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        c[u] = lds[o_ctr4 + vbase + k0 + u];
+        cb[u] = ldsf[4 * o_ctr1 + vbase + k0 + u];
+      }
+      if (more) {
+#pragma unroll
+        for (int u = 4; u < 8; ++u) {
+          c[u] = lds[o_ctr4 + vbase + k0 + u];
+          cb[u] = ldsf[4 * o_ctr1 + vbase + k0 + u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool on = (k0 + u) < deg;
+        const float Xn = X + c[u].x, W1n = (W1 + c[u].y) + c[u].w, W2n = (W2 + c[u].z) + cb[u];
+        X = on ? Xn : X, W1 = on ? W1n : W1, W2 = on ? W2n : W2;
+      }
+      if (more) {
+#pragma unroll
+        for (int u = 4; u < 8; ++u) {
+          const bool on = (k0 + u) < deg;
+          const float Xn = X + c[u].x, W1n = (W1 + c[u].y) + c[u].w, W2n = (W2 + c[u].z) + cb[u];
+          X = on ? Xn : X, W1 = on ? W1n : W1, W2 = on ? W2n : W2;
+        }
+      }
+    }
+    // ---- vertex update: proxL1 (cc:147-151), extragradient (cc:160-171) --------------------------
+    const float xn = prox_l1(p.x_min, p.x_max, p.step_x, lam_w, X, data);
+    float nb = xn + p.theta * (xn - x);
+    nb = (nb < p.x_min) ? p.x_min : nb;
+    nb = (nb > p.x_max) ? p.x_max : nb;
+    const float w1bn = W1 + p.theta * (W1 - w1);
+    const float w2bn = W2 + p.theta * (W2 - w2);
+    if (is_tail) {
+      if (publishes) {
+        v4i_t o;
+        o.x = __float_as_int(nb), o.y = __float_as_int(w1bn), o.z = __float_as_int(w2bn), o.w = (int)(s + 1u);
+        const int so = ((s + 1u) & 1u) ? par : 0;
+        __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
+        if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
+      }
+      lds[wbase + loc] = make_float4(nb, w1bn, w2bn, 0.0f);
+    }
+    x_prev = x, w1_prev = w1, w2_prev = w2;  // step()'s prev copy, cc:37-42
+    x = xn, w1 = W1, w2 = W2;
+    xb = nb, w1b = w1bn, w2b = w2bn;
+    if (PROBE) {
+      const unsigned pr_t4 = (unsigned)clock64();
+      if ((tid & 63) == 0 && probe) {  // per wave and step: {sleep, poll, barrier wait, compute, polls, step start}
+        unsigned* o = probe + ((size_t)(wg * W + wv) * n_iters + it) * 8;
+        o[0] = pr_t1 - pr_t0, o[1] = pr_t2 - pr_t1, o[2] = pr_t3 - (wave_fetches ? pr_t2 : pr_t0), o[3] = pr_t4 - pr_t3;
+        o[4] = pr_polls, o[5] = pr_t0, o[6] = (unsigned)wall_clock64(), o[7] = (unsigned)wave_fetches;
+      }
+      pr_polls = 0;
+      pr_t0 = pr_t4;
+    }
+  }
+
+  if (timed_out || wg_flag != 0) {
+    if (tid == 0) {
+      __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicOr(err, 2);
+    }
+    return;  // the run is reported as failed; the host takes it back
+  }
+
+  if (is_tail) {
+    vstate_out[pv] = make_float4(x, w1, w2, data);
+    bar_out[pv] = make_float4(xb, w1b, w2b, 0.0f);
+    vprev[pv] = make_float4(x_prev, w1_prev, w2_prev, 0.0f);
+    float* const export_out = tail->export_out;
+    float* const photo_err = tail->photo.err;
+    if (export_out || photo_err) {
+      const int o = perm[pv];  // the caller's vertex index
+      if (o >= 0 && export_out) export_out[o] = x * tail->export_scale;
+      if (o >= 0 && photo_err) {
+        const PhotoFuse& photo = tail->photo;
+        photo_err[o] = photo_residual_at(photo.pos[o], x * photo.graph_scale, photo.geo, photo.ref, photo.cmp, photo.rows,
+                                         photo.cols, photo.step, photo.border);
+      }
+    }
+  }
+  if (active) hq_out[slot] = make_float4(q1, q2, q3, beta);
+  if (!ok) atomicOr(err, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Persistent run, throughput form: same dataflow protocol as k_persistent_he (tagged 16-byte bar
 // records, two parity buffers, bounded waits), but one VERTEX per lane with up to 8 half-edge slots
 // held in registers -- ~5x fewer instructions per half-edge than the lane-per-half-edge form, at the
@@ -1203,7 +1513,7 @@ int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, boo
 }
 
 // Persistent run (single launch).  form 1 = lane per half-edge (k_persistent_he), form 2 = vertex per
-// lane (k_persistent_tv).  Returns the hipError_t unchanged (e.g. hipErrorCooperativeLaunchTooLarge)
+// lane (k_persistent_tv), form 3 = patch per workgroup (k_persistent_wg).  Returns the hipError_t unchanged (e.g. hipErrorCooperativeLaunchTooLarge)
 // so the caller can fall back to per-step launches.
 int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, int wave_begin, int n_waves,
                           int parity_in, unsigned tag0, int n_iters, int waves_per_block, unsigned max_spins,
@@ -1238,6 +1548,22 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
   void* args[] = {&wave_begin, &n_waves, &wpx, &i0, &i1, &i2, &i3, &hrec, &hq, &vstate, &hq_out, &vstate_out, &vaux,
                   &bin, &bout, &vprev, &xbuf, &rec_bytes, &dual, &tag0, &n_iters, &max_spins, &presleep, &pp, &err,
                   &abort_flag, &perm, &tail};
+  if (form == 3) {  // patch-per-workgroup form: n_waves / wave_begin count WORKGROUPS
+    int wgx = (n_waves + xcds - 1) / xcds;
+    const dim3 g3((unsigned)(wgx * 8)), b3((unsigned)(64 * a.wg_waves));
+    int lcap = a.wg_lcap, rcap = a.wg_rcap;
+    const int32_t *w0 = a.wg_slot, *w1 = a.wg_vid, *w3 = a.wg_nbr, *w4 = a.wg_fetch, *w5 = a.wg_info, *w6 = a.wg_wave_chain;
+    const uint32_t* w2 = a.wg_meta;
+    unsigned* probe = a.probe;
+    void* wargs[] = {&wave_begin, &n_waves, &wgx, &lcap, &rcap, &w0, &w1, &w2, &w3, &w4, &w5, &w6, &hrec, &hq, &vstate,
+                     &hq_out, &vstate_out, &vaux, &bin, &bout, &vprev, &xbuf, &rec_bytes, &dual, &tag0, &n_iters,
+                     &max_spins, &presleep, &pp, &err, &abort_flag, &perm, &tail, &probe};
+    const int T = 64 * a.wg_waves;
+    const unsigned lds3 = 16u * (unsigned)(2 * (lcap + rcap) + T + kWgPad) + 4u * (unsigned)(T + kWgPad);
+    const void* f3 = probe ? (const void*)k_persistent_wg<true> : (const void*)k_persistent_wg<false>;
+    if (cooperative) return (int)hipLaunchCooperativeKernel(f3, g3, b3, wargs, lds3, stream);
+    return (int)hipLaunchKernel(f3, g3, b3, wargs, lds3, stream);
+  }
   const bool tv_lds = form == 2 && (tv_static_in_lds != 0);
   const void* fn = (form == 2) ? (tv_lds ? (const void*)k_persistent_tv<true> : (const void*)k_persistent_tv<false>)
                                : (const void*)k_persistent_he;

@@ -26,9 +26,9 @@ _LIB = None
 _FP = C.POINTER(C.c_float)
 _IP = C.POINTER(C.c_int32)
 
-OPT_SOLVER, OPT_USE_HIPGRAPH, OPT_BLOCK_WAVES, OPT_UNROLL, OPT_PERSISTENT, OPT_DUAL_PUBLISH, OPT_TV_LDS, OPT_PRESLEEP, OPT_XCDS, OPT_FAULT_INJECT = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+OPT_SOLVER, OPT_USE_HIPGRAPH, OPT_BLOCK_WAVES, OPT_UNROLL, OPT_PERSISTENT, OPT_DUAL_PUBLISH, OPT_TV_LDS, OPT_PRESLEEP, OPT_XCDS, OPT_FAULT_INJECT, OPT_WG_WAVES, OPT_PROBE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
 RUN_PATHS = {0: "none", 1: "persistent", 2: "per-step hipGraph", 3: "per-step eager", 4: "canonical 4-sweep",
-             5: "persistent-tv"}
+             5: "persistent-tv", 6: "persistent-wg"}
 ERR_NAN = -5
 
 VERTEX_STATE = ("x", "w1", "w2", "x_bar", "w1_bar", "w2_bar", "x_prev", "w1_prev", "w2_prev")
@@ -94,7 +94,7 @@ ABI_SYMBOLS = (
     "flame_nltgv2_costs", "flame_nltgv2_download_state", "flame_nltgv2_export_idepth_device",
     "flame_nltgv2_export_idepth_device_async", "flame_nltgv2_set_export_target",
     "flame_nltgv2_set_option", "flame_nltgv2_get_info", "flame_nltgv2_last_error", "flame_nltgv2_last_hip_error",
-    "flame_nltgv2_status_string", "flame_nltgv2_abi_version", "flame_nltgv2_pack_probe",
+    "flame_nltgv2_status_string", "flame_nltgv2_abi_version", "flame_nltgv2_pack_probe", "flame_nltgv2_read_probe",
     "flame_nltgv2_photo_set_images", "flame_nltgv2_photo_residual", "flame_nltgv2_photo_fuse",
     "flame_nltgv2_photo_residual_last", "flame_nltgv2_sync_graph",
     "flame_nltgv2_get_topology", "flame_nltgv2_set_feature_ids", "flame_nltgv2_interpolate_mesh",
@@ -144,6 +144,7 @@ def load_library():
         "flame_nltgv2_status_string": (C.c_char_p, [C.c_int]),
         "flame_nltgv2_abi_version": (C.c_int, []),
         "flame_nltgv2_pack_probe": (C.c_int, [GP, _IP, _IP, _IP, _IP, C.c_int64, C.POINTER(C.c_int64)]),
+        "flame_nltgv2_read_probe": (C.c_int, [ctx, C.POINTER(C.c_uint32), C.c_int64, C.POINTER(C.c_int64)]),
         "flame_nltgv2_photo_set_images": (C.c_int, [ctx, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int]),
         "flame_nltgv2_photo_residual": (C.c_int, [ctx, _FP, _FP, C.c_float, C.c_int, _FP]),
         "flame_nltgv2_photo_fuse": (C.c_int, [ctx, _FP, _FP, C.c_float, C.c_int, C.c_int]),
@@ -479,6 +480,16 @@ class Regularizer:
         """While set, every run also leaves scale * x (original vertex order) in this device buffer."""
         self._chk(self._L.flame_nltgv2_set_export_target(self._ctx, C.c_void_p(device_ptr or 0), C.c_float(scale)),
                   "set_export_target")
+
+    def read_probe(self) -> np.ndarray:
+        """Cycle probe of the last patch-per-workgroup run (OPT_PROBE): uint32 [waves, steps, 8] flattened."""
+        n = C.c_int64(0)
+        self._chk(self._L.flame_nltgv2_read_probe(self._ctx, None, 0, C.byref(n)), "read_probe")
+        out = np.zeros(int(n.value), dtype=np.uint32)
+        if out.size:
+            self._chk(self._L.flame_nltgv2_read_probe(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint32)), out.size,
+                                                      C.byref(n)), "read_probe")
+        return out
 
     def info(self) -> dict:
         i = _Info()

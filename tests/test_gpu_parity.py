@@ -74,7 +74,7 @@ def test_config_parity(env, config, n):
     g = synth.make_graph(config, seed=4242)
     ref, bad = cpu_run(oracle, g, n)
     assert bad == 0
-    for persistent in (1, 2, 3, 0):  # auto, lane-per-half-edge, vertex-per-lane, one launch per step
+    for persistent in (1, 2, 3, 4, 0):  # auto, lane-per-half-edge, vertex-per-lane, patch-per-workgroup, one launch per step
         out = gpu_run(flame_amd, g, n, options=[(5, persistent)], expect_path=None if persistent else 2)
         assert rms(out["x"], ref["x"]) <= TOL_RMS
         assert_state_equal(out, ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"{config} p={persistent}")
@@ -126,11 +126,13 @@ def test_internal_steps_individually(env):
     [(5, 0), (3, 4), (4, 4)], [(5, 0), (3, 4), (4, 16)], [(5, 0), (2, 0)], [(5, 1)], [(5, 2)], [(5, 3)], [(5, 2), (6, 0)], [(5, 3), (6, 0)], [(5, 2), (6, 2)], [(5, 3), (6, 2)], [(5, 3), (7, 2)], [(5, 3), (6, 2), (7, 2)], [(5, 3), (7, 0)],
     [(5, 2), (9, 1)], [(5, 2), (9, 2)], [(5, 2), (9, 4)], [(5, 2), (9, 8)], [(5, 3), (9, 1)], [(5, 2), (8, 1)], [(5, 2), (8, 21)],
     [(5, 3), (8, 9)], [(5, 2), (9, 1), (6, 0)],
+    [(5, 4)], [(5, 4), (6, 0)], [(5, 4), (6, 2)], [(5, 4), (9, 1)], [(5, 4), (9, 2)], [(5, 4), (9, 8)], [(5, 4), (8, 1)], [(5, 4), (8, 12)],
+    [(11, 1), (5, 4)], [(11, 2), (5, 4)], [(11, 8), (5, 4)], [(11, 16), (5, 4)], [(11, 16), (5, 4), (9, 1), (6, 0)],
 ])
 def test_launch_configurations_are_bit_identical(env, opts):
     """waves per workgroup (opt 3), slot chunk (opt 4), hipGraph on/off (opt 2), persistent single
     launch vs one launch per step (opt 5), same-XCD L2 exchange on/off (opt 6), slot constants in LDS (opt 7), the pre-poll sleep (opt 8) and the number of
-    XCDs a persistent launch is spread over (opt 9) never change a bit."""
+    XCDs a persistent launch is spread over (opt 9), the waves per workgroup of the patch-per-workgroup form (opt 11) never change a bit."""
     flame_amd, oracle = env
     g = synth.make_graph("320x240", seed=3)
     ref, _ = cpu_run(oracle, g, 21)
@@ -243,14 +245,37 @@ def test_batch_of_frames_equals_individual_frames(env):
     flame_amd, oracle = env
     frames = [synth.make_graph("320x240", seed=100 + i) for i in range(5)]
     union = synth.concat_graphs(frames)
-    out = gpu_run(flame_amd, union, 40)
+    refs = [cpu_run(oracle, f, 40)[0] for f in frames]
+    for opts in ([], [(5, 4)], [(5, 4), (11, 8)]):  # auto; patch-per-workgroup form (4 and 8 waves per workgroup)
+        out = gpu_run(flame_amd, union, 40, options=opts)
+        vo = eo = 0
+        for f, ref in zip(frames, refs):
+            for k in ("x", "w1", "w2", "x_bar"):
+                assert np.array_equal(out[k][vo:vo + f["V"]], ref[k]), (opts, k)
+            for k in ("q1", "q2", "q3"):
+                assert np.array_equal(out[k][eo:eo + f["E"]], ref[k]), (opts, k)
+            vo += f["V"]
+            eo += f["E"]
+
+
+def test_large_batch_as_groups_of_patch_workgroups(env):
+    """12 frames of 640x480 in the patch-per-workgroup form exceed its residency cap: groups of whole frames."""
+    flame_amd, oracle = env
+    frames = [synth.make_graph("640x480", seed=500 + i) for i in range(12)]
+    union = synth.concat_graphs(frames)
+    with flame_amd.Regularizer(0) as reg:
+        reg.set_option(5, 4)
+        reg.upload_graph(union)
+        reg.run(flame_amd.Params(), 20)
+        info = reg.info()
+        out = reg.download_state(("x", "q3"))
+    assert info["last_run_path"] == 6 and info["last_run_groups"] >= 2
     vo = eo = 0
-    for f in frames:
-        ref, _ = cpu_run(oracle, f, 40)
-        for k in ("x", "w1", "w2", "x_bar"):
-            assert np.array_equal(out[k][vo:vo + f["V"]], ref[k]), k
-        for k in ("q1", "q2", "q3"):
-            assert np.array_equal(out[k][eo:eo + f["E"]], ref[k]), k
+    for i, f in enumerate(frames):
+        if i % 5 == 0 or i == len(frames) - 1:
+            ref, _ = cpu_run(oracle, f, 20)
+            assert np.array_equal(out["x"][vo:vo + f["V"]], ref["x"]), i
+            assert np.array_equal(out["q3"][eo:eo + f["E"]], ref["q3"]), i
         vo += f["V"]
         eo += f["E"]
 
@@ -342,7 +367,7 @@ def test_nan_is_reported_not_fatal(env):
             reg.run(flame_amd.Params(), 1)
 
 
-@pytest.mark.parametrize("form", [2, 3])
+@pytest.mark.parametrize("form", [2, 3, 4])
 def test_persistent_timeout_is_rolled_back_and_redone(env, form):
     """A persistent run whose neighbour wait expires (fault injection: one wave withholds its first record) must
     leave the state it started from untouched; run() then does the same steps with one launch per step."""
@@ -355,7 +380,7 @@ def test_persistent_timeout_is_rolled_back_and_redone(env, form):
         reg.upload_graph(g)
         reg.run(p, 30)                       # a normal persistent run first (odd/even parity both follow)
         oracle.run(ref, 30)
-        assert reg.info()["last_run_path"] in (1, 5)
+        assert reg.info()["last_run_path"] in (1, 5, 6)
         reg.set_option(10, 200)              # FLAME_NLTGV2_OPT_FAULT_INJECT
         reg.run(p, 41)                       # times out inside, recovered
         oracle.run(ref, 41)
@@ -368,7 +393,7 @@ def test_persistent_timeout_is_rolled_back_and_redone(env, form):
         reg.set_option(10, 0)                # fault off: persistent runs again
         reg.run(p, 25)
         oracle.run(ref, 25)
-        assert reg.info()["last_run_path"] in (1, 5)
+        assert reg.info()["last_run_path"] in (1, 5, 6)
         assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="after the fault")
         # chained asynchronous runs cannot be taken back: reported, not hidden
         reg.set_option(10, 200)
@@ -439,7 +464,7 @@ def test_export_idepth_device_and_stream(env):
         reg.set_stream(None)
 
 
-@pytest.mark.parametrize("form", [0, 2, 3])
+@pytest.mark.parametrize("form", [0, 2, 3, 4])
 def test_standing_export_target(env, form):
     """flame_nltgv2_set_export_target: every run leaves scale * x in the caller's vertex order, on all paths."""
     import torch
@@ -499,7 +524,7 @@ def test_randomized_run_sequences(env, trial):
         reg.upload_graph(g)
         reg.set_export_target(buf.data_ptr(), 2.0)
         for step in range(12):
-            form = int(rng.choice([0, 1, 2, 3]))
+            form = int(rng.choice([0, 1, 2, 3, 4]))
             reg.set_option(5, form)
             reg.set_option(1, int(rng.random() < 0.15))      # canonical four-sweep path now and then
             reg.set_option(6, int(rng.choice([0, 1, 2])))

@@ -2,11 +2,14 @@
 sound, and a numpy EMULATION of the fused sweep over that packed layout (one vertex per lane, slots
 in ascending edge id, private q copy per half-edge) reproduces the checker bit for bit -- i.e. the
 vertex-gather re-association the GPU kernels use is exact, not approximate."""
+import os
+
 import numpy as np
 import pytest
 
 from flame_amd import regularizer, synth
 from oracle import capi as oracle
+from tests.conftest import ROOT
 from tests.helpers import assert_state_equal, load_golden, random_graph
 
 ROLE = np.uint32(0x80000000)
@@ -173,3 +176,17 @@ def test_batch_frames_stay_contiguous(built):
     V1 = frames[0]["V"]
     frame_of = pr["perm"][: g["V"]] // V1
     assert np.all(np.diff(frame_of) >= 0)
+
+
+def test_wg_layout_replay(built, tmp_path):
+    """Layout (E) of nltgv2_pack.hpp (patch-per-workgroup rows): tests/cpp/wg_layout_test.cc replays the kernel's data
+    movement on the CPU with the device code's visibility rules and compares with the checker bit for bit."""
+    import subprocess
+
+    exe = str(tmp_path / "wg_layout_test")
+    subprocess.check_call([
+        "g++", "-std=c++17", "-O1", "-ffp-contract=off", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+        "-I", os.path.join(ROOT, "flame_amd", "csrc"), os.path.join(ROOT, "tests", "cpp", "wg_layout_test.cc"), "-o", exe,
+        "-L", os.path.join(ROOT, "oracle"), "-loracle_nltgv2", f"-Wl,-rpath,{os.path.join(ROOT, 'oracle')}"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "all ok" in r.stdout, r.stdout + r.stderr
