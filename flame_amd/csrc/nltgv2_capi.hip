@@ -30,6 +30,7 @@ constexpr int kGraphChunk = 256;      // steps per captured hipGraph (even: keep
 constexpr int kMaxCachedGraphs = 6;
 constexpr int kHeWavesPerCu = 24;      // residency cap of k_persistent_he (<= 64 VGPRs: the hardware admits 32)
 constexpr int kTvLdsWavesPerCu = 16;   // ... with the slot constants in LDS (<= 128 VGPRs -> 4 waves per SIMD; 10 KB LDS per wave = all 160 KB)
+constexpr int kWgPollGap = 2;          // x64 cycles between the pipelined polls of the communication wave
 constexpr int kWgWavesPerCu = 24;      // residency cap of k_persistent_wg (<= 64 VGPRs; its LDS use is a few KB per workgroup)
 constexpr int kTvWavesPerCu = 8;       // residency of k_persistent_tv (<= 256 VGPRs -> 2 waves per SIMD)
 constexpr int kDualMinWavesPerCu = 0;  // auto: exchange through the XCD's L2 when more waves than this share a CU
@@ -78,6 +79,7 @@ struct flame_nltgv2_ctx {
   int opt_fault = 0;     // test hook: > 0 = the next persistent runs time out after this many spins
   int opt_presleep = 0;  // 0: auto (kPreSleep*); n > 0: (n - 1) x 64 cycles
   int opt_wg_waves = 4;  // waves per workgroup of the patch-per-workgroup form (layout (E); applies at the next upload)
+  int opt_poll_gap = 0;  // patch-per-workgroup form: 0 = default, n > 0 = (n - 1) x 64 cycles between pipelined polls
   int opt_probe = 0;     // > 0: k_persistent_wg records a per-wave, per-step cycle probe (flame_nltgv2_read_probe)
   size_t probe_words = 0;
   int opt_tv_lds = 1;  // 0 registers, 1 auto (LDS when the register form is not resident in one launch), 2 LDS
@@ -290,7 +292,7 @@ int plan_persistent(const flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* 
   const bool tv_lds = ctx->opt_tv_lds == 2 || (ctx->opt_tv_lds == 1 && L.tv_waves > kTvWavesPerCu * cus);
   const int he_cap = kHeWavesPerCu * cus, tv_cap = (tv_lds ? kTvLdsWavesPerCu : kTvWavesPerCu) * cus;
   if (use_tv_lds) *use_tv_lds = tv_lds ? 1 : 0;
-  const int wg_cap = (kWgWavesPerCu / std::max(1, L.wg_waves)) * cus;  // in workgroups
+  const int wg_cap = (kWgWavesPerCu / (L.wg_waves + 1)) * cus;  // in workgroups (compute waves + the communication wave)
   const bool he_fits = L.he_ok && L.he_waves > 0 && L.he_waves <= he_cap;
   const bool tv_fits = L.tv_ok && L.tv_waves > 0 && L.tv_waves <= tv_cap;
   if (ctx->opt_persistent == 2 && !L.he_ok) return 0;
@@ -523,9 +525,10 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
                                                                             : kPreSleepHe;
       const unsigned spins_arg = ctx->opt_fault > 0 ? (0x80000000u | (unsigned)ctx->opt_fault) : kMaxSpins;
       if (form == 3) {
+        ctx->f.wg_poll_gap = ctx->opt_poll_gap > 0 ? ctx->opt_poll_gap - 1 : kWgPollGap;
         ctx->f.probe = nullptr;
         if (ctx->opt_probe) {
-          const size_t words = (size_t)ctx->L.wg_count * ctx->L.wg_waves * (size_t)n * 8;
+          const size_t words = (size_t)ctx->L.wg_count * (ctx->L.wg_waves + 1) * (size_t)n * 8;
           rc = ensure(ctx, ctx->probe, words * sizeof(unsigned));
           if (rc) return rc;
           ctx->f.probe = (unsigned*)ctx->probe.p;
@@ -767,8 +770,12 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
       ctx->opt_persistent = value;
       return 0;
     case FLAME_NLTGV2_OPT_WG_WAVES:
-      if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      if (value != 1 && value != 2 && value != 4 && value != 8) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_wg_waves = value;
+      return 0;
+    case FLAME_NLTGV2_OPT_POLL_GAP:
+      if (value < 0 || value > 64) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_poll_gap = value;
       return 0;
     case FLAME_NLTGV2_OPT_PROBE:
       ctx->opt_probe = value ? 1 : 0;

@@ -99,6 +99,7 @@ struct FusedArgs {
   int32_t* wg_fetch = nullptr;
   int32_t* wg_info = nullptr;
   int32_t* wg_wave_chain = nullptr;
+  int wg_poll_gap = 2;                 // x64 cycles between the pipelined polls of the communication wave
   unsigned* probe = nullptr;           // optional per-wave, per-step cycle probe of k_persistent_wg (tools/probe_wg.py)
   int* abort_flag = nullptr;
   int* err = nullptr;

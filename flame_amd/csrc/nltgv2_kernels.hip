@@ -532,32 +532,49 @@ k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd
 }
 
 // ------------------------------------------------------------------------------------------------
-// Persistent run, patch-per-workgroup form ("wg"): the lane-per-half-edge arithmetic of k_persistent_he, but the
-// exchange is organised around what bounds a step on this chip -- the NUMBER of memory-side requests per step and the
-// length of the dependent chain between a record arriving and the next one leaving:
+// Persistent run, patch-per-workgroup form ("wg"): the lane-per-half-edge arithmetic of k_persistent_he, organised
+// around what bounds a step on this chip.  Measured (profiles/r02_wg_probe.json): a lone wave issues one instruction
+// per ~4 cycles, so a step costs (instructions on the path between a record arriving and the next one leaving) x 4
+// cycles, plus one cross-CU hand-off whose price is the load round trip (~600 cycles) times the polls it takes.
 //
-//   * a workgroup (blockDim/64 waves on one CU) owns a compact Morton patch of vertices.  Neighbours inside the patch
-//     exchange their records through LDS (two parity areas, one workgroup barrier per step); a vertex is published to
-//     memory only if it has a neighbour in another patch.
-//   * every DISTINCT foreign record a patch needs is fetched by exactly one polling lane (sorted by record id, records
-//     numbered in walk order, so a producer's records share cache lines) and handed to the half-edge lanes through
-//     LDS: a 640x480 graph issues ~7 k polls per step instead of one per half-edge (~51 k).
-//   * the ordered accumulation (cc:120-142: ascending edge id) is done by EVERY lane of the vertex from the
-//     contributions its lanes left in LDS -- (W + a) + b in exactly the reference's order -- so there is no DPP ripple
-//     and no hand-back: all lanes of a vertex hold bit-identical state at all times.
+//   * a workgroup = W compute waves + ONE communication wave, and owns a compact Morton patch of vertices.  Neighbours
+//     inside the patch exchange their records through LDS (two parity areas, one workgroup barrier per step); a vertex
+//     is published to memory only if it has a neighbour in another patch.
+//   * the communication wave does nothing but fetch: one lane per DISTINCT foreign record the patch needs (two per lane
+//     beyond 64; sorted by record id, records numbered in walk order so a producer's records share cache lines), polls
+//     pipelined three deep so that a miss costs a fraction of a round trip instead of a whole one, results into LDS.
+//     It runs one step ahead of the compute waves (it fetches the records of step s+1 while they compute step s) and
+//     never stores, so its loads do not queue behind write-through stores; the compute waves never wait for memory.
+//   * the compute waves' step is straight-line code: the per-role selects of the dual update are folded into signed
+//     per-lane constants (exact: IEEE negation and a*(-b) == -(a*b)), the w1/w2 halves run as packed-f32 pairs, and
+//     the ordered accumulation (cc:120-142: ascending edge id) is done by EVERY lane of the vertex from an LDS slab of
+//     8 contribution slots per vertex whose unused slots hold -0.0f (x + -0.0f == x for every x): no predication, no
+//     DPP ripple, no hand-back -- all lanes of a vertex hold bit-identical state at all times.  Vertices of degree > 8
+//     continue from a per-lane overflow strip (rare in a Delaunay graph).
 //
 // Protocol (tags, two parity buffers, remote/local copies, XCC table, bounded waits, transactional outputs) is that of
-// k_persistent_he.  LDS: [rec par0: lcap local + rcap fetched | rec par1 | contributions (T+kWgPad) x {cx,a1,a2,b1} |
-// (T+kWgPad) x b2]; the pad lets the batched contribution reads run past a vertex's last lane without a bounds test.
+// k_persistent_he.  LDS (float4 units): [rec par0: lcap local + rcap fetched | rec par1 | slabA lcap*8 x {a1,a2,b1,b2} |
+// ovfA T | slabC lcap*8 floats | ovfC T floats].
 // ------------------------------------------------------------------------------------------------
-constexpr int kWgPad = 80;
 constexpr unsigned kWgTailBit = 1u << 24, kWgActiveBit = 1u << 25, kWgValidBit = 1u << 26, kWgPublishBit = 1u << 27;
+constexpr int kWgSlab = 8;  // contribution slots per vertex in the slab; positions beyond go to the overflow strip
+typedef float v2f_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void lds_wave_sync() {  // LDS operations of one wave are processed in issue order
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 __device__ __forceinline__ void lds_wg_barrier() {  // no vmcnt wait: a step's publish stores stay in flight
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// One 16-byte-per-lane LDS-DMA load: lane i's 16 bytes at gsrc land at LDS byte address lds_dst + 16*i.  M0 is the
+// destination base; it is compiler-reserved, so it is saved, written and restored inside the one statement.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
 }
 
 template <bool PROBE>
@@ -569,38 +586,148 @@ k_persistent_wg(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
                 const int32_t* __restrict__ wg_wave_chain, const int4* hrec, const float4* hq, const float4* vstate,
                 float4* hq_out, float4* vstate_out, const float2* vaux, const float4* bar_in, float4* bar_out, float4* vprev,
                 void* xbuf, const int rec_bytes, const int dual, const unsigned tag0, const int n_iters,
-                const unsigned max_spins_arg, const int presleep, const SolverParams p, int* __restrict__ err,
-                int* __restrict__ abort_flag, const int32_t* __restrict__ perm, const RunTail* __restrict__ tail,
-                unsigned* __restrict__ probe) {
+                const unsigned max_spins_arg, const int presleep, const int poll_gap, const SolverParams p,
+                int* __restrict__ err, int* __restrict__ abort_flag, const int32_t* __restrict__ perm,
+                const RunTail* __restrict__ tail, unsigned* __restrict__ probe) {
   extern __shared__ float4 lds[];
-  __shared__ int wg_flag;  // != 0: a wait of this workgroup expired (set before, read after the step's barrier)
+  __shared__ int wg_flag;  // != 0: a wait of this workgroup expired (set before, read after a step's barrier)
   const unsigned max_spins = max_spins_arg & 0x7fffffffu;
-  const int T = (int)blockDim.x, tid = (int)threadIdx.x, wv = tid >> 6, W = T >> 6;
+  const int tid = (int)threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int W = ((int)blockDim.x >> 6) - 1, T = W << 6;  // compute waves / lanes; wave W is the communication wave
   const int b = blockIdx.x;
   const int xcd = b & 7, idx = b >> 3;
   if (idx >= wgs_per_xcd) return;
   if (xcd * wgs_per_xcd + idx >= n_wgs) return;
   const int wg = wg_begin + xcd * wgs_per_xcd + idx;  // this launch covers workgroups [wg_begin, +n_wgs)
-
   const int rid_base = wg_info[4 * wg], n_fetch = wg_info[4 * wg + 1];
+  // LDS map, in float4 units
+  const int rec_stride = lcap + rcap;
+  const int o_slabA = 2 * rec_stride, o_ovfA = o_slabA + lcap * kWgSlab, o_slabC = o_ovfA + T;  // slabC/ovfC: floats
+  float* const ldsf = reinterpret_cast<float*>(lds);
+  const int f_slabC = 4 * o_slabC, f_ovfC = f_slabC + lcap * kWgSlab;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(xbuf);
+  const int S = rec_bytes, par = 2 * rec_bytes;
+  if (tid == 0) wg_flag = 0;
+  const unsigned xcc_want = (tag0 & 0x0fffffffu) << 4;
+
+  if (wv == W) {
+    // ============================ communication wave ===========================================================
+    const int f0 = (lane < n_fetch) ? wg_fetch[(size_t)wg * T + lane] : -1;
+    const int f1 = (64 + lane < n_fetch) ? wg_fetch[(size_t)wg * T + 64 + lane] : -1;
+    const bool has0 = f0 >= 0, has1 = f1 >= 0;
+    int off0 = has0 ? (f0 << 4) : 0, off1 = has1 ? (f1 << 4) : off0;  // a lane without a record re-reads a harmless one
+    lds_wg_barrier();  // (A) wg_flag initialised, slabs cleared
+    bool failed = false;
+    if (dual && n_fetch > 0) {  // one-time XCC exchange: which producers run on my XCD?
+      const unsigned my_xcc = read_xcc_id();
+      bool p0 = has0, p1 = has1;
+      unsigned g0 = 0, g1 = 0, spins = 0;
+      for (;;) {
+        if (p0) {
+          int o = 4 * S + (f0 << 2);
+          asm volatile("" : "+v"(o)::"memory");
+          g0 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, kAuxSc1);
+          p0 = ((g0 & ~15u) != xcc_want);
+        }
+        if (p1) {
+          int o = 4 * S + (f1 << 2);
+          asm volatile("" : "+v"(o)::"memory");
+          g1 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, kAuxSc1);
+          p1 = ((g1 & ~15u) != xcc_want);
+        }
+        if (!__any(p0 || p1)) break;
+        if (++spins > max_spins) {
+          failed = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (!failed) {
+        if (has0 && (g0 & 15u) == my_xcc) off0 += S;
+        if (has1 && (g1 & 15u) == my_xcc) off1 += S;
+      }
+    }
+    // Polling is LDS-DMA (global_load_lds_dwordx4 sc1, lane i -> slot i of the step's fetch area): no register ever
+    // waits for a poll, so rounds are issued every `poll_gap` x 64 cycles regardless of the round trip, several in
+    // flight; a round that finds an old record rewrites the slot with that old record, one that finds the new one
+    // makes the slot's tag word equal to s (loads of one wave land in issue order, and a record only ever moves
+    // forward).  The wave watches the tag words in LDS.  Rounds still in flight when the last tag arrives land later
+    // with the same bytes.
+    const char* const xb_base = static_cast<const char*>(xbuf);
+    const unsigned lds_addr0 = (unsigned)(size_t)(lds);  // LDS byte address of the dynamic array
+    const int* const ldsi = reinterpret_cast<const int*>(lds);
+    const bool two = n_fetch > 64;  // wave-uniform
+    unsigned pr_t0 = 0;
+    if (PROBE) pr_t0 = (unsigned)clock64();
+    for (int it = 0; it < n_iters; ++it) {
+      const unsigned s = tag0 + (unsigned)it;
+      const int so_in = (s & 1u) ? par : 0;
+      const int rdst = ((s & 1u) ? rec_stride : 0) + lcap + lane;
+      unsigned pr_t1 = 0, pr_rounds = 0;
+      if (n_fetch > 0 && !failed) {
+        const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds_addr0 + 16u * (unsigned)(rdst - lane));
+        const char* const src0 = xb_base + off0 + so_in;
+        const char* const src1 = xb_base + off1 + so_in;
+        // the producers of step s records are computing step s-1 right now: nothing can arrive before that is done
+        if (it > 0)
+          for (int z = 0; z < presleep; ++z) __builtin_amdgcn_s_sleep(1);
+        if (PROBE) pr_t1 = (unsigned)clock64();
+        unsigned spins = 0;
+        for (;;) {
+          if (has0) lds_dma16(src0, dst0);
+          if (two && has1) lds_dma16(src1, dst0 + 1024u);
+          for (int z = 0; z < poll_gap; ++z) __builtin_amdgcn_s_sleep(1);
+          asm volatile("" ::: "memory");
+          const unsigned t0 = (unsigned)ldsi[4 * rdst + 3];
+          const unsigned t1 = (unsigned)ldsi[4 * (rdst + 64) + 3];
+          const bool pend = (has0 && t0 != s) || (has1 && t1 != s);
+          if (PROBE) ++pr_rounds;
+          if (!__any(pend)) break;
+          ++spins;
+          if ((spins & 63u) == 0u) {
+            const int ab = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ab != 0 || spins > max_spins) {
+              failed = true;
+              break;
+            }
+          }
+        }
+      }
+      if (failed) wg_flag = 1;
+      unsigned pr_t2 = 0;
+      if (PROBE) pr_t2 = (unsigned)clock64();
+      lds_wg_barrier();  // (B_s) records of step s are in LDS
+      if (PROBE) {
+        const unsigned pr_t3 = (unsigned)clock64();
+        if (lane == 0 && probe) {  // {pre-sleep, poll, barrier wait, -, poll rounds, step start, 100 MHz clock, 1 = comm wave}
+          unsigned* o = probe + ((size_t)(wg * (W + 1) + wv) * n_iters + it) * 8;
+          o[0] = pr_t1 - pr_t0, o[1] = pr_t2 - pr_t1, o[2] = pr_t3 - pr_t2, o[3] = 0;
+          o[4] = pr_rounds, o[5] = pr_t0, o[6] = (unsigned)wall_clock64(), o[7] = 1u;
+        }
+        pr_t0 = pr_t3;
+      }
+      if (failed) break;  // the compute waves read wg_flag after the same barrier and leave as well
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA in flight when the wave ends
+    if (failed && lane == 0) {
+      __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicOr(err, 2);
+    }
+    return;
+  }
+
+  // ================================ compute waves ================================================================
   const int chain = __builtin_amdgcn_readfirstlane(wg_wave_chain[wg * W + wv]);
   const size_t hl = (size_t)wg * T + tid;
   const unsigned meta = wg_meta[hl];
   const int slot = wg_slot[hl];
   const int pv = wg_vid[hl];
   const int nbr_code = wg_nbr[hl];
-  const int frid = wg_fetch[hl];
   const int first = (int)(meta & 63u), deg = (int)((meta >> 6) & 127u), loc = (int)((meta >> 13) & 2047u);
   const bool is_tail = (meta & kWgTailBit) != 0u, active = (meta & kWgActiveBit) != 0u;
   const bool valid = (meta & kWgValidBit) != 0u, publishes = (meta & kWgPublishBit) != 0u;
-  const bool is_fetch = frid >= 0;
-  const bool wave_fetches = (wv << 6) < n_fetch;  // wave-uniform
-  // LDS map, in float4 units
-  const int rec_stride = lcap + rcap;
-  const int o_ctr4 = 2 * rec_stride, o_ctr1 = o_ctr4 + T + kWgPad;
-  float* const ldsf = reinterpret_cast<float*>(lds);
   const int nbr_idx = (nbr_code < 0) ? lcap + (nbr_code & 0x7fffffff) : nbr_code;
-  const int vbase = (wv << 6) + first;  // LDS index of the vertex's first lane (its contributions: vbase .. vbase+deg-1)
+  const int pos = lane - first;  // this half-edge's position among its vertex's (ascending edge id)
 
   int4 rec = make_int4(0, 0, 0, 0);
   float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -611,220 +738,178 @@ k_persistent_wg(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   const bool is_target = rec.x < 0;
   const float alpha = __int_as_float(rec.y), dx = __int_as_float(rec.z), dy = __int_as_float(rec.w);
   const float beta = q.w;
-  float q1 = q.x, q2 = q.y, q3 = q.z;
+  float q1 = q.x;
+  v2f_t q23 = {q.y, q.z};
+  // Signed per-lane constants (i = source, j = target of the EDGE; "own" = this lane's vertex, "nb" = the other one):
+  //   alpha*(xb_i - xb_j)     == as * (own - nb)     with as  = source ? alpha : -alpha
+  //   beta*(wb_i - wb_j)      == bs * (own - nb)     with bs  = source ? beta : -beta
+  //   cx = target ? t1 : -t1  == u1 * ac            with ac  = target ? alpha : -alpha,  u1 = q1*step_x
+  //   source: a = t1*(dx,dy)  == cx * (-dx,-dy);   b = -(t2,t3) == (u2,u3) * (-beta)
+  //   target: a = (t2,t3)     == (u2,u3) * beta;   b = (-0,-0)
+  const float as = is_target ? -alpha : alpha, bs = is_target ? -beta : beta, ac = is_target ? alpha : -alpha;
+  const v2f_t P12 = {alpha * dx, alpha * dy};  // cc:100-101: alpha * dx * w1_bar evaluates (alpha*dx) first
+  const v2f_t C2 = is_target ? v2f_t{beta, beta} : v2f_t{-dx, -dy};
+  const float nbeta = -beta;
 
-  float4 st = make_float4(0.f, 0.f, 0.f, 0.f), bs = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 st = make_float4(0.f, 0.f, 0.f, 0.f), bs4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float2 aux = make_float2(0.f, 0.f);
   if (valid) {  // every lane of a vertex reads the same words (broadcast load)
     st = vstate[pv];
     aux = vaux[pv];
-    bs = bar_in[pv];
+    bs4 = bar_in[pv];
   }
   const float data = st.w;
-  const float lam_w = p.data_factor * aux.x;
-  float x = st.x, w1 = st.y, w2 = st.z;  // invariant: every lane of a vertex holds the vertex's state
-  float xb = bs.x, w1b = bs.y, w2b = bs.z;
-  float x_prev = x, w1_prev = w1, w2_prev = w2;
+  const float thr = p.step_x * (p.data_factor * aux.x);  // proxL1's thresh, h:185 with the call site's weight cc:149-150
+  float x = st.x;               // invariant: every lane of a vertex holds the vertex's state
+  v2f_t w12 = {st.y, st.z};
+  float xb = bs4.x;
+  v2f_t wb12 = {bs4.y, bs4.z};
+  float x_prev = x;
+  v2f_t w_prev = w12;
   bool ok = true;
   bool timed_out = false;
 
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(xbuf);
   const int my_off = (rid_base + loc) << 4;
-  const int S = rec_bytes, par = 2 * rec_bytes;
-  int poll_off = is_fetch ? (frid << 4) : 0;  // remote copy by default
+  // LDS addresses of this lane (float4 / float indices)
+  // (a lane without a half-edge writes to its own overflow entry, which no vertex reads)
+  const bool in_slab = active && pos < kWgSlab;
+  const int wrA = in_slab ? o_slabA + loc * kWgSlab + pos : o_ovfA + tid;
+  const int wrC = in_slab ? f_slabC + loc * kWgSlab + pos : f_ovfC + tid;
+  const int rdA = o_slabA + loc * kWgSlab, rdC4 = (f_slabC + loc * kWgSlab) >> 2;  // slabC of a vertex = two float4
+  const int ovf_base = (wv << 6) + first;  // overflow strip index of the vertex's position-0 lane
 
-  if (tid == 0) wg_flag = 0;
-  lds_wg_barrier();
-  if (dual) {  // one-time XCC exchange: which producers run on my XCD?
-    const unsigned my_xcc = read_xcc_id();
-    const unsigned want = (tag0 & 0x0fffffffu) << 4;
-    if (is_tail && publishes)
-      __builtin_amdgcn_raw_buffer_store_b32((int)(want | my_xcc), rx, 4 * S + (my_off >> 2), 0, kAuxSc1);
-    if (wave_fetches) {
-      bool pend = is_fetch;
-      unsigned spins = 0;
-      unsigned got = 0;
-      for (;;) {
-        if (pend) {
-          int o = 4 * S + (frid << 2);
-          asm volatile("" : "+v"(o)::"memory");
-          got = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, kAuxSc1);
-          pend = ((got & ~15u) != want);
-        }
-        if (!__any(pend)) break;
-        if (++spins > max_spins) {
-          wg_flag = 1;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(2);
-      }
-      if (is_fetch && (got & 15u) == my_xcc && (got & ~15u) == want) poll_off += S;
-    }
+  // clear the contribution slabs: slots no lane writes must read as -0.0f for the whole run; and the fetch areas:
+  // their tag words (0 is never a live tag) are what the communication wave watches
+  for (int i = tid; i < lcap * kWgSlab; i += T) {
+    lds[o_slabA + i] = make_float4(-0.0f, -0.0f, -0.0f, -0.0f);
+    ldsf[f_slabC + i] = -0.0f;
   }
-
+  for (int i = tid; i < rcap; i += T) {
+    lds[lcap + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    lds[rec_stride + lcap + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (dual && is_tail && publishes) {
+    const unsigned my_xcc = read_xcc_id();
+    __builtin_amdgcn_raw_buffer_store_b32((int)(xcc_want | my_xcc), rx, 4 * S + (my_off >> 2), 0, kAuxSc1);
+  }
   // test hook (FLAME_NLTGV2_OPT_FAULT_INJECT): the first workgroup of the launch never publishes its first records
   const bool mute = (max_spins_arg >> 31) != 0u && wg == wg_begin;
-  if (is_tail) {  // bar(tag0): into the patch's LDS area, and to memory where another patch reads it
+  if (valid) lds[((tag0 & 1u) ? rec_stride : 0) + loc] = make_float4(xb, wb12.x, wb12.y, 0.0f);
+  if (is_tail && publishes && !mute) {  // bar(tag0) to memory where another patch reads it
     v4i_t o;
-    o.x = __float_as_int(xb), o.y = __float_as_int(w1b), o.z = __float_as_int(w2b), o.w = (int)tag0;
-    lds[((tag0 & 1u) ? rec_stride : 0) + loc] = make_float4(xb, w1b, w2b, 0.0f);
-    if (publishes && !mute) {
-      const int so = (tag0 & 1u) ? par : 0;
-      __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
-      if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
-    }
+    o.x = __float_as_int(xb), o.y = __float_as_int(wb12.x), o.z = __float_as_int(wb12.y), o.w = (int)tag0;
+    const int so = (tag0 & 1u) ? par : 0;
+    __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
+    if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
   }
-  unsigned pr_t0 = 0, pr_polls = 0;
+  lds_wg_barrier();  // (A)
+  unsigned pr_t0 = 0;
   if (PROBE) pr_t0 = (unsigned)clock64();
+  const bool pub_lane = is_tail && publishes;
 
   for (int it = 0; it < n_iters; ++it) {
     const unsigned s = tag0 + (unsigned)it;
-    const int rbase = (s & 1u) ? rec_stride : 0;       // this step's record area
-    const int wbase = (s & 1u) ? 0 : rec_stride;       // next step's
-    // ---- fetch: one polling lane per distinct foreign record, result into LDS ----------------------------------
-    unsigned pr_t1 = 0, pr_t2 = 0;
-    if (wave_fetches) {
-      bool pend = is_fetch;
-      unsigned spins = 0;
-      const int so_in = (s & 1u) ? par : 0;
-      for (int z = 0; z < presleep; ++z) __builtin_amdgcn_s_sleep(1);
-      if (PROBE) pr_t1 = (unsigned)clock64();
-      for (;;) {
-        if (pend) {
-          int o = poll_off;
-          asm volatile("" : "+v"(o)::"memory");
-          const v4i_t g = __builtin_amdgcn_raw_buffer_load_b128(rx, o, so_in, kAuxSc1);
-          if ((unsigned)g.w == s) {
-            lds[rbase + lcap + tid] = make_float4(__int_as_float(g.x), __int_as_float(g.y), __int_as_float(g.z), 0.0f);
-            pend = false;
-          }
-        }
-        if (PROBE) ++pr_polls;
-        if (!__any(pend)) break;
-        ++spins;
-        if ((spins & 63u) == 0u) {
-          const int ab = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (ab != 0 || spins > max_spins) {
-            wg_flag = 1;
-            break;
-          }
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      if (PROBE) pr_t2 = (unsigned)clock64();
-    }
-    lds_wg_barrier();
+    const int rbase = (s & 1u) ? rec_stride : 0;  // this step's record area
+    const int wbase = (s & 1u) ? 0 : rec_stride;  // next step's
+    lds_wg_barrier();  // (B_s)
     unsigned pr_t3 = 0;
     if (PROBE) pr_t3 = (unsigned)clock64();
     // ---- neighbour record from LDS; workgroup-uniform abort flag -----------------------------------------------
-    float4 nb4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (active) nb4 = lds[rbase + nbr_idx];
+    const float4 nb4 = lds[rbase + nbr_idx];
     if (wg_flag != 0) {
       timed_out = true;
       break;
     }
     // ---- dual update of this half-edge's private q copy (cc:99-110) ------------------------------
-    const float nxb = nb4.x, nw1b = nb4.y, nw2b = nb4.z;
-    const float xbi = is_target ? nxb : xb, xbj = is_target ? xb : nxb;
-    const float w1bi = is_target ? nw1b : w1b, w1bj = is_target ? w1b : nw1b;
-    const float w2bi = is_target ? nw2b : w2b, w2bj = is_target ? w2b : nw2b;
-    bool okq = true;
-    const EdgeOut e = edge_dual(p, alpha, beta, dx, dy, q1, q2, q3, xbi, w1bi, w2bi, xbj, w1bj, w2bj, okq);
+    const v2f_t nbw = {nb4.y, nb4.z};
+    const float d0 = xb - nb4.x;
+    const v2f_t d12 = wb12 - nbw;
+    const v2f_t wbi = is_target ? nbw : wb12;  // the SOURCE vertex's (w1_bar, w2_bar)
+    float K1 = as * d0;
+    const v2f_t m12 = P12 * wbi;
+    K1 -= m12.x;
+    K1 -= m12.y;
+    const v2f_t K23 = bs * d12;
+    const float q1r = q1 + p.step_q * K1;
+    const v2f_t q23r = q23 + p.step_q * K23;
+    ok = ok && (__builtin_fabsf(q1r) <= 3.402823466e+38f) && (__builtin_fabsf(q23r.x) <= 3.402823466e+38f) &&
+         (__builtin_fabsf(q23r.y) <= 3.402823466e+38f);  // NaN/Inf: the reference's FLAME_ASSERT h:174
+    q1 = __builtin_fminf(__builtin_fmaxf(q1r, -1.0f), 1.0f);
+    q23.x = __builtin_fminf(__builtin_fmaxf(q23r.x, -1.0f), 1.0f);
+    q23.y = __builtin_fminf(__builtin_fmaxf(q23r.y, -1.0f), 1.0f);
     // ---- this endpoint's share of the primal scatter (cc:126-141) as ordered contributions -------
-    const float t1 = e.q1 * p.step_x * alpha;
-    const float t2 = e.q2 * p.step_x * beta;
-    const float t3 = e.q3 * p.step_x * beta;
-    float cx = is_target ? t1 : -t1;      // x_j += t1        | x_i -= t1
-    float a1 = is_target ? t2 : t1 * dx;  // w1_j += t2       | w1_i += t1*dx
-    float b1 = is_target ? -0.0f : -t2;   //                  | w1_i -= t2
-    float a2 = is_target ? t3 : t1 * dy;
-    float b2 = is_target ? -0.0f : -t3;
-    if (active) {
-      q1 = e.q1, q2 = e.q2, q3 = e.q3;
-      ok = ok && okq;
-      lds[o_ctr4 + tid] = make_float4(cx, a1, a2, b1);
-      ldsf[4 * o_ctr1 + tid] = b2;
-    }
+    const float u1 = q1 * p.step_x;
+    const v2f_t u23 = q23 * p.step_x;
+    const float cx = u1 * ac;
+    const v2f_t M2 = is_target ? u23 : v2f_t{cx, cx};
+    const v2f_t a12 = M2 * C2;
+    v2f_t b12 = u23 * nbeta;
+    b12 = is_target ? v2f_t{-0.0f, -0.0f} : b12;
+    lds[wrA] = make_float4(a12.x, a12.y, b12.x, b12.y);
+    ldsf[wrC] = cx;
     lds_wave_sync();  // a vertex's lanes are lanes of this wave
-    // ---- ordered accumulation, by every lane of the vertex (ascending edge id = ascending lane) --------------
-    // Reads are issued in batches of up to 8 (two LDS round trips cover degree 16); entries past the vertex's last
-    // lane are read (the pad keeps them in bounds) and not used.
-    float X = x, W1 = w1, W2 = w2;
-    for (int k0 = 0; k0 < chain; k0 += 8) {
-      float4 c[8];
-      float cb[8];
-      const bool more = (k0 + 4) < chain;  // wave-uniform
+    // ---- ordered accumulation, by every lane of the vertex (ascending edge id = ascending slot) --------------
+    float X = x;
+    v2f_t Wa = w12;
+    {
+      float4 c[kWgSlab];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        c[u] = lds[o_ctr4 + vbase + k0 + u];
-        cb[u] = ldsf[4 * o_ctr1 + vbase + k0 + u];
+      for (int k = 0; k < kWgSlab; ++k) c[k] = lds[rdA + k];
+      const float4 cxa = lds[rdC4], cxb = lds[rdC4 + 1];
+      const float cxs[kWgSlab] = {cxa.x, cxa.y, cxa.z, cxa.w, cxb.x, cxb.y, cxb.z, cxb.w};
+#pragma unroll
+      for (int k = 0; k < kWgSlab; ++k) {
+        X = X + cxs[k];
+        Wa = (Wa + v2f_t{c[k].x, c[k].y}) + v2f_t{c[k].z, c[k].w};
       }
-      if (more) {
-#pragma unroll
-        for (int u = 4; u < 8; ++u) {
-          c[u] = lds[o_ctr4 + vbase + k0 + u];
-          cb[u] = ldsf[4 * o_ctr1 + vbase + k0 + u];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool on = (k0 + u) < deg;
-        const float Xn = X + c[u].x, W1n = (W1 + c[u].y) + c[u].w, W2n = (W2 + c[u].z) + cb[u];
-        X = on ? Xn : X, W1 = on ? W1n : W1, W2 = on ? W2n : W2;
-      }
-      if (more) {
-#pragma unroll
-        for (int u = 4; u < 8; ++u) {
-          const bool on = (k0 + u) < deg;
-          const float Xn = X + c[u].x, W1n = (W1 + c[u].y) + c[u].w, W2n = (W2 + c[u].z) + cb[u];
-          X = on ? Xn : X, W1 = on ? W1n : W1, W2 = on ? W2n : W2;
+    }
+    if (chain > kWgSlab) {  // wave-uniform: some vertex of this wave has more than 8 incident edges
+      for (int k = kWgSlab; k < chain; ++k) {
+        if (k < deg) {
+          const float4 c = lds[o_ovfA + ovf_base + k];
+          X = X + ldsf[f_ovfC + ovf_base + k];
+          Wa = (Wa + v2f_t{c.x, c.y}) + v2f_t{c.z, c.w};
         }
       }
     }
-    // ---- vertex update: proxL1 (cc:147-151), extragradient (cc:160-171) --------------------------
-    const float xn = prox_l1(p.x_min, p.x_max, p.step_x, lam_w, X, data);
+    // ---- vertex update: proxL1 (cc:147-151, h:179-197), extragradient (cc:160-171) --------------------------
+    const float diff = X - data;
+    float xn = (diff > thr) ? X - thr : ((diff < -thr) ? X + thr : data);
+    xn = (xn < p.x_min) ? p.x_min : xn;
+    xn = (xn > p.x_max) ? p.x_max : xn;
     float nb = xn + p.theta * (xn - x);
     nb = (nb < p.x_min) ? p.x_min : nb;
     nb = (nb > p.x_max) ? p.x_max : nb;
-    const float w1bn = W1 + p.theta * (W1 - w1);
-    const float w2bn = W2 + p.theta * (W2 - w2);
-    if (is_tail) {
-      if (publishes) {
-        v4i_t o;
-        o.x = __float_as_int(nb), o.y = __float_as_int(w1bn), o.z = __float_as_int(w2bn), o.w = (int)(s + 1u);
-        const int so = ((s + 1u) & 1u) ? par : 0;
-        __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
-        if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
-      }
-      lds[wbase + loc] = make_float4(nb, w1bn, w2bn, 0.0f);
+    const v2f_t wbn = Wa + p.theta * (Wa - w12);
+    if (pub_lane) {
+      v4i_t o;
+      o.x = __float_as_int(nb), o.y = __float_as_int(wbn.x), o.z = __float_as_int(wbn.y), o.w = (int)(s + 1u);
+      const int so = ((s + 1u) & 1u) ? par : 0;
+      __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
+      if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
     }
-    x_prev = x, w1_prev = w1, w2_prev = w2;  // step()'s prev copy, cc:37-42
-    x = xn, w1 = W1, w2 = W2;
-    xb = nb, w1b = w1bn, w2b = w2bn;
+    lds[wbase + loc] = make_float4(nb, wbn.x, wbn.y, 0.0f);  // every lane of the vertex: same value, same address
+    x_prev = x, w_prev = w12;  // step()'s prev copy, cc:37-42
+    x = xn, w12 = Wa;
+    xb = nb, wb12 = wbn;
     if (PROBE) {
       const unsigned pr_t4 = (unsigned)clock64();
-      if ((tid & 63) == 0 && probe) {  // per wave and step: {sleep, poll, barrier wait, compute, polls, step start}
-        unsigned* o = probe + ((size_t)(wg * W + wv) * n_iters + it) * 8;
-        o[0] = pr_t1 - pr_t0, o[1] = pr_t2 - pr_t1, o[2] = pr_t3 - (wave_fetches ? pr_t2 : pr_t0), o[3] = pr_t4 - pr_t3;
-        o[4] = pr_polls, o[5] = pr_t0, o[6] = (unsigned)wall_clock64(), o[7] = (unsigned)wave_fetches;
+      if (lane == 0 && probe) {  // {-, -, barrier wait, compute, -, step start, 100 MHz clock, 0 = compute wave}
+        unsigned* o = probe + ((size_t)(wg * (W + 1) + wv) * n_iters + it) * 8;
+        o[0] = 0, o[1] = 0, o[2] = pr_t3 - pr_t0, o[3] = pr_t4 - pr_t3;
+        o[4] = 0, o[5] = pr_t0, o[6] = (unsigned)wall_clock64(), o[7] = 0u;
       }
-      pr_polls = 0;
       pr_t0 = pr_t4;
     }
   }
 
-  if (timed_out || wg_flag != 0) {
-    if (tid == 0) {
-      __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      atomicOr(err, 2);
-    }
-    return;  // the run is reported as failed; the host takes it back
-  }
+  if (timed_out) return;  // the communication wave reports; the host takes the run back
 
+  // The results go to the OTHER copies of the state arrays (the host swaps the roles only when the whole run succeeded)
   if (is_tail) {
-    vstate_out[pv] = make_float4(x, w1, w2, data);
-    bar_out[pv] = make_float4(xb, w1b, w2b, 0.0f);
-    vprev[pv] = make_float4(x_prev, w1_prev, w2_prev, 0.0f);
+    vstate_out[pv] = make_float4(x, w12.x, w12.y, data);
+    bar_out[pv] = make_float4(xb, wb12.x, wb12.y, 0.0f);
+    vprev[pv] = make_float4(x_prev, w_prev.x, w_prev.y, 0.0f);
     float* const export_out = tail->export_out;
     float* const photo_err = tail->photo.err;
     if (export_out || photo_err) {
@@ -837,8 +922,8 @@ k_persistent_wg(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
       }
     }
   }
-  if (active) hq_out[slot] = make_float4(q1, q2, q3, beta);
-  if (!ok) atomicOr(err, 1);
+  if (active) hq_out[slot] = make_float4(q1, q23.x, q23.y, beta);
+  if (!ok && active) atomicOr(err, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1550,16 +1635,17 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
                   &abort_flag, &perm, &tail};
   if (form == 3) {  // patch-per-workgroup form: n_waves / wave_begin count WORKGROUPS
     int wgx = (n_waves + xcds - 1) / xcds;
-    const dim3 g3((unsigned)(wgx * 8)), b3((unsigned)(64 * a.wg_waves));
+    const dim3 g3((unsigned)(wgx * 8)), b3((unsigned)(64 * (a.wg_waves + 1)));  // + the communication wave
     int lcap = a.wg_lcap, rcap = a.wg_rcap;
     const int32_t *w0 = a.wg_slot, *w1 = a.wg_vid, *w3 = a.wg_nbr, *w4 = a.wg_fetch, *w5 = a.wg_info, *w6 = a.wg_wave_chain;
     const uint32_t* w2 = a.wg_meta;
     unsigned* probe = a.probe;
+    int poll_gap = a.wg_poll_gap;
     void* wargs[] = {&wave_begin, &n_waves, &wgx, &lcap, &rcap, &w0, &w1, &w2, &w3, &w4, &w5, &w6, &hrec, &hq, &vstate,
                      &hq_out, &vstate_out, &vaux, &bin, &bout, &vprev, &xbuf, &rec_bytes, &dual, &tag0, &n_iters,
-                     &max_spins, &presleep, &pp, &err, &abort_flag, &perm, &tail, &probe};
+                     &max_spins, &presleep, &poll_gap, &pp, &err, &abort_flag, &perm, &tail, &probe};
     const int T = 64 * a.wg_waves;
-    const unsigned lds3 = 16u * (unsigned)(2 * (lcap + rcap) + T + kWgPad) + 4u * (unsigned)(T + kWgPad);
+    const unsigned lds3 = 16u * (unsigned)(2 * (lcap + rcap) + lcap * kWgSlab + T) + 4u * (unsigned)(lcap * kWgSlab + T);
     const void* f3 = probe ? (const void*)k_persistent_wg<true> : (const void*)k_persistent_wg<false>;
     if (cooperative) return (int)hipLaunchCooperativeKernel(f3, g3, b3, wargs, lds3, stream);
     return (int)hipLaunchKernel(f3, g3, b3, wargs, lds3, stream);

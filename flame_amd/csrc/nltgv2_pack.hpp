@@ -122,7 +122,7 @@ inline void build_wg_rows(PackedLayout* L, const std::vector<int32_t>& order_m, 
   L->wg_count = 0, L->wg_lcap = 0, L->wg_rcap = 0;
   L->wg_slot.clear(), L->wg_vid.clear(), L->wg_meta.clear(), L->wg_nbr.clear(), L->wg_fetch.clear();
   L->wg_info.clear(), L->wg_wave_chain.clear(), L->comp_wg.clear();
-  if (wg_waves < 1 || wg_waves > 16 || L->max_degree > kWave || V <= 0) return;
+  if (wg_waves < 1 || wg_waves > 15 || L->max_degree > kWave || V <= 0) return;
   const int32_t T = kWave * wg_waves;
   const size_t n_packed = static_cast<size_t>(L->n_slices) * kWave;
   std::vector<int32_t> v_wg(n_packed, -1), v_loc(n_packed, -1);
@@ -212,7 +212,7 @@ inline void build_wg_rows(PackedLayout* L, const std::vector<int32_t>& order_m, 
       }
     }
   }
-  L->wg_ok = true;
+  L->wg_ok = L->wg_rcap <= 2 * kWave;  // the communication wave fetches at most two records per lane
 }
 
 inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L, int wg_waves = 4) {

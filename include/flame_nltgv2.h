@@ -262,8 +262,10 @@ enum {
                                         n in 1..64 = (n-1) x 64 cycles */
   FLAME_NLTGV2_OPT_XCDS = 9,         /* persistent run: number of XCDs (of 8) the waves are spread over: 0 (default) =
                                         one XCD for graphs small enough to run there, else all eight; 1..8 */
-  FLAME_NLTGV2_OPT_WG_WAVES = 11,    /* patch-per-workgroup persistent form: waves per workgroup (1,2,4 (default),8,16);
+  FLAME_NLTGV2_OPT_WG_WAVES = 11,    /* patch-per-workgroup persistent form: compute waves per workgroup (1,2,4 (default),8);
                                         takes effect at the next upload_graph / sync_graph */
+  FLAME_NLTGV2_OPT_POLL_GAP = 13,    /* patch-per-workgroup form: pause between the communication wave's pipelined polls:
+                                        0 (default) = built-in, n in 1..64 = (n-1) x 64 cycles */
   FLAME_NLTGV2_OPT_PROBE = 12,       /* 1 = the patch-per-workgroup kernel records a per-wave, per-step cycle probe
                                         (8 words: sleep, poll, barrier wait, compute cycles, polls, step start, 100 MHz
                                         clock, fetch flag), read with flame_nltgv2_read_probe; 0 (default) = off */

@@ -274,7 +274,7 @@ static int replay(HostGraph& hg, int wg_waves, int n_iters, const nltgv2_params&
 int main() {
   const nltgv2_params p = {0.1f, 0.001f, 125.0f, 0.25f, 0.0f, 10.0f};
   for (int frames : {1, 3}) {
-    for (int w : {1, 2, 4, 8, 16}) {
+    for (int w : {1, 2, 4, 8}) {
       HostGraph g = make_graph(61, 47, frames, 1234 + frames);
       const int rc = replay(g, w, 6, p);
       if (rc) {

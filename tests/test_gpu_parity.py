@@ -127,7 +127,7 @@ def test_internal_steps_individually(env):
     [(5, 2), (9, 1)], [(5, 2), (9, 2)], [(5, 2), (9, 4)], [(5, 2), (9, 8)], [(5, 3), (9, 1)], [(5, 2), (8, 1)], [(5, 2), (8, 21)],
     [(5, 3), (8, 9)], [(5, 2), (9, 1), (6, 0)],
     [(5, 4)], [(5, 4), (6, 0)], [(5, 4), (6, 2)], [(5, 4), (9, 1)], [(5, 4), (9, 2)], [(5, 4), (9, 8)], [(5, 4), (8, 1)], [(5, 4), (8, 12)],
-    [(11, 1), (5, 4)], [(11, 2), (5, 4)], [(11, 8), (5, 4)], [(11, 16), (5, 4)], [(11, 16), (5, 4), (9, 1), (6, 0)],
+    [(11, 1), (5, 4)], [(11, 2), (5, 4)], [(11, 8), (5, 4)], [(11, 8), (5, 4), (13, 1)], [(11, 2), (5, 4), (9, 1), (6, 0), (13, 5)],
 ])
 def test_launch_configurations_are_bit_identical(env, opts):
     """waves per workgroup (opt 3), slot chunk (opt 4), hipGraph on/off (opt 2), persistent single

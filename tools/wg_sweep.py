@@ -14,7 +14,7 @@ import torch  # noqa: F401  (one HIP runtime per process)
 import flame_amd
 from flame_amd import synth
 from flame_amd.regularizer import (OPT_PERSISTENT, OPT_PRESLEEP, OPT_XCDS, OPT_WG_WAVES, OPT_PROBE, OPT_DUAL_PUBLISH,
-                                   RUN_PATHS)
+                                   OPT_POLL_GAP, RUN_PATHS)
 
 params = flame_amd.Params()
 N = 200
@@ -51,23 +51,21 @@ def probe_summary(g, opts, label):
     finally:
         r.close()
     p = p[:, 20:, :]
-    fetch = p[:, 0, 7] == 1
-    res = {"label": label, "waves": int(p.shape[0]), "fetch_waves": int(fetch.sum())}
-    for name, sel in (("fetch_waves", fetch), ("other_waves", ~fetch)):
-        if sel.sum() == 0:
-            continue
-        q = p[sel]
-        d = {"sleep": float(q[:, :, 0].mean()), "poll": float(q[:, :, 1].mean()), "barrier_wait": float(q[:, :, 2].mean()),
-             "compute": float(q[:, :, 3].mean()), "polls_per_step": float(q[:, :, 4].mean())}
-        if name == "other_waves":
-            d["sleep"] = d["poll"] = 0.0
-        d["step_total"] = d["sleep"] + d["poll"] + d["barrier_wait"] + d["compute"]
-        res[name + "_cycles"] = {k: round(v, 1) for k, v in d.items()}
-    # step period from the 100 MHz clock (word 6), first wave
+    comm = p[:, 0, 7] == 1
+    res = {"label": label, "waves": int(p.shape[0]), "comm_waves": int(comm.sum())}
+    q = p[comm]
+    if q.size:
+        res["comm_wave_cycles"] = {"presleep": round(float(q[:, :, 0].mean()), 1), "poll": round(float(q[:, :, 1].mean()), 1),
+                                   "barrier_wait": round(float(q[:, :, 2].mean()), 1),
+                                   "poll_rounds_per_step": round(float(q[:, :, 4].mean()), 2)}
+    q = p[~comm]
+    if q.size:
+        res["compute_wave_cycles"] = {"barrier_wait": round(float(q[:, :, 2].mean()), 1), "compute": round(float(q[:, :, 3].mean()), 1),
+                                      "compute_p10": round(float(np.percentile(q[:, :, 3], 10)), 1),
+                                      "compute_p90": round(float(np.percentile(q[:, :, 3], 90)), 1)}
     t = p[0, :, 6]
     dt = np.diff(t) & 0xffffffff
     res["step_period_us_100MHz_clock"] = round(float(dt.mean()) / 100.0, 4)
-    # cycles per step from the shader clock (word 5)
     c = p[0, :, 5]
     dc = np.diff(c) & 0xffffffff
     res["step_period_shader_cycles"] = round(float(dc.mean()), 1)
@@ -86,19 +84,20 @@ def main():
         row = {"config": cfg, "V": int(g["V"]), "E": int(g["E"]), "he_us_per_iter": round(us_he, 3), "wg": []}
         print(cfg, "V", g["V"], "he", f"{us_he:.3f} us/it", path, flush=True)
         best = None
-        for W in ((4,) if quick else (2, 4, 8, 16)):
-            for ps in ((3,) if quick else (1, 2, 4, 7)):
+        for W in ((4,) if quick else (1, 2, 4, 8)):
+            for ps in ((7,) if quick else (1, 5, 9, 13)):
                 for xc in ((0,) if (quick or g["V"] > 4000) else (0, 1, 8)):
-                    for dual in ((1,) if quick else (1, 0)):
-                        if dual == 0 and ps != 2:
+                    for gap in ((0,) if quick else (1, 2, 3, 5)):
+                        dual = 1
+                        if xc != 0 and (gap != 2 or ps != 5):
                             continue
-                        opts = [(OPT_PERSISTENT, 4), (OPT_WG_WAVES, W), (OPT_PRESLEEP, ps), (OPT_XCDS, xc), (OPT_DUAL_PUBLISH, dual)]
+                        opts = [(OPT_PERSISTENT, 4), (OPT_WG_WAVES, W), (OPT_PRESLEEP, ps), (OPT_XCDS, xc), (OPT_POLL_GAP, gap)]
                         try:
                             us, path, _, same = timed(g, opts, want=want)
                         except Exception as e:  # noqa: BLE001
-                            print("  W", W, "ps", ps, "xcds", xc, "ERR", e, flush=True)
+                            print("  W", W, "ps", ps, "xcds", xc, "gap", gap, "ERR", e, flush=True)
                             continue
-                        rec = {"W": W, "presleep": ps, "xcds": xc, "dual": dual, "us_per_iter": round(us, 3), "path": path, "bit_identical": same}
+                        rec = {"W": W, "presleep": ps, "xcds": xc, "gap": gap, "us_per_iter": round(us, 3), "path": path, "bit_identical": same}
                         row["wg"].append(rec)
                         print("  ", json.dumps(rec), flush=True)
                         if path == "persistent-wg" and same and (best is None or us < best[0]):
