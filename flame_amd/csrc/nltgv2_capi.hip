@@ -30,6 +30,7 @@ constexpr int kGraphChunk = 256;      // steps per captured hipGraph (even: keep
 constexpr int kMaxCachedGraphs = 6;
 constexpr int kHeWavesPerCu = 24;      // residency cap of k_persistent_he (<= 64 VGPRs: the hardware admits 32)
 constexpr int kTvLdsWavesPerCu = 16;   // ... with the slot constants in LDS (<= 128 VGPRs -> 4 waves per SIMD; 10 KB LDS per wave = all 160 KB)
+constexpr size_t kXbufBytesPerVertex = 4 * 128 + 4;  // exchange buffers: four record arrays of up to 128 B per vertex + XCC table
 constexpr int kWgPollGap = 2;          // x64 cycles between the pipelined polls of the communication wave
 constexpr int kWgWavesPerCu = 24;      // residency cap of k_persistent_wg (<= 64 VGPRs; its LDS use is a few KB per workgroup)
 constexpr int kTvWavesPerCu = 8;       // residency of k_persistent_tv (<= 256 VGPRs -> 2 waves per SIMD)
@@ -80,6 +81,10 @@ struct flame_nltgv2_ctx {
   int opt_presleep = 0;  // 0: auto (kPreSleep*); n > 0: (n - 1) x 64 cycles
   int opt_wg_waves = 4;  // waves per workgroup of the patch-per-workgroup form (layout (E); applies at the next upload)
   int opt_poll_gap = 0;  // patch-per-workgroup form: 0 = default, n > 0 = (n - 1) x 64 cycles between pipelined polls
+  int opt_wg_rec = 0x14;  // patch-per-workgroup form: log2(bytes per exchange record) | copies per publish << 4
+  mutable int wg_occ = 0;            // resident workgroups of k_persistent_wg per CU for the current layout
+  mutable uint64_t wg_occ_topo = ~0ull;
+  int opt_pw_roles = 0;  // patch-per-wave form: 0 = one wave per patch, 1 = + a communication wave, 2 = roles from the SIMD ids
   int opt_probe = 0;     // > 0: k_persistent_wg records a per-wave, per-step cycle probe (flame_nltgv2_read_probe)
   size_t probe_words = 0;
   int opt_tv_lds = 1;  // 0 registers, 1 auto (LDS when the register form is not resident in one launch), 2 LDS
@@ -222,6 +227,7 @@ void refresh_args(flame_nltgv2_ctx* ctx) {
   f.tv_meta = (uint32_t*)ctx->tv_meta.p, f.tv_wave = (uint32_t*)ctx->tv_wave.p;
   f.wg_count = ctx->L.wg_ok ? ctx->L.wg_count : 0;
   f.wg_waves = ctx->L.wg_waves, f.wg_lcap = ctx->L.wg_lcap, f.wg_rcap = ctx->L.wg_rcap;
+  f.wg_slab_slots = ctx->L.wg_slab_slots;
   f.wg_slot = (int32_t*)ctx->wg_slot.p, f.wg_vid = (int32_t*)ctx->wg_vid.p, f.wg_meta = (uint32_t*)ctx->wg_meta.p;
   f.wg_nbr = (int32_t*)ctx->wg_nbr.p, f.wg_fetch = (int32_t*)ctx->wg_fetch.p, f.wg_info = (int32_t*)ctx->wg_info.p;
   f.wg_wave_chain = (int32_t*)ctx->wg_wave_chain.p;
@@ -292,7 +298,12 @@ int plan_persistent(const flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* 
   const bool tv_lds = ctx->opt_tv_lds == 2 || (ctx->opt_tv_lds == 1 && L.tv_waves > kTvWavesPerCu * cus);
   const int he_cap = kHeWavesPerCu * cus, tv_cap = (tv_lds ? kTvLdsWavesPerCu : kTvWavesPerCu) * cus;
   if (use_tv_lds) *use_tv_lds = tv_lds ? 1 : 0;
-  const int wg_cap = (kWgWavesPerCu / (L.wg_waves + 1)) * cus;  // in workgroups (compute waves + the communication wave)
+  if (L.wg_ok && ctx->wg_occ_topo != ctx->topo) {  // ask the runtime once per topology (block size and LDS use vary with it)
+    ctx->wg_occ = wg_blocks_per_cu(ctx->f);
+    ctx->wg_occ_topo = ctx->topo;
+  }
+  const int wg_wpb = (L.wg_waves == 1 && ctx->opt_pw_roles == 0) ? 1 : L.wg_waves + 1;  // waves per workgroup
+  const int wg_cap = std::min(kWgWavesPerCu / wg_wpb, ctx->wg_occ) * cus;  // in workgroups
   const bool he_fits = L.he_ok && L.he_waves > 0 && L.he_waves <= he_cap;
   const bool tv_fits = L.tv_ok && L.tv_waves > 0 && L.tv_waves <= tv_cap;
   if (ctx->opt_persistent == 2 && !L.he_ok) return 0;
@@ -483,7 +494,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   if (form != 0) {
     // tags must stay unique: clear the record buffers long before the 28-bit tag of the XCC table wraps
     if ((uint64_t)ctx->tag_next + (uint64_t)n >= 0x07ff0000ull) {
-      const size_t bytes = 68 * (size_t)ctx->L.n_slices * kWave;
+      const size_t bytes = kXbufBytesPerVertex * (size_t)ctx->L.n_slices * kWave;
       HIPCHK(ctx, hipMemsetAsync(ctx->xbuf.p, 0, bytes, ctx->stream));
       ctx->tag_next = 1;
     }
@@ -517,21 +528,29 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       // this would need cost more than the shorter hop saves).
       const int cus_per_xcd = ctx->prop.multiProcessorCount / 8;
       const int unit = form == 3 ? ctx->L.wg_waves : 1;  // waves per launch unit
-      const int xcds = ctx->opt_xcds > 0 ? ctx->opt_xcds : (form != 2 && gr.count * unit <= 8 * cus_per_xcd) ? 1 : 8;
-      const int presleep = ctx->opt_presleep > 0 ? ctx->opt_presleep - 1
+      // (patch-per-wave form: one XCD while its CUs get at most two patches each)
+      const bool one_xcd = form == 3 && ctx->L.wg_waves == 1 ? gr.count <= 2 * cus_per_xcd : (form != 2 && gr.count * unit <= 8 * cus_per_xcd);
+      const int xcds = ctx->opt_xcds > 0 ? ctx->opt_xcds : one_xcd ? 1 : 8;
+      const int presleep = (form == 3 && ctx->L.wg_waves == 1 && ctx->opt_presleep == 0) ? -1  // adaptive, in the kernel
+                           : ctx->opt_presleep > 0 ? ctx->opt_presleep - 1
                            : form == 2                ? kPreSleepTv
                            : xcds == 1                ? kPreSleepHeOneXcd
                            : gr.count * unit > 12 * ctx->prop.multiProcessorCount ? kPreSleepHeDense
                                                                             : kPreSleepHe;
       const unsigned spins_arg = ctx->opt_fault > 0 ? (0x80000000u | (unsigned)ctx->opt_fault) : kMaxSpins;
       if (form == 3) {
-        ctx->f.wg_poll_gap = ctx->opt_poll_gap > 0 ? ctx->opt_poll_gap - 1 : kWgPollGap;
+        ctx->f.wg_poll_gap = ctx->opt_poll_gap > 0 ? (((ctx->opt_poll_gap & 0xff) - 1) | (ctx->opt_poll_gap & 0xf00)) : kWgPollGap;
+        ctx->f.wg_rec_shift = ctx->opt_wg_rec & 15, ctx->f.wg_rec_rep = ctx->opt_wg_rec >> 4;
+        ctx->f.pw_roles = ctx->opt_pw_roles;
         ctx->f.probe = nullptr;
         if (ctx->opt_probe) {
-          const size_t words = (size_t)ctx->L.wg_count * (ctx->L.wg_waves + 1) * (size_t)n * 8;
+          const size_t words1 = (size_t)ctx->L.wg_count * ((ctx->L.wg_waves == 1 && ctx->opt_pw_roles == 0) ? 1 : ctx->L.wg_waves + 1) * (size_t)n * 8;
+          const size_t words = words1 + (size_t)ctx->L.wg_count * (size_t)n * 128;  // + hop latency per fetched record
           rc = ensure(ctx, ctx->probe, words * sizeof(unsigned));
           if (rc) return rc;
+          HIPCHK(ctx, hipMemsetAsync(ctx->probe.p, 0xff, words * sizeof(unsigned), ctx->stream));
           ctx->f.probe = (unsigned*)ctx->probe.p;
+          ctx->f.probe_lat_base = words1;
           ctx->probe_words = words;
         }
       }
@@ -774,8 +793,21 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
       ctx->opt_wg_waves = value;
       return 0;
     case FLAME_NLTGV2_OPT_POLL_GAP:
-      if (value < 0 || value > 64) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      if (value < 0 || value > 0xfff) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_poll_gap = value;
+      return 0;
+    case FLAME_NLTGV2_OPT_WG_RECORD: {
+      const int sh = value & 15, rp = value >> 4;
+      if (sh < 4 || sh > 7 || rp < 1 || rp > (1 << (sh - 4))) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_wg_rec = value;
+      return 0;
+    }
+    case FLAME_NLTGV2_OPT_PW_ROLES:
+      if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_pw_roles = value;
+      ctx->f.pw_roles = value;
+      ctx->wg_occ_topo = ~0ull;
+      ctx->coop_checked_key = ~0ull;
       return 0;
     case FLAME_NLTGV2_OPT_PROBE:
       ctx->opt_probe = value ? 1 : 0;
@@ -848,7 +880,7 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
       {&ctx->vstate, sizeof(float4) * n_packed}, {&ctx->vaux, sizeof(float2) * n_packed},
       {&ctx->hq_alt, sizeof(float4) * n_slots}, {&ctx->vstate_alt, sizeof(float4) * n_packed}, {&ctx->photo_err, fV},
       {&ctx->bar0, sizeof(float4) * n_packed}, {&ctx->bar1, sizeof(float4) * n_packed},
-      {&ctx->vprev, sizeof(float4) * n_packed}, {&ctx->xbuf, 68 * n_packed + 64},
+      {&ctx->vprev, sizeof(float4) * n_packed}, {&ctx->xbuf, kXbufBytesPerVertex * n_packed + 64},
       {&ctx->abort_flag, sizeof(int)}, {&ctx->he_slot, sizeof(int32_t) * L.he_slot.size()},
       {&ctx->he_vid, sizeof(int32_t) * L.he_vid.size()}, {&ctx->he_meta, sizeof(uint32_t) * L.he_meta.size()},
       {&ctx->he_wave_chain, sizeof(int32_t) * L.he_wave_chain.size()},
@@ -905,7 +937,7 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
   if (rc) return rc;
   HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, sizeof(int), ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->abort_flag.p, 0, sizeof(int), ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(ctx->xbuf.p, 0, 68 * n_packed + 64, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->xbuf.p, 0, kXbufBytesPerVertex * n_packed + 64, ctx->stream));
   // empty slots / padding vertices of the second copies: zero, as the packing kernels write them in the first
   HIPCHK(ctx, hipMemsetAsync(ctx->hq_alt.p, 0, sizeof(float4) * n_slots, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->vstate_alt.p, 0, sizeof(float4) * n_packed, ctx->stream));

@@ -92,7 +92,8 @@ struct PackedLayout {
   std::vector<uint32_t> wg_meta;       // [wg_count*T] first lane | deg<<6 | local index<<13 | flags<<24
   std::vector<int32_t> wg_nbr;         // [wg_count*T] neighbour: local index, or 0x80000000 | fetch index
   std::vector<int32_t> wg_fetch;       // [wg_count*T] record id fetched by this lane, -1 none
-  std::vector<int32_t> wg_info;        // [wg_count*4] first record id, fetched records, local vertices, 0
+  std::vector<int32_t> wg_info;        // [wg_count*4] first record id, fetched records, local vertices, slab stride
+  int32_t wg_slab_slots = 0;           // most (local vertices x slab stride) of any workgroup (LDS sizing, wg_waves == 1)
   std::vector<int32_t> wg_wave_chain;  // [wg_count*wg_waves] max(1, max degree) of the wave's vertices
   std::vector<int32_t> comp_wg;        // [n_comp+1] first workgroup of each component
 };
@@ -212,7 +213,18 @@ inline void build_wg_rows(PackedLayout* L, const std::vector<int32_t>& order_m, 
       }
     }
   }
-  L->wg_ok = L->wg_rcap <= 2 * kWave;  // the communication wave fetches at most two records per lane
+  // contribution slab of the patch-per-wave form: every vertex of a patch gets `stride` slots, stride = the patch's
+  // largest degree rounded up to a multiple of 4 (at least 8): the slots a vertex does not use hold -0.0f
+  L->wg_slab_slots = 0;
+  for (int32_t wg = 0; wg < L->wg_count; ++wg) {
+    int32_t ch = 1;
+    for (int32_t w = 0; w < wg_waves; ++w) ch = std::max(ch, L->wg_wave_chain[static_cast<size_t>(wg) * wg_waves + w]);
+    const int32_t stride = std::max(8, (ch + 3) & ~3);
+    L->wg_info[static_cast<size_t>(wg) * 4 + 3] = stride;
+    L->wg_slab_slots = std::max(L->wg_slab_slots, stride * L->wg_info[static_cast<size_t>(wg) * 4 + 2]);
+  }
+  // the communication wave fetches at most two records per lane (one in the patch-per-wave form, wg_waves == 1)
+  L->wg_ok = L->wg_rcap <= (wg_waves == 1 ? kWave : 2 * kWave);
 }
 
 inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L, int wg_waves = 4) {

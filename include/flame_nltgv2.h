@@ -266,6 +266,10 @@ enum {
                                         takes effect at the next upload_graph / sync_graph */
   FLAME_NLTGV2_OPT_POLL_GAP = 13,    /* patch-per-workgroup form: pause between the communication wave's pipelined polls:
                                         0 (default) = built-in, n in 1..64 = (n-1) x 64 cycles */
+  FLAME_NLTGV2_OPT_WG_RECORD = 14,   /* patch-per-workgroup form: layout of a published record: (log2 of the bytes reserved
+                                        per record, 4..7) | (16-byte copies written per publish, 1..bytes/16) << 4 */
+  FLAME_NLTGV2_OPT_PW_ROLES = 15,  /* patch-per-wave form (OPT_WG_WAVES = 1): 1 (default) = a patch's two waves choose who computes
+                                        from their SIMD ids (spreads the compute waves over a CU's SIMDs), 0 = wave 0 computes */
   FLAME_NLTGV2_OPT_PROBE = 12,       /* 1 = the patch-per-workgroup kernel records a per-wave, per-step cycle probe
                                         (8 words: sleep, poll, barrier wait, compute cycles, polls, step start, 100 MHz
                                         clock, fetch flag), read with flame_nltgv2_read_probe; 0 (default) = off */
