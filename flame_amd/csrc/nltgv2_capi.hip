@@ -31,8 +31,7 @@ constexpr int kMaxCachedGraphs = 6;
 constexpr int kHeWavesPerCu = 24;      // residency cap of k_persistent_he (<= 64 VGPRs: the hardware admits 32)
 constexpr int kTvLdsWavesPerCu = 16;   // ... with the slot constants in LDS (<= 128 VGPRs -> 4 waves per SIMD; 10 KB LDS per wave = all 160 KB)
 constexpr size_t kXbufBytesPerVertex = 4 * 128 + 4;  // exchange buffers: four record arrays of up to 128 B per vertex + XCC table
-constexpr int kWgPollGap = 2;          // x64 cycles between the pipelined polls of the communication wave
-constexpr int kWgWavesPerCu = 24;      // residency cap of k_persistent_wg (<= 64 VGPRs; its LDS use is a few KB per workgroup)
+constexpr int kPvPollGap = 1;          // s_sleep 1 between the polls of k_persistent_pv (measured: 1 beats 0 by 1-3 %)
 constexpr int kTvWavesPerCu = 8;       // residency of k_persistent_tv (<= 256 VGPRs -> 2 waves per SIMD)
 constexpr int kDualMinWavesPerCu = 0;  // auto: exchange through the XCD's L2 when more waves than this share a CU
 // x64-cycle sleep between publishing and the first neighbour poll (measured optimum, r01 sweep: he 6 at
@@ -79,13 +78,10 @@ struct flame_nltgv2_ctx {
   float export_scale = 1.0f;
   int opt_fault = 0;     // test hook: > 0 = the next persistent runs time out after this many spins
   int opt_presleep = 0;  // 0: auto (kPreSleep*); n > 0: (n - 1) x 64 cycles
-  int opt_wg_waves = 4;  // waves per workgroup of the patch-per-workgroup form (layout (E); applies at the next upload)
-  int opt_poll_gap = 0;  // patch-per-workgroup form: 0 = default, n > 0 = (n - 1) x 64 cycles between pipelined polls
-  int opt_wg_rec = 0x14;  // patch-per-workgroup form: log2(bytes per exchange record) | copies per publish << 4
-  mutable int wg_occ = 0;            // resident workgroups of k_persistent_wg per CU for the current layout
-  mutable uint64_t wg_occ_topo = ~0ull;
-  int opt_pw_roles = 0;  // patch-per-wave form: 0 = one wave per patch, 1 = + a communication wave, 2 = roles from the SIMD ids
-  int opt_probe = 0;     // > 0: k_persistent_wg records a per-wave, per-step cycle probe (flame_nltgv2_read_probe)
+  int opt_poll_gap = 0;  // patch-per-wave form: 0 = default (kPvPollGap), 1 = no sleep between polls, 2 = one s_sleep
+  mutable int pv_occ = 0;            // patches of k_persistent_pv the runtime keeps resident per CU for the current layout
+  mutable uint64_t pv_occ_topo = ~0ull;
+  int opt_probe = 0;     // > 0: k_persistent_pv records a per-patch, per-step cycle probe (flame_nltgv2_read_probe)
   size_t probe_words = 0;
   int opt_tv_lds = 1;  // 0 registers, 1 auto (LDS when the register form is not resident in one launch), 2 LDS
   uint32_t tag_next = 1;  // persistent run: tag of the current bar values (monotonic)
@@ -120,7 +116,7 @@ struct flame_nltgv2_ctx {
   std::vector<float> h_terms;
   DevBuf hq_alt, vstate_alt;  // the other copies of hq / vstate: a persistent run writes there, success swaps the roles
   DevBuf xbuf, abort_flag, he_slot, he_vid, he_meta, he_wave_chain, tv_slot, tv_vid, tv_meta, tv_wave;
-  DevBuf wg_slot, wg_vid, wg_meta, wg_nbr, wg_fetch, wg_info, wg_wave_chain, probe;
+  DevBuf wg_slot, wg_vid, wg_meta, wg_nbr, wg_fetch, wg_info, probe;
   // misc
   DevBuf err, cost_out, img_ref, img_cmp, photo_err, r_tris, r_valid, r_keys, r_img, r_cov, r_vtx, r_val;
   int img_rows = 0, img_cols = 0, img_step = 0;
@@ -226,11 +222,9 @@ void refresh_args(flame_nltgv2_ctx* ctx) {
   f.tv_slot = (int32_t*)ctx->tv_slot.p, f.tv_vid = (int32_t*)ctx->tv_vid.p;
   f.tv_meta = (uint32_t*)ctx->tv_meta.p, f.tv_wave = (uint32_t*)ctx->tv_wave.p;
   f.wg_count = ctx->L.wg_ok ? ctx->L.wg_count : 0;
-  f.wg_waves = ctx->L.wg_waves, f.wg_lcap = ctx->L.wg_lcap, f.wg_rcap = ctx->L.wg_rcap;
-  f.wg_slab_slots = ctx->L.wg_slab_slots;
+  f.wg_lcap = ctx->L.wg_lcap, f.wg_slab_slots = ctx->L.wg_slab_slots;
   f.wg_slot = (int32_t*)ctx->wg_slot.p, f.wg_vid = (int32_t*)ctx->wg_vid.p, f.wg_meta = (uint32_t*)ctx->wg_meta.p;
   f.wg_nbr = (int32_t*)ctx->wg_nbr.p, f.wg_fetch = (int32_t*)ctx->wg_fetch.p, f.wg_info = (int32_t*)ctx->wg_info.p;
-  f.wg_wave_chain = (int32_t*)ctx->wg_wave_chain.p;
   f.abort_flag = (int*)ctx->abort_flag.p;
   f.err = (int*)ctx->err.p;
 }
@@ -298,21 +292,22 @@ int plan_persistent(const flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* 
   const bool tv_lds = ctx->opt_tv_lds == 2 || (ctx->opt_tv_lds == 1 && L.tv_waves > kTvWavesPerCu * cus);
   const int he_cap = kHeWavesPerCu * cus, tv_cap = (tv_lds ? kTvLdsWavesPerCu : kTvWavesPerCu) * cus;
   if (use_tv_lds) *use_tv_lds = tv_lds ? 1 : 0;
-  if (L.wg_ok && ctx->wg_occ_topo != ctx->topo) {  // ask the runtime once per topology (block size and LDS use vary with it)
-    ctx->wg_occ = wg_blocks_per_cu(ctx->f);
-    ctx->wg_occ_topo = ctx->topo;
+  if (L.wg_ok && ctx->pv_occ_topo != ctx->topo) {  // ask the runtime once per topology (the LDS use varies with it)
+    ctx->pv_occ = pv_patches_per_cu(ctx->f);
+    ctx->pv_occ_topo = ctx->topo;
   }
-  const int wg_wpb = (L.wg_waves == 1 && ctx->opt_pw_roles == 0) ? 1 : L.wg_waves + 1;  // waves per workgroup
-  const int wg_cap = std::min(kWgWavesPerCu / wg_wpb, ctx->wg_occ) * cus;  // in workgroups
+  const int wg_cap = ctx->pv_occ * cus;  // patch-per-wave form, in patches
   const bool he_fits = L.he_ok && L.he_waves > 0 && L.he_waves <= he_cap;
   const bool tv_fits = L.tv_ok && L.tv_waves > 0 && L.tv_waves <= tv_cap;
   if (ctx->opt_persistent == 2 && !L.he_ok) return 0;
   if (ctx->opt_persistent == 3 && !L.tv_ok) return 0;
   if (ctx->opt_persistent == 4 && !L.wg_ok) return 0;
+  const bool pv_fits = L.wg_ok && L.wg_count > 0 && L.wg_count <= wg_cap;
   int form = 0;
   if (ctx->opt_persistent == 4) form = 3;
   else if (ctx->opt_persistent == 2) form = 1;
   else if (ctx->opt_persistent == 3) form = 2;
+  else if (pv_fits) form = 3;  // lowest latency wherever all patches are resident: 320x240 ... 1280x720 single frames
   else if (he_fits) form = 1;
   else if (tv_fits) form = 2;
   else form = L.tv_ok ? 2 : (L.he_ok ? 1 : 0);  // too big for one launch: vertex-per-lane groups
@@ -527,30 +522,24 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       // stays in that XCD's L2 (measured 320x240: 1.23 instead of 1.47 us per step; at 640x480 the 26 waves per CU
       // this would need cost more than the shorter hop saves).
       const int cus_per_xcd = ctx->prop.multiProcessorCount / 8;
-      const int unit = form == 3 ? ctx->L.wg_waves : 1;  // waves per launch unit
-      // (patch-per-wave form: one XCD while its CUs get at most two patches each)
-      const bool one_xcd = form == 3 && ctx->L.wg_waves == 1 ? gr.count <= 2 * cus_per_xcd : (form != 2 && gr.count * unit <= 8 * cus_per_xcd);
+      // (patch-per-wave form: one XCD while its CUs get at most two patches each -- measured: 48 patches 0.98 against
+      // 1.21 us per step on all eight, 208 patches 1.53 against 1.33)
+      const bool one_xcd = form == 3 ? gr.count <= 2 * cus_per_xcd : (form == 1 && gr.count <= 8 * cus_per_xcd);
       const int xcds = ctx->opt_xcds > 0 ? ctx->opt_xcds : one_xcd ? 1 : 8;
-      const int presleep = (form == 3 && ctx->L.wg_waves == 1 && ctx->opt_presleep == 0) ? -1  // adaptive, in the kernel
-                           : ctx->opt_presleep > 0 ? ctx->opt_presleep - 1
+      const int presleep = ctx->opt_presleep > 0 ? ctx->opt_presleep - 1
                            : form == 2                ? kPreSleepTv
                            : xcds == 1                ? kPreSleepHeOneXcd
-                           : gr.count * unit > 12 * ctx->prop.multiProcessorCount ? kPreSleepHeDense
+                           : gr.count > 12 * ctx->prop.multiProcessorCount ? kPreSleepHeDense
                                                                             : kPreSleepHe;
       const unsigned spins_arg = ctx->opt_fault > 0 ? (0x80000000u | (unsigned)ctx->opt_fault) : kMaxSpins;
       if (form == 3) {
-        ctx->f.wg_poll_gap = ctx->opt_poll_gap > 0 ? (((ctx->opt_poll_gap & 0xff) - 1) | (ctx->opt_poll_gap & 0xf00)) : kWgPollGap;
-        ctx->f.wg_rec_shift = ctx->opt_wg_rec & 15, ctx->f.wg_rec_rep = ctx->opt_wg_rec >> 4;
-        ctx->f.pw_roles = ctx->opt_pw_roles;
+        ctx->f.wg_poll_gap = ctx->opt_poll_gap > 0 ? ctx->opt_poll_gap - 1 : kPvPollGap;
         ctx->f.probe = nullptr;
-        if (ctx->opt_probe) {
-          const size_t words1 = (size_t)ctx->L.wg_count * ((ctx->L.wg_waves == 1 && ctx->opt_pw_roles == 0) ? 1 : ctx->L.wg_waves + 1) * (size_t)n * 8;
-          const size_t words = words1 + (size_t)ctx->L.wg_count * (size_t)n * 128;  // + hop latency per fetched record
+        if (ctx->opt_probe) {  // [patch][step][8 words]
+          const size_t words = (size_t)ctx->L.wg_count * (size_t)n * 8;
           rc = ensure(ctx, ctx->probe, words * sizeof(unsigned));
           if (rc) return rc;
-          HIPCHK(ctx, hipMemsetAsync(ctx->probe.p, 0xff, words * sizeof(unsigned), ctx->stream));
           ctx->f.probe = (unsigned*)ctx->probe.p;
-          ctx->f.probe_lat_base = words1;
           ctx->probe_words = words;
         }
       }
@@ -788,26 +777,9 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
       if (value < 0 || value > 4) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_persistent = value;
       return 0;
-    case FLAME_NLTGV2_OPT_WG_WAVES:
-      if (value != 1 && value != 2 && value != 4 && value != 8) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-      ctx->opt_wg_waves = value;
-      return 0;
     case FLAME_NLTGV2_OPT_POLL_GAP:
-      if (value < 0 || value > 0xfff) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-      ctx->opt_poll_gap = value;
-      return 0;
-    case FLAME_NLTGV2_OPT_WG_RECORD: {
-      const int sh = value & 15, rp = value >> 4;
-      if (sh < 4 || sh > 7 || rp < 1 || rp > (1 << (sh - 4))) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-      ctx->opt_wg_rec = value;
-      return 0;
-    }
-    case FLAME_NLTGV2_OPT_PW_ROLES:
       if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-      ctx->opt_pw_roles = value;
-      ctx->f.pw_roles = value;
-      ctx->wg_occ_topo = ~0ull;
-      ctx->coop_checked_key = ~0ull;
+      ctx->opt_poll_gap = value;
       return 0;
     case FLAME_NLTGV2_OPT_PROBE:
       ctx->opt_probe = value ? 1 : 0;
@@ -857,7 +829,7 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
   ctx->have_graph = false;
   const bool trace = std::getenv("FLAME_NLTGV2_TRACE") != nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
-  rc = build_layout(g, &ctx->L, ctx->opt_wg_waves);
+  rc = build_layout(g, &ctx->L);
   if (rc) return fail(ctx, rc);
   const auto t_packed = std::chrono::steady_clock::now();
   const PackedLayout& L = ctx->L;
@@ -889,7 +861,6 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
       {&ctx->wg_slot, sizeof(int32_t) * L.wg_slot.size()}, {&ctx->wg_vid, sizeof(int32_t) * L.wg_vid.size()},
       {&ctx->wg_meta, sizeof(uint32_t) * L.wg_meta.size()}, {&ctx->wg_nbr, sizeof(int32_t) * L.wg_nbr.size()},
       {&ctx->wg_fetch, sizeof(int32_t) * L.wg_fetch.size()}, {&ctx->wg_info, sizeof(int32_t) * L.wg_info.size()},
-      {&ctx->wg_wave_chain, sizeof(int32_t) * L.wg_wave_chain.size()},
       {&ctx->err, sizeof(int)},
       {&ctx->cost_out, 2 * sizeof(float)}};
   for (auto& r : req) {
@@ -928,8 +899,7 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
       {&ctx->wg_meta, L.wg_meta.data(), sizeof(uint32_t) * L.wg_meta.size()},
       {&ctx->wg_nbr, L.wg_nbr.data(), sizeof(int32_t) * L.wg_nbr.size()},
       {&ctx->wg_fetch, L.wg_fetch.data(), sizeof(int32_t) * L.wg_fetch.size()},
-      {&ctx->wg_info, L.wg_info.data(), sizeof(int32_t) * L.wg_info.size()},
-      {&ctx->wg_wave_chain, L.wg_wave_chain.data(), sizeof(int32_t) * L.wg_wave_chain.size()}};
+      {&ctx->wg_info, L.wg_info.data(), sizeof(int32_t) * L.wg_info.size()}};
   for (auto& c : cp) {
     if (rc) return rc;
     rc = h2d(ctx, *c.b, c.src, c.bytes);

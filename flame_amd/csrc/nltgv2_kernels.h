@@ -91,20 +91,16 @@ struct FusedArgs {
   int32_t* tv_vid = nullptr;
   uint32_t* tv_meta = nullptr;
   uint32_t* tv_wave = nullptr;
-  int wg_slab_slots = 0;
-  int wg_count = 0, wg_waves = 0, wg_lcap = 0, wg_rcap = 0;  // persistent run, patch-per-workgroup rows (nltgv2_pack.hpp (E))
+  // persistent run, patch-per-wave rows (nltgv2_pack.hpp (E)): one wave per patch
+  int wg_count = 0, wg_lcap = 0, wg_slab_slots = 0;
   int32_t* wg_slot = nullptr;
   int32_t* wg_vid = nullptr;
   uint32_t* wg_meta = nullptr;
   int32_t* wg_nbr = nullptr;
   int32_t* wg_fetch = nullptr;
   int32_t* wg_info = nullptr;
-  int32_t* wg_wave_chain = nullptr;
-  int wg_poll_gap = 2;                 // x64 cycles between the pipelined polls of the communication wave
-  int wg_rec_shift = 4, wg_rec_rep = 1;  // bytes per exchange record = 1 << shift; 16-byte copies written per publish
-  size_t probe_lat_base = 0;           // word offset of the per-record hop-latency area in `probe`
-  int pw_roles = 0;                    // patch-per-wave form: 0 = one wave per patch, 1 = + a communication wave, 2 = roles from SIMD ids
-  unsigned* probe = nullptr;           // optional per-wave, per-step cycle probe of k_persistent_wg (tools/probe_wg.py)
+  int wg_poll_gap = 1;                 // 1: one s_sleep between the polls of k_persistent_pv, 0: none
+  unsigned* probe = nullptr;           // optional per-patch, per-step cycle probe of k_persistent_pv (tools/pv_probe.py)
   int* abort_flag = nullptr;
   int* err = nullptr;
 };
@@ -115,7 +111,7 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
                           int parity_in, unsigned tag0, int n_iters, int waves_per_block, unsigned max_spins,
                           int presleep, int dual, int tv_static_in_lds, int xcds, const RunTail* tail, bool cooperative,
                           hipStream_t stream);
-int wg_blocks_per_cu(const FusedArgs& a);
+int pv_patches_per_cu(const FusedArgs& a);
 int launch_save_prev(const CanonArgs& c, hipStream_t s);
 int launch_dual(const CanonArgs& c, const SolverParams& p, hipStream_t s);
 int launch_primal(const CanonArgs& c, const SolverParams& p, hipStream_t s);

@@ -532,902 +532,57 @@ k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd
 }
 
 // ------------------------------------------------------------------------------------------------
-// Persistent run, patch-per-workgroup form ("wg"): the lane-per-half-edge arithmetic of k_persistent_he, organised
-// around what bounds a step on this chip.  Measured (profiles/r02_wg_probe.json): a lone wave issues one instruction
-// per ~4 cycles, so a step costs (instructions on the path between a record arriving and the next one leaving) x 4
-// cycles, plus one cross-CU hand-off whose price is the load round trip (~600 cycles) times the polls it takes.
+// Persistent run, patch-per-wave form ("pv"): the lane-per-half-edge arithmetic of k_persistent_he, reorganised around
+// what the in-kernel probes of round 2 measured (profiles/r02_persistent/):
+//   * a lone wave issues one instruction every ~4.5 cycles and an LDS round trip costs ~120: a step costs what the
+//     instructions and LDS trips BETWEEN a record arriving and the next one leaving cost (k_persistent_he: ~1400 cycles,
+//     of which the DPP ripple 750; here ~850);
+//   * a hand-off costs a store, a load round trip, and however much later than the arrival the consumer looks; one
+//     record per half-edge polled with blocking loads made that ~2200 cycles per step;
+//   * the period of the whole lock-step network is set by its SLOWEST adjacent pair, not by the average wave.
 //
-//   * a workgroup = W compute waves + ONE communication wave, and owns a compact Morton patch of vertices.  Neighbours
-//     inside the patch exchange their records through LDS (two parity areas, one workgroup barrier per step); a vertex
-//     is published to memory only if it has a neighbour in another patch.
-//   * the communication wave does nothing but fetch: one lane per DISTINCT foreign record the patch needs (two per lane
-//     beyond 64; sorted by record id, records numbered in walk order so a producer's records share cache lines), polls
-//     pipelined three deep so that a miss costs a fraction of a round trip instead of a whole one, results into LDS.
-//     It runs one step ahead of the compute waves (it fetches the records of step s+1 while they compute step s) and
-//     never stores, so its loads do not queue behind write-through stores; the compute waves never wait for memory.
-//   * the compute waves' step is straight-line code: the per-role selects of the dual update are folded into signed
-//     per-lane constants (exact: IEEE negation and a*(-b) == -(a*b)), the w1/w2 halves run as packed-f32 pairs, and
-//     the ordered accumulation (cc:120-142: ascending edge id) is done by EVERY lane of the vertex from an LDS slab of
-//     8 contribution slots per vertex whose unused slots hold -0.0f (x + -0.0f == x for every x): no predication, no
-//     DPP ripple, no hand-back -- all lanes of a vertex hold bit-identical state at all times.  Vertices of degree > 8
-//     continue from a per-lane overflow strip (rare in a Delaunay graph).
-//
-// Protocol (tags, two parity buffers, remote/local copies, XCC table, bounded waits, transactional outputs) is that of
-// k_persistent_he.  LDS (float4 units): [rec par0: lcap local + rcap fetched | rec par1 | slabA lcap*8 x {a1,a2,b1,b2} |
-// ovfA T | slabC lcap*8 floats | ovfC T floats].
+// Layout (E) of nltgv2_pack.hpp: a wave owns a compact Morton patch of ~10 vertices (64 half-edge lanes, a vertex's
+// lanes contiguous, ascending edge id).
+//   exchange   Neighbours inside the patch meet in LDS.  Every DISTINCT foreign record the patch needs is fetched by
+//              exactly one lane (sorted by record id; records are numbered in walk order, so a producer's records share
+//              cache lines) with an LDS-DMA load (global_load_lds_dwordx4 sc1: lane i's 16 bytes land in fetch slot i of
+//              the step's LDS area, no register waits for them), issued round after round from a six-instruction loop
+//              that also reads every lane's neighbour record (tag word first, then the 16 bytes) from LDS and leaves when
+//              all tags are the step's.  A poll that finds an old record only rewrites the slot with the bytes it already
+//              holds: a producer cannot publish step s+2 into that parity before this patch has published s+1, i.e.
+//              consumed s.  A vertex is published to memory only if another patch reads it.
+//   step       Straight-line code: the per-role selects of the dual update are folded into signed per-lane constants
+//              (exact: IEEE negation, a*(-b) == -(a*b)), the w1/w2 halves run as packed-f32 pairs, and the ordered
+//              accumulation (cc:120-142: ascending edge id) is done by EVERY lane of the vertex from an LDS slab of
+//              `stride` contribution slots per vertex (the patch's largest degree rounded up to 4, at least 8) whose
+//              unused slots hold -0.0f (x + -0.0f == x for every x): no predication, no DPP ripple, no hand-back -- all
+//              lanes of a vertex hold bit-identical state at all times.
+// Protocol (tags, two parity buffers, remote / XCD-local copies chosen from the true XCC ids, bounded waits,
+// transactional outputs) is that of k_persistent_he.
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned kWgTailBit = 1u << 24, kWgActiveBit = 1u << 25, kWgValidBit = 1u << 26, kWgPublishBit = 1u << 27;
-constexpr int kWgSlab = 16;  // contribution slots per vertex in the slab (read in batches of 8); positions beyond go to the overflow strip
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void lds_wave_sync() {  // LDS operations of one wave are processed in issue order
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
-__device__ __forceinline__ void lds_wg_barrier() {  // no vmcnt wait: a step's publish stores stay in flight
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// One 16-byte-per-lane LDS-DMA load: lane i's 16 bytes at gsrc land at LDS byte address lds_dst + 16*i.  M0 is the
-// destination base; it is compiler-reserved, so it is saved, written and restored inside the one statement.
-__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
-}
-
-template <bool PROBE>
-__global__ void __launch_bounds__(1024)
-k_persistent_wg(const int wg_begin, const int n_wgs, const int wgs_per_xcd, const int lcap, const int rcap,
-                const int32_t* __restrict__ wg_slot, const int32_t* __restrict__ wg_vid,
-                const uint32_t* __restrict__ wg_meta, const int32_t* __restrict__ wg_nbr,
-                const int32_t* __restrict__ wg_fetch, const int32_t* __restrict__ wg_info,
-                const int32_t* __restrict__ wg_wave_chain, const int4* hrec, const float4* hq, const float4* vstate,
-                float4* hq_out, float4* vstate_out, const float2* vaux, const float4* bar_in, float4* bar_out, float4* vprev,
-                void* xbuf, const int rec_bytes, const int dual, const unsigned tag0, const int n_iters,
-                const unsigned max_spins_arg, const int presleep, const int poll_gap, const int rec_shift, const int rec_rep,
-                const SolverParams p, int* __restrict__ err, int* __restrict__ abort_flag,
-                const int32_t* __restrict__ perm, const RunTail* __restrict__ tail, unsigned* __restrict__ probe,
-                const size_t probe_lat_base) {
-  extern __shared__ float4 lds[];
-  __shared__ int wg_flag;  // != 0: a wait of this workgroup expired (set before, read after a step's barrier)
-  const unsigned max_spins = max_spins_arg & 0x7fffffffu;
-  const int tid = (int)threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const int W = ((int)blockDim.x >> 6) - 1, T = W << 6;  // compute waves / lanes; wave W is the communication wave
-  const int b = blockIdx.x;
-  const int xcd = b & 7, idx = b >> 3;
-  if (idx >= wgs_per_xcd) return;
-  if (xcd * wgs_per_xcd + idx >= n_wgs) return;
-  const int wg = wg_begin + xcd * wgs_per_xcd + idx;  // this launch covers workgroups [wg_begin, +n_wgs)
-  const int rid_base = wg_info[4 * wg], n_fetch = wg_info[4 * wg + 1];
-  // LDS map, in float4 units
-  const int rec_stride = lcap + rcap;
-  const int o_slabA = 2 * rec_stride, o_ovfA = o_slabA + lcap * kWgSlab, o_slabC = o_ovfA + T;  // slabC/ovfC: floats
-  float* const ldsf = reinterpret_cast<float*>(lds);
-  const int f_slabC = 4 * o_slabC, f_ovfC = f_slabC + lcap * kWgSlab;
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(xbuf);
-  const int S = rec_bytes, par = 2 * rec_bytes;
-  if (tid == 0) wg_flag = 0;
-  const unsigned xcc_want = (tag0 & 0x0fffffffu) << 4;
-
-  if (wv == W) {
-    // ============================ communication wave ===========================================================
-    __builtin_amdgcn_s_setprio(0);  // it shares a SIMD with a compute wave: never take an issue slot that wave could use
-    const int f0 = (lane < n_fetch) ? wg_fetch[(size_t)wg * T + lane] : -1;
-    const int f1 = (64 + lane < n_fetch) ? wg_fetch[(size_t)wg * T + 64 + lane] : -1;
-    const bool has0 = f0 >= 0, has1 = f1 >= 0;
-    int off0 = has0 ? (f0 << rec_shift) : 0, off1 = has1 ? (f1 << rec_shift) : off0;  // (no record: a harmless one)
-    lds_wg_barrier();  // (A) wg_flag initialised, slabs cleared
-    bool failed = false;
-    if (dual && n_fetch > 0) {  // one-time XCC exchange: which producers run on my XCD?
-      const unsigned my_xcc = read_xcc_id();
-      bool p0 = has0, p1 = has1;
-      unsigned g0 = 0, g1 = 0, spins = 0;
-      for (;;) {
-        if (p0) {
-          int o = 4 * S + (f0 << 2);
-          asm volatile("" : "+v"(o)::"memory");
-          g0 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, kAuxSc1);
-          p0 = ((g0 & ~15u) != xcc_want);
-        }
-        if (p1) {
-          int o = 4 * S + (f1 << 2);
-          asm volatile("" : "+v"(o)::"memory");
-          g1 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, kAuxSc1);
-          p1 = ((g1 & ~15u) != xcc_want);
-        }
-        if (!__any(p0 || p1)) break;
-        if (++spins > max_spins) {
-          failed = true;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(2);
-      }
-      if (!failed) {
-        if (has0 && (g0 & 15u) == my_xcc) off0 += S;
-        if (has1 && (g1 & 15u) == my_xcc) off1 += S;
-      }
-    }
-    // Polling is LDS-DMA (global_load_lds_dwordx4 sc1, lane i -> slot i of the step's fetch area): no register ever
-    // waits for a poll, so rounds are issued every `poll_gap` x 64 cycles regardless of the round trip, several in
-    // flight; a round that finds an old record rewrites the slot with that old record, one that finds the new one
-    // makes the slot's tag word equal to s (loads of one wave land in issue order, and a record only ever moves
-    // forward).  The wave watches the tag words in LDS.  Rounds still in flight when the last tag arrives land later
-    // with the same bytes.
-    const char* const xb_base = static_cast<const char*>(xbuf);
-    const unsigned lds_addr0 = (unsigned)(size_t)(lds);  // LDS byte address of the dynamic array
-    const int* const ldsi = reinterpret_cast<const int*>(lds);
-    const bool two = n_fetch > 64;  // wave-uniform
-    unsigned pr_t0 = 0;
-    if (PROBE) pr_t0 = (unsigned)clock64();
-    for (int it = 0; it < n_iters; ++it) {
-      const unsigned s = tag0 + (unsigned)it;
-      const int so_in = (s & 1u) ? par : 0;
-      const int rdst = ((s & 1u) ? rec_stride : 0) + lcap + lane;
-      unsigned pr_t1 = 0, pr_rounds = 0;
-      if (n_fetch > 0 && !failed) {
-        const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds_addr0 + 16u * (unsigned)(rdst - lane));
-        const char* const src0 = xb_base + off0 + so_in;
-        const char* const src1 = xb_base + off1 + so_in;
-        // the producers of step s records are computing step s-1 right now: nothing can arrive before that is done
-        if (it > 0)
-          for (int z = 0; z < presleep; ++z) __builtin_amdgcn_s_sleep(1);
-        if (PROBE) pr_t1 = (unsigned)clock64();
-        unsigned spins = 0;
-        for (;;) {
-          if (has0) lds_dma16(src0, dst0);
-          if (two && has1) lds_dma16(src1, dst0 + 1024u);
-          for (int z = 0; z < (poll_gap & 0xff); ++z) __builtin_amdgcn_s_sleep(1);
-          asm volatile("" ::: "memory");
-          const unsigned t0 = (unsigned)ldsi[4 * rdst + 3];
-          const unsigned t1 = (unsigned)ldsi[4 * (rdst + 64) + 3];
-          const bool pend = (has0 && t0 != s) || (has1 && t1 != s);
-          if (PROBE) ++pr_rounds;
-          if (!__any(pend)) break;
-          ++spins;
-          if ((spins & 63u) == 0u) {
-            const int ab = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ab != 0 || spins > max_spins) {
-              failed = true;
-              break;
-            }
-          }
-        }
-      }
-      if (poll_gap & 0x100) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // debug: drain the rounds in flight
-      if ((poll_gap & 0x200) && n_fetch > 0 && !failed) {                      // debug: one more, complete fetch
-        const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds_addr0 + 16u * (unsigned)(rdst - lane));
-        if (has0) lds_dma16(xb_base + off0 + so_in, dst0);
-        if (two && has1) lds_dma16(xb_base + off1 + so_in, dst0 + 1024u);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      if (failed) wg_flag = 1;
-      unsigned pr_t2 = 0;
-      if (PROBE) pr_t2 = (unsigned)clock64();
-      if (PROBE && probe && rec_shift >= 5 && !failed) {
-        // hop latency per fetched record: the producer's second 16-byte slot carries its 100 MHz clock at publish time
-        const unsigned now = (unsigned)wall_clock64();
-        unsigned* const lat = probe + probe_lat_base + ((size_t)(wg - wg_begin) * n_iters + it) * 128;
-        v4i_t t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
-        if (has0) t0 = __builtin_amdgcn_raw_buffer_load_b128(rx, off0 + 16, so_in, kAuxSc1);
-        if (has1) t1 = __builtin_amdgcn_raw_buffer_load_b128(rx, off1 + 16, so_in, kAuxSc1);
-        lat[lane] = (has0 && (unsigned)t0.w == s) ? ((now - (unsigned)t0.x) | ((unsigned)t0.y << 24)) : 0xffffffffu;
-        lat[64 + lane] = (has1 && (unsigned)t1.w == s) ? ((now - (unsigned)t1.x) | ((unsigned)t1.y << 24)) : 0xffffffffu;
-      }
-      lds_wg_barrier();  // (B_s) records of step s are in LDS
-      if (PROBE) {
-        const unsigned pr_t3 = (unsigned)clock64();
-        if (lane == 0 && probe) {  // {pre-sleep, poll, barrier wait, -, poll rounds, step start, 100 MHz clock, 1 = comm wave}
-          unsigned* o = probe + ((size_t)(wg * (W + 1) + wv) * n_iters + it) * 8;
-          o[0] = pr_t1 - pr_t0, o[1] = pr_t2 - pr_t1, o[2] = pr_t3 - pr_t2, o[3] = read_xcc_id();
-          o[4] = pr_rounds, o[5] = pr_t0, o[6] = (unsigned)wall_clock64(), o[7] = 1u;
-        }
-        pr_t0 = pr_t3;
-      }
-      if (failed) break;  // the compute waves read wg_flag after the same barrier and leave as well
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA in flight when the wave ends
-    if (failed && lane == 0) {
-      __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      atomicOr(err, 2);
-    }
-    return;
-  }
-
-  // ================================ compute waves ================================================================
-  __builtin_amdgcn_s_setprio(3);
-  const int chain = __builtin_amdgcn_readfirstlane(wg_wave_chain[wg * W + wv]);
-  const size_t hl = (size_t)wg * T + tid;
-  const unsigned meta = wg_meta[hl];
-  const int slot = wg_slot[hl];
-  const int pv = wg_vid[hl];
-  const int nbr_code = wg_nbr[hl];
-  const int first = (int)(meta & 63u), deg = (int)((meta >> 6) & 127u), loc = (int)((meta >> 13) & 2047u);
-  const bool is_tail = (meta & kWgTailBit) != 0u, active = (meta & kWgActiveBit) != 0u;
-  const bool valid = (meta & kWgValidBit) != 0u, publishes = (meta & kWgPublishBit) != 0u;
-  const int nbr_idx = (nbr_code < 0) ? lcap + (nbr_code & 0x7fffffff) : nbr_code;
-  const int pos = lane - first;  // this half-edge's position among its vertex's (ascending edge id)
-
-  int4 rec = make_int4(0, 0, 0, 0);
-  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (active) {
-    rec = hrec[slot];
-    q = hq[slot];
-  }
-  const bool is_target = rec.x < 0;
-  const float alpha = __int_as_float(rec.y), dx = __int_as_float(rec.z), dy = __int_as_float(rec.w);
-  const float beta = q.w;
-  float q1 = q.x;
-  v2f_t q23 = {q.y, q.z};
-  // Signed per-lane constants (i = source, j = target of the EDGE; "own" = this lane's vertex, "nb" = the other one):
-  //   alpha*(xb_i - xb_j)     == as * (own - nb)     with as  = source ? alpha : -alpha
-  //   beta*(wb_i - wb_j)      == bs * (own - nb)     with bs  = source ? beta : -beta
-  //   cx = target ? t1 : -t1  == u1 * ac            with ac  = target ? alpha : -alpha,  u1 = q1*step_x
-  //   source: a = t1*(dx,dy)  == cx * (-dx,-dy);   b = -(t2,t3) == (u2,u3) * (-beta)
-  //   target: a = (t2,t3)     == (u2,u3) * beta;   b = (-0,-0)
-  const float as = is_target ? -alpha : alpha, bs = is_target ? -beta : beta, ac = is_target ? alpha : -alpha;
-  const v2f_t P12 = {alpha * dx, alpha * dy};  // cc:100-101: alpha * dx * w1_bar evaluates (alpha*dx) first
-  const v2f_t C2 = is_target ? v2f_t{beta, beta} : v2f_t{-dx, -dy};
-  const float nbeta = -beta;
-
-  float4 st = make_float4(0.f, 0.f, 0.f, 0.f), bs4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float2 aux = make_float2(0.f, 0.f);
-  if (valid) {  // every lane of a vertex reads the same words (broadcast load)
-    st = vstate[pv];
-    aux = vaux[pv];
-    bs4 = bar_in[pv];
-  }
-  const float data = st.w;
-  const float thr = p.step_x * (p.data_factor * aux.x);  // proxL1's thresh, h:185 with the call site's weight cc:149-150
-  float x = st.x;               // invariant: every lane of a vertex holds the vertex's state
-  v2f_t w12 = {st.y, st.z};
-  float xb = bs4.x;
-  v2f_t wb12 = {bs4.y, bs4.z};
-  float x_prev = x;
-  v2f_t w_prev = w12;
-  bool ok = true;
-  bool timed_out = false;
-
-  // A record occupies 1 << rec_shift bytes of the exchange buffers; the first rec_rep lanes of the vertex each write
-  // one 16-byte copy of it (all lanes of a vertex hold the same values), so that a publish fills whole cache sectors.
-  const int my_off = ((rid_base + loc) << rec_shift) + ((pos > 0 && pos < (1 << (rec_shift - 4))) ? (pos << 4) : 0);
-  const int my_rid4 = (rid_base + loc) << 2;
-  // LDS addresses of this lane (float4 / float indices)
-  // (a lane without a half-edge writes to its own overflow entry, which no vertex reads)
-  const bool in_slab = active && pos < kWgSlab;
-  const int wrA = in_slab ? o_slabA + loc * kWgSlab + pos : o_ovfA + tid;
-  const int wrC = in_slab ? f_slabC + loc * kWgSlab + pos : f_ovfC + tid;
-  const int rdA = o_slabA + loc * kWgSlab, rdC4 = (f_slabC + loc * kWgSlab) >> 2;  // slabC of a vertex = two float4
-  const int ovf_base = (wv << 6) + first;  // overflow strip index of the vertex's position-0 lane
-  // where this lane leaves its vertex's record for the patch: every lane of a vertex writes the same value to the
-  // same slot (no exec masking); a lane that owns no vertex writes to its own, never read, overflow entry
-  const int rec_w = valid ? loc : o_ovfA + tid, rec_wstride = valid ? rec_stride : 0;
-
-  // clear the contribution slabs: slots no lane writes must read as -0.0f for the whole run; and the fetch areas:
-  // their tag words (0 is never a live tag) are what the communication wave watches
-  for (int i = tid; i < lcap * kWgSlab; i += T) {
-    lds[o_slabA + i] = make_float4(-0.0f, -0.0f, -0.0f, -0.0f);
-    ldsf[f_slabC + i] = -0.0f;
-  }
-  for (int i = tid; i < rcap; i += T) {
-    lds[lcap + i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    lds[rec_stride + lcap + i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  if (dual && is_tail && publishes) {
-    const unsigned my_xcc = read_xcc_id();
-    __builtin_amdgcn_raw_buffer_store_b32((int)(xcc_want | my_xcc), rx, 4 * S + my_rid4, 0, kAuxSc1);
-  }
-  // test hook (FLAME_NLTGV2_OPT_FAULT_INJECT): the first workgroup of the launch never publishes its first records
-  const bool mute = (max_spins_arg >> 31) != 0u && wg == wg_begin;
-  if (valid) lds[((tag0 & 1u) ? rec_stride : 0) + loc] = make_float4(xb, wb12.x, wb12.y, 0.0f);
-  const bool pub_lane = valid && publishes && (pos < rec_rep || (PROBE && probe && rec_shift >= 5 && pos == 1)) && (pos == 0 || active);
-  if (pub_lane && !mute) {  // bar(tag0) to memory where another patch reads it
-    v4i_t o;
-    o.x = __float_as_int(xb), o.y = __float_as_int(wb12.x), o.z = __float_as_int(wb12.y), o.w = (int)tag0;
-    const int so = (tag0 & 1u) ? par : 0;
-    __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
-    if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
-  }
-  lds_wg_barrier();  // (A)
-  unsigned pr_t0 = 0;
-  if (PROBE) pr_t0 = (unsigned)clock64();
-
-  for (int it = 0; it < n_iters; ++it) {
-    const unsigned s = tag0 + (unsigned)it;
-    const int rbase = (s & 1u) ? rec_stride : 0;  // this step's record area
-    const int wbase = (s & 1u) ? 0 : rec_wstride;  // next step's
-    lds_wg_barrier();  // (B_s)
-    unsigned pr_t3 = 0;
-    if (PROBE) pr_t3 = (unsigned)clock64();
-    // ---- neighbour record from LDS; workgroup-uniform abort flag -----------------------------------------------
-    float4 nb4 = lds[rbase + nbr_idx];
-    const int fl = wg_flag;
-    asm volatile("" : "+v"(nb4.x), "+v"(nb4.y), "+v"(nb4.z));  // both reads in flight before the one wait
-    if (fl != 0) {
-      timed_out = true;
-      break;
-    }
-    // ---- dual update of this half-edge's private q copy (cc:99-110) ------------------------------
-    const v2f_t nbw = {nb4.y, nb4.z};
-    const float d0 = xb - nb4.x;
-    const v2f_t d12 = wb12 - nbw;
-    const v2f_t wbi = is_target ? nbw : wb12;  // the SOURCE vertex's (w1_bar, w2_bar)
-    float K1 = as * d0;
-    const v2f_t m12 = P12 * wbi;
-    K1 -= m12.x;
-    K1 -= m12.y;
-    const v2f_t K23 = bs * d12;
-    const float q1r = q1 + p.step_q * K1;
-    const v2f_t q23r = q23 + p.step_q * K23;
-    ok = ok && (__builtin_fabsf(q1r) <= 3.402823466e+38f) && (__builtin_fabsf(q23r.x) <= 3.402823466e+38f) &&
-         (__builtin_fabsf(q23r.y) <= 3.402823466e+38f);  // NaN/Inf: the reference's FLAME_ASSERT h:174
-    q1 = __builtin_fminf(__builtin_fmaxf(q1r, -1.0f), 1.0f);
-    q23.x = __builtin_fminf(__builtin_fmaxf(q23r.x, -1.0f), 1.0f);
-    q23.y = __builtin_fminf(__builtin_fmaxf(q23r.y, -1.0f), 1.0f);
-    // ---- this endpoint's share of the primal scatter (cc:126-141) as ordered contributions -------
-    const float u1 = q1 * p.step_x;
-    const v2f_t u23 = q23 * p.step_x;
-    const float cx = u1 * ac;
-    const v2f_t M2 = is_target ? u23 : v2f_t{cx, cx};
-    const v2f_t a12 = M2 * C2;
-    v2f_t b12 = u23 * nbeta;
-    b12 = is_target ? v2f_t{-0.0f, -0.0f} : b12;
-    lds[wrA] = make_float4(a12.x, a12.y, b12.x, b12.y);
-    ldsf[wrC] = cx;
-    lds_wave_sync();  // a vertex's lanes are lanes of this wave
-    // ---- ordered accumulation, by every lane of the vertex (ascending edge id = ascending slot) --------------
-    float X = x;
-    v2f_t Wa = w12;
-#define WG_ACC8(K0)                                                                  \
-  {                                                                                  \
-    float4 c[8];                                                                     \
-    _Pragma("unroll") for (int k = 0; k < 8; ++k) c[k] = lds[rdA + (K0) + k];        \
-    const float4 cxa = lds[rdC4 + (K0) / 4], cxb = lds[rdC4 + (K0) / 4 + 1];         \
-    const float cxs[8] = {cxa.x, cxa.y, cxa.z, cxa.w, cxb.x, cxb.y, cxb.z, cxb.w};   \
-    _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                  \
-      X = X + cxs[k];                                                                \
-      Wa = (Wa + v2f_t{c[k].x, c[k].y}) + v2f_t{c[k].z, c[k].w};                     \
-    }                                                                                \
-  }
-    WG_ACC8(0)
-    if (chain > 8) {  // wave-uniform: some vertex of this wave has more than 8 incident edges
-      WG_ACC8(8)
-      for (int k = kWgSlab; k < chain; ++k) {  // beyond 16: per-lane overflow strip (not a Delaunay case)
-        if (k < deg) {
-          const float4 c = lds[o_ovfA + ovf_base + k];
-          X = X + ldsf[f_ovfC + ovf_base + k];
-          Wa = (Wa + v2f_t{c.x, c.y}) + v2f_t{c.z, c.w};
-        }
-      }
-    }
-#undef WG_ACC8
-    // ---- vertex update: proxL1 (cc:147-151, h:179-197), extragradient (cc:160-171) --------------------------
-    const float diff = X - data;
-    float xn = (diff > thr) ? X - thr : ((diff < -thr) ? X + thr : data);
-    xn = (xn < p.x_min) ? p.x_min : xn;
-    xn = (xn > p.x_max) ? p.x_max : xn;
-    float nb = xn + p.theta * (xn - x);
-    nb = (nb < p.x_min) ? p.x_min : nb;
-    nb = (nb > p.x_max) ? p.x_max : nb;
-    const v2f_t wbn = Wa + p.theta * (Wa - w12);
-    if (pub_lane) {
-      v4i_t o;
-      o.x = __float_as_int(nb), o.y = __float_as_int(wbn.x), o.z = __float_as_int(wbn.y), o.w = (int)(s + 1u);
-      if (PROBE && probe && rec_shift >= 5 && pos == 1) o.x = (int)(unsigned)wall_clock64(), o.y = (int)read_xcc_id();
-      const int so = ((s + 1u) & 1u) ? par : 0;
-      if (poll_gap & 0x400) {  // debug A/B: the XCD-local copy first / only
-        if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
-        if (!(poll_gap & 0x800)) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
-      } else {
-        __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
-        if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
-      }
-    }
-    lds[wbase + rec_w] = make_float4(nb, wbn.x, wbn.y, 0.0f);
-    x_prev = x, w_prev = w12;  // step()'s prev copy, cc:37-42
-    x = xn, w12 = Wa;
-    xb = nb, wb12 = wbn;
-    if (PROBE) {
-      const unsigned pr_t4 = (unsigned)clock64();
-      if (lane == 0 && probe) {  // {-, -, barrier wait, compute, -, step start, 100 MHz clock, 0 = compute wave}
-        unsigned* o = probe + ((size_t)(wg * (W + 1) + wv) * n_iters + it) * 8;
-        o[0] = 0, o[1] = 0, o[2] = pr_t3 - pr_t0, o[3] = pr_t4 - pr_t3;
-        o[4] = 0, o[5] = pr_t0, o[6] = (unsigned)wall_clock64(), o[7] = 0u;
-      }
-      pr_t0 = pr_t4;
-    }
-  }
-
-  if (timed_out) return;  // the communication wave reports; the host takes the run back
-
-  // The results go to the OTHER copies of the state arrays (the host swaps the roles only when the whole run succeeded)
-  if (is_tail) {
-    vstate_out[pv] = make_float4(x, w12.x, w12.y, data);
-    bar_out[pv] = make_float4(xb, wb12.x, wb12.y, 0.0f);
-    vprev[pv] = make_float4(x_prev, w_prev.x, w_prev.y, 0.0f);
-    float* const export_out = tail->export_out;
-    float* const photo_err = tail->photo.err;
-    if (export_out || photo_err) {
-      const int o = perm[pv];  // the caller's vertex index
-      if (o >= 0 && export_out) export_out[o] = x * tail->export_scale;
-      if (o >= 0 && photo_err) {
-        const PhotoFuse& photo = tail->photo;
-        photo_err[o] = photo_residual_at(photo.pos[o], x * photo.graph_scale, photo.geo, photo.ref, photo.cmp, photo.rows,
-                                         photo.cols, photo.step, photo.border);
-      }
-    }
-  }
-  if (active) hq_out[slot] = make_float4(q1, q23.x, q23.y, beta);
-  if (!ok && active) atomicOr(err, 1);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Persistent run, patch-per-wave form ("pw"): layout (E) with ONE compute wave per workgroup, plus one communication
-// wave.  No barrier in the step loop at all: the two waves meet only through tag words in LDS.
-//
-//   compute wave   lane <-> half-edge (the arithmetic and the LDS contribution slabs of k_persistent_wg).  A step begins
-//                  by reading the neighbour's record from LDS (ds_read_b128: payload + tag) until the tag is the step's
-//                  -- for a neighbour of the same patch that is immediately, the wave wrote it itself -- and ends by
-//                  writing its vertices' records, tagged for the next step, to LDS and (patch-boundary vertices) to memory.
-//   communication  keeps one LDS-DMA load per foreign record in flight, round after round in a five-instruction loop,
-//   wave           and watches the tag words land; when all carry the step's tag it moves on to the next step's area.
-//                  It never waits for the compute wave: a poll that finds an old record only rewrites the slot with the
-//                  bytes it already holds (a producer cannot publish step s+2 into that parity before this patch has
-//                  published s+1, i.e. consumed s).
-//
-// Measured on the 640x480 graph (profiles/): a hand-off costs what one store and one load cost, and a step is that plus
-// the ~110 instructions between a record arriving and the next one leaving.
-// ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned read_hw_id() {
   unsigned v;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v));
   return v;
 }
 
-// Which of a patch's two waves computes: the hardware places a workgroup's waves on consecutive SIMDs, so with fixed
-// roles the compute waves of the patches sharing a CU would pile up on SIMDs 0 and 2 (measured: the slowest compute
-// waves, which set everyone's pace, ran 1.5x longer than the rest).  With `roles` = 1 the wave whose
-// (SIMD id ^ wave slot) is even computes: the patches that share a SIMD pair then compute on different SIMDs.
-template <bool PROBE>
-__global__ void __launch_bounds__(128)
-k_persistent_pw(const int wg_begin, const int n_wgs, const int wgs_per_xcd, const int lcap, const int rcap,
-                const int32_t* __restrict__ wg_slot, const int32_t* __restrict__ wg_vid,
-                const uint32_t* __restrict__ wg_meta, const int32_t* __restrict__ wg_nbr,
-                const int32_t* __restrict__ wg_fetch, const int32_t* __restrict__ wg_info,
-                const int32_t* __restrict__ wg_wave_chain, const int4* hrec, const float4* hq, const float4* vstate,
-                float4* hq_out, float4* vstate_out, const float2* vaux, const float4* bar_in, float4* bar_out, float4* vprev,
-                void* xbuf, const int rec_bytes, const int dual, const unsigned tag0, const int n_iters,
-                const unsigned max_spins_arg, const int presleep, const int poll_gap, const int roles, const SolverParams p,
-                int* __restrict__ err, int* __restrict__ abort_flag, const int32_t* __restrict__ perm,
-                const RunTail* __restrict__ tail, unsigned* __restrict__ probe) {
-  extern __shared__ float4 lds[];
-  __shared__ int wg_flag;         // != 0: a wait of this patch expired
-  __shared__ unsigned hw_ids[2];  // HW_REG_HW_ID of the two waves
-  constexpr int T = 64;
-  const unsigned max_spins = max_spins_arg & 0x7fffffffu;
-  const int tid = (int)threadIdx.x & 63, lane = tid;
-  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int b = blockIdx.x;
-  const int xcd = b & 7, idx = b >> 3;
-  if (idx >= wgs_per_xcd) return;
-  if (xcd * wgs_per_xcd + idx >= n_wgs) return;
-  const int wg = wg_begin + xcd * wgs_per_xcd + idx;  // this launch covers patches [wg_begin, +n_wgs)
-  const int rid_base = wg_info[4 * wg], n_fetch = wg_info[4 * wg + 1];
-  if (lane == 0) hw_ids[wave] = read_hw_id();
-  if (tid == 0 && wave == 0) wg_flag = 0;
-  lds_wg_barrier();  // (R)
-  int wv = wave;  // 0 = compute, 1 = communication
-  if (roles) {
-    const unsigned h0 = hw_ids[0], h1 = hw_ids[1];
-    const unsigned c0 = ((h0 >> 4) ^ h0) & 1u, c1 = ((h1 >> 4) ^ h1) & 1u;  // 1: this wave would rather communicate
-    if (c0 != c1) wv = (wave == 0) ? (int)c0 : (int)c1;
-  }
-  // LDS map of one patch, in float4 units (as k_persistent_wg with T = 64)
-  const int rec_stride = lcap + rcap;
-  const int o_slabA = 2 * rec_stride, o_ovfA = o_slabA + lcap * kWgSlab, o_slabC = o_ovfA + T;
-  float* const ldsf = reinterpret_cast<float*>(lds);
-  const int f_slabC = 4 * o_slabC, f_ovfC = f_slabC + lcap * kWgSlab;
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(xbuf);
-  const int S = rec_bytes, par = 2 * rec_bytes;
-  const unsigned xcc_want = (tag0 & 0x0fffffffu) << 4;
-  const unsigned p0 = tag0 & 1u;  // parity of the first step: its records live in area p0
-
-  if (wv == 1) {
-    // ============================ communication wave ===========================================================
-    __builtin_amdgcn_s_setprio(0);
-    const int f0 = (lane < n_fetch) ? wg_fetch[(size_t)wg * T + lane] : -1;
-    const bool has0 = f0 >= 0;
-    int off0 = has0 ? (f0 << 4) : 0;
-    lds_wg_barrier();  // (A) LDS initialised by the compute wave
-    bool failed = n_fetch > T;  // (the host never launches such a layout in this form)
-    if (dual && n_fetch > 0 && !failed) {  // one-time XCC exchange: which producers run on my XCD?
-      const unsigned my_xcc = read_xcc_id();
-      bool pend = has0;
-      unsigned g0 = 0, spins = 0;
-      for (;;) {
-        if (pend) {
-          int o = 4 * S + (f0 << 2);
-          asm volatile("" : "+v"(o)::"memory");
-          g0 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, kAuxSc1);
-          pend = ((g0 & ~15u) != xcc_want);
-        }
-        if (!__any(pend)) break;
-        if (++spins > max_spins) {
-          failed = true;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(2);
-      }
-      if (!failed && has0 && (g0 & 15u) == my_xcc) off0 += S;
-    }
-    const char* const xb_base = static_cast<const char*>(xbuf);
-    const unsigned lds_addr0 = (unsigned)(size_t)(lds);  // LDS byte address of the dynamic array
-    unsigned pr_t0 = 0;
-    if (PROBE) pr_t0 = (unsigned)clock64();
-    // Polling costs the memory system requests, so the wave sleeps through most of the wait: presleep < 0 (default) =
-    // three quarters of what the previous step's wait took (a geometric rule: it follows the period down as well as up,
-    // which "sleep until just before the last arrival" cannot); presleep >= 0 = that many x 64 cycles.
-    int ps_dyn = 0;
-    unsigned t_step = (unsigned)clock64();
-    for (int it = 0; it < n_iters && !failed; ++it) {
-      const unsigned s = tag0 + (unsigned)it;
-      const int so_in = (s & 1u) ? par : 0;
-      const int area = ((s & 1u) ? rec_stride : 0) + lcap;  // float4 index of the step's fetch slots
-      unsigned rounds = 0;
-      if (n_fetch > 0) {
-        const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds_addr0 + 16u * (unsigned)area);
-        const unsigned tag_addr = lds_addr0 + 16u * (unsigned)(area + lane) + 12u;
-        const char* const src0 = xb_base + off0 + so_in;
-        if (it > 0) {
-          const int ps = presleep >= 0 ? presleep : ps_dyn;
-          for (int z = 0; z < ps; ++z) __builtin_amdgcn_s_sleep(1);
-        }
-        unsigned outer = 0;
-        for (;;) {
-          unsigned cnt = 0, keep, t = 0;
-          if (has0) {
-            // 64 rounds at most per statement: one LDS-DMA load per lane, then look at the tag words in LDS
-            if (poll_gap == 0) {
-              asm volatile(
-                  "s_mov_b32 %[keep], m0\n\t"
-                  "s_mov_b32 m0, %[dst]\n\t"
-                  "s_mov_b32 %[cnt], 0\n\t"
-                  "1:\n\t"
-                  "global_load_lds_dwordx4 %[src], off sc1\n\t"
-                  "ds_read_b32 %[t], %[ta]\n\t"
-                  "s_add_u32 %[cnt], %[cnt], 1\n\t"
-                  "s_waitcnt lgkmcnt(0)\n\t"
-                  "v_cmp_ne_u32_e32 vcc, %[tag], %[t]\n\t"
-                  "s_cmp_lt_u32 %[cnt], 64\n\t"
-                  "s_cbranch_vccz 2f\n\t"
-                  "s_cbranch_scc1 1b\n\t"
-                  "2:\n\t"
-                  "s_mov_b32 m0, %[keep]"
-                  : [keep] "=&s"(keep), [cnt] "=&s"(cnt), [t] "=&v"(t)
-                  : [src] "v"(src0), [dst] "s"(dst0), [ta] "v"(tag_addr), [tag] "s"(s)
-                  : "vcc", "scc", "memory");
-            } else {
-              asm volatile(
-                  "s_mov_b32 %[keep], m0\n\t"
-                  "s_mov_b32 m0, %[dst]\n\t"
-                  "s_mov_b32 %[cnt], 0\n\t"
-                  "1:\n\t"
-                  "global_load_lds_dwordx4 %[src], off sc1\n\t"
-                  "s_sleep 1\n\t"
-                  "ds_read_b32 %[t], %[ta]\n\t"
-                  "s_add_u32 %[cnt], %[cnt], 1\n\t"
-                  "s_waitcnt lgkmcnt(0)\n\t"
-                  "v_cmp_ne_u32_e32 vcc, %[tag], %[t]\n\t"
-                  "s_cmp_lt_u32 %[cnt], 64\n\t"
-                  "s_cbranch_vccz 2f\n\t"
-                  "s_cbranch_scc1 1b\n\t"
-                  "2:\n\t"
-                  "s_mov_b32 m0, %[keep]"
-                  : [keep] "=&s"(keep), [cnt] "=&s"(cnt), [t] "=&v"(t)
-                  : [src] "v"(src0), [dst] "s"(dst0), [ta] "v"(tag_addr), [tag] "s"(s)
-                  : "vcc", "scc", "memory");
-            }
-          }
-          const unsigned cmax = (unsigned)__builtin_amdgcn_readfirstlane((int)cnt);  // (lanes without a record: 0)
-          rounds += cmax;
-          // done unless some lane left the statement with a stale tag
-          bool pend = false;
-          if (has0) pend = (t != s);
-          if (!__any(pend)) break;
-          const int ab = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (ab != 0 || ++outer > (max_spins >> 4)) {
-            failed = true;
-            break;
-          }
-        }
-      }
-      {
-        const unsigned now = (unsigned)clock64();
-        ps_dyn = (int)(((now - t_step) * 3u) >> 8);  // 3/4 of the wait, in 64-cycle sleeps
-        t_step = now;
-      }
-      if (PROBE) {
-        const unsigned pr_t1 = (unsigned)clock64();
-        if (lane == 0 && probe) {  // {-, step cycles, -, hw id, poll rounds, step start, 100 MHz clock, 1 = comm wave}
-          unsigned* o = probe + ((size_t)(wg * 2 + 1) * n_iters + it) * 8;
-          o[0] = 0, o[1] = pr_t1 - pr_t0, o[2] = 0, o[3] = read_hw_id();
-          o[4] = rounds, o[5] = pr_t0, o[6] = (unsigned)wall_clock64(), o[7] = 1u;
-        }
-        pr_t0 = pr_t1;
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA in flight when the wave ends
-    if (failed) {
-      wg_flag = 1;
-      if (lane == 0) {
-        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        atomicOr(err, 2);
-      }
-    }
-    return;
-  }
-
-  // ================================ compute wave ==================================================================
-  __builtin_amdgcn_s_setprio(3);
-  const int chain = __builtin_amdgcn_readfirstlane(wg_wave_chain[wg]);
-  const size_t hl = (size_t)wg * T + tid;
-  const unsigned meta = wg_meta[hl];
-  const int slot = wg_slot[hl];
-  const int pv = wg_vid[hl];
-  const int nbr_code = wg_nbr[hl];
-  const int first = (int)(meta & 63u), deg = (int)((meta >> 6) & 127u), loc = (int)((meta >> 13) & 2047u);
-  const bool is_tail = (meta & kWgTailBit) != 0u, active = (meta & kWgActiveBit) != 0u;
-  const bool valid = (meta & kWgValidBit) != 0u, publishes = (meta & kWgPublishBit) != 0u;
-  const int nbr_idx = (nbr_code < 0) ? lcap + (nbr_code & 0x7fffffff) : nbr_code;
-  const int pos = lane - first;  // this half-edge's position among its vertex's (ascending edge id)
-
-  int4 rec = make_int4(0, 0, 0, 0);
-  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (active) {
-    rec = hrec[slot];
-    q = hq[slot];
-  }
-  const bool is_target = rec.x < 0;
-  const float alpha = __int_as_float(rec.y), dx = __int_as_float(rec.z), dy = __int_as_float(rec.w);
-  const float beta = q.w;
-  float q1 = q.x;
-  v2f_t q23 = {q.y, q.z};
-  // signed per-lane constants: see k_persistent_wg
-  const float as = is_target ? -alpha : alpha, bs = is_target ? -beta : beta, ac = is_target ? alpha : -alpha;
-  const v2f_t P12 = {alpha * dx, alpha * dy};
-  const v2f_t C2 = is_target ? v2f_t{beta, beta} : v2f_t{-dx, -dy};
-  const float nbeta = -beta;
-
-  float4 st = make_float4(0.f, 0.f, 0.f, 0.f), bs4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float2 aux = make_float2(0.f, 0.f);
-  if (valid) {
-    st = vstate[pv];
-    aux = vaux[pv];
-    bs4 = bar_in[pv];
-  }
-  const float data = st.w;
-  const float thr = p.step_x * (p.data_factor * aux.x);
-  float x = st.x;
-  v2f_t w12 = {st.y, st.z};
-  float xb = bs4.x;
-  v2f_t wb12 = {bs4.y, bs4.z};
-  float x_prev = x;
-  v2f_t w_prev = w12;
-  bool ok = true;
-  bool timed_out = false;
-
-  const int my_off = (rid_base + loc) << 4;
-  const bool in_slab = active && pos < kWgSlab;
-  const int wrA = in_slab ? o_slabA + loc * kWgSlab + pos : o_ovfA + tid;
-  const int wrC = in_slab ? f_slabC + loc * kWgSlab + pos : f_ovfC + tid;
-  const int rdA = o_slabA + loc * kWgSlab, rdC4 = (f_slabC + loc * kWgSlab) >> 2;
-  const int ovf_base = first;
-  const int rec_w = valid ? loc : o_ovfA + tid, rec_wstride = valid ? rec_stride : 0;
-
-  for (int i = tid; i < lcap * kWgSlab; i += T) {
-    lds[o_slabA + i] = make_float4(-0.0f, -0.0f, -0.0f, -0.0f);
-    ldsf[f_slabC + i] = -0.0f;
-  }
-  for (int i = tid; i < rcap; i += T) {  // tag 0 is never a live tag
-    lds[lcap + i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    lds[rec_stride + lcap + i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  if (dual && is_tail && publishes) {
-    const unsigned my_xcc = read_xcc_id();
-    __builtin_amdgcn_raw_buffer_store_b32((int)(xcc_want | my_xcc), rx, 4 * S + (my_off >> 2), 0, kAuxSc1);
-  }
-  const bool mute = (max_spins_arg >> 31) != 0u && wg == wg_begin;  // test hook: FLAME_NLTGV2_OPT_FAULT_INJECT
-  const bool pub_lane = is_tail && publishes;
-  {
-    const float tagf = __uint_as_float(tag0);
-    lds[(p0 ? rec_wstride : 0) + rec_w] = make_float4(xb, wb12.x, wb12.y, tagf);  // area A
-    if (pub_lane && !mute) {
-      v4i_t o;
-      o.x = __float_as_int(xb), o.y = __float_as_int(wb12.x), o.z = __float_as_int(wb12.y), o.w = (int)tag0;
-      const int so = p0 ? par : 0;
-      __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
-      if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
-    }
-  }
-  lds_wg_barrier();  // (A) the only barrier: LDS initialised before the first DMA lands
-  unsigned pr_t0 = 0;
-  if (PROBE) pr_t0 = (unsigned)clock64();
-
-  // One step.  rd / wr: float4 index of the record area read / written; so_out: memory offset of the parity written.
-  auto step = [&](const unsigned s, const int rd_nbr, const int wr_rec, const int so_out, const int it) {
-    // ---- the neighbour's record of step s, from LDS ------------------------------------------------------------
-    float4 nb4;
-    unsigned spins = 0;
-    for (;;) {
-      asm volatile("" ::: "memory");
-      nb4 = lds[rd_nbr];
-      const bool pend = active && (__float_as_uint(nb4.w) != s);
-      if (!__any(pend)) break;
-      if ((++spins & 127u) == 0u) {
-        if (wg_flag != 0 || spins > max_spins) {
-          timed_out = true;
-          break;
-        }
-      }
-    }
-    unsigned pr_t1 = 0;
-    if (PROBE) pr_t1 = (unsigned)clock64();
-    // ---- dual update of this half-edge's private q copy (cc:99-110) ------------------------------
-    const v2f_t nbw = {nb4.y, nb4.z};
-    const float d0 = xb - nb4.x;
-    const v2f_t d12 = wb12 - nbw;
-    const v2f_t wbi = is_target ? nbw : wb12;  // the SOURCE vertex's (w1_bar, w2_bar)
-    float K1 = as * d0;
-    const v2f_t m12 = P12 * wbi;
-    K1 -= m12.x;
-    K1 -= m12.y;
-    const v2f_t K23 = bs * d12;
-    const float q1r = q1 + p.step_q * K1;
-    const v2f_t q23r = q23 + p.step_q * K23;
-    ok = ok && (__builtin_fabsf(q1r) <= 3.402823466e+38f) && (__builtin_fabsf(q23r.x) <= 3.402823466e+38f) &&
-         (__builtin_fabsf(q23r.y) <= 3.402823466e+38f);  // NaN/Inf: the reference's FLAME_ASSERT h:174
-    q1 = __builtin_fminf(__builtin_fmaxf(q1r, -1.0f), 1.0f);
-    q23.x = __builtin_fminf(__builtin_fmaxf(q23r.x, -1.0f), 1.0f);
-    q23.y = __builtin_fminf(__builtin_fmaxf(q23r.y, -1.0f), 1.0f);
-    // ---- this endpoint's share of the primal scatter (cc:126-141) as ordered contributions -------
-    const float u1 = q1 * p.step_x;
-    const v2f_t u23 = q23 * p.step_x;
-    const float cx = u1 * ac;
-    const v2f_t M2 = is_target ? u23 : v2f_t{cx, cx};
-    const v2f_t a12 = M2 * C2;
-    v2f_t b12 = u23 * nbeta;
-    b12 = is_target ? v2f_t{-0.0f, -0.0f} : b12;
-    lds[wrA] = make_float4(a12.x, a12.y, b12.x, b12.y);
-    ldsf[wrC] = cx;
-    lds_wave_sync();
-    // ---- ordered accumulation, by every lane of the vertex (ascending edge id = ascending slot) --------------
-    float X = x;
-    v2f_t Wa = w12;
-#define PW_ACC(K0, N)                                                                 \
-  {                                                                                   \
-    float4 c[N];                                                                      \
-    _Pragma("unroll") for (int k = 0; k < N; ++k) c[k] = lds[rdA + (K0) + k];         \
-    float cxs[8];                                                                     \
-    {                                                                                 \
-      const float4 cxa = lds[rdC4 + (K0) / 4];                                        \
-      cxs[0] = cxa.x, cxs[1] = cxa.y, cxs[2] = cxa.z, cxs[3] = cxa.w;                 \
-    }                                                                                 \
-    if (N > 4) {                                                                      \
-      const float4 cxb = lds[rdC4 + (K0) / 4 + 1];                                    \
-      cxs[4] = cxb.x, cxs[5] = cxb.y, cxs[6] = cxb.z, cxs[7] = cxb.w;                 \
-    }                                                                                 \
-    _Pragma("unroll") for (int k = 0; k < N; ++k) {                                   \
-      X = X + cxs[k];                                                                 \
-      Wa = (Wa + v2f_t{c[k].x, c[k].y}) + v2f_t{c[k].z, c[k].w};                      \
-    }                                                                                 \
-  }
-    PW_ACC(0, 8)
-    if (chain > 8) {  // wave-uniform: some vertex of this wave has more than 8 incident edges
-      if (chain <= 12) {
-        PW_ACC(8, 4)
-      } else {
-        PW_ACC(8, 8)
-        for (int k = kWgSlab; k < chain; ++k) {  // beyond 16: per-lane overflow strip (not a Delaunay case)
-          if (k < deg) {
-            const float4 c = lds[o_ovfA + ovf_base + k];
-            X = X + ldsf[f_ovfC + ovf_base + k];
-            Wa = (Wa + v2f_t{c.x, c.y}) + v2f_t{c.z, c.w};
-          }
-        }
-      }
-    }
-#undef PW_ACC
-    // ---- vertex update: proxL1 (cc:147-151, h:179-197), extragradient (cc:160-171) --------------------------
-    const float diff = X - data;
-    float xn = (diff > thr) ? X - thr : ((diff < -thr) ? X + thr : data);
-    xn = (xn < p.x_min) ? p.x_min : xn;
-    xn = (xn > p.x_max) ? p.x_max : xn;
-    float nb = xn + p.theta * (xn - x);
-    nb = (nb < p.x_min) ? p.x_min : nb;
-    nb = (nb > p.x_max) ? p.x_max : nb;
-    const v2f_t wbn = Wa + p.theta * (Wa - w12);
-    if (pub_lane) {
-      v4i_t o;
-      o.x = __float_as_int(nb), o.y = __float_as_int(wbn.x), o.z = __float_as_int(wbn.y), o.w = (int)(s + 1u);
-      __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so_out, kAuxSc1);
-      if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so_out, 0);
-    }
-    lds[wr_rec] = make_float4(nb, wbn.x, wbn.y, __uint_as_float(s + 1u));
-    x_prev = x, w_prev = w12;  // step()'s prev copy, cc:37-42
-    x = xn, w12 = Wa;
-    xb = nb, wb12 = wbn;
-    if (PROBE) {
-      const unsigned pr_t2 = (unsigned)clock64();
-      if (lane == 0 && probe) {  // {-, -, LDS wait, compute, LDS polls, step start, 100 MHz clock, 0 = compute wave}
-        unsigned* o = probe + ((size_t)(wg * 2) * n_iters + it) * 8;
-        o[0] = read_hw_id(), o[1] = 0, o[2] = pr_t1 - pr_t0, o[3] = pr_t2 - pr_t1;
-        o[4] = spins, o[5] = pr_t0, o[6] = (unsigned)wall_clock64(), o[7] = 0u;
-      }
-      pr_t0 = pr_t2;
-    }
-  };
-
-  // Two steps per trip with the parities fixed: area A holds the records of the first step, B those of the next.
-  const int areaA = p0 ? rec_stride : 0, areaB = p0 ? 0 : rec_stride;
-  const int soA = p0 ? par : 0, soB = p0 ? 0 : par;  // memory offsets of the parities
-  const int rdA_nbr = areaA + nbr_idx, rdB_nbr = areaB + nbr_idx;  // per lane: where the neighbour's record is read ...
-  const int wrA_rec = (valid ? areaA : 0) + rec_w, wrB_rec = (valid ? areaB : 0) + rec_w;  // ... and the own one left
-  int it = 0;
-  for (; it + 1 < n_iters && !timed_out; it += 2) {
-    step(tag0 + (unsigned)it, rdA_nbr, wrB_rec, soB, it);
-    if (timed_out) break;
-    step(tag0 + (unsigned)it + 1u, rdB_nbr, wrA_rec, soA, it + 1);
-  }
-  if (it < n_iters && !timed_out) step(tag0 + (unsigned)it, rdA_nbr, wrB_rec, soB, it);
-
-  if (timed_out) {
-    if (lane == 0) {
-      __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      atomicOr(err, 2);
-    }
-    return;
-  }
-
-  if (is_tail) {
-    vstate_out[pv] = make_float4(x, w12.x, w12.y, data);
-    bar_out[pv] = make_float4(xb, wb12.x, wb12.y, 0.0f);
-    vprev[pv] = make_float4(x_prev, w_prev.x, w_prev.y, 0.0f);
-    float* const export_out = tail->export_out;
-    float* const photo_err = tail->photo.err;
-    if (export_out || photo_err) {
-      const int o = perm[pv];  // the caller's vertex index
-      if (o >= 0 && export_out) export_out[o] = x * tail->export_scale;
-      if (o >= 0 && photo_err) {
-        const PhotoFuse& photo = tail->photo;
-        photo_err[o] = photo_residual_at(photo.pos[o], x * photo.graph_scale, photo.geo, photo.ref, photo.cmp, photo.rows,
-                                         photo.cols, photo.step, photo.border);
-      }
-    }
-  }
-  if (active) hq_out[slot] = make_float4(q1, q23.x, q23.y, beta);
-  if (!ok && active) atomicOr(err, 1);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Persistent run, patch-per-wave form, ONE wave per patch ("pv"): layout (E) with wg_waves = 1.  The patch's wave does
-// everything: no second wave to share a SIMD with, no barrier, no flag.  Between publishing its records of step s+1 and
-// starting step s+1 it runs one six-instruction loop: issue an LDS-DMA load of the patch's foreign records (lane i's
-// record lands in fetch slot i of the step's LDS area; nothing waits for it), read every half-edge lane's neighbour
-// record from LDS (payload + tag), leave when all tags are the step's.  A neighbour inside the patch is there from the
-// start (the wave wrote it itself at the end of the previous step).  The records come out of the loop in registers.
-// ------------------------------------------------------------------------------------------------
 template <bool PROBE>
 __global__ void __launch_bounds__(64)
 k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, const int lcap, const int slab_slots,
                 const int32_t* __restrict__ wg_slot, const int32_t* __restrict__ wg_vid,
                 const uint32_t* __restrict__ wg_meta, const int32_t* __restrict__ wg_nbr,
-                const int32_t* __restrict__ wg_fetch, const int32_t* __restrict__ wg_info,
-                const int32_t* __restrict__ wg_wave_chain, const int4* hrec, const float4* hq, const float4* vstate,
+                const int32_t* __restrict__ wg_fetch, const int32_t* __restrict__ wg_info, const int4* hrec,
+                const float4* hq, const float4* vstate,
                 float4* hq_out, float4* vstate_out, const float2* vaux, const float4* bar_in, float4* bar_out, float4* vprev,
                 void* xbuf, const int rec_bytes, const int dual, const unsigned tag0, const int n_iters,
-                const unsigned max_spins_arg, const int presleep, const int poll_gap, const SolverParams p,
+                const unsigned max_spins_arg, const int poll_gap, const SolverParams p,
                 int* __restrict__ err, int* __restrict__ abort_flag, const int32_t* __restrict__ perm,
                 const RunTail* __restrict__ tail, unsigned* __restrict__ probe) {
   extern __shared__ float4 lds[];
@@ -1519,7 +674,6 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
 
   // ---- where this lane's polls read: the remote copy of its foreign record, or the copy in this XCD's L2 ------------
   int off0 = (frid >= 0) ? (frid << 4) : 0;
-  bool is_local = false;  // this lane's foreign record is produced on this XCD
   if (dual) {
     const unsigned my_xcc = read_xcc_id();
     if (is_tail && publishes)
@@ -1541,18 +695,10 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
         }
         __builtin_amdgcn_s_sleep(2);
       }
-      if (!timed_out && frid >= 0 && (g0 & 15u) == my_xcc) {
-        off0 += S;
-        is_local = true;
-      }
+      if (!timed_out && frid >= 0 && (g0 & 15u) == my_xcc) off0 += S;
     }
   }
   const unsigned long long fetch_mask = __ballot(frid >= 0);  // the lanes with a fetch duty (the wave runs with all 64 lanes)
-  // A record from another XCD cannot be there before its producer has computed a step and a write-through has crossed
-  // the fabric: the first `presleep` rounds of a wait poll the XCD-local records only (remote polls are requests to the
-  // memory side, the scarce resource: with all records polled remotely a 640x480 step takes 3.5 us instead of 1.3).
-  const unsigned long long fetch_local = __ballot(is_local);
-  const unsigned local_rounds = (unsigned)presleep;
   const bool mute = (max_spins_arg >> 31) != 0u && wg == wg_begin;  // test hook: FLAME_NLTGV2_OPT_FAULT_INJECT
   const bool pub_lane = is_tail && publishes;
   {
@@ -1588,8 +734,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
                "s_mov_b32 m0, %[dst]\n\t"                                                               \
                "s_mov_b32 %[cnt], 0\n\t"                                                                \
                "1:\n\t"                                                                                 \
-               "s_cmp_lt_u32 %[cnt], %[rl]\n\t"                                                         \
-               "s_cselect_b64 exec, %[fl], %[fm]\n\t"                                                   \
+               "s_mov_b64 exec, %[fm]\n\t"                                                              \
                "global_load_lds_dwordx4 %[src], off " POLICY "\n\t"                                     \
                "s_mov_b64 exec, -1\n\t" GAP "ds_read_b32 %[t], %[ra] offset:12\n\t"                   \
                "ds_read_b128 %[nb], %[ra]\n\t"                                                          \
@@ -1604,15 +749,11 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
                "s_or_b32 %[pl], %[pl], vcc_hi\n\t"                                                      \
                "s_mov_b32 m0, %[keep]"                                                                   \
                : [keep] "=&s"(keep), [cnt] "=&s"(cnt), [pl] "=&s"(pend_lo), [nb] "=&v"(nbv), [t] "=&v"(tagv) \
-               : [src] "v"(src), [dst] "s"(dst), [ra] "v"(rd_nbr), [tag] "s"(s), [fm] "s"(fetch_mask),      \
-                 [fl] "s"(fetch_local), [rl] "s"(local_rounds)                                               \
+               : [src] "v"(src), [dst] "s"(dst), [ra] "v"(rd_nbr), [tag] "s"(s), [fm] "s"(fetch_mask)       \
                : "vcc", "scc", "memory")
-        const int pol = poll_gap >> 8;
-        if (pol == 1) {
-          PV_POLL("sc0 sc1", "");
-        } else if (pol == 2) {
-          PV_POLL("sc1 nt", "");
-        } else if ((poll_gap & 0xff) == 0) {
+        // up to 64 rounds per statement: one LDS-DMA load per fetch lane (M0 = destination base, saved and restored
+        // inside the statement), then every lane's neighbour record from LDS; vcc = lanes still waiting
+        if (poll_gap == 0) {
           PV_POLL("sc1", "");
         } else {
           PV_POLL("sc1", "s_sleep 1\n\t");
@@ -2446,27 +1587,11 @@ int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, boo
   return (int)hipGetLastError();
 }
 
-// Workgroups of k_persistent_wg the runtime keeps resident per CU for this layout (block size and LDS use).
-int wg_blocks_per_cu(const FusedArgs& a) {
-  const int T = 64 * a.wg_waves;
-  const size_t lds3 = 16u * (size_t)(2 * (a.wg_lcap + a.wg_rcap) + a.wg_lcap * kWgSlab + T) + 4u * (size_t)(a.wg_lcap * kWgSlab + T);
+// Patches of k_persistent_pv (one wave each) the runtime keeps resident per CU for this layout's LDS use.
+int pv_patches_per_cu(const FusedArgs& a) {
+  const size_t ldsv = 16u * (size_t)(2 * (a.wg_lcap + 64) + a.wg_slab_slots + 64) + 4u * (size_t)(a.wg_slab_slots + 64);
   int n = 0;
-  if (a.wg_waves == 1 && a.pw_roles == 0) {
-    const size_t ldsv = 16u * (size_t)(2 * (a.wg_lcap + 64) + a.wg_slab_slots + 64) + 4u * (size_t)(a.wg_slab_slots + 64);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_persistent_pv<false>, 64, ldsv) != hipSuccess) {
-      (void)hipGetLastError();
-      return 0;
-    }
-    return n;
-  }
-  if (a.wg_waves == 1) {  // in PATCHES per CU
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_persistent_pw<false>, 128, lds3) != hipSuccess) {
-      (void)hipGetLastError();
-      return 0;
-    }
-    return n;
-  }
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_persistent_wg<false>, 64 * (a.wg_waves + 1), lds3) != hipSuccess) {
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_persistent_pv<false>, 64, ldsv) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
@@ -2474,7 +1599,7 @@ int wg_blocks_per_cu(const FusedArgs& a) {
 }
 
 // Persistent run (single launch).  form 1 = lane per half-edge (k_persistent_he), form 2 = vertex per
-// lane (k_persistent_tv), form 3 = patch per workgroup (k_persistent_wg).  Returns the hipError_t unchanged (e.g. hipErrorCooperativeLaunchTooLarge)
+// lane (k_persistent_tv), form 3 = patch per wave (k_persistent_pv).  Returns the hipError_t unchanged (e.g. hipErrorCooperativeLaunchTooLarge)
 // so the caller can fall back to per-step launches.
 int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, int wave_begin, int n_waves,
                           int parity_in, unsigned tag0, int n_iters, int waves_per_block, unsigned max_spins,
@@ -2509,48 +1634,20 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
   void* args[] = {&wave_begin, &n_waves, &wpx, &i0, &i1, &i2, &i3, &hrec, &hq, &vstate, &hq_out, &vstate_out, &vaux,
                   &bin, &bout, &vprev, &xbuf, &rec_bytes, &dual, &tag0, &n_iters, &max_spins, &presleep, &pp, &err,
                   &abort_flag, &perm, &tail};
-  if (form == 3) {  // patch-per-workgroup form: n_waves / wave_begin count WORKGROUPS
+  if (form == 3) {  // patch-per-wave form: n_waves / wave_begin count PATCHES (one wave each)
     int wgx = (n_waves + xcds - 1) / xcds;
-    const dim3 g3((unsigned)(wgx * 8)), b3((unsigned)(64 * (a.wg_waves + 1)));  // + the communication wave
-    int lcap = a.wg_lcap, rcap = a.wg_rcap;
-    const int32_t *w0 = a.wg_slot, *w1 = a.wg_vid, *w3 = a.wg_nbr, *w4 = a.wg_fetch, *w5 = a.wg_info, *w6 = a.wg_wave_chain;
+    const dim3 gv((unsigned)(wgx * 8)), bv(64u);
+    int lcap = a.wg_lcap, slab_slots = a.wg_slab_slots, poll_gap = a.wg_poll_gap;
+    const int32_t *w0 = a.wg_slot, *w1 = a.wg_vid, *w3 = a.wg_nbr, *w4 = a.wg_fetch, *w5 = a.wg_info;
     const uint32_t* w2 = a.wg_meta;
     unsigned* probe = a.probe;
-    int poll_gap = a.wg_poll_gap;
-    int rec_shift = a.wg_rec_shift, rec_rep = a.wg_rec_rep;
-    int rec_bytes3 = (a.n_slices * 64) << rec_shift;
-    size_t probe_lat_base = a.probe_lat_base;
-    void* wargs[] = {&wave_begin, &n_waves, &wgx, &lcap, &rcap, &w0, &w1, &w2, &w3, &w4, &w5, &w6, &hrec, &hq, &vstate,
-                     &hq_out, &vstate_out, &vaux, &bin, &bout, &vprev, &xbuf, &rec_bytes3, &dual, &tag0, &n_iters,
-                     &max_spins, &presleep, &poll_gap, &rec_shift, &rec_rep, &pp, &err, &abort_flag, &perm, &tail, &probe,
-                     &probe_lat_base};
-    const int T = 64 * a.wg_waves;
-    const unsigned lds3 = 16u * (unsigned)(2 * (lcap + rcap) + lcap * kWgSlab + T) + 4u * (unsigned)(lcap * kWgSlab + T);
-    if (a.wg_waves == 1 && a.pw_roles == 0) {  // patch-per-wave form, one wave per patch
-      const dim3 gv((unsigned)(wgx * 8)), bv(64u);
-      int slab_slots = a.wg_slab_slots;
-      const unsigned ldsv = 16u * (unsigned)(2 * (lcap + 64) + slab_slots + 64) + 4u * (unsigned)(slab_slots + 64);
-      void* vargs[] = {&wave_begin, &n_waves, &wgx, &lcap, &slab_slots, &w0, &w1, &w2, &w3, &w4, &w5, &w6, &hrec, &hq, &vstate,
-                       &hq_out, &vstate_out, &vaux, &bin, &bout, &vprev, &xbuf, &rec_bytes, &dual, &tag0, &n_iters,
-                       &max_spins, &presleep, &poll_gap, &pp, &err, &abort_flag, &perm, &tail, &probe};
-      const void* fv = probe ? (const void*)k_persistent_pv<true> : (const void*)k_persistent_pv<false>;
-      if (cooperative) return (int)hipLaunchCooperativeKernel(fv, gv, bv, vargs, ldsv, stream);
-      return (int)hipLaunchKernel(fv, gv, bv, vargs, ldsv, stream);
-    }
-    if (a.wg_waves == 1) {  // patch-per-wave form: one compute wave + one communication wave, no barrier in the loop
-      int roles = a.pw_roles == 2 ? 1 : 0;
-      const dim3 gp((unsigned)(wgx * 8)), bp(128u);
-      const unsigned ldsp = lds3;
-      void* pargs[] = {&wave_begin, &n_waves, &wgx, &lcap, &rcap, &w0, &w1, &w2, &w3, &w4, &w5, &w6, &hrec, &hq, &vstate,
-                       &hq_out, &vstate_out, &vaux, &bin, &bout, &vprev, &xbuf, &rec_bytes, &dual, &tag0, &n_iters,
-                       &max_spins, &presleep, &poll_gap, &roles, &pp, &err, &abort_flag, &perm, &tail, &probe};
-      const void* fp = probe ? (const void*)k_persistent_pw<true> : (const void*)k_persistent_pw<false>;
-      if (cooperative) return (int)hipLaunchCooperativeKernel(fp, gp, bp, pargs, ldsp, stream);
-      return (int)hipLaunchKernel(fp, gp, bp, pargs, ldsp, stream);
-    }
-    const void* f3 = probe ? (const void*)k_persistent_wg<true> : (const void*)k_persistent_wg<false>;
-    if (cooperative) return (int)hipLaunchCooperativeKernel(f3, g3, b3, wargs, lds3, stream);
-    return (int)hipLaunchKernel(f3, g3, b3, wargs, lds3, stream);
+    const unsigned ldsv = 16u * (unsigned)(2 * (lcap + 64) + slab_slots + 64) + 4u * (unsigned)(slab_slots + 64);
+    void* vargs[] = {&wave_begin, &n_waves, &wgx, &lcap, &slab_slots, &w0, &w1, &w2, &w3, &w4, &w5, &hrec, &hq, &vstate,
+                     &hq_out, &vstate_out, &vaux, &bin, &bout, &vprev, &xbuf, &rec_bytes, &dual, &tag0, &n_iters,
+                     &max_spins, &poll_gap, &pp, &err, &abort_flag, &perm, &tail, &probe};
+    const void* fv = probe ? (const void*)k_persistent_pv<true> : (const void*)k_persistent_pv<false>;
+    if (cooperative) return (int)hipLaunchCooperativeKernel(fv, gv, bv, vargs, ldsv, stream);
+    return (int)hipLaunchKernel(fv, gv, bv, vargs, ldsv, stream);
   }
   const bool tv_lds = form == 2 && (tv_static_in_lds != 0);
   const void* fn = (form == 2) ? (tv_lds ? (const void*)k_persistent_tv<true> : (const void*)k_persistent_tv<false>)

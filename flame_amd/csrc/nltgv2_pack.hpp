@@ -78,27 +78,24 @@ struct PackedLayout {
   std::vector<int32_t> comp_start;     // [n_comp+1] first packed vertex of each component
   std::vector<int32_t> comp_he_wave;   // [n_comp+1] first (C) wave of each component
   std::vector<int32_t> comp_tv_wave;   // [n_comp+1] first (D) wave of each component
-  // (E) patch-per-workgroup rows of the persistent run ("wg" form): the half-edge lanes of (C), but `wg_waves`
-  // consecutive waves form ONE workgroup that owns a compact Morton patch of vertices.  Inside the patch the
-  // exchange goes through LDS; only the DISTINCT vertices of other patches that the patch touches are fetched
-  // from memory (one polling lane each, sorted by record id), and only vertices with a neighbour in another
-  // patch publish.  Records are numbered in walk order (rid), so a patch's records are contiguous.
+  // (E) patch-per-wave rows of the persistent run (k_persistent_pv): the half-edge lanes of (C), one wave = one compact
+  // Morton patch of vertices.  Inside the patch the exchange goes through LDS; only the DISTINCT vertices of other
+  // patches that the patch touches are fetched from memory (one lane each, sorted by record id), and only vertices
+  // with a neighbour in another patch publish.  Records are numbered in walk order (rid), so a patch's records are
+  // contiguous.
   bool wg_ok = false;
-  int32_t wg_waves = 0;                // waves per workgroup this layout was built for
-  int32_t wg_count = 0;
-  int32_t wg_lcap = 0, wg_rcap = 0;    // most local vertices / fetched records of any workgroup (LDS sizing)
-  std::vector<int32_t> wg_slot;        // [wg_count*T] SELL slot of the lane's half-edge, -1 idle   (T = 64*wg_waves)
-  std::vector<int32_t> wg_vid;         // [wg_count*T] packed vertex owning the lane, -1 unused lane
-  std::vector<uint32_t> wg_meta;       // [wg_count*T] first lane | deg<<6 | local index<<13 | flags<<24
-  std::vector<int32_t> wg_nbr;         // [wg_count*T] neighbour: local index, or 0x80000000 | fetch index
-  std::vector<int32_t> wg_fetch;       // [wg_count*T] record id fetched by this lane, -1 none
+  int32_t wg_count = 0;                // patches
+  int32_t wg_lcap = 0, wg_rcap = 0;    // most local vertices / fetched records of any patch (LDS sizing; wg_ok needs rcap <= 64)
+  int32_t wg_slab_slots = 0;           // most (local vertices x slab stride) of any patch (LDS sizing)
+  std::vector<int32_t> wg_slot;        // [wg_count*64] SELL slot of the lane's half-edge, -1 idle
+  std::vector<int32_t> wg_vid;         // [wg_count*64] packed vertex owning the lane, -1 unused lane
+  std::vector<uint32_t> wg_meta;       // [wg_count*64] first lane | deg<<6 | local index<<13 | flags<<24
+  std::vector<int32_t> wg_nbr;         // [wg_count*64] neighbour: local index, or 0x80000000 | fetch index
+  std::vector<int32_t> wg_fetch;       // [wg_count*64] record id fetched by this lane, -1 none
   std::vector<int32_t> wg_info;        // [wg_count*4] first record id, fetched records, local vertices, slab stride
-  int32_t wg_slab_slots = 0;           // most (local vertices x slab stride) of any workgroup (LDS sizing, wg_waves == 1)
-  std::vector<int32_t> wg_wave_chain;  // [wg_count*wg_waves] max(1, max degree) of the wave's vertices
-  std::vector<int32_t> comp_wg;        // [n_comp+1] first workgroup of each component
+  std::vector<int32_t> comp_wg;        // [n_comp+1] first patch of each component
 };
 constexpr uint32_t kWgTail = 1u << 24, kWgActive = 1u << 25, kWgValid = 1u << 26, kWgPublish = 1u << 27;
-constexpr int kWgMaxLocal = 2048;  // 11 bits of local index
 constexpr int kTvSlots = 8;
 constexpr uint32_t kTvOwner = 1u << 16, kTvValid = 1u << 17;
 
@@ -114,50 +111,49 @@ inline uint32_t morton_spread16(uint32_t v) {
 }
 
 // Returns FLAME_NLTGV2_OK or FLAME_NLTGV2_ERR_INVALID_ARG.
-// ---- (E) patch-per-workgroup rows ------------------------------------------------------------------
+// ---- (E) patch-per-wave rows ------------------------------------------------------------------------
 // order_m = the vertices in (component, Morton) order; needs (B) (iperm, pdeg, slice_row, rec_nbr) and comp_start.
-inline void build_wg_rows(PackedLayout* L, const std::vector<int32_t>& order_m, int wg_waves) {
+inline void build_patch_rows(PackedLayout* L, const std::vector<int32_t>& order_m) {
   const int32_t V = L->V;
+  constexpr int32_t T = kWave;
   L->wg_ok = false;
-  L->wg_waves = wg_waves;
-  L->wg_count = 0, L->wg_lcap = 0, L->wg_rcap = 0;
+  L->wg_count = 0, L->wg_lcap = 0, L->wg_rcap = 0, L->wg_slab_slots = 0;
   L->wg_slot.clear(), L->wg_vid.clear(), L->wg_meta.clear(), L->wg_nbr.clear(), L->wg_fetch.clear();
-  L->wg_info.clear(), L->wg_wave_chain.clear(), L->comp_wg.clear();
-  if (wg_waves < 1 || wg_waves > 15 || L->max_degree > kWave || V <= 0) return;
-  const int32_t T = kWave * wg_waves;
+  L->wg_info.clear(), L->comp_wg.clear();
+  if (L->max_degree > kWave || V <= 0) return;
   const size_t n_packed = static_cast<size_t>(L->n_slices) * kWave;
   std::vector<int32_t> v_wg(n_packed, -1), v_loc(n_packed, -1);
-  // pass 1: place the vertices (same greedy walk as (C); a workgroup = wg_waves consecutive waves of one component)
-  int32_t fill = kWave, wave_in_wg = wg_waves, n_local = 0, rid = 0;
+  // pass 1: place the vertices (the greedy walk of (C): a vertex's lanes never straddle two waves, a component
+  // begins a new wave)
+  int32_t fill = kWave, n_local = 0, rid = 0, max_deg = 1;
   size_t next_comp = 0;
-  auto new_wg = [&]() {
-    L->wg_slot.resize(L->wg_slot.size() + T, -1);
-    L->wg_vid.resize(L->wg_vid.size() + T, -1);
-    L->wg_meta.resize(L->wg_meta.size() + T, 0u);
-    L->wg_nbr.resize(L->wg_nbr.size() + T, 0);
-    L->wg_fetch.resize(L->wg_fetch.size() + T, -1);
-    L->wg_info.resize(L->wg_info.size() + 4, 0);
-    L->wg_wave_chain.resize(L->wg_wave_chain.size() + wg_waves, 1);
-    L->wg_info[static_cast<size_t>(L->wg_count) * 4] = rid;
-    L->wg_count++;
-    wave_in_wg = 0, fill = 0, n_local = 0;
+  auto close_patch = [&]() {  // slab stride of the patch just filled: its largest degree rounded up to 4, at least 8
+    if (L->wg_count == 0) return;
+    const int32_t stride = std::max(8, (max_deg + 3) & ~3);
+    L->wg_info[static_cast<size_t>(L->wg_count - 1) * 4 + 3] = stride;
+    L->wg_slab_slots = std::max(L->wg_slab_slots, stride * n_local);
   };
   for (int32_t i = 0; i < V; ++i) {
     const int32_t s = L->iperm[order_m[i]];
     const int32_t d = L->pdeg[s];
     const int32_t need = std::max(d, 1);
     const bool comp_begin = next_comp < L->comp_start.size() && L->comp_start[next_comp] == i;
-    if (comp_begin) {
-      L->comp_wg.push_back(L->wg_count);
-      ++next_comp;
-    }
-    if (comp_begin || (fill + need > kWave && wave_in_wg + 1 >= wg_waves) || n_local >= kWgMaxLocal) {
-      new_wg();
-    } else if (fill + need > kWave) {
-      ++wave_in_wg, fill = 0;
+    if (comp_begin) ++next_comp;
+    if (comp_begin || fill + need > kWave) {
+      close_patch();
+      if (comp_begin) L->comp_wg.push_back(L->wg_count);
+      L->wg_slot.resize(L->wg_slot.size() + T, -1);
+      L->wg_vid.resize(L->wg_vid.size() + T, -1);
+      L->wg_meta.resize(L->wg_meta.size() + T, 0u);
+      L->wg_nbr.resize(L->wg_nbr.size() + T, 0);
+      L->wg_fetch.resize(L->wg_fetch.size() + T, -1);
+      L->wg_info.resize(L->wg_info.size() + 4, 0);
+      L->wg_info[static_cast<size_t>(L->wg_count) * 4] = rid;
+      L->wg_count++;
+      fill = 0, n_local = 0, max_deg = 1;
     }
     const int32_t wg = L->wg_count - 1;
-    const size_t base = static_cast<size_t>(wg) * T + static_cast<size_t>(wave_in_wg) * kWave + fill;
+    const size_t base = static_cast<size_t>(wg) * T + fill;
     const int64_t row0 = L->slice_row[s / kWave];
     for (int32_t k = 0; k < need; ++k) {
       uint32_t m = static_cast<uint32_t>(fill) | (static_cast<uint32_t>(d) << 6) | (static_cast<uint32_t>(n_local) << 13) |
@@ -170,16 +166,16 @@ inline void build_wg_rows(PackedLayout* L, const std::vector<int32_t>& order_m, 
       L->wg_vid[base + k] = s;
       L->wg_meta[base + k] = m;
     }
-    int32_t& ch = L->wg_wave_chain[static_cast<size_t>(wg) * wg_waves + wave_in_wg];
-    ch = std::max(ch, need);
+    max_deg = std::max(max_deg, need);
     v_wg[s] = wg, v_loc[s] = n_local;
     L->wg_info[static_cast<size_t>(wg) * 4 + 2] = ++n_local;
     L->wg_lcap = std::max(L->wg_lcap, n_local);
     fill += need;
     ++rid;
   }
+  close_patch();
   L->comp_wg.push_back(L->wg_count);
-  // pass 2: neighbours -- local index, or one fetch lane per distinct vertex of another workgroup (sorted by record id)
+  // pass 2: neighbours -- local index, or one fetch lane per distinct vertex of another patch (sorted by record id)
   std::vector<int32_t> want;
   for (int32_t wg = 0; wg < L->wg_count; ++wg) {
     const size_t b = static_cast<size_t>(wg) * T;
@@ -208,26 +204,14 @@ inline void build_wg_rows(PackedLayout* L, const std::vector<int32_t>& order_m, 
         // this lane's own vertex has a neighbour outside the patch: it publishes (mark all its lanes)
         const int32_t first = static_cast<int32_t>(L->wg_meta[b + t] & 63u);
         const int32_t need = std::max<int32_t>(1, static_cast<int32_t>((L->wg_meta[b + t] >> 6) & 127u));
-        const size_t wb = b + static_cast<size_t>(t / kWave) * kWave;
-        for (int32_t k = 0; k < need; ++k) L->wg_meta[wb + first + k] |= kWgPublish;
+        for (int32_t k = 0; k < need; ++k) L->wg_meta[b + first + k] |= kWgPublish;
       }
     }
   }
-  // contribution slab of the patch-per-wave form: every vertex of a patch gets `stride` slots, stride = the patch's
-  // largest degree rounded up to a multiple of 4 (at least 8): the slots a vertex does not use hold -0.0f
-  L->wg_slab_slots = 0;
-  for (int32_t wg = 0; wg < L->wg_count; ++wg) {
-    int32_t ch = 1;
-    for (int32_t w = 0; w < wg_waves; ++w) ch = std::max(ch, L->wg_wave_chain[static_cast<size_t>(wg) * wg_waves + w]);
-    const int32_t stride = std::max(8, (ch + 3) & ~3);
-    L->wg_info[static_cast<size_t>(wg) * 4 + 3] = stride;
-    L->wg_slab_slots = std::max(L->wg_slab_slots, stride * L->wg_info[static_cast<size_t>(wg) * 4 + 2]);
-  }
-  // the communication wave fetches at most two records per lane (one in the patch-per-wave form, wg_waves == 1)
-  L->wg_ok = L->wg_rcap <= (wg_waves == 1 ? kWave : 2 * kWave);
+  L->wg_ok = true;  // (a patch has at most 64 half-edges, hence at most 64 distinct foreign records: one per lane)
 }
 
-inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L, int wg_waves = 4) {
+inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
   if (!g || g->V < 0 || g->E < 0) return FLAME_NLTGV2_ERR_INVALID_ARG;
   const int32_t V = g->V, E = g->E;
   if (V > 0 && !g->pos) return FLAME_NLTGV2_ERR_INVALID_ARG;
@@ -493,7 +477,7 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L, int wg_wav
     L->comp_tv_wave.push_back(L->tv_waves);
   }
   PROF_T(5);
-  build_wg_rows(L, order_m, wg_waves);
+  build_patch_rows(L, order_m);
   PROF_T(6);
   return FLAME_NLTGV2_OK;
 }

@@ -26,9 +26,10 @@ _LIB = None
 _FP = C.POINTER(C.c_float)
 _IP = C.POINTER(C.c_int32)
 
-OPT_SOLVER, OPT_USE_HIPGRAPH, OPT_BLOCK_WAVES, OPT_UNROLL, OPT_PERSISTENT, OPT_DUAL_PUBLISH, OPT_TV_LDS, OPT_PRESLEEP, OPT_XCDS, OPT_FAULT_INJECT, OPT_WG_WAVES, OPT_PROBE, OPT_POLL_GAP, OPT_WG_RECORD, OPT_PW_ROLES = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
+OPT_SOLVER, OPT_USE_HIPGRAPH, OPT_BLOCK_WAVES, OPT_UNROLL, OPT_PERSISTENT, OPT_DUAL_PUBLISH, OPT_TV_LDS, OPT_PRESLEEP, OPT_XCDS, OPT_FAULT_INJECT = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+OPT_PROBE, OPT_POLL_GAP = 12, 13
 RUN_PATHS = {0: "none", 1: "persistent", 2: "per-step hipGraph", 3: "per-step eager", 4: "canonical 4-sweep",
-             5: "persistent-tv", 6: "persistent-wg"}
+             5: "persistent-tv", 6: "persistent-pv"}
 ERR_NAN = -5
 
 VERTEX_STATE = ("x", "w1", "w2", "x_bar", "w1_bar", "w2_bar", "x_prev", "w1_prev", "w2_prev")
@@ -482,7 +483,7 @@ class Regularizer:
                   "set_export_target")
 
     def read_probe(self) -> np.ndarray:
-        """Cycle probe of the last patch-per-workgroup run (OPT_PROBE): uint32 [waves, steps, 8] flattened."""
+        """Cycle probe of the last patch-per-wave run (OPT_PROBE): uint32 [patches, steps, 8] flattened."""
         n = C.c_int64(0)
         self._chk(self._L.flame_nltgv2_read_probe(self._ctx, None, 0, C.byref(n)), "read_probe")
         out = np.zeros(int(n.value), dtype=np.uint32)

@@ -249,7 +249,7 @@ enum {
   FLAME_NLTGV2_OPT_PERSISTENT = 5,   /* 1 (default) = run() uses ONE persistent launch for all n_iters steps
                                         when the graph fits on the chip, picking the form by occupancy;
                                         2 = force the lane-per-half-edge form, 3 = force the vertex-per-lane
-                                        form, 4 = force the patch-per-workgroup form (each only if it fits);
+                                        form, 4 = force the patch-per-wave form (each only if it fits);
                                         0 = always one launch per step */
   FLAME_NLTGV2_OPT_DUAL_PUBLISH = 6, /* persistent run: neighbours on the same XCD exchange through that XCD's
                                         L2 (plain store + local record copy), others through write-through
@@ -262,17 +262,11 @@ enum {
                                         n in 1..64 = (n-1) x 64 cycles */
   FLAME_NLTGV2_OPT_XCDS = 9,         /* persistent run: number of XCDs (of 8) the waves are spread over: 0 (default) =
                                         one XCD for graphs small enough to run there, else all eight; 1..8 */
-  FLAME_NLTGV2_OPT_WG_WAVES = 11,    /* patch-per-workgroup persistent form: compute waves per workgroup (1,2,4 (default),8);
-                                        takes effect at the next upload_graph / sync_graph */
-  FLAME_NLTGV2_OPT_POLL_GAP = 13,    /* patch-per-workgroup form: pause between the communication wave's pipelined polls:
-                                        0 (default) = built-in, n in 1..64 = (n-1) x 64 cycles */
-  FLAME_NLTGV2_OPT_WG_RECORD = 14,   /* patch-per-workgroup form: layout of a published record: (log2 of the bytes reserved
-                                        per record, 4..7) | (16-byte copies written per publish, 1..bytes/16) << 4 */
-  FLAME_NLTGV2_OPT_PW_ROLES = 15,  /* patch-per-wave form (OPT_WG_WAVES = 1): 1 (default) = a patch's two waves choose who computes
-                                        from their SIMD ids (spreads the compute waves over a CU's SIMDs), 0 = wave 0 computes */
-  FLAME_NLTGV2_OPT_PROBE = 12,       /* 1 = the patch-per-workgroup kernel records a per-wave, per-step cycle probe
-                                        (8 words: sleep, poll, barrier wait, compute cycles, polls, step start, 100 MHz
-                                        clock, fetch flag), read with flame_nltgv2_read_probe; 0 (default) = off */
+  FLAME_NLTGV2_OPT_POLL_GAP = 13,    /* patch-per-wave form: 0 (default) = built-in, 1 = no pause between the polls of a
+                                        wait, 2 = one s_sleep (64 cycles) */
+  FLAME_NLTGV2_OPT_PROBE = 12,       /* 1 = the patch-per-wave kernel records a per-patch, per-step cycle probe (8 words:
+                                        HW id, XCC id, wait cycles, compute cycles, poll rounds, step start, 100 MHz clock,
+                                        0), read with flame_nltgv2_read_probe; 0 (default) = off */
   FLAME_NLTGV2_OPT_FAULT_INJECT = 10 /* test hook: n > 0 = one wave of every persistent run withholds its first record, so
                                         the run times out after n polls and the recovery path (state rolled back, steps
                                         redone with one launch per step) is exercised; 0 (default) = off */
@@ -293,7 +287,7 @@ typedef struct flame_nltgv2_info {
   char gcn_arch[32];
   int32_t last_run_path; /* 0 none, 1 persistent launch (lane per half-edge), 2 one launch per step
                             (hipGraph), 3 one launch per step (eager), 4 four canonical sweeps per step,
-                            5 persistent launch (vertex per lane), 6 persistent launch (patch per workgroup) */
+                            5 persistent launch (vertex per lane), 6 persistent launch (patch per wave) */
   int32_t he_waves;      /* waves of the lane-per-half-edge persistent form (0: not applicable) */
   int32_t tv_waves;      /* waves of the vertex-per-lane persistent form (0: not applicable) */
   int32_t tv_wave_capacity; /* vertex-per-lane waves the device keeps resident */
@@ -308,8 +302,8 @@ int flame_nltgv2_last_hip_error(flame_nltgv2_ctx* ctx); /* raw hipError_t of the
 const char* flame_nltgv2_status_string(int status);
 int flame_nltgv2_abi_version(void);
 
-/* Measurement aid: copies out the cycle probe the last patch-per-workgroup run recorded (FLAME_NLTGV2_OPT_PROBE):
- * [workgroup][wave][step][8] words; *n_words = words available.  Not part of the reference's surface. */
+/* Measurement aid: copies out the cycle probe the last patch-per-wave run recorded (FLAME_NLTGV2_OPT_PROBE):
+ * [patch][step][8] words; *n_words = words available.  Not part of the reference's surface. */
 int flame_nltgv2_read_probe(flame_nltgv2_ctx* ctx, uint32_t* out, int64_t max_words, int64_t* n_words);
 
 /* Host-only packing probe (no device needed; used by the CPU test-suite): builds the packed

@@ -1,8 +1,8 @@
 // tests/cpp/wg_layout_test.cc -- host-only check of layout (E) of flame_amd/csrc/nltgv2_pack.hpp (the
-// patch-per-workgroup rows k_persistent_wg runs on).  The kernel's data movement is replayed on the CPU, lane
+// patch-per-wave rows k_persistent_pv runs on).  The kernel's data movement is replayed on the CPU, lane
 // by lane, with exactly the visibility rules of the device code:
-//   * a lane sees a neighbour's record either in its workgroup's local record area or in the slot its
-//     workgroup's fetch lane copied from the global exchange buffer -- nothing else;
+//   * a lane sees a neighbour's record either in its patch's local record area or in the slot its
+//     patch's fetch lane copied from the global exchange buffer -- nothing else;
 //   * only vertices flagged "publishes" write the global exchange buffer;
 //   * every lane of a vertex accumulates the contributions of the vertex's lanes first..first+deg-1 in order.
 // After n steps every state array must be bit-identical to the CPU checker (oracle/liboracle_nltgv2.so, linked
@@ -118,11 +118,11 @@ static float prox_l1(float x_min, float x_max, float step_x, float w, float x, f
 
 struct Rec { float xb, w1b, w2b; unsigned tag; };
 
-static int replay(HostGraph& hg, int wg_waves, int n_iters, const nltgv2_params& p) {
+static int replay(HostGraph& hg, int n_iters, const nltgv2_params& p) {
   flame_nltgv2_graph g = hg.view();
   PackedLayout L;
-  if (build_layout(&g, &L, wg_waves) != 0 || !L.wg_ok) return 1;
-  const int T = 64 * wg_waves, V = g.V;
+  if (build_layout(&g, &L) != 0 || !L.wg_ok) return 1;
+  const int T = 64, V = g.V;
   // structural invariants
   std::vector<int> seen(L.n_slices * 64, 0);
   for (int wg = 0; wg < L.wg_count; ++wg) {
@@ -140,6 +140,12 @@ static int replay(HostGraph& hg, int wg_waves, int n_iters, const nltgv2_params&
       if ((int)((m >> 13) & 2047) >= L.wg_info[4 * wg + 2] || L.wg_info[4 * wg + 2] > L.wg_lcap) return 6;
     }
     if (L.wg_info[4 * wg + 1] > L.wg_rcap || L.wg_info[4 * wg + 1] > T) return 7;
+    {  // slab stride: a multiple of 4, at least 8, covers the patch's largest degree, and fits the LDS sizing figure
+      const int stride = L.wg_info[4 * wg + 3];
+      if (stride < 8 || (stride & 3) || stride * L.wg_info[4 * wg + 2] > L.wg_slab_slots) return 13;
+      for (int t = 0; t < T; ++t)
+        if ((L.wg_meta[(size_t)wg * T + t] & kWgValid) && (int)((L.wg_meta[(size_t)wg * T + t] >> 6) & 127) > stride) return 14;
+    }
     for (int i = 1; i < L.wg_info[4 * wg + 1]; ++i)
       if (L.wg_fetch[(size_t)wg * T + i] <= L.wg_fetch[(size_t)wg * T + i - 1]) return 8;  // sorted, distinct
   }
@@ -260,27 +266,25 @@ static int replay(HostGraph& hg, int wg_waves, int n_iters, const nltgv2_params&
     }
   }
   if (bad) {
-    std::printf("wg_waves=%d: %ld lanes differ from the checker\n", wg_waves, bad);
+    std::printf("%ld lanes differ from the checker\n", bad);
     return 12;
   }
   long pub = 0, fetch = 0;
   for (size_t hl = 0; hl < NL; ++hl) pub += (L.wg_meta[hl] & (kWgTail | kWgPublish)) == (kWgTail | kWgPublish);
   for (int wg = 0; wg < L.wg_count; ++wg) fetch += L.wg_info[4 * wg + 1];
-  std::printf("wg_waves=%2d: V=%d E=%d workgroups=%d lcap=%d rcap=%d publishing=%ld fetched/step=%ld (half-edges %d) ok\n", wg_waves, V,
-              g.E, L.wg_count, L.wg_lcap, L.wg_rcap, pub, fetch, 2 * g.E);
+  std::printf("V=%d E=%d patches=%d lcap=%d rcap=%d slab slots=%d publishing=%ld fetched/step=%ld (half-edges %d) ok\n", V, g.E,
+              L.wg_count, L.wg_lcap, L.wg_rcap, L.wg_slab_slots, pub, fetch, 2 * g.E);
   return 0;
 }
 
 int main() {
   const nltgv2_params p = {0.1f, 0.001f, 125.0f, 0.25f, 0.0f, 10.0f};
   for (int frames : {1, 3}) {
-    for (int w : {1, 2, 4, 8}) {
-      HostGraph g = make_graph(61, 47, frames, 1234 + frames);
-      const int rc = replay(g, w, 6, p);
-      if (rc) {
-        std::printf("FAILED frames=%d wg_waves=%d rc=%d\n", frames, w, rc);
-        return 1;
-      }
+    HostGraph g = make_graph(61, 47, frames, 1234 + frames);
+    const int rc = replay(g, 6, p);
+    if (rc) {
+      std::printf("FAILED frames=%d rc=%d\n", frames, rc);
+      return 1;
     }
   }
   std::printf("all ok\n");

@@ -74,7 +74,7 @@ def test_config_parity(env, config, n):
     g = synth.make_graph(config, seed=4242)
     ref, bad = cpu_run(oracle, g, n)
     assert bad == 0
-    for persistent in (1, 2, 3, 4, 0):  # auto, lane-per-half-edge, vertex-per-lane, patch-per-workgroup, one launch per step
+    for persistent in (1, 2, 3, 4, 0):  # auto, lane-per-half-edge, vertex-per-lane, patch-per-wave, one launch per step
         out = gpu_run(flame_amd, g, n, options=[(5, persistent)], expect_path=None if persistent else 2)
         assert rms(out["x"], ref["x"]) <= TOL_RMS
         assert_state_equal(out, ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"{config} p={persistent}")
@@ -84,7 +84,9 @@ def test_four_kernel_path_matches_fused_and_checker(env):
     flame_amd, oracle = env
     g = synth.make_graph("320x240", seed=11)
     ref, _ = cpu_run(oracle, g, 37)
-    persistent = gpu_run(flame_amd, g, 37, expect_path=1)
+    persistent = gpu_run(flame_amd, g, 37, expect_path=6)  # auto: the patch-per-wave form
+    persistent_he = gpu_run(flame_amd, g, 37, options=[(5, 2)], expect_path=1)
+    assert_state_equal(persistent_he, ref, what="persistent lane-per-half-edge")
     persistent_tv = gpu_run(flame_amd, g, 37, options=[(5, 3)], expect_path=5)
     assert_state_equal(persistent_tv, ref, what="persistent vertex-per-lane")
     fused = gpu_run(flame_amd, g, 37, options=[(5, 0)], expect_path=2)
@@ -126,13 +128,13 @@ def test_internal_steps_individually(env):
     [(5, 0), (3, 4), (4, 4)], [(5, 0), (3, 4), (4, 16)], [(5, 0), (2, 0)], [(5, 1)], [(5, 2)], [(5, 3)], [(5, 2), (6, 0)], [(5, 3), (6, 0)], [(5, 2), (6, 2)], [(5, 3), (6, 2)], [(5, 3), (7, 2)], [(5, 3), (6, 2), (7, 2)], [(5, 3), (7, 0)],
     [(5, 2), (9, 1)], [(5, 2), (9, 2)], [(5, 2), (9, 4)], [(5, 2), (9, 8)], [(5, 3), (9, 1)], [(5, 2), (8, 1)], [(5, 2), (8, 21)],
     [(5, 3), (8, 9)], [(5, 2), (9, 1), (6, 0)],
-    [(5, 4)], [(5, 4), (6, 0)], [(5, 4), (6, 2)], [(5, 4), (9, 1)], [(5, 4), (9, 2)], [(5, 4), (9, 8)], [(5, 4), (8, 1)], [(5, 4), (8, 12)],
-    [(11, 1), (5, 4)], [(11, 2), (5, 4)], [(11, 8), (5, 4)], [(11, 8), (5, 4), (13, 1)], [(11, 2), (5, 4), (9, 1), (6, 0), (13, 5)],
+    [(5, 4)], [(5, 4), (6, 0)], [(5, 4), (6, 2)], [(5, 4), (9, 1)], [(5, 4), (9, 2)], [(5, 4), (9, 8)], [(5, 4), (13, 1)], [(5, 4), (13, 2)],
+    [(5, 4), (9, 1), (6, 0), (13, 1)], [(5, 4), (12, 1)],
 ])
 def test_launch_configurations_are_bit_identical(env, opts):
     """waves per workgroup (opt 3), slot chunk (opt 4), hipGraph on/off (opt 2), persistent single
     launch vs one launch per step (opt 5), same-XCD L2 exchange on/off (opt 6), slot constants in LDS (opt 7), the pre-poll sleep (opt 8) and the number of
-    XCDs a persistent launch is spread over (opt 9), the waves per workgroup of the patch-per-workgroup form (opt 11) never change a bit."""
+    XCDs a persistent launch is spread over (opt 9), the poll pause and the cycle probe of the patch-per-wave form (opts 13, 12) never change a bit."""
     flame_amd, oracle = env
     g = synth.make_graph("320x240", seed=3)
     ref, _ = cpu_run(oracle, g, 21)
@@ -246,7 +248,7 @@ def test_batch_of_frames_equals_individual_frames(env):
     frames = [synth.make_graph("320x240", seed=100 + i) for i in range(5)]
     union = synth.concat_graphs(frames)
     refs = [cpu_run(oracle, f, 40)[0] for f in frames]
-    for opts in ([], [(5, 4)], [(5, 4), (11, 8)]):  # auto; patch-per-workgroup form (4 and 8 waves per workgroup)
+    for opts in ([], [(5, 4)], [(5, 2)]):  # auto; patch-per-wave form; lane-per-half-edge form
         out = gpu_run(flame_amd, union, 40, options=opts)
         vo = eo = 0
         for f, ref in zip(frames, refs):
@@ -258,8 +260,8 @@ def test_batch_of_frames_equals_individual_frames(env):
             eo += f["E"]
 
 
-def test_large_batch_as_groups_of_patch_workgroups(env):
-    """12 frames of 640x480 in the patch-per-workgroup form exceed its residency cap: groups of whole frames."""
+def test_large_batch_as_groups_of_patches(env):
+    """12 frames of 640x480 in the patch-per-wave form exceed its residency cap: groups of whole frames."""
     flame_amd, oracle = env
     frames = [synth.make_graph("640x480", seed=500 + i) for i in range(12)]
     union = synth.concat_graphs(frames)
