@@ -159,27 +159,35 @@ def main():
     out = None
     if rank == 0:
         B_iter = info["algorithmic_bytes_per_iter"]
-        # Dominant kernel.  Persistent path: ONE k_persistent_he launch per step covers all `iters`
-        # primal-dual iterations, so algorithmic bytes per launch = iters * (64V + 40E) and the launch
-        # duration is the HIP-event time of the step (events recorded on the solver's stream right
-        # around the launch).  Per-step path: one k_fused_step launch per iteration; the event time
-        # divided by the launches then includes the ~3.5 us dependent-launch gaps.
-        persistent = run_path == "persistent"
+        # Dominant kernel.  Persistent paths: ONE launch per step covers all `iters` primal-dual iterations, so algorithmic
+        # bytes per launch = iters * (64V + 40E) and the launch duration is the HIP-event time of the step (events
+        # recorded on the solver's stream right around the launch).  Per-step path: one k_fused_step launch per
+        # iteration; the event time divided by the launches then includes the ~3.5 us dependent-launch gaps.
+        kernel = {"persistent": "k_persistent_he", "persistent-pv": "k_persistent_pv", "persistent-tv": "k_persistent_tv"}.get(run_path, "k_fused_step")
+        persistent = run_path.startswith("persistent")
         launches_per_step = 1 if persistent else a.iters
         launch_us = ev_ms * 1e3 / (a.steps * launches_per_step)
         bytes_per_launch = B_iter * (a.iters if persistent else 1)
         achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
         per_iter_us = ev_ms * 1e3 / (a.steps * a.iters)
         roofline = {
-            "bound": "hbm", "kernel": "k_persistent_he" if persistent else "k_fused_step",
+            # what binds ONE small frame is the dependency latency of a step (one cross-CU hand-off + the instructions
+            # between a record arriving and the next leaving), not bandwidth: `frac` is still quoted against the HBM
+            # peak, as SURVEY.md 8(d) defines it, so that it is comparable with the throughput regime below
+            "bound": "latency", "peak_of": "hbm", "kernel": kernel,
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": measured_traffic(a.config, run_path),
             "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": round(launch_us, 3),
             "launches_per_step": launches_per_step, "per_iteration_us": round(per_iter_us, 3),
-            "note": "single frame: dependency-latency bound, not bandwidth bound -- the whole state (1.6 MB) is "
-                    "register/L2 resident and each iteration waits one cross-CU neighbour hand-off (~0.5 us); "
-                    "see 'batched' for the throughput regime",
+            "note": "single frame: dependency-latency bound -- the whole state (1.6 MB) is register/LDS resident, HBM traffic "
+                    "is a fraction of the algorithmic bytes, and each iteration waits one cross-CU neighbour hand-off; "
+                    "'step_cycles' is the in-kernel cycle account of the same kernel, 'batched' the throughput regime",
         }
+        if run_path == "persistent-pv":
+            try:
+                roofline["step_cycles"] = pv_step_cycles(flame_amd, g, params, a.iters, local_rank)
+            except Exception as e:  # noqa: BLE001
+                roofline["step_cycles"] = f"{type(e).__name__}: {e}"
         out = {
             "metric": "NLTGV2 primal-dual iters/sec on 640x480 Delaunay graph; depth RMS vs CPU",
             "value": round(value, 1), "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -249,6 +257,33 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pv_step_cycles(flame_amd, g, params, iters, device):
+    """In-kernel cycle account of k_persistent_pv (FLAME_NLTGV2_OPT_PROBE) on this run's graph: per patch and step the
+    shader cycles spent waiting for the neighbours' records, and the cycles from their arrival to the next publish."""
+    from flame_amd.regularizer import OPT_PERSISTENT, OPT_PROBE
+
+    r = flame_amd.Regularizer(device)
+    try:
+        r.set_option(OPT_PERSISTENT, 4)
+        r.set_option(OPT_PROBE, 1)
+        r.upload_graph(g)
+        r.run(params, iters)
+        r.run(params, iters)
+        p = r.read_probe().reshape(-1, iters, 8).astype(np.int64)[:, iters // 10:, :]
+    finally:
+        r.close()
+    wait, comp = p[:, :, 2].mean(axis=1), p[:, :, 3].mean(axis=1)
+    period = float((np.diff(p[0, :, 5]) & 0xffffffff).mean())
+    us = float((np.diff(p[0, :, 6]) & 0xffffffff).mean()) / 100.0
+    crit = int(np.argmin(wait))
+    return {"period": round(period, 0), "period_us": round(us, 3), "shader_clock_GHz": round(period / (us * 1e3), 3),
+            "compute_median": round(float(np.median(comp)), 0), "compute_max": round(float(comp.max()), 0),
+            "wait_median": round(float(np.median(wait)), 0), "wait_min": round(float(wait.min()), 0),
+            "least_slack_patch": {"compute": round(float(comp[crit]), 0), "wait": round(float(wait[crit]), 0)},
+            "poll_rounds_per_step": round(float(p[:, :, 4].mean()), 2), "patches": int(p.shape[0]),
+            "note": "cycles per step with the probe compiled in (+3-5 %); the lock-step network runs at the pace of its least-slack patches: period = their compute + their wait (one hand-off)"}
 
 
 def measured_traffic(config, run_path):

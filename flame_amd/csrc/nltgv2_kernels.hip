@@ -598,6 +598,9 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   // Contribution slab: `stride` slots per vertex of this patch (its largest degree rounded up to a multiple of 4, at least 8); the
   // slots a vertex does not use hold -0.0f for the whole run, so the accumulation needs no predication.
   const int stride = wg_info[4 * wg + 3];
+  // In LDS a vertex's 16-byte slots are stride + 1 apart: an odd distance, so that the ~10 vertices of a wave, which read
+  // their slabs with the same instruction, start in different banks (a multiple of 8 slots apart they would all collide).
+  const int strideA = stride + 1;
   // LDS map, float4 units: [rec area 0: lcap local + 64 fetch slots | rec area 1 | slabA slab_slots | spare 64 | slabC | spare]
   const int rec_stride = lcap + T;
   const int o_slabA = 2 * rec_stride, o_ovfA = o_slabA + slab_slots, o_slabC = o_ovfA + T;
@@ -659,9 +662,9 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
 
   const int my_off = (rid_base + loc) << 4;
   // (a lane without a half-edge writes to its own spare entry, which nobody reads)
-  const int wrA = active ? o_slabA + loc * stride + pos : o_ovfA + lane;
+  const int wrA = active ? o_slabA + loc * strideA + pos : o_ovfA + lane;
   const int wrC = active ? f_slabC + loc * stride + pos : f_ovfC + lane;
-  const int rdA = o_slabA + loc * stride, rdC4 = (f_slabC + loc * stride) >> 2;
+  const int rdA = o_slabA + loc * strideA, rdC4 = (f_slabC + loc * stride) >> 2;
   const int rec_w = valid ? loc : o_ovfA + lane, rec_wstride = valid ? rec_stride : 0;
 
   for (int i = lane; i < slab_slots; i += T) {

@@ -131,7 +131,7 @@ inline void build_patch_rows(PackedLayout* L, const std::vector<int32_t>& order_
     if (L->wg_count == 0) return;
     const int32_t stride = std::max(8, (max_deg + 3) & ~3);
     L->wg_info[static_cast<size_t>(L->wg_count - 1) * 4 + 3] = stride;
-    L->wg_slab_slots = std::max(L->wg_slab_slots, stride * n_local);
+    L->wg_slab_slots = std::max(L->wg_slab_slots, (stride + 1) * n_local);  // (+1: the kernel pads a vertex's slab, see there)
   };
   for (int32_t i = 0; i < V; ++i) {
     const int32_t s = L->iperm[order_m[i]];

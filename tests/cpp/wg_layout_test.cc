@@ -142,7 +142,7 @@ static int replay(HostGraph& hg, int n_iters, const nltgv2_params& p) {
     if (L.wg_info[4 * wg + 1] > L.wg_rcap || L.wg_info[4 * wg + 1] > T) return 7;
     {  // slab stride: a multiple of 4, at least 8, covers the patch's largest degree, and fits the LDS sizing figure
       const int stride = L.wg_info[4 * wg + 3];
-      if (stride < 8 || (stride & 3) || stride * L.wg_info[4 * wg + 2] > L.wg_slab_slots) return 13;
+      if (stride < 8 || (stride & 3) || (stride + 1) * L.wg_info[4 * wg + 2] > L.wg_slab_slots) return 13;
       for (int t = 0; t < T; ++t)
         if ((L.wg_meta[(size_t)wg * T + t] & kWgValid) && (int)((L.wg_meta[(size_t)wg * T + t] >> 6) & 127) > stride) return 14;
     }

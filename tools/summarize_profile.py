@@ -1,20 +1,20 @@
 #!/usr/bin/env python3
-"""tools/summarize_profile.py ROUND -- turns gpurun_out/prof_<ROUND>/ (tools/profile.sh) into the
-committed evidence under profiles/: <ROUND>_kernel_stats*.csv (rocprofv3 --kernel-trace --stats),
-<ROUND>_counters.json and profiles/traffic.json (HBM bytes per launch that bench.py reports as
-roofline.traffic).
+"""tools/summarize_profile.py ROUND -- turns gpurun_out/prof_<ROUND>/ (tools/profile.sh) into the committed evidence
+under profiles/: <ROUND>_kernel_stats_<case>.csv (rocprofv3 --kernel-trace --stats), <ROUND>_counters.json and
+profiles/traffic.json (per workload and run path: HBM bytes and VALU instructions per launch, which bench.py reports as
+roofline.traffic and as the VALU roofline of the batched lines).
 
-HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
-reports half of the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM) -> doubled as the guide
-prescribes.  That correction is calibrated for wide streaming reads; the persistent kernel's 16-byte
-sc1 record reads are a different access pattern, so its absolute figure is an upper bound."""
+HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of
+the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM) -> doubled as the guide prescribes.  That correction is
+calibrated for wide streaming reads; the persistent kernels' 16-byte sc1 record reads are a different access pattern, so
+their absolute figure is an upper bound."""
 import csv
 import json
 import os
 import shutil
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{R}")
 DST = os.path.join(ROOT, "profiles")
@@ -34,40 +34,64 @@ def kstat(path, kernel):
     with open(path) as f:
         for r in csv.DictReader(f):
             if kernel in r["Name"]:
-                return {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
+                return {"name": r["Name"][:60], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
                         "max_ns": float(r["MaxNs"])}
     return None
 
 
-out = {}
-traffic = {}
-for tag, sub, kernel, path_name in (("persistent", "", "k_persistent_he", "persistent"),
-                                    ("per_step", "_step", "k_fused_step", "per-step hipGraph"),
-                                    ("stream_64_frames", "_stream", "k_fused_step", None),
-                                    ("resident_30_frames", "_batch", "k_persistent_tv", None),
-                                    ("feature_update", "_stereo", "k_update_feature_idepths", None)):
-    kt = os.path.join(SRC, "kt" + sub, "kt_kernel_stats.csv")
+def last_json(path):
+    try:
+        for line in reversed(open(path).read().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+    except Exception:  # noqa: BLE001
+        pass
+    return None
+
+
+# tag -> (dominant kernel, traffic.json key or None)
+CASES = {"bench": ("k_persistent_pv", "640x480:persistent-pv"), "bench_he": ("k_persistent_he", "640x480:persistent"),
+         "bench_step": ("k_fused_step", "640x480:per-step hipGraph"), "cfg3": ("k_persistent_pv", "1280x720:persistent-pv"),
+         "cfg5": ("k_persistent_he", "1920x1080:persistent"), "batch30": ("k_persistent_tv", "640x480x30:persistent-tv"),
+         "batch64": ("k_persistent_tv", "640x480x64:persistent-tv"), "stream64": ("k_fused_step", None),
+         "stereo": ("k_update_feature_idepths", None)}
+out, traffic = {}, {}
+for tag, (kernel, key) in CASES.items():
+    kt = os.path.join(SRC, f"kt_{tag}", "kt_kernel_stats.csv")
     if not os.path.exists(kt):
         continue
-    shutil.copy(kt, os.path.join(DST, f"{R}_kernel_stats{sub}.csv"))
-    entry = {"kernel": kernel, "kernel_stats": kstat(kt, kernel)}
+    shutil.copy(kt, os.path.join(DST, f"{R}_kernel_stats_{tag}.csv"))
+    entry = {"kernel": kernel, "kernel_stats": kstat(kt, kernel), "workload": last_json(os.path.join(SRC, f"kt_{tag}.log"))}
+    if entry["workload"] and "roofline" in entry["workload"]:  # a bench line: keep the essentials only
+        w = entry["workload"]
+        entry["workload"] = {"value": w["value"], "ms_per_step": w["ms_per_step"], "run_path": w.get("run_path"), "roofline": w["roofline"]}
     c = {}
-    for d, f in (("fetch" + sub, "f_counter_collection.csv"), ("write" + sub, "w_counter_collection.csv"),
-                 ("sq" + sub, "s_counter_collection.csv")):
+    for d, f in ((f"fetch_{tag}", "f_counter_collection.csv"), (f"write_{tag}", "w_counter_collection.csv"), (f"sq_{tag}", "s_counter_collection.csv")):
         p = os.path.join(SRC, d, f)
         if os.path.exists(p):
             c.update(counters(p, kernel))
     entry["counters_per_launch"] = c
+    t = {"kernel": kernel, "source": f"profiles/{R}_counters.json"}
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         hbm = (2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024.0
         entry["hbm_bytes_per_launch"] = hbm
         entry["hbm_formula"] = "(2*FETCH_SIZE + WRITE_SIZE)*1024  [KiB counters; x2 = gfx950 FETCH_SIZE correction]"
-        if path_name:
-            traffic[f"640x480:{path_name}"] = {"hbm_bytes_per_launch": round(hbm), "kernel": kernel,
-                                                "source": f"profiles/{R}_counters.json"}
+        t["hbm_bytes_per_launch"] = round(hbm)
         if entry["kernel_stats"]:
             entry["measured_hbm_GBps"] = round(hbm / (entry["kernel_stats"]["avg_ns"] * 1e-9) / 1e9, 1)
+    if "SQ_INSTS_VALU" in c:
+        t["valu_insts_per_launch"] = round(c["SQ_INSTS_VALU"]["mean"])
+        if entry["kernel_stats"]:  # chip VALU issue peak: 1024 SIMDs x one wave-instruction per 2 cycles at 2.4 GHz
+            rate = c["SQ_INSTS_VALU"]["mean"] / (entry["kernel_stats"]["avg_ns"] * 1e-9)
+            entry["valu_insts_per_s"] = rate
+            entry["valu_issue_frac_of_peak"] = round(rate / (1024 * 1.2e9), 4)
+    if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"]["mean"] > 0:
+        entry["wait_any_over_wave_cycles"] = round(c["SQ_WAIT_ANY"]["mean"] / c["SQ_WAVE_CYCLES"]["mean"], 4)
+        if "SQ_ACTIVE_INST_ANY" in c:
+            entry["active_inst_over_wave_cycles"] = round(c["SQ_ACTIVE_INST_ANY"]["mean"] / c["SQ_WAVE_CYCLES"]["mean"], 4)
+    if key:
+        traffic[key] = t
     out[tag] = entry
 json.dump(out, open(os.path.join(DST, f"{R}_counters.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
-print(json.dumps(out, indent=1)[:3000])
+print(json.dumps({k: {kk: v.get(kk) for kk in ("kernel_stats", "hbm_bytes_per_launch", "valu_issue_frac_of_peak", "wait_any_over_wave_cycles")} for k, v in out.items()}, indent=1)[:6000])
