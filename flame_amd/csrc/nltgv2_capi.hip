@@ -91,14 +91,26 @@ struct flame_nltgv2_ctx {
   uint64_t coop_checked_key = 0;  // (topology, form) whose persistent grid the runtime has verified as resident
   int buf_gen = 0;                // which of the two (hq, vstate) copies is current; part of the hipGraph cache key
   int timeouts_recovered = 0;     // persistent runs that timed out and were redone on the per-step path
-  // The persistent run in flight, until finish() has seen its error word: what is needed to take it back
+  // The persistent run(s) in flight, until finish() has seen the error word: what is needed to take them back.  One
+  // run is taken back by swapping the buffer roles (it wrote the other copies).  When more work is enqueued before the
+  // first run has been checked (run_async back to back: the frame loop, bench.py), the state the chain started from is
+  // copied aside first (three device-to-device copies, once per chain), and the chain is kept as a list of operations:
+  // a wait that expires anywhere in it restores that state and replays the list on the one-launch-per-step path.
+  struct PendingOp {
+    int kind = 0;  // 0 run, 1 explicit export of x * scale
+    flame_nltgv2_params params{};
+    int n = 0;
+    float* dst = nullptr;
+    float scale = 1.0f;
+  };
   struct PendingRun {
     bool active = false;
-    bool chained = false;  // a further run was enqueued before this one was checked: no longer possible to take back
-    int n = 0, parity_before = 0;
+    bool snapshotted = false;  // the pre-chain state is in snap_hq / snap_vstate / snap_bar
+    int parity_before = 0;
     bool have_prev_before = false;
-    flame_nltgv2_params params{};
+    std::vector<PendingOp> ops;
   } pending;
+  DevBuf snap_hq, snap_vstate, snap_bar;
 
   PackedLayout L;
   std::vector<int32_t> h_src, h_dst, h_feat;  // host image of the current topology (for sync_graph)
@@ -236,6 +248,8 @@ int h2d(flame_nltgv2_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
 }
 
 int finish(flame_nltgv2_ctx* ctx);
+int snapshot_chain_start(flame_nltgv2_ctx* ctx);
+constexpr size_t kMaxChain = 256;  // operations enqueued behind an unchecked persistent run before the host settles it
 
 int ensure_canon(flame_nltgv2_ctx* ctx) {
   if (ctx->pending.active) {  // a persistent run is still unchecked: settle it before anything reads or edits the state
@@ -481,6 +495,14 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   }
   int rc = ensure_fused(ctx);
   if (rc) return rc;
+  if (ctx->pending.active) {  // chaining onto an unchecked persistent run
+    if (ctx->pending.ops.size() >= kMaxChain) {
+      rc = finish(ctx);
+    } else {
+      rc = snapshot_chain_start(ctx);
+    }
+    if (rc) return rc;
+  }
   int unroll, wpb;
   pick_config(ctx, &unroll, &wpb);
   std::vector<WaveGroup> groups;
@@ -551,12 +573,15 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
     if (e == 0) {
       // The kernels wrote (will write) hq / vstate / bar into the other copies: make those current.  finish() takes
       // this back if the run reports a timeout.
-      if (ctx->pending.active) {
-        ctx->pending.chained = true;
-      } else {
-        ctx->pending.active = true, ctx->pending.chained = false;
-        ctx->pending.n = n, ctx->pending.params = *p;
+      if (!ctx->pending.active) {
+        ctx->pending.active = true, ctx->pending.snapshotted = false;
+        ctx->pending.ops.clear();
         ctx->pending.parity_before = ctx->parity, ctx->pending.have_prev_before = ctx->have_prev;
+      }
+      {
+        flame_nltgv2_ctx::PendingOp op;
+        op.kind = 0, op.params = *p, op.n = n;
+        ctx->pending.ops.push_back(op);
       }
       std::swap(ctx->hq, ctx->hq_alt);
       std::swap(ctx->vstate, ctx->vstate_alt);
@@ -571,11 +596,22 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       return 0;
     }
     // e.g. cooperative launch too large.  Groups already enqueued write into the other copies only: the current
-    // state is intact, the steps are done on the one-launch-per-step path below.
+    // state is intact, the steps are done on the one-launch-per-step path below.  Let those groups drain first and
+    // forget what they reported (their waits expire without the missing groups): that is not a failure of a run.
     (void)hipGetLastError();
     ctx->persist_refused_topo = ctx->topo;  // do not try again for this topology
+    if (groups.size() > 1 && !ctx->pending.active) {
+      HIPCHK(ctx, hipMemsetAsync(ctx->abort_flag.p, 0xff, sizeof(int), ctx->stream));  // tells them to leave at once
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, sizeof(int), ctx->stream));
+      HIPCHK(ctx, hipMemsetAsync(ctx->abort_flag.p, 0, sizeof(int), ctx->stream));
+    }
   }
-  if (ctx->pending.active) ctx->pending.chained = true;
+  if (ctx->pending.active) {
+    flame_nltgv2_ctx::PendingOp op;
+    op.kind = 0, op.params = *p, op.n = n;
+    ctx->pending.ops.push_back(op);
+  }
   int left = n;
   while (left > 0) {
     const int chunk = left >= kGraphChunk ? kGraphChunk : left;
@@ -602,31 +638,69 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
 int finish(flame_nltgv2_ctx* ctx) {
   HIPCHK(ctx, hipMemcpyAsync(ctx->h_err, ctx->err.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  const flame_nltgv2_ctx::PendingRun run = ctx->pending;
-  ctx->pending.active = false;
+  flame_nltgv2_ctx::PendingRun run;
+  std::swap(run, ctx->pending);  // (ctx->pending is now inactive and empty)
   if (*ctx->h_err & 2) {
-    // A neighbour wait of the persistent run expired (its waves were not all resident: the GPU is shared with
-    // something that keeps CUs full).  Its results went to the other copies of the state; take the swap back, and
-    // do the same steps on the one-launch-per-step path, which needs no co-residency.
-    if (!run.active || run.chained) {  // several runs were chained without a sync in between: state lost
+    // A neighbour wait of a persistent run expired (its waves were not all resident: the GPU is shared with
+    // something that keeps CUs full).  Go back to the state the run -- or the chain of runs enqueued behind it --
+    // started from, and do the same steps on the one-launch-per-step path, which needs no co-residency.
+    if (!run.active) {  // nothing recorded to go back to
       ctx->have_graph = false;
       return fail(ctx, FLAME_NLTGV2_ERR_TIMEOUT);
     }
-    std::swap(ctx->hq, ctx->hq_alt);
-    std::swap(ctx->vstate, ctx->vstate_alt);
-    ctx->buf_gen ^= 1;
-    refresh_args(ctx);
+    if (run.snapshotted) {
+      const size_t n_slots = (size_t)(ctx->L.rows + kRowPad) * kWave, n_packed = (size_t)ctx->L.n_slices * kWave;
+      HIPCHK(ctx, hipMemcpyAsync(ctx->hq.p, ctx->snap_hq.p, sizeof(float4) * n_slots, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->vstate.p, ctx->snap_vstate.p, sizeof(float4) * n_packed, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->f.bar[run.parity_before], ctx->snap_bar.p, sizeof(float4) * n_packed, hipMemcpyDeviceToDevice,
+                                 ctx->stream));
+    } else {  // a single run: it wrote the other copies, its input is intact
+      std::swap(ctx->hq, ctx->hq_alt);
+      std::swap(ctx->vstate, ctx->vstate_alt);
+      ctx->buf_gen ^= 1;
+      refresh_args(ctx);
+    }
     ctx->parity = run.parity_before;
     ctx->have_prev = run.have_prev_before;
+    ctx->fused_valid = true, ctx->canon_valid = false;
     ctx->persist_refused_topo = ctx->topo;
     ctx->timeouts_recovered++;
     HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, sizeof(int), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->abort_flag.p, 0, sizeof(int), ctx->stream));
-    int rc = enqueue_run(ctx, &run.params, run.n);
-    if (rc) return rc;
+    for (const flame_nltgv2_ctx::PendingOp& op : run.ops) {
+      if (op.kind == 0) {
+        const int rc = enqueue_run(ctx, &op.params, op.n);
+        if (rc) return rc;
+      } else {
+        LAUNCHCHK(ctx, launch_export(ctx->c, ctx->f, true, op.scale, op.dst, ctx->stream));
+      }
+    }
     return finish(ctx);
   }
-  if (*ctx->h_err != 0) return fail(ctx, FLAME_NLTGV2_ERR_NAN);
+  if (*ctx->h_err != 0) {
+    // NaN/Inf in a dual variable (the reference's FLAME_ASSERT h:174): reported once; the state stays readable
+    // (download_state, costs) and the solve can go on or be re-initialised -- q was clamped to +-1 where it happened
+    HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, sizeof(int), ctx->stream));
+    return fail(ctx, FLAME_NLTGV2_ERR_NAN);
+  }
+  return 0;
+}
+
+// Copies the state a chain of asynchronous runs started from aside, once per chain, before anything behind the first
+// (still unchecked) persistent run is enqueued: that run read (hq, vstate, bar[parity_before]) and wrote the other
+// copies, so the stream-ordered copies below still see its input.
+int snapshot_chain_start(flame_nltgv2_ctx* ctx) {
+  if (!ctx->pending.active || ctx->pending.snapshotted) return 0;
+  const size_t n_slots = (size_t)(ctx->L.rows + kRowPad) * kWave, n_packed = (size_t)ctx->L.n_slices * kWave;
+  int rc = ensure(ctx, ctx->snap_hq, sizeof(float4) * n_slots);
+  if (!rc) rc = ensure(ctx, ctx->snap_vstate, sizeof(float4) * n_packed);
+  if (!rc) rc = ensure(ctx, ctx->snap_bar, sizeof(float4) * n_packed);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->snap_hq.p, ctx->hq_alt.p, sizeof(float4) * n_slots, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->snap_vstate.p, ctx->vstate_alt.p, sizeof(float4) * n_packed, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->snap_bar.p, ctx->f.bar[ctx->pending.parity_before], sizeof(float4) * n_packed, hipMemcpyDeviceToDevice,
+                             ctx->stream));
+  ctx->pending.snapshotted = true;
   return 0;
 }
 
@@ -730,7 +804,8 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
               &ctx->rec_nbr, &ctx->rec_edge, &ctx->edge_src_slot, &ctx->hrec, &ctx->hq, &ctx->vstate, &ctx->hq_alt, &ctx->vstate_alt, &ctx->cost_terms, &ctx->run_tail,
               &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->xbuf, &ctx->abort_flag, &ctx->he_slot, &ctx->he_vid, &ctx->he_meta, &ctx->he_wave_chain, &ctx->tv_slot, &ctx->tv_vid, &ctx->tv_meta, &ctx->tv_wave, &ctx->err,
               &ctx->cost_out, &ctx->img_ref, &ctx->img_cmp, &ctx->photo_err, &ctx->r_tris, &ctx->r_valid, &ctx->r_keys,
-              &ctx->r_img, &ctx->r_cov, &ctx->r_vtx, &ctx->r_val};
+              &ctx->r_img, &ctx->r_cov, &ctx->r_vtx, &ctx->r_val, &ctx->wg_slot, &ctx->wg_vid, &ctx->wg_meta, &ctx->wg_nbr,
+              &ctx->wg_fetch, &ctx->wg_info, &ctx->probe, &ctx->snap_hq, &ctx->snap_vstate, &ctx->snap_bar};
   *out = ctx;
   return FLAME_NLTGV2_OK;
 }
@@ -911,7 +986,7 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
   // empty slots / padding vertices of the second copies: zero, as the packing kernels write them in the first
   HIPCHK(ctx, hipMemsetAsync(ctx->hq_alt.p, 0, sizeof(float4) * n_slots, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->vstate_alt.p, 0, sizeof(float4) * n_packed, ctx->stream));
-  ctx->pending.active = false;
+  ctx->pending = flame_nltgv2_ctx::PendingRun{};
   ctx->tag_next = 1;
   ctx->static_stale = false;
   LAUNCHCHK(ctx, launch_pack_static(ctx->c, ctx->f, ctx->stream));
@@ -1323,6 +1398,21 @@ static int export_idepth(flame_nltgv2_ctx* ctx, void* dst_device, float scale, b
   if (rc) return rc;
   if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
   if (!dst_device && ctx->L.V > 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  if (ctx->pending.active) {
+    // an unchecked persistent run is in flight: the waiting form settles it first (so that what it copies out is the
+    // checked result), the asynchronous form joins the chain and is redone should the chain have to be replayed
+    if (wait) {
+      rc = finish(ctx);
+    } else {
+      rc = snapshot_chain_start(ctx);
+      if (!rc) {
+        flame_nltgv2_ctx::PendingOp op;
+        op.kind = 1, op.dst = (float*)dst_device, op.scale = scale;
+        ctx->pending.ops.push_back(op);
+      }
+    }
+    if (rc) return rc;
+  }
   const bool packed = !ctx->canon_valid;
   LAUNCHCHK(ctx, launch_export(ctx->c, ctx->f, packed, scale, (float*)dst_device, ctx->stream));
   if (wait) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

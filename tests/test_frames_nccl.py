@@ -1,0 +1,85 @@
+"""Config 4's result gather on the device: one process, `nccl` backend (= RCCL), world_size 1 -- the driver's GPU box has
+one GPU, so this is the widest form of the RCCL path a -m gpu test can execute there: init_process_group("nccl"), the
+solver leaving x * graph_scale in the gather's send row from its own launch (flame_nltgv2_set_export_target,
+flame.cc:372-380), IdepthGather.gather() as an RCCL all_gather_into_tensor on the device, the gathered row compared
+with the CPU checker.  The world_size-2 logic (who owns which frame, ragged layout) is covered on CPU by
+tests/test_frames_gloo.py."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import flame_amd
+        from flame_amd import synth
+        from flame_amd.frames import IdepthGather
+        from oracle import capi as oracle
+
+        dev = torch.device("cuda", 0)
+        frames = [synth.make_graph("320x240", seed=700 + i) for i in range(2)]  # two local frames, ragged sizes
+        refs = [synth.copy_graph(g) for g in frames]
+        ig = IdepthGather(dist, [g["V"] for g in frames], len(frames), dev)
+        stream = torch.cuda.Stream(device=dev)
+        regs = []
+        for g in frames:
+            r = flame_amd.Regularizer(0)
+            r.set_stream(stream.cuda_stream)
+            r.upload_graph(g)
+            regs.append(r)
+        p = flame_amd.Params()
+        ok, paths = True, []
+        for step, n in enumerate((40, 25, 7)):  # three steps: both send buffers get used, asynchronous gathers in between
+            for i, r in enumerate(regs):
+                r.set_export_target(ig.local_row(i).data_ptr(), 2.0)
+                r.run_async(p, n)
+                oracle.run(refs[i], n)
+            with torch.cuda.stream(stream):
+                ig.gather(async_op=(step != 2))
+            for i, ref in enumerate(refs):
+                got = ig.frame(i).cpu().numpy()
+                ok = ok and got.shape[0] == ref["V"] and np.array_equal(got, ref["x"] * np.float32(2.0))
+        for r in regs:
+            r.sync()
+            paths.append(r.info()["last_run_path"])
+            r.close()
+        q.put((ok, paths, dist.get_backend()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_nccl_world1_solver_export_and_gather_on_the_device():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    proc = ctx.Process(target=_worker, args=(_free_port(), q))
+    proc.start()
+    ok, paths, backend = q.get(timeout=300)
+    proc.join(timeout=60)
+    assert proc.exitcode == 0
+    assert backend == "nccl"
+    assert ok, "gathered rows differ from the CPU checker"
+    assert all(p in (1, 5, 6) for p in paths), paths  # the persistent kernels wrote the send rows themselves

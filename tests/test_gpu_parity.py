@@ -80,6 +80,30 @@ def test_config_parity(env, config, n):
         assert_state_equal(out, ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"{config} p={persistent}")
 
 
+@pytest.mark.parametrize("idx", [0, 1])
+def test_config_hashes_fixture_on_gpu(env, idx):
+    """tests/golden/config_hashes.json: the 1280x720 / 1920x1080 BASELINE graphs after 200 steps must hash (SHA-256 of
+    all nine state arrays, both costs) to what the checker produced in the build container."""
+    import hashlib
+    import json
+    import os
+
+    from tests.conftest import ROOT
+
+    flame_amd, _ = env
+    e = json.load(open(os.path.join(ROOT, "tests", "golden", "config_hashes.json")))[idx]
+    g = synth.make_graph(e["config"], e["seed"])
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert {k: sha(g[k]) for k in e["inputs"]} == e["inputs"], "the synthetic input itself differs on this machine"
+    with flame_amd.Regularizer(0) as reg:
+        reg.upload_graph(g)
+        reg.run(flame_amd.Params(), e["iters"])
+        out = reg.download_state()
+        sm, dc = reg.costs(flame_amd.Params())
+    assert {k: sha(out[k]) for k in e["state"]} == e["state"]
+    assert [int(np.float32(sm).view(np.uint32)), int(np.float32(dc).view(np.uint32))] == e["costs_f32_bits"]
+
+
 def test_four_kernel_path_matches_fused_and_checker(env):
     flame_amd, oracle = env
     g = synth.make_graph("320x240", seed=11)
@@ -358,6 +382,17 @@ def test_nan_is_reported_not_fatal(env):
         with pytest.raises(flame_amd.NLTGV2Error) as ei:
             reg.run(flame_amd.Params(), 1)
         assert ei.value.status == flame_amd.regularizer.ERR_NAN
+        # reported once, not sticky: the state stays readable (the caller can look at what happened) ...
+        st = reg.download_state(("x", "q1"))
+        assert st["x"].shape[0] == g["V"] and np.abs(st["q1"]).max() <= 1.0
+        reg.costs(flame_amd.Params())
+        for opt in (2, 3, 4, 0):  # ... and every persistent form reports it the same way
+            reg.set_option(5, opt)
+            reg.upload_graph(bad)
+            with pytest.raises(flame_amd.NLTGV2Error) as ei:
+                reg.run(flame_amd.Params(), 6)
+            assert ei.value.status == flame_amd.regularizer.ERR_NAN, opt
+        reg.set_option(5, 1)
         reg.upload_graph(g)  # recovers
         reg.run(flame_amd.Params(), 2)
         ref, _ = cpu_run(oracle, g, 2)
@@ -397,13 +432,34 @@ def test_persistent_timeout_is_rolled_back_and_redone(env, form):
         oracle.run(ref, 25)
         assert reg.info()["last_run_path"] in (1, 5, 6)
         assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="after the fault")
-        # chained asynchronous runs cannot be taken back: reported, not hidden
+        # chained asynchronous runs (run_async back to back, an asynchronous export in between, a short per-step run):
+        # the chain's starting state was copied aside, the whole chain is replayed on the per-step path
+        import torch
+
         reg.set_option(10, 200)
+        buf = torch.zeros(g["V"], dtype=torch.float32, device="cuda")
+        before = reg.info()["timeouts_recovered"]
         reg.run_async(p, 8)
-        reg.run_async(p, 8)
-        with pytest.raises(flame_amd.NLTGV2Error) as ei:
-            reg.sync()
-        assert ei.value.status == -7
+        reg.run_async(p, 9)
+        reg.export_idepth_device(buf.data_ptr(), 3.0, wait=False)
+        reg.run_async(p, 2)
+        reg.run_async(p, 12)
+        reg.sync()
+        oracle.run(ref, 17)
+        want_export = ref["x"] * np.float32(3.0)
+        oracle.run(ref, 14)
+        assert reg.info()["timeouts_recovered"] == before + 1
+        assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="after a replayed chain")
+        torch.cuda.synchronize()
+        assert np.array_equal(buf.cpu().numpy(), want_export)
+        # and a chain that does not time out is left alone
+        reg.set_option(10, 0)
+        reg.run_async(p, 6)
+        reg.run_async(p, 7)
+        reg.sync()
+        oracle.run(ref, 13)
+        assert reg.info()["timeouts_recovered"] == before + 1
+        assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="after a clean chain")
 
 
 def test_invalid_arguments(env):
