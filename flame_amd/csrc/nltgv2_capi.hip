@@ -91,6 +91,8 @@ struct flame_nltgv2_ctx {
   uint64_t coop_checked_key = 0;  // (topology, form) whose persistent grid the runtime has verified as resident
   int buf_gen = 0;                // which of the two (hq, vstate) copies is current; part of the hipGraph cache key
   int timeouts_recovered = 0;     // persistent runs that timed out and were redone on the per-step path
+  int torn_records_detected = 0;  // ... that the record verification (opt_verify) stopped, redone the same way
+  int opt_verify = 0;             // 1: persistent kernels re-read every record after its tag matched; 2: + test hook
   // The persistent run(s) in flight, until finish() has seen the error word: what is needed to take them back.  One
   // run is taken back by swapping the buffer roles (it wrote the other copies).  When more work is enqueued before the
   // first run has been checked (run_async back to back: the frame loop, bench.py), the state the chain started from is
@@ -539,7 +541,8 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       const int pw = gr.count <= 4 * ctx->prop.multiProcessorCount ? 1 : 4;  // waves per workgroup
       // same-XCD exchange through L2: with the waves laid out along the Morton curve it wins at every size
       // (measured per step: 640x480 -16 %, 1280x720 -23 %, 1080p -18 %, 7-frame batch -20 %, 15 frames -19 %)
-      const int dual = ctx->opt_dual == 2 || (ctx->opt_dual == 1 && gr.count > kDualMinWavesPerCu * ctx->prop.multiProcessorCount);
+      const int dual = (ctx->opt_dual == 2 || (ctx->opt_dual == 1 && gr.count > kDualMinWavesPerCu * ctx->prop.multiProcessorCount) ? 1 : 0) |
+                       (ctx->opt_verify == 2 ? 6 : ctx->opt_verify == 1 ? 2 : 0);  // bits 1, 2: record verification, its test hook
       // A graph of <= 8 lane-per-half-edge waves per CU of ONE XCD (32 CUs) runs there entirely: every exchange
       // stays in that XCD's L2 (measured 320x240: 1.23 instead of 1.47 us per step; at 640x480 the 26 waves per CU
       // this would need cost more than the shorter hop saves).
@@ -640,7 +643,8 @@ int finish(flame_nltgv2_ctx* ctx) {
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   flame_nltgv2_ctx::PendingRun run;
   std::swap(run, ctx->pending);  // (ctx->pending is now inactive and empty)
-  if (*ctx->h_err & 2) {
+  if (*ctx->h_err & 6) {
+    if (*ctx->h_err & 4) ctx->torn_records_detected++;  // the record verification found a second read that differed
     // A neighbour wait of a persistent run expired (its waves were not all resident: the GPU is shared with
     // something that keeps CUs full).  Go back to the state the run -- or the chain of runs enqueued behind it --
     // started from, and do the same steps on the one-launch-per-step path, which needs no co-residency.
@@ -664,7 +668,7 @@ int finish(flame_nltgv2_ctx* ctx) {
     ctx->have_prev = run.have_prev_before;
     ctx->fused_valid = true, ctx->canon_valid = false;
     ctx->persist_refused_topo = ctx->topo;
-    ctx->timeouts_recovered++;
+    if (!(*ctx->h_err & 4)) ctx->timeouts_recovered++;
     HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, sizeof(int), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->abort_flag.p, 0, sizeof(int), ctx->stream));
     for (const flame_nltgv2_ctx::PendingOp& op : run.ops) {
@@ -855,6 +859,11 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
     case FLAME_NLTGV2_OPT_POLL_GAP:
       if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_poll_gap = value;
+      return 0;
+    case FLAME_NLTGV2_OPT_VERIFY_RECORDS:
+      if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_verify = value;
+      if (value != 2) ctx->persist_refused_topo = ~0ull;  // hook off: let the persistent path be tried again
       return 0;
     case FLAME_NLTGV2_OPT_PROBE:
       ctx->opt_probe = value ? 1 : 0;
@@ -1593,6 +1602,7 @@ int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info) {
   info->tv_wave_capacity = (ctx->opt_tv_lds ? kTvLdsWavesPerCu : kTvWavesPerCu) * ctx->prop.multiProcessorCount;
   info->last_run_groups = ctx->last_run_groups;
   info->timeouts_recovered = ctx->timeouts_recovered;
+  info->torn_records_detected = ctx->torn_records_detected;
   return FLAME_NLTGV2_OK;
 }
 

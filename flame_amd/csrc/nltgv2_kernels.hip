@@ -299,10 +299,13 @@ k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd
                 const int32_t* __restrict__ he_vid, const uint32_t* __restrict__ he_meta,
                 const int32_t* __restrict__ he_wave_chain, const int4* hrec, const float4* hq, const float4* vstate,
                 float4* hq_out, float4* vstate_out, const float2* vaux, const float4* bar_in, float4* bar_out,
-                float4* vprev, void* xbuf, const int rec_bytes, const int dual, const unsigned tag0, const int n_iters,
+                float4* vprev, void* xbuf, const int rec_bytes, const int dual_arg, const unsigned tag0, const int n_iters,
                 const unsigned max_spins_arg, const int presleep, const SolverParams p, int* __restrict__ err,
                 int* __restrict__ abort_flag, const int32_t* __restrict__ perm, const RunTail* __restrict__ tail) {
   const unsigned max_spins = max_spins_arg & 0x7fffffffu;
+  const int dual = dual_arg & 1;       // bit 0: same-XCD exchange through L2
+  const int verify = dual_arg >> 1;    // bit 1: re-read every record after its tag matched and compare all four dwords
+                                       // (FLAME_NLTGV2_OPT_VERIFY_RECORDS); bit 2: test hook, corrupts one re-read
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
   const int b = blockIdx.x;
@@ -348,7 +351,7 @@ k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd
   float xb = bs.x, w1b = bs.y, w2b = bs.z;
   float x_prev = x, w1_prev = w1, w2_prev = w2;
   bool ok = true;
-  bool timed_out = false;
+  bool timed_out = false, torn = false;
   const int ps = presleep;  // x64 cycles between publishing and the first poll (fixed per launch)
 
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(xbuf);
@@ -427,6 +430,16 @@ k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd
       __builtin_amdgcn_s_sleep(1);
     }
     if (timed_out) break;
+    if (verify) {  // the record is final once its tag is visible: a second read must return the same 16 bytes
+      int o = poll_off;
+      asm volatile("" : "+v"(o)::"memory");
+      v4i_t g2 = __builtin_amdgcn_raw_buffer_load_b128(rx, o, so_in, kAuxSc1);
+      if ((verify & 2) && it == 2 && w == wave_begin && lane == 0) g2.x ^= 0x00400000;
+      if (__any(active && (g2.x != g.x || g2.y != g.y || g2.z != g.z || g2.w != g.w))) {
+        torn = true;
+        break;
+      }
+    }
 
     // ---- dual update of this half-edge's private q copy (cc:99-110) ------------------------------
     const float nxb = __int_as_float(g.x), nw1b = __int_as_float(g.y), nw2b = __int_as_float(g.z);
@@ -498,12 +511,12 @@ k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd
     w2b = __shfl(w2bn, tail_lane, 64);
   }
 
-  if (timed_out) {
+  if (timed_out || torn) {
     if (lane == 0) {
       __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      atomicOr(err, 2);
+      atomicOr(err, torn ? 4 : 2);
     }
-    return;  // the run is reported as failed; the host invalidates the state
+    return;  // the run is reported as failed; the host takes it back
   }
 
   // The results go to the OTHER copies of the state arrays (the host swaps the roles only when the whole run
@@ -581,13 +594,14 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
                 const int32_t* __restrict__ wg_fetch, const int32_t* __restrict__ wg_info, const int4* hrec,
                 const float4* hq, const float4* vstate,
                 float4* hq_out, float4* vstate_out, const float2* vaux, const float4* bar_in, float4* bar_out, float4* vprev,
-                void* xbuf, const int rec_bytes, const int dual, const unsigned tag0, const int n_iters,
+                void* xbuf, const int rec_bytes, const int dual_arg, const unsigned tag0, const int n_iters,
                 const unsigned max_spins_arg, const int poll_gap, const SolverParams p,
                 int* __restrict__ err, int* __restrict__ abort_flag, const int32_t* __restrict__ perm,
                 const RunTail* __restrict__ tail, unsigned* __restrict__ probe) {
   extern __shared__ float4 lds[];
   constexpr int T = 64;
   const unsigned max_spins = max_spins_arg & 0x7fffffffu;
+  const int dual = dual_arg & 1, verify = dual_arg >> 1;  // as in k_persistent_he
   const int lane = (int)threadIdx.x;
   const int b = blockIdx.x;
   const int xcd = b & 7, idx = b >> 3;
@@ -659,6 +673,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   v2f_t w_prev = w12;
   bool ok = true;
   bool timed_out = n_fetch > T;  // (the host never launches such a layout in this form)
+  bool torn = false;
 
   const int my_off = (rid_base + loc) << 4;
   // (a lane without a half-edge writes to its own spare entry, which nobody reads)
@@ -724,7 +739,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   // src: this lane's poll address; wr_rec: float4 index where the own record of the next step goes; so_out: memory offset
   // of the parity published.
   auto step = [&](const unsigned s, const unsigned rd_nbr, const unsigned dst, const char* const src, const int wr_rec,
-                  const int so_out, const int it) {
+                  const int so_out, const int so_in, const int fetch_area, const int it) {
     // ---- wait for the neighbours' records of step s ----------------------------------------------------------------
     v4f_t nbv;  // the tag word is read first, the record after it: a tag that matches vouches for the payload
     unsigned rounds = 0;
@@ -770,6 +785,18 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
           break;
         }
       }
+    }
+    if (verify && !timed_out) {
+      // Every fetch lane reads its foreign record once more, with an ordinary load, and compares all four dwords with
+      // what the LDS-DMA left in its slot: a record is final once its tag is visible, so a difference means a torn
+      // 16-byte access (memory side or LDS side) -- reported, the run is taken back and redone per step.
+      v4i_t g2 = {0, 0, 0, 0};
+      if (frid >= 0) g2 = __builtin_amdgcn_raw_buffer_load_b128(rx, off0, so_in, kAuxSc1);
+      const float4 l4 = lds[fetch_area + lane];
+      if ((verify & 2) && it == 2 && wg == wg_begin && lane == 0) g2.x ^= 0x00400000;  // test hook
+      const bool bad = frid >= 0 && (g2.x != __float_as_int(l4.x) || g2.y != __float_as_int(l4.y) || g2.z != __float_as_int(l4.z) ||
+                                     (unsigned)g2.w != s || __float_as_uint(l4.w) != s);
+      if (__any(bad)) torn = timed_out = true;
     }
     unsigned pr_t1 = 0;
     if (PROBE) pr_t1 = (unsigned)clock64();
@@ -884,17 +911,17 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   const int wrA_rec = (valid ? areaA : 0) + rec_w, wrB_rec = (valid ? areaB : 0) + rec_w;
   int it = 0;
   for (; it + 1 < n_iters && !timed_out; it += 2) {
-    step(tag0 + (unsigned)it, rdA_nbr, dstA, srcA, wrB_rec, soB, it);
+    step(tag0 + (unsigned)it, rdA_nbr, dstA, srcA, wrB_rec, soB, soA, areaA + lcap, it);
     if (timed_out) break;
-    step(tag0 + (unsigned)it + 1u, rdB_nbr, dstB, srcB, wrA_rec, soA, it + 1);
+    step(tag0 + (unsigned)it + 1u, rdB_nbr, dstB, srcB, wrA_rec, soA, soB, areaB + lcap, it + 1);
   }
-  if (it < n_iters && !timed_out) step(tag0 + (unsigned)it, rdA_nbr, dstA, srcA, wrB_rec, soB, it);
+  if (it < n_iters && !timed_out) step(tag0 + (unsigned)it, rdA_nbr, dstA, srcA, wrB_rec, soB, soA, areaA + lcap, it);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA in flight when the wave ends
 
   if (timed_out) {
     if (lane == 0) {
       __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      atomicOr(err, 2);
+      atomicOr(err, torn ? 4 : 2);
     }
     return;
   }
@@ -947,10 +974,11 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
                 const int32_t* __restrict__ tv_vid, const uint32_t* __restrict__ tv_meta,
                 const uint32_t* __restrict__ tv_wave, const int4* hrec, const float4* hq, const float4* vstate,
                 float4* hq_out, float4* vstate_out, const float2* vaux, const float4* bar_in, float4* bar_out,
-                float4* vprev, void* xbuf, const int rec_bytes, const int dual, const unsigned tag0, const int n_iters,
+                float4* vprev, void* xbuf, const int rec_bytes, const int dual_arg, const unsigned tag0, const int n_iters,
                 const unsigned max_spins_arg, const int presleep, const SolverParams p, int* __restrict__ err,
                 int* __restrict__ abort_flag, const int32_t* __restrict__ perm, const RunTail* __restrict__ tail) {
   const unsigned max_spins = max_spins_arg & 0x7fffffffu;
+  const int dual = dual_arg & 1, verify = dual_arg >> 1;  // as in k_persistent_he
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
   const int b = blockIdx.x;
@@ -1009,7 +1037,7 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
   float xb = bs.x, w1b = bs.y, w2b = bs.z;
   float x_prev = x, w1_prev = w1, w2_prev = w2;
   bool ok = true;
-  bool timed_out = false;
+  bool timed_out = false, torn = false;
   const int ps = presleep;
 
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(xbuf);
@@ -1091,6 +1119,23 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
       __builtin_amdgcn_s_sleep(1);
     }
     if (timed_out) break;
+    if (verify) {  // a record is final once its tag is visible: a second read must return the same 16 bytes
+      bool bad = false;
+#pragma unroll
+      for (int k = 0; k < kTvS; ++k) {
+        if ((all_mask >> k) & 1u) {
+          int o = NBR(k) & 0x7fffffff;
+          asm volatile("" : "+v"(o)::"memory");
+          v4i_t g2 = __builtin_amdgcn_raw_buffer_load_b128(rx, o, so_in, kAuxSc1);
+          if ((verify & 2) && it == 2 && w == wave_begin && lane == 0 && k == 0) g2.x ^= 0x00400000;  // test hook
+          bad = bad || g2.x != g[k].x || g2.y != g[k].y || g2.z != g[k].z || g2.w != g[k].w;
+        }
+      }
+      if (__any(bad)) {
+        torn = true;
+        break;
+      }
+    }
 
     // ---- phase A, every lane at once: dual update of each slot's private q copy (cc:99-110) and the three
     // step-scaled values its primal scatter needs (cc:126-141).  They overwrite the neighbour record of the slot
@@ -1172,10 +1217,10 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
     }
   }
 
-  if (timed_out) {
+  if (timed_out || torn) {
     if (lane == 0) {
       __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      atomicOr(err, 2);
+      atomicOr(err, torn ? 4 : 2);
     }
     return;
   }

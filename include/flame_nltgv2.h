@@ -42,13 +42,15 @@ typedef enum flame_nltgv2_status {
   FLAME_NLTGV2_ERR_NO_GRAPH = -4,    /* compute call before flame_nltgv2_upload_graph */
   FLAME_NLTGV2_ERR_NAN = -5,         /* a dual variable became NaN/Inf: the condition on which the
                                         reference's FLAME_ASSERT(!std::isnan(new_q)) fires
-                                        (nltgv2...h:174).  Sticky until the next upload. */
+                                        (nltgv2...h:174).  Reported once by the call that finds it; the state
+                                        stays readable (q was clamped to +-1 where it happened) and usable. */
   FLAME_NLTGV2_ERR_OOM = -6,
   FLAME_NLTGV2_ERR_TIMEOUT = -7,     /* persistent run: a bounded neighbour wait expired.  run()/sync() normally hide
                                         this: the run's results go to second copies of the state, so the state is
                                         rolled back and the steps are redone with one launch per step (get_info:
-                                        timeouts_recovered).  Returned only when several runs were chained with
-                                        run_async() and no sync() in between: then the state is lost, upload again */
+                                        timeouts_recovered); runs chained with run_async() are covered too (the chain's
+                                        starting state is copied aside once, the chain replayed).  Returned only if that
+                                        recovery itself is impossible */
   FLAME_NLTGV2_ERR_ASSERT = -8       /* flame_stereo.h: an input on which the reference's FLAME_ASSERT would
                                         exit(1) (assert.h:111) */
 } flame_nltgv2_status;
@@ -264,6 +266,12 @@ enum {
                                         one XCD for graphs small enough to run there, else all eight; 1..8 */
   FLAME_NLTGV2_OPT_POLL_GAP = 13,    /* patch-per-wave form: 0 (default) = built-in, 1 = no pause between the polls of a
                                         wait, 2 = one s_sleep (64 cycles) */
+  FLAME_NLTGV2_OPT_VERIFY_RECORDS = 14, /* persistent kernels: 1 = after a neighbour record's tag matched, read the 16 bytes
+                                        once more and compare all four dwords (the exchange relies on an aligned 16-byte
+                                        access never being torn between payload and tag; this checks it at run time, at the
+                                        price of one more load round trip per step); a difference takes the run back like a
+                                        timeout and counts in flame_nltgv2_info.torn_records_detected.  2 = the same plus a
+                                        test hook that corrupts one re-read.  0 (default) = off */
   FLAME_NLTGV2_OPT_PROBE = 12,       /* 1 = the patch-per-wave kernel records a per-patch, per-step cycle probe (8 words:
                                         HW id, XCC id, wait cycles, compute cycles, poll rounds, step start, 100 MHz clock,
                                         0), read with flame_nltgv2_read_probe; 0 (default) = off */
@@ -293,6 +301,8 @@ typedef struct flame_nltgv2_info {
   int32_t tv_wave_capacity; /* vertex-per-lane waves the device keeps resident */
   int32_t last_run_groups;  /* persistent launches the last run was split into (groups of whole components) */
   int32_t timeouts_recovered; /* persistent runs whose wait expired: state rolled back, steps redone one launch per step */
+  int32_t torn_records_detected; /* persistent runs stopped by FLAME_NLTGV2_OPT_VERIFY_RECORDS (a record whose second
+                                    read differed from the first): rolled back and redone the same way */
 } flame_nltgv2_info;
 int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info);
 

@@ -462,6 +462,38 @@ def test_persistent_timeout_is_rolled_back_and_redone(env, form):
         assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="after a clean chain")
 
 
+@pytest.mark.parametrize("form", [2, 3, 4])
+def test_record_verification_detects_a_corrupted_read_and_recovers(env, form):
+    """FLAME_NLTGV2_OPT_VERIFY_RECORDS: the persistent kernels re-read every neighbour record after its tag matched and
+    compare all four dwords -- the run-time guard of the one hardware property the exchange relies on (an aligned 16-byte
+    access is never torn between payload and tag).  Clean runs pass it; with the test hook (one re-read gets a flipped
+    payload bit) the run is stopped, counted, rolled back and redone with one launch per step: same result."""
+    flame_amd, oracle = env
+    g = synth.make_graph("320x240", seed=19)
+    p = flame_amd.Params()
+    ref = synth.copy_graph(g)
+    with flame_amd.Regularizer(0) as reg:
+        reg.set_option(5, form)
+        reg.set_option(14, 1)
+        reg.upload_graph(g)
+        reg.run(p, 60)
+        oracle.run(ref, 60)
+        info = reg.info()
+        assert info["torn_records_detected"] == 0 and info["timeouts_recovered"] == 0 and info["last_run_path"] in (1, 5, 6)
+        assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="verified run")
+        reg.set_option(14, 2)  # the hook corrupts one re-read in step 2 of the next persistent run
+        reg.run(p, 33)
+        oracle.run(ref, 33)
+        info = reg.info()
+        assert info["torn_records_detected"] == 1 and info["timeouts_recovered"] == 0 and info["last_run_path"] in (2, 3)
+        assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="after a detected corruption")
+        reg.set_option(14, 1)
+        reg.run(p, 20)
+        oracle.run(ref, 20)
+        assert reg.info()["last_run_path"] in (1, 5, 6) and reg.info()["torn_records_detected"] == 1
+        assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="verified again")
+
+
 def test_invalid_arguments(env):
     flame_amd, _ = env
     g = synth.make_graph("320x240", seed=9)

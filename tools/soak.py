@@ -3,14 +3,15 @@
 
 Every record hand-off of the persistent kernels is a 16-byte {value,tag} access; a torn or stale read
 would change some bit of the result.  This runs many more steps than the test-suite does, in every
-persistent configuration, and compares ALL state arrays with the CPU checker bit for bit."""
+persistent configuration (half of them with FLAME_NLTGV2_OPT_VERIFY_RECORDS: the kernels re-read every record after
+its tag matched and compare all four dwords), and compares ALL state arrays with the CPU checker bit for bit."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch  # noqa
 import flame_amd
 from flame_amd import synth
-from flame_amd.regularizer import OPT_DUAL_PUBLISH, OPT_PERSISTENT, OPT_TV_LDS
+from flame_amd.regularizer import OPT_DUAL_PUBLISH, OPT_PERSISTENT, OPT_TV_LDS, OPT_VERIFY_RECORDS
 from oracle import capi as oracle
 
 ITERS = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
@@ -43,11 +44,12 @@ for cfg, seed in cases:
     t0 = time.time()
     oracle.run(ref, ITERS)
     cpu_s = time.time() - t0
-    for form, dual, lds in ((2, 0, 0), (2, 2, 0), (3, 0, 0), (3, 2, 0), (3, 2, 2)):
+    for form, dual, lds, verify in ((4, 2, 0, 0), (4, 2, 0, 1), (4, 0, 0, 1), (2, 0, 0, 0), (2, 2, 0, 1), (3, 0, 0, 1), (3, 2, 0, 0), (3, 2, 2, 1)):
         with flame_amd.Regularizer(0) as reg:
             reg.set_option(OPT_PERSISTENT, form)
             reg.set_option(OPT_DUAL_PUBLISH, dual)
             reg.set_option(OPT_TV_LDS, lds)
+            reg.set_option(OPT_VERIFY_RECORDS, verify)
             reg.upload_graph(g)
             done = 0
             rng = np.random.default_rng(form * 10 + dual)
@@ -58,13 +60,16 @@ for cfg, seed in cases:
                 done += n
                 launches += 1
             out = reg.download_state(KEYS)
-            path = reg.info()["last_run_path"]
+            info = reg.info()
+            path = info["last_run_path"]
         ok = all(np.array_equal(out[k], ref[k]) for k in KEYS)
         results.append(dict(config=cfg, V=g["V"], E=g["E"], iters=ITERS, launches=launches, form=form, dual=dual, tv_lds=lds,
-                            run_path=path, bit_identical=bool(ok)))
+                            verify_records=verify, torn_records_detected=info["torn_records_detected"],
+                            timeouts_recovered=info["timeouts_recovered"], run_path=path, bit_identical=bool(ok)))
         print(results[-1], flush=True)
 stop = True
 if LOAD:
     th.join(timeout=10)
-print(json.dumps(dict(under_load=LOAD, all_ok=all(r["bit_identical"] for r in results), seconds=round(time.time() - t_start, 1),
+print(json.dumps(dict(under_load=LOAD, all_ok=all(r["bit_identical"] for r in results),
+                      torn_records_detected=sum(r["torn_records_detected"] for r in results), seconds=round(time.time() - t_start, 1),
                       results=results)))
