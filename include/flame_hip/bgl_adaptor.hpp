@@ -2,10 +2,11 @@
 //   using Graph = boost::adjacency_list<hash_setS, hash_setS, undirectedS, VertexData, EdgeData>
 //   (/root/reference/src/flame/optimizers/nltgv2_l1_graph_regularizer.h:107-112).
 //
-// Include this header AFTER the reference's nltgv2_l1_graph_regularizer.h inside the FLaME tree (it
-// needs Boost.Graph and the reference's VertexData/EdgeData, neither of which exists in the build
-// image of this repository, so it is compile-checked only there; the packing logic it shares with
-// flame_hip::FlatGraph is what the tests exercise).
+// Include this header AFTER the reference's nltgv2_l1_graph_regularizer.h inside the FLaME tree.  It needs
+// Boost.Graph and the reference's VertexData/EdgeData; Boost is absent from the build image of this repository, so here
+// it is compiled and run only against tests/cpp/mock_boost/ -- a test-only look-alike of the dozen BGL calls it makes
+// (not the reference, not Boost: a compile check of the call shapes, stated as such in DESIGN.md) -- and against real
+// Boost only inside the FLaME tree.
 //
 // Order and orientation are taken exactly as the reference's loops see them:
 //   vertices: boost::vertices(graph) order               (cc:35-42, 145-151, 158-171)
@@ -54,7 +55,12 @@ struct GraphAccess<boost::adjacency_list<OutEdgeS, VertexS, DirS, VP, EP, GP, Ed
     }
   }
 
+  static void size(const Graph& g, size_t* V, size_t* E) { *V = boost::num_vertices(g), *E = boost::num_edges(g); }
+
+  // By position in vertices()/edges() order: DeviceGraph::download() only calls this for a graph with the vertex and
+  // edge counts (and, where the caller tracks it, the edit generation) of the one that was packed.
   static void unpack(const FlatArrays& f, Graph* g) {
+    if (boost::num_vertices(*g) != f.x.size() || boost::num_edges(*g) != f.src.size()) return;
     typename Graph::vertex_iterator vit, vend;
     boost::tie(vit, vend) = boost::vertices(*g);
     for (int32_t v = 0; vit != vend; ++vit, ++v) {

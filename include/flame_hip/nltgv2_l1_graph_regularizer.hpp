@@ -67,6 +67,7 @@ struct FlatArrays {
 // Specialise for a graph container:
 //   static void pack(const Graph&, FlatArrays*)      vertices()/edges() order; (src,dst) = (source,target)
 //   static void unpack(const FlatArrays&, Graph*)    writes x,w,x_bar,w_bar,x_prev,w_prev,q back
+//   static void size(const Graph&, size_t* V, size_t* E)
 template <class Graph>
 struct GraphAccess;
 
@@ -108,6 +109,7 @@ struct GraphAccess<FlatGraph> {
       f->q1[e] = d.q1, f->q2[e] = d.q2, f->q3[e] = d.q3;
     }
   }
+  static void size(const FlatGraph& g, size_t* V, size_t* E) { *V = g.vertices.size(), *E = g.edges.size(); }
   static void unpack(const FlatArrays& f, FlatGraph* g) {
     for (size_t v = 0; v < g->vertices.size(); ++v) {
       VertexData& d = g->vertices[v];
@@ -175,19 +177,32 @@ class DeviceGraph {
   DeviceGraph& operator=(const DeviceGraph&) = delete;
 
   // After Flame::syncGraph changed vertices / edges / data (flame.cc:1940-2188).
+  // `generation`: any caller-side counter of graph edits; download() of another generation is refused.
   template <class Graph>
-  void upload(const Graph& graph) {
+  void upload(const Graph& graph, uint64_t generation = 0) {
     flame_hip::GraphAccess<Graph>::pack(graph, &flat_);
     flame_nltgv2_graph v = flat_.view();
     check(flame_nltgv2_upload_graph(ctx_, &v), "upload_graph");
+    uploaded_v_ = flat_.x.size(), uploaded_e_ = flat_.src.size(), generation_ = generation, uploaded_ = true;
   }
-  // Before Flame::update reads x, w1, w2 (flame.cc:372-380) or edits the graph.
+  // Before Flame::update reads x, w1, w2 (flame.cc:372-380) or edits the graph.  Values go back to the objects they
+  // came from BY POSITION in vertices()/edges() order, so the graph must be the one that was uploaded: a graph whose
+  // vertex or edge count differs, or (when the caller tracks edits) whose generation differs, is refused
+  // (FLAME_NLTGV2_ERR_INVALID_ARG) instead of receiving values that belong to other vertices.
   template <class Graph>
-  void download(Graph* graph) {
+  void download(Graph* graph, uint64_t generation = 0) {
+    if (!matches(*graph, generation)) throw flame_hip::Error(FLAME_NLTGV2_ERR_INVALID_ARG, "download: the graph changed since upload()");
     flame_nltgv2_graph v = flat_.view();
     check(flame_nltgv2_download_state(ctx_, &v), "download_state");
     flame_hip::GraphAccess<Graph>::unpack(flat_, graph);
   }
+  template <class Graph>
+  bool matches(const Graph& graph, uint64_t generation = 0) const {
+    size_t V = 0, E = 0;
+    flame_hip::GraphAccess<Graph>::size(graph, &V, &E);
+    return uploaded_ && V == uploaded_v_ && E == uploaded_e_ && generation == generation_;
+  }
+  uint64_t generation() const { return generation_; }
 
   // Per-frame warm-start synchronisation: Flame::syncGraph's graph edits (flame.cc:1985-2121) applied to the
   // device image; see flame_nltgv2_sync_graph.  `edges` = triangulator->edges() as index pairs.
@@ -245,6 +260,9 @@ class DeviceGraph {
   }
   flame_nltgv2_ctx* ctx_;
   flame_hip::FlatArrays flat_;
+  size_t uploaded_v_ = 0, uploaded_e_ = 0;
+  uint64_t generation_ = 0;
+  bool uploaded_ = false;
 };
 
 // ---- the reference's free functions, same signatures (h:134-168) -----------------------------------

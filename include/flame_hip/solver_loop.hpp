@@ -1,0 +1,176 @@
+// flame_hip/solver_loop.hpp -- the reference's solver thread (Flame::Flame, /root/reference/src/flame/flame.cc:99-112:
+// `while (true) { lock graph_mtx_; step(params, &graph_); }`, joined in ~Flame flame.cc:120-124 -- a loop that cannot
+// exit) as a class that can: the device-side counterpart of that thread for a pipeline that keeps `Graph graph_` on the
+// host (flame.h:536) and lets the GPU iterate on its image of it.
+//
+//   flame_hip::SolverLoop<Graph> loop(&graph_, &graph_mtx_, params);   // in Flame::Flame
+//   loop.start();
+//   ...
+//   {  std::lock_guard<std::recursive_mutex> lock(graph_mtx_);          // Flame::update, as today (flame.cc:302-381)
+//      loop.readBack();                  // x, w1, w2, q of the device image -> graph_   (before reading / editing it)
+//      syncGraph(); ...                  // edit graph_
+//      loop.markDirty();                 // the loop uploads the edited graph before its next round
+//   }
+//   loop.stop();                         // or the destructor: sets the flag, wakes the thread, joins
+//
+// Locking: the caller's mutex protects the HOST graph exactly as in the reference; the loop takes it only to upload.  An
+// internal mutex serialises the calls into the (not thread-safe) device context: the loop holds it for one round of
+// `iters_per_round` iterations (~1.3 us each at 640x480), readBack() waits for that round at most.  Lock order is always
+// caller's mutex, then the internal one.  A graph edited without markDirty() is not written to: readBack() compares vertex
+// and edge counts and the edit generation with what was uploaded and returns false instead.
+#ifndef FLAME_HIP_SOLVER_LOOP_HPP_
+#define FLAME_HIP_SOLVER_LOOP_HPP_
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <thread>
+
+#include "flame_hip/nltgv2_l1_graph_regularizer.hpp"
+
+namespace flame_hip {
+
+template <class Graph, class GraphMutex = std::recursive_mutex>
+class SolverLoop {
+ public:
+  typedef flame::optimizers::nltgv2_l1_graph_regularizer::hip::Params Params;
+  typedef flame::optimizers::nltgv2_l1_graph_regularizer::hip::DeviceGraph DeviceGraph;
+
+  // max_rounds_per_upload = 0: iterate until stopped (the reference's behaviour); > 0: that many rounds after every
+  // upload, then idle until the next markDirty() (a fixed iteration budget per frame; also what makes tests exact).
+  SolverLoop(Graph* graph, GraphMutex* graph_mtx, const Params& params, int iters_per_round = 32, int max_rounds_per_upload = 0,
+             int device = 0)
+      : graph_(graph), graph_mtx_(graph_mtx), params_(params), iters_per_round_(iters_per_round > 0 ? iters_per_round : 1),
+        max_rounds_(max_rounds_per_upload), dev_(device) {}
+  ~SolverLoop() { stop(); }
+  SolverLoop(const SolverLoop&) = delete;
+  SolverLoop& operator=(const SolverLoop&) = delete;
+
+  void start() {
+    std::lock_guard<std::mutex> lk(state_mtx_);
+    if (thread_.joinable()) return;
+    stop_.store(false);
+    thread_ = std::thread([this] { run(); });
+  }
+  void stop() {  // idempotent; returns after the thread has exited (at most one round later)
+    {
+      std::lock_guard<std::mutex> lk(state_mtx_);
+      stop_.store(true);
+    }
+    cv_.notify_all();
+    if (thread_.joinable()) thread_.join();
+  }
+  bool running() const { return thread_.joinable() && !stop_.load(); }
+
+  // Caller holds graph_mtx: the graph was edited (vertices, edges, data terms); the loop re-uploads it before iterating on.
+  void markDirty() {
+    {
+      std::lock_guard<std::mutex> lk(state_mtx_);
+      ++dirty_generation_;
+    }
+    cv_.notify_all();
+  }
+  // Caller holds graph_mtx: copies x, w, x_bar, w_bar, x_prev, w_prev, q of the device image into the graph.  Returns
+  // false -- and leaves the graph alone -- when the device image is not of this graph (edited since the last upload, or
+  // nothing uploaded yet).
+  bool readBack() {
+    std::lock_guard<std::mutex> dev_lk(dev_mtx_);
+    uint64_t want;
+    {
+      std::lock_guard<std::mutex> lk(state_mtx_);
+      want = dirty_generation_;
+    }
+    if (!dev_.matches(*graph_, want)) return false;
+    dev_.download(graph_, want);
+    return true;
+  }
+  // iterations done on the device image since start(); error text of the thread, if it stopped on one
+  uint64_t iterations() const { return iterations_.load(); }
+  uint64_t uploads() const { return uploads_.load(); }
+  std::string error() const {
+    std::lock_guard<std::mutex> lk(state_mtx_);
+    return error_;
+  }
+  void setParams(const Params& p) {
+    std::lock_guard<std::mutex> dev_lk(dev_mtx_);
+    params_ = p;
+  }
+
+ private:
+  void run() {
+    int rounds_left = 0;
+    try {
+      while (!stop_.load()) {
+        uint64_t dirty;
+        {
+          std::lock_guard<std::mutex> lk(state_mtx_);
+          dirty = dirty_generation_;
+        }
+        bool have = false;
+        {
+          std::lock_guard<std::mutex> dev_lk(dev_mtx_);
+          have = dev_.generation() == dirty && uploaded_once_;
+        }
+        if (!have) {  // (re)upload under the caller's mutex: nobody edits the graph meanwhile
+          std::lock_guard<GraphMutex> g_lk(*graph_mtx_);
+          std::lock_guard<std::mutex> dev_lk(dev_mtx_);
+          {
+            std::lock_guard<std::mutex> lk(state_mtx_);
+            dirty = dirty_generation_;  // the edit we are about to see
+          }
+          dev_.upload(*graph_, dirty);
+          uploaded_once_ = true;
+          uploads_.fetch_add(1);
+          rounds_left = max_rounds_;
+        }
+        size_t V = 0, E = 0;
+        bool idle = false;
+        {
+          std::lock_guard<std::mutex> dev_lk(dev_mtx_);
+          V = dev_vertices();
+          if (V == 0 || (max_rounds_ > 0 && rounds_left == 0)) {
+            idle = true;
+          } else {
+            dev_.run(params_, iters_per_round_);
+            iterations_.fetch_add(static_cast<uint64_t>(iters_per_round_));
+            if (max_rounds_ > 0) --rounds_left;
+          }
+        }
+        (void)E;
+        if (idle) {  // nothing to do until the graph changes or we are told to stop
+          std::unique_lock<std::mutex> lk(state_mtx_);
+          cv_.wait_for(lk, std::chrono::milliseconds(50), [&] { return stop_.load() || dirty_generation_ != dirty; });
+        }
+      }
+    } catch (const std::exception& e) {
+      std::lock_guard<std::mutex> lk(state_mtx_);
+      error_ = e.what();
+      stop_.store(true);
+    }
+  }
+  size_t dev_vertices() {
+    flame_nltgv2_info info;
+    return flame_nltgv2_get_info(dev_.handle(), &info) == 0 ? static_cast<size_t>(info.V) : 0;
+  }
+
+  Graph* graph_;
+  GraphMutex* graph_mtx_;
+  Params params_;
+  const int iters_per_round_, max_rounds_;
+  DeviceGraph dev_;
+  std::mutex dev_mtx_;            // serialises calls into dev_ (the context is not thread-safe)
+  mutable std::mutex state_mtx_;  // dirty_generation_, error_, thread_ start/stop
+  std::condition_variable cv_;
+  std::thread thread_;
+  std::atomic<bool> stop_{false};
+  std::atomic<uint64_t> iterations_{0}, uploads_{0};
+  uint64_t dirty_generation_ = 1;  // the graph as handed to the constructor is "edit 1": uploaded by the first round
+  bool uploaded_once_ = false;
+  std::string error_;
+};
+
+}  // namespace flame_hip
+
+#endif  // FLAME_HIP_SOLVER_LOOP_HPP_

@@ -82,3 +82,32 @@ def test_facade_end_to_end(built, tmp_path):
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count(" ok") >= 5
+
+
+def build_solver_loop_program(tmp_path):
+    exe = str(tmp_path / "solver_loop_test")
+    lib_dir = os.path.join(ROOT, "flame_amd")
+    subprocess.check_call([
+        "g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-Werror", "-pthread", "-I", os.path.join(ROOT, "include"),
+        os.path.join(ROOT, "tests", "cpp", "solver_loop_test.cc"), "-o", exe,
+        "-L", lib_dir, "-lflame_nltgv2_hip", "-L", os.path.join(ROOT, "oracle"), "-loracle_nltgv2",
+        f"-Wl,-rpath,{lib_dir}", f"-Wl,-rpath,{os.path.join(ROOT, 'oracle')}", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_solver_loop_compiles_and_fails_loudly_without_a_device(built, tmp_path):
+    """include/flame_hip/solver_loop.hpp: the solver thread of flame.cc:99-112 with a stop flag (C++11, -pthread)."""
+    exe = build_solver_loop_program(tmp_path)
+    from tests.conftest import HAS_GPU
+
+    if not HAS_GPU:
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 77 and "no usable HIP device" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_solver_loop_end_to_end(built, tmp_path):
+    """start, three frames of edit -> dirty -> resume (bit-identical to the checker), the stale-graph guard, stop and join."""
+    r = subprocess.run([build_solver_loop_program(tmp_path)], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and r.stdout.count(" ok") >= 8 and "FAIL" not in r.stdout, r.stdout + r.stderr
