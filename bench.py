@@ -382,9 +382,16 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
     r = flame_amd.Regularizer(0)
     r.upload_graph(g)
     r.run(params, a.iters)
+    up_call = []
+    for _ in range(10):
+        tc = _t.perf_counter()
+        r.upload_graph(g)  # returns once everything is staged and enqueued ...
+        up_call.append((_t.perf_counter() - tc) * 1e3)
+        r.sync()
     t0 = _t.perf_counter()
     for _ in range(10):
         r.upload_graph(g)
+        r.sync()           # ... this is until the device has it all
     t1 = _t.perf_counter()
     for _ in range(10):
         r.run(params, 1)
@@ -394,6 +401,7 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
         r.run(params, 1)
     t3 = _t.perf_counter()
     up_ms, down_ms = (t1 - t0) * 100, ((t2 - t1) - (t3 - t2)) * 100
+    up_call_ms = sorted(up_call)[len(up_call) // 2]
     r.run(params, a.iters)
     ms = min(r.run_timed(params, a.iters) for _ in range(5))
     # per-frame warm-start synchronisation (syncGraph's graph edits): ~8 % vertex churn, new triangulation
@@ -416,15 +424,27 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
                        "note": "host code (the reference's Triangle is host code too), exact predicates"}
     r.upload_graph(g)
     r.run(params, 50)
-    r.sync_graph(_np.arange(g["V"], dtype=_np.int32), g["pos"], g["data_term"], g["data_weight"],
-                 _np.stack([g["src"], g["dst"]], 1))  # warm-up of the sync path (allocations, hash tables)
+    fid0, edges0 = _np.arange(g["V"], dtype=_np.int32), _np.stack([g["src"], g["dst"]], 1)
+    ones2 = _np.ones(len(fid), _np.float32)
+    r.sync_graph(fid0, g["pos"], g["data_term"], g["data_weight"], edges0)  # warm-up of the sync path (allocations)
+    sync_call, sync_done = [], []
+    for _ in range(5):  # frame A -> frame B (8 % churn) timed, B -> A back untimed
+        r.run(params, 50)
+        t4 = _t.perf_counter()
+        r.sync_graph(fid, pos2, data2, ones2, edges2)
+        t5 = _t.perf_counter()
+        r.sync()
+        sync_call.append((t5 - t4) * 1e3)
+        sync_done.append((_t.perf_counter() - t4) * 1e3)
+        r.run(params, 50)
+        r.sync_graph(fid0, g["pos"], g["data_term"], g["data_weight"], edges0)
     r.run(params, 50)
-    t4 = _t.perf_counter()
-    r.sync_graph(fid, pos2, data2, _np.ones(len(fid), _np.float32), edges2)
-    t5 = _t.perf_counter()
+    r.sync_graph(fid, pos2, data2, ones2, edges2)
     r.run(params, 50)
-    out["frame_sync"] = {"sync_graph_ms": round((t5 - t4) * 1e3, 3), "churn": "8 % of vertices replaced, re-triangulated",
-                         "V": int(len(fid)), "E": int(r.info()["E"])}
+    out["frame_sync"] = {"sync_graph_ms": round(sorted(sync_done)[2], 3), "sync_graph_call_ms": round(sorted(sync_call)[2], 3),
+                         "churn": "8 % of vertices replaced, re-triangulated", "V": int(len(fid)), "E": int(r.info()["E"]),
+                         "note": "median of 5; sync_graph_ms = until the device holds the new frame (call + stream sync), "
+                                 "call_ms = until the call returns (index maps, tables, one staged copy, kernels enqueued)"}
     # mesh -> dense idepthmap (utils::interpolateMesh, next row 8(f)-2), incl. the D2H copy of the map
     tris = tris2
     r.interpolate_mesh(tris, h_, w_)
@@ -441,7 +461,7 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
         t8 = _t.perf_counter()
         _oracle.raster_interpolate_mesh(tris, pos2, xs, h_, w_)
         out["rasterize"]["cpu_checker_ms"] = round((_t.perf_counter() - t8) * 1e3, 3)
-    out["host_boundary"] = {"upload_graph_ms": round(up_ms, 3), "download_state_ms": round(down_ms, 3),
+    out["host_boundary"] = {"upload_graph_ms": round(up_ms, 3), "upload_graph_call_ms": round(up_call_ms, 3), "download_state_ms": round(down_ms, 3),
                             "pcie_inclusive_iters_per_s": round(a.iters / ((ms + up_ms + down_ms) * 1e-3), 1),
                             "note": "upload+200 iters+download per frame; never reported as value"}
     r.close()

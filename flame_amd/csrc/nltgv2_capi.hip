@@ -16,6 +16,7 @@
 #include <chrono>
 #include <cmath>
 #include <new>
+#include <memory>
 #include <vector>
 
 #include "flame_nltgv2.h"
@@ -30,7 +31,7 @@ constexpr int kGraphChunk = 256;      // steps per captured hipGraph (even: keep
 constexpr int kMaxCachedGraphs = 6;
 constexpr int kHeWavesPerCu = 24;      // residency cap of k_persistent_he (<= 64 VGPRs: the hardware admits 32)
 constexpr int kTvLdsWavesPerCu = 16;   // ... with the slot constants in LDS (<= 128 VGPRs -> 4 waves per SIMD; 10 KB LDS per wave = all 160 KB)
-constexpr size_t kXbufBytesPerVertex = 4 * 128 + 4;  // exchange buffers: four record arrays of up to 128 B per vertex + XCC table
+constexpr size_t kXbufBytesPerVertex = 4 * 16 + 4;  // exchange buffers: four arrays of 16-byte records + the XCC table
 constexpr int kPvPollGap = 1;          // s_sleep 1 between the polls of k_persistent_pv (measured: 1 beats 0 by 1-3 %)
 constexpr int kTvWavesPerCu = 8;       // residency of k_persistent_tv (<= 256 VGPRs -> 2 waves per SIMD)
 constexpr int kDualMinWavesPerCu = 0;  // auto: exchange through the XCD's L2 when more waves than this share a CU
@@ -52,6 +53,50 @@ struct CachedGraph {
   uint64_t stamp = 0;
 };
 
+// Open-addressing hash map u64 -> i32 (linear probing, power-of-two capacity, no erase): the per-frame
+// bookkeeping of sync_graph looks up ~V feature ids and ~E feature pairs; std::unordered_map made that the
+// most expensive part of a frame (2.0-2.5 ms at 640x480), this table does it in a fraction.
+class FlatMap {
+ public:
+  explicit FlatMap(size_t n) {
+    size_t cap = 16;
+    while (cap < 2 * n + 2) cap <<= 1;
+    mask_ = cap - 1;
+    keys_.assign(cap, kEmpty);
+    vals_.resize(cap);
+  }
+  // inserts (k,v) if k is absent; returns the slot's value pointer and whether it was inserted
+  std::pair<int32_t*, bool> emplace(uint64_t k, int32_t v) {
+    size_t i = hash(k) & mask_;
+    for (;; i = (i + 1) & mask_) {
+      if (keys_[i] == kEmpty) {
+        keys_[i] = k;
+        vals_[i] = v;
+        return {&vals_[i], true};
+      }
+      if (keys_[i] == k) return {&vals_[i], false};
+    }
+  }
+  const int32_t* find(uint64_t k) const {
+    size_t i = hash(k) & mask_;
+    for (;; i = (i + 1) & mask_) {
+      if (keys_[i] == kEmpty) return nullptr;
+      if (keys_[i] == k) return &vals_[i];
+    }
+  }
+
+ private:
+  static constexpr uint64_t kEmpty = ~0ull;  // feature ids are non-negative int32: never a real key
+  static size_t hash(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return (size_t)(z ^ (z >> 31));
+  }
+  size_t mask_;
+  std::vector<uint64_t> keys_;
+  std::vector<int32_t> vals_;
+};
+
 }  // namespace
 
 struct flame_nltgv2_ctx {
@@ -65,6 +110,9 @@ struct flame_nltgv2_ctx {
 
   bool have_graph = false;
   bool canon_valid = false, fused_valid = false, have_prev = false;
+  DevBuf sp_v[9], sp_q[3], sync_init, sync_vmap, sync_emap, sync_need;  // sync_graph: spare state arrays, inputs, index maps
+  std::vector<int32_t> h_old_of_new, h_old_of_new_edge;
+  std::unique_ptr<FlatMap> feat_map;  // feature id -> vertex of the CURRENT graph (h_feat), kept from one sync to the next
   int parity = 0;
   uint64_t topo = 0, stamp = 0;
 
@@ -113,6 +161,11 @@ struct flame_nltgv2_ctx {
     std::vector<PendingOp> ops;
   } pending;
   DevBuf snap_hq, snap_vstate, snap_bar;
+  DevBuf iperm, order_m, rid_of;   // per-vertex tables the device-side layout expansion reads (nltgv2_layout.hip)
+  bool he_built = false, tv_built = false;  // layouts (C) / (D) exist for the current topology (built on demand)
+  void* h_stage = nullptr;         // pinned staging buffer of the uploads
+  DevBuf d_stage;                 // ... and its device-side landing area (one copy; k_scatter distributes)
+  size_t stage_cap = 0;
 
   PackedLayout L;
   std::vector<int32_t> h_src, h_dst, h_feat;  // host image of the current topology (for sync_graph)
@@ -229,10 +282,10 @@ void refresh_args(flame_nltgv2_ctx* ctx) {
   f.bar[0] = (float4*)ctx->bar0.p, f.bar[1] = (float4*)ctx->bar1.p;
   f.vprev = (float4*)ctx->vprev.p;
   f.xbuf = ctx->xbuf.p;
-  f.he_waves = ctx->L.he_ok ? ctx->L.he_waves : 0;
+  f.he_waves = (ctx->he_built && ctx->L.he_ok) ? ctx->L.he_waves : 0;
   f.he_slot = (int32_t*)ctx->he_slot.p, f.he_vid = (int32_t*)ctx->he_vid.p;
   f.he_meta = (uint32_t*)ctx->he_meta.p, f.he_wave_chain = (int32_t*)ctx->he_wave_chain.p;
-  f.tv_waves = ctx->L.tv_ok ? ctx->L.tv_waves : 0;
+  f.tv_waves = (ctx->tv_built && ctx->L.tv_ok) ? ctx->L.tv_waves : 0;
   f.tv_slot = (int32_t*)ctx->tv_slot.p, f.tv_vid = (int32_t*)ctx->tv_vid.p;
   f.tv_meta = (uint32_t*)ctx->tv_meta.p, f.tv_wave = (uint32_t*)ctx->tv_wave.p;
   f.wg_count = ctx->L.wg_ok ? ctx->L.wg_count : 0;
@@ -296,37 +349,45 @@ struct WaveGroup {
 // is resident as a whole is one group.  A disjoint union too large for that (a big batch of frames) is run
 // group of connected components by group, each group resident on its own: the components are independent,
 // so running them one after the other for all n steps is exactly the same computation.
-int plan_persistent(const flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups, int* use_tv_lds = nullptr) {
+int ensure_form_rows(flame_nltgv2_ctx* ctx, int form);
+
+int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups, int* use_tv_lds = nullptr) {
   groups->clear();
   if (use_tv_lds) *use_tv_lds = 0;
   if (!ctx->opt_persistent || n < 4 || n > (1 << 24) || !ctx->prop.cooperativeLaunch) return 0;
   if (ctx->persist_refused_topo == ctx->topo) return 0;
-  const PackedLayout& L = ctx->L;
+  PackedLayout& L = ctx->L;
   const int cus = ctx->prop.multiProcessorCount;
-  // vertex-per-lane form: slot constants in registers (8 waves/CU, fastest per wave) while the graph is resident
-  // that way, else in LDS (16 waves/CU: 30 frames of 640x480 resident in one launch)
-  const bool tv_lds = ctx->opt_tv_lds == 2 || (ctx->opt_tv_lds == 1 && L.tv_waves > kTvWavesPerCu * cus);
-  const int he_cap = kHeWavesPerCu * cus, tv_cap = (tv_lds ? kTvLdsWavesPerCu : kTvWavesPerCu) * cus;
-  if (use_tv_lds) *use_tv_lds = tv_lds ? 1 : 0;
   if (L.wg_ok && ctx->pv_occ_topo != ctx->topo) {  // ask the runtime once per topology (the LDS use varies with it)
     ctx->pv_occ = pv_patches_per_cu(ctx->f);
     ctx->pv_occ_topo = ctx->topo;
   }
   const int wg_cap = ctx->pv_occ * cus;  // patch-per-wave form, in patches
-  const bool he_fits = L.he_ok && L.he_waves > 0 && L.he_waves <= he_cap;
-  const bool tv_fits = L.tv_ok && L.tv_waves > 0 && L.tv_waves <= tv_cap;
-  if (ctx->opt_persistent == 2 && !L.he_ok) return 0;
-  if (ctx->opt_persistent == 3 && !L.tv_ok) return 0;
-  if (ctx->opt_persistent == 4 && !L.wg_ok) return 0;
+  const int he_cap = kHeWavesPerCu * cus;
+  // The lane-per-half-edge rows (C) come from the same greedy walk as the patches (E): as many waves, possible under the
+  // same condition (no vertex of more than 64 incident edges).  They, and the vertex-per-lane rows (D), are built only
+  // when their form is actually chosen.
   const bool pv_fits = L.wg_ok && L.wg_count > 0 && L.wg_count <= wg_cap;
+  const bool he_possible = L.wg_ok && L.wg_count > 0;
   int form = 0;
-  if (ctx->opt_persistent == 4) form = 3;
-  else if (ctx->opt_persistent == 2) form = 1;
+  if (ctx->opt_persistent == 4) form = L.wg_ok ? 3 : 0;
+  else if (ctx->opt_persistent == 2) form = he_possible ? 1 : 0;
   else if (ctx->opt_persistent == 3) form = 2;
   else if (pv_fits) form = 3;  // lowest latency wherever all patches are resident: 320x240 ... 1280x720 single frames
-  else if (he_fits) form = 1;
-  else if (tv_fits) form = 2;
-  else form = L.tv_ok ? 2 : (L.he_ok ? 1 : 0);  // too big for one launch: vertex-per-lane groups
+  else if (he_possible && L.wg_count <= he_cap) form = 1;
+  else form = 2;               // too big for that: vertex-per-lane, in groups of whole components if need be
+  if (form == 1 || form == 2) {
+    if (ensure_form_rows(ctx, form) != 0) return 0;
+    if (form == 2 && !L.tv_ok) {
+      form = he_possible ? 1 : 0;
+      if (form == 1 && ensure_form_rows(ctx, 1) != 0) return 0;
+    }
+  }
+  // vertex-per-lane form: slot constants in registers (8 waves/CU, fastest per wave) while the graph is resident
+  // that way, else in LDS (16 waves/CU: 30 frames of 640x480 resident in one launch)
+  const bool tv_lds = form == 2 && (ctx->opt_tv_lds == 2 || (ctx->opt_tv_lds == 1 && L.tv_waves > kTvWavesPerCu * cus));
+  const int tv_cap = (tv_lds ? kTvLdsWavesPerCu : kTvWavesPerCu) * cus;
+  if (use_tv_lds) *use_tv_lds = tv_lds ? 1 : 0;
   if (form == 0) return 0;
   const int total = form == 3 ? L.wg_count : form == 2 ? L.tv_waves : L.he_waves;
   const int cap = form == 3 ? wg_cap : form == 2 ? tv_cap : he_cap;
@@ -373,7 +434,7 @@ int plan_persistent(const flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* 
   }
   return form;
 }
-bool persistent_eligible(const flame_nltgv2_ctx* ctx, int n) {
+bool persistent_eligible(flame_nltgv2_ctx* ctx, int n) {
   std::vector<WaveGroup> g;
   return plan_persistent(ctx, n, &g) != 0;
 }
@@ -708,51 +769,167 @@ int snapshot_chain_start(flame_nltgv2_ctx* ctx) {
   return 0;
 }
 
-bool params_ok(const flame_nltgv2_params* p) { return p != nullptr; }
-
-// Open-addressing hash map u64 -> i32 (linear probing, power-of-two capacity, no erase): the per-frame
-// bookkeeping of sync_graph looks up ~V feature ids and ~E feature pairs; std::unordered_map made that the
-// most expensive part of a frame (2.0-2.5 ms at 640x480), this table does it in a fraction.
-class FlatMap {
- public:
-  explicit FlatMap(size_t n) {
-    size_t cap = 16;
-    while (cap < 2 * n + 2) cap <<= 1;
-    mask_ = cap - 1;
-    keys_.assign(cap, kEmpty);
-    vals_.resize(cap);
-  }
-  // inserts (k,v) if k is absent; returns the slot's value pointer and whether it was inserted
-  std::pair<int32_t*, bool> emplace(uint64_t k, int32_t v) {
-    size_t i = hash(k) & mask_;
-    for (;; i = (i + 1) & mask_) {
-      if (keys_[i] == kEmpty) {
-        keys_[i] = k;
-        vals_[i] = v;
-        return {&vals_[i], true};
-      }
-      if (keys_[i] == k) return {&vals_[i], false};
-    }
-  }
-  const int32_t* find(uint64_t k) const {
-    size_t i = hash(k) & mask_;
-    for (;; i = (i + 1) & mask_) {
-      if (keys_[i] == kEmpty) return nullptr;
-      if (keys_[i] == k) return &vals_[i];
-    }
-  }
-
- private:
-  static constexpr uint64_t kEmpty = ~0ull;  // feature ids are non-negative int32: never a real key
-  static size_t hash(uint64_t z) {
-    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-    return (size_t)(z ^ (z >> 31));
-  }
-  size_t mask_;
-  std::vector<uint64_t> keys_;
-  std::vector<int32_t> vals_;
+// ---- uploading a topology ---------------------------------------------------------------------------------------------
+// The host computes only the per-vertex tables (nltgv2_pack.hpp with host_expand = false); every array goes through ONE
+// pinned staging buffer (the copies out of it are asynchronous and cost a few microseconds each; out of pageable memory
+// each of the ~35 copies of round 1 was a synchronous staging round trip); the per-slot and per-lane arrays are expanded
+// on the device (nltgv2_layout.hip).
+struct StageCopy {
+  DevBuf* b;
+  const void* src;
+  size_t bytes;
 };
+
+struct StageFill {
+  void* dst;
+  size_t bytes;
+  uint32_t word;
+};
+
+// All of `cp` through the pinned staging buffer as ONE host-to-device copy into a device-side blob, then one kernel that
+// distributes the pieces to their buffers and does the clears of `fills` (k_scatter).  The caller's arrays are free when
+// this returns (they were copied into the staging buffer); the staging buffer itself is reused by the next upload, which
+// synchronises the stream first.
+int staged_h2d(flame_nltgv2_ctx* ctx, const StageCopy* cp, size_t n, const StageFill* fills = nullptr, size_t n_fills = 0) {
+  size_t total = 0;
+  for (size_t i = 0; i < n; ++i) total += (cp[i].bytes + 255) & ~size_t(255);
+  if (total >= (size_t)0xffffff00u) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  if (total > ctx->stage_cap) {
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    ctx->h_stage = nullptr, ctx->stage_cap = 0;
+    const size_t want = total + total / 2;
+    if (hipHostMalloc(&ctx->h_stage, want, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(ctx, FLAME_NLTGV2_ERR_OOM);
+    }
+    ctx->stage_cap = want;
+  }
+  int rc = ensure(ctx, ctx->d_stage, ctx->stage_cap);
+  if (rc) return rc;
+  std::vector<ScatterTable> tables(1);
+  auto push = [&](const ScatterEntry& e) {
+    if (tables.back().n == kScatterMax) tables.emplace_back();
+    ScatterTable& t = tables.back();
+    t.e[t.n++] = e;
+  };
+  size_t off = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (cp[i].bytes == 0) continue;
+    std::memcpy(static_cast<char*>(ctx->h_stage) + off, cp[i].src, cp[i].bytes);
+    push(ScatterEntry{cp[i].b->p, (uint32_t)off, 0u, cp[i].bytes});
+    off += (cp[i].bytes + 255) & ~size_t(255);
+  }
+  for (size_t i = 0; i < n_fills; ++i)
+    if (fills[i].bytes) push(ScatterEntry{fills[i].dst, kScatterFill, fills[i].word, fills[i].bytes});
+  if (off) HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage.p, ctx->h_stage, off, hipMemcpyHostToDevice, ctx->stream));
+  for (const ScatterTable& t : tables) LAUNCHCHK(ctx, launch_scatter(t, ctx->d_stage.p, ctx->stream));
+  return 0;
+}
+
+// Layout + topology arrays of `g` (V, E, pos, src, dst) onto the device; the caller adds the state.  On return the
+// stream still holds the copies: the caller synchronises before the staging buffer or `g`'s arrays may change.
+int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const StageCopy* extra, size_t n_extra) {
+  const int32_t V = g->V, E = g->E;
+  int rc = build_layout(g, &ctx->L, /*host_expand=*/false);
+  if (rc) return fail(ctx, rc);
+  const PackedLayout& L = ctx->L;
+  const size_t n_slots = (size_t)(L.rows + kRowPad) * kWave;
+  if (n_slots > (size_t)0x7fffffff) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  const size_t n_packed = (size_t)L.n_slices * kWave;
+  const size_t lanes = (size_t)L.wg_count * kWave;
+  const size_t fV = sizeof(float) * (size_t)V, fE = sizeof(float) * (size_t)E, iV = sizeof(int32_t) * (size_t)V;
+  struct { DevBuf* b; size_t bytes; } req[] = {
+      {&ctx->pos, 2 * fV}, {&ctx->src, fE}, {&ctx->dst, fE},
+      {&ctx->row_ptr, sizeof(int32_t) * ((size_t)V + 1)}, {&ctx->half, 2 * fE},
+      {&ctx->slice_row, sizeof(int32_t) * ((size_t)L.n_slices + 1)}, {&ctx->perm, sizeof(int32_t) * n_packed},
+      {&ctx->pdeg, sizeof(int32_t) * n_packed}, {&ctx->iperm, iV}, {&ctx->order_m, iV}, {&ctx->rid_of, iV},
+      {&ctx->rec_nbr, sizeof(uint32_t) * n_slots}, {&ctx->rec_edge, sizeof(int32_t) * n_slots}, {&ctx->edge_src_slot, fE},
+      {&ctx->hrec, sizeof(int4) * n_slots}, {&ctx->hq, sizeof(float4) * n_slots},
+      {&ctx->vstate, sizeof(float4) * n_packed}, {&ctx->vaux, sizeof(float2) * n_packed},
+      {&ctx->hq_alt, sizeof(float4) * n_slots}, {&ctx->vstate_alt, sizeof(float4) * n_packed}, {&ctx->photo_err, fV},
+      {&ctx->bar0, sizeof(float4) * n_packed}, {&ctx->bar1, sizeof(float4) * n_packed},
+      {&ctx->vprev, sizeof(float4) * n_packed}, {&ctx->xbuf, kXbufBytesPerVertex * n_packed + 64},
+      {&ctx->abort_flag, sizeof(int)}, {&ctx->err, sizeof(int)}, {&ctx->cost_out, 2 * sizeof(float)},
+      {&ctx->wg_slot, sizeof(int32_t) * lanes}, {&ctx->wg_vid, sizeof(int32_t) * lanes}, {&ctx->wg_meta, sizeof(uint32_t) * lanes},
+      {&ctx->wg_nbr, sizeof(int32_t) * lanes}, {&ctx->wg_fetch, sizeof(int32_t) * lanes},
+      {&ctx->wg_info, sizeof(int32_t) * L.wg_info.size()}};
+  for (auto& r : req) {
+    rc = ensure(ctx, *r.b, r.bytes);
+    if (rc) return rc;
+  }
+  ctx->topo++;
+  ctx->he_built = ctx->tv_built = false;
+  drop_graphs(ctx);
+  refresh_args(ctx);
+
+  std::vector<StageCopy> cp = {
+      {&ctx->pos, g->pos, 2 * fV}, {&ctx->src, g->src, fE}, {&ctx->dst, g->dst, fE},
+      {&ctx->row_ptr, L.row_ptr.data(), sizeof(int32_t) * ((size_t)V + 1)}, {&ctx->half, L.half.data(), 2 * fE},
+      {&ctx->slice_row, L.slice_row.data(), sizeof(int32_t) * ((size_t)L.n_slices + 1)},
+      {&ctx->perm, L.perm.data(), sizeof(int32_t) * n_packed}, {&ctx->pdeg, L.pdeg.data(), sizeof(int32_t) * n_packed},
+      {&ctx->iperm, L.iperm.data(), iV}, {&ctx->order_m, L.order_m.data(), iV}, {&ctx->rid_of, L.rid_of.data(), iV},
+      {&ctx->wg_info, L.wg_info.data(), sizeof(int32_t) * L.wg_info.size()}};
+  cp.insert(cp.end(), extra, extra + n_extra);
+  const StageFill fills[] = {
+      {ctx->err.p, sizeof(int), 0u}, {ctx->abort_flag.p, sizeof(int), 0u}, {ctx->xbuf.p, kXbufBytesPerVertex * n_packed + 64, 0u},
+      // empty slots / padding vertices of the second copies: zero, as the packing kernels write them in the first
+      {ctx->hq_alt.p, sizeof(float4) * n_slots, 0u}, {ctx->vstate_alt.p, sizeof(float4) * n_packed, 0u},
+      // the spare rows behind the last slice: no edge, neighbour 0 (what the unrolled sweeps may read past a slice's end)
+      {(char*)ctx->rec_edge.p + sizeof(int32_t) * (size_t)L.rows * kWave, sizeof(int32_t) * kRowPad * kWave, 0xffffffffu},
+      {(char*)ctx->rec_nbr.p + sizeof(uint32_t) * (size_t)L.rows * kWave, sizeof(uint32_t) * kRowPad * kWave, 0u}};
+  rc = staged_h2d(ctx, cp.data(), cp.size(), fills, sizeof(fills) / sizeof(fills[0]));
+  if (rc) return rc;
+  LAUNCHCHK(ctx, launch_build_sell(ctx->c, ctx->f, (const int32_t*)ctx->iperm.p, ctx->stream));
+  if (L.wg_ok)
+    LAUNCHCHK(ctx, launch_build_patches(ctx->c, ctx->f, (const int32_t*)ctx->order_m.p, (const int32_t*)ctx->rid_of.p,
+                                        (const int32_t*)ctx->iperm.p, ctx->stream));
+  ctx->pending = flame_nltgv2_ctx::PendingRun{};
+  ctx->tag_next = 1;
+  ctx->static_stale = false;
+  ctx->h_src.assign(g->src, g->src + E);
+  ctx->h_dst.assign(g->dst, g->dst + E);
+  return 0;
+}
+
+// (C) / (D) rows: built and uploaded when the lane-per-half-edge / vertex-per-lane persistent form is first wanted for
+// the current topology (single frames run in the patch-per-wave form and never need them).
+int ensure_form_rows(flame_nltgv2_ctx* ctx, int form) {
+  PackedLayout& L = ctx->L;
+  if (form == 1 && !ctx->he_built) {
+    build_he_rows(&L);
+    struct { DevBuf* b; const void* src; size_t bytes; } cp[] = {
+        {&ctx->he_slot, L.he_slot.data(), sizeof(int32_t) * L.he_slot.size()}, {&ctx->he_vid, L.he_vid.data(), sizeof(int32_t) * L.he_vid.size()},
+        {&ctx->he_meta, L.he_meta.data(), sizeof(uint32_t) * L.he_meta.size()},
+        {&ctx->he_wave_chain, L.he_wave_chain.data(), sizeof(int32_t) * L.he_wave_chain.size()}};
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (a buffer may be reallocated)
+    for (auto& c : cp) {
+      int rc = ensure(ctx, *c.b, c.bytes);
+      if (!rc) rc = h2d(ctx, *c.b, c.src, c.bytes);
+      if (rc) return rc;
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->he_built = true;
+    refresh_args(ctx);
+  }
+  if (form == 2 && !ctx->tv_built) {
+    build_tv_rows(&L);
+    struct { DevBuf* b; const void* src; size_t bytes; } cp[] = {
+        {&ctx->tv_slot, L.tv_slot.data(), sizeof(int32_t) * L.tv_slot.size()}, {&ctx->tv_vid, L.tv_vid.data(), sizeof(int32_t) * L.tv_vid.size()},
+        {&ctx->tv_meta, L.tv_meta.data(), sizeof(uint32_t) * L.tv_meta.size()}, {&ctx->tv_wave, L.tv_wave.data(), sizeof(uint32_t) * L.tv_wave.size()}};
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& c : cp) {
+      int rc = ensure(ctx, *c.b, c.bytes);
+      if (!rc) rc = h2d(ctx, *c.b, c.src, c.bytes);
+      if (rc) return rc;
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->tv_built = true;
+    refresh_args(ctx);
+  }
+  return 0;
+}
+
+bool params_ok(const flame_nltgv2_params* p) { return p != nullptr; }
 
 }  // namespace
 
@@ -809,7 +986,10 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
               &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->xbuf, &ctx->abort_flag, &ctx->he_slot, &ctx->he_vid, &ctx->he_meta, &ctx->he_wave_chain, &ctx->tv_slot, &ctx->tv_vid, &ctx->tv_meta, &ctx->tv_wave, &ctx->err,
               &ctx->cost_out, &ctx->img_ref, &ctx->img_cmp, &ctx->photo_err, &ctx->r_tris, &ctx->r_valid, &ctx->r_keys,
               &ctx->r_img, &ctx->r_cov, &ctx->r_vtx, &ctx->r_val, &ctx->wg_slot, &ctx->wg_vid, &ctx->wg_meta, &ctx->wg_nbr,
-              &ctx->wg_fetch, &ctx->wg_info, &ctx->probe, &ctx->snap_hq, &ctx->snap_vstate, &ctx->snap_bar};
+              &ctx->wg_fetch, &ctx->wg_info, &ctx->probe, &ctx->snap_hq, &ctx->snap_vstate, &ctx->snap_bar, &ctx->iperm,
+              &ctx->order_m, &ctx->rid_of, &ctx->d_stage, &ctx->sync_init, &ctx->sync_vmap, &ctx->sync_emap, &ctx->sync_need};
+  for (auto& b : ctx->sp_v) ctx->all.push_back(&b);
+  for (auto& b : ctx->sp_q) ctx->all.push_back(&b);
   *out = ctx;
   return FLAME_NLTGV2_OK;
 }
@@ -823,6 +1003,7 @@ int flame_nltgv2_destroy(flame_nltgv2_ctx* ctx) {
     if (b->p) (void)hipFree(b->p);
   if (ctx->h_err) (void)hipHostFree(ctx->h_err);
   if (ctx->h_cost) (void)hipHostFree(ctx->h_cost);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -913,103 +1094,40 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
   ctx->have_graph = false;
   const bool trace = std::getenv("FLAME_NLTGV2_TRACE") != nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
-  rc = build_layout(g, &ctx->L);
-  if (rc) return fail(ctx, rc);
-  const auto t_packed = std::chrono::steady_clock::now();
-  const PackedLayout& L = ctx->L;
-  const size_t n_slots = (size_t)(L.rows + kRowPad) * kWave;
-  if (n_slots > (size_t)0x7fffffff) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-  const size_t n_packed = (size_t)L.n_slices * kWave;
-
-  // Make sure nothing in flight still uses buffers we may reallocate.
+  // Make sure nothing in flight still uses buffers we may reallocate (or the staging buffer).
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   const size_t fV = sizeof(float) * (size_t)V, fE = sizeof(float) * (size_t)E;
   struct { DevBuf* b; size_t bytes; } req[] = {
-      {&ctx->pos, 2 * fV}, {&ctx->x, fV}, {&ctx->w1, fV}, {&ctx->w2, fV}, {&ctx->xb, fV}, {&ctx->w1b, fV},
-      {&ctx->w2b, fV}, {&ctx->xp, fV}, {&ctx->w1p, fV}, {&ctx->w2p, fV}, {&ctx->data, fV}, {&ctx->weight, fV},
-      {&ctx->src, fE}, {&ctx->dst, fE}, {&ctx->alpha, fE}, {&ctx->beta, fE}, {&ctx->q1, fE}, {&ctx->q2, fE},
-      {&ctx->q3, fE}, {&ctx->row_ptr, sizeof(int32_t) * ((size_t)V + 1)}, {&ctx->half, 2 * fE},
-      {&ctx->slice_row, sizeof(int32_t) * ((size_t)L.n_slices + 1)}, {&ctx->perm, sizeof(int32_t) * n_packed},
-      {&ctx->pdeg, sizeof(int32_t) * n_packed}, {&ctx->rec_nbr, sizeof(uint32_t) * n_slots},
-      {&ctx->rec_edge, sizeof(int32_t) * n_slots}, {&ctx->edge_src_slot, fE},
-      {&ctx->hrec, sizeof(int4) * n_slots}, {&ctx->hq, sizeof(float4) * n_slots},
-      {&ctx->vstate, sizeof(float4) * n_packed}, {&ctx->vaux, sizeof(float2) * n_packed},
-      {&ctx->hq_alt, sizeof(float4) * n_slots}, {&ctx->vstate_alt, sizeof(float4) * n_packed}, {&ctx->photo_err, fV},
-      {&ctx->bar0, sizeof(float4) * n_packed}, {&ctx->bar1, sizeof(float4) * n_packed},
-      {&ctx->vprev, sizeof(float4) * n_packed}, {&ctx->xbuf, kXbufBytesPerVertex * n_packed + 64},
-      {&ctx->abort_flag, sizeof(int)}, {&ctx->he_slot, sizeof(int32_t) * L.he_slot.size()},
-      {&ctx->he_vid, sizeof(int32_t) * L.he_vid.size()}, {&ctx->he_meta, sizeof(uint32_t) * L.he_meta.size()},
-      {&ctx->he_wave_chain, sizeof(int32_t) * L.he_wave_chain.size()},
-      {&ctx->tv_slot, sizeof(int32_t) * L.tv_slot.size()}, {&ctx->tv_vid, sizeof(int32_t) * L.tv_vid.size()},
-      {&ctx->tv_meta, sizeof(uint32_t) * L.tv_meta.size()}, {&ctx->tv_wave, sizeof(uint32_t) * L.tv_wave.size()},
-      {&ctx->wg_slot, sizeof(int32_t) * L.wg_slot.size()}, {&ctx->wg_vid, sizeof(int32_t) * L.wg_vid.size()},
-      {&ctx->wg_meta, sizeof(uint32_t) * L.wg_meta.size()}, {&ctx->wg_nbr, sizeof(int32_t) * L.wg_nbr.size()},
-      {&ctx->wg_fetch, sizeof(int32_t) * L.wg_fetch.size()}, {&ctx->wg_info, sizeof(int32_t) * L.wg_info.size()},
-      {&ctx->err, sizeof(int)},
-      {&ctx->cost_out, 2 * sizeof(float)}};
+      {&ctx->x, fV}, {&ctx->w1, fV}, {&ctx->w2, fV}, {&ctx->xb, fV}, {&ctx->w1b, fV}, {&ctx->w2b, fV}, {&ctx->xp, fV},
+      {&ctx->w1p, fV}, {&ctx->w2p, fV}, {&ctx->data, fV}, {&ctx->weight, fV}, {&ctx->alpha, fE}, {&ctx->beta, fE},
+      {&ctx->q1, fE}, {&ctx->q2, fE}, {&ctx->q3, fE}};
   for (auto& r : req) {
     rc = ensure(ctx, *r.b, r.bytes);
     if (rc) return rc;
   }
-  ctx->topo++;
-  drop_graphs(ctx);
-  refresh_args(ctx);
-
-  rc = h2d(ctx, ctx->pos, g->pos, 2 * fV);
-  const struct { DevBuf* b; const void* src; size_t bytes; } cp[] = {
+  const StageCopy state[] = {
       {&ctx->x, g->x, fV}, {&ctx->w1, g->w1, fV}, {&ctx->w2, g->w2, fV}, {&ctx->xb, g->x_bar, fV},
       {&ctx->w1b, g->w1_bar, fV}, {&ctx->w2b, g->w2_bar, fV},
       {&ctx->xp, g->x_prev ? g->x_prev : g->x, fV}, {&ctx->w1p, g->w1_prev ? g->w1_prev : g->w1, fV},
       {&ctx->w2p, g->w2_prev ? g->w2_prev : g->w2, fV}, {&ctx->data, g->data_term, fV},
-      {&ctx->weight, g->data_weight, fV}, {&ctx->src, g->src, fE}, {&ctx->dst, g->dst, fE},
-      {&ctx->alpha, g->alpha, fE}, {&ctx->beta, g->beta, fE}, {&ctx->q1, g->q1, fE}, {&ctx->q2, g->q2, fE},
-      {&ctx->q3, g->q3, fE}, {&ctx->row_ptr, L.row_ptr.data(), sizeof(int32_t) * ((size_t)V + 1)},
-      {&ctx->half, L.half.data(), 2 * fE},
-      {&ctx->slice_row, L.slice_row.data(), sizeof(int32_t) * ((size_t)L.n_slices + 1)},
-      {&ctx->perm, L.perm.data(), sizeof(int32_t) * n_packed}, {&ctx->pdeg, L.pdeg.data(), sizeof(int32_t) * n_packed},
-      {&ctx->rec_nbr, L.rec_nbr.data(), sizeof(uint32_t) * n_slots},
-      {&ctx->rec_edge, L.rec_edge.data(), sizeof(int32_t) * n_slots},
-      {&ctx->edge_src_slot, L.edge_src_slot.data(), fE},
-      {&ctx->he_slot, L.he_slot.data(), sizeof(int32_t) * L.he_slot.size()},
-      {&ctx->he_vid, L.he_vid.data(), sizeof(int32_t) * L.he_vid.size()},
-      {&ctx->he_meta, L.he_meta.data(), sizeof(uint32_t) * L.he_meta.size()},
-      {&ctx->he_wave_chain, L.he_wave_chain.data(), sizeof(int32_t) * L.he_wave_chain.size()},
-      {&ctx->tv_slot, L.tv_slot.data(), sizeof(int32_t) * L.tv_slot.size()},
-      {&ctx->tv_vid, L.tv_vid.data(), sizeof(int32_t) * L.tv_vid.size()},
-      {&ctx->tv_meta, L.tv_meta.data(), sizeof(uint32_t) * L.tv_meta.size()},
-      {&ctx->tv_wave, L.tv_wave.data(), sizeof(uint32_t) * L.tv_wave.size()},
-      {&ctx->wg_slot, L.wg_slot.data(), sizeof(int32_t) * L.wg_slot.size()},
-      {&ctx->wg_vid, L.wg_vid.data(), sizeof(int32_t) * L.wg_vid.size()},
-      {&ctx->wg_meta, L.wg_meta.data(), sizeof(uint32_t) * L.wg_meta.size()},
-      {&ctx->wg_nbr, L.wg_nbr.data(), sizeof(int32_t) * L.wg_nbr.size()},
-      {&ctx->wg_fetch, L.wg_fetch.data(), sizeof(int32_t) * L.wg_fetch.size()},
-      {&ctx->wg_info, L.wg_info.data(), sizeof(int32_t) * L.wg_info.size()}};
-  for (auto& c : cp) {
-    if (rc) return rc;
-    rc = h2d(ctx, *c.b, c.src, c.bytes);
-  }
+      {&ctx->weight, g->data_weight, fV}, {&ctx->alpha, g->alpha, fE}, {&ctx->beta, g->beta, fE}, {&ctx->q1, g->q1, fE},
+      {&ctx->q2, g->q2, fE}, {&ctx->q3, g->q3, fE}};
+  rc = upload_topology(ctx, g, state, sizeof(state) / sizeof(state[0]));
   if (rc) return rc;
-  HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, sizeof(int), ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(ctx->abort_flag.p, 0, sizeof(int), ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(ctx->xbuf.p, 0, kXbufBytesPerVertex * n_packed + 64, ctx->stream));
-  // empty slots / padding vertices of the second copies: zero, as the packing kernels write them in the first
-  HIPCHK(ctx, hipMemsetAsync(ctx->hq_alt.p, 0, sizeof(float4) * n_slots, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(ctx->vstate_alt.p, 0, sizeof(float4) * n_packed, ctx->stream));
-  ctx->pending = flame_nltgv2_ctx::PendingRun{};
-  ctx->tag_next = 1;
-  ctx->static_stale = false;
+  const auto t_packed = std::chrono::steady_clock::now();
   LAUNCHCHK(ctx, launch_pack_static(ctx->c, ctx->f, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors / caller arrays may go away
+  // No wait here: the caller's arrays were copied into the staging buffer, the device work is ordered on the stream in
+  // front of whatever comes next (a run, an export), and the next upload synchronises before it reuses the staging buffer.
   if (trace) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const auto t_end = std::chrono::steady_clock::now();
-    std::fprintf(stderr, "[flame_nltgv2] upload_graph V=%d E=%d: host pack %.3f ms, alloc+copy+device pack %.3f ms\n", V, E,
+    std::fprintf(stderr, "[flame_nltgv2] upload_graph V=%d E=%d: host tables + enqueue %.3f ms, device %.3f ms\n", V, E,
                  std::chrono::duration<double, std::milli>(t_packed - t_begin).count(),
                  std::chrono::duration<double, std::milli>(t_end - t_packed).count());
   }
-  ctx->h_src.assign(g->src, g->src + E);
-  ctx->h_dst.assign(g->dst, g->dst + E);
   ctx->h_feat.resize((size_t)V);
   for (int32_t v = 0; v < V; ++v) ctx->h_feat[(size_t)v] = v;  // default feature id = vertex index
+  ctx->feat_map.reset();
   ctx->canon_valid = true;
   ctx->fused_valid = false;
   ctx->have_prev = false;
@@ -1046,45 +1164,32 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
 
   const bool trace = std::getenv("FLAME_NLTGV2_TRACE") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
-  // previous state -> host
-  const int32_t Vo = ctx->L.V, Eo = ctx->L.E;
-  std::vector<float> ox(Vo), ow1(Vo), ow2(Vo), oxb(Vo), ow1b(Vo), ow2b(Vo), oxp(Vo), ow1p(Vo), ow2p(Vo), oq1(Eo), oq2(Eo), oq3(Eo);
-  flame_nltgv2_graph old{};
-  old.x = ox.data(), old.w1 = ow1.data(), old.w2 = ow2.data();
-  old.x_bar = oxb.data(), old.w1_bar = ow1b.data(), old.w2_bar = ow2b.data();
-  old.x_prev = oxp.data(), old.w1_prev = ow1p.data(), old.w2_prev = ow2p.data();
-  old.q1 = oq1.data(), old.q2 = oq2.data(), old.q3 = oq3.data();
-  rc = flame_nltgv2_download_state(ctx, &old);
+  // The previous state stays on the device: the canonical arrays are brought up to date (a kernel, enqueued) while the
+  // host works out the index maps below.
+  rc = ensure_canon(ctx);
   if (rc) return rc;
-  const auto t1 = std::chrono::steady_clock::now();
+  const int32_t Vo = ctx->L.V, Eo = ctx->L.E;
 
   for (int32_t v = 0; v < V; ++v)
     if (in->feat_id[v] < 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-  FlatMap old_of_feat((size_t)Vo);
-  for (int32_t v = 0; v < Vo; ++v) old_of_feat.emplace((uint64_t)(uint32_t)ctx->h_feat[(size_t)v], v);
+  if (!ctx->feat_map) {  // (after an upload / set_feature_ids; otherwise the map the previous sync built)
+    ctx->feat_map.reset(new FlatMap((size_t)Vo));
+    for (int32_t v = 0; v < Vo; ++v) ctx->feat_map->emplace((uint64_t)(uint32_t)ctx->h_feat[(size_t)v], v);
+  }
+  const FlatMap& old_of_feat = *ctx->feat_map;
   auto key = [](int32_t a, int32_t b) {
     const uint32_t lo = (uint32_t)std::min(a, b), hi = (uint32_t)std::max(a, b);
     return ((uint64_t)hi << 32) | lo;
   };
 
-  // vertices
-  std::vector<float> x(V), w1(V, 0.f), w2(V, 0.f), xb(V), w1b(V, 0.f), w2b(V, 0.f), xp(V), w1p(V, 0.f), w2p(V, 0.f);
-  std::vector<int32_t> old_of_new((size_t)V, -1);  // new vertex -> its index in the previous graph
-  FlatMap seen((size_t)V);
+  // vertices: new vertex -> its index in the previous graph (-1: new)
+  std::vector<int32_t>& old_of_new = ctx->h_old_of_new;
+  old_of_new.assign((size_t)V, -1);
+  std::unique_ptr<FlatMap> seen(new FlatMap((size_t)V));  // ... and the next sync's old_of_feat
   for (int32_t v = 0; v < V; ++v) {
-    if (!seen.emplace((uint64_t)(uint32_t)in->feat_id[v], v).second) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // duplicate id
+    if (!seen->emplace((uint64_t)(uint32_t)in->feat_id[v], v).second) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // duplicate id
     const int32_t* it = old_of_feat.find((uint64_t)(uint32_t)in->feat_id[v]);
-    if (it) {
-      const int32_t o = *it;
-      old_of_new[(size_t)v] = o;
-      x[v] = ox[o], w1[v] = ow1[o], w2[v] = ow2[o];
-      xb[v] = oxb[o], w1b[v] = ow1b[o], w2b[v] = ow2b[o];
-      xp[v] = oxp[o], w1p[v] = ow1p[o], w2p[v] = ow2p[o];
-      if (in->check_sticky_obstacles && (x[v] - in->data_term[v] > in->sticky_threshold)) x[v] = in->data_term[v];
-    } else {
-      const float xi = in->init_x ? in->init_x[v] : in->data_term[v];
-      x[v] = xb[v] = xp[v] = xi;
-    }
+    if (it) old_of_new[(size_t)v] = *it;
   }
   // edges.  A surviving edge joins two surviving vertices: it is looked up in the previous graph's adjacency (the
   // host copy of the packed layout: ~6 incident edges per vertex, one cache line) instead of a hash table over all
@@ -1098,24 +1203,24 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
   int32_t n_keep = 0;
   const std::vector<int32_t>& orow = ctx->L.row_ptr;
   const std::vector<uint32_t>& ohalf = ctx->L.half;
+  const std::vector<int32_t>& onbr = ctx->L.half_nbr;
   for (int32_t k = 0; k < E; ++k) {
     const int32_t a = in->edges[2 * k], b = in->edges[2 * k + 1];
     if (a < 0 || a >= V || b < 0 || b >= V || a == b) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
     const int32_t oa = old_of_new[(size_t)a], ob = old_of_new[(size_t)b];
     int32_t e = -1;
+    bool same = true;  // the old edge runs oa -> ob
     if (oa >= 0 && ob >= 0) {
       for (int32_t h = orow[(size_t)oa]; h < orow[(size_t)oa + 1]; ++h) {
-        const int32_t cand = (int32_t)(ohalf[(size_t)h] & ~kRoleBit);
-        const int32_t other = ctx->h_src[(size_t)cand] == oa ? ctx->h_dst[(size_t)cand] : ctx->h_src[(size_t)cand];
-        if (other == ob) {
-          e = cand;  // the first (lowest id) of possible parallel edges, as boost::edge() on the list would find
+        if (onbr[(size_t)h] == ob) {
+          e = (int32_t)(ohalf[(size_t)h] & ~kRoleBit);  // the first (lowest id) of possible parallel edges, as
+          same = (ohalf[(size_t)h] & kRoleBit) == 0u;   // boost::edge() on the list would find
           break;
         }
       }
     }
     if (e >= 0) {
       if (keep_of_old[(size_t)e].a >= 0) continue;  // the same pair again: boost::edge() finds the edge, nothing is added
-      const bool same = ctx->h_src[(size_t)e] == oa;
       keep_of_old[(size_t)e] = Keep{same ? a : b, same ? b : a};
       ++n_keep;
     } else {
@@ -1130,46 +1235,83 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
     fresh.resize(n);
   }
   const int32_t En = (int32_t)((size_t)n_keep + fresh.size());
-  std::vector<int32_t> src(En), dst(En);
-  std::vector<float> alpha(En), beta(En, 1.0f), q1(En, 0.f), q2(En, 0.f), q3(En, 0.f);
+  std::vector<int32_t> src((size_t)En), dst((size_t)En);
+  std::vector<int32_t>& old_of_new_edge = ctx->h_old_of_new_edge;
+  old_of_new_edge.assign((size_t)En, -1);
   int32_t e = 0;
   for (int32_t o = 0; o < Eo; ++o) {
     const Keep& kp = keep_of_old[(size_t)o];
     if (kp.a < 0) continue;
-    src[e] = kp.a, dst[e] = kp.b;
-    q1[e] = oq1[o], q2[e] = oq2[o], q3[e] = oq3[o];
+    src[(size_t)e] = kp.a, dst[(size_t)e] = kp.b;
+    old_of_new_edge[(size_t)e] = o;
     ++e;
   }
   for (const auto& f : fresh) {
-    src[e] = f.first, dst[e] = f.second;
+    src[(size_t)e] = f.first, dst[(size_t)e] = f.second;
     ++e;
   }
-  for (int32_t k = 0; k < En; ++k) {  // flame.cc:2087-2103 (diff = u_ii - u_jj of the triangulator edge;
-    const float dx = in->pos[2 * src[k]] - in->pos[2 * dst[k]];  //  the squares make the sign irrelevant)
-    const float dy = in->pos[2 * src[k] + 1] - in->pos[2 * dst[k] + 1];
-    alpha[k] = 1.0f / std::sqrt(dx * dx + dy * dy);
-  }
+  const auto t1 = std::chrono::steady_clock::now();
 
-  const auto t2 = std::chrono::steady_clock::now();
+  // New topology + the frame's inputs up, state gathered on the device out of the previous arrays into spare ones,
+  // which then take their place.
+  ctx->have_graph = false;  // (until the new graph stands)
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // nothing in flight uses buffers that may be reallocated below
+  const size_t fV = sizeof(float) * (size_t)V, fE = sizeof(float) * (size_t)En;
+  DevBuf* cur_v[9] = {&ctx->x, &ctx->w1, &ctx->w2, &ctx->xb, &ctx->w1b, &ctx->w2b, &ctx->xp, &ctx->w1p, &ctx->w2p};
+  DevBuf* cur_q[3] = {&ctx->q1, &ctx->q2, &ctx->q3};
+  for (int i = 0; i < 9 && !rc; ++i) rc = ensure(ctx, ctx->sp_v[i], fV);
+  for (int i = 0; i < 3 && !rc; ++i) rc = ensure(ctx, ctx->sp_q[i], fE);
+  if (!rc) rc = ensure(ctx, ctx->data, fV);
+  if (!rc) rc = ensure(ctx, ctx->weight, fV);
+  if (!rc) rc = ensure(ctx, ctx->alpha, fE);
+  if (!rc) rc = ensure(ctx, ctx->beta, fE);
+  if (!rc) rc = ensure(ctx, ctx->sync_init, fV);
+  if (!rc) rc = ensure(ctx, ctx->sync_vmap, sizeof(int32_t) * (size_t)V);
+  if (!rc) rc = ensure(ctx, ctx->sync_emap, sizeof(int32_t) * (size_t)En);
+  if (!rc) rc = ensure(ctx, ctx->sync_need, (size_t)V);
+  if (rc) return rc;
   flame_nltgv2_graph g{};
   g.V = V, g.E = En;
   g.pos = const_cast<float*>(in->pos);
-  g.x = x.data(), g.w1 = w1.data(), g.w2 = w2.data();
-  g.x_bar = xb.data(), g.w1_bar = w1b.data(), g.w2_bar = w2b.data();
-  g.x_prev = xp.data(), g.w1_prev = w1p.data(), g.w2_prev = w2p.data();
-  g.data_term = const_cast<float*>(in->data_term), g.data_weight = const_cast<float*>(in->data_weight);
   g.src = src.data(), g.dst = dst.data();
-  g.alpha = alpha.data(), g.beta = beta.data();
-  g.q1 = q1.data(), g.q2 = q2.data(), g.q3 = q3.data();
-  rc = flame_nltgv2_upload_graph(ctx, &g);
+  const StageCopy extra[] = {
+      {&ctx->data, in->data_term, fV}, {&ctx->weight, in->data_weight, fV},
+      {&ctx->sync_init, in->init_x, in->init_x ? fV : 0},
+      {&ctx->sync_vmap, old_of_new.data(), sizeof(int32_t) * (size_t)V},
+      {&ctx->sync_emap, old_of_new_edge.data(), sizeof(int32_t) * (size_t)En}};
+  rc = upload_topology(ctx, &g, extra, sizeof(extra) / sizeof(extra[0]));
   if (rc) return rc;
-  if (trace) {
-    const auto t3 = std::chrono::steady_clock::now();
+  SyncArgs sa;
+  sa.V = V, sa.E = En;
+  sa.old_of_new = (const int32_t*)ctx->sync_vmap.p, sa.old_of_new_edge = (const int32_t*)ctx->sync_emap.p;
+  sa.data = (const float*)ctx->data.p, sa.weight = (const float*)ctx->weight.p;
+  sa.init_x = in->init_x ? (const float*)ctx->sync_init.p : nullptr;
+  sa.check_sticky = in->check_sticky_obstacles ? 1 : 0, sa.sticky_threshold = in->sticky_threshold;
+  sa.graph_scale = in->init_graph_scale;
+  for (int i = 0; i < 9; ++i) sa.o[i] = (const float*)cur_v[i]->p, sa.n[i] = (float*)ctx->sp_v[i].p;
+  for (int i = 0; i < 3; ++i) sa.oq[i] = (const float*)cur_q[i]->p, sa.nq[i] = (float*)ctx->sp_q[i].p;
+  sa.src = (const int32_t*)ctx->src.p, sa.dst = (const int32_t*)ctx->dst.p, sa.row_ptr = (const int32_t*)ctx->row_ptr.p;
+  sa.half = (const uint32_t*)ctx->half.p, sa.pos = (const float2*)ctx->pos.p;
+  sa.alpha = (float*)ctx->alpha.p, sa.beta = (float*)ctx->beta.p, sa.need_nbr = (uint8_t*)ctx->sync_need.p;
+  LAUNCHCHK(ctx, launch_sync_state(sa, ctx->stream));
+  for (int i = 0; i < 9; ++i) std::swap(*cur_v[i], ctx->sp_v[i]);
+  for (int i = 0; i < 3; ++i) std::swap(*cur_q[i], ctx->sp_q[i]);
+  refresh_args(ctx);
+  LAUNCHCHK(ctx, launch_pack_static(ctx->c, ctx->f, ctx->stream));
+  if (trace) {  // (no wait otherwise: see flame_nltgv2_upload_graph)
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const auto t2 = std::chrono::steady_clock::now();
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    std::fprintf(stderr, "[flame_nltgv2] sync_graph: download %.3f ms, remap %.3f ms, upload %.3f ms\n", ms(t0, t1), ms(t1, t2),
-                 ms(t2, t3));
+    std::fprintf(stderr, "[flame_nltgv2] sync_graph: index maps %.3f ms, tables + upload + device gather %.3f ms\n", ms(t0, t1), ms(t1, t2));
   }
   ctx->h_feat.assign(in->feat_id, in->feat_id + V);
+  ctx->feat_map = std::move(seen);
+  ctx->canon_valid = true;
+  ctx->fused_valid = false;
+  ctx->have_prev = false;
+  ctx->parity = 0;
+  ctx->have_graph = true;
+  ctx->last_error = 0;
   return FLAME_NLTGV2_OK;
 }
 
@@ -1226,6 +1368,7 @@ int flame_nltgv2_set_feature_ids(flame_nltgv2_ctx* ctx, const int32_t* feat_id) 
   for (int32_t v = 0; v < ctx->L.V; ++v)
     if (feat_id[v] < 0 || !seen.emplace((uint64_t)(uint32_t)feat_id[v], v).second) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
   ctx->h_feat.assign(feat_id, feat_id + ctx->L.V);
+  ctx->feat_map.reset();
   return FLAME_NLTGV2_OK;
 }
 
@@ -1597,8 +1740,13 @@ int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info) {
   std::snprintf(info->device_name, sizeof(info->device_name), "%s", ctx->prop.name);
   std::snprintf(info->gcn_arch, sizeof(info->gcn_arch), "%s", ctx->prop.gcnArchName);
   info->last_run_path = ctx->last_run_path;
-  info->he_waves = ctx->L.he_ok ? ctx->L.he_waves : 0;
+  info->he_waves = ctx->L.wg_ok ? ctx->L.wg_count : 0;  // (the same greedy walk as the patches)
+  if (ctx->have_graph && !ctx->tv_built) {  // the vertex-per-lane rows are built on demand; a caller sizing a batch asks here
+    ctx->L.tv_waves = 0;
+    build_tv_rows(&ctx->L);  // host table only; the upload happens when the form is first used
+  }
   info->tv_waves = ctx->L.tv_ok ? ctx->L.tv_waves : 0;
+  info->patches = ctx->L.wg_ok ? ctx->L.wg_count : 0;
   info->tv_wave_capacity = (ctx->opt_tv_lds ? kTvLdsWavesPerCu : kTvWavesPerCu) * ctx->prop.multiProcessorCount;
   info->last_run_groups = ctx->last_run_groups;
   info->timeouts_recovered = ctx->timeouts_recovered;
@@ -1623,6 +1771,51 @@ int flame_nltgv2_read_probe(flame_nltgv2_ctx* ctx, uint32_t* out, int64_t max_wo
     const int64_t n = std::min(have, max_words);
     if (n > 0) HIPCHK(ctx, hipMemcpy(out, ctx->probe.p, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
   }
+  return FLAME_NLTGV2_OK;
+}
+
+// The per-slot / per-lane layout arrays as the device expanded them (nltgv2_layout.hip) against the host builders of
+// nltgv2_pack.hpp on the same topology: number of differing words (0 = identical).
+int flame_nltgv2_layout_selftest(flame_nltgv2_ctx* ctx, int64_t* mismatches) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!mismatches) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  rc = ensure_canon(ctx);
+  if (rc) return rc;
+  const int32_t V = ctx->L.V, E = ctx->L.E;
+  std::vector<float> pos(2 * (size_t)V);
+  HIPCHK(ctx, hipMemcpyAsync(pos.data(), ctx->pos.p, sizeof(float) * pos.size(), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  flame_nltgv2_graph g{};
+  g.V = V, g.E = E, g.pos = pos.data(), g.src = ctx->h_src.data(), g.dst = ctx->h_dst.data();
+  PackedLayout H;
+  rc = build_layout(&g, &H, /*host_expand=*/true);
+  if (rc) return fail(ctx, rc);
+  int64_t bad = 0;
+  auto cmp = [&](const DevBuf& b, const void* host, size_t bytes) -> int {
+    if (bytes == 0) return 0;
+    std::vector<uint32_t> d(bytes / 4);
+    if (hipMemcpy(d.data(), b.p, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    const uint32_t* h = static_cast<const uint32_t*>(host);
+    for (size_t i = 0; i < d.size(); ++i) bad += d[i] != h[i];
+    return 0;
+  };
+  const PackedLayout& L = ctx->L;
+  bad += (H.rows != L.rows) + (H.n_slices != L.n_slices) + (H.wg_ok != L.wg_ok) + (H.wg_count != L.wg_count) +
+         (H.wg_lcap != L.wg_lcap) + (H.wg_slab_slots != L.wg_slab_slots);
+  if (bad == 0) {
+    const size_t n = (size_t)L.rows * kWave, lanes = (size_t)L.wg_count * kWave;
+    int e = cmp(ctx->rec_nbr, H.rec_nbr.data(), 4 * n) | cmp(ctx->rec_edge, H.rec_edge.data(), 4 * n) |
+            cmp(ctx->edge_src_slot, H.edge_src_slot.data(), 4 * (size_t)E) | cmp(ctx->perm, H.perm.data(), 4 * H.perm.size()) |
+            cmp(ctx->slice_row, H.slice_row.data(), 4 * H.slice_row.size());
+    if (L.wg_ok)
+      e |= cmp(ctx->wg_slot, H.wg_slot.data(), 4 * lanes) | cmp(ctx->wg_vid, H.wg_vid.data(), 4 * lanes) |
+           cmp(ctx->wg_meta, H.wg_meta.data(), 4 * lanes) | cmp(ctx->wg_nbr, H.wg_nbr.data(), 4 * lanes) |
+           cmp(ctx->wg_fetch, H.wg_fetch.data(), 4 * lanes) | cmp(ctx->wg_info, H.wg_info.data(), 4 * H.wg_info.size());
+    if (e) return fail(ctx, FLAME_NLTGV2_ERR_HIP);
+  }
+  *mismatches = bad;
   return FLAME_NLTGV2_OK;
 }
 

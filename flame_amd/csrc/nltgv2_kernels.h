@@ -111,7 +111,47 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
                           int parity_in, unsigned tag0, int n_iters, int waves_per_block, unsigned max_spins,
                           int presleep, int dual, int tv_static_in_lds, int xcds, const RunTail* tail, bool cooperative,
                           hipStream_t stream);
+// One upload blob -> its buffers (and clears), nltgv2_layout.hip
+constexpr uint32_t kScatterFill = 0xffffffffu;
+struct ScatterEntry {
+  void* dst;
+  uint32_t src_off;  // byte offset in the blob (16-byte aligned), or kScatterFill: fill with `fill`
+  uint32_t fill;
+  size_t bytes;
+};
+constexpr int kScatterMax = 48;
+struct ScatterTable {
+  int n = 0;
+  ScatterEntry e[kScatterMax];
+};
+int launch_scatter(const ScatterTable& t, const void* blob, hipStream_t s);
+// flame_nltgv2_sync_graph on the device: index maps in, state gathered from the previous arrays (o / oq) into new ones (n / nq)
+struct SyncArgs {
+  int V = 0, E = 0;
+  const int32_t* old_of_new = nullptr;       // [V] previous index of a surviving vertex, -1 new
+  const int32_t* old_of_new_edge = nullptr;  // [E] previous index of a surviving edge, -1 new
+  const float* data = nullptr;               // [V] new data terms, weights
+  const float* weight = nullptr;
+  const float* init_x = nullptr;             // [V] or nullptr
+  int check_sticky = 0;
+  float sticky_threshold = 0.0f;
+  float graph_scale = 0.0f;                  // > 0: a NaN init value is replaced by the neighbours' mean (flame.cc:2133-2158)
+  const float* o[9] = {};                    // previous x, w1, w2, x_bar, w1_bar, w2_bar, x_prev, w1_prev, w2_prev
+  float* n[9] = {};
+  const float* oq[3] = {};
+  float* nq[3] = {};
+  const int32_t *src = nullptr, *dst = nullptr, *row_ptr = nullptr;  // the NEW topology
+  const uint32_t* half = nullptr;
+  const float2* pos = nullptr;
+  float *alpha = nullptr, *beta = nullptr;
+  uint8_t* need_nbr = nullptr;               // [V] scratch
+};
+int launch_sync_state(const SyncArgs& a, hipStream_t s);
 int pv_patches_per_cu(const FusedArgs& a);
+// device-side expansion of the layout arrays (nltgv2_layout.hip)
+int launch_build_sell(const CanonArgs& c, const FusedArgs& a, const int32_t* iperm, hipStream_t s);
+int launch_build_patches(const CanonArgs& c, const FusedArgs& a, const int32_t* order_m, const int32_t* rid_of,
+                         const int32_t* iperm, hipStream_t s);
 int launch_save_prev(const CanonArgs& c, hipStream_t s);
 int launch_dual(const CanonArgs& c, const SolverParams& p, hipStream_t s);
 int launch_primal(const CanonArgs& c, const SolverParams& p, hipStream_t s);

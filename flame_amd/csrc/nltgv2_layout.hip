@@ -1,0 +1,329 @@
+// nltgv2_layout.hip -- the slot- and lane-level layout arrays of nltgv2_pack.hpp, expanded ON THE DEVICE.
+//
+// A topology change (upload_graph, sync_graph: every frame of the real pipeline, flame.cc:1985-2121) used to cost
+// ~1 ms of host packing and ~35 host-to-device copies.  What genuinely needs the host is per-VERTEX: the CSR of
+// incident half-edges in ascending edge id (A), the (component, Morton) order, the slice table of (B) and the greedy
+// patch walk of (E) -- a few tens of KB.  Everything per SLOT and per LANE (rec_nbr, rec_edge, edge_src_slot of (B);
+// wg_slot, wg_vid, wg_meta, wg_nbr, wg_fetch of (E): ~2 MB at 640x480) follows from those and is produced here, by the
+// same rules as the host builders in nltgv2_pack.hpp (which remain the reference: flame_nltgv2_layout_selftest and
+// tests/test_pack.py compare the two bit for bit).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nltgv2_kernels.h"
+
+namespace flame_hip {
+
+namespace {
+
+constexpr uint32_t kRole = 0x80000000u;
+constexpr uint32_t kWgTail = 1u << 24, kWgActive = 1u << 25, kWgValid = 1u << 26, kWgPublish = 1u << 27;
+
+// (B) body: one thread per packed vertex slot p = slice*64 + lane (padding lanes included): its column of the slice's
+// rows.  Row k of a real vertex = its k-th incident half-edge (ascending edge id, from the CSR); every other slot of the
+// slice is "empty": rec_edge -1, rec_nbr = the lane's own packed index (a harmless, in-range gather target).
+__global__ void __launch_bounds__(256)
+k_build_sell(const int n_packed, const int32_t* __restrict__ perm, const int32_t* __restrict__ slice_row,
+             const int32_t* __restrict__ row_ptr, const uint32_t* __restrict__ half, const int32_t* __restrict__ src,
+             const int32_t* __restrict__ dst, const int32_t* __restrict__ iperm, uint32_t* __restrict__ rec_nbr,
+             int32_t* __restrict__ rec_edge, int32_t* __restrict__ edge_src_slot) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_packed) return;
+  const int s = p >> 6, l = p & 63;
+  const int row0 = slice_row[s], row1 = slice_row[s + 1];
+  const int o = perm[p];
+  int base = 0, deg = 0;
+  if (o >= 0) {
+    base = row_ptr[o];
+    deg = row_ptr[o + 1] - base;
+  }
+  for (int r = row0; r < row1; ++r) {
+    const int k = r - row0;
+    const size_t slot = (size_t)r * 64 + l;
+    if (k < deg) {
+      const uint32_t h = half[base + k];
+      const int e = (int)(h & ~kRole);
+      const bool is_target = (h & kRole) != 0u;
+      const int other = is_target ? src[e] : dst[e];
+      rec_edge[slot] = e;
+      rec_nbr[slot] = (uint32_t)iperm[other] | (is_target ? kRole : 0u);
+      if (!is_target) edge_src_slot[e] = (int)slot;
+    } else {
+      rec_edge[slot] = -1;
+      rec_nbr[slot] = (uint32_t)p;
+    }
+  }
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int u = __shfl_up(v, d, 64);
+    if (lane >= d) v += u;
+  }
+  return v;
+}
+
+// (E) lanes: one wave per patch.  Host input per patch: wg_info[4p] = position in the walk of its first vertex (= first
+// record id), wg_info[4p+2] = its vertex count; order_m = the walk (caller's vertex ids), rid_of its inverse.
+// Output: the 64 lanes of the patch (wg_slot, wg_vid, wg_meta, wg_nbr), its fetch list (wg_fetch: the DISTINCT records
+// of other patches it reads, ascending) and wg_info[4p+1] = their number.
+__global__ void __launch_bounds__(64)
+k_build_patch(const int n_patches, int32_t* __restrict__ wg_info, const int32_t* __restrict__ order_m,
+              const int32_t* __restrict__ rid_of, const int32_t* __restrict__ iperm, const int32_t* __restrict__ slice_row,
+              const int32_t* __restrict__ row_ptr, const uint32_t* __restrict__ half, const int32_t* __restrict__ src,
+              const int32_t* __restrict__ dst, int32_t* __restrict__ wg_slot, int32_t* __restrict__ wg_vid,
+              uint32_t* __restrict__ wg_meta, int32_t* __restrict__ wg_nbr, int32_t* __restrict__ wg_fetch) {
+  __shared__ int s_first[64], s_o[64], s_vtx_of_lane[64], s_pub[64], s_list[64];
+  const int p = blockIdx.x;
+  if (p >= n_patches) return;
+  const int lane = threadIdx.x;
+  const int r0 = wg_info[4 * p], n_local = wg_info[4 * p + 2];
+  // vertex j of the patch -> its first lane (an isolated vertex still owns one lane)
+  int o = -1, deg = 0, need = 0;
+  if (lane < n_local) {
+    o = order_m[r0 + lane];
+    deg = row_ptr[o + 1] - row_ptr[o];
+    need = deg > 1 ? deg : 1;
+  }
+  const int first = wave_incl_scan(need, lane) - need;
+  s_vtx_of_lane[lane] = -1;
+  s_pub[lane] = 0;
+  __syncthreads();
+  if (lane < n_local) {
+    s_first[lane] = first, s_o[lane] = o;
+    for (int k = 0; k < need; ++k) s_vtx_of_lane[first + k] = lane;
+  }
+  __syncthreads();
+  // lane t of the patch
+  const int j = s_vtx_of_lane[lane];
+  int slot = -1, vid = -1, nbr = 0, cand = 0x7fffffff;
+  uint32_t meta = 0u;
+  if (j >= 0) {
+    const int oj = s_o[j], fj = s_first[j];
+    const int dj = row_ptr[oj + 1] - row_ptr[oj], needj = dj > 1 ? dj : 1;
+    const int k = lane - fj;
+    const int sp = iperm[oj];
+    vid = sp;
+    meta = (uint32_t)fj | ((uint32_t)dj << 6) | ((uint32_t)j << 13) | kWgValid;
+    if (k == needj - 1) meta |= kWgTail;
+    if (k < dj) {
+      meta |= kWgActive;
+      slot = (slice_row[sp >> 6] + k) * 64 + (sp & 63);
+      const uint32_t h = half[row_ptr[oj] + k];
+      const int e = (int)(h & ~kRole);
+      const int other = (h & kRole) ? src[e] : dst[e];
+      const int r = rid_of[other];
+      if (r >= r0 && r < r0 + n_local) {
+        nbr = r - r0;
+      } else {
+        cand = r;          // a record of another patch
+        s_pub[j] = 1;      // ... and that patch reads this vertex (the graph is undirected)
+      }
+    }
+  }
+  // the DISTINCT foreign records, ascending: bitonic sort of the 64 candidates, drop repeats, compact
+  int v = cand;
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int d = k >> 1; d > 0; d >>= 1) {
+      const int u = __shfl_xor(v, d, 64);
+      const bool up = (lane & k) == 0, lower = (lane & d) == 0;
+      v = (lower == up) ? (v < u ? v : u) : (v > u ? v : u);
+    }
+  }
+  const int prev = __shfl_up(v, 1, 64);
+  const bool keep = v != 0x7fffffff && (lane == 0 || v != prev);
+  const unsigned long long km = __ballot(keep);
+  const int rank = __popcll(km & ((1ull << lane) - 1ull));
+  const int n_fetch = __popcll(km);
+  if (keep) s_list[rank] = v;
+  __syncthreads();
+  const size_t hl = (size_t)p * 64 + lane;
+  wg_fetch[hl] = lane < n_fetch ? s_list[lane] : -1;
+  if (cand != 0x7fffffff) {  // index of this lane's record in the fetch list
+    int lo = 0, hi = n_fetch - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (s_list[mid] < cand) lo = mid + 1; else hi = mid;
+    }
+    nbr = (int)(0x80000000u | (unsigned)lo);
+  }
+  if (j >= 0 && s_pub[j]) meta |= kWgPublish;
+  wg_slot[hl] = slot, wg_vid[hl] = vid, wg_meta[hl] = meta, wg_nbr[hl] = nbr;
+  if (lane == 0) wg_info[4 * p + 1] = n_fetch;
+}
+
+inline dim3 grid1d(long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+
+}  // namespace
+
+int launch_build_sell(const CanonArgs& c, const FusedArgs& a, const int32_t* iperm, hipStream_t s) {
+  const int n_packed = a.n_slices * 64;
+  if (n_packed <= 0) return 0;
+  hipLaunchKernelGGL(k_build_sell, grid1d(n_packed), dim3(256), 0, s, n_packed, a.perm, a.slice_row, c.row_ptr, c.half,
+                     c.src, c.dst, iperm, a.rec_nbr, a.rec_edge, a.edge_src_slot);
+  return (int)hipGetLastError();
+}
+
+int launch_build_patches(const CanonArgs& c, const FusedArgs& a, const int32_t* order_m, const int32_t* rid_of,
+                         const int32_t* iperm, hipStream_t s) {
+  if (a.wg_count <= 0) return 0;
+  hipLaunchKernelGGL(k_build_patch, dim3((unsigned)a.wg_count), dim3(64), 0, s, a.wg_count, a.wg_info, order_m, rid_of, iperm,
+                     a.slice_row, c.row_ptr, c.half, c.src, c.dst, a.wg_slot, a.wg_vid, a.wg_meta, a.wg_nbr, a.wg_fetch);
+  return (int)hipGetLastError();
+}
+
+}  // namespace flame_hip
+
+// ---- one blob up, one kernel to distribute it -----------------------------------------------------------------------------
+// An upload is ~20 arrays of 30-200 KB; as separate host-to-device copies they cost ~7 us each on the stream (measured:
+// 18 copies = 131 us of a 250 us upload) and the clears ~4.6 us each.  They travel as ONE blob instead and this kernel
+// copies every piece to its buffer (and does the clears): blockIdx.y = table entry.
+namespace flame_hip {
+namespace {
+__global__ void __launch_bounds__(256) k_scatter(const ScatterTable t, const uint8_t* __restrict__ blob) {
+  const ScatterEntry e = t.e[blockIdx.y];
+  const size_t n16 = e.bytes >> 4;
+  uint4* __restrict__ d16 = static_cast<uint4*>(e.dst);
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e.src_off == kScatterFill) {
+    const uint4 v = make_uint4(e.fill, e.fill, e.fill, e.fill);
+    for (size_t i = i0; i < n16; i += stride) d16[i] = v;
+    uint32_t* d4 = static_cast<uint32_t*>(e.dst);
+    for (size_t i = (n16 << 2) + i0; i < (e.bytes >> 2); i += stride) d4[i] = e.fill;
+  } else {
+    const uint4* __restrict__ s16 = reinterpret_cast<const uint4*>(blob + e.src_off);
+    for (size_t i = i0; i < n16; i += stride) d16[i] = s16[i];
+    uint32_t* d4 = static_cast<uint32_t*>(e.dst);
+    const uint32_t* s4 = reinterpret_cast<const uint32_t*>(blob + e.src_off);
+    for (size_t i = (n16 << 2) + i0; i < (e.bytes >> 2); i += stride) d4[i] = s4[i];
+    // (every array here is a whole number of 32-bit words, except the byte tail handled by the first thread)
+    if (i0 == 0)
+      for (size_t b = e.bytes & ~size_t(3); b < e.bytes; ++b) static_cast<uint8_t*>(e.dst)[b] = blob[e.src_off + b];
+  }
+}
+}  // namespace
+
+int launch_scatter(const ScatterTable& t, const void* blob, hipStream_t s) {
+  if (t.n <= 0) return 0;
+  size_t mx = 0;
+  for (int i = 0; i < t.n; ++i) mx = t.e[i].bytes > mx ? t.e[i].bytes : mx;
+  unsigned gx = (unsigned)((mx / 16 + 4 * 256 - 1) / (4 * 256));  // ~4 vectors per thread of the largest entry
+  gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+  hipLaunchKernelGGL(k_scatter, dim3(gx, (unsigned)t.n), dim3(256), 0, s, t, static_cast<const uint8_t*>(blob));
+  return (int)hipGetLastError();
+}
+}  // namespace flame_hip
+
+// ---- per-frame graph synchronisation on the device (flame_nltgv2_sync_graph) --------------------------------------------
+// The host works out WHO survives (feature ids, edge identity and orientation: index maps only); the state moves here.
+namespace flame_hip {
+namespace {
+
+// Vertices, flame.cc:1996-2014, 2035-2048, 2160-2162: a survivor keeps (x, w, x_bar, w_bar, x_prev, w_prev), with the
+// sticky-obstacle reset of x; a new vertex starts at x = x_bar = x_prev = init (or its data term), w = 0.  need_nbr[v] = 1
+// marks a new vertex whose init value is NaN and is to be replaced by the mean of its neighbours (k_sync_init_from_neighbours).
+__global__ void __launch_bounds__(256)
+k_sync_vertices(const int V, const int32_t* __restrict__ old_of_new, const float* __restrict__ data, const float* __restrict__ init_x,
+                const int check_sticky, const float sticky_threshold, const int nbr_fallback, const float* __restrict__ ox,
+                const float* __restrict__ ow1, const float* __restrict__ ow2, const float* __restrict__ oxb,
+                const float* __restrict__ ow1b, const float* __restrict__ ow2b, const float* __restrict__ oxp,
+                const float* __restrict__ ow1p, const float* __restrict__ ow2p, float* __restrict__ x, float* __restrict__ w1,
+                float* __restrict__ w2, float* __restrict__ xb, float* __restrict__ w1b, float* __restrict__ w2b,
+                float* __restrict__ xp, float* __restrict__ w1p, float* __restrict__ w2p, uint8_t* __restrict__ need_nbr) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const int o = old_of_new[v];
+  uint8_t need = 0;
+  if (o >= 0) {
+    float xv = ox[o];
+    if (check_sticky && (xv - data[v] > sticky_threshold)) xv = data[v];
+    x[v] = xv, w1[v] = ow1[o], w2[v] = ow2[o];
+    xb[v] = oxb[o], w1b[v] = ow1b[o], w2b[v] = ow2b[o];
+    xp[v] = oxp[o], w1p[v] = ow1p[o], w2p[v] = ow2p[o];
+  } else {
+    float xi = init_x ? init_x[v] : data[v];
+    if (nbr_fallback && xi != xi) {
+      xi = data[v];  // what the vertex holds (flame.cc:2046-2048) while its neighbours' means are formed
+      need = 1;
+    }
+    x[v] = xb[v] = xp[v] = xi;
+    w1[v] = w2[v] = w1b[v] = w2b[v] = w1p[v] = w2p[v] = 0.0f;
+  }
+  need_nbr[v] = need;
+}
+
+// Edges, flame.cc:2085-2104: a surviving edge keeps its dual, a new one starts at q = 0; every edge gets
+// alpha = 1/||pos_a - pos_b|| from the NEW positions and beta = 1.
+__global__ void __launch_bounds__(256)
+k_sync_edges(const int E, const int32_t* __restrict__ old_of_new_edge, const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+             const float2* __restrict__ pos, const float* __restrict__ oq1, const float* __restrict__ oq2, const float* __restrict__ oq3,
+             float* __restrict__ q1, float* __restrict__ q2, float* __restrict__ q3, float* __restrict__ alpha, float* __restrict__ beta) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int o = old_of_new_edge[e];
+  q1[e] = o >= 0 ? oq1[o] : 0.0f;
+  q2[e] = o >= 0 ? oq2[o] : 0.0f;
+  q3[e] = o >= 0 ? oq3[o] : 0.0f;
+  const float2 a = pos[src[e]], b = pos[dst[e]];
+  const float dx = a.x - b.x, dy = a.y - b.y;
+  alpha[e] = 1.0f / sqrtf(dx * dx + dy * dy);  // (sqrtf: correctly rounded in this build; __fsqrt_rn is the raw v_sqrt_f32)
+  beta[e] = 1.0f;
+}
+
+// flame.cc:2133-2158 (init_with_prediction, no valid prediction): mean of x * graph_scale over the neighbours with
+// data_weight > 0, in ascending edge id (the reference walks a hash set: its order is unspecified); none -> data term.
+// The result goes to x_bar only; k_sync_init_commit copies it to x and x_prev -- so that every mean is formed from the
+// same, settled neighbour values.
+__global__ void __launch_bounds__(256)
+k_sync_init_from_neighbours(const int V, const uint8_t* __restrict__ need_nbr, const int32_t* __restrict__ row_ptr,
+                            const uint32_t* __restrict__ half, const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                            const float* __restrict__ weight, const float* __restrict__ x, const float* __restrict__ data,
+                            const float graph_scale, float* __restrict__ xb) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V || !need_nbr[v]) return;
+  float sum = 0.0f;
+  int count = 0;
+  for (int h = row_ptr[v]; h < row_ptr[v + 1]; ++h) {
+    const uint32_t he = half[h];
+    const int e = (int)(he & ~kRole);
+    const int nb = (he & kRole) ? src[e] : dst[e];
+    if (weight[nb] > 0.0f) {
+      sum += x[nb] * graph_scale;
+      ++count;
+    }
+  }
+  xb[v] = count > 0 ? (sum / (float)count) / graph_scale : data[v];
+}
+__global__ void __launch_bounds__(256)
+k_sync_init_commit(const int V, const uint8_t* __restrict__ need_nbr, float* __restrict__ x, const float* __restrict__ xb,
+                   float* __restrict__ xp) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V || !need_nbr[v]) return;
+  x[v] = xp[v] = xb[v];
+}
+
+}  // namespace
+
+int launch_sync_state(const SyncArgs& a, hipStream_t s) {
+  if (a.V > 0) {
+    hipLaunchKernelGGL(k_sync_vertices, grid1d(a.V), dim3(256), 0, s, a.V, a.old_of_new, a.data, a.init_x, a.check_sticky,
+                       a.sticky_threshold, a.graph_scale > 0.0f ? 1 : 0, a.o[0], a.o[1], a.o[2], a.o[3], a.o[4], a.o[5], a.o[6], a.o[7],
+                       a.o[8], a.n[0], a.n[1], a.n[2], a.n[3], a.n[4], a.n[5], a.n[6], a.n[7], a.n[8], a.need_nbr);
+  }
+  if (a.E > 0) {
+    hipLaunchKernelGGL(k_sync_edges, grid1d(a.E), dim3(256), 0, s, a.E, a.old_of_new_edge, a.src, a.dst, a.pos, a.oq[0], a.oq[1],
+                       a.oq[2], a.nq[0], a.nq[1], a.nq[2], a.alpha, a.beta);
+  }
+  if (a.V > 0 && a.graph_scale > 0.0f) {
+    hipLaunchKernelGGL(k_sync_init_from_neighbours, grid1d(a.V), dim3(256), 0, s, a.V, a.need_nbr, a.row_ptr, a.half, a.src, a.dst,
+                       a.weight, a.n[0], a.data, a.graph_scale, a.n[3]);
+    hipLaunchKernelGGL(k_sync_init_commit, grid1d(a.V), dim3(256), 0, s, a.V, a.need_nbr, a.n[0], a.n[3], a.n[6]);
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace flame_hip

@@ -46,6 +46,8 @@ constexpr uint32_t kRoleBit = 0x80000000u;  // set: the owning vertex is the TAR
 struct PackedLayout {
   int32_t V = 0, E = 0, n_slices = 0, max_degree = 0;
   int64_t rows = 0;                    // 64-wide rows actually used (excluding kRowPad)
+  std::vector<int32_t> order_m;        // [V] the vertices in (component, Morton) order: the walk of (C), (D), (E)
+  std::vector<int32_t> rid_of;         // [V] inverse of order_m: a vertex's position in the walk = its record id in (E)
   std::vector<int32_t> perm;           // [n_slices*64] packed slot -> original vertex (-1 padding)
   std::vector<int32_t> iperm;          // [V] original vertex -> packed slot
   std::vector<int32_t> pdeg;           // [n_slices*64] degree of packed vertex
@@ -55,6 +57,7 @@ struct PackedLayout {
   std::vector<int32_t> edge_src_slot;  // [E] slot of the source-side copy of edge e
   std::vector<int32_t> row_ptr;        // [V+1]  (A)
   std::vector<uint32_t> half;          // [2E]   (A) edge id | role bit, ascending edge id per vertex
+  std::vector<int32_t> half_nbr;       // [2E]   (A) the vertex at the other end of that half-edge (host only)
   // (C) wave-aligned half-edge rows of the persistent run: one LANE per half-edge, the lanes of a
   // vertex contiguous (ascending edge id) inside ONE wave; isolated vertices get one idle lane.
   bool he_ok = false;                  // false: some vertex has more than 64 incident edges
@@ -111,9 +114,121 @@ inline uint32_t morton_spread16(uint32_t v) {
 }
 
 // Returns FLAME_NLTGV2_OK or FLAME_NLTGV2_ERR_INVALID_ARG.
+// ---- (C): needs (B)'s header (iperm, pdeg, slice_row), comp_start and order_m.  Built on demand: only the lane-per-half-edge
+// persistent form reads it.
+inline void build_he_rows(PackedLayout* L) {
+  const int32_t V = L->V, maxdeg = L->max_degree;
+  const std::vector<int32_t>& order_m = L->order_m;
+  // ---- (C) wave-aligned half-edge rows -------------------------------------------------------------
+  L->he_ok = (maxdeg <= kWave);
+  L->he_waves = 0;
+  L->he_max_chain = 0;
+  L->he_slot.clear(), L->he_vid.clear(), L->he_meta.clear(), L->he_wave_chain.clear();
+  L->comp_he_wave.clear();
+  if (L->he_ok && V > 0) {
+    int32_t fill = kWave;  // forces a new wave for the first vertex
+    size_t next_comp = 0;
+    for (int32_t i = 0; i < V; ++i) {
+      const int32_t s = L->iperm[order_m[i]];  // packed index of the i-th vertex in Morton order
+      const int32_t d = L->pdeg[s];
+      const int32_t need = std::max(d, 1);
+      const bool comp_begin = next_comp < L->comp_start.size() && L->comp_start[next_comp] == i;
+      if (comp_begin) {
+        L->comp_he_wave.push_back(L->he_waves);
+        ++next_comp;
+      }
+      if (fill + need > kWave || comp_begin) {
+        L->he_slot.resize(L->he_slot.size() + kWave, -1);
+        L->he_vid.resize(L->he_vid.size() + kWave, -1);
+        L->he_meta.resize(L->he_meta.size() + kWave, 0u);
+        L->he_wave_chain.push_back(1);
+        L->he_waves++;
+        fill = 0;
+      }
+      const size_t base = static_cast<size_t>(L->he_waves - 1) * kWave + fill;
+      const int32_t tail_lane = fill + need - 1;
+      const int64_t row0 = L->slice_row[s / kWave];
+      for (int32_t k = 0; k < need; ++k) {
+        uint32_t m = static_cast<uint32_t>(k) | (static_cast<uint32_t>(tail_lane) << 6) | kHeValid;
+        if (k == need - 1) m |= kHeTail;
+        if (k < d) {
+          m |= kHeActive;
+          L->he_slot[base + k] = static_cast<int32_t>((row0 + k) * kWave + (s % kWave));
+        }
+        L->he_vid[base + k] = s;
+        L->he_meta[base + k] = m;
+      }
+      L->he_wave_chain.back() = std::max(L->he_wave_chain.back(), need);
+      L->he_max_chain = std::max(L->he_max_chain, need);
+      fill += need;
+    }
+    L->comp_he_wave.push_back(L->he_waves);
+  }
+
+}
+
+// ---- (D): as (C); only the vertex-per-lane persistent form reads it.
+inline void build_tv_rows(PackedLayout* L) {
+  const int32_t V = L->V, maxdeg = L->max_degree;
+  const std::vector<int32_t>& order_m = L->order_m;
+  // ---- (D) one-vertex-per-lane rows, kTvSlots register slots per lane ------------------------------
+  L->tv_ok = (maxdeg <= kTvSlots * kWave);
+  L->tv_waves = 0;
+  L->tv_slot.clear(), L->tv_vid.clear(), L->tv_meta.clear(), L->tv_wave.clear();
+  L->comp_tv_wave.clear();
+  if (L->tv_ok && V > 0) {
+    int32_t fill = kWave;
+    size_t next_comp = 0;
+    for (int32_t i = 0; i < V; ++i) {
+      const int32_t s = L->iperm[order_m[i]];
+      const int32_t d = L->pdeg[s];
+      const int32_t lanes = std::max(1, (d + kTvSlots - 1) / kTvSlots);
+      const bool comp_begin = next_comp < L->comp_start.size() && L->comp_start[next_comp] == i;
+      if (comp_begin) {
+        L->comp_tv_wave.push_back(L->tv_waves);
+        ++next_comp;
+      }
+      if (fill + lanes > kWave || comp_begin) {
+        L->tv_slot.resize(L->tv_slot.size() + static_cast<size_t>(kTvSlots) * kWave, -1);
+        L->tv_vid.resize(L->tv_vid.size() + kWave, -1);
+        L->tv_meta.resize(L->tv_meta.size() + kWave, 0u);
+        L->tv_wave.push_back(1u);
+        L->tv_waves++;
+        fill = 0;
+      }
+      const size_t w = static_cast<size_t>(L->tv_waves - 1);
+      const int64_t row0 = L->slice_row[s / kWave];
+      const int32_t owner_lane = fill + lanes - 1;
+      for (int32_t c = 0; c < lanes; ++c) {
+        const int32_t lane = fill + c;
+        const int32_t k0 = c * kTvSlots;
+        const int32_t ns = std::max(0, std::min(kTvSlots, d - k0));
+        uint32_t m = static_cast<uint32_t>(ns) | (static_cast<uint32_t>(c) << 4) |
+                     (static_cast<uint32_t>(owner_lane) << 10) | kTvValid;
+        if (c == lanes - 1) m |= kTvOwner;
+        L->tv_meta[w * kWave + lane] = m;
+        L->tv_vid[w * kWave + lane] = s;
+        for (int32_t k = 0; k < ns; ++k) {
+          L->tv_slot[(w * kTvSlots + k) * kWave + lane] =
+              static_cast<int32_t>((row0 + k0 + k) * kWave + (s % kWave));
+        }
+      }
+      uint32_t& wi = L->tv_wave[w];
+      const uint32_t passes = std::max<uint32_t>(wi & 0xffu, static_cast<uint32_t>(lanes));
+      uint32_t k_first = (wi >> 16) & 15u, k_later = (wi >> 20) & 15u;
+      k_first = std::max<uint32_t>(k_first, static_cast<uint32_t>(std::min(d, kTvSlots)));
+      if (lanes > 1) k_later = std::max<uint32_t>(k_later, lanes > 2 ? kTvSlots : static_cast<uint32_t>(d - kTvSlots));
+      wi = passes | ((passes > 1u || (wi & 0x100u)) ? 0x100u : 0u) | (k_first << 16) | (k_later << 20);
+      fill += lanes;
+    }
+    L->comp_tv_wave.push_back(L->tv_waves);
+  }
+}
+
 // ---- (E) patch-per-wave rows ------------------------------------------------------------------------
 // order_m = the vertices in (component, Morton) order; needs (B) (iperm, pdeg, slice_row, rec_nbr) and comp_start.
-inline void build_patch_rows(PackedLayout* L, const std::vector<int32_t>& order_m) {
+inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const std::vector<int32_t>& order_m, bool host_expand) {
+  (void)g;
   const int32_t V = L->V;
   constexpr int32_t T = kWave;
   L->wg_ok = false;
@@ -121,97 +236,102 @@ inline void build_patch_rows(PackedLayout* L, const std::vector<int32_t>& order_
   L->wg_slot.clear(), L->wg_vid.clear(), L->wg_meta.clear(), L->wg_nbr.clear(), L->wg_fetch.clear();
   L->wg_info.clear(), L->comp_wg.clear();
   if (L->max_degree > kWave || V <= 0) return;
-  const size_t n_packed = static_cast<size_t>(L->n_slices) * kWave;
-  std::vector<int32_t> v_wg(n_packed, -1), v_loc(n_packed, -1);
-  // pass 1: place the vertices (the greedy walk of (C): a vertex's lanes never straddle two waves, a component
-  // begins a new wave)
-  int32_t fill = kWave, n_local = 0, rid = 0, max_deg = 1;
+  L->wg_info.reserve(((static_cast<size_t>(2) * L->E + V) * 9 / 8 / T + L->comp_start.size() + 2) * 4);
+  // pass 1 (host, per vertex): the greedy walk of (C) -- a vertex's lanes never straddle two waves, a component begins a
+  // new wave.  A vertex's record id is its position in the walk (L->rid_of).  Per patch: first record id, vertex count,
+  // slab stride (its largest degree rounded up to 4, at least 8).
+  int32_t fill = kWave, n_local = 0, max_deg = 1;
   size_t next_comp = 0;
-  auto close_patch = [&]() {  // slab stride of the patch just filled: its largest degree rounded up to 4, at least 8
+  auto close_patch = [&]() {
     if (L->wg_count == 0) return;
     const int32_t stride = std::max(8, (max_deg + 3) & ~3);
     L->wg_info[static_cast<size_t>(L->wg_count - 1) * 4 + 3] = stride;
     L->wg_slab_slots = std::max(L->wg_slab_slots, (stride + 1) * n_local);  // (+1: the kernel pads a vertex's slab, see there)
   };
   for (int32_t i = 0; i < V; ++i) {
-    const int32_t s = L->iperm[order_m[i]];
-    const int32_t d = L->pdeg[s];
-    const int32_t need = std::max(d, 1);
+    const int32_t o = order_m[i];
+    const int32_t need = std::max(L->row_ptr[o + 1] - L->row_ptr[o], 1);
     const bool comp_begin = next_comp < L->comp_start.size() && L->comp_start[next_comp] == i;
     if (comp_begin) ++next_comp;
     if (comp_begin || fill + need > kWave) {
       close_patch();
       if (comp_begin) L->comp_wg.push_back(L->wg_count);
-      L->wg_slot.resize(L->wg_slot.size() + T, -1);
-      L->wg_vid.resize(L->wg_vid.size() + T, -1);
-      L->wg_meta.resize(L->wg_meta.size() + T, 0u);
-      L->wg_nbr.resize(L->wg_nbr.size() + T, 0);
-      L->wg_fetch.resize(L->wg_fetch.size() + T, -1);
       L->wg_info.resize(L->wg_info.size() + 4, 0);
-      L->wg_info[static_cast<size_t>(L->wg_count) * 4] = rid;
+      L->wg_info[static_cast<size_t>(L->wg_count) * 4] = i;
       L->wg_count++;
       fill = 0, n_local = 0, max_deg = 1;
     }
-    const int32_t wg = L->wg_count - 1;
-    const size_t base = static_cast<size_t>(wg) * T + fill;
-    const int64_t row0 = L->slice_row[s / kWave];
-    for (int32_t k = 0; k < need; ++k) {
-      uint32_t m = static_cast<uint32_t>(fill) | (static_cast<uint32_t>(d) << 6) | (static_cast<uint32_t>(n_local) << 13) |
-                   kWgValid;
-      if (k == need - 1) m |= kWgTail;
-      if (k < d) {
-        m |= kWgActive;
-        L->wg_slot[base + k] = static_cast<int32_t>((row0 + k) * kWave + (s % kWave));
-      }
-      L->wg_vid[base + k] = s;
-      L->wg_meta[base + k] = m;
-    }
     max_deg = std::max(max_deg, need);
-    v_wg[s] = wg, v_loc[s] = n_local;
-    L->wg_info[static_cast<size_t>(wg) * 4 + 2] = ++n_local;
+    L->wg_info[static_cast<size_t>(L->wg_count - 1) * 4 + 2] = ++n_local;
     L->wg_lcap = std::max(L->wg_lcap, n_local);
     fill += need;
-    ++rid;
   }
   close_patch();
   L->comp_wg.push_back(L->wg_count);
-  // pass 2: neighbours -- local index, or one fetch lane per distinct vertex of another patch (sorted by record id)
-  std::vector<int32_t> want;
-  for (int32_t wg = 0; wg < L->wg_count; ++wg) {
-    const size_t b = static_cast<size_t>(wg) * T;
-    want.clear();
-    for (int32_t t = 0; t < T; ++t) {
-      const int32_t slot = L->wg_slot[b + t];
-      if (slot < 0) continue;
-      const int32_t nb = static_cast<int32_t>(L->rec_nbr[slot] & ~kRoleBit);
-      if (v_wg[nb] != wg) want.push_back(L->wg_info[static_cast<size_t>(v_wg[nb]) * 4] + v_loc[nb]);
-    }
-    std::sort(want.begin(), want.end());
-    want.erase(std::unique(want.begin(), want.end()), want.end());
-    for (size_t i = 0; i < want.size(); ++i) L->wg_fetch[b + i] = want[i];
-    L->wg_info[static_cast<size_t>(wg) * 4 + 1] = static_cast<int32_t>(want.size());
-    L->wg_rcap = std::max(L->wg_rcap, static_cast<int32_t>(want.size()));
-    for (int32_t t = 0; t < T; ++t) {
-      const int32_t slot = L->wg_slot[b + t];
-      if (slot < 0) continue;
-      const int32_t nb = static_cast<int32_t>(L->rec_nbr[slot] & ~kRoleBit);
-      if (v_wg[nb] == wg) {
-        L->wg_nbr[b + t] = v_loc[nb];
-      } else {
-        const int32_t r = L->wg_info[static_cast<size_t>(v_wg[nb]) * 4] + v_loc[nb];
-        const int32_t fi = static_cast<int32_t>(std::lower_bound(want.begin(), want.end(), r) - want.begin());
-        L->wg_nbr[b + t] = static_cast<int32_t>(0x80000000u | static_cast<uint32_t>(fi));
-        // this lane's own vertex has a neighbour outside the patch: it publishes (mark all its lanes)
-        const int32_t first = static_cast<int32_t>(L->wg_meta[b + t] & 63u);
-        const int32_t need = std::max<int32_t>(1, static_cast<int32_t>((L->wg_meta[b + t] >> 6) & 127u));
-        for (int32_t k = 0; k < need; ++k) L->wg_meta[b + first + k] |= kWgPublish;
+  if (host_expand) {
+    // pass 2 (the device does this in k_build_patch, nltgv2_layout.hip): the 64 lanes of every patch and its fetch list.
+    // A neighbour is local iff its record id lies in the patch's range; the others are fetched -- one lane per DISTINCT
+    // record, sorted by record id.
+    const size_t lanes = static_cast<size_t>(L->wg_count) * T;
+    L->wg_slot.assign(lanes, -1), L->wg_vid.assign(lanes, -1), L->wg_meta.assign(lanes, 0u), L->wg_nbr.assign(lanes, 0);
+    L->wg_fetch.assign(lanes, -1);
+    const std::vector<int32_t>& rid_of = L->rid_of;
+    int32_t want[kWave];
+    for (int32_t wg = 0; wg < L->wg_count; ++wg) {
+      const size_t b = static_cast<size_t>(wg) * T;
+      const int32_t r0 = L->wg_info[static_cast<size_t>(wg) * 4], r1 = r0 + L->wg_info[static_cast<size_t>(wg) * 4 + 2];
+      int32_t n_want = 0;
+      for (int32_t i = r0; i < r1; ++i) {
+        const int32_t o = order_m[i];
+        for (int32_t h = L->row_ptr[o]; h < L->row_ptr[o + 1]; ++h) {
+          const int32_t r = rid_of[static_cast<size_t>(L->half_nbr[h])];
+          if (r < r0 || r >= r1) want[n_want++] = r;
+        }
+      }
+      std::sort(want, want + n_want);
+      n_want = static_cast<int32_t>(std::unique(want, want + n_want) - want);
+      for (int32_t k = 0; k < n_want; ++k) L->wg_fetch[b + k] = want[k];
+      L->wg_info[static_cast<size_t>(wg) * 4 + 1] = n_want;
+      L->wg_rcap = std::max(L->wg_rcap, n_want);
+      int32_t lane = 0;
+      for (int32_t i = r0; i < r1; ++i) {
+        const int32_t o = order_m[i];
+        const int32_t s = L->iperm[o];
+        const int32_t d = L->row_ptr[o + 1] - L->row_ptr[o], need = std::max(d, 1);
+        const int64_t row0 = L->slice_row[s / kWave];
+        bool publishes = false;
+        for (int32_t k = 0; k < need; ++k) {
+          uint32_t m = static_cast<uint32_t>(lane) | (static_cast<uint32_t>(d) << 6) | (static_cast<uint32_t>(i - r0) << 13) | kWgValid;
+          if (k == need - 1) m |= kWgTail;
+          if (k < d) {
+            m |= kWgActive;
+            L->wg_slot[b + lane + k] = static_cast<int32_t>((row0 + k) * kWave + (s % kWave));
+            const int32_t r = rid_of[static_cast<size_t>(L->half_nbr[L->row_ptr[o] + k])];
+            if (r >= r0 && r < r1) {
+              L->wg_nbr[b + lane + k] = r - r0;
+            } else {
+              const int32_t fi = static_cast<int32_t>(std::lower_bound(want, want + n_want, r) - want);
+              L->wg_nbr[b + lane + k] = static_cast<int32_t>(0x80000000u | static_cast<uint32_t>(fi));
+              publishes = true;  // a neighbour outside the patch reads this vertex
+            }
+          }
+          L->wg_vid[b + lane + k] = s;
+          L->wg_meta[b + lane + k] = m;
+        }
+        if (publishes)
+          for (int32_t k = 0; k < need; ++k) L->wg_meta[b + lane + k] |= kWgPublish;
+        lane += need;
       }
     }
   }
   L->wg_ok = true;  // (a patch has at most 64 half-edges, hence at most 64 distinct foreign records: one per lane)
 }
 
-inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
+// host_expand = false: only what needs the host (per-vertex tables: (A), the walk order, (B)'s slice table, (E)'s patch
+// walk); the per-slot / per-lane arrays of (B) and (E) are then produced on the device (nltgv2_layout.hip) and (C), (D)
+// on demand.  host_expand = true: everything here -- the reference the device expansion is checked against, and what the
+// CPU test-suite looks at.
+inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L, bool host_expand = true) {
   if (!g || g->V < 0 || g->E < 0) return FLAME_NLTGV2_ERR_INVALID_ARG;
   const int32_t V = g->V, E = g->E;
   if (V > 0 && !g->pos) return FLAME_NLTGV2_ERR_INVALID_ARG;
@@ -231,11 +351,15 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
   }
   for (int32_t v = 0; v < V; ++v) L->row_ptr[v + 1] += L->row_ptr[v];
   L->half.assign(static_cast<size_t>(2) * E, 0);
+  L->half_nbr.assign(static_cast<size_t>(2) * E, 0);
   {
     std::vector<int32_t> cur(L->row_ptr.begin(), L->row_ptr.end() - 1);
     for (int32_t k = 0; k < E; ++k) {
-      L->half[cur[g->src[k]]++] = static_cast<uint32_t>(k);
-      L->half[cur[g->dst[k]]++] = static_cast<uint32_t>(k) | kRoleBit;
+      const int32_t i = g->src[k], j = g->dst[k];
+      L->half_nbr[cur[i]] = j;
+      L->half[cur[i]++] = static_cast<uint32_t>(k);
+      L->half_nbr[cur[j]] = i;
+      L->half[cur[j]++] = static_cast<uint32_t>(k) | kRoleBit;
     }
   }
   int32_t maxdeg = 0;
@@ -302,7 +426,10 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
   // The persistent layouts (C)/(D) walk the vertices in this pure Morton order: a wave then holds a compact
   // patch, so its graph neighbours sit in few other waves (fewer producers to wait for, better L2 locality).
   // Only the SELL-64 slices of the per-step sweep want the degree-sorted order below (uniform slice widths).
-  const std::vector<int32_t> order_m(order);
+  L->order_m = order;
+  const std::vector<int32_t>& order_m = L->order_m;
+  L->rid_of.assign(static_cast<size_t>(V), 0);
+  for (int32_t i = 0; i < V; ++i) L->rid_of[static_cast<size_t>(order_m[i])] = i;
   auto degree = [&](int32_t v) { return L->row_ptr[v + 1] - L->row_ptr[v]; };
   // stable counting sort by descending degree inside windows that never straddle two components
   // (frames of a batch)
@@ -348,6 +475,8 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
   }
   L->rows = L->slice_row[n_slices];
   const size_t n_slots = static_cast<size_t>(L->rows + kRowPad) * kWave;
+  L->rec_edge.clear(), L->rec_nbr.clear(), L->edge_src_slot.clear();
+  if (host_expand) {  // (else: k_build_sell, nltgv2_layout.hip)
   L->rec_edge.assign(n_slots, -1);
   L->rec_nbr.assign(n_slots, 0);
   // empty slots point at a harmless, in-range vertex: the lane's own packed index where there is
@@ -376,108 +505,14 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L) {
       if (!is_target) L->edge_src_slot[e] = static_cast<int32_t>(slot);
     }
   }
+  }
 
   PROF_T(3);
-  // ---- (C) wave-aligned half-edge rows -------------------------------------------------------------
-  L->he_ok = (maxdeg <= kWave);
-  L->he_waves = 0;
-  L->he_max_chain = 0;
-  L->he_slot.clear(), L->he_vid.clear(), L->he_meta.clear(), L->he_wave_chain.clear();
-  L->comp_he_wave.clear(), L->comp_tv_wave.clear();
-  if (L->he_ok && V > 0) {
-    int32_t fill = kWave;  // forces a new wave for the first vertex
-    size_t next_comp = 0;
-    for (int32_t i = 0; i < V; ++i) {
-      const int32_t s = L->iperm[order_m[i]];  // packed index of the i-th vertex in Morton order
-      const int32_t d = L->pdeg[s];
-      const int32_t need = std::max(d, 1);
-      const bool comp_begin = next_comp < L->comp_start.size() && L->comp_start[next_comp] == i;
-      if (comp_begin) {
-        L->comp_he_wave.push_back(L->he_waves);
-        ++next_comp;
-      }
-      if (fill + need > kWave || comp_begin) {
-        L->he_slot.resize(L->he_slot.size() + kWave, -1);
-        L->he_vid.resize(L->he_vid.size() + kWave, -1);
-        L->he_meta.resize(L->he_meta.size() + kWave, 0u);
-        L->he_wave_chain.push_back(1);
-        L->he_waves++;
-        fill = 0;
-      }
-      const size_t base = static_cast<size_t>(L->he_waves - 1) * kWave + fill;
-      const int32_t tail_lane = fill + need - 1;
-      const int64_t row0 = L->slice_row[s / kWave];
-      for (int32_t k = 0; k < need; ++k) {
-        uint32_t m = static_cast<uint32_t>(k) | (static_cast<uint32_t>(tail_lane) << 6) | kHeValid;
-        if (k == need - 1) m |= kHeTail;
-        if (k < d) {
-          m |= kHeActive;
-          L->he_slot[base + k] = static_cast<int32_t>((row0 + k) * kWave + (s % kWave));
-        }
-        L->he_vid[base + k] = s;
-        L->he_meta[base + k] = m;
-      }
-      L->he_wave_chain.back() = std::max(L->he_wave_chain.back(), need);
-      L->he_max_chain = std::max(L->he_max_chain, need);
-      fill += need;
-    }
-    L->comp_he_wave.push_back(L->he_waves);
-  }
-
+  if (host_expand) build_he_rows(L);
   PROF_T(4);
-  // ---- (D) one-vertex-per-lane rows, kTvSlots register slots per lane ------------------------------
-  L->tv_ok = (maxdeg <= kTvSlots * kWave);
-  L->tv_waves = 0;
-  L->tv_slot.clear(), L->tv_vid.clear(), L->tv_meta.clear(), L->tv_wave.clear();
-  if (L->tv_ok && V > 0) {
-    int32_t fill = kWave;
-    size_t next_comp = 0;
-    for (int32_t i = 0; i < V; ++i) {
-      const int32_t s = L->iperm[order_m[i]];
-      const int32_t d = L->pdeg[s];
-      const int32_t lanes = std::max(1, (d + kTvSlots - 1) / kTvSlots);
-      const bool comp_begin = next_comp < L->comp_start.size() && L->comp_start[next_comp] == i;
-      if (comp_begin) {
-        L->comp_tv_wave.push_back(L->tv_waves);
-        ++next_comp;
-      }
-      if (fill + lanes > kWave || comp_begin) {
-        L->tv_slot.resize(L->tv_slot.size() + static_cast<size_t>(kTvSlots) * kWave, -1);
-        L->tv_vid.resize(L->tv_vid.size() + kWave, -1);
-        L->tv_meta.resize(L->tv_meta.size() + kWave, 0u);
-        L->tv_wave.push_back(1u);
-        L->tv_waves++;
-        fill = 0;
-      }
-      const size_t w = static_cast<size_t>(L->tv_waves - 1);
-      const int64_t row0 = L->slice_row[s / kWave];
-      const int32_t owner_lane = fill + lanes - 1;
-      for (int32_t c = 0; c < lanes; ++c) {
-        const int32_t lane = fill + c;
-        const int32_t k0 = c * kTvSlots;
-        const int32_t ns = std::max(0, std::min(kTvSlots, d - k0));
-        uint32_t m = static_cast<uint32_t>(ns) | (static_cast<uint32_t>(c) << 4) |
-                     (static_cast<uint32_t>(owner_lane) << 10) | kTvValid;
-        if (c == lanes - 1) m |= kTvOwner;
-        L->tv_meta[w * kWave + lane] = m;
-        L->tv_vid[w * kWave + lane] = s;
-        for (int32_t k = 0; k < ns; ++k) {
-          L->tv_slot[(w * kTvSlots + k) * kWave + lane] =
-              static_cast<int32_t>((row0 + k0 + k) * kWave + (s % kWave));
-        }
-      }
-      uint32_t& wi = L->tv_wave[w];
-      const uint32_t passes = std::max<uint32_t>(wi & 0xffu, static_cast<uint32_t>(lanes));
-      uint32_t k_first = (wi >> 16) & 15u, k_later = (wi >> 20) & 15u;
-      k_first = std::max<uint32_t>(k_first, static_cast<uint32_t>(std::min(d, kTvSlots)));
-      if (lanes > 1) k_later = std::max<uint32_t>(k_later, lanes > 2 ? kTvSlots : static_cast<uint32_t>(d - kTvSlots));
-      wi = passes | ((passes > 1u || (wi & 0x100u)) ? 0x100u : 0u) | (k_first << 16) | (k_later << 20);
-      fill += lanes;
-    }
-    L->comp_tv_wave.push_back(L->tv_waves);
-  }
+  if (host_expand) build_tv_rows(L);
   PROF_T(5);
-  build_patch_rows(L, order_m);
+  build_patch_rows(g, L, order_m, host_expand);
   PROF_T(6);
   return FLAME_NLTGV2_OK;
 }

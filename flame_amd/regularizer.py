@@ -63,7 +63,7 @@ class _Graph(C.Structure):
 class _SyncInput(C.Structure):
     _fields_ = [("V", C.c_int32), ("feat_id", _IP), ("pos", _FP), ("data_term", _FP), ("data_weight", _FP),
                 ("init_x", _FP), ("E", C.c_int32), ("edges", _IP), ("check_sticky_obstacles", C.c_int32),
-                ("sticky_threshold", C.c_float)]
+                ("sticky_threshold", C.c_float), ("init_graph_scale", C.c_float)]
 
 
 class _Projection(C.Structure):
@@ -79,7 +79,7 @@ class _Info(C.Structure):
         ("device_bytes", C.c_int64), ("algorithmic_bytes_per_iter", C.c_int64), ("compute_units", C.c_int32),
         ("device_name", C.c_char * 64), ("gcn_arch", C.c_char * 32), ("last_run_path", C.c_int32), ("he_waves", C.c_int32), ("tv_waves", C.c_int32),
         ("tv_wave_capacity", C.c_int32), ("last_run_groups", C.c_int32), ("timeouts_recovered", C.c_int32),
-        ("torn_records_detected", C.c_int32),
+        ("patches", C.c_int32), ("torn_records_detected", C.c_int32),
     ]
 
 
@@ -96,7 +96,7 @@ ABI_SYMBOLS = (
     "flame_nltgv2_costs", "flame_nltgv2_download_state", "flame_nltgv2_export_idepth_device",
     "flame_nltgv2_export_idepth_device_async", "flame_nltgv2_set_export_target",
     "flame_nltgv2_set_option", "flame_nltgv2_get_info", "flame_nltgv2_last_error", "flame_nltgv2_last_hip_error",
-    "flame_nltgv2_status_string", "flame_nltgv2_abi_version", "flame_nltgv2_pack_probe", "flame_nltgv2_read_probe",
+    "flame_nltgv2_status_string", "flame_nltgv2_abi_version", "flame_nltgv2_pack_probe", "flame_nltgv2_read_probe", "flame_nltgv2_layout_selftest",
     "flame_nltgv2_photo_set_images", "flame_nltgv2_photo_residual", "flame_nltgv2_photo_fuse",
     "flame_nltgv2_photo_residual_last", "flame_nltgv2_sync_graph",
     "flame_nltgv2_get_topology", "flame_nltgv2_set_feature_ids", "flame_nltgv2_interpolate_mesh",
@@ -145,6 +145,7 @@ def load_library():
         "flame_nltgv2_last_hip_error": (C.c_int, [ctx]),
         "flame_nltgv2_status_string": (C.c_char_p, [C.c_int]),
         "flame_nltgv2_abi_version": (C.c_int, []),
+        "flame_nltgv2_layout_selftest": (C.c_int, [ctx, C.POINTER(C.c_int64)]),
         "flame_nltgv2_pack_probe": (C.c_int, [GP, _IP, _IP, _IP, _IP, C.c_int64, C.POINTER(C.c_int64)]),
         "flame_nltgv2_read_probe": (C.c_int, [ctx, C.POINTER(C.c_uint32), C.c_int64, C.POINTER(C.c_int64)]),
         "flame_nltgv2_photo_set_images": (C.c_int, [ctx, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int]),
@@ -277,8 +278,11 @@ class Regularizer:
         self.V, self.E = int(g["V"]), int(g["E"])
 
     def sync_graph(self, feat_id, pos, data_term, data_weight, edges, init_x=None, check_sticky_obstacles=False,
-                   sticky_threshold=0.25):
-        """Per-frame warm-start synchronisation (Flame::syncGraph's graph edits, flame.cc:1985-2121)."""
+                   sticky_threshold=0.25, init_graph_scale=0.0):
+        """Per-frame warm-start synchronisation (Flame::syncGraph's graph edits, flame.cc:1985-2121).
+
+        init_graph_scale > 0: new vertices whose init_x is NaN start at their neighbours' mean
+        (init_with_prediction's fallback, flame.cc:2133-2158)."""
         V = int(len(feat_id))
         fid = _as(feat_id, np.int32, V, "feat_id")
         p = _as(pos, np.float32, 2 * V, "pos")
@@ -296,9 +300,16 @@ class Regularizer:
         si.edges = ed.ctypes.data_as(_IP)
         si.check_sticky_obstacles = 1 if check_sticky_obstacles else 0
         si.sticky_threshold = sticky_threshold
+        si.init_graph_scale = float(init_graph_scale)
         self._chk(self._L.flame_nltgv2_sync_graph(self._ctx, C.byref(si)), "sync_graph")
         info = self.info()
         self.V, self.E = info["V"], info["E"]
+
+    def layout_selftest(self) -> int:
+        """Words of the device-expanded layout arrays that differ from the host builders' (0 = identical)."""
+        n = C.c_int64(-1)
+        self._chk(self._L.flame_nltgv2_layout_selftest(self._ctx, C.byref(n)), "layout_selftest")
+        return int(n.value)
 
     def set_feature_ids(self, feat_id):
         fid = _as(feat_id, np.int32, self.V, "feat_id")

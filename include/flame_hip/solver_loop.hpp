@@ -15,7 +15,8 @@
 //
 // Locking: the caller's mutex protects the HOST graph exactly as in the reference; the loop takes it only to upload.  An
 // internal mutex serialises the calls into the (not thread-safe) device context: the loop holds it for one round of
-// `iters_per_round` iterations (~1.3 us each at 640x480), readBack() waits for that round at most.  Lock order is always
+// `iters_per_round` iterations (~1.3 us each at 640x480), readBack() waits for that round at most (the loop gives way to
+// a waiting caller before it takes the mutex again).  Lock order is always
 // caller's mutex, then the internal one.  A graph edited without markDirty() is not written to: readBack() compares vertex
 // and edge counts and the edit generation with what was uploaded and returns false instead.
 #ifndef FLAME_HIP_SOLVER_LOOP_HPP_
@@ -76,7 +77,7 @@ class SolverLoop {
   // false -- and leaves the graph alone -- when the device image is not of this graph (edited since the last upload, or
   // nothing uploaded yet).
   bool readBack() {
-    std::lock_guard<std::mutex> dev_lk(dev_mtx_);
+    CallerAccess dev_lk(this);
     uint64_t want;
     {
       std::lock_guard<std::mutex> lk(state_mtx_);
@@ -94,11 +95,27 @@ class SolverLoop {
     return error_;
   }
   void setParams(const Params& p) {
-    std::lock_guard<std::mutex> dev_lk(dev_mtx_);
+    CallerAccess dev_lk(this);
     params_ = p;
   }
 
  private:
+  // std::mutex is not fair: the loop re-takes dev_mtx_ microseconds after releasing it and a caller blocked on it can
+  // starve for seconds.  Callers announce themselves; the loop lets them pass before its next round.
+  struct CallerAccess {
+    explicit CallerAccess(SolverLoop* s) : s_(s) {
+      s_->callers_waiting_.fetch_add(1);
+      s_->dev_mtx_.lock();
+    }
+    ~CallerAccess() {
+      s_->dev_mtx_.unlock();
+      s_->callers_waiting_.fetch_sub(1);
+    }
+    SolverLoop* s_;
+  };
+  void give_way() const {
+    while (callers_waiting_.load() > 0 && !stop_.load()) std::this_thread::yield();
+  }
   void run() {
     int rounds_left = 0;
     try {
@@ -109,6 +126,7 @@ class SolverLoop {
           dirty = dirty_generation_;
         }
         bool have = false;
+        give_way();
         {
           std::lock_guard<std::mutex> dev_lk(dev_mtx_);
           have = dev_.generation() == dirty && uploaded_once_;
@@ -166,6 +184,7 @@ class SolverLoop {
   std::thread thread_;
   std::atomic<bool> stop_{false};
   std::atomic<uint64_t> iterations_{0}, uploads_{0};
+  std::atomic<int> callers_waiting_{0};
   uint64_t dirty_generation_ = 1;  // the graph as handed to the constructor is "edit 1": uploaded by the first round
   bool uploaded_once_ = false;
   std::string error_;

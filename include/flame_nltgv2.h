@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FLAME_NLTGV2_ABI_VERSION 1
+#define FLAME_NLTGV2_ABI_VERSION 2
 
 typedef struct flame_nltgv2_ctx flame_nltgv2_ctx;
 
@@ -117,6 +117,12 @@ typedef struct flame_nltgv2_sync_input {
   const int32_t* edges;     /* [2E] triangulator->edges(): pairs of indices into the new vertex list */
   int32_t check_sticky_obstacles; /* params.check_sticky_obstacles, flame.cc:2011 */
   float sticky_threshold;         /* 0.25f in the reference */
+  float init_graph_scale;         /* > 0: a NEW vertex whose init_x is NaN (no valid prediction) starts at the mean of
+                                   * x*scale over its neighbours with data_weight > 0, / scale -- all means formed from
+                                   * the neighbours' values as they stand after the vertex pass (survivors: their x; new:
+                                   * init_x, or data_term where that is NaN too), neighbours in ascending edge id --, or at
+                                   * data_term when it has none (init_with_prediction, flame.cc:2133-2158).  0: init_x is
+                                   * taken as it is. */
 } flame_nltgv2_sync_input;
 int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in);
 /* Declares the feature ids of the vertices of a graph brought in with flame_nltgv2_upload_graph (V ints,
@@ -301,6 +307,7 @@ typedef struct flame_nltgv2_info {
   int32_t tv_wave_capacity; /* vertex-per-lane waves the device keeps resident */
   int32_t last_run_groups;  /* persistent launches the last run was split into (groups of whole components) */
   int32_t timeouts_recovered; /* persistent runs whose wait expired: state rolled back, steps redone one launch per step */
+  int32_t patches;       /* waves (patches of ~10 vertices) of the patch-per-wave persistent form (0: not applicable) */
   int32_t torn_records_detected; /* persistent runs stopped by FLAME_NLTGV2_OPT_VERIFY_RECORDS (a record whose second
                                     read differed from the first): rolled back and redone the same way */
 } flame_nltgv2_info;
@@ -316,6 +323,9 @@ int flame_nltgv2_abi_version(void);
  * [patch][step][8] words; *n_words = words available.  Not part of the reference's surface. */
 int flame_nltgv2_read_probe(flame_nltgv2_ctx* ctx, uint32_t* out, int64_t max_words, int64_t* n_words);
 
+/* Test hook: the layout arrays the device expanded for the current topology (nltgv2_layout.hip) compared word for word
+ * with the host builders (nltgv2_pack.hpp); *mismatches = number of differing words. */
+int flame_nltgv2_layout_selftest(flame_nltgv2_ctx* ctx, int64_t* mismatches);
 /* Host-only packing probe (no device needed; used by the CPU test-suite): builds the packed
  * SELL-64 layout the fused sweep runs on and copies it out.  Any output pointer may be NULL.
  *   perm[n_slices*64]       packed slot -> original vertex id (-1 = padding lane)

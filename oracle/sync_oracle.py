@@ -43,7 +43,8 @@ class RefGraph:
         return None
 
 
-def sync(gr: RefGraph, feat_id, pos, data_term, data_weight, tri_edges, init_x=None, check_sticky=False, thr=0.25):
+def sync(gr: RefGraph, feat_id, pos, data_term, data_weight, tri_edges, init_x=None, check_sticky=False, thr=0.25,
+         init_graph_scale=0.0):
     feat_id = [int(f) for f in feat_id]
     idx = {f: i for i, f in enumerate(feat_id)}
     feats_to_update = set(feat_id)
@@ -94,11 +95,39 @@ def sync(gr: RefGraph, feat_id, pos, data_term, data_weight, tri_edges, init_x=N
         ed[2]["beta"] = F(1.0)
         ed[2]["valid"] = True
     gr.e = [ed for ed in gr.e if ed[2]["valid"]]
-    # ---- initial x of the new vertices (flame.cc:2123-2163, init_with_prediction handled by the caller)
+    # ---- initial x of the new vertices (flame.cc:2123-2163).  init_x = the caller's idepthmap lookup / graph_scale.
+    # With init_graph_scale > 0 a NaN entry falls back to the mean of the neighbours (flame.cc:2133-2158).  The reference
+    # walks feats_to_update (an unordered_set) and each vertex's adjacency (hash-set out edges) in unspecified order, so
+    # its result depends on the hash order when new vertices neighbour each other.  The order fixed here (and in
+    # k_sync_init_from_neighbours): first every vertex with a valid prediction takes it; then all the others form their
+    # means at once, from the values standing at that point (a new vertex without prediction stands at its data term,
+    # flame.cc:2046-2048), neighbours in ascending edge id.
+    need = []
     for f in new:
         i = idx[f]
         xi = F(data_term[i]) if init_x is None else F(init_x[i])
+        if init_graph_scale > 0 and np.isnan(xi):
+            need.append(f)
+            xi = F(data_term[i])
         gr.v[f]["x"] = gr.v[f]["x_bar"] = gr.v[f]["x_prev"] = xi
+    if need:
+        gs = F(init_graph_scale)
+        adj = {f: [] for f in need}
+        for ed in gr.e:  # ascending edge id
+            if ed[0] in adj:
+                adj[ed[0]].append(ed[1])
+            if ed[1] in adj:
+                adj[ed[1]].append(ed[0])
+        res = {}
+        for f in need:
+            s, cnt = F(0), 0
+            for nb in adj[f]:
+                if gr.v[nb]["data_weight"] > 0:
+                    s = F(s + F(gr.v[nb]["x"] * gs))
+                    cnt += 1
+            res[f] = F(F(s / F(cnt)) / gs) if cnt > 0 else F(gr.v[f]["data_term"])
+        for f in need:
+            gr.v[f]["x"] = gr.v[f]["x_bar"] = gr.v[f]["x_prev"] = res[f]
     return gr
 
 

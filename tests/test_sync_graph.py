@@ -66,9 +66,15 @@ def test_frame_sequence_matches_syncgraph_restatement(built):
                 edges = edges[:, ::-1].copy()  # the triangulator's orientation is arbitrary; survivors keep theirs
             init_x = (data * np.float32(1.02)).astype(np.float32)
             sticky = frame >= 2
+            gs = 0.0
+            if frame % 2:  # no valid prediction for a third of the vertices: neighbours' mean (flame.cc:2133-2158)
+                init_x[rng.random(len(feat_id)) < 0.33] = np.nan
+                weight[rng.random(len(feat_id)) < 0.1] = 0.0  # ... over the neighbours with a data weight
+                gs = 1.7
             reg.sync_graph(feat_id, pos, data, weight, edges, init_x=init_x, check_sticky_obstacles=sticky,
-                           sticky_threshold=0.02)
-            sync_oracle.sync(ref, feat_id, pos, data, weight, edges, init_x=init_x, check_sticky=sticky, thr=0.02)
+                           sticky_threshold=0.02, init_graph_scale=gs)
+            sync_oracle.sync(ref, feat_id, pos, data, weight, edges, init_x=init_x, check_sticky=sticky, thr=0.02,
+                             init_graph_scale=gs)
         flat = sync_oracle.flatten(ref, feat_id)
         assert_state_equal(reg.download_state(), flat, keys=OUT_KEYS + ("x_prev",), what="after last sync")
 
@@ -88,3 +94,24 @@ def test_sync_rejects_bad_input(built):
         with pytest.raises(flame_amd.NLTGV2Error):
             reg.sync_graph(np.arange(g["V"], dtype=np.int32), g["pos"], g["data_term"], g["data_weight"],
                            np.array([[0, g["V"]]], np.int32))
+
+
+@pytest.mark.parametrize("config", ["320x240", "640x480", "1280x720", "1920x1080"])
+def test_device_expanded_layout_matches_host_builders(built, config):
+    """Per-slot (B) and per-lane (E) layout arrays are expanded on the device (nltgv2_layout.hip): word for word what the
+    host builders of nltgv2_pack.hpp make of the same topology -- after an upload and after a frame sync."""
+    import torch  # noqa: F401
+
+    import flame_amd
+
+    g = synth.make_graph(config, seed=3)
+    with flame_amd.Regularizer(0) as reg:
+        reg.upload_graph(g)
+        assert reg.layout_selftest() == 0
+        rng = np.random.default_rng(5)
+        w, h = (int(s) for s in config.split("x"))
+        fid, pos, data, _ = next_frame(rng, np.arange(g["V"], dtype=np.int32), g["pos"].copy(), g["data_term"].copy(), g["V"], w, h)
+        reg.sync_graph(fid, pos, data, np.ones(len(fid), np.float32), synth.delaunay_edges_scipy(pos))
+        assert reg.layout_selftest() == 0
+        reg.run(flame_amd.Params(), 16)
+        assert reg.layout_selftest() == 0
