@@ -23,70 +23,6 @@
 namespace flame_hip {
 namespace {
 
-struct V2 {
-  float x, y;
-};
-struct V3 {
-  float x, y, z;
-};
-
-// ---- Eigen semantics (Quaternionf * Vector3f, toRotationMatrix, fixed 3x3 products) ------------------------
-__device__ __forceinline__ V3 rotate(const float* q, V3 v) {  // q = (w, x, y, z); Eigen _transformVector
-  const float w = q[0];
-  const V3 u = {q[1], q[2], q[3]};
-  V3 uv = {u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
-  uv.x += uv.x;
-  uv.y += uv.y;
-  uv.z += uv.z;
-  const V3 c = {u.y * uv.z - u.z * uv.y, u.z * uv.x - u.x * uv.z, u.x * uv.y - u.y * uv.x};
-  return {(v.x + w * uv.x) + c.x, (v.y + w * uv.y) + c.y, (v.z + w * uv.z) + c.z};
-}
-
-struct Geo {           // EpipolarGeometry<float> after loadGeometry (epipolar_geometry.h:84-102)
-  float q[4];          // q_ref_to_cmp
-  V3 t;                // t_ref_to_cmp
-  V3 tcr;              // t_cmp_to_ref
-  float M[9];          // KRKinv
-  V3 Kt;
-  V2 epipole;
-};
-
-__device__ __forceinline__ void mul3(const float* a, const float* b, float* c) {
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) c[3 * i + j] = (a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j]) + a[3 * i + 2] * b[6 + j];
-}
-
-__device__ void load_geometry(Geo& g, const StereoCamera& cam, const float* q, const float* t) {
-  g.q[0] = q[0], g.q[1] = q[1], g.q[2] = q[2], g.q[3] = q[3];
-  g.t = {t[0], t[1], t[2]};
-  const float w = q[0], x = q[1], y = q[2], z = q[3];
-  // Quaternion::inverse(): conjugate / squaredNorm (packet reduction order of the 4 coefficients x,y,z,w)
-  const float n2 = (x * x + z * z) + (y * y + w * w);
-  float qi[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  if (n2 > 0.0f) qi[0] = w / n2, qi[1] = -x / n2, qi[2] = -y / n2, qi[3] = -z / n2;
-  const V3 r = rotate(qi, g.t);
-  g.tcr = {-r.x, -r.y, -r.z};
-  const float tx = 2.0f * x, ty = 2.0f * y, tz = 2.0f * z;
-  const float twx = tx * w, twy = ty * w, twz = tz * w;
-  const float txx = tx * x, txy = ty * x, txz = tz * x;
-  const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
-  const float R[9] = {1.0f - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1.0f - (txx + tzz),
-                      tyz - twx,          txz - twy, tyz + twx, 1.0f - (txx + tyy)};
-  float KR[9];
-  mul3(cam.K, R, KR);
-  mul3(KR, cam.Kinv, g.M);
-  g.Kt.x = (cam.K[0] * t[0] + cam.K[1] * t[1]) + cam.K[2] * t[2];
-  g.Kt.y = (cam.K[3] * t[0] + cam.K[4] * t[1]) + cam.K[5] * t[2];
-  g.Kt.z = (cam.K[6] * t[0] + cam.K[7] * t[1]) + cam.K[8] * t[2];
-  g.epipole = {0.0f, 0.0f};
-  if (t[2] > 0) {
-    g.epipole.x = (cam.K[0] * t[0] + cam.K[2] * t[2]) / t[2];
-    g.epipole.y = (cam.K[4] * t[1] + cam.K[5] * t[2]) / t[2];
-  }
-}
-
 __device__ __forceinline__ V2 max_depth_projection(const Geo& g, V2 u) {  // h:191-201
   const float h0 = (g.M[0] * u.x + g.M[1] * u.y) + g.M[2] * 1.0f;
   const float h1 = (g.M[3] * u.x + g.M[4] * u.y) + g.M[5] * 1.0f;
@@ -412,31 +348,220 @@ __device__ int line_match(const StereoParams& P, float rescale_factor, const flo
   return 0;
 }
 
+// ---- line_stereo::match, 16 lanes per feature ------------------------------------------------------------------------
+// The walk along the epipolar segment is a chain of ~33 dependent bilinear samples for one lane.  Here the 16 lanes of a
+// DPP row share one feature: lane k of round r owns step t = 16 r + k.  What makes the reference's loop sequential is
+//   * the position  cp_t = cp_{t-1} + inc  (a rounded float accumulation: no closed form) -- reproduced by a 16-step
+//     shift-and-add across the row (v_add_f32 with a row_shr:1 operand; lane 0 picks up lane 15 of the round before);
+//   * the sliding sample window -- every sample has ONE position whichever step reads it (the leading sample of step t
+//     at cp_t + 2 inc, the first four at cp_0 + {-2,-1,0,1} inc), so lane k computes the leading sample of its own step
+//     and reads the other five of its window from its neighbours' registers (row_shr / row_ror);
+//   * the best / second-best bookkeeping -- which is "the two smallest (cost, step) pairs in lexicographic order" with
+//     the costs of the steps next to the best one: every lane keeps that for its own steps, one row reduction at the end.
+// Same values, same expression order per value as line_match above: bit-identical results.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float old, float src) {  // lanes without a source in the row keep `old`
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int old, int src) {
+  return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xf, 0xf, false);
+}
+constexpr int kRowShl = 0x100, kRowShr = 0x110, kRowRor = 0x120;
+
+// positions of one round: on entry (x, y) of lane 0 is the round's first position; after the call lane k holds that
+// plus k sequentially rounded additions of (incx, incy)
+__device__ __forceinline__ void row_position_chain(float& x, float& y, float incx, float incy, int k) {
+  const float ax = k ? incx : 0.0f, ay = k ? incy : 0.0f;  // lane 0: + 0.0f keeps its (positive) value
+#pragma unroll
+  for (int i = 1; i < 16; ++i) {
+    x = dpp_mov<kRowShr + 1>(x, x) + ax;
+    y = dpp_mov<kRowShr + 1>(y, y) + ay;
+  }
+}
+
+// lexicographic (value, index) minimum over the 16 lanes of the row, result in every lane
+__device__ __forceinline__ void row_min_pair(float& v, int& i) {
+#define FLAME_ROW_MIN_STEP(N)                                        \
+  {                                                                  \
+    const float ov = dpp_mov<kRowRor + N>(v, v);                     \
+    const int oi = dpp_mov<kRowRor + N>(i, i);                       \
+    const bool take = (ov < v) || (ov == v && oi < i);               \
+    v = take ? ov : v, i = take ? oi : i;                            \
+  }
+  FLAME_ROW_MIN_STEP(8) FLAME_ROW_MIN_STEP(4) FLAME_ROW_MIN_STEP(2) FLAME_ROW_MIN_STEP(1)
+#undef FLAME_ROW_MIN_STEP
+}
+
+__device__ __forceinline__ uint32_t row_ballot(bool pred, int lane) {
+  return (uint32_t)(__ballot(pred) >> (lane & 48)) & 0xffffu;
+}
+
+__device__ int line_match_row(const StereoParams& P, float rescale_factor, const float (&ref)[5],
+                              const uint8_t* __restrict__ img, int rows, int cols, V2 start, V2 end, int lane, V2* match) {
+  const int k = lane & 15;
+  float incx = end.x - start.x, incy = end.y - start.y;
+  const float epl = sqrtf(incx * incx + incy * incy);
+  incx *= P.sample_dist / epl;
+  incy *= P.sample_dist / epl;
+  const float inc2x = 2 * incx, inc2y = 2 * incy;
+  const float qnan = __builtin_nanf("");
+  const float fmax = 3.402823466e+38f;
+  // the four samples behind the first leading one live in lanes 12..15 of the "previous round" Z (m2, m1, centre, p1);
+  // lane 11 is the residual the reference has not computed yet at step 0 (NaN)
+  float Z = qnan;
+  {
+    const float px = (k == 12) ? start.x - 2.0f * incx : (k == 13) ? start.x - incx : (k == 14) ? start.x : start.x + incx;
+    const float py = (k == 12) ? start.y - 2.0f * incy : (k == 13) ? start.y - incy : (k == 14) ? start.y : start.y + incy;
+    const bool ok = sample_ok(rows, cols, px, py);
+    if (row_ballot(k >= 12 && !ok, lane)) return -1;
+    if (k >= 12) Z = bilinear<uint8_t>(img, cols, px, py);
+  }
+  auto keeps_going = [&](float x, float y) { return ((incx < 0) == (x > end.x)) && ((incy < 0) == (y > end.y)); };
+  auto lead_sample = [&](float x, float y, bool* ok) {
+    const float lx = x + inc2x, ly = y + inc2y;
+    *ok = sample_ok(rows, cols, lx, ly);
+    return bilinear<uint8_t>(img, cols, *ok ? lx : 0.0f, *ok ? ly : 0.0f);
+  };
+  // round 0: positions, loop condition, leading samples
+  float ax = start.x, ay = start.y;
+  row_position_chain(ax, ay, incx, incy, k);
+  bool okA;
+  float A = lead_sample(ax, ay, &okA);
+  uint32_t goA = row_ballot(keeps_going(ax, ay) || k == 0, lane);  // (`|| loop == 0`)
+  float lb = fmax, ls = fmax;            // this lane's best and second-best cost over its own steps
+  int lb_i = 0x7fffffff, ls_i = 0x7fffffff;
+  float c_pre = -1, c_dpre = qnan, c_post = -1, c_dpost = -1, c_x = -1, c_y = -1;  // ... and what goes with its best
+  for (int base = 0;; base += 16) {
+    // the next round, one ahead: lane 15's step is followed by its lane 0
+    float bx = dpp_mov<kRowRor + 1>(ax, ax) + incx, by = dpp_mov<kRowRor + 1>(ay, ay) + incy;
+    row_position_chain(bx, by, incx, incy, k);
+    bool okB;
+    const float B = lead_sample(bx, by, &okB);
+    const uint32_t goB = row_ballot(keeps_going(bx, by), lane);
+    const int n_valid = __builtin_ctz(~goA | 0x10000u);  // steps base .. base + n_valid - 1 run
+    const bool valid = k < n_valid;
+    if (row_ballot(valid && (!okA || base + k >= kMaxSearchSteps), lane)) return -1;
+    // window: L_m = leading sample of step t - m
+    const float Lm1 = dpp_mov<kRowShl + 1>(dpp_mov<kRowRor + 15>(B, B), A);
+    const float L0 = A;
+    const float L1 = dpp_mov<kRowShr + 1>(dpp_mov<kRowRor + 1>(Z, Z), A);
+    const float L2 = dpp_mov<kRowShr + 2>(dpp_mov<kRowRor + 2>(Z, Z), A);
+    const float L3 = dpp_mov<kRowShr + 3>(dpp_mov<kRowRor + 3>(Z, Z), A);
+    const float L4 = dpp_mov<kRowShr + 4>(dpp_mov<kRowRor + 4>(Z, Z), A);
+    const float L5 = dpp_mov<kRowShr + 5>(dpp_mov<kRowRor + 5>(Z, Z), A);
+    // residuals of this step (c), the one before (p) and the one after (n): e[j] = sample - ref[4 - j]
+    const float c0 = L0 - ref[4], c1 = L1 - ref[3], c2 = L2 - ref[2], c3 = L3 - ref[1], c4 = L4 - ref[0];
+    const float p0 = L1 - ref[4], p1 = L2 - ref[3], p2 = L3 - ref[2], p3 = L4 - ref[1], p4 = L5 - ref[0];
+    const float n0 = Lm1 - ref[4], n1 = L0 - ref[3], n2 = L1 - ref[2], n3 = L2 - ref[1], n4 = L3 - ref[0];
+    const float ee = (((c0 * c0 + c1 * c1) + c2 * c2) + c3 * c3) + c4 * c4;
+    const float ee_prev = (((p0 * p0 + p1 * p1) + p2 * p2) + p3 * p3) + p4 * p4;
+    const float ee_next = (((n0 * n0 + n1 * n1) + n2 * n2) + n3 * n3) + n4 * n4;
+    const float cross = (((c0 * p0 + c1 * p1) + c2 * p2) + c3 * p3) + c4 * p4;
+    const float cross_next = (((n0 * c0 + n1 * c1) + n2 * c2) + n3 * c3) + n4 * c4;
+    const bool has_next = (k < 15) ? (k + 1 < n_valid) : (n_valid == 16 && (goB & 1u));
+    if (valid) {
+      if (ee < lb) {
+        ls = lb, ls_i = lb_i;
+        lb = ee, lb_i = base + k;
+        c_pre = (base + k) ? ee_prev : -1.0f, c_dpre = cross;
+        c_post = has_next ? ee_next : -1.0f, c_dpost = has_next ? cross_next : -1.0f;
+        c_x = ax, c_y = ay;
+      } else if (ee < ls) {
+        ls = ee, ls_i = base + k;
+      }
+    }
+    if (n_valid < 16 || !(goB & 1u)) break;
+    Z = A, A = B, okA = okB, ax = bx, ay = by, goA = goB;
+  }
+  // the row's best step, and the best of the rest
+  float best = lb;
+  int c_best = lb_i;
+  row_min_pair(best, c_best);
+  const bool winner = (lb_i == c_best);
+  float second = winner ? ls : lb;
+  int c_second = winner ? ls_i : lb_i;
+  row_min_pair(second, c_second);
+  if (c_second == 0x7fffffff) c_second = -1;
+  const int src = (lane & 48) | (c_best & 15);  // step t lives in lane t mod 16
+  const float err_pre = __shfl(c_pre, src, 64), diff_pre = __shfl(c_dpre, src, 64);
+  const float err_post = __shfl(c_post, src, 64), diff_post = __shfl(c_dpost, src, 64);
+  float best_x = __shfl(c_x, src, 64), best_y = __shfl(c_y, src, 64);
+  if (best > 4.0f * P.max_cost) return 2;
+  {
+    const int d = c_best - c_second;
+    if (((float)(d > 0 ? d : -d) > 1.0f) && (P.second_best_factor * best > second)) return 1;
+  }
+  if (P.do_subpixel) {
+    const float g_pre_pre = -(err_pre - diff_pre);
+    const float g_pre_this = +(best - diff_pre);
+    const float g_post_this = -(best - diff_post);
+    const float g_post_post = +(err_post - diff_post);
+    bool interp_pre = false, interp_post = false;
+    if (err_pre < 0 || err_post < 0) {
+    } else if ((g_post_this < 0) ^ (g_pre_this < 0)) {
+    } else if ((g_pre_pre < 0) ^ (g_pre_this < 0)) {
+      if (!((g_post_post < 0) ^ (g_post_this < 0))) interp_pre = true;
+    } else if ((g_post_post < 0) ^ (g_post_this < 0)) {
+      interp_post = true;
+    }
+    if (interp_pre) {
+      const float d = g_pre_this / (g_pre_this - g_pre_pre);
+      best_x -= d * incx;
+      best_y -= d * incy;
+      best = best - 2 * d * g_pre_this - (g_pre_pre - g_pre_this) * d * d;
+    } else if (interp_post) {
+      const float d = g_post_this / (g_post_this - g_post_post);
+      best_x += d * incx;
+      best_y += d * incy;
+      best = best + 2 * d * g_post_this + (g_post_post - g_post_this) * d * d;
+    }
+  }
+  const float sample_dist = P.sample_dist * rescale_factor;
+  float grad = 0;
+  float tmp = ref[4] - ref[3];
+  grad += tmp * tmp;
+  tmp = ref[3] - ref[2];
+  grad += tmp * tmp;
+  tmp = ref[2] - ref[1];
+  grad += tmp * tmp;
+  tmp = ref[1] - ref[0];
+  grad += tmp * tmp;
+  grad /= sample_dist * sample_dist;
+  if (best > P.max_cost + sqrtf(grad) * 20) return 2;
+  *match = {best_x, best_y};
+  return 0;
+}
+
+
 // cv::Rect::contains(Point2f): the point becomes a Point2i through cvRound
 __device__ __forceinline__ bool rect_contains(int rx, int ry, int rw, int rh, V2 p) {
   const int ix = __float2int_rn(p.x), iy = __float2int_rn(p.y);
   return rx <= ix && ix < rx + rw && ry <= iy && iy < ry + rh;
 }
 
-__device__ __forceinline__ void fail_feature(const StereoParams& P, StereoFeature& f, int* __restrict__ stats) {
+__device__ __forceinline__ uint32_t fail_feature(const StereoParams& P, StereoFeature& f) {  // -> counters to bump (bit c)
+  uint32_t bits = 0;
   f.idepth_var *= P.process_fail_var_factor;
   if (f.idepth_var > P.idepth_var_max) {
     f.valid = 0;
-    atomicAdd(&stats[1], 1);
+    bits |= 1u << 1;
   }
   f.num_dropouts++;
   if (f.num_dropouts > (uint32_t)P.max_dropouts) {
     f.valid = 0;
-    atomicAdd(&stats[2], 1);
+    bits |= 1u << 2;
   }
+  return bits;
 }
 
-__global__ __launch_bounds__(64) void k_update_feature_idepths(
-    const StereoParams P, const StereoCamera cam, const int n_poses, const StereoPoseEntry* __restrict__ poses,
-    const uint8_t* __restrict__ new_img, const float* __restrict__ new_gx, const float* __restrict__ new_gy,
-    const uint32_t curr_pf_id, const int n, StereoFeature* __restrict__ feats, int* __restrict__ stats) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// Returns the statistics counters this feature bumps (bit c = stats[c]); the kernel adds them up per wave.
+template <int G>
+__device__ uint32_t update_one_feature(const StereoParams& P, const StereoCamera& cam, const int n_poses,
+                                       const StereoPoseEntry* __restrict__ poses, const uint8_t* __restrict__ new_img,
+                                       const float* __restrict__ new_gx, const float* __restrict__ new_gy, const uint32_t curr_pf_id,
+                                       const int i, const bool leader, StereoFeature* __restrict__ feats, int* __restrict__ stats) {
+  uint32_t bits = 0;
   StereoFeature f = feats[i];
   // pfs.at(fii.frame_id)
   int slot = -1;
@@ -446,17 +571,14 @@ __global__ __launch_bounds__(64) void k_update_feature_idepths(
       break;
     }
   if (slot < 0) {
-    atomicMin(&stats[kStatBadFrame], i);
-    return;
+    if (leader) atomicMin(&stats[kStatBadFrame], i);
+    return 0;
   }
   const StereoPoseEntry& pe = poses[slot];
-  Geo geo;
-  load_geometry(geo, cam, pe.q_ref_to_new, pe.t_ref_to_new);
-  {
-    const float* t = pe.t_ref_to_new;
-    const float baseline = sqrtf((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]);
-    if (baseline < P.min_baseline) return;
-  }
+  // EpipolarGeometry::loadGeometry depends on the pose-frame only: done once per pose by the host (stereo_kernels.h,
+  // same float operations in the same order, no contraction on either side), not once per feature here.
+  const Geo& geo = pe.geo_new;
+  if (pe.baseline < P.min_baseline) return 0;
   const int width = cam.width, height = cam.height, pad = cam.border;
   const int rows = height + 2 * pad, cols = width + 2 * pad;
   bool asserted = false, tracked = false;
@@ -480,8 +602,7 @@ __global__ __launch_bounds__(64) void k_update_feature_idepths(
     }
     if ((rescale <= P.rescale_factor_min) || (rescale >= P.rescale_factor_max)) {
       // the patch warp is too large: re-anchor the feature in the newest pose-frame (flame.cc:1596-1659)
-      Geo gpf;
-      load_geometry(gpf, cam, pe.q_ref_to_pf, pe.t_ref_to_pf);
+      const Geo& gpf = pe.geo_pf;
       V2 u_pf;
       float idepth_pf, var_pf;
       const Outcome mr = predict(gpf, cam, P.process_var_factor, xy, f.idepth_mu, f.idepth_var, &u_pf, &idepth_pf, &var_pf);
@@ -541,8 +662,13 @@ __global__ __launch_bounds__(64) void k_update_feature_idepths(
     if (gmax < P.min_grad_mag) {
       status = 1;  // FAIL_REF_PATCH_GRADIENT
     } else {
-      const int r = line_match(P, rescale, patch, new_img, rows, cols, {u_start.x + off, u_start.y + off},
-                               {u_end.x + off, u_end.y + off}, &m);
+      int r;
+      if constexpr (G == 16)
+        r = line_match_row(P, rescale, patch, new_img, rows, cols, {u_start.x + off, u_start.y + off},
+                           {u_end.x + off, u_end.y + off}, (int)threadIdx.x, &m);
+      else
+        r = line_match(P, rescale, patch, new_img, rows, cols, {u_start.x + off, u_start.y + off},
+                       {u_end.x + off, u_end.y + off}, &m);
       if (r < 0) {
         asserted = true;
         break;
@@ -555,13 +681,13 @@ __global__ __launch_bounds__(64) void k_update_feature_idepths(
     tracked = true;
   } while (false);
   if (asserted) {
-    atomicMin(&stats[kStatAssert], i);
-    return;
+    if (leader) atomicMin(&stats[kStatAssert], i);
+    return 0;
   }
   // failure-type counters read the status field whatever wrote it last (flame.cc:1337-1345)
-  if (f.search_status == 1) atomicAdd(&stats[3], 1);
-  else if (f.search_status == 2) atomicAdd(&stats[4], 1);
-  else if (f.search_status == 3) atomicAdd(&stats[5], 1);
+  if (f.search_status == 1) bits |= 1u << 3;
+  else if (f.search_status == 2) bits |= 1u << 4;
+  else if (f.search_status == 3) bits |= 1u << 5;
   bool updated = false;
   if (tracked) {
     // ---- InverseDepthMeasModel::idepth (inverse_depth_meas_model.cc:48-154) ------------------------------
@@ -606,8 +732,8 @@ __global__ __launch_bounds__(64) void k_update_feature_idepths(
       sensed = true;
     } while (false);
     if (asserted) {
-      atomicMin(&stats[kStatAssert], i);
-      return;
+      if (leader) atomicMin(&stats[kStatAssert], i);
+      return 0;
     }
     if (sensed) {
       // ---- inverse_depth_filter::update (inverse_depth_filter.cc:265-303) --------------------------------
@@ -625,22 +751,49 @@ __global__ __launch_bounds__(64) void k_update_feature_idepths(
       if (!(dist > P.outlier_sigma_thresh * P.outlier_sigma_thresh)) {
         mu_post = (mu_post <= 0) ? 0.0f : mu_post;
         if (isnan(mu_post) || isnan(var_post) || !(var_post >= 0)) {
-          atomicMin(&stats[kStatAssert], i);
-          return;
+          if (leader) atomicMin(&stats[kStatAssert], i);
+          return 0;
         }
         if (P.do_meas_fusion) f.idepth_mu = mu_post, f.idepth_var = var_post;
         else f.idepth_mu = mu_meas, f.idepth_var = var_meas;
         f.valid = 1;
         f.num_updates++;
         f.num_dropouts = 0;
-        atomicAdd(&stats[0], 1);
+        bits |= 1u;
         updated = true;
       }
     }
   }
-  if (!updated) fail_feature(P, f, stats);
-  feats[i] = f;
+  if (!updated) bits |= fail_feature(P, f);
+  if (leader) feats[i] = f;
+  return bits;
 }
+
+// G lanes per feature: 16 (a DPP row shares the feature: every lane runs the short scalar parts redundantly -- they cost
+// the wave the same whether 1 or 16 lanes are live -- and the row splits the epipolar walk, line_match_row), or 1 (the
+// whole body in one lane, line_match).  Lane 0 of a group stores; the six statistics counters are summed over the wave
+// (ballot + popcount) and added with one atomic each into one of kStatSlots copies of the counter block: every feature
+// adding to the same six words made the kernel run at the speed of same-address atomics (2.9 ns per feature: 24 us at
+// 8.4 k features, 171 us at 57 k, whatever the rest of the kernel did).
+template <int G>
+__global__ __launch_bounds__(64) void k_update_feature_idepths(
+    const StereoParams P, const StereoCamera cam, const int n_poses, const StereoPoseEntry* __restrict__ poses,
+    const uint8_t* __restrict__ new_img, const float* __restrict__ new_gx, const float* __restrict__ new_gy,
+    const uint32_t curr_pf_id, const int n, StereoFeature* __restrict__ feats, int* __restrict__ stats) {
+  const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) / G);
+  const bool leader = (threadIdx.x % G) == 0;
+  uint32_t bits = 0;
+  if (i < n) bits = update_one_feature<G>(P, cam, n_poses, poses, new_img, new_gx, new_gy, curr_pf_id, i, leader, feats, stats);
+  if (!leader) bits = 0;
+  int* slot = stats + kStatCount + (blockIdx.x % kStatSlots) * kStatSlotStride;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const unsigned long long m = __ballot((bits >> c) & 1u);
+    if (threadIdx.x == 0 && m) atomicAdd(&slot[c], __popcll(m));
+  }
+}
+
+
 
 // utils::Frame::create level 0: img_pad = copyMakeBorder(REFLECT_101), grad*_pad = copyMakeBorder(
 // getCentralGradient(img), CONSTANT 0).  The differences of two bytes (and their halves) are exact in float.
@@ -677,11 +830,16 @@ __global__ __launch_bounds__(256) void k_frame_pad_gradient(const uint8_t* __res
 hipError_t launch_update_feature_idepths(const StereoParams& P, const StereoCamera& cam, int n_poses,
                                          const StereoPoseEntry* poses, const uint8_t* new_img, const float* new_gx,
                                          const float* new_gy, uint32_t curr_pf_id, int n, StereoFeature* feats, int* stats,
-                                         hipStream_t stream) {
+                                         int lanes_per_feature, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
-  const int block = 64;  // one wave per workgroup: 8.5 k features are only 133 waves, spread them over the CUs
-  hipLaunchKernelGGL(k_update_feature_idepths, dim3((n + block - 1) / block), dim3(block), 0, stream, P, cam, n_poses,
-                     poses, new_img, new_gx, new_gy, curr_pf_id, n, feats, stats);
+  const int block = 64;  // one wave per workgroup, spread over the CUs: 8.5 k features are 2100 waves (133 at one lane each)
+  if (lanes_per_feature == 16) {
+    hipLaunchKernelGGL(k_update_feature_idepths<16>, dim3((n + 3) / 4), dim3(block), 0, stream, P, cam, n_poses, poses, new_img,
+                       new_gx, new_gy, curr_pf_id, n, feats, stats);
+  } else {
+    hipLaunchKernelGGL(k_update_feature_idepths<1>, dim3((n + block - 1) / block), dim3(block), 0, stream, P, cam, n_poses,
+                       poses, new_img, new_gx, new_gy, curr_pf_id, n, feats, stats);
+  }
   return hipGetLastError();
 }
 

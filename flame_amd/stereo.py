@@ -56,8 +56,10 @@ STEREO_ABI_SYMBOLS = (
     "flame_stereo_default_params", "flame_stereo_create", "flame_stereo_destroy", "flame_stereo_set_stream",
     "flame_stereo_set_camera", "flame_stereo_add_frame", "flame_stereo_drop_frame", "flame_stereo_frame_count",
     "flame_stereo_download_frame", "flame_stereo_update_feature_idepths", "flame_stereo_update_feature_idepths_device",
-    "flame_stereo_last_kernel_ms", "flame_stereo_last_hip_error",
+    "flame_stereo_last_kernel_ms", "flame_stereo_last_hip_error", "flame_stereo_set_features",
+    "flame_stereo_update_resident", "flame_stereo_get_features", "flame_stereo_features_device", "flame_stereo_set_option",
 )
+OPT_LANES_PER_FEATURE = 1
 
 _READY = False
 _FP = C.POINTER(C.c_float)
@@ -84,6 +86,12 @@ def _lib():
             "flame_stereo_update_feature_idepths_device": (C.c_int, [ctx, PP, C.c_uint32, C.c_uint32, C.c_int,
                                                                      C.POINTER(_Pose), C.c_int, C.c_void_p,
                                                                      C.POINTER(_Stats)]),
+            "flame_stereo_set_features": (C.c_int, [ctx, C.c_int, C.c_void_p]),
+            "flame_stereo_update_resident": (C.c_int, [ctx, PP, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_Pose),
+                                                       C.POINTER(_Stats)]),
+            "flame_stereo_get_features": (C.c_int, [ctx, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
+            "flame_stereo_features_device": (C.c_int, [ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+            "flame_stereo_set_option": (C.c_int, [ctx, C.c_int, C.c_int]),
             "flame_stereo_last_kernel_ms": (C.c_float, [ctx]),
             "flame_stereo_last_hip_error": (C.c_int, [ctx]),
         }
@@ -185,6 +193,42 @@ class FeatureTracker:
                                                                 C.c_void_p(feats_device_ptr), C.byref(st) if wait else None)
         self._chk(rc, "update_feature_idepths_device")
         return {n: int(getattr(st, n)) for n, _ in _Stats._fields_} if wait else None
+
+    # ---- the resident feature set (the default way to run the path: features stay on the device between frames) ----
+    def set_features(self, feats: np.ndarray):
+        if feats.dtype != FEATURE_DTYPE or not feats.flags.c_contiguous:
+            raise ValueError("feats must be a contiguous FEATURE_DTYPE array")
+        self._chk(self._L.flame_stereo_set_features(self._ctx, feats.shape[0], feats.ctypes.data), "set_features")
+
+    def update_resident(self, params: StereoParams, new_frame_id: int, curr_pf_id: int, poses, wait: bool = True,
+                        raise_on_error: bool = True):
+        """Flame::updateFeatureIDepths on the resident set, in place on the device.  Returns (status, stats dict)
+        (wait=False: enqueued only, stats None)."""
+        st = _Stats()
+        rc = self._L.flame_stereo_update_resident(self._ctx, C.byref(params), new_frame_id, curr_pf_id, len(poses),
+                                                  self._poses(poses), C.byref(st) if wait else None)
+        if not wait:
+            self._chk(rc, "update_resident")
+            return rc, None
+        stats = {n: int(getattr(st, n)) for n, _ in _Stats._fields_}
+        if rc != 0 and raise_on_error:
+            raise NLTGV2Error(rc, "update_resident: %s (feature %d)" % (status_string(rc), stats["error_feature"]))
+        return rc, stats
+
+    def get_features(self) -> np.ndarray:
+        n = C.c_int(0)
+        self._chk(self._L.flame_stereo_get_features(self._ctx, 0, None, C.byref(n)), "get_features")
+        out = np.empty(n.value, FEATURE_DTYPE)
+        self._chk(self._L.flame_stereo_get_features(self._ctx, n.value, out.ctypes.data, C.byref(n)), "get_features")
+        return out
+
+    def features_device(self):
+        p, n = C.c_void_p(), C.c_int(0)
+        self._chk(self._L.flame_stereo_features_device(self._ctx, C.byref(p), C.byref(n)), "features_device")
+        return p.value or 0, n.value
+
+    def set_lanes_per_feature(self, lanes: int):
+        self._chk(self._L.flame_stereo_set_option(self._ctx, OPT_LANES_PER_FEATURE, int(lanes)), "set_option")
 
     def set_stream(self, hip_stream_ptr):
         self._chk(self._L.flame_stereo_set_stream(self._ctx, C.c_void_p(hip_stream_ptr or 0)), "set_stream")

@@ -14,7 +14,7 @@
  *
  * The boundary sits where the reference hands Eigen/Sophus values to its stereo code: the caller keeps the
  * pose algebra (Sophus::SE3f products, flame.cc:1315-1316, 1614) and passes one (quaternion, translation) pair
- * per pose-frame; everything from EpipolarGeometry::loadGeometry down runs on the GPU, one lane per feature.
+ * per pose-frame; everything from EpipolarGeometry::loadGeometry down runs on the GPU, a 16-lane row per feature.
  * Results are bit-identical to the reference's scalar float code (same expression order, no FMA contraction).
  * Debug drawing (params.debug_draw_matches) and the stderr diagnostics are not part of the path.
  *
@@ -136,6 +136,25 @@ int flame_stereo_update_feature_idepths_device(flame_stereo_ctx* ctx, const flam
                                                uint32_t new_frame_id, uint32_t curr_pf_id, int n_poses,
                                                const flame_stereo_pose* poses, int n_feats, void* feats_device,
                                                flame_stereo_stats* stats);
+/* The resident feature set -- the default way to run the path: the features live in device memory from detection to
+ * removal (as Flame::feats_ lives in the Flame object, flame.h:529), every frame runs the update on them in place, and the
+ * host reads them back only when it needs them (new detections, the data terms of the graph).
+ *   set_features     replaces the resident set (host array of n_feats records);
+ *   update_resident  Flame::updateFeatureIDepths on it; `stats` NULL = enqueue only (results are ordered on the stream);
+ *   get_features     copies it back (feats may be NULL to query the count);
+ *   features_device  its device address and count (valid until the next set_features). */
+int flame_stereo_set_features(flame_stereo_ctx* ctx, int n_feats, const flame_stereo_feature* feats);
+int flame_stereo_update_resident(flame_stereo_ctx* ctx, const flame_stereo_params* params, uint32_t new_frame_id,
+                                 uint32_t curr_pf_id, int n_poses, const flame_stereo_pose* poses, flame_stereo_stats* stats);
+int flame_stereo_get_features(flame_stereo_ctx* ctx, int max_feats, flame_stereo_feature* feats, int* n_feats);
+int flame_stereo_features_device(flame_stereo_ctx* ctx, void** feats_device, int* n_feats);
+
+/* Options.  LANES_PER_FEATURE: 16 (a 16-lane row shares a feature and splits the epipolar walk), 1 (one lane walks the
+ * whole per-feature body) or 0 (default: 16 up to 10240 features, 1 above -- whichever is faster on MI355X); same results
+ * bit for bit. */
+enum { FLAME_STEREO_OPT_LANES_PER_FEATURE = 1 };
+int flame_stereo_set_option(flame_stereo_ctx* ctx, int option, int value);
+
 /* Device time of the last update kernel in milliseconds (HIP events on the context's stream); < 0 if none. */
 float flame_stereo_last_kernel_ms(flame_stereo_ctx* ctx);
 int flame_stereo_last_hip_error(const flame_stereo_ctx* ctx);

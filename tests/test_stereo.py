@@ -420,6 +420,18 @@ def _gpu_update(sc, imgs, feats, poses, pkw, pad=5, curr_pf=11, new=12, raise_on
             tr.add_frame(fid, img)
         out = feats.copy().view(FEATURE_DTYPE)
         rc, stats = tr.update_feature_idepths(_product_params(**pkw), new, curr_pf, poses, out, raise_on_error=raise_on_error)
+        # the same through the other two ways in: one lane per feature instead of a 16-lane row, and the resident set
+        tr.set_lanes_per_feature(1)
+        out1 = feats.copy().view(FEATURE_DTYPE)
+        rc1, stats1 = tr.update_feature_idepths(_product_params(**pkw), new, curr_pf, poses, out1, raise_on_error=False)
+        tr.set_lanes_per_feature(16)
+        tr.set_features(feats.copy().view(FEATURE_DTYPE))
+        rc2, stats2 = tr.update_resident(_product_params(**pkw), new, curr_pf, poses, raise_on_error=False)
+        out2 = tr.get_features()
+        assert (rc1, stats1) == (rc, stats) and (rc2, stats2) == (rc, stats), ((rc, stats), (rc1, stats1), (rc2, stats2))
+        if rc == 0:
+            assert out1.tobytes() == out.tobytes(), "1 lane per feature differs from the 16-lane row"
+            assert out2.tobytes() == out.tobytes(), "resident feature set differs from the host-array call"
     return rc, stats, out.view(so.FEATURE_DTYPE)
 
 
