@@ -299,6 +299,31 @@ def measured_traffic(config, run_path):
         return None
 
 
+VALU_PEAK_WINST_PER_S = 256 * 4 * 1.2e9  # 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles at 2.4 GHz
+#                                          (MI355X_MICROARCH.md "Wave scheduling"; x 64 lanes x 2 flop = the 157.3 TFLOP/s fp32 peak)
+
+
+def measured_counters(key):
+    """The committed rocprofv3 PMC record of a workload (profiles/traffic.json: FETCH_SIZE/WRITE_SIZE bytes and SQ_INSTS_VALU
+    per launch of its dominant kernel), or {}."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(key, {})
+    except Exception:
+        return {}
+
+
+def valu_roofline(key, launch_s):
+    """VALU-issue roofline of one launch: SQ_INSTS_VALU (wave instructions, measured offline with the same command) over
+    the launch time measured now, against the chip's VALU issue rate."""
+    n = measured_counters(key).get("valu_insts_per_launch")
+    if not n or launch_s <= 0:
+        return None
+    rate = n / launch_s
+    return {"bound": "valu", "insts_per_launch": int(n), "achieved": round(rate / 1e9, 1), "peak": round(VALU_PEAK_WINST_PER_S / 1e9, 1),
+            "unit": "G wave-instr/s", "frac": round(rate / VALU_PEAK_WINST_PER_S, 4), "source": "profiles/traffic.json"}
+
+
 def reg_profile_kernel(reg, params, n=400):
     """Mean duration (us) of ONE k_fused_step launch: eager launches, hipGraph off, each `run(1)`
     bracketed by HIP events on the solver's stream (flame_nltgv2_run_timed)."""
@@ -338,8 +363,13 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
         out["batched"][label] = {
             "frames": nf, "V": bi["V"], "E": bi["E"], "run_path": path, "launch_groups": b.info()["last_run_groups"],
             "frame_iters_per_s": round(nf * iters / (ms * 1e-3), 1), "per_iteration_us": round(per_iter_us, 2),
-            "achieved_GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4),
+            "achieved_GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4), "bound": "hbm",
         }
+        groups = max(1, b.info()["last_run_groups"])
+        key = f"{a.config}x{nf}:{path}"
+        out["batched"][label]["traffic"] = measured_counters(key).get("hbm_bytes_per_launch")
+        out["batched"][label]["algorithmic_bytes_per_launch"] = int(bi["algorithmic_bytes_per_iter"] * iters / groups)
+        out["batched"][label]["valu"] = valu_roofline(key, ms * 1e-3 / groups)
         b.close()
     # (2) the other single-GPU BASELINE configs, 200 iterations each
     oc = {}
@@ -368,6 +398,13 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
         oc[cfg] = {"V": g["V"], "E": g["E"], "iters_per_s": round(200 / (ms * 1e-3), 1),
                    "run_path": flame_amd.regularizer.RUN_PATHS.get(bi["last_run_path"], "?"),
                    "achieved_GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4)}
+        key = f"{cfg}:{oc[cfg]['run_path']}"
+        oc[cfg]["bound"] = "latency"  # (one frame: the state is on chip, each iteration waits one neighbour hand-off)
+        oc[cfg]["peak_of"] = "hbm"
+        oc[cfg]["traffic"] = measured_counters(key).get("hbm_bytes_per_launch")
+        oc[cfg]["algorithmic_bytes_per_launch"] = int(bi["algorithmic_bytes_per_iter"] * 200)
+        oc[cfg]["avg_launch_us"] = round(ms * 1e3, 1)
+        oc[cfg]["valu"] = valu_roofline(key, ms * 1e-3)
         if fused:
             res = r.photo_residual_last()
             oc[cfg]["photometric_residual"] = {"fused_into_the_solver_launch": True,

@@ -23,8 +23,9 @@ prof bench_he $B --persistent 2                 # the lane-per-half-edge kernel 
 prof bench_step $B --persistent 0               # one launch per step
 prof cfg3 python tools/profile_case.py single:1280x720
 prof cfg5 python tools/profile_case.py single:1920x1080
-prof batch30 python tools/profile_case.py batch:30
-prof batch64 python tools/profile_case.py batch:64
+prof batch30 python tools/profile_case.py batch:30:200   # bench.py batched.resident (200 iterations per launch)
+prof batch64 python tools/profile_case.py batch:64:100   # bench.py batched.large (100 iterations, 3 launch groups)
 prof stream64 python tools/profile_case.py stream:64
 rocprofv3 --kernel-trace --stats -d $OUT/kt_stereo -o kt --output-format csv -- python tools/stereo_bench.py > $OUT/kt_stereo.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_INSTS_LDS -d $OUT/sq_stereo -o s --output-format csv -- python tools/stereo_bench.py > $OUT/sq_stereo.log 2>&1
 tail -3 $OUT/kt_stereo.log

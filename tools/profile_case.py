@@ -2,8 +2,9 @@
 """tools/profile_case.py CASE -- one workload per process, for rocprofv3 (tools/profile.sh).
 
   single:<config>[:<persistent option>]   one frame, 200-iteration runs (1920x1080 with the fused photometric residual)
-  batch:<frames>                          frames of 640x480 as one disjoint union, default path (resident: k_persistent_tv)
-  stream:<frames>                         the same through the one-launch-per-step sweep (k_fused_step)
+  batch:<frames>[:<iters>]                frames of 640x480 as one disjoint union, default path (resident: k_persistent_tv);
+                                          iterations per run as bench.py's batched lines use them (resident 200, large 100)
+  stream:<frames>[:<iters>]               the same through the one-launch-per-step sweep (k_fused_step)
 Prints one JSON line with the HIP-event time per launch and the algorithmic bytes per launch."""
 import json
 import os
@@ -37,11 +38,12 @@ if kind == "single":
         r.photo_set_images(ref_img, np.roll(ref_img, 3, axis=1))
         r.photo_fuse(np.eye(3, dtype=np.float32), (K @ np.array([0.04, -0.01, 0.003])).astype(np.float32), graph_scale=1.0, border=4)
 else:
-    nf = int(rest)
+    nfs, _, its = rest.partition(":")
+    nf = int(nfs)
     g = synth.concat_graphs([synth.make_graph("640x480", seed=5000 + i) for i in range(nf)])
     if kind == "stream":
         r.set_option(OPT_PERSISTENT, 0)
-    iters = 100
+    iters = int(its) if its else 100
     r.upload_graph(g)
 r.run(p, iters)
 ms = min(r.run_timed(p, iters) for _ in range(5))

@@ -92,6 +92,29 @@ for tag, (kernel, key) in CASES.items():
     if key:
         traffic[key] = t
     out[tag] = entry
+# the feature-update kernel: instructions and (quad-)cycles per wave, by template instance (lanes per feature) and grid
+sq = os.path.join(SRC, "sq_stereo", "s_counter_collection.csv")
+if os.path.exists(sq):
+    agg = {}
+    with open(sq) as f:
+        for r in csv.DictReader(f):
+            if "k_update_feature_idepths" not in r["Kernel_Name"]:
+                continue
+            lanes = "16" if "<16>" in r["Kernel_Name"] or "ILi16E" in r["Kernel_Name"] else "1"
+            agg.setdefault((lanes, int(r["Grid_Size"])), {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    rows = []
+    for (lanes, grid), v in sorted(agg.items(), key=lambda kv: (kv[0][1] // int(kv[0][0]), kv[0][0])):
+        w = sum(v["SQ_WAVES"]) / len(v["SQ_WAVES"])
+        row = {"lanes_per_feature": int(lanes), "features": grid // int(lanes), "waves": round(w)}
+        for c, x in v.items():
+            if c != "SQ_WAVES":
+                row[c + "_per_wave"] = round(sum(x) / len(x) / w, 1)
+        row["note"] = "SQ_WAVE_CYCLES counts quad-cycles"
+        rows.append(row)
+    out.setdefault("stereo", {"kernel": "k_update_feature_idepths"})["per_wave_counters"] = rows
+    log = os.path.join(SRC, "kt_stereo.log")
+    if os.path.exists(log):
+        out["stereo"]["bench_lines"] = [ln.strip() for ln in open(log).read().splitlines() if " feats " in ln]
 json.dump(out, open(os.path.join(DST, f"{R}_counters.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
 print(json.dumps({k: {kk: v.get(kk) for kk in ("kernel_stats", "hbm_bytes_per_launch", "valu_issue_frac_of_peak", "wait_any_over_wave_cycles")} for k, v in out.items()}, indent=1)[:6000])
