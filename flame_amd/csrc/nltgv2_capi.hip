@@ -32,7 +32,8 @@ constexpr int kMaxCachedGraphs = 6;
 constexpr int kHeWavesPerCu = 24;      // residency cap of k_persistent_he (<= 64 VGPRs: the hardware admits 32)
 constexpr int kTvLdsWavesPerCu = 16;   // ... with the slot constants in LDS (<= 128 VGPRs -> 4 waves per SIMD; 10 KB LDS per wave = all 160 KB)
 constexpr size_t kXbufBytesPerVertex = 4 * 16 + 4;  // exchange buffers: four arrays of 16-byte records + the XCC table
-constexpr int kPvPollGap = 1;          // s_sleep 1 between the polls of k_persistent_pv (measured: 1 beats 0 by 1-3 %)
+constexpr int kPvPollGap = 3;          // k_persistent_pv polls: s_sleep 1 between rounds (beats none by 1-3 %), re-loading only the fetch
+                                       // entries still waiting (another 1-1.5 %)
 constexpr int kTvWavesPerCu = 8;       // residency of k_persistent_tv (<= 256 VGPRs -> 2 waves per SIMD)
 constexpr int kDualMinWavesPerCu = 0;  // auto: exchange through the XCD's L2 when more waves than this share a CU
 // x64-cycle sleep between publishing and the first neighbour poll (measured optimum, r01 sweep: he 6 at
@@ -126,7 +127,7 @@ struct flame_nltgv2_ctx {
   float export_scale = 1.0f;
   int opt_fault = 0;     // test hook: > 0 = the next persistent runs time out after this many spins
   int opt_presleep = 0;  // 0: auto (kPreSleep*); n > 0: (n - 1) x 64 cycles
-  int opt_poll_gap = 0;  // patch-per-wave form: 0 = default (kPvPollGap), 1 = no sleep between polls, 2 = one s_sleep
+  int opt_poll_gap = 0;  // patch-per-wave form: 0 = default (kPvPollGap), 1 = no sleep between polls, 2 = one s_sleep, 3 / 4 = the same, narrowed
   mutable int pv_occ = 0;            // patches of k_persistent_pv the runtime keeps resident per CU for the current layout
   mutable uint64_t pv_occ_topo = ~0ull;
   int opt_probe = 0;     // > 0: k_persistent_pv records a per-patch, per-step cycle probe (flame_nltgv2_read_probe)
@@ -1038,7 +1039,7 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
       ctx->opt_persistent = value;
       return 0;
     case FLAME_NLTGV2_OPT_POLL_GAP:
-      if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      if (value < 0 || value > 4) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_poll_gap = value;
       return 0;
     case FLAME_NLTGV2_OPT_VERIFY_RECORDS:

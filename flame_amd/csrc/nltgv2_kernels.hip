@@ -771,12 +771,49 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
                : "vcc", "scc", "memory")
         // up to 64 rounds per statement: one LDS-DMA load per fetch lane (M0 = destination base, saved and restored
         // inside the statement), then every lane's neighbour record from LDS; vcc = lanes still waiting
+        // ... narrowed: a fetch lane whose own slot already shows the step's tag stops re-loading it (`pn` = fetch lanes
+        // still waiting), so the poll traffic shrinks to the stragglers instead of the whole fetch list every round
+#define PV_POLL_N(POLICY, GAP)                                                                           \
+  asm volatile("s_mov_b32 %[keep], m0\n\t"                                                              \
+               "s_mov_b32 m0, %[dst]\n\t"                                                               \
+               "s_mov_b32 %[cnt], 0\n\t"                                                                \
+               "s_mov_b64 %[pn], %[fm]\n\t"                                                             \
+               "1:\n\t"                                                                                 \
+               "s_mov_b64 exec, %[pn]\n\t"                                                              \
+               "global_load_lds_dwordx4 %[src], off " POLICY "\n\t"                                     \
+               "s_mov_b64 exec, -1\n\t" GAP "ds_read_b32 %[t], %[ra] offset:12\n\t"                   \
+               "ds_read_b32 %[t2], %[fa] offset:12\n\t"                                                 \
+               "ds_read_b128 %[nb], %[ra]\n\t"                                                          \
+               "s_add_u32 %[cnt], %[cnt], 1\n\t"                                                        \
+               "s_waitcnt lgkmcnt(0)\n\t"                                                               \
+               "v_cmp_ne_u32_e32 vcc, %[tag], %[t2]\n\t"                                                \
+               "s_and_b64 %[pn], vcc, %[fm]\n\t"                                                        \
+               "v_cmp_ne_u32_e32 vcc, %[tag], %[t]\n\t"                                                 \
+               "s_cmp_lt_u32 %[cnt], 64\n\t"                                                            \
+               "s_cbranch_vccz 2f\n\t"                                                                  \
+               "s_cbranch_scc1 1b\n\t"                                                                  \
+               "2:\n\t"                                                                                 \
+               "s_mov_b32 %[pl], vcc_lo\n\t"                                                            \
+               "s_or_b32 %[pl], %[pl], vcc_hi\n\t"                                                      \
+               "s_mov_b32 m0, %[keep]"                                                                   \
+               : [keep] "=&s"(keep), [cnt] "=&s"(cnt), [pl] "=&s"(pend_lo), [nb] "=&v"(nbv), [t] "=&v"(tagv), \
+                 [t2] "=&v"(tagf), [pn] "=&s"(pnarrow)                                                     \
+               : [src] "v"(src), [dst] "s"(dst), [ra] "v"(rd_nbr), [fa] "v"(own_slot), [tag] "s"(s), [fm] "s"(fetch_mask) \
+               : "vcc", "scc", "memory")
+        unsigned tagf;
+        unsigned long long pnarrow;
+        const unsigned own_slot = dst + 16u * (unsigned)lane;
         if (poll_gap == 0) {
           PV_POLL("sc1", "");
-        } else {
+        } else if (poll_gap == 1) {
           PV_POLL("sc1", "s_sleep 1\n\t");
+        } else if (poll_gap == 2) {
+          PV_POLL_N("sc1", "");
+        } else {
+          PV_POLL_N("sc1", "s_sleep 1\n\t");
         }
 #undef PV_POLL
+#undef PV_POLL_N
         rounds += cnt;
         if (pend_lo == 0u) break;  // every lane saw the step's tag
         const int ab = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

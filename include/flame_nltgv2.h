@@ -271,7 +271,8 @@ enum {
   FLAME_NLTGV2_OPT_XCDS = 9,         /* persistent run: number of XCDs (of 8) the waves are spread over: 0 (default) =
                                         one XCD for graphs small enough to run there, else all eight; 1..8 */
   FLAME_NLTGV2_OPT_POLL_GAP = 13,    /* patch-per-wave form: 0 (default) = built-in, 1 = no pause between the polls of a
-                                        wait, 2 = one s_sleep (64 cycles) */
+                                        wait, 2 = one s_sleep (64 cycles); 3 / 4 = the same with the polls narrowed to the
+                                        records that have not arrived yet (4 is the built-in) */
   FLAME_NLTGV2_OPT_VERIFY_RECORDS = 14, /* persistent kernels: 1 = after a neighbour record's tag matched, read the 16 bytes
                                         once more and compare all four dwords (the exchange relies on an aligned 16-byte
                                         access never being torn between payload and tag; this checks it at run time, at the

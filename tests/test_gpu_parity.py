@@ -152,7 +152,7 @@ def test_internal_steps_individually(env):
     [(5, 0), (3, 4), (4, 4)], [(5, 0), (3, 4), (4, 16)], [(5, 0), (2, 0)], [(5, 1)], [(5, 2)], [(5, 3)], [(5, 2), (6, 0)], [(5, 3), (6, 0)], [(5, 2), (6, 2)], [(5, 3), (6, 2)], [(5, 3), (7, 2)], [(5, 3), (6, 2), (7, 2)], [(5, 3), (7, 0)],
     [(5, 2), (9, 1)], [(5, 2), (9, 2)], [(5, 2), (9, 4)], [(5, 2), (9, 8)], [(5, 3), (9, 1)], [(5, 2), (8, 1)], [(5, 2), (8, 21)],
     [(5, 3), (8, 9)], [(5, 2), (9, 1), (6, 0)],
-    [(5, 4)], [(5, 4), (6, 0)], [(5, 4), (6, 2)], [(5, 4), (9, 1)], [(5, 4), (9, 2)], [(5, 4), (9, 8)], [(5, 4), (13, 1)], [(5, 4), (13, 2)],
+    [(5, 4)], [(5, 4), (6, 0)], [(5, 4), (6, 2)], [(5, 4), (9, 1)], [(5, 4), (9, 2)], [(5, 4), (9, 8)], [(5, 4), (13, 1)], [(5, 4), (13, 2)], [(5, 4), (13, 3)], [(5, 4), (13, 4)],
     [(5, 4), (9, 1), (6, 0), (13, 1)], [(5, 4), (12, 1)],
 ])
 def test_launch_configurations_are_bit_identical(env, opts):
