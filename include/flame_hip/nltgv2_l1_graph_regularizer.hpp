@@ -253,6 +253,15 @@ class DeviceGraph {
     const flame_nltgv2_params c = to_c(p);
     check(flame_nltgv2_costs(ctx_, &c, smooth, data), "costs");
   }
+  // Asynchronous use (multi-GPU hosts, frame_gather.hpp): the solver's stream, a standing device target that every run
+  // leaves x * scale in (the read-back of flame.cc:372-380, on the device), enqueue-only runs and the matching wait.
+  void setStream(void* hip_stream) { check(flame_nltgv2_set_stream(ctx_, hip_stream), "set_stream"); }
+  void setExportTarget(void* dst_device, float scale) { check(flame_nltgv2_set_export_target(ctx_, dst_device, scale), "set_export_target"); }
+  void runAsync(const Params& p, int n_iters) {
+    const flame_nltgv2_params c = to_c(p);
+    check(flame_nltgv2_run_async(ctx_, &c, n_iters), "run_async");
+  }
+  void sync() { check(flame_nltgv2_sync(ctx_), "sync"); }
   flame_nltgv2_ctx* handle() { return ctx_; }
 
  private:

@@ -9,7 +9,12 @@ import pytest
 
 from tests.conftest import HAS_GPU, ROOT
 
-HEADERS = [os.path.join(ROOT, "include", h) for h in ("flame_nltgv2.h", "flame_stereo.h")]
+HEADERS = [os.path.join(ROOT, "include", h) for h in ("flame_nltgv2.h", "flame_stereo.h", "flame_frames.h")]
+
+
+FRAMES_ABI_SYMBOLS = ("flame_frames_create", "flame_frames_destroy", "flame_frames_count", "flame_frames_local_row",
+                      "flame_frames_stream", "flame_frames_gather", "flame_frames_wait", "flame_frames_gathered",
+                      "flame_frames_download", "flame_frames_last_error_text")
 
 
 def declared_symbols():
@@ -17,7 +22,7 @@ def declared_symbols():
     for h in HEADERS:
         txt = open(h).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-        out |= set(re.findall(r"\b(flame_(?:nltgv2|delaunay|stereo)_[a-z_0-9]+)\s*\(", txt))
+        out |= set(re.findall(r"\b(flame_(?:nltgv2|delaunay|stereo|frames)_[a-z_0-9]+)\s*\(", txt))
     return sorted(out)
 
 
@@ -26,6 +31,8 @@ def test_header_symbols_are_exported(built):
     from flame_amd.regularizer import ABI_SYMBOLS
     from flame_amd.stereo import STEREO_ABI_SYMBOLS
 
+    STEREO_ABI_SYMBOLS = tuple(STEREO_ABI_SYMBOLS) + FRAMES_ABI_SYMBOLS
+
     decl = declared_symbols()
     assert len(decl) >= 38
     assert set(decl) == set(ABI_SYMBOLS) | set(STEREO_ABI_SYMBOLS), set(decl) ^ (set(ABI_SYMBOLS) | set(STEREO_ABI_SYMBOLS))
@@ -33,14 +40,14 @@ def test_header_symbols_are_exported(built):
     for name in decl:
         assert hasattr(lib, name), name
     nm = subprocess.check_output(["nm", "-D", "--defined-only", flame_amd.library_path()], text=True)
-    exported = set(re.findall(r" T (flame_(?:nltgv2|delaunay|stereo)_[a-z_0-9]+)", nm))
+    exported = set(re.findall(r" T (flame_(?:nltgv2|delaunay|stereo|frames)_[a-z_0-9]+)", nm))
     assert set(decl) <= exported
 
 
 def test_header_is_plain_c(built, tmp_path):
     """The boundary is a C ABI: the header must compile as C99 and as C++."""
     src = tmp_path / "t.c"
-    src.write_text('#include "flame_nltgv2.h"\n#include "flame_stereo.h"\nint main(void){flame_nltgv2_params p; flame_stereo_feature f; (void)p; (void)f;'
+    src.write_text('#include "flame_nltgv2.h"\n#include "flame_stereo.h"\n#include "flame_frames.h"\nint main(void){flame_nltgv2_params p; flame_stereo_feature f; (void)p; (void)f;'
                    ' return FLAME_NLTGV2_ABI_VERSION - 1 + (int)sizeof(flame_stereo_feature) - 40;}\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-c", str(src),
                            "-o", str(tmp_path / "t.o")])

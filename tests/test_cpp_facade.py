@@ -111,3 +111,34 @@ def test_solver_loop_end_to_end(built, tmp_path):
     r = subprocess.run([build_solver_loop_program(tmp_path)], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and r.stdout.count(" ok") >= 8 and "FAIL" not in r.stdout, r.stdout + r.stderr
+
+
+def build_gather_program(tmp_path):
+    exe = str(tmp_path / "frame_gather_test")
+    lib_dir = os.path.join(ROOT, "flame_amd")
+    subprocess.check_call([
+        "g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+        os.path.join(ROOT, "tests", "cpp", "frame_gather_test.cc"), "-o", exe,
+        "-L", lib_dir, "-lflame_nltgv2_hip", "-L", os.path.join(ROOT, "oracle"), "-loracle_nltgv2", "-L/opt/rocm/lib", "-lamdhip64",
+        f"-Wl,-rpath,{lib_dir}", f"-Wl,-rpath,{os.path.join(ROOT, 'oracle')}", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_frame_gather_compiles_and_fails_loudly_without_a_device(built, tmp_path):
+    """include/flame_hip/frame_gather.hpp + include/flame_frames.h: the C++ host's multi-GPU gather (RCCL, bound at run time)."""
+    exe = build_gather_program(tmp_path)
+    from tests.conftest import HAS_GPU
+
+    if not HAS_GPU:
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 77, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_frame_gather_end_to_end(built, tmp_path):
+    """Configuration 4 from C++: one solver per visible GPU, device-side export, one grouped ncclAllGather, compared
+    with the checker on every device."""
+    r = subprocess.run([build_gather_program(tmp_path)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "RCCL all-gather over" in r.stdout and "FAIL" not in r.stdout, r.stdout + r.stderr
