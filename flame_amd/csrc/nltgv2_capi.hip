@@ -897,18 +897,21 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
 int ensure_form_rows(flame_nltgv2_ctx* ctx, int form) {
   PackedLayout& L = ctx->L;
   if (form == 1 && !ctx->he_built) {
-    build_he_rows(&L);
-    struct { DevBuf* b; const void* src; size_t bytes; } cp[] = {
-        {&ctx->he_slot, L.he_slot.data(), sizeof(int32_t) * L.he_slot.size()}, {&ctx->he_vid, L.he_vid.data(), sizeof(int32_t) * L.he_vid.size()},
-        {&ctx->he_meta, L.he_meta.data(), sizeof(uint32_t) * L.he_meta.size()},
-        {&ctx->he_wave_chain, L.he_wave_chain.data(), sizeof(int32_t) * L.he_wave_chain.size()}};
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (a buffer may be reallocated)
-    for (auto& c : cp) {
-      int rc = ensure(ctx, *c.b, c.bytes);
-      if (!rc) rc = h2d(ctx, *c.b, c.src, c.bytes);
+    // (C) is (E) lane for lane (the same greedy walk): converted on the device from the patch rows, no host work
+    const size_t lanes = (size_t)L.wg_count * kWave;
+    L.he_ok = L.wg_ok, L.he_waves = L.wg_count, L.he_max_chain = std::max(L.max_degree, 1), L.comp_he_wave = L.comp_wg;
+    struct { DevBuf* b; size_t bytes; } req[] = {{&ctx->he_slot, sizeof(int32_t) * lanes}, {&ctx->he_vid, sizeof(int32_t) * lanes},
+                                                 {&ctx->he_meta, sizeof(uint32_t) * lanes},
+                                                 {&ctx->he_wave_chain, sizeof(int32_t) * (size_t)L.wg_count}};
+    bool grow = false;
+    for (auto& r : req) grow = grow || r.bytes > r.b->cap;
+    if (grow) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (a buffer is about to be reallocated)
+    for (auto& r : req) {
+      const int rc = ensure(ctx, *r.b, r.bytes);
       if (rc) return rc;
     }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    LAUNCHCHK(ctx, launch_he_from_patches(ctx->f, (int32_t*)ctx->he_slot.p, (int32_t*)ctx->he_vid.p, (uint32_t*)ctx->he_meta.p,
+                                          (int32_t*)ctx->he_wave_chain.p, ctx->stream));
     ctx->he_built = true;
     refresh_args(ctx);
   }
@@ -1814,6 +1817,10 @@ int flame_nltgv2_layout_selftest(flame_nltgv2_ctx* ctx, int64_t* mismatches) {
       e |= cmp(ctx->wg_slot, H.wg_slot.data(), 4 * lanes) | cmp(ctx->wg_vid, H.wg_vid.data(), 4 * lanes) |
            cmp(ctx->wg_meta, H.wg_meta.data(), 4 * lanes) | cmp(ctx->wg_nbr, H.wg_nbr.data(), 4 * lanes) |
            cmp(ctx->wg_fetch, H.wg_fetch.data(), 4 * lanes) | cmp(ctx->wg_info, H.wg_info.data(), 4 * H.wg_info.size());
+    if (ctx->he_built)  // (C), converted on the device from (E), against the host's own walk
+      e |= cmp(ctx->he_slot, H.he_slot.data(), 4 * lanes) | cmp(ctx->he_vid, H.he_vid.data(), 4 * lanes) |
+           cmp(ctx->he_meta, H.he_meta.data(), 4 * lanes) | cmp(ctx->he_wave_chain, H.he_wave_chain.data(), 4 * H.he_wave_chain.size());
+    if (ctx->he_built) bad += (H.he_waves != L.he_waves) + (H.he_max_chain != L.he_max_chain) + (H.comp_he_wave != L.comp_he_wave);
     if (e) return fail(ctx, FLAME_NLTGV2_ERR_HIP);
   }
   *mismatches = bad;

@@ -115,3 +115,6 @@ def test_device_expanded_layout_matches_host_builders(built, config):
         assert reg.layout_selftest() == 0
         reg.run(flame_amd.Params(), 16)
         assert reg.layout_selftest() == 0
+        reg.set_option(flame_amd.regularizer.OPT_PERSISTENT, 2)  # the lane-per-half-edge rows: converted on the device
+        reg.run(flame_amd.Params(), 16)
+        assert reg.info()["last_run_path"] == 1 and reg.layout_selftest() == 0
