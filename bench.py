@@ -262,6 +262,8 @@ def main():
 def pv_step_cycles(flame_amd, g, params, iters, device):
     """In-kernel cycle account of k_persistent_pv (FLAME_NLTGV2_OPT_PROBE) on this run's graph: per patch and step the
     shader cycles spent waiting for the neighbours' records, and the cycles from their arrival to the next publish."""
+    import numpy as np
+
     from flame_amd.regularizer import OPT_PERSISTENT, OPT_PROBE
 
     r = flame_amd.Regularizer(device)
