@@ -118,3 +118,55 @@ def test_device_expanded_layout_matches_host_builders(built, config):
         reg.set_option(flame_amd.regularizer.OPT_PERSISTENT, 2)  # the lane-per-half-edge rows: converted on the device
         reg.run(flame_amd.Params(), 16)
         assert reg.info()["last_run_path"] == 1 and reg.layout_selftest() == 0
+
+
+def test_sync_behind_an_unchecked_chain_and_with_growing_graphs(built):
+    """sync_graph settles a chain of asynchronous runs first; consecutive syncs without a run in between; the graph grows
+    past every buffer's capacity and shrinks again; a rejected sync leaves the previous graph intact."""
+    import torch  # noqa: F401
+
+    import flame_amd
+
+    rng = np.random.default_rng(11)
+    params = flame_amd.Params()
+    g0 = synth.make_graph("320x240", seed=5)
+    feat_id = np.arange(g0["V"], dtype=np.int32)
+    ref = sync_oracle.RefGraph.from_flat(g0, feat_id)
+
+    def both_run(reg, n, asynchronous=False):
+        flat = sync_oracle.flatten(ref, feat_id)
+        assert oracle.run(flat, n) == 0
+        sync_oracle.absorb(ref, flat, feat_id)
+        (reg.run_async if asynchronous else reg.run)(params, n)
+
+    with flame_amd.Regularizer(0) as reg:
+        reg.upload_graph(g0)
+        reg.set_feature_ids(feat_id)
+        pos, data, next_id = g0["pos"].copy(), g0["data_term"].copy(), g0["V"]
+        both_run(reg, 12, asynchronous=True)
+        both_run(reg, 9, asynchronous=True)   # a chain: the second run sits behind an unchecked persistent run
+        for frame, (w, h) in enumerate([(320, 240), (640, 480), (640, 480), (320, 240)]):
+            if frame in (1, 3):  # a much larger / smaller frame: every vertex is new, every buffer is re-sized
+                g = synth.make_graph(f"{w}x{h}", seed=20 + frame)
+                feat_id = np.arange(next_id, next_id + g["V"], dtype=np.int32)
+                pos, data, next_id = g["pos"].copy(), g["data_term"].copy(), next_id + g["V"]
+            else:
+                feat_id, pos, data, next_id = next_frame(rng, feat_id, pos, data, next_id, w, h)
+            weight = np.ones(len(feat_id), np.float32)
+            edges = synth.delaunay_edges_scipy(pos)
+            reg.sync_graph(feat_id, pos, data, weight, edges)
+            sync_oracle.sync(ref, feat_id, pos, data, weight, edges)
+            if frame == 2:   # twice in a row, nothing run in between (the state is in the canonical arrays)
+                feat_id, pos, data, next_id = next_frame(rng, feat_id, pos, data, next_id, w, h)
+                weight = np.ones(len(feat_id), np.float32)
+                edges = synth.delaunay_edges_scipy(pos)
+                reg.sync_graph(feat_id, pos, data, weight, edges)
+                sync_oracle.sync(ref, feat_id, pos, data, weight, edges)
+            bad = feat_id.copy()
+            bad[1] = bad[0]
+            with pytest.raises(flame_amd.NLTGV2Error):
+                reg.sync_graph(bad, pos, data, weight, edges)  # refused: the graph of this frame stays
+            both_run(reg, 20)
+            assert_state_equal(reg.download_state(), sync_oracle.flatten(ref, feat_id),
+                               keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"frame {frame}")
+            assert reg.layout_selftest() == 0
