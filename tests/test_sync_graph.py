@@ -170,3 +170,33 @@ def test_sync_behind_an_unchecked_chain_and_with_growing_graphs(built):
             assert_state_equal(reg.download_state(), sync_oracle.flatten(ref, feat_id),
                                keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"frame {frame}")
             assert reg.layout_selftest() == 0
+
+
+def test_sync_to_empty_edgeless_and_single_vertex_frames(built):
+    """Degenerate frames: no vertices at all, vertices without edges, one vertex -- and back to a full frame (all new)."""
+    import torch  # noqa: F401
+
+    import flame_amd
+
+    p = flame_amd.Params()
+    g = synth.make_graph("320x240", seed=2)
+    e0 = np.zeros((0, 2), np.int32)
+    fid = np.arange(g["V"], dtype=np.int32)
+    with flame_amd.Regularizer(0) as r:
+        r.upload_graph(g)
+        r.run(p, 10)
+        r.sync_graph(np.zeros(0, np.int32), np.zeros((0, 2), np.float32), np.zeros(0, np.float32), np.zeros(0, np.float32), e0)
+        assert (r.info()["V"], r.info()["E"]) == (0, 0)
+        r.run(p, 5)
+        assert r.download_state()["x"].shape == (0,)
+        r.sync_graph(fid, g["pos"], g["data_term"], g["data_weight"], np.stack([g["src"], g["dst"]], 1))
+        r.run(p, 10)
+        ref = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in g.items()}
+        assert oracle.run(ref, 10) == 0
+        assert_state_equal(r.download_state(), ref, what="empty -> full frame")
+        r.sync_graph(fid[:50], g["pos"][:50], g["data_term"][:50], g["data_weight"][:50], e0)
+        r.run(p, 7)
+        assert (r.info()["V"], r.info()["E"]) == (50, 0) and r.layout_selftest() == 0
+        r.sync_graph(fid[:1], g["pos"][:1], g["data_term"][:1], g["data_weight"][:1], e0)
+        r.run(p, 3)
+        assert r.download_state()["x"].shape == (1,)
