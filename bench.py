@@ -274,6 +274,8 @@ def pv_step_cycles(flame_amd, g, params, iters, device):
         r.run(params, iters)
         r.run(params, iters)
         p = r.read_probe().reshape(-1, iters, 8).astype(np.int64)[:, iters // 10:, :]
+        p = p[p[:, 0, 5] != 0]  # (idle padding behind an XCD's instances never runs a step)
+        info = r.info()
     finally:
         r.close()
     wait, comp = p[:, :, 2].mean(axis=1), p[:, :, 3].mean(axis=1)
@@ -284,7 +286,8 @@ def pv_step_cycles(flame_amd, g, params, iters, device):
             "compute_median": round(float(np.median(comp)), 0), "compute_max": round(float(comp.max()), 0),
             "wait_median": round(float(np.median(wait)), 0), "wait_min": round(float(wait.min()), 0),
             "least_slack_patch": {"compute": round(float(comp[crit]), 0), "wait": round(float(wait[crit]), 0)},
-            "poll_rounds_per_step": round(float(p[:, :, 4].mean()), 2), "patches": int(p.shape[0]),
+            "poll_rounds_per_step": round(float(p[:, :, 4].mean()), 2), "patches": int(info["he_waves"]),
+            "instances": int(p.shape[0]),
             "note": "cycles per step with the probe compiled in (+3-5 %); the lock-step network runs at the pace of its least-slack patches: period = their compute + their wait (one hand-off)"}
 
 

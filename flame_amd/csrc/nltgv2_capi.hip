@@ -32,6 +32,7 @@ constexpr int kMaxCachedGraphs = 6;
 constexpr int kHeWavesPerCu = 24;      // residency cap of k_persistent_he (<= 64 VGPRs: the hardware admits 32)
 constexpr int kTvLdsWavesPerCu = 16;   // ... with the slot constants in LDS (<= 128 VGPRs -> 4 waves per SIMD; 10 KB LDS per wave = all 160 KB)
 constexpr size_t kXbufBytesPerVertex = 4 * 16 + 4;  // exchange buffers: four arrays of 16-byte records + the XCC table
+constexpr int kPvPreSleep = 0;         // k_persistent_pv: x64 cycles between a step's start and its first poll
 constexpr int kPvPollGap = 3;          // k_persistent_pv polls: s_sleep 1 between rounds (beats none by 1-3 %), re-loading only the fetch
                                        // entries still waiting (another 1-1.5 %)
 constexpr int kTvWavesPerCu = 8;       // residency of k_persistent_tv (<= 256 VGPRs -> 2 waves per SIMD)
@@ -119,6 +120,7 @@ struct flame_nltgv2_ctx {
 
   int opt_solver = 0, opt_use_graph = 1, opt_block_waves = 0, opt_unroll = 0, opt_persistent = 1, opt_dual = 1;
   int opt_xcds = 0;      // XCDs a persistent launch spreads over: 0 = auto, 1..8
+  int opt_shadows = 0;   // shadow patches across XCD borders: 0 = built-in choice, 1 = none, 2 = one side, 3 = both sides (next upload)
   bool photo_fused = false;     // flame_nltgv2_photo_fuse: every run also leaves the photometric residual in photo_err
   PhotoGeometry photo_geo{};
   float photo_scale = 1.0f;
@@ -184,7 +186,7 @@ struct flame_nltgv2_ctx {
   std::vector<float> h_terms;
   DevBuf hq_alt, vstate_alt;  // the other copies of hq / vstate: a persistent run writes there, success swaps the roles
   DevBuf xbuf, abort_flag, he_slot, he_vid, he_meta, he_wave_chain, tv_slot, tv_vid, tv_meta, tv_wave;
-  DevBuf wg_slot, wg_vid, wg_meta, wg_nbr, wg_fetch, wg_info, probe;
+  DevBuf wg_slot, wg_vid, wg_meta, wg_nbr, wg_fetch, wg_info, wg_v0, rid_on, probe;
   // misc
   DevBuf err, cost_out, img_ref, img_cmp, photo_err, r_tris, r_valid, r_keys, r_img, r_cov, r_vtx, r_val;
   int img_rows = 0, img_cols = 0, img_step = 0;
@@ -290,6 +292,7 @@ void refresh_args(flame_nltgv2_ctx* ctx) {
   f.tv_slot = (int32_t*)ctx->tv_slot.p, f.tv_vid = (int32_t*)ctx->tv_vid.p;
   f.tv_meta = (uint32_t*)ctx->tv_meta.p, f.tv_wave = (uint32_t*)ctx->tv_wave.p;
   f.wg_count = ctx->L.wg_ok ? ctx->L.wg_count : 0;
+  f.n_rec = ctx->L.n_rec;
   f.wg_lcap = ctx->L.wg_lcap, f.wg_slab_slots = ctx->L.wg_slab_slots;
   f.wg_slot = (int32_t*)ctx->wg_slot.p, f.wg_vid = (int32_t*)ctx->wg_vid.p, f.wg_meta = (uint32_t*)ctx->wg_meta.p;
   f.wg_nbr = (int32_t*)ctx->wg_nbr.p, f.wg_fetch = (int32_t*)ctx->wg_fetch.p, f.wg_info = (int32_t*)ctx->wg_info.p;
@@ -306,6 +309,13 @@ int h2d(flame_nltgv2_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
 int finish(flame_nltgv2_ctx* ctx);
 int snapshot_chain_start(flame_nltgv2_ctx* ctx);
 constexpr size_t kMaxChain = 256;  // operations enqueued behind an unchecked persistent run before the host settles it
+
+// records the exchange buffers hold: one per packed vertex slot (the he / tv forms index by packed vertex), more when
+// shadow patches publish copies under record ids of their own
+size_t records_capacity(const PackedLayout& L) {
+  const size_t n_packed = (size_t)L.n_slices * kWave, n_rec = ((size_t)L.n_rec + kWave - 1) / kWave * kWave;
+  return std::max(n_packed, n_rec);
+}
 
 int ensure_canon(flame_nltgv2_ctx* ctx) {
   if (ctx->pending.active) {  // a persistent run is still unchecked: settle it before anything reads or edits the state
@@ -575,7 +585,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   if (form != 0) {
     // tags must stay unique: clear the record buffers long before the 28-bit tag of the XCC table wraps
     if ((uint64_t)ctx->tag_next + (uint64_t)n >= 0x07ff0000ull) {
-      const size_t bytes = kXbufBytesPerVertex * (size_t)ctx->L.n_slices * kWave;
+      const size_t bytes = kXbufBytesPerVertex * records_capacity(ctx->L);
       HIPCHK(ctx, hipMemsetAsync(ctx->xbuf.p, 0, bytes, ctx->stream));
       ctx->tag_next = 1;
     }
@@ -620,7 +630,8 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
                                                                             : kPreSleepHe;
       const unsigned spins_arg = ctx->opt_fault > 0 ? (0x80000000u | (unsigned)ctx->opt_fault) : kMaxSpins;
       if (form == 3) {
-        ctx->f.wg_poll_gap = ctx->opt_poll_gap > 0 ? ctx->opt_poll_gap - 1 : kPvPollGap;
+        ctx->f.wg_poll_gap = (ctx->opt_poll_gap > 0 ? ctx->opt_poll_gap - 1 : kPvPollGap) |
+                             ((ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : kPvPreSleep) << 8);
         ctx->f.probe = nullptr;
         if (ctx->opt_probe) {  // [patch][step][8 words]
           const size_t words = (size_t)ctx->L.wg_count * (size_t)n * 8;
@@ -628,6 +639,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
           if (rc) return rc;
           ctx->f.probe = (unsigned*)ctx->probe.p;
           ctx->probe_words = words;
+          HIPCHK(ctx, hipMemsetAsync(ctx->probe.p, 0, words * sizeof(unsigned), ctx->stream));  // (idle instances write nothing)
         }
       }
       e = launch_persistent_run(ctx->f, to_sp(p), form, gr.begin, gr.count, ctx->parity, tag0, n, pw, spins_arg, presleep, dual,
@@ -827,11 +839,21 @@ int staged_h2d(flame_nltgv2_ctx* ctx, const StageCopy* cp, size_t n, const Stage
   return 0;
 }
 
+// Shadow patches by default: the higher-numbered side of every XCD border, as long as every instance still gets a SIMD of
+// its own (measured, 5 graphs each: 320x240 1.156 -> 1.114 us per iteration, 640x480 1.285 -> 1.239; with more instances
+// than SIMDs -- 1280x720 -- the copies cost more than they save: 1.40 -> 1.52).  An explicit option is taken as it is.
+constexpr int kShadowModeDefault = 1;
+int shadow_mode(const flame_nltgv2_ctx* ctx) { return ctx->opt_shadows ? ctx->opt_shadows - 1 : kShadowModeDefault; }
+int shadow_cap(const flame_nltgv2_ctx* ctx) { return ctx->opt_shadows ? 0x7fffffff : 4 * ctx->prop.multiProcessorCount; }
+
 // Layout + topology arrays of `g` (V, E, pos, src, dst) onto the device; the caller adds the state.  On return the
 // stream still holds the copies: the caller synchronises before the staging buffer or `g`'s arrays may change.
-int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const StageCopy* extra, size_t n_extra) {
+int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const StageCopy* extra, size_t n_extra, bool long_lived) {
   const int32_t V = g->V, E = g->E;
-  int rc = build_layout(g, &ctx->L, /*host_expand=*/false);
+  // Shadow patches cost ~0.2 ms of host work per topology and save ~9 us per 200 iterations: by default only for a
+  // topology that was uploaded to stay (upload_graph), not for the per-frame edits of sync_graph
+  const int sm = (ctx->opt_shadows || long_lived) ? shadow_mode(ctx) : 0;
+  int rc = build_layout(g, &ctx->L, /*host_expand=*/false, sm, shadow_cap(ctx));
   if (rc) return fail(ctx, rc);
   const PackedLayout& L = ctx->L;
   const size_t n_slots = (size_t)(L.rows + kRowPad) * kWave;
@@ -849,7 +871,8 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
       {&ctx->vstate, sizeof(float4) * n_packed}, {&ctx->vaux, sizeof(float2) * n_packed},
       {&ctx->hq_alt, sizeof(float4) * n_slots}, {&ctx->vstate_alt, sizeof(float4) * n_packed}, {&ctx->photo_err, fV},
       {&ctx->bar0, sizeof(float4) * n_packed}, {&ctx->bar1, sizeof(float4) * n_packed},
-      {&ctx->vprev, sizeof(float4) * n_packed}, {&ctx->xbuf, kXbufBytesPerVertex * n_packed + 64},
+      {&ctx->vprev, sizeof(float4) * n_packed}, {&ctx->xbuf, kXbufBytesPerVertex * records_capacity(L) + 64},
+      {&ctx->wg_v0, sizeof(int32_t) * L.wg_v0.size()}, {&ctx->rid_on, sizeof(int32_t) * L.rid_on.size()},
       {&ctx->abort_flag, sizeof(int)}, {&ctx->err, sizeof(int)}, {&ctx->cost_out, 2 * sizeof(float)},
       {&ctx->wg_slot, sizeof(int32_t) * lanes}, {&ctx->wg_vid, sizeof(int32_t) * lanes}, {&ctx->wg_meta, sizeof(uint32_t) * lanes},
       {&ctx->wg_nbr, sizeof(int32_t) * lanes}, {&ctx->wg_fetch, sizeof(int32_t) * lanes},
@@ -869,10 +892,11 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
       {&ctx->slice_row, L.slice_row.data(), sizeof(int32_t) * ((size_t)L.n_slices + 1)},
       {&ctx->perm, L.perm.data(), sizeof(int32_t) * n_packed}, {&ctx->pdeg, L.pdeg.data(), sizeof(int32_t) * n_packed},
       {&ctx->iperm, L.iperm.data(), iV}, {&ctx->order_m, L.order_m.data(), iV}, {&ctx->rid_of, L.rid_of.data(), iV},
-      {&ctx->wg_info, L.wg_info.data(), sizeof(int32_t) * L.wg_info.size()}};
+      {&ctx->wg_info, L.wg_info.data(), sizeof(int32_t) * L.wg_info.size()},
+      {&ctx->wg_v0, L.wg_v0.data(), sizeof(int32_t) * L.wg_v0.size()}, {&ctx->rid_on, L.rid_on.data(), sizeof(int32_t) * L.rid_on.size()}};
   cp.insert(cp.end(), extra, extra + n_extra);
   const StageFill fills[] = {
-      {ctx->err.p, sizeof(int), 0u}, {ctx->abort_flag.p, sizeof(int), 0u}, {ctx->xbuf.p, kXbufBytesPerVertex * n_packed + 64, 0u},
+      {ctx->err.p, sizeof(int), 0u}, {ctx->abort_flag.p, sizeof(int), 0u}, {ctx->xbuf.p, kXbufBytesPerVertex * records_capacity(L) + 64, 0u},
       // empty slots / padding vertices of the second copies: zero, as the packing kernels write them in the first
       {ctx->hq_alt.p, sizeof(float4) * n_slots, 0u}, {ctx->vstate_alt.p, sizeof(float4) * n_packed, 0u},
       // the spare rows behind the last slice: no edge, neighbour 0 (what the unrolled sweeps may read past a slice's end)
@@ -882,7 +906,8 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
   if (rc) return rc;
   LAUNCHCHK(ctx, launch_build_sell(ctx->c, ctx->f, (const int32_t*)ctx->iperm.p, ctx->stream));
   if (L.wg_ok)
-    LAUNCHCHK(ctx, launch_build_patches(ctx->c, ctx->f, (const int32_t*)ctx->order_m.p, (const int32_t*)ctx->rid_of.p,
+    LAUNCHCHK(ctx, launch_build_patches(ctx->c, ctx->f, (const int32_t*)ctx->wg_v0.p, (const int32_t*)ctx->order_m.p,
+                                        (const int32_t*)(L.wg_per_xcd ? ctx->rid_on.p : ctx->rid_of.p), L.wg_per_xcd,
                                         (const int32_t*)ctx->iperm.p, ctx->stream));
   ctx->pending = flame_nltgv2_ctx::PendingRun{};
   ctx->tag_next = 1;
@@ -896,6 +921,23 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
 // the current topology (single frames run in the patch-per-wave form and never need them).
 int ensure_form_rows(flame_nltgv2_ctx* ctx, int form) {
   PackedLayout& L = ctx->L;
+  if (form == 1 && !ctx->he_built && L.wg_per_xcd > 0) {
+    // a shadow layout holds more instances than the walk has patches: (C) comes from the host's own walk then
+    build_he_rows(&L);
+    struct { DevBuf* b; const void* src; size_t bytes; } cp[] = {
+        {&ctx->he_slot, L.he_slot.data(), sizeof(int32_t) * L.he_slot.size()}, {&ctx->he_vid, L.he_vid.data(), sizeof(int32_t) * L.he_vid.size()},
+        {&ctx->he_meta, L.he_meta.data(), sizeof(uint32_t) * L.he_meta.size()},
+        {&ctx->he_wave_chain, L.he_wave_chain.data(), sizeof(int32_t) * L.he_wave_chain.size()}};
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (a buffer may be reallocated)
+    for (auto& c : cp) {
+      int rc = ensure(ctx, *c.b, c.bytes);
+      if (!rc) rc = h2d(ctx, *c.b, c.src, c.bytes);
+      if (rc) return rc;
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->he_built = true;
+    refresh_args(ctx);
+  }
   if (form == 1 && !ctx->he_built) {
     // (C) is (E) lane for lane (the same greedy walk): converted on the device from the patch rows, no host work
     const size_t lanes = (size_t)L.wg_count * kWave;
@@ -990,7 +1032,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
               &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->xbuf, &ctx->abort_flag, &ctx->he_slot, &ctx->he_vid, &ctx->he_meta, &ctx->he_wave_chain, &ctx->tv_slot, &ctx->tv_vid, &ctx->tv_meta, &ctx->tv_wave, &ctx->err,
               &ctx->cost_out, &ctx->img_ref, &ctx->img_cmp, &ctx->photo_err, &ctx->r_tris, &ctx->r_valid, &ctx->r_keys,
               &ctx->r_img, &ctx->r_cov, &ctx->r_vtx, &ctx->r_val, &ctx->wg_slot, &ctx->wg_vid, &ctx->wg_meta, &ctx->wg_nbr,
-              &ctx->wg_fetch, &ctx->wg_info, &ctx->probe, &ctx->snap_hq, &ctx->snap_vstate, &ctx->snap_bar, &ctx->iperm,
+              &ctx->wg_fetch, &ctx->wg_info, &ctx->wg_v0, &ctx->rid_on, &ctx->probe, &ctx->snap_hq, &ctx->snap_vstate, &ctx->snap_bar, &ctx->iperm,
               &ctx->order_m, &ctx->rid_of, &ctx->d_stage, &ctx->sync_init, &ctx->sync_vmap, &ctx->sync_emap, &ctx->sync_need};
   for (auto& b : ctx->sp_v) ctx->all.push_back(&b);
   for (auto& b : ctx->sp_q) ctx->all.push_back(&b);
@@ -1041,8 +1083,12 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
       if (value < 0 || value > 4) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_persistent = value;
       return 0;
+    case FLAME_NLTGV2_OPT_SHADOWS:
+      if (value < 0 || value > 3) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_shadows = value;
+      return 0;
     case FLAME_NLTGV2_OPT_POLL_GAP:
-      if (value < 0 || value > 4) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      if (value < 0 || value > 7) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_poll_gap = value;
       return 0;
     case FLAME_NLTGV2_OPT_VERIFY_RECORDS:
@@ -1116,7 +1162,7 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
       {&ctx->w2p, g->w2_prev ? g->w2_prev : g->w2, fV}, {&ctx->data, g->data_term, fV},
       {&ctx->weight, g->data_weight, fV}, {&ctx->alpha, g->alpha, fE}, {&ctx->beta, g->beta, fE}, {&ctx->q1, g->q1, fE},
       {&ctx->q2, g->q2, fE}, {&ctx->q3, g->q3, fE}};
-  rc = upload_topology(ctx, g, state, sizeof(state) / sizeof(state[0]));
+  rc = upload_topology(ctx, g, state, sizeof(state) / sizeof(state[0]), /*long_lived=*/true);
   if (rc) return rc;
   const auto t_packed = std::chrono::steady_clock::now();
   LAUNCHCHK(ctx, launch_pack_static(ctx->c, ctx->f, ctx->stream));
@@ -1283,7 +1329,7 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
       {&ctx->sync_init, in->init_x, in->init_x ? fV : 0},
       {&ctx->sync_vmap, old_of_new.data(), sizeof(int32_t) * (size_t)V},
       {&ctx->sync_emap, old_of_new_edge.data(), sizeof(int32_t) * (size_t)En}};
-  rc = upload_topology(ctx, &g, extra, sizeof(extra) / sizeof(extra[0]));
+  rc = upload_topology(ctx, &g, extra, sizeof(extra) / sizeof(extra[0]), /*long_lived=*/false);
   if (rc) return rc;
   SyncArgs sa;
   sa.V = V, sa.E = En;
@@ -1744,13 +1790,13 @@ int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info) {
   std::snprintf(info->device_name, sizeof(info->device_name), "%s", ctx->prop.name);
   std::snprintf(info->gcn_arch, sizeof(info->gcn_arch), "%s", ctx->prop.gcnArchName);
   info->last_run_path = ctx->last_run_path;
-  info->he_waves = ctx->L.wg_ok ? ctx->L.wg_count : 0;  // (the same greedy walk as the patches)
+  info->he_waves = ctx->L.wg_ok ? ctx->L.wg_prim : 0;  // (the same greedy walk as the patches)
   if (ctx->have_graph && !ctx->tv_built) {  // the vertex-per-lane rows are built on demand; a caller sizing a batch asks here
     ctx->L.tv_waves = 0;
     build_tv_rows(&ctx->L);  // host table only; the upload happens when the form is first used
   }
   info->tv_waves = ctx->L.tv_ok ? ctx->L.tv_waves : 0;
-  info->patches = ctx->L.wg_ok ? ctx->L.wg_count : 0;
+  info->patches = ctx->L.wg_ok ? ctx->L.wg_count : 0;  // (instances: with shadow patches more than the walk's patches)
   info->tv_wave_capacity = (ctx->opt_tv_lds ? kTvLdsWavesPerCu : kTvWavesPerCu) * ctx->prop.multiProcessorCount;
   info->last_run_groups = ctx->last_run_groups;
   info->timeouts_recovered = ctx->timeouts_recovered;
@@ -1794,7 +1840,7 @@ int flame_nltgv2_layout_selftest(flame_nltgv2_ctx* ctx, int64_t* mismatches) {
   flame_nltgv2_graph g{};
   g.V = V, g.E = E, g.pos = pos.data(), g.src = ctx->h_src.data(), g.dst = ctx->h_dst.data();
   PackedLayout H;
-  rc = build_layout(&g, &H, /*host_expand=*/true);
+  rc = build_layout(&g, &H, /*host_expand=*/true, ctx->L.shadow_mode);  // (the mode the layout was actually built with)
   if (rc) return fail(ctx, rc);
   int64_t bad = 0;
   auto cmp = [&](const DevBuf& b, const void* host, size_t bytes) -> int {
@@ -1807,7 +1853,8 @@ int flame_nltgv2_layout_selftest(flame_nltgv2_ctx* ctx, int64_t* mismatches) {
   };
   const PackedLayout& L = ctx->L;
   bad += (H.rows != L.rows) + (H.n_slices != L.n_slices) + (H.wg_ok != L.wg_ok) + (H.wg_count != L.wg_count) +
-         (H.wg_lcap != L.wg_lcap) + (H.wg_slab_slots != L.wg_slab_slots);
+         (H.wg_lcap != L.wg_lcap) + (H.wg_slab_slots != L.wg_slab_slots) + (H.n_rec != L.n_rec) + (H.wg_per_xcd != L.wg_per_xcd) +
+         (H.wg_v0 != L.wg_v0) + (H.rid_on != L.rid_on);
   if (bad == 0) {
     const size_t n = (size_t)L.rows * kWave, lanes = (size_t)L.wg_count * kWave;
     int e = cmp(ctx->rec_nbr, H.rec_nbr.data(), 4 * n) | cmp(ctx->rec_edge, H.rec_edge.data(), 4 * n) |
@@ -1818,8 +1865,9 @@ int flame_nltgv2_layout_selftest(flame_nltgv2_ctx* ctx, int64_t* mismatches) {
            cmp(ctx->wg_meta, H.wg_meta.data(), 4 * lanes) | cmp(ctx->wg_nbr, H.wg_nbr.data(), 4 * lanes) |
            cmp(ctx->wg_fetch, H.wg_fetch.data(), 4 * lanes) | cmp(ctx->wg_info, H.wg_info.data(), 4 * H.wg_info.size());
     if (ctx->he_built)  // (C), converted on the device from (E), against the host's own walk
-      e |= cmp(ctx->he_slot, H.he_slot.data(), 4 * lanes) | cmp(ctx->he_vid, H.he_vid.data(), 4 * lanes) |
-           cmp(ctx->he_meta, H.he_meta.data(), 4 * lanes) | cmp(ctx->he_wave_chain, H.he_wave_chain.data(), 4 * H.he_wave_chain.size());
+      e |= cmp(ctx->he_slot, H.he_slot.data(), 4 * H.he_slot.size()) | cmp(ctx->he_vid, H.he_vid.data(), 4 * H.he_vid.size()) |
+           cmp(ctx->he_meta, H.he_meta.data(), 4 * H.he_meta.size()) |
+           cmp(ctx->he_wave_chain, H.he_wave_chain.data(), 4 * H.he_wave_chain.size());
     if (ctx->he_built) bad += (H.he_waves != L.he_waves) + (H.he_max_chain != L.he_max_chain) + (H.comp_he_wave != L.comp_he_wave);
     if (e) return fail(ctx, FLAME_NLTGV2_ERR_HIP);
   }

@@ -595,13 +595,14 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
                 const float4* hq, const float4* vstate,
                 float4* hq_out, float4* vstate_out, const float2* vaux, const float4* bar_in, float4* bar_out, float4* vprev,
                 void* xbuf, const int rec_bytes, const int dual_arg, const unsigned tag0, const int n_iters,
-                const unsigned max_spins_arg, const int poll_gap, const SolverParams p,
+                const unsigned max_spins_arg, const int poll_gap_arg, const SolverParams p,
                 int* __restrict__ err, int* __restrict__ abort_flag, const int32_t* __restrict__ perm,
                 const RunTail* __restrict__ tail, unsigned* __restrict__ probe) {
   extern __shared__ float4 lds[];
   constexpr int T = 64;
   const unsigned max_spins = max_spins_arg & 0x7fffffffu;
   const int dual = dual_arg & 1, verify = dual_arg >> 1;  // as in k_persistent_he
+  const int poll_gap = poll_gap_arg & 255, pv_presleep = poll_gap_arg >> 8;
   const int lane = (int)threadIdx.x;
   const int b = blockIdx.x;
   const int xcd = b & 7, idx = b >> 3;
@@ -609,6 +610,10 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   if (xcd * wgs_per_xcd + idx >= n_wgs) return;
   const int wg = wg_begin + xcd * wgs_per_xcd + idx;  // this launch covers patches [wg_begin, +n_wgs)
   const int rid_base = wg_info[4 * wg], n_fetch = wg_info[4 * wg + 1];
+  const int count_flags = wg_info[4 * wg + 2];
+  if ((count_flags & 0xffff) == 0) return;                 // idle padding behind an XCD's instances (shadow layouts)
+  const bool shadow = (count_flags & (1 << 16)) != 0;      // a second copy of a patch on another XCD: computes and
+                                                           // publishes like the original, writes no state back
   // Contribution slab: `stride` slots per vertex of this patch (its largest degree rounded up to a multiple of 4, at least 8); the
   // slots a vertex does not use hold -0.0f for the whole run, so the accumulation needs no predication.
   const int stride = wg_info[4 * wg + 3];
@@ -743,6 +748,9 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
     // ---- wait for the neighbours' records of step s ----------------------------------------------------------------
     v4f_t nbv;  // the tag word is read first, the record after it: a tag that matches vouches for the payload
     unsigned rounds = 0;
+    // no record can be here sooner than one hand-off after its producer's previous publish: polls before that only load
+    // the L2s and the fabric (pv_presleep x 64 cycles, fixed per launch)
+    for (int z = 0; z < pv_presleep; ++z) __builtin_amdgcn_s_sleep(1);
     {
       unsigned outer = 0;
       for (;;) {
@@ -809,8 +817,14 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
           PV_POLL("sc1", "s_sleep 1\n\t");
         } else if (poll_gap == 2) {
           PV_POLL_N("sc1", "");
-        } else {
+        } else if (poll_gap == 3) {
           PV_POLL_N("sc1", "s_sleep 1\n\t");
+        } else if (poll_gap == 4) {  // at most 1 / 2 / 3 poll loads in flight
+          PV_POLL_N("sc1", "s_waitcnt vmcnt(0)\n\t");
+        } else if (poll_gap == 5) {
+          PV_POLL_N("sc1", "s_sleep 1\n\ts_waitcnt vmcnt(1)\n\t");
+        } else {
+          PV_POLL_N("sc1", "s_sleep 1\n\ts_waitcnt vmcnt(2)\n\t");
         }
 #undef PV_POLL
 #undef PV_POLL_N
@@ -963,6 +977,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
     return;
   }
 
+  if (shadow) return;
   if (is_tail) {
     vstate_out[pv] = make_float4(x, w12.x, w12.y, data);
     bar_out[pv] = make_float4(xb, wb12.x, wb12.y, 0.0f);
@@ -1711,7 +1726,7 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
   float4* bout = a.bar[parity_in ^ 1];  // always the other buffer: the input of a failed run stays intact
   float4* vprev = a.vprev;
   void* xbuf = a.xbuf;
-  int rec_bytes = a.n_slices * 64 * 16;
+  int rec_bytes = (a.n_rec > a.n_slices * 64 ? a.n_rec : a.n_slices * 64) * 16;
   SolverParams pp = p;
   int* err = a.err;
   int* abort_flag = a.abort_flag;

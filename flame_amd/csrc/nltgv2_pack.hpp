@@ -95,9 +95,24 @@ struct PackedLayout {
   std::vector<uint32_t> wg_meta;       // [wg_count*64] first lane | deg<<6 | local index<<13 | flags<<24
   std::vector<int32_t> wg_nbr;         // [wg_count*64] neighbour: local index, or 0x80000000 | fetch index
   std::vector<int32_t> wg_fetch;       // [wg_count*64] record id fetched by this lane, -1 none
-  std::vector<int32_t> wg_info;        // [wg_count*4] first record id, fetched records, local vertices, slab stride
+  std::vector<int32_t> wg_info;        // [wg_count*4] first record id, fetched records, local vertices (| kWgShadow), slab stride
   std::vector<int32_t> comp_wg;        // [n_comp+1] first patch of each component
+  // Shadow patches (shadow_mode > 0, 65..2048 patches: graphs that run resident as a whole, spread over all XCDs): the chip is eight XCDs and a record
+  // crosses from one to another ~0.25 us later than it reaches a reader on its own XCD; the lock-step network runs at its
+  // worst cycle mean, and today that is a pair of patches on two XCDs reading each other.  A patch next to the border is
+  // therefore ALSO computed by a second wave on the neighbouring XCD (same vertices, same inputs, same instructions ->
+  // bit-identical records under its own record ids), and that XCD's patches read the copy instead of the original: the
+  // cycles through the border then contain one crossing per two (mode 1: only the higher-numbered side is shadowed) or
+  // three (mode 2: both sides) hand-offs instead of a crossing per hand-off.  Instances are ordered XCD by XCD (the XCD's
+  // own patches in walk order, then its shadows, then idle padding), wg_per_xcd each; a shadow does not write state back.
+  int32_t shadow_mode = 0;
+  int32_t wg_prim = 0;                 // patches of the walk (wg_count - shadows - padding)
+  int32_t wg_per_xcd = 0;              // instances per XCD when shadows exist, else 0
+  int32_t n_rec = 0;                   // record ids in use: V + shadow vertices
+  std::vector<int32_t> wg_v0;          // [wg_count] walk position of the instance's first vertex (= first record id for a primary)
+  std::vector<int32_t> rid_on;         // [8*V] with shadows: the record id an instance on XCD k reads for vertex u (k*V + u)
 };
+constexpr int32_t kWgShadow = 1 << 16;  // in wg_info[4p+2]
 constexpr uint32_t kWgTail = 1u << 24, kWgActive = 1u << 25, kWgValid = 1u << 26, kWgPublish = 1u << 27;
 constexpr int kTvSlots = 8;
 constexpr uint32_t kTvOwner = 1u << 16, kTvValid = 1u << 17;
@@ -227,7 +242,8 @@ inline void build_tv_rows(PackedLayout* L) {
 
 // ---- (E) patch-per-wave rows ------------------------------------------------------------------------
 // order_m = the vertices in (component, Morton) order; needs (B) (iperm, pdeg, slice_row, rec_nbr) and comp_start.
-inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const std::vector<int32_t>& order_m, bool host_expand) {
+inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const std::vector<int32_t>& order_m, bool host_expand,
+                             int shadow_mode = 0, int shadow_max_instances = 0x7fffffff) {
   (void)g;
   const int32_t V = L->V;
   constexpr int32_t T = kWave;
@@ -235,6 +251,8 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
   L->wg_count = 0, L->wg_lcap = 0, L->wg_rcap = 0, L->wg_slab_slots = 0;
   L->wg_slot.clear(), L->wg_vid.clear(), L->wg_meta.clear(), L->wg_nbr.clear(), L->wg_fetch.clear();
   L->wg_info.clear(), L->comp_wg.clear();
+  L->shadow_mode = 0, L->wg_prim = 0, L->wg_per_xcd = 0, L->n_rec = V;
+  L->wg_v0.clear(), L->rid_on.clear();
   if (L->max_degree > kWave || V <= 0) return;
   L->wg_info.reserve(((static_cast<size_t>(2) * L->E + V) * 9 / 8 / T + L->comp_start.size() + 2) * 4);
   // pass 1 (host, per vertex): the greedy walk of (C) -- a vertex's lanes never straddle two waves, a component begins a
@@ -268,6 +286,90 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
   }
   close_patch();
   L->comp_wg.push_back(L->wg_count);
+  L->wg_prim = L->wg_count;
+  L->wg_v0.resize(static_cast<size_t>(L->wg_count));
+  for (int32_t q = 0; q < L->wg_count; ++q) L->wg_v0[static_cast<size_t>(q)] = L->wg_info[static_cast<size_t>(q) * 4];
+  constexpr int32_t kXcds = 8;
+  // (graphs that are resident as a whole anyway -- components are then not needed for grouping; not the one-XCD sizes)
+  if (shadow_mode > 0 && L->wg_count > 2 * 32 && L->wg_count <= 2048) {
+    // ---- shadow patches (see PackedLayout) -----------------------------------------------------------------------
+    const int32_t P = L->wg_count;
+    std::vector<int32_t> patch_of_pos(static_cast<size_t>(V));
+    for (int32_t q = 0; q < P; ++q) {
+      const int32_t r0 = L->wg_info[static_cast<size_t>(q) * 4], n = L->wg_info[static_cast<size_t>(q) * 4 + 2];
+      for (int32_t j = 0; j < n; ++j) patch_of_pos[static_cast<size_t>(r0 + j)] = q;
+    }
+    // XCD k owns the patches [cut[k], cut[k+1]) of the walk.  Shadows land unevenly (an XCD in the middle of the image has
+    // more borders), and a wave wants a SIMD of its own (an XCD has 128): the cuts are moved until own patches + shadows
+    // are about the same everywhere.
+    int32_t cut[kXcds + 1];
+    for (int32_t k = 0; k <= kXcds; ++k) cut[k] = static_cast<int32_t>(static_cast<int64_t>(P) * k / kXcds);
+    std::vector<uint8_t> region(static_cast<size_t>(P)), need(static_cast<size_t>(P));
+    int32_t per[kXcds], most = 0, total = P;
+    for (int round = 0; round < 4; ++round) {
+      for (int32_t k = 0; k < kXcds; ++k)
+        for (int32_t q = cut[k]; q < cut[k + 1]; ++q) region[static_cast<size_t>(q)] = static_cast<uint8_t>(k);
+      std::fill(need.begin(), need.end(), static_cast<uint8_t>(0));  // bit k: XCD k holds a patch that reads this one
+      for (int32_t q = 0; q < P; ++q) {
+        const int32_t m = region[static_cast<size_t>(q)], r0 = L->wg_info[static_cast<size_t>(q) * 4], n = L->wg_info[static_cast<size_t>(q) * 4 + 2];
+        for (int32_t j = 0; j < n; ++j) {
+          const int32_t o = order_m[static_cast<size_t>(r0 + j)];
+          for (int32_t h = L->row_ptr[o]; h < L->row_ptr[o + 1]; ++h) {
+            const int32_t k = region[static_cast<size_t>(patch_of_pos[static_cast<size_t>(L->rid_of[static_cast<size_t>(L->half_nbr[h])])])];
+            if (k != m && (shadow_mode >= 2 || k < m)) need[static_cast<size_t>(q)] |= static_cast<uint8_t>(1u << k);
+          }
+        }
+      }
+      int32_t shadows[kXcds];
+      most = 0, total = P;
+      for (int32_t k = 0; k < kXcds; ++k) {
+        shadows[k] = 0;
+        for (int32_t q = 0; q < P; ++q) shadows[k] += (need[static_cast<size_t>(q)] >> k) & 1;
+        per[k] = cut[k + 1] - cut[k] + shadows[k];
+        most = std::max(most, per[k]);
+        total += shadows[k];
+      }
+      if (round == 3) break;
+      // next cuts: every XCD gets total/8 instances, its own share being that minus the shadows it hosts now
+      int32_t at = 0;
+      for (int32_t k = 0; k < kXcds; ++k) {
+        cut[k] = at;
+        const int32_t want = static_cast<int32_t>(static_cast<int64_t>(total) * (k + 1) / kXcds - static_cast<int64_t>(total) * k / kXcds);
+        at = std::min(P, at + std::max(1, want - shadows[k]));
+      }
+      cut[kXcds] = P;
+      for (int32_t k = kXcds - 1; k > 0 && cut[k] > cut[k + 1] - 1; --k) cut[k] = std::max(k, cut[k + 1] - 1);  // (no empty XCD)
+    }
+    // (a wave wants a SIMD of its own: where the copies would not fit next to the originals they cost more than they save)
+    if (total <= shadow_max_instances) {
+      std::vector<int32_t> info(static_cast<size_t>(kXcds) * most * 4, 0), v0(static_cast<size_t>(kXcds) * most, 0);
+      L->rid_on.resize(static_cast<size_t>(kXcds) * V);
+      for (int32_t k = 0; k < kXcds; ++k)
+        for (int32_t u = 0; u < V; ++u) L->rid_on[static_cast<size_t>(k) * V + u] = L->rid_of[static_cast<size_t>(u)];
+      int32_t next_rid = V;
+      for (int32_t k = 0; k < kXcds; ++k) {
+        int32_t at = k * most;
+        for (int32_t q = cut[k]; q < cut[k + 1]; ++q, ++at) {
+          for (int c = 0; c < 4; ++c) info[static_cast<size_t>(at) * 4 + c] = L->wg_info[static_cast<size_t>(q) * 4 + c];
+          v0[static_cast<size_t>(at)] = L->wg_info[static_cast<size_t>(q) * 4];
+        }
+        for (int32_t q = 0; q < P; ++q) {
+          if (!((need[static_cast<size_t>(q)] >> k) & 1)) continue;
+          const int32_t r0 = L->wg_info[static_cast<size_t>(q) * 4], n = L->wg_info[static_cast<size_t>(q) * 4 + 2];
+          info[static_cast<size_t>(at) * 4] = next_rid;
+          info[static_cast<size_t>(at) * 4 + 2] = n | kWgShadow;
+          info[static_cast<size_t>(at) * 4 + 3] = L->wg_info[static_cast<size_t>(q) * 4 + 3];
+          v0[static_cast<size_t>(at)] = r0;
+          for (int32_t j = 0; j < n; ++j) L->rid_on[static_cast<size_t>(k) * V + order_m[static_cast<size_t>(r0 + j)]] = next_rid + j;
+          next_rid += n;
+          ++at;
+        }
+      }
+      L->wg_info.swap(info), L->wg_v0.swap(v0);
+      L->wg_count = kXcds * most, L->wg_per_xcd = most, L->n_rec = next_rid, L->shadow_mode = shadow_mode;
+      L->comp_wg.assign({0, L->wg_count});
+    }
+  }
   if (host_expand) {
     // pass 2 (the device does this in k_build_patch, nltgv2_layout.hip): the 64 lanes of every patch and its fetch list.
     // A neighbour is local iff its record id lies in the patch's range; the others are fetched -- one lane per DISTINCT
@@ -275,16 +377,19 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
     const size_t lanes = static_cast<size_t>(L->wg_count) * T;
     L->wg_slot.assign(lanes, -1), L->wg_vid.assign(lanes, -1), L->wg_meta.assign(lanes, 0u), L->wg_nbr.assign(lanes, 0);
     L->wg_fetch.assign(lanes, -1);
-    const std::vector<int32_t>& rid_of = L->rid_of;
     int32_t want[kWave];
     for (int32_t wg = 0; wg < L->wg_count; ++wg) {
       const size_t b = static_cast<size_t>(wg) * T;
-      const int32_t r0 = L->wg_info[static_cast<size_t>(wg) * 4], r1 = r0 + L->wg_info[static_cast<size_t>(wg) * 4 + 2];
+      const int32_t r0 = L->wg_info[static_cast<size_t>(wg) * 4];
+      const int32_t n_loc = L->wg_info[static_cast<size_t>(wg) * 4 + 2] & 0xffff, r1 = r0 + n_loc;
+      const int32_t v0 = L->wg_v0[static_cast<size_t>(wg)];
+      // the record an instance on this XCD reads for a vertex: its own XCD's copy where there is one
+      const int32_t* rid = L->wg_per_xcd ? &L->rid_on[static_cast<size_t>(wg / L->wg_per_xcd) * V] : L->rid_of.data();
       int32_t n_want = 0;
-      for (int32_t i = r0; i < r1; ++i) {
-        const int32_t o = order_m[i];
+      for (int32_t i = 0; i < n_loc; ++i) {
+        const int32_t o = order_m[v0 + i];
         for (int32_t h = L->row_ptr[o]; h < L->row_ptr[o + 1]; ++h) {
-          const int32_t r = rid_of[static_cast<size_t>(L->half_nbr[h])];
+          const int32_t r = rid[L->half_nbr[h]];
           if (r < r0 || r >= r1) want[n_want++] = r;
         }
       }
@@ -294,19 +399,19 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
       L->wg_info[static_cast<size_t>(wg) * 4 + 1] = n_want;
       L->wg_rcap = std::max(L->wg_rcap, n_want);
       int32_t lane = 0;
-      for (int32_t i = r0; i < r1; ++i) {
-        const int32_t o = order_m[i];
+      for (int32_t i = 0; i < n_loc; ++i) {
+        const int32_t o = order_m[v0 + i];
         const int32_t s = L->iperm[o];
         const int32_t d = L->row_ptr[o + 1] - L->row_ptr[o], need = std::max(d, 1);
         const int64_t row0 = L->slice_row[s / kWave];
         bool publishes = false;
         for (int32_t k = 0; k < need; ++k) {
-          uint32_t m = static_cast<uint32_t>(lane) | (static_cast<uint32_t>(d) << 6) | (static_cast<uint32_t>(i - r0) << 13) | kWgValid;
+          uint32_t m = static_cast<uint32_t>(lane) | (static_cast<uint32_t>(d) << 6) | (static_cast<uint32_t>(i) << 13) | kWgValid;
           if (k == need - 1) m |= kWgTail;
           if (k < d) {
             m |= kWgActive;
             L->wg_slot[b + lane + k] = static_cast<int32_t>((row0 + k) * kWave + (s % kWave));
-            const int32_t r = rid_of[static_cast<size_t>(L->half_nbr[L->row_ptr[o] + k])];
+            const int32_t r = rid[L->half_nbr[L->row_ptr[o] + k]];
             if (r >= r0 && r < r1) {
               L->wg_nbr[b + lane + k] = r - r0;
             } else {
@@ -331,7 +436,8 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
 // walk); the per-slot / per-lane arrays of (B) and (E) are then produced on the device (nltgv2_layout.hip) and (C), (D)
 // on demand.  host_expand = true: everything here -- the reference the device expansion is checked against, and what the
 // CPU test-suite looks at.
-inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L, bool host_expand = true) {
+inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L, bool host_expand = true, int shadow_mode = 0,
+                        int shadow_max_instances = 0x7fffffff) {
   if (!g || g->V < 0 || g->E < 0) return FLAME_NLTGV2_ERR_INVALID_ARG;
   const int32_t V = g->V, E = g->E;
   if (V > 0 && !g->pos) return FLAME_NLTGV2_ERR_INVALID_ARG;
@@ -512,7 +618,7 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L, bool host_
   PROF_T(4);
   if (host_expand) build_tv_rows(L);
   PROF_T(5);
-  build_patch_rows(g, L, order_m, host_expand);
+  build_patch_rows(g, L, order_m, host_expand, shadow_mode, shadow_max_instances);
   PROF_T(6);
   return FLAME_NLTGV2_OK;
 }

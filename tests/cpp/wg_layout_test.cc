@@ -118,10 +118,11 @@ static float prox_l1(float x_min, float x_max, float step_x, float w, float x, f
 
 struct Rec { float xb, w1b, w2b; unsigned tag; };
 
-static int replay(HostGraph& hg, int n_iters, const nltgv2_params& p) {
+static int replay(HostGraph& hg, int n_iters, const nltgv2_params& p, int shadow_mode) {
   flame_nltgv2_graph g = hg.view();
   PackedLayout L;
-  if (build_layout(&g, &L) != 0 || !L.wg_ok) return 1;
+  if (build_layout(&g, &L, true, shadow_mode) != 0 || !L.wg_ok) return 1;
+  if (shadow_mode > 0 && L.wg_prim > 64 && L.wg_prim <= 2048 && L.wg_per_xcd == 0) return 15;  // shadows expected at this size
   const int T = 64, V = g.V;
   // structural invariants
   std::vector<int> seen(L.n_slices * 64, 0);
@@ -136,13 +137,14 @@ static int replay(HostGraph& hg, int n_iters, const nltgv2_params& p) {
       if (k < 0 || k >= need) return 3;
       if (((m & kWgTail) != 0) != (k == need - 1)) return 4;
       if (((m & kWgActive) != 0) != (k < deg)) return 5;
-      if (m & kWgTail) seen[L.wg_vid[hl]]++;
-      if ((int)((m >> 13) & 2047) >= L.wg_info[4 * wg + 2] || L.wg_info[4 * wg + 2] > L.wg_lcap) return 6;
+      if ((m & kWgTail) && !(L.wg_info[4 * wg + 2] & kWgShadow)) seen[L.wg_vid[hl]]++;
+      if ((int)((m >> 13) & 2047) >= (L.wg_info[4 * wg + 2] & 0xffff) || (L.wg_info[4 * wg + 2] & 0xffff) > L.wg_lcap) return 6;
     }
     if (L.wg_info[4 * wg + 1] > L.wg_rcap || L.wg_info[4 * wg + 1] > T) return 7;
     {  // slab stride: a multiple of 4, at least 8, covers the patch's largest degree, and fits the LDS sizing figure
       const int stride = L.wg_info[4 * wg + 3];
-      if (stride < 8 || (stride & 3) || (stride + 1) * L.wg_info[4 * wg + 2] > L.wg_slab_slots) return 13;
+      if ((L.wg_info[4 * wg + 2] & 0xffff) == 0) continue;  // idle padding of a shadow layout
+      if (stride < 8 || (stride & 3) || (stride + 1) * (L.wg_info[4 * wg + 2] & 0xffff) > L.wg_slab_slots) return 13;
       for (int t = 0; t < T; ++t)
         if ((L.wg_meta[(size_t)wg * T + t] & kWgValid) && (int)((L.wg_meta[(size_t)wg * T + t] >> 6) & 127) > stride) return 14;
     }
@@ -156,7 +158,7 @@ static int replay(HostGraph& hg, int n_iters, const nltgv2_params& p) {
   const size_t NL = (size_t)L.wg_count * T;
   struct Lane { float x, w1, w2, xb, w1b, w2b, xp, w1p, w2p, q1, q2, q3; };
   std::vector<Lane> ln(NL);
-  std::vector<Rec> glob[2] = {std::vector<Rec>(V, Rec{0, 0, 0, 0}), std::vector<Rec>(V, Rec{0, 0, 0, 0})};
+  std::vector<Rec> glob[2] = {std::vector<Rec>(L.n_rec, Rec{0, 0, 0, 0}), std::vector<Rec>(L.n_rec, Rec{0, 0, 0, 0})};
   const int stride = L.wg_lcap + L.wg_rcap;
   std::vector<Rec> area[2] = {std::vector<Rec>((size_t)L.wg_count * stride), std::vector<Rec>((size_t)L.wg_count * stride)};
   auto edge_of = [&](int slot) { return L.rec_edge[slot]; };
@@ -272,21 +274,22 @@ static int replay(HostGraph& hg, int n_iters, const nltgv2_params& p) {
   long pub = 0, fetch = 0;
   for (size_t hl = 0; hl < NL; ++hl) pub += (L.wg_meta[hl] & (kWgTail | kWgPublish)) == (kWgTail | kWgPublish);
   for (int wg = 0; wg < L.wg_count; ++wg) fetch += L.wg_info[4 * wg + 1];
-  std::printf("V=%d E=%d patches=%d lcap=%d rcap=%d slab slots=%d publishing=%ld fetched/step=%ld (half-edges %d) ok\n", V, g.E,
-              L.wg_count, L.wg_lcap, L.wg_rcap, L.wg_slab_slots, pub, fetch, 2 * g.E);
+  std::printf("V=%d E=%d shadows=%d instances=%d (walk %d, per XCD %d) records=%d lcap=%d rcap=%d slab slots=%d publishing=%ld fetched/step=%ld (half-edges %d) ok\n",
+              V, g.E, shadow_mode, L.wg_count, L.wg_prim, L.wg_per_xcd, L.n_rec, L.wg_lcap, L.wg_rcap, L.wg_slab_slots, pub, fetch, 2 * g.E);
   return 0;
 }
 
 int main() {
   const nltgv2_params p = {0.1f, 0.001f, 125.0f, 0.25f, 0.0f, 10.0f};
-  for (int frames : {1, 3}) {
-    HostGraph g = make_graph(61, 47, frames, 1234 + frames);
-    const int rc = replay(g, 6, p);
-    if (rc) {
-      std::printf("FAILED frames=%d rc=%d\n", frames, rc);
-      return 1;
+  for (int frames : {1, 3})
+    for (int shadow_mode : {0, 1, 2}) {
+      HostGraph g = make_graph(61, 47, frames, 1234 + frames);
+      const int rc = replay(g, 6, p, shadow_mode);
+      if (rc) {
+        std::printf("FAILED frames=%d shadows=%d rc=%d\n", frames, shadow_mode, rc);
+        return 1;
+      }
     }
-  }
   std::printf("all ok\n");
   return 0;
 }

@@ -153,12 +153,14 @@ def test_internal_steps_individually(env):
     [(5, 2), (9, 1)], [(5, 2), (9, 2)], [(5, 2), (9, 4)], [(5, 2), (9, 8)], [(5, 3), (9, 1)], [(5, 2), (8, 1)], [(5, 2), (8, 21)],
     [(5, 3), (8, 9)], [(5, 2), (9, 1), (6, 0)],
     [(5, 4)], [(5, 4), (6, 0)], [(5, 4), (6, 2)], [(5, 4), (9, 1)], [(5, 4), (9, 2)], [(5, 4), (9, 8)], [(5, 4), (13, 1)], [(5, 4), (13, 2)], [(5, 4), (13, 3)], [(5, 4), (13, 4)],
-    [(5, 4), (9, 1), (6, 0), (13, 1)], [(5, 4), (12, 1)],
+    [(5, 4), (9, 1), (6, 0), (13, 1)], [(5, 4), (12, 1)], [(5, 4), (15, 2)], [(5, 4), (15, 3)], [(5, 4), (15, 3), (6, 0)],
+    [(5, 2), (15, 3)], [(5, 3), (15, 2)],
 ])
 def test_launch_configurations_are_bit_identical(env, opts):
     """waves per workgroup (opt 3), slot chunk (opt 4), hipGraph on/off (opt 2), persistent single
     launch vs one launch per step (opt 5), same-XCD L2 exchange on/off (opt 6), slot constants in LDS (opt 7), the pre-poll sleep (opt 8) and the number of
-    XCDs a persistent launch is spread over (opt 9), the poll pause and the cycle probe of the patch-per-wave form (opts 13, 12) never change a bit."""
+    XCDs a persistent launch is spread over (opt 9), the poll pause and the cycle probe of the patch-per-wave form (opts 13, 12) and shadow
+    patches across the XCD borders (opt 15, also under the other forms, which ignore them) never change a bit."""
     flame_amd, oracle = env
     g = synth.make_graph("320x240", seed=3)
     ref, _ = cpu_run(oracle, g, 21)
@@ -635,3 +637,36 @@ def test_randomized_run_sequences(env, trial):
         sm, dc = reg.costs(p)
         rs, rd = oracle.costs(ref, rp)
         assert np.float32(sm) == np.float32(rs) and np.float32(dc) == np.float32(rd)
+
+
+@pytest.mark.parametrize("config,shadows", [("320x240", 2), ("320x240", 3), ("640x480", 2), ("1280x720", 2)])
+def test_shadow_patches_are_bit_identical(env, config, shadows):
+    """FLAME_NLTGV2_OPT_SHADOWS: patches next to an XCD border computed a second time on the neighbouring XCD.  Same state
+    after odd and even run lengths, after a chain of asynchronous runs, with record verification on, and the device-built
+    layout (shadow instances, per-XCD record tables) equals the host builders'."""
+    flame_amd, oracle = env
+    from flame_amd.regularizer import OPT_PERSISTENT, OPT_SHADOWS, OPT_VERIFY_RECORDS
+
+    g = synth.make_graph(config, seed=21)
+    p = flame_amd.Params()
+    ref = synth.copy_graph(g)
+    with flame_amd.Regularizer(0) as reg:
+        reg.set_option(OPT_PERSISTENT, 4)
+        reg.set_option(OPT_SHADOWS, shadows)
+        reg.upload_graph(g)
+        base = reg.info()["he_waves"]
+        assert reg.info()["patches"] > base, "no shadow instances were created"
+        assert reg.layout_selftest() == 0
+        for n in (7, 40):
+            reg.run(p, n)
+            assert oracle.run(ref, n) == 0
+            assert reg.info()["last_run_path"] == 6
+            assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"{config} after {n}")
+        reg.set_option(OPT_VERIFY_RECORDS, 1)
+        reg.run_async(p, 9)
+        reg.run_async(p, 16)
+        reg.sync()
+        assert oracle.run(ref, 25) == 0
+        assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"{config} chain")
+        info = reg.info()
+        assert info["timeouts_recovered"] == 0 and info["torn_records_detected"] == 0
