@@ -294,10 +294,10 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
   if (shadow_mode > 0 && L->wg_count > 2 * 32 && L->wg_count <= 2048) {
     // ---- shadow patches (see PackedLayout) -----------------------------------------------------------------------
     const int32_t P = L->wg_count;
-    std::vector<int32_t> patch_of_pos(static_cast<size_t>(V));
+    std::vector<int32_t> patch_of_vertex(static_cast<size_t>(V));  // by the caller's vertex id
     for (int32_t q = 0; q < P; ++q) {
       const int32_t r0 = L->wg_info[static_cast<size_t>(q) * 4], n = L->wg_info[static_cast<size_t>(q) * 4 + 2];
-      for (int32_t j = 0; j < n; ++j) patch_of_pos[static_cast<size_t>(r0 + j)] = q;
+      for (int32_t j = 0; j < n; ++j) patch_of_vertex[static_cast<size_t>(order_m[static_cast<size_t>(r0 + j)])] = q;
     }
     // XCD k owns the patches [cut[k], cut[k+1]) of the walk.  Shadows land unevenly (an XCD in the middle of the image has
     // more borders), and a wave wants a SIMD of its own (an XCD has 128): the cuts are moved until own patches + shadows
@@ -305,20 +305,35 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
     int32_t cut[kXcds + 1];
     for (int32_t k = 0; k <= kXcds; ++k) cut[k] = static_cast<int32_t>(static_cast<int64_t>(P) * k / kXcds);
     std::vector<uint8_t> region(static_cast<size_t>(P)), need(static_cast<size_t>(P));
+    // which patches a patch reads, once (the rounds below only look at regions): distinct neighbours, ~6 per patch
+    std::vector<int32_t> adj_ptr(static_cast<size_t>(P) + 1, 0), adj, stamp(static_cast<size_t>(P), -1);
+    adj.reserve(static_cast<size_t>(P) * 8);
+    for (int32_t q = 0; q < P; ++q) {
+      const int32_t r0 = L->wg_info[static_cast<size_t>(q) * 4], n = L->wg_info[static_cast<size_t>(q) * 4 + 2];
+      stamp[static_cast<size_t>(q)] = q;
+      for (int32_t j = 0; j < n; ++j) {
+        const int32_t o = order_m[static_cast<size_t>(r0 + j)];
+        for (int32_t h = L->row_ptr[o]; h < L->row_ptr[o + 1]; ++h) {
+          const int32_t nb = patch_of_vertex[static_cast<size_t>(L->half_nbr[h])];
+          if (stamp[static_cast<size_t>(nb)] == q) continue;  // itself, or met before
+          stamp[static_cast<size_t>(nb)] = q;
+          adj.push_back(nb);
+        }
+      }
+      adj_ptr[static_cast<size_t>(q) + 1] = static_cast<int32_t>(adj.size());
+    }
     int32_t per[kXcds], most = 0, total = P;
     for (int round = 0; round < 4; ++round) {
       for (int32_t k = 0; k < kXcds; ++k)
         for (int32_t q = cut[k]; q < cut[k + 1]; ++q) region[static_cast<size_t>(q)] = static_cast<uint8_t>(k);
-      std::fill(need.begin(), need.end(), static_cast<uint8_t>(0));  // bit k: XCD k holds a patch that reads this one
-      for (int32_t q = 0; q < P; ++q) {
-        const int32_t m = region[static_cast<size_t>(q)], r0 = L->wg_info[static_cast<size_t>(q) * 4], n = L->wg_info[static_cast<size_t>(q) * 4 + 2];
-        for (int32_t j = 0; j < n; ++j) {
-          const int32_t o = order_m[static_cast<size_t>(r0 + j)];
-          for (int32_t h = L->row_ptr[o]; h < L->row_ptr[o + 1]; ++h) {
-            const int32_t k = region[static_cast<size_t>(patch_of_pos[static_cast<size_t>(L->rid_of[static_cast<size_t>(L->half_nbr[h])])])];
-            if (k != m && (shadow_mode >= 2 || k < m)) need[static_cast<size_t>(q)] |= static_cast<uint8_t>(1u << k);
-          }
+      for (int32_t q = 0; q < P; ++q) {  // bit k: XCD k holds a patch that reads this one
+        const int32_t m = region[static_cast<size_t>(q)];
+        uint8_t bits = 0;
+        for (int32_t i = adj_ptr[static_cast<size_t>(q)]; i < adj_ptr[static_cast<size_t>(q) + 1]; ++i) {
+          const int32_t k = region[static_cast<size_t>(adj[static_cast<size_t>(i)])];
+          if (k != m && (shadow_mode >= 2 || k < m)) bits |= static_cast<uint8_t>(1u << k);
         }
+        need[static_cast<size_t>(q)] = bits;
       }
       int32_t shadows[kXcds];
       most = 0, total = P;
