@@ -839,20 +839,23 @@ int staged_h2d(flame_nltgv2_ctx* ctx, const StageCopy* cp, size_t n, const Stage
   return 0;
 }
 
-// Shadow patches by default: the higher-numbered side of every XCD border, as long as every instance still gets a SIMD of
-// its own (measured, 5 graphs each: 320x240 1.156 -> 1.114 us per iteration, 640x480 1.285 -> 1.239; with more instances
-// than SIMDs -- 1280x720 -- the copies cost more than they save: 1.40 -> 1.52).  An explicit option is taken as it is.
-constexpr int kShadowModeDefault = 1;
+// Shadow patches are OPT-IN (FLAME_NLTGV2_OPT_SHADOWS): they are worth 3.6 % at 320x240 / 640x480 (measured, 5 graphs each:
+// 1.156 -> 1.114 and 1.285 -> 1.239 us per iteration with the higher-numbered side of every XCD border copied), but they
+// weaken the flow control of the two-buffer record exchange: a producer only waits for the instances it reads, and a
+// shadow that reads a producer is not one of them -- it is kept in step only through a chain of other instances, so its
+// lag behind the producer is no longer bounded by one step.  A 480 000-iteration soak with record verification on saw one
+// shadow re-read a record its producer had just overwritten with the step after next (counted as a torn record, taken
+// back and redone correctly); a little more lag would have been a lost record and a timeout (also recovered, but a
+// second late).  Until the exchange has four buffers and a layout-time bound on those chains, the default is off.
+constexpr int kShadowModeDefault = 0;
 int shadow_mode(const flame_nltgv2_ctx* ctx) { return ctx->opt_shadows ? ctx->opt_shadows - 1 : kShadowModeDefault; }
 int shadow_cap(const flame_nltgv2_ctx* ctx) { return ctx->opt_shadows ? 0x7fffffff : 4 * ctx->prop.multiProcessorCount; }
 
 // Layout + topology arrays of `g` (V, E, pos, src, dst) onto the device; the caller adds the state.  On return the
 // stream still holds the copies: the caller synchronises before the staging buffer or `g`'s arrays may change.
-int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const StageCopy* extra, size_t n_extra, bool long_lived) {
+int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const StageCopy* extra, size_t n_extra) {
   const int32_t V = g->V, E = g->E;
-  // Shadow patches cost ~0.2 ms of host work per topology and save ~9 us per 200 iterations: by default only for a
-  // topology that was uploaded to stay (upload_graph), not for the per-frame edits of sync_graph
-  const int sm = (ctx->opt_shadows || long_lived) ? shadow_mode(ctx) : 0;
+  const int sm = shadow_mode(ctx);  // (opt-in; ~0.2 ms of host work per topology when on)
   int rc = build_layout(g, &ctx->L, /*host_expand=*/false, sm, shadow_cap(ctx));
   if (rc) return fail(ctx, rc);
   const PackedLayout& L = ctx->L;
@@ -1162,7 +1165,7 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
       {&ctx->w2p, g->w2_prev ? g->w2_prev : g->w2, fV}, {&ctx->data, g->data_term, fV},
       {&ctx->weight, g->data_weight, fV}, {&ctx->alpha, g->alpha, fE}, {&ctx->beta, g->beta, fE}, {&ctx->q1, g->q1, fE},
       {&ctx->q2, g->q2, fE}, {&ctx->q3, g->q3, fE}};
-  rc = upload_topology(ctx, g, state, sizeof(state) / sizeof(state[0]), /*long_lived=*/true);
+  rc = upload_topology(ctx, g, state, sizeof(state) / sizeof(state[0]));
   if (rc) return rc;
   const auto t_packed = std::chrono::steady_clock::now();
   LAUNCHCHK(ctx, launch_pack_static(ctx->c, ctx->f, ctx->stream));
@@ -1329,7 +1332,7 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
       {&ctx->sync_init, in->init_x, in->init_x ? fV : 0},
       {&ctx->sync_vmap, old_of_new.data(), sizeof(int32_t) * (size_t)V},
       {&ctx->sync_emap, old_of_new_edge.data(), sizeof(int32_t) * (size_t)En}};
-  rc = upload_topology(ctx, &g, extra, sizeof(extra) / sizeof(extra[0]), /*long_lived=*/false);
+  rc = upload_topology(ctx, &g, extra, sizeof(extra) / sizeof(extra[0]));
   if (rc) return rc;
   SyncArgs sa;
   sa.V = V, sa.E = En;

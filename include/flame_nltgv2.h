@@ -273,13 +273,14 @@ enum {
   FLAME_NLTGV2_OPT_POLL_GAP = 13,    /* patch-per-wave form: 0 (default) = built-in, 1 = no pause between the polls of a
                                         wait, 2 = one s_sleep (64 cycles); 3 / 4 = the same with the polls narrowed to the
                                         records that have not arrived yet (4 is the built-in) */
-  FLAME_NLTGV2_OPT_SHADOWS = 15,     /* patch-per-wave form, graphs of one component spread over the eight XCDs: patches next to
-                                        an XCD border are also computed by a wave on the neighbouring XCD, whose patches then
-                                        read that copy (same bits) instead of waiting for a record to cross the fabric.
-                                        0 (default) = built-in choice (after upload_graph: one side, if every instance still
-                                        gets a SIMD of its own; after sync_graph: none -- building them costs more host time
-                                        per frame than they save), 1 = none, 2 = the higher-numbered side of a border only,
-                                        3 = both sides.  Takes effect with the next upload_graph / sync_graph */
+  FLAME_NLTGV2_OPT_SHADOWS = 15,     /* EXPERIMENTAL, off by default.  Patch-per-wave form, graphs spread over the eight XCDs:
+                                        patches next to an XCD border are also computed by a wave on the neighbouring XCD,
+                                        whose patches then read that copy (same bits) instead of waiting for a record to
+                                        cross the fabric (-3.6 % per iteration at 320x240 / 640x480).  A copy is not part of
+                                        its producers' flow control, so a badly delayed copy can miss a record: the bounded
+                                        waits / FLAME_NLTGV2_OPT_VERIFY_RECORDS catch that and the run is redone on the
+                                        per-step path (correct, but late).  0 / 1 = none, 2 = the higher-numbered side of a
+                                        border only, 3 = both sides.  Takes effect with the next upload_graph / sync_graph */
   FLAME_NLTGV2_OPT_VERIFY_RECORDS = 14, /* persistent kernels: 1 = after a neighbour record's tag matched, read the 16 bytes
                                         once more and compare all four dwords (the exchange relies on an aligned 16-byte
                                         access never being torn between payload and tag; this checks it at run time, at the
