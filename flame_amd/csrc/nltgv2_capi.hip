@@ -31,7 +31,8 @@ constexpr int kGraphChunk = 256;      // steps per captured hipGraph (even: keep
 constexpr int kMaxCachedGraphs = 6;
 constexpr int kHeWavesPerCu = 24;      // residency cap of k_persistent_he (<= 64 VGPRs: the hardware admits 32)
 constexpr int kTvLdsWavesPerCu = 16;   // ... with the slot constants in LDS (<= 128 VGPRs -> 4 waves per SIMD; 10 KB LDS per wave = all 160 KB)
-constexpr size_t kXbufBytesPerVertex = 4 * 16 + 4;  // exchange buffers: four arrays of 16-byte records + the XCC table
+constexpr size_t kXbufBytesPerVertex = 8 * 16 + 4;  // exchange buffers: up to four step buffers x (remote + same-XCD copy) of
+                                                    // 16-byte records (the patch-per-wave form; the others use two) + the XCC table
 constexpr int kPvPreSleep = 0;         // k_persistent_pv: x64 cycles between a step's start and its first poll
 constexpr int kPvPollGap = 3;          // k_persistent_pv polls: s_sleep 1 between rounds (beats none by 1-3 %), re-loading only the fetch
                                        // entries still waiting (another 1-1.5 %)
@@ -119,8 +120,9 @@ struct flame_nltgv2_ctx {
   uint64_t topo = 0, stamp = 0;
 
   int opt_solver = 0, opt_use_graph = 1, opt_block_waves = 0, opt_unroll = 0, opt_persistent = 1, opt_dual = 1;
+  int xbuf_form = 0;     // the persistent form whose records the exchange buffers hold (0: cleared)
   int opt_xcds = 0;      // XCDs a persistent launch spreads over: 0 = auto, 1..8
-  int opt_shadows = 0;   // shadow patches across XCD borders: 0 = built-in choice, 1 = none, 2 = one side, 3 = both sides (next upload)
+  int opt_shadows = 0;   // shadow patches across XCD borders: 0 = built-in choice, 1 = none, 2 = always (next upload / sync)
   bool photo_fused = false;     // flame_nltgv2_photo_fuse: every run also leaves the photometric residual in photo_err
   PhotoGeometry photo_geo{};
   float photo_scale = 1.0f;
@@ -583,12 +585,14 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   int tv_lds = 0;
   const int form = plan_persistent(ctx, n, &groups, &tv_lds);
   if (form != 0) {
-    // tags must stay unique: clear the record buffers long before the 28-bit tag of the XCC table wraps
-    if ((uint64_t)ctx->tag_next + (uint64_t)n >= 0x07ff0000ull) {
+    // tags must stay unique: clear the record buffers long before the 28-bit tag of the XCC table wraps -- and when the
+    // form changes (the forms lay the buffers out differently: one's XCC table is another's record area)
+    if ((uint64_t)ctx->tag_next + (uint64_t)n >= 0x07ff0000ull || (ctx->xbuf_form != 0 && ctx->xbuf_form != form)) {
       const size_t bytes = kXbufBytesPerVertex * records_capacity(ctx->L);
       HIPCHK(ctx, hipMemsetAsync(ctx->xbuf.p, 0, bytes, ctx->stream));
       ctx->tag_next = 1;
     }
+    ctx->xbuf_form = form;
     // a fresh first tag per run: records left by earlier runs (whose state may since have been changed
     // by per-step launches or host uploads) can never satisfy a wait of this one
     const uint32_t tag0 = ctx->tag_next + 2;
@@ -631,7 +635,8 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       const unsigned spins_arg = ctx->opt_fault > 0 ? (0x80000000u | (unsigned)ctx->opt_fault) : kMaxSpins;
       if (form == 3) {
         ctx->f.wg_poll_gap = (ctx->opt_poll_gap > 0 ? ctx->opt_poll_gap - 1 : kPvPollGap) |
-                             ((ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : kPvPreSleep) << 8);
+                             ((ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : kPvPreSleep) << 8) |
+                             ((ctx->L.wg_per_xcd > 0 || std::getenv("FLAME_NLTGV2_FOUR_BUFFERS")) ? (1 << 30) : 0);
         ctx->f.probe = nullptr;
         if (ctx->opt_probe) {  // [patch][step][8 words]
           const size_t words = (size_t)ctx->L.wg_count * (size_t)n * 8;
@@ -839,23 +844,21 @@ int staged_h2d(flame_nltgv2_ctx* ctx, const StageCopy* cp, size_t n, const Stage
   return 0;
 }
 
-// Shadow patches are OPT-IN (FLAME_NLTGV2_OPT_SHADOWS): they are worth 3.6 % at 320x240 / 640x480 (measured, 5 graphs each:
-// 1.156 -> 1.114 and 1.285 -> 1.239 us per iteration with the higher-numbered side of every XCD border copied), but they
-// weaken the flow control of the two-buffer record exchange: a producer only waits for the instances it reads, and a
-// shadow that reads a producer is not one of them -- it is kept in step only through a chain of other instances, so its
-// lag behind the producer is no longer bounded by one step.  A 480 000-iteration soak with record verification on saw one
-// shadow re-read a record its producer had just overwritten with the step after next (counted as a torn record, taken
-// back and redone correctly); a little more lag would have been a lost record and a timeout (also recovered, but a
-// second late).  Until the exchange has four buffers and a layout-time bound on those chains, the default is off.
-constexpr int kShadowModeDefault = 0;
-int shadow_mode(const flame_nltgv2_ctx* ctx) { return ctx->opt_shadows ? ctx->opt_shadows - 1 : kShadowModeDefault; }
+// Shadow patches (nltgv2_pack.hpp) are opt-in.  Copying every border patch was worth 3.6 % (5 graphs each at 320x240 and
+// 640x480) but left a hole in the record exchange's flow control (a soak caught a shadow re-reading a record two steps
+// stale); with the rules that close it -- fewer copies, four record buffers -- the same-box A/B at 640x480 is 1.274 ->
+// 1.260 us per iteration on average over three graphs (-4.5 %, +1.5 %, 0 %), for ~0.15 ms more host time per topology.
+int shadow_mode(const flame_nltgv2_ctx* ctx, bool long_lived) {
+  (void)long_lived;
+  return ctx->opt_shadows == 2 ? 2 : 0;
+}
 int shadow_cap(const flame_nltgv2_ctx* ctx) { return ctx->opt_shadows ? 0x7fffffff : 4 * ctx->prop.multiProcessorCount; }
 
 // Layout + topology arrays of `g` (V, E, pos, src, dst) onto the device; the caller adds the state.  On return the
 // stream still holds the copies: the caller synchronises before the staging buffer or `g`'s arrays may change.
-int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const StageCopy* extra, size_t n_extra) {
+int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const StageCopy* extra, size_t n_extra, bool long_lived) {
   const int32_t V = g->V, E = g->E;
-  const int sm = shadow_mode(ctx);  // (opt-in; ~0.2 ms of host work per topology when on)
+  const int sm = shadow_mode(ctx, long_lived);
   int rc = build_layout(g, &ctx->L, /*host_expand=*/false, sm, shadow_cap(ctx));
   if (rc) return fail(ctx, rc);
   const PackedLayout& L = ctx->L;
@@ -914,6 +917,7 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
                                         (const int32_t*)ctx->iperm.p, ctx->stream));
   ctx->pending = flame_nltgv2_ctx::PendingRun{};
   ctx->tag_next = 1;
+  ctx->xbuf_form = 0;
   ctx->static_stale = false;
   ctx->h_src.assign(g->src, g->src + E);
   ctx->h_dst.assign(g->dst, g->dst + E);
@@ -1087,7 +1091,7 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
       ctx->opt_persistent = value;
       return 0;
     case FLAME_NLTGV2_OPT_SHADOWS:
-      if (value < 0 || value > 3) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_shadows = value;
       return 0;
     case FLAME_NLTGV2_OPT_POLL_GAP:
@@ -1165,7 +1169,7 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
       {&ctx->w2p, g->w2_prev ? g->w2_prev : g->w2, fV}, {&ctx->data, g->data_term, fV},
       {&ctx->weight, g->data_weight, fV}, {&ctx->alpha, g->alpha, fE}, {&ctx->beta, g->beta, fE}, {&ctx->q1, g->q1, fE},
       {&ctx->q2, g->q2, fE}, {&ctx->q3, g->q3, fE}};
-  rc = upload_topology(ctx, g, state, sizeof(state) / sizeof(state[0]));
+  rc = upload_topology(ctx, g, state, sizeof(state) / sizeof(state[0]), /*long_lived=*/true);
   if (rc) return rc;
   const auto t_packed = std::chrono::steady_clock::now();
   LAUNCHCHK(ctx, launch_pack_static(ctx->c, ctx->f, ctx->stream));
@@ -1332,7 +1336,7 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
       {&ctx->sync_init, in->init_x, in->init_x ? fV : 0},
       {&ctx->sync_vmap, old_of_new.data(), sizeof(int32_t) * (size_t)V},
       {&ctx->sync_emap, old_of_new_edge.data(), sizeof(int32_t) * (size_t)En}};
-  rc = upload_topology(ctx, &g, extra, sizeof(extra) / sizeof(extra[0]));
+  rc = upload_topology(ctx, &g, extra, sizeof(extra) / sizeof(extra[0]), /*long_lived=*/false);
   if (rc) return rc;
   SyncArgs sa;
   sa.V = V, sa.E = En;

@@ -602,7 +602,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   constexpr int T = 64;
   const unsigned max_spins = max_spins_arg & 0x7fffffffu;
   const int dual = dual_arg & 1, verify = dual_arg >> 1;  // as in k_persistent_he
-  const int poll_gap = poll_gap_arg & 255, pv_presleep = poll_gap_arg >> 8;
+  const int poll_gap = poll_gap_arg & 255, pv_presleep = (poll_gap_arg >> 8) & 255;
   const int lane = (int)threadIdx.x;
   const int b = blockIdx.x;
   const int xcd = b & 7, idx = b >> 3;
@@ -626,7 +626,14 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   float* const ldsf = reinterpret_cast<float*>(lds);
   const int f_slabC = 4 * o_slabC, f_ovfC = f_slabC + slab_slots;
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(xbuf);
-  const int S = rec_bytes, par = 2 * rec_bytes;
+  // Memory side of the exchange: FOUR buffers by step (tag & 3), each [remote copy S bytes | same-XCD copy S bytes], then
+  // the XCC table.  Two would do between instances that read each other (a record of step s is only overwritten by s+2
+  // after every reader published s+1, i.e. consumed s); a shadow patch is read by, but does not read, some of its
+  // producers -- those wait for it through a chain of up to three instances (nltgv2_pack.hpp), so the overwrite has to
+  // be four steps away.
+  // (Without shadow patches the layout asks for two.)
+  const int kPar = (poll_gap_arg >> 30) & 1 ? 4 : 2;
+  const int S = rec_bytes, par = 2 * rec_bytes, tab_off = kPar * par;
   const unsigned xcc_want = (tag0 & 0x0fffffffu) << 4;
   const unsigned p0 = tag0 & 1u;  // parity of the first step: its records live in area p0
 
@@ -700,13 +707,13 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   if (dual) {
     const unsigned my_xcc = read_xcc_id();
     if (is_tail && publishes)
-      __builtin_amdgcn_raw_buffer_store_b32((int)(xcc_want | my_xcc), rx, 4 * S + (my_off >> 2), 0, kAuxSc1);
+      __builtin_amdgcn_raw_buffer_store_b32((int)(xcc_want | my_xcc), rx, tab_off + (my_off >> 2), 0, kAuxSc1);
     if (n_fetch > 0 && !timed_out) {
       bool pend = frid >= 0;
       unsigned g0 = 0, spins = 0;
       for (;;) {
         if (pend) {
-          int o = 4 * S + (frid << 2);
+          int o = tab_off + (frid << 2);
           asm volatile("" : "+v"(o)::"memory");
           g0 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, kAuxSc1);
           pend = ((g0 & ~15u) != xcc_want);
@@ -729,7 +736,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
     if (pub_lane && !mute) {
       v4i_t o;
       o.x = __float_as_int(xb), o.y = __float_as_int(wb12.x), o.z = __float_as_int(wb12.y), o.w = (int)tag0;
-      const int so = p0 ? par : 0;
+      const int so = (int)(tag0 & (kPar - 1)) * par;
       __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
       if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
     }
@@ -743,8 +750,9 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   // One step.  rd_nbr: LDS byte address of the neighbour's record; dst: LDS byte address of the step's fetch slots;
   // src: this lane's poll address; wr_rec: float4 index where the own record of the next step goes; so_out: memory offset
   // of the parity published.
-  auto step = [&](const unsigned s, const unsigned rd_nbr, const unsigned dst, const char* const src, const int wr_rec,
-                  const int so_out, const int so_in, const int fetch_area, const int it) {
+  auto step = [&](const unsigned s, const unsigned rd_nbr, const unsigned dst, const int wr_rec, const int fetch_area, const int it) {
+    const int so_in = (int)(s & (kPar - 1)) * par, so_out = (int)((s + 1u) & (kPar - 1)) * par;  // (wave-uniform)
+    const char* const src = xb_base + off0 + so_in;
     // ---- wait for the neighbours' records of step s ----------------------------------------------------------------
     v4f_t nbv;  // the tag word is read first, the record after it: a tag that matches vouches for the payload
     unsigned rounds = 0;
@@ -953,20 +961,17 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
 
   // Two steps per trip with the parities fixed: area A holds the records of the first step, B those of the next.
   const int areaA = p0 ? rec_stride : 0, areaB = p0 ? 0 : rec_stride;
-  const int soA = p0 ? par : 0, soB = p0 ? 0 : par;  // memory offsets of the parities
   const unsigned rdA_nbr = lds_addr0 + 16u * (unsigned)(areaA + nbr_idx), rdB_nbr = lds_addr0 + 16u * (unsigned)(areaB + nbr_idx);
   const unsigned dstA = __builtin_amdgcn_readfirstlane(lds_addr0 + 16u * (unsigned)(areaA + lcap));
   const unsigned dstB = __builtin_amdgcn_readfirstlane(lds_addr0 + 16u * (unsigned)(areaB + lcap));
-  const char* const srcA = xb_base + off0 + soA;
-  const char* const srcB = xb_base + off0 + soB;
   const int wrA_rec = (valid ? areaA : 0) + rec_w, wrB_rec = (valid ? areaB : 0) + rec_w;
   int it = 0;
   for (; it + 1 < n_iters && !timed_out; it += 2) {
-    step(tag0 + (unsigned)it, rdA_nbr, dstA, srcA, wrB_rec, soB, soA, areaA + lcap, it);
+    step(tag0 + (unsigned)it, rdA_nbr, dstA, wrB_rec, areaA + lcap, it);
     if (timed_out) break;
-    step(tag0 + (unsigned)it + 1u, rdB_nbr, dstB, srcB, wrA_rec, soA, soB, areaB + lcap, it + 1);
+    step(tag0 + (unsigned)it + 1u, rdB_nbr, dstB, wrA_rec, areaB + lcap, it + 1);
   }
-  if (it < n_iters && !timed_out) step(tag0 + (unsigned)it, rdA_nbr, dstA, srcA, wrB_rec, soB, soA, areaA + lcap, it);
+  if (it < n_iters && !timed_out) step(tag0 + (unsigned)it, rdA_nbr, dstA, wrB_rec, areaA + lcap, it);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA in flight when the wave ends
 
   if (timed_out) {

@@ -97,14 +97,15 @@ struct PackedLayout {
   std::vector<int32_t> wg_fetch;       // [wg_count*64] record id fetched by this lane, -1 none
   std::vector<int32_t> wg_info;        // [wg_count*4] first record id, fetched records, local vertices (| kWgShadow), slab stride
   std::vector<int32_t> comp_wg;        // [n_comp+1] first patch of each component
-  // Shadow patches (shadow_mode > 0, 65..2048 patches: graphs that run resident as a whole, spread over all XCDs): the chip is eight XCDs and a record
-  // crosses from one to another ~0.25 us later than it reaches a reader on its own XCD; the lock-step network runs at its
-  // worst cycle mean, and today that is a pair of patches on two XCDs reading each other.  A patch next to the border is
-  // therefore ALSO computed by a second wave on the neighbouring XCD (same vertices, same inputs, same instructions ->
-  // bit-identical records under its own record ids), and that XCD's patches read the copy instead of the original: the
-  // cycles through the border then contain one crossing per two (mode 1: only the higher-numbered side is shadowed) or
-  // three (mode 2: both sides) hand-offs instead of a crossing per hand-off.  Instances are ordered XCD by XCD (the XCD's
-  // own patches in walk order, then its shadows, then idle padding), wg_per_xcd each; a shadow does not write state back.
+  // Shadow patches (shadow_mode > 0, 65..2048 patches: graphs that run resident as a whole, spread over all XCDs):
+  // the chip is eight XCDs and a record crosses from one to another later than it reaches a reader on its own XCD; the
+  // lock-step network runs at its worst cycle mean, and that is a pair of patches on two XCDs reading each other.  A patch
+  // next to the border (higher-numbered side) is therefore ALSO computed by a second wave on the neighbouring XCD (same
+  // vertices, same inputs, same instructions -> bit-identical records under its own record ids), and that XCD's patches
+  // read the copy instead of the original: the cycles through the border then contain one crossing per two hand-offs
+  // instead of one per hand-off.  Instances are ordered XCD by XCD (the XCD's own patches in walk order, then its
+  // shadows, then idle padding), wg_per_xcd each; a shadow does not write state back.  build_patch_rows has the rules
+  // that keep the record exchange's flow control sound with them.
   int32_t shadow_mode = 0;
   int32_t wg_prim = 0;                 // patches of the walk (wg_count - shadows - padding)
   int32_t wg_per_xcd = 0;              // instances per XCD when shadows exist, else 0
@@ -290,8 +291,11 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
   L->wg_v0.resize(static_cast<size_t>(L->wg_count));
   for (int32_t q = 0; q < L->wg_count; ++q) L->wg_v0[static_cast<size_t>(q)] = L->wg_info[static_cast<size_t>(q) * 4];
   constexpr int32_t kXcds = 8;
-  // (graphs that are resident as a whole anyway -- components are then not needed for grouping; not the one-XCD sizes)
-  if (shadow_mode > 0 && L->wg_count > 2 * 32 && L->wg_count <= 2048) {
+  // (graphs that are resident as a whole anyway -- components are then not needed for grouping; not the one-XCD sizes.
+  //  shadow_mode 1 = where it pays: from 512 patches on -- a smaller graph's XCD regions are a few patches across, most border
+  //  patches touch three of them and are not copied, and the rest costs more than it saves: 320x240 1.148 -> 1.179 us;
+  //  shadow_mode 2 = whenever possible)
+  if (shadow_mode > 0 && L->wg_count > 2 * 32 && L->wg_count <= 2048 && (shadow_mode >= 2 || L->wg_count >= 512)) {
     // ---- shadow patches (see PackedLayout) -----------------------------------------------------------------------
     const int32_t P = L->wg_count;
     std::vector<int32_t> patch_of_vertex(static_cast<size_t>(V));  // by the caller's vertex id
@@ -304,7 +308,7 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
     // are about the same everywhere.
     int32_t cut[kXcds + 1];
     for (int32_t k = 0; k <= kXcds; ++k) cut[k] = static_cast<int32_t>(static_cast<int64_t>(P) * k / kXcds);
-    std::vector<uint8_t> region(static_cast<size_t>(P)), need(static_cast<size_t>(P));
+    std::vector<uint8_t> region(static_cast<size_t>(P)), need(static_cast<size_t>(P)), touches(static_cast<size_t>(P));
     // which patches a patch reads, once (the rounds below only look at regions): distinct neighbours, ~6 per patch
     std::vector<int32_t> adj_ptr(static_cast<size_t>(P) + 1, 0), adj, stamp(static_cast<size_t>(P), -1);
     adj.reserve(static_cast<size_t>(P) * 8);
@@ -326,12 +330,34 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
     for (int round = 0; round < 4; ++round) {
       for (int32_t k = 0; k < kXcds; ++k)
         for (int32_t q = cut[k]; q < cut[k + 1]; ++q) region[static_cast<size_t>(q)] = static_cast<uint8_t>(k);
-      for (int32_t q = 0; q < P; ++q) {  // bit k: XCD k holds a patch that reads this one
+      // Which patches get a copy, and where.  Patch C of XCD m is copied to XCD k < m (only the higher-numbered side of
+      // a border is copied) iff (i) every neighbour of C lies on XCD k or m, at least one of them on k, and (ii) at least one
+      // neighbour D on m touches no patch of XCD k.  These two rules are what makes FOUR record buffers enough
+      // (k_persistent_pv): an instance that is read by an instance it does not read itself waits for that reader through
+      // at most three hand-offs --
+      //   D is read by the copy C' (which reads D because D has no copy on k, (ii)):  D reads C, C reads A (a neighbour on
+      //     k: no patch of the lower side is ever copied), A reads C';
+      //   A (on k) is read by C, but itself reads C':  A reads C', C' reads D, D reads C;
+      //   every other pair reads each other (copies on k read each other's copies, patches of m read each other).
+      // A patch that touches three XCDs is never copied ((i)), so no other constellation exists.
+      for (int32_t q = 0; q < P; ++q) touches[static_cast<size_t>(q)] = 0;
+      for (int32_t q = 0; q < P; ++q)
+        for (int32_t i = adj_ptr[static_cast<size_t>(q)]; i < adj_ptr[static_cast<size_t>(q) + 1]; ++i)
+          touches[static_cast<size_t>(q)] |= static_cast<uint8_t>(1u << region[static_cast<size_t>(adj[static_cast<size_t>(i)])]);
+      for (int32_t q = 0; q < P; ++q) {  // need: bit k = XCD k gets a copy of this patch
         const int32_t m = region[static_cast<size_t>(q)];
+        const uint32_t others = touches[static_cast<size_t>(q)] & ~(1u << m);
         uint8_t bits = 0;
-        for (int32_t i = adj_ptr[static_cast<size_t>(q)]; i < adj_ptr[static_cast<size_t>(q) + 1]; ++i) {
-          const int32_t k = region[static_cast<size_t>(adj[static_cast<size_t>(i)])];
-          if (k != m && (shadow_mode >= 2 || k < m)) bits |= static_cast<uint8_t>(1u << k);
+        if (others != 0 && (others & (others - 1)) == 0) {  // exactly one other XCD ...
+          const int32_t k = __builtin_ctz(others);
+          if (k < m) {                                       // ... and it is the lower one
+            bool inner = false;                              // (ii)
+            for (int32_t i = adj_ptr[static_cast<size_t>(q)]; i < adj_ptr[static_cast<size_t>(q) + 1] && !inner; ++i) {
+              const int32_t d = adj[static_cast<size_t>(i)];
+              inner = region[static_cast<size_t>(d)] == m && !((touches[static_cast<size_t>(d)] >> k) & 1);
+            }
+            if (inner) bits = static_cast<uint8_t>(1u << k);
+          }
         }
         need[static_cast<size_t>(q)] = bits;
       }

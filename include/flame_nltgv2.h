@@ -273,14 +273,12 @@ enum {
   FLAME_NLTGV2_OPT_POLL_GAP = 13,    /* patch-per-wave form: 0 (default) = built-in, 1 = no pause between the polls of a
                                         wait, 2 = one s_sleep (64 cycles); 3 / 4 = the same with the polls narrowed to the
                                         records that have not arrived yet (4 is the built-in) */
-  FLAME_NLTGV2_OPT_SHADOWS = 15,     /* EXPERIMENTAL, off by default.  Patch-per-wave form, graphs spread over the eight XCDs:
-                                        patches next to an XCD border are also computed by a wave on the neighbouring XCD,
-                                        whose patches then read that copy (same bits) instead of waiting for a record to
-                                        cross the fabric (-3.6 % per iteration at 320x240 / 640x480).  A copy is not part of
-                                        its producers' flow control, so a badly delayed copy can miss a record: the bounded
-                                        waits / FLAME_NLTGV2_OPT_VERIFY_RECORDS catch that and the run is redone on the
-                                        per-step path (correct, but late).  0 / 1 = none, 2 = the higher-numbered side of a
-                                        border only, 3 = both sides.  Takes effect with the next upload_graph / sync_graph */
+  FLAME_NLTGV2_OPT_SHADOWS = 15,     /* patch-per-wave form, graphs of 65..2048 patches spread over the eight XCDs: 2 = patches
+                                        on the higher-numbered side of an XCD border are also computed by a wave on the
+                                        neighbouring XCD, whose patches then read that copy (same bits) instead of waiting for
+                                        a record to cross the fabric.  Measured -1 % per iteration on average at 640x480
+                                        (between -4.5 % and +1.5 % by graph) for ~0.15 ms more host time per topology, hence
+                                        off by default (0, 1).  Takes effect with the next upload_graph / sync_graph */
   FLAME_NLTGV2_OPT_VERIFY_RECORDS = 14, /* persistent kernels: 1 = after a neighbour record's tag matched, read the 16 bytes
                                         once more and compare all four dwords (the exchange relies on an aligned 16-byte
                                         access never being torn between payload and tag; this checks it at run time, at the

@@ -153,8 +153,8 @@ def test_internal_steps_individually(env):
     [(5, 2), (9, 1)], [(5, 2), (9, 2)], [(5, 2), (9, 4)], [(5, 2), (9, 8)], [(5, 3), (9, 1)], [(5, 2), (8, 1)], [(5, 2), (8, 21)],
     [(5, 3), (8, 9)], [(5, 2), (9, 1), (6, 0)],
     [(5, 4)], [(5, 4), (6, 0)], [(5, 4), (6, 2)], [(5, 4), (9, 1)], [(5, 4), (9, 2)], [(5, 4), (9, 8)], [(5, 4), (13, 1)], [(5, 4), (13, 2)], [(5, 4), (13, 3)], [(5, 4), (13, 4)],
-    [(5, 4), (9, 1), (6, 0), (13, 1)], [(5, 4), (12, 1)], [(5, 4), (15, 2)], [(5, 4), (15, 3)], [(5, 4), (15, 3), (6, 0)],
-    [(5, 2), (15, 3)], [(5, 3), (15, 2)],
+    [(5, 4), (9, 1), (6, 0), (13, 1)], [(5, 4), (12, 1)], [(5, 4), (15, 2)], [(5, 4), (15, 1)], [(5, 4), (15, 2), (6, 0)],
+    [(5, 2), (15, 2)], [(5, 3), (15, 2)],
 ])
 def test_launch_configurations_are_bit_identical(env, opts):
     """waves per workgroup (opt 3), slot chunk (opt 4), hipGraph on/off (opt 2), persistent single
@@ -639,7 +639,7 @@ def test_randomized_run_sequences(env, trial):
         assert np.float32(sm) == np.float32(rs) and np.float32(dc) == np.float32(rd)
 
 
-@pytest.mark.parametrize("config,shadows", [("320x240", 2), ("320x240", 3), ("640x480", 2), ("1280x720", 2)])
+@pytest.mark.parametrize("config,shadows", [("320x240", 2), ("640x480", 2), ("1280x720", 2)])
 def test_shadow_patches_are_bit_identical(env, config, shadows):
     """FLAME_NLTGV2_OPT_SHADOWS: patches next to an XCD border computed a second time on the neighbouring XCD.  Same state
     after odd and even run lengths, after a chain of asynchronous runs, with record verification on, and the device-built
