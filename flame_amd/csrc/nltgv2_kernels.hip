@@ -825,14 +825,8 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
           PV_POLL("sc1", "s_sleep 1\n\t");
         } else if (poll_gap == 2) {
           PV_POLL_N("sc1", "");
-        } else if (poll_gap == 3) {
-          PV_POLL_N("sc1", "s_sleep 1\n\t");
-        } else if (poll_gap == 4) {  // at most 1 / 2 / 3 poll loads in flight
-          PV_POLL_N("sc1", "s_waitcnt vmcnt(0)\n\t");
-        } else if (poll_gap == 5) {
-          PV_POLL_N("sc1", "s_sleep 1\n\ts_waitcnt vmcnt(1)\n\t");
         } else {
-          PV_POLL_N("sc1", "s_sleep 1\n\ts_waitcnt vmcnt(2)\n\t");
+          PV_POLL_N("sc1", "s_sleep 1\n\t");
         }
 #undef PV_POLL
 #undef PV_POLL_N
