@@ -61,43 +61,55 @@ struct CachedGraph {
 // most expensive part of a frame (2.0-2.5 ms at 640x480), this table does it in a fraction.
 class FlatMap {
  public:
-  explicit FlatMap(size_t n) {
+  FlatMap() = default;
+  explicit FlatMap(size_t n) { reset(n); }
+  // Empties the table for up to n keys.  A slot is live only if it carries the current generation, so a table that is
+  // big enough is emptied by counting the generation up -- nothing is cleared (the per-frame sync empties two of these).
+  void reset(size_t n) {
     size_t cap = 16;
     while (cap < 2 * n + 2) cap <<= 1;
-    mask_ = cap - 1;
-    keys_.assign(cap, kEmpty);
-    vals_.resize(cap);
+    if (cap > slots_.size() || gen_ == 0xffffffffu) {
+      slots_.assign(std::max(cap, slots_.size()), Slot{0, 0, 0});
+      gen_ = 0;
+    }
+    mask_ = slots_.size() - 1;
+    ++gen_;
   }
   // inserts (k,v) if k is absent; returns the slot's value pointer and whether it was inserted
   std::pair<int32_t*, bool> emplace(uint64_t k, int32_t v) {
     size_t i = hash(k) & mask_;
     for (;; i = (i + 1) & mask_) {
-      if (keys_[i] == kEmpty) {
-        keys_[i] = k;
-        vals_[i] = v;
-        return {&vals_[i], true};
+      Slot& s = slots_[i];
+      if (s.gen != gen_) {
+        s = Slot{k, v, gen_};
+        return {&s.val, true};
       }
-      if (keys_[i] == k) return {&vals_[i], false};
+      if (s.key == k) return {&s.val, false};
     }
   }
   const int32_t* find(uint64_t k) const {
     size_t i = hash(k) & mask_;
     for (;; i = (i + 1) & mask_) {
-      if (keys_[i] == kEmpty) return nullptr;
-      if (keys_[i] == k) return &vals_[i];
+      const Slot& s = slots_[i];
+      if (s.gen != gen_) return nullptr;
+      if (s.key == k) return &s.val;
     }
   }
 
  private:
-  static constexpr uint64_t kEmpty = ~0ull;  // feature ids are non-negative int32: never a real key
+  struct Slot {
+    uint64_t key;
+    int32_t val;
+    uint32_t gen;
+  };
   static size_t hash(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
     z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
     return (size_t)(z ^ (z >> 31));
   }
-  size_t mask_;
-  std::vector<uint64_t> keys_;
-  std::vector<int32_t> vals_;
+  size_t mask_ = 0;
+  uint32_t gen_ = 0;
+  std::vector<Slot> slots_;
 };
 
 }  // namespace
@@ -115,7 +127,9 @@ struct flame_nltgv2_ctx {
   bool canon_valid = false, fused_valid = false, have_prev = false;
   DevBuf sp_v[9], sp_q[3], sync_init, sync_vmap, sync_emap, sync_need;  // sync_graph: spare state arrays, inputs, index maps
   std::vector<int32_t> h_old_of_new, h_old_of_new_edge;
-  std::unique_ptr<FlatMap> feat_map;  // feature id -> vertex of the CURRENT graph (h_feat), kept from one sync to the next
+  FlatMap feat_maps[3];     // [cur]: feature id -> vertex of the CURRENT graph (h_feat), kept from one sync to the next; the
+  int feat_cur = 0;         // next sync fills the other one; [2]: scratch of a sync (new edges' duplicates)
+  bool feat_map_valid = false;
   int parity = 0;
   uint64_t topo = 0, stamp = 0;
 
@@ -1184,7 +1198,7 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
   }
   ctx->h_feat.resize((size_t)V);
   for (int32_t v = 0; v < V; ++v) ctx->h_feat[(size_t)v] = v;  // default feature id = vertex index
-  ctx->feat_map.reset();
+  ctx->feat_map_valid = false;
   ctx->canon_valid = true;
   ctx->fused_valid = false;
   ctx->have_prev = false;
@@ -1229,11 +1243,13 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
 
   for (int32_t v = 0; v < V; ++v)
     if (in->feat_id[v] < 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-  if (!ctx->feat_map) {  // (after an upload / set_feature_ids; otherwise the map the previous sync built)
-    ctx->feat_map.reset(new FlatMap((size_t)Vo));
-    for (int32_t v = 0; v < Vo; ++v) ctx->feat_map->emplace((uint64_t)(uint32_t)ctx->h_feat[(size_t)v], v);
+  if (!ctx->feat_map_valid) {  // (after an upload / set_feature_ids; otherwise the map the previous sync built)
+    FlatMap& m = ctx->feat_maps[ctx->feat_cur];
+    m.reset((size_t)Vo);
+    for (int32_t v = 0; v < Vo; ++v) m.emplace((uint64_t)(uint32_t)ctx->h_feat[(size_t)v], v);
+    ctx->feat_map_valid = true;
   }
-  const FlatMap& old_of_feat = *ctx->feat_map;
+  const FlatMap& old_of_feat = ctx->feat_maps[ctx->feat_cur];
   auto key = [](int32_t a, int32_t b) {
     const uint32_t lo = (uint32_t)std::min(a, b), hi = (uint32_t)std::max(a, b);
     return ((uint64_t)hi << 32) | lo;
@@ -1242,9 +1258,10 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
   // vertices: new vertex -> its index in the previous graph (-1: new)
   std::vector<int32_t>& old_of_new = ctx->h_old_of_new;
   old_of_new.assign((size_t)V, -1);
-  std::unique_ptr<FlatMap> seen(new FlatMap((size_t)V));  // ... and the next sync's old_of_feat
+  FlatMap& seen = ctx->feat_maps[ctx->feat_cur ^ 1];  // ... and the next sync's old_of_feat
+  seen.reset((size_t)V);
   for (int32_t v = 0; v < V; ++v) {
-    if (!seen->emplace((uint64_t)(uint32_t)in->feat_id[v], v).second) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // duplicate id
+    if (!seen.emplace((uint64_t)(uint32_t)in->feat_id[v], v).second) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // duplicate id
     const int32_t* it = old_of_feat.find((uint64_t)(uint32_t)in->feat_id[v]);
     if (it) old_of_new[(size_t)v] = *it;
   }
@@ -1285,7 +1302,8 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
     }
   }
   if (!fresh.empty()) {  // no parallel edges among the new ones either (boost::edge() finds the one just added)
-    FlatMap dup(fresh.size());
+    FlatMap& dup = ctx->feat_maps[2];
+    dup.reset(fresh.size());
     size_t n = 0;
     for (const auto& f : fresh)
       if (dup.emplace(key(in->feat_id[f.first], in->feat_id[f.second]), 1).second) fresh[n++] = f;
@@ -1362,7 +1380,7 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
     std::fprintf(stderr, "[flame_nltgv2] sync_graph: index maps %.3f ms, tables + upload + device gather %.3f ms\n", ms(t0, t1), ms(t1, t2));
   }
   ctx->h_feat.assign(in->feat_id, in->feat_id + V);
-  ctx->feat_map = std::move(seen);
+  ctx->feat_cur ^= 1;  // (the map filled above is of the graph that stands now)
   ctx->canon_valid = true;
   ctx->fused_valid = false;
   ctx->have_prev = false;
@@ -1425,7 +1443,7 @@ int flame_nltgv2_set_feature_ids(flame_nltgv2_ctx* ctx, const int32_t* feat_id) 
   for (int32_t v = 0; v < ctx->L.V; ++v)
     if (feat_id[v] < 0 || !seen.emplace((uint64_t)(uint32_t)feat_id[v], v).second) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
   ctx->h_feat.assign(feat_id, feat_id + ctx->L.V);
-  ctx->feat_map.reset();
+  ctx->feat_map_valid = false;
   return FLAME_NLTGV2_OK;
 }
 
