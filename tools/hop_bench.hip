@@ -6,6 +6,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -o hop_bench hop_bench.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 typedef int v4i __attribute__((ext_vector_type(4)));
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
@@ -95,6 +96,33 @@ int main() {
   printf("dpp wave_shr:1 :"); for (int i = 0; i < 64; i += 1) printf(" %d", h[i]); printf("\n");
   printf("dpp row_shr:1  :"); for (int i = 0; i < 64; i += 1) printf(" %d", h[64 + i]); printf("\n");
   const int iters = 2000;
+  // (3) does the KIND of memory matter for the cross-XCD hand-off?  fine-grained / uncached allocations bypass the L2s by
+  //     memory type instead of by instruction policy
+  {
+    v4i *fg = nullptr, *uc = nullptr;
+    const size_t bytes = 4096 * 64 * 16;
+    if (hipExtMallocWithFlags((void**)&fg, bytes, hipDeviceMallocFinegrained) != hipSuccess) fg = nullptr;
+    if (hipExtMallocWithFlags((void**)&uc, bytes, hipDeviceMallocUncached) != hipSuccess) uc = nullptr;
+    (void)hipGetLastError();
+    for (int nb : {2, 256, 1024}) {
+      for (int px : {1, 8}) {
+        if (px >= nb) continue;
+        run<16, 16, false>("coarse: st sc1 / ld sc1", buf, cyc, xcc, nb, px, iters);
+        if (fg) {
+          run<16, 16, false>("fine-grained: st sc1 / ld sc1", fg, cyc, xcc, nb, px, iters);
+          run<0, 0, true>("fine-grained: st plain / ld plain", fg, cyc, xcc, nb, px, iters);
+          run<0, 16, true>("fine-grained: st plain / ld sc1", fg, cyc, xcc, nb, px, iters);
+        }
+        if (uc) {
+          run<16, 16, false>("uncached: st sc1 / ld sc1", uc, cyc, xcc, nb, px, iters);
+          run<0, 0, true>("uncached: st plain / ld plain", uc, cyc, xcc, nb, px, iters);
+        }
+      }
+    }
+    if (fg) (void)hipFree(fg);
+    if (uc) (void)hipFree(uc);
+    if (getenv("HOP_BENCH_MEMTYPE_ONLY")) return 0;
+  }
   for (int nb : {2, 16, 256, 1024}) {
     for (int px : {1, 8}) {  // xor 1: partner on a different XCD (b%8 differs); xor 8: same XCD
       if (px >= nb) continue;
