@@ -58,6 +58,83 @@ __global__ void __launch_bounds__(64) k_pingpong(v4i* buf, int partner_xor, int 
   if (threadIdx.x == 0) cycles[b] = wall_clock64() - t0;
 }
 
+
+// (4) the consumer side as k_persistent_pv does it: the poll is an LDS-DMA load (no VGPR destination), re-issued every
+//     round without waiting, and the tag is read back from LDS
+template <bool PLAIN_STORE, int GAP>
+__global__ void __launch_bounds__(64) k_pingpong_dma(v4i* buf, int partner_xor, int iters, long long* cycles, int* xcc_of_block) {
+  __shared__ v4i slot[64];
+  const int b = blockIdx.x, partner = b ^ partner_xor, lane = threadIdx.x;
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  if (lane == 0) xcc_of_block[b] = (int)(xcc & 0xf);
+  const bool first = (b & partner_xor) == 0;
+  __amdgpu_buffer_rsrc_t r = rsrc(buf);
+  const int my_off = (b * 64 + lane) * 16;
+  const char* src = (const char*)buf + (partner * 64 + lane) * 16;
+  const unsigned dst = (unsigned)(size_t)slot, ra = dst + 16u * lane;
+  slot[lane] = v4i{0, 0, 0, 0};
+  __syncthreads();
+  long long t0 = 0;
+  int tag = 0;
+  auto wait_tag = [&](int want) -> bool {
+    for (unsigned outer = 0; outer < (1u << 14); ++outer) {
+      unsigned keep, cnt, pl, t;
+      asm volatile("s_mov_b32 %[keep], m0\n\t"
+                   "s_mov_b32 m0, %[dst]\n\t"
+                   "s_mov_b32 %[cnt], 0\n\t"
+                   "1:\n\t"
+                   "global_load_lds_dwordx4 %[src], off sc1\n\t"
+                   ".if %[gap] == 9\n\ts_waitcnt vmcnt(0)\n\t.else\n\ts_sleep %[gap]\n\t.endif\n\t"
+                   "ds_read_b32 %[t], %[ra] offset:12\n\t"
+                   "s_add_u32 %[cnt], %[cnt], 1\n\t"
+                   "s_waitcnt lgkmcnt(0)\n\t"
+                   "v_cmp_ne_u32_e32 vcc, %[tag], %[t]\n\t"
+                   "s_cmp_lt_u32 %[cnt], 64\n\t"
+                   "s_cbranch_vccz 2f\n\t"
+                   "s_cbranch_scc1 1b\n\t"
+                   "2:\n\t"
+                   "s_mov_b32 %[pl], vcc_lo\n\t"
+                   "s_or_b32 %[pl], %[pl], vcc_hi\n\t"
+                   "s_mov_b32 m0, %[keep]"
+                   : [keep] "=&s"(keep), [cnt] "=&s"(cnt), [pl] "=&s"(pl), [t] "=&v"(t)
+                   : [src] "v"(src), [dst] "s"(dst), [ra] "v"(ra), [tag] "s"(want), [gap] "n"(GAP)
+                   : "vcc", "scc", "memory");
+      if (pl == 0u) return true;
+    }
+    return false;
+  };
+  for (int it = 0; it <= iters; ++it) {
+    if (it == 1) t0 = wall_clock64();
+    ++tag;
+    if (!first && !wait_tag(tag)) { if (lane == 0) cycles[b] = -(long long)it - 1; return; }
+    v4i rec = {lane, it, b, tag};
+    if (PLAIN_STORE) *(v4i*)((char*)buf + my_off) = rec; else __builtin_amdgcn_raw_buffer_store_b128(rec, r, my_off, 0, 16);
+    if (first && !wait_tag(tag)) { if (lane == 0) cycles[b] = -(long long)it - 1; return; }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) cycles[b] = wall_clock64() - t0;
+}
+
+template <bool PLAIN, int GAP>
+int run_dma(const char* name, v4i* buf, long long* cyc, int* xcc, int nblocks, int partner_xor, int iters) {
+  CHECK(hipMemset(buf, 0, nblocks * 64 * 16));
+  CHECK(hipMemset(cyc, 0, nblocks * 8));
+  hipLaunchKernelGGL((k_pingpong_dma<PLAIN, GAP>), dim3(nblocks), dim3(64), 0, 0, buf, partner_xor, iters, cyc, xcc);
+  CHECK(hipGetLastError());
+  CHECK(hipDeviceSynchronize());
+  std::vector<long long> h(nblocks);
+  std::vector<int> hx(nblocks);
+  CHECK(hipMemcpy(h.data(), cyc, sizeof(long long) * nblocks, hipMemcpyDeviceToHost));
+  CHECK(hipMemcpy(hx.data(), xcc, sizeof(int) * nblocks, hipMemcpyDeviceToHost));
+  double sum = 0; long long mx = 0;
+  for (int i = 0; i < nblocks; ++i) { sum += h[i]; if (h[i] > mx) mx = h[i]; }
+  double us_rt = (sum / nblocks) / 100.0 / iters;
+  printf("[c0=%lld] %-40s blocks=%4d xor=%3d (xcc %d<->%d): one-way %.3f us (max %.3f)\n", h[0], name, nblocks, partner_xor, hx[0],
+         hx[partner_xor], us_rt / 2, mx / 100.0 / iters / 2);
+  return 0;
+}
+
 __global__ void k_dpp(int* out) {
   int lane = threadIdx.x;
   int v = lane * 10;
@@ -121,6 +198,21 @@ int main() {
     }
     if (fg) (void)hipFree(fg);
     if (uc) (void)hipFree(uc);
+    for (int nb : {2, 256, 1024}) {
+      for (int px : {1, 8}) {
+        if (px >= nb) continue;
+        run<16, 16, false>("VGPR poll: st sc1 / ld sc1", buf, cyc, xcc, nb, px, iters);
+        run_dma<false, 0>("LDS-DMA poll, no gap: st sc1 / ld sc1", buf, cyc, xcc, nb, px, iters);
+        run_dma<false, 1>("LDS-DMA poll, s_sleep 1: st sc1 / ld sc1", buf, cyc, xcc, nb, px, iters);
+        run_dma<false, 9>("LDS-DMA poll, one in flight: st sc1 / ld sc1", buf, cyc, xcc, nb, px, iters);
+        if (px == 8) {
+          run<0, 16, true>("VGPR poll: st plain / ld sc1", buf, cyc, xcc, nb, px, iters);
+          run_dma<true, 0>("LDS-DMA poll, no gap: st plain / ld sc1", buf, cyc, xcc, nb, px, iters);
+          run_dma<true, 1>("LDS-DMA poll, s_sleep 1: st plain / ld sc1", buf, cyc, xcc, nb, px, iters);
+          run_dma<true, 9>("LDS-DMA poll, one in flight: st plain / ld sc1", buf, cyc, xcc, nb, px, iters);
+        }
+      }
+    }
     if (getenv("HOP_BENCH_MEMTYPE_ONLY")) return 0;
   }
   for (int nb : {2, 16, 256, 1024}) {
