@@ -650,7 +650,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       if (form == 3) {
         ctx->f.wg_poll_gap = (ctx->opt_poll_gap > 0 ? ctx->opt_poll_gap - 1 : kPvPollGap) |
                              ((ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : kPvPreSleep) << 8) |
-                             ((ctx->L.wg_per_xcd > 0 || std::getenv("FLAME_NLTGV2_FOUR_BUFFERS")) ? (1 << 30) : 0);
+                             ((ctx->L.wg_per_xcd > 0) ? (1 << 30) : 0);
         ctx->f.probe = nullptr;
         if (ctx->opt_probe) {  // [patch][step][8 words]
           const size_t words = (size_t)ctx->L.wg_count * (size_t)n * 8;
