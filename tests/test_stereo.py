@@ -720,3 +720,39 @@ def test_gpu_randomized_differential(built, trial):
         assert rc_o == 0 and rc_g == 0, (rc_o, rc_g, st_g)
         assert out_g.tobytes() == out_o.tobytes()
         assert st_g["num_idepth_updates"] == st_o[0] and st_g["num_fail_max_cost"] == st_o[5]
+
+
+@gpu
+def test_gpu_resident_feature_set_api(built):
+    """flame_stereo_set_features / update_resident / get_features / features_device: sizes, replacement, argument errors."""
+    import ctypes as C
+
+    from flame_amd import NLTGV2Error
+    from flame_amd.stereo import FEATURE_DTYPE, FeatureTracker, _lib
+
+    sc, imgs, feats, poses = _scene_case(320, 240, 200)
+    f = feats.copy().view(FEATURE_DTYPE)
+    with FeatureTracker(sc.K32, sc.Kinv32, sc.width, sc.height, border=5) as tr:
+        for fid, img in imgs.items():
+            tr.add_frame(fid, img)
+        assert tr.get_features().shape == (0,) and tr.features_device() == (0, 0)
+        tr.set_features(f)
+        ptr, n = tr.features_device()
+        assert ptr != 0 and n == f.shape[0]
+        assert tr.get_features().tobytes() == f.tobytes()            # round trip before any update
+        rc, st = tr.update_resident(_product_params(), 12, 11, poses)
+        assert rc == 0 and st["num_idepth_updates"] > 0
+        once = tr.get_features()
+        rc, _ = tr.update_resident(_product_params(), 12, 11, poses, wait=False)   # enqueued only; ordered on the stream
+        twice = tr.get_features()
+        assert rc == 0 and (twice["num_updates"] >= once["num_updates"]).all() and twice.tobytes() != once.tobytes()
+        tr.set_features(f[:17])                                       # replaced by a smaller set
+        assert tr.get_features().shape == (17,)
+        L = _lib()
+        n_out = C.c_int(0)
+        small = np.empty(3, FEATURE_DTYPE)
+        assert L.flame_stereo_get_features(tr._ctx, 3, small.ctypes.data, C.byref(n_out)) == -1 and n_out.value == 17
+        assert L.flame_stereo_set_features(tr._ctx, -1, None) == -1
+        assert L.flame_stereo_set_option(tr._ctx, 1, 7) == -1 and L.flame_stereo_set_option(tr._ctx, 99, 0) == -1
+        with pytest.raises(NLTGV2Error):
+            tr.update_resident(_product_params(), 12, 77, [dict(p, id=99) for p in poses])  # a pose-frame that is not resident
