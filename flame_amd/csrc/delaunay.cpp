@@ -176,14 +176,17 @@ class Triangulator {
       for (int i = 0; i < 3; ++i)
         if (t[cur].v[i] == GHOST) cur = t[cur].n[i];
     }
+    int from = -1;  // the triangle the walk came from: d is on this side of the shared edge, no need to test it again
     for (size_t guard = 0; guard < t.size() + 8; ++guard) {
       const Tri& T = t[cur];
       bool moved = false;
       for (int i = 0; i < 3; ++i) {
+        if (T.n[i] == from) continue;
         const int a = T.v[(i + 1) % 3], b = T.v[(i + 2) % 3];
         if (orient(a, b, d) < 0) {
           const int nb = T.n[i];
           if (is_ghost(t[nb])) return nb;
+          from = cur;
           cur = nb;
           moved = true;
           break;
@@ -318,10 +321,17 @@ extern "C" int flame_delaunay_triangulate(const float* xy, int32_t n, int32_t* t
       const uint32_t qx = (uint32_t)(((double)xy[2 * i] - minx) * sx), qy = (uint32_t)(((double)xy[2 * i + 1] - miny) * sy);
       key[(size_t)i] = spread16(qx) | (spread16(qy) << 1);
     }
-    std::vector<uint64_t> packed((size_t)n);  // (key, index): ties keep index order, as a stable sort would
-    for (int32_t i = 0; i < n; ++i) packed[(size_t)i] = ((uint64_t)key[(size_t)i] << 32) | (uint32_t)i;
-    std::sort(packed.begin(), packed.end());
-    for (int32_t i = 0; i < n; ++i) order[(size_t)i] = (int)(uint32_t)packed[(size_t)i];
+    // stable LSD radix sort by key (3 passes of 11 bits): ties keep index order
+    std::vector<int> tmp((size_t)n);
+    std::vector<uint32_t> count(2049);
+    for (int pass = 0; pass < 3; ++pass) {
+      const int shift = 11 * pass;
+      std::fill(count.begin(), count.end(), 0u);
+      for (int32_t i = 0; i < n; ++i) count[((key[(size_t)order[(size_t)i]] >> shift) & 2047u) + 1]++;
+      for (int b = 0; b < 2048; ++b) count[(size_t)b + 1] += count[(size_t)b];
+      for (int32_t i = 0; i < n; ++i) tmp[count[(key[(size_t)order[(size_t)i]] >> shift) & 2047u]++] = order[(size_t)i];
+      order.swap(tmp);
+    }
   }
 
   // ---- first non-degenerate triangle --------------------------------------------------------------------
