@@ -81,10 +81,13 @@ struct Pt {
 
 const int GHOST = -1;
 
-struct Tri {
+struct alignas(32) Tri {
   int v[3];
-  int n[3];  // neighbour across the edge opposite v[i]
-  bool alive;
+  int n[3];         // neighbour across the edge opposite v[i]
+  uint8_t alive;
+  uint8_t ghost;    // one of v[] is GHOST
+  uint8_t in_cavity;  // scratch of insert(), reset after each insertion
+  uint8_t pad_[5];
 };
 
 class Triangulator {
@@ -92,13 +95,18 @@ class Triangulator {
   std::vector<Pt> p;
   std::vector<Tri> t;
   std::vector<int> cavity, stack_;
-  std::vector<char> in_cavity;  // per triangle, reset after each insertion
   bool filter_ok = false;       // differences of coordinates are exact in double
+  // the filters' error bounds with every coordinate difference replaced by the extent D of the point set:
+  // orient: 4e-16 (|l| + |r|) <= 4e-16 * 2 D^2;  incircle: 1.2e-15 * permanent <= 1.2e-15 * 12 D^4
+  double ori_static = 0.0, icc_static = 0.0;
 
   int orient(int a, int b, int c) const {  // > 0: c to the left of a->b (counter-clockwise), exact
     if (filter_ok) {  // the differences are exact in double; only the two products and their difference round
       const double l = (p[b].fx - p[a].fx) * (p[c].fy - p[a].fy), r = (p[b].fy - p[a].fy) * (p[c].fx - p[a].fx);
-      const double det = l - r, bound = 4.0e-16 * (std::fabs(l) + std::fabs(r));  // > (3 + 16 eps) eps, Shewchuk's ccwerrboundA
+      const double det = l - r;
+      if (det > ori_static) return 1;  // (the a-priori bound over the whole point set: no need to form this call's own)
+      if (det < -ori_static) return -1;
+      const double bound = 4.0e-16 * (std::fabs(l) + std::fabs(r));  // > (3 + 16 eps) eps, Shewchuk's ccwerrboundA
       if (det > bound) return 1;
       if (det < -bound) return -1;
     }
@@ -115,6 +123,8 @@ class Triangulator {
       const double adxbdy = adx * bdy, bdxady = bdx * ady;
       const double alift = adx * adx + ady * ady, blift = bdx * bdx + bdy * bdy, clift = cdx * cdx + cdy * cdy;
       const double det = alift * (bdxcdy - cdxbdy) + blift * (cdxady - adxcdy) + clift * (adxbdy - bdxady);
+      if (det > icc_static) return 1;
+      if (det < -icc_static) return -1;
       const double permanent = (std::fabs(bdxcdy) + std::fabs(cdxbdy)) * alift +
                                (std::fabs(cdxady) + std::fabs(adxcdy)) * blift +
                                (std::fabs(adxbdy) + std::fabs(bdxady)) * clift;
@@ -135,6 +145,7 @@ class Triangulator {
   // (a, b, GHOST) the "disk" is the open half-plane to the left of a->b plus the open segment ab.
   bool in_disk(int ti, int d) const {
     const Tri& T = t[ti];
+    if (!T.ghost) return incircle(T.v[0], T.v[1], T.v[2], d) > 0;
     for (int i = 0; i < 3; ++i) {
       if (T.v[i] == GHOST) {
         const int a = T.v[(i + 1) % 3], b = T.v[(i + 2) % 3];
@@ -154,7 +165,9 @@ class Triangulator {
     Tri T;
     T.v[0] = a, T.v[1] = b, T.v[2] = c;
     T.n[0] = T.n[1] = T.n[2] = -1;
-    T.alive = true;
+    T.alive = 1;
+    T.ghost = (a == GHOST || b == GHOST || c == GHOST) ? 1 : 0;
+    T.in_cavity = 0;
     if (!free_.empty()) {  // reuse the slot of a removed triangle: the working set stays ~2n triangles
       const int i = free_.back();
       free_.pop_back();
@@ -162,11 +175,10 @@ class Triangulator {
       return i;
     }
     t.push_back(T);
-    in_cavity.push_back(0);
     return (int)t.size() - 1;
   }
 
-  static bool is_ghost(const Tri& T) { return T.v[0] == GHOST || T.v[1] == GHOST || T.v[2] == GHOST; }
+  static bool is_ghost(const Tri& T) { return T.ghost != 0; }
 
   // Visibility walk from a real triangle; returns a triangle (real or ghost) whose disk contains d, or -1
   // when d coincides with an existing vertex.
@@ -202,15 +214,15 @@ class Triangulator {
     cavity.clear();
     stack_.clear();
     stack_.push_back(seed);
-    in_cavity[seed] = 1;
+    t[seed].in_cavity = 1;
     while (!stack_.empty()) {
       const int ti = stack_.back();
       stack_.pop_back();
       cavity.push_back(ti);
       for (int i = 0; i < 3; ++i) {
         const int nb = t[ti].n[i];
-        if (nb >= 0 && !in_cavity[nb] && in_disk(nb, d)) {
-          in_cavity[nb] = 1;
+        if (nb >= 0 && !t[nb].in_cavity && in_disk(nb, d)) {
+          t[nb].in_cavity = 1;
           stack_.push_back(nb);
         }
       }
@@ -220,12 +232,12 @@ class Triangulator {
     for (int ti : cavity) {
       for (int i = 0; i < 3; ++i) {
         const int nb = t[ti].n[i];
-        if (nb < 0 || !in_cavity[nb]) be.push_back(BE{t[ti].v[(i + 1) % 3], t[ti].v[(i + 2) % 3], nb, -1});
+        if (nb < 0 || !t[nb].in_cavity) be.push_back(BE{t[ti].v[(i + 1) % 3], t[ti].v[(i + 2) % 3], nb, -1});
       }
     }
     for (int ti : cavity) {  // retire the cavity (their slots are reused by the fan below)
-      t[ti].alive = false;
-      in_cavity[ti] = 0;
+      t[ti].alive = 0;
+      t[ti].in_cavity = 0;
       free_.push_back(ti);
     }
     for (BE& e : be) {
@@ -311,6 +323,12 @@ extern "C" int flame_delaunay_triangulate(const float* xy, int32_t n, int32_t* t
     miny = std::min(miny, xy[2 * i + 1]), maxy = std::max(maxy, xy[2 * i + 1]);
   }
 
+  {
+    const double D = std::max((double)maxx - (double)minx, (double)maxy - (double)miny) * 1.0000001;
+    T.ori_static = 4.0e-16 * 2.0 * D * D;
+    T.icc_static = 1.2e-15 * 12.0 * D * D * D * D;
+  }
+
   // ---- insertion order: Morton curve (consecutive points are close: short walks) ----------------------
   std::vector<int> order((size_t)n);
   std::iota(order.begin(), order.end(), 0);
@@ -347,7 +365,6 @@ extern "C" int flame_delaunay_triangulate(const float* xy, int32_t n, int32_t* t
   int v0 = a, v1 = b, v2 = c;
   if (T.orient(v0, v1, v2) < 0) std::swap(v1, v2);
   T.t.reserve((size_t)n * 4 + 16);
-  T.in_cavity.reserve((size_t)n * 4 + 16);
   const int t0 = T.new_tri(v0, v1, v2);
   // ghosts: across edge opposite v[i] of t0, i.e. edge (v[i+1], v[i+2]); the ghost holds it reversed
   int g[3];
