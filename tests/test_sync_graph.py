@@ -200,3 +200,62 @@ def test_sync_to_empty_edgeless_and_single_vertex_frames(built):
         r.sync_graph(fid[:1], g["pos"][:1], g["data_term"][:1], g["data_weight"][:1], e0)
         r.run(p, 3)
         assert r.download_state()["x"].shape == (1,)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_randomized_frame_sequences(built, seed):
+    """Thirty frames of random churn (0-60 % of the vertices replaced), random triangulator orientation, zero data weights,
+    missing predictions (neighbour-mean init), sticky obstacles, random run lengths, synchronous and chained asynchronous
+    runs: every state array and the edge list equal the syncGraph restatement's after every frame."""
+    import torch  # noqa: F401
+
+    import flame_amd
+
+    rng = np.random.default_rng(100 + seed)
+    g0 = synth.make_graph("320x240", seed=30 + seed)
+    feat_id = (np.arange(g0["V"], dtype=np.int32) * 7 + 3)
+    pos, data = g0["pos"].copy(), g0["data_term"].copy()
+    next_id = int(feat_id.max()) + 1
+    params = flame_amd.Params()
+    ref = sync_oracle.RefGraph.from_flat(g0, feat_id)
+    with flame_amd.Regularizer(0) as reg:
+        reg.upload_graph(g0)
+        reg.set_feature_ids(feat_id)
+        for frame in range(30):
+            flat = sync_oracle.flatten(ref, feat_id)
+            n_total = 0
+            for _ in range(int(rng.integers(1, 4))):
+                n = int(rng.integers(1, 40))
+                (reg.run_async if rng.random() < 0.5 else reg.run)(params, n)
+                n_total += n
+            assert oracle.run(flat, n_total) == 0
+            sync_oracle.absorb(ref, flat, feat_id)
+            # next frame
+            keep = rng.random(len(feat_id)) > rng.random() * 0.6
+            keep[: 3] = True
+            n_new = int(rng.integers(0, 200))
+            new_pos = np.stack([rng.random(n_new) * 312 + 4, rng.random(n_new) * 232 + 4], 1).astype(np.float32)
+            order = rng.permutation(int(keep.sum()) + n_new)
+            feat_id = np.concatenate([feat_id[keep], np.arange(next_id, next_id + n_new)])[order].astype(np.int32)
+            next_id += n_new
+            pos = np.concatenate([(pos[keep] + rng.normal(0, 0.4, (int(keep.sum()), 2))).astype(np.float32), new_pos])[order]
+            pos = np.ascontiguousarray(np.clip(pos, 1.0, [318.0, 238.0]).astype(np.float32))
+            data = np.concatenate([data[keep], (0.5 + rng.random(n_new)).astype(np.float32)])[order].astype(np.float32)
+            weight = (0.5 + rng.random(len(feat_id))).astype(np.float32)
+            weight[rng.random(len(feat_id)) < 0.1] = 0.0
+            edges = synth.delaunay_edges_scipy(pos)
+            if rng.random() < 0.5:
+                edges = edges[:, ::-1].copy()
+            init_x = (data * np.float32(1.0 + 0.05 * rng.random())).astype(np.float32)
+            gs = 0.0
+            if rng.random() < 0.5:
+                init_x[rng.random(len(feat_id)) < 0.3] = np.nan
+                gs = float(0.5 + rng.random() * 2)
+            sticky = bool(rng.random() < 0.5)
+            reg.sync_graph(feat_id, pos, data, weight, edges, init_x=init_x, check_sticky_obstacles=sticky, sticky_threshold=0.03,
+                           init_graph_scale=gs)
+            sync_oracle.sync(ref, feat_id, pos, data, weight, edges, init_x=init_x, check_sticky=sticky, thr=0.03, init_graph_scale=gs)
+            flat = sync_oracle.flatten(ref, feat_id)
+            src, dst, fid = reg.topology()
+            assert np.array_equal(src, flat["src"]) and np.array_equal(dst, flat["dst"]) and np.array_equal(fid, feat_id), frame
+            assert_state_equal(reg.download_state(), flat, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"seed {seed} frame {frame}")
