@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -27,14 +28,17 @@ struct Rccl {
   ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string error;
+  std::mutex mu;
   bool load() {
+    std::lock_guard<std::mutex> lock(mu);
     if (lib) return true;
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
       lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
       if (lib) break;
     }
     if (!lib) {
-      error = std::string("dlopen librccl: ") + (dlerror() ? dlerror() : "?");
+      const char* why = dlerror();  // (reading it clears it: once)
+      error = std::string("dlopen librccl: ") + (why ? why : "?");
       return false;
     }
     bool ok = true;
@@ -82,6 +86,16 @@ int nccl_fail(flame_frames_ctx* ctx, ncclResult_t r, const char* what) {
   ctx->error = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error");
   return FLAME_NLTGV2_ERR_HIP;
 }
+// The calls below walk over the devices of the context; the caller's current device is put back on every way out.
+struct DeviceGuard {
+  int prev = -1;
+  DeviceGuard() {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
 #define FHIP(ctx, expr, what)                         \
   do {                                                \
     hipError_t _e = (expr);                           \
@@ -109,6 +123,7 @@ int flame_frames_create(flame_frames_ctx** out, int n_devices, const int* device
     ctx->error = g_rccl.error;
     return FLAME_NLTGV2_ERR_HIP;
   }
+  DeviceGuard guard;
   ctx->streams.assign((size_t)n_devices, nullptr);
   ctx->send.assign((size_t)n_devices, nullptr);
   ctx->recv.assign((size_t)n_devices, nullptr);
@@ -130,6 +145,7 @@ int flame_frames_create(flame_frames_ctx** out, int n_devices, const int* device
 
 int flame_frames_destroy(flame_frames_ctx* ctx) {
   if (!ctx) return FLAME_NLTGV2_OK;
+  DeviceGuard guard;
   for (size_t k = 0; k < ctx->devices.size(); ++k) {
     (void)hipSetDevice(ctx->devices[k]);
     if (k < ctx->streams.size() && ctx->streams[k]) (void)hipStreamSynchronize(ctx->streams[k]);
@@ -177,6 +193,7 @@ int flame_frames_gather(flame_frames_ctx* ctx) {
 
 int flame_frames_wait(flame_frames_ctx* ctx) {
   if (!ctx) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  DeviceGuard guard;
   for (size_t k = 0; k < ctx->streams.size(); ++k) {
     FHIP(ctx, hipSetDevice(ctx->devices[k]), "hipSetDevice");
     FHIP(ctx, hipStreamSynchronize(ctx->streams[k]), "hipStreamSynchronize");
@@ -192,6 +209,7 @@ int flame_frames_gathered(flame_frames_ctx* ctx, int k, void** block_device) {
 
 int flame_frames_download(flame_frames_ctx* ctx, int k, float* host_block) {
   if (!ctx || !host_block || k < 0 || k >= (int)ctx->comms.size()) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  DeviceGuard guard;
   FHIP(ctx, hipSetDevice(ctx->devices[(size_t)k]), "hipSetDevice");
   FHIP(ctx, hipStreamSynchronize(ctx->streams[(size_t)k]), "hipStreamSynchronize");
   FHIP(ctx, hipMemcpy(host_block, ctx->recv[(size_t)k], sizeof(float) * ctx->vmax * ctx->comms.size(), hipMemcpyDeviceToHost), "hipMemcpy");
