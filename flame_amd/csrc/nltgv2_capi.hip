@@ -160,6 +160,15 @@ struct flame_nltgv2_ctx {
   int timeouts_recovered = 0;     // persistent runs that timed out and were redone on the per-step path
   int torn_records_detected = 0;  // ... that the record verification (opt_verify) stopped, redone the same way
   int opt_verify = 0;             // 1: persistent kernels re-read every record after its tag matched; 2: + test hook
+  // Record placement of the patch-per-wave form (nltgv2_layout.hip): a pool of pages measured once per context, the
+  // records read across XCDs assigned to them once per topology
+  int opt_place = 1;              // 1 (default) on, 0 off
+  int place_state = 0;            // 0 not calibrated yet, 1 page ranking on the device, -1 unavailable (calibration failed)
+  uint64_t place_topo = ~0ull;    // topology / patches per XCD the record offsets are valid for
+  int place_per_xcd = 0;
+  char* place_base = nullptr;     // the pool, 4 KB aligned inside place_pool
+  float place_best_us = 0.0f, place_mean_us = 0.0f, place_worst_us = 0.0f;  // one-way hand-off by page choice, mean over XCD pairs
+  DevBuf place_pool, place_rank, place_fill, place_rec_off, place_patch, place_meas;
   // The persistent run(s) in flight, until finish() has seen the error word: what is needed to take them back.  One
   // run is taken back by swapping the buffer roles (it wrote the other copies).  When more work is enqueued before the
   // first run has been checked (run_async back to back: the frame loop, bench.py), the state the chain started from is
@@ -566,6 +575,86 @@ int enqueue_photo_sweep(flame_nltgv2_ctx* ctx, bool packed_current) {
   return 0;
 }
 
+// Record placement, once per context: every page of the pool is timed for all 28 pairs of XCDs (k_place_calibrate) and
+// ranked per pair.  ~3 ms, at the first run that can use it.  Anything unexpected (a pair missing because two blocks
+// shared an XCD, a wait that expired because the GPU is busy with someone else's work) switches placement off for this
+// context: the records then keep their linear places.
+int place_calibrate(flame_nltgv2_ctx* ctx) {
+  ctx->place_state = -1;
+  constexpr int P = kPlacePages, kIters = 12;
+  const size_t pool_bytes = (size_t)2 * P * 4096;
+  int rc = ensure(ctx, ctx->place_pool, pool_bytes + 4096);
+  if (!rc) rc = ensure(ctx, ctx->place_meas, sizeof(unsigned) * 64 * 2 * P + sizeof(int) * 64 + sizeof(int));
+  if (!rc) rc = ensure(ctx, ctx->place_rank, sizeof(uint16_t) * 2 * 64 * P);
+  if (!rc) rc = ensure(ctx, ctx->place_fill, sizeof(int) * (2 * P + 16));  // (+ the rotation word of the launches)
+  if (rc) return rc;
+  ctx->place_base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ctx->place_pool.p) + 4095) & ~uintptr_t(4095));
+  unsigned* d_out = (unsigned*)ctx->place_meas.p;
+  int* d_xcc = (int*)(d_out + (size_t)64 * 2 * P);
+  int* d_fail = d_xcc + 64;
+  HIPCHK(ctx, hipMemsetAsync(ctx->place_base, 0, pool_bytes, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->place_meas.p, 0, sizeof(unsigned) * 64 * 2 * P + sizeof(int) * 65, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->place_fill.p, 0, sizeof(int) * (2 * P + 16), ctx->stream));
+  LAUNCHCHK(ctx, launch_place_calibrate(ctx->place_base, 2 * P, kIters, d_out, d_xcc, d_fail, ctx->stream));
+  std::vector<unsigned> out((size_t)64 * 2 * P);
+  int xcc[65];
+  HIPCHK(ctx, hipMemcpyAsync(out.data(), d_out, sizeof(unsigned) * out.size(), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(xcc, d_xcc, sizeof(int) * 65, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->place_base, 0, pool_bytes, ctx->stream));  // (tags of the calibration: gone)
+  if (xcc[64] != 0) return 0;  // a wait expired
+  std::vector<unsigned> lat((size_t)64 * 2 * P, 0u);  // [8 a + b][page]: a record written on XCD a, seen on XCD b
+  bool have[64] = {false};
+  for (int b = 8; b < 64; ++b) {
+    const int x = b & 7, j = b >> 3, pb = ((8 - j) & 7) * 8 + ((x + j) & 7);
+    const int from = xcc[pb], to = xcc[b];  // block b timed what its partner sent
+    if (from < 0 || from > 7 || to < 0 || to > 7 || from == to) return 0;
+    for (int pg = 0; pg < 2 * P; ++pg) {
+      const unsigned t = out[(size_t)b * 2 * P + pg];
+      if (t == 0u || t > (1u << 24)) return 0;  // (a clock that ran backwards between two XCDs would show up here)
+      lat[(size_t)(from * 8 + to) * 2 * P + pg] = t;
+    }
+    have[from * 8 + to] = true;
+  }
+  for (int a = 0; a < 8; ++a)
+    for (int b = 0; b < 8; ++b)
+      if (a != b && !have[a * 8 + b]) return 0;
+  std::vector<uint16_t> rank((size_t)2 * 64 * P);
+  double best = 0.0, mean = 0.0, worst = 0.0;
+  for (int par = 0; par < 2; ++par)
+    for (int c = 0; c < 64; ++c) {
+      uint16_t* r = &rank[((size_t)par * 64 + c) * P];
+      for (int t = 0; t < P; ++t) r[t] = (uint16_t)t;
+      if (c / 8 == c % 8) continue;
+      const unsigned* l = &lat[(size_t)c * 2 * P + (size_t)par * P];
+      std::stable_sort(r, r + P, [&](uint16_t u, uint16_t v) { return l[u] < l[v]; });
+      double m = 0.0;
+      for (int t = 0; t < P; ++t) m += l[t];
+      best += l[r[0]], worst += l[r[P - 1]], mean += m / P;
+    }
+  const double to_us = 1.0 / (100.0 * kIters) / (2.0 * 56.0);  // 100 MHz ticks of kIters hand-offs; mean of 2 x 56 classes
+  ctx->place_best_us = (float)(best * to_us), ctx->place_mean_us = (float)(mean * to_us), ctx->place_worst_us = (float)(worst * to_us);
+  HIPCHK(ctx, hipMemcpyAsync(ctx->place_rank.p, rank.data(), sizeof(uint16_t) * rank.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (`rank` is pageable and leaves scope)
+  ctx->place_state = 1;
+  return 0;
+}
+
+// ... and once per topology: the records that are read across XCDs get their places (k_place_assign)
+int place_records(flame_nltgv2_ctx* ctx, int per_xcd) {
+  const size_t stride = records_capacity(ctx->L);
+  int rc = ensure(ctx, ctx->place_rec_off, sizeof(int32_t) * 2 * stride);
+  if (!rc) rc = ensure(ctx, ctx->place_patch, sizeof(int32_t) * stride);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemsetAsync(ctx->place_rec_off.p, 0xff, sizeof(int32_t) * 2 * stride, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->place_fill.p, 0, sizeof(int) * 2 * kPlacePages, ctx->stream));
+  LAUNCHCHK(ctx, launch_place_records(ctx->c, ctx->f, per_xcd, (const int32_t*)ctx->wg_v0.p, (const int32_t*)ctx->order_m.p,
+                                      (const int32_t*)ctx->rid_of.p, (int32_t*)ctx->place_patch.p, (const uint16_t*)ctx->place_rank.p,
+                                      kPlacePages, (int*)ctx->place_fill.p, (int32_t*)ctx->place_rec_off.p, (int)stride, ctx->stream));
+  ctx->place_topo = ctx->topo, ctx->place_per_xcd = per_xcd;
+  return 0;
+}
+
 int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   if (n <= 0) return 0;
   if (ctx->opt_solver == 1) {  // canonical 4-sweep path
@@ -604,6 +693,10 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
     if ((uint64_t)ctx->tag_next + (uint64_t)n >= 0x07ff0000ull || (ctx->xbuf_form != 0 && ctx->xbuf_form != form)) {
       const size_t bytes = kXbufBytesPerVertex * records_capacity(ctx->L);
       HIPCHK(ctx, hipMemsetAsync(ctx->xbuf.p, 0, bytes, ctx->stream));
+      if (ctx->place_base) {
+        HIPCHK(ctx, hipMemsetAsync(ctx->place_base, 0, (size_t)2 * kPlacePages * 4096, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync((int*)ctx->place_fill.p + 2 * kPlacePages, 0, 64, ctx->stream));
+      }
       ctx->tag_next = 1;
     }
     ctx->xbuf_form = form;
@@ -651,6 +744,23 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
         ctx->f.wg_poll_gap = (ctx->opt_poll_gap > 0 ? ctx->opt_poll_gap - 1 : kPvPollGap) |
                              ((ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : kPvPreSleep) << 8) |
                              ((ctx->L.wg_per_xcd > 0) ? (1 << 30) : 0);
+        ctx->f.rec_off = nullptr, ctx->f.place_pool = nullptr;
+        if (ctx->opt_place && ctx->L.wg_per_xcd == 0 && groups.size() == 1 && gr.begin == 0 && xcds == 8 && (dual & 1)) {
+          if (ctx->place_state == 0) {
+            rc = place_calibrate(ctx);
+            if (rc) return rc;
+          }
+          const int per_xcd = (gr.count + xcds - 1) / xcds;
+          if (ctx->place_state == 1 && (ctx->place_topo != ctx->topo || ctx->place_per_xcd != per_xcd)) {
+            rc = place_records(ctx, per_xcd);
+            if (rc) return rc;
+          }
+          if (ctx->place_state == 1) {
+            ctx->f.place_pool = ctx->place_base, ctx->f.rec_off = (const int32_t*)ctx->place_rec_off.p;
+            ctx->f.rec_off_stride = (int)records_capacity(ctx->L);
+            ctx->f.rot_word = (unsigned*)ctx->place_fill.p + 2 * kPlacePages;
+          }
+        }
         ctx->f.probe = nullptr;
         if (ctx->opt_probe) {  // [patch][step][8 words]
           const size_t words = (size_t)ctx->L.wg_count * (size_t)n * 8;
@@ -915,14 +1025,19 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
       {&ctx->wg_info, L.wg_info.data(), sizeof(int32_t) * L.wg_info.size()},
       {&ctx->wg_v0, L.wg_v0.data(), sizeof(int32_t) * L.wg_v0.size()}, {&ctx->rid_on, L.rid_on.data(), sizeof(int32_t) * L.rid_on.size()}};
   cp.insert(cp.end(), extra, extra + n_extra);
-  const StageFill fills[] = {
+  std::vector<StageFill> fills = {
       {ctx->err.p, sizeof(int), 0u}, {ctx->abort_flag.p, sizeof(int), 0u}, {ctx->xbuf.p, kXbufBytesPerVertex * records_capacity(L) + 64, 0u},
       // empty slots / padding vertices of the second copies: zero, as the packing kernels write them in the first
       {ctx->hq_alt.p, sizeof(float4) * n_slots, 0u}, {ctx->vstate_alt.p, sizeof(float4) * n_packed, 0u},
       // the spare rows behind the last slice: no edge, neighbour 0 (what the unrolled sweeps may read past a slice's end)
       {(char*)ctx->rec_edge.p + sizeof(int32_t) * (size_t)L.rows * kWave, sizeof(int32_t) * kRowPad * kWave, 0xffffffffu},
       {(char*)ctx->rec_nbr.p + sizeof(uint32_t) * (size_t)L.rows * kWave, sizeof(uint32_t) * kRowPad * kWave, 0u}};
-  rc = staged_h2d(ctx, cp.data(), cp.size(), fills, sizeof(fills) / sizeof(fills[0]));
+  // (the tags start over below: no record of an earlier topology may survive, in the placement pool either)
+  if (ctx->place_base) {
+    fills.push_back(StageFill{ctx->place_base, (size_t)2 * kPlacePages * 4096, 0u});
+    fills.push_back(StageFill{(int*)ctx->place_fill.p + 2 * kPlacePages, 64, 0u});
+  }
+  rc = staged_h2d(ctx, cp.data(), cp.size(), fills.data(), fills.size());
   if (rc) return rc;
   LAUNCHCHK(ctx, launch_build_sell(ctx->c, ctx->f, (const int32_t*)ctx->iperm.p, ctx->stream));
   if (L.wg_ok)
@@ -1054,7 +1169,8 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
               &ctx->cost_out, &ctx->img_ref, &ctx->img_cmp, &ctx->photo_err, &ctx->r_tris, &ctx->r_valid, &ctx->r_keys,
               &ctx->r_img, &ctx->r_cov, &ctx->r_vtx, &ctx->r_val, &ctx->wg_slot, &ctx->wg_vid, &ctx->wg_meta, &ctx->wg_nbr,
               &ctx->wg_fetch, &ctx->wg_info, &ctx->wg_v0, &ctx->rid_on, &ctx->probe, &ctx->snap_hq, &ctx->snap_vstate, &ctx->snap_bar, &ctx->iperm,
-              &ctx->order_m, &ctx->rid_of, &ctx->d_stage, &ctx->sync_init, &ctx->sync_vmap, &ctx->sync_emap, &ctx->sync_need};
+              &ctx->order_m, &ctx->rid_of, &ctx->d_stage, &ctx->sync_init, &ctx->sync_vmap, &ctx->sync_emap, &ctx->sync_need,
+              &ctx->place_pool, &ctx->place_rank, &ctx->place_fill, &ctx->place_rec_off, &ctx->place_patch, &ctx->place_meas};
   for (auto& b : ctx->sp_v) ctx->all.push_back(&b);
   for (auto& b : ctx->sp_q) ctx->all.push_back(&b);
   *out = ctx;
@@ -1107,6 +1223,10 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
     case FLAME_NLTGV2_OPT_SHADOWS:
       if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_shadows = value;
+      return 0;
+    case FLAME_NLTGV2_OPT_PLACEMENT:
+      if (value < 0 || value > 1) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_place = value;
       return 0;
     case FLAME_NLTGV2_OPT_POLL_GAP:
       if (value < 0 || value > 4) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
@@ -1896,7 +2016,53 @@ int flame_nltgv2_layout_selftest(flame_nltgv2_ctx* ctx, int64_t* mismatches) {
     if (ctx->he_built) bad += (H.he_waves != L.he_waves) + (H.he_max_chain != L.he_max_chain) + (H.comp_he_wave != L.comp_he_wave);
     if (e) return fail(ctx, FLAME_NLTGV2_ERR_HIP);
   }
+  if (bad == 0 && ctx->place_state == 1 && ctx->place_topo == ctx->topo && L.wg_per_xcd == 0 && L.wg_ok) {
+    // placed records: aligned, inside their parity's half of the pool, no slot given out twice -- and exactly the records a
+    // patch on another XCD reads (host: the same rule as k_place_assign, from the host's own patch walk)
+    const size_t stride = records_capacity(L);
+    std::vector<int32_t> off(2 * stride);
+    if (hipMemcpy(off.data(), ctx->place_rec_off.p, sizeof(int32_t) * off.size(), hipMemcpyDeviceToHost) != hipSuccess)
+      return fail(ctx, FLAME_NLTGV2_ERR_HIP);
+    std::vector<int32_t> patch_of_rec((size_t)V, -1);
+    for (int32_t q = 0; q < H.wg_count; ++q)
+      for (int32_t i = 0; i < (H.wg_info[(size_t)q * 4 + 2] & 0xffff); ++i) patch_of_rec[(size_t)H.wg_info[(size_t)q * 4] + i] = q;
+    const int32_t per = ctx->place_per_xcd;
+    for (int par = 0; par < 2; ++par) {
+      std::vector<int32_t> used;
+      for (int32_t u = 0; u < V; ++u) {
+        const int32_t r = H.rid_of[(size_t)u], a = patch_of_rec[(size_t)r] / per;
+        bool crosses = false;
+        for (int32_t h = H.row_ptr[(size_t)u]; h < H.row_ptr[(size_t)u + 1] && !crosses; ++h)
+          crosses = patch_of_rec[(size_t)H.rid_of[(size_t)H.half_nbr[(size_t)h]]] / per != a;
+        const int32_t o = off[(size_t)par * stride + r];
+        bad += crosses != (o >= 0);
+        if (o < 0) continue;
+        bad += (o & 15) != 0 || o < par * kPlacePages * 4096 || o >= (par + 1) * kPlacePages * 4096;
+        used.push_back(o);
+      }
+      std::sort(used.begin(), used.end());
+      for (size_t i = 1; i < used.size(); ++i) bad += used[i] == used[i - 1];
+    }
+  }
   *mismatches = bad;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_placement_info(flame_nltgv2_ctx* ctx, int32_t* state, int32_t* placed_records, float* us) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (state) *state = ctx->place_state;
+  if (us) us[0] = ctx->place_best_us, us[1] = ctx->place_mean_us, us[2] = ctx->place_worst_us;
+  if (placed_records) {
+    *placed_records = 0;
+    if (ctx->have_graph && ctx->place_state == 1 && ctx->place_topo == ctx->topo) {
+      const size_t stride = records_capacity(ctx->L);
+      std::vector<int32_t> off(stride);
+      HIPCHK(ctx, hipMemcpyAsync(off.data(), ctx->place_rec_off.p, sizeof(int32_t) * stride, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      for (int32_t o : off) *placed_records += o >= 0;
+    }
+  }
   return FLAME_NLTGV2_OK;
 }
 

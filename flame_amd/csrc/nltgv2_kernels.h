@@ -101,6 +101,10 @@ struct FusedArgs {
   int32_t* wg_info = nullptr;
   int n_rec = 0;                       // record ids in use (>= V; more with shadow patches): sizes the exchange buffers
   int wg_poll_gap = 1;                 // 1: one s_sleep between the polls of k_persistent_pv, 0: none
+  char* place_pool = nullptr;          // record placement (nltgv2_layout.hip): pool of pages for the remote copies of the
+  const int32_t* rec_off = nullptr;    // records other XCDs read; rec_off[parity * stride + record] = byte offset or -1
+  int rec_off_stride = 0;
+  unsigned* rot_word = nullptr;        // ... and the word in which block 0 of a launch says which XCD it is on
   unsigned* probe = nullptr;           // optional per-patch, per-step cycle probe of k_persistent_pv (tools/pv_probe.py)
   int* abort_flag = nullptr;
   int* err = nullptr;
@@ -112,6 +116,13 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
                           int parity_in, unsigned tag0, int n_iters, int waves_per_block, unsigned max_spins,
                           int presleep, int dual, int tv_static_in_lds, int xcds, const RunTail* tail, bool cooperative,
                           hipStream_t stream);
+// Record placement (nltgv2_layout.hip): calibrate a pool of 2 x kPlacePages pages, then per topology give the records read
+// across XCDs a slot on a page that suits their pair of XCDs
+constexpr int kPlacePages = 96;
+int launch_place_calibrate(char* pool, int n_pages, int iters, unsigned* out, int* xcc_out, int* fail, hipStream_t s);
+int launch_place_records(const CanonArgs& c, const FusedArgs& a, int per_xcd, const int32_t* wg_v0, const int32_t* order_m,
+                         const int32_t* rid_of, int32_t* patch_of_rec, const uint16_t* ranking, int n_pages, int* fill,
+                         int32_t* rec_off, int stride, hipStream_t s);
 // One upload blob -> its buffers (and clears), nltgv2_layout.hip
 constexpr uint32_t kScatterFill = 0xffffffffu;
 struct ScatterEntry {

@@ -597,14 +597,39 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
                 void* xbuf, const int rec_bytes, const int dual_arg, const unsigned tag0, const int n_iters,
                 const unsigned max_spins_arg, const int poll_gap_arg, const SolverParams p,
                 int* __restrict__ err, int* __restrict__ abort_flag, const int32_t* __restrict__ perm,
-                const RunTail* __restrict__ tail, unsigned* __restrict__ probe) {
+                const RunTail* __restrict__ tail, unsigned* __restrict__ probe, char* place_pool,
+                const int32_t* __restrict__ rec_off, const int rec_off_stride, unsigned* rot_word) {
   extern __shared__ float4 lds[];
   constexpr int T = 64;
   const unsigned max_spins = max_spins_arg & 0x7fffffffu;
   const int dual = dual_arg & 1, verify = dual_arg >> 1;  // as in k_persistent_he
   const int poll_gap = poll_gap_arg & 255, pv_presleep = (poll_gap_arg >> 8) & 255;
   const int lane = (int)threadIdx.x;
-  const int b = blockIdx.x;
+  int b = blockIdx.x;
+  if (rot_word) {
+    // The dispatcher deals workgroups to the XCDs round-robin, but goes on where the previous dispatch stopped: block 0 lands
+    // on XCD r, block i on (i + r) % 8.  Record placement ranks pages by the XCDs a record really travels between, so the
+    // blocks are renumbered to make group k of the layout the one on XCD k: block 0 says where it is, everybody rotates by
+    // that (a bijection of the grid, whatever r is; if the dispatch was not a plain rotation the groups are merely less
+    // well placed, as they would be without this).
+    const unsigned want = (tag0 & 0x0fffffffu) << 4;
+    if (b == 0 && lane == 0) __hip_atomic_store(rot_word, want | read_xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned v = 0;
+    for (unsigned spins = 0;; ++spins) {
+      v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(rot_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if ((v & ~15u) == want) break;
+      if (spins > (max_spins_arg & 0x7fffffffu)) {
+        if (lane == 0) {
+          __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicOr(err, 2);
+        }
+        return;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    b += (int)(v & 7u);
+    if (b >= (int)gridDim.x) b -= (int)gridDim.x;
+  }
   const int xcd = b & 7, idx = b >> 3;
   if (idx >= wgs_per_xcd) return;
   if (xcd * wgs_per_xcd + idx >= n_wgs) return;
@@ -626,6 +651,11 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   float* const ldsf = reinterpret_cast<float*>(lds);
   const int f_slabC = 4 * o_slabC, f_ovfC = f_slabC + slab_slots;
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(xbuf);
+  // Placed records (nltgv2_layout.hip, "record placement"): the remote copy of a record that another XCD reads lives in a
+  // pool of 4 KB pages instead of the linear buffer, on a page whose home memory channel is close to both XCDs (the
+  // hand-off through the fabric takes 0.39-0.66 us depending on the page); rec_off[parity][record] is its byte offset in
+  // the pool, negative = the linear place.
+  const __amdgpu_buffer_rsrc_t rp = make_rsrc(place_pool ? static_cast<void*>(place_pool) : xbuf);
   // Memory side of the exchange: FOUR buffers by step (tag & 3), each [remote copy S bytes | same-XCD copy S bytes], then
   // the XCC table.  Two would do between instances that read each other (a record of step s is only overwritten by s+2
   // after every reader published s+1, i.e. consumed s); a shadow patch is read by, but does not read, some of its
@@ -704,6 +734,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
 
   // ---- where this lane's polls read: the remote copy of its foreign record, or the copy in this XCD's L2 ------------
   int off0 = (frid >= 0) ? (frid << 4) : 0;
+  bool fetch_remote = frid >= 0;
   if (dual) {
     const unsigned my_xcc = read_xcc_id();
     if (is_tail && publishes)
@@ -725,24 +756,43 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
         }
         __builtin_amdgcn_s_sleep(2);
       }
-      if (!timed_out && frid >= 0 && (g0 & 15u) == my_xcc) off0 += S;
+      if (!timed_out && frid >= 0 && (g0 & 15u) == my_xcc) off0 += S, fetch_remote = false;
     }
   }
   const unsigned long long fetch_mask = __ballot(frid >= 0);  // the lanes with a fetch duty (the wave runs with all 64 lanes)
   const bool mute = (max_spins_arg >> 31) != 0u && wg == wg_begin;  // test hook: FLAME_NLTGV2_OPT_FAULT_INJECT
   const bool pub_lane = is_tail && publishes;
+  const char* const xb_base = static_cast<const char*>(xbuf);
+  // by parity of the record's step (two buffers; with shadow patches -- four -- nothing is placed)
+  const bool placed = place_pool != nullptr && kPar == 2;
+  int pub0 = -1, pub1 = -1;
+  const char* src0 = xb_base + off0;
+  const char* src1 = xb_base + off0 + par;
+  if (placed) {
+    if (pub_lane) pub0 = rec_off[rid_base + loc], pub1 = rec_off[rec_off_stride + rid_base + loc];
+    if (fetch_remote) {
+      const int o0 = rec_off[frid], o1 = rec_off[rec_off_stride + frid];
+      if (o0 >= 0) src0 = place_pool + o0;
+      if (o1 >= 0) src1 = place_pool + o1;
+    }
+  }
+  auto publish = [&](const v4i_t o, const int pub, const int so) {  // (pub lanes only)
+    if (pub >= 0) {
+      __builtin_amdgcn_raw_buffer_store_b128(o, rp, pub, 0, kAuxSc1);
+    } else {
+      __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
+    }
+    if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
+  };
   {
     lds[(p0 ? rec_wstride : 0) + rec_w] = make_float4(xb, wb12.x, wb12.y, __uint_as_float(tag0));  // area A
     if (pub_lane && !mute) {
       v4i_t o;
       o.x = __float_as_int(xb), o.y = __float_as_int(wb12.x), o.z = __float_as_int(wb12.y), o.w = (int)tag0;
-      const int so = (int)(tag0 & (kPar - 1)) * par;
-      __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
-      if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
+      publish(o, p0 ? pub1 : pub0, (int)(tag0 & (kPar - 1)) * par);
     }
   }
   lds_wave_sync();
-  const char* const xb_base = static_cast<const char*>(xbuf);
   const unsigned lds_addr0 = (unsigned)(size_t)(lds);  // LDS byte address of the dynamic array
   unsigned pr_t0 = 0;
   if (PROBE) pr_t0 = (unsigned)clock64();
@@ -750,9 +800,11 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   // One step.  rd_nbr: LDS byte address of the neighbour's record; dst: LDS byte address of the step's fetch slots;
   // src: this lane's poll address; wr_rec: float4 index where the own record of the next step goes; so_out: memory offset
   // of the parity published.
-  auto step = [&](const unsigned s, const unsigned rd_nbr, const unsigned dst, const int wr_rec, const int fetch_area, const int it) {
+  auto step = [&](const unsigned s, const unsigned rd_nbr, const unsigned dst, const int wr_rec, const int fetch_area, const int it,
+                  const char* const src2, const int pub2) {
     const int so_in = (int)(s & (kPar - 1)) * par, so_out = (int)((s + 1u) & (kPar - 1)) * par;  // (wave-uniform)
-    const char* const src = xb_base + off0 + so_in;
+    // two buffers: the step's parity is fixed at the call site (src2: where this lane polls, pub2: where it publishes)
+    const char* const src = kPar == 2 ? src2 : xb_base + off0 + so_in;
     // ---- wait for the neighbours' records of step s ----------------------------------------------------------------
     v4f_t nbv;  // the tag word is read first, the record after it: a tag that matches vouches for the payload
     unsigned rounds = 0;
@@ -844,7 +896,9 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
       // what the LDS-DMA left in its slot: a record is final once its tag is visible, so a difference means a torn
       // 16-byte access (memory side or LDS side) -- reported, the run is taken back and redone per step.
       v4i_t g2 = {0, 0, 0, 0};
-      if (frid >= 0) g2 = __builtin_amdgcn_raw_buffer_load_b128(rx, off0, so_in, kAuxSc1);
+      if (frid >= 0) {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g2) : "v"(src) : "memory");
+      }
       const float4 l4 = lds[fetch_area + lane];
       if ((verify & 2) && it == 2 && wg == wg_begin && lane == 0) g2.x ^= 0x00400000;  // test hook
       const bool bad = frid >= 0 && (g2.x != __float_as_int(l4.x) || g2.y != __float_as_int(l4.y) || g2.z != __float_as_int(l4.z) ||
@@ -935,8 +989,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
     if (pub_lane) {
       v4i_t o;
       o.x = __float_as_int(nb), o.y = __float_as_int(wbn.x), o.z = __float_as_int(wbn.y), o.w = (int)(s + 1u);
-      __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so_out, kAuxSc1);
-      if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so_out, 0);
+      publish(o, pub2, so_out);
     }
     lds[wr_rec] = make_float4(nb, wbn.x, wbn.y, __uint_as_float(s + 1u));
     x_prev = x, w_prev = w12;  // step()'s prev copy, cc:37-42
@@ -959,13 +1012,17 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   const unsigned dstA = __builtin_amdgcn_readfirstlane(lds_addr0 + 16u * (unsigned)(areaA + lcap));
   const unsigned dstB = __builtin_amdgcn_readfirstlane(lds_addr0 + 16u * (unsigned)(areaB + lcap));
   const int wrA_rec = (valid ? areaA : 0) + rec_w, wrB_rec = (valid ? areaB : 0) + rec_w;
+  // the records of step tag0 + even are in memory buffer p0 ("A"), those of the odd steps in the other
+  const char* const srcA = p0 ? src1 : src0;
+  const char* const srcB = p0 ? src0 : src1;
+  const int pubA = p0 ? pub1 : pub0, pubB = p0 ? pub0 : pub1;
   int it = 0;
   for (; it + 1 < n_iters && !timed_out; it += 2) {
-    step(tag0 + (unsigned)it, rdA_nbr, dstA, wrB_rec, areaA + lcap, it);
+    step(tag0 + (unsigned)it, rdA_nbr, dstA, wrB_rec, areaA + lcap, it, srcA, pubB);
     if (timed_out) break;
-    step(tag0 + (unsigned)it + 1u, rdB_nbr, dstB, wrA_rec, areaB + lcap, it + 1);
+    step(tag0 + (unsigned)it + 1u, rdB_nbr, dstB, wrA_rec, areaB + lcap, it + 1, srcB, pubA);
   }
-  if (it < n_iters && !timed_out) step(tag0 + (unsigned)it, rdA_nbr, dstA, wrB_rec, areaA + lcap, it);
+  if (it < n_iters && !timed_out) step(tag0 + (unsigned)it, rdA_nbr, dstA, wrB_rec, areaA + lcap, it, srcA, pubB);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA in flight when the wave ends
 
   if (timed_out) {
@@ -1740,10 +1797,14 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
     const int32_t *w0 = a.wg_slot, *w1 = a.wg_vid, *w3 = a.wg_nbr, *w4 = a.wg_fetch, *w5 = a.wg_info;
     const uint32_t* w2 = a.wg_meta;
     unsigned* probe = a.probe;
+    char* place_pool = (a.rec_off && wave_begin == 0 && xcds == 8) ? a.place_pool : nullptr;
+    const int32_t* rec_off = a.rec_off;
+    int rec_off_stride = a.rec_off_stride;
+    unsigned* rot_word = place_pool ? a.rot_word : nullptr;
     const unsigned ldsv = 16u * (unsigned)(2 * (lcap + 64) + slab_slots + 64) + 4u * (unsigned)(slab_slots + 64);
     void* vargs[] = {&wave_begin, &n_waves, &wgx, &lcap, &slab_slots, &w0, &w1, &w2, &w3, &w4, &w5, &hrec, &hq, &vstate,
                      &hq_out, &vstate_out, &vaux, &bin, &bout, &vprev, &xbuf, &rec_bytes, &dual, &tag0, &n_iters,
-                     &max_spins, &poll_gap, &pp, &err, &abort_flag, &perm, &tail, &probe};
+                     &max_spins, &poll_gap, &pp, &err, &abort_flag, &perm, &tail, &probe, &place_pool, &rec_off, &rec_off_stride, &rot_word};
     const void* fv = probe ? (const void*)k_persistent_pv<true> : (const void*)k_persistent_pv<false>;
     if (cooperative) return (int)hipLaunchCooperativeKernel(fv, gv, bv, vargs, ldsv, stream);
     return (int)hipLaunchKernel(fv, gv, bv, vargs, ldsv, stream);

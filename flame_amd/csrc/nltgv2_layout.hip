@@ -191,6 +191,148 @@ k_he_from_patches(const int n_patches, const int32_t* __restrict__ wg_slot, cons
   if (lane == 0) he_wave_chain[p] = mx > 1 ? mx : 1;
 }
 
+// ---- record placement -------------------------------------------------------------------------------------------------
+// The hand-off of a 16-byte record from one XCD to another goes through the memory channel the record's address belongs
+// to, and how long that takes depends on where that channel sits relative to the two XCDs: measured on MI355X
+// (tools/hop_bench, HOP_BENCH_ADDR_SCAN) 0.39-0.46 us on one half of the 4 KB pages and 0.59-0.66 us on the other half for
+// two XCDs of the same half of the package, 0.48-0.58 us for two XCDs of different halves -- the pattern repeats every
+// four pages, with a phase that differs from allocation to allocation.  k_persistent_pv's period is the slowest hand-off
+// plus a step's arithmetic, so the records other XCDs read are worth placing:
+//   * k_place_calibrate measures, once per context, every page of a small pool (2 step parities x kPlacePages) for all 56
+//     ordered pairs of XCDs at once: 56 single-wave blocks ping-pong a record per page; the host ranks the pages per pair
+//     and direction;
+//   * k_place_assign gives, per topology, every record that a patch on another XCD reads a slot on the best page of its
+//     (producer XCD, consumer XCD) pair that still has room -- a patch's records of one pair stay contiguous, as they are
+//     in the linear buffer -- and leaves -1 for the others (they keep their linear place).
+// Only addresses change: which XCD a patch really runs on is still found out at run time (the XCC table), a wrong guess
+// here costs time, not correctness.
+__device__ __forceinline__ unsigned place_xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 15u;
+}
+
+// Block b = 8 j + x (x = its XCD by dispatch order, j = 1..7) and block 8 (8 - j) + (x + j) % 8 are partners; the lower
+// one starts.  Per page they exchange `iters` round trips on a 64-byte line of their own.  The two directions of a pair
+// differ (the reader's side of the path is travelled more often than the writer's: 0.41-0.47 us on a page near the reader,
+// 0.57-0.61 us on one near the writer, for XCDs of different halves), so each record carries the device-wide 100 MHz clock
+// of its store and the receiver adds up (its clock when it sees the tag) - (the stamp):
+// out[b][page] = ticks of `iters` hand-offs partner -> b, xcc_out[b] = the XCD the block really ran on.
+__global__ void __launch_bounds__(64)
+k_place_calibrate(char* pool, const int n_pages, const int iters, unsigned* __restrict__ out, int* __restrict__ xcc_out,
+                  int* fail) {
+  const int b = blockIdx.x, x = b & 7, j = b >> 3;
+  if (threadIdx.x == 0) xcc_out[b] = (int)place_xcc_id();
+  if (j == 0) return;
+  const int pb = ((8 - j) & 7) * 8 + ((x + j) & 7);
+  const bool first = b < pb;
+  const int line = (first ? b : pb) * 64;
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(pool, 0, 0x7fffffff, 0x00020000);
+  typedef int v4i_t __attribute__((ext_vector_type(4)));
+  int tag = 0;
+  bool dead = false;
+  unsigned stamp = 0;
+  auto wait_tag = [&](const int off, const int want) {
+    for (unsigned spin = 0; spin < (1u << 17); ++spin) {
+      int o = off;
+      asm volatile("" : "+v"(o)::"memory");
+      const v4i_t g = __builtin_amdgcn_raw_buffer_load_b128(r, o, 0, 16);
+      if (g.w == want) {
+        stamp = (unsigned)g.x;
+        return true;
+      }
+      if ((spin & 1023u) == 1023u && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+    }
+    return false;
+  };
+  for (int pg = 0; pg < n_pages && !dead; ++pg) {
+    const int mine = pg * 4096 + line + (first ? 0 : 16), theirs = pg * 4096 + line + (first ? 16 : 0);
+    unsigned sum = 0;
+    for (int it = 0; it < iters + 2; ++it) {
+      ++tag;
+      if (!first) {
+        if (!wait_tag(theirs, tag)) {
+          dead = true;
+          break;
+        }
+        if (it >= 2) sum += (unsigned)wall_clock64() - stamp;
+      }
+      const v4i_t rec = {(int)(unsigned)wall_clock64(), 0, 0, tag};
+      __builtin_amdgcn_raw_buffer_store_b128(rec, r, mine, 0, 16);
+      if (first) {
+        if (!wait_tag(theirs, tag)) {
+          dead = true;
+          break;
+        }
+        if (it >= 2) sum += (unsigned)wall_clock64() - stamp;
+      }
+    }
+    if (threadIdx.x == 0) out[(size_t)b * n_pages + pg] = dead ? 0u : sum;
+  }
+  if (dead && threadIdx.x == 0) __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(256)
+k_place_patch_of_record(const int n_patches, const int32_t* __restrict__ wg_info, int32_t* __restrict__ patch_of_rec) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_patches) return;
+  const int r0 = wg_info[4 * p], n = wg_info[4 * p + 2] & 0xffff;
+  for (int i = 0; i < n; ++i) patch_of_rec[r0 + i] = p;
+}
+
+// One thread per patch (<= 64 vertices, ~10): the class of each of its records -- 8 a + b for the first neighbour found on
+// another XCD b, none if every reader is on the patch's own XCD a -- then, per parity and class, a run of slots on the first
+// page of the class's ranking that has room (pages hold 256 records; the counters may overshoot, a page that refused a
+// run simply stays a little emptier).
+__global__ void __launch_bounds__(64)
+k_place_assign(const int n_patches, const int per_xcd, const int32_t* __restrict__ wg_info, const int32_t* __restrict__ wg_v0,
+               const int32_t* __restrict__ order_m, const int32_t* __restrict__ rid_of, const int32_t* __restrict__ row_ptr,
+               const uint32_t* __restrict__ half, const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+               const int32_t* __restrict__ patch_of_rec, const uint16_t* __restrict__ ranking, const int n_pages,
+               int* __restrict__ fill, int32_t* __restrict__ rec_off, const int stride) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_patches) return;
+  const int r0 = wg_info[4 * p], n = wg_info[4 * p + 2] & 0xffff, v0 = wg_v0[p];
+  const int a = p / per_xcd;
+  signed char cls[64];
+  for (int i = 0; i < n && i < 64; ++i) {
+    const int o = order_m[v0 + i];
+    int c = -1;
+    for (int h = row_ptr[o]; h < row_ptr[o + 1] && c < 0; ++h) {
+      const uint32_t hh = half[h];
+      const int e = (int)(hh & ~kRole);
+      const int other = (hh & kRole) ? src[e] : dst[e];
+      const int xb = patch_of_rec[rid_of[other]] / per_xcd;
+      if (xb != a) c = a * 8 + xb;
+    }
+    cls[i] = (signed char)c;
+  }
+  for (int par = 0; par < 2; ++par) {
+    unsigned long long done = 0ull;
+    for (int i = 0; i < n && i < 64; ++i) {
+      const int c = cls[i];
+      if (c < 0 || ((done >> i) & 1ull)) continue;
+      int m = 0;
+      for (int k = i; k < n && k < 64; ++k) m += cls[k] == c;
+      const uint16_t* const rk = ranking + ((size_t)par * 64 + c) * n_pages;
+      int base = -1;
+      // (a run starts on a 128-byte line of its own: the records of one patch are written by one instruction; lines shared
+      //  with another patch's records would be invalidated under the reader at that patch's pace as well)
+      const int m8 = (m + 7) & ~7;
+      for (int t = 0; t < n_pages && base < 0; ++t) {
+        const int pg = rk[t];
+        const int s0 = atomicAdd(&fill[par * n_pages + pg], m8);
+        if (s0 + m8 <= 256) base = (par * n_pages + pg) * 4096 + s0 * 16;
+      }
+      for (int k = i; k < n && k < 64; ++k) {
+        if (cls[k] != c) continue;
+        done |= 1ull << k;
+        if (base >= 0) rec_off[(size_t)par * stride + r0 + k] = base, base += 16;
+      }
+    }
+  }
+}
+
 inline dim3 grid1d(long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
 }  // namespace
@@ -208,6 +350,21 @@ int launch_build_sell(const CanonArgs& c, const FusedArgs& a, const int32_t* ipe
   if (n_packed <= 0) return 0;
   hipLaunchKernelGGL(k_build_sell, grid1d(n_packed), dim3(256), 0, s, n_packed, a.perm, a.slice_row, c.row_ptr, c.half,
                      c.src, c.dst, iperm, a.rec_nbr, a.rec_edge, a.edge_src_slot);
+  return (int)hipGetLastError();
+}
+
+int launch_place_calibrate(char* pool, int n_pages, int iters, unsigned* out, int* xcc_out, int* fail, hipStream_t s) {
+  hipLaunchKernelGGL(k_place_calibrate, dim3(64), dim3(64), 0, s, pool, n_pages, iters, out, xcc_out, fail);
+  return (int)hipGetLastError();
+}
+
+int launch_place_records(const CanonArgs& c, const FusedArgs& a, int per_xcd, const int32_t* wg_v0, const int32_t* order_m,
+                         const int32_t* rid_of, int32_t* patch_of_rec, const uint16_t* ranking, int n_pages, int* fill,
+                         int32_t* rec_off, int stride, hipStream_t s) {
+  if (a.wg_count <= 0 || per_xcd <= 0) return 0;
+  hipLaunchKernelGGL(k_place_patch_of_record, grid1d(a.wg_count), dim3(256), 0, s, a.wg_count, a.wg_info, patch_of_rec);
+  hipLaunchKernelGGL(k_place_assign, grid1d(a.wg_count, 64), dim3(64), 0, s, a.wg_count, per_xcd, a.wg_info, wg_v0, order_m, rid_of,
+                     c.row_ptr, c.half, c.src, c.dst, patch_of_rec, ranking, n_pages, fill, rec_off, stride);
   return (int)hipGetLastError();
 }
 

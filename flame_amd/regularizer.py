@@ -27,7 +27,7 @@ _FP = C.POINTER(C.c_float)
 _IP = C.POINTER(C.c_int32)
 
 OPT_SOLVER, OPT_USE_HIPGRAPH, OPT_BLOCK_WAVES, OPT_UNROLL, OPT_PERSISTENT, OPT_DUAL_PUBLISH, OPT_TV_LDS, OPT_PRESLEEP, OPT_XCDS, OPT_FAULT_INJECT = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
-OPT_PROBE, OPT_POLL_GAP, OPT_VERIFY_RECORDS, OPT_SHADOWS = 12, 13, 14, 15
+OPT_PROBE, OPT_POLL_GAP, OPT_VERIFY_RECORDS, OPT_SHADOWS, OPT_PLACEMENT = 12, 13, 14, 15, 16
 RUN_PATHS = {0: "none", 1: "persistent", 2: "per-step hipGraph", 3: "per-step eager", 4: "canonical 4-sweep",
              5: "persistent-tv", 6: "persistent-pv"}
 ERR_NAN = -5
@@ -96,7 +96,7 @@ ABI_SYMBOLS = (
     "flame_nltgv2_costs", "flame_nltgv2_download_state", "flame_nltgv2_export_idepth_device",
     "flame_nltgv2_export_idepth_device_async", "flame_nltgv2_set_export_target",
     "flame_nltgv2_set_option", "flame_nltgv2_get_info", "flame_nltgv2_last_error", "flame_nltgv2_last_hip_error",
-    "flame_nltgv2_status_string", "flame_nltgv2_abi_version", "flame_nltgv2_pack_probe", "flame_nltgv2_read_probe", "flame_nltgv2_layout_selftest",
+    "flame_nltgv2_status_string", "flame_nltgv2_abi_version", "flame_nltgv2_pack_probe", "flame_nltgv2_read_probe", "flame_nltgv2_layout_selftest", "flame_nltgv2_placement_info",
     "flame_nltgv2_photo_set_images", "flame_nltgv2_photo_residual", "flame_nltgv2_photo_fuse",
     "flame_nltgv2_photo_residual_last", "flame_nltgv2_sync_graph",
     "flame_nltgv2_get_topology", "flame_nltgv2_set_feature_ids", "flame_nltgv2_interpolate_mesh",
@@ -146,6 +146,7 @@ def load_library():
         "flame_nltgv2_status_string": (C.c_char_p, [C.c_int]),
         "flame_nltgv2_abi_version": (C.c_int, []),
         "flame_nltgv2_layout_selftest": (C.c_int, [ctx, C.POINTER(C.c_int64)]),
+        "flame_nltgv2_placement_info": (C.c_int, [ctx, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
         "flame_nltgv2_pack_probe": (C.c_int, [GP, _IP, _IP, _IP, _IP, C.c_int64, C.POINTER(C.c_int64)]),
         "flame_nltgv2_read_probe": (C.c_int, [ctx, C.POINTER(C.c_uint32), C.c_int64, C.POINTER(C.c_int64)]),
         "flame_nltgv2_photo_set_images": (C.c_int, [ctx, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int]),
@@ -304,6 +305,15 @@ class Regularizer:
         self._chk(self._L.flame_nltgv2_sync_graph(self._ctx, C.byref(si)), "sync_graph")
         info = self.info()
         self.V, self.E = info["V"], info["E"]
+
+    def placement_info(self) -> dict:
+        """Record placement of the patch-per-wave form (FLAME_NLTGV2_OPT_PLACEMENT): state (1 in use, 0 not yet, -1
+        unavailable), records placed for the current topology, one-way hand-off (us) on the best / mean / worst page."""
+        st, n = C.c_int32(0), C.c_int32(0)
+        us = (C.c_float * 3)()
+        self._chk(self._L.flame_nltgv2_placement_info(self._ctx, C.byref(st), C.byref(n), us), "placement_info")
+        return {"state": int(st.value), "placed_records": int(n.value), "best_us": float(us[0]), "mean_us": float(us[1]),
+                "worst_us": float(us[2])}
 
     def layout_selftest(self) -> int:
         """Words of the device-expanded layout arrays that differ from the host builders' (0 = identical)."""

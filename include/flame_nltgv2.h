@@ -279,6 +279,11 @@ enum {
                                         a record to cross the fabric.  Measured -1 % per iteration on average at 640x480
                                         (between -4.5 % and +1.5 % by graph) for ~0.15 ms more host time per topology, hence
                                         off by default (0, 1).  Takes effect with the next upload_graph / sync_graph */
+  FLAME_NLTGV2_OPT_PLACEMENT = 16,   /* patch-per-wave form on all eight XCDs: 1 (default) = the records another XCD reads are
+                                        placed on memory pages whose home channel suits that pair of XCDs (a hand-off across
+                                        XCDs takes 0.39-0.66 us depending on the page; measured once per context, ~3 ms at
+                                        the first such run), 0 = every record at its linear place.  Addresses only: results
+                                        are bit-identical either way */
   FLAME_NLTGV2_OPT_VERIFY_RECORDS = 14, /* persistent kernels: 1 = after a neighbour record's tag matched, read the 16 bytes
                                         once more and compare all four dwords (the exchange relies on an aligned 16-byte
                                         access never being torn between payload and tag; this checks it at run time, at the
@@ -330,8 +335,16 @@ int flame_nltgv2_abi_version(void);
  * [patch][step][8] words; *n_words = words available.  Not part of the reference's surface. */
 int flame_nltgv2_read_probe(flame_nltgv2_ctx* ctx, uint32_t* out, int64_t max_words, int64_t* n_words);
 
+/* Measurement aid: the record placement (FLAME_NLTGV2_OPT_PLACEMENT).  *state: 1 = calibrated and in use, 0 = not yet (no
+ * run has needed it), -1 = unavailable (the calibration did not complete; records keep their linear places).
+ * *placed_records = records of the current topology that were given a place in the pool (per step parity);
+ * us[0..2] = one-way hand-off by choice of page as the calibration measured it, mean over the XCD pairs: the best page,
+ * the mean page, the worst page.  Any output pointer may be NULL.  Not part of the reference's surface. */
+int flame_nltgv2_placement_info(flame_nltgv2_ctx* ctx, int32_t* state, int32_t* placed_records, float* us);
+
 /* Test hook: the layout arrays the device expanded for the current topology (nltgv2_layout.hip) compared word for word
- * with the host builders (nltgv2_pack.hpp); *mismatches = number of differing words. */
+ * with the host builders (nltgv2_pack.hpp); *mismatches = number of differing words -- plus, when records are placed, the
+ * number of placed offsets that are misaligned, out of the pool or given out twice. */
 int flame_nltgv2_layout_selftest(flame_nltgv2_ctx* ctx, int64_t* mismatches);
 /* Host-only packing probe (no device needed; used by the CPU test-suite): builds the packed
  * SELL-64 layout the fused sweep runs on and copies it out.  Any output pointer may be NULL.

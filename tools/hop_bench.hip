@@ -116,6 +116,199 @@ __global__ void __launch_bounds__(64) k_pingpong_dma(v4i* buf, int partner_xor, 
   if (lane == 0) cycles[b] = wall_clock64() - t0;
 }
 
+
+// (5) does the ADDRESS matter?  One record (all lanes the same 16 bytes) at byte offset `off` (echo in the same 64-byte
+//     line, 16 bytes further), two blocks on different XCDs: the line's home channel sits somewhere between them
+__global__ void __launch_bounds__(64) k_pingpong_addr(v4i* buf, int partner_xor, int iters, long long* cycles, int* xcc_of_block, unsigned off) {
+  const int b = blockIdx.x;
+  if (b != 0 && b != partner_xor) return;
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  if (threadIdx.x == 0) xcc_of_block[b] = (int)(xcc & 0xf);
+  const bool first = b == 0;
+  __amdgpu_buffer_rsrc_t r = rsrc(buf);
+  const int my_off = (int)off + (first ? 0 : 16), pa_off = (int)off + (first ? 16 : 0);
+  long long t0 = 0;
+  int tag = 0;
+  for (int it = 0; it <= iters; ++it) {
+    if (it == 1) t0 = wall_clock64();
+    ++tag;
+    if (!first) {
+      for (unsigned spin = 0;; ++spin) {
+        int o = pa_off;
+        asm volatile("" : "+v"(o) :: "memory");
+        v4i g = __builtin_amdgcn_raw_buffer_load_b128(r, o, 0, 16);
+        if (__all(g.w == tag)) break;
+        if (spin > (1u << 18)) { if (threadIdx.x == 0) cycles[b] = -(long long)it - 1; return; }
+      }
+    }
+    v4i rec = {0, it, b, tag};
+    __builtin_amdgcn_raw_buffer_store_b128(rec, r, my_off, 0, 16);
+    if (first) {
+      for (unsigned spin = 0;; ++spin) {
+        int o = pa_off;
+        asm volatile("" : "+v"(o) :: "memory");
+        v4i g = __builtin_amdgcn_raw_buffer_load_b128(r, o, 0, 16);
+        if (__all(g.w == tag)) break;
+        if (spin > (1u << 18)) { if (threadIdx.x == 0) cycles[b] = -(long long)it - 1; return; }
+      }
+    }
+  }
+  if (threadIdx.x == 0) cycles[b] = wall_clock64() - t0;
+}
+
+static int addr_scan(v4i* buf, long long* cyc, int* xcc) {
+  const int iters = 1000;
+  printf("address scan: one-way latency (us) of one 16-byte record, block 0 <-> block x, by byte offset of the record\n");
+  for (int px : {1, 2, 3, 4, 5, 6, 7}) {
+    for (unsigned stride : {4096u}) {
+      double lo = 1e9, hi = 0, sum = 0;
+      int xa = -1, xb = -1;
+      std::vector<double> v;
+      const int n = 64;
+      for (int k = 0; k < n; ++k) {
+        const unsigned off = (unsigned)k * stride;
+        CHECK(hipMemset(buf, 0, 4096 * 64 * 16));
+        CHECK(hipMemset(cyc, 0, 64 * 8));
+        hipLaunchKernelGGL(k_pingpong_addr, dim3(8), dim3(64), 0, 0, buf, px, iters, cyc, xcc, off);
+        CHECK(hipDeviceSynchronize());
+        long long h[8]; int hx[8];
+        CHECK(hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(hx, xcc, sizeof(hx), hipMemcpyDeviceToHost));
+        const double us = h[0] / 100.0 / iters / 2;
+        v.push_back(us);
+        lo = us < lo ? us : lo, hi = us > hi ? us : hi, sum += us;
+        xa = hx[0], xb = hx[px];
+      }
+      printf("xcc %d<->%d stride %7u: min %.3f mean %.3f max %.3f |", xa, xb, stride, lo, sum / n, hi);
+      for (double u : v) printf(" %.2f", u);
+      printf("\n");
+    }
+  }
+  return 0;
+}
+
+// (6) the same question asked one XCD at a time: round trip of a dependent sc1 load from block b's XCD to each 4 KB page
+//     (what a run-time calibration of the exchange buffer would measure)
+__global__ void __launch_bounds__(64) k_load_rt(v4i* buf, int n_pages, int reps, unsigned* out, int* xcc_of_block) {
+  const int b = blockIdx.x;
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  if (threadIdx.x == 0) xcc_of_block[b] = (int)(xcc & 0xf);
+  __amdgpu_buffer_rsrc_t r = rsrc(buf);
+  int chain = 0;
+  for (int p = 0; p < n_pages; ++p) {
+    long long best = 1ll << 60;
+    for (int rep = 0; rep < 3; ++rep) {
+      const long long t0 = clock64();
+      for (int k = 0; k < reps; ++k) {
+        int o = p * 4096 + (chain & 0);
+        asm volatile("" : "+v"(o) :: "memory");
+        v4i g = __builtin_amdgcn_raw_buffer_load_b128(r, o, 0, 16);
+        chain += g.x;
+      }
+      const long long t1 = clock64();
+      best = (t1 - t0) < best ? (t1 - t0) : best;
+    }
+    if (threadIdx.x == 0) out[b * n_pages + p] = (unsigned)(best / reps);
+  }
+  if (chain == 12345 && threadIdx.x == 0) out[0] = 0;
+}
+
+static int load_scan(v4i* buf, int* xcc) {
+  const int n_pages = 64, reps = 64;
+  unsigned* out;
+  CHECK(hipMalloc(&out, 8 * n_pages * 4));
+  CHECK(hipMemset(buf, 0, 4096 * 64 * 16));
+  for (int pass = 0; pass < 2; ++pass) {
+    // pass 0: the eight blocks one after the other (each alone on the chip); pass 1: all eight at once
+    std::vector<unsigned> h(8 * n_pages);
+    int hx[8];
+    if (pass == 0) {
+      hipLaunchKernelGGL(k_load_rt, dim3(8), dim3(64), 0, 0, buf, n_pages, reps, out, xcc);
+    } else {
+      hipLaunchKernelGGL(k_load_rt, dim3(8), dim3(64), 0, 0, buf, n_pages, reps, out, xcc);
+    }
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemcpy(h.data(), out, h.size() * 4, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(hx, xcc, sizeof(hx), hipMemcpyDeviceToHost));
+    printf("load round trip (shader cycles) by 4 KB page, pass %d\n", pass);
+    for (int b = 0; b < 8; ++b) {
+      printf("xcc %d:", hx[b]);
+      for (int p = 0; p < n_pages; ++p) printf(" %u", h[b * n_pages + p]);
+      printf("\n");
+    }
+  }
+  return 0;
+}
+
+// (7) ... and in which DIRECTION: the producer stamps the record with the device-wide 100 MHz clock, the consumer reads the
+//     clock when it sees the tag.  out[0] = mean one-way ticks block 0 -> block x, out[1] = block x -> block 0.
+__global__ void __launch_bounds__(64) k_oneway_addr(v4i* buf, int partner_xor, int iters, long long* sums, int* xcc_of_block, unsigned off) {
+  const int b = blockIdx.x;
+  if (b != 0 && b != partner_xor) return;
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  if (threadIdx.x == 0) xcc_of_block[b] = (int)(xcc & 0xf);
+  const bool first = b == 0;
+  __amdgpu_buffer_rsrc_t r = rsrc(buf);
+  const int my_off = (int)off + (first ? 0 : 16), pa_off = (int)off + (first ? 16 : 0);
+  long long sum = 0;
+  int tag = 0;
+  for (int it = 0; it <= iters; ++it) {
+    ++tag;
+    if (!first) {
+      v4i g;
+      for (unsigned spin = 0;; ++spin) {
+        int o = pa_off;
+        asm volatile("" : "+v"(o) :: "memory");
+        g = __builtin_amdgcn_raw_buffer_load_b128(r, o, 0, 16);
+        if (__all(g.w == tag)) break;
+        if (spin > (1u << 18)) { if (threadIdx.x == 0) sums[b] = -1; return; }
+      }
+      if (it > 0) sum += (long long)((unsigned)wall_clock64() - (unsigned)g.x);
+    }
+    v4i rec = {(int)(unsigned)wall_clock64(), it, b, tag};
+    __builtin_amdgcn_raw_buffer_store_b128(rec, r, my_off, 0, 16);
+    if (first) {
+      v4i g;
+      for (unsigned spin = 0;; ++spin) {
+        int o = pa_off;
+        asm volatile("" : "+v"(o) :: "memory");
+        g = __builtin_amdgcn_raw_buffer_load_b128(r, o, 0, 16);
+        if (__all(g.w == tag)) break;
+        if (spin > (1u << 18)) { if (threadIdx.x == 0) sums[b] = -1; return; }
+      }
+      if (it > 0) sum += (long long)((unsigned)wall_clock64() - (unsigned)g.x);
+    }
+  }
+  if (threadIdx.x == 0) sums[b] = sum;
+}
+
+static int oneway_scan(v4i* buf, long long* cyc, int* xcc) {
+  const int iters = 1000;
+  printf("one-way scan: latency (us) of one 16-byte record by direction, block 0 <-> block x, by 4 KB page; 'a>b' = written on a, seen on b\n");
+  for (int px : {1, 2, 3, 4, 5, 6, 7}) {
+    std::vector<double> f, bk;
+    int xa = -1, xb = -1;
+    for (int k = 0; k < 16; ++k) {
+      CHECK(hipMemset(buf, 0, 4096 * 64 * 16));
+      CHECK(hipMemset(cyc, 0, 64 * 8));
+      hipLaunchKernelGGL(k_oneway_addr, dim3(8), dim3(64), 0, 0, buf, px, iters, cyc, xcc, (unsigned)k * 4096u);
+      CHECK(hipDeviceSynchronize());
+      long long h[8]; int hx[8];
+      CHECK(hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost));
+      CHECK(hipMemcpy(hx, xcc, sizeof(hx), hipMemcpyDeviceToHost));
+      // block px measured 0 -> px, block 0 measured px -> 0
+      f.push_back(h[px] / 100.0 / iters), bk.push_back(h[0] / 100.0 / iters);
+      xa = hx[0], xb = hx[px];
+    }
+    printf("xcc %d>%d:", xa, xb); for (double u : f) printf(" %.2f", u); printf("\n");
+    printf("xcc %d>%d:", xb, xa); for (double u : bk) printf(" %.2f", u); printf("\n");
+  }
+  return 0;
+}
+
 template <bool PLAIN, int GAP>
 int run_dma(const char* name, v4i* buf, long long* cyc, int* xcc, int nblocks, int partner_xor, int iters) {
   CHECK(hipMemset(buf, 0, nblocks * 64 * 16));
@@ -173,6 +366,9 @@ int main() {
   printf("dpp wave_shr:1 :"); for (int i = 0; i < 64; i += 1) printf(" %d", h[i]); printf("\n");
   printf("dpp row_shr:1  :"); for (int i = 0; i < 64; i += 1) printf(" %d", h[64 + i]); printf("\n");
   const int iters = 2000;
+  if (getenv("HOP_BENCH_ONEWAY_SCAN")) return oneway_scan(buf, cyc, xcc);
+  if (getenv("HOP_BENCH_LOAD_SCAN")) load_scan(buf, xcc);
+  if (getenv("HOP_BENCH_ADDR_SCAN")) return addr_scan(buf, cyc, xcc);
   // (3) does the KIND of memory matter for the cross-XCD hand-off?  fine-grained / uncached allocations bypass the L2s by
   //     memory type instead of by instruction policy
   {
