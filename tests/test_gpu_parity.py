@@ -155,12 +155,14 @@ def test_internal_steps_individually(env):
     [(5, 4)], [(5, 4), (6, 0)], [(5, 4), (6, 2)], [(5, 4), (9, 1)], [(5, 4), (9, 2)], [(5, 4), (9, 8)], [(5, 4), (13, 1)], [(5, 4), (13, 2)], [(5, 4), (13, 3)], [(5, 4), (13, 4)],
     [(5, 4), (9, 1), (6, 0), (13, 1)], [(5, 4), (12, 1)], [(5, 4), (15, 2)], [(5, 4), (15, 1)], [(5, 4), (15, 2), (6, 0)],
     [(5, 2), (15, 2)], [(5, 3), (15, 2)],
+    [(5, 4), (16, 0)], [(5, 4), (16, 0), (6, 0)], [(5, 4), (16, 1), (12, 1)], [(5, 4), (16, 1), (14, 1)], [(5, 4), (16, 1), (9, 4)],
 ])
 def test_launch_configurations_are_bit_identical(env, opts):
     """waves per workgroup (opt 3), slot chunk (opt 4), hipGraph on/off (opt 2), persistent single
     launch vs one launch per step (opt 5), same-XCD L2 exchange on/off (opt 6), slot constants in LDS (opt 7), the pre-poll sleep (opt 8) and the number of
     XCDs a persistent launch is spread over (opt 9), the poll pause and the cycle probe of the patch-per-wave form (opts 13, 12) and shadow
-    patches across the XCD borders (opt 15, also under the other forms, which ignore them) never change a bit."""
+    patches across the XCD borders (opt 15, also under the other forms, which ignore them) and the placement of the records read
+    across XCDs (opt 16) never change a bit."""
     flame_amd, oracle = env
     g = synth.make_graph("320x240", seed=3)
     ref, _ = cpu_run(oracle, g, 21)
@@ -637,6 +639,36 @@ def test_randomized_run_sequences(env, trial):
         sm, dc = reg.costs(p)
         rs, rd = oracle.costs(ref, rp)
         assert np.float32(sm) == np.float32(rs) and np.float32(dc) == np.float32(rd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["320x240", "640x480", "1280x720"])
+def test_record_placement_is_bit_identical_and_well_formed(env, config):
+    """FLAME_NLTGV2_OPT_PLACEMENT (on by default): the records another XCD reads live in a pool of pages ranked per pair of
+    XCDs.  Same bits with and without, and with the run-time record verification on (whose second read goes through the
+    placed address too); the placed offsets are aligned, inside the pool, unique, and exactly the records the host's own
+    patch walk says cross an XCD border (flame_nltgv2_layout_selftest)."""
+    flame_amd, oracle = env
+    from flame_amd.regularizer import OPT_PERSISTENT, OPT_PLACEMENT, OPT_VERIFY_RECORDS
+    g = synth.make_graph(config, seed=11)
+    ref, _ = cpu_run(oracle, g, 60)
+    for place, verify in ((1, 0), (0, 0), (1, 1)):
+        with flame_amd.Regularizer(0) as reg:
+            reg.set_option(OPT_PERSISTENT, 4)
+            reg.set_option(OPT_PLACEMENT, place)
+            reg.set_option(OPT_VERIFY_RECORDS, verify)
+            reg.upload_graph(g)
+            reg.run(flame_amd.Params(), 30)
+            reg.run(flame_amd.Params(), 30)
+            assert_state_equal(reg.download_state(), ref, what=f"placement {place} verify {verify}")
+            info, pi = reg.info(), reg.placement_info()
+            assert info["last_run_path"] == 6 and info["timeouts_recovered"] == 0 and info["torn_records_detected"] == 0
+            if place:
+                assert pi["state"] == 1 and pi["placed_records"] > 0, pi
+                assert 0.0 < pi["best_us"] <= pi["mean_us"] <= pi["worst_us"] < 5.0, pi
+                assert reg.layout_selftest() == 0
+            else:
+                assert pi["state"] == 0 and pi["placed_records"] == 0, pi
 
 
 @pytest.mark.parametrize("config,shadows", [("320x240", 2), ("640x480", 2), ("1280x720", 2)])

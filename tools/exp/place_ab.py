@@ -9,11 +9,11 @@ from flame_amd.regularizer import OPT_PLACEMENT
 
 sizes = sys.argv[1:] or ["640x480"]
 for size in sizes:
-    for seed in (7,):
+    for seed in (7, 8, 9):
         g = synth.make_graph(size, seed=seed)
         ref = None
         for rnd in range(2):
-            for place in (0, 1):
+            for place in (1, 2):
                 with flame_amd.Regularizer(0) as reg:
                     reg.set_option(OPT_PLACEMENT, min(place, 1))
                     reg.upload_graph(g)
@@ -28,7 +28,7 @@ for size in sizes:
                     out = reg.download_state()
                     info = reg.info()
                     pi = reg.placement_info()
-                    if place and rnd == 0:
+                    if False:
                         from flame_amd.regularizer import OPT_PROBE
                         reg.set_option(OPT_PROBE, 1)
                         reg.run(flame_amd.Params(), 20)
