@@ -184,6 +184,17 @@ def main():
                     "'step_cycles' is the in-kernel cycle account of the same kernel, 'batched' the throughput regime",
         }
         if run_path == "persistent-pv":
+            try:  # where the records that cross XCDs were put (FLAME_NLTGV2_OPT_PLACEMENT) and what the calibration measured
+                pi = reg.placement_info()
+                roofline["record_placement"] = {
+                    "state": pi["state"], "placed_records": pi["placed_records"],
+                    "cross_xcd_handoff_us_by_page": {"best": round(pi["best_us"], 3), "mean": round(pi["mean_us"], 3),
+                                                     "worst": round(pi["worst_us"], 3)},
+                    "note": "one-way hand-off of a 16-byte record between two XCDs, by the 4 KB page it lives on (mean over the "
+                            "56 ordered XCD pairs, all pairs exchanging at once); records read across XCDs are put on the best "
+                            "page of their pair, 128-byte aligned per producing patch"}
+            except Exception as e:  # noqa: BLE001
+                roofline["record_placement"] = f"{type(e).__name__}: {e}"
             try:
                 roofline["step_cycles"] = pv_step_cycles(flame_amd, g, params, a.iters, local_rank)
             except Exception as e:  # noqa: BLE001

@@ -366,6 +366,17 @@ int main() {
   printf("dpp wave_shr:1 :"); for (int i = 0; i < 64; i += 1) printf(" %d", h[i]); printf("\n");
   printf("dpp row_shr:1  :"); for (int i = 0; i < 64; i += 1) printf(" %d", h[64 + i]); printf("\n");
   const int iters = 2000;
+  if (getenv("HOP_BENCH_POLICY_SCAN")) {  // does any load policy skip the reader's L2 (and with it the invalidate + refetch)?
+    for (int nb : {2, 256}) {
+      run<16, 16, false>("st sc1 / ld sc1", buf, cyc, xcc, nb, 1, iters);
+      run<16, 18, false>("st sc1 / ld sc1 nt", buf, cyc, xcc, nb, 1, iters);
+      run<16, 19, false>("st sc1 / ld sc0 sc1 nt", buf, cyc, xcc, nb, 1, iters);
+      run<18, 18, false>("st sc1 nt / ld sc1 nt", buf, cyc, xcc, nb, 1, iters);
+      run<19, 19, false>("st sc0sc1nt / ld sc0sc1nt", buf, cyc, xcc, nb, 1, iters);
+      run<16, 17, false>("st sc1 / ld sc0 sc1", buf, cyc, xcc, nb, 1, iters);
+    }
+    return 0;
+  }
   if (getenv("HOP_BENCH_ONEWAY_SCAN")) return oneway_scan(buf, cyc, xcc);
   if (getenv("HOP_BENCH_LOAD_SCAN")) load_scan(buf, xcc);
   if (getenv("HOP_BENCH_ADDR_SCAN")) return addr_scan(buf, cyc, xcc);
