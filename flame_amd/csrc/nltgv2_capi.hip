@@ -162,6 +162,7 @@ struct flame_nltgv2_ctx {
   int opt_verify = 0;             // 1: persistent kernels re-read every record after its tag matched; 2: + test hook
   // Record placement of the patch-per-wave form (nltgv2_layout.hip): a pool of pages measured once per context, the
   // records read across XCDs assigned to them once per topology
+  int opt_rowpack = 1;            // patch-per-wave form: 1 (default) row-packed patches + DPP accumulation, 0 contiguous lanes + LDS slab
   int opt_place = 1;              // 1 (default) on, 0 off
   int place_state = 0;            // 0 not calibrated yet, 1 page ranking on the device, -1 unavailable (calibration failed)
   uint64_t place_topo = ~0ull;    // topology / patches per XCD the record offsets are valid for
@@ -211,7 +212,7 @@ struct flame_nltgv2_ctx {
   std::vector<float> h_terms;
   DevBuf hq_alt, vstate_alt;  // the other copies of hq / vstate: a persistent run writes there, success swaps the roles
   DevBuf xbuf, abort_flag, he_slot, he_vid, he_meta, he_wave_chain, tv_slot, tv_vid, tv_meta, tv_wave;
-  DevBuf wg_slot, wg_vid, wg_meta, wg_nbr, wg_fetch, wg_info, wg_v0, rid_on, probe;
+  DevBuf wg_slot, wg_vid, wg_meta, wg_nbr, wg_fetch, wg_info, wg_v0, rid_on, wg_vfirst, probe;
   // misc
   DevBuf err, cost_out, img_ref, img_cmp, photo_err, r_tris, r_valid, r_keys, r_img, r_cov, r_vtx, r_val;
   int img_rows = 0, img_cols = 0, img_step = 0;
@@ -319,6 +320,7 @@ void refresh_args(flame_nltgv2_ctx* ctx) {
   f.wg_count = ctx->L.wg_ok ? ctx->L.wg_count : 0;
   f.n_rec = ctx->L.n_rec;
   f.wg_lcap = ctx->L.wg_lcap, f.wg_slab_slots = ctx->L.wg_slab_slots;
+  f.wg_rowpack = ctx->L.wg_rowpack ? 1 : 0;
   f.wg_slot = (int32_t*)ctx->wg_slot.p, f.wg_vid = (int32_t*)ctx->wg_vid.p, f.wg_meta = (uint32_t*)ctx->wg_meta.p;
   f.wg_nbr = (int32_t*)ctx->wg_nbr.p, f.wg_fetch = (int32_t*)ctx->wg_fetch.p, f.wg_info = (int32_t*)ctx->wg_info.p;
   f.abort_flag = (int*)ctx->abort_flag.p;
@@ -983,7 +985,8 @@ int shadow_cap(const flame_nltgv2_ctx* ctx) { return ctx->opt_shadows ? 0x7fffff
 int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const StageCopy* extra, size_t n_extra, bool long_lived) {
   const int32_t V = g->V, E = g->E;
   const int sm = shadow_mode(ctx, long_lived);
-  int rc = build_layout(g, &ctx->L, /*host_expand=*/false, sm, shadow_cap(ctx));
+  int rc = build_layout(g, &ctx->L, /*host_expand=*/false, sm, shadow_cap(ctx), /*rowpack=*/ctx->opt_rowpack != 0,
+                        /*rowpack_max_patches=*/10 * ctx->prop.multiProcessorCount);
   if (rc) return fail(ctx, rc);
   const PackedLayout& L = ctx->L;
   const size_t n_slots = (size_t)(L.rows + kRowPad) * kWave;
@@ -1003,7 +1006,7 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
       {&ctx->bar0, sizeof(float4) * n_packed}, {&ctx->bar1, sizeof(float4) * n_packed},
       {&ctx->vprev, sizeof(float4) * n_packed}, {&ctx->xbuf, kXbufBytesPerVertex * records_capacity(L) + 64},
       {&ctx->wg_v0, sizeof(int32_t) * L.wg_v0.size()}, {&ctx->rid_on, sizeof(int32_t) * L.rid_on.size()},
-      {&ctx->abort_flag, sizeof(int)}, {&ctx->err, sizeof(int)}, {&ctx->cost_out, 2 * sizeof(float)},
+      {&ctx->wg_vfirst, L.wg_vfirst.size() + 16}, {&ctx->abort_flag, sizeof(int)}, {&ctx->err, sizeof(int)}, {&ctx->cost_out, 2 * sizeof(float)},
       {&ctx->wg_slot, sizeof(int32_t) * lanes}, {&ctx->wg_vid, sizeof(int32_t) * lanes}, {&ctx->wg_meta, sizeof(uint32_t) * lanes},
       {&ctx->wg_nbr, sizeof(int32_t) * lanes}, {&ctx->wg_fetch, sizeof(int32_t) * lanes},
       {&ctx->wg_info, sizeof(int32_t) * L.wg_info.size()}};
@@ -1023,7 +1026,8 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
       {&ctx->perm, L.perm.data(), sizeof(int32_t) * n_packed}, {&ctx->pdeg, L.pdeg.data(), sizeof(int32_t) * n_packed},
       {&ctx->iperm, L.iperm.data(), iV}, {&ctx->order_m, L.order_m.data(), iV}, {&ctx->rid_of, L.rid_of.data(), iV},
       {&ctx->wg_info, L.wg_info.data(), sizeof(int32_t) * L.wg_info.size()},
-      {&ctx->wg_v0, L.wg_v0.data(), sizeof(int32_t) * L.wg_v0.size()}, {&ctx->rid_on, L.rid_on.data(), sizeof(int32_t) * L.rid_on.size()}};
+      {&ctx->wg_v0, L.wg_v0.data(), sizeof(int32_t) * L.wg_v0.size()}, {&ctx->rid_on, L.rid_on.data(), sizeof(int32_t) * L.rid_on.size()},
+      {&ctx->wg_vfirst, L.wg_vfirst.data(), L.wg_vfirst.size()}};
   cp.insert(cp.end(), extra, extra + n_extra);
   std::vector<StageFill> fills = {
       {ctx->err.p, sizeof(int), 0u}, {ctx->abort_flag.p, sizeof(int), 0u}, {ctx->xbuf.p, kXbufBytesPerVertex * records_capacity(L) + 64, 0u},
@@ -1042,7 +1046,8 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
   LAUNCHCHK(ctx, launch_build_sell(ctx->c, ctx->f, (const int32_t*)ctx->iperm.p, ctx->stream));
   if (L.wg_ok)
     LAUNCHCHK(ctx, launch_build_patches(ctx->c, ctx->f, (const int32_t*)ctx->wg_v0.p, (const int32_t*)ctx->order_m.p,
-                                        (const int32_t*)(L.wg_per_xcd ? ctx->rid_on.p : ctx->rid_of.p), L.wg_per_xcd,
+                                        (const int32_t*)(L.wg_per_xcd ? ctx->rid_on.p : ctx->rid_of.p), (const uint8_t*)ctx->wg_vfirst.p,
+                                        L.wg_per_xcd,
                                         (const int32_t*)ctx->iperm.p, ctx->stream));
   ctx->pending = flame_nltgv2_ctx::PendingRun{};
   ctx->tag_next = 1;
@@ -1170,7 +1175,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
               &ctx->r_img, &ctx->r_cov, &ctx->r_vtx, &ctx->r_val, &ctx->wg_slot, &ctx->wg_vid, &ctx->wg_meta, &ctx->wg_nbr,
               &ctx->wg_fetch, &ctx->wg_info, &ctx->wg_v0, &ctx->rid_on, &ctx->probe, &ctx->snap_hq, &ctx->snap_vstate, &ctx->snap_bar, &ctx->iperm,
               &ctx->order_m, &ctx->rid_of, &ctx->d_stage, &ctx->sync_init, &ctx->sync_vmap, &ctx->sync_emap, &ctx->sync_need,
-              &ctx->place_pool, &ctx->place_rank, &ctx->place_fill, &ctx->place_rec_off, &ctx->place_patch, &ctx->place_meas};
+              &ctx->wg_vfirst, &ctx->place_pool, &ctx->place_rank, &ctx->place_fill, &ctx->place_rec_off, &ctx->place_patch, &ctx->place_meas};
   for (auto& b : ctx->sp_v) ctx->all.push_back(&b);
   for (auto& b : ctx->sp_q) ctx->all.push_back(&b);
   *out = ctx;
@@ -1223,6 +1228,10 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
     case FLAME_NLTGV2_OPT_SHADOWS:
       if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_shadows = value;
+      return 0;
+    case FLAME_NLTGV2_OPT_ROWPACK:
+      if (value < 0 || value > 1) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_rowpack = value;
       return 0;
     case FLAME_NLTGV2_OPT_PLACEMENT:
       if (value < 0 || value > 1) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
@@ -1985,7 +1994,7 @@ int flame_nltgv2_layout_selftest(flame_nltgv2_ctx* ctx, int64_t* mismatches) {
   flame_nltgv2_graph g{};
   g.V = V, g.E = E, g.pos = pos.data(), g.src = ctx->h_src.data(), g.dst = ctx->h_dst.data();
   PackedLayout H;
-  rc = build_layout(&g, &H, /*host_expand=*/true, ctx->L.shadow_mode);  // (the mode the layout was actually built with)
+  rc = build_layout(&g, &H, /*host_expand=*/true, ctx->L.shadow_mode, 0x7fffffff, ctx->L.wg_rowpack);  // (the modes the layout was actually built with)
   if (rc) return fail(ctx, rc);
   int64_t bad = 0;
   auto cmp = [&](const DevBuf& b, const void* host, size_t bytes) -> int {
@@ -1999,7 +2008,7 @@ int flame_nltgv2_layout_selftest(flame_nltgv2_ctx* ctx, int64_t* mismatches) {
   const PackedLayout& L = ctx->L;
   bad += (H.rows != L.rows) + (H.n_slices != L.n_slices) + (H.wg_ok != L.wg_ok) + (H.wg_count != L.wg_count) +
          (H.wg_lcap != L.wg_lcap) + (H.wg_slab_slots != L.wg_slab_slots) + (H.n_rec != L.n_rec) + (H.wg_per_xcd != L.wg_per_xcd) +
-         (H.wg_v0 != L.wg_v0) + (H.rid_on != L.rid_on);
+         (H.wg_v0 != L.wg_v0) + (H.rid_on != L.rid_on) + (H.wg_vfirst != L.wg_vfirst) + (H.wg_rowpack != L.wg_rowpack);
   if (bad == 0) {
     const size_t n = (size_t)L.rows * kWave, lanes = (size_t)L.wg_count * kWave;
     int e = cmp(ctx->rec_nbr, H.rec_nbr.data(), 4 * n) | cmp(ctx->rec_edge, H.rec_edge.data(), 4 * n) |

@@ -93,6 +93,7 @@ struct FusedArgs {
   uint32_t* tv_wave = nullptr;
   // persistent run, patch-per-wave rows (nltgv2_pack.hpp (E)): one wave per patch
   int wg_count = 0, wg_lcap = 0, wg_slab_slots = 0;
+  int wg_rowpack = 0;                  // patches are row-packed (nltgv2_pack.hpp): the DPP form of k_persistent_pv runs them
   int32_t* wg_slot = nullptr;
   int32_t* wg_vid = nullptr;
   uint32_t* wg_meta = nullptr;
@@ -165,7 +166,7 @@ int launch_build_sell(const CanonArgs& c, const FusedArgs& a, const int32_t* ipe
 int launch_he_from_patches(const FusedArgs& a, int32_t* he_slot, int32_t* he_vid, uint32_t* he_meta, int32_t* he_wave_chain,
                            hipStream_t s);
 int launch_build_patches(const CanonArgs& c, const FusedArgs& a, const int32_t* wg_v0, const int32_t* order_m,
-                         const int32_t* rid_tab, int wg_per_xcd, const int32_t* iperm, hipStream_t s);
+                         const int32_t* rid_tab, const uint8_t* vfirst, int wg_per_xcd, const int32_t* iperm, hipStream_t s);
 int launch_save_prev(const CanonArgs& c, hipStream_t s);
 int launch_dual(const CanonArgs& c, const SolverParams& p, hipStream_t s);
 int launch_primal(const CanonArgs& c, const SolverParams& p, hipStream_t s);

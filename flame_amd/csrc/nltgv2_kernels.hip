@@ -573,7 +573,7 @@ k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd
 // Protocol (tags, two parity buffers, remote / XCD-local copies chosen from the true XCC ids, bounded waits,
 // transactional outputs) is that of k_persistent_he.
 // ------------------------------------------------------------------------------------------------
-constexpr unsigned kWgTailBit = 1u << 24, kWgActiveBit = 1u << 25, kWgValidBit = 1u << 26, kWgPublishBit = 1u << 27;
+constexpr unsigned kWgTailBit = 1u << 24, kWgActiveBit = 1u << 25, kWgValidBit = 1u << 26, kWgPublishBit = 1u << 27, kWgHeadBit = 1u << 28;
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 
@@ -586,7 +586,7 @@ __device__ __forceinline__ unsigned read_hw_id() {
   return v;
 }
 
-template <bool PROBE>
+template <bool PROBE, bool RIPPLE, bool VERIFY>
 __global__ void __launch_bounds__(64)
 k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, const int lcap, const int slab_slots,
                 const int32_t* __restrict__ wg_slot, const int32_t* __restrict__ wg_vid,
@@ -602,7 +602,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   extern __shared__ float4 lds[];
   constexpr int T = 64;
   const unsigned max_spins = max_spins_arg & 0x7fffffffu;
-  const int dual = dual_arg & 1, verify = dual_arg >> 1;  // as in k_persistent_he
+  const int dual = dual_arg & 1, verify = VERIFY ? dual_arg >> 1 : 0;  // as in k_persistent_he (VERIFY: compiled in only where asked for)
   const int poll_gap = poll_gap_arg & 255, pv_presleep = (poll_gap_arg >> 8) & 255;
   const int lane = (int)threadIdx.x;
   int b = blockIdx.x;
@@ -655,7 +655,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   // pool of 4 KB pages instead of the linear buffer, on a page whose home memory channel is close to both XCDs (the
   // hand-off through the fabric takes 0.39-0.66 us depending on the page); rec_off[parity][record] is its byte offset in
   // the pool, negative = the linear place.
-  const __amdgpu_buffer_rsrc_t rp = make_rsrc(place_pool ? static_cast<void*>(place_pool) : xbuf);
+
   // Memory side of the exchange: FOUR buffers by step (tag & 3), each [remote copy S bytes | same-XCD copy S bytes], then
   // the XCC table.  Two would do between instances that read each other (a record of step s is only overwritten by s+2
   // after every reader published s+1, i.e. consumed s); a shadow patch is read by, but does not read, some of its
@@ -676,6 +676,13 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   const int first = (int)(meta & 63u), loc = (int)((meta >> 13) & 2047u);
   const bool is_tail = (meta & kWgTailBit) != 0u, active = (meta & kWgActiveBit) != 0u;
   const bool valid = (meta & kWgValidBit) != 0u, publishes = (meta & kWgPublishBit) != 0u;
+  // The lane that holds a vertex's state, publishes its record and writes it back: the LAST lane of the vertex where every
+  // lane keeps the state (slab form), the FIRST where the sum runs across the lanes towards it (RIPPLE: row-packed patches).
+  const bool state_lane = RIPPLE ? (meta & kWgHeadBit) != 0u : is_tail;
+  const unsigned degx = (meta & kWgHeadBit) ? ((meta >> 6) & 127u) : 255u;  // RIPPLE: a head takes part in shift j while j < its degree
+  // ... as a destination; the lanes written by shift j, for the shifts every patch runs (RIPPLE)
+  const unsigned long long rm1 = __ballot(degx > 1u), rm2 = __ballot(degx > 2u), rm3 = __ballot(degx > 3u), rm4 = __ballot(degx > 4u),
+                           rm5 = __ballot(degx > 5u), rm6 = __ballot(degx > 6u), rm7 = __ballot(degx > 7u);
   // whose record this lane waits for: its half-edge's other end; a lane without a half-edge looks at its own vertex's
   // record, a lane without a vertex at the patch's first vertex -- both carry the step's tag from the start
   const int nbr_idx = active ? ((nbr_code < 0) ? lcap + (nbr_code & 0x7fffffff) : nbr_code) : (valid ? loc : 0);
@@ -724,10 +731,11 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   const int rdA = o_slabA + loc * strideA, rdC4 = (f_slabC + loc * stride) >> 2;
   const int rec_w = valid ? loc : o_ovfA + lane, rec_wstride = valid ? rec_stride : 0;
 
-  for (int i = lane; i < slab_slots; i += T) {
-    lds[o_slabA + i] = make_float4(-0.0f, -0.0f, -0.0f, -0.0f);
-    ldsf[f_slabC + i] = -0.0f;
-  }
+  if (!RIPPLE)
+    for (int i = lane; i < slab_slots; i += T) {
+      lds[o_slabA + i] = make_float4(-0.0f, -0.0f, -0.0f, -0.0f);
+      ldsf[f_slabC + i] = -0.0f;
+    }
   // fetch slots: tag 0 is never a live tag
   lds[lcap + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
   lds[rec_stride + lcap + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -737,7 +745,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   bool fetch_remote = frid >= 0;
   if (dual) {
     const unsigned my_xcc = read_xcc_id();
-    if (is_tail && publishes)
+    if (state_lane && publishes)
       __builtin_amdgcn_raw_buffer_store_b32((int)(xcc_want | my_xcc), rx, tab_off + (my_off >> 2), 0, kAuxSc1);
     if (n_fetch > 0 && !timed_out) {
       bool pend = frid >= 0;
@@ -761,7 +769,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   }
   const unsigned long long fetch_mask = __ballot(frid >= 0);  // the lanes with a fetch duty (the wave runs with all 64 lanes)
   const bool mute = (max_spins_arg >> 31) != 0u && wg == wg_begin;  // test hook: FLAME_NLTGV2_OPT_FAULT_INJECT
-  const bool pub_lane = is_tail && publishes;
+  const bool pub_lane = state_lane && publishes;
   const char* const xb_base = static_cast<const char*>(xbuf);
   // by parity of the record's step (two buffers; with shadow patches -- four -- nothing is placed)
   const bool placed = place_pool != nullptr && kPar == 2;
@@ -776,12 +784,14 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
       if (o1 >= 0) src1 = place_pool + o1;
     }
   }
-  auto publish = [&](const v4i_t o, const int pub, const int so) {  // (pub lanes only)
-    if (pub >= 0) {
-      __builtin_amdgcn_raw_buffer_store_b128(o, rp, pub, 0, kAuxSc1);
-    } else {
-      __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
-    }
+  // where the remote copy of this lane's record goes, by parity: its place in the pool, or the linear one (two buffers:
+  // one address per parity, no decision left for the step)
+  char* const xb_w = static_cast<char*>(xbuf);
+  char* const pa0 = pub0 >= 0 ? place_pool + pub0 : xb_w + my_off;
+  char* const pa1 = pub1 >= 0 ? place_pool + pub1 : xb_w + my_off + par;
+  auto publish = [&](const v4i_t o, char* pa, const int so) {  // (pub lanes only)
+    if (kPar != 2) pa = xb_w + my_off + so;  // (four buffers: the step's, linear)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(pa), "v"(o) : "memory");
     if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
   };
   {
@@ -789,7 +799,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
     if (pub_lane && !mute) {
       v4i_t o;
       o.x = __float_as_int(xb), o.y = __float_as_int(wb12.x), o.z = __float_as_int(wb12.y), o.w = (int)tag0;
-      publish(o, p0 ? pub1 : pub0, (int)(tag0 & (kPar - 1)) * par);
+      publish(o, p0 ? pa1 : pa0, (int)(tag0 & (kPar - 1)) * par);
     }
   }
   lds_wave_sync();
@@ -801,7 +811,11 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   // src: this lane's poll address; wr_rec: float4 index where the own record of the next step goes; so_out: memory offset
   // of the parity published.
   auto step = [&](const unsigned s, const unsigned rd_nbr, const unsigned dst, const int wr_rec, const int fetch_area, const int it,
-                  const char* const src2, const int pub2) {
+                  const char* const src2, char* const pub2, const int rd_rec) {
+    // RIPPLE: only the head of a vertex computes its state; the other lanes take (x_bar, w_bar) of their vertex from the
+    // record the head left in LDS at the end of the previous step (read here, ahead of the wait: off the critical path)
+    float4 own = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (RIPPLE) own = lds[rd_rec];
     const int so_in = (int)(s & (kPar - 1)) * par, so_out = (int)((s + 1u) & (kPar - 1)) * par;  // (wave-uniform)
     // two buffers: the step's parity is fixed at the call site (src2: where this lane polls, pub2: where it publishes)
     const char* const src = kPar == 2 ? src2 : xb_base + off0 + so_in;
@@ -891,7 +905,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
         }
       }
     }
-    if (verify && !timed_out) {
+    if (VERIFY && verify && !timed_out) {
       // Every fetch lane reads its foreign record once more, with an ordinary load, and compares all four dwords with
       // what the LDS-DMA left in its slot: a record is final once its tag is visible, so a difference means a torn
       // 16-byte access (memory side or LDS side) -- reported, the run is taken back and redone per step.
@@ -907,6 +921,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
     }
     unsigned pr_t1 = 0;
     if (PROBE) pr_t1 = (unsigned)clock64();
+    if (RIPPLE) xb = own.x, wb12 = v2f_t{own.y, own.z};
     // ---- dual update of this half-edge's private q copy (cc:99-110) ------------------------------
     const v2f_t nbw = {nbv.y, nbv.z};
     const float d0 = xb - nbv.x;
@@ -919,8 +934,6 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
     const v2f_t K23 = bs * d12;
     const float q1r = q1 + p.step_q * K1;
     const v2f_t q23r = q23 + p.step_q * K23;
-    ok = ok && (__builtin_fabsf(q1r) <= 3.402823466e+38f) && (__builtin_fabsf(q23r.x) <= 3.402823466e+38f) &&
-         (__builtin_fabsf(q23r.y) <= 3.402823466e+38f);  // NaN/Inf: the reference's FLAME_ASSERT h:174
     q1 = __builtin_fminf(__builtin_fmaxf(q1r, -1.0f), 1.0f);
     q23.x = __builtin_fminf(__builtin_fmaxf(q23r.x, -1.0f), 1.0f);
     q23.y = __builtin_fminf(__builtin_fmaxf(q23r.y, -1.0f), 1.0f);
@@ -932,12 +945,57 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
     const v2f_t a12 = M2 * C2;
     v2f_t b12 = u23 * nbeta;
     b12 = is_target ? v2f_t{-0.0f, -0.0f} : b12;
+    float X = x;
+    v2f_t Wa = w12;
+    if constexpr (RIPPLE) {
+      // ---- ordered accumulation across the lanes of the vertex, towards its head ------------------------------------
+      // The head (lane `first`) starts with (x + c_0, (w + a_0) + b_0) of its own half-edge; shift j = 1, 2, ... adds the
+      // contribution of lane first + j, taken with a DPP row shift (the patch is row-packed: a vertex's lanes share a 16-lane
+      // row).  Every lane stays enabled as a SOURCE; as a DESTINATION a head is masked out once j reaches its degree (it
+      // would pick up the next vertex's lanes), the other lanes compute values nobody reads.  The masks are compared one
+      // shift ahead (v_cmp into an SGPR pair, then a scalar move to EXEC: a VALU write of EXEC would stall the DPP adds
+      // that follow).  ~30 cycles per shift against ~70 per slot of the LDS slab (tools/ripple_bench: 264 vs 580 cycles for 8).
+      float W1 = (w12.x + a12.x) + b12.x, W2 = (w12.y + a12.y) + b12.y;
+      X = x + cx;
+      unsigned long long ma, mb;
+#define PV_ADDS(J)                                                                                    \
+  "v_add_f32_dpp %[X], %[cx], %[X] row_shl:" #J " row_mask:0xf bank_mask:0xf\n\t"                      \
+  "v_add_f32_dpp %[W1], %[a1], %[W1] row_shl:" #J " row_mask:0xf bank_mask:0xf\n\t"                    \
+  "v_add_f32_dpp %[W2], %[a2], %[W2] row_shl:" #J " row_mask:0xf bank_mask:0xf\n\t"                    \
+  "v_add_f32_dpp %[W1], %[b1], %[W1] row_shl:" #J " row_mask:0xf bank_mask:0xf\n\t"                    \
+  "v_add_f32_dpp %[W2], %[b2], %[W2] row_shl:" #J " row_mask:0xf bank_mask:0xf\n\t"
+#define PV_RM(J, M) "s_mov_b64 exec, %[" #M "]\n\t" PV_ADDS(J)
+#define PV_RS(J, J1, CUR, NXT)                                                                        \
+  "s_cmp_le_u32 %[md], " #J "\n\t"                                                                     \
+  "s_cbranch_scc1 9f\n\t"                                                                              \
+  "v_cmp_lt_u32_e64 %[" #NXT "], " #J1 ", %[dx]\n\t"                                                   \
+  "s_mov_b64 exec, %[" #CUR "]\n\t" PV_ADDS(J)
+      // shifts 1..7: straight line, masks from registers (a shift past a head's degree finds it masked out; a patch whose
+      // largest degree is below 8 runs the spare shifts on nothing).  Shifts 8..15 only where a vertex has that many edges:
+      // mask compared on the spot, one branch per shift (16 + 16 cycles more per shift: measured, tools/exp/ripple_bench)
+      asm volatile("s_nop 1\n\t"
+                   PV_RM(1, m1) PV_RM(2, m2) PV_RM(3, m3) PV_RM(4, m4) PV_RM(5, m5) PV_RM(6, m6) PV_RM(7, m7)
+                   "s_cmp_le_u32 %[md], 8\n\t"
+                   "s_cbranch_scc1 9f\n\t"
+                   "s_mov_b64 exec, -1\n\t"
+                   "v_cmp_lt_u32_e64 %[ma], 8, %[dx]\n\t"
+                   PV_RS(8, 9, ma, mb) PV_RS(9, 10, mb, ma) PV_RS(10, 11, ma, mb) PV_RS(11, 12, mb, ma)
+                   PV_RS(12, 13, ma, mb) PV_RS(13, 14, mb, ma) PV_RS(14, 15, ma, mb) PV_RS(15, 16, mb, ma)
+                   "9:\n\t"
+                   "s_mov_b64 exec, -1"
+                   : [X] "+v"(X), [W1] "+v"(W1), [W2] "+v"(W2), [ma] "=&s"(ma), [mb] "=&s"(mb)
+                   : [cx] "v"(cx), [a1] "v"(a12.x), [a2] "v"(a12.y), [b1] "v"(b12.x), [b2] "v"(b12.y), [dx] "v"(degx), [md] "s"(stride),
+                     [m1] "s"(rm1), [m2] "s"(rm2), [m3] "s"(rm3), [m4] "s"(rm4), [m5] "s"(rm5), [m6] "s"(rm6), [m7] "s"(rm7)
+                   : "scc");
+#undef PV_RS
+#undef PV_RM
+#undef PV_ADDS
+      Wa = v2f_t{W1, W2};
+    } else {
     lds[wrA] = make_float4(a12.x, a12.y, b12.x, b12.y);
     ldsf[wrC] = cx;
     lds_wave_sync();
     // ---- ordered accumulation, by every lane of the vertex (ascending edge id = ascending slot) --------------
-    float X = x;
-    v2f_t Wa = w12;
 #define PV_LOAD(N, c, cxs, K0)                                                      \
   _Pragma("unroll") for (int k = 0; k < N; ++k) c[k] = lds[rdA + (K0) + k];         \
   {                                                                                 \
@@ -977,9 +1035,12 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
     }
 #undef PV_LOAD
 #undef PV_ADD
+    }
     // ---- vertex update: proxL1 (cc:147-151, h:179-197), extragradient (cc:160-171) --------------------------
-    const float diff = X - data;
-    float xn = (diff > thr) ? X - thr : ((diff < -thr) ? X + thr : data);
+    // (both shifted values up front and two selects: as branches this was three exec-masked blocks in the hand-off path)
+    const float diff = X - data, x_dn = X - thr, x_up = X + thr;
+    float xn = (diff < -thr) ? x_up : data;
+    xn = (diff > thr) ? x_dn : xn;
     xn = (xn < p.x_min) ? p.x_min : xn;
     xn = (xn > p.x_max) ? p.x_max : xn;
     float nb = xn + p.theta * (xn - x);
@@ -991,16 +1052,20 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
       o.x = __float_as_int(nb), o.y = __float_as_int(wbn.x), o.z = __float_as_int(wbn.y), o.w = (int)(s + 1u);
       publish(o, pub2, so_out);
     }
-    lds[wr_rec] = make_float4(nb, wbn.x, wbn.y, __uint_as_float(s + 1u));
+    if (!RIPPLE || state_lane || !valid) lds[wr_rec] = make_float4(nb, wbn.x, wbn.y, __uint_as_float(s + 1u));
+    // (between a record arriving and the next one leaving every instruction counts, needed or not: a lone wave issues
+    //  one per ~5 cycles -- so what the publish does not need comes after it)
+    ok = ok && (__builtin_fabsf(q1r) <= 3.402823466e+38f) && (__builtin_fabsf(q23r.x) <= 3.402823466e+38f) &&
+         (__builtin_fabsf(q23r.y) <= 3.402823466e+38f);  // NaN/Inf: the reference's FLAME_ASSERT h:174
     x_prev = x, w_prev = w12;  // step()'s prev copy, cc:37-42
     x = xn, w12 = Wa;
     xb = nb, wb12 = wbn;
     if (PROBE) {
       const unsigned pr_t2 = (unsigned)clock64();
-      if (lane == 0 && probe) {  // {hw id, -, wait, compute, poll rounds, step start, 100 MHz clock, 0}
+      if (lane == 0 && probe) {  // {hw id, xcc id, wait, compute, poll rounds, step start, 100 MHz clock, slab stride | fetch lanes << 8}
         unsigned* o = probe + ((size_t)wg * n_iters + it) * 8;
         o[0] = read_hw_id(), o[1] = read_xcc_id(), o[2] = pr_t1 - pr_t0, o[3] = pr_t2 - pr_t1;
-        o[4] = rounds, o[5] = pr_t0, o[6] = (unsigned)wall_clock64(), o[7] = 0u;
+        o[4] = rounds, o[5] = pr_t0, o[6] = (unsigned)wall_clock64(), o[7] = (unsigned)stride | ((unsigned)n_fetch << 8);
       }
       pr_t0 = pr_t2;
     }
@@ -1015,14 +1080,15 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   // the records of step tag0 + even are in memory buffer p0 ("A"), those of the odd steps in the other
   const char* const srcA = p0 ? src1 : src0;
   const char* const srcB = p0 ? src0 : src1;
-  const int pubA = p0 ? pub1 : pub0, pubB = p0 ? pub0 : pub1;
+  char* const pubA = p0 ? pa1 : pa0;
+  char* const pubB = p0 ? pa0 : pa1;
   int it = 0;
   for (; it + 1 < n_iters && !timed_out; it += 2) {
-    step(tag0 + (unsigned)it, rdA_nbr, dstA, wrB_rec, areaA + lcap, it, srcA, pubB);
+    step(tag0 + (unsigned)it, rdA_nbr, dstA, wrB_rec, areaA + lcap, it, srcA, pubB, wrA_rec);
     if (timed_out) break;
-    step(tag0 + (unsigned)it + 1u, rdB_nbr, dstB, wrA_rec, areaB + lcap, it + 1, srcB, pubA);
+    step(tag0 + (unsigned)it + 1u, rdB_nbr, dstB, wrA_rec, areaB + lcap, it + 1, srcB, pubA, wrB_rec);
   }
-  if (it < n_iters && !timed_out) step(tag0 + (unsigned)it, rdA_nbr, dstA, wrB_rec, areaA + lcap, it, srcA, pubB);
+  if (it < n_iters && !timed_out) step(tag0 + (unsigned)it, rdA_nbr, dstA, wrB_rec, areaA + lcap, it, srcA, pubB, wrA_rec);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA in flight when the wave ends
 
   if (timed_out) {
@@ -1034,7 +1100,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   }
 
   if (shadow) return;
-  if (is_tail) {
+  if (state_lane) {
     vstate_out[pv] = make_float4(x, w12.x, w12.y, data);
     bar_out[pv] = make_float4(xb, wb12.x, wb12.y, 0.0f);
     vprev[pv] = make_float4(x_prev, w_prev.x, w_prev.y, 0.0f);
@@ -1747,7 +1813,8 @@ int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, boo
 int pv_patches_per_cu(const FusedArgs& a) {
   const size_t ldsv = 16u * (size_t)(2 * (a.wg_lcap + 64) + a.wg_slab_slots + 64) + 4u * (size_t)(a.wg_slab_slots + 64);
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_persistent_pv<false>, 64, ldsv) != hipSuccess) {
+  const void* fv = a.wg_rowpack ? (const void*)k_persistent_pv<false, true, true> : (const void*)k_persistent_pv<false, false, true>;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fv, 64, ldsv) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
@@ -1805,7 +1872,11 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
     void* vargs[] = {&wave_begin, &n_waves, &wgx, &lcap, &slab_slots, &w0, &w1, &w2, &w3, &w4, &w5, &hrec, &hq, &vstate,
                      &hq_out, &vstate_out, &vaux, &bin, &bout, &vprev, &xbuf, &rec_bytes, &dual, &tag0, &n_iters,
                      &max_spins, &poll_gap, &pp, &err, &abort_flag, &perm, &tail, &probe, &place_pool, &rec_off, &rec_off_stride, &rot_word};
-    const void* fv = probe ? (const void*)k_persistent_pv<true> : (const void*)k_persistent_pv<false>;
+    const bool vr = (dual >> 1) != 0;  // record verification asked for
+    const void* fv = a.wg_rowpack ? (probe ? (const void*)k_persistent_pv<true, true, true>
+                                           : vr ? (const void*)k_persistent_pv<false, true, true> : (const void*)k_persistent_pv<false, true, false>)
+                                  : (probe ? (const void*)k_persistent_pv<true, false, true>
+                                           : vr ? (const void*)k_persistent_pv<false, false, true> : (const void*)k_persistent_pv<false, false, false>);
     if (cooperative) return (int)hipLaunchCooperativeKernel(fv, gv, bv, vargs, ldsv, stream);
     return (int)hipLaunchKernel(fv, gv, bv, vargs, ldsv, stream);
   }

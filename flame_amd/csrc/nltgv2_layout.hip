@@ -17,7 +17,7 @@ namespace flame_hip {
 namespace {
 
 constexpr uint32_t kRole = 0x80000000u;
-constexpr uint32_t kWgTail = 1u << 24, kWgActive = 1u << 25, kWgValid = 1u << 26, kWgPublish = 1u << 27;
+constexpr uint32_t kWgTail = 1u << 24, kWgActive = 1u << 25, kWgValid = 1u << 26, kWgPublish = 1u << 27, kWgHead = 1u << 28;
 
 // (B) body: one thread per packed vertex slot p = slice*64 + lane (padding lanes included): its column of the slice's
 // rows.  Row k of a real vertex = its k-th incident half-edge (ascending edge id, from the CSR); every other slot of the
@@ -55,15 +55,6 @@ k_build_sell(const int n_packed, const int32_t* __restrict__ perm, const int32_t
   }
 }
 
-__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int u = __shfl_up(v, d, 64);
-    if (lane >= d) v += u;
-  }
-  return v;
-}
-
 // (E) lanes: one wave per patch instance.  Host input per instance: wg_info[4p] = its first record id, wg_info[4p+2] = its
 // vertex count (| kWgShadow), wg_v0[p] = position in the walk of its first vertex (= the record id for a primary);
 // order_m = the walk (caller's vertex ids); rid_tab = the record an instance reads for a vertex: rid_of (inverse of the
@@ -72,7 +63,8 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 // of other instances it reads, ascending) and wg_info[4p+1] = their number.
 __global__ void __launch_bounds__(64)
 k_build_patch(const int n_patches, int32_t* __restrict__ wg_info, const int32_t* __restrict__ wg_v0, const int32_t* __restrict__ order_m,
-              const int32_t* __restrict__ rid_tab, const int V, const int wg_per_xcd, const int32_t* __restrict__ iperm,
+              const int32_t* __restrict__ rid_tab, const uint8_t* __restrict__ vfirst, const int V, const int wg_per_xcd,
+              const int32_t* __restrict__ iperm,
               const int32_t* __restrict__ slice_row,
               const int32_t* __restrict__ row_ptr, const uint32_t* __restrict__ half, const int32_t* __restrict__ src,
               const int32_t* __restrict__ dst, int32_t* __restrict__ wg_slot, int32_t* __restrict__ wg_vid,
@@ -90,7 +82,8 @@ k_build_patch(const int n_patches, int32_t* __restrict__ wg_info, const int32_t*
     deg = row_ptr[o + 1] - row_ptr[o];
     need = deg > 1 ? deg : 1;
   }
-  const int first = wave_incl_scan(need, lane) - need;
+  // (the host's walk places a vertex's lanes: one after the other, or -- row-packed patches -- never across a 16-lane row)
+  const int first = lane < n_local ? (int)vfirst[v0 + lane] : 0;
   s_vtx_of_lane[lane] = -1;
   s_pub[lane] = 0;
   __syncthreads();
@@ -111,6 +104,7 @@ k_build_patch(const int n_patches, int32_t* __restrict__ wg_info, const int32_t*
     vid = sp;
     meta = (uint32_t)fj | ((uint32_t)dj << 6) | ((uint32_t)j << 13) | kWgValid;
     if (k == needj - 1) meta |= kWgTail;
+    if (k == 0) meta |= kWgHead;
     if (k < dj) {
       meta |= kWgActive;
       slot = (slice_row[sp >> 6] + k) * 64 + (sp & 63);
@@ -369,10 +363,10 @@ int launch_place_records(const CanonArgs& c, const FusedArgs& a, int per_xcd, co
 }
 
 int launch_build_patches(const CanonArgs& c, const FusedArgs& a, const int32_t* wg_v0, const int32_t* order_m,
-                         const int32_t* rid_tab, int wg_per_xcd, const int32_t* iperm, hipStream_t s) {
+                         const int32_t* rid_tab, const uint8_t* vfirst, int wg_per_xcd, const int32_t* iperm, hipStream_t s) {
   if (a.wg_count <= 0) return 0;
-  hipLaunchKernelGGL(k_build_patch, dim3((unsigned)a.wg_count), dim3(64), 0, s, a.wg_count, a.wg_info, wg_v0, order_m, rid_tab, c.V,
-                     wg_per_xcd, iperm, a.slice_row, c.row_ptr, c.half, c.src, c.dst, a.wg_slot, a.wg_vid, a.wg_meta, a.wg_nbr,
+  hipLaunchKernelGGL(k_build_patch, dim3((unsigned)a.wg_count), dim3(64), 0, s, a.wg_count, a.wg_info, wg_v0, order_m, rid_tab, vfirst,
+                     c.V, wg_per_xcd, iperm, a.slice_row, c.row_ptr, c.half, c.src, c.dst, a.wg_slot, a.wg_vid, a.wg_meta, a.wg_nbr,
                      a.wg_fetch);
   return (int)hipGetLastError();
 }

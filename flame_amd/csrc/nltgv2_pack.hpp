@@ -96,6 +96,13 @@ struct PackedLayout {
   std::vector<int32_t> wg_nbr;         // [wg_count*64] neighbour: local index, or 0x80000000 | fetch index
   std::vector<int32_t> wg_fetch;       // [wg_count*64] record id fetched by this lane, -1 none
   std::vector<int32_t> wg_info;        // [wg_count*4] first record id, fetched records, local vertices (| kWgShadow), slab stride
+                                       //               (row-packed patches: the patch's largest degree instead)
+  // Row-packed patches (wg_rowpack; every graph whose largest degree is <= 16): a vertex's lanes lie inside one 16-lane row
+  // of the wave (the walk fits each vertex into the first of the wave's four rows that has room), which is what lets the
+  // kernel add a vertex's contributions up across lanes with DPP row shifts instead of through LDS.  wg_vfirst[i] = first lane, within its patch,
+  // of the i-th vertex of the walk (either way).
+  bool wg_rowpack = false;
+  std::vector<uint8_t> wg_vfirst;
   std::vector<int32_t> comp_wg;        // [n_comp+1] first patch of each component
   // Shadow patches (shadow_mode > 0, 65..2048 patches: graphs that run resident as a whole, spread over all XCDs):
   // the chip is eight XCDs and a record crosses from one to another later than it reaches a reader on its own XCD; the
@@ -114,7 +121,8 @@ struct PackedLayout {
   std::vector<int32_t> rid_on;         // [8*V] with shadows: the record id an instance on XCD k reads for vertex u (k*V + u)
 };
 constexpr int32_t kWgShadow = 1 << 16;  // in wg_info[4p+2]
-constexpr uint32_t kWgTail = 1u << 24, kWgActive = 1u << 25, kWgValid = 1u << 26, kWgPublish = 1u << 27;
+constexpr uint32_t kWgTail = 1u << 24, kWgActive = 1u << 25, kWgValid = 1u << 26, kWgPublish = 1u << 27, kWgHead = 1u << 28;
+constexpr int32_t kWgRow = 16;  // lanes of a DPP row
 constexpr int kTvSlots = 8;
 constexpr uint32_t kTvOwner = 1u << 16, kTvValid = 1u << 17;
 
@@ -129,6 +137,35 @@ inline uint32_t morton_spread16(uint32_t v) {
   return v;
 }
 
+// Where the next vertex of the walk goes in the current wave: lanes back to back, or -- row-packed (see PackedLayout::
+// wg_rowpack) -- first fit into the wave's four 16-lane rows, a vertex's lanes contiguous inside one row.  Shared by the
+// walks of (C) and (E), which must cut the same waves.
+struct WaveFit {
+  bool rows = false;
+  int32_t fill = kWave;                                  // back to back: lanes used
+  int32_t row[4] = {16, 16, 16, 16};                      // row-packed: lanes used per row
+  void open() {
+    fill = 0;
+    row[0] = row[1] = row[2] = row[3] = 0;
+  }
+  // first lane for a vertex of `need` lanes, or -1: the wave is full for it
+  int32_t place(int32_t need) {
+    if (!rows) {
+      if (fill + need > kWave) return -1;
+      const int32_t f = fill;
+      fill += need;
+      return f;
+    }
+    for (int32_t r = 0; r < 4; ++r)
+      if (row[r] + need <= 16) {
+        const int32_t f = 16 * r + row[r];
+        row[r] += need;
+        return f;
+      }
+    return -1;
+  }
+};
+
 // Returns FLAME_NLTGV2_OK or FLAME_NLTGV2_ERR_INVALID_ARG.
 // ---- (C): needs (B)'s header (iperm, pdeg, slice_row), comp_start and order_m.  Built on demand: only the lane-per-half-edge
 // persistent form reads it.
@@ -142,7 +179,8 @@ inline void build_he_rows(PackedLayout* L) {
   L->he_slot.clear(), L->he_vid.clear(), L->he_meta.clear(), L->he_wave_chain.clear();
   L->comp_he_wave.clear();
   if (L->he_ok && V > 0) {
-    int32_t fill = kWave;  // forces a new wave for the first vertex
+    WaveFit fit;  // (starts full: forces a new wave for the first vertex)
+    fit.rows = L->wg_rowpack;
     size_t next_comp = 0;
     for (int32_t i = 0; i < V; ++i) {
       const int32_t s = L->iperm[order_m[i]];  // packed index of the i-th vertex in Morton order
@@ -153,13 +191,15 @@ inline void build_he_rows(PackedLayout* L) {
         L->comp_he_wave.push_back(L->he_waves);
         ++next_comp;
       }
-      if (fill + need > kWave || comp_begin) {
+      int32_t fill = comp_begin ? -1 : fit.place(need);
+      if (fill < 0) {
         L->he_slot.resize(L->he_slot.size() + kWave, -1);
         L->he_vid.resize(L->he_vid.size() + kWave, -1);
         L->he_meta.resize(L->he_meta.size() + kWave, 0u);
         L->he_wave_chain.push_back(1);
         L->he_waves++;
-        fill = 0;
+        fit.open();
+        fill = fit.place(need);
       }
       const size_t base = static_cast<size_t>(L->he_waves - 1) * kWave + fill;
       const int32_t tail_lane = fill + need - 1;
@@ -176,7 +216,6 @@ inline void build_he_rows(PackedLayout* L) {
       }
       L->he_wave_chain.back() = std::max(L->he_wave_chain.back(), need);
       L->he_max_chain = std::max(L->he_max_chain, need);
-      fill += need;
     }
     L->comp_he_wave.push_back(L->he_waves);
   }
@@ -244,7 +283,8 @@ inline void build_tv_rows(PackedLayout* L) {
 // ---- (E) patch-per-wave rows ------------------------------------------------------------------------
 // order_m = the vertices in (component, Morton) order; needs (B) (iperm, pdeg, slice_row, rec_nbr) and comp_start.
 inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const std::vector<int32_t>& order_m, bool host_expand,
-                             int shadow_mode = 0, int shadow_max_instances = 0x7fffffff) {
+                             int shadow_mode = 0, int shadow_max_instances = 0x7fffffff, bool rowpack = true,
+                             int rowpack_max_patches = 0x7fffffff) {
   (void)g;
   const int32_t V = L->V;
   constexpr int32_t T = kWave;
@@ -254,15 +294,27 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
   L->wg_info.clear(), L->comp_wg.clear();
   L->shadow_mode = 0, L->wg_prim = 0, L->wg_per_xcd = 0, L->n_rec = V;
   L->wg_v0.clear(), L->rid_on.clear();
+  L->wg_vfirst.clear();
+  // (row packing fills a wave to ~54 of its 64 lanes: more, smaller patches.  That pays where a patch has a SIMD to itself
+  //  or nearly; a graph too big for the patch-per-wave form keeps its lanes back to back, for the forms that then run it)
+  L->wg_rowpack = rowpack && L->max_degree <= kWgRow &&
+                  (static_cast<int64_t>(2) * L->E + V / 32) / 54 + 1 <= static_cast<int64_t>(rowpack_max_patches);
   if (L->max_degree > kWave || V <= 0) return;
+  L->wg_vfirst.resize(static_cast<size_t>(V));
   L->wg_info.reserve(((static_cast<size_t>(2) * L->E + V) * 9 / 8 / T + L->comp_start.size() + 2) * 4);
   // pass 1 (host, per vertex): the greedy walk of (C) -- a vertex's lanes never straddle two waves, a component begins a
   // new wave.  A vertex's record id is its position in the walk (L->rid_of).  Per patch: first record id, vertex count,
   // slab stride (its largest degree rounded up to 4, at least 8).
-  int32_t fill = kWave, n_local = 0, max_deg = 1;
+  int32_t n_local = 0, max_deg = 1;
+  WaveFit fit;
+  fit.rows = L->wg_rowpack;
   size_t next_comp = 0;
   auto close_patch = [&]() {
     if (L->wg_count == 0) return;
+    if (L->wg_rowpack) {
+      L->wg_info[static_cast<size_t>(L->wg_count - 1) * 4 + 3] = max_deg;
+      return;
+    }
     const int32_t stride = std::max(8, (max_deg + 3) & ~3);
     L->wg_info[static_cast<size_t>(L->wg_count - 1) * 4 + 3] = stride;
     L->wg_slab_slots = std::max(L->wg_slab_slots, (stride + 1) * n_local);  // (+1: the kernel pads a vertex's slab, see there)
@@ -272,18 +324,21 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
     const int32_t need = std::max(L->row_ptr[o + 1] - L->row_ptr[o], 1);
     const bool comp_begin = next_comp < L->comp_start.size() && L->comp_start[next_comp] == i;
     if (comp_begin) ++next_comp;
-    if (comp_begin || fill + need > kWave) {
+    int32_t fill = comp_begin ? -1 : fit.place(need);
+    if (fill < 0) {
       close_patch();
       if (comp_begin) L->comp_wg.push_back(L->wg_count);
       L->wg_info.resize(L->wg_info.size() + 4, 0);
       L->wg_info[static_cast<size_t>(L->wg_count) * 4] = i;
       L->wg_count++;
-      fill = 0, n_local = 0, max_deg = 1;
+      n_local = 0, max_deg = 1;
+      fit.open();
+      fill = fit.place(need);
     }
     max_deg = std::max(max_deg, need);
     L->wg_info[static_cast<size_t>(L->wg_count - 1) * 4 + 2] = ++n_local;
     L->wg_lcap = std::max(L->wg_lcap, n_local);
-    fill += need;
+    L->wg_vfirst[static_cast<size_t>(i)] = static_cast<uint8_t>(fill);
   }
   close_patch();
   L->comp_wg.push_back(L->wg_count);
@@ -439,16 +494,17 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
       for (int32_t k = 0; k < n_want; ++k) L->wg_fetch[b + k] = want[k];
       L->wg_info[static_cast<size_t>(wg) * 4 + 1] = n_want;
       L->wg_rcap = std::max(L->wg_rcap, n_want);
-      int32_t lane = 0;
       for (int32_t i = 0; i < n_loc; ++i) {
         const int32_t o = order_m[v0 + i];
         const int32_t s = L->iperm[o];
         const int32_t d = L->row_ptr[o + 1] - L->row_ptr[o], need = std::max(d, 1);
+        const int32_t lane = L->wg_vfirst[static_cast<size_t>(v0 + i)];
         const int64_t row0 = L->slice_row[s / kWave];
         bool publishes = false;
         for (int32_t k = 0; k < need; ++k) {
           uint32_t m = static_cast<uint32_t>(lane) | (static_cast<uint32_t>(d) << 6) | (static_cast<uint32_t>(i) << 13) | kWgValid;
           if (k == need - 1) m |= kWgTail;
+          if (k == 0) m |= kWgHead;
           if (k < d) {
             m |= kWgActive;
             L->wg_slot[b + lane + k] = static_cast<int32_t>((row0 + k) * kWave + (s % kWave));
@@ -466,7 +522,6 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
         }
         if (publishes)
           for (int32_t k = 0; k < need; ++k) L->wg_meta[b + lane + k] |= kWgPublish;
-        lane += need;
       }
     }
   }
@@ -478,7 +533,7 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
 // on demand.  host_expand = true: everything here -- the reference the device expansion is checked against, and what the
 // CPU test-suite looks at.
 inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L, bool host_expand = true, int shadow_mode = 0,
-                        int shadow_max_instances = 0x7fffffff) {
+                        int shadow_max_instances = 0x7fffffff, bool rowpack = true, int rowpack_max_patches = 0x7fffffff) {
   if (!g || g->V < 0 || g->E < 0) return FLAME_NLTGV2_ERR_INVALID_ARG;
   const int32_t V = g->V, E = g->E;
   if (V > 0 && !g->pos) return FLAME_NLTGV2_ERR_INVALID_ARG;
@@ -655,11 +710,11 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L, bool host_
   }
 
   PROF_T(3);
-  if (host_expand) build_he_rows(L);
+  build_patch_rows(g, L, order_m, host_expand, shadow_mode, shadow_max_instances, rowpack, rowpack_max_patches);
   PROF_T(4);
-  if (host_expand) build_tv_rows(L);
+  if (host_expand) build_he_rows(L);  // (after (E): the two walks cut the same waves, row-packed or not -- L->wg_rowpack)
   PROF_T(5);
-  build_patch_rows(g, L, order_m, host_expand, shadow_mode, shadow_max_instances);
+  if (host_expand) build_tv_rows(L);
   PROF_T(6);
   return FLAME_NLTGV2_OK;
 }

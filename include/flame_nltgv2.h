@@ -284,6 +284,11 @@ enum {
                                         XCDs takes 0.39-0.66 us depending on the page; measured once per context, ~3 ms at
                                         the first such run), 0 = every record at its linear place.  Addresses only: results
                                         are bit-identical either way */
+  FLAME_NLTGV2_OPT_ROWPACK = 17,     /* patch-per-wave form: 1 (default) = a vertex's lanes never straddle a 16-lane row of the wave
+                                        (graphs whose largest degree is <= 16) and its contributions are added up across lanes
+                                        with DPP row shifts; 0 = lanes back to back, contributions through an LDS slab (round 2's
+                                        first form; also what graphs with a vertex of more than 16 edges get).  Bit-identical
+                                        either way.  Takes effect with the next upload_graph / sync_graph */
   FLAME_NLTGV2_OPT_VERIFY_RECORDS = 14, /* persistent kernels: 1 = after a neighbour record's tag matched, read the 16 bytes
                                         once more and compare all four dwords (the exchange relies on an aligned 16-byte
                                         access never being torn between payload and tag; this checks it at run time, at the

@@ -9,6 +9,7 @@
 // as test infrastructure).  A wrong neighbour index, a missing publish flag or fetch entry, a vertex straddling
 // two waves -- all show up as a mismatch here, before any GPU time is spent.
 // Build+run: tests/test_pack.py::test_wg_layout_replay.  Compile with -ffp-contract=off.  Exit code 0 = pass.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -50,7 +51,7 @@ struct HostGraph {
 
 // n_frames disjoint jittered grids with random diagonals, random edge orientation, a few isolated vertices and one
 // high-degree hub per frame; state mid-solve-like (random w, q) so that every term of the update matters.
-static HostGraph make_graph(int nx, int ny, int n_frames, unsigned long long seed) {
+static HostGraph make_graph(int nx, int ny, int n_frames, unsigned long long seed, bool with_hub = true) {
   HostGraph g;
   for (int f = 0; f < n_frames; ++f) {
     const int base = (int)g.x.size();
@@ -89,7 +90,7 @@ static HostGraph make_graph(int nx, int ny, int n_frames, unsigned long long see
       }
     // a hub: vertex (nx/2, ny/2) also connected to 40 far vertices (degree ~46 <= 64)
     const int hub = (ny / 2) * nx + nx / 2;
-    for (int k = 0; k < 40 && k * 7 + 3 < nx * ny; ++k)
+    for (int k = 0; k < (with_hub ? 40 : 9) && k * 7 + 3 < nx * ny; ++k)  // (without the hub: degree ~15, still row-packable)
       if (std::abs(k * 7 + 3 - hub) > nx + 1) add(hub, k * 7 + 3);
     // two isolated vertices
     for (int k = 0; k < 2; ++k) {
@@ -118,10 +119,11 @@ static float prox_l1(float x_min, float x_max, float step_x, float w, float x, f
 
 struct Rec { float xb, w1b, w2b; unsigned tag; };
 
-static int replay(HostGraph& hg, int n_iters, const nltgv2_params& p, int shadow_mode) {
+static int replay(HostGraph& hg, int n_iters, const nltgv2_params& p, int shadow_mode, bool rowpack, bool expect_rowpack) {
   flame_nltgv2_graph g = hg.view();
   PackedLayout L;
-  if (build_layout(&g, &L, true, shadow_mode) != 0 || !L.wg_ok) return 1;
+  if (build_layout(&g, &L, true, shadow_mode, 0x7fffffff, rowpack) != 0 || !L.wg_ok) return 1;
+  if (L.wg_rowpack != expect_rowpack) return 16;
   if (shadow_mode >= 2 && L.wg_prim > 64 && L.wg_prim <= 2048 && L.wg_per_xcd == 0) return 15;  // shadows expected at this size
   const int T = 64, V = g.V;
   // structural invariants
@@ -133,6 +135,8 @@ static int replay(HostGraph& hg, int n_iters, const nltgv2_params& p, int shadow
       if (!(m & kWgValid)) continue;
       const int first = m & 63, deg = (m >> 6) & 127, need = deg > 1 ? deg : 1;
       if (first + need > 64) return 2;                        // a vertex inside one wave
+      if (L.wg_rowpack && first / 16 != (first + need - 1) / 16) return 17;  // ... and, row-packed, inside one 16-lane row
+      if (((m & kWgHead) != 0) != ((t & 63) == first)) return 18;
       const int k = (t & 63) - first;
       if (k < 0 || k >= need) return 3;
       if (((m & kWgTail) != 0) != (k == need - 1)) return 4;
@@ -144,7 +148,13 @@ static int replay(HostGraph& hg, int n_iters, const nltgv2_params& p, int shadow
     {  // slab stride: a multiple of 4, at least 8, covers the patch's largest degree, and fits the LDS sizing figure
       const int stride = L.wg_info[4 * wg + 3];
       if ((L.wg_info[4 * wg + 2] & 0xffff) == 0) continue;  // idle padding of a shadow layout
-      if (stride < 8 || (stride & 3) || (stride + 1) * (L.wg_info[4 * wg + 2] & 0xffff) > L.wg_slab_slots) return 13;
+      if (L.wg_rowpack) {  // row-packed: the patch's largest degree itself (the number of DPP shifts + 1), no slab
+        if (stride < 1 || stride > 16 || L.wg_slab_slots != 0) return 13;
+        bool reached = false;
+        for (int t = 0; t < T; ++t)
+          reached |= (L.wg_meta[(size_t)wg * T + t] & kWgValid) && (int)std::max(1u, (L.wg_meta[(size_t)wg * T + t] >> 6) & 127) == stride;
+        if (!reached) return 19;
+      } else if (stride < 8 || (stride & 3) || (stride + 1) * (L.wg_info[4 * wg + 2] & 0xffff) > L.wg_slab_slots) return 13;
       for (int t = 0; t < T; ++t)
         if ((L.wg_meta[(size_t)wg * T + t] & kWgValid) && (int)((L.wg_meta[(size_t)wg * T + t] >> 6) & 127) > stride) return 14;
     }
@@ -282,14 +292,16 @@ static int replay(HostGraph& hg, int n_iters, const nltgv2_params& p, int shadow
 int main() {
   const nltgv2_params p = {0.1f, 0.001f, 125.0f, 0.25f, 0.0f, 10.0f};
   for (int frames : {1, 3})
-    for (int shadow_mode : {0, 2}) {
-      HostGraph g = make_graph(61, 47, frames, 1234 + frames);
-      const int rc = replay(g, 6, p, shadow_mode);
-      if (rc) {
-        std::printf("FAILED frames=%d shadows=%d rc=%d\n", frames, shadow_mode, rc);
-        return 1;
+    for (int shadow_mode : {0, 2})
+      for (int variant = 0; variant < 3; ++variant) {  // hub of degree ~46 (never row-packed); degree <= 16: row-packed, or not by request
+        const bool hub = variant == 0, rowpack = variant != 2;
+        HostGraph g = make_graph(61, 47, frames, 1234 + frames, hub);
+        const int rc = replay(g, 6, p, shadow_mode, rowpack, !hub && rowpack);
+        if (rc) {
+          std::printf("FAILED frames=%d shadows=%d variant=%d rc=%d\n", frames, shadow_mode, variant, rc);
+          return 1;
+        }
       }
-    }
   std::printf("all ok\n");
   return 0;
 }
