@@ -679,10 +679,12 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   // The lane that holds a vertex's state, publishes its record and writes it back: the LAST lane of the vertex where every
   // lane keeps the state (slab form), the FIRST where the sum runs across the lanes towards it (RIPPLE: row-packed patches).
   const bool state_lane = RIPPLE ? (meta & kWgHeadBit) != 0u : is_tail;
-  const unsigned degx = (meta & kWgHeadBit) ? ((meta >> 6) & 127u) : 255u;  // RIPPLE: a head takes part in shift j while j < its degree
+  // RIPPLE: a head takes part in shift j while j < its degree; the other lanes of a vertex only serve as sources, and a lane
+  // without a half-edge is disabled altogether (a DPP read of a disabled lane leaves the destination as it is)
+  const unsigned degx = (meta & kWgHeadBit) ? ((meta >> 6) & 127u) : (active ? 255u : 0u);
   // ... as a destination; the lanes written by shift j, for the shifts every patch runs (RIPPLE)
   const unsigned long long rm1 = __ballot(degx > 1u), rm2 = __ballot(degx > 2u), rm3 = __ballot(degx > 3u), rm4 = __ballot(degx > 4u),
-                           rm5 = __ballot(degx > 5u), rm6 = __ballot(degx > 6u), rm7 = __ballot(degx > 7u);
+                           rm5 = __ballot(degx > 5u), rm6 = __ballot(degx > 6u), rm7 = __ballot(degx > 7u), rm8 = __ballot(degx > 8u);
   // whose record this lane waits for: its half-edge's other end; a lane without a half-edge looks at its own vertex's
   // record, a lane without a vertex at the patch's first vertex -- both carry the step's tag from the start
   const int nbr_idx = active ? ((nbr_code < 0) ? lcap + (nbr_code & 0x7fffffff) : nbr_code) : (valid ? loc : 0);
@@ -702,7 +704,9 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   // signed per-lane constants: see k_persistent_wg
   const float as = is_target ? -alpha : alpha, bs = is_target ? -beta : beta, ac = is_target ? alpha : -alpha;
   const v2f_t P12 = {alpha * dx, alpha * dy};
-  const v2f_t C2 = is_target ? v2f_t{beta, beta} : v2f_t{-dx, -dy};
+  // (a lane without a half-edge has all-zero constants and q = +0 for good: its (cx, a, b) come out as (-0, a, -0) with
+  //  a = (-0) * C2 -- C2 = +0 there makes that -0 as well, so the head of an isolated vertex adds exactly nothing to its own state)
+  const v2f_t C2 = !active ? v2f_t{0.0f, 0.0f} : is_target ? v2f_t{beta, beta} : v2f_t{-dx, -dy};
   const float nbeta = -beta;
 
   float4 st = make_float4(0.f, 0.f, 0.f, 0.f), bs4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -826,50 +830,37 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
     // the L2s and the fabric (pv_presleep x 64 cycles, fixed per launch)
     for (int z = 0; z < pv_presleep; ++z) __builtin_amdgcn_s_sleep(1);
     {
-      unsigned outer = 0;
-      for (;;) {
-        unsigned cnt, keep, pend_lo, tagv;
-#define PV_POLL(POLICY, GAP)                                                                             \
-  asm volatile("s_mov_b32 %[keep], m0\n\t"                                                              \
-               "s_mov_b32 m0, %[dst]\n\t"                                                               \
-               "s_mov_b32 %[cnt], 0\n\t"                                                                \
-               "1:\n\t"                                                                                 \
-               "s_mov_b64 exec, %[fm]\n\t"                                                              \
-               "global_load_lds_dwordx4 %[src], off " POLICY "\n\t"                                     \
-               "s_mov_b64 exec, -1\n\t" GAP "ds_read_b32 %[t], %[ra] offset:12\n\t"                   \
-               "ds_read_b128 %[nb], %[ra]\n\t"                                                          \
-               "s_add_u32 %[cnt], %[cnt], 1\n\t"                                                        \
-               "s_waitcnt lgkmcnt(0)\n\t"                                                               \
-               "v_cmp_ne_u32_e32 vcc, %[tag], %[t]\n\t"                                                 \
-               "s_cmp_lt_u32 %[cnt], 64\n\t"                                                            \
-               "s_cbranch_vccz 2f\n\t"                                                                  \
-               "s_cbranch_scc1 1b\n\t"                                                                  \
-               "2:\n\t"                                                                                 \
-               "s_mov_b32 %[pl], vcc_lo\n\t"                                                            \
-               "s_or_b32 %[pl], %[pl], vcc_hi\n\t"                                                      \
-               "s_mov_b32 m0, %[keep]"                                                                   \
-               : [keep] "=&s"(keep), [cnt] "=&s"(cnt), [pl] "=&s"(pend_lo), [nb] "=&v"(nbv), [t] "=&v"(tagv) \
-               : [src] "v"(src), [dst] "s"(dst), [ra] "v"(rd_nbr), [tag] "s"(s), [fm] "s"(fetch_mask)       \
-               : "vcc", "scc", "memory")
-        // up to 64 rounds per statement: one LDS-DMA load per fetch lane (M0 = destination base, saved and restored
-        // inside the statement), then every lane's neighbour record from LDS; vcc = lanes still waiting
-        // ... narrowed: a fetch lane whose own slot already shows the step's tag stops re-loading it (`pn` = fetch lanes
-        // still waiting), so the poll traffic shrinks to the stragglers instead of the whole fetch list every round
-#define PV_POLL_N(POLICY, GAP)                                                                           \
+      // up to 64 rounds per statement: one LDS-DMA load per fetch lane that still waits (M0 = destination base, saved and
+      // restored inside the statement; `pn` = those lanes: a lane whose own slot shows the step's tag stops re-loading it,
+      // unless the launch asks for the un-narrowed poll), an optional s_sleep, then every lane's neighbour record from LDS;
+      // vcc = lanes still waiting.  One statement for all pacing variants (two scalar flags), and the common exit falls
+      // straight through into the step: the instructions after the last record's arrival are the ones that count.
+      unsigned cnt, keep, pend_lo, tagv, tagf;
+      unsigned long long pnarrow;
+      const unsigned own_slot = dst + 16u * (unsigned)lane;
+      const unsigned f_sleep = (unsigned)(poll_gap & 1), f_narrow = (unsigned)(poll_gap >> 1);
+#define PV_POLL_U                                                                                         \
   asm volatile("s_mov_b32 %[keep], m0\n\t"                                                              \
                "s_mov_b32 m0, %[dst]\n\t"                                                               \
                "s_mov_b32 %[cnt], 0\n\t"                                                                \
                "s_mov_b64 %[pn], %[fm]\n\t"                                                             \
                "1:\n\t"                                                                                 \
                "s_mov_b64 exec, %[pn]\n\t"                                                              \
-               "global_load_lds_dwordx4 %[src], off " POLICY "\n\t"                                     \
-               "s_mov_b64 exec, -1\n\t" GAP "ds_read_b32 %[t], %[ra] offset:12\n\t"                   \
+               "global_load_lds_dwordx4 %[src], off sc1\n\t"                                            \
+               "s_mov_b64 exec, -1\n\t"                                                                 \
+               "s_cmp_eq_u32 %[fs], 0\n\t"                                                              \
+               "s_cbranch_scc1 3f\n\t"                                                                  \
+               "s_sleep 1\n\t"                                                                          \
+               "3:\n\t"                                                                                 \
+               "ds_read_b32 %[t], %[ra] offset:12\n\t"                                                  \
                "ds_read_b32 %[t2], %[fa] offset:12\n\t"                                                 \
                "ds_read_b128 %[nb], %[ra]\n\t"                                                          \
                "s_add_u32 %[cnt], %[cnt], 1\n\t"                                                        \
                "s_waitcnt lgkmcnt(0)\n\t"                                                               \
                "v_cmp_ne_u32_e32 vcc, %[tag], %[t2]\n\t"                                                \
                "s_and_b64 %[pn], vcc, %[fm]\n\t"                                                        \
+               "s_cmp_eq_u32 %[fn], 0\n\t"                                                              \
+               "s_cselect_b64 %[pn], %[fm], %[pn]\n\t"                                                  \
                "v_cmp_ne_u32_e32 vcc, %[tag], %[t]\n\t"                                                 \
                "s_cmp_lt_u32 %[cnt], 64\n\t"                                                            \
                "s_cbranch_vccz 2f\n\t"                                                                  \
@@ -880,30 +871,24 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
                "s_mov_b32 m0, %[keep]"                                                                   \
                : [keep] "=&s"(keep), [cnt] "=&s"(cnt), [pl] "=&s"(pend_lo), [nb] "=&v"(nbv), [t] "=&v"(tagv), \
                  [t2] "=&v"(tagf), [pn] "=&s"(pnarrow)                                                     \
-               : [src] "v"(src), [dst] "s"(dst), [ra] "v"(rd_nbr), [fa] "v"(own_slot), [tag] "s"(s), [fm] "s"(fetch_mask) \
+               : [src] "v"(src), [dst] "s"(dst), [ra] "v"(rd_nbr), [fa] "v"(own_slot), [tag] "s"(s), [fm] "s"(fetch_mask), \
+                 [fs] "s"(f_sleep), [fn] "s"(f_narrow)                                                     \
                : "vcc", "scc", "memory")
-        unsigned tagf;
-        unsigned long long pnarrow;
-        const unsigned own_slot = dst + 16u * (unsigned)lane;
-        if (poll_gap == 0) {
-          PV_POLL("sc1", "");
-        } else if (poll_gap == 1) {
-          PV_POLL("sc1", "s_sleep 1\n\t");
-        } else if (poll_gap == 2) {
-          PV_POLL_N("sc1", "");
-        } else {
-          PV_POLL_N("sc1", "s_sleep 1\n\t");
-        }
-#undef PV_POLL
-#undef PV_POLL_N
-        rounds += cnt;
-        if (pend_lo == 0u) break;  // every lane saw the step's tag
-        const int ab = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ab != 0 || ++outer > (max_spins >> 4)) {
-          timed_out = true;
-          break;
+      PV_POLL_U;
+      rounds += cnt;
+      if (__builtin_expect(pend_lo != 0u, 0)) {  // 64 rounds were not enough (or the run is being aborted): keep polling, bounded
+        for (unsigned outer = 0;;) {
+          const int ab = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (ab != 0 || ++outer > (max_spins >> 4)) {
+            timed_out = true;
+            break;
+          }
+          PV_POLL_U;
+          rounds += cnt;
+          if (pend_lo == 0u) break;  // every lane saw the step's tag
         }
       }
+#undef PV_POLL_U
     }
     if (VERIFY && verify && !timed_out) {
       // Every fetch lane reads its foreign record once more, with an ordinary load, and compares all four dwords with
@@ -957,7 +942,6 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
       // that follow).  ~30 cycles per shift against ~70 per slot of the LDS slab (tools/ripple_bench: 264 vs 580 cycles for 8).
       float W1 = (w12.x + a12.x) + b12.x, W2 = (w12.y + a12.y) + b12.y;
       X = x + cx;
-      unsigned long long ma, mb;
 #define PV_ADDS(J)                                                                                    \
   "v_add_f32_dpp %[X], %[cx], %[X] row_shl:" #J " row_mask:0xf bank_mask:0xf\n\t"                      \
   "v_add_f32_dpp %[W1], %[a1], %[W1] row_shl:" #J " row_mask:0xf bank_mask:0xf\n\t"                    \
@@ -965,27 +949,27 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   "v_add_f32_dpp %[W1], %[b1], %[W1] row_shl:" #J " row_mask:0xf bank_mask:0xf\n\t"                    \
   "v_add_f32_dpp %[W2], %[b2], %[W2] row_shl:" #J " row_mask:0xf bank_mask:0xf\n\t"
 #define PV_RM(J, M) "s_mov_b64 exec, %[" #M "]\n\t" PV_ADDS(J)
-#define PV_RS(J, J1, CUR, NXT)                                                                        \
-  "s_cmp_le_u32 %[md], " #J "\n\t"                                                                     \
-  "s_cbranch_scc1 9f\n\t"                                                                              \
-  "v_cmp_lt_u32_e64 %[" #NXT "], " #J1 ", %[dx]\n\t"                                                   \
-  "s_mov_b64 exec, %[" #CUR "]\n\t" PV_ADDS(J)
       // shifts 1..7: straight line, masks from registers (a shift past a head's degree finds it masked out; a patch whose
-      // largest degree is below 8 runs the spare shifts on nothing).  Shifts 8..15 only where a vertex has that many edges:
-      // mask compared on the spot, one branch per shift (16 + 16 cycles more per shift: measured, tools/exp/ripple_bench)
+      // largest degree is below 8 runs the spare shifts on nothing).  A vertex of more than 8 edges has its row to itself
+      // (nltgv2_pack.hpp, WaveFit): from shift 8 on ONE mask -- those heads and the lanes that only serve as sources -- does
+      // for all shifts, the lanes past such a vertex's last edge being idle (-0.0 contributions); three exits by the patch's
+      // largest degree instead of one per shift (a branch costs 16 cycles, a shift 26: tools/ripple_bench)
       asm volatile("s_nop 1\n\t"
                    PV_RM(1, m1) PV_RM(2, m2) PV_RM(3, m3) PV_RM(4, m4) PV_RM(5, m5) PV_RM(6, m6) PV_RM(7, m7)
                    "s_cmp_le_u32 %[md], 8\n\t"
                    "s_cbranch_scc1 9f\n\t"
-                   "s_mov_b64 exec, -1\n\t"
-                   "v_cmp_lt_u32_e64 %[ma], 8, %[dx]\n\t"
-                   PV_RS(8, 9, ma, mb) PV_RS(9, 10, mb, ma) PV_RS(10, 11, ma, mb) PV_RS(11, 12, mb, ma)
-                   PV_RS(12, 13, ma, mb) PV_RS(13, 14, mb, ma) PV_RS(14, 15, ma, mb) PV_RS(15, 16, mb, ma)
+                   PV_RM(8, m8) PV_ADDS(9)
+                   "s_cmp_le_u32 %[md], 10\n\t"
+                   "s_cbranch_scc1 9f\n\t"
+                   PV_ADDS(10) PV_ADDS(11)
+                   "s_cmp_le_u32 %[md], 12\n\t"
+                   "s_cbranch_scc1 9f\n\t"
+                   PV_ADDS(12) PV_ADDS(13) PV_ADDS(14) PV_ADDS(15)
                    "9:\n\t"
                    "s_mov_b64 exec, -1"
-                   : [X] "+v"(X), [W1] "+v"(W1), [W2] "+v"(W2), [ma] "=&s"(ma), [mb] "=&s"(mb)
-                   : [cx] "v"(cx), [a1] "v"(a12.x), [a2] "v"(a12.y), [b1] "v"(b12.x), [b2] "v"(b12.y), [dx] "v"(degx), [md] "s"(stride),
-                     [m1] "s"(rm1), [m2] "s"(rm2), [m3] "s"(rm3), [m4] "s"(rm4), [m5] "s"(rm5), [m6] "s"(rm6), [m7] "s"(rm7)
+                   : [X] "+v"(X), [W1] "+v"(W1), [W2] "+v"(W2)
+                   : [cx] "v"(cx), [a1] "v"(a12.x), [a2] "v"(a12.y), [b1] "v"(b12.x), [b2] "v"(b12.y), [md] "s"(stride),
+                     [m1] "s"(rm1), [m2] "s"(rm2), [m3] "s"(rm3), [m4] "s"(rm4), [m5] "s"(rm5), [m6] "s"(rm6), [m7] "s"(rm7), [m8] "s"(rm8)
                    : "scc");
 #undef PV_RS
 #undef PV_RM

@@ -156,12 +156,18 @@ struct WaveFit {
       fill += need;
       return f;
     }
-    for (int32_t r = 0; r < 4; ++r)
+    for (int32_t r = 0; r < 4; ++r) {
+      if (need > 8) {  // a vertex of more than 8 edges gets a row to itself: its shifts 8.. then run over lanes of its own or
+        if (row[r] != 0) continue;  // idle ones only, and need no mask of their own (k_persistent_pv)
+        row[r] = 16;
+        return 16 * r;
+      }
       if (row[r] + need <= 16) {
         const int32_t f = 16 * r + row[r];
         row[r] += need;
         return f;
       }
+    }
     return -1;
   }
 };

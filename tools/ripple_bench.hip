@@ -126,6 +126,40 @@ __global__ void __launch_bounds__(64) k_ripple_k(const int* first, const int* de
   if (lane == 0) cyc[blockIdx.x] = (t1 - t0) / reps;
 }
 
+// the accumulation block of k_persistent_pv<.., RIPPLE, ..> as shipped: masks for shifts 1..7, one mask from shift 8 on (a vertex
+// of more than 8 edges has its row to itself), idle lanes disabled as sources (a DPP read of a disabled lane leaves the
+// destination untouched: bound_ctrl 0) -- their contributions are set to garbage here to prove it
+__global__ void __launch_bounds__(64) k_ripple_ship(const int* first, const int* deg, const int* active, const float* c5, float* out, long long* cyc, int reps, int maxdeg) {
+  const int lane = threadIdx.x;
+  const int f = first[lane], d = deg[lane];
+  const bool head = f == lane;
+  const unsigned degx = head ? (active[lane] ? (unsigned)d : 0u) : (active[lane] ? 255u : 0u);
+  float cx = c5[lane * 5], a1 = c5[lane * 5 + 1], a2 = c5[lane * 5 + 2], b1 = c5[lane * 5 + 3], b2 = c5[lane * 5 + 4];
+  if (!active[lane]) cx = a1 = a2 = b1 = b2 = 1e30f;
+  float x = 1.0f + lane, w1 = 0.5f, w2 = -0.25f;
+  float X = 0, W1 = 0, W2 = 0;
+  const unsigned long long m1 = __ballot(degx > 1u), m2 = __ballot(degx > 2u), m3 = __ballot(degx > 3u), m4 = __ballot(degx > 4u), m5 = __ballot(degx > 5u),
+                           m6 = __ballot(degx > 6u), m7 = __ballot(degx > 7u), m8 = __ballot(degx > 8u);
+  const long long t0 = clock64();
+  for (int r = 0; r < reps; ++r) {
+    X = x + cx, W1 = (w1 + a1) + b1, W2 = (w2 + a2) + b2;
+#define RM(J, M) "s_mov_b64 exec, %[" #M "]\n\t" PV_ADDS(J)
+    asm volatile("s_nop 1\n\t" RM(1, m1) RM(2, m2) RM(3, m3) RM(4, m4) RM(5, m5) RM(6, m6) RM(7, m7)
+                 "s_cmp_le_u32 %[md], 8\n\ts_cbranch_scc1 9f\n\t" RM(8, m8) PV_ADDS(9)
+                 "s_cmp_le_u32 %[md], 10\n\ts_cbranch_scc1 9f\n\t" PV_ADDS(10) PV_ADDS(11)
+                 "s_cmp_le_u32 %[md], 12\n\ts_cbranch_scc1 9f\n\t" PV_ADDS(12) PV_ADDS(13) PV_ADDS(14) PV_ADDS(15)
+                 "9:\n\ts_mov_b64 exec, -1"
+                 : [X] "+v"(X), [W1] "+v"(W1), [W2] "+v"(W2)
+                 : [cx] "v"(cx), [a1] "v"(a1), [a2] "v"(a2), [b1] "v"(b1), [b2] "v"(b2), [md] "s"(maxdeg), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3),
+                   [m4] "s"(m4), [m5] "s"(m5), [m6] "s"(m6), [m7] "s"(m7), [m8] "s"(m8) : "scc");
+#undef RM
+    x = head ? X * 1e-30f + x : x;
+  }
+  const long long t1 = clock64();
+  out[lane * 3] = X, out[lane * 3 + 1] = W1, out[lane * 3 + 2] = W2;
+  if (lane == 0) cyc[blockIdx.x] = (t1 - t0) / reps;
+}
+
 template <int J>
 __device__ __forceinline__ void ripple_step(float& X, float& W1, float& W2, const float cx, const float a1, const float a2, const float b1,
                                             const float b2, const unsigned degx) {
@@ -221,15 +255,15 @@ __global__ void __launch_bounds__(64) k_slab(const int* first, const int* deg, c
 
 int main() {
   // segments: rows of 16 lanes; degrees chosen to fill rows: (6,6,4) (7,5,4) (16) (8,8)  -- second config caps at 8
-  for (int cfg = 0; cfg < 2; ++cfg) {
-    std::vector<int> degs = cfg == 0 ? std::vector<int>{6, 6, 4, 7, 5, 4, 16, 8, 8} : std::vector<int>{6, 6, 4, 7, 5, 4, 6, 5, 5, 8, 8};
-    std::vector<int> first(64, 0), deg(64, 1), vtx(64, 0);
+  for (int cfg = 0; cfg < 3; ++cfg) {
+    std::vector<int> degs = cfg == 0 ? std::vector<int>{6, 6, 4, 7, 5, 4, 16, 8, 8} : cfg == 1 ? std::vector<int>{6, 6, 4, 7, 5, 4, 6, 5, 5, 8, 8} : std::vector<int>{9, 6, 5, 13, 7, 6};
+    std::vector<int> first(64, 0), deg(64, 1), vtx(64, 0), act(64, 0);
     int lane = 0, v = 0, maxdeg = 1;
     std::vector<int> vfirst;
     for (int d : degs) {
-      if (lane % 16 + d > 16) { while (lane % 16) { first[lane] = lane, deg[lane] = 1, vtx[lane] = 63; ++lane; } }
+      if (lane % 16 + d > 16 || (cfg == 2 && (d > 8 || (lane % 16 && deg[lane - 1] > 8)))) { while (lane % 16) { first[lane] = lane, deg[lane] = 1, vtx[lane] = 63; ++lane; } }
       vfirst.push_back(lane);
-      for (int k = 0; k < d; ++k) first[lane + k] = lane, deg[lane + k] = d, vtx[lane + k] = v;
+      for (int k = 0; k < d; ++k) first[lane + k] = lane, deg[lane + k] = d, vtx[lane + k] = v, act[lane + k] = 1;
       lane += d, ++v;
       maxdeg = std::max(maxdeg, d);
     }
@@ -251,6 +285,16 @@ int main() {
       ex[f0 * 3] = X, ex[f0 * 3 + 1] = W1, ex[f0 * 3 + 2] = W2;
     }
     std::vector<float> out(64 * 3); long long cyc[1024];
+    {
+      int* dact; CHECK(hipMalloc(&dact, 256)); CHECK(hipMemcpy(dact, act.data(), 256, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(k_ripple_ship, dim3(1024), dim3(64), 0, 0, dfirst, ddeg, dact, dc, dout, dcyc, 2000, maxdeg);
+      CHECK(hipDeviceSynchronize());
+      CHECK(hipMemcpy(out.data(), dout, 64 * 3 * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(cyc, dcyc, sizeof(long long) * 1024, hipMemcpyDeviceToHost));
+      int bad = 0;
+      for (size_t i = 0; i < degs.size(); ++i) for (int k = 0; k < 3; ++k) bad += std::memcmp(&out[vfirst[i] * 3 + k], &ex[vfirst[i] * 3 + k], 4) != 0;
+      printf("cfg %d maxdeg %2d as shipped (idle lanes hold garbage, disabled as sources): %lld cycles per accumulation, mismatching head sums %d\n", cfg, maxdeg, cyc[0], bad);
+    }
+    if (cfg < 2)
     for (int nb : {1, 1024}) {
       hipLaunchKernelGGL(k_ripple, dim3(nb), dim3(64), 0, 0, dfirst, ddeg, dc, dout, dcyc, 2000, maxdeg);
       CHECK(hipDeviceSynchronize());
