@@ -637,6 +637,9 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   const int rid_base = wg_info[4 * wg], n_fetch = wg_info[4 * wg + 1];
   const int count_flags = wg_info[4 * wg + 2];
   if ((count_flags & 0xffff) == 0) return;                 // idle padding behind an XCD's instances (shadow layouts)
+  // RIPPLE layouts: a patch that holds a vertex of more than 16 edges is laid out back to back and accumulates through the
+  // LDS slab like the other kernel variant does for every patch (wave-uniform)
+  const bool slab = !RIPPLE || (count_flags & (1 << 17)) != 0;
   const bool shadow = (count_flags & (1 << 16)) != 0;      // a second copy of a patch on another XCD: computes and
                                                            // publishes like the original, writes no state back
   // Contribution slab: `stride` slots per vertex of this patch (its largest degree rounded up to a multiple of 4, at least 8); the
@@ -678,7 +681,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   const bool valid = (meta & kWgValidBit) != 0u, publishes = (meta & kWgPublishBit) != 0u;
   // The lane that holds a vertex's state, publishes its record and writes it back: the LAST lane of the vertex where every
   // lane keeps the state (slab form), the FIRST where the sum runs across the lanes towards it (RIPPLE: row-packed patches).
-  const bool state_lane = RIPPLE ? (meta & kWgHeadBit) != 0u : is_tail;
+  const bool state_lane = slab ? is_tail : (meta & kWgHeadBit) != 0u;
   // RIPPLE: a head takes part in shift j while j < its degree; the other lanes of a vertex only serve as sources, and a lane
   // without a half-edge is disabled altogether (a DPP read of a disabled lane leaves the destination as it is)
   const unsigned degx = (meta & kWgHeadBit) ? ((meta >> 6) & 127u) : (active ? 255u : 0u);
@@ -735,7 +738,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   const int rdA = o_slabA + loc * strideA, rdC4 = (f_slabC + loc * stride) >> 2;
   const int rec_w = valid ? loc : o_ovfA + lane, rec_wstride = valid ? rec_stride : 0;
 
-  if (!RIPPLE)
+  if (slab)
     for (int i = lane; i < slab_slots; i += T) {
       lds[o_slabA + i] = make_float4(-0.0f, -0.0f, -0.0f, -0.0f);
       ldsf[f_slabC + i] = -0.0f;
@@ -932,7 +935,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
     b12 = is_target ? v2f_t{-0.0f, -0.0f} : b12;
     float X = x;
     v2f_t Wa = w12;
-    if constexpr (RIPPLE) {
+    if (!slab) {
       // ---- ordered accumulation across the lanes of the vertex, towards its head ------------------------------------
       // The head (lane `first`) starts with (x + c_0, (w + a_0) + b_0) of its own half-edge; shift j = 1, 2, ... adds the
       // contribution of lane first + j, taken with a DPP row shift (the patch is row-packed: a vertex's lanes share a 16-lane

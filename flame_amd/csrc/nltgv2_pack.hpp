@@ -97,9 +97,10 @@ struct PackedLayout {
   std::vector<int32_t> wg_fetch;       // [wg_count*64] record id fetched by this lane, -1 none
   std::vector<int32_t> wg_info;        // [wg_count*4] first record id, fetched records, local vertices (| kWgShadow), slab stride
                                        //               (row-packed patches: the patch's largest degree instead)
-  // Row-packed patches (wg_rowpack; every graph whose largest degree is <= 16): a vertex's lanes lie inside one 16-lane row
-  // of the wave (the walk fits each vertex into the first of the wave's four rows that has room), which is what lets the
-  // kernel add a vertex's contributions up across lanes with DPP row shifts instead of through LDS.  wg_vfirst[i] = first lane, within its patch,
+  // Row-packed patches (wg_rowpack): a vertex's lanes lie inside one 16-lane row of the wave (the walk fits each vertex into
+  // the first of the wave's four rows that has room; one of more than 8 edges gets a row to itself), which is what lets the
+  // kernel add a vertex's contributions up across lanes with DPP row shifts instead of through LDS.  A vertex of more than 16
+  // edges starts a patch of the other kind (lanes back to back, kWgSlab in its info word; the LDS-slab accumulation).  wg_vfirst[i] = first lane, within its patch,
   // of the i-th vertex of the walk (either way).
   bool wg_rowpack = false;
   std::vector<uint8_t> wg_vfirst;
@@ -121,6 +122,7 @@ struct PackedLayout {
   std::vector<int32_t> rid_on;         // [8*V] with shadows: the record id an instance on XCD k reads for vertex u (k*V + u)
 };
 constexpr int32_t kWgShadow = 1 << 16;  // in wg_info[4p+2]
+constexpr int32_t kWgSlab = 1 << 17;    // in wg_info[4p+2], row-packed layouts: this patch is not (it holds a vertex of > 16 edges)
 constexpr uint32_t kWgTail = 1u << 24, kWgActive = 1u << 25, kWgValid = 1u << 26, kWgPublish = 1u << 27, kWgHead = 1u << 28;
 constexpr int32_t kWgRow = 16;  // lanes of a DPP row
 constexpr int kTvSlots = 8;
@@ -141,14 +143,18 @@ inline uint32_t morton_spread16(uint32_t v) {
 // wg_rowpack) -- first fit into the wave's four 16-lane rows, a vertex's lanes contiguous inside one row.  Shared by the
 // walks of (C) and (E), which must cut the same waves.
 struct WaveFit {
-  bool rows = false;
+  bool rowpack = false;                                  // the layout is row-packed wherever the degrees allow
+  bool rows = false;                                     // ... and so is the current wave
   int32_t fill = kWave;                                  // back to back: lanes used
   int32_t row[4] = {16, 16, 16, 16};                      // row-packed: lanes used per row
-  void open() {
+  // A new wave, for a vertex of `need` lanes first.  A vertex of more than 16 edges cannot lie inside a row: the wave it
+  // starts is filled back to back (and runs the LDS-slab accumulation), the next wave is row-packed again.
+  void open(int32_t need) {
+    rows = rowpack && need <= 16;
     fill = 0;
     row[0] = row[1] = row[2] = row[3] = 0;
   }
-  // first lane for a vertex of `need` lanes, or -1: the wave is full for it
+  // first lane for a vertex of `need` lanes, or -1: the wave is full for it (or cannot take it)
   int32_t place(int32_t need) {
     if (!rows) {
       if (fill + need > kWave) return -1;
@@ -156,6 +162,7 @@ struct WaveFit {
       fill += need;
       return f;
     }
+    if (need > 16) return -1;
     for (int32_t r = 0; r < 4; ++r) {
       if (need > 8) {  // a vertex of more than 8 edges gets a row to itself: its shifts 8.. then run over lanes of its own or
         if (row[r] != 0) continue;  // idle ones only, and need no mask of their own (k_persistent_pv)
@@ -186,7 +193,7 @@ inline void build_he_rows(PackedLayout* L) {
   L->comp_he_wave.clear();
   if (L->he_ok && V > 0) {
     WaveFit fit;  // (starts full: forces a new wave for the first vertex)
-    fit.rows = L->wg_rowpack;
+    fit.rowpack = L->wg_rowpack;
     size_t next_comp = 0;
     for (int32_t i = 0; i < V; ++i) {
       const int32_t s = L->iperm[order_m[i]];  // packed index of the i-th vertex in Morton order
@@ -204,7 +211,7 @@ inline void build_he_rows(PackedLayout* L) {
         L->he_meta.resize(L->he_meta.size() + kWave, 0u);
         L->he_wave_chain.push_back(1);
         L->he_waves++;
-        fit.open();
+        fit.open(need);
         fill = fit.place(need);
       }
       const size_t base = static_cast<size_t>(L->he_waves - 1) * kWave + fill;
@@ -303,8 +310,7 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
   L->wg_vfirst.clear();
   // (row packing fills a wave to ~54 of its 64 lanes: more, smaller patches.  That pays where a patch has a SIMD to itself
   //  or nearly; a graph too big for the patch-per-wave form keeps its lanes back to back, for the forms that then run it)
-  L->wg_rowpack = rowpack && L->max_degree <= kWgRow &&
-                  (static_cast<int64_t>(2) * L->E + V / 32) / 54 + 1 <= static_cast<int64_t>(rowpack_max_patches);
+  L->wg_rowpack = rowpack && (static_cast<int64_t>(2) * L->E + V / 32) / 54 + 1 <= static_cast<int64_t>(rowpack_max_patches);
   if (L->max_degree > kWave || V <= 0) return;
   L->wg_vfirst.resize(static_cast<size_t>(V));
   L->wg_info.reserve(((static_cast<size_t>(2) * L->E + V) * 9 / 8 / T + L->comp_start.size() + 2) * 4);
@@ -313,14 +319,16 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
   // slab stride (its largest degree rounded up to 4, at least 8).
   int32_t n_local = 0, max_deg = 1;
   WaveFit fit;
-  fit.rows = L->wg_rowpack;
+  fit.rowpack = L->wg_rowpack;
+  bool slab_patch = !L->wg_rowpack;
   size_t next_comp = 0;
   auto close_patch = [&]() {
     if (L->wg_count == 0) return;
-    if (L->wg_rowpack) {
+    if (!slab_patch) {
       L->wg_info[static_cast<size_t>(L->wg_count - 1) * 4 + 3] = max_deg;
       return;
     }
+    if (L->wg_rowpack) L->wg_info[static_cast<size_t>(L->wg_count - 1) * 4 + 2] |= kWgSlab;
     const int32_t stride = std::max(8, (max_deg + 3) & ~3);
     L->wg_info[static_cast<size_t>(L->wg_count - 1) * 4 + 3] = stride;
     L->wg_slab_slots = std::max(L->wg_slab_slots, (stride + 1) * n_local);  // (+1: the kernel pads a vertex's slab, see there)
@@ -338,11 +346,12 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
       L->wg_info[static_cast<size_t>(L->wg_count) * 4] = i;
       L->wg_count++;
       n_local = 0, max_deg = 1;
-      fit.open();
+      fit.open(need);
+      slab_patch = !fit.rows;
       fill = fit.place(need);
     }
     max_deg = std::max(max_deg, need);
-    L->wg_info[static_cast<size_t>(L->wg_count - 1) * 4 + 2] = ++n_local;
+    L->wg_info[static_cast<size_t>(L->wg_count - 1) * 4 + 2] = ++n_local;  // (| kWgSlab when the patch is closed)
     L->wg_lcap = std::max(L->wg_lcap, n_local);
     L->wg_vfirst[static_cast<size_t>(i)] = static_cast<uint8_t>(fill);
   }
@@ -361,7 +370,7 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
     const int32_t P = L->wg_count;
     std::vector<int32_t> patch_of_vertex(static_cast<size_t>(V));  // by the caller's vertex id
     for (int32_t q = 0; q < P; ++q) {
-      const int32_t r0 = L->wg_info[static_cast<size_t>(q) * 4], n = L->wg_info[static_cast<size_t>(q) * 4 + 2];
+      const int32_t r0 = L->wg_info[static_cast<size_t>(q) * 4], n = L->wg_info[static_cast<size_t>(q) * 4 + 2] & 0xffff;
       for (int32_t j = 0; j < n; ++j) patch_of_vertex[static_cast<size_t>(order_m[static_cast<size_t>(r0 + j)])] = q;
     }
     // XCD k owns the patches [cut[k], cut[k+1]) of the walk.  Shadows land unevenly (an XCD in the middle of the image has
@@ -374,7 +383,7 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
     std::vector<int32_t> adj_ptr(static_cast<size_t>(P) + 1, 0), adj, stamp(static_cast<size_t>(P), -1);
     adj.reserve(static_cast<size_t>(P) * 8);
     for (int32_t q = 0; q < P; ++q) {
-      const int32_t r0 = L->wg_info[static_cast<size_t>(q) * 4], n = L->wg_info[static_cast<size_t>(q) * 4 + 2];
+      const int32_t r0 = L->wg_info[static_cast<size_t>(q) * 4], n = L->wg_info[static_cast<size_t>(q) * 4 + 2] & 0xffff;
       stamp[static_cast<size_t>(q)] = q;
       for (int32_t j = 0; j < n; ++j) {
         const int32_t o = order_m[static_cast<size_t>(r0 + j)];
@@ -457,9 +466,9 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
         }
         for (int32_t q = 0; q < P; ++q) {
           if (!((need[static_cast<size_t>(q)] >> k) & 1)) continue;
-          const int32_t r0 = L->wg_info[static_cast<size_t>(q) * 4], n = L->wg_info[static_cast<size_t>(q) * 4 + 2];
+          const int32_t r0 = L->wg_info[static_cast<size_t>(q) * 4], n = L->wg_info[static_cast<size_t>(q) * 4 + 2] & 0xffff;
           info[static_cast<size_t>(at) * 4] = next_rid;
-          info[static_cast<size_t>(at) * 4 + 2] = n | kWgShadow;
+          info[static_cast<size_t>(at) * 4 + 2] = n | kWgShadow | (L->wg_info[static_cast<size_t>(q) * 4 + 2] & kWgSlab);
           info[static_cast<size_t>(at) * 4 + 3] = L->wg_info[static_cast<size_t>(q) * 4 + 3];
           v0[static_cast<size_t>(at)] = r0;
           for (int32_t j = 0; j < n; ++j) L->rid_on[static_cast<size_t>(k) * V + order_m[static_cast<size_t>(r0 + j)]] = next_rid + j;

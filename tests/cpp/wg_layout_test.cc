@@ -135,7 +135,10 @@ static int replay(HostGraph& hg, int n_iters, const nltgv2_params& p, int shadow
       if (!(m & kWgValid)) continue;
       const int first = m & 63, deg = (m >> 6) & 127, need = deg > 1 ? deg : 1;
       if (first + need > 64) return 2;                        // a vertex inside one wave
-      if (L.wg_rowpack && first / 16 != (first + need - 1) / 16) return 17;  // ... and, row-packed, inside one 16-lane row
+      const bool rowp = L.wg_rowpack && !(L.wg_info[4 * wg + 2] & kWgSlab);  // this patch is row-packed
+      if (rowp && first / 16 != (first + need - 1) / 16) return 17;  // ... then a vertex lies inside one 16-lane row,
+      if (rowp && need > 8 && (first % 16 != 0)) return 20;          // one of more than 8 edges at the start of a row of its own
+      if (L.wg_rowpack && need > 16 && rowp) return 21;              // and one of more than 16 is in a patch of the other kind
       if (((m & kWgHead) != 0) != ((t & 63) == first)) return 18;
       const int k = (t & 63) - first;
       if (k < 0 || k >= need) return 3;
@@ -148,8 +151,8 @@ static int replay(HostGraph& hg, int n_iters, const nltgv2_params& p, int shadow
     {  // slab stride: a multiple of 4, at least 8, covers the patch's largest degree, and fits the LDS sizing figure
       const int stride = L.wg_info[4 * wg + 3];
       if ((L.wg_info[4 * wg + 2] & 0xffff) == 0) continue;  // idle padding of a shadow layout
-      if (L.wg_rowpack) {  // row-packed: the patch's largest degree itself (the number of DPP shifts + 1), no slab
-        if (stride < 1 || stride > 16 || L.wg_slab_slots != 0) return 13;
+      if (L.wg_rowpack && !(L.wg_info[4 * wg + 2] & kWgSlab)) {  // row-packed: the patch's largest degree itself (the DPP shifts + 1)
+        if (stride < 1 || stride > 16) return 13;
         bool reached = false;
         for (int t = 0; t < T; ++t)
           reached |= (L.wg_meta[(size_t)wg * T + t] & kWgValid) && (int)std::max(1u, (L.wg_meta[(size_t)wg * T + t] >> 6) & 127) == stride;
@@ -293,10 +296,10 @@ int main() {
   const nltgv2_params p = {0.1f, 0.001f, 125.0f, 0.25f, 0.0f, 10.0f};
   for (int frames : {1, 3})
     for (int shadow_mode : {0, 2})
-      for (int variant = 0; variant < 3; ++variant) {  // hub of degree ~46 (never row-packed); degree <= 16: row-packed, or not by request
+      for (int variant = 0; variant < 3; ++variant) {  // hub of degree ~46 (a back-to-back patch among row-packed ones); degree <= 16; not row-packed by request
         const bool hub = variant == 0, rowpack = variant != 2;
         HostGraph g = make_graph(61, 47, frames, 1234 + frames, hub);
-        const int rc = replay(g, 6, p, shadow_mode, rowpack, !hub && rowpack);
+        const int rc = replay(g, 6, p, shadow_mode, rowpack, rowpack);
         if (rc) {
           std::printf("FAILED frames=%d shadows=%d variant=%d rc=%d\n", frames, shadow_mode, variant, rc);
           return 1;
