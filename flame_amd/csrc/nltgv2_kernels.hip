@@ -586,7 +586,10 @@ __device__ __forceinline__ unsigned read_hw_id() {
   return v;
 }
 
-template <bool PROBE, bool RIPPLE, bool VERIFY>
+// LAYOUT: 0 = every patch back to back, LDS-slab accumulation; 1 = every patch row-packed, DPP accumulation; 2 = row-packed
+// with back-to-back patches among them (where a vertex has more than 16 edges): both schemes compiled in, chosen per patch --
+// a separate instance because carrying the slab code costs the all-row-packed case 3-5 % (registers, code layout; measured)
+template <bool PROBE, int LAYOUT, bool VERIFY>
 __global__ void __launch_bounds__(64)
 k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, const int lcap, const int slab_slots,
                 const int32_t* __restrict__ wg_slot, const int32_t* __restrict__ wg_vid,
@@ -639,7 +642,8 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   if ((count_flags & 0xffff) == 0) return;                 // idle padding behind an XCD's instances (shadow layouts)
   // RIPPLE layouts: a patch that holds a vertex of more than 16 edges is laid out back to back and accumulates through the
   // LDS slab like the other kernel variant does for every patch (wave-uniform)
-  const bool slab = !RIPPLE || (count_flags & (1 << 17)) != 0;
+  constexpr bool RIPPLE = LAYOUT != 0;
+  const bool slab = LAYOUT == 0 || (LAYOUT == 2 && (count_flags & (1 << 17)) != 0);
   const bool shadow = (count_flags & (1 << 16)) != 0;      // a second copy of a patch on another XCD: computes and
                                                            // publishes like the original, writes no state back
   // Contribution slab: `stride` slots per vertex of this patch (its largest degree rounded up to a multiple of 4, at least 8); the
@@ -1800,7 +1804,8 @@ int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, boo
 int pv_patches_per_cu(const FusedArgs& a) {
   const size_t ldsv = 16u * (size_t)(2 * (a.wg_lcap + 64) + a.wg_slab_slots + 64) + 4u * (size_t)(a.wg_slab_slots + 64);
   int n = 0;
-  const void* fv = a.wg_rowpack ? (const void*)k_persistent_pv<false, true, true> : (const void*)k_persistent_pv<false, false, true>;
+  const void* fv = !a.wg_rowpack ? (const void*)k_persistent_pv<false, 0, true>
+                   : a.wg_slab_slots > 0 ? (const void*)k_persistent_pv<false, 2, true> : (const void*)k_persistent_pv<false, 1, true>;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fv, 64, ldsv) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
@@ -1860,10 +1865,19 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
                      &hq_out, &vstate_out, &vaux, &bin, &bout, &vprev, &xbuf, &rec_bytes, &dual, &tag0, &n_iters,
                      &max_spins, &poll_gap, &pp, &err, &abort_flag, &perm, &tail, &probe, &place_pool, &rec_off, &rec_off_stride, &rot_word};
     const bool vr = (dual >> 1) != 0;  // record verification asked for
-    const void* fv = a.wg_rowpack ? (probe ? (const void*)k_persistent_pv<true, true, true>
-                                           : vr ? (const void*)k_persistent_pv<false, true, true> : (const void*)k_persistent_pv<false, true, false>)
-                                  : (probe ? (const void*)k_persistent_pv<true, false, true>
-                                           : vr ? (const void*)k_persistent_pv<false, false, true> : (const void*)k_persistent_pv<false, false, false>);
+    const int layout = !a.wg_rowpack ? 0 : a.wg_slab_slots > 0 ? 2 : 1;
+    const void* fv = nullptr;
+#define PV_PICK(LY)                                                                                                         \
+  fv = probe ? (const void*)k_persistent_pv<true, LY, true>                                                                 \
+             : vr ? (const void*)k_persistent_pv<false, LY, true> : (const void*)k_persistent_pv<false, LY, false>
+    if (layout == 0) {
+      PV_PICK(0);
+    } else if (layout == 1) {
+      PV_PICK(1);
+    } else {
+      PV_PICK(2);
+    }
+#undef PV_PICK
     if (cooperative) return (int)hipLaunchCooperativeKernel(fv, gv, bv, vargs, ldsv, stream);
     return (int)hipLaunchKernel(fv, gv, bv, vargs, ldsv, stream);
   }

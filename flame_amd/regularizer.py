@@ -84,7 +84,8 @@ class _Info(C.Structure):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "libflame_nltgv2_hip.so")
+    # (FLAME_AMD_LIBRARY: another build of the same library -- same-box A/B of two builds, tools/ab.py)
+    return os.environ.get("FLAME_AMD_LIBRARY") or os.path.join(_HERE, "libflame_nltgv2_hip.so")
 
 
 # every symbol include/flame_nltgv2.h declares (checked by tests/test_abi.py)
