@@ -118,7 +118,9 @@ def main():
 
     # the solver runs on a torch stream: torch's HIP events can then bracket its launches, and (N > 1) export ->
     # all_gather is ordered on the device without a host round trip between them
-    solver_stream = torch.cuda.Stream(device=local_rank)
+    # (high priority: the solver's waves win the issue slots they share with the overlapped gather's kernel -- a lock-step network
+    #  runs at the pace of its slowest member; worth 1-4 % under torch.distributed.run, nothing without a gather)
+    solver_stream = torch.cuda.Stream(device=local_rank, priority=-1)
     reg.set_stream(solver_stream.cuda_stream)
     before_step = after_step = None
     if dist is not None:
