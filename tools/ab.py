@@ -1,6 +1,6 @@
 """tools/ab.py SIZE[,SIZE..] OPT=V[,OPT=V..] [OPT=V..] ... -- same-box A/B of option settings of the solver (run on the GPU box).
 Each argument after the sizes is one setting (comma-separated option=value pairs by number, e.g. 17=0 or 16=0,17=0; "-" =
-defaults).  Per size and graph: microseconds per iteration (median of 12 runs of 2000 iterations), bit-identity to the first
+defaults).  Per size and graph: microseconds per iteration (median of 12 runs of AB_ITERS = 2000 iterations, host clock around the call), bit-identity to the first
 setting, and the in-kernel cycle account (median compute / least-slack wait) where the patch-per-wave form ran."""
 import os
 import sys
@@ -32,10 +32,11 @@ for size in sizes:
                         ref = out
                     same = all(np.array_equal(out[k], ref[k]) for k in ref)
                     ts = []
+                    n_it = int(os.environ.get("AB_ITERS", "2000"))  # iterations per timed run (one launch each)
                     for _ in range(12):
                         t0 = time.perf_counter()
-                        reg.run(flame_amd.Params(), 2000)
-                        ts.append((time.perf_counter() - t0) / 2000 * 1e6)
+                        reg.run(flame_amd.Params(), n_it)
+                        ts.append((time.perf_counter() - t0) / n_it * 1e6)
                     info = reg.info()
                     acct = ""
                     if rnd == 0 and info["last_run_path"] == 6:
