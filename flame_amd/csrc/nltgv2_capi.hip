@@ -396,9 +396,9 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
   if (ctx->persist_refused_topo == ctx->topo) return 0;
   PackedLayout& L = ctx->L;
   const int cus = ctx->prop.multiProcessorCount;
-  if (L.wg_ok && ctx->pv_occ_topo != ctx->topo) {  // ask the runtime once per topology (the LDS use varies with it)
-    ctx->pv_occ = pv_patches_per_cu(ctx->f);
-    ctx->pv_occ_topo = ctx->topo;
+  if (L.wg_ok && ctx->pv_occ_topo != ctx->topo * 2 + (ctx->opt_verify != 0)) {  // ask the runtime once per topology (the LDS use varies with it)
+    ctx->pv_occ = pv_patches_per_cu(ctx->f, ctx->opt_verify != 0 || ctx->opt_probe != 0);
+    ctx->pv_occ_topo = ctx->topo * 2 + (ctx->opt_verify != 0);
   }
   const int wg_cap = ctx->pv_occ * cus;  // patch-per-wave form, in patches
   const int he_cap = kHeWavesPerCu * cus;

@@ -160,7 +160,7 @@ struct SyncArgs {
   uint8_t* need_nbr = nullptr;               // [V] scratch
 };
 int launch_sync_state(const SyncArgs& a, hipStream_t s);
-int pv_patches_per_cu(const FusedArgs& a);
+int pv_patches_per_cu(const FusedArgs& a, bool verify);
 // device-side expansion of the layout arrays (nltgv2_layout.hip)
 int launch_build_sell(const CanonArgs& c, const FusedArgs& a, const int32_t* iperm, hipStream_t s);
 int launch_he_from_patches(const FusedArgs& a, int32_t* he_slot, int32_t* he_vid, uint32_t* he_meta, int32_t* he_wave_chain,

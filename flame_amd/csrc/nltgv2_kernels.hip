@@ -1801,11 +1801,12 @@ int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, boo
 }
 
 // Patches of k_persistent_pv (one wave each) the runtime keeps resident per CU for this layout's LDS use.
-int pv_patches_per_cu(const FusedArgs& a) {
+int pv_patches_per_cu(const FusedArgs& a, bool verify) {
   const size_t ldsv = 16u * (size_t)(2 * (a.wg_lcap + 64) + a.wg_slab_slots + 64) + 4u * (size_t)(a.wg_slab_slots + 64);
   int n = 0;
-  const void* fv = !a.wg_rowpack ? (const void*)k_persistent_pv<false, 0, true>
-                   : a.wg_slab_slots > 0 ? (const void*)k_persistent_pv<false, 2, true> : (const void*)k_persistent_pv<false, 1, true>;
+  const void* fv = !a.wg_rowpack ? (verify ? (const void*)k_persistent_pv<false, 0, true> : (const void*)k_persistent_pv<false, 0, false>)
+                   : a.wg_slab_slots > 0 ? (verify ? (const void*)k_persistent_pv<false, 2, true> : (const void*)k_persistent_pv<false, 2, false>)
+                                         : (verify ? (const void*)k_persistent_pv<false, 1, true> : (const void*)k_persistent_pv<false, 1, false>);
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fv, 64, ldsv) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
