@@ -803,6 +803,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       ctx->canon_valid = false;
       return 0;
     }
+    if (std::getenv("FLAME_NLTGV2_TRACE")) std::fprintf(stderr, "[flame_nltgv2] persistent launch refused: hip error %d (%s), form %d, pv_occ %d\n", e, hipGetErrorString((hipError_t)e), form, ctx->pv_occ);
     // e.g. cooperative launch too large.  Groups already enqueued write into the other copies only: the current
     // state is intact, the steps are done on the one-launch-per-step path below.  Let those groups drain first and
     // forget what they reported (their waits expire without the missing groups): that is not a failure of a run.
