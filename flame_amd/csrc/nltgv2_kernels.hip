@@ -565,11 +565,21 @@ k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd
 //              holds: a producer cannot publish step s+2 into that parity before this patch has published s+1, i.e.
 //              consumed s.  A vertex is published to memory only if another patch reads it.
 //   step       Straight-line code: the per-role selects of the dual update are folded into signed per-lane constants
-//              (exact: IEEE negation, a*(-b) == -(a*b)), the w1/w2 halves run as packed-f32 pairs, and the ordered
-//              accumulation (cc:120-142: ascending edge id) is done by EVERY lane of the vertex from an LDS slab of
-//              `stride` contribution slots per vertex (the patch's largest degree rounded up to 4, at least 8) whose
-//              unused slots hold -0.0f (x + -0.0f == x for every x): no predication, no DPP ripple, no hand-back -- all
-//              lanes of a vertex hold bit-identical state at all times.
+//              (exact: IEEE negation, a*(-b) == -(a*b)), the w1/w2 halves run as packed-f32 pairs.  The ordered
+//              accumulation (cc:120-142: ascending edge id) comes in two forms, by the patch's layout:
+//              row-packed patches (a vertex's lanes inside one 16-lane row; the default wherever this kernel runs) --
+//              the sum runs across the lanes towards the vertex's first lane, which alone holds its state: shift j adds
+//              the contribution of lane first + j with the DPP row shift of a plain add, EXEC masks (moved in by the scalar
+//              unit, computed once per launch) say which heads a shift may still write; the other lanes take (x_bar, w_bar)
+//              of their vertex from the record its head leaves in LDS.  ~26 cycles per shift, no LDS in the hand-off path.
+//              Back-to-back patches (a vertex of more than 16 edges, or FLAME_NLTGV2_OPT_ROWPACK 0) -- EVERY lane of the
+//              vertex adds up an LDS slab of `stride` contribution slots per vertex (the patch's largest degree rounded up to
+//              4, at least 8) whose unused slots hold -0.0f (x + -0.0f == x for every x): all lanes of a vertex hold
+//              bit-identical state at all times, ~70 cycles per slot.
+//   hand-off   Between a record arriving and the next one leaving every instruction costs ~5 cycles, needed or not, and
+//              a taken branch ~16: the NaN check, the prev copies and the LDS record come after the publish, the record
+//              verification is a template flag, the wait is one statement whose common exit falls through (DESIGN.md 4,
+//              "The hand-off path").
 // Protocol (tags, two parity buffers, remote / XCD-local copies chosen from the true XCC ids, bounded waits,
 // transactional outputs) is that of k_persistent_he.
 // ------------------------------------------------------------------------------------------------
