@@ -34,8 +34,9 @@ constexpr int kTvLdsWavesPerCu = 16;   // ... with the slot constants in LDS (<=
 constexpr size_t kXbufBytesPerVertex = 8 * 16 + 4;  // exchange buffers: up to four step buffers x (remote + same-XCD copy) of
                                                     // 16-byte records (the patch-per-wave form; the others use two) + the XCC table
 constexpr int kPvPreSleep = 0;         // k_persistent_pv: x64 cycles between a step's start and its first poll
-constexpr int kPvPollGap = 3;          // k_persistent_pv polls: s_sleep 1 between rounds (beats none by 1-3 %), re-loading only the fetch
-                                       // entries still waiting (another 1-1.5 %)
+constexpr int kPvPollGap = 2;          // k_persistent_pv polls: re-loading only the fetch entries still waiting, no pause between
+                                       // rounds (with the round-2 first form of the kernel an s_sleep between rounds won by 1-3 %;
+                                       // with the shorter hand-off path of its final form no pause wins by 3-4 % at 640x480)
 constexpr int kTvWavesPerCu = 8;       // residency of k_persistent_tv (<= 256 VGPRs -> 2 waves per SIMD)
 constexpr int kDualMinWavesPerCu = 0;  // auto: exchange through the XCD's L2 when more waves than this share a CU
 // x64-cycle sleep between publishing and the first neighbour poll (measured optimum, r01 sweep: he 6 at

@@ -272,7 +272,7 @@ enum {
                                         one XCD for graphs small enough to run there, else all eight; 1..8 */
   FLAME_NLTGV2_OPT_POLL_GAP = 13,    /* patch-per-wave form: 0 (default) = built-in, 1 = no pause between the polls of a
                                         wait, 2 = one s_sleep (64 cycles); 3 / 4 = the same with the polls narrowed to the
-                                        records that have not arrived yet (4 is the built-in) */
+                                        records that have not arrived yet (3 is the built-in) */
   FLAME_NLTGV2_OPT_SHADOWS = 15,     /* patch-per-wave form, graphs of 65..2048 patches spread over the eight XCDs: 2 = patches
                                         on the higher-numbered side of an XCD border are also computed by a wave on the
                                         neighbouring XCD, whose patches then read that copy (same bits) instead of waiting for
