@@ -647,13 +647,13 @@ int place_calibrate(flame_nltgv2_ctx* ctx) {
 int place_records(flame_nltgv2_ctx* ctx, int per_xcd) {
   const size_t stride = records_capacity(ctx->L);
   int rc = ensure(ctx, ctx->place_rec_off, sizeof(int32_t) * 2 * stride);
-  if (!rc) rc = ensure(ctx, ctx->place_patch, sizeof(int32_t) * stride);
+  if (!rc) rc = ensure(ctx, ctx->place_patch, sizeof(int32_t) * stride + stride);  // [patch of a record | its class (1 byte)]
   if (rc) return rc;
-  HIPCHK(ctx, hipMemsetAsync(ctx->place_rec_off.p, 0xff, sizeof(int32_t) * 2 * stride, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(ctx->place_fill.p, 0, sizeof(int) * 2 * kPlacePages, ctx->stream));
-  LAUNCHCHK(ctx, launch_place_records(ctx->c, ctx->f, per_xcd, (const int32_t*)ctx->wg_v0.p, (const int32_t*)ctx->order_m.p,
-                                      (const int32_t*)ctx->rid_of.p, (int32_t*)ctx->place_patch.p, (const uint16_t*)ctx->place_rank.p,
-                                      kPlacePages, (int*)ctx->place_fill.p, (int32_t*)ctx->place_rec_off.p, (int)stride, ctx->stream));
+  // (records beyond the walk -- the exchange buffers are sized for the packed vertex count -- are never read through this table)
+  LAUNCHCHK(ctx, launch_place_records(ctx->c, ctx->f, per_xcd, (const int32_t*)ctx->order_m.p, (const int32_t*)ctx->rid_of.p,
+                                      (int32_t*)ctx->place_patch.p, (int8_t*)((int32_t*)ctx->place_patch.p + stride),
+                                      (const uint16_t*)ctx->place_rank.p, kPlacePages, (int*)ctx->place_fill.p,
+                                      (int32_t*)ctx->place_rec_off.p, (int)stride, ctx->stream));
   ctx->place_topo = ctx->topo, ctx->place_per_xcd = per_xcd;
   return 0;
 }
@@ -1051,6 +1051,14 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
                                         (const int32_t*)(L.wg_per_xcd ? ctx->rid_on.p : ctx->rid_of.p), (const uint8_t*)ctx->wg_vfirst.p,
                                         L.wg_per_xcd,
                                         (const int32_t*)ctx->iperm.p, ctx->stream));
+  // where the records that cross XCDs go (if the pages have been timed already; otherwise the first run does both): on
+  // the stream behind the layout kernels, nobody waits for it
+  if (L.wg_ok && ctx->place_state == 1 && ctx->opt_place && L.wg_per_xcd == 0 && L.wg_count > 2 * (ctx->prop.multiProcessorCount / 8) &&
+      (ctx->opt_xcds == 0 || ctx->opt_xcds == 8)) {
+    refresh_args(ctx);
+    rc = place_records(ctx, (L.wg_count + 7) / 8);
+    if (rc) return rc;
+  }
   ctx->pending = flame_nltgv2_ctx::PendingRun{};
   ctx->tag_next = 1;
   ctx->xbuf_form = 0;
@@ -2067,9 +2075,8 @@ int flame_nltgv2_placement_info(flame_nltgv2_ctx* ctx, int32_t* state, int32_t* 
   if (placed_records) {
     *placed_records = 0;
     if (ctx->have_graph && ctx->place_state == 1 && ctx->place_topo == ctx->topo) {
-      const size_t stride = records_capacity(ctx->L);
-      std::vector<int32_t> off(stride);
-      HIPCHK(ctx, hipMemcpyAsync(off.data(), ctx->place_rec_off.p, sizeof(int32_t) * stride, hipMemcpyDeviceToHost, ctx->stream));
+      std::vector<int32_t> off((size_t)ctx->L.V);  // (parity 0; the walk's records)
+      HIPCHK(ctx, hipMemcpyAsync(off.data(), ctx->place_rec_off.p, sizeof(int32_t) * off.size(), hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
       for (int32_t o : off) *placed_records += o >= 0;
     }

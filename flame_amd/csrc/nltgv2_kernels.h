@@ -121,9 +121,9 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
 // across XCDs a slot on a page that suits their pair of XCDs
 constexpr int kPlacePages = 96;
 int launch_place_calibrate(char* pool, int n_pages, int iters, unsigned* out, int* xcc_out, int* fail, hipStream_t s);
-int launch_place_records(const CanonArgs& c, const FusedArgs& a, int per_xcd, const int32_t* wg_v0, const int32_t* order_m,
-                         const int32_t* rid_of, int32_t* patch_of_rec, const uint16_t* ranking, int n_pages, int* fill,
-                         int32_t* rec_off, int stride, hipStream_t s);
+int launch_place_records(const CanonArgs& c, const FusedArgs& a, int per_xcd, const int32_t* order_m, const int32_t* rid_of,
+                         int32_t* patch_of_rec, int8_t* cls, const uint16_t* ranking, int n_pages, int* fill, int32_t* rec_off,
+                         int stride, hipStream_t s);
 // One upload blob -> its buffers (and clears), nltgv2_layout.hip
 constexpr uint32_t kScatterFill = 0xffffffffu;
 struct ScatterEntry {

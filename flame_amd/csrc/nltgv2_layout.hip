@@ -266,41 +266,53 @@ k_place_calibrate(char* pool, const int n_pages, const int iters, unsigned* __re
   if (dead && threadIdx.x == 0) __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Step 1, one thread per patch: which patch a record belongs to; every record starts unplaced; the page counters start at 0.
 __global__ void __launch_bounds__(256)
-k_place_patch_of_record(const int n_patches, const int32_t* __restrict__ wg_info, int32_t* __restrict__ patch_of_rec) {
+k_place_patch_of_record(const int n_patches, const int32_t* __restrict__ wg_info, int32_t* __restrict__ patch_of_rec,
+                        int32_t* __restrict__ rec_off, const int stride, int* __restrict__ fill, const int n_fill) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n_fill) fill[p] = 0;
+  if (p >= n_patches) return;
+  const int r0 = wg_info[4 * p], n = wg_info[4 * p + 2] & 0xffff;
+  for (int i = 0; i < n; ++i) patch_of_rec[r0 + i] = p, rec_off[r0 + i] = -1, rec_off[stride + r0 + i] = -1;
+}
+
+// Step 2, one thread per record (= position in the walk): its class -- 8 a + b for the first neighbour found on another XCD
+// b, -1 if every reader is on the record's own XCD a.  (Per record, not per patch: a patch's ~70 neighbour look-ups are
+// two dependent loads each; in one thread they took 170 us.)
+__global__ void __launch_bounds__(256)
+k_place_classify(const int V, const int per_xcd, const int32_t* __restrict__ order_m, const int32_t* __restrict__ rid_of,
+                 const int32_t* __restrict__ row_ptr, const uint32_t* __restrict__ half, const int32_t* __restrict__ src,
+                 const int32_t* __restrict__ dst, const int32_t* __restrict__ patch_of_rec, int8_t* __restrict__ cls) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= V) return;
+  const int o = order_m[r];
+  const int a = patch_of_rec[r] / per_xcd;
+  int c = -1;
+  for (int h = row_ptr[o]; h < row_ptr[o + 1] && c < 0; ++h) {
+    const uint32_t hh = half[h];
+    const int e = (int)(hh & ~kRole);
+    const int other = (hh & kRole) ? src[e] : dst[e];
+    const int xb = patch_of_rec[rid_of[other]] / per_xcd;
+    if (xb != a) c = a * 8 + xb;
+  }
+  cls[r] = (int8_t)c;
+}
+
+// Step 3, one thread per patch (<= 64 vertices, ~10): per parity and class a run of slots on the first page of the class's
+// ranking that has room (pages hold 256 records; the counters may overshoot, a page that refused a run simply stays a
+// little emptier).
+__global__ void __launch_bounds__(64)
+k_place_assign(const int n_patches, const int32_t* __restrict__ wg_info, const int8_t* __restrict__ cls_of_rec,
+               const uint16_t* __restrict__ ranking, const int n_pages, int* __restrict__ fill, int32_t* __restrict__ rec_off,
+               const int stride) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_patches) return;
   const int r0 = wg_info[4 * p], n = wg_info[4 * p + 2] & 0xffff;
-  for (int i = 0; i < n; ++i) patch_of_rec[r0 + i] = p;
-}
-
-// One thread per patch (<= 64 vertices, ~10): the class of each of its records -- 8 a + b for the first neighbour found on
-// another XCD b, none if every reader is on the patch's own XCD a -- then, per parity and class, a run of slots on the first
-// page of the class's ranking that has room (pages hold 256 records; the counters may overshoot, a page that refused a
-// run simply stays a little emptier).
-__global__ void __launch_bounds__(64)
-k_place_assign(const int n_patches, const int per_xcd, const int32_t* __restrict__ wg_info, const int32_t* __restrict__ wg_v0,
-               const int32_t* __restrict__ order_m, const int32_t* __restrict__ rid_of, const int32_t* __restrict__ row_ptr,
-               const uint32_t* __restrict__ half, const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
-               const int32_t* __restrict__ patch_of_rec, const uint16_t* __restrict__ ranking, const int n_pages,
-               int* __restrict__ fill, int32_t* __restrict__ rec_off, const int stride) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n_patches) return;
-  const int r0 = wg_info[4 * p], n = wg_info[4 * p + 2] & 0xffff, v0 = wg_v0[p];
-  const int a = p / per_xcd;
   signed char cls[64];
-  for (int i = 0; i < n && i < 64; ++i) {
-    const int o = order_m[v0 + i];
-    int c = -1;
-    for (int h = row_ptr[o]; h < row_ptr[o + 1] && c < 0; ++h) {
-      const uint32_t hh = half[h];
-      const int e = (int)(hh & ~kRole);
-      const int other = (hh & kRole) ? src[e] : dst[e];
-      const int xb = patch_of_rec[rid_of[other]] / per_xcd;
-      if (xb != a) c = a * 8 + xb;
-    }
-    cls[i] = (signed char)c;
-  }
+  bool any = false;
+  for (int i = 0; i < n && i < 64; ++i) cls[i] = cls_of_rec[r0 + i], any |= cls[i] >= 0;
+  if (!any) return;
   for (int par = 0; par < 2; ++par) {
     unsigned long long done = 0ull;
     for (int i = 0; i < n && i < 64; ++i) {
@@ -352,13 +364,17 @@ int launch_place_calibrate(char* pool, int n_pages, int iters, unsigned* out, in
   return (int)hipGetLastError();
 }
 
-int launch_place_records(const CanonArgs& c, const FusedArgs& a, int per_xcd, const int32_t* wg_v0, const int32_t* order_m,
-                         const int32_t* rid_of, int32_t* patch_of_rec, const uint16_t* ranking, int n_pages, int* fill,
-                         int32_t* rec_off, int stride, hipStream_t s) {
+int launch_place_records(const CanonArgs& c, const FusedArgs& a, int per_xcd, const int32_t* order_m, const int32_t* rid_of,
+                         int32_t* patch_of_rec, int8_t* cls, const uint16_t* ranking, int n_pages, int* fill, int32_t* rec_off,
+                         int stride, hipStream_t s) {
   if (a.wg_count <= 0 || per_xcd <= 0) return 0;
-  hipLaunchKernelGGL(k_place_patch_of_record, grid1d(a.wg_count), dim3(256), 0, s, a.wg_count, a.wg_info, patch_of_rec);
-  hipLaunchKernelGGL(k_place_assign, grid1d(a.wg_count, 64), dim3(64), 0, s, a.wg_count, per_xcd, a.wg_info, wg_v0, order_m, rid_of,
-                     c.row_ptr, c.half, c.src, c.dst, patch_of_rec, ranking, n_pages, fill, rec_off, stride);
+  const int n0 = a.wg_count > 2 * n_pages ? a.wg_count : 2 * n_pages;
+  hipLaunchKernelGGL(k_place_patch_of_record, grid1d(n0), dim3(256), 0, s, a.wg_count, a.wg_info, patch_of_rec, rec_off, stride, fill,
+                     2 * n_pages);
+  hipLaunchKernelGGL(k_place_classify, grid1d(c.V), dim3(256), 0, s, c.V, per_xcd, order_m, rid_of, c.row_ptr, c.half, c.src, c.dst,
+                     patch_of_rec, cls);
+  hipLaunchKernelGGL(k_place_assign, grid1d(a.wg_count, 64), dim3(64), 0, s, a.wg_count, a.wg_info, cls, ranking, n_pages, fill, rec_off,
+                     stride);
   return (int)hipGetLastError();
 }
 
