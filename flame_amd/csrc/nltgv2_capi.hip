@@ -398,7 +398,9 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
   PackedLayout& L = ctx->L;
   const int cus = ctx->prop.multiProcessorCount;
   if (L.wg_ok && ctx->pv_occ_topo != ctx->topo * 2 + (ctx->opt_verify != 0)) {  // ask the runtime once per topology (the LDS use varies with it)
-    ctx->pv_occ = pv_patches_per_cu(ctx->f, ctx->opt_verify != 0 || ctx->opt_probe != 0);
+    // (at most 12 per CU: the residency the form has been run at -- three waves per SIMD.  A 1080p graph row-packed into 6.4 k
+    //  patches passed the runtime's cooperative-launch check at 25 per CU and then sat in its first wait until it expired)
+    ctx->pv_occ = std::min(12, pv_patches_per_cu(ctx->f, ctx->opt_verify != 0 || ctx->opt_probe != 0));
     ctx->pv_occ_topo = ctx->topo * 2 + (ctx->opt_verify != 0);
   }
   const int wg_cap = ctx->pv_occ * cus;  // patch-per-wave form, in patches
