@@ -954,9 +954,10 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
       // The head (lane `first`) starts with (x + c_0, (w + a_0) + b_0) of its own half-edge; shift j = 1, 2, ... adds the
       // contribution of lane first + j, taken with a DPP row shift (the patch is row-packed: a vertex's lanes share a 16-lane
       // row).  Every lane stays enabled as a SOURCE; as a DESTINATION a head is masked out once j reaches its degree (it
-      // would pick up the next vertex's lanes), the other lanes compute values nobody reads.  The masks are compared one
-      // shift ahead (v_cmp into an SGPR pair, then a scalar move to EXEC: a VALU write of EXEC would stall the DPP adds
-      // that follow).  ~30 cycles per shift against ~70 per slot of the LDS slab (tools/ripple_bench: 264 vs 580 cycles for 8).
+      // would pick up the next vertex's lanes), the other lanes compute values nobody reads; a lane without a half-edge is
+      // disabled (a DPP read of a disabled lane leaves the destination as it is).  The masks are computed once per launch and
+      // moved to EXEC by the scalar unit (a v_cmpx per shift stalls the DPP adds behind it: +22 cycles per shift).  ~26 cycles
+      // per shift against ~70 per slot of the LDS slab (tools/ripple_bench.hip: 264 vs 580 cycles for 8 contributions).
       float W1 = (w12.x + a12.x) + b12.x, W2 = (w12.y + a12.y) + b12.y;
       X = x + cx;
 #define PV_ADDS(J)                                                                                    \
@@ -988,7 +989,6 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
                    : [cx] "v"(cx), [a1] "v"(a12.x), [a2] "v"(a12.y), [b1] "v"(b12.x), [b2] "v"(b12.y), [md] "s"(stride),
                      [m1] "s"(rm1), [m2] "s"(rm2), [m3] "s"(rm3), [m4] "s"(rm4), [m5] "s"(rm5), [m6] "s"(rm6), [m7] "s"(rm7), [m8] "s"(rm8)
                    : "scc");
-#undef PV_RS
 #undef PV_RM
 #undef PV_ADDS
       Wa = v2f_t{W1, W2};
