@@ -33,6 +33,9 @@ constexpr int kHeWavesPerCu = 24;      // residency cap of k_persistent_he (<= 6
 constexpr int kTvLdsWavesPerCu = 16;   // ... with the slot constants in LDS (<= 128 VGPRs -> 4 waves per SIMD; 10 KB LDS per wave = all 160 KB)
 constexpr size_t kXbufBytesPerVertex = 8 * 16 + 4;  // exchange buffers: up to four step buffers x (remote + same-XCD copy) of
                                                     // 16-byte records (the patch-per-wave form; the others use two) + the XCC table
+constexpr int kPvDensePerCu = 23;      // k_persistent_pv is used up to this many patches per CU (24 are resident: 6 waves per SIMD)
+constexpr int kPvPaceAbovePerCu = 17;  // ... and above this many its polls are paced (kPvDensePreSleep, kPvDenseGap)
+constexpr int kPvDensePreSleep = 8, kPvDenseGap = 4;  // x64 cycles before the first poll of a step / between poll rounds
 constexpr int kPvPreSleep = 0;         // k_persistent_pv: x64 cycles between a step's start and its first poll
 constexpr int kPvPollGap = 2;          // k_persistent_pv polls: re-loading only the fetch entries still waiting, no pause between
                                        // rounds (with the round-2 first form of the kernel an s_sleep between rounds won by 1-3 %;
@@ -42,6 +45,7 @@ constexpr int kDualMinWavesPerCu = 0;  // auto: exchange through the XCD's L2 wh
 // x64-cycle sleep between publishing and the first neighbour poll (measured optimum, r01 sweep: he 6 at
 // <= 12 waves/CU, 10 above; tv is insensitive, shortest wins)
 constexpr int kPreSleepHe = 6, kPreSleepHeDense = 10, kPreSleepHeOneXcd = 4, kPreSleepTv = 2;
+constexpr size_t kErrBytes = 16 * sizeof(int);  // the flag word + what the first expired wait reports (report_expired)
 constexpr unsigned kMaxSpins = 1u << 20;  // bound of every neighbour wait in the persistent run (~1 s of polling bursts)
 
 struct DevBuf {
@@ -213,11 +217,12 @@ struct flame_nltgv2_ctx {
   std::vector<float> h_terms;
   DevBuf hq_alt, vstate_alt;  // the other copies of hq / vstate: a persistent run writes there, success swaps the roles
   DevBuf xbuf, abort_flag, he_slot, he_vid, he_meta, he_wave_chain, tv_slot, tv_vid, tv_meta, tv_wave;
-  DevBuf wg_slot, wg_vid, wg_meta, wg_nbr, wg_fetch, wg_info, wg_v0, rid_on, wg_vfirst, probe;
+  DevBuf wg_slot, wg_vid, wg_meta, wg_nbr, wg_fetch, wg_info, wg_v0, rid_on, wg_vfirst, probe, progress;
   // misc
   DevBuf err, cost_out, img_ref, img_cmp, photo_err, r_tris, r_valid, r_keys, r_img, r_cov, r_vtx, r_val;
   int img_rows = 0, img_cols = 0, img_step = 0;
-  int* h_err = nullptr;    // pinned
+  int* h_err = nullptr;    // pinned, kErrBytes
+  int last_expired[16] = {0};  // what the most recent expired wait reported (report_expired)
   float* h_cost = nullptr; // pinned
   std::vector<CachedGraph> graphs;
   size_t device_bytes = 0;
@@ -397,11 +402,17 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
   if (ctx->persist_refused_topo == ctx->topo) return 0;
   PackedLayout& L = ctx->L;
   const int cus = ctx->prop.multiProcessorCount;
-  if (L.wg_ok && ctx->pv_occ_topo != ctx->topo * 2 + (ctx->opt_verify != 0)) {  // ask the runtime once per topology (the LDS use varies with it)
-    // (at most 12 per CU: the residency the form has been run at -- three waves per SIMD.  A 1080p graph row-packed into 6.4 k
-    //  patches passed the runtime's cooperative-launch check at 25 per CU and then sat in its first wait until it expired)
-    ctx->pv_occ = std::min(12, pv_patches_per_cu(ctx->f, ctx->opt_verify != 0 || ctx->opt_probe != 0));
-    ctx->pv_occ_topo = ctx->topo * 2 + (ctx->opt_verify != 0);
+  // ask once per (topology, kernel instance): the LDS use varies with the layout, the registers with the instance
+  const uint64_t occ_key = ctx->topo * 4 + (ctx->opt_verify != 0 ? 1 : 0) + (ctx->opt_probe != 0 ? 2 : 0);
+  if (L.wg_ok && ctx->pv_occ_topo != occ_key) {
+    // The REAL residency (pv_patches_per_cu: the runtime's query over-reports, tools/residency_probe.hip), and of that at most
+    // kPvDensePerCu: beyond it the lane-per-half-edge / vertex-per-lane forms are as fast or faster (tools/pv_big.py,
+    // profiles/r03_pv_dense.txt: the hand-off itself gets slower with the number of polling waves)
+    ctx->pv_occ = std::min(kPvDensePerCu, pv_patches_per_cu(ctx->f, ctx->opt_verify != 0 || ctx->opt_probe != 0));
+    if (std::getenv("FLAME_NLTGV2_TRACE"))
+      std::fprintf(stderr, "[flame_nltgv2] pv: %d patches, row-packed %d, slab slots %d, local records %d -> %d resident per CU\n", L.wg_count,
+                   (int)L.wg_rowpack, ctx->f.wg_slab_slots, ctx->f.wg_lcap, ctx->pv_occ);
+    ctx->pv_occ_topo = occ_key;
   }
   const int wg_cap = ctx->pv_occ * cus;  // patch-per-wave form, in patches
   const int he_cap = kHeWavesPerCu * cus;
@@ -708,13 +719,21 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
     // a fresh first tag per run: records left by earlier runs (whose state may since have been changed
     // by per-step launches or host uploads) can never satisfy a wait of this one
     const uint32_t tag0 = ctx->tag_next + 2;
-    const uint64_t key = ctx->topo * 8 + (uint64_t)form * 2 + (uint64_t)tv_lds;
+    // (topology, form, kernel instance): a new instance -- other registers, other LDS -- gets a cooperative first launch
+    const uint64_t key = ctx->topo * 256 + (uint64_t)form * 64 + (uint64_t)tv_lds * 32 + (ctx->opt_verify != 0 ? 16 : 0) + (ctx->opt_probe != 0 ? 8 : 0) +
+                         (ctx->opt_dual == 2 ? 4 : ctx->opt_dual == 1 ? 2 : 0) + (ctx->opt_xcds > 0 ? 1 : 0);
     {  // standing outputs: (re)send the small block the kernels read in their epilogue when it changed
       RunTail want;
       std::memset(static_cast<void*>(&want), 0, sizeof want);
       want.export_out = ctx->export_ptr, want.export_scale = ctx->export_scale;
       const PhotoFuse pf = photo_target(ctx);
       std::memcpy(static_cast<void*>(&want.photo), &pf, sizeof pf);
+      if (form == 3 && std::getenv("FLAME_NLTGV2_TRACE")) {
+        rc = ensure(ctx, ctx->progress, 2 * sizeof(unsigned) * (size_t)ctx->L.wg_count);  // [how far | started when]
+        if (rc) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->progress.p, 0, 2 * sizeof(unsigned) * (size_t)ctx->L.wg_count, ctx->stream));
+        want.progress = (unsigned*)ctx->progress.p;
+      }
       rc = ensure(ctx, ctx->run_tail, sizeof(RunTail));
       if (rc) return rc;
       if (!ctx->tail_valid || std::memcmp(&want, &ctx->tail_sent, sizeof(RunTail)) != 0) {
@@ -746,8 +765,14 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
                                                                             : kPreSleepHe;
       const unsigned spins_arg = ctx->opt_fault > 0 ? (0x80000000u | (unsigned)ctx->opt_fault) : kMaxSpins;
       if (form == 3) {
-        ctx->f.wg_poll_gap = (ctx->opt_poll_gap > 0 ? ctx->opt_poll_gap - 1 : kPvPollGap) |
-                             ((ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : kPvPreSleep) << 8) |
+        // pacing: none where a CU holds few patches (a poll costs nothing there and a pause only delays the hand-off); at
+        // high residency the polls of ~20 waves per CU saturate the L2s' request ports and the fabric and it is the hand-off
+        // itself that slows down (probe: 0.72 us at 4 patches per CU, 1.03 at 15; 26 per CU unpaced: 50 us per step) -- a
+        // pause before the first poll and between rounds then wins (tools/pv_big.py sweeps, profiles/r03_pv_dense.txt)
+        const bool dense = gr.count > kPvPaceAbovePerCu * ctx->prop.multiProcessorCount;
+        const int gap = ctx->opt_poll_gap > 0 ? ctx->opt_poll_gap - 1 : dense ? (3 | ((kPvDenseGap - 1) << 4)) : kPvPollGap;
+        ctx->f.wg_poll_gap = gap |
+                             ((ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : dense ? kPvDensePreSleep : kPvPreSleep) << 8) |
                              ((ctx->L.wg_per_xcd > 0) ? (1 << 30) : 0);
         ctx->f.rec_off = nullptr, ctx->f.place_pool = nullptr;
         if (ctx->opt_place && ctx->L.wg_per_xcd == 0 && groups.size() == 1 && gr.begin == 0 && xcds == 8 && (dual & 1)) {
@@ -815,7 +840,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
     if (groups.size() > 1 && !ctx->pending.active) {
       HIPCHK(ctx, hipMemsetAsync(ctx->abort_flag.p, 0xff, sizeof(int), ctx->stream));  // tells them to leave at once
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-      HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, sizeof(int), ctx->stream));
+      HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, kErrBytes, ctx->stream));
       HIPCHK(ctx, hipMemsetAsync(ctx->abort_flag.p, 0, sizeof(int), ctx->stream));
     }
   }
@@ -847,13 +872,55 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   return enqueue_photo_sweep(ctx, true);
 }
 
+// FLAME_NLTGV2_TRACE: which wait of the persistent run expired first, and how far every patch had got
+void trace_expired_wait(flame_nltgv2_ctx* ctx) {
+  const int* e = ctx->h_err;
+  static const char* const kWhich[] = {"?", "rotation word", "XCC table", "step records"};
+  std::fprintf(stderr, "[flame_nltgv2] persistent run taken back (flags %d): first expired wait = %s, patch %d, step %d, lanes waiting %08x%08x, "
+               "first of them for record %d (tag seen %u, wanted %u), on XCC %d hw_id %08x\n", e[0], kWhich[e[1] & 3], e[2], e[3], (unsigned)e[5],
+               (unsigned)e[4], e[6], (unsigned)e[7], (unsigned)e[8], e[9], (unsigned)e[10]);
+  if (!ctx->progress.p || ctx->L.wg_count <= 0) return;
+  std::vector<unsigned> pg((size_t)2 * ctx->L.wg_count);
+  if (hipMemcpy(pg.data(), ctx->progress.p, sizeof(unsigned) * pg.size(), hipMemcpyDeviceToHost) != hipSuccess) return;
+  size_t silent = 0, left = 0;
+  unsigned lo = ~0u, hi = 0;
+  int first_silent = -1;
+  const size_t n_p = (size_t)ctx->L.wg_count;
+  {  // when the patches started: all within microseconds of each other if they were co-resident
+    unsigned t_lo = ~0u, t_hi = 0;
+    size_t started = 0, late = 0;
+    for (size_t i = 0; i < n_p; ++i)
+      if (pg[n_p + i]) ++started, t_lo = std::min(t_lo, pg[n_p + i]), t_hi = std::max(t_hi, pg[n_p + i]);
+    int first_late = -1;
+    for (size_t i = 0; i < n_p; ++i)
+      if (pg[n_p + i] && pg[n_p + i] - t_lo > 10000u) {
+        if (first_late < 0) first_late = (int)i;
+        ++late;
+      }
+    std::fprintf(stderr, "[flame_nltgv2]   %zu of %zu patches started, over %u us; %zu of them more than 10 ms after the first (first such patch: %d)\n",
+                 started, n_p, started ? t_hi - t_lo : 0u, late, first_late);
+  }
+  for (size_t i = 0; i < n_p; ++i) {
+    if (pg[i] == 0) {
+      if (first_silent < 0) first_silent = (int)i;
+      ++silent;
+    } else {
+      ++left, lo = std::min(lo, pg[i] & 0x7fffffffu), hi = std::max(hi, pg[i] & 0x7fffffffu);
+    }
+  }
+  std::fprintf(stderr, "[flame_nltgv2]   %zu patches left through an expired wait (in steps %u..%u), %zu wrote nothing (finished, or never ran; first: %d)\n",
+               left, left ? lo - 1 : 0, left ? hi - 1 : 0, silent, first_silent);
+}
+
 int finish(flame_nltgv2_ctx* ctx) {
-  HIPCHK(ctx, hipMemcpyAsync(ctx->h_err, ctx->err.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_err, ctx->err.p, kErrBytes, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   flame_nltgv2_ctx::PendingRun run;
   std::swap(run, ctx->pending);  // (ctx->pending is now inactive and empty)
   if (*ctx->h_err & 6) {
     if (*ctx->h_err & 4) ctx->torn_records_detected++;  // the record verification found a second read that differed
+    std::memcpy(ctx->last_expired, ctx->h_err, kErrBytes);
+    if (std::getenv("FLAME_NLTGV2_TRACE")) trace_expired_wait(ctx);
     // A neighbour wait of a persistent run expired (its waves were not all resident: the GPU is shared with
     // something that keeps CUs full).  Go back to the state the run -- or the chain of runs enqueued behind it --
     // started from, and do the same steps on the one-launch-per-step path, which needs no co-residency.
@@ -878,7 +945,7 @@ int finish(flame_nltgv2_ctx* ctx) {
     ctx->fused_valid = true, ctx->canon_valid = false;
     ctx->persist_refused_topo = ctx->topo;
     if (!(*ctx->h_err & 4)) ctx->timeouts_recovered++;
-    HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, sizeof(int), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, kErrBytes, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->abort_flag.p, 0, sizeof(int), ctx->stream));
     for (const flame_nltgv2_ctx::PendingOp& op : run.ops) {
       if (op.kind == 0) {
@@ -893,7 +960,7 @@ int finish(flame_nltgv2_ctx* ctx) {
   if (*ctx->h_err != 0) {
     // NaN/Inf in a dual variable (the reference's FLAME_ASSERT h:174): reported once; the state stays readable
     // (download_state, costs) and the solve can go on or be re-initialised -- q was clamped to +-1 where it happened
-    HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, sizeof(int), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, kErrBytes, ctx->stream));
     return fail(ctx, FLAME_NLTGV2_ERR_NAN);
   }
   return 0;
@@ -990,8 +1057,16 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
   const int32_t V = g->V, E = g->E;
   const int sm = shadow_mode(ctx, long_lived);
   int rc = build_layout(g, &ctx->L, /*host_expand=*/false, sm, shadow_cap(ctx), /*rowpack=*/ctx->opt_rowpack != 0,
-                        /*rowpack_max_patches=*/10 * ctx->prop.multiProcessorCount);
+                        /*rowpack_max_patches=*/kPvDensePerCu * ctx->prop.multiProcessorCount);
   if (rc) return fail(ctx, rc);
+  // Row packing costs ~15 % more waves than lanes back to back.  It pays where the patch-per-wave kernel runs them; a layout
+  // that turns out too large for that kernel (more patches than the estimate, or a vertex of more than 16 edges, whose
+  // instance of the kernel keeps 12 patches per CU) is better off back to back, for the lane-per-half-edge form.
+  if (ctx->L.wg_ok && ctx->L.wg_rowpack &&
+      ctx->L.wg_count > (ctx->L.wg_slab_slots > 0 ? 4 * pv_real_waves_per_simd(2, false) : kPvDensePerCu) * ctx->prop.multiProcessorCount) {
+    rc = build_layout(g, &ctx->L, /*host_expand=*/false, sm, shadow_cap(ctx), /*rowpack=*/false, 0);
+    if (rc) return fail(ctx, rc);
+  }
   const PackedLayout& L = ctx->L;
   const size_t n_slots = (size_t)(L.rows + kRowPad) * kWave;
   if (n_slots > (size_t)0x7fffffff) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
@@ -1010,7 +1085,7 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
       {&ctx->bar0, sizeof(float4) * n_packed}, {&ctx->bar1, sizeof(float4) * n_packed},
       {&ctx->vprev, sizeof(float4) * n_packed}, {&ctx->xbuf, kXbufBytesPerVertex * records_capacity(L) + 64},
       {&ctx->wg_v0, sizeof(int32_t) * L.wg_v0.size()}, {&ctx->rid_on, sizeof(int32_t) * L.rid_on.size()},
-      {&ctx->wg_vfirst, L.wg_vfirst.size() + 16}, {&ctx->abort_flag, sizeof(int)}, {&ctx->err, sizeof(int)}, {&ctx->cost_out, 2 * sizeof(float)},
+      {&ctx->wg_vfirst, L.wg_vfirst.size() + 16}, {&ctx->abort_flag, sizeof(int)}, {&ctx->err, kErrBytes}, {&ctx->cost_out, 2 * sizeof(float)},
       {&ctx->wg_slot, sizeof(int32_t) * lanes}, {&ctx->wg_vid, sizeof(int32_t) * lanes}, {&ctx->wg_meta, sizeof(uint32_t) * lanes},
       {&ctx->wg_nbr, sizeof(int32_t) * lanes}, {&ctx->wg_fetch, sizeof(int32_t) * lanes},
       {&ctx->wg_info, sizeof(int32_t) * L.wg_info.size()}};
@@ -1034,7 +1109,7 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
       {&ctx->wg_vfirst, L.wg_vfirst.data(), L.wg_vfirst.size()}};
   cp.insert(cp.end(), extra, extra + n_extra);
   std::vector<StageFill> fills = {
-      {ctx->err.p, sizeof(int), 0u}, {ctx->abort_flag.p, sizeof(int), 0u}, {ctx->xbuf.p, kXbufBytesPerVertex * records_capacity(L) + 64, 0u},
+      {ctx->err.p, kErrBytes, 0u}, {ctx->abort_flag.p, sizeof(int), 0u}, {ctx->xbuf.p, kXbufBytesPerVertex * records_capacity(L) + 64, 0u},
       // empty slots / padding vertices of the second copies: zero, as the packing kernels write them in the first
       {ctx->hq_alt.p, sizeof(float4) * n_slots, 0u}, {ctx->vstate_alt.p, sizeof(float4) * n_packed, 0u},
       // the spare rows behind the last slice: no edge, neighbour 0 (what the unrolled sweeps may read past a slice's end)
@@ -1170,7 +1245,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
   ok = ok && hipGetDeviceProperties(&ctx->prop, device) == hipSuccess;
   ok = ok && hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess;
-  ok = ok && hipHostMalloc((void**)&ctx->h_err, sizeof(int), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&ctx->h_err, kErrBytes, hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->h_cost, 2 * sizeof(float), hipHostMallocDefault) == hipSuccess;
   if (!ok) {
     flame_nltgv2_destroy(ctx);
@@ -1187,7 +1262,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
               &ctx->r_img, &ctx->r_cov, &ctx->r_vtx, &ctx->r_val, &ctx->wg_slot, &ctx->wg_vid, &ctx->wg_meta, &ctx->wg_nbr,
               &ctx->wg_fetch, &ctx->wg_info, &ctx->wg_v0, &ctx->rid_on, &ctx->probe, &ctx->snap_hq, &ctx->snap_vstate, &ctx->snap_bar, &ctx->iperm,
               &ctx->order_m, &ctx->rid_of, &ctx->d_stage, &ctx->sync_init, &ctx->sync_vmap, &ctx->sync_emap, &ctx->sync_need,
-              &ctx->wg_vfirst, &ctx->place_pool, &ctx->place_rank, &ctx->place_fill, &ctx->place_rec_off, &ctx->place_patch, &ctx->place_meas};
+              &ctx->wg_vfirst, &ctx->place_pool, &ctx->place_rank, &ctx->place_fill, &ctx->place_rec_off, &ctx->place_patch, &ctx->place_meas, &ctx->progress};
   for (auto& b : ctx->sp_v) ctx->all.push_back(&b);
   for (auto& b : ctx->sp_q) ctx->all.push_back(&b);
   *out = ctx;
@@ -1276,7 +1351,7 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
       ctx->coop_checked_key = ~0ull;
       return 0;
     case FLAME_NLTGV2_OPT_PRESLEEP:
-      if (value < 0 || value > 64) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      if (value < 0 || value > 256) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_presleep = value;
       return 0;
     case FLAME_NLTGV2_OPT_TV_LDS:
@@ -1631,7 +1706,7 @@ int flame_nltgv2_upload_state(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* s
     rc = h2d(ctx, *c.b, c.src, c.bytes);
     if (rc) return rc;
   }
-  HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, sizeof(int), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, kErrBytes, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->fused_valid = false;
   ctx->last_error = 0;

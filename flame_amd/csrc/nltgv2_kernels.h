@@ -35,6 +35,7 @@ struct RunTail {
   float export_scale = 1.0f;
   int reserved_ = 0;
   PhotoFuse photo;              // flame_nltgv2_photo_fuse (photo.err == nullptr: off)
+  unsigned* progress = nullptr; // FLAME_NLTGV2_TRACE: where a patch that leaves a run through an expired wait says how far it got
 };
 
 // Everything EpipolarGeometry::project(u, idepth, &u_new, &idepth_new) reads (stereo/epipolar_geometry.h:152-180)
@@ -161,6 +162,7 @@ struct SyncArgs {
 };
 int launch_sync_state(const SyncArgs& a, hipStream_t s);
 int pv_patches_per_cu(const FusedArgs& a, bool verify);
+int pv_real_waves_per_simd(int layout, bool verify_or_probe);
 // device-side expansion of the layout arrays (nltgv2_layout.hip)
 int launch_build_sell(const CanonArgs& c, const FusedArgs& a, const int32_t* iperm, hipStream_t s);
 int launch_he_from_patches(const FusedArgs& a, int32_t* he_slot, int32_t* he_vid, uint32_t* he_meta, int32_t* he_wave_chain,

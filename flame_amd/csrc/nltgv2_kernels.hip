@@ -596,6 +596,17 @@ __device__ __forceinline__ unsigned read_hw_id() {
   return v;
 }
 
+// Which wait of a persistent run expired, for the host's trace (FLAME_NLTGV2_TRACE) and flame_nltgv2_info: the first wave
+// to give up leaves {which wait, patch, step, lanes still waiting, the foreign record of the first of them, tag seen / wanted,
+// XCC and HW ids} in err[1..10] (err[0] stays the flag word).  which: 1 rotation word, 2 XCC table, 3 a step's records.
+__device__ __forceinline__ void report_expired(int* err, int which, int wg, int it, unsigned long long pend, int frid, unsigned seen,
+                                               unsigned want) {
+  if (atomicCAS(&err[1], 0, which) == 0) {
+    err[2] = wg, err[3] = it, err[4] = (int)(unsigned)pend, err[5] = (int)(unsigned)(pend >> 32), err[6] = frid;
+    err[7] = (int)seen, err[8] = (int)want, err[9] = (int)read_xcc_id(), err[10] = (int)read_hw_id();
+  }
+}
+
 // LAYOUT: 0 = every patch back to back, LDS-slab accumulation; 1 = every patch row-packed, DPP accumulation; 2 = row-packed
 // with back-to-back patches among them (where a vertex has more than 16 edges): both schemes compiled in, chosen per patch --
 // a separate instance because carrying the slab code costs the all-row-packed case 3-5 % (registers, code layout; measured)
@@ -635,6 +646,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
         if (lane == 0) {
           __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           atomicOr(err, 2);
+          report_expired(err, 1, (int)blockIdx.x, -1, 0ull, -1, v, want);
         }
         return;
       }
@@ -650,6 +662,9 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   const int rid_base = wg_info[4 * wg], n_fetch = wg_info[4 * wg + 1];
   const int count_flags = wg_info[4 * wg + 2];
   if ((count_flags & 0xffff) == 0) return;                 // idle padding behind an XCD's instances (shadow layouts)
+  if (unsigned* const pg = tail->progress) {               // (trace runs only) when this patch started, in us of the 100 MHz clock
+    if (lane == 0) pg[n_wgs + (wg - wg_begin)] = (unsigned)(wall_clock64() / 100u) | 1u;
+  }
   // RIPPLE layouts: a patch that holds a vertex of more than 16 edges is laid out back to back and accumulates through the
   // LDS slab like the other kernel variant does for every patch (wave-uniform)
   constexpr bool RIPPLE = LAYOUT != 0;
@@ -781,6 +796,11 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
         if (!__any(pend)) break;
         if (++spins > max_spins) {
           timed_out = true;
+          const unsigned long long pm = __ballot(pend);
+          const int fl = __ffsll((long long)pm) - 1;
+          const int ff = __shfl(frid, fl, 64);
+          const unsigned gs = (unsigned)__shfl((int)g0, fl, 64);
+          if (lane == 0) report_expired(err, 2, wg, -1, pm, ff, gs, xcc_want);
           break;
         }
         __builtin_amdgcn_s_sleep(2);
@@ -852,10 +872,11 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
       // unless the launch asks for the un-narrowed poll), an optional s_sleep, then every lane's neighbour record from LDS;
       // vcc = lanes still waiting.  One statement for all pacing variants (two scalar flags), and the common exit falls
       // straight through into the step: the instructions after the last record's arrival are the ones that count.
-      unsigned cnt, keep, pend_lo, tagv, tagf;
+      unsigned cnt, keep, pend_lo, tagv, tagf, gapk;
       unsigned long long pnarrow;
       const unsigned own_slot = dst + 16u * (unsigned)lane;
-      const unsigned f_sleep = (unsigned)(poll_gap & 1), f_narrow = (unsigned)(poll_gap >> 1);
+      // (pacing: bit 0 = pause between rounds, bits 4..7 = its length - 1 in s_sleep 1 units, bit 1 = narrowed re-loads)
+      const unsigned f_sleep = (poll_gap & 1) ? 1u + (((unsigned)poll_gap >> 4) & 15u) : 0u, f_narrow = (unsigned)((poll_gap >> 1) & 1);
 #define PV_POLL_U                                                                                         \
   asm volatile("s_mov_b32 %[keep], m0\n\t"                                                              \
                "s_mov_b32 m0, %[dst]\n\t"                                                               \
@@ -865,9 +886,13 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
                "s_mov_b64 exec, %[pn]\n\t"                                                              \
                "global_load_lds_dwordx4 %[src], off sc1\n\t"                                            \
                "s_mov_b64 exec, -1\n\t"                                                                 \
-               "s_cmp_eq_u32 %[fs], 0\n\t"                                                              \
+               "s_mov_b32 %[k], %[fs]\n\t"                                                             \
+               "4:\n\t"                                                                                 \
+               "s_cmp_eq_u32 %[k], 0\n\t"                                                               \
                "s_cbranch_scc1 3f\n\t"                                                                  \
                "s_sleep 1\n\t"                                                                          \
+               "s_sub_u32 %[k], %[k], 1\n\t"                                                            \
+               "s_branch 4b\n\t"                                                                        \
                "3:\n\t"                                                                                 \
                "ds_read_b32 %[t], %[ra] offset:12\n\t"                                                  \
                "ds_read_b32 %[t2], %[fa] offset:12\n\t"                                                 \
@@ -887,7 +912,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
                "s_or_b32 %[pl], %[pl], vcc_hi\n\t"                                                      \
                "s_mov_b32 m0, %[keep]"                                                                   \
                : [keep] "=&s"(keep), [cnt] "=&s"(cnt), [pl] "=&s"(pend_lo), [nb] "=&v"(nbv), [t] "=&v"(tagv), \
-                 [t2] "=&v"(tagf), [pn] "=&s"(pnarrow)                                                     \
+                 [t2] "=&v"(tagf), [pn] "=&s"(pnarrow), [k] "=&s"(gapk)                                     \
                : [src] "v"(src), [dst] "s"(dst), [ra] "v"(rd_nbr), [fa] "v"(own_slot), [tag] "s"(s), [fm] "s"(fetch_mask), \
                  [fs] "s"(f_sleep), [fn] "s"(f_narrow)                                                     \
                : "vcc", "scc", "memory")
@@ -898,6 +923,14 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
           const int ab = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (ab != 0 || ++outer > (max_spins >> 4)) {
             timed_out = true;
+            if (ab == 0) {  // (the first to give up: the others leave through the abort flag)
+              const unsigned long long pm = __ballot(tagv != s);
+              const int fl = __ffsll((long long)pm) - 1;
+              const int ni = __shfl(nbr_idx, fl, 64);
+              const int ff = ni >= lcap ? __shfl(frid, ni - lcap, 64) : -2 - ni;  // foreign record id, or -2 - (local index)
+              const unsigned gs = (unsigned)__shfl((int)tagv, fl, 64);
+              if (lane == 0) report_expired(err, 3, wg, it, pm, ff, gs, s);
+            }
             break;
           }
           PV_POLL_U;
@@ -1096,6 +1129,8 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
     if (lane == 0) {
       __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       atomicOr(err, torn ? 4 : 2);
+      unsigned* const pg = tail->progress;  // (trace runs only) the step this patch was in when it left
+      if (pg) pg[wg - wg_begin] = 0x80000000u | (unsigned)(it + 1);
     }
     return;
   }
@@ -1810,18 +1845,37 @@ int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, boo
   return (int)hipGetLastError();
 }
 
-// Patches of k_persistent_pv (one wave each) the runtime keeps resident per CU for this layout's LDS use.
+// Patches of k_persistent_pv (one wave each) that are REALLY co-resident per CU for this layout.
+//
+// The runtime's occupancy query (and with it the cooperative-launch check) over-reports on this part: the hardware adds 16
+// scalar registers to every wave's allocation for the trap handler, which neither hipOccupancyMaxActiveBlocksPerMultiprocessor
+// nor the compiler's "Occupancy [waves/SIMD]" remark knows about.  Measured with tools/residency_probe.hip (profiles/
+// r03_residency.txt: 64-thread blocks, 3.8 KB of LDS, <= 72 VGPRs): a kernel of 27 SGPRs keeps 32 waves per CU, one of 86-94
+// keeps 28 where the query says 32, one of 102-106 keeps 24 where it says 28.  That is round 2's open question: the row-packed
+// instance of this kernel (65 VGPRs, 106 SGPRs) passed the cooperative check at 25-28 patches per CU, 24 became resident, and
+// the others only started when the first expired waits freed their slots.  So: waves per SIMD = min(512 / VGPRs rounded up to 8,
+// 800 / (SGPRs rounded up to 16, + 16), 8), from the register counts of the instances as built (tests/test_abi.py re-derives them
+// from the compiler's resource report and fails when an instance outgrows its row here); the runtime's answer still bounds it
+// from above (it knows the LDS use, which varies with the layout).
+int pv_real_waves_per_simd(int layout, bool verify_or_probe) {
+  // {VGPRs, SGPRs} -> waves: LAYOUT 1 plain {65, 106} -> min(7, 6); verify / probe {75, 106} -> min(6, 6);
+  // LAYOUT 0 / 2 (slab code compiled in) {156-165, 106} -> 3
+  (void)verify_or_probe;
+  return layout == 1 ? 6 : 3;
+}
+
 int pv_patches_per_cu(const FusedArgs& a, bool verify) {
   const size_t ldsv = 16u * (size_t)(2 * (a.wg_lcap + 64) + a.wg_slab_slots + 64) + 4u * (size_t)(a.wg_slab_slots + 64);
   int n = 0;
-  const void* fv = !a.wg_rowpack ? (verify ? (const void*)k_persistent_pv<false, 0, true> : (const void*)k_persistent_pv<false, 0, false>)
-                   : a.wg_slab_slots > 0 ? (verify ? (const void*)k_persistent_pv<false, 2, true> : (const void*)k_persistent_pv<false, 2, false>)
-                                         : (verify ? (const void*)k_persistent_pv<false, 1, true> : (const void*)k_persistent_pv<false, 1, false>);
+  const int layout = !a.wg_rowpack ? 0 : a.wg_slab_slots > 0 ? 2 : 1;
+  const void* fv = layout == 0 ? (verify ? (const void*)k_persistent_pv<false, 0, true> : (const void*)k_persistent_pv<false, 0, false>)
+                   : layout == 2 ? (verify ? (const void*)k_persistent_pv<false, 2, true> : (const void*)k_persistent_pv<false, 2, false>)
+                                 : (verify ? (const void*)k_persistent_pv<false, 1, true> : (const void*)k_persistent_pv<false, 1, false>);
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fv, 64, ldsv) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
-  return n;
+  return n < 4 * pv_real_waves_per_simd(layout, verify) ? n : 4 * pv_real_waves_per_simd(layout, verify);
 }
 
 // Persistent run (single launch).  form 1 = lane per half-edge (k_persistent_he), form 2 = vertex per
