@@ -136,12 +136,19 @@ def main():
 
         def after_step():
             with torch.cuda.stream(solver_stream):
-                ig.gather(async_op=True)  # overlaps the next step's solve; completed before the buffer is reused
+                # overlaps the next step's solve; completed before the buffer is reused.  (The gather reads the row of a run
+                # nobody has checked yet: a consumer of the gathered block calls ig.settle([reg]) first, which re-gathers if the
+                # run had to be taken back and redone -- done once below, after the timed region.)
+                ig.gather(async_op=True, regs=[reg])
 
     wall, ev_ms = measure(reg, params, a.iters, a.steps, a.warmup, sync, barrier, solver_stream, before_step, after_step)
     gather_us = None
+    gather_ok = None
     if dist is not None:
-        ig.wait()
+        regathered = ig.settle([reg])
+        # the last gathered block against this rank's own state: row `rank` must be x * 1.0 of the timed context
+        mine = ig.frame(rank).cpu().numpy()
+        gather_ok = bool(np.array_equal(mine, reg.download_state(("x",))["x"]))
         # latency of the result gather on its own (configs[3]: "RCCL gather over xGMI"), outside the timed region
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -201,6 +208,10 @@ def main():
                 roofline["step_cycles"] = pv_step_cycles(flame_amd, g, params, a.iters, local_rank)
             except Exception as e:  # noqa: BLE001
                 roofline["step_cycles"] = f"{type(e).__name__}: {e}"
+            try:  # what `frac` has to be read against: the physical floor of one iteration of ONE small frame, measured by this run
+                roofline["floor"] = latency_floor(flame_amd, synth, params, a.iters, local_rank, B_iter, roofline)
+            except Exception as e:  # noqa: BLE001
+                roofline["floor"] = f"{type(e).__name__}: {e}"
         out = {
             "metric": "NLTGV2 primal-dual iters/sec on 640x480 Delaunay graph; depth RMS vs CPU",
             "value": round(value, 1), "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -215,6 +226,7 @@ def main():
         }
         if gather_us is not None:
             out["result_gather"] = {"all_gather_us": round(gather_us, 1), "bytes_per_rank": int(g["V"]) * 4, "ranks": world,
+                                    "last_row_matches_state": gather_ok, "regathered_after_replay": int(regathered),
                                     "note": "blocking all_gather_into_tensor of x*graph_scale incl. host launch + sync; in the "
                                             "step loop it is asynchronous and overlaps the next solve"}
         # ---- parity of THIS run's input against the CPU checker (same seeded input, same iteration count)
@@ -231,6 +243,23 @@ def main():
         out["parity"] = {"depth_rms_vs_cpu": float(np.sqrt(np.mean(d * d))), "max_abs": float(np.abs(d).max()),
                          "bit_identical": bool(all(np.array_equal(got[k], ref[k]) for k in got)),
                          "iters": a.iters, "tolerance_rms": 1e-4}
+        # ... and the TIMED context itself: `reg` has by now done (warmup + steps) x iters iterations from the uploaded input
+        # on the solver's stream (the launches `value` was measured on); its whole state must be what the checker has after as many
+        total_run = (a.warmup + a.steps) * a.iters
+        state_keys = ("x", "w1", "w2", "x_bar", "w1_bar", "w2_bar", "q1", "q2", "q3")
+        timed_state = reg.download_state(state_keys)
+        ref_t = synth.copy_graph(g)
+        t_chk = time.perf_counter()
+        threads = min(16, os.cpu_count() or 1)
+        if threads >= 4:   # the OpenMP two-phase form of the checker: bit-identical to the sequential one for any thread count
+            oracle.omp_run(ref_t, total_run, threads)
+        else:
+            oracle.run(ref_t, total_run)
+        dt = timed_state["x"].astype(np.float64) - ref_t["x"].astype(np.float64)
+        out["parity"]["timed_context_bit_identical"] = bool(all(np.array_equal(timed_state[k], ref_t[k]) for k in state_keys))
+        out["parity"]["timed_context"] = {"iters": total_run, "depth_rms_vs_cpu": float(np.sqrt(np.mean(dt * dt))),
+                                          "arrays_compared": list(state_keys), "checker_s": round(time.perf_counter() - t_chk, 2),
+                                          "timeouts_recovered": int(reg.info()["timeouts_recovered"])}
         # ---- CPU baseline on this box's host cores: reference-layout restatement, 1 thread (the
         # reference runs its solver on exactly one thread, flame.cc:99-112)
         if not a.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N=1 only
@@ -304,6 +333,61 @@ def pv_step_cycles(flame_amd, g, params, iters, device):
             "note": "cycles per step with the probe compiled in (+3-5 %); the lock-step network runs at the pace of its least-slack patches: period = their compute + their wait (one hand-off)"}
 
 
+def latency_floor(flame_amd, synth, params, iters, device, B_iter, roofline):
+    """The floor under one iteration of one small frame, measured by this run.  An iteration is one dependent exchange of
+    16-byte records between neighbouring patches (intrinsic: x_bar of step t feeds step t + 1) plus the instructions between
+    a record arriving and the next one leaving; the exchange crosses an XCD border wherever the graph does.
+      * cross-XCD hand-off: what this context's page calibration measured (k_place_calibrate, all 56 XCD pairs at once);
+      * uncoupled period: eight DISJOINT graphs of the same total size, one per XCD -- no record crosses an XCD -- run by the
+        same kernel: the period the coupled graph would have without its crossings; its least-slack patch's wait is the
+        same-XCD hand-off as the kernel sees it (publish -> arrival, detection included);
+      * HBM period: the algorithmic bytes of one iteration at the HBM peak -- what `frac` divides by."""
+    import numpy as np
+
+    from flame_amd.regularizer import OPT_PERSISTENT, OPT_PROBE
+
+    def small(w, h, seed):
+        pos = synth.make_points(w, h, 6, seed)
+        return synth.assemble_graph(pos, synth.make_data_term(pos, w, h, seed), synth.delaunay_edges_native(pos))
+
+    g8 = synth.concat_graphs([small(228, 168, 100 + k) for k in range(8)])  # 8 x ~1060 vertices ~ one 640x480 frame
+    r = flame_amd.Regularizer(device)
+    try:
+        r.set_option(OPT_PERSISTENT, 4)
+        r.upload_graph(g8)
+        r.run(params, iters)
+        ms, _ = timed_launches(r, params, iters, 5)
+        path = flame_amd.regularizer.RUN_PATHS.get(r.info()["last_run_path"], "?")
+    finally:
+        r.close()
+    r = flame_amd.Regularizer(device)
+    try:
+        r.set_option(OPT_PERSISTENT, 4)
+        r.set_option(OPT_PROBE, 1)
+        r.upload_graph(g8)
+        r.run(params, iters)
+        r.run(params, iters)
+        p = r.read_probe().reshape(-1, iters, 8).astype(np.int64)[:, iters // 10:, :]
+        p = p[p[:, 0, 5] != 0]
+    finally:
+        r.close()
+    wait = p[:, :, 2].mean(axis=1)
+    ghz = float((np.diff(p[0, :, 5]) & 0xffffffff).mean()) / (float((np.diff(p[0, :, 6]) & 0xffffffff).mean()) * 10.0)
+    uncoupled_us = ms * 1e3 / iters
+    out = {"uncoupled_period_us": round(uncoupled_us, 3), "uncoupled_run_path": path,
+           "uncoupled_graphs": f"8 disjoint Delaunay graphs, V={g8['V']} E={g8['E']} in total, one per XCD",
+           "same_xcd_handoff_us": round(float(wait.min()) / (ghz * 1e3), 3),
+           "hbm_period_us": round(B_iter / (HBM_PEAK_GBPS * 1e9) * 1e6, 3),
+           "measured_period_us": roofline["per_iteration_us"]}
+    rp = roofline.get("record_placement")
+    if isinstance(rp, dict):
+        out["cross_xcd_handoff_us"] = rp["cross_xcd_handoff_us_by_page"]
+    out["frac_of_hbm_at_uncoupled_period"] = round(out["hbm_period_us"] / uncoupled_us, 4)
+    out["note"] = ("one small frame cannot iterate faster than one hand-off plus the ~600 cycles of dependent instructions behind it; "
+                   "`frac_of_hbm_at_uncoupled_period` is the roofline fraction this frame would show if none of its records crossed an XCD")
+    return out
+
+
 def measured_traffic(config, run_path):
     """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE),
     measured offline with the same command and committed under profiles/ (the counters cannot be read
@@ -342,6 +426,13 @@ def valu_roofline(key, launch_s):
             "unit": "G wave-instr/s", "frac": round(rate / VALU_PEAK_WINST_PER_S, 4), "source": "profiles/traffic.json"}
 
 
+def timed_launches(r, params, iters, n=10):
+    """(mean, min) duration in ms of n launches of `iters` iterations, each bracketed by HIP events on the solver's stream.
+    Fractions are computed from the MEAN, so that they agree with the rocprofv3 average of the same command under profiles/."""
+    ts = [r.run_timed(params, iters) for _ in range(n)]
+    return sum(ts) / len(ts), min(ts)
+
+
 def reg_profile_kernel(reg, params, n=400):
     """Mean duration (us) of ONE k_fused_step launch: eager launches, hipGraph off, each `run(1)`
     bracketed by HIP events on the solver's stream (flame_nltgv2_run_timed)."""
@@ -374,7 +465,7 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
         b.upload_graph(union)
         bi = b.info()
         b.run(params, iters)
-        ms = min(b.run_timed(params, iters) for _ in range(5))
+        ms, ms_min = timed_launches(b, params, iters)
         path = flame_amd.regularizer.RUN_PATHS.get(b.info()["last_run_path"], "?")
         per_iter_us = ms * 1e3 / iters
         gbps = bi["algorithmic_bytes_per_iter"] / (per_iter_us * 1e-6) / 1e9
@@ -382,6 +473,9 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
             "frames": nf, "V": bi["V"], "E": bi["E"], "run_path": path, "launch_groups": b.info()["last_run_groups"],
             "frame_iters_per_s": round(nf * iters / (ms * 1e-3), 1), "per_iteration_us": round(per_iter_us, 2),
             "achieved_GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4), "bound": "hbm",
+            "timing": "mean of 10 launches (HIP events)", "best_launch_per_iteration_us": round(ms_min * 1e3 / iters, 2),
+            "note": "frac counts ALGORITHMIC bytes (64 V + 40 E per iteration) against the HBM peak; the state is register / LDS "
+                    "resident, the real HBM traffic is `traffic`",
         }
         groups = max(1, b.info()["last_run_groups"])
         key = f"{a.config}x{nf}:{path}"
@@ -410,7 +504,7 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
             r.photo_set_images(ref_img, cmp_img)
             r.photo_fuse(_np2.eye(3, dtype=_np2.float32), Kt, graph_scale=1.0, border=4)
         r.run(params, 200)
-        ms = min(r.run_timed(params, 200) for _ in range(5))
+        ms, ms_min = timed_launches(r, params, 200)
         bi = r.info()
         gbps = bi["algorithmic_bytes_per_iter"] * 200 / (ms * 1e-3) / 1e9
         oc[cfg] = {"V": g["V"], "E": g["E"], "iters_per_s": round(200 / (ms * 1e-3), 1),
@@ -422,6 +516,8 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
         oc[cfg]["traffic"] = measured_counters(key).get("hbm_bytes_per_launch")
         oc[cfg]["algorithmic_bytes_per_launch"] = int(bi["algorithmic_bytes_per_iter"] * 200)
         oc[cfg]["avg_launch_us"] = round(ms * 1e3, 1)
+        oc[cfg]["best_launch_us"] = round(ms_min * 1e3, 1)
+        oc[cfg]["timing"] = "mean of 10 launches (HIP events)"
         oc[cfg]["valu"] = valu_roofline(key, ms * 1e-3)
         if fused:
             res = r.photo_residual_last()

@@ -1858,10 +1858,9 @@ int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, boo
 // from the compiler's resource report and fails when an instance outgrows its row here); the runtime's answer still bounds it
 // from above (it knows the LDS use, which varies with the layout).
 int pv_real_waves_per_simd(int layout, bool verify_or_probe) {
-  // {VGPRs, SGPRs} -> waves: LAYOUT 1 plain {65, 106} -> min(7, 6); verify / probe {75, 106} -> min(6, 6);
+  // {VGPRs, SGPRs} -> waves: LAYOUT 1 plain {65, 106} -> min(7, 6); verify / probe {75-81, 106} -> min(5, 6);
   // LAYOUT 0 / 2 (slab code compiled in) {156-165, 106} -> 3
-  (void)verify_or_probe;
-  return layout == 1 ? 6 : 3;
+  return layout == 1 ? (verify_or_probe ? 5 : 6) : 3;
 }
 
 int pv_patches_per_cu(const FusedArgs& a, bool verify) {

@@ -70,16 +70,48 @@ class IdepthGather:
             self._work[self._cur] = None
         return self._local[self._cur][i]
 
-    def gather(self, async_op: bool = False) -> None:
-        """all_gather of the current local buffer.  async_op=True returns at once; frame() / wait() or the
-        next reuse of the buffer completes it."""
+    @staticmethod
+    def _replays(regs):
+        out = []
+        for r in regs:
+            i = r.info()
+            out.append(i["timeouts_recovered"] + i["torn_records_detected"])
+        return out
+
+    def gather(self, async_op: bool = False, regs=None) -> None:
+        """all_gather of the current local buffer.  async_op=True returns at once; frame() / wait() / settle() or
+        the next reuse of the buffer completes it.  `regs` (the local solvers whose runs feed the rows): remembered
+        for settle()."""
         k = self._cur
+        self._replays_at_gather = self._replays(regs) if regs is not None else None
         w = self.dist.all_gather_into_tensor(self._gathered[k], self._local[k], async_op=async_op)
         self._work[k] = w if async_op else None
         self.gathered = self._gathered[k]
         self._last = k
         self._cur = 1 - k
         self.local = self._local[self._cur]
+
+    def settle(self, regs) -> int:
+        """Completes the gather and makes sure it carried rows of runs that really finished.  `gather()` right behind
+        `run_async()` reads the export rows of unchecked runs: a persistent run whose neighbour wait expires leaves
+        before its epilogue writes the row, and `Regularizer.sync()` only then takes it back, redoes the steps and
+        re-exports -- after the collective has delivered the previous frame's row.  settle() syncs every local solver
+        and, if any rank had to redo a run since the gather was issued, gathers once more from the re-exported rows
+        (collectively: the ranks agree through one small all_reduce).  Returns the number of re-gathers (0 or 1)."""
+        before = getattr(self, "_replays_at_gather", None) or self._replays(regs)
+        for r in regs:
+            r.sync()
+        redo = 1 if self._replays(regs) != before else 0
+        self._replays_at_gather = None
+        self.wait()
+        if self.world > 1:
+            t = torch.tensor([redo], dtype=torch.int32, device=self._local[0].device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            redo = int(t.item())
+        if redo:
+            self._cur = self._last  # the rows the solvers have just re-exported into
+            self.gather(async_op=False)
+        return redo
 
     def wait(self) -> None:
         for k in (0, 1):

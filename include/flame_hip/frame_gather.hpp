@@ -6,11 +6,19 @@
 //   flame_hip::FrameGather gather(devices, vmax);                      // once
 //   for k: solver[k].setStream(gather.stream(k));                      // export ordered before the gather, no host sync
 //          solver[k].setExportTarget(gather.localRow(k), graph_scale); // every run() leaves x * graph_scale in the row
-//   per step:  for k: solver[k].runAsync(params, n);   gather.gather();   ...   gather.wait();
+//   per step:  for k: solver[k].runAsync(params, n);   gather.gather();   ...   gather.settle(solvers);
 //              gather.download(k, &block)  /  gather.gathered(k)  -> row j = frame j, first V_j entries
+//
+// ORDERING.  gather() right behind runAsync() all-gathers the export rows of runs nobody has checked yet.  A persistent run
+// whose neighbour wait expires (the GPU shared with something that keeps its CUs full) leaves before its epilogue writes
+// the row; DeviceGraph::sync() then takes the run back, redoes the steps and re-exports -- AFTER the collective has already
+// delivered the previous frame's row to every GPU.  So the gathered block may only be consumed after settle(): it syncs
+// every solver, and if any of them had to redo its run (DeviceGraph::replays() moved) it gathers again.  wait() alone is
+// for callers that synced their solvers before gather().
 #ifndef FLAME_HIP_FRAME_GATHER_HPP_
 #define FLAME_HIP_FRAME_GATHER_HPP_
 
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -48,6 +56,36 @@ class FrameGather {
   }
   void gather() { check(flame_frames_gather(ctx_), "gather"); }
   void wait() { check(flame_frames_wait(ctx_), "wait"); }
+  // gather() that remembers how often each solver has had to redo a run so far: the baseline of settle()
+  template <class Solvers>
+  void gather(Solvers& solvers) {
+    replays_at_gather_.clear();
+    for (auto& s : solvers) replays_at_gather_.push_back(deref(s).replays());
+    gather();
+  }
+  // Completes the gather and makes sure it carried the rows of runs that really finished: syncs every solver; if one of
+  // them was taken back and redone since the gather was issued, the (re-exported) rows are gathered again.  Returns the
+  // number of re-gathers (0 or 1).
+  template <class Solvers>
+  int settle(Solvers& solvers) {
+    std::vector<int> before = replays_at_gather_;
+    if (before.size() != static_cast<size_t>(solvers.size())) {
+      before.clear();
+      for (auto& s : solvers) before.push_back(deref(s).replays());
+    }
+    bool again = false;
+    size_t k = 0;
+    for (auto& s : solvers) {
+      deref(s).sync();
+      again = again || deref(s).replays() != before[k++];
+    }
+    replays_at_gather_.clear();
+    wait();
+    if (!again) return 0;
+    gather();
+    wait();
+    return 1;
+  }
   const float* gathered(int k) {
     void* p = nullptr;
     check(flame_frames_gathered(ctx_, k, &p), "gathered");
@@ -62,8 +100,12 @@ class FrameGather {
   void check(int rc, const char* what) const {
     if (rc != 0) throw Error(rc, (std::string(what) + ": " + flame_frames_last_error_text(ctx_)).c_str());
   }
+  template <class T> static T& deref(T& t) { return t; }
+  template <class T> static T& deref(T* t) { return *t; }
+  template <class T> static T& deref(std::unique_ptr<T>& t) { return *t; }
   flame_frames_ctx* ctx_;
   int32_t vmax_;
+  std::vector<int> replays_at_gather_;
 };
 
 }  // namespace flame_hip

@@ -262,6 +262,14 @@ class DeviceGraph {
     check(flame_nltgv2_run_async(ctx_, &c, n_iters), "run_async");
   }
   void sync() { check(flame_nltgv2_sync(ctx_), "sync"); }
+  // Asynchronous runs that sync() had to take back and redo (an expired neighbour wait or a torn record: the state is
+  // right again when sync() returns, but anything that consumed the export row BEFORE sync() -- a gather enqueued right
+  // behind runAsync() -- read the previous frame's values).  A caller compares this before and after its sync().
+  int replays() {
+    flame_nltgv2_info info;
+    check(flame_nltgv2_get_info(ctx_, &info), "get_info");
+    return info.timeouts_recovered + info.torn_records_detected;
+  }
   flame_nltgv2_ctx* handle() { return ctx_; }
 
  private:

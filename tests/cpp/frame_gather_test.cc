@@ -89,19 +89,31 @@ int main() {
       solver[k]->upload(frames[k]);
       solver[k]->setExportTarget(gather.localRow(k), graph_scale);
     }
-    for (int step = 0; step < 2; ++step) {  // two steps of the frame loop: solve everywhere, gather once
+    int regathers = 0;
+    for (int step = 0; step < 3; ++step) {  // three steps of the frame loop: solve everywhere, gather once
+      // step 2: solver 0's persistent run is made to time out (one patch withholds its first record): it leaves before its
+      // epilogue exports the row, the gather enqueued right behind it carries step 1's row, sync() takes the run back and
+      // redoes it -- settle() has to notice and gather again
+      if (step == 2) flame_nltgv2_set_option(solver[0]->handle(), FLAME_NLTGV2_OPT_FAULT_INJECT, 3000);
       for (int k = 0; k < n_dev; ++k) solver[k]->runAsync(params, n_iters);
-      gather.gather();
-      gather.wait();
-      for (int k = 0; k < n_dev; ++k) solver[k]->sync();
+      gather.gather(solver);
+      regathers += gather.settle(solver);
+      if (step == 2) flame_nltgv2_set_option(solver[0]->handle(), FLAME_NLTGV2_OPT_FAULT_INJECT, 0);
     }
-    // the checker: 2 * n_iters iterations per frame, x * graph_scale
+    {
+      flame_nltgv2_info info;
+      flame_nltgv2_get_info(solver[0]->handle(), &info);
+      const bool ok = info.timeouts_recovered == regathers && regathers <= 1;
+      std::printf("run taken back %d time(s), %d re-gather(s)                  %s\n", info.timeouts_recovered, regathers, ok ? "ok" : "FAIL");
+      fails += !ok;
+    }
+    // the checker: 3 * n_iters iterations per frame, x * graph_scale
     std::vector<std::vector<float>> want;
     for (int k = 0; k < n_dev; ++k) {
       flame_hip::FlatArrays a;
       flame_hip::GraphAccess<flame_hip::FlatGraph>::pack(frames[k], &a);
       flame_nltgv2_graph v = a.view();
-      nltgv2_oracle_run(&cp, &v, 2 * n_iters);
+      nltgv2_oracle_run(&cp, &v, 3 * n_iters);
       std::vector<float> row(a.x.size());
       for (size_t i = 0; i < row.size(); ++i) row[i] = a.x[i] * graph_scale;
       want.push_back(row);

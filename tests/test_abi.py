@@ -93,3 +93,34 @@ def test_product_package_never_imports_the_checker():
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dirpath, f)
                 assert "liboracle" not in txt and "nltgv2_oracle" not in txt, os.path.join(dirpath, f)
+
+
+def test_pv_residency_table_matches_the_build(tmp_path):
+    """The planner's residency of k_persistent_pv (pv_real_waves_per_simd, nltgv2_kernels.hip) is derived from the
+    register counts of the instances as built: waves per SIMD = min(512 // VGPRs rounded up to 8,
+    800 // (SGPRs rounded up to 16, + 16 for the trap handler), 8) -- the rule tools/residency_probe.hip measured on
+    the hardware (profiles/r03_residency.txt), which the runtime's occupancy query does not follow.  Compiles the
+    kernels with the compiler's resource report and checks every instance against its row of the table."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "flame_amd", "csrc", "nltgv2_kernels.hip")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "flame_amd", "csrc"), "-c", src, "-o", str(tmp_path / "k.o"),
+           "-Rpass-analysis=kernel-resource-usage"]
+    rep = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
+    found = {}
+    for m in re.finditer(r"Function Name: (\S+).*?TotalSGPRs: (\d+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)", rep, flags=re.S):
+        name, sg, vg, scratch = m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4))
+        k = re.search(r"k_persistent_pvILb([01])ELi([012])ELb([01])E", name)
+        if k:
+            found[(int(k.group(1)), int(k.group(2)), int(k.group(3)))] = (sg, vg, scratch)
+    assert len(found) >= 9, sorted(found)
+    txt = open(src).read()
+    assert "return layout == 1 ? (verify_or_probe ? 5 : 6) : 3;" in txt, "the table in this test mirrors pv_real_waves_per_simd"
+    for (probe, layout, verify), (sg, vg, scratch) in sorted(found.items()):
+        real = min(512 // ((vg + 7) // 8 * 8), 800 // ((sg + 15) // 16 * 16 + 16), 8)
+        want = (5 if (probe or verify) else 6) if layout == 1 else 3
+        assert real >= want, f"instance probe={probe} layout={layout} verify={verify}: {vg} VGPRs / {sg} SGPRs keep {real} waves per SIMD, the planner assumes {want}"
+    # the instance the bench runs (no probe, row-packed, no verification) must not spill
+    assert found[(0, 1, 0)][2] == 0

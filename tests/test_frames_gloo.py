@@ -81,3 +81,72 @@ def test_shard_frames_properties():
             assert max(c) - min(c) <= 1
     with pytest.raises(ValueError):
         shard_frames(4, 2, 2)
+
+
+class _FakeSolver:
+    """Stands in for a Regularizer in the host-logic test of IdepthGather.settle(): run() fills the send row the way the
+    solver's export does, except that a 'timed-out' run leaves the row alone until sync() redoes it (what a persistent run
+    that leaves through an expired wait does: no epilogue export; flame_nltgv2_sync replays and re-exports)."""
+
+    def __init__(self):
+        self.recovered, self.pending = 0, None
+
+    def run(self, row, value, time_out=False):
+        if time_out:
+            self.pending = (row, value)
+        else:
+            row[:] = value
+
+    def sync(self):
+        if self.pending is not None:
+            row, value = self.pending
+            row[:] = value          # the replay's export
+            self.recovered += 1
+            self.pending = None
+
+    def info(self):
+        return {"timeouts_recovered": self.recovered, "torn_records_detected": 0}
+
+
+def _settle_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from flame_amd.frames import IdepthGather
+
+        ig = IdepthGather(dist, [5], world, torch.device("cpu"))
+        s = _FakeSolver()
+        out = []
+        for step in range(3):
+            # step 1: rank 1's run "times out" -- its row still holds step 0's values when the gather reads it
+            s.run(ig.local_row(0), float(10 * step + rank), time_out=(step == 1 and rank == 1))
+            ig.gather(async_op=True, regs=[s])
+            stale = [float(ig.frame(f)[0]) for f in range(world)] if step == 1 else None
+            redo = ig.settle([s])
+            out.append((redo, [float(ig.frame(f)[0]) for f in range(world)], stale))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo_settle_regathers_after_a_replayed_run():
+    """ADVICE r02 (frame_gather.hpp:9): a gather enqueued behind an unchecked run can carry a stale row; settle() must notice
+    on EVERY rank (the rank that replayed and the ones that did not) and gather again."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_settle_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        (r0, v0, _), (r1, v1, stale), (r2, v2, _) = res[rank]
+        assert (r0, r1, r2) == (0, 1, 0), (rank, r0, r1, r2)
+        assert v0 == [0.0, 1.0] and v2 == [20.0, 21.0]
+        assert stale[0] == 10.0 and stale[1] != 11.0  # what the first gather of step 1 delivered: rank 1's row as the run found it
+        assert v1 == [10.0, 11.0]       # ... and what settle() left

@@ -22,6 +22,65 @@ def _free_port():
     return p
 
 
+def _worker_cfg4(port, q):
+    """BASELINE configs[3] at FULL size on one device: 8 different 640x480 frames, one solver context each (as 8 ranks would
+    hold one each), 200 iterations per step, every solver exporting x * graph_scale into its row of the gather from its own
+    launch, one RCCL all_gather_into_tensor per step, every gathered row against the checker.  What only an 8-GPU node adds
+    is the xGMI transport between the ranks (and the scaling curve)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import flame_amd
+        from flame_amd import synth
+        from flame_amd.frames import IdepthGather
+        from flame_amd.regularizer import OPT_FAULT_INJECT
+        from oracle import capi as oracle
+
+        dev = torch.device("cuda", 0)
+        n_frames, iters = 8, 200
+        frames = [synth.make_graph("640x480", seed=1234 + i) for i in range(n_frames)]  # bench.py's per-rank seeds
+        refs = [synth.copy_graph(g) for g in frames]
+        ig = IdepthGather(dist, [g["V"] for g in frames], n_frames, dev)
+        stream = torch.cuda.Stream(device=dev)
+        regs = []
+        for g in frames:
+            r = flame_amd.Regularizer(0)
+            r.set_stream(stream.cuda_stream)
+            r.upload_graph(g)
+            regs.append(r)
+        p = flame_amd.Params()
+        ok, regathers, paths = True, [], []
+        for step in range(3):
+            if step == 2:  # frame 5's run is made to time out: the gather behind it carries a stale row until settle()
+                regs[5].set_option(OPT_FAULT_INJECT, 3000)
+            for i, r in enumerate(regs):
+                r.set_export_target(ig.local_row(i).data_ptr(), 1.0)
+                r.run_async(p, iters)
+            if step == 0:
+                paths = [r.info()["last_run_path"] for r in regs]
+            with torch.cuda.stream(stream):
+                ig.gather(async_op=True, regs=regs)
+            for ref in refs:
+                oracle.omp_run(ref, iters, min(16, os.cpu_count() or 1))  # (bit-identical to the sequential checker)
+            regathers.append(ig.settle(regs))
+            regs[5].set_option(OPT_FAULT_INJECT, 0)
+            for i, ref in enumerate(refs):
+                got = ig.frame(i).cpu().numpy()
+                ok = ok and got.shape[0] == ref["V"] and np.array_equal(got, ref["x"])
+        recovered = [r.info()["timeouts_recovered"] for r in regs]
+        for r in regs:
+            r.close()
+        q.put((ok, regathers, recovered, paths, dist.get_backend()))
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker(port, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -83,3 +142,21 @@ def test_nccl_world1_solver_export_and_gather_on_the_device():
     assert backend == "nccl"
     assert ok, "gathered rows differ from the CPU checker"
     assert all(p in (1, 5, 6) for p in paths), paths  # the persistent kernels wrote the send rows themselves
+
+
+@pytest.mark.gpu
+def test_cfg4_eight_full_size_frames_on_one_device_with_rccl_gather():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    proc = ctx.Process(target=_worker_cfg4, args=(_free_port(), q))
+    proc.start()
+    ok, regathers, recovered, paths, backend = q.get(timeout=600)
+    proc.join(timeout=60)
+    assert proc.exitcode == 0
+    assert backend == "nccl"
+    assert ok, "a gathered row differs from the CPU checker"
+    assert all(p == 6 for p in paths), paths          # every frame ran the patch-per-wave persistent kernel
+    assert regathers == [0, 0, 1], regathers          # the timed-out run was noticed: one re-gather, after its replay
+    assert recovered[5] == 1 and sum(recovered) == 1, recovered
