@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "flame_nltgv2.h"
+#include "roctx_ranges.hpp"
 
 namespace {
 
@@ -287,6 +288,7 @@ inline uint32_t spread16(uint32_t v) {
 extern "C" int flame_delaunay_triangulate(const float* xy, int32_t n, int32_t* triangles, int32_t tri_capacity,
                                           int32_t* n_triangles, int32_t* edges, int32_t edge_capacity,
                                           int32_t* n_edges) {
+  flame_hip::RoctxRange roctx_range_("flame_delaunay_triangulate");
   if (n < 0 || (n > 0 && !xy) || !n_triangles || !n_edges) return FLAME_NLTGV2_ERR_INVALID_ARG;
   *n_triangles = 0;
   *n_edges = 0;

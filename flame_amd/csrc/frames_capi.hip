@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "flame_frames.h"
+#include "roctx_ranges.hpp"
 
 namespace {
 
@@ -177,6 +178,7 @@ int flame_frames_stream(flame_frames_ctx* ctx, int k, void** hip_stream) {
 }
 
 int flame_frames_gather(flame_frames_ctx* ctx) {
+  flame_hip::RoctxRange roctx_range_("flame_frames_gather");
   if (!ctx || ctx->comms.empty()) return FLAME_NLTGV2_ERR_INVALID_ARG;
   ncclResult_t r = g_rccl.GroupStart();
   if (r != 0) return nccl_fail(ctx, r, "ncclGroupStart");
@@ -192,6 +194,7 @@ int flame_frames_gather(flame_frames_ctx* ctx) {
 }
 
 int flame_frames_wait(flame_frames_ctx* ctx) {
+  flame_hip::RoctxRange roctx_range_("flame_frames_wait");
   if (!ctx) return FLAME_NLTGV2_ERR_INVALID_ARG;
   DeviceGuard guard;
   for (size_t k = 0; k < ctx->streams.size(); ++k) {

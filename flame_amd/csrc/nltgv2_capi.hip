@@ -22,6 +22,7 @@
 #include "flame_nltgv2.h"
 #include "nltgv2_kernels.h"
 #include "nltgv2_pack.hpp"
+#include "roctx_ranges.hpp"
 
 using namespace flame_hip;
 
@@ -1368,6 +1369,7 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
 }
 
 int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_upload_graph");
   int rc = enter(ctx);
   if (rc) return rc;
   if (!g) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
@@ -1441,6 +1443,7 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
 //   * resulting edge order = surviving edges in their previous relative order, then the new edges in
 //     triangulator order (boost::edges() walks a std::list: erase keeps order, add_edge appends).
 int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_sync_graph");
   int rc = enter(ctx);
   if (rc) return rc;
   if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
@@ -1608,6 +1611,7 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
 
 int flame_nltgv2_project_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_projection* pr, float graph_scale,
                                uint8_t* keep_out, float* pos_out) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_project_graph");
   int rc = enter(ctx);
   if (rc) return rc;
   if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
@@ -1635,6 +1639,7 @@ int flame_nltgv2_project_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_project
 }
 
 int flame_nltgv2_rescale_data(flame_nltgv2_ctx* ctx, float graph_scale, float* new_graph_scale, flame_nltgv2_params* p) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_rescale_data");
   int rc = enter(ctx);
   if (rc) return rc;
   if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
@@ -1673,6 +1678,7 @@ int flame_nltgv2_get_topology(flame_nltgv2_ctx* ctx, int32_t* src, int32_t* dst,
 }
 
 int flame_nltgv2_update_data(flame_nltgv2_ctx* ctx, const float* data_term, const float* data_weight) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_update_data");
   int rc = enter(ctx);
   if (rc) return rc;
   if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
@@ -1714,6 +1720,7 @@ int flame_nltgv2_upload_state(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* s
 }
 
 int flame_nltgv2_run_async(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n_iters) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_run_async");
   int rc = enter(ctx);
   if (rc) return rc;
   if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
@@ -1722,6 +1729,7 @@ int flame_nltgv2_run_async(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, 
 }
 
 int flame_nltgv2_sync(flame_nltgv2_ctx* ctx) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_sync");
   int rc = enter(ctx);
   if (rc) return rc;
   if (!ctx->have_graph) {
@@ -1732,6 +1740,7 @@ int flame_nltgv2_sync(flame_nltgv2_ctx* ctx) {
 }
 
 int flame_nltgv2_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n_iters) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_run");
   int rc = flame_nltgv2_run_async(ctx, p, n_iters);
   if (rc) return rc;
   return finish(ctx);
@@ -1790,6 +1799,7 @@ int flame_nltgv2_save_prev(flame_nltgv2_ctx* ctx) {
 }
 
 int flame_nltgv2_costs(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, float* smoothness, float* data) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_costs");
   int rc = enter(ctx);
   if (rc) return rc;
   if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
@@ -1816,6 +1826,7 @@ int flame_nltgv2_costs(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, floa
 }
 
 int flame_nltgv2_download_state(flame_nltgv2_ctx* ctx, flame_nltgv2_graph* out) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_download_state");
   int rc = enter(ctx);
   if (rc) return rc;
   if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
@@ -1915,6 +1926,7 @@ static int interpolate_common(flame_nltgv2_ctx* ctx, const int32_t* triangles, i
 
 int flame_nltgv2_interpolate_mesh(flame_nltgv2_ctx* ctx, const int32_t* triangles, int32_t T, const uint8_t* tri_valid,
                                   int rows, int cols, float graph_scale, float* idepthmap_out, int32_t* coverage_out) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_interpolate_mesh");
   int rc = enter(ctx);
   if (rc) return rc;
   if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
@@ -1928,6 +1940,7 @@ int flame_nltgv2_interpolate_mesh_arrays(flame_nltgv2_ctx* ctx, const int32_t* t
                                          const float* values, int32_t V, const uint8_t* vtx_valid,
                                          const uint8_t* tri_valid, int rows, int cols, float* img_out,
                                          int32_t* coverage_out) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_interpolate_mesh_arrays");
   int rc = enter(ctx);
   if (rc) return rc;
   if (V < 0 || (V > 0 && (!vertices_xy || !values))) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);

@@ -11,6 +11,7 @@
 
 #include "flame_stereo.h"
 #include "stereo_kernels.h"
+#include "roctx_ranges.hpp"
 
 using namespace flame_hip;
 
@@ -263,6 +264,7 @@ int flame_stereo_set_camera(flame_stereo_ctx* ctx, const float K[9], const float
 }
 
 int flame_stereo_add_frame(flame_stereo_ctx* ctx, uint32_t frame_id, const uint8_t* img, int row_stride_bytes) {
+  flame_hip::RoctxRange roctx_range_("flame_stereo_add_frame");
   if (int rc = enter(ctx)) return rc;
   if (!ctx->have_camera) return FLAME_NLTGV2_ERR_NO_GRAPH;
   const int w = ctx->cam.width, h = ctx->cam.height;
@@ -317,6 +319,7 @@ int flame_stereo_download_frame(flame_stereo_ctx* ctx, uint32_t frame_id, uint8_
 int flame_stereo_update_feature_idepths(flame_stereo_ctx* ctx, const flame_stereo_params* params, uint32_t new_frame_id,
                                         uint32_t curr_pf_id, int n_poses, const flame_stereo_pose* poses, int n_feats,
                                         flame_stereo_feature* feats, flame_stereo_stats* stats) {
+  flame_hip::RoctxRange roctx_range_("flame_stereo_update_feature_idepths");
   if (int rc = enter(ctx)) return rc;
   if (!stats || n_feats < 0 || (n_feats > 0 && !feats)) return FLAME_NLTGV2_ERR_INVALID_ARG;
   if (int rc = grow(ctx, &ctx->d_feats, &ctx->feats_cap, (size_t)n_feats + 1)) return rc;
@@ -334,6 +337,7 @@ int flame_stereo_update_feature_idepths_device(flame_stereo_ctx* ctx, const flam
                                                uint32_t new_frame_id, uint32_t curr_pf_id, int n_poses,
                                                const flame_stereo_pose* poses, int n_feats, void* feats_device,
                                                flame_stereo_stats* stats) {
+  flame_hip::RoctxRange roctx_range_("flame_stereo_update_feature_idepths_device");
   if (int rc = enter(ctx)) return rc;
   if (n_feats < 0 || (n_feats > 0 && !feats_device)) return FLAME_NLTGV2_ERR_INVALID_ARG;
   if (int rc = enqueue_update(ctx, params, new_frame_id, curr_pf_id, n_poses, poses, n_feats, (StereoFeature*)feats_device))
@@ -356,6 +360,7 @@ int flame_stereo_set_option(flame_stereo_ctx* ctx, int option, int value) {
 }
 
 int flame_stereo_set_features(flame_stereo_ctx* ctx, int n_feats, const flame_stereo_feature* feats) {
+  flame_hip::RoctxRange roctx_range_("flame_stereo_set_features");
   if (int rc = enter(ctx)) return rc;
   if (n_feats < 0 || (n_feats > 0 && !feats)) return FLAME_NLTGV2_ERR_INVALID_ARG;
   SCHK(ctx, hipStreamSynchronize(ctx->stream));  // (the array may be reallocated)
@@ -369,6 +374,7 @@ int flame_stereo_set_features(flame_stereo_ctx* ctx, int n_feats, const flame_st
 }
 
 int flame_stereo_get_features(flame_stereo_ctx* ctx, int max_feats, flame_stereo_feature* feats, int* n_feats) {
+  flame_hip::RoctxRange roctx_range_("flame_stereo_get_features");
   if (int rc = enter(ctx)) return rc;
   if (n_feats) *n_feats = ctx->n_res;
   if (!feats) return 0;
@@ -388,6 +394,7 @@ int flame_stereo_features_device(flame_stereo_ctx* ctx, void** feats_device, int
 
 int flame_stereo_update_resident(flame_stereo_ctx* ctx, const flame_stereo_params* params, uint32_t new_frame_id,
                                  uint32_t curr_pf_id, int n_poses, const flame_stereo_pose* poses, flame_stereo_stats* stats) {
+  flame_hip::RoctxRange roctx_range_("flame_stereo_update_resident");
   if (int rc = enter(ctx)) return rc;
   if (int rc = enqueue_update(ctx, params, new_frame_id, curr_pf_id, n_poses, poses, ctx->n_res, ctx->d_res)) return rc;
   if (!stats) return 0;
