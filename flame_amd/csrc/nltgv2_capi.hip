@@ -142,7 +142,6 @@ struct flame_nltgv2_ctx {
   int opt_solver = 0, opt_use_graph = 1, opt_block_waves = 0, opt_unroll = 0, opt_persistent = 1, opt_dual = 1;
   int xbuf_form = 0;     // the persistent form whose records the exchange buffers hold (0: cleared)
   int opt_xcds = 0;      // XCDs a persistent launch spreads over: 0 = auto, 1..8
-  int opt_shadows = 0;   // shadow patches across XCD borders: 0 = built-in choice, 1 = none, 2 = always (next upload / sync)
   bool photo_fused = false;     // flame_nltgv2_photo_fuse: every run also leaves the photometric residual in photo_err
   PhotoGeometry photo_geo{};
   float photo_scale = 1.0f;
@@ -168,7 +167,6 @@ struct flame_nltgv2_ctx {
   int opt_verify = 0;             // 1: persistent kernels re-read every record after its tag matched; 2: + test hook
   // Record placement of the patch-per-wave form (nltgv2_layout.hip): a pool of pages measured once per context, the
   // records read across XCDs assigned to them once per topology
-  int opt_rowpack = 1;            // patch-per-wave form: 1 (default) row-packed patches + DPP accumulation, 0 contiguous lanes + LDS slab
   int opt_place = 1;              // 1 (default) on, 0 off
   int place_state = 0;            // 0 not calibrated yet, 1 page ranking on the device, -1 unavailable (calibration failed)
   uint64_t place_topo = ~0ull;    // topology / patches per XCD the record offsets are valid for
@@ -218,7 +216,7 @@ struct flame_nltgv2_ctx {
   std::vector<float> h_terms;
   DevBuf hq_alt, vstate_alt;  // the other copies of hq / vstate: a persistent run writes there, success swaps the roles
   DevBuf xbuf, abort_flag, he_slot, he_vid, he_meta, he_wave_chain, tv_slot, tv_vid, tv_meta, tv_wave;
-  DevBuf wg_slot, wg_vid, wg_meta, wg_nbr, wg_fetch, wg_info, wg_v0, rid_on, wg_vfirst, probe, progress;
+  DevBuf wg_slot, wg_vid, wg_meta, wg_nbr, wg_fetch, wg_info, wg_v0, wg_vfirst, probe, progress;
   // misc
   DevBuf err, cost_out, img_ref, img_cmp, photo_err, r_tris, r_valid, r_keys, r_img, r_cov, r_vtx, r_val;
   int img_rows = 0, img_cols = 0, img_step = 0;
@@ -344,8 +342,7 @@ int finish(flame_nltgv2_ctx* ctx);
 int snapshot_chain_start(flame_nltgv2_ctx* ctx);
 constexpr size_t kMaxChain = 256;  // operations enqueued behind an unchecked persistent run before the host settles it
 
-// records the exchange buffers hold: one per packed vertex slot (the he / tv forms index by packed vertex), more when
-// shadow patches publish copies under record ids of their own
+// records the exchange buffers hold: one per packed vertex slot (the he / tv forms index by packed vertex)
 size_t records_capacity(const PackedLayout& L) {
   const size_t n_packed = (size_t)L.n_slices * kWave, n_rec = ((size_t)L.n_rec + kWave - 1) / kWave * kWave;
   return std::max(n_packed, n_rec);
@@ -420,10 +417,10 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
   // The lane-per-half-edge rows (C) come from the same greedy walk as the patches (E): as many waves, possible under the
   // same condition (no vertex of more than 64 incident edges).  They, and the vertex-per-lane rows (D), are built only
   // when their form is actually chosen.
-  const bool pv_fits = L.wg_ok && L.wg_count > 0 && L.wg_count <= wg_cap;
+  const bool pv_fits = L.wg_ok && L.wg_rowpack && L.wg_count > 0 && L.wg_count <= wg_cap;  // (the kernel runs row-packed patches)
   const bool he_possible = L.wg_ok && L.wg_count > 0;
   int form = 0;
-  if (ctx->opt_persistent == 4) form = L.wg_ok ? 3 : 0;
+  if (ctx->opt_persistent == 4) form = (L.wg_ok && L.wg_rowpack) ? 3 : 0;
   else if (ctx->opt_persistent == 2) form = he_possible ? 1 : 0;
   else if (ctx->opt_persistent == 3) form = 2;
   else if (pv_fits) form = 3;  // lowest latency wherever all patches are resident: 320x240 ... 1280x720 single frames
@@ -774,9 +771,9 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
         const int gap = ctx->opt_poll_gap > 0 ? ctx->opt_poll_gap - 1 : dense ? (3 | ((kPvDenseGap - 1) << 4)) : kPvPollGap;
         ctx->f.wg_poll_gap = gap |
                              ((ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : dense ? kPvDensePreSleep : kPvPreSleep) << 8) |
-                             ((ctx->L.wg_per_xcd > 0) ? (1 << 30) : 0);
+                             0;
         ctx->f.rec_off = nullptr, ctx->f.place_pool = nullptr;
-        if (ctx->opt_place && ctx->L.wg_per_xcd == 0 && groups.size() == 1 && gr.begin == 0 && xcds == 8 && (dual & 1)) {
+        if (ctx->opt_place && groups.size() == 1 && gr.begin == 0 && xcds == 8 && (dual & 1)) {
           if (ctx->place_state == 0) {
             rc = place_calibrate(ctx);
             if (rc) return rc;
@@ -1042,30 +1039,22 @@ int staged_h2d(flame_nltgv2_ctx* ctx, const StageCopy* cp, size_t n, const Stage
   return 0;
 }
 
-// Shadow patches (nltgv2_pack.hpp) are opt-in.  Copying every border patch was worth 3.6 % (5 graphs each at 320x240 and
-// 640x480) but left a hole in the record exchange's flow control (a soak caught a shadow re-reading a record two steps
-// stale); with the rules that close it -- fewer copies, four record buffers -- the same-box A/B at 640x480 is 1.274 ->
-// 1.260 us per iteration on average over three graphs (-4.5 %, +1.5 %, 0 %), for ~0.15 ms more host time per topology.
-int shadow_mode(const flame_nltgv2_ctx* ctx, bool long_lived) {
-  (void)long_lived;
-  return ctx->opt_shadows == 2 ? 2 : 0;
-}
-int shadow_cap(const flame_nltgv2_ctx* ctx) { return ctx->opt_shadows ? 0x7fffffff : 4 * ctx->prop.multiProcessorCount; }
-
 // Layout + topology arrays of `g` (V, E, pos, src, dst) onto the device; the caller adds the state.  On return the
 // stream still holds the copies: the caller synchronises before the staging buffer or `g`'s arrays may change.
 int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const StageCopy* extra, size_t n_extra, bool long_lived) {
   const int32_t V = g->V, E = g->E;
-  const int sm = shadow_mode(ctx, long_lived);
-  int rc = build_layout(g, &ctx->L, /*host_expand=*/false, sm, shadow_cap(ctx), /*rowpack=*/ctx->opt_rowpack != 0,
-                        /*rowpack_max_patches=*/kPvDensePerCu * ctx->prop.multiProcessorCount);
+  (void)long_lived;
+  int rc = build_layout(g, &ctx->L, /*host_expand=*/false, /*rowpack=*/true,
+                        /*rowpack_max_patches=*/ctx->opt_persistent == 4 ? 0x7fffffff : kPvDensePerCu * ctx->prop.multiProcessorCount);
   if (rc) return fail(ctx, rc);
   // Row packing costs ~15 % more waves than lanes back to back.  It pays where the patch-per-wave kernel runs them; a layout
   // that turns out too large for that kernel (more patches than the estimate, or a vertex of more than 16 edges, whose
   // instance of the kernel keeps 12 patches per CU) is better off back to back, for the lane-per-half-edge form.
-  if (ctx->L.wg_ok && ctx->L.wg_rowpack &&
+  // (FLAME_NLTGV2_OPT_PERSISTENT 4 -- the patch-per-wave form asked for by name -- keeps the row-packed layout whatever the
+  //  size: the kernel then runs it as groups of whole components)
+  if (ctx->L.wg_ok && ctx->L.wg_rowpack && ctx->opt_persistent != 4 &&
       ctx->L.wg_count > (ctx->L.wg_slab_slots > 0 ? 4 * pv_real_waves_per_simd(2, false) : kPvDensePerCu) * ctx->prop.multiProcessorCount) {
-    rc = build_layout(g, &ctx->L, /*host_expand=*/false, sm, shadow_cap(ctx), /*rowpack=*/false, 0);
+    rc = build_layout(g, &ctx->L, /*host_expand=*/false, /*rowpack=*/false, 0);
     if (rc) return fail(ctx, rc);
   }
   const PackedLayout& L = ctx->L;
@@ -1085,7 +1074,7 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
       {&ctx->hq_alt, sizeof(float4) * n_slots}, {&ctx->vstate_alt, sizeof(float4) * n_packed}, {&ctx->photo_err, fV},
       {&ctx->bar0, sizeof(float4) * n_packed}, {&ctx->bar1, sizeof(float4) * n_packed},
       {&ctx->vprev, sizeof(float4) * n_packed}, {&ctx->xbuf, kXbufBytesPerVertex * records_capacity(L) + 64},
-      {&ctx->wg_v0, sizeof(int32_t) * L.wg_v0.size()}, {&ctx->rid_on, sizeof(int32_t) * L.rid_on.size()},
+      {&ctx->wg_v0, sizeof(int32_t) * L.wg_v0.size()},
       {&ctx->wg_vfirst, L.wg_vfirst.size() + 16}, {&ctx->abort_flag, sizeof(int)}, {&ctx->err, kErrBytes}, {&ctx->cost_out, 2 * sizeof(float)},
       {&ctx->wg_slot, sizeof(int32_t) * lanes}, {&ctx->wg_vid, sizeof(int32_t) * lanes}, {&ctx->wg_meta, sizeof(uint32_t) * lanes},
       {&ctx->wg_nbr, sizeof(int32_t) * lanes}, {&ctx->wg_fetch, sizeof(int32_t) * lanes},
@@ -1106,7 +1095,7 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
       {&ctx->perm, L.perm.data(), sizeof(int32_t) * n_packed}, {&ctx->pdeg, L.pdeg.data(), sizeof(int32_t) * n_packed},
       {&ctx->iperm, L.iperm.data(), iV}, {&ctx->order_m, L.order_m.data(), iV}, {&ctx->rid_of, L.rid_of.data(), iV},
       {&ctx->wg_info, L.wg_info.data(), sizeof(int32_t) * L.wg_info.size()},
-      {&ctx->wg_v0, L.wg_v0.data(), sizeof(int32_t) * L.wg_v0.size()}, {&ctx->rid_on, L.rid_on.data(), sizeof(int32_t) * L.rid_on.size()},
+      {&ctx->wg_v0, L.wg_v0.data(), sizeof(int32_t) * L.wg_v0.size()},
       {&ctx->wg_vfirst, L.wg_vfirst.data(), L.wg_vfirst.size()}};
   cp.insert(cp.end(), extra, extra + n_extra);
   std::vector<StageFill> fills = {
@@ -1126,12 +1115,11 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
   LAUNCHCHK(ctx, launch_build_sell(ctx->c, ctx->f, (const int32_t*)ctx->iperm.p, ctx->stream));
   if (L.wg_ok)
     LAUNCHCHK(ctx, launch_build_patches(ctx->c, ctx->f, (const int32_t*)ctx->wg_v0.p, (const int32_t*)ctx->order_m.p,
-                                        (const int32_t*)(L.wg_per_xcd ? ctx->rid_on.p : ctx->rid_of.p), (const uint8_t*)ctx->wg_vfirst.p,
-                                        L.wg_per_xcd,
+                                        (const int32_t*)ctx->rid_of.p, (const uint8_t*)ctx->wg_vfirst.p,
                                         (const int32_t*)ctx->iperm.p, ctx->stream));
   // where the records that cross XCDs go (if the pages have been timed already; otherwise the first run does both): on
   // the stream behind the layout kernels, nobody waits for it
-  if (L.wg_ok && ctx->place_state == 1 && ctx->opt_place && L.wg_per_xcd == 0 && L.wg_count > 2 * (ctx->prop.multiProcessorCount / 8) &&
+  if (L.wg_ok && ctx->place_state == 1 && ctx->opt_place && L.wg_count > 2 * (ctx->prop.multiProcessorCount / 8) &&
       (ctx->opt_xcds == 0 || ctx->opt_xcds == 8)) {
     refresh_args(ctx);
     rc = place_records(ctx, (L.wg_count + 7) / 8);
@@ -1150,23 +1138,6 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
 // the current topology (single frames run in the patch-per-wave form and never need them).
 int ensure_form_rows(flame_nltgv2_ctx* ctx, int form) {
   PackedLayout& L = ctx->L;
-  if (form == 1 && !ctx->he_built && L.wg_per_xcd > 0) {
-    // a shadow layout holds more instances than the walk has patches: (C) comes from the host's own walk then
-    build_he_rows(&L);
-    struct { DevBuf* b; const void* src; size_t bytes; } cp[] = {
-        {&ctx->he_slot, L.he_slot.data(), sizeof(int32_t) * L.he_slot.size()}, {&ctx->he_vid, L.he_vid.data(), sizeof(int32_t) * L.he_vid.size()},
-        {&ctx->he_meta, L.he_meta.data(), sizeof(uint32_t) * L.he_meta.size()},
-        {&ctx->he_wave_chain, L.he_wave_chain.data(), sizeof(int32_t) * L.he_wave_chain.size()}};
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (a buffer may be reallocated)
-    for (auto& c : cp) {
-      int rc = ensure(ctx, *c.b, c.bytes);
-      if (!rc) rc = h2d(ctx, *c.b, c.src, c.bytes);
-      if (rc) return rc;
-    }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->he_built = true;
-    refresh_args(ctx);
-  }
   if (form == 1 && !ctx->he_built) {
     // (C) is (E) lane for lane (the same greedy walk): converted on the device from the patch rows, no host work
     const size_t lanes = (size_t)L.wg_count * kWave;
@@ -1261,7 +1232,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
               &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->xbuf, &ctx->abort_flag, &ctx->he_slot, &ctx->he_vid, &ctx->he_meta, &ctx->he_wave_chain, &ctx->tv_slot, &ctx->tv_vid, &ctx->tv_meta, &ctx->tv_wave, &ctx->err,
               &ctx->cost_out, &ctx->img_ref, &ctx->img_cmp, &ctx->photo_err, &ctx->r_tris, &ctx->r_valid, &ctx->r_keys,
               &ctx->r_img, &ctx->r_cov, &ctx->r_vtx, &ctx->r_val, &ctx->wg_slot, &ctx->wg_vid, &ctx->wg_meta, &ctx->wg_nbr,
-              &ctx->wg_fetch, &ctx->wg_info, &ctx->wg_v0, &ctx->rid_on, &ctx->probe, &ctx->snap_hq, &ctx->snap_vstate, &ctx->snap_bar, &ctx->iperm,
+              &ctx->wg_fetch, &ctx->wg_info, &ctx->wg_v0, &ctx->probe, &ctx->snap_hq, &ctx->snap_vstate, &ctx->snap_bar, &ctx->iperm,
               &ctx->order_m, &ctx->rid_of, &ctx->d_stage, &ctx->sync_init, &ctx->sync_vmap, &ctx->sync_emap, &ctx->sync_need,
               &ctx->wg_vfirst, &ctx->place_pool, &ctx->place_rank, &ctx->place_fill, &ctx->place_rec_off, &ctx->place_patch, &ctx->place_meas, &ctx->progress};
   for (auto& b : ctx->sp_v) ctx->all.push_back(&b);
@@ -1312,14 +1283,6 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
     case FLAME_NLTGV2_OPT_PERSISTENT:
       if (value < 0 || value > 4) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_persistent = value;
-      return 0;
-    case FLAME_NLTGV2_OPT_SHADOWS:
-      if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-      ctx->opt_shadows = value;
-      return 0;
-    case FLAME_NLTGV2_OPT_ROWPACK:
-      if (value < 0 || value > 1) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-      ctx->opt_rowpack = value;
       return 0;
     case FLAME_NLTGV2_OPT_PLACEMENT:
       if (value < 0 || value > 1) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
@@ -2044,13 +2007,13 @@ int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info) {
   std::snprintf(info->device_name, sizeof(info->device_name), "%s", ctx->prop.name);
   std::snprintf(info->gcn_arch, sizeof(info->gcn_arch), "%s", ctx->prop.gcnArchName);
   info->last_run_path = ctx->last_run_path;
-  info->he_waves = ctx->L.wg_ok ? ctx->L.wg_prim : 0;  // (the same greedy walk as the patches)
+  info->he_waves = ctx->L.wg_ok ? ctx->L.wg_count : 0;  // (the same greedy walk as the patches)
   if (ctx->have_graph && !ctx->tv_built) {  // the vertex-per-lane rows are built on demand; a caller sizing a batch asks here
     ctx->L.tv_waves = 0;
     build_tv_rows(&ctx->L);  // host table only; the upload happens when the form is first used
   }
   info->tv_waves = ctx->L.tv_ok ? ctx->L.tv_waves : 0;
-  info->patches = ctx->L.wg_ok ? ctx->L.wg_count : 0;  // (instances: with shadow patches more than the walk's patches)
+  info->patches = ctx->L.wg_ok ? ctx->L.wg_count : 0;
   info->tv_wave_capacity = (ctx->opt_tv_lds ? kTvLdsWavesPerCu : kTvWavesPerCu) * ctx->prop.multiProcessorCount;
   info->last_run_groups = ctx->last_run_groups;
   info->timeouts_recovered = ctx->timeouts_recovered;
@@ -2094,7 +2057,7 @@ int flame_nltgv2_layout_selftest(flame_nltgv2_ctx* ctx, int64_t* mismatches) {
   flame_nltgv2_graph g{};
   g.V = V, g.E = E, g.pos = pos.data(), g.src = ctx->h_src.data(), g.dst = ctx->h_dst.data();
   PackedLayout H;
-  rc = build_layout(&g, &H, /*host_expand=*/true, ctx->L.shadow_mode, 0x7fffffff, ctx->L.wg_rowpack);  // (the modes the layout was actually built with)
+  rc = build_layout(&g, &H, /*host_expand=*/true, ctx->L.wg_rowpack);  // (the modes the layout was actually built with)
   if (rc) return fail(ctx, rc);
   int64_t bad = 0;
   auto cmp = [&](const DevBuf& b, const void* host, size_t bytes) -> int {
@@ -2107,8 +2070,8 @@ int flame_nltgv2_layout_selftest(flame_nltgv2_ctx* ctx, int64_t* mismatches) {
   };
   const PackedLayout& L = ctx->L;
   bad += (H.rows != L.rows) + (H.n_slices != L.n_slices) + (H.wg_ok != L.wg_ok) + (H.wg_count != L.wg_count) +
-         (H.wg_lcap != L.wg_lcap) + (H.wg_slab_slots != L.wg_slab_slots) + (H.n_rec != L.n_rec) + (H.wg_per_xcd != L.wg_per_xcd) +
-         (H.wg_v0 != L.wg_v0) + (H.rid_on != L.rid_on) + (H.wg_vfirst != L.wg_vfirst) + (H.wg_rowpack != L.wg_rowpack);
+         (H.wg_lcap != L.wg_lcap) + (H.wg_slab_slots != L.wg_slab_slots) + (H.n_rec != L.n_rec) +
+         (H.wg_v0 != L.wg_v0) + (H.wg_vfirst != L.wg_vfirst) + (H.wg_rowpack != L.wg_rowpack);
   if (bad == 0) {
     const size_t n = (size_t)L.rows * kWave, lanes = (size_t)L.wg_count * kWave;
     int e = cmp(ctx->rec_nbr, H.rec_nbr.data(), 4 * n) | cmp(ctx->rec_edge, H.rec_edge.data(), 4 * n) |
@@ -2125,7 +2088,7 @@ int flame_nltgv2_layout_selftest(flame_nltgv2_ctx* ctx, int64_t* mismatches) {
     if (ctx->he_built) bad += (H.he_waves != L.he_waves) + (H.he_max_chain != L.he_max_chain) + (H.comp_he_wave != L.comp_he_wave);
     if (e) return fail(ctx, FLAME_NLTGV2_ERR_HIP);
   }
-  if (bad == 0 && ctx->place_state == 1 && ctx->place_topo == ctx->topo && L.wg_per_xcd == 0 && L.wg_ok) {
+  if (bad == 0 && ctx->place_state == 1 && ctx->place_topo == ctx->topo && L.wg_ok) {
     // placed records: aligned, inside their parity's half of the pool, no slot given out twice -- and exactly the records a
     // patch on another XCD reads (host: the same rule as k_place_assign, from the host's own patch walk)
     const size_t stride = records_capacity(L);

@@ -101,7 +101,7 @@ struct FusedArgs {
   int32_t* wg_nbr = nullptr;
   int32_t* wg_fetch = nullptr;
   int32_t* wg_info = nullptr;
-  int n_rec = 0;                       // record ids in use (>= V; more with shadow patches): sizes the exchange buffers
+  int n_rec = 0;                       // record ids in use (= V): sizes the exchange buffers
   int wg_poll_gap = 1;                 // 1: one s_sleep between the polls of k_persistent_pv, 0: none
   char* place_pool = nullptr;          // record placement (nltgv2_layout.hip): pool of pages for the remote copies of the
   const int32_t* rec_off = nullptr;    // records other XCDs read; rec_off[parity * stride + record] = byte offset or -1
@@ -168,7 +168,7 @@ int launch_build_sell(const CanonArgs& c, const FusedArgs& a, const int32_t* ipe
 int launch_he_from_patches(const FusedArgs& a, int32_t* he_slot, int32_t* he_vid, uint32_t* he_meta, int32_t* he_wave_chain,
                            hipStream_t s);
 int launch_build_patches(const CanonArgs& c, const FusedArgs& a, const int32_t* wg_v0, const int32_t* order_m,
-                         const int32_t* rid_tab, const uint8_t* vfirst, int wg_per_xcd, const int32_t* iperm, hipStream_t s);
+                         const int32_t* rid_tab, const uint8_t* vfirst, const int32_t* iperm, hipStream_t s);
 int launch_save_prev(const CanonArgs& c, hipStream_t s);
 int launch_dual(const CanonArgs& c, const SolverParams& p, hipStream_t s);
 int launch_primal(const CanonArgs& c, const SolverParams& p, hipStream_t s);

@@ -572,7 +572,7 @@ k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd
 //              the contribution of lane first + j with the DPP row shift of a plain add, EXEC masks (moved in by the scalar
 //              unit, computed once per launch) say which heads a shift may still write; the other lanes take (x_bar, w_bar)
 //              of their vertex from the record its head leaves in LDS.  ~26 cycles per shift, no LDS in the hand-off path.
-//              Back-to-back patches (a vertex of more than 16 edges, or FLAME_NLTGV2_OPT_ROWPACK 0) -- EVERY lane of the
+//              Back-to-back patches (those that hold a vertex of more than 16 edges) -- EVERY lane of the
 //              vertex adds up an LDS slab of `stride` contribution slots per vertex (the patch's largest degree rounded up to
 //              4, at least 8) whose unused slots hold -0.0f (x + -0.0f == x for every x): all lanes of a vertex hold
 //              bit-identical state at all times, ~70 cycles per slot.
@@ -607,9 +607,10 @@ __device__ __forceinline__ void report_expired(int* err, int which, int wg, int 
   }
 }
 
-// LAYOUT: 0 = every patch back to back, LDS-slab accumulation; 1 = every patch row-packed, DPP accumulation; 2 = row-packed
-// with back-to-back patches among them (where a vertex has more than 16 edges): both schemes compiled in, chosen per patch --
-// a separate instance because carrying the slab code costs the all-row-packed case 3-5 % (registers, code layout; measured)
+// LAYOUT: 1 = every patch row-packed, DPP accumulation; 2 = row-packed with back-to-back patches among them (where a vertex has
+// more than 16 edges): both schemes compiled in, chosen per patch -- a separate instance because carrying the slab code costs
+// the all-row-packed case 3-5 % (registers, code layout; measured).  (Layouts that are not row-packed at all -- too large for
+// this kernel -- run in the lane-per-half-edge form.)
 template <bool PROBE, int LAYOUT, bool VERIFY>
 __global__ void __launch_bounds__(64)
 k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, const int lcap, const int slab_slots,
@@ -661,16 +662,15 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   const int wg = wg_begin + xcd * wgs_per_xcd + idx;  // this launch covers patches [wg_begin, +n_wgs)
   const int rid_base = wg_info[4 * wg], n_fetch = wg_info[4 * wg + 1];
   const int count_flags = wg_info[4 * wg + 2];
-  if ((count_flags & 0xffff) == 0) return;                 // idle padding behind an XCD's instances (shadow layouts)
+  if ((count_flags & 0xffff) == 0) return;                 // (a patch without a vertex: nothing to do)
   if (unsigned* const pg = tail->progress) {               // (trace runs only) when this patch started, in us of the 100 MHz clock
     if (lane == 0) pg[n_wgs + (wg - wg_begin)] = (unsigned)(wall_clock64() / 100u) | 1u;
   }
   // RIPPLE layouts: a patch that holds a vertex of more than 16 edges is laid out back to back and accumulates through the
   // LDS slab like the other kernel variant does for every patch (wave-uniform)
-  constexpr bool RIPPLE = LAYOUT != 0;
-  const bool slab = LAYOUT == 0 || (LAYOUT == 2 && (count_flags & (1 << 17)) != 0);
-  const bool shadow = (count_flags & (1 << 16)) != 0;      // a second copy of a patch on another XCD: computes and
-                                                           // publishes like the original, writes no state back
+  static_assert(LAYOUT == 1 || LAYOUT == 2, "row-packed layouts only");
+  constexpr bool RIPPLE = true;
+  const bool slab = LAYOUT == 2 && (count_flags & (1 << 17)) != 0;
   // Contribution slab: `stride` slots per vertex of this patch (its largest degree rounded up to a multiple of 4, at least 8); the
   // slots a vertex does not use hold -0.0f for the whole run, so the accumulation needs no predication.
   const int stride = wg_info[4 * wg + 3];
@@ -688,13 +688,9 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   // hand-off through the fabric takes 0.39-0.66 us depending on the page); rec_off[parity][record] is its byte offset in
   // the pool, negative = the linear place.
 
-  // Memory side of the exchange: FOUR buffers by step (tag & 3), each [remote copy S bytes | same-XCD copy S bytes], then
-  // the XCC table.  Two would do between instances that read each other (a record of step s is only overwritten by s+2
-  // after every reader published s+1, i.e. consumed s); a shadow patch is read by, but does not read, some of its
-  // producers -- those wait for it through a chain of up to three instances (nltgv2_pack.hpp), so the overwrite has to
-  // be four steps away.
-  // (Without shadow patches the layout asks for two.)
-  const int kPar = (poll_gap_arg >> 30) & 1 ? 4 : 2;
+  // Memory side of the exchange: TWO buffers by step parity, each [remote copy S bytes | same-XCD copy S bytes], then the XCC
+  // table (a record of step s is only overwritten by s + 2 after every reader published s + 1, i.e. consumed s).
+  constexpr int kPar = 2;
   const int S = rec_bytes, par = 2 * rec_bytes, tab_off = kPar * par;
   const unsigned xcc_want = (tag0 & 0x0fffffffu) << 4;
   const unsigned p0 = tag0 & 1u;  // parity of the first step: its records live in area p0
@@ -812,8 +808,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   const bool mute = (max_spins_arg >> 31) != 0u && wg == wg_begin;  // test hook: FLAME_NLTGV2_OPT_FAULT_INJECT
   const bool pub_lane = state_lane && publishes;
   const char* const xb_base = static_cast<const char*>(xbuf);
-  // by parity of the record's step (two buffers; with shadow patches -- four -- nothing is placed)
-  const bool placed = place_pool != nullptr && kPar == 2;
+  const bool placed = place_pool != nullptr;
   int pub0 = -1, pub1 = -1;
   const char* src0 = xb_base + off0;
   const char* src1 = xb_base + off0 + par;
@@ -831,7 +826,6 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   char* const pa0 = pub0 >= 0 ? place_pool + pub0 : xb_w + my_off;
   char* const pa1 = pub1 >= 0 ? place_pool + pub1 : xb_w + my_off + par;
   auto publish = [&](const v4i_t o, char* pa, const int so) {  // (pub lanes only)
-    if (kPar != 2) pa = xb_w + my_off + so;  // (four buffers: the step's, linear)
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(pa), "v"(o) : "memory");
     if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
   };
@@ -857,9 +851,9 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
     // record the head left in LDS at the end of the previous step (read here, ahead of the wait: off the critical path)
     float4 own = make_float4(0.f, 0.f, 0.f, 0.f);
     if (RIPPLE) own = lds[rd_rec];
-    const int so_in = (int)(s & (kPar - 1)) * par, so_out = (int)((s + 1u) & (kPar - 1)) * par;  // (wave-uniform)
+    const int so_out = (int)((s + 1u) & (kPar - 1)) * par;  // (wave-uniform)
     // two buffers: the step's parity is fixed at the call site (src2: where this lane polls, pub2: where it publishes)
-    const char* const src = kPar == 2 ? src2 : xb_base + off0 + so_in;
+    const char* const src = src2;
     // ---- wait for the neighbours' records of step s ----------------------------------------------------------------
     v4f_t nbv;  // the tag word is read first, the record after it: a tag that matches vouches for the payload
     unsigned rounds = 0;
@@ -1135,7 +1129,6 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
     return;
   }
 
-  if (shadow) return;
   if (state_lane) {
     vstate_out[pv] = make_float4(x, w12.x, w12.y, data);
     bar_out[pv] = make_float4(xb, wb12.x, wb12.y, 0.0f);
@@ -1859,7 +1852,7 @@ int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, boo
 // from above (it knows the LDS use, which varies with the layout).
 int pv_real_waves_per_simd(int layout, bool verify_or_probe) {
   // {VGPRs, SGPRs} -> waves: LAYOUT 1 plain {65, 106} -> min(7, 6); verify / probe {75-81, 106} -> min(5, 6);
-  // LAYOUT 0 / 2 (slab code compiled in) {156-165, 106} -> 3
+  // LAYOUT 2 (slab code compiled in) {157-165, 106} -> 3
   return layout == 1 ? (verify_or_probe ? 5 : 6) : 3;
 }
 
@@ -1867,9 +1860,9 @@ int pv_patches_per_cu(const FusedArgs& a, bool verify) {
   const size_t ldsv = 16u * (size_t)(2 * (a.wg_lcap + 64) + a.wg_slab_slots + 64) + 4u * (size_t)(a.wg_slab_slots + 64);
   int n = 0;
   const int layout = !a.wg_rowpack ? 0 : a.wg_slab_slots > 0 ? 2 : 1;
-  const void* fv = layout == 0 ? (verify ? (const void*)k_persistent_pv<false, 0, true> : (const void*)k_persistent_pv<false, 0, false>)
-                   : layout == 2 ? (verify ? (const void*)k_persistent_pv<false, 2, true> : (const void*)k_persistent_pv<false, 2, false>)
-                                 : (verify ? (const void*)k_persistent_pv<false, 1, true> : (const void*)k_persistent_pv<false, 1, false>);
+  if (layout == 0) return 0;  // (not row-packed: the lane-per-half-edge form's layout)
+  const void* fv = layout == 2 ? (verify ? (const void*)k_persistent_pv<false, 2, true> : (const void*)k_persistent_pv<false, 2, false>)
+                               : (verify ? (const void*)k_persistent_pv<false, 1, true> : (const void*)k_persistent_pv<false, 1, false>);
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fv, 64, ldsv) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
@@ -1934,9 +1927,8 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
 #define PV_PICK(LY)                                                                                                         \
   fv = probe ? (const void*)k_persistent_pv<true, LY, true>                                                                 \
              : vr ? (const void*)k_persistent_pv<false, LY, true> : (const void*)k_persistent_pv<false, LY, false>
-    if (layout == 0) {
-      PV_PICK(0);
-    } else if (layout == 1) {
+    if (layout == 0) return (int)hipErrorInvalidConfiguration;  // (the planner never asks: the kernel runs row-packed patches)
+    if (layout == 1) {
       PV_PICK(1);
     } else {
       PV_PICK(2);

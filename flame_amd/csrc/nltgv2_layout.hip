@@ -55,15 +55,14 @@ k_build_sell(const int n_packed, const int32_t* __restrict__ perm, const int32_t
   }
 }
 
-// (E) lanes: one wave per patch instance.  Host input per instance: wg_info[4p] = its first record id, wg_info[4p+2] = its
-// vertex count (| kWgShadow), wg_v0[p] = position in the walk of its first vertex (= the record id for a primary);
-// order_m = the walk (caller's vertex ids); rid_tab = the record an instance reads for a vertex: rid_of (inverse of the
-// walk), or with shadow patches the table of the instance's XCD (p / wg_per_xcd), V entries each.
-// Output: the 64 lanes of the instance (wg_slot, wg_vid, wg_meta, wg_nbr), its fetch list (wg_fetch: the DISTINCT records
-// of other instances it reads, ascending) and wg_info[4p+1] = their number.
+// (E) lanes: one wave per patch.  Host input per patch: wg_info[4p] = its first record id, wg_info[4p+2] = its vertex count
+// (| kWgSlab), wg_v0[p] = position in the walk of its first vertex (= that record id); order_m = the walk (caller's vertex
+// ids); rid_tab = rid_of, the inverse of the walk: the record of a vertex.
+// Output: the 64 lanes of the patch (wg_slot, wg_vid, wg_meta, wg_nbr), its fetch list (wg_fetch: the DISTINCT records
+// of other patches it reads, ascending) and wg_info[4p+1] = their number.
 __global__ void __launch_bounds__(64)
 k_build_patch(const int n_patches, int32_t* __restrict__ wg_info, const int32_t* __restrict__ wg_v0, const int32_t* __restrict__ order_m,
-              const int32_t* __restrict__ rid_tab, const uint8_t* __restrict__ vfirst, const int V, const int wg_per_xcd,
+              const int32_t* __restrict__ rid_tab, const uint8_t* __restrict__ vfirst, const int V,
               const int32_t* __restrict__ iperm,
               const int32_t* __restrict__ slice_row,
               const int32_t* __restrict__ row_ptr, const uint32_t* __restrict__ half, const int32_t* __restrict__ src,
@@ -74,7 +73,7 @@ k_build_patch(const int n_patches, int32_t* __restrict__ wg_info, const int32_t*
   if (p >= n_patches) return;
   const int lane = threadIdx.x;
   const int r0 = wg_info[4 * p], n_local = wg_info[4 * p + 2] & 0xffff, v0 = wg_v0[p];
-  const int32_t* __restrict__ rid_of = rid_tab + (wg_per_xcd ? (size_t)(p / wg_per_xcd) * V : 0);
+  const int32_t* __restrict__ rid_of = rid_tab;
   // vertex j of the patch -> its first lane (an isolated vertex still owns one lane)
   int o = -1, deg = 0, need = 0;
   if (lane < n_local) {
@@ -379,10 +378,10 @@ int launch_place_records(const CanonArgs& c, const FusedArgs& a, int per_xcd, co
 }
 
 int launch_build_patches(const CanonArgs& c, const FusedArgs& a, const int32_t* wg_v0, const int32_t* order_m,
-                         const int32_t* rid_tab, const uint8_t* vfirst, int wg_per_xcd, const int32_t* iperm, hipStream_t s) {
+                         const int32_t* rid_tab, const uint8_t* vfirst, const int32_t* iperm, hipStream_t s) {
   if (a.wg_count <= 0) return 0;
   hipLaunchKernelGGL(k_build_patch, dim3((unsigned)a.wg_count), dim3(64), 0, s, a.wg_count, a.wg_info, wg_v0, order_m, rid_tab, vfirst,
-                     c.V, wg_per_xcd, iperm, a.slice_row, c.row_ptr, c.half, c.src, c.dst, a.wg_slot, a.wg_vid, a.wg_meta, a.wg_nbr,
+                     c.V, iperm, a.slice_row, c.row_ptr, c.half, c.src, c.dst, a.wg_slot, a.wg_vid, a.wg_meta, a.wg_nbr,
                      a.wg_fetch);
   return (int)hipGetLastError();
 }

@@ -95,7 +95,7 @@ struct PackedLayout {
   std::vector<uint32_t> wg_meta;       // [wg_count*64] first lane | deg<<6 | local index<<13 | flags<<24
   std::vector<int32_t> wg_nbr;         // [wg_count*64] neighbour: local index, or 0x80000000 | fetch index
   std::vector<int32_t> wg_fetch;       // [wg_count*64] record id fetched by this lane, -1 none
-  std::vector<int32_t> wg_info;        // [wg_count*4] first record id, fetched records, local vertices (| kWgShadow), slab stride
+  std::vector<int32_t> wg_info;        // [wg_count*4] first record id, fetched records, local vertices (| kWgSlab), slab stride
                                        //               (row-packed patches: the patch's largest degree instead)
   // Row-packed patches (wg_rowpack): a vertex's lanes lie inside one 16-lane row of the wave (the walk fits each vertex into
   // the first of the wave's four rows that has room; one of more than 8 edges gets a row to itself), which is what lets the
@@ -105,23 +105,9 @@ struct PackedLayout {
   bool wg_rowpack = false;
   std::vector<uint8_t> wg_vfirst;
   std::vector<int32_t> comp_wg;        // [n_comp+1] first patch of each component
-  // Shadow patches (shadow_mode > 0, 65..2048 patches: graphs that run resident as a whole, spread over all XCDs):
-  // the chip is eight XCDs and a record crosses from one to another later than it reaches a reader on its own XCD; the
-  // lock-step network runs at its worst cycle mean, and that is a pair of patches on two XCDs reading each other.  A patch
-  // next to the border (higher-numbered side) is therefore ALSO computed by a second wave on the neighbouring XCD (same
-  // vertices, same inputs, same instructions -> bit-identical records under its own record ids), and that XCD's patches
-  // read the copy instead of the original: the cycles through the border then contain one crossing per two hand-offs
-  // instead of one per hand-off.  Instances are ordered XCD by XCD (the XCD's own patches in walk order, then its
-  // shadows, then idle padding), wg_per_xcd each; a shadow does not write state back.  build_patch_rows has the rules
-  // that keep the record exchange's flow control sound with them.
-  int32_t shadow_mode = 0;
-  int32_t wg_prim = 0;                 // patches of the walk (wg_count - shadows - padding)
-  int32_t wg_per_xcd = 0;              // instances per XCD when shadows exist, else 0
-  int32_t n_rec = 0;                   // record ids in use: V + shadow vertices
-  std::vector<int32_t> wg_v0;          // [wg_count] walk position of the instance's first vertex (= first record id for a primary)
-  std::vector<int32_t> rid_on;         // [8*V] with shadows: the record id an instance on XCD k reads for vertex u (k*V + u)
+  int32_t n_rec = 0;                   // record ids in use (= V: a record's id is its vertex's position in the walk)
+  std::vector<int32_t> wg_v0;          // [wg_count] walk position of the patch's first vertex (= its first record id)
 };
-constexpr int32_t kWgShadow = 1 << 16;  // in wg_info[4p+2]
 constexpr int32_t kWgSlab = 1 << 17;    // in wg_info[4p+2], row-packed layouts: this patch is not (it holds a vertex of > 16 edges)
 constexpr uint32_t kWgTail = 1u << 24, kWgActive = 1u << 25, kWgValid = 1u << 26, kWgPublish = 1u << 27, kWgHead = 1u << 28;
 constexpr int32_t kWgRow = 16;  // lanes of a DPP row
@@ -296,8 +282,7 @@ inline void build_tv_rows(PackedLayout* L) {
 // ---- (E) patch-per-wave rows ------------------------------------------------------------------------
 // order_m = the vertices in (component, Morton) order; needs (B) (iperm, pdeg, slice_row, rec_nbr) and comp_start.
 inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const std::vector<int32_t>& order_m, bool host_expand,
-                             int shadow_mode = 0, int shadow_max_instances = 0x7fffffff, bool rowpack = true,
-                             int rowpack_max_patches = 0x7fffffff) {
+                             bool rowpack = true, int rowpack_max_patches = 0x7fffffff) {
   (void)g;
   const int32_t V = L->V;
   constexpr int32_t T = kWave;
@@ -305,8 +290,8 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
   L->wg_count = 0, L->wg_lcap = 0, L->wg_rcap = 0, L->wg_slab_slots = 0;
   L->wg_slot.clear(), L->wg_vid.clear(), L->wg_meta.clear(), L->wg_nbr.clear(), L->wg_fetch.clear();
   L->wg_info.clear(), L->comp_wg.clear();
-  L->shadow_mode = 0, L->wg_prim = 0, L->wg_per_xcd = 0, L->n_rec = V;
-  L->wg_v0.clear(), L->rid_on.clear();
+  L->n_rec = V;
+  L->wg_v0.clear();
   L->wg_vfirst.clear();
   // (row packing fills a wave to ~54 of its 64 lanes: more, smaller patches.  That pays where a patch has a SIMD to itself
   //  or nearly; a graph too big for the patch-per-wave form keeps its lanes back to back, for the forms that then run it)
@@ -357,130 +342,8 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
   }
   close_patch();
   L->comp_wg.push_back(L->wg_count);
-  L->wg_prim = L->wg_count;
   L->wg_v0.resize(static_cast<size_t>(L->wg_count));
   for (int32_t q = 0; q < L->wg_count; ++q) L->wg_v0[static_cast<size_t>(q)] = L->wg_info[static_cast<size_t>(q) * 4];
-  constexpr int32_t kXcds = 8;
-  // (graphs that are resident as a whole anyway -- components are then not needed for grouping; not the one-XCD sizes.
-  //  shadow_mode 1 = where it pays: from 512 patches on -- a smaller graph's XCD regions are a few patches across, most border
-  //  patches touch three of them and are not copied, and the rest costs more than it saves: 320x240 1.148 -> 1.179 us;
-  //  shadow_mode 2 = whenever possible)
-  if (shadow_mode > 0 && L->wg_count > 2 * 32 && L->wg_count <= 2048 && (shadow_mode >= 2 || L->wg_count >= 512)) {
-    // ---- shadow patches (see PackedLayout) -----------------------------------------------------------------------
-    const int32_t P = L->wg_count;
-    std::vector<int32_t> patch_of_vertex(static_cast<size_t>(V));  // by the caller's vertex id
-    for (int32_t q = 0; q < P; ++q) {
-      const int32_t r0 = L->wg_info[static_cast<size_t>(q) * 4], n = L->wg_info[static_cast<size_t>(q) * 4 + 2] & 0xffff;
-      for (int32_t j = 0; j < n; ++j) patch_of_vertex[static_cast<size_t>(order_m[static_cast<size_t>(r0 + j)])] = q;
-    }
-    // XCD k owns the patches [cut[k], cut[k+1]) of the walk.  Shadows land unevenly (an XCD in the middle of the image has
-    // more borders), and a wave wants a SIMD of its own (an XCD has 128): the cuts are moved until own patches + shadows
-    // are about the same everywhere.
-    int32_t cut[kXcds + 1];
-    for (int32_t k = 0; k <= kXcds; ++k) cut[k] = static_cast<int32_t>(static_cast<int64_t>(P) * k / kXcds);
-    std::vector<uint8_t> region(static_cast<size_t>(P)), need(static_cast<size_t>(P)), touches(static_cast<size_t>(P));
-    // which patches a patch reads, once (the rounds below only look at regions): distinct neighbours, ~6 per patch
-    std::vector<int32_t> adj_ptr(static_cast<size_t>(P) + 1, 0), adj, stamp(static_cast<size_t>(P), -1);
-    adj.reserve(static_cast<size_t>(P) * 8);
-    for (int32_t q = 0; q < P; ++q) {
-      const int32_t r0 = L->wg_info[static_cast<size_t>(q) * 4], n = L->wg_info[static_cast<size_t>(q) * 4 + 2] & 0xffff;
-      stamp[static_cast<size_t>(q)] = q;
-      for (int32_t j = 0; j < n; ++j) {
-        const int32_t o = order_m[static_cast<size_t>(r0 + j)];
-        for (int32_t h = L->row_ptr[o]; h < L->row_ptr[o + 1]; ++h) {
-          const int32_t nb = patch_of_vertex[static_cast<size_t>(L->half_nbr[h])];
-          if (stamp[static_cast<size_t>(nb)] == q) continue;  // itself, or met before
-          stamp[static_cast<size_t>(nb)] = q;
-          adj.push_back(nb);
-        }
-      }
-      adj_ptr[static_cast<size_t>(q) + 1] = static_cast<int32_t>(adj.size());
-    }
-    int32_t per[kXcds], most = 0, total = P;
-    for (int round = 0; round < 4; ++round) {
-      for (int32_t k = 0; k < kXcds; ++k)
-        for (int32_t q = cut[k]; q < cut[k + 1]; ++q) region[static_cast<size_t>(q)] = static_cast<uint8_t>(k);
-      // Which patches get a copy, and where.  Patch C of XCD m is copied to XCD k < m (only the higher-numbered side of
-      // a border is copied) iff (i) every neighbour of C lies on XCD k or m, at least one of them on k, and (ii) at least one
-      // neighbour D on m touches no patch of XCD k.  These two rules are what makes FOUR record buffers enough
-      // (k_persistent_pv): an instance that is read by an instance it does not read itself waits for that reader through
-      // at most three hand-offs --
-      //   D is read by the copy C' (which reads D because D has no copy on k, (ii)):  D reads C, C reads A (a neighbour on
-      //     k: no patch of the lower side is ever copied), A reads C';
-      //   A (on k) is read by C, but itself reads C':  A reads C', C' reads D, D reads C;
-      //   every other pair reads each other (copies on k read each other's copies, patches of m read each other).
-      // A patch that touches three XCDs is never copied ((i)), so no other constellation exists.
-      for (int32_t q = 0; q < P; ++q) touches[static_cast<size_t>(q)] = 0;
-      for (int32_t q = 0; q < P; ++q)
-        for (int32_t i = adj_ptr[static_cast<size_t>(q)]; i < adj_ptr[static_cast<size_t>(q) + 1]; ++i)
-          touches[static_cast<size_t>(q)] |= static_cast<uint8_t>(1u << region[static_cast<size_t>(adj[static_cast<size_t>(i)])]);
-      for (int32_t q = 0; q < P; ++q) {  // need: bit k = XCD k gets a copy of this patch
-        const int32_t m = region[static_cast<size_t>(q)];
-        const uint32_t others = touches[static_cast<size_t>(q)] & ~(1u << m);
-        uint8_t bits = 0;
-        if (others != 0 && (others & (others - 1)) == 0) {  // exactly one other XCD ...
-          const int32_t k = __builtin_ctz(others);
-          if (k < m) {                                       // ... and it is the lower one
-            bool inner = false;                              // (ii)
-            for (int32_t i = adj_ptr[static_cast<size_t>(q)]; i < adj_ptr[static_cast<size_t>(q) + 1] && !inner; ++i) {
-              const int32_t d = adj[static_cast<size_t>(i)];
-              inner = region[static_cast<size_t>(d)] == m && !((touches[static_cast<size_t>(d)] >> k) & 1);
-            }
-            if (inner) bits = static_cast<uint8_t>(1u << k);
-          }
-        }
-        need[static_cast<size_t>(q)] = bits;
-      }
-      int32_t shadows[kXcds];
-      most = 0, total = P;
-      for (int32_t k = 0; k < kXcds; ++k) {
-        shadows[k] = 0;
-        for (int32_t q = 0; q < P; ++q) shadows[k] += (need[static_cast<size_t>(q)] >> k) & 1;
-        per[k] = cut[k + 1] - cut[k] + shadows[k];
-        most = std::max(most, per[k]);
-        total += shadows[k];
-      }
-      if (round == 3) break;
-      // next cuts: every XCD gets total/8 instances, its own share being that minus the shadows it hosts now
-      int32_t at = 0;
-      for (int32_t k = 0; k < kXcds; ++k) {
-        cut[k] = at;
-        const int32_t want = static_cast<int32_t>(static_cast<int64_t>(total) * (k + 1) / kXcds - static_cast<int64_t>(total) * k / kXcds);
-        at = std::min(P, at + std::max(1, want - shadows[k]));
-      }
-      cut[kXcds] = P;
-      for (int32_t k = kXcds - 1; k > 0 && cut[k] > cut[k + 1] - 1; --k) cut[k] = std::max(k, cut[k + 1] - 1);  // (no empty XCD)
-    }
-    // (a wave wants a SIMD of its own: where the copies would not fit next to the originals they cost more than they save)
-    if (total <= shadow_max_instances) {
-      std::vector<int32_t> info(static_cast<size_t>(kXcds) * most * 4, 0), v0(static_cast<size_t>(kXcds) * most, 0);
-      L->rid_on.resize(static_cast<size_t>(kXcds) * V);
-      for (int32_t k = 0; k < kXcds; ++k)
-        for (int32_t u = 0; u < V; ++u) L->rid_on[static_cast<size_t>(k) * V + u] = L->rid_of[static_cast<size_t>(u)];
-      int32_t next_rid = V;
-      for (int32_t k = 0; k < kXcds; ++k) {
-        int32_t at = k * most;
-        for (int32_t q = cut[k]; q < cut[k + 1]; ++q, ++at) {
-          for (int c = 0; c < 4; ++c) info[static_cast<size_t>(at) * 4 + c] = L->wg_info[static_cast<size_t>(q) * 4 + c];
-          v0[static_cast<size_t>(at)] = L->wg_info[static_cast<size_t>(q) * 4];
-        }
-        for (int32_t q = 0; q < P; ++q) {
-          if (!((need[static_cast<size_t>(q)] >> k) & 1)) continue;
-          const int32_t r0 = L->wg_info[static_cast<size_t>(q) * 4], n = L->wg_info[static_cast<size_t>(q) * 4 + 2] & 0xffff;
-          info[static_cast<size_t>(at) * 4] = next_rid;
-          info[static_cast<size_t>(at) * 4 + 2] = n | kWgShadow | (L->wg_info[static_cast<size_t>(q) * 4 + 2] & kWgSlab);
-          info[static_cast<size_t>(at) * 4 + 3] = L->wg_info[static_cast<size_t>(q) * 4 + 3];
-          v0[static_cast<size_t>(at)] = r0;
-          for (int32_t j = 0; j < n; ++j) L->rid_on[static_cast<size_t>(k) * V + order_m[static_cast<size_t>(r0 + j)]] = next_rid + j;
-          next_rid += n;
-          ++at;
-        }
-      }
-      L->wg_info.swap(info), L->wg_v0.swap(v0);
-      L->wg_count = kXcds * most, L->wg_per_xcd = most, L->n_rec = next_rid, L->shadow_mode = shadow_mode;
-      L->comp_wg.assign({0, L->wg_count});
-    }
-  }
   if (host_expand) {
     // pass 2 (the device does this in k_build_patch, nltgv2_layout.hip): the 64 lanes of every patch and its fetch list.
     // A neighbour is local iff its record id lies in the patch's range; the others are fetched -- one lane per DISTINCT
@@ -494,8 +357,7 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
       const int32_t r0 = L->wg_info[static_cast<size_t>(wg) * 4];
       const int32_t n_loc = L->wg_info[static_cast<size_t>(wg) * 4 + 2] & 0xffff, r1 = r0 + n_loc;
       const int32_t v0 = L->wg_v0[static_cast<size_t>(wg)];
-      // the record an instance on this XCD reads for a vertex: its own XCD's copy where there is one
-      const int32_t* rid = L->wg_per_xcd ? &L->rid_on[static_cast<size_t>(wg / L->wg_per_xcd) * V] : L->rid_of.data();
+      const int32_t* rid = L->rid_of.data();
       int32_t n_want = 0;
       for (int32_t i = 0; i < n_loc; ++i) {
         const int32_t o = order_m[v0 + i];
@@ -547,8 +409,8 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
 // walk); the per-slot / per-lane arrays of (B) and (E) are then produced on the device (nltgv2_layout.hip) and (C), (D)
 // on demand.  host_expand = true: everything here -- the reference the device expansion is checked against, and what the
 // CPU test-suite looks at.
-inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L, bool host_expand = true, int shadow_mode = 0,
-                        int shadow_max_instances = 0x7fffffff, bool rowpack = true, int rowpack_max_patches = 0x7fffffff) {
+inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L, bool host_expand = true, bool rowpack = true,
+                        int rowpack_max_patches = 0x7fffffff) {
   if (!g || g->V < 0 || g->E < 0) return FLAME_NLTGV2_ERR_INVALID_ARG;
   const int32_t V = g->V, E = g->E;
   if (V > 0 && !g->pos) return FLAME_NLTGV2_ERR_INVALID_ARG;
@@ -725,7 +587,7 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L, bool host_
   }
 
   PROF_T(3);
-  build_patch_rows(g, L, order_m, host_expand, shadow_mode, shadow_max_instances, rowpack, rowpack_max_patches);
+  build_patch_rows(g, L, order_m, host_expand, rowpack, rowpack_max_patches);
   PROF_T(4);
   if (host_expand) build_he_rows(L);  // (after (E): the two walks cut the same waves, row-packed or not -- L->wg_rowpack)
   PROF_T(5);

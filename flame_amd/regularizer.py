@@ -26,8 +26,10 @@ _LIB = None
 _FP = C.POINTER(C.c_float)
 _IP = C.POINTER(C.c_int32)
 
-OPT_SOLVER, OPT_USE_HIPGRAPH, OPT_BLOCK_WAVES, OPT_UNROLL, OPT_PERSISTENT, OPT_DUAL_PUBLISH, OPT_TV_LDS, OPT_PRESLEEP, OPT_XCDS, OPT_FAULT_INJECT = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
-OPT_PROBE, OPT_POLL_GAP, OPT_VERIFY_RECORDS, OPT_SHADOWS, OPT_PLACEMENT, OPT_ROWPACK = 12, 13, 14, 15, 16, 17
+# stable options (include/flame_nltgv2.h) ...
+OPT_SOLVER, OPT_USE_HIPGRAPH, OPT_PERSISTENT, OPT_PROBE, OPT_VERIFY_RECORDS, OPT_PLACEMENT = 1, 2, 5, 12, 14, 16
+# ... and the experimental range (tuning knobs / test hooks of the current kernels; tools/ and the tests use them)
+OPT_BLOCK_WAVES, OPT_UNROLL, OPT_DUAL_PUBLISH, OPT_TV_LDS, OPT_PRESLEEP, OPT_XCDS, OPT_FAULT_INJECT, OPT_POLL_GAP = 103, 104, 106, 107, 108, 109, 110, 113
 RUN_PATHS = {0: "none", 1: "persistent", 2: "per-step hipGraph", 3: "per-step eager", 4: "canonical 4-sweep",
              5: "persistent-tv", 6: "persistent-pv"}
 ERR_NAN = -5

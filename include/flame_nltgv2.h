@@ -247,60 +247,49 @@ int flame_nltgv2_photo_fuse(flame_nltgv2_ctx* ctx, const float* KRKinv, const fl
                             int enable);
 int flame_nltgv2_photo_residual_last(flame_nltgv2_ctx* ctx, float* err_out);
 
-/* Options (flame_nltgv2_set_option). */
+/* Options (flame_nltgv2_set_option).  The values below 100 are the stable surface; FLAME_NLTGV2_OPT_EXPERIMENTAL and above
+ * are tuning knobs and test hooks of the current kernels (what DESIGN.md's A/B tables were measured with): they may change or
+ * go with any release and a caller never needs them -- every default is the measured best. */
 enum {
-  FLAME_NLTGV2_OPT_SOLVER = 1,       /* 0 = fused one-kernel-per-step sweep (default), 1 = 4-kernel
-                                        canonical sweeps (save_prev/dual/primal/extragradient) */
-  FLAME_NLTGV2_OPT_USE_HIPGRAPH = 2, /* 1 (default) = capture the n_iters launches in a hipGraph */
-  FLAME_NLTGV2_OPT_BLOCK_WAVES = 3,  /* waves per workgroup of the fused sweep: 0 = auto, 1,2,4 */
-  FLAME_NLTGV2_OPT_UNROLL = 4,       /* half-edge slots per load chunk of the fused sweep: 0 = auto, 4,8,16 */
-  FLAME_NLTGV2_OPT_PERSISTENT = 5,   /* 1 (default) = run() uses ONE persistent launch for all n_iters steps
-                                        when the graph fits on the chip, picking the form by occupancy;
-                                        2 = force the lane-per-half-edge form, 3 = force the vertex-per-lane
-                                        form, 4 = force the patch-per-wave form (each only if it fits);
+  FLAME_NLTGV2_OPT_SOLVER = 1,       /* 0 = fused / persistent kernels (default), 1 = the reference's four loops one by one
+                                        (save_prev / dual / primal / extragradient sweeps on the canonical arrays) */
+  FLAME_NLTGV2_OPT_USE_HIPGRAPH = 2, /* 1 (default) = the one-launch-per-step path replays its launches from a hipGraph */
+  FLAME_NLTGV2_OPT_PERSISTENT = 5,   /* 1 (default) = run() uses ONE persistent launch for all n_iters steps when the graph
+                                        fits on the chip, picking the form by size; 2 = force the lane-per-half-edge form,
+                                        3 = the vertex-per-lane form, 4 = the patch-per-wave form (each only if it fits);
                                         0 = always one launch per step */
-  FLAME_NLTGV2_OPT_DUAL_PUBLISH = 6, /* persistent run: neighbours on the same XCD exchange through that XCD's
-                                        L2 (plain store + local record copy), others through write-through
-                                        records: 1 (default) and 2 = on, 0 = write-through records only */
-  FLAME_NLTGV2_OPT_TV_LDS = 7,       /* vertex-per-lane persistent form: per-slot constants in LDS instead of registers
-                                        (12 instead of 8 waves per CU resident): 2 = always, 1 (default) = when the
-                                        register form is not resident in one launch, 0 = never */
-  FLAME_NLTGV2_OPT_PRESLEEP = 8,     /* persistent run, sleep between publishing a step's record and the first
-                                        neighbour poll: 0 (default) = chosen from the waves per CU;
-                                        n in 1..64 = (n-1) x 64 cycles */
-  FLAME_NLTGV2_OPT_XCDS = 9,         /* persistent run: number of XCDs (of 8) the waves are spread over: 0 (default) =
-                                        one XCD for graphs small enough to run there, else all eight; 1..8 */
-  FLAME_NLTGV2_OPT_POLL_GAP = 13,    /* patch-per-wave form: 0 (default) = built-in, 1 = no pause between the polls of a
-                                        wait, 2 = one s_sleep (64 cycles); 3 / 4 = the same with the polls narrowed to the
-                                        records that have not arrived yet (3 is the built-in) */
-  FLAME_NLTGV2_OPT_SHADOWS = 15,     /* patch-per-wave form, graphs of 65..2048 patches spread over the eight XCDs: 2 = patches
-                                        on the higher-numbered side of an XCD border are also computed by a wave on the
-                                        neighbouring XCD, whose patches then read that copy (same bits) instead of waiting for
-                                        a record to cross the fabric.  Measured -1 % per iteration on average at 640x480
-                                        (between -4.5 % and +1.5 % by graph) for ~0.15 ms more host time per topology, hence
-                                        off by default (0, 1).  Takes effect with the next upload_graph / sync_graph */
-  FLAME_NLTGV2_OPT_PLACEMENT = 16,   /* patch-per-wave form on all eight XCDs: 1 (default) = the records another XCD reads are
-                                        placed on memory pages whose home channel suits that pair of XCDs (a hand-off across
-                                        XCDs takes 0.39-0.66 us depending on the page; measured once per context, ~3 ms at
-                                        the first such run), 0 = every record at its linear place.  Addresses only: results
-                                        are bit-identical either way */
-  FLAME_NLTGV2_OPT_ROWPACK = 17,     /* patch-per-wave form: 1 (default) = a vertex's lanes never straddle a 16-lane row of the wave
-                                        (graphs whose largest degree is <= 16) and its contributions are added up across lanes
-                                        with DPP row shifts; 0 = lanes back to back, contributions through an LDS slab (round 2's
-                                        first form; also what graphs with a vertex of more than 16 edges get).  Bit-identical
-                                        either way.  Takes effect with the next upload_graph / sync_graph */
+  FLAME_NLTGV2_OPT_PROBE = 12,       /* 1 = the patch-per-wave kernel records a per-patch, per-step cycle probe (8 words:
+                                        HW id, XCC id, wait cycles, compute cycles, poll rounds, step start, 100 MHz clock,
+                                        0), read with flame_nltgv2_read_probe; 0 (default) = off */
   FLAME_NLTGV2_OPT_VERIFY_RECORDS = 14, /* persistent kernels: 1 = after a neighbour record's tag matched, read the 16 bytes
                                         once more and compare all four dwords (the exchange relies on an aligned 16-byte
                                         access never being torn between payload and tag; this checks it at run time, at the
                                         price of one more load round trip per step); a difference takes the run back like a
                                         timeout and counts in flame_nltgv2_info.torn_records_detected.  2 = the same plus a
                                         test hook that corrupts one re-read.  0 (default) = off */
-  FLAME_NLTGV2_OPT_PROBE = 12,       /* 1 = the patch-per-wave kernel records a per-patch, per-step cycle probe (8 words:
-                                        HW id, XCC id, wait cycles, compute cycles, poll rounds, step start, 100 MHz clock,
-                                        0), read with flame_nltgv2_read_probe; 0 (default) = off */
-  FLAME_NLTGV2_OPT_FAULT_INJECT = 10 /* test hook: n > 0 = one wave of every persistent run withholds its first record, so
-                                        the run times out after n polls and the recovery path (state rolled back, steps
-                                        redone with one launch per step) is exercised; 0 (default) = off */
+  FLAME_NLTGV2_OPT_PLACEMENT = 16,   /* patch-per-wave form on all eight XCDs: 1 (default) = the records another XCD reads are
+                                        placed on memory pages whose home channel suits that pair of XCDs (a hand-off across
+                                        XCDs takes 0.39-0.66 us depending on the page; measured once per context, ~3 ms at
+                                        the first such run), 0 = every record at its linear place.  Addresses only: results
+                                        are bit-identical either way */
+
+  FLAME_NLTGV2_OPT_EXPERIMENTAL = 100, /* ---- not part of the stable surface from here on ---- */
+  FLAME_NLTGV2_OPT_BLOCK_WAVES = 103,  /* waves per workgroup of the fused sweep: 0 = auto, 1,2,4 */
+  FLAME_NLTGV2_OPT_UNROLL = 104,       /* half-edge slots per load chunk of the fused sweep: 0 = auto, 4,8,16 */
+  FLAME_NLTGV2_OPT_DUAL_PUBLISH = 106, /* persistent run: neighbours on the same XCD exchange through that XCD's L2 (plain store
+                                          + local record copy): 1 (default) and 2 = on, 0 = write-through records only */
+  FLAME_NLTGV2_OPT_TV_LDS = 107,       /* vertex-per-lane form: per-slot constants in LDS instead of registers: 2 = always,
+                                          1 (default) = when the register form is not resident in one launch, 0 = never */
+  FLAME_NLTGV2_OPT_PRESLEEP = 108,     /* persistent run, pause between a step's publish and its first poll: 0 (default) =
+                                          chosen from the waves per CU; n in 1..256 = (n-1) x 64 cycles */
+  FLAME_NLTGV2_OPT_XCDS = 109,         /* persistent run: XCDs (of 8) the waves are spread over: 0 (default) = one XCD for
+                                          graphs small enough to run there, else all eight; 1..8 */
+  FLAME_NLTGV2_OPT_FAULT_INJECT = 110, /* test hook: n > 0 = one wave of every persistent run withholds its first record, so the
+                                          run times out after n polls and the recovery path (state rolled back, steps redone
+                                          with one launch per step) is exercised; 0 (default) = off */
+  FLAME_NLTGV2_OPT_POLL_GAP = 113      /* patch-per-wave form: 0 (default) = chosen from the patches per CU, 1 = no pause between
+                                          the poll rounds of a wait, 2 = one s_sleep (64 cycles); 3 / 4 = the same with the polls
+                                          narrowed to the records that have not arrived yet */
 };
 int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value);
 

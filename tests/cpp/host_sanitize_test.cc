@@ -4,7 +4,7 @@
 //   * flame_amd/csrc/delaunay.cpp          flame_delaunay_triangulate: exact-predicate Bowyer-Watson (utils/delaunay.cc:31-77's
 //                                          counterpart), on random, co-circular (grid), duplicated, collinear and invalid inputs;
 //   * flame_amd/csrc/nltgv2_pack.hpp       build_layout: CSR, components, Morton walk, SELL-64, the patch / half-edge / vertex
-//                                          rows, with and without row packing and shadow patches, host-expanded, on ragged,
+//                                          rows, with and without row packing, host-expanded or not, on ragged,
 //                                          empty, star-shaped and batched graphs;
 //   * include/flame_hip/*.hpp              the facade's FlatGraph <-> flat array packing (GraphAccess).
 // Built and run by `make -C flame_amd/csrc sanitize` and tests/test_sanitizers.py with
@@ -117,11 +117,10 @@ static HostGraph delaunay_graph(int nx, int ny, unsigned long long seed, float o
 
 static void check_layout(HostGraph& h, const char* name) {
   flame_nltgv2_graph g = h.view();
-  for (int shadow = 0; shadow <= 2; shadow += 2)
-    for (int rowpack = 0; rowpack <= 1; ++rowpack)
+  for (int rowpack = 0; rowpack <= 1; ++rowpack)
       for (int host_expand = 0; host_expand <= 1; ++host_expand) {
         PackedLayout L;
-        const int rc = build_layout(&g, &L, host_expand != 0, shadow, 0x7fffffff, rowpack != 0, 0x7fffffff);
+        const int rc = build_layout(&g, &L, host_expand != 0, rowpack != 0, 0x7fffffff);
         EXPECT(rc == 0, name);
         if (rc != 0) continue;
         if (host_expand) {

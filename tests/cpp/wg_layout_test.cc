@@ -119,12 +119,11 @@ static float prox_l1(float x_min, float x_max, float step_x, float w, float x, f
 
 struct Rec { float xb, w1b, w2b; unsigned tag; };
 
-static int replay(HostGraph& hg, int n_iters, const nltgv2_params& p, int shadow_mode, bool rowpack, bool expect_rowpack) {
+static int replay(HostGraph& hg, int n_iters, const nltgv2_params& p, bool rowpack, bool expect_rowpack) {
   flame_nltgv2_graph g = hg.view();
   PackedLayout L;
-  if (build_layout(&g, &L, true, shadow_mode, 0x7fffffff, rowpack) != 0 || !L.wg_ok) return 1;
+  if (build_layout(&g, &L, true, rowpack) != 0 || !L.wg_ok) return 1;
   if (L.wg_rowpack != expect_rowpack) return 16;
-  if (shadow_mode >= 2 && L.wg_prim > 64 && L.wg_prim <= 2048 && L.wg_per_xcd == 0) return 15;  // shadows expected at this size
   const int T = 64, V = g.V;
   // structural invariants
   std::vector<int> seen(L.n_slices * 64, 0);
@@ -144,13 +143,13 @@ static int replay(HostGraph& hg, int n_iters, const nltgv2_params& p, int shadow
       if (k < 0 || k >= need) return 3;
       if (((m & kWgTail) != 0) != (k == need - 1)) return 4;
       if (((m & kWgActive) != 0) != (k < deg)) return 5;
-      if ((m & kWgTail) && !(L.wg_info[4 * wg + 2] & kWgShadow)) seen[L.wg_vid[hl]]++;
+      if (m & kWgTail) seen[L.wg_vid[hl]]++;
       if ((int)((m >> 13) & 2047) >= (L.wg_info[4 * wg + 2] & 0xffff) || (L.wg_info[4 * wg + 2] & 0xffff) > L.wg_lcap) return 6;
     }
     if (L.wg_info[4 * wg + 1] > L.wg_rcap || L.wg_info[4 * wg + 1] > T) return 7;
     {  // slab stride: a multiple of 4, at least 8, covers the patch's largest degree, and fits the LDS sizing figure
       const int stride = L.wg_info[4 * wg + 3];
-      if ((L.wg_info[4 * wg + 2] & 0xffff) == 0) continue;  // idle padding of a shadow layout
+      if ((L.wg_info[4 * wg + 2] & 0xffff) == 0) continue;
       if (L.wg_rowpack && !(L.wg_info[4 * wg + 2] & kWgSlab)) {  // row-packed: the patch's largest degree itself (the DPP shifts + 1)
         if (stride < 1 || stride > 16) return 13;
         bool reached = false;
@@ -287,21 +286,20 @@ static int replay(HostGraph& hg, int n_iters, const nltgv2_params& p, int shadow
   long pub = 0, fetch = 0;
   for (size_t hl = 0; hl < NL; ++hl) pub += (L.wg_meta[hl] & (kWgTail | kWgPublish)) == (kWgTail | kWgPublish);
   for (int wg = 0; wg < L.wg_count; ++wg) fetch += L.wg_info[4 * wg + 1];
-  std::printf("V=%d E=%d shadows=%d instances=%d (walk %d, per XCD %d) records=%d lcap=%d rcap=%d slab slots=%d publishing=%ld fetched/step=%ld (half-edges %d) ok\n",
-              V, g.E, shadow_mode, L.wg_count, L.wg_prim, L.wg_per_xcd, L.n_rec, L.wg_lcap, L.wg_rcap, L.wg_slab_slots, pub, fetch, 2 * g.E);
+  std::printf("V=%d E=%d patches=%d records=%d lcap=%d rcap=%d slab slots=%d publishing=%ld fetched/step=%ld (half-edges %d) ok\n",
+              V, g.E, L.wg_count, L.n_rec, L.wg_lcap, L.wg_rcap, L.wg_slab_slots, pub, fetch, 2 * g.E);
   return 0;
 }
 
 int main() {
   const nltgv2_params p = {0.1f, 0.001f, 125.0f, 0.25f, 0.0f, 10.0f};
   for (int frames : {1, 3})
-    for (int shadow_mode : {0, 2})
-      for (int variant = 0; variant < 3; ++variant) {  // hub of degree ~46 (a back-to-back patch among row-packed ones); degree <= 16; not row-packed by request
+    for (int variant = 0; variant < 3; ++variant) {  // hub of degree ~46 (a back-to-back patch among row-packed ones); degree <= 16; not row-packed by request
         const bool hub = variant == 0, rowpack = variant != 2;
         HostGraph g = make_graph(61, 47, frames, 1234 + frames, hub);
-        const int rc = replay(g, 6, p, shadow_mode, rowpack, rowpack);
+        const int rc = replay(g, 6, p, rowpack, rowpack);
         if (rc) {
-          std::printf("FAILED frames=%d shadows=%d variant=%d rc=%d\n", frames, shadow_mode, variant, rc);
+          std::printf("FAILED frames=%d variant=%d rc=%d\n", frames, variant, rc);
           return 1;
         }
       }

@@ -112,10 +112,10 @@ def test_pv_residency_table_matches_the_build(tmp_path):
     found = {}
     for m in re.finditer(r"Function Name: (\S+).*?TotalSGPRs: (\d+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)", rep, flags=re.S):
         name, sg, vg, scratch = m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4))
-        k = re.search(r"k_persistent_pvILb([01])ELi([012])ELb([01])E", name)
+        k = re.search(r"k_persistent_pvILb([01])ELi([12])ELb([01])E", name)
         if k:
             found[(int(k.group(1)), int(k.group(2)), int(k.group(3)))] = (sg, vg, scratch)
-    assert len(found) >= 9, sorted(found)
+    assert len(found) >= 6, sorted(found)
     txt = open(src).read()
     assert "return layout == 1 ? (verify_or_probe ? 5 : 6) : 3;" in txt, "the table in this test mirrors pv_real_waves_per_simd"
     for (probe, layout, verify), (sg, vg, scratch) in sorted(found.items()):

@@ -147,24 +147,31 @@ def test_internal_steps_individually(env):
         assert_state_equal(reg.download_state(), ref, what="mixed")
 
 
-@pytest.mark.parametrize("opts", [
-    [(5, 0), (3, 1), (4, 4)], [(5, 0), (3, 1), (4, 8)], [(5, 0), (3, 1), (4, 16)], [(5, 0), (3, 2), (4, 8)],
-    [(5, 0), (3, 4), (4, 4)], [(5, 0), (3, 4), (4, 16)], [(5, 0), (2, 0)], [(5, 1)], [(5, 2)], [(5, 3)], [(5, 2), (6, 0)], [(5, 3), (6, 0)], [(5, 2), (6, 2)], [(5, 3), (6, 2)], [(5, 3), (7, 2)], [(5, 3), (6, 2), (7, 2)], [(5, 3), (7, 0)],
-    [(5, 2), (9, 1)], [(5, 2), (9, 2)], [(5, 2), (9, 4)], [(5, 2), (9, 8)], [(5, 3), (9, 1)], [(5, 2), (8, 1)], [(5, 2), (8, 21)],
-    [(5, 3), (8, 9)], [(5, 2), (9, 1), (6, 0)],
-    [(5, 4)], [(5, 4), (6, 0)], [(5, 4), (6, 2)], [(5, 4), (9, 1)], [(5, 4), (9, 2)], [(5, 4), (9, 8)], [(5, 4), (13, 1)], [(5, 4), (13, 2)], [(5, 4), (13, 3)], [(5, 4), (13, 4)],
-    [(5, 4), (9, 1), (6, 0), (13, 1)], [(5, 4), (12, 1)], [(5, 4), (15, 2)], [(5, 4), (15, 1)], [(5, 4), (15, 2), (6, 0)],
-    [(5, 2), (15, 2)], [(5, 3), (15, 2)],
-    [(5, 4), (17, 0)], [(5, 4), (17, 0), (16, 0)], [(5, 4), (17, 0), (14, 1)], [(5, 4), (17, 0), (15, 2)], [(5, 2), (17, 0)], [(5, 3), (17, 0)],
-    [(5, 4), (16, 0)], [(5, 4), (16, 0), (6, 0)], [(5, 4), (16, 1), (12, 1)], [(5, 4), (16, 1), (14, 1)], [(5, 4), (16, 1), (9, 4)],
-])
+def _opt_sets():
+    from flame_amd.regularizer import (OPT_BLOCK_WAVES as BW, OPT_DUAL_PUBLISH as DUAL, OPT_PERSISTENT as P, OPT_PLACEMENT as PLACE,
+                                       OPT_POLL_GAP as GAP, OPT_PRESLEEP as PRE, OPT_PROBE as PROBE, OPT_TV_LDS as TVLDS, OPT_UNROLL as U,
+                                       OPT_USE_HIPGRAPH as HG, OPT_VERIFY_RECORDS as VERIFY, OPT_XCDS as XCDS)
+    return [
+        # one launch per step: waves per workgroup x slot chunk, hipGraph off
+        [(P, 0), (BW, 1), (U, 4)], [(P, 0), (BW, 1), (U, 16)], [(P, 0), (BW, 4), (U, 8)], [(P, 0), (HG, 0)],
+        [(P, 1)],  # automatic choice
+        # lane per half-edge
+        [(P, 2)], [(P, 2), (DUAL, 0)], [(P, 2), (XCDS, 1)], [(P, 2), (XCDS, 4)], [(P, 2), (PRE, 21)],
+        # vertex per lane
+        [(P, 3)], [(P, 3), (DUAL, 0)], [(P, 3), (TVLDS, 2)], [(P, 3), (TVLDS, 0)], [(P, 3), (XCDS, 1)],
+        # patch per wave
+        [(P, 4)], [(P, 4), (DUAL, 0)], [(P, 4), (DUAL, 2)], [(P, 4), (XCDS, 1)], [(P, 4), (XCDS, 8)], [(P, 4), (GAP, 1)], [(P, 4), (GAP, 2)],
+        [(P, 4), (GAP, 4)], [(P, 4), (PRE, 9), (GAP, 4)], [(P, 4), (PROBE, 1)], [(P, 4), (PLACE, 0)], [(P, 4), (PLACE, 0), (DUAL, 0)],
+        [(P, 4), (PLACE, 1), (VERIFY, 1)],
+    ]
+
+
+@pytest.mark.parametrize("opts", _opt_sets(), ids=lambda o: "-".join(f"{k}={v}" for k, v in o))
 def test_launch_configurations_are_bit_identical(env, opts):
-    """waves per workgroup (opt 3), slot chunk (opt 4), hipGraph on/off (opt 2), persistent single
-    launch vs one launch per step (opt 5), same-XCD L2 exchange on/off (opt 6), slot constants in LDS (opt 7), the pre-poll sleep (opt 8) and the number of
-    XCDs a persistent launch is spread over (opt 9), the poll pause and the cycle probe of the patch-per-wave form (opts 13, 12) and shadow
-    patches across the XCD borders (opt 15, also under the other forms, which ignore them) and the placement of the records read
-    across XCDs (opt 16) and the patch layout with its accumulation scheme (opt 17: row-packed + DPP, or back to back + LDS slab)
-    never change a bit."""
+    """Every launch configuration computes the same bits: the one-launch-per-step sweep (waves per workgroup, slot chunk,
+    hipGraph on / off), the automatic choice and the three persistent forms with their knobs -- same-XCD exchange through L2
+    on / off, slot constants in LDS, the pre-poll pause, the XCDs a launch is spread over, the poll pacing, the cycle probe,
+    the placement of the records read across XCDs and the record verification."""
     flame_amd, oracle = env
     g = synth.make_graph("320x240", seed=3)
     ref, _ = cpu_run(oracle, g, 21)
@@ -233,7 +240,7 @@ def test_star_graph_high_degree(env):
     ref, bad = cpu_run(oracle, g, 25)
     assert bad == 0
     for unroll in (4, 16):  # one launch per step
-        out = gpu_run(flame_amd, g, 25, options=[(5, 0), (4, unroll)], expect_path=2)
+        out = gpu_run(flame_amd, g, 25, options=[(5, 0), (flame_amd.regularizer.OPT_UNROLL, unroll)], expect_path=2)
         assert_state_equal(out, ref, what=f"star U={unroll}")
     # degree 999 > 64 lanes: the lane-per-half-edge form cannot hold it, the vertex-per-lane form
     # cannot either (999 > 8*64) -> automatic fall back to per-step launches
@@ -424,7 +431,7 @@ def test_persistent_timeout_is_rolled_back_and_redone(env, form):
         reg.run(p, 30)                       # a normal persistent run first (odd/even parity both follow)
         oracle.run(ref, 30)
         assert reg.info()["last_run_path"] in (1, 5, 6)
-        reg.set_option(10, 200)              # FLAME_NLTGV2_OPT_FAULT_INJECT
+        reg.set_option(flame_amd.regularizer.OPT_FAULT_INJECT, 200)
         reg.run(p, 41)                       # times out inside, recovered
         oracle.run(ref, 41)
         info = reg.info()
@@ -433,7 +440,7 @@ def test_persistent_timeout_is_rolled_back_and_redone(env, form):
         reg.run(p, 10)                       # the topology stays on the per-step path while the fault is on
         oracle.run(ref, 10)
         assert reg.info()["timeouts_recovered"] == 1
-        reg.set_option(10, 0)                # fault off: persistent runs again
+        reg.set_option(flame_amd.regularizer.OPT_FAULT_INJECT, 0)  # fault off: persistent runs again
         reg.run(p, 25)
         oracle.run(ref, 25)
         assert reg.info()["last_run_path"] in (1, 5, 6)
@@ -442,7 +449,7 @@ def test_persistent_timeout_is_rolled_back_and_redone(env, form):
         # the chain's starting state was copied aside, the whole chain is replayed on the per-step path
         import torch
 
-        reg.set_option(10, 200)
+        reg.set_option(flame_amd.regularizer.OPT_FAULT_INJECT, 200)
         buf = torch.zeros(g["V"], dtype=torch.float32, device="cuda")
         before = reg.info()["timeouts_recovered"]
         reg.run_async(p, 8)
@@ -459,7 +466,7 @@ def test_persistent_timeout_is_rolled_back_and_redone(env, form):
         torch.cuda.synchronize()
         assert np.array_equal(buf.cpu().numpy(), want_export)
         # and a chain that does not time out is left alone
-        reg.set_option(10, 0)
+        reg.set_option(flame_amd.regularizer.OPT_FAULT_INJECT, 0)
         reg.run_async(p, 6)
         reg.run_async(p, 7)
         reg.sync()
@@ -623,8 +630,8 @@ def test_randomized_run_sequences(env, trial):
             form = int(rng.choice([0, 1, 2, 3, 4]))
             reg.set_option(5, form)
             reg.set_option(1, int(rng.random() < 0.15))      # canonical four-sweep path now and then
-            reg.set_option(6, int(rng.choice([0, 1, 2])))
-            reg.set_option(7, int(rng.choice([0, 1, 2])))
+            reg.set_option(flame_amd.regularizer.OPT_DUAL_PUBLISH, int(rng.choice([0, 1, 2])))
+            reg.set_option(flame_amd.regularizer.OPT_TV_LDS, int(rng.choice([0, 1, 2])))
             n = int(rng.choice([1, 2, 3, 5, 8, 13, 40, 120]))
             reg.run(p, n)
             assert oracle.run(ref, n, rp) == 0
@@ -671,39 +678,3 @@ def test_record_placement_is_bit_identical_and_well_formed(env, config):
                 assert reg.layout_selftest() == 0
             else:
                 assert pi["state"] == 0 and pi["placed_records"] == 0, pi
-
-
-@pytest.mark.parametrize("config,shadows", [("320x240", 2), ("640x480", 2), ("1280x720", 2)])
-def test_shadow_patches_are_bit_identical(env, config, shadows):
-    """FLAME_NLTGV2_OPT_SHADOWS: patches next to an XCD border computed a second time on the neighbouring XCD.  Same state
-    after odd and even run lengths, after a chain of asynchronous runs, with record verification on, and the device-built
-    layout (shadow instances, per-XCD record tables) equals the host builders'."""
-    flame_amd, oracle = env
-    from flame_amd.regularizer import OPT_PERSISTENT, OPT_SHADOWS, OPT_VERIFY_RECORDS
-
-    g = synth.make_graph(config, seed=21)
-    p = flame_amd.Params()
-    ref = synth.copy_graph(g)
-    with flame_amd.Regularizer(0) as reg:
-        reg.set_option(OPT_PERSISTENT, 4)
-        reg.set_option(OPT_SHADOWS, shadows)
-        if config == "1280x720":  # (row-packed, this graph has more patches than the 2048 shadow layouts are made for)
-            from flame_amd.regularizer import OPT_ROWPACK
-            reg.set_option(OPT_ROWPACK, 0)
-        reg.upload_graph(g)
-        base = reg.info()["he_waves"]
-        assert reg.info()["patches"] > base, "no shadow instances were created"
-        assert reg.layout_selftest() == 0
-        for n in (7, 40):
-            reg.run(p, n)
-            assert oracle.run(ref, n) == 0
-            assert reg.info()["last_run_path"] == 6
-            assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"{config} after {n}")
-        reg.set_option(OPT_VERIFY_RECORDS, 1)
-        reg.run_async(p, 9)
-        reg.run_async(p, 16)
-        reg.sync()
-        assert oracle.run(ref, 25) == 0
-        assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"{config} chain")
-        info = reg.info()
-        assert info["timeouts_recovered"] == 0 and info["torn_records_detected"] == 0

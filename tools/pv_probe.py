@@ -15,7 +15,7 @@ import torch  # noqa: F401  (one HIP runtime per process)
 
 import flame_amd
 from flame_amd import synth
-from flame_amd.regularizer import OPT_PERSISTENT, OPT_POLL_GAP, OPT_PROBE, OPT_SHADOWS, RUN_PATHS
+from flame_amd.regularizer import OPT_PERSISTENT, OPT_POLL_GAP, OPT_PROBE, RUN_PATHS
 
 params = flame_amd.Params()
 N = 200
@@ -49,7 +49,7 @@ def probe_summary(g, opts):
         r.run(params, N)
         ms = r.run_timed(params, N)
         p = r.read_probe().reshape(-1, N, 8).astype(np.int64)[:, 20:, :]
-        p = p[p[:, 0, 5] != 0]  # (idle padding of a shadow layout never runs a step)
+        p = p[p[:, 0, 5] != 0]
     finally:
         r.close()
     wait, comp = p[:, :, 2].mean(axis=1), p[:, :, 3].mean(axis=1)
@@ -84,7 +84,7 @@ def main():
         print(json.dumps(row), flush=True)
         results.append(row)
     # what the XCD borders cost: eight disjoint graphs, each on its own XCD (no record crosses an XCD), against one coupled
-    # graph of the same size; and the shadow-patch option on the coupled graph
+    # graph of the same size
     def small(w, h, seed):
         pos = synth.make_points(w, h, 6, seed)
         return synth.assemble_graph(pos, synth.make_data_term(pos, w, h, seed), synth.delaunay_edges_native(pos))
@@ -92,8 +92,7 @@ def main():
     g1 = synth.make_graph("640x480", seed=1234)
     g8 = synth.concat_graphs([small(228, 168, 100 + k) for k in range(8)])
     border = {"coupled_640x480": probe_summary(g1, [(OPT_PERSISTENT, 4)]),
-              "eight_disjoint_228x168_one_per_xcd": probe_summary(g8, [(OPT_PERSISTENT, 4)]),
-              "coupled_640x480_with_shadow_patches": probe_summary(g1, [(OPT_PERSISTENT, 4), (OPT_SHADOWS, 2)])}
+              "eight_disjoint_228x168_one_per_xcd": probe_summary(g8, [(OPT_PERSISTENT, 4)])}
     for k, v in border.items():
         print(k, json.dumps({kk: v[kk] for kk in ("patches", "us_per_iter_with_probe", "step_period_shader_cycles")}), flush=True)
     os.makedirs("gpurun_out", exist_ok=True)

@@ -11,7 +11,7 @@ import numpy as np
 import torch  # noqa
 import flame_amd
 from flame_amd import synth
-from flame_amd.regularizer import OPT_DUAL_PUBLISH, OPT_PERSISTENT, OPT_PLACEMENT, OPT_SHADOWS, OPT_TV_LDS, OPT_VERIFY_RECORDS
+from flame_amd.regularizer import OPT_DUAL_PUBLISH, OPT_PERSISTENT, OPT_PLACEMENT, OPT_TV_LDS, OPT_VERIFY_RECORDS
 from oracle import capi as oracle
 
 ITERS = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
@@ -44,16 +44,14 @@ for cfg, seed in cases:
     t0 = time.time()
     oracle.run(ref, ITERS)
     cpu_s = time.time() - t0
-    # (form, same-XCD exchange, tv constants in LDS, record verification, shadow patches: 2 = on, record placement)
-    for form, dual, lds, verify, shadows, place in ((4, 2, 0, 0, 0, 1), (4, 2, 0, 1, 0, 1), (4, 2, 0, 1, 0, 0), (4, 0, 0, 1, 0, 1), (2, 0, 0, 0, 0, 1),
-                                                   (2, 2, 0, 1, 0, 1), (3, 0, 0, 1, 0, 1), (3, 2, 0, 0, 0, 1), (3, 2, 2, 1, 0, 1), (4, 2, 0, 1, 2, 1),
-                                                   (4, 0, 0, 1, 2, 1)):
+    # (form, same-XCD exchange, tv constants in LDS, record verification, record placement)
+    for form, dual, lds, verify, place in ((4, 2, 0, 0, 1), (4, 2, 0, 1, 1), (4, 2, 0, 1, 0), (4, 0, 0, 1, 1), (2, 0, 0, 0, 1),
+                                          (2, 2, 0, 1, 1), (3, 0, 0, 1, 1), (3, 2, 0, 0, 1), (3, 2, 2, 1, 1)):
         with flame_amd.Regularizer(0) as reg:
             reg.set_option(OPT_PERSISTENT, form)
             reg.set_option(OPT_DUAL_PUBLISH, dual)
             reg.set_option(OPT_TV_LDS, lds)
             reg.set_option(OPT_VERIFY_RECORDS, verify)
-            reg.set_option(OPT_SHADOWS, shadows)
             reg.set_option(OPT_PLACEMENT, place)
             reg.upload_graph(g)
             done = 0
@@ -70,7 +68,7 @@ for cfg, seed in cases:
             path = info["last_run_path"]
         ok = all(np.array_equal(out[k], ref[k]) for k in KEYS)
         results.append(dict(config=cfg, V=g["V"], E=g["E"], iters=ITERS, launches=launches, form=form, dual=dual, tv_lds=lds,
-                            verify_records=verify, shadows=shadows, placement=place, placed_records=placed, torn_records_detected=info["torn_records_detected"],
+                            verify_records=verify, placement=place, placed_records=placed, torn_records_detected=info["torn_records_detected"],
                             timeouts_recovered=info["timeouts_recovered"], run_path=path, bit_identical=bool(ok)))
         print(results[-1], flush=True)
 stop = True

@@ -5,8 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa
 import flame_amd
 from flame_amd import synth
-from flame_amd.regularizer import OPT_PERSISTENT, OPT_DUAL_PUBLISH, RUN_PATHS
-OPT_TV_LDS = 7
+from flame_amd.regularizer import OPT_PERSISTENT, OPT_DUAL_PUBLISH, OPT_TV_LDS, RUN_PATHS
 
 params = flame_amd.Params()
 cases = [("640x480", 1), ("1280x720", 1), ("1920x1080", 1), ("640x480", 4), ("640x480", 7), ("640x480", 12), ("640x480", 15), ("640x480", 30)]
