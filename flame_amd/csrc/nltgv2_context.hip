@@ -1,0 +1,625 @@
+// nltgv2_context.hip -- solver context: buffers, uploads of a topology, life cycle, options, info, self-tests (see nltgv2_context.hpp).
+#include "nltgv2_context.hpp"
+
+namespace flame_hip {
+namespace host {
+
+int fail(flame_nltgv2_ctx* ctx, int status) {
+  if (ctx) ctx->last_error = status;
+  return status;
+}
+
+int ensure(flame_nltgv2_ctx* ctx, DevBuf& b, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  if (b.cap >= bytes) return 0;
+  size_t want = bytes + bytes / 2;  // geometric growth, reused across frames
+  want = (want + 255) & ~size_t(255);
+  if (b.p) {
+    HIPCHK(ctx, hipFree(b.p));
+    ctx->device_bytes -= b.cap;
+    b.p = nullptr, b.cap = 0;
+  }
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    ctx->last_hip = (int)e;
+    b.p = nullptr;
+    return fail(ctx, e == hipErrorOutOfMemory ? FLAME_NLTGV2_ERR_OOM : FLAME_NLTGV2_ERR_HIP);
+  }
+  b.cap = want;
+  ctx->device_bytes += want;
+  return 0;
+}
+
+void drop_graphs(flame_nltgv2_ctx* ctx) {
+  for (auto& g : ctx->graphs)
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  ctx->graphs.clear();
+}
+
+SolverParams to_sp(const flame_nltgv2_params* p) {
+  return SolverParams{p->data_factor, p->step_x, p->step_q, p->theta, p->x_min, p->x_max};
+}
+
+int enter(flame_nltgv2_ctx* ctx) {
+  if (!ctx) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return 0;
+}
+
+void refresh_args(flame_nltgv2_ctx* ctx) {
+  CanonArgs& c = ctx->c;
+  c.V = ctx->L.V, c.E = ctx->L.E;
+  c.pos = (float2*)ctx->pos.p;
+  c.x = (float*)ctx->x.p, c.w1 = (float*)ctx->w1.p, c.w2 = (float*)ctx->w2.p;
+  c.xb = (float*)ctx->xb.p, c.w1b = (float*)ctx->w1b.p, c.w2b = (float*)ctx->w2b.p;
+  c.xp = (float*)ctx->xp.p, c.w1p = (float*)ctx->w1p.p, c.w2p = (float*)ctx->w2p.p;
+  c.data = (float*)ctx->data.p, c.weight = (float*)ctx->weight.p;
+  c.src = (int32_t*)ctx->src.p, c.dst = (int32_t*)ctx->dst.p;
+  c.alpha = (float*)ctx->alpha.p, c.beta = (float*)ctx->beta.p;
+  c.q1 = (float*)ctx->q1.p, c.q2 = (float*)ctx->q2.p, c.q3 = (float*)ctx->q3.p;
+  c.row_ptr = (int32_t*)ctx->row_ptr.p, c.half = (uint32_t*)ctx->half.p;
+  c.err = (int*)ctx->err.p;
+  FusedArgs& f = ctx->f;
+  f.n_slices = ctx->L.n_slices;
+  f.n_slots = (ctx->L.rows + kRowPad) * kWave;
+  f.slice_row = (int32_t*)ctx->slice_row.p, f.perm = (int32_t*)ctx->perm.p, f.pdeg = (int32_t*)ctx->pdeg.p;
+  f.rec_nbr = (uint32_t*)ctx->rec_nbr.p, f.rec_edge = (int32_t*)ctx->rec_edge.p;
+  f.edge_src_slot = (int32_t*)ctx->edge_src_slot.p;
+  f.hrec = (int4*)ctx->hrec.p, f.hq = (float4*)ctx->hq.p;
+  f.vstate = (float4*)ctx->vstate.p, f.vaux = (float2*)ctx->vaux.p;
+  f.hq_out = (float4*)ctx->hq_alt.p, f.vstate_out = (float4*)ctx->vstate_alt.p;
+  f.bar[0] = (float4*)ctx->bar0.p, f.bar[1] = (float4*)ctx->bar1.p;
+  f.vprev = (float4*)ctx->vprev.p;
+  f.xbuf = ctx->xbuf.p;
+  f.he_waves = (ctx->he_built && ctx->L.he_ok) ? ctx->L.he_waves : 0;
+  f.he_slot = (int32_t*)ctx->he_slot.p, f.he_vid = (int32_t*)ctx->he_vid.p;
+  f.he_meta = (uint32_t*)ctx->he_meta.p, f.he_wave_chain = (int32_t*)ctx->he_wave_chain.p;
+  f.tv_waves = (ctx->tv_built && ctx->L.tv_ok) ? ctx->L.tv_waves : 0;
+  f.tv_slot = (int32_t*)ctx->tv_slot.p, f.tv_vid = (int32_t*)ctx->tv_vid.p;
+  f.tv_meta = (uint32_t*)ctx->tv_meta.p, f.tv_wave = (uint32_t*)ctx->tv_wave.p;
+  f.wg_count = ctx->L.wg_ok ? ctx->L.wg_count : 0;
+  f.n_rec = ctx->L.n_rec;
+  f.wg_lcap = ctx->L.wg_lcap, f.wg_slab_slots = ctx->L.wg_slab_slots;
+  f.wg_rowpack = ctx->L.wg_rowpack ? 1 : 0;
+  f.wg_slot = (int32_t*)ctx->wg_slot.p, f.wg_vid = (int32_t*)ctx->wg_vid.p, f.wg_meta = (uint32_t*)ctx->wg_meta.p;
+  f.wg_nbr = (int32_t*)ctx->wg_nbr.p, f.wg_fetch = (int32_t*)ctx->wg_fetch.p, f.wg_info = (int32_t*)ctx->wg_info.p;
+  f.abort_flag = (int*)ctx->abort_flag.p;
+  f.err = (int*)ctx->err.p;
+}
+
+int h2d(flame_nltgv2_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
+  if (bytes == 0) return 0;
+  HIPCHK(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return 0;
+}
+
+// records the exchange buffers hold: one per packed vertex slot (the he / tv forms index by packed vertex)
+size_t records_capacity(const PackedLayout& L) {
+  const size_t n_packed = (size_t)L.n_slices * kWave, n_rec = ((size_t)L.n_rec + kWave - 1) / kWave * kWave;
+  return std::max(n_packed, n_rec);
+}
+
+int ensure_canon(flame_nltgv2_ctx* ctx) {
+  if (ctx->pending.active) {  // a persistent run is still unchecked: settle it before anything reads or edits the state
+    const int rc = finish(ctx);
+    if (rc) return rc;
+  }
+  if (ctx->canon_valid) return 0;
+  LAUNCHCHK(ctx, launch_unpack_state(ctx->c, ctx->f, ctx->parity, ctx->have_prev, ctx->stream));
+  ctx->canon_valid = true;
+  return 0;
+}
+
+int ensure_fused(flame_nltgv2_ctx* ctx) {
+  if (ctx->fused_valid) return 0;
+  if (ctx->static_stale) {  // positions moved: dx, dy of the packed records follow (alpha stays the caller's)
+    LAUNCHCHK(ctx, launch_pack_static(ctx->c, ctx->f, ctx->stream));
+    ctx->static_stale = false;
+  }
+  LAUNCHCHK(ctx, launch_pack_state(ctx->c, ctx->f, ctx->parity, ctx->stream));
+  ctx->fused_valid = true;
+  ctx->have_prev = false;
+  return 0;
+}
+
+
+// ---- uploading a topology ---------------------------------------------------------------------------------------------
+// The host computes only the per-vertex tables (nltgv2_pack.hpp with host_expand = false); every array goes through ONE
+// pinned staging buffer (the copies out of it are asynchronous and cost a few microseconds each; out of pageable memory
+// each of the ~35 copies of round 1 was a synchronous staging round trip); the per-slot and per-lane arrays are expanded
+// on the device (nltgv2_layout.hip).
+// All of `cp` through the pinned staging buffer as ONE host-to-device copy into a device-side blob, then one kernel that
+// distributes the pieces to their buffers and does the clears of `fills` (k_scatter).  The caller's arrays are free when
+// this returns (they were copied into the staging buffer); the staging buffer itself is reused by the next upload, which
+// synchronises the stream first.
+int staged_h2d(flame_nltgv2_ctx* ctx, const StageCopy* cp, size_t n, const StageFill* fills, size_t n_fills) {
+  size_t total = 0;
+  for (size_t i = 0; i < n; ++i) total += (cp[i].bytes + 255) & ~size_t(255);
+  if (total >= (size_t)0xffffff00u) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  if (total > ctx->stage_cap) {
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    ctx->h_stage = nullptr, ctx->stage_cap = 0;
+    const size_t want = total + total / 2;
+    if (hipHostMalloc(&ctx->h_stage, want, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(ctx, FLAME_NLTGV2_ERR_OOM);
+    }
+    ctx->stage_cap = want;
+  }
+  int rc = ensure(ctx, ctx->d_stage, ctx->stage_cap);
+  if (rc) return rc;
+  std::vector<ScatterTable> tables(1);
+  auto push = [&](const ScatterEntry& e) {
+    if (tables.back().n == kScatterMax) tables.emplace_back();
+    ScatterTable& t = tables.back();
+    t.e[t.n++] = e;
+  };
+  size_t off = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (cp[i].bytes == 0) continue;
+    std::memcpy(static_cast<char*>(ctx->h_stage) + off, cp[i].src, cp[i].bytes);
+    push(ScatterEntry{cp[i].b->p, (uint32_t)off, 0u, cp[i].bytes});
+    off += (cp[i].bytes + 255) & ~size_t(255);
+  }
+  for (size_t i = 0; i < n_fills; ++i)
+    if (fills[i].bytes) push(ScatterEntry{fills[i].dst, kScatterFill, fills[i].word, fills[i].bytes});
+  if (off) HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage.p, ctx->h_stage, off, hipMemcpyHostToDevice, ctx->stream));
+  for (const ScatterTable& t : tables) LAUNCHCHK(ctx, launch_scatter(t, ctx->d_stage.p, ctx->stream));
+  return 0;
+}
+
+// Layout + topology arrays of `g` (V, E, pos, src, dst) onto the device; the caller adds the state.  On return the
+// stream still holds the copies: the caller synchronises before the staging buffer or `g`'s arrays may change.
+int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const StageCopy* extra, size_t n_extra, bool long_lived) {
+  const int32_t V = g->V, E = g->E;
+  (void)long_lived;
+  int rc = build_layout(g, &ctx->L, /*host_expand=*/false, /*rowpack=*/true,
+                        /*rowpack_max_patches=*/ctx->opt_persistent == 4 ? 0x7fffffff : kPvDensePerCu * ctx->prop.multiProcessorCount);
+  if (rc) return fail(ctx, rc);
+  // Row packing costs ~15 % more waves than lanes back to back.  It pays where the patch-per-wave kernel runs them; a layout
+  // that turns out too large for that kernel (more patches than the estimate, or a vertex of more than 16 edges, whose
+  // instance of the kernel keeps 12 patches per CU) is better off back to back, for the lane-per-half-edge form.
+  // (FLAME_NLTGV2_OPT_PERSISTENT 4 -- the patch-per-wave form asked for by name -- keeps the row-packed layout whatever the
+  //  size: the kernel then runs it as groups of whole components)
+  if (ctx->L.wg_ok && ctx->L.wg_rowpack && ctx->opt_persistent != 4 &&
+      ctx->L.wg_count > (ctx->L.wg_slab_slots > 0 ? 4 * pv_real_waves_per_simd(2, false) : kPvDensePerCu) * ctx->prop.multiProcessorCount) {
+    rc = build_layout(g, &ctx->L, /*host_expand=*/false, /*rowpack=*/false, 0);
+    if (rc) return fail(ctx, rc);
+  }
+  const PackedLayout& L = ctx->L;
+  const size_t n_slots = (size_t)(L.rows + kRowPad) * kWave;
+  if (n_slots > (size_t)0x7fffffff) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  const size_t n_packed = (size_t)L.n_slices * kWave;
+  const size_t lanes = (size_t)L.wg_count * kWave;
+  const size_t fV = sizeof(float) * (size_t)V, fE = sizeof(float) * (size_t)E, iV = sizeof(int32_t) * (size_t)V;
+  struct { DevBuf* b; size_t bytes; } req[] = {
+      {&ctx->pos, 2 * fV}, {&ctx->src, fE}, {&ctx->dst, fE},
+      {&ctx->row_ptr, sizeof(int32_t) * ((size_t)V + 1)}, {&ctx->half, 2 * fE},
+      {&ctx->slice_row, sizeof(int32_t) * ((size_t)L.n_slices + 1)}, {&ctx->perm, sizeof(int32_t) * n_packed},
+      {&ctx->pdeg, sizeof(int32_t) * n_packed}, {&ctx->iperm, iV}, {&ctx->order_m, iV}, {&ctx->rid_of, iV},
+      {&ctx->rec_nbr, sizeof(uint32_t) * n_slots}, {&ctx->rec_edge, sizeof(int32_t) * n_slots}, {&ctx->edge_src_slot, fE},
+      {&ctx->hrec, sizeof(int4) * n_slots}, {&ctx->hq, sizeof(float4) * n_slots},
+      {&ctx->vstate, sizeof(float4) * n_packed}, {&ctx->vaux, sizeof(float2) * n_packed},
+      {&ctx->hq_alt, sizeof(float4) * n_slots}, {&ctx->vstate_alt, sizeof(float4) * n_packed}, {&ctx->photo_err, fV},
+      {&ctx->bar0, sizeof(float4) * n_packed}, {&ctx->bar1, sizeof(float4) * n_packed},
+      {&ctx->vprev, sizeof(float4) * n_packed}, {&ctx->xbuf, kXbufBytesPerVertex * records_capacity(L) + 64},
+      {&ctx->wg_v0, sizeof(int32_t) * L.wg_v0.size()},
+      {&ctx->wg_vfirst, L.wg_vfirst.size() + 16}, {&ctx->abort_flag, sizeof(int)}, {&ctx->err, kErrBytes}, {&ctx->cost_out, 2 * sizeof(float)},
+      {&ctx->wg_slot, sizeof(int32_t) * lanes}, {&ctx->wg_vid, sizeof(int32_t) * lanes}, {&ctx->wg_meta, sizeof(uint32_t) * lanes},
+      {&ctx->wg_nbr, sizeof(int32_t) * lanes}, {&ctx->wg_fetch, sizeof(int32_t) * lanes},
+      {&ctx->wg_info, sizeof(int32_t) * L.wg_info.size()}};
+  for (auto& r : req) {
+    rc = ensure(ctx, *r.b, r.bytes);
+    if (rc) return rc;
+  }
+  ctx->topo++;
+  ctx->he_built = ctx->tv_built = false;
+  drop_graphs(ctx);
+  refresh_args(ctx);
+
+  std::vector<StageCopy> cp = {
+      {&ctx->pos, g->pos, 2 * fV}, {&ctx->src, g->src, fE}, {&ctx->dst, g->dst, fE},
+      {&ctx->row_ptr, L.row_ptr.data(), sizeof(int32_t) * ((size_t)V + 1)}, {&ctx->half, L.half.data(), 2 * fE},
+      {&ctx->slice_row, L.slice_row.data(), sizeof(int32_t) * ((size_t)L.n_slices + 1)},
+      {&ctx->perm, L.perm.data(), sizeof(int32_t) * n_packed}, {&ctx->pdeg, L.pdeg.data(), sizeof(int32_t) * n_packed},
+      {&ctx->iperm, L.iperm.data(), iV}, {&ctx->order_m, L.order_m.data(), iV}, {&ctx->rid_of, L.rid_of.data(), iV},
+      {&ctx->wg_info, L.wg_info.data(), sizeof(int32_t) * L.wg_info.size()},
+      {&ctx->wg_v0, L.wg_v0.data(), sizeof(int32_t) * L.wg_v0.size()},
+      {&ctx->wg_vfirst, L.wg_vfirst.data(), L.wg_vfirst.size()}};
+  cp.insert(cp.end(), extra, extra + n_extra);
+  std::vector<StageFill> fills = {
+      {ctx->err.p, kErrBytes, 0u}, {ctx->abort_flag.p, sizeof(int), 0u}, {ctx->xbuf.p, kXbufBytesPerVertex * records_capacity(L) + 64, 0u},
+      // empty slots / padding vertices of the second copies: zero, as the packing kernels write them in the first
+      {ctx->hq_alt.p, sizeof(float4) * n_slots, 0u}, {ctx->vstate_alt.p, sizeof(float4) * n_packed, 0u},
+      // the spare rows behind the last slice: no edge, neighbour 0 (what the unrolled sweeps may read past a slice's end)
+      {(char*)ctx->rec_edge.p + sizeof(int32_t) * (size_t)L.rows * kWave, sizeof(int32_t) * kRowPad * kWave, 0xffffffffu},
+      {(char*)ctx->rec_nbr.p + sizeof(uint32_t) * (size_t)L.rows * kWave, sizeof(uint32_t) * kRowPad * kWave, 0u}};
+  // (the tags start over below: no record of an earlier topology may survive, in the placement pool either)
+  if (ctx->place_base) {
+    fills.push_back(StageFill{ctx->place_base, (size_t)2 * kPlacePages * 4096, 0u});
+    fills.push_back(StageFill{(int*)ctx->place_fill.p + 2 * kPlacePages, 64, 0u});
+  }
+  rc = staged_h2d(ctx, cp.data(), cp.size(), fills.data(), fills.size());
+  if (rc) return rc;
+  LAUNCHCHK(ctx, launch_build_sell(ctx->c, ctx->f, (const int32_t*)ctx->iperm.p, ctx->stream));
+  if (L.wg_ok)
+    LAUNCHCHK(ctx, launch_build_patches(ctx->c, ctx->f, (const int32_t*)ctx->wg_v0.p, (const int32_t*)ctx->order_m.p,
+                                        (const int32_t*)ctx->rid_of.p, (const uint8_t*)ctx->wg_vfirst.p,
+                                        (const int32_t*)ctx->iperm.p, ctx->stream));
+  // where the records that cross XCDs go (if the pages have been timed already; otherwise the first run does both): on
+  // the stream behind the layout kernels, nobody waits for it
+  if (L.wg_ok && ctx->place_state == 1 && ctx->opt_place && L.wg_count > 2 * (ctx->prop.multiProcessorCount / 8) &&
+      (ctx->opt_xcds == 0 || ctx->opt_xcds == 8)) {
+    refresh_args(ctx);
+    rc = place_records(ctx, (L.wg_count + 7) / 8);
+    if (rc) return rc;
+  }
+  ctx->pending = flame_nltgv2_ctx::PendingRun{};
+  ctx->tag_next = 1;
+  ctx->xbuf_form = 0;
+  ctx->static_stale = false;
+  ctx->h_src.assign(g->src, g->src + E);
+  ctx->h_dst.assign(g->dst, g->dst + E);
+  return 0;
+}
+
+// (C) / (D) rows: built and uploaded when the lane-per-half-edge / vertex-per-lane persistent form is first wanted for
+// the current topology (single frames run in the patch-per-wave form and never need them).
+int ensure_form_rows(flame_nltgv2_ctx* ctx, int form) {
+  PackedLayout& L = ctx->L;
+  if (form == 1 && !ctx->he_built) {
+    // (C) is (E) lane for lane (the same greedy walk): converted on the device from the patch rows, no host work
+    const size_t lanes = (size_t)L.wg_count * kWave;
+    L.he_ok = L.wg_ok, L.he_waves = L.wg_count, L.he_max_chain = std::max(L.max_degree, 1), L.comp_he_wave = L.comp_wg;
+    struct { DevBuf* b; size_t bytes; } req[] = {{&ctx->he_slot, sizeof(int32_t) * lanes}, {&ctx->he_vid, sizeof(int32_t) * lanes},
+                                                 {&ctx->he_meta, sizeof(uint32_t) * lanes},
+                                                 {&ctx->he_wave_chain, sizeof(int32_t) * (size_t)L.wg_count}};
+    bool grow = false;
+    for (auto& r : req) grow = grow || r.bytes > r.b->cap;
+    if (grow) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (a buffer is about to be reallocated)
+    for (auto& r : req) {
+      const int rc = ensure(ctx, *r.b, r.bytes);
+      if (rc) return rc;
+    }
+    LAUNCHCHK(ctx, launch_he_from_patches(ctx->f, (int32_t*)ctx->he_slot.p, (int32_t*)ctx->he_vid.p, (uint32_t*)ctx->he_meta.p,
+                                          (int32_t*)ctx->he_wave_chain.p, ctx->stream));
+    ctx->he_built = true;
+    refresh_args(ctx);
+  }
+  if (form == 2 && !ctx->tv_built) {
+    build_tv_rows(&L);
+    struct { DevBuf* b; const void* src; size_t bytes; } cp[] = {
+        {&ctx->tv_slot, L.tv_slot.data(), sizeof(int32_t) * L.tv_slot.size()}, {&ctx->tv_vid, L.tv_vid.data(), sizeof(int32_t) * L.tv_vid.size()},
+        {&ctx->tv_meta, L.tv_meta.data(), sizeof(uint32_t) * L.tv_meta.size()}, {&ctx->tv_wave, L.tv_wave.data(), sizeof(uint32_t) * L.tv_wave.size()}};
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& c : cp) {
+      int rc = ensure(ctx, *c.b, c.bytes);
+      if (!rc) rc = h2d(ctx, *c.b, c.src, c.bytes);
+      if (rc) return rc;
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->tv_built = true;
+    refresh_args(ctx);
+  }
+  return 0;
+}
+
+bool params_ok(const flame_nltgv2_params* p) { return p != nullptr; }
+
+}  // namespace host
+}  // namespace flame_hip
+
+extern "C" {
+
+int flame_nltgv2_abi_version(void) { return FLAME_NLTGV2_ABI_VERSION; }
+
+void flame_nltgv2_default_params(flame_nltgv2_params* p) {
+  if (!p) return;
+  p->data_factor = 0.1f, p->step_x = 0.001f, p->step_q = 125.0f;
+  p->theta = 0.25f, p->x_min = 0.0f, p->x_max = 10.0f;
+}
+
+const char* flame_nltgv2_status_string(int status) {
+  switch (status) {
+    case FLAME_NLTGV2_OK: return "ok";
+    case FLAME_NLTGV2_ERR_INVALID_ARG: return "invalid argument";
+    case FLAME_NLTGV2_ERR_NO_DEVICE: return "no usable HIP device";
+    case FLAME_NLTGV2_ERR_HIP: return "HIP runtime error";
+    case FLAME_NLTGV2_ERR_NO_GRAPH: return "no graph uploaded";
+    case FLAME_NLTGV2_ERR_NAN: return "dual variable became NaN/Inf (reference FLAME_ASSERT, h:174)";
+    case FLAME_NLTGV2_ERR_OOM: return "out of device memory";
+    case FLAME_NLTGV2_ERR_TIMEOUT: return "persistent run: neighbour wait timed out";
+    case FLAME_NLTGV2_ERR_ASSERT: return "input on which the reference asserts (FLAME_ASSERT)";
+    default: return "unknown status";
+  }
+}
+
+int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
+  if (!out) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return FLAME_NLTGV2_ERR_NO_DEVICE;
+  if (device < 0 || device >= count) return FLAME_NLTGV2_ERR_NO_DEVICE;
+  flame_nltgv2_ctx* ctx = new (std::nothrow) flame_nltgv2_ctx();
+  if (!ctx) return FLAME_NLTGV2_ERR_OOM;
+  ctx->device = device;
+  bool ok = hipSetDevice(device) == hipSuccess;
+  ok = ok && hipGetDeviceProperties(&ctx->prop, device) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&ctx->h_err, kErrBytes, hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&ctx->h_cost, 2 * sizeof(float), hipHostMallocDefault) == hipSuccess;
+  if (!ok) {
+    flame_nltgv2_destroy(ctx);
+    return FLAME_NLTGV2_ERR_HIP;
+  }
+  ctx->stream = ctx->own_stream;
+  *ctx->h_err = 0;
+  ctx->all = {&ctx->pos, &ctx->x, &ctx->w1, &ctx->w2, &ctx->xb, &ctx->w1b, &ctx->w2b, &ctx->xp, &ctx->w1p,
+              &ctx->w2p, &ctx->data, &ctx->weight, &ctx->src, &ctx->dst, &ctx->alpha, &ctx->beta, &ctx->q1,
+              &ctx->q2, &ctx->q3, &ctx->row_ptr, &ctx->half, &ctx->slice_row, &ctx->perm, &ctx->pdeg,
+              &ctx->rec_nbr, &ctx->rec_edge, &ctx->edge_src_slot, &ctx->hrec, &ctx->hq, &ctx->vstate, &ctx->hq_alt, &ctx->vstate_alt, &ctx->cost_terms, &ctx->run_tail,
+              &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->xbuf, &ctx->abort_flag, &ctx->he_slot, &ctx->he_vid, &ctx->he_meta, &ctx->he_wave_chain, &ctx->tv_slot, &ctx->tv_vid, &ctx->tv_meta, &ctx->tv_wave, &ctx->err,
+              &ctx->cost_out, &ctx->img_ref, &ctx->img_cmp, &ctx->photo_err, &ctx->r_tris, &ctx->r_valid, &ctx->r_keys,
+              &ctx->r_img, &ctx->r_cov, &ctx->r_vtx, &ctx->r_val, &ctx->wg_slot, &ctx->wg_vid, &ctx->wg_meta, &ctx->wg_nbr,
+              &ctx->wg_fetch, &ctx->wg_info, &ctx->wg_v0, &ctx->probe, &ctx->snap_hq, &ctx->snap_vstate, &ctx->snap_bar, &ctx->iperm,
+              &ctx->order_m, &ctx->rid_of, &ctx->d_stage, &ctx->sync_init, &ctx->sync_vmap, &ctx->sync_emap, &ctx->sync_need,
+              &ctx->wg_vfirst, &ctx->place_pool, &ctx->place_rank, &ctx->place_fill, &ctx->place_rec_off, &ctx->place_patch, &ctx->place_meas, &ctx->progress};
+  for (auto& b : ctx->sp_v) ctx->all.push_back(&b);
+  for (auto& b : ctx->sp_q) ctx->all.push_back(&b);
+  *out = ctx;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_destroy(flame_nltgv2_ctx* ctx) {
+  if (!ctx) return FLAME_NLTGV2_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  drop_graphs(ctx);
+  for (DevBuf* b : ctx->all)
+    if (b->p) (void)hipFree(b->p);
+  if (ctx->h_err) (void)hipHostFree(ctx->h_err);
+  if (ctx->h_cost) (void)hipHostFree(ctx->h_cost);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_set_stream(flame_nltgv2_ctx* ctx, void* hip_stream) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
+  if (!ctx) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  switch (option) {
+    case FLAME_NLTGV2_OPT_SOLVER:
+      if (value != 0 && value != 1) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_solver = value;
+      return 0;
+    case FLAME_NLTGV2_OPT_USE_HIPGRAPH:
+      ctx->opt_use_graph = value ? 1 : 0;
+      return 0;
+    case FLAME_NLTGV2_OPT_BLOCK_WAVES:
+      if (value != 0 && value != 1 && value != 2 && value != 4) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_block_waves = value;
+      return 0;
+    case FLAME_NLTGV2_OPT_PERSISTENT:
+      if (value < 0 || value > 4) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_persistent = value;
+      return 0;
+    case FLAME_NLTGV2_OPT_PLACEMENT:
+      if (value < 0 || value > 1) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_place = value;
+      return 0;
+    case FLAME_NLTGV2_OPT_POLL_GAP:
+      if (value < 0 || value > 4) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_poll_gap = value;
+      return 0;
+    case FLAME_NLTGV2_OPT_VERIFY_RECORDS:
+      if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_verify = value;
+      if (value != 2) ctx->persist_refused_topo = ~0ull;  // hook off: let the persistent path be tried again
+      return 0;
+    case FLAME_NLTGV2_OPT_PROBE:
+      ctx->opt_probe = value ? 1 : 0;
+      return 0;
+    case FLAME_NLTGV2_OPT_DUAL_PUBLISH:
+      if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_dual = value;
+      return 0;
+    case FLAME_NLTGV2_OPT_FAULT_INJECT:
+      if (value < 0 || value > (1 << 24)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_fault = value;
+      if (value == 0) ctx->persist_refused_topo = ~0ull;  // let the persistent path be tried again
+      return 0;
+    case FLAME_NLTGV2_OPT_XCDS:
+      if (value < 0 || value > 8) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_xcds = value;
+      ctx->coop_checked_key = ~0ull;
+      return 0;
+    case FLAME_NLTGV2_OPT_PRESLEEP:
+      if (value < 0 || value > 256) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_presleep = value;
+      return 0;
+    case FLAME_NLTGV2_OPT_TV_LDS:
+      if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_tv_lds = value;
+      return 0;
+    case FLAME_NLTGV2_OPT_UNROLL:
+      if (value != 0 && value != 4 && value != 8 && value != 16) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_unroll = value;
+      return 0;
+    default:
+      return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  }
+}
+
+
+int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info) {
+  if (!ctx || !info) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  std::memset(info, 0, sizeof(*info));
+  info->abi_version = FLAME_NLTGV2_ABI_VERSION;
+  info->device = ctx->device;
+  info->V = ctx->L.V, info->E = ctx->L.E;
+  info->n_slices = ctx->L.n_slices;
+  info->max_degree = ctx->L.max_degree;
+  info->padded_half_edges = ctx->L.rows * kWave;
+  info->device_bytes = (int64_t)ctx->device_bytes;
+  info->algorithmic_bytes_per_iter = 64ll * ctx->L.V + 40ll * ctx->L.E;
+  info->compute_units = ctx->prop.multiProcessorCount;
+  std::snprintf(info->device_name, sizeof(info->device_name), "%s", ctx->prop.name);
+  std::snprintf(info->gcn_arch, sizeof(info->gcn_arch), "%s", ctx->prop.gcnArchName);
+  info->last_run_path = ctx->last_run_path;
+  info->he_waves = ctx->L.wg_ok ? ctx->L.wg_count : 0;  // (the same greedy walk as the patches)
+  if (ctx->have_graph && !ctx->tv_built) {  // the vertex-per-lane rows are built on demand; a caller sizing a batch asks here
+    ctx->L.tv_waves = 0;
+    build_tv_rows(&ctx->L);  // host table only; the upload happens when the form is first used
+  }
+  info->tv_waves = ctx->L.tv_ok ? ctx->L.tv_waves : 0;
+  info->patches = ctx->L.wg_ok ? ctx->L.wg_count : 0;
+  info->tv_wave_capacity = (ctx->opt_tv_lds ? kTvLdsWavesPerCu : kTvWavesPerCu) * ctx->prop.multiProcessorCount;
+  info->last_run_groups = ctx->last_run_groups;
+  info->timeouts_recovered = ctx->timeouts_recovered;
+  info->torn_records_detected = ctx->torn_records_detected;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_last_error(flame_nltgv2_ctx* ctx) { return ctx ? ctx->last_error : FLAME_NLTGV2_ERR_INVALID_ARG; }
+int flame_nltgv2_last_hip_error(flame_nltgv2_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
+
+int flame_nltgv2_read_probe(flame_nltgv2_ctx* ctx, uint32_t* out, int64_t max_words, int64_t* n_words) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (ctx->pending.active) {
+    rc = finish(ctx);
+    if (rc) return rc;
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const int64_t have = (int64_t)ctx->probe_words;
+  if (n_words) *n_words = have;
+  if (out && ctx->probe.p) {
+    const int64_t n = std::min(have, max_words);
+    if (n > 0) HIPCHK(ctx, hipMemcpy(out, ctx->probe.p, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
+  }
+  return FLAME_NLTGV2_OK;
+}
+
+// The per-slot / per-lane layout arrays as the device expanded them (nltgv2_layout.hip) against the host builders of
+// nltgv2_pack.hpp on the same topology: number of differing words (0 = identical).
+int flame_nltgv2_layout_selftest(flame_nltgv2_ctx* ctx, int64_t* mismatches) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!mismatches) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  rc = ensure_canon(ctx);
+  if (rc) return rc;
+  const int32_t V = ctx->L.V, E = ctx->L.E;
+  std::vector<float> pos(2 * (size_t)V);
+  HIPCHK(ctx, hipMemcpyAsync(pos.data(), ctx->pos.p, sizeof(float) * pos.size(), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  flame_nltgv2_graph g{};
+  g.V = V, g.E = E, g.pos = pos.data(), g.src = ctx->h_src.data(), g.dst = ctx->h_dst.data();
+  PackedLayout H;
+  rc = build_layout(&g, &H, /*host_expand=*/true, ctx->L.wg_rowpack);  // (the modes the layout was actually built with)
+  if (rc) return fail(ctx, rc);
+  int64_t bad = 0;
+  auto cmp = [&](const DevBuf& b, const void* host, size_t bytes) -> int {
+    if (bytes == 0) return 0;
+    std::vector<uint32_t> d(bytes / 4);
+    if (hipMemcpy(d.data(), b.p, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    const uint32_t* h = static_cast<const uint32_t*>(host);
+    for (size_t i = 0; i < d.size(); ++i) bad += d[i] != h[i];
+    return 0;
+  };
+  const PackedLayout& L = ctx->L;
+  bad += (H.rows != L.rows) + (H.n_slices != L.n_slices) + (H.wg_ok != L.wg_ok) + (H.wg_count != L.wg_count) +
+         (H.wg_lcap != L.wg_lcap) + (H.wg_slab_slots != L.wg_slab_slots) + (H.n_rec != L.n_rec) +
+         (H.wg_v0 != L.wg_v0) + (H.wg_vfirst != L.wg_vfirst) + (H.wg_rowpack != L.wg_rowpack);
+  if (bad == 0) {
+    const size_t n = (size_t)L.rows * kWave, lanes = (size_t)L.wg_count * kWave;
+    int e = cmp(ctx->rec_nbr, H.rec_nbr.data(), 4 * n) | cmp(ctx->rec_edge, H.rec_edge.data(), 4 * n) |
+            cmp(ctx->edge_src_slot, H.edge_src_slot.data(), 4 * (size_t)E) | cmp(ctx->perm, H.perm.data(), 4 * H.perm.size()) |
+            cmp(ctx->slice_row, H.slice_row.data(), 4 * H.slice_row.size());
+    if (L.wg_ok)
+      e |= cmp(ctx->wg_slot, H.wg_slot.data(), 4 * lanes) | cmp(ctx->wg_vid, H.wg_vid.data(), 4 * lanes) |
+           cmp(ctx->wg_meta, H.wg_meta.data(), 4 * lanes) | cmp(ctx->wg_nbr, H.wg_nbr.data(), 4 * lanes) |
+           cmp(ctx->wg_fetch, H.wg_fetch.data(), 4 * lanes) | cmp(ctx->wg_info, H.wg_info.data(), 4 * H.wg_info.size());
+    if (ctx->he_built)  // (C), converted on the device from (E), against the host's own walk
+      e |= cmp(ctx->he_slot, H.he_slot.data(), 4 * H.he_slot.size()) | cmp(ctx->he_vid, H.he_vid.data(), 4 * H.he_vid.size()) |
+           cmp(ctx->he_meta, H.he_meta.data(), 4 * H.he_meta.size()) |
+           cmp(ctx->he_wave_chain, H.he_wave_chain.data(), 4 * H.he_wave_chain.size());
+    if (ctx->he_built) bad += (H.he_waves != L.he_waves) + (H.he_max_chain != L.he_max_chain) + (H.comp_he_wave != L.comp_he_wave);
+    if (e) return fail(ctx, FLAME_NLTGV2_ERR_HIP);
+  }
+  if (bad == 0 && ctx->place_state == 1 && ctx->place_topo == ctx->topo && L.wg_ok) {
+    // placed records: aligned, inside their parity's half of the pool, no slot given out twice -- and exactly the records a
+    // patch on another XCD reads (host: the same rule as k_place_assign, from the host's own patch walk)
+    const size_t stride = records_capacity(L);
+    std::vector<int32_t> off(2 * stride);
+    if (hipMemcpy(off.data(), ctx->place_rec_off.p, sizeof(int32_t) * off.size(), hipMemcpyDeviceToHost) != hipSuccess)
+      return fail(ctx, FLAME_NLTGV2_ERR_HIP);
+    std::vector<int32_t> patch_of_rec((size_t)V, -1);
+    for (int32_t q = 0; q < H.wg_count; ++q)
+      for (int32_t i = 0; i < (H.wg_info[(size_t)q * 4 + 2] & 0xffff); ++i) patch_of_rec[(size_t)H.wg_info[(size_t)q * 4] + i] = q;
+    const int32_t per = ctx->place_per_xcd;
+    for (int par = 0; par < 2; ++par) {
+      std::vector<int32_t> used;
+      for (int32_t u = 0; u < V; ++u) {
+        const int32_t r = H.rid_of[(size_t)u], a = patch_of_rec[(size_t)r] / per;
+        bool crosses = false;
+        for (int32_t h = H.row_ptr[(size_t)u]; h < H.row_ptr[(size_t)u + 1] && !crosses; ++h)
+          crosses = patch_of_rec[(size_t)H.rid_of[(size_t)H.half_nbr[(size_t)h]]] / per != a;
+        const int32_t o = off[(size_t)par * stride + r];
+        bad += crosses != (o >= 0);
+        if (o < 0) continue;
+        bad += (o & 15) != 0 || o < par * kPlacePages * 4096 || o >= (par + 1) * kPlacePages * 4096;
+        used.push_back(o);
+      }
+      std::sort(used.begin(), used.end());
+      for (size_t i = 1; i < used.size(); ++i) bad += used[i] == used[i - 1];
+    }
+  }
+  *mismatches = bad;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_placement_info(flame_nltgv2_ctx* ctx, int32_t* state, int32_t* placed_records, float* us) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (state) *state = ctx->place_state;
+  if (us) us[0] = ctx->place_best_us, us[1] = ctx->place_mean_us, us[2] = ctx->place_worst_us;
+  if (placed_records) {
+    *placed_records = 0;
+    if (ctx->have_graph && ctx->place_state == 1 && ctx->place_topo == ctx->topo) {
+      std::vector<int32_t> off((size_t)ctx->L.V);  // (parity 0; the walk's records)
+      HIPCHK(ctx, hipMemcpyAsync(off.data(), ctx->place_rec_off.p, sizeof(int32_t) * off.size(), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      for (int32_t o : off) *placed_records += o >= 0;
+    }
+  }
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_pack_probe(const flame_nltgv2_graph* g, int32_t* perm, int32_t* slice_row, int32_t* rec_nbr,
+                            int32_t* rec_edge, int64_t capacity_rows, int64_t* rows_out) {
+  PackedLayout L;
+  int rc = build_layout(g, &L);
+  if (rc) return rc;
+  if (rows_out) *rows_out = L.rows;
+  if (perm) std::memcpy(perm, L.perm.data(), sizeof(int32_t) * L.perm.size());
+  if (slice_row) std::memcpy(slice_row, L.slice_row.data(), sizeof(int32_t) * L.slice_row.size());
+  if ((rec_nbr || rec_edge) && capacity_rows < L.rows) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  const size_t n = (size_t)L.rows * kWave;
+  if (rec_nbr) std::memcpy(rec_nbr, L.rec_nbr.data(), sizeof(int32_t) * n);
+  if (rec_edge) std::memcpy(rec_edge, L.rec_edge.data(), sizeof(int32_t) * n);
+  return L.n_slices;
+}
+
+}  // extern "C"

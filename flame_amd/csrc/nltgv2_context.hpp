@@ -1,0 +1,302 @@
+// nltgv2_context.hpp -- internal to libflame_nltgv2_hip.so: the solver context behind flame_nltgv2_ctx (include/flame_nltgv2.h) and the
+// host-side functions the C-ABI translation units share.  Host side of the drop-in boundary for
+// flame::optimizers::nltgv2_l1_graph_regularizer (/root/reference/src/flame/optimizers/nltgv2_l1_graph_regularizer.h:134-168).
+// The context owns the device image of one reference Graph (h:107-112) in two forms:
+//   canonical  SoA arrays in the caller's vertex/edge order  (upload/download, the individually callable
+//              dual/primal/extragradient sweeps, costs)
+//   packed     SELL-64 layout of the fused one-kernel-per-step sweep and the row layouts of the persistent kernels (run)
+// and converts between them on the device only when the other form is asked for.
+//   nltgv2_context.hip     buffers, uploads of a topology, context life cycle, options, info, self-tests
+//   nltgv2_run.hip         which kernels run n steps (planner), enqueue / settle / roll back, the run entry points
+//   nltgv2_graph_capi.hip  graph in / out: upload, per-frame sync, projection, rescale, state download, costs, export
+//   nltgv2_frame_capi.hip  the rows around the solver that work on its device state: mesh rasteriser, photometric residual
+#ifndef FLAME_AMD_NLTGV2_CONTEXT_HPP_
+#define FLAME_AMD_NLTGV2_CONTEXT_HPP_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <new>
+#include <memory>
+#include <vector>
+
+#include "flame_nltgv2.h"
+#include "nltgv2_kernels.h"
+#include "nltgv2_pack.hpp"
+#include "roctx_ranges.hpp"
+
+namespace flame_hip {
+namespace host {
+
+constexpr int kGraphChunk = 256;      // steps per captured hipGraph (even: keeps ping-pong parity)
+constexpr int kMaxCachedGraphs = 6;
+constexpr int kHeWavesPerCu = 24;      // residency cap of k_persistent_he (<= 64 VGPRs: the hardware admits 32)
+constexpr int kTvLdsWavesPerCu = 16;   // ... with the slot constants in LDS (<= 128 VGPRs -> 4 waves per SIMD; 10 KB LDS per wave = all 160 KB)
+constexpr size_t kXbufBytesPerVertex = 8 * 16 + 4;  // exchange buffers: up to four step buffers x (remote + same-XCD copy) of
+                                                    // 16-byte records (the patch-per-wave form; the others use two) + the XCC table
+constexpr int kPvDensePerCu = 23;      // k_persistent_pv is used up to this many patches per CU (24 are resident: 6 waves per SIMD)
+constexpr int kPvPaceAbovePerCu = 17;  // ... and above this many its polls are paced (kPvDensePreSleep, kPvDenseGap)
+constexpr int kPvDensePreSleep = 8, kPvDenseGap = 4;  // x64 cycles before the first poll of a step / between poll rounds
+constexpr int kPvPreSleep = 0;         // k_persistent_pv: x64 cycles between a step's start and its first poll
+constexpr int kPvPollGap = 2;          // k_persistent_pv polls: re-loading only the fetch entries still waiting, no pause between
+                                       // rounds (with the round-2 first form of the kernel an s_sleep between rounds won by 1-3 %;
+                                       // with the shorter hand-off path of its final form no pause wins by 3-4 % at 640x480)
+constexpr int kTvWavesPerCu = 8;       // residency of k_persistent_tv (<= 256 VGPRs -> 2 waves per SIMD)
+constexpr int kDualMinWavesPerCu = 0;  // auto: exchange through the XCD's L2 when more waves than this share a CU
+// x64-cycle sleep between publishing and the first neighbour poll (measured optimum, r01 sweep: he 6 at
+// <= 12 waves/CU, 10 above; tv is insensitive, shortest wins)
+constexpr int kPreSleepHe = 6, kPreSleepHeDense = 10, kPreSleepHeOneXcd = 4, kPreSleepTv = 2;
+constexpr size_t kErrBytes = 16 * sizeof(int);  // the flag word + what the first expired wait reports (report_expired)
+constexpr unsigned kMaxSpins = 1u << 20;  // bound of every neighbour wait in the persistent run (~1 s of polling bursts)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct CachedGraph {
+  hipGraphExec_t exec = nullptr;
+  int n = 0, parity = 0, unroll = 0, wpb = 0, gen = 0;
+  uint64_t topo = 0;
+  flame_nltgv2_params params{};
+  uint64_t stamp = 0;
+};
+
+// Open-addressing hash map u64 -> i32 (linear probing, power-of-two capacity, no erase): the per-frame
+// bookkeeping of sync_graph looks up ~V feature ids and ~E feature pairs; std::unordered_map made that the
+// most expensive part of a frame (2.0-2.5 ms at 640x480), this table does it in a fraction.
+class FlatMap {
+ public:
+  FlatMap() = default;
+  explicit FlatMap(size_t n) { reset(n); }
+  // Empties the table for up to n keys.  A slot is live only if it carries the current generation, so a table that is
+  // big enough is emptied by counting the generation up -- nothing is cleared (the per-frame sync empties two of these).
+  void reset(size_t n) {
+    size_t cap = 16;
+    while (cap < 2 * n + 2) cap <<= 1;
+    if (cap > slots_.size() || gen_ == 0xffffffffu) {
+      slots_.assign(std::max(cap, slots_.size()), Slot{0, 0, 0});
+      gen_ = 0;
+    }
+    mask_ = slots_.size() - 1;
+    ++gen_;
+  }
+  // inserts (k,v) if k is absent; returns the slot's value pointer and whether it was inserted
+  std::pair<int32_t*, bool> emplace(uint64_t k, int32_t v) {
+    size_t i = hash(k) & mask_;
+    for (;; i = (i + 1) & mask_) {
+      Slot& s = slots_[i];
+      if (s.gen != gen_) {
+        s = Slot{k, v, gen_};
+        return {&s.val, true};
+      }
+      if (s.key == k) return {&s.val, false};
+    }
+  }
+  const int32_t* find(uint64_t k) const {
+    size_t i = hash(k) & mask_;
+    for (;; i = (i + 1) & mask_) {
+      const Slot& s = slots_[i];
+      if (s.gen != gen_) return nullptr;
+      if (s.key == k) return &s.val;
+    }
+  }
+
+ private:
+  struct Slot {
+    uint64_t key;
+    int32_t val;
+    uint32_t gen;
+  };
+  static size_t hash(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return (size_t)(z ^ (z >> 31));
+  }
+  size_t mask_ = 0;
+  uint32_t gen_ = 0;
+  std::vector<Slot> slots_;
+};
+
+}  // namespace host
+}  // namespace flame_hip
+
+using namespace flame_hip;
+using namespace flame_hip::host;
+
+struct flame_nltgv2_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int last_error = 0;
+  int last_hip = 0;
+  hipDeviceProp_t prop{};
+
+  bool have_graph = false;
+  bool canon_valid = false, fused_valid = false, have_prev = false;
+  DevBuf sp_v[9], sp_q[3], sync_init, sync_vmap, sync_emap, sync_need;  // sync_graph: spare state arrays, inputs, index maps
+  std::vector<int32_t> h_old_of_new, h_old_of_new_edge;
+  FlatMap feat_maps[3];     // [cur]: feature id -> vertex of the CURRENT graph (h_feat), kept from one sync to the next; the
+  int feat_cur = 0;         // next sync fills the other one; [2]: scratch of a sync (new edges' duplicates)
+  bool feat_map_valid = false;
+  int parity = 0;
+  uint64_t topo = 0, stamp = 0;
+
+  int opt_solver = 0, opt_use_graph = 1, opt_block_waves = 0, opt_unroll = 0, opt_persistent = 1, opt_dual = 1;
+  int xbuf_form = 0;     // the persistent form whose records the exchange buffers hold (0: cleared)
+  int opt_xcds = 0;      // XCDs a persistent launch spreads over: 0 = auto, 1..8
+  bool photo_fused = false;     // flame_nltgv2_photo_fuse: every run also leaves the photometric residual in photo_err
+  PhotoGeometry photo_geo{};
+  float photo_scale = 1.0f;
+  int photo_border = 3;
+  float* export_ptr = nullptr;  // flame_nltgv2_set_export_target: every run also leaves x * scale there
+  float export_scale = 1.0f;
+  int opt_fault = 0;     // test hook: > 0 = the next persistent runs time out after this many spins
+  int opt_presleep = 0;  // 0: auto (kPreSleep*); n > 0: (n - 1) x 64 cycles
+  int opt_poll_gap = 0;  // patch-per-wave form: 0 = default (kPvPollGap), 1 = no sleep between polls, 2 = one s_sleep, 3 / 4 = the same, narrowed
+  mutable int pv_occ = 0;            // patches of k_persistent_pv the runtime keeps resident per CU for the current layout
+  mutable uint64_t pv_occ_topo = ~0ull;
+  int opt_probe = 0;     // > 0: k_persistent_pv records a per-patch, per-step cycle probe (flame_nltgv2_read_probe)
+  size_t probe_words = 0;
+  int opt_tv_lds = 1;  // 0 registers, 1 auto (LDS when the register form is not resident in one launch), 2 LDS
+  uint32_t tag_next = 1;  // persistent run: tag of the current bar values (monotonic)
+  int last_run_path = 0, last_run_groups = 0;
+  uint64_t persist_refused_topo = ~0ull;  // topology for which the runtime refused the persistent grid
+  bool static_stale = false;  // pos changed on the device (project_graph): packed alpha/dx/dy need a re-pack
+  uint64_t coop_checked_key = 0;  // (topology, form) whose persistent grid the runtime has verified as resident
+  int buf_gen = 0;                // which of the two (hq, vstate) copies is current; part of the hipGraph cache key
+  int timeouts_recovered = 0;     // persistent runs that timed out and were redone on the per-step path
+  int torn_records_detected = 0;  // ... that the record verification (opt_verify) stopped, redone the same way
+  int opt_verify = 0;             // 1: persistent kernels re-read every record after its tag matched; 2: + test hook
+  // Record placement of the patch-per-wave form (nltgv2_layout.hip): a pool of pages measured once per context, the
+  // records read across XCDs assigned to them once per topology
+  int opt_place = 1;              // 1 (default) on, 0 off
+  int place_state = 0;            // 0 not calibrated yet, 1 page ranking on the device, -1 unavailable (calibration failed)
+  uint64_t place_topo = ~0ull;    // topology / patches per XCD the record offsets are valid for
+  int place_per_xcd = 0;
+  char* place_base = nullptr;     // the pool, 4 KB aligned inside place_pool
+  float place_best_us = 0.0f, place_mean_us = 0.0f, place_worst_us = 0.0f;  // one-way hand-off by page choice, mean over XCD pairs
+  DevBuf place_pool, place_rank, place_fill, place_rec_off, place_patch, place_meas;
+  // The persistent run(s) in flight, until finish() has seen the error word: what is needed to take them back.  One
+  // run is taken back by swapping the buffer roles (it wrote the other copies).  When more work is enqueued before the
+  // first run has been checked (run_async back to back: the frame loop, bench.py), the state the chain started from is
+  // copied aside first (three device-to-device copies, once per chain), and the chain is kept as a list of operations:
+  // a wait that expires anywhere in it restores that state and replays the list on the one-launch-per-step path.
+  struct PendingOp {
+    int kind = 0;  // 0 run, 1 explicit export of x * scale
+    flame_nltgv2_params params{};
+    int n = 0;
+    float* dst = nullptr;
+    float scale = 1.0f;
+  };
+  struct PendingRun {
+    bool active = false;
+    bool snapshotted = false;  // the pre-chain state is in snap_hq / snap_vstate / snap_bar
+    int parity_before = 0;
+    bool have_prev_before = false;
+    std::vector<PendingOp> ops;
+  } pending;
+  DevBuf snap_hq, snap_vstate, snap_bar;
+  DevBuf iperm, order_m, rid_of;   // per-vertex tables the device-side layout expansion reads (nltgv2_layout.hip)
+  bool he_built = false, tv_built = false;  // layouts (C) / (D) exist for the current topology (built on demand)
+  void* h_stage = nullptr;         // pinned staging buffer of the uploads
+  DevBuf d_stage;                 // ... and its device-side landing area (one copy; k_scatter distributes)
+  size_t stage_cap = 0;
+
+  PackedLayout L;
+  std::vector<int32_t> h_src, h_dst, h_feat;  // host image of the current topology (for sync_graph)
+  CanonArgs c;
+  FusedArgs f;
+  std::vector<DevBuf*> all;
+  // canonical
+  DevBuf pos, x, w1, w2, xb, w1b, w2b, xp, w1p, w2p, data, weight, src, dst, alpha, beta, q1, q2, q3, row_ptr, half;
+  // packed
+  DevBuf slice_row, perm, pdeg, rec_nbr, rec_edge, edge_src_slot, hrec, hq, vstate, vaux, bar0, bar1, vprev;
+  DevBuf cost_terms;          // addends of smoothnessCost / dataCost
+  DevBuf run_tail;            // RunTail of the persistent kernels (standing export / photometric targets)
+  RunTail tail_sent{};        // what run_tail currently holds
+  bool tail_valid = false;
+  std::vector<float> h_terms;
+  DevBuf hq_alt, vstate_alt;  // the other copies of hq / vstate: a persistent run writes there, success swaps the roles
+  DevBuf xbuf, abort_flag, he_slot, he_vid, he_meta, he_wave_chain, tv_slot, tv_vid, tv_meta, tv_wave;
+  DevBuf wg_slot, wg_vid, wg_meta, wg_nbr, wg_fetch, wg_info, wg_v0, wg_vfirst, probe, progress;
+  // misc
+  DevBuf err, cost_out, img_ref, img_cmp, photo_err, r_tris, r_valid, r_keys, r_img, r_cov, r_vtx, r_val;
+  int img_rows = 0, img_cols = 0, img_step = 0;
+  int* h_err = nullptr;    // pinned, kErrBytes
+  int last_expired[16] = {0};  // what the most recent expired wait reported (report_expired)
+  float* h_cost = nullptr; // pinned
+  std::vector<CachedGraph> graphs;
+  size_t device_bytes = 0;
+};
+
+#define HIPCHK(ctx, expr)                              \
+  do {                                                 \
+    hipError_t _e = (expr);                            \
+    if (_e != hipSuccess) {                            \
+      (ctx)->last_hip = (int)_e;                       \
+      (ctx)->last_error = FLAME_NLTGV2_ERR_HIP;        \
+      return FLAME_NLTGV2_ERR_HIP;                     \
+    }                                                  \
+  } while (0)
+
+#define LAUNCHCHK(ctx, expr)                           \
+  do {                                                 \
+    int _e = (expr);                                   \
+    if (_e != 0) {                                     \
+      (ctx)->last_hip = _e;                            \
+      (ctx)->last_error = FLAME_NLTGV2_ERR_HIP;        \
+      return FLAME_NLTGV2_ERR_HIP;                     \
+    }                                                  \
+  } while (0)
+
+namespace flame_hip {
+namespace host {
+
+// ---- nltgv2_context.hip ------------------------------------------------------------------------------------------------
+int fail(flame_nltgv2_ctx* ctx, int status);
+int ensure(flame_nltgv2_ctx* ctx, DevBuf& b, size_t bytes);   // grows a device buffer geometrically, reused across frames
+void drop_graphs(flame_nltgv2_ctx* ctx);
+SolverParams to_sp(const flame_nltgv2_params* p);
+int enter(flame_nltgv2_ctx* ctx);
+void refresh_args(flame_nltgv2_ctx* ctx);                     // kernel argument blocks from the current buffers
+int h2d(flame_nltgv2_ctx* ctx, DevBuf& b, const void* src, size_t bytes);
+size_t records_capacity(const PackedLayout& L);
+int ensure_canon(flame_nltgv2_ctx* ctx);                      // settles a pending run, unpacks the state if needed
+int ensure_fused(flame_nltgv2_ctx* ctx);
+bool params_ok(const flame_nltgv2_params* p);
+struct StageCopy {
+  DevBuf* b;
+  const void* src;
+  size_t bytes;
+};
+struct StageFill {
+  void* dst;
+  size_t bytes;
+  uint32_t word;
+};
+int staged_h2d(flame_nltgv2_ctx* ctx, const StageCopy* cp, size_t n, const StageFill* fills = nullptr, size_t n_fills = 0);
+int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const StageCopy* extra, size_t n_extra, bool long_lived);
+int ensure_form_rows(flame_nltgv2_ctx* ctx, int form);
+
+// ---- nltgv2_run.hip ----------------------------------------------------------------------------------------------------
+constexpr size_t kMaxChain = 256;  // operations enqueued behind an unchecked persistent run before the host settles it
+bool persistent_eligible(flame_nltgv2_ctx* ctx, int n);
+int prepare_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n);
+PhotoFuse photo_target(const flame_nltgv2_ctx* ctx);
+int enqueue_photo_sweep(flame_nltgv2_ctx* ctx, bool packed_current);
+int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n);
+int finish(flame_nltgv2_ctx* ctx);                            // reads the error word; rolls a failed persistent run back and redoes it
+int snapshot_chain_start(flame_nltgv2_ctx* ctx);
+int place_records(flame_nltgv2_ctx* ctx, int per_xcd);        // record placement, once per topology (k_place_assign)
+
+}  // namespace host
+}  // namespace flame_hip
+
+#endif  // FLAME_AMD_NLTGV2_CONTEXT_HPP_

@@ -1,0 +1,149 @@
+// nltgv2_frame_capi.hip -- the rows around the solver that work on its device state: mesh -> dense inverse-depth map, photometric
+// residual (see nltgv2_context.hpp).
+#include "nltgv2_context.hpp"
+
+extern "C" {
+
+// Shared tail of the two interpolate_mesh entry points: triangles/validity -> device, rasterise, copy back.
+static int interpolate_common(flame_nltgv2_ctx* ctx, const int32_t* triangles, int32_t T, int32_t V,
+                              const uint8_t* vtx_valid, const uint8_t* tri_valid, const float2* d_vtx,
+                              const float* d_val, float value_scale, int rows, int cols, float* out, int32_t* coverage) {
+  if (T < 0 || rows <= 0 || cols <= 0 || !out || (T > 0 && !triangles)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  for (int32_t t = 0; t < 3 * T; ++t)
+    if (triangles[t] < 0 || triangles[t] >= V) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  const size_t n = (size_t)rows * (size_t)cols;
+  int rc = ensure(ctx, ctx->r_tris, sizeof(int32_t) * 3 * (size_t)T);
+  if (!rc) rc = ensure(ctx, ctx->r_valid, (size_t)T + (size_t)V + 16);
+  if (!rc) rc = ensure(ctx, ctx->r_keys, sizeof(unsigned long long) * n);
+  if (!rc) rc = ensure(ctx, ctx->r_img, sizeof(float) * n);
+  if (!rc) rc = ensure(ctx, ctx->r_cov, sizeof(int));
+  if (rc) return rc;
+  if (T > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->r_tris.p, triangles, sizeof(int32_t) * 3 * (size_t)T, hipMemcpyHostToDevice, ctx->stream));
+  uint8_t* d_tv = nullptr;
+  uint8_t* d_vv = nullptr;
+  if (tri_valid && T > 0) {
+    d_tv = (uint8_t*)ctx->r_valid.p;
+    HIPCHK(ctx, hipMemcpyAsync(d_tv, tri_valid, (size_t)T, hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (vtx_valid && V > 0) {
+    d_vv = (uint8_t*)ctx->r_valid.p + (size_t)T;
+    HIPCHK(ctx, hipMemcpyAsync(d_vv, vtx_valid, (size_t)V, hipMemcpyHostToDevice, ctx->stream));
+  }
+  LAUNCHCHK(ctx, launch_interpolate_mesh(T, (const int32_t*)ctx->r_tris.p, d_vtx, d_val, value_scale, d_vv, d_tv,
+                                         (unsigned long long*)ctx->r_keys.p, (float*)ctx->r_img.p, (int*)ctx->r_cov.p,
+                                         rows, cols, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(out, ctx->r_img.p, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
+  int cov = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&cov, ctx->r_cov.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (coverage) *coverage = cov;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_interpolate_mesh(flame_nltgv2_ctx* ctx, const int32_t* triangles, int32_t T, const uint8_t* tri_valid,
+                                  int rows, int cols, float graph_scale, float* idepthmap_out, int32_t* coverage_out) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_interpolate_mesh");
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  rc = ensure_canon(ctx);
+  if (rc) return rc;
+  return interpolate_common(ctx, triangles, T, ctx->L.V, nullptr, tri_valid, ctx->c.pos, ctx->c.x, graph_scale, rows,
+                            cols, idepthmap_out, coverage_out);
+}
+
+int flame_nltgv2_interpolate_mesh_arrays(flame_nltgv2_ctx* ctx, const int32_t* triangles, int32_t T, const float* vertices_xy,
+                                         const float* values, int32_t V, const uint8_t* vtx_valid,
+                                         const uint8_t* tri_valid, int rows, int cols, float* img_out,
+                                         int32_t* coverage_out) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_interpolate_mesh_arrays");
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (V < 0 || (V > 0 && (!vertices_xy || !values))) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  rc = ensure(ctx, ctx->r_vtx, sizeof(float) * 2 * (size_t)V);
+  if (!rc) rc = ensure(ctx, ctx->r_val, sizeof(float) * (size_t)V);
+  if (rc) return rc;
+  if (V > 0) {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->r_vtx.p, vertices_xy, sizeof(float) * 2 * (size_t)V, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->r_val.p, values, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, ctx->stream));
+  }
+  return interpolate_common(ctx, triangles, T, V, vtx_valid, tri_valid, (const float2*)ctx->r_vtx.p,
+                            (const float*)ctx->r_val.p, 1.0f, rows, cols, img_out, coverage_out);
+}
+
+int flame_nltgv2_photo_set_images(flame_nltgv2_ctx* ctx, const uint8_t* ref, const uint8_t* cmp, int rows, int cols,
+                                  int step_bytes) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ref || !cmp || rows < 2 || cols < 2 || step_bytes < cols) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  const size_t bytes = (size_t)rows * (size_t)step_bytes;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  rc = ensure(ctx, ctx->img_ref, bytes + 16);
+  if (!rc) rc = ensure(ctx, ctx->img_cmp, bytes + 16);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->img_ref.p, ref, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->img_cmp.p, cmp, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->img_rows = rows, ctx->img_cols = cols, ctx->img_step = step_bytes;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_photo_residual(flame_nltgv2_ctx* ctx, const float* KRKinv, const float* Kt, float graph_scale,
+                                int border, float* err_out) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!KRKinv || !Kt || !err_out || border < 1 || ctx->img_rows == 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  rc = ensure_canon(ctx);
+  if (rc) return rc;
+  const size_t fV = sizeof(float) * (size_t)ctx->L.V;
+  rc = ensure(ctx, ctx->photo_err, fV);
+  if (rc) return rc;
+  PhotoGeometry geo;
+  std::memcpy(geo.KRKinv, KRKinv, sizeof(geo.KRKinv));
+  std::memcpy(geo.Kt, Kt, sizeof(geo.Kt));
+  LAUNCHCHK(ctx, launch_photo_residual(ctx->c, graph_scale, geo, (const uint8_t*)ctx->img_ref.p,
+                                       (const uint8_t*)ctx->img_cmp.p, ctx->img_rows, ctx->img_cols, ctx->img_step,
+                                       border, (float*)ctx->photo_err.p, ctx->stream));
+  if (fV) HIPCHK(ctx, hipMemcpyAsync(err_out, ctx->photo_err.p, fV, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_photo_fuse(flame_nltgv2_ctx* ctx, const float* KRKinv, const float* Kt, float graph_scale, int border,
+                            int enable) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!enable) {
+    ctx->photo_fused = false;
+    return FLAME_NLTGV2_OK;
+  }
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!KRKinv || !Kt || border < 1 || ctx->img_rows == 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  rc = ensure(ctx, ctx->photo_err, sizeof(float) * (size_t)ctx->L.V);
+  if (rc) return rc;
+  std::memcpy(ctx->photo_geo.KRKinv, KRKinv, sizeof(ctx->photo_geo.KRKinv));
+  std::memcpy(ctx->photo_geo.Kt, Kt, sizeof(ctx->photo_geo.Kt));
+  ctx->photo_scale = graph_scale, ctx->photo_border = border;
+  ctx->photo_fused = true;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_photo_residual_last(flame_nltgv2_ctx* ctx, float* err_out) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!ctx->photo_fused || !err_out) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  if (ctx->pending.active) {
+    rc = finish(ctx);
+    if (rc) return rc;
+  }
+  const size_t fV = sizeof(float) * (size_t)ctx->L.V;
+  if (fV) HIPCHK(ctx, hipMemcpyAsync(err_out, ctx->photo_err.p, fV, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FLAME_NLTGV2_OK;
+}
+
+
+}  // extern "C"

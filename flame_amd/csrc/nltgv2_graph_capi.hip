@@ -1,0 +1,450 @@
+// nltgv2_graph_capi.hip -- graph in / out over the C-ABI: upload, per-frame warm-start sync, projection, rescale, state download,
+// costs, export of x * graph_scale (see nltgv2_context.hpp).
+#include "nltgv2_context.hpp"
+
+extern "C" {
+
+int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_upload_graph");
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!g) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  const int32_t V = g->V, E = g->E;
+  if (V < 0 || E < 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  if (V > 0 && (!g->pos || !g->x || !g->w1 || !g->w2 || !g->x_bar || !g->w1_bar || !g->w2_bar ||
+                !g->data_term || !g->data_weight))
+    return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  if (E > 0 && (!g->src || !g->dst || !g->alpha || !g->beta || !g->q1 || !g->q2 || !g->q3))
+    return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  ctx->have_graph = false;
+  const bool trace = std::getenv("FLAME_NLTGV2_TRACE") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  // Make sure nothing in flight still uses buffers we may reallocate (or the staging buffer).
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const size_t fV = sizeof(float) * (size_t)V, fE = sizeof(float) * (size_t)E;
+  struct { DevBuf* b; size_t bytes; } req[] = {
+      {&ctx->x, fV}, {&ctx->w1, fV}, {&ctx->w2, fV}, {&ctx->xb, fV}, {&ctx->w1b, fV}, {&ctx->w2b, fV}, {&ctx->xp, fV},
+      {&ctx->w1p, fV}, {&ctx->w2p, fV}, {&ctx->data, fV}, {&ctx->weight, fV}, {&ctx->alpha, fE}, {&ctx->beta, fE},
+      {&ctx->q1, fE}, {&ctx->q2, fE}, {&ctx->q3, fE}};
+  for (auto& r : req) {
+    rc = ensure(ctx, *r.b, r.bytes);
+    if (rc) return rc;
+  }
+  const StageCopy state[] = {
+      {&ctx->x, g->x, fV}, {&ctx->w1, g->w1, fV}, {&ctx->w2, g->w2, fV}, {&ctx->xb, g->x_bar, fV},
+      {&ctx->w1b, g->w1_bar, fV}, {&ctx->w2b, g->w2_bar, fV},
+      {&ctx->xp, g->x_prev ? g->x_prev : g->x, fV}, {&ctx->w1p, g->w1_prev ? g->w1_prev : g->w1, fV},
+      {&ctx->w2p, g->w2_prev ? g->w2_prev : g->w2, fV}, {&ctx->data, g->data_term, fV},
+      {&ctx->weight, g->data_weight, fV}, {&ctx->alpha, g->alpha, fE}, {&ctx->beta, g->beta, fE}, {&ctx->q1, g->q1, fE},
+      {&ctx->q2, g->q2, fE}, {&ctx->q3, g->q3, fE}};
+  rc = upload_topology(ctx, g, state, sizeof(state) / sizeof(state[0]), /*long_lived=*/true);
+  if (rc) return rc;
+  const auto t_packed = std::chrono::steady_clock::now();
+  LAUNCHCHK(ctx, launch_pack_static(ctx->c, ctx->f, ctx->stream));
+  // No wait here: the caller's arrays were copied into the staging buffer, the device work is ordered on the stream in
+  // front of whatever comes next (a run, an export), and the next upload synchronises before it reuses the staging buffer.
+  if (trace) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const auto t_end = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[flame_nltgv2] upload_graph V=%d E=%d: host tables + enqueue %.3f ms, device %.3f ms\n", V, E,
+                 std::chrono::duration<double, std::milli>(t_packed - t_begin).count(),
+                 std::chrono::duration<double, std::milli>(t_end - t_packed).count());
+  }
+  ctx->h_feat.resize((size_t)V);
+  for (int32_t v = 0; v < V; ++v) ctx->h_feat[(size_t)v] = v;  // default feature id = vertex index
+  ctx->feat_map_valid = false;
+  ctx->canon_valid = true;
+  ctx->fused_valid = false;
+  ctx->have_prev = false;
+  ctx->parity = 0;
+  ctx->have_graph = true;
+  ctx->last_error = 0;
+  return FLAME_NLTGV2_OK;
+}
+
+// ---- per-frame graph synchronisation: the graph-edit part of Flame::syncGraph / projectGraph --------
+// (flame.cc:1985-2121 and 1862-1938), on explicit orders instead of BGL's hash-set iteration order:
+//   * a vertex whose feature id was in the previous graph keeps x,w1,w2,x_bar,w_bar,x_prev,w_prev
+//     (warm start); pos / data_term / data_weight are replaced (flame.cc:1996-2001); with
+//     check_sticky_obstacles, x is reset to data_term where x - data_term > threshold (flame.cc:2011-2014);
+//     vertices absent from the new list disappear together with their edges (flame.cc:2020-2028,
+//     1923-1931);
+//   * a new vertex starts at x = x_bar = x_prev = init_x (or data_term), w = 0 (flame.cc:2035-2048,
+//     2160-2162);
+//   * an edge of the new triangulation that already connected the same two features keeps its dual
+//     (q1,q2,q3) AND its old (source,target) orientation -- boost::edge(u,v) finds it either way
+//     (flame.cc:2094-2100); other old edges are dropped (flame.cc:2108-2119); new edges get q = 0 and the
+//     orientation (edges[2k], edges[2k+1]) = add_edge(v[e0], v[e1]) (flame.cc:2085-2096);
+//   * every edge gets alpha = 1/||pos_a - pos_b|| from the NEW positions and beta = 1 (flame.cc:2087-2103);
+//   * resulting edge order = surviving edges in their previous relative order, then the new edges in
+//     triangulator order (boost::edges() walks a std::list: erase keeps order, add_edge appends).
+int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_sync_graph");
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!in || in->V < 0 || in->E < 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  const int32_t V = in->V, E = in->E;
+  if (V > 0 && (!in->feat_id || !in->pos || !in->data_term || !in->data_weight)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  if (E > 0 && !in->edges) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+
+  const bool trace = std::getenv("FLAME_NLTGV2_TRACE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  // The previous state stays on the device: the canonical arrays are brought up to date (a kernel, enqueued) while the
+  // host works out the index maps below.
+  rc = ensure_canon(ctx);
+  if (rc) return rc;
+  const int32_t Vo = ctx->L.V, Eo = ctx->L.E;
+
+  for (int32_t v = 0; v < V; ++v)
+    if (in->feat_id[v] < 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  if (!ctx->feat_map_valid) {  // (after an upload / set_feature_ids; otherwise the map the previous sync built)
+    FlatMap& m = ctx->feat_maps[ctx->feat_cur];
+    m.reset((size_t)Vo);
+    for (int32_t v = 0; v < Vo; ++v) m.emplace((uint64_t)(uint32_t)ctx->h_feat[(size_t)v], v);
+    ctx->feat_map_valid = true;
+  }
+  const FlatMap& old_of_feat = ctx->feat_maps[ctx->feat_cur];
+  auto key = [](int32_t a, int32_t b) {
+    const uint32_t lo = (uint32_t)std::min(a, b), hi = (uint32_t)std::max(a, b);
+    return ((uint64_t)hi << 32) | lo;
+  };
+
+  // vertices: new vertex -> its index in the previous graph (-1: new)
+  std::vector<int32_t>& old_of_new = ctx->h_old_of_new;
+  old_of_new.assign((size_t)V, -1);
+  FlatMap& seen = ctx->feat_maps[ctx->feat_cur ^ 1];  // ... and the next sync's old_of_feat
+  seen.reset((size_t)V);
+  for (int32_t v = 0; v < V; ++v) {
+    if (!seen.emplace((uint64_t)(uint32_t)in->feat_id[v], v).second) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // duplicate id
+    const int32_t* it = old_of_feat.find((uint64_t)(uint32_t)in->feat_id[v]);
+    if (it) old_of_new[(size_t)v] = *it;
+  }
+  // edges.  A surviving edge joins two surviving vertices: it is looked up in the previous graph's adjacency (the
+  // host copy of the packed layout: ~6 incident edges per vertex, one cache line) instead of a hash table over all
+  // edges.  Survivors must come out in their PREVIOUS relative order (boost::edges() walks a std::list: erase keeps
+  // the order of the rest): they are met in triangulator order, so they are parked in a table indexed by the old
+  // edge id and read back in one pass -- no sort.
+  struct Keep { int32_t a, b; };
+  std::vector<Keep> keep_of_old((size_t)Eo, Keep{-1, -1});
+  std::vector<std::pair<int32_t, int32_t>> fresh;
+  fresh.reserve((size_t)E / 4 + 16);
+  int32_t n_keep = 0;
+  const std::vector<int32_t>& orow = ctx->L.row_ptr;
+  const std::vector<uint32_t>& ohalf = ctx->L.half;
+  const std::vector<int32_t>& onbr = ctx->L.half_nbr;
+  for (int32_t k = 0; k < E; ++k) {
+    const int32_t a = in->edges[2 * k], b = in->edges[2 * k + 1];
+    if (a < 0 || a >= V || b < 0 || b >= V || a == b) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+    const int32_t oa = old_of_new[(size_t)a], ob = old_of_new[(size_t)b];
+    int32_t e = -1;
+    bool same = true;  // the old edge runs oa -> ob
+    if (oa >= 0 && ob >= 0) {
+      for (int32_t h = orow[(size_t)oa]; h < orow[(size_t)oa + 1]; ++h) {
+        if (onbr[(size_t)h] == ob) {
+          e = (int32_t)(ohalf[(size_t)h] & ~kRoleBit);  // the first (lowest id) of possible parallel edges, as
+          same = (ohalf[(size_t)h] & kRoleBit) == 0u;   // boost::edge() on the list would find
+          break;
+        }
+      }
+    }
+    if (e >= 0) {
+      if (keep_of_old[(size_t)e].a >= 0) continue;  // the same pair again: boost::edge() finds the edge, nothing is added
+      keep_of_old[(size_t)e] = Keep{same ? a : b, same ? b : a};
+      ++n_keep;
+    } else {
+      fresh.emplace_back(a, b);
+    }
+  }
+  if (!fresh.empty()) {  // no parallel edges among the new ones either (boost::edge() finds the one just added)
+    FlatMap& dup = ctx->feat_maps[2];
+    dup.reset(fresh.size());
+    size_t n = 0;
+    for (const auto& f : fresh)
+      if (dup.emplace(key(in->feat_id[f.first], in->feat_id[f.second]), 1).second) fresh[n++] = f;
+    fresh.resize(n);
+  }
+  const int32_t En = (int32_t)((size_t)n_keep + fresh.size());
+  std::vector<int32_t> src((size_t)En), dst((size_t)En);
+  std::vector<int32_t>& old_of_new_edge = ctx->h_old_of_new_edge;
+  old_of_new_edge.assign((size_t)En, -1);
+  int32_t e = 0;
+  for (int32_t o = 0; o < Eo; ++o) {
+    const Keep& kp = keep_of_old[(size_t)o];
+    if (kp.a < 0) continue;
+    src[(size_t)e] = kp.a, dst[(size_t)e] = kp.b;
+    old_of_new_edge[(size_t)e] = o;
+    ++e;
+  }
+  for (const auto& f : fresh) {
+    src[(size_t)e] = f.first, dst[(size_t)e] = f.second;
+    ++e;
+  }
+  const auto t1 = std::chrono::steady_clock::now();
+
+  // New topology + the frame's inputs up, state gathered on the device out of the previous arrays into spare ones,
+  // which then take their place.
+  ctx->have_graph = false;  // (until the new graph stands)
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // nothing in flight uses buffers that may be reallocated below
+  const size_t fV = sizeof(float) * (size_t)V, fE = sizeof(float) * (size_t)En;
+  DevBuf* cur_v[9] = {&ctx->x, &ctx->w1, &ctx->w2, &ctx->xb, &ctx->w1b, &ctx->w2b, &ctx->xp, &ctx->w1p, &ctx->w2p};
+  DevBuf* cur_q[3] = {&ctx->q1, &ctx->q2, &ctx->q3};
+  for (int i = 0; i < 9 && !rc; ++i) rc = ensure(ctx, ctx->sp_v[i], fV);
+  for (int i = 0; i < 3 && !rc; ++i) rc = ensure(ctx, ctx->sp_q[i], fE);
+  if (!rc) rc = ensure(ctx, ctx->data, fV);
+  if (!rc) rc = ensure(ctx, ctx->weight, fV);
+  if (!rc) rc = ensure(ctx, ctx->alpha, fE);
+  if (!rc) rc = ensure(ctx, ctx->beta, fE);
+  if (!rc) rc = ensure(ctx, ctx->sync_init, fV);
+  if (!rc) rc = ensure(ctx, ctx->sync_vmap, sizeof(int32_t) * (size_t)V);
+  if (!rc) rc = ensure(ctx, ctx->sync_emap, sizeof(int32_t) * (size_t)En);
+  if (!rc) rc = ensure(ctx, ctx->sync_need, (size_t)V);
+  if (rc) return rc;
+  flame_nltgv2_graph g{};
+  g.V = V, g.E = En;
+  g.pos = const_cast<float*>(in->pos);
+  g.src = src.data(), g.dst = dst.data();
+  const StageCopy extra[] = {
+      {&ctx->data, in->data_term, fV}, {&ctx->weight, in->data_weight, fV},
+      {&ctx->sync_init, in->init_x, in->init_x ? fV : 0},
+      {&ctx->sync_vmap, old_of_new.data(), sizeof(int32_t) * (size_t)V},
+      {&ctx->sync_emap, old_of_new_edge.data(), sizeof(int32_t) * (size_t)En}};
+  rc = upload_topology(ctx, &g, extra, sizeof(extra) / sizeof(extra[0]), /*long_lived=*/false);
+  if (rc) return rc;
+  SyncArgs sa;
+  sa.V = V, sa.E = En;
+  sa.old_of_new = (const int32_t*)ctx->sync_vmap.p, sa.old_of_new_edge = (const int32_t*)ctx->sync_emap.p;
+  sa.data = (const float*)ctx->data.p, sa.weight = (const float*)ctx->weight.p;
+  sa.init_x = in->init_x ? (const float*)ctx->sync_init.p : nullptr;
+  sa.check_sticky = in->check_sticky_obstacles ? 1 : 0, sa.sticky_threshold = in->sticky_threshold;
+  sa.graph_scale = in->init_graph_scale;
+  for (int i = 0; i < 9; ++i) sa.o[i] = (const float*)cur_v[i]->p, sa.n[i] = (float*)ctx->sp_v[i].p;
+  for (int i = 0; i < 3; ++i) sa.oq[i] = (const float*)cur_q[i]->p, sa.nq[i] = (float*)ctx->sp_q[i].p;
+  sa.src = (const int32_t*)ctx->src.p, sa.dst = (const int32_t*)ctx->dst.p, sa.row_ptr = (const int32_t*)ctx->row_ptr.p;
+  sa.half = (const uint32_t*)ctx->half.p, sa.pos = (const float2*)ctx->pos.p;
+  sa.alpha = (float*)ctx->alpha.p, sa.beta = (float*)ctx->beta.p, sa.need_nbr = (uint8_t*)ctx->sync_need.p;
+  LAUNCHCHK(ctx, launch_sync_state(sa, ctx->stream));
+  for (int i = 0; i < 9; ++i) std::swap(*cur_v[i], ctx->sp_v[i]);
+  for (int i = 0; i < 3; ++i) std::swap(*cur_q[i], ctx->sp_q[i]);
+  refresh_args(ctx);
+  LAUNCHCHK(ctx, launch_pack_static(ctx->c, ctx->f, ctx->stream));
+  if (trace) {  // (no wait otherwise: see flame_nltgv2_upload_graph)
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const auto t2 = std::chrono::steady_clock::now();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::fprintf(stderr, "[flame_nltgv2] sync_graph: index maps %.3f ms, tables + upload + device gather %.3f ms\n", ms(t0, t1), ms(t1, t2));
+  }
+  ctx->h_feat.assign(in->feat_id, in->feat_id + V);
+  ctx->feat_cur ^= 1;  // (the map filled above is of the graph that stands now)
+  ctx->canon_valid = true;
+  ctx->fused_valid = false;
+  ctx->have_prev = false;
+  ctx->parity = 0;
+  ctx->have_graph = true;
+  ctx->last_error = 0;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_project_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_projection* pr, float graph_scale,
+                               uint8_t* keep_out, float* pos_out) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_project_graph");
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!pr || !(graph_scale > 0.0f) || (ctx->L.V > 0 && !keep_out)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  rc = ensure_canon(ctx);
+  if (rc) return rc;
+  const size_t V = (size_t)ctx->L.V;
+  rc = ensure(ctx, ctx->r_valid, V + 16);
+  if (rc) return rc;
+  ProjectGeometry geo;
+  std::memcpy(geo.K, pr->K, sizeof(geo.K));
+  std::memcpy(geo.Kinv, pr->Kinv, sizeof(geo.Kinv));
+  std::memcpy(geo.KRKinv, pr->KRKinv, sizeof(geo.KRKinv));
+  std::memcpy(geo.q, pr->q_ref_to_cmp, sizeof(geo.q));
+  std::memcpy(geo.t, pr->t_ref_to_cmp, sizeof(geo.t));
+  geo.rx = pr->region_x, geo.ry = pr->region_y, geo.rw = pr->region_w, geo.rh = pr->region_h;
+  LAUNCHCHK(ctx, launch_project_graph(ctx->c, graph_scale, geo, (uint8_t*)ctx->r_valid.p, ctx->stream));
+  if (V) HIPCHK(ctx, hipMemcpyAsync(keep_out, ctx->r_valid.p, V, hipMemcpyDeviceToHost, ctx->stream));
+  if (V && pos_out) HIPCHK(ctx, hipMemcpyAsync(pos_out, ctx->pos.p, sizeof(float) * 2 * V, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->fused_valid = false;  // x changed; pos changed: alpha/dx/dy of the packed records are stale until the next
+                             // sync_graph / upload_graph re-derives them (the reference re-triangulates right after)
+  ctx->static_stale = true;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_rescale_data(flame_nltgv2_ctx* ctx, float graph_scale, float* new_graph_scale, flame_nltgv2_params* p) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_rescale_data");
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!new_graph_scale || !p || ctx->L.V <= 0 || !(graph_scale > 0.0f)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  rc = ensure_canon(ctx);
+  if (rc) return rc;
+  LAUNCHCHK(ctx, launch_rescale(ctx->c, graph_scale, (float*)ctx->cost_out.p, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_cost, ctx->cost_out.p, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const float ns = ctx->h_cost[0];
+  p->data_factor *= ns / graph_scale;  // flame.cc:349
+  *new_graph_scale = ns;
+  ctx->fused_valid = false;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_set_feature_ids(flame_nltgv2_ctx* ctx, const int32_t* feat_id) {
+  if (!ctx) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!feat_id && ctx->L.V > 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  FlatMap seen((size_t)ctx->L.V);
+  for (int32_t v = 0; v < ctx->L.V; ++v)
+    if (feat_id[v] < 0 || !seen.emplace((uint64_t)(uint32_t)feat_id[v], v).second) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  ctx->h_feat.assign(feat_id, feat_id + ctx->L.V);
+  ctx->feat_map_valid = false;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_get_topology(flame_nltgv2_ctx* ctx, int32_t* src, int32_t* dst, int32_t* feat_id) {
+  if (!ctx) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (src) std::copy(ctx->h_src.begin(), ctx->h_src.end(), src);
+  if (dst) std::copy(ctx->h_dst.begin(), ctx->h_dst.end(), dst);
+  if (feat_id) std::copy(ctx->h_feat.begin(), ctx->h_feat.end(), feat_id);
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_update_data(flame_nltgv2_ctx* ctx, const float* data_term, const float* data_weight) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_update_data");
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (ctx->L.V > 0 && (!data_term || !data_weight)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  rc = ensure_canon(ctx);
+  if (rc) return rc;
+  const size_t fV = sizeof(float) * (size_t)ctx->L.V;
+  rc = h2d(ctx, ctx->data, data_term, fV);
+  if (!rc) rc = h2d(ctx, ctx->weight, data_weight, fV);
+  if (rc) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->fused_valid = false;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_upload_state(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* s) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!s) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  rc = ensure_canon(ctx);
+  if (rc) return rc;
+  const size_t fV = sizeof(float) * (size_t)ctx->L.V, fE = sizeof(float) * (size_t)ctx->L.E;
+  const struct { DevBuf* b; const float* src; size_t bytes; } cp[] = {
+      {&ctx->x, s->x, fV}, {&ctx->w1, s->w1, fV}, {&ctx->w2, s->w2, fV}, {&ctx->xb, s->x_bar, fV},
+      {&ctx->w1b, s->w1_bar, fV}, {&ctx->w2b, s->w2_bar, fV}, {&ctx->xp, s->x_prev, fV},
+      {&ctx->w1p, s->w1_prev, fV}, {&ctx->w2p, s->w2_prev, fV}, {&ctx->q1, s->q1, fE}, {&ctx->q2, s->q2, fE},
+      {&ctx->q3, s->q3, fE}};
+  for (auto& c : cp) {
+    if (!c.src) continue;
+    rc = h2d(ctx, *c.b, c.src, c.bytes);
+    if (rc) return rc;
+  }
+  HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, kErrBytes, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->fused_valid = false;
+  ctx->last_error = 0;
+  return FLAME_NLTGV2_OK;
+}
+
+
+int flame_nltgv2_costs(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, float* smoothness, float* data) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_costs");
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!params_ok(p)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  rc = ensure_canon(ctx);
+  if (rc) return rc;
+  // The reference adds the terms up sequentially in float (edge order, then vertex order): the device forms the
+  // addends, the host adds them in that order -- the result is the reference's to the last bit.  (A statistics call,
+  // flame.cc:2172-2173: 2E + V dependent additions, ~60 us at 640x480.)
+  const size_t E = (size_t)ctx->L.E, V = (size_t)ctx->L.V, n = 2 * E + V;
+  rc = ensure(ctx, ctx->cost_terms, sizeof(float) * n);
+  if (rc) return rc;
+  ctx->h_terms.resize(n);
+  LAUNCHCHK(ctx, launch_cost_terms(ctx->c, (float*)ctx->cost_terms.p, ctx->stream));
+  if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->h_terms.data(), ctx->cost_terms.p, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  float cost = 0.0f;
+  for (size_t k = 0; k < 2 * E; ++k) cost += ctx->h_terms[k];
+  float dcost = 0.0f;
+  for (size_t k = 0; k < V; ++k) dcost += ctx->h_terms[2 * E + k];
+  if (smoothness) *smoothness = p->data_factor * cost;
+  if (data) *data = dcost;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_download_state(flame_nltgv2_ctx* ctx, flame_nltgv2_graph* out) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_download_state");
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!out) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  rc = ensure_canon(ctx);
+  if (rc) return rc;
+  const size_t fV = sizeof(float) * (size_t)ctx->L.V, fE = sizeof(float) * (size_t)ctx->L.E;
+  const struct { float* dst; DevBuf* b; size_t bytes; } cp[] = {
+      {out->x, &ctx->x, fV}, {out->w1, &ctx->w1, fV}, {out->w2, &ctx->w2, fV}, {out->x_bar, &ctx->xb, fV},
+      {out->w1_bar, &ctx->w1b, fV}, {out->w2_bar, &ctx->w2b, fV}, {out->x_prev, &ctx->xp, fV},
+      {out->w1_prev, &ctx->w1p, fV}, {out->w2_prev, &ctx->w2p, fV}, {out->q1, &ctx->q1, fE},
+      {out->q2, &ctx->q2, fE}, {out->q3, &ctx->q3, fE}};
+  for (auto& c : cp) {
+    if (!c.dst || c.bytes == 0) continue;
+    HIPCHK(ctx, hipMemcpyAsync(c.dst, c.b->p, c.bytes, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  out->V = ctx->L.V, out->E = ctx->L.E;
+  return finish(ctx);
+}
+
+static int export_idepth(flame_nltgv2_ctx* ctx, void* dst_device, float scale, bool wait) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!dst_device && ctx->L.V > 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  if (ctx->pending.active) {
+    // an unchecked persistent run is in flight: the waiting form settles it first (so that what it copies out is the
+    // checked result), the asynchronous form joins the chain and is redone should the chain have to be replayed
+    if (wait) {
+      rc = finish(ctx);
+    } else {
+      rc = snapshot_chain_start(ctx);
+      if (!rc) {
+        flame_nltgv2_ctx::PendingOp op;
+        op.kind = 1, op.dst = (float*)dst_device, op.scale = scale;
+        ctx->pending.ops.push_back(op);
+      }
+    }
+    if (rc) return rc;
+  }
+  const bool packed = !ctx->canon_valid;
+  LAUNCHCHK(ctx, launch_export(ctx->c, ctx->f, packed, scale, (float*)dst_device, ctx->stream));
+  if (wait) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_set_export_target(flame_nltgv2_ctx* ctx, void* dst_device, float scale) {
+  if (!ctx) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  ctx->export_ptr = (float*)dst_device;
+  ctx->export_scale = scale;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_export_idepth_device(flame_nltgv2_ctx* ctx, void* dst_device, float scale) {
+  return export_idepth(ctx, dst_device, scale, true);
+}
+
+int flame_nltgv2_export_idepth_device_async(flame_nltgv2_ctx* ctx, void* dst_device, float scale) {
+  return export_idepth(ctx, dst_device, scale, false);
+}
+
+
+}  // extern "C"

@@ -1,5 +1,5 @@
-// nltgv2_kernels.h -- argument bundles and launch wrappers shared by nltgv2_kernels.hip (device
-// code) and nltgv2_capi.hip (context + C-ABI).
+// nltgv2_kernels.h -- argument bundles and launch wrappers shared by the kernel files (nltgv2_kernels.hip,
+// nltgv2_persistent*.hip, nltgv2_layout.hip) and the host side (nltgv2_context.hpp and the C-ABI files behind it).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -81,7 +81,7 @@ struct FusedArgs {
   float2* vaux = nullptr;   // [n_slices*64] {data_weight, degree bits}
   float4* bar[2] = {nullptr, nullptr};  // ping-pong {x_bar,w1_bar,w2_bar,-}
   float4* vprev = nullptr;  // {x_prev,w1_prev,w2_prev,-} written by the last step of a run
-  void* xbuf = nullptr;  // persistent run: [R0|L0|R1|L1|XCC] exchange buffer, see nltgv2_kernels.hip
+  void* xbuf = nullptr;  // persistent run: [R0|L0|R1|L1|XCC] exchange buffer, see nltgv2_persistent.hip
   int he_waves = 0;                    // persistent run: wave-aligned half-edge rows (nltgv2_pack.hpp (C))
   int32_t* he_slot = nullptr;
   int32_t* he_vid = nullptr;
@@ -163,6 +163,7 @@ struct SyncArgs {
 int launch_sync_state(const SyncArgs& a, hipStream_t s);
 int pv_patches_per_cu(const FusedArgs& a, bool verify);
 int pv_real_waves_per_simd(int layout, bool verify_or_probe);
+const void* persistent_tv_kernel(bool static_in_lds, int waves_per_block, unsigned* lds_bytes);  // nltgv2_persistent_tv.hip
 // device-side expansion of the layout arrays (nltgv2_layout.hip)
 int launch_build_sell(const CanonArgs& c, const FusedArgs& a, const int32_t* iperm, hipStream_t s);
 int launch_he_from_patches(const FusedArgs& a, int32_t* he_slot, int32_t* he_vid, uint32_t* he_meta, int32_t* he_wave_chain,

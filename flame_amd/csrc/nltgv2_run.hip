@@ -1,0 +1,704 @@
+// nltgv2_run.hip -- running n steps: which kernels (planner), enqueue, settle, roll back and redo; the run entry points of the C-ABI
+// (see nltgv2_context.hpp).
+#include "nltgv2_context.hpp"
+
+namespace flame_hip {
+namespace host {
+
+void pick_config(const flame_nltgv2_ctx* ctx, int* unroll, int* wpb) {
+  // Small graphs are latency bound: one wave per workgroup spreads the slices over as many CUs as
+  // possible and a deep chunk (all slots of a slice in one round of loads) shortens the dependent
+  // chain.  Large graphs / batches are bandwidth bound: 4-wave workgroups, shallow chunks keep the
+  // register footprint (and thus occupancy) reasonable.
+  const bool small = ctx->L.n_slices <= 8 * ctx->prop.multiProcessorCount;
+  *unroll = ctx->opt_unroll ? ctx->opt_unroll : (small ? 8 : 4);
+  *wpb = ctx->opt_block_waves ? ctx->opt_block_waves : (small ? 1 : 4);
+}
+
+// A persistent launch covers a contiguous range of waves of one form.
+struct WaveGroup {
+  int begin, count;
+};
+
+// Which persistent form (if any) runs n steps -- 0 none (one launch per step), 1 lane-per-half-edge
+// (lowest latency), 2 vertex-per-lane (fewest instructions) -- and over which wave groups.  A graph that
+// is resident as a whole is one group.  A disjoint union too large for that (a big batch of frames) is run
+// group of connected components by group, each group resident on its own: the components are independent,
+// so running them one after the other for all n steps is exactly the same computation.
+int ensure_form_rows(flame_nltgv2_ctx* ctx, int form);
+
+int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups, int* use_tv_lds = nullptr) {
+  groups->clear();
+  if (use_tv_lds) *use_tv_lds = 0;
+  if (!ctx->opt_persistent || n < 4 || n > (1 << 24) || !ctx->prop.cooperativeLaunch) return 0;
+  if (ctx->persist_refused_topo == ctx->topo) return 0;
+  PackedLayout& L = ctx->L;
+  const int cus = ctx->prop.multiProcessorCount;
+  // ask once per (topology, kernel instance): the LDS use varies with the layout, the registers with the instance
+  const uint64_t occ_key = ctx->topo * 4 + (ctx->opt_verify != 0 ? 1 : 0) + (ctx->opt_probe != 0 ? 2 : 0);
+  if (L.wg_ok && ctx->pv_occ_topo != occ_key) {
+    // The REAL residency (pv_patches_per_cu: the runtime's query over-reports, tools/residency_probe.hip), and of that at most
+    // kPvDensePerCu: beyond it the lane-per-half-edge / vertex-per-lane forms are as fast or faster (tools/pv_big.py,
+    // profiles/r03_pv_dense.txt: the hand-off itself gets slower with the number of polling waves)
+    ctx->pv_occ = std::min(kPvDensePerCu, pv_patches_per_cu(ctx->f, ctx->opt_verify != 0 || ctx->opt_probe != 0));
+    if (std::getenv("FLAME_NLTGV2_TRACE"))
+      std::fprintf(stderr, "[flame_nltgv2] pv: %d patches, row-packed %d, slab slots %d, local records %d -> %d resident per CU\n", L.wg_count,
+                   (int)L.wg_rowpack, ctx->f.wg_slab_slots, ctx->f.wg_lcap, ctx->pv_occ);
+    ctx->pv_occ_topo = occ_key;
+  }
+  const int wg_cap = ctx->pv_occ * cus;  // patch-per-wave form, in patches
+  const int he_cap = kHeWavesPerCu * cus;
+  // The lane-per-half-edge rows (C) come from the same greedy walk as the patches (E): as many waves, possible under the
+  // same condition (no vertex of more than 64 incident edges).  They, and the vertex-per-lane rows (D), are built only
+  // when their form is actually chosen.
+  const bool pv_fits = L.wg_ok && L.wg_rowpack && L.wg_count > 0 && L.wg_count <= wg_cap;  // (the kernel runs row-packed patches)
+  const bool he_possible = L.wg_ok && L.wg_count > 0;
+  int form = 0;
+  if (ctx->opt_persistent == 4) form = (L.wg_ok && L.wg_rowpack) ? 3 : 0;
+  else if (ctx->opt_persistent == 2) form = he_possible ? 1 : 0;
+  else if (ctx->opt_persistent == 3) form = 2;
+  else if (pv_fits) form = 3;  // lowest latency wherever all patches are resident: 320x240 ... 1280x720 single frames
+  else if (he_possible && L.wg_count <= he_cap) form = 1;
+  else form = 2;               // too big for that: vertex-per-lane, in groups of whole components if need be
+  if (form == 1 || form == 2) {
+    if (ensure_form_rows(ctx, form) != 0) return 0;
+    if (form == 2 && !L.tv_ok) {
+      form = he_possible ? 1 : 0;
+      if (form == 1 && ensure_form_rows(ctx, 1) != 0) return 0;
+    }
+  }
+  // vertex-per-lane form: slot constants in registers (8 waves/CU, fastest per wave) while the graph is resident
+  // that way, else in LDS (16 waves/CU: 30 frames of 640x480 resident in one launch)
+  const bool tv_lds = form == 2 && (ctx->opt_tv_lds == 2 || (ctx->opt_tv_lds == 1 && L.tv_waves > kTvWavesPerCu * cus));
+  const int tv_cap = (tv_lds ? kTvLdsWavesPerCu : kTvWavesPerCu) * cus;
+  if (use_tv_lds) *use_tv_lds = tv_lds ? 1 : 0;
+  if (form == 0) return 0;
+  const int total = form == 3 ? L.wg_count : form == 2 ? L.tv_waves : L.he_waves;
+  const int cap = form == 3 ? wg_cap : form == 2 ? tv_cap : he_cap;
+  if (total <= 0) return 0;
+  if (total <= cap) {
+    groups->push_back(WaveGroup{0, total});
+    return form;
+  }
+  const std::vector<int32_t>& cw = form == 3 ? L.comp_wg : form == 2 ? L.comp_tv_wave : L.comp_he_wave;
+  if (cw.size() < 3) return 0;  // one component that does not fit: stream it
+  // Groups of about equal size (the per-step time of a group grows with its waves, and a small last group would run
+  // at low occupancy): cut at the component boundaries nearest to k * total / n_groups, never beyond what the chip
+  // holds; if the components are too uneven for that, fall back to filling each group greedily.
+  for (size_t c = 0; c + 1 < cw.size(); ++c)
+    if (cw[c + 1] - cw[c] > cap) return 0;  // a single component larger than the chip
+  const int n_groups = (total + cap - 1) / cap;
+  bool ok = true;
+  {
+    size_t c = 0;
+    int begin = cw[0];
+    for (int gi = 1; gi <= n_groups && ok; ++gi) {
+      const long ideal = cw[0] + (long)gi * total / n_groups;
+      size_t e = c + 1;  // at least one component per group
+      while (e + 1 < cw.size() && cw[e] < ideal) ++e;
+      if (gi == n_groups) e = cw.size() - 1;
+      while (e > c + 1 && cw[e] - begin > cap) --e;
+      if (cw[e] - begin > cap) ok = false;
+      groups->push_back(WaveGroup{begin, cw[e] - begin});
+      begin = cw[e], c = e;
+      if (c + 1 >= cw.size() && gi < n_groups) break;
+    }
+    if (ok && begin != cw.back()) ok = false;  // balanced cuts did not cover everything within n_groups groups
+  }
+  if (!ok) {
+    groups->clear();
+    int begin = cw[0];
+    for (size_t c = 0; c + 1 < cw.size(); ++c) {
+      if (cw[c + 1] - begin > cap) {
+        groups->push_back(WaveGroup{begin, cw[c] - begin});
+        begin = cw[c];
+      }
+    }
+    groups->push_back(WaveGroup{begin, cw.back() - begin});
+  }
+  return form;
+}
+bool persistent_eligible(flame_nltgv2_ctx* ctx, int n) {
+  std::vector<WaveGroup> g;
+  return plan_persistent(ctx, n, &g) != 0;
+}
+
+bool same_params(const flame_nltgv2_params& a, const flame_nltgv2_params& b) {
+  return std::memcmp(&a, &b, sizeof(a)) == 0;
+}
+
+int enqueue_fused_eager(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n, int parity, int unroll,
+                        int wpb, bool prev_on_last) {
+  const SolverParams sp = to_sp(p);
+  for (int it = 0; it < n; ++it) {
+    LAUNCHCHK(ctx, launch_fused_step(ctx->f, sp, parity ^ (it & 1), prev_on_last && it == n - 1, unroll, wpb,
+                                     ctx->stream));
+  }
+  return 0;
+}
+
+int get_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n, int parity, int unroll, int wpb,
+              hipGraphExec_t* out) {
+  for (auto& g : ctx->graphs) {
+    if (g.n == n && g.parity == parity && g.unroll == unroll && g.wpb == wpb && g.topo == ctx->topo &&
+        g.gen == ctx->buf_gen && same_params(g.params, *p)) {
+      g.stamp = ++ctx->stamp;
+      *out = g.exec;
+      return 0;
+    }
+  }
+  hipGraph_t graph = nullptr;
+  HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+  int rc = enqueue_fused_eager(ctx, p, n, parity, unroll, wpb, true);
+  hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+  if (rc != 0) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
+  }
+  HIPCHK(ctx, e);
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  HIPCHK(ctx, e);
+  if ((int)ctx->graphs.size() >= kMaxCachedGraphs) {
+    size_t victim = 0;
+    for (size_t i = 1; i < ctx->graphs.size(); ++i)
+      if (ctx->graphs[i].stamp < ctx->graphs[victim].stamp) victim = i;
+    (void)hipGraphExecDestroy(ctx->graphs[victim].exec);
+    ctx->graphs.erase(ctx->graphs.begin() + (long)victim);
+  }
+  CachedGraph cg;
+  cg.exec = exec, cg.n = n, cg.parity = parity, cg.unroll = unroll, cg.wpb = wpb, cg.topo = ctx->topo;
+  cg.gen = ctx->buf_gen;
+  cg.params = *p, cg.stamp = ++ctx->stamp;
+  ctx->graphs.push_back(cg);
+  *out = exec;
+  return 0;
+}
+
+// Builds (if needed) every hipGraph a run of n steps will replay, without running anything: keeps
+// graph instantiation out of timed regions.
+int prepare_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
+  if (ctx->opt_solver != 0 || !ctx->opt_use_graph || persistent_eligible(ctx, n)) return 0;
+  int unroll, wpb;
+  pick_config(ctx, &unroll, &wpb);
+  int parity = ctx->parity;
+  hipGraphExec_t exec;
+  if (n >= kGraphChunk) {
+    int rc = get_graph(ctx, p, kGraphChunk, parity, unroll, wpb, &exec);
+    if (rc) return rc;
+  }
+  const int rem = n % kGraphChunk;
+  if (rem >= 4) {
+    int rc = get_graph(ctx, p, rem, parity, unroll, wpb, &exec);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+PhotoFuse photo_target(const flame_nltgv2_ctx* ctx) {
+  PhotoFuse f;
+  std::memset(static_cast<void*>(&f), 0, sizeof f);  // padding too: the block is compared bytewise before it is re-sent
+  f.graph_scale = 1.0f;
+  if (!ctx->photo_fused || ctx->img_rows == 0) return f;
+  f.pos = (const float2*)ctx->pos.p;
+  f.ref = (const uint8_t*)ctx->img_ref.p, f.cmp = (const uint8_t*)ctx->img_cmp.p;
+  f.err = (float*)ctx->photo_err.p;
+  f.geo = ctx->photo_geo;
+  f.graph_scale = ctx->photo_scale;
+  f.rows = ctx->img_rows, f.cols = ctx->img_cols, f.step = ctx->img_step, f.border = ctx->photo_border;
+  return f;
+}
+
+// after a run on a path whose kernels have no photometric epilogue
+int enqueue_photo_sweep(flame_nltgv2_ctx* ctx, bool packed_current) {
+  const PhotoFuse f = photo_target(ctx);
+  if (!f.err) return 0;
+  if (packed_current) {
+    LAUNCHCHK(ctx, launch_photo_residual_packed(ctx->f, f, ctx->stream));
+  } else {
+    LAUNCHCHK(ctx, launch_photo_residual(ctx->c, f.graph_scale, f.geo, f.ref, f.cmp, f.rows, f.cols, f.step, f.border, f.err,
+                                         ctx->stream));
+  }
+  return 0;
+}
+
+// Record placement, once per context: every page of the pool is timed for all 28 pairs of XCDs (k_place_calibrate) and
+// ranked per pair.  ~3 ms, at the first run that can use it.  Anything unexpected (a pair missing because two blocks
+// shared an XCD, a wait that expired because the GPU is busy with someone else's work) switches placement off for this
+// context: the records then keep their linear places.
+int place_calibrate(flame_nltgv2_ctx* ctx) {
+  ctx->place_state = -1;
+  constexpr int P = kPlacePages, kIters = 12;
+  const size_t pool_bytes = (size_t)2 * P * 4096;
+  int rc = ensure(ctx, ctx->place_pool, pool_bytes + 4096);
+  if (!rc) rc = ensure(ctx, ctx->place_meas, sizeof(unsigned) * 64 * 2 * P + sizeof(int) * 64 + sizeof(int));
+  if (!rc) rc = ensure(ctx, ctx->place_rank, sizeof(uint16_t) * 2 * 64 * P);
+  if (!rc) rc = ensure(ctx, ctx->place_fill, sizeof(int) * (2 * P + 16));  // (+ the rotation word of the launches)
+  if (rc) return rc;
+  ctx->place_base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ctx->place_pool.p) + 4095) & ~uintptr_t(4095));
+  unsigned* d_out = (unsigned*)ctx->place_meas.p;
+  int* d_xcc = (int*)(d_out + (size_t)64 * 2 * P);
+  int* d_fail = d_xcc + 64;
+  HIPCHK(ctx, hipMemsetAsync(ctx->place_base, 0, pool_bytes, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->place_meas.p, 0, sizeof(unsigned) * 64 * 2 * P + sizeof(int) * 65, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->place_fill.p, 0, sizeof(int) * (2 * P + 16), ctx->stream));
+  LAUNCHCHK(ctx, launch_place_calibrate(ctx->place_base, 2 * P, kIters, d_out, d_xcc, d_fail, ctx->stream));
+  std::vector<unsigned> out((size_t)64 * 2 * P);
+  int xcc[65];
+  HIPCHK(ctx, hipMemcpyAsync(out.data(), d_out, sizeof(unsigned) * out.size(), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(xcc, d_xcc, sizeof(int) * 65, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->place_base, 0, pool_bytes, ctx->stream));  // (tags of the calibration: gone)
+  if (xcc[64] != 0) return 0;  // a wait expired
+  std::vector<unsigned> lat((size_t)64 * 2 * P, 0u);  // [8 a + b][page]: a record written on XCD a, seen on XCD b
+  bool have[64] = {false};
+  for (int b = 8; b < 64; ++b) {
+    const int x = b & 7, j = b >> 3, pb = ((8 - j) & 7) * 8 + ((x + j) & 7);
+    const int from = xcc[pb], to = xcc[b];  // block b timed what its partner sent
+    if (from < 0 || from > 7 || to < 0 || to > 7 || from == to) return 0;
+    for (int pg = 0; pg < 2 * P; ++pg) {
+      const unsigned t = out[(size_t)b * 2 * P + pg];
+      if (t == 0u || t > (1u << 24)) return 0;  // (a clock that ran backwards between two XCDs would show up here)
+      lat[(size_t)(from * 8 + to) * 2 * P + pg] = t;
+    }
+    have[from * 8 + to] = true;
+  }
+  for (int a = 0; a < 8; ++a)
+    for (int b = 0; b < 8; ++b)
+      if (a != b && !have[a * 8 + b]) return 0;
+  std::vector<uint16_t> rank((size_t)2 * 64 * P);
+  double best = 0.0, mean = 0.0, worst = 0.0;
+  for (int par = 0; par < 2; ++par)
+    for (int c = 0; c < 64; ++c) {
+      uint16_t* r = &rank[((size_t)par * 64 + c) * P];
+      for (int t = 0; t < P; ++t) r[t] = (uint16_t)t;
+      if (c / 8 == c % 8) continue;
+      const unsigned* l = &lat[(size_t)c * 2 * P + (size_t)par * P];
+      std::stable_sort(r, r + P, [&](uint16_t u, uint16_t v) { return l[u] < l[v]; });
+      double m = 0.0;
+      for (int t = 0; t < P; ++t) m += l[t];
+      best += l[r[0]], worst += l[r[P - 1]], mean += m / P;
+    }
+  const double to_us = 1.0 / (100.0 * kIters) / (2.0 * 56.0);  // 100 MHz ticks of kIters hand-offs; mean of 2 x 56 classes
+  ctx->place_best_us = (float)(best * to_us), ctx->place_mean_us = (float)(mean * to_us), ctx->place_worst_us = (float)(worst * to_us);
+  HIPCHK(ctx, hipMemcpyAsync(ctx->place_rank.p, rank.data(), sizeof(uint16_t) * rank.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (`rank` is pageable and leaves scope)
+  ctx->place_state = 1;
+  return 0;
+}
+
+// ... and once per topology: the records that are read across XCDs get their places (k_place_assign)
+int place_records(flame_nltgv2_ctx* ctx, int per_xcd) {
+  const size_t stride = records_capacity(ctx->L);
+  int rc = ensure(ctx, ctx->place_rec_off, sizeof(int32_t) * 2 * stride);
+  if (!rc) rc = ensure(ctx, ctx->place_patch, sizeof(int32_t) * stride + stride);  // [patch of a record | its class (1 byte)]
+  if (rc) return rc;
+  // (records beyond the walk -- the exchange buffers are sized for the packed vertex count -- are never read through this table)
+  LAUNCHCHK(ctx, launch_place_records(ctx->c, ctx->f, per_xcd, (const int32_t*)ctx->order_m.p, (const int32_t*)ctx->rid_of.p,
+                                      (int32_t*)ctx->place_patch.p, (int8_t*)((int32_t*)ctx->place_patch.p + stride),
+                                      (const uint16_t*)ctx->place_rank.p, kPlacePages, (int*)ctx->place_fill.p,
+                                      (int32_t*)ctx->place_rec_off.p, (int)stride, ctx->stream));
+  ctx->place_topo = ctx->topo, ctx->place_per_xcd = per_xcd;
+  return 0;
+}
+
+int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
+  if (n <= 0) return 0;
+  if (ctx->opt_solver == 1) {  // canonical 4-sweep path
+    int rc = ensure_canon(ctx);  // (settles a pending persistent run first)
+    if (rc) return rc;
+    const SolverParams sp = to_sp(p);
+    for (int it = 0; it < n; ++it) {
+      LAUNCHCHK(ctx, launch_save_prev(ctx->c, ctx->stream));
+      LAUNCHCHK(ctx, launch_dual(ctx->c, sp, ctx->stream));
+      LAUNCHCHK(ctx, launch_primal(ctx->c, sp, ctx->stream));
+      LAUNCHCHK(ctx, launch_extragradient(ctx->c, sp, ctx->stream));
+    }
+    ctx->fused_valid = false;
+    ctx->last_run_path = 4;
+    if (ctx->export_ptr) LAUNCHCHK(ctx, launch_export(ctx->c, ctx->f, false, ctx->export_scale, ctx->export_ptr, ctx->stream));
+    return enqueue_photo_sweep(ctx, false);
+  }
+  int rc = ensure_fused(ctx);
+  if (rc) return rc;
+  if (ctx->pending.active) {  // chaining onto an unchecked persistent run
+    if (ctx->pending.ops.size() >= kMaxChain) {
+      rc = finish(ctx);
+    } else {
+      rc = snapshot_chain_start(ctx);
+    }
+    if (rc) return rc;
+  }
+  int unroll, wpb;
+  pick_config(ctx, &unroll, &wpb);
+  std::vector<WaveGroup> groups;
+  int tv_lds = 0;
+  const int form = plan_persistent(ctx, n, &groups, &tv_lds);
+  if (form != 0) {
+    // tags must stay unique: clear the record buffers long before the 28-bit tag of the XCC table wraps -- and when the
+    // form changes (the forms lay the buffers out differently: one's XCC table is another's record area)
+    if ((uint64_t)ctx->tag_next + (uint64_t)n >= 0x07ff0000ull || (ctx->xbuf_form != 0 && ctx->xbuf_form != form)) {
+      const size_t bytes = kXbufBytesPerVertex * records_capacity(ctx->L);
+      HIPCHK(ctx, hipMemsetAsync(ctx->xbuf.p, 0, bytes, ctx->stream));
+      if (ctx->place_base) {
+        HIPCHK(ctx, hipMemsetAsync(ctx->place_base, 0, (size_t)2 * kPlacePages * 4096, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync((int*)ctx->place_fill.p + 2 * kPlacePages, 0, 64, ctx->stream));
+      }
+      ctx->tag_next = 1;
+    }
+    ctx->xbuf_form = form;
+    // a fresh first tag per run: records left by earlier runs (whose state may since have been changed
+    // by per-step launches or host uploads) can never satisfy a wait of this one
+    const uint32_t tag0 = ctx->tag_next + 2;
+    // (topology, form, kernel instance): a new instance -- other registers, other LDS -- gets a cooperative first launch
+    const uint64_t key = ctx->topo * 256 + (uint64_t)form * 64 + (uint64_t)tv_lds * 32 + (ctx->opt_verify != 0 ? 16 : 0) + (ctx->opt_probe != 0 ? 8 : 0) +
+                         (ctx->opt_dual == 2 ? 4 : ctx->opt_dual == 1 ? 2 : 0) + (ctx->opt_xcds > 0 ? 1 : 0);
+    {  // standing outputs: (re)send the small block the kernels read in their epilogue when it changed
+      RunTail want;
+      std::memset(static_cast<void*>(&want), 0, sizeof want);
+      want.export_out = ctx->export_ptr, want.export_scale = ctx->export_scale;
+      const PhotoFuse pf = photo_target(ctx);
+      std::memcpy(static_cast<void*>(&want.photo), &pf, sizeof pf);
+      if (form == 3 && std::getenv("FLAME_NLTGV2_TRACE")) {
+        rc = ensure(ctx, ctx->progress, 2 * sizeof(unsigned) * (size_t)ctx->L.wg_count);  // [how far | started when]
+        if (rc) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->progress.p, 0, 2 * sizeof(unsigned) * (size_t)ctx->L.wg_count, ctx->stream));
+        want.progress = (unsigned*)ctx->progress.p;
+      }
+      rc = ensure(ctx, ctx->run_tail, sizeof(RunTail));
+      if (rc) return rc;
+      if (!ctx->tail_valid || std::memcmp(&want, &ctx->tail_sent, sizeof(RunTail)) != 0) {
+        // pageable source: the runtime stages it during the call, so `want` may go out of scope
+        HIPCHK(ctx, hipMemcpyAsync(ctx->run_tail.p, &want, sizeof(RunTail), hipMemcpyHostToDevice, ctx->stream));
+        ctx->tail_sent = want;
+        ctx->tail_valid = true;
+      }
+    }
+    int e = 0;
+    for (const WaveGroup& gr : groups) {
+      const int pw = gr.count <= 4 * ctx->prop.multiProcessorCount ? 1 : 4;  // waves per workgroup
+      // same-XCD exchange through L2: with the waves laid out along the Morton curve it wins at every size
+      // (measured per step: 640x480 -16 %, 1280x720 -23 %, 1080p -18 %, 7-frame batch -20 %, 15 frames -19 %)
+      const int dual = (ctx->opt_dual == 2 || (ctx->opt_dual == 1 && gr.count > kDualMinWavesPerCu * ctx->prop.multiProcessorCount) ? 1 : 0) |
+                       (ctx->opt_verify == 2 ? 6 : ctx->opt_verify == 1 ? 2 : 0);  // bits 1, 2: record verification, its test hook
+      // A graph of <= 8 lane-per-half-edge waves per CU of ONE XCD (32 CUs) runs there entirely: every exchange
+      // stays in that XCD's L2 (measured 320x240: 1.23 instead of 1.47 us per step; at 640x480 the 26 waves per CU
+      // this would need cost more than the shorter hop saves).
+      const int cus_per_xcd = ctx->prop.multiProcessorCount / 8;
+      // (patch-per-wave form: one XCD while its CUs get at most two patches each -- measured: 48 patches 0.98 against
+      // 1.21 us per step on all eight, 208 patches 1.53 against 1.33)
+      const bool one_xcd = form == 3 ? gr.count <= 2 * cus_per_xcd : (form == 1 && gr.count <= 8 * cus_per_xcd);
+      const int xcds = ctx->opt_xcds > 0 ? ctx->opt_xcds : one_xcd ? 1 : 8;
+      const int presleep = ctx->opt_presleep > 0 ? ctx->opt_presleep - 1
+                           : form == 2                ? kPreSleepTv
+                           : xcds == 1                ? kPreSleepHeOneXcd
+                           : gr.count > 12 * ctx->prop.multiProcessorCount ? kPreSleepHeDense
+                                                                            : kPreSleepHe;
+      const unsigned spins_arg = ctx->opt_fault > 0 ? (0x80000000u | (unsigned)ctx->opt_fault) : kMaxSpins;
+      if (form == 3) {
+        // pacing: none where a CU holds few patches (a poll costs nothing there and a pause only delays the hand-off); at
+        // high residency the polls of ~20 waves per CU saturate the L2s' request ports and the fabric and it is the hand-off
+        // itself that slows down (probe: 0.72 us at 4 patches per CU, 1.03 at 15; 26 per CU unpaced: 50 us per step) -- a
+        // pause before the first poll and between rounds then wins (tools/pv_big.py sweeps, profiles/r03_pv_dense.txt)
+        const bool dense = gr.count > kPvPaceAbovePerCu * ctx->prop.multiProcessorCount;
+        const int gap = ctx->opt_poll_gap > 0 ? ctx->opt_poll_gap - 1 : dense ? (3 | ((kPvDenseGap - 1) << 4)) : kPvPollGap;
+        ctx->f.wg_poll_gap = gap |
+                             ((ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : dense ? kPvDensePreSleep : kPvPreSleep) << 8) |
+                             0;
+        ctx->f.rec_off = nullptr, ctx->f.place_pool = nullptr;
+        if (ctx->opt_place && groups.size() == 1 && gr.begin == 0 && xcds == 8 && (dual & 1)) {
+          if (ctx->place_state == 0) {
+            rc = place_calibrate(ctx);
+            if (rc) return rc;
+          }
+          const int per_xcd = (gr.count + xcds - 1) / xcds;
+          if (ctx->place_state == 1 && (ctx->place_topo != ctx->topo || ctx->place_per_xcd != per_xcd)) {
+            rc = place_records(ctx, per_xcd);
+            if (rc) return rc;
+          }
+          if (ctx->place_state == 1) {
+            ctx->f.place_pool = ctx->place_base, ctx->f.rec_off = (const int32_t*)ctx->place_rec_off.p;
+            ctx->f.rec_off_stride = (int)records_capacity(ctx->L);
+            ctx->f.rot_word = (unsigned*)ctx->place_fill.p + 2 * kPlacePages;
+          }
+        }
+        ctx->f.probe = nullptr;
+        if (ctx->opt_probe) {  // [patch][step][8 words]
+          const size_t words = (size_t)ctx->L.wg_count * (size_t)n * 8;
+          rc = ensure(ctx, ctx->probe, words * sizeof(unsigned));
+          if (rc) return rc;
+          ctx->f.probe = (unsigned*)ctx->probe.p;
+          ctx->probe_words = words;
+          HIPCHK(ctx, hipMemsetAsync(ctx->probe.p, 0, words * sizeof(unsigned), ctx->stream));  // (idle instances write nothing)
+        }
+      }
+      e = launch_persistent_run(ctx->f, to_sp(p), form, gr.begin, gr.count, ctx->parity, tag0, n, pw, spins_arg, presleep, dual,
+                                tv_lds, xcds, (const RunTail*)ctx->run_tail.p, ctx->coop_checked_key != key, ctx->stream);
+      if (e != 0) break;
+    }
+    ctx->tag_next = tag0 + (uint32_t)n;
+    if (e == 0) {
+      // The kernels wrote (will write) hq / vstate / bar into the other copies: make those current.  finish() takes
+      // this back if the run reports a timeout.
+      if (!ctx->pending.active) {
+        ctx->pending.active = true, ctx->pending.snapshotted = false;
+        ctx->pending.ops.clear();
+        ctx->pending.parity_before = ctx->parity, ctx->pending.have_prev_before = ctx->have_prev;
+      }
+      {
+        flame_nltgv2_ctx::PendingOp op;
+        op.kind = 0, op.params = *p, op.n = n;
+        ctx->pending.ops.push_back(op);
+      }
+      std::swap(ctx->hq, ctx->hq_alt);
+      std::swap(ctx->vstate, ctx->vstate_alt);
+      ctx->buf_gen ^= 1;
+      refresh_args(ctx);
+      ctx->coop_checked_key = key;
+      ctx->last_run_path = form == 3 ? 6 : form == 2 ? 5 : 1;
+      ctx->last_run_groups = (int)groups.size();
+      ctx->parity ^= 1;
+      ctx->have_prev = true;
+      ctx->canon_valid = false;
+      return 0;
+    }
+    if (std::getenv("FLAME_NLTGV2_TRACE")) std::fprintf(stderr, "[flame_nltgv2] persistent launch refused: hip error %d (%s), form %d, pv_occ %d\n", e, hipGetErrorString((hipError_t)e), form, ctx->pv_occ);
+    // e.g. cooperative launch too large.  Groups already enqueued write into the other copies only: the current
+    // state is intact, the steps are done on the one-launch-per-step path below.  Let those groups drain first and
+    // forget what they reported (their waits expire without the missing groups): that is not a failure of a run.
+    (void)hipGetLastError();
+    ctx->persist_refused_topo = ctx->topo;  // do not try again for this topology
+    if (groups.size() > 1 && !ctx->pending.active) {
+      HIPCHK(ctx, hipMemsetAsync(ctx->abort_flag.p, 0xff, sizeof(int), ctx->stream));  // tells them to leave at once
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, kErrBytes, ctx->stream));
+      HIPCHK(ctx, hipMemsetAsync(ctx->abort_flag.p, 0, sizeof(int), ctx->stream));
+    }
+  }
+  if (ctx->pending.active) {
+    flame_nltgv2_ctx::PendingOp op;
+    op.kind = 0, op.params = *p, op.n = n;
+    ctx->pending.ops.push_back(op);
+  }
+  int left = n;
+  while (left > 0) {
+    const int chunk = left >= kGraphChunk ? kGraphChunk : left;
+    if (ctx->opt_use_graph && chunk >= 4) {
+      hipGraphExec_t exec = nullptr;
+      rc = get_graph(ctx, p, chunk, ctx->parity, unroll, wpb, &exec);
+      if (rc) return rc;
+      HIPCHK(ctx, hipGraphLaunch(exec, ctx->stream));
+      ctx->last_run_path = 2;
+    } else {
+      rc = enqueue_fused_eager(ctx, p, chunk, ctx->parity, unroll, wpb, true);
+      if (rc) return rc;
+      ctx->last_run_path = 3;
+    }
+    ctx->parity ^= (chunk & 1);
+    left -= chunk;
+  }
+  ctx->have_prev = true;
+  ctx->canon_valid = false;
+  if (ctx->export_ptr) LAUNCHCHK(ctx, launch_export(ctx->c, ctx->f, true, ctx->export_scale, ctx->export_ptr, ctx->stream));
+  return enqueue_photo_sweep(ctx, true);
+}
+
+// FLAME_NLTGV2_TRACE: which wait of the persistent run expired first, and how far every patch had got
+void trace_expired_wait(flame_nltgv2_ctx* ctx) {
+  const int* e = ctx->h_err;
+  static const char* const kWhich[] = {"?", "rotation word", "XCC table", "step records"};
+  std::fprintf(stderr, "[flame_nltgv2] persistent run taken back (flags %d): first expired wait = %s, patch %d, step %d, lanes waiting %08x%08x, "
+               "first of them for record %d (tag seen %u, wanted %u), on XCC %d hw_id %08x\n", e[0], kWhich[e[1] & 3], e[2], e[3], (unsigned)e[5],
+               (unsigned)e[4], e[6], (unsigned)e[7], (unsigned)e[8], e[9], (unsigned)e[10]);
+  if (!ctx->progress.p || ctx->L.wg_count <= 0) return;
+  std::vector<unsigned> pg((size_t)2 * ctx->L.wg_count);
+  if (hipMemcpy(pg.data(), ctx->progress.p, sizeof(unsigned) * pg.size(), hipMemcpyDeviceToHost) != hipSuccess) return;
+  size_t silent = 0, left = 0;
+  unsigned lo = ~0u, hi = 0;
+  int first_silent = -1;
+  const size_t n_p = (size_t)ctx->L.wg_count;
+  {  // when the patches started: all within microseconds of each other if they were co-resident
+    unsigned t_lo = ~0u, t_hi = 0;
+    size_t started = 0, late = 0;
+    for (size_t i = 0; i < n_p; ++i)
+      if (pg[n_p + i]) ++started, t_lo = std::min(t_lo, pg[n_p + i]), t_hi = std::max(t_hi, pg[n_p + i]);
+    int first_late = -1;
+    for (size_t i = 0; i < n_p; ++i)
+      if (pg[n_p + i] && pg[n_p + i] - t_lo > 10000u) {
+        if (first_late < 0) first_late = (int)i;
+        ++late;
+      }
+    std::fprintf(stderr, "[flame_nltgv2]   %zu of %zu patches started, over %u us; %zu of them more than 10 ms after the first (first such patch: %d)\n",
+                 started, n_p, started ? t_hi - t_lo : 0u, late, first_late);
+  }
+  for (size_t i = 0; i < n_p; ++i) {
+    if (pg[i] == 0) {
+      if (first_silent < 0) first_silent = (int)i;
+      ++silent;
+    } else {
+      ++left, lo = std::min(lo, pg[i] & 0x7fffffffu), hi = std::max(hi, pg[i] & 0x7fffffffu);
+    }
+  }
+  std::fprintf(stderr, "[flame_nltgv2]   %zu patches left through an expired wait (in steps %u..%u), %zu wrote nothing (finished, or never ran; first: %d)\n",
+               left, left ? lo - 1 : 0, left ? hi - 1 : 0, silent, first_silent);
+}
+
+int finish(flame_nltgv2_ctx* ctx) {
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_err, ctx->err.p, kErrBytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  flame_nltgv2_ctx::PendingRun run;
+  std::swap(run, ctx->pending);  // (ctx->pending is now inactive and empty)
+  if (*ctx->h_err & 6) {
+    if (*ctx->h_err & 4) ctx->torn_records_detected++;  // the record verification found a second read that differed
+    std::memcpy(ctx->last_expired, ctx->h_err, kErrBytes);
+    if (std::getenv("FLAME_NLTGV2_TRACE")) trace_expired_wait(ctx);
+    // A neighbour wait of a persistent run expired (its waves were not all resident: the GPU is shared with
+    // something that keeps CUs full).  Go back to the state the run -- or the chain of runs enqueued behind it --
+    // started from, and do the same steps on the one-launch-per-step path, which needs no co-residency.
+    if (!run.active) {  // nothing recorded to go back to
+      ctx->have_graph = false;
+      return fail(ctx, FLAME_NLTGV2_ERR_TIMEOUT);
+    }
+    if (run.snapshotted) {
+      const size_t n_slots = (size_t)(ctx->L.rows + kRowPad) * kWave, n_packed = (size_t)ctx->L.n_slices * kWave;
+      HIPCHK(ctx, hipMemcpyAsync(ctx->hq.p, ctx->snap_hq.p, sizeof(float4) * n_slots, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->vstate.p, ctx->snap_vstate.p, sizeof(float4) * n_packed, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->f.bar[run.parity_before], ctx->snap_bar.p, sizeof(float4) * n_packed, hipMemcpyDeviceToDevice,
+                                 ctx->stream));
+    } else {  // a single run: it wrote the other copies, its input is intact
+      std::swap(ctx->hq, ctx->hq_alt);
+      std::swap(ctx->vstate, ctx->vstate_alt);
+      ctx->buf_gen ^= 1;
+      refresh_args(ctx);
+    }
+    ctx->parity = run.parity_before;
+    ctx->have_prev = run.have_prev_before;
+    ctx->fused_valid = true, ctx->canon_valid = false;
+    ctx->persist_refused_topo = ctx->topo;
+    if (!(*ctx->h_err & 4)) ctx->timeouts_recovered++;
+    HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, kErrBytes, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->abort_flag.p, 0, sizeof(int), ctx->stream));
+    for (const flame_nltgv2_ctx::PendingOp& op : run.ops) {
+      if (op.kind == 0) {
+        const int rc = enqueue_run(ctx, &op.params, op.n);
+        if (rc) return rc;
+      } else {
+        LAUNCHCHK(ctx, launch_export(ctx->c, ctx->f, true, op.scale, op.dst, ctx->stream));
+      }
+    }
+    return finish(ctx);
+  }
+  if (*ctx->h_err != 0) {
+    // NaN/Inf in a dual variable (the reference's FLAME_ASSERT h:174): reported once; the state stays readable
+    // (download_state, costs) and the solve can go on or be re-initialised -- q was clamped to +-1 where it happened
+    HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, kErrBytes, ctx->stream));
+    return fail(ctx, FLAME_NLTGV2_ERR_NAN);
+  }
+  return 0;
+}
+
+// Copies the state a chain of asynchronous runs started from aside, once per chain, before anything behind the first
+// (still unchecked) persistent run is enqueued: that run read (hq, vstate, bar[parity_before]) and wrote the other
+// copies, so the stream-ordered copies below still see its input.
+int snapshot_chain_start(flame_nltgv2_ctx* ctx) {
+  if (!ctx->pending.active || ctx->pending.snapshotted) return 0;
+  const size_t n_slots = (size_t)(ctx->L.rows + kRowPad) * kWave, n_packed = (size_t)ctx->L.n_slices * kWave;
+  int rc = ensure(ctx, ctx->snap_hq, sizeof(float4) * n_slots);
+  if (!rc) rc = ensure(ctx, ctx->snap_vstate, sizeof(float4) * n_packed);
+  if (!rc) rc = ensure(ctx, ctx->snap_bar, sizeof(float4) * n_packed);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->snap_hq.p, ctx->hq_alt.p, sizeof(float4) * n_slots, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->snap_vstate.p, ctx->vstate_alt.p, sizeof(float4) * n_packed, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->snap_bar.p, ctx->f.bar[ctx->pending.parity_before], sizeof(float4) * n_packed, hipMemcpyDeviceToDevice,
+                             ctx->stream));
+  ctx->pending.snapshotted = true;
+  return 0;
+}
+
+}  // namespace host
+}  // namespace flame_hip
+
+extern "C" {
+
+int flame_nltgv2_run_async(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n_iters) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_run_async");
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!params_ok(p) || n_iters < 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  return enqueue_run(ctx, p, n_iters);
+}
+
+int flame_nltgv2_sync(flame_nltgv2_ctx* ctx) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_sync");
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+  }
+  return finish(ctx);
+}
+
+int flame_nltgv2_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n_iters) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_run");
+  int rc = flame_nltgv2_run_async(ctx, p, n_iters);
+  if (rc) return rc;
+  return finish(ctx);
+}
+
+int flame_nltgv2_run_timed(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n_iters, float* elapsed_ms) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!params_ok(p) || n_iters < 0 || !elapsed_ms) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  // layout conversion and graph instantiation are not part of the steady-state step
+  if (ctx->opt_solver == 0) rc = ensure_fused(ctx); else rc = ensure_canon(ctx);
+  if (rc) return rc;
+  rc = prepare_run(ctx, p, n_iters);
+  if (rc) return rc;
+  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  rc = enqueue_run(ctx, p, n_iters);
+  if (rc) return rc;
+  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  rc = finish(ctx);
+  float ms = 0.f;
+  HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *elapsed_ms = ms;
+  return rc;
+}
+
+int flame_nltgv2_step(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p) { return flame_nltgv2_run(ctx, p, 1); }
+
+#define CANON_OP(NAME, LAUNCH)                                                  \
+  int NAME(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p) {               \
+    int rc = enter(ctx);                                                        \
+    if (rc) return rc;                                                          \
+    if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);          \
+    if (!params_ok(p)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);          \
+    rc = ensure_canon(ctx);                                                     \
+    if (rc) return rc;                                                          \
+    const SolverParams sp = to_sp(p);                                           \
+    LAUNCHCHK(ctx, LAUNCH(ctx->c, sp, ctx->stream));                            \
+    ctx->fused_valid = false;                                                   \
+    return finish(ctx);                                                         \
+  }
+CANON_OP(flame_nltgv2_dual_step, launch_dual)
+CANON_OP(flame_nltgv2_primal_step, launch_primal)
+CANON_OP(flame_nltgv2_extragradient_step, launch_extragradient)
+#undef CANON_OP
+
+int flame_nltgv2_save_prev(flame_nltgv2_ctx* ctx) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  rc = ensure_canon(ctx);
+  if (rc) return rc;
+  LAUNCHCHK(ctx, launch_save_prev(ctx->c, ctx->stream));
+  ctx->fused_valid = false;
+  return finish(ctx);
+}
+
+
+}  // extern "C"

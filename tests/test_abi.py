@@ -96,7 +96,7 @@ def test_product_package_never_imports_the_checker():
 
 
 def test_pv_residency_table_matches_the_build(tmp_path):
-    """The planner's residency of k_persistent_pv (pv_real_waves_per_simd, nltgv2_kernels.hip) is derived from the
+    """The planner's residency of k_persistent_pv (pv_real_waves_per_simd, nltgv2_persistent.hip) is derived from the
     register counts of the instances as built: waves per SIMD = min(512 // VGPRs rounded up to 8,
     800 // (SGPRs rounded up to 16, + 16 for the trap handler), 8) -- the rule tools/residency_probe.hip measured on
     the hardware (profiles/r03_residency.txt), which the runtime's occupancy query does not follow.  Compiles the
@@ -104,7 +104,7 @@ def test_pv_residency_table_matches_the_build(tmp_path):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
-    src = os.path.join(ROOT, "flame_amd", "csrc", "nltgv2_kernels.hip")
+    src = os.path.join(ROOT, "flame_amd", "csrc", "nltgv2_persistent.hip")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
            "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "flame_amd", "csrc"), "-c", src, "-o", str(tmp_path / "k.o"),
            "-Rpass-analysis=kernel-resource-usage"]

@@ -3,7 +3,7 @@ ctypes binding of include/flame_nltgv2.h), against the CPU checker in oracle/ on
 
 Tolerance stated by north_star: converged inverse depth within 1e-4 RMS of the reference CPU solver.
 The implementation is designed to be BIT-IDENTICAL (same IEEE operations in the same order, see
-flame_amd/csrc/nltgv2_kernels.hip), so most tests assert exact equality; `TOL_RMS` is asserted as
+flame_amd/csrc/nltgv2_kernels.hip, nltgv2_persistent*.hip), so most tests assert exact equality; `TOL_RMS` is asserted as
 well where the comparison is the north_star one.
 """
 import numpy as np
