@@ -17,11 +17,28 @@
 // Output conventions (matching Triangle's): triangles counter-clockwise in x-right / y-up coordinates;
 // edges unique and undirected, listed as first met walking the triangles (v0,v1),(v1,v2),(v2,v0).
 // Exact duplicates of an earlier point are skipped (Triangle ignores them as well).
+//
+// Large inputs (>= 4096 points) are triangulated in parallel (round 3: the triangulation had become 60 % of a frame):
+// the points are cut into vertical strips of equal counts; every strip triangulates, on its own thread and with the same
+// exact algorithm, the points of its x range widened by a halo plus the points near the top / bottom of the bounding box
+// over the whole width, and reports the triangles whose leftmost vertex lies in its own range -- each after a CERTIFICATE
+// that it is a triangle of the global Delaunay triangulation: its circumdisk (for a hull edge: the outer half-plane) does
+// not reach into the part of the bounding box whose points the strip did not look at.  A strip that cannot certify a
+// triangle retries with a three times wider halo; if that fails too, or if the strips' counts do not add up to a
+// triangulation (Euler), the whole input is triangulated sequentially.  The number of strips depends on the number of points
+// only, never on the machine: the output is the same whatever the thread count.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 #include "flame_nltgv2.h"
@@ -283,6 +300,362 @@ inline uint32_t spread16(uint32_t v) {
   return v;
 }
 
+
+// ---- a few persistent worker threads (creating a thread per call would cost what the parallel build saves) --------------
+class Workers {
+ public:
+  static Workers& get() {
+    static Workers w;
+    return w;
+  }
+  int threads() const { return n_threads_; }
+  // runs job(0) .. job(n - 1), the calling thread included; returns when all are done
+  void run(int n, const std::function<void(int)>& job) {
+    std::unique_lock<std::mutex> call(call_mtx_);  // one parallel region at a time
+    if (n_threads_ <= 1 || n <= 1) {
+      for (int i = 0; i < n; ++i) job(i);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> lk(mtx_);
+      job_ = &job, n_jobs_ = n, next_.store(0), pending_ = n, ++generation_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(mtx_);
+    done_cv_.wait(lk, [&] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  Workers() {
+    int want = (int)std::thread::hardware_concurrency();
+    if (const char* e = std::getenv("FLAME_DELAUNAY_THREADS")) want = std::atoi(e);
+    n_threads_ = std::max(1, std::min(want, 32));
+    for (int i = 1; i < n_threads_; ++i) pool_.emplace_back([this] { loop(); });
+  }
+  ~Workers() {
+    {
+      std::lock_guard<std::mutex> lk(mtx_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : pool_) t.join();
+  }
+  void work() {
+    for (;;) {
+      const int i = next_.fetch_add(1);
+      if (i >= n_jobs_) return;
+      (*job_)(i);
+      std::lock_guard<std::mutex> lk(mtx_);
+      if (--pending_ == 0) done_cv_.notify_all();
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mtx_);
+        cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
+        if (stop_) return;
+        seen = generation_;
+      }
+      work();
+    }
+  }
+  std::mutex call_mtx_, mtx_;
+  std::condition_variable cv_, done_cv_;
+  std::vector<std::thread> pool_;
+  const std::function<void(int)>* job_ = nullptr;
+  std::atomic<int> next_{0};
+  int n_jobs_ = 0, pending_ = 0, n_threads_ = 1;
+  uint64_t generation_ = 0;
+  bool stop_ = false;
+};
+
+// What every (sub)triangulation of one input shares: the exact integer image of the coordinates and the bounding box.
+struct Input {
+  const float* xy = nullptr;
+  int32_t n = 0;
+  double to_int = 1.0;
+  bool filter_ok = false;
+  float minx = 0, maxx = 0, miny = 0, maxy = 0;
+  double ori_static = 0.0, icc_static = 0.0;
+};
+
+// Triangulates the points ids[0..m) of `in` (global ids, ascending within equal Morton keys): T's vertex k is ids[k].
+// Returns false when the subset has no triangle (fewer than three distinct points, or all collinear).
+bool triangulate_subset(const Input& in, const int* ids, int m, Triangulator& T) {
+  const float* xy = in.xy;
+  T.filter_ok = in.filter_ok, T.ori_static = in.ori_static, T.icc_static = in.icc_static;
+  T.p.resize((size_t)m);
+  for (int k = 0; k < m; ++k) {
+    const int i = ids[k];
+    T.p[(size_t)k].x = (int64_t)((double)xy[2 * i] * in.to_int);  // exact: a power-of-two scale, |result| < 2^58
+    T.p[(size_t)k].y = (int64_t)((double)xy[2 * i + 1] * in.to_int);
+    T.p[(size_t)k].fx = (double)xy[2 * i];
+    T.p[(size_t)k].fy = (double)xy[2 * i + 1];
+  }
+  // ---- insertion order: Morton curve (consecutive points are close: short walks).  The keys are quantised over the
+  // bounding box of the WHOLE input, and ties keep the order of `ids`: two points are inserted in the same relative order
+  // in every subset that holds both (what breaks co-circular ties the same way in neighbouring strips)
+  std::vector<int> order((size_t)m);
+  std::iota(order.begin(), order.end(), 0);
+  {
+    const double sx = in.maxx > in.minx ? 65535.0 / ((double)in.maxx - in.minx) : 0.0;
+    const double sy = in.maxy > in.miny ? 65535.0 / ((double)in.maxy - in.miny) : 0.0;
+    std::vector<uint32_t> key((size_t)m);
+    for (int k = 0; k < m; ++k) {
+      const int i = ids[k];
+      const uint32_t qx = (uint32_t)(((double)xy[2 * i] - in.minx) * sx), qy = (uint32_t)(((double)xy[2 * i + 1] - in.miny) * sy);
+      key[(size_t)k] = spread16(qx) | (spread16(qy) << 1);
+    }
+    // stable LSD radix sort by key (3 passes of 11 bits)
+    std::vector<int> tmp((size_t)m);
+    std::vector<uint32_t> count(2049);
+    for (int pass = 0; pass < 3; ++pass) {
+      const int shift = 11 * pass;
+      std::fill(count.begin(), count.end(), 0u);
+      for (int k = 0; k < m; ++k) count[((key[(size_t)order[(size_t)k]] >> shift) & 2047u) + 1]++;
+      for (int b = 0; b < 2048; ++b) count[(size_t)b + 1] += count[(size_t)b];
+      for (int k = 0; k < m; ++k) tmp[count[(key[(size_t)order[(size_t)k]] >> shift) & 2047u]++] = order[(size_t)k];
+      order.swap(tmp);
+    }
+  }
+
+  // ---- first non-degenerate triangle --------------------------------------------------------------------
+  const int a = order[0];
+  size_t ib = 1;
+  while (ib < order.size() && T.p[(size_t)order[ib]].x == T.p[(size_t)a].x && T.p[(size_t)order[ib]].y == T.p[(size_t)a].y) ++ib;
+  if (ib >= order.size()) return false;  // all points identical
+  const int b = order[ib];
+  size_t ic = ib + 1;
+  while (ic < order.size() && T.orient(a, b, order[ic]) == 0) ++ic;
+  if (ic >= order.size()) return false;  // all points collinear: no triangles
+  int c = order[ic];
+  int v0 = a, v1 = b, v2 = c;
+  if (T.orient(v0, v1, v2) < 0) std::swap(v1, v2);
+  T.t.clear();
+  T.t.reserve((size_t)m * 4 + 16);
+  const int t0 = T.new_tri(v0, v1, v2);
+  // ghosts: across edge opposite v[i] of t0, i.e. edge (v[i+1], v[i+2]); the ghost holds it reversed
+  int g[3];
+  for (int i = 0; i < 3; ++i) g[i] = T.new_tri(T.t[t0].v[(i + 2) % 3], T.t[t0].v[(i + 1) % 3], GHOST);
+  for (int i = 0; i < 3; ++i) {
+    T.t[t0].n[i] = g[i];
+    T.t[g[i]].n[2] = t0;  // across its real edge (opposite GHOST)
+  }
+  // ghost i = (u, w, G) with u = v[i+2], w = v[i+1]: edge w-G (opposite u, index 0) is shared with the ghost
+  // that starts at w, i.e. ghost (i+2) = (v[i+1], v[i], G); edge G-u (opposite w, index 1) with ghost (i+1).
+  for (int i = 0; i < 3; ++i) {
+    T.t[g[i]].n[0] = g[(i + 2) % 3];
+    T.t[g[i]].n[1] = g[(i + 1) % 3];
+  }
+
+  std::vector<char> used((size_t)m, 0);
+  used[(size_t)v0] = used[(size_t)v1] = used[(size_t)v2] = 1;
+  int last = t0;
+  for (size_t k = 0; k < order.size(); ++k) {
+    const int d = order[k];
+    if (used[(size_t)d]) continue;
+    used[(size_t)d] = 1;
+    int seed = T.locate(last, d);
+    // duplicate of an existing vertex: the located triangle has it as a corner
+    bool dup = false;
+    for (int i = 0; i < 3; ++i) {
+      const int v = T.t[seed].v[i];
+      if (v != GHOST && T.p[(size_t)v].x == T.p[(size_t)d].x && T.p[(size_t)v].y == T.p[(size_t)d].y) dup = true;
+    }
+    if (dup) continue;
+    if (!T.in_disk(seed, d)) {
+      // d lies on the boundary of the located triangle's disk only when it is ON an edge / hull line:
+      // one of the neighbours then contains it in its open disk
+      int alt = -1;
+      for (int i = 0; i < 3 && alt < 0; ++i) {
+        const int nb = T.t[seed].n[i];
+        if (nb >= 0 && T.in_disk(nb, d)) alt = nb;
+      }
+      if (alt < 0) continue;  // cannot happen for a point not equal to a vertex; skip defensively
+      seed = alt;
+    }
+    last = T.insert(seed, d);
+  }
+  return true;
+}
+
+struct Rect {
+  double x0, x1, y0, y1;  // empty when x0 >= x1 or y0 >= y1
+  bool empty() const { return !(x0 < x1 && y0 < y1); }
+};
+
+// ---- one strip of the parallel build ------------------------------------------------------------------------------------
+struct StripResult {
+  std::vector<int32_t> tris, edges;  // global vertex ids
+  int64_t hull_edges = 0, vertices = 0;  // hull edges among `edges`; distinct points of the strip's own x range in its triangulation
+  bool certified = true;
+};
+
+// Is the closed disk through the (counter-clockwise) triangle a, b, c clear of rectangle r?  In double: the coordinates are
+// integer multiples of a common power of two with <= 25 significant bits here (filter_ok), so the orientation determinant
+// is exact and centre / radius are good to ~1e-15 relative; the comparison keeps a margin far above that.
+inline bool disk_clear_of(const Pt& a, const Pt& b, const Pt& c, const Rect& r) {
+  if (r.empty()) return true;
+  const double bx = b.fx - a.fx, by = b.fy - a.fy, cx = c.fx - a.fx, cy = c.fy - a.fy;
+  const double d = 2.0 * (bx * cy - by * cx);
+  if (!(d > 0.0)) return false;
+  const double bl = bx * bx + by * by, cl = cx * cx + cy * cy;
+  const double ux = (cy * bl - by * cl) / d, uy = (bx * cl - cx * bl) / d;  // centre relative to a
+  const double r2 = ux * ux + uy * uy;
+  const double ox = a.fx + ux, oy = a.fy + uy;
+  const double dx = std::max(std::max(r.x0 - ox, 0.0), ox - r.x1), dy = std::max(std::max(r.y0 - oy, 0.0), oy - r.y1);
+  const double dist2 = dx * dx + dy * dy;
+  return dist2 > r2 * (1.0 + 1e-9) + 1e-9 * (1.0 + std::fabs(ox) + std::fabs(oy));
+}
+
+// Is the open half-plane to the RIGHT of u -> v (the outer side of a hull edge whose triangle lies on the left) clear of r?
+inline bool outer_side_clear_of(const Pt& u, const Pt& v, const Rect& r) {
+  if (r.empty()) return true;
+  const double ex = v.fx - u.fx, ey = v.fy - u.fy;
+  const double tol = 1e-9 * (std::fabs(ex) + std::fabs(ey)) * (1.0 + std::fabs(r.x1 - r.x0) + std::fabs(r.y1 - r.y0));
+  const double xs[2] = {r.x0, r.x1}, ys[2] = {r.y0, r.y1};
+  for (double x : xs)
+    for (double y : ys)
+      if (ex * (y - u.fy) - ey * (x - u.fx) < tol) return false;  // a corner on the line or right of it
+  return true;
+}
+
+constexpr int kBins = 1024;
+
+// Strip s owns the points of x bins [core0, core1); it triangulates the bins [core0 - halo, core1 + halo) plus the band points
+// (y within `band` of the bounding box's top / bottom) of all other bins.
+void run_strip(const Input& in, const std::vector<int>& by_bin, const std::vector<int>& bin_start, const std::vector<int>& band_pts,
+               const std::vector<uint16_t>& bin_of, int core0, int core1, int halo, double band, StripResult* out) {
+  const int lo = std::max(0, core0 - halo), hi = std::min(kBins, core1 + halo);
+  std::vector<int> ids(by_bin.begin() + bin_start[(size_t)lo], by_bin.begin() + bin_start[(size_t)hi]);
+  const size_t n_block = ids.size();
+  for (int i : band_pts)
+    if (bin_of[(size_t)i] < lo || bin_of[(size_t)i] >= hi) ids.push_back(i);
+  // ascending ids inside a bin, bins ascending; the band points of other bins come last (their Morton keys differ from every
+  // block point's: another x bin) -- the relative order of equal keys is that of the whole input
+  (void)n_block;
+  out->tris.clear(), out->edges.clear(), out->hull_edges = 0, out->vertices = 0, out->certified = true;
+  Triangulator T;
+  if (!triangulate_subset(in, ids.data(), (int)ids.size(), T)) {
+    out->certified = false;
+    return;
+  }
+  const double bw = ((double)in.maxx - (double)in.minx) / kBins;
+  const double xlo = lo == 0 ? -1e300 : (double)in.minx + bw * lo, xhi = hi == kBins ? 1e300 : (double)in.minx + bw * hi;
+  // what this strip has NOT looked at: the boxes left and right of its x range, between the bands (shrunk by nothing:
+  // a point exactly on a bin edge belongs to the higher bin, the boxes are closed -- conservative)
+  const Rect left = {(double)in.minx, xlo, (double)in.miny + band, (double)in.maxy - band};
+  const Rect right = {xhi, (double)in.maxx, (double)in.miny + band, (double)in.maxy - band};
+  std::vector<char> in_tri(ids.size(), 0);
+  auto own = [&](int v) { return bin_of[(size_t)ids[(size_t)v]] >= core0 && bin_of[(size_t)ids[(size_t)v]] < core1; };
+  for (size_t ti = 0; ti < T.t.size(); ++ti) {
+    const Tri& tr = T.t[ti];
+    if (!tr.alive || Triangulator::is_ghost(tr)) continue;
+    for (int i = 0; i < 3; ++i) in_tri[(size_t)tr.v[i]] = 1;
+    // the leftmost vertex (smallest x, then smallest global id) decides whose triangle this is
+    int lm = 0;
+    for (int i = 1; i < 3; ++i) {
+      const Pt &q = T.p[(size_t)tr.v[i]], &m = T.p[(size_t)tr.v[lm]];
+      if (q.x < m.x || (q.x == m.x && ids[(size_t)tr.v[i]] < ids[(size_t)tr.v[lm]])) lm = i;
+    }
+    if (!own(tr.v[lm])) continue;
+    const Pt &a = T.p[(size_t)tr.v[0]], &b = T.p[(size_t)tr.v[1]], &c = T.p[(size_t)tr.v[2]];
+    if (!disk_clear_of(a, b, c, left) || !disk_clear_of(a, b, c, right)) {
+      if (std::getenv("FLAME_DELAUNAY_TRACE"))
+        std::fprintf(stderr, "[delaunay] strip bins [%d,%d) halo %d: disk of (%g,%g) (%g,%g) (%g,%g) reaches an unseen box [%g,%g] / [%g,%g] x [%g,%g]\n", core0, core1, halo,
+                     a.fx, a.fy, b.fx, b.fy, c.fx, c.fy, left.x0, left.x1, right.x0, right.x1, left.y0, left.y1);
+      out->certified = false;
+      return;
+    }
+    out->tris.push_back(ids[(size_t)tr.v[0]]), out->tris.push_back(ids[(size_t)tr.v[1]]), out->tris.push_back(ids[(size_t)tr.v[2]]);
+    for (int i = 0; i < 3; ++i) {
+      const int u = tr.v[i], v = tr.v[(i + 1) % 3];  // the triangle is on the left of u -> v
+      const int nb = tr.n[(i + 2) % 3];
+      const bool hull = nb < 0 || Triangulator::is_ghost(T.t[(size_t)nb]);
+      if (hull) {
+        if (!outer_side_clear_of(T.p[(size_t)u], T.p[(size_t)v], left) || !outer_side_clear_of(T.p[(size_t)u], T.p[(size_t)v], right)) {
+          if (std::getenv("FLAME_DELAUNAY_TRACE"))
+            std::fprintf(stderr, "[delaunay] strip bins [%d,%d) halo %d: hull edge (%g,%g)->(%g,%g): its outer side reaches an unseen box\n", core0, core1, halo,
+                         T.p[(size_t)u].fx, T.p[(size_t)u].fy, T.p[(size_t)v].fx, T.p[(size_t)v].fy);
+          out->certified = false;
+          return;
+        }
+        out->hull_edges++;
+      }
+      // an inner edge is listed by the triangle that has it as lower id -> higher id, a hull edge by its only triangle
+      if (hull || ids[(size_t)u] < ids[(size_t)v]) out->edges.push_back(ids[(size_t)u]), out->edges.push_back(ids[(size_t)v]);
+    }
+  }
+  for (size_t k = 0; k < ids.size(); ++k)
+    if (in_tri[k] && own((int)k)) out->vertices++;
+}
+
+// The parallel build; false = not certified (the caller triangulates sequentially).
+bool triangulate_strips(const Input& in, int n_strips, std::vector<int32_t>* tris, std::vector<int32_t>* edges) {
+  const int32_t n = in.n;
+  if (!in.filter_ok || !(in.maxx > in.minx) || !(in.maxy > in.miny)) return false;
+  // x bins (the Morton key's x quantisation >> 6: equal keys share a bin), counting sort by bin
+  std::vector<uint16_t> bin_of((size_t)n);
+  std::vector<int> bin_start(kBins + 1, 0), by_bin((size_t)n), band_pts;
+  const double sx = 65535.0 / ((double)in.maxx - in.minx);
+  for (int32_t i = 0; i < n; ++i) {
+    bin_of[(size_t)i] = (uint16_t)((uint32_t)(((double)in.xy[2 * i] - in.minx) * sx) >> 6);
+    bin_start[(size_t)bin_of[(size_t)i] + 1]++;
+  }
+  for (int b = 0; b < kBins; ++b) bin_start[(size_t)b + 1] += bin_start[(size_t)b];
+  {
+    std::vector<int> at(bin_start.begin(), bin_start.end() - 1);
+    for (int32_t i = 0; i < n; ++i) by_bin[(size_t)at[bin_of[(size_t)i]]++] = i;
+  }
+  // mean spacing of the points -> halo (in bins) and band height
+  const double W = (double)in.maxx - in.minx, H = (double)in.maxy - in.miny;
+  const double spacing = std::sqrt(W * H / std::max(1, n));
+  const double band = std::min(0.25 * H, 2.0 * spacing);
+  const int halo0 = std::max(1, (int)std::ceil(4.0 * spacing / (W / kBins)));
+  for (int32_t i = 0; i < n; ++i) {
+    const double y = in.xy[2 * i + 1];
+    if (y <= (double)in.miny + band || y >= (double)in.maxy - band) band_pts.push_back(i);
+  }
+  // strips of equal point counts, cut at bin edges
+  std::vector<int> cut((size_t)n_strips + 1, 0);
+  cut[(size_t)n_strips] = kBins;
+  for (int s = 1; s < n_strips; ++s) {
+    const int want = (int)((int64_t)n * s / n_strips);
+    cut[(size_t)s] = (int)(std::upper_bound(bin_start.begin(), bin_start.end(), want) - bin_start.begin()) - 1;
+    cut[(size_t)s] = std::max(cut[(size_t)s], cut[(size_t)s - 1] + 1);
+    if (cut[(size_t)s] >= kBins) return false;
+  }
+  std::vector<StripResult> res((size_t)n_strips);
+  Workers::get().run(n_strips, [&](int s) {
+    run_strip(in, by_bin, bin_start, band_pts, bin_of, cut[(size_t)s], cut[(size_t)s + 1], halo0, band, &res[(size_t)s]);
+    if (!res[(size_t)s].certified)  // once more, looking three times as far
+      run_strip(in, by_bin, bin_start, band_pts, bin_of, cut[(size_t)s], cut[(size_t)s + 1], 3 * halo0, band, &res[(size_t)s]);
+  });
+  int64_t nt = 0, ne = 0, nh = 0, nv = 0;
+  for (const StripResult& r : res) {
+    if (!r.certified) return false;
+    nt += (int64_t)r.tris.size() / 3, ne += (int64_t)r.edges.size() / 2, nh += r.hull_edges, nv += r.vertices;
+  }
+  // Euler: a triangulation of nv points with nh hull edges has 2 nv - 2 - nh triangles and 3 nv - 3 - nh edges
+  if (nv < 3 || nt != 2 * nv - 2 - nh || ne != 3 * nv - 3 - nh) {
+    if (std::getenv("FLAME_DELAUNAY_TRACE"))
+      std::fprintf(stderr, "[delaunay] strips do not add up: %lld vertices, %lld hull edges, %lld triangles, %lld edges\n", (long long)nv, (long long)nh,
+                   (long long)nt, (long long)ne);
+    return false;
+  }
+  tris->clear(), edges->clear();
+  tris->reserve((size_t)nt * 3), edges->reserve((size_t)ne * 2);
+  for (const StripResult& r : res) {
+    tris->insert(tris->end(), r.tris.begin(), r.tris.end());
+    edges->insert(edges->end(), r.edges.begin(), r.edges.end());
+  }
+  return true;
+}
+
 }  // namespace
 
 extern "C" int flame_delaunay_triangulate(const float* xy, int32_t n, int32_t* triangles, int32_t tri_capacity,
@@ -311,105 +684,46 @@ extern "C" int flame_delaunay_triangulate(const float* xy, int32_t n, int32_t* t
   }
   if (emin == 1000) return FLAME_NLTGV2_OK;  // all points at the origin
   if (emax - emin > 58) return FLAME_NLTGV2_ERR_INVALID_ARG;  // dynamic range beyond the exact predicates
-  Triangulator T;
-  T.filter_ok = (emax - emin) <= 50;  // differences exact in double, products well inside the error bound
-  T.p.resize((size_t)n);
-  float minx = xy[0], maxx = xy[0], miny = xy[1], maxy = xy[1];
-  const double to_int = std::ldexp(1.0, -emin);
+  Input in;
+  in.xy = xy, in.n = n;
+  in.filter_ok = (emax - emin) <= 50;  // differences exact in double, products well inside the error bound
+  in.to_int = std::ldexp(1.0, -emin);
+  in.minx = in.maxx = xy[0], in.miny = in.maxy = xy[1];
   for (int32_t i = 0; i < n; ++i) {
-    T.p[(size_t)i].x = (int64_t)((double)xy[2 * i] * to_int);  // exact: a power-of-two scale, |result| < 2^58
-    T.p[(size_t)i].y = (int64_t)((double)xy[2 * i + 1] * to_int);
-    T.p[(size_t)i].fx = (double)xy[2 * i];
-    T.p[(size_t)i].fy = (double)xy[2 * i + 1];
-    minx = std::min(minx, xy[2 * i]), maxx = std::max(maxx, xy[2 * i]);
-    miny = std::min(miny, xy[2 * i + 1]), maxy = std::max(maxy, xy[2 * i + 1]);
+    in.minx = std::min(in.minx, xy[2 * i]), in.maxx = std::max(in.maxx, xy[2 * i]);
+    in.miny = std::min(in.miny, xy[2 * i + 1]), in.maxy = std::max(in.maxy, xy[2 * i + 1]);
   }
-
   {
-    const double D = std::max((double)maxx - (double)minx, (double)maxy - (double)miny) * 1.0000001;
-    T.ori_static = 4.0e-16 * 2.0 * D * D;
-    T.icc_static = 1.2e-15 * 12.0 * D * D * D * D;
+    const double D = std::max((double)in.maxx - (double)in.minx, (double)in.maxy - (double)in.miny) * 1.0000001;
+    in.ori_static = 4.0e-16 * 2.0 * D * D;
+    in.icc_static = 1.2e-15 * 12.0 * D * D * D * D;
   }
 
-  // ---- insertion order: Morton curve (consecutive points are close: short walks) ----------------------
-  std::vector<int> order((size_t)n);
-  std::iota(order.begin(), order.end(), 0);
-  {
-    const double sx = maxx > minx ? 65535.0 / ((double)maxx - minx) : 0.0, sy = maxy > miny ? 65535.0 / ((double)maxy - miny) : 0.0;
-    std::vector<uint32_t> key((size_t)n);
-    for (int32_t i = 0; i < n; ++i) {
-      const uint32_t qx = (uint32_t)(((double)xy[2 * i] - minx) * sx), qy = (uint32_t)(((double)xy[2 * i + 1] - miny) * sy);
-      key[(size_t)i] = spread16(qx) | (spread16(qy) << 1);
-    }
-    // stable LSD radix sort by key (3 passes of 11 bits): ties keep index order
-    std::vector<int> tmp((size_t)n);
-    std::vector<uint32_t> count(2049);
-    for (int pass = 0; pass < 3; ++pass) {
-      const int shift = 11 * pass;
-      std::fill(count.begin(), count.end(), 0u);
-      for (int32_t i = 0; i < n; ++i) count[((key[(size_t)order[(size_t)i]] >> shift) & 2047u) + 1]++;
-      for (int b = 0; b < 2048; ++b) count[(size_t)b + 1] += count[(size_t)b];
-      for (int32_t i = 0; i < n; ++i) tmp[count[(key[(size_t)order[(size_t)i]] >> shift) & 2047u]++] = order[(size_t)i];
-      order.swap(tmp);
-    }
-  }
-
-  // ---- first non-degenerate triangle --------------------------------------------------------------------
-  const int a = order[0];
-  size_t ib = 1;
-  while (ib < order.size() && T.p[(size_t)order[ib]].x == T.p[(size_t)a].x && T.p[(size_t)order[ib]].y == T.p[(size_t)a].y) ++ib;
-  if (ib >= order.size()) return FLAME_NLTGV2_OK;  // all points identical
-  const int b = order[ib];
-  size_t ic = ib + 1;
-  while (ic < order.size() && T.orient(a, b, order[ic]) == 0) ++ic;
-  if (ic >= order.size()) return FLAME_NLTGV2_OK;  // all points collinear: no triangles
-  int c = order[ic];
-  int v0 = a, v1 = b, v2 = c;
-  if (T.orient(v0, v1, v2) < 0) std::swap(v1, v2);
-  T.t.reserve((size_t)n * 4 + 16);
-  const int t0 = T.new_tri(v0, v1, v2);
-  // ghosts: across edge opposite v[i] of t0, i.e. edge (v[i+1], v[i+2]); the ghost holds it reversed
-  int g[3];
-  for (int i = 0; i < 3; ++i) g[i] = T.new_tri(T.t[t0].v[(i + 2) % 3], T.t[t0].v[(i + 1) % 3], GHOST);
-  for (int i = 0; i < 3; ++i) {
-    T.t[t0].n[i] = g[i];
-    T.t[g[i]].n[2] = t0;  // across its real edge (opposite GHOST)
-  }
-  // ghost i = (u, w, G) with u = v[i+2], w = v[i+1]: edge w-G (opposite u, index 0) is shared with the ghost
-  // that starts at w, i.e. ghost (i+2) = (v[i+1], v[i], G); edge G-u (opposite w, index 1) with ghost (i+1).
-  for (int i = 0; i < 3; ++i) {
-    T.t[g[i]].n[0] = g[(i + 2) % 3];
-    T.t[g[i]].n[1] = g[(i + 1) % 3];
-  }
-
-  std::vector<char> used((size_t)n, 0);
-  used[(size_t)v0] = used[(size_t)v1] = used[(size_t)v2] = 1;
-  int last = t0;
-  for (size_t k = 0; k < order.size(); ++k) {
-    const int d = order[k];
-    if (used[(size_t)d]) continue;
-    used[(size_t)d] = 1;
-    int seed = T.locate(last, d);
-    // duplicate of an existing vertex: the located triangle has it as a corner
-    bool dup = false;
-    for (int i = 0; i < 3; ++i) {
-      const int v = T.t[seed].v[i];
-      if (v != GHOST && T.p[(size_t)v].x == T.p[(size_t)d].x && T.p[(size_t)v].y == T.p[(size_t)d].y) dup = true;
-    }
-    if (dup) continue;
-    if (!T.in_disk(seed, d)) {
-      // d lies on the boundary of the located triangle's disk only when it is ON an edge / hull line:
-      // one of the neighbours then contains it in its open disk
-      int alt = -1;
-      for (int i = 0; i < 3 && alt < 0; ++i) {
-        const int nb = T.t[seed].n[i];
-        if (nb >= 0 && T.in_disk(nb, d)) alt = nb;
+  // ---- large inputs: strips in parallel (same triangulation; the order of the output is the strips') ------------------
+  int n_strips = n < 4096 ? 1 : std::min(32, n / 1024);
+  if (const char* e = std::getenv("FLAME_DELAUNAY_STRIPS")) n_strips = std::max(1, std::min(std::atoi(e), std::min(64, n / 64 + 1)));  // (tests)
+  if (n_strips > 1) {
+    std::vector<int32_t> pt, pe;
+    if (triangulate_strips(in, n_strips, &pt, &pe)) {
+      const int32_t nt = (int32_t)(pt.size() / 3), ne = (int32_t)(pe.size() / 2);
+      *n_triangles = nt, *n_edges = ne;
+      if (triangles) {
+        if (tri_capacity < nt) return FLAME_NLTGV2_ERR_INVALID_ARG;
+        std::memcpy(triangles, pt.data(), sizeof(int32_t) * pt.size());
       }
-      if (alt < 0) continue;  // cannot happen for a point not equal to a vertex; skip defensively
-      seed = alt;
+      if (edges) {
+        if (edge_capacity < ne) return FLAME_NLTGV2_ERR_INVALID_ARG;
+        std::memcpy(edges, pe.data(), sizeof(int32_t) * pe.size());
+      }
+      return FLAME_NLTGV2_OK;
     }
-    last = T.insert(seed, d);
   }
+
+  // ---- sequential: one triangulation of everything ------------------------------------------------------------------
+  Triangulator T;
+  std::vector<int> all((size_t)n);
+  std::iota(all.begin(), all.end(), 0);
+  if (!triangulate_subset(in, all.data(), n, T)) return FLAME_NLTGV2_OK;
 
   // ---- output ---------------------------------------------------------------------------------------------
   int32_t nt = 0;

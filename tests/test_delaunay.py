@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 from flame_amd import regularizer, synth
+from tests.conftest import ROOT
 from tests.helpers import GOLDEN
 
 
@@ -123,3 +124,63 @@ def test_result_feeds_the_solver_graph(built):
     g = synth.assemble_graph(pts, synth.make_data_term(pts, 320, 240, 5), edg)
     pr = regularizer.pack_probe(g)
     assert pr["n_slices"] == (g["V"] + 63) // 64
+
+
+def _sets(tris, edges):
+    return ({tuple(sorted(map(int, t))) for t in tris}, {tuple(sorted(map(int, e))) for e in edges})
+
+
+def _triangulate_in_subprocess(pos, strips, threads):
+    """flame_delaunay_triangulate in a fresh process (the worker pool and the strip count are read from the environment once)."""
+    import subprocess
+    import sys
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "pos.npy"), pos)
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); from flame_amd.regularizer import delaunay; "
+                "t, e = delaunay(np.load(%r)); np.save(%r, t); np.save(%r, e)"
+                % (ROOT, os.path.join(d, "pos.npy"), os.path.join(d, "t.npy"), os.path.join(d, "e.npy")))
+        env = dict(os.environ, FLAME_DELAUNAY_THREADS=str(threads))
+        if strips:
+            env["FLAME_DELAUNAY_STRIPS"] = str(strips)
+        subprocess.check_call([sys.executable, "-c", code], env=env)
+        return np.load(os.path.join(d, "t.npy")), np.load(os.path.join(d, "e.npy"))
+
+
+@pytest.mark.parametrize("case", ["jittered grid", "exact grid (all co-circular)", "clustered + sparse", "duplicates + collinear rows"])
+def test_parallel_strips_equal_the_sequential_triangulation(built, case):
+    """Round 3: inputs of >= 4096 points are triangulated as certified strips on worker threads.  Same triangle / edge SETS as
+    the sequential build (one strip), for any thread count; identical OUTPUT (order included) for 1 and 4 threads -- the
+    number of strips depends on the input only; the cases that cannot be certified (sparse regions, co-circular grids whose
+    ties the strips would break differently) fall back to the sequential build and still agree."""
+    rng = np.random.default_rng(5)
+    if case == "jittered grid":
+        pos = synth.make_points(640, 480, 6, 3)
+    elif case == "exact grid (all co-circular)":
+        xs, ys = np.meshgrid(np.arange(90, dtype=np.float32) * 4, np.arange(60, dtype=np.float32) * 4)
+        pos = np.stack([xs.ravel(), ys.ravel()], 1)
+    elif case == "clustered + sparse":
+        a = rng.normal([100, 100], 15, (3000, 2))
+        b = rng.normal([500, 300], 40, (2500, 2))
+        c = rng.random((300, 2)) * [640, 480]
+        pos = np.concatenate([a, b, c]).astype(np.float32)
+    else:
+        g = synth.make_points(640, 480, 6, 9)
+        rows = np.stack([np.arange(400, dtype=np.float32) * 1.5, np.full(400, 240.0, np.float32)], 1)
+        pos = np.concatenate([g, g[::17], rows]).astype(np.float32)
+    seq = _triangulate_in_subprocess(pos, 1, 1)
+    par1 = _triangulate_in_subprocess(pos, 0, 1)
+    par4 = _triangulate_in_subprocess(pos, 0, 4)
+    many = _triangulate_in_subprocess(pos, 24, 3)
+    assert np.array_equal(par1[0], par4[0]) and np.array_equal(par1[1], par4[1]), "output depends on the thread count"
+    if case != "exact grid (all co-circular)":  # (a co-circular set has many Delaunay triangulations: only validity is comparable)
+        assert _sets(*seq) == _sets(*par1) == _sets(*many)
+    for tris, edges in (seq, par1, many):
+        n_used = len(np.unique(tris))
+        hull = 3 * n_used - 3 - len(edges)
+        assert len(tris) == 2 * n_used - 2 - hull and hull >= 3
+        p = pos.astype(np.float64)
+        a, b, c = p[tris[:, 0]], p[tris[:, 1]], p[tris[:, 2]]
+        assert np.all((b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0]) > 0)
+        assert len(_sets(tris, edges)[1]) == len(edges)
