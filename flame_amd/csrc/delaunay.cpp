@@ -42,6 +42,7 @@
 #include <vector>
 
 #include "flame_nltgv2.h"
+#include "host_workers.hpp"
 #include "roctx_ranges.hpp"
 
 namespace {
@@ -301,78 +302,6 @@ inline uint32_t spread16(uint32_t v) {
 }
 
 
-// ---- a few persistent worker threads (creating a thread per call would cost what the parallel build saves) --------------
-class Workers {
- public:
-  static Workers& get() {
-    static Workers w;
-    return w;
-  }
-  int threads() const { return n_threads_; }
-  // runs job(0) .. job(n - 1), the calling thread included; returns when all are done
-  void run(int n, const std::function<void(int)>& job) {
-    std::unique_lock<std::mutex> call(call_mtx_);  // one parallel region at a time
-    if (n_threads_ <= 1 || n <= 1) {
-      for (int i = 0; i < n; ++i) job(i);
-      return;
-    }
-    {
-      std::lock_guard<std::mutex> lk(mtx_);
-      job_ = &job, n_jobs_ = n, next_.store(0), pending_ = n, ++generation_;
-    }
-    cv_.notify_all();
-    work();
-    std::unique_lock<std::mutex> lk(mtx_);
-    done_cv_.wait(lk, [&] { return pending_ == 0; });
-    job_ = nullptr;
-  }
-
- private:
-  Workers() {
-    int want = (int)std::thread::hardware_concurrency();
-    if (const char* e = std::getenv("FLAME_DELAUNAY_THREADS")) want = std::atoi(e);
-    n_threads_ = std::max(1, std::min(want, 32));
-    for (int i = 1; i < n_threads_; ++i) pool_.emplace_back([this] { loop(); });
-  }
-  ~Workers() {
-    {
-      std::lock_guard<std::mutex> lk(mtx_);
-      stop_ = true;
-    }
-    cv_.notify_all();
-    for (auto& t : pool_) t.join();
-  }
-  void work() {
-    for (;;) {
-      const int i = next_.fetch_add(1);
-      if (i >= n_jobs_) return;
-      (*job_)(i);
-      std::lock_guard<std::mutex> lk(mtx_);
-      if (--pending_ == 0) done_cv_.notify_all();
-    }
-  }
-  void loop() {
-    uint64_t seen = 0;
-    for (;;) {
-      {
-        std::unique_lock<std::mutex> lk(mtx_);
-        cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
-        if (stop_) return;
-        seen = generation_;
-      }
-      work();
-    }
-  }
-  std::mutex call_mtx_, mtx_;
-  std::condition_variable cv_, done_cv_;
-  std::vector<std::thread> pool_;
-  const std::function<void(int)>* job_ = nullptr;
-  std::atomic<int> next_{0};
-  int n_jobs_ = 0, pending_ = 0, n_threads_ = 1;
-  uint64_t generation_ = 0;
-  bool stop_ = false;
-};
-
 // What every (sub)triangulation of one input shares: the exact integer image of the coordinates and the bounding box.
 struct Input {
   const float* xy = nullptr;
@@ -630,7 +559,7 @@ bool triangulate_strips(const Input& in, int n_strips, std::vector<int32_t>* tri
     if (cut[(size_t)s] >= kBins) return false;
   }
   std::vector<StripResult> res((size_t)n_strips);
-  Workers::get().run(n_strips, [&](int s) {
+  flame_hip::Workers::get().run(n_strips, [&](int s) {
     run_strip(in, by_bin, bin_start, band_pts, bin_of, cut[(size_t)s], cut[(size_t)s + 1], halo0, band, &res[(size_t)s]);
     if (!res[(size_t)s].certified)  // once more, looking three times as far
       run_strip(in, by_bin, bin_start, band_pts, bin_of, cut[(size_t)s], cut[(size_t)s + 1], 3 * halo0, band, &res[(size_t)s]);

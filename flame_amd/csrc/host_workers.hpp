@@ -1,0 +1,100 @@
+// host_workers.hpp -- a few persistent worker threads for the host-side stages that sit between GPU stages of a frame (the
+// Delaunay triangulation, the index maps of the per-frame graph sync): fork-join over a handful of jobs, the calling thread
+// included.  Creating a thread per call would cost what the parallel stage saves (~40 us each); these sleep on a condition
+// variable between calls.  FLAME_DELAUNAY_THREADS caps the pool (default: the machine's cores, at most 32).
+#ifndef FLAME_AMD_HOST_WORKERS_HPP_
+#define FLAME_AMD_HOST_WORKERS_HPP_
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdlib>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace flame_hip {
+
+class Workers {
+ public:
+  static Workers& get() {
+    static Workers w;
+    return w;
+  }
+  int threads() const { return n_threads_; }
+  // runs job(0) .. job(n - 1), the calling thread included; returns when all are done
+  void run(int n, const std::function<void(int)>& job) {
+    std::unique_lock<std::mutex> call(call_mtx_);  // one parallel region at a time
+    if (n_threads_ <= 1 || n <= 1) {
+      for (int i = 0; i < n; ++i) job(i);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> lk(mtx_);
+      job_ = &job, n_jobs_ = n, next_.store(0), pending_ = n, ++generation_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(mtx_);
+    done_cv_.wait(lk, [&] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  Workers() {
+    int want = (int)std::thread::hardware_concurrency();
+    if (const char* e = std::getenv("FLAME_DELAUNAY_THREADS")) want = std::atoi(e);
+    n_threads_ = std::max(1, std::min(want, 32));
+    for (int i = 1; i < n_threads_; ++i) pool_.emplace_back([this] { loop(); });
+  }
+  ~Workers() {
+    {
+      std::lock_guard<std::mutex> lk(mtx_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : pool_) t.join();
+  }
+  void work() {
+    for (;;) {
+      const int i = next_.fetch_add(1);
+      if (i >= n_jobs_) return;
+      (*job_)(i);
+      std::lock_guard<std::mutex> lk(mtx_);
+      if (--pending_ == 0) done_cv_.notify_all();
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mtx_);
+        cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
+        if (stop_) return;
+        seen = generation_;
+      }
+      work();
+    }
+  }
+  std::mutex call_mtx_, mtx_;
+  std::condition_variable cv_, done_cv_;
+  std::vector<std::thread> pool_;
+  const std::function<void(int)>* job_ = nullptr;
+  std::atomic<int> next_{0};
+  int n_jobs_ = 0, pending_ = 0, n_threads_ = 1;
+  uint64_t generation_ = 0;
+  bool stop_ = false;
+};
+
+
+// job(begin, end) over [0, n) in `parts` contiguous chunks
+inline void parallel_chunks(int64_t n, int parts, const std::function<void(int64_t, int64_t)>& job) {
+  parts = (int)std::max<int64_t>(1, std::min<int64_t>(parts, n));
+  Workers::get().run(parts, [&](int k) { job(n * k / parts, n * (k + 1) / parts); });
+}
+
+}  // namespace flame_hip
+
+#endif  // FLAME_AMD_HOST_WORKERS_HPP_

@@ -51,6 +51,7 @@ constexpr int kDualMinWavesPerCu = 0;  // auto: exchange through the XCD's L2 wh
 // x64-cycle sleep between publishing and the first neighbour poll (measured optimum, r01 sweep: he 6 at
 // <= 12 waves/CU, 10 above; tv is insensitive, shortest wins)
 constexpr int kPreSleepHe = 6, kPreSleepHeDense = 10, kPreSleepHeOneXcd = 4, kPreSleepTv = 2;
+constexpr int32_t kFeatDirectMax = 1 << 22;  // sync_graph: feature ids below this are looked up in a plain table (16 MB at most), others hashed
 constexpr size_t kErrBytes = 16 * sizeof(int);  // the flag word + what the first expired wait reports (report_expired)
 constexpr unsigned kMaxSpins = 1u << 20;  // bound of every neighbour wait in the persistent run (~1 s of polling bursts)
 
@@ -141,10 +142,14 @@ struct flame_nltgv2_ctx {
   bool have_graph = false;
   bool canon_valid = false, fused_valid = false, have_prev = false;
   DevBuf sp_v[9], sp_q[3], sync_init, sync_vmap, sync_emap, sync_need;  // sync_graph: spare state arrays, inputs, index maps
-  std::vector<int32_t> h_old_of_new, h_old_of_new_edge;
+  std::vector<int32_t> h_old_of_new, h_old_of_new_edge, h_old_edge_of_pair, h_first_pair_of_old, h_bucket_start, h_bucket_item, h_bucket_at;
   FlatMap feat_maps[3];     // [cur]: feature id -> vertex of the CURRENT graph (h_feat), kept from one sync to the next; the
   int feat_cur = 0;         // next sync fills the other one; [2]: scratch of a sync (new edges' duplicates)
   bool feat_map_valid = false;
+  std::vector<int32_t> feat_tab;     // the same map as a plain table id -> vertex (-1: absent) while the ids stay below kFeatDirectMax
+  std::vector<uint32_t> feat_stamp;  // duplicate check of a sync: the sync (feat_stamp_now) that last saw the id
+  uint32_t feat_stamp_now = 0;
+  bool feat_tab_valid = false;
   int parity = 0;
   uint64_t topo = 0, stamp = 0;
 

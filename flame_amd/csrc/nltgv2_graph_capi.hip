@@ -2,6 +2,10 @@
 // costs, export of x * graph_scale (see nltgv2_context.hpp).
 #include "nltgv2_context.hpp"
 
+#include <atomic>
+
+#include "host_workers.hpp"
+
 extern "C" {
 
 int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g) {
@@ -52,7 +56,7 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
   }
   ctx->h_feat.resize((size_t)V);
   for (int32_t v = 0; v < V; ++v) ctx->h_feat[(size_t)v] = v;  // default feature id = vertex index
-  ctx->feat_map_valid = false;
+  ctx->feat_map_valid = false, ctx->feat_tab_valid = false;
   ctx->canon_valid = true;
   ctx->fused_valid = false;
   ctx->have_prev = false;
@@ -96,73 +100,145 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
   if (rc) return rc;
   const int32_t Vo = ctx->L.V, Eo = ctx->L.E;
 
-  for (int32_t v = 0; v < V; ++v)
-    if (in->feat_id[v] < 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-  if (!ctx->feat_map_valid) {  // (after an upload / set_feature_ids; otherwise the map the previous sync built)
-    FlatMap& m = ctx->feat_maps[ctx->feat_cur];
-    m.reset((size_t)Vo);
-    for (int32_t v = 0; v < Vo; ++v) m.emplace((uint64_t)(uint32_t)ctx->h_feat[(size_t)v], v);
-    ctx->feat_map_valid = true;
-  }
-  const FlatMap& old_of_feat = ctx->feat_maps[ctx->feat_cur];
-  auto key = [](int32_t a, int32_t b) {
-    const uint32_t lo = (uint32_t)std::min(a, b), hi = (uint32_t)std::max(a, b);
-    return ((uint64_t)hi << 32) | lo;
-  };
+  // (the look-ups below -- ~V hash probes, ~E walks over a previous vertex's ~6 incident edges -- are independent of each
+  //  other and read-only: they run in chunks on the library's worker threads, host_workers.hpp; what depends on order, the
+  //  duplicate checks and "first of equal pairs wins", is done afterwards in one cheap sequential pass)
+  const int parts = V + E >= 8192 ? std::min(Workers::get().threads(), 8) : 1;
+  std::chrono::steady_clock::time_point tp[6];
+  tp[0] = std::chrono::steady_clock::now();
 
-  // vertices: new vertex -> its index in the previous graph (-1: new)
+  // vertices: new vertex -> its index in the previous graph (-1: new).  Feature ids are small non-negative counters in the
+  // reference (flame.cc feature ids grow by one per detection): while the largest id stays below kFeatDirectMax the
+  // id -> vertex map is a plain table (a probe is one load; ids arrive roughly in order, so it streams), beyond that a hash map.
   std::vector<int32_t>& old_of_new = ctx->h_old_of_new;
   old_of_new.assign((size_t)V, -1);
-  FlatMap& seen = ctx->feat_maps[ctx->feat_cur ^ 1];  // ... and the next sync's old_of_feat
-  seen.reset((size_t)V);
+  std::atomic<int> bad{0};
+  int32_t max_id = -1;
   for (int32_t v = 0; v < V; ++v) {
-    if (!seen.emplace((uint64_t)(uint32_t)in->feat_id[v], v).second) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // duplicate id
-    const int32_t* it = old_of_feat.find((uint64_t)(uint32_t)in->feat_id[v]);
-    if (it) old_of_new[(size_t)v] = *it;
+    if (in->feat_id[v] < 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+    max_id = std::max(max_id, in->feat_id[v]);
   }
+  for (int32_t id : ctx->h_feat) max_id = std::max(max_id, id);
+  const bool direct = max_id < kFeatDirectMax;
+  if (direct) {
+    if (ctx->feat_tab.size() <= (size_t)max_id) {
+      ctx->feat_tab.resize((size_t)max_id + 1 + (size_t)max_id / 2, -1);
+      ctx->feat_stamp.resize(ctx->feat_tab.size(), 0u);
+      ctx->feat_tab_valid = false;
+    }
+    if (!ctx->feat_tab_valid) {  // (after an upload / set_feature_ids / a frame that went through the hash map)
+      std::fill(ctx->feat_tab.begin(), ctx->feat_tab.end(), -1);
+      for (int32_t v = 0; v < Vo; ++v) ctx->feat_tab[(size_t)ctx->h_feat[(size_t)v]] = v;
+      ctx->feat_tab_valid = true;
+    }
+    const uint32_t stamp = ++ctx->feat_stamp_now;
+    if (stamp == 0u) std::fill(ctx->feat_stamp.begin(), ctx->feat_stamp.end(), 0u), ctx->feat_stamp_now = 1u;
+    for (int32_t v = 0; v < V; ++v) {
+      const size_t id = (size_t)in->feat_id[v];
+      if (ctx->feat_stamp[id] == ctx->feat_stamp_now) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // duplicate id
+      ctx->feat_stamp[id] = ctx->feat_stamp_now;
+      old_of_new[(size_t)v] = ctx->feat_tab[id];
+    }
+  } else {
+    if (!ctx->feat_map_valid) {  // (after an upload / set_feature_ids; otherwise the map the previous sync built)
+      FlatMap& m = ctx->feat_maps[ctx->feat_cur];
+      m.reset((size_t)Vo);
+      for (int32_t v = 0; v < Vo; ++v) m.emplace((uint64_t)(uint32_t)ctx->h_feat[(size_t)v], v);
+      ctx->feat_map_valid = true;
+    }
+    const FlatMap& old_of_feat = ctx->feat_maps[ctx->feat_cur];
+    parallel_chunks(V, parts, [&](int64_t v0, int64_t v1) {
+      for (int64_t v = v0; v < v1; ++v) {
+        const int32_t* it = old_of_feat.find((uint64_t)(uint32_t)in->feat_id[v]);
+        if (it) old_of_new[(size_t)v] = *it;
+      }
+    });
+    FlatMap& seen = ctx->feat_maps[ctx->feat_cur ^ 1];  // duplicate ids, and the next sync's old_of_feat
+    seen.reset((size_t)V);
+    for (int32_t v = 0; v < V; ++v)
+      if (!seen.emplace((uint64_t)(uint32_t)in->feat_id[v], v).second) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // duplicate id
+  }
+  tp[1] = std::chrono::steady_clock::now();
   // edges.  A surviving edge joins two surviving vertices: it is looked up in the previous graph's adjacency (the
   // host copy of the packed layout: ~6 incident edges per vertex, one cache line) instead of a hash table over all
-  // edges.  Survivors must come out in their PREVIOUS relative order (boost::edges() walks a std::list: erase keeps
-  // the order of the rest): they are met in triangulator order, so they are parked in a table indexed by the old
-  // edge id and read back in one pass -- no sort.
-  struct Keep { int32_t a, b; };
-  std::vector<Keep> keep_of_old((size_t)Eo, Keep{-1, -1});
+  // edges -- in chunks on the worker threads (host_workers.hpp): the look-ups are independent and read-only.  Of several
+  // triangulator edges that join the same two features the FIRST keeps the old edge (boost::edge() finds it, nothing is
+  // added for the others): an atomic minimum over the triangulator index per old edge.  Survivors must come out in their
+  // PREVIOUS relative order (boost::edges() walks a std::list: erase keeps the order of the rest): read back by old edge id
+  // in one pass -- no sort.
   std::vector<std::pair<int32_t, int32_t>> fresh;
-  fresh.reserve((size_t)E / 4 + 16);
-  int32_t n_keep = 0;
+  fresh.reserve((size_t)E);
   const std::vector<int32_t>& orow = ctx->L.row_ptr;
   const std::vector<uint32_t>& ohalf = ctx->L.half;
   const std::vector<int32_t>& onbr = ctx->L.half_nbr;
-  for (int32_t k = 0; k < E; ++k) {
-    const int32_t a = in->edges[2 * k], b = in->edges[2 * k + 1];
-    if (a < 0 || a >= V || b < 0 || b >= V || a == b) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-    const int32_t oa = old_of_new[(size_t)a], ob = old_of_new[(size_t)b];
-    int32_t e = -1;
-    bool same = true;  // the old edge runs oa -> ob
-    if (oa >= 0 && ob >= 0) {
+  std::vector<int32_t>& old_edge = ctx->h_old_edge_of_pair;  // per triangulator edge: the previous edge | orientation bit 31, -1 = none
+  std::vector<int32_t>& first_k = ctx->h_first_pair_of_old;  // per previous edge: the first triangulator edge that keeps it
+  old_edge.assign((size_t)E, -1);
+  first_k.assign((size_t)Eo, 0x7fffffff);
+  parallel_chunks(E, parts, [&](int64_t k0, int64_t k1) {
+    for (int64_t k = k0; k < k1; ++k) {
+      const int32_t a = in->edges[2 * k], b = in->edges[2 * k + 1];
+      if (a < 0 || a >= V || b < 0 || b >= V || a == b) {
+        bad.store(1);
+        return;
+      }
+      const int32_t oa = old_of_new[(size_t)a], ob = old_of_new[(size_t)b];
+      if (oa < 0 || ob < 0) continue;
       for (int32_t h = orow[(size_t)oa]; h < orow[(size_t)oa + 1]; ++h) {
         if (onbr[(size_t)h] == ob) {
-          e = (int32_t)(ohalf[(size_t)h] & ~kRoleBit);  // the first (lowest id) of possible parallel edges, as
-          same = (ohalf[(size_t)h] & kRoleBit) == 0u;   // boost::edge() on the list would find
+          // the first (lowest id) of possible parallel edges, as boost::edge() on the list would find; bit 31: the old edge
+          // runs ob -> oa
+          const int32_t e = (int32_t)(ohalf[(size_t)h] & ~kRoleBit);
+          old_edge[(size_t)k] = e | ((ohalf[(size_t)h] & kRoleBit) ? (int32_t)0x80000000u : 0);
+          int32_t cur = __atomic_load_n(&first_k[(size_t)e], __ATOMIC_RELAXED);
+          while ((int32_t)k < cur && !__atomic_compare_exchange_n(&first_k[(size_t)e], &cur, (int32_t)k, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+          }
           break;
         }
       }
     }
-    if (e >= 0) {
-      if (keep_of_old[(size_t)e].a >= 0) continue;  // the same pair again: boost::edge() finds the edge, nothing is added
-      keep_of_old[(size_t)e] = Keep{same ? a : b, same ? b : a};
-      ++n_keep;
-    } else {
-      fresh.emplace_back(a, b);
+  });
+  tp[2] = std::chrono::steady_clock::now();
+  if (bad.load()) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  for (int32_t k = 0; k < E; ++k)
+    if (old_edge[(size_t)k] == -1) fresh.emplace_back(in->edges[2 * k], in->edges[2 * k + 1]);
+  int32_t n_keep = 0;
+  for (int32_t o = 0; o < Eo; ++o) n_keep += first_k[(size_t)o] != 0x7fffffff;
+  tp[3] = std::chrono::steady_clock::now();
+  if (!fresh.empty()) {
+    // No parallel edges among the new ones either (boost::edge() finds the one just added): of several new edges between the
+    // same two vertices the first stays.  The edges are bucketed by their lower vertex (a counting sort: two streaming passes;
+    // a vertex has ~3 of them), equal pairs found inside a bucket, the later ones dropped in place -- no hashing.
+    std::vector<int32_t>& start = ctx->h_bucket_start;
+    std::vector<int32_t>& item = ctx->h_bucket_item;  // (higher vertex, index into fresh) pairs, bucket by bucket
+    start.assign((size_t)V + 1, 0);
+    item.resize(2 * fresh.size());
+    for (const auto& f : fresh) start[(size_t)std::min(f.first, f.second) + 1]++;
+    for (int32_t v = 0; v < V; ++v) start[(size_t)v + 1] += start[(size_t)v];
+    {
+      std::vector<int32_t>& at = ctx->h_bucket_at;
+      at.assign(start.begin(), start.end() - 1);
+      for (size_t i = 0; i < fresh.size(); ++i) {
+        const int32_t lo = std::min(fresh[i].first, fresh[i].second), hi = std::max(fresh[i].first, fresh[i].second);
+        const int32_t p = at[(size_t)lo]++;
+        item[2 * (size_t)p] = hi, item[2 * (size_t)p + 1] = (int32_t)i;
+      }
     }
-  }
-  if (!fresh.empty()) {  // no parallel edges among the new ones either (boost::edge() finds the one just added)
-    FlatMap& dup = ctx->feat_maps[2];
-    dup.reset(fresh.size());
-    size_t n = 0;
-    for (const auto& f : fresh)
-      if (dup.emplace(key(in->feat_id[f.first], in->feat_id[f.second]), 1).second) fresh[n++] = f;
-    fresh.resize(n);
+    size_t dropped = 0;
+    for (int32_t v = 0; v < V; ++v)
+      for (int32_t i = start[(size_t)v] + 1; i < start[(size_t)v + 1]; ++i)      // (a bucket holds its edges in list order)
+        for (int32_t j = start[(size_t)v]; j < i; ++j)
+          if (item[2 * (size_t)j] == item[2 * (size_t)i] && fresh[(size_t)item[2 * (size_t)j + 1]].first >= 0) {
+            fresh[(size_t)item[2 * (size_t)i + 1]].first = -1;  // the same pair as an earlier new edge
+            ++dropped;
+            break;
+          }
+    if (dropped) {
+      size_t n = 0;
+      for (const auto& f : fresh)
+        if (f.first >= 0) fresh[n++] = f;
+      fresh.resize(n);
+    }
   }
   const int32_t En = (int32_t)((size_t)n_keep + fresh.size());
   std::vector<int32_t> src((size_t)En), dst((size_t)En);
@@ -170,9 +246,11 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
   old_of_new_edge.assign((size_t)En, -1);
   int32_t e = 0;
   for (int32_t o = 0; o < Eo; ++o) {
-    const Keep& kp = keep_of_old[(size_t)o];
-    if (kp.a < 0) continue;
-    src[(size_t)e] = kp.a, dst[(size_t)e] = kp.b;
+    const int32_t k = first_k[(size_t)o];
+    if (k == 0x7fffffff) continue;
+    const int32_t a = in->edges[2 * k], b = in->edges[2 * k + 1];
+    const bool same = old_edge[(size_t)k] >= 0;  // the old edge runs old(a) -> old(b): it keeps that orientation
+    src[(size_t)e] = same ? a : b, dst[(size_t)e] = same ? b : a;
     old_of_new_edge[(size_t)e] = o;
     ++e;
   }
@@ -181,6 +259,10 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
     ++e;
   }
   const auto t1 = std::chrono::steady_clock::now();
+  if (trace) {
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::fprintf(stderr, "[flame_nltgv2] sync_graph maps: settle %.3f, vertices %.3f, edge look-ups %.3f (%d chunks), new-edge list %.3f, order + duplicates %.3f ms\n", ms(t0, tp[0]), ms(tp[0], tp[1]), ms(tp[1], tp[2]), parts, ms(tp[2], tp[3]), ms(tp[3], t1));
+  }
 
   // New topology + the frame's inputs up, state gathered on the device out of the previous arrays into spare ones,
   // which then take their place.
@@ -234,8 +316,15 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     std::fprintf(stderr, "[flame_nltgv2] sync_graph: index maps %.3f ms, tables + upload + device gather %.3f ms\n", ms(t0, t1), ms(t1, t2));
   }
+  if (direct) {  // the table follows the graph: the previous graph's ids out, this one's in
+    for (int32_t id : ctx->h_feat) ctx->feat_tab[(size_t)id] = -1;
+    for (int32_t v = 0; v < V; ++v) ctx->feat_tab[(size_t)in->feat_id[v]] = v;
+    ctx->feat_map_valid = false;  // (the hash maps no longer describe the current graph)
+  } else {
+    ctx->feat_cur ^= 1;  // (the map filled above is of the graph that stands now)
+    ctx->feat_tab_valid = false;
+  }
   ctx->h_feat.assign(in->feat_id, in->feat_id + V);
-  ctx->feat_cur ^= 1;  // (the map filled above is of the graph that stands now)
   ctx->canon_valid = true;
   ctx->fused_valid = false;
   ctx->have_prev = false;
@@ -300,7 +389,7 @@ int flame_nltgv2_set_feature_ids(flame_nltgv2_ctx* ctx, const int32_t* feat_id) 
   for (int32_t v = 0; v < ctx->L.V; ++v)
     if (feat_id[v] < 0 || !seen.emplace((uint64_t)(uint32_t)feat_id[v], v).second) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
   ctx->h_feat.assign(feat_id, feat_id + ctx->L.V);
-  ctx->feat_map_valid = false;
+  ctx->feat_map_valid = false, ctx->feat_tab_valid = false;
   return FLAME_NLTGV2_OK;
 }
 
