@@ -619,19 +619,20 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
       // vcc = lanes still waiting.  One statement for all pacing variants (two scalar flags), and the common exit falls
       // straight through into the step: the instructions after the last record's arrival are the ones that count.
       unsigned cnt, keep, pend_lo, tagv, tagf, gapk;
-      unsigned long long pnarrow;
+      unsigned long long pnarrow, exec_saved;  // (EXEC is saved and put back by the statement itself, not assumed to be all ones)
       const unsigned own_slot = dst + 16u * (unsigned)lane;
       // (pacing: bit 0 = pause between rounds, bits 4..7 = its length - 1 in s_sleep 1 units, bit 1 = narrowed re-loads)
       const unsigned f_sleep = (poll_gap & 1) ? 1u + (((unsigned)poll_gap >> 4) & 15u) : 0u, f_narrow = (unsigned)((poll_gap >> 1) & 1);
 #define PV_POLL_U                                                                                         \
-  asm volatile("s_mov_b32 %[keep], m0\n\t"                                                              \
+  asm volatile("s_mov_b64 %[ex], exec\n\t"                                                             \
+               "s_mov_b32 %[keep], m0\n\t"                                                              \
                "s_mov_b32 m0, %[dst]\n\t"                                                               \
                "s_mov_b32 %[cnt], 0\n\t"                                                                \
                "s_mov_b64 %[pn], %[fm]\n\t"                                                             \
                "1:\n\t"                                                                                 \
                "s_mov_b64 exec, %[pn]\n\t"                                                              \
                "global_load_lds_dwordx4 %[src], off sc1\n\t"                                            \
-               "s_mov_b64 exec, -1\n\t"                                                                 \
+               "s_mov_b64 exec, %[ex]\n\t"                                                              \
                "s_mov_b32 %[k], %[fs]\n\t"                                                             \
                "4:\n\t"                                                                                 \
                "s_cmp_eq_u32 %[k], 0\n\t"                                                               \
@@ -658,7 +659,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
                "s_or_b32 %[pl], %[pl], vcc_hi\n\t"                                                      \
                "s_mov_b32 m0, %[keep]"                                                                   \
                : [keep] "=&s"(keep), [cnt] "=&s"(cnt), [pl] "=&s"(pend_lo), [nb] "=&v"(nbv), [t] "=&v"(tagv), \
-                 [t2] "=&v"(tagf), [pn] "=&s"(pnarrow), [k] "=&s"(gapk)                                     \
+                 [t2] "=&v"(tagf), [pn] "=&s"(pnarrow), [k] "=&s"(gapk), [ex] "=&s"(exec_saved)            \
                : [src] "v"(src), [dst] "s"(dst), [ra] "v"(rd_nbr), [fa] "v"(own_slot), [tag] "s"(s), [fm] "s"(fetch_mask), \
                  [fs] "s"(f_sleep), [fn] "s"(f_narrow)                                                     \
                : "vcc", "scc", "memory")
@@ -751,7 +752,9 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
       // (nltgv2_pack.hpp, WaveFit): from shift 8 on ONE mask -- those heads and the lanes that only serve as sources -- does
       // for all shifts, the lanes past such a vertex's last edge being idle (-0.0 contributions); three exits by the patch's
       // largest degree instead of one per shift (a branch costs 16 cycles, a shift 26: tools/ripple_bench)
-      asm volatile("s_nop 1\n\t"
+      unsigned long long exec_saved;  // (the masks below narrow EXEC; it is put back as it was found, not assumed to be all ones)
+      asm volatile("s_mov_b64 %[ex], exec\n\t"
+                   "s_nop 1\n\t"
                    PV_RM(1, m1) PV_RM(2, m2) PV_RM(3, m3) PV_RM(4, m4) PV_RM(5, m5) PV_RM(6, m6) PV_RM(7, m7)
                    "s_cmp_le_u32 %[md], 8\n\t"
                    "s_cbranch_scc1 9f\n\t"
@@ -763,8 +766,8 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
                    "s_cbranch_scc1 9f\n\t"
                    PV_ADDS(12) PV_ADDS(13) PV_ADDS(14) PV_ADDS(15)
                    "9:\n\t"
-                   "s_mov_b64 exec, -1"
-                   : [X] "+v"(X), [W1] "+v"(W1), [W2] "+v"(W2)
+                   "s_mov_b64 exec, %[ex]"
+                   : [X] "+v"(X), [W1] "+v"(W1), [W2] "+v"(W2), [ex] "=&s"(exec_saved)
                    : [cx] "v"(cx), [a1] "v"(a12.x), [a2] "v"(a12.y), [b1] "v"(b12.x), [b2] "v"(b12.y), [md] "s"(stride),
                      [m1] "s"(rm1), [m2] "s"(rm2), [m3] "s"(rm3), [m4] "s"(rm4), [m5] "s"(rm5), [m6] "s"(rm6), [m7] "s"(rm7), [m8] "s"(rm8)
                    : "scc");

@@ -50,20 +50,36 @@ class SolverLoop {
   SolverLoop& operator=(const SolverLoop&) = delete;
 
   void start() {
+    std::thread dead;
+    {
+      std::lock_guard<std::mutex> lk(state_mtx_);
+      if (thread_.joinable() && !exited_) return;  // already running
+      dead.swap(thread_);                         // a thread that ended on its own (an error: see error()) is joined and replaced
+    }
+    if (dead.joinable()) dead.join();
     std::lock_guard<std::mutex> lk(state_mtx_);
     if (thread_.joinable()) return;
     stop_.store(false);
+    exited_ = false;
+    error_.clear();
     thread_ = std::thread([this] { run(); });
   }
-  void stop() {  // idempotent; returns after the thread has exited (at most one round later)
+  // Idempotent; returns after the thread has exited (at most one round later).  May be called with the graph mutex held: the
+  // loop never blocks on that mutex (it polls it, see run()), so the join cannot deadlock against the caller.
+  void stop() {
+    std::thread t;
     {
       std::lock_guard<std::mutex> lk(state_mtx_);
       stop_.store(true);
+      t.swap(thread_);
     }
     cv_.notify_all();
-    if (thread_.joinable()) thread_.join();
+    if (t.joinable()) t.join();
   }
-  bool running() const { return thread_.joinable() && !stop_.load(); }
+  bool running() const {
+    std::lock_guard<std::mutex> lk(state_mtx_);
+    return thread_.joinable() && !exited_ && !stop_.load();
+  }
 
   // Caller holds graph_mtx: the graph was edited (vertices, edges, data terms); the loop re-uploads it before iterating on.
   void markDirty() {
@@ -132,7 +148,14 @@ class SolverLoop {
           have = dev_.generation() == dirty && uploaded_once_;
         }
         if (!have) {  // (re)upload under the caller's mutex: nobody edits the graph meanwhile
-          std::lock_guard<GraphMutex> g_lk(*graph_mtx_);
+          // (polled, never blocked on: a caller may hold the graph mutex while it stop()s -- or destroys -- this loop)
+          std::unique_lock<GraphMutex> g_lk(*graph_mtx_, std::try_to_lock);
+          while (!g_lk.owns_lock()) {
+            if (stop_.load()) break;
+            std::this_thread::yield();
+            g_lk.try_lock();
+          }
+          if (!g_lk.owns_lock()) break;  // told to stop while waiting for the graph
           std::lock_guard<std::mutex> dev_lk(dev_mtx_);
           {
             std::lock_guard<std::mutex> lk(state_mtx_);
@@ -167,6 +190,8 @@ class SolverLoop {
       error_ = e.what();
       stop_.store(true);
     }
+    std::lock_guard<std::mutex> lk(state_mtx_);
+    exited_ = true;
   }
   size_t dev_vertices() {
     flame_nltgv2_info info;
@@ -187,6 +212,7 @@ class SolverLoop {
   std::atomic<int> callers_waiting_{0};
   uint64_t dirty_generation_ = 1;  // the graph as handed to the constructor is "edit 1": uploaded by the first round
   bool uploaded_once_ = false;
+  bool exited_ = false;            // the thread function has returned (state_mtx_)
   std::string error_;
 };
 

@@ -164,6 +164,31 @@ int main() {
                 (unsigned long long)its, ms);
     fails += !ok;
   }
+  {  // ---- (2b) stop() under the graph mutex, restart, state queries (advisor r02: the join used to deadlock against a loop
+     //      blocked on that mutex; running() raced with start(); a loop that had ended could not be started again) ---------
+    flame_hip::SolverLoop<flame_hip::FlatGraph> loop(&graph, &graph_mtx, params, 10);
+    bool ok = !loop.running();
+    loop.start();
+    ok = ok && loop.running() && wait_for([&] { return loop.iterations() >= 50; }, 3000);
+    const auto t0 = std::chrono::steady_clock::now();
+    {
+      std::lock_guard<std::recursive_mutex> lock(graph_mtx);  // the caller edits ...
+      graph.vertices[0].data_term += 0.01f;
+      loop.markDirty();                                        // ... the loop now wants the mutex for its re-upload ...
+      std::this_thread::sleep_for(std::chrono::milliseconds(20));
+      loop.stop();                                             // ... and is stopped while the caller still holds it
+    }
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ok = ok && ms < 1000.0 && !loop.running();
+    const uint64_t before = loop.iterations();
+    loop.start();  // a stopped loop starts again
+    ok = ok && loop.running() && wait_for([&] { return loop.iterations() >= before + 50; }, 3000);
+    loop.stop();
+    loop.stop();   // idempotent
+    ok = ok && !loop.running() && loop.error().empty();
+    std::printf("%-44s %s (stop under the mutex: %.1f ms)\n", "stop() with the graph mutex held, restart", ok ? "ok" : "FAIL", ms);
+    fails += !ok;
+  }
   {  // ---- (3) DeviceGraph::download refuses a graph that is not the uploaded one -----------------------------------------
     dgraph::DeviceGraph dev;
     dev.upload(graph, 5);
