@@ -79,7 +79,7 @@ def next_frame(rng, feat_id, pos, data, next_id):
     pos[:, 0] = np.clip(pos[:, 0], 1, W - 1)
     pos[:, 1] = np.clip(pos[:, 1], 1, H - 1)
     data = (data + rng.normal(0, 0.01, data.shape)).astype(np.float32)
-    n_new = int(0.08 * len(keep))
+    n_new = int((~keep).sum())  # as many new features as were lost: the graph keeps its size
     new_pos = np.stack([rng.random(n_new) * (W - 8) + 4, rng.random(n_new) * (H - 8) + 4], 1).astype(np.float32)
     new_data = (0.5 + rng.random(n_new)).astype(np.float32)
     order = rng.permutation(len(feat_id) + n_new)
