@@ -177,12 +177,11 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
                         /*rowpack_max_patches=*/ctx->opt_persistent == 4 ? 0x7fffffff : kPvDensePerCu * ctx->prop.multiProcessorCount);
   if (rc) return fail(ctx, rc);
   // Row packing costs ~15 % more waves than lanes back to back.  It pays where the patch-per-wave kernel runs them; a layout
-  // that turns out too large for that kernel (more patches than the estimate, or a vertex of more than 16 edges, whose
-  // instance of the kernel keeps 12 patches per CU) is better off back to back, for the lane-per-half-edge form.
+  // that turns out too large for that kernel (more patches than the estimate) is better off back to back, for the
+  // lane-per-half-edge form.
   // (FLAME_NLTGV2_OPT_PERSISTENT 4 -- the patch-per-wave form asked for by name -- keeps the row-packed layout whatever the
   //  size: the kernel then runs it as groups of whole components)
-  if (ctx->L.wg_ok && ctx->L.wg_rowpack && ctx->opt_persistent != 4 &&
-      ctx->L.wg_count > (ctx->L.wg_slab_slots > 0 ? 4 * pv_real_waves_per_simd(2, false) : kPvDensePerCu) * ctx->prop.multiProcessorCount) {
+  if (ctx->L.wg_ok && ctx->L.wg_rowpack && ctx->opt_persistent != 4 && ctx->L.wg_count > kPvDensePerCu * ctx->prop.multiProcessorCount) {
     rc = build_layout(g, &ctx->L, /*host_expand=*/false, /*rowpack=*/false, 0);
     if (rc) return fail(ctx, rc);
   }

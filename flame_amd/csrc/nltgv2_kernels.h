@@ -162,7 +162,7 @@ struct SyncArgs {
 };
 int launch_sync_state(const SyncArgs& a, hipStream_t s);
 int pv_patches_per_cu(const FusedArgs& a, bool verify);
-int pv_real_waves_per_simd(int layout, bool verify_or_probe);
+int pv_real_waves_per_simd(bool verify_or_probe);
 const void* persistent_tv_kernel(bool static_in_lds, int waves_per_block, unsigned* lds_bytes);  // nltgv2_persistent_tv.hip
 // device-side expansion of the layout arrays (nltgv2_layout.hip)
 int launch_build_sell(const CanonArgs& c, const FusedArgs& a, const int32_t* iperm, hipStream_t s);

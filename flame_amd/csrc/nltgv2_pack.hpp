@@ -100,8 +100,8 @@ struct PackedLayout {
   // Row-packed patches (wg_rowpack): a vertex's lanes lie inside one 16-lane row of the wave (the walk fits each vertex into
   // the first of the wave's four rows that has room; one of more than 8 edges gets a row to itself), which is what lets the
   // kernel add a vertex's contributions up across lanes with DPP row shifts instead of through LDS.  A vertex of more than 16
-  // edges starts a patch of the other kind (lanes back to back, kWgSlab in its info word; the LDS-slab accumulation).  wg_vfirst[i] = first lane, within its patch,
-  // of the i-th vertex of the walk (either way).
+  // edges starts a patch at lane 0 and fills whole rows (the kernel continues its sum row after row).  wg_vfirst[i] = first
+  // lane, within its patch, of the i-th vertex of the walk (either way).
   bool wg_rowpack = false;
   std::vector<uint8_t> wg_vfirst;
   std::vector<int32_t> comp_wg;        // [n_comp+1] first patch of each component
@@ -133,10 +133,10 @@ struct WaveFit {
   bool rows = false;                                     // ... and so is the current wave
   int32_t fill = kWave;                                  // back to back: lanes used
   int32_t row[4] = {16, 16, 16, 16};                      // row-packed: lanes used per row
-  // A new wave, for a vertex of `need` lanes first.  A vertex of more than 16 edges cannot lie inside a row: the wave it
-  // starts is filled back to back (and runs the LDS-slab accumulation), the next wave is row-packed again.
+  // A new wave, for a vertex of `need` lanes first.
   void open(int32_t need) {
-    rows = rowpack && need <= 16;
+    (void)need;
+    rows = rowpack;
     fill = 0;
     row[0] = row[1] = row[2] = row[3] = 0;
   }
@@ -148,7 +148,13 @@ struct WaveFit {
       fill += need;
       return f;
     }
-    if (need > 16) return -1;
+    if (need > 16) {
+      // a vertex of more than 16 edges starts a wave of its own at lane 0 and fills ceil(need / 16) whole rows: its sum runs row
+      // after row (k_persistent_pv: the head of row r takes the running sums over from row r - 1); the other rows are packed as usual
+      if (row[0] | row[1] | row[2] | row[3]) return -1;
+      for (int32_t r = 0; r < (need + 15) / 16; ++r) row[r] = 16;
+      return 0;
+    }
     for (int32_t r = 0; r < 4; ++r) {
       if (need > 8) {  // a vertex of more than 8 edges gets a row to itself: its shifts 8.. then run over lanes of its own or
         if (row[r] != 0) continue;  // idle ones only, and need no mask of their own (k_persistent_pv)

@@ -318,16 +318,14 @@ k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd
 //              consumed s.  A vertex is published to memory only if another patch reads it.
 //   step       Straight-line code: the per-role selects of the dual update are folded into signed per-lane constants
 //              (exact: IEEE negation, a*(-b) == -(a*b)), the w1/w2 halves run as packed-f32 pairs.  The ordered
-//              accumulation (cc:120-142: ascending edge id) comes in two forms, by the patch's layout:
-//              row-packed patches (a vertex's lanes inside one 16-lane row; the default wherever this kernel runs) --
-//              the sum runs across the lanes towards the vertex's first lane, which alone holds its state: shift j adds
-//              the contribution of lane first + j with the DPP row shift of a plain add, EXEC masks (moved in by the scalar
+//              accumulation (cc:120-142: ascending edge id) runs across the lanes of a vertex towards its first lane, which
+//              alone holds its state (patches are row-packed: a vertex's lanes inside one 16-lane row): shift j adds the
+//              contribution of lane first + j with the DPP row shift of a plain add, EXEC masks (moved in by the scalar
 //              unit, computed once per launch) say which heads a shift may still write; the other lanes take (x_bar, w_bar)
 //              of their vertex from the record its head leaves in LDS.  ~26 cycles per shift, no LDS in the hand-off path.
-//              Back-to-back patches (those that hold a vertex of more than 16 edges) -- EVERY lane of the
-//              vertex adds up an LDS slab of `stride` contribution slots per vertex (the patch's largest degree rounded up to
-//              4, at least 8) whose unused slots hold -0.0f (x + -0.0f == x for every x): all lanes of a vertex hold
-//              bit-identical state at all times, ~70 cycles per slot.
+//              A vertex of more than 16 edges starts its patch at lane 0 and fills whole rows: after row 0 the running sums
+//              move (v_readlane / v_writelane) to the first lane of the next row, which adds its own row the same way, and
+//              back to lane 0 at the end -- the same additions in the same order, ~500 cycles per further row.
 //   hand-off   Between a record arriving and the next one leaving every instruction costs ~5 cycles, needed or not, and
 //              a taken branch ~16: the NaN check, the prev copies and the LDS record come after the publish, the record
 //              verification is a template flag, the wait is one statement whose common exit falls through (DESIGN.md 4,
@@ -335,7 +333,7 @@ k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd
 // Protocol (tags, two parity buffers, remote / XCD-local copies chosen from the true XCC ids, bounded waits,
 // transactional outputs) is that of k_persistent_he.
 // ------------------------------------------------------------------------------------------------
-constexpr unsigned kWgTailBit = 1u << 24, kWgActiveBit = 1u << 25, kWgValidBit = 1u << 26, kWgPublishBit = 1u << 27, kWgHeadBit = 1u << 28;
+constexpr unsigned kWgActiveBit = 1u << 25, kWgValidBit = 1u << 26, kWgPublishBit = 1u << 27, kWgHeadBit = 1u << 28;
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 
@@ -359,11 +357,7 @@ __device__ __forceinline__ void report_expired(int* err, int which, int wg, int 
   }
 }
 
-// LAYOUT: 1 = every patch row-packed, DPP accumulation; 2 = row-packed with back-to-back patches among them (where a vertex has
-// more than 16 edges): both schemes compiled in, chosen per patch -- a separate instance because carrying the slab code costs
-// the all-row-packed case 3-5 % (registers, code layout; measured).  (Layouts that are not row-packed at all -- too large for
-// this kernel -- run in the lane-per-half-edge form.)
-template <bool PROBE, int LAYOUT, bool VERIFY>
+template <bool PROBE, bool VERIFY>
 __global__ void __launch_bounds__(64)
 k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, const int lcap, const int slab_slots,
                 const int32_t* __restrict__ wg_slot, const int32_t* __restrict__ wg_vid,
@@ -418,22 +412,11 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   if (unsigned* const pg = tail->progress) {               // (trace runs only) when this patch started, in us of the 100 MHz clock
     if (lane == 0) pg[n_wgs + (wg - wg_begin)] = (unsigned)(wall_clock64() / 100u) | 1u;
   }
-  // RIPPLE layouts: a patch that holds a vertex of more than 16 edges is laid out back to back and accumulates through the
-  // LDS slab like the other kernel variant does for every patch (wave-uniform)
-  static_assert(LAYOUT == 1 || LAYOUT == 2, "row-packed layouts only");
-  constexpr bool RIPPLE = true;
-  const bool slab = LAYOUT == 2 && (count_flags & (1 << 17)) != 0;
-  // Contribution slab: `stride` slots per vertex of this patch (its largest degree rounded up to a multiple of 4, at least 8); the
-  // slots a vertex does not use hold -0.0f for the whole run, so the accumulation needs no predication.
+  // the patch's largest degree: how many shifts the ordered accumulation runs (above 16: over how many rows)
   const int stride = wg_info[4 * wg + 3];
-  // In LDS a vertex's 16-byte slots are stride + 1 apart: an odd distance, so that the ~10 vertices of a wave, which read
-  // their slabs with the same instruction, start in different banks (a multiple of 8 slots apart they would all collide).
-  const int strideA = stride + 1;
-  // LDS map, float4 units: [rec area 0: lcap local + 64 fetch slots | rec area 1 | slabA slab_slots | spare 64 | slabC | spare]
+  // LDS map, float4 units: [rec area 0: lcap local + 64 fetch slots | rec area 1 | slab_slots (unused: 0) | spare 64]
   const int rec_stride = lcap + T;
-  const int o_slabA = 2 * rec_stride, o_ovfA = o_slabA + slab_slots, o_slabC = o_ovfA + T;
-  float* const ldsf = reinterpret_cast<float*>(lds);
-  const int f_slabC = 4 * o_slabC, f_ovfC = f_slabC + slab_slots;
+  const int o_ovfA = 2 * rec_stride + slab_slots;
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(xbuf);
   // Placed records (nltgv2_layout.hip, "record placement"): the remote copy of a record that another XCD reads lives in a
   // pool of 4 KB pages instead of the linear buffer, on a page whose home memory channel is close to both XCDs (the
@@ -453,22 +436,20 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   const int pv = wg_vid[hl];
   const int nbr_code = wg_nbr[hl];
   const int frid = (lane < n_fetch) ? wg_fetch[hl] : -1;  // the foreign record this lane fetches
-  const int first = (int)(meta & 63u), loc = (int)((meta >> 13) & 2047u);
-  const bool is_tail = (meta & kWgTailBit) != 0u, active = (meta & kWgActiveBit) != 0u;
+  const int loc = (int)((meta >> 13) & 2047u);
+  const bool active = (meta & kWgActiveBit) != 0u;
   const bool valid = (meta & kWgValidBit) != 0u, publishes = (meta & kWgPublishBit) != 0u;
-  // The lane that holds a vertex's state, publishes its record and writes it back: the LAST lane of the vertex where every
-  // lane keeps the state (slab form), the FIRST where the sum runs across the lanes towards it (RIPPLE: row-packed patches).
-  const bool state_lane = slab ? is_tail : (meta & kWgHeadBit) != 0u;
-  // RIPPLE: a head takes part in shift j while j < its degree; the other lanes of a vertex only serve as sources, and a lane
+  // The lane that holds a vertex's state, publishes its record and writes it back: its FIRST (the sum runs across the lanes
+  // towards it).  A head takes part in shift j while j < its degree; the other lanes of a vertex only serve as sources, and a lane
   // without a half-edge is disabled altogether (a DPP read of a disabled lane leaves the destination as it is)
+  const bool state_lane = (meta & kWgHeadBit) != 0u;
   const unsigned degx = (meta & kWgHeadBit) ? ((meta >> 6) & 127u) : (active ? 255u : 0u);
-  // ... as a destination; the lanes written by shift j, for the shifts every patch runs (RIPPLE)
+  // ... as a destination; the lanes written by shift j, for the shifts every patch runs
   const unsigned long long rm1 = __ballot(degx > 1u), rm2 = __ballot(degx > 2u), rm3 = __ballot(degx > 3u), rm4 = __ballot(degx > 4u),
                            rm5 = __ballot(degx > 5u), rm6 = __ballot(degx > 6u), rm7 = __ballot(degx > 7u), rm8 = __ballot(degx > 8u);
   // whose record this lane waits for: its half-edge's other end; a lane without a half-edge looks at its own vertex's
   // record, a lane without a vertex at the patch's first vertex -- both carry the step's tag from the start
   const int nbr_idx = active ? ((nbr_code < 0) ? lcap + (nbr_code & 0x7fffffff) : nbr_code) : (valid ? loc : 0);
-  const int pos = lane - first;
 
   int4 rec = make_int4(0, 0, 0, 0);
   float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -509,17 +490,9 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   bool torn = false;
 
   const int my_off = (rid_base + loc) << 4;
-  // (a lane without a half-edge writes to its own spare entry, which nobody reads)
-  const int wrA = active ? o_slabA + loc * strideA + pos : o_ovfA + lane;
-  const int wrC = active ? f_slabC + loc * stride + pos : f_ovfC + lane;
-  const int rdA = o_slabA + loc * strideA, rdC4 = (f_slabC + loc * stride) >> 2;
+  // (a lane without a vertex writes its record to a spare entry of its own, which nobody reads)
   const int rec_w = valid ? loc : o_ovfA + lane, rec_wstride = valid ? rec_stride : 0;
 
-  if (slab)
-    for (int i = lane; i < slab_slots; i += T) {
-      lds[o_slabA + i] = make_float4(-0.0f, -0.0f, -0.0f, -0.0f);
-      ldsf[f_slabC + i] = -0.0f;
-    }
   // fetch slots: tag 0 is never a live tag
   lds[lcap + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
   lds[rec_stride + lcap + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -599,10 +572,10 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   // of the parity published.
   auto step = [&](const unsigned s, const unsigned rd_nbr, const unsigned dst, const int wr_rec, const int fetch_area, const int it,
                   const char* const src2, char* const pub2, const int rd_rec) {
-    // RIPPLE: only the head of a vertex computes its state; the other lanes take (x_bar, w_bar) of their vertex from the
+    // Only the head of a vertex computes its state; the other lanes take (x_bar, w_bar) of their vertex from the
     // record the head left in LDS at the end of the previous step (read here, ahead of the wait: off the critical path)
     float4 own = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (RIPPLE) own = lds[rd_rec];
+    own = lds[rd_rec];
     const int so_out = (int)((s + 1u) & (kPar - 1)) * par;  // (wave-uniform)
     // two buffers: the step's parity is fixed at the call site (src2: where this lane polls, pub2: where it publishes)
     const char* const src = src2;
@@ -703,7 +676,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
     }
     unsigned pr_t1 = 0;
     if (PROBE) pr_t1 = (unsigned)clock64();
-    if (RIPPLE) xb = own.x, wb12 = v2f_t{own.y, own.z};
+    xb = own.x, wb12 = v2f_t{own.y, own.z};
     // ---- dual update of this half-edge's private q copy (cc:99-110) ------------------------------
     const v2f_t nbw = {nbv.y, nbv.z};
     const float d0 = xb - nbv.x;
@@ -729,7 +702,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
     b12 = is_target ? v2f_t{-0.0f, -0.0f} : b12;
     float X = x;
     v2f_t Wa = w12;
-    if (!slab) {
+    {
       // ---- ordered accumulation across the lanes of the vertex, towards its head ------------------------------------
       // The head (lane `first`) starts with (x + c_0, (w + a_0) + b_0) of its own half-edge; shift j = 1, 2, ... adds the
       // contribution of lane first + j, taken with a DPP row shift (the patch is row-packed: a vertex's lanes share a 16-lane
@@ -737,7 +710,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
       // would pick up the next vertex's lanes), the other lanes compute values nobody reads; a lane without a half-edge is
       // disabled (a DPP read of a disabled lane leaves the destination as it is).  The masks are computed once per launch and
       // moved to EXEC by the scalar unit (a v_cmpx per shift stalls the DPP adds behind it: +22 cycles per shift).  ~26 cycles
-      // per shift against ~70 per slot of the LDS slab (tools/ripple_bench.hip: 264 vs 580 cycles for 8 contributions).
+      // per shift (tools/ripple_bench.hip: 264 cycles for 8 contributions; an LDS slab read back by every lane took 580).
       float W1 = (w12.x + a12.x) + b12.x, W2 = (w12.y + a12.y) + b12.y;
       X = x + cx;
 #define PV_ADDS(J)                                                                                    \
@@ -747,12 +720,42 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   "v_add_f32_dpp %[W1], %[b1], %[W1] row_shl:" #J " row_mask:0xf bank_mask:0xf\n\t"                    \
   "v_add_f32_dpp %[W2], %[b2], %[W2] row_shl:" #J " row_mask:0xf bank_mask:0xf\n\t"
 #define PV_RM(J, M) "s_mov_b64 exec, %[" #M "]\n\t" PV_ADDS(J)
+#define PV_ROW(L)                                                                                     \
+  "s_nop 1\n\t"                                                                                       \
+  "v_readlane_b32 %[s0], %[X], 0\n\t"                                                                 \
+  "v_readlane_b32 %[s1], %[W1], 0\n\t"                                                                \
+  "v_readlane_b32 %[s2], %[W2], 0\n\t"                                                                \
+  "s_nop 3\n\t"                                                                                       \
+  "v_writelane_b32 %[X], %[s0], " #L "\n\t"                                                           \
+  "v_writelane_b32 %[W1], %[s1], " #L "\n\t"                                                          \
+  "v_writelane_b32 %[W2], %[s2], " #L "\n\t"                                                          \
+  "s_sub_u32 %[s0], %[md], " #L "\n\t"                                                                \
+  "s_min_u32 %[s0], %[s0], 16\n\t"                                                                    \
+  "s_bfm_b64 exec, %[s0], " #L "\n\t"                                                                 \
+  "s_nop 4\n\t"                                                                                       \
+  "v_add_f32 %[X], %[X], %[cx]\n\t"                                                                   \
+  "v_add_f32 %[W1], %[W1], %[a1]\n\t"                                                                 \
+  "v_add_f32 %[W2], %[W2], %[a2]\n\t"                                                                 \
+  "v_add_f32 %[W1], %[W1], %[b1]\n\t"                                                                 \
+  "v_add_f32 %[W2], %[W2], %[b2]\n\t"                                                                 \
+  "s_nop 1\n\t"                                                                                       \
+  PV_ADDS(1) PV_ADDS(2) PV_ADDS(3) PV_ADDS(4) PV_ADDS(5) PV_ADDS(6) PV_ADDS(7) PV_ADDS(8)              \
+  PV_ADDS(9) PV_ADDS(10) PV_ADDS(11) PV_ADDS(12) PV_ADDS(13) PV_ADDS(14) PV_ADDS(15)                   \
+  "s_nop 1\n\t"                                                                                       \
+  "v_readlane_b32 %[s0], %[X], " #L "\n\t"                                                            \
+  "v_readlane_b32 %[s1], %[W1], " #L "\n\t"                                                           \
+  "v_readlane_b32 %[s2], %[W2], " #L "\n\t"                                                           \
+  "s_nop 3\n\t"                                                                                       \
+  "v_writelane_b32 %[X], %[s0], 0\n\t"                                                                \
+  "v_writelane_b32 %[W1], %[s1], 0\n\t"                                                               \
+  "v_writelane_b32 %[W2], %[s2], 0\n\t"
       // shifts 1..7: straight line, masks from registers (a shift past a head's degree finds it masked out; a patch whose
       // largest degree is below 8 runs the spare shifts on nothing).  A vertex of more than 8 edges has its row to itself
       // (nltgv2_pack.hpp, WaveFit): from shift 8 on ONE mask -- those heads and the lanes that only serve as sources -- does
       // for all shifts, the lanes past such a vertex's last edge being idle (-0.0 contributions); three exits by the patch's
       // largest degree instead of one per shift (a branch costs 16 cycles, a shift 26: tools/ripple_bench)
       unsigned long long exec_saved;  // (the masks below narrow EXEC; it is put back as it was found, not assumed to be all ones)
+      unsigned row_s0, row_s1, row_s2;  // (scalar temporaries of the further rows of a vertex of more than 16 edges)
       asm volatile("s_mov_b64 %[ex], exec\n\t"
                    "s_nop 1\n\t"
                    PV_RM(1, m1) PV_RM(2, m2) PV_RM(3, m3) PV_RM(4, m4) PV_RM(5, m5) PV_RM(6, m6) PV_RM(7, m7)
@@ -765,59 +768,29 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
                    "s_cmp_le_u32 %[md], 12\n\t"
                    "s_cbranch_scc1 9f\n\t"
                    PV_ADDS(12) PV_ADDS(13) PV_ADDS(14) PV_ADDS(15)
+                   "s_cmp_le_u32 %[md], 16\n\t"
+                   "s_cbranch_scc1 9f\n\t"
+                   // A vertex of more than 16 edges (rare: a hull vertex of a Delaunay graph): it begins at lane 0 and fills
+                   // rows 0 .. ceil(md / 16) - 1 of this patch (nltgv2_pack.hpp, WaveFit).  Lane 0 now holds the sums over its
+                   // first 16 edges; the first lane of each further row takes them over, adds its own edge and then its row by
+                   // the same shifts (only that row's lanes enabled: min(16, md - L) of them), and hands the sums back to lane 0.
+                   PV_ROW(16)
+                   "s_cmp_le_u32 %[md], 32\n\t"
+                   "s_cbranch_scc1 9f\n\t"
+                   PV_ROW(32)
+                   "s_cmp_le_u32 %[md], 48\n\t"
+                   "s_cbranch_scc1 9f\n\t"
+                   PV_ROW(48)
                    "9:\n\t"
                    "s_mov_b64 exec, %[ex]"
-                   : [X] "+v"(X), [W1] "+v"(W1), [W2] "+v"(W2), [ex] "=&s"(exec_saved)
+                   : [X] "+v"(X), [W1] "+v"(W1), [W2] "+v"(W2), [ex] "=&s"(exec_saved), [s0] "=&s"(row_s0), [s1] "=&s"(row_s1), [s2] "=&s"(row_s2)
                    : [cx] "v"(cx), [a1] "v"(a12.x), [a2] "v"(a12.y), [b1] "v"(b12.x), [b2] "v"(b12.y), [md] "s"(stride),
                      [m1] "s"(rm1), [m2] "s"(rm2), [m3] "s"(rm3), [m4] "s"(rm4), [m5] "s"(rm5), [m6] "s"(rm6), [m7] "s"(rm7), [m8] "s"(rm8)
                    : "scc");
+#undef PV_ROW
 #undef PV_RM
 #undef PV_ADDS
       Wa = v2f_t{W1, W2};
-    } else {
-    lds[wrA] = make_float4(a12.x, a12.y, b12.x, b12.y);
-    ldsf[wrC] = cx;
-    lds_wave_sync();
-    // ---- ordered accumulation, by every lane of the vertex (ascending edge id = ascending slot) --------------
-#define PV_LOAD(N, c, cxs, K0)                                                      \
-  _Pragma("unroll") for (int k = 0; k < N; ++k) c[k] = lds[rdA + (K0) + k];         \
-  {                                                                                 \
-    const float4 cxa = lds[rdC4 + (K0) / 4];                                        \
-    cxs[0] = cxa.x, cxs[1] = cxa.y, cxs[2] = cxa.z, cxs[3] = cxa.w;                 \
-  }                                                                                 \
-  if (N > 4) {                                                                      \
-    const float4 cxb = lds[rdC4 + (K0) / 4 + 1];                                    \
-    cxs[4] = cxb.x, cxs[5] = cxb.y, cxs[6] = cxb.z, cxs[7] = cxb.w;                 \
-  }
-#define PV_ADD(N, c, cxs)                                                           \
-  _Pragma("unroll") for (int k = 0; k < N; ++k) {                                   \
-    X = X + cxs[k];                                                                 \
-    Wa = (Wa + v2f_t{c[k].x, c[k].y}) + v2f_t{c[k].z, c[k].w};                      \
-  }
-    {
-      float4 c[8];
-      float cxs[8];
-      PV_LOAD(8, c, cxs, 0)
-      if (stride <= 8) {  // wave-uniform: the usual patch
-        PV_ADD(8, c, cxs)
-      } else {            // a vertex of more than 8 incident edges: the further slots are requested before 0..7 are added up
-        float4 d[4], e[4];
-        float dxs[8], exs[8];
-        PV_LOAD(4, d, dxs, 8)
-        if (stride > 12) PV_LOAD(4, e, exs, 12)
-        PV_ADD(8, c, cxs)
-        PV_ADD(4, d, dxs)
-        if (stride > 12) {
-          PV_ADD(4, e, exs)
-          for (int k0 = 16; k0 < stride; k0 += 4) {
-            PV_LOAD(4, d, dxs, k0)
-            PV_ADD(4, d, dxs)
-          }
-        }
-      }
-    }
-#undef PV_LOAD
-#undef PV_ADD
     }
     // ---- vertex update: proxL1 (cc:147-151, h:179-197), extragradient (cc:160-171) --------------------------
     // (both shifted values up front and two selects: as branches this was three exec-masked blocks in the hand-off path)
@@ -835,7 +808,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
       o.x = __float_as_int(nb), o.y = __float_as_int(wbn.x), o.z = __float_as_int(wbn.y), o.w = (int)(s + 1u);
       publish(o, pub2, so_out);
     }
-    if (!RIPPLE || state_lane || !valid) lds[wr_rec] = make_float4(nb, wbn.x, wbn.y, __uint_as_float(s + 1u));
+    if (state_lane || !valid) lds[wr_rec] = make_float4(nb, wbn.x, wbn.y, __uint_as_float(s + 1u));
     // (between a record arriving and the next one leaving every instruction counts, needed or not: a lone wave issues
     //  one per ~5 cycles -- so what the publish does not need comes after it)
     ok = ok && (__builtin_fabsf(q1r) <= 3.402823466e+38f) && (__builtin_fabsf(q23r.x) <= 3.402823466e+38f) &&
@@ -918,24 +891,21 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
 // 800 / (SGPRs rounded up to 16, + 16), 8), from the register counts of the instances as built (tests/test_abi.py re-derives them
 // from the compiler's resource report and fails when an instance outgrows its row here); the runtime's answer still bounds it
 // from above (it knows the LDS use, which varies with the layout).
-int pv_real_waves_per_simd(int layout, bool verify_or_probe) {
-  // {VGPRs, SGPRs} -> waves: LAYOUT 1 plain {65, 106} -> min(7, 6); verify / probe {75-81, 106} -> min(5, 6);
-  // LAYOUT 2 (slab code compiled in) {157-165, 106} -> 3
-  return layout == 1 ? (verify_or_probe ? 5 : 6) : 3;
+int pv_real_waves_per_simd(bool verify_or_probe) {
+  // {VGPRs, SGPRs} -> waves: plain {<= 72, <= 112} -> min(7, 6); verify / probe {<= 88, <= 112} -> min(5, 6)
+  return verify_or_probe ? 5 : 6;
 }
 
 int pv_patches_per_cu(const FusedArgs& a, bool verify) {
-  const size_t ldsv = 16u * (size_t)(2 * (a.wg_lcap + 64) + a.wg_slab_slots + 64) + 4u * (size_t)(a.wg_slab_slots + 64);
+  if (!a.wg_rowpack) return 0;  // (not row-packed: the lane-per-half-edge form's layout)
+  const size_t ldsv = 16u * (size_t)(2 * (a.wg_lcap + 64) + a.wg_slab_slots + 64);
   int n = 0;
-  const int layout = !a.wg_rowpack ? 0 : a.wg_slab_slots > 0 ? 2 : 1;
-  if (layout == 0) return 0;  // (not row-packed: the lane-per-half-edge form's layout)
-  const void* fv = layout == 2 ? (verify ? (const void*)k_persistent_pv<false, 2, true> : (const void*)k_persistent_pv<false, 2, false>)
-                               : (verify ? (const void*)k_persistent_pv<false, 1, true> : (const void*)k_persistent_pv<false, 1, false>);
+  const void* fv = verify ? (const void*)k_persistent_pv<false, true> : (const void*)k_persistent_pv<false, false>;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fv, 64, ldsv) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
-  return n < 4 * pv_real_waves_per_simd(layout, verify) ? n : 4 * pv_real_waves_per_simd(layout, verify);
+  return n < 4 * pv_real_waves_per_simd(verify) ? n : 4 * pv_real_waves_per_simd(verify);
 }
 
 // Persistent run (single launch).  form 1 = lane per half-edge (k_persistent_he), form 2 = vertex per
@@ -985,23 +955,14 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
     const int32_t* rec_off = a.rec_off;
     int rec_off_stride = a.rec_off_stride;
     unsigned* rot_word = place_pool ? a.rot_word : nullptr;
-    const unsigned ldsv = 16u * (unsigned)(2 * (lcap + 64) + slab_slots + 64) + 4u * (unsigned)(slab_slots + 64);
+    const unsigned ldsv = 16u * (unsigned)(2 * (lcap + 64) + slab_slots + 64);
     void* vargs[] = {&wave_begin, &n_waves, &wgx, &lcap, &slab_slots, &w0, &w1, &w2, &w3, &w4, &w5, &hrec, &hq, &vstate,
                      &hq_out, &vstate_out, &vaux, &bin, &bout, &vprev, &xbuf, &rec_bytes, &dual, &tag0, &n_iters,
                      &max_spins, &poll_gap, &pp, &err, &abort_flag, &perm, &tail, &probe, &place_pool, &rec_off, &rec_off_stride, &rot_word};
     const bool vr = (dual >> 1) != 0;  // record verification asked for
-    const int layout = !a.wg_rowpack ? 0 : a.wg_slab_slots > 0 ? 2 : 1;
-    const void* fv = nullptr;
-#define PV_PICK(LY)                                                                                                         \
-  fv = probe ? (const void*)k_persistent_pv<true, LY, true>                                                                 \
-             : vr ? (const void*)k_persistent_pv<false, LY, true> : (const void*)k_persistent_pv<false, LY, false>
-    if (layout == 0) return (int)hipErrorInvalidConfiguration;  // (the planner never asks: the kernel runs row-packed patches)
-    if (layout == 1) {
-      PV_PICK(1);
-    } else {
-      PV_PICK(2);
-    }
-#undef PV_PICK
+    if (!a.wg_rowpack) return (int)hipErrorInvalidConfiguration;  // (the planner never asks: the kernel runs row-packed patches)
+    const void* fv = probe ? (const void*)k_persistent_pv<true, true>
+                           : vr ? (const void*)k_persistent_pv<false, true> : (const void*)k_persistent_pv<false, false>;
     if (cooperative) return (int)hipLaunchCooperativeKernel(fv, gv, bv, vargs, ldsv, stream);
     return (int)hipLaunchKernel(fv, gv, bv, vargs, ldsv, stream);
   }

@@ -134,10 +134,10 @@ static int replay(HostGraph& hg, int n_iters, const nltgv2_params& p, bool rowpa
       if (!(m & kWgValid)) continue;
       const int first = m & 63, deg = (m >> 6) & 127, need = deg > 1 ? deg : 1;
       if (first + need > 64) return 2;                        // a vertex inside one wave
-      const bool rowp = L.wg_rowpack && !(L.wg_info[4 * wg + 2] & kWgSlab);  // this patch is row-packed
-      if (rowp && first / 16 != (first + need - 1) / 16) return 17;  // ... then a vertex lies inside one 16-lane row,
+      const bool rowp = L.wg_rowpack;  // this patch is row-packed
+      if (rowp && need <= 16 && first / 16 != (first + need - 1) / 16) return 17;  // ... then a vertex lies inside one 16-lane row,
       if (rowp && need > 8 && (first % 16 != 0)) return 20;          // one of more than 8 edges at the start of a row of its own
-      if (L.wg_rowpack && need > 16 && rowp) return 21;              // and one of more than 16 is in a patch of the other kind
+      if (rowp && need > 16 && first != 0) return 21;                // and one of more than 16 at the start of its patch (whole rows)
       if (((m & kWgHead) != 0) != ((t & 63) == first)) return 18;
       const int k = (t & 63) - first;
       if (k < 0 || k >= need) return 3;
@@ -150,8 +150,8 @@ static int replay(HostGraph& hg, int n_iters, const nltgv2_params& p, bool rowpa
     {  // slab stride: a multiple of 4, at least 8, covers the patch's largest degree, and fits the LDS sizing figure
       const int stride = L.wg_info[4 * wg + 3];
       if ((L.wg_info[4 * wg + 2] & 0xffff) == 0) continue;
-      if (L.wg_rowpack && !(L.wg_info[4 * wg + 2] & kWgSlab)) {  // row-packed: the patch's largest degree itself (the DPP shifts + 1)
-        if (stride < 1 || stride > 16) return 13;
+      if (L.wg_rowpack) {  // row-packed: the patch's largest degree itself (the DPP shifts + 1; above 16: the rows of its big vertex)
+        if (stride < 1 || stride > 64) return 13;
         bool reached = false;
         for (int t = 0; t < T; ++t)
           reached |= (L.wg_meta[(size_t)wg * T + t] & kWgValid) && (int)std::max(1u, (L.wg_meta[(size_t)wg * T + t] >> 6) & 127) == stride;

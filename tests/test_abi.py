@@ -112,15 +112,15 @@ def test_pv_residency_table_matches_the_build(tmp_path):
     found = {}
     for m in re.finditer(r"Function Name: (\S+).*?TotalSGPRs: (\d+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)", rep, flags=re.S):
         name, sg, vg, scratch = m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4))
-        k = re.search(r"k_persistent_pvILb([01])ELi([12])ELb([01])E", name)
+        k = re.search(r"k_persistent_pvILb([01])ELb([01])E", name)
         if k:
-            found[(int(k.group(1)), int(k.group(2)), int(k.group(3)))] = (sg, vg, scratch)
-    assert len(found) >= 6, sorted(found)
+            found[(int(k.group(1)), int(k.group(2)))] = (sg, vg, scratch)
+    assert len(found) == 3, sorted(found)
     txt = open(src).read()
-    assert "return layout == 1 ? (verify_or_probe ? 5 : 6) : 3;" in txt, "the table in this test mirrors pv_real_waves_per_simd"
-    for (probe, layout, verify), (sg, vg, scratch) in sorted(found.items()):
+    assert "return verify_or_probe ? 5 : 6;" in txt, "the table in this test mirrors pv_real_waves_per_simd"
+    for (probe, verify), (sg, vg, scratch) in sorted(found.items()):
         real = min(512 // ((vg + 7) // 8 * 8), 800 // ((sg + 15) // 16 * 16 + 16), 8)
-        want = (5 if (probe or verify) else 6) if layout == 1 else 3
-        assert real >= want, f"instance probe={probe} layout={layout} verify={verify}: {vg} VGPRs / {sg} SGPRs keep {real} waves per SIMD, the planner assumes {want}"
-    # the instance the bench runs (no probe, row-packed, no verification) must not spill
-    assert found[(0, 1, 0)][2] == 0
+        want = 5 if (probe or verify) else 6
+        assert real >= want, f"instance probe={probe} verify={verify}: {vg} VGPRs / {sg} SGPRs keep {real} waves per SIMD, the planner assumes {want}"
+    # the instance the bench runs (no probe, no verification) must not spill
+    assert found[(0, 0)][2] == 0

@@ -256,6 +256,41 @@ def test_star_graph_high_degree(env):
         assert_state_equal(out, ref2, what=f"hub of degree 300, persistent option {form}")
 
 
+@pytest.mark.parametrize("hub_degrees", [(17,), (18, 31, 32), (33, 47, 48), (49, 63, 64), (16, 17, 20, 40, 64)])
+def test_vertices_of_more_than_sixteen_edges_in_the_patch_kernel(env, hub_degrees):
+    """k_persistent_pv adds a vertex's contributions up across the lanes of a 16-lane row; a vertex of 17..64 edges fills two
+    to four rows of its patch and its sum runs row after row (the running sums handed from the first lane of one row to the
+    next).  Hubs at every row boundary, both edge orientations, odd and even run lengths: all three persistent forms and the
+    per-step path agree with the checker bit for bit."""
+    flame_amd, oracle = env
+    rng = np.random.default_rng(sum(hub_degrees))
+    g0 = synth.make_graph("320x240", seed=40 + len(hub_degrees))
+    V = g0["V"]
+    edges = [tuple(e) for e in np.stack([g0["src"], g0["dst"]], 1)]
+    deg = np.bincount(np.concatenate([g0["src"], g0["dst"]]), minlength=V)
+    hubs = rng.choice(V, len(hub_degrees), replace=False)
+    for h, want in zip(hubs, hub_degrees):
+        have = {b if a == h else a for a, b in edges if h in (a, b)}
+        cands = [v for v in rng.permutation(V) if v != h and v not in have and v not in hubs and deg[v] < 12]
+        for v in cands[: max(0, want - len(have))]:
+            edges.append((h, v) if rng.random() < 0.5 else (v, h))
+            deg[v] += 1
+        deg[h] = want
+    perm = rng.permutation(len(edges))  # the hubs' edges spread over the edge list (ascending edge id = accumulation order)
+    e = np.array(edges, np.int32)[perm]
+    g = synth.assemble_graph(g0["pos"], g0["data_term"], e)
+    got_deg = np.bincount(np.concatenate([g["src"], g["dst"]]), minlength=V)
+    assert sorted(got_deg[hubs]) == sorted(hub_degrees), (got_deg[hubs], hub_degrees)
+    for n in (1, 2, 37):
+        ref, bad = cpu_run(oracle, g, n)
+        assert bad == 0
+        for form, path in ((4, 6), (2, 1), (3, 5)):
+            out = gpu_run(flame_amd, g, n, options=[(5, form)], expect_path=path if n >= 4 else None)
+            assert_state_equal(out, ref, what=f"hubs {hub_degrees}, form {form}, {n} steps")
+    out = gpu_run(flame_amd, g, 37, options=[(5, 0)], expect_path=2)
+    assert_state_equal(out, cpu_run(oracle, g, 37)[0], what=f"hubs {hub_degrees}, per step")
+
+
 def test_edge_order_and_orientation_semantics(env):
     """Shuffling edge ORDER changes results only at rounding level; flipping ORIENTATION is a
     different operator (SURVEY.md 7 'Orientation is semantic').  GPU follows the checker in both."""
