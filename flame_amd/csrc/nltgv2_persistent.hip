@@ -739,8 +739,17 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   "v_add_f32 %[W1], %[W1], %[b1]\n\t"                                                                 \
   "v_add_f32 %[W2], %[W2], %[b2]\n\t"                                                                 \
   "s_nop 1\n\t"                                                                                       \
-  PV_ADDS(1) PV_ADDS(2) PV_ADDS(3) PV_ADDS(4) PV_ADDS(5) PV_ADDS(6) PV_ADDS(7) PV_ADDS(8)              \
-  PV_ADDS(9) PV_ADDS(10) PV_ADDS(11) PV_ADDS(12) PV_ADDS(13) PV_ADDS(14) PV_ADDS(15)                   \
+  PV_ADDS(1)                                                                                          \
+  "s_cmp_le_u32 %[s0], 2\n\t"                                                                         \
+  "s_cbranch_scc1 1" #L "f\n\t"                                                                       \
+  PV_ADDS(2) PV_ADDS(3)                                                                               \
+  "s_cmp_le_u32 %[s0], 4\n\t"                                                                         \
+  "s_cbranch_scc1 1" #L "f\n\t"                                                                       \
+  PV_ADDS(4) PV_ADDS(5) PV_ADDS(6) PV_ADDS(7)                                                         \
+  "s_cmp_le_u32 %[s0], 8\n\t"                                                                         \
+  "s_cbranch_scc1 1" #L "f\n\t"                                                                       \
+  PV_ADDS(8) PV_ADDS(9) PV_ADDS(10) PV_ADDS(11) PV_ADDS(12) PV_ADDS(13) PV_ADDS(14) PV_ADDS(15)       \
+  "1" #L ":\n\t"                                                                                      \
   "s_nop 1\n\t"                                                                                       \
   "v_readlane_b32 %[s0], %[X], " #L "\n\t"                                                            \
   "v_readlane_b32 %[s1], %[W1], " #L "\n\t"                                                           \
@@ -773,7 +782,8 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
                    // A vertex of more than 16 edges (rare: a hull vertex of a Delaunay graph): it begins at lane 0 and fills
                    // rows 0 .. ceil(md / 16) - 1 of this patch (nltgv2_pack.hpp, WaveFit).  Lane 0 now holds the sums over its
                    // first 16 edges; the first lane of each further row takes them over, adds its own edge and then its row by
-                   // the same shifts (only that row's lanes enabled: min(16, md - L) of them), and hands the sums back to lane 0.
+                   // the same shifts (only that row's lanes enabled: min(16, md - L) of them; exits by that count), and hands the sums
+                   // back to lane 0.
                    PV_ROW(16)
                    "s_cmp_le_u32 %[md], 32\n\t"
                    "s_cbranch_scc1 9f\n\t"

@@ -4,7 +4,7 @@
 # tracing), as /opt/skills/guides prescribe.  Output: gpurun_out/prof_<ROUND>/ ; summarise with
 # tools/summarize_profile.py and commit the summaries under profiles/.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/prof_$R
@@ -23,6 +23,7 @@ prof bench_he $B --persistent 2                 # the lane-per-half-edge kernel 
 prof bench_step $B --persistent 0               # one launch per step
 prof cfg3 python tools/profile_case.py single:1280x720
 prof cfg5 python tools/profile_case.py single:1920x1080
+prof batch5 python tools/profile_case.py batch:5:200     # five frames in the patch-per-wave kernel (19 patches per CU; round 3's planner)
 prof batch30 python tools/profile_case.py batch:30:200   # bench.py batched.resident (200 iterations per launch)
 prof batch64 python tools/profile_case.py batch:64:100   # bench.py batched.large (100 iterations, 3 launch groups)
 prof stream64 python tools/profile_case.py stream:64

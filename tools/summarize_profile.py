@@ -14,7 +14,7 @@ import os
 import shutil
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{R}")
 DST = os.path.join(ROOT, "profiles")
@@ -52,7 +52,7 @@ def last_json(path):
 # tag -> (dominant kernel, traffic.json key or None)
 CASES = {"bench": ("k_persistent_pv", "640x480:persistent-pv"), "bench_he": ("k_persistent_he", "640x480:persistent"),
          "bench_step": ("k_fused_step", "640x480:per-step hipGraph"), "cfg3": ("k_persistent_pv", "1280x720:persistent-pv"),
-         "cfg5": ("k_persistent_he", "1920x1080:persistent"), "batch30": ("k_persistent_tv", "640x480x30:persistent-tv"),
+         "cfg5": ("k_persistent_he", "1920x1080:persistent"), "batch5": ("k_persistent_pv", "640x480x5:persistent-pv"), "batch30": ("k_persistent_tv", "640x480x30:persistent-tv"),
          "batch64": ("k_persistent_tv", "640x480x64:persistent-tv"), "stream64": ("k_fused_step", None),
          "stereo": ("k_update_feature_idepths", None)}
 out, traffic = {}, {}
