@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FLAME_NLTGV2_ABI_VERSION 2
+#define FLAME_NLTGV2_ABI_VERSION 3
 
 typedef struct flame_nltgv2_ctx flame_nltgv2_ctx;
 
