@@ -582,7 +582,7 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
     for _ in range(5):  # frame A -> frame B (8 % churn) timed, B -> A back untimed
         r.run(params, 50)
         t4 = _t.perf_counter()
-        r.sync_graph(fid, pos2, data2, ones2, edges2)
+        r.sync_graph(fid, pos2, data2, ones2, edges2, edges_unique=True)  # (the triangulator's own edge list)
         t5 = _t.perf_counter()
         r.sync()
         sync_call.append((t5 - t4) * 1e3)

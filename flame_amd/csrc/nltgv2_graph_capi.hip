@@ -205,7 +205,7 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
   int32_t n_keep = 0;
   for (int32_t o = 0; o < Eo; ++o) n_keep += first_k[(size_t)o] != 0x7fffffff;
   tp[3] = std::chrono::steady_clock::now();
-  if (!fresh.empty()) {
+  if (!fresh.empty() && !in->edges_unique) {
     // No parallel edges among the new ones either (boost::edge() finds the one just added): of several new edges between the
     // same two vertices the first stays.  The edges are bucketed by their lower vertex (a counting sort: two streaming passes;
     // a vertex has ~3 of them), equal pairs found inside a bucket, the later ones dropped in place -- no hashing.

@@ -65,7 +65,7 @@ class _Graph(C.Structure):
 class _SyncInput(C.Structure):
     _fields_ = [("V", C.c_int32), ("feat_id", _IP), ("pos", _FP), ("data_term", _FP), ("data_weight", _FP),
                 ("init_x", _FP), ("E", C.c_int32), ("edges", _IP), ("check_sticky_obstacles", C.c_int32),
-                ("sticky_threshold", C.c_float), ("init_graph_scale", C.c_float)]
+                ("sticky_threshold", C.c_float), ("init_graph_scale", C.c_float), ("edges_unique", C.c_int32)]
 
 
 class _Projection(C.Structure):
@@ -282,7 +282,7 @@ class Regularizer:
         self.V, self.E = int(g["V"]), int(g["E"])
 
     def sync_graph(self, feat_id, pos, data_term, data_weight, edges, init_x=None, check_sticky_obstacles=False,
-                   sticky_threshold=0.25, init_graph_scale=0.0):
+                   sticky_threshold=0.25, init_graph_scale=0.0, edges_unique=False):
         """Per-frame warm-start synchronisation (Flame::syncGraph's graph edits, flame.cc:1985-2121).
 
         init_graph_scale > 0: new vertices whose init_x is NaN start at their neighbours' mean
@@ -305,6 +305,7 @@ class Regularizer:
         si.check_sticky_obstacles = 1 if check_sticky_obstacles else 0
         si.sticky_threshold = sticky_threshold
         si.init_graph_scale = float(init_graph_scale)
+        si.edges_unique = 1 if edges_unique else 0  # (the caller vouches: e.g. the edges of flame_amd.delaunay)
         self._chk(self._L.flame_nltgv2_sync_graph(self._ctx, C.byref(si)), "sync_graph")
         info = self.info()
         self.V, self.E = info["V"], info["E"]

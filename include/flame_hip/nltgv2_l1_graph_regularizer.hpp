@@ -208,9 +208,10 @@ class DeviceGraph {
   // device image; see flame_nltgv2_sync_graph.  `edges` = triangulator->edges() as index pairs.
   void sync(const std::vector<int32_t>& feat_id, const std::vector<float>& pos_xy, const std::vector<float>& data_term,
             const std::vector<float>& data_weight, const std::vector<int32_t>& edges, bool check_sticky_obstacles = false,
-            const float* init_x = nullptr, float init_graph_scale = 0.0f) {
+            const float* init_x = nullptr, float init_graph_scale = 0.0f, bool edges_unique = false) {
     flame_nltgv2_sync_input in{};
     in.init_graph_scale = init_graph_scale;  // > 0: NaN entries of init_x -> neighbours' mean (flame.cc:2133-2158)
+    in.edges_unique = edges_unique ? 1 : 0;  // the caller vouches (a triangulator's edge list): no search for repeated pairs
     in.V = static_cast<int32_t>(feat_id.size());
     in.feat_id = feat_id.data(), in.pos = pos_xy.data();
     in.data_term = data_term.data(), in.data_weight = data_weight.data();

@@ -123,6 +123,10 @@ typedef struct flame_nltgv2_sync_input {
                                    * init_x, or data_term where that is NaN too), neighbours in ascending edge id --, or at
                                    * data_term when it has none (init_with_prediction, flame.cc:2133-2158).  0: init_x is
                                    * taken as it is. */
+  int32_t edges_unique;           /* != 0: the caller vouches that `edges` lists every vertex pair at most once (what
+                                   * flame_delaunay_triangulate -- and the reference's Triangle -- return): the search for
+                                   * duplicates among the new edges is skipped.  0 (default): pairs that repeat are dropped as
+                                   * boost::edge() / add_edge do it in the reference (flame.cc:2094-2100), the first one stays */
 } flame_nltgv2_sync_input;
 int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in);
 /* Declares the feature ids of the vertices of a graph brought in with flame_nltgv2_upload_graph (V ints,

@@ -259,3 +259,30 @@ def test_randomized_frame_sequences(built, seed):
             src, dst, fid = reg.topology()
             assert np.array_equal(src, flat["src"]) and np.array_equal(dst, flat["dst"]) and np.array_equal(fid, feat_id), frame
             assert_state_equal(reg.download_state(), flat, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"seed {seed} frame {frame}")
+
+
+def test_edges_unique_flag_skips_nothing_but_the_search(built):
+    """flame_nltgv2_sync_input.edges_unique: with a duplicate-free edge list (a triangulator's) the flag only skips the search for
+    repeated pairs -- the resulting edge list and state are those of the default path."""
+    import torch  # noqa: F401
+
+    import flame_amd
+
+    rng = np.random.default_rng(3)
+    g0 = synth.make_graph("320x240", seed=5)
+    feat_id = np.arange(g0["V"], dtype=np.int32)
+    f1, p1, d1, _ = next_frame(rng, feat_id, g0["pos"].copy(), g0["data_term"].copy(), g0["V"], 320, 240)
+    edges = synth.delaunay_edges_native(p1)
+    ones = np.ones(len(f1), np.float32)
+    outs = []
+    for flag in (False, True):
+        with flame_amd.Regularizer(0) as reg:
+            reg.upload_graph(g0)
+            reg.set_feature_ids(feat_id)
+            reg.run(flame_amd.Params(), 30)
+            reg.sync_graph(f1, p1, d1, ones, edges, edges_unique=flag)
+            reg.run(flame_amd.Params(), 30)
+            outs.append((reg.topology(), reg.download_state()))
+    (ta, sa), (tb, sb) = outs
+    assert all(np.array_equal(x, y) for x, y in zip(ta, tb))
+    assert_state_equal(sa, sb, keys=OUT_KEYS, what="edges_unique")

@@ -76,7 +76,7 @@ for k in news:
         R = (sc.cams[k][0] @ sc.cams[prev][0].T).astype(np.float32)
         KRKinv = (sc.K32 @ R @ sc.Kinv32).astype(np.float32)
         t0 = time.perf_counter(); reg.project_graph(sc.K32, sc.Kinv32, KRKinv, q, t, (M, M, W - 2 * M, H - 2 * M)); tick("projectGraph", t0)
-        t0 = time.perf_counter(); reg.sync_graph(fid, pos, idp, np.ones(len(fid), np.float32), edges); tick("syncGraph", t0)
+        t0 = time.perf_counter(); reg.sync_graph(fid, pos, idp, np.ones(len(fid), np.float32), edges, edges_unique=True); tick("syncGraph", t0)
     t0 = time.perf_counter(); reg.run(P, a.iters); tick("%d NLTGV2 steps" % a.iters, t0)
     t0 = time.perf_counter(); dense, cov = reg.interpolate_mesh(tris, H, W); tick("interpolateMesh (+ D2H of the map)", t0)
     tr.drop_frame(k)
