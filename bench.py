@@ -472,10 +472,11 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
         out["batched"][label] = {
             "frames": nf, "V": bi["V"], "E": bi["E"], "run_path": path, "launch_groups": b.info()["last_run_groups"],
             "frame_iters_per_s": round(nf * iters / (ms * 1e-3), 1), "per_iteration_us": round(per_iter_us, 2),
-            "achieved_GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4), "bound": "hbm",
+            "achieved_GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4), "bound": "on-chip", "peak_of": "hbm",
             "timing": "mean of 10 launches (HIP events)", "best_launch_per_iteration_us": round(ms_min * 1e3 / iters, 2),
             "note": "frac counts ALGORITHMIC bytes (64 V + 40 E per iteration) against the HBM peak; the state is register / LDS "
-                    "resident, the real HBM traffic is `traffic`",
+                    "resident, the real HBM traffic is `traffic` (a tenth of it), so the rate may pass the HBM peak: what binds "
+                    "is instruction issue (`valu`) and the neighbour exchange, not memory",
         }
         groups = max(1, b.info()["last_run_groups"])
         key = f"{a.config}x{nf}:{path}"

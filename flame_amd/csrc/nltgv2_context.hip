@@ -418,7 +418,7 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
       ctx->opt_place = value;
       return 0;
     case FLAME_NLTGV2_OPT_POLL_GAP:
-      if (value < 0 || value > 4) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      if (value < 0 || value > 256) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_poll_gap = value;
       return 0;
     case FLAME_NLTGV2_OPT_VERIFY_RECORDS:

@@ -40,8 +40,9 @@ constexpr int kTvLdsWavesPerCu = 16;   // ... with the slot constants in LDS (<=
 constexpr size_t kXbufBytesPerVertex = 8 * 16 + 4;  // exchange buffers: up to four step buffers x (remote + same-XCD copy) of
                                                     // 16-byte records (the patch-per-wave form; the others use two) + the XCC table
 constexpr int kPvDensePerCu = 23;      // k_persistent_pv is used up to this many patches per CU (24 are resident: 6 waves per SIMD)
-constexpr int kPvPaceAbovePerCu = 17;  // ... and above this many its polls are paced (kPvDensePreSleep, kPvDenseGap)
-constexpr int kPvDensePreSleep = 8, kPvDenseGap = 4;  // x64 cycles before the first poll of a step / between poll rounds
+constexpr int kPvPaceAbovePerCu = 13;  // ... and above this many its polls are paced (kPvDensePreSleep, kPvDenseGap)
+constexpr int kPvDensePreSleep = 3, kPvDenseGap = 2;  // x64 cycles before the first poll of a step / between poll rounds (re-swept
+                                                      // with the issue priorities in: 8 / 4 before them; profiles/r03_priority.txt)
 constexpr int kPvPreSleep = 0;         // k_persistent_pv: x64 cycles between a step's start and its first poll
 constexpr int kPvPollGap = 2;          // k_persistent_pv polls: re-loading only the fetch entries still waiting, no pause between
                                        // rounds (with the round-2 first form of the kernel an s_sleep between rounds won by 1-3 %;

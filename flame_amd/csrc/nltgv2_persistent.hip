@@ -193,6 +193,7 @@ k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd
       }
     }
 
+    __builtin_amdgcn_s_setprio(3);  // from the records' arrival to the publish this wave goes before the polling ones (k_persistent_pv)
     // ---- dual update of this half-edge's private q copy (cc:99-110) ------------------------------
     const float nxb = __int_as_float(g.x), nw1b = __int_as_float(g.y), nw2b = __int_as_float(g.z);
     const float xbi = is_target ? nxb : xb, xbj = is_target ? xb : nxb;
@@ -253,6 +254,7 @@ k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd
       __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
       if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
     }
+    __builtin_amdgcn_s_setprio(0);
     // ---- hand the vertex's new state back to all of its lanes -------------------------------------
     x_prev = x, w1_prev = w1, w2_prev = w2;  // step()'s prev copy, cc:37-42
     x = __shfl(xn, tail_lane, 64);
@@ -591,13 +593,15 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
       // unless the launch asks for the un-narrowed poll), an optional s_sleep, then every lane's neighbour record from LDS;
       // vcc = lanes still waiting.  One statement for all pacing variants (two scalar flags), and the common exit falls
       // straight through into the step: the instructions after the last record's arrival are the ones that count.
+      // The statement polls at issue priority 0 and leaves at 3 (see below).
       unsigned cnt, keep, pend_lo, tagv, tagf, gapk;
       unsigned long long pnarrow, exec_saved;  // (EXEC is saved and put back by the statement itself, not assumed to be all ones)
       const unsigned own_slot = dst + 16u * (unsigned)lane;
       // (pacing: bit 0 = pause between rounds, bits 4..7 = its length - 1 in s_sleep 1 units, bit 1 = narrowed re-loads)
       const unsigned f_sleep = (poll_gap & 1) ? 1u + (((unsigned)poll_gap >> 4) & 15u) : 0u, f_narrow = (unsigned)((poll_gap >> 1) & 1);
 #define PV_POLL_U                                                                                         \
-  asm volatile("s_mov_b64 %[ex], exec\n\t"                                                             \
+  asm volatile("s_setprio 0\n\t"                                                                        \
+               "s_mov_b64 %[ex], exec\n\t"                                                             \
                "s_mov_b32 %[keep], m0\n\t"                                                              \
                "s_mov_b32 m0, %[dst]\n\t"                                                               \
                "s_mov_b32 %[cnt], 0\n\t"                                                                \
@@ -628,8 +632,8 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
                "s_cbranch_vccz 2f\n\t"                                                                  \
                "s_cbranch_scc1 1b\n\t"                                                                  \
                "2:\n\t"                                                                                 \
-               "s_mov_b32 %[pl], vcc_lo\n\t"                                                            \
-               "s_or_b32 %[pl], %[pl], vcc_hi\n\t"                                                      \
+               "s_setprio 3\n\t"                                                                        \
+               "s_or_b32 %[pl], vcc_lo, vcc_hi\n\t"                                                     \
                "s_mov_b32 m0, %[keep]"                                                                   \
                : [keep] "=&s"(keep), [cnt] "=&s"(cnt), [pl] "=&s"(pend_lo), [nb] "=&v"(nbv), [t] "=&v"(tagv), \
                  [t2] "=&v"(tagf), [pn] "=&s"(pnarrow), [k] "=&s"(gapk), [ex] "=&s"(exec_saved)            \
@@ -676,6 +680,11 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
     }
     unsigned pr_t1 = 0;
     if (PROBE) pr_t1 = (unsigned)clock64();
+    // Issue priority (round 3): the waves of a CU are in different phases -- most of them polling, a few computing the step
+    // that their neighbours are waiting for.  At equal priority the arbiter serves the OLDEST ready wave, i.e. a polling
+    // loop as readily as the hand-off path; from the wait's exit (s_setprio 3 inside the statement, in the place of an
+    // instruction it could do without) to the publish this wave goes first, polling waves last: -3 % at 720p, -7 % at 15-23
+    // patches per CU, nothing at 4 per CU (one wave per SIMD); a level by patch length on top of it gained nothing.
     xb = own.x, wb12 = v2f_t{own.y, own.z};
     // ---- dual update of this half-edge's private q copy (cc:99-110) ------------------------------
     const v2f_t nbw = {nbv.y, nbv.z};
@@ -818,6 +827,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
       o.x = __float_as_int(nb), o.y = __float_as_int(wbn.x), o.z = __float_as_int(wbn.y), o.w = (int)(s + 1u);
       publish(o, pub2, so_out);
     }
+    __builtin_amdgcn_s_setprio(0);
     if (state_lane || !valid) lds[wr_rec] = make_float4(nb, wbn.x, wbn.y, __uint_as_float(s + 1u));
     // (between a record arriving and the next one leaving every instruction counts, needed or not: a lone wave issues
     //  one per ~5 cycles -- so what the publish does not need comes after it)

@@ -198,6 +198,7 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
       }
     }
 
+    __builtin_amdgcn_s_setprio(3);  // from the records' arrival to the publish this wave goes before the polling ones (k_persistent_pv)
     // ---- phase A, every lane at once: dual update of each slot's private q copy (cc:99-110) and the three
     // step-scaled values its primal scatter needs (cc:126-141).  They overwrite the neighbour record of the slot
     // (dead from here on), so the ordered accumulation below costs no registers.
@@ -265,6 +266,7 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
       __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
       if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
     }
+    __builtin_amdgcn_s_setprio(0);
     x_prev = x, w1_prev = w1, w2_prev = w2;
     if (has_chain) {  // wave-uniform: hand the owner's new state back to every lane of its chain
       x = __shfl(xn, owner_lane, 64);
