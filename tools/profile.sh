@@ -11,10 +11,10 @@ OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 prof() {  # prof TAG "command": kernel stats + FETCH + WRITE + SQ counters, each in its own process
   local tag=$1; shift
-  rocprofv3 --kernel-trace --stats -d $OUT/kt_$tag -o kt --output-format csv -- "$@" > $OUT/kt_$tag.log 2>&1
-  rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch_$tag -o f --output-format csv -- "$@" > $OUT/fetch_$tag.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE -d $OUT/write_$tag -o w --output-format csv -- "$@" > $OUT/write_$tag.log 2>&1
-  rocprofv3 --pmc SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/sq_$tag -o s --output-format csv -- "$@" > $OUT/sq_$tag.log 2>&1
+  timeout 150 rocprofv3 --kernel-trace --stats -d $OUT/kt_$tag -o kt --output-format csv -- "$@" > $OUT/kt_$tag.log 2>&1
+  timeout 150 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch_$tag -o f --output-format csv -- "$@" > $OUT/fetch_$tag.log 2>&1
+  timeout 150 rocprofv3 --pmc WRITE_SIZE -d $OUT/write_$tag -o w --output-format csv -- "$@" > $OUT/write_$tag.log 2>&1
+  timeout 150 rocprofv3 --pmc SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/sq_$tag -o s --output-format csv -- "$@" > $OUT/sq_$tag.log 2>&1
   tail -1 $OUT/kt_$tag.log | cut -c1-400
 }
 B="python bench.py --steps 20 --warmup 2 --no-extras --no-cpu-baseline"
@@ -27,6 +27,6 @@ prof batch5 python tools/profile_case.py batch:5:200     # five frames in the pa
 prof batch30 python tools/profile_case.py batch:30:200   # bench.py batched.resident (200 iterations per launch)
 prof batch64 python tools/profile_case.py batch:64:100   # bench.py batched.large (100 iterations, 3 launch groups)
 prof stream64 python tools/profile_case.py stream:64
-rocprofv3 --kernel-trace --stats -d $OUT/kt_stereo -o kt --output-format csv -- python tools/stereo_bench.py > $OUT/kt_stereo.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_INSTS_LDS -d $OUT/sq_stereo -o s --output-format csv -- python tools/stereo_bench.py > $OUT/sq_stereo.log 2>&1
+timeout 150 rocprofv3 --kernel-trace --stats -d $OUT/kt_stereo -o kt --output-format csv -- python tools/stereo_bench.py > $OUT/kt_stereo.log 2>&1
+timeout 150 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_INSTS_LDS -d $OUT/sq_stereo -o s --output-format csv -- python tools/stereo_bench.py > $OUT/sq_stereo.log 2>&1
 tail -3 $OUT/kt_stereo.log
