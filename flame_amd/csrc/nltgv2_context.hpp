@@ -35,14 +35,19 @@ namespace host {
 
 constexpr int kGraphChunk = 256;      // steps per captured hipGraph (even: keeps ping-pong parity)
 constexpr int kMaxCachedGraphs = 6;
-constexpr int kHeWavesPerCu = 24;      // residency cap of k_persistent_he (<= 64 VGPRs: the hardware admits 32)
+constexpr int kHeWavesPerCu = 24;      // k_persistent_he is planned for at most this many waves per CU (six 256-thread blocks) ...
+constexpr int kHeWavesPerCuReal = 28;  // ... of the 28 really resident (82 SGPRs -> 96 + the trap handler's 16: seven waves per SIMD);
+                                       // all of them only where the form is asked for by name (a row-packed 1080p layout has 25 per CU)
 constexpr int kTvLdsWavesPerCu = 16;   // ... with the slot constants in LDS (<= 128 VGPRs -> 4 waves per SIMD; 10 KB LDS per wave = all 160 KB)
 constexpr size_t kXbufBytesPerVertex = 8 * 16 + 4;  // exchange buffers: up to four step buffers x (remote + same-XCD copy) of
                                                     // 16-byte records (the patch-per-wave form; the others use two) + the XCC table
-constexpr int kPvDensePerCu = 23;      // k_persistent_pv is used up to this many patches per CU (24 are resident: 6 waves per SIMD)
+constexpr int kCrowdedWavesPerCu = 16, kCrowdedTopologies = 64;  // (see flame_nltgv2_ctx::crowded_until_topo)
+constexpr int kPvDensePerCu = 27;      // k_persistent_pv is used up to this many patches per CU (28 are resident: 7 waves per SIMD at <= 96 SGPRs)
 constexpr int kPvPaceAbovePerCu = 13;  // ... and above this many its polls are paced (kPvDensePreSleep, kPvDenseGap)
 constexpr int kPvDensePreSleep = 3, kPvDenseGap = 2;  // x64 cycles before the first poll of a step / between poll rounds (re-swept
                                                       // with the issue priorities in: 8 / 4 before them; profiles/r03_priority.txt)
+constexpr int kPvPaceMoreAbovePerCu = 23;  // ... and above this many more slowly (a 1080p frame: 25 per CU)
+constexpr int kPvDenserPreSleep = 5, kPvDenserGap = 4;
 constexpr int kPvPreSleep = 0;         // k_persistent_pv: x64 cycles between a step's start and its first poll
 constexpr int kPvPollGap = 2;          // k_persistent_pv polls: re-loading only the fetch entries still waiting, no pause between
                                        // rounds (with the round-2 first form of the kernel an s_sleep between rounds won by 1-3 %;
@@ -174,6 +179,12 @@ struct flame_nltgv2_ctx {
   uint32_t tag_next = 1;  // persistent run: tag of the current bar values (monotonic)
   int last_run_path = 0, last_run_groups = 0;
   uint64_t persist_refused_topo = ~0ull;  // topology for which the runtime refused the persistent grid
+  // A persistent run that needs most of the chip's wave slots (a 1080p frame: 25 of the 28 a CU really holds) only starts
+  // whole when nothing else keeps slots busy; when such a run expires beside other kernels (the tracker's, the rasteriser's:
+  // tools/soak_pipeline.py at 1080p), the next kCrowdedTopologies topologies are planned for at most kCrowdedWavesPerCu waves per
+  // CU -- for a 1080p frame that is the vertex-per-lane form (4 waves per CU) -- then the full residency is tried again.
+  uint64_t crowded_until_topo = 0;
+  int last_run_waves_per_cu = 0;
   bool static_stale = false;  // pos changed on the device (project_graph): packed alpha/dx/dy need a re-pack
   uint64_t coop_checked_key = 0;  // (topology, form) whose persistent grid the runtime has verified as resident
   int buf_gen = 0;                // which of the two (hq, vstate) copies is current; part of the hipGraph cache key

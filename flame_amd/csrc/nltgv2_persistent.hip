@@ -359,8 +359,11 @@ __device__ __forceinline__ void report_expired(int* err, int which, int wg, int 
   }
 }
 
+// amdgpu_num_sgpr(92): 90 SGPRs as built -> 96 + the trap handler's 16 = 112 per wave, SEVEN waves per SIMD really resident (at the
+// compiler's own choice, 106, it is six: "Round 3" in DESIGN.md section 4); the scalar spills this costs stay outside the hand-off path
+// (640x480: 0.962 against 0.962 us per iteration, profiles/r03_priority.txt (7)) and a 1080p frame's 25 patches per CU fit one launch.
 template <bool PROBE, bool VERIFY>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(92)))
 k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, const int lcap, const int slab_slots,
                 const int32_t* __restrict__ wg_slot, const int32_t* __restrict__ wg_vid,
                 const uint32_t* __restrict__ wg_meta, const int32_t* __restrict__ wg_nbr,
@@ -912,8 +915,8 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
 // from the compiler's resource report and fails when an instance outgrows its row here); the runtime's answer still bounds it
 // from above (it knows the LDS use, which varies with the layout).
 int pv_real_waves_per_simd(bool verify_or_probe) {
-  // {VGPRs, SGPRs} -> waves: plain {<= 72, <= 112} -> min(7, 6); verify / probe {<= 88, <= 112} -> min(5, 6)
-  return verify_or_probe ? 5 : 6;
+  // {VGPRs, SGPRs} -> waves: plain {<= 72, <= 96} -> min(7, 7); verify / probe {<= 88, <= 96} -> min(5, 7)
+  return verify_or_probe ? 5 : 7;
 }
 
 int pv_patches_per_cu(const FusedArgs& a, bool verify) {

@@ -46,8 +46,9 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
                    (int)L.wg_rowpack, ctx->f.wg_slab_slots, ctx->f.wg_lcap, ctx->pv_occ);
     ctx->pv_occ_topo = occ_key;
   }
-  const int wg_cap = ctx->pv_occ * cus;  // patch-per-wave form, in patches
-  const int he_cap = kHeWavesPerCu * cus;
+  const bool crowded = ctx->topo < ctx->crowded_until_topo && ctx->opt_persistent == 1;  // (a form asked for by name is run as asked)
+  const int wg_cap = (crowded ? std::min(ctx->pv_occ, kCrowdedWavesPerCu) : ctx->pv_occ) * cus;  // patch-per-wave form, in patches
+  const int he_cap = (ctx->opt_persistent == 2 ? kHeWavesPerCuReal : crowded ? kCrowdedWavesPerCu : kHeWavesPerCu) * cus;
   // The lane-per-half-edge rows (C) come from the same greedy walk as the patches (E): as many waves, possible under the
   // same condition (no vertex of more than 64 incident edges).  They, and the vertex-per-lane rows (D), are built only
   // when their form is actually chosen.
@@ -402,10 +403,10 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
         // itself that slows down (probe: 0.72 us at 4 patches per CU, 1.03 at 15; 26 per CU unpaced: 50 us per step) -- a
         // pause before the first poll and between rounds then wins (tools/pv_big.py sweeps, profiles/r03_pv_dense.txt)
         const bool dense = gr.count > kPvPaceAbovePerCu * ctx->prop.multiProcessorCount;
-        const int gap = ctx->opt_poll_gap > 0 ? ctx->opt_poll_gap - 1 : dense ? (3 | ((kPvDenseGap - 1) << 4)) : kPvPollGap;
-        ctx->f.wg_poll_gap = gap |
-                             ((ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : dense ? kPvDensePreSleep : kPvPreSleep) << 8) |
-                             0;
+        const bool denser = gr.count > kPvPaceMoreAbovePerCu * ctx->prop.multiProcessorCount;
+        const int dense_gap = denser ? kPvDenserGap : kPvDenseGap, dense_pre = denser ? kPvDenserPreSleep : kPvDensePreSleep;
+        const int gap = ctx->opt_poll_gap > 0 ? ctx->opt_poll_gap - 1 : dense ? (3 | ((dense_gap - 1) << 4)) : kPvPollGap;
+        ctx->f.wg_poll_gap = gap | ((ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : dense ? dense_pre : kPvPreSleep) << 8);
         ctx->f.rec_off = nullptr, ctx->f.place_pool = nullptr;
         if (ctx->opt_place && groups.size() == 1 && gr.begin == 0 && xcds == 8 && (dual & 1)) {
           if (ctx->place_state == 0) {
@@ -458,6 +459,8 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       ctx->coop_checked_key = key;
       ctx->last_run_path = form == 3 ? 6 : form == 2 ? 5 : 1;
       ctx->last_run_groups = (int)groups.size();
+      ctx->last_run_waves_per_cu = 0;
+      for (const WaveGroup& gr : groups) ctx->last_run_waves_per_cu = std::max(ctx->last_run_waves_per_cu, (gr.count + ctx->prop.multiProcessorCount - 1) / ctx->prop.multiProcessorCount);
       ctx->parity ^= 1;
       ctx->have_prev = true;
       ctx->canon_valid = false;
@@ -576,7 +579,10 @@ int finish(flame_nltgv2_ctx* ctx) {
     ctx->have_prev = run.have_prev_before;
     ctx->fused_valid = true, ctx->canon_valid = false;
     ctx->persist_refused_topo = ctx->topo;
-    if (!(*ctx->h_err & 4)) ctx->timeouts_recovered++;
+    if (!(*ctx->h_err & 4)) {
+      ctx->timeouts_recovered++;
+      if (ctx->last_run_waves_per_cu > kCrowdedWavesPerCu) ctx->crowded_until_topo = ctx->topo + 1 + kCrowdedTopologies;
+    }
     HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, kErrBytes, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->abort_flag.p, 0, sizeof(int), ctx->stream));
     for (const flame_nltgv2_ctx::PendingOp& op : run.ops) {

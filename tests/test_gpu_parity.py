@@ -713,3 +713,46 @@ def test_record_placement_is_bit_identical_and_well_formed(env, config):
                 assert reg.layout_selftest() == 0
             else:
                 assert pi["state"] == 0 and pi["placed_records"] == 0, pi
+
+
+@pytest.mark.gpu
+def test_an_expired_run_at_high_residency_makes_the_planner_leave_room(env):
+    """A 1080p frame takes 25 of the 28 wave slots a CU really holds in the patch-per-wave form.  When such a run expires
+    (here: fault injection; in a pipeline: other kernels keeping slots busy), the following topologies are planned for at most
+    16 waves per CU -- the vertex-per-lane form for this graph -- instead of trying the same launch frame after frame; a small
+    graph is not affected.  Everything stays bit-identical to the checker."""
+    flame_amd, oracle = env
+    from flame_amd.regularizer import OPT_FAULT_INJECT
+
+    g = synth.make_graph("1920x1080", seed=12)
+    p = flame_amd.Params()
+    ref = synth.copy_graph(g)
+    with flame_amd.Regularizer(0) as reg:
+        reg.upload_graph(g)
+        reg.run(p, 20)
+        oracle.run(ref, 20)
+        assert reg.info()["last_run_path"] == 6 and reg.info()["patches"] > 20 * 256
+        reg.set_option(OPT_FAULT_INJECT, 200)
+        reg.run(p, 21)                       # expires, taken back, redone per step
+        oracle.run(ref, 21)
+        assert reg.info()["timeouts_recovered"] == 1 and reg.info()["last_run_path"] in (2, 3)
+        reg.set_option(OPT_FAULT_INJECT, 0)
+        for k in range(3):                   # new topologies (the same graph uploaded again): planned with room to spare
+            st = reg.download_state()
+            g2 = synth.copy_graph(g)
+            g2.update({key: st[key] for key in st})
+            reg.upload_graph(g2)
+            reg.run(p, 10 + k)
+            oracle.run(ref, 10 + k)
+            assert reg.info()["last_run_path"] == 5, reg.info()["last_run_path"]
+        assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS, what="after the crowded topologies")
+        assert reg.info()["timeouts_recovered"] == 1
+    small = synth.make_graph("640x480", seed=12)
+    with flame_amd.Regularizer(0) as reg:    # 4 patches per CU: an expired run changes nothing for the next topology
+        reg.upload_graph(small)
+        reg.set_option(OPT_FAULT_INJECT, 200)
+        reg.run(p, 20)
+        reg.set_option(OPT_FAULT_INJECT, 0)
+        reg.upload_graph(small)
+        reg.run(p, 20)
+        assert reg.info()["last_run_path"] == 6

@@ -94,7 +94,7 @@ def main():
     pos, data = g0["pos"].copy(), g0["data_term"].copy()
     next_id = int(feat_id.max()) + 1
     A, B = flame_amd.Regularizer(0), flame_amd.Regularizer(0)
-    A.set_option(OPT_PERSISTENT, 4)
+    A.set_option(OPT_PERSISTENT, int(os.environ.get("SOAK_FORM", "4")))  # 4 = the patch-per-wave kernel by name; 1 = the planner's choice, 2 = lane per half-edge
     B.set_option(OPT_PERSISTENT, 0)
     for r in (A, B):
         r.upload_graph(g0)
@@ -147,11 +147,11 @@ def main():
                 r.sync_graph(feat_id, pos, data, ones, edges)
             if frame < CHECK:
                 sync_oracle.sync(ref, feat_id, pos, data, ones, edges)
+            if (frame + 1) % max(1, FRAMES // 10) == 0:  # (under the lock: a context is one thread's at a time)
+                print(f"frame {frame + 1}: {len(mismatches)} mismatching, A recovered {A.info()['timeouts_recovered']} timeouts, "
+                      f"{time.time() - t0:.0f} s", flush=True)
             budget["left"] = ITERS
             frame_ready.notify_all()
-        if (frame + 1) % max(1, FRAMES // 10) == 0:
-            print(f"frame {frame + 1}: {len(mismatches)} mismatching, A recovered {A.info()['timeouts_recovered']} timeouts, "
-                  f"{time.time() - t0:.0f} s", flush=True)
     stop.set()
     with frame_ready:
         frame_ready.notify_all()
