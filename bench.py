@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip batched / other-config measurements")
     ap.add_argument("--cpu-iters", type=int, default=20000)
-    ap.add_argument("--persistent", type=int, default=1, help="0: one launch per step; 1: persistent single launch")
+    ap.add_argument("--persistent", type=int, default=1, help="0: one launch per step; 1: persistent single launch (form by size); 3 / 4: the vertex-per-lane / patch-per-wave form by name")
     return ap.parse_args()
 
 
@@ -172,7 +172,7 @@ def main():
         # bytes per launch = iters * (64V + 40E) and the launch duration is the HIP-event time of the step (events
         # recorded on the solver's stream right around the launch).  Per-step path: one k_fused_step launch per
         # iteration; the event time divided by the launches then includes the ~3.5 us dependent-launch gaps.
-        kernel = {"persistent": "k_persistent_he", "persistent-pv": "k_persistent_pv", "persistent-tv": "k_persistent_tv"}.get(run_path, "k_fused_step")
+        kernel = {"persistent-pv": "k_persistent_pv", "persistent-tv": "k_persistent_tv"}.get(run_path, "k_fused_step")
         persistent = run_path.startswith("persistent")
         launches_per_step = 1 if persistent else a.iters
         launch_us = ev_ms * 1e3 / (a.steps * launches_per_step)

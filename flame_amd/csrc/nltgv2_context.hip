@@ -71,9 +71,6 @@ void refresh_args(flame_nltgv2_ctx* ctx) {
   f.bar[0] = (float4*)ctx->bar0.p, f.bar[1] = (float4*)ctx->bar1.p;
   f.vprev = (float4*)ctx->vprev.p;
   f.xbuf = ctx->xbuf.p;
-  f.he_waves = (ctx->he_built && ctx->L.he_ok) ? ctx->L.he_waves : 0;
-  f.he_slot = (int32_t*)ctx->he_slot.p, f.he_vid = (int32_t*)ctx->he_vid.p;
-  f.he_meta = (uint32_t*)ctx->he_meta.p, f.he_wave_chain = (int32_t*)ctx->he_wave_chain.p;
   f.tv_waves = (ctx->tv_built && ctx->L.tv_ok) ? ctx->L.tv_waves : 0;
   f.tv_slot = (int32_t*)ctx->tv_slot.p, f.tv_vid = (int32_t*)ctx->tv_vid.p;
   f.tv_meta = (uint32_t*)ctx->tv_meta.p, f.tv_wave = (uint32_t*)ctx->tv_wave.p;
@@ -212,7 +209,7 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
     if (rc) return rc;
   }
   ctx->topo++;
-  ctx->he_built = ctx->tv_built = false;
+  ctx->tv_built = false;
   drop_graphs(ctx);
   refresh_args(ctx);
 
@@ -262,29 +259,10 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
   return 0;
 }
 
-// (C) / (D) rows: built and uploaded when the lane-per-half-edge / vertex-per-lane persistent form is first wanted for
-// the current topology (single frames run in the patch-per-wave form and never need them).
+// (D) rows: built and uploaded when the vertex-per-lane persistent form is first wanted for the current topology (single
+// frames run in the patch-per-wave form and never need them).
 int ensure_form_rows(flame_nltgv2_ctx* ctx, int form) {
   PackedLayout& L = ctx->L;
-  if (form == 1 && !ctx->he_built) {
-    // (C) is (E) lane for lane (the same greedy walk): converted on the device from the patch rows, no host work
-    const size_t lanes = (size_t)L.wg_count * kWave;
-    L.he_ok = L.wg_ok, L.he_waves = L.wg_count, L.he_max_chain = std::max(L.max_degree, 1), L.comp_he_wave = L.comp_wg;
-    struct { DevBuf* b; size_t bytes; } req[] = {{&ctx->he_slot, sizeof(int32_t) * lanes}, {&ctx->he_vid, sizeof(int32_t) * lanes},
-                                                 {&ctx->he_meta, sizeof(uint32_t) * lanes},
-                                                 {&ctx->he_wave_chain, sizeof(int32_t) * (size_t)L.wg_count}};
-    bool grow = false;
-    for (auto& r : req) grow = grow || r.bytes > r.b->cap;
-    if (grow) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (a buffer is about to be reallocated)
-    for (auto& r : req) {
-      const int rc = ensure(ctx, *r.b, r.bytes);
-      if (rc) return rc;
-    }
-    LAUNCHCHK(ctx, launch_he_from_patches(ctx->f, (int32_t*)ctx->he_slot.p, (int32_t*)ctx->he_vid.p, (uint32_t*)ctx->he_meta.p,
-                                          (int32_t*)ctx->he_wave_chain.p, ctx->stream));
-    ctx->he_built = true;
-    refresh_args(ctx);
-  }
   if (form == 2 && !ctx->tv_built) {
     build_tv_rows(&L);
     struct { DevBuf* b; const void* src; size_t bytes; } cp[] = {
@@ -358,7 +336,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
               &ctx->w2p, &ctx->data, &ctx->weight, &ctx->src, &ctx->dst, &ctx->alpha, &ctx->beta, &ctx->q1,
               &ctx->q2, &ctx->q3, &ctx->row_ptr, &ctx->half, &ctx->slice_row, &ctx->perm, &ctx->pdeg,
               &ctx->rec_nbr, &ctx->rec_edge, &ctx->edge_src_slot, &ctx->hrec, &ctx->hq, &ctx->vstate, &ctx->hq_alt, &ctx->vstate_alt, &ctx->cost_terms, &ctx->run_tail,
-              &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->xbuf, &ctx->abort_flag, &ctx->he_slot, &ctx->he_vid, &ctx->he_meta, &ctx->he_wave_chain, &ctx->tv_slot, &ctx->tv_vid, &ctx->tv_meta, &ctx->tv_wave, &ctx->err,
+              &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->xbuf, &ctx->abort_flag, &ctx->tv_slot, &ctx->tv_vid, &ctx->tv_meta, &ctx->tv_wave, &ctx->err,
               &ctx->cost_out, &ctx->img_ref, &ctx->img_cmp, &ctx->photo_err, &ctx->r_tris, &ctx->r_valid, &ctx->r_keys,
               &ctx->r_img, &ctx->r_cov, &ctx->r_vtx, &ctx->r_val, &ctx->wg_slot, &ctx->wg_vid, &ctx->wg_meta, &ctx->wg_nbr,
               &ctx->wg_fetch, &ctx->wg_info, &ctx->wg_v0, &ctx->probe, &ctx->snap_hq, &ctx->snap_vstate, &ctx->snap_bar, &ctx->iperm,
@@ -410,7 +388,7 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
       ctx->opt_block_waves = value;
       return 0;
     case FLAME_NLTGV2_OPT_PERSISTENT:
-      if (value < 0 || value > 4) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      if (value < 0 || value > 4 || value == 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // (2: the retired lane-per-half-edge form)
       ctx->opt_persistent = value;
       return 0;
     case FLAME_NLTGV2_OPT_PLACEMENT:
@@ -476,7 +454,7 @@ int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info) {
   std::snprintf(info->device_name, sizeof(info->device_name), "%s", ctx->prop.name);
   std::snprintf(info->gcn_arch, sizeof(info->gcn_arch), "%s", ctx->prop.gcnArchName);
   info->last_run_path = ctx->last_run_path;
-  info->he_waves = ctx->L.wg_ok ? ctx->L.wg_count : 0;  // (the same greedy walk as the patches)
+  info->he_waves = 0;  // (the lane-per-half-edge form was retired in round 3; the field stays for the ABI)
   if (ctx->have_graph && !ctx->tv_built) {  // the vertex-per-lane rows are built on demand; a caller sizing a batch asks here
     ctx->L.tv_waves = 0;
     build_tv_rows(&ctx->L);  // host table only; the upload happens when the form is first used
@@ -550,11 +528,6 @@ int flame_nltgv2_layout_selftest(flame_nltgv2_ctx* ctx, int64_t* mismatches) {
       e |= cmp(ctx->wg_slot, H.wg_slot.data(), 4 * lanes) | cmp(ctx->wg_vid, H.wg_vid.data(), 4 * lanes) |
            cmp(ctx->wg_meta, H.wg_meta.data(), 4 * lanes) | cmp(ctx->wg_nbr, H.wg_nbr.data(), 4 * lanes) |
            cmp(ctx->wg_fetch, H.wg_fetch.data(), 4 * lanes) | cmp(ctx->wg_info, H.wg_info.data(), 4 * H.wg_info.size());
-    if (ctx->he_built)  // (C), converted on the device from (E), against the host's own walk
-      e |= cmp(ctx->he_slot, H.he_slot.data(), 4 * H.he_slot.size()) | cmp(ctx->he_vid, H.he_vid.data(), 4 * H.he_vid.size()) |
-           cmp(ctx->he_meta, H.he_meta.data(), 4 * H.he_meta.size()) |
-           cmp(ctx->he_wave_chain, H.he_wave_chain.data(), 4 * H.he_wave_chain.size());
-    if (ctx->he_built) bad += (H.he_waves != L.he_waves) + (H.he_max_chain != L.he_max_chain) + (H.comp_he_wave != L.comp_he_wave);
     if (e) return fail(ctx, FLAME_NLTGV2_ERR_HIP);
   }
   if (bad == 0 && ctx->place_state == 1 && ctx->place_topo == ctx->topo && L.wg_ok) {

@@ -35,9 +35,6 @@ namespace host {
 
 constexpr int kGraphChunk = 256;      // steps per captured hipGraph (even: keeps ping-pong parity)
 constexpr int kMaxCachedGraphs = 6;
-constexpr int kHeWavesPerCu = 24;      // k_persistent_he is planned for at most this many waves per CU (six 256-thread blocks) ...
-constexpr int kHeWavesPerCuReal = 28;  // ... of the 28 really resident (82 SGPRs -> 96 + the trap handler's 16: seven waves per SIMD);
-                                       // all of them only where the form is asked for by name (a row-packed 1080p layout has 25 per CU)
 constexpr int kTvLdsWavesPerCu = 16;   // ... with the slot constants in LDS (<= 128 VGPRs -> 4 waves per SIMD; 10 KB LDS per wave = all 160 KB)
 constexpr size_t kXbufBytesPerVertex = 8 * 16 + 4;  // exchange buffers: up to four step buffers x (remote + same-XCD copy) of
                                                     // 16-byte records (the patch-per-wave form; the others use two) + the XCC table
@@ -54,9 +51,8 @@ constexpr int kPvPollGap = 2;          // k_persistent_pv polls: re-loading only
                                        // with the shorter hand-off path of its final form no pause wins by 3-4 % at 640x480)
 constexpr int kTvWavesPerCu = 8;       // residency of k_persistent_tv (<= 256 VGPRs -> 2 waves per SIMD)
 constexpr int kDualMinWavesPerCu = 0;  // auto: exchange through the XCD's L2 when more waves than this share a CU
-// x64-cycle sleep between publishing and the first neighbour poll (measured optimum, r01 sweep: he 6 at
-// <= 12 waves/CU, 10 above; tv is insensitive, shortest wins)
-constexpr int kPreSleepHe = 6, kPreSleepHeDense = 10, kPreSleepHeOneXcd = 4, kPreSleepTv = 2;
+// x64-cycle sleep between publishing and the first neighbour poll of k_persistent_tv (insensitive, shortest wins)
+constexpr int kPreSleepTv = 2;
 constexpr int32_t kFeatDirectMax = 1 << 22;  // sync_graph: feature ids below this are looked up in a plain table (16 MB at most), others hashed
 constexpr size_t kErrBytes = 16 * sizeof(int);  // the flag word + what the first expired wait reports (report_expired)
 constexpr unsigned kMaxSpins = 1u << 20;  // bound of every neighbour wait in the persistent run (~1 s of polling bursts)
@@ -221,7 +217,7 @@ struct flame_nltgv2_ctx {
   } pending;
   DevBuf snap_hq, snap_vstate, snap_bar;
   DevBuf iperm, order_m, rid_of;   // per-vertex tables the device-side layout expansion reads (nltgv2_layout.hip)
-  bool he_built = false, tv_built = false;  // layouts (C) / (D) exist for the current topology (built on demand)
+  bool tv_built = false;  // layout (D) exists for the current topology (built on demand)
   void* h_stage = nullptr;         // pinned staging buffer of the uploads
   DevBuf d_stage;                 // ... and its device-side landing area (one copy; k_scatter distributes)
   size_t stage_cap = 0;
@@ -241,7 +237,7 @@ struct flame_nltgv2_ctx {
   bool tail_valid = false;
   std::vector<float> h_terms;
   DevBuf hq_alt, vstate_alt;  // the other copies of hq / vstate: a persistent run writes there, success swaps the roles
-  DevBuf xbuf, abort_flag, he_slot, he_vid, he_meta, he_wave_chain, tv_slot, tv_vid, tv_meta, tv_wave;
+  DevBuf xbuf, abort_flag, tv_slot, tv_vid, tv_meta, tv_wave;
   DevBuf wg_slot, wg_vid, wg_meta, wg_nbr, wg_fetch, wg_info, wg_v0, wg_vfirst, probe, progress;
   // misc
   DevBuf err, cost_out, img_ref, img_cmp, photo_err, r_tris, r_valid, r_keys, r_img, r_cov, r_vtx, r_val;

@@ -82,11 +82,6 @@ struct FusedArgs {
   float4* bar[2] = {nullptr, nullptr};  // ping-pong {x_bar,w1_bar,w2_bar,-}
   float4* vprev = nullptr;  // {x_prev,w1_prev,w2_prev,-} written by the last step of a run
   void* xbuf = nullptr;  // persistent run: [R0|L0|R1|L1|XCC] exchange buffer, see nltgv2_persistent.hip
-  int he_waves = 0;                    // persistent run: wave-aligned half-edge rows (nltgv2_pack.hpp (C))
-  int32_t* he_slot = nullptr;
-  int32_t* he_vid = nullptr;
-  uint32_t* he_meta = nullptr;
-  int32_t* he_wave_chain = nullptr;
   int tv_waves = 0;                    // persistent run, vertex-per-lane rows (nltgv2_pack.hpp (D))
   int32_t* tv_slot = nullptr;
   int32_t* tv_vid = nullptr;
@@ -166,8 +161,6 @@ int pv_real_waves_per_simd(bool verify_or_probe);
 const void* persistent_tv_kernel(bool static_in_lds, int waves_per_block, unsigned* lds_bytes);  // nltgv2_persistent_tv.hip
 // device-side expansion of the layout arrays (nltgv2_layout.hip)
 int launch_build_sell(const CanonArgs& c, const FusedArgs& a, const int32_t* iperm, hipStream_t s);
-int launch_he_from_patches(const FusedArgs& a, int32_t* he_slot, int32_t* he_vid, uint32_t* he_meta, int32_t* he_wave_chain,
-                           hipStream_t s);
 int launch_build_patches(const CanonArgs& c, const FusedArgs& a, const int32_t* wg_v0, const int32_t* order_m,
                          const int32_t* rid_tab, const uint8_t* vfirst, const int32_t* iperm, hipStream_t s);
 int launch_save_prev(const CanonArgs& c, hipStream_t s);

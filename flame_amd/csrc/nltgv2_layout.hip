@@ -152,38 +152,6 @@ k_build_patch(const int n_patches, int32_t* __restrict__ wg_info, const int32_t*
   if (lane == 0) wg_info[4 * p + 1] = n_fetch;
 }
 
-// (C) lane-per-half-edge rows from the patch rows: the two come from the same greedy walk (a vertex's lanes never straddle
-// a wave, a component begins a new wave), so wave w of (C) is patch w of (E), lane for lane -- only the meta word is
-// encoded differently (position in the vertex | tail lane << 6 | flags) and (C) wants the longest chain of each wave.
-constexpr uint32_t kHeTail = 1u << 12, kHeActive = 1u << 13, kHeValid = 1u << 14;
-__global__ void __launch_bounds__(64)
-k_he_from_patches(const int n_patches, const int32_t* __restrict__ wg_slot, const int32_t* __restrict__ wg_vid,
-                  const uint32_t* __restrict__ wg_meta, int32_t* __restrict__ he_slot, int32_t* __restrict__ he_vid,
-                  uint32_t* __restrict__ he_meta, int32_t* __restrict__ he_wave_chain) {
-  const int p = blockIdx.x;
-  if (p >= n_patches) return;
-  const int lane = threadIdx.x;
-  const size_t hl = (size_t)p * 64 + lane;
-  const uint32_t m = wg_meta[hl];
-  uint32_t hm = 0u;
-  int need = 0;
-  if (m & kWgValid) {
-    const int first = (int)(m & 63u), deg = (int)((m >> 6) & 127u);
-    need = deg > 1 ? deg : 1;
-    hm = (uint32_t)(lane - first) | ((uint32_t)(first + need - 1) << 6) | kHeValid;
-    if (m & kWgTail) hm |= kHeTail;
-    if (m & kWgActive) hm |= kHeActive;
-  }
-  he_slot[hl] = wg_slot[hl], he_vid[hl] = wg_vid[hl], he_meta[hl] = hm;
-  int mx = need;
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    const int o = __shfl_xor(mx, d, 64);
-    mx = o > mx ? o : mx;
-  }
-  if (lane == 0) he_wave_chain[p] = mx > 1 ? mx : 1;
-}
-
 // ---- record placement -------------------------------------------------------------------------------------------------
 // The hand-off of a 16-byte record from one XCD to another goes through the memory channel the record's address belongs
 // to, and how long that takes depends on where that channel sits relative to the two XCDs: measured on MI355X
@@ -342,13 +310,6 @@ inline dim3 grid1d(long n, int block = 256) { return dim3((unsigned)((n + block 
 
 }  // namespace
 
-int launch_he_from_patches(const FusedArgs& a, int32_t* he_slot, int32_t* he_vid, uint32_t* he_meta, int32_t* he_wave_chain,
-                           hipStream_t s) {
-  if (a.wg_count <= 0) return 0;
-  hipLaunchKernelGGL(k_he_from_patches, dim3((unsigned)a.wg_count), dim3(64), 0, s, a.wg_count, a.wg_slot, a.wg_vid, a.wg_meta, he_slot,
-                     he_vid, he_meta, he_wave_chain);
-  return (int)hipGetLastError();
-}
 
 int launch_build_sell(const CanonArgs& c, const FusedArgs& a, const int32_t* iperm, hipStream_t s) {
   const int n_packed = a.n_slices * 64;

@@ -46,7 +46,7 @@ constexpr uint32_t kRoleBit = 0x80000000u;  // set: the owning vertex is the TAR
 struct PackedLayout {
   int32_t V = 0, E = 0, n_slices = 0, max_degree = 0;
   int64_t rows = 0;                    // 64-wide rows actually used (excluding kRowPad)
-  std::vector<int32_t> order_m;        // [V] the vertices in (component, Morton) order: the walk of (C), (D), (E)
+  std::vector<int32_t> order_m;        // [V] the vertices in (component, Morton) order: the walk of (D) and (E)
   std::vector<int32_t> rid_of;         // [V] inverse of order_m: a vertex's position in the walk = its record id in (E)
   std::vector<int32_t> perm;           // [n_slices*64] packed slot -> original vertex (-1 padding)
   std::vector<int32_t> iperm;          // [V] original vertex -> packed slot
@@ -58,15 +58,6 @@ struct PackedLayout {
   std::vector<int32_t> row_ptr;        // [V+1]  (A)
   std::vector<uint32_t> half;          // [2E]   (A) edge id | role bit, ascending edge id per vertex
   std::vector<int32_t> half_nbr;       // [2E]   (A) the vertex at the other end of that half-edge (host only)
-  // (C) wave-aligned half-edge rows of the persistent run: one LANE per half-edge, the lanes of a
-  // vertex contiguous (ascending edge id) inside ONE wave; isolated vertices get one idle lane.
-  bool he_ok = false;                  // false: some vertex has more than 64 incident edges
-  int32_t he_waves = 0;
-  int32_t he_max_chain = 0;            // longest per-wave chain (= max degree)
-  std::vector<int32_t> he_slot;        // [he_waves*64] slot of this half-edge in the SELL arrays, -1 idle
-  std::vector<int32_t> he_vid;         // [he_waves*64] packed vertex owning the lane, -1 unused lane
-  std::vector<uint32_t> he_meta;       // [he_waves*64] pos | tail_lane<<6 | is_tail<<12 | active<<13 | valid<<14
-  std::vector<int32_t> he_wave_chain;  // [he_waves] max(1, max degree) of the wave's vertices
   // (D) one-vertex-per-lane rows of the register-resident persistent run (throughput form): a lane
   // holds up to kTvSlots half-edges; a vertex of higher degree occupies ceil(deg/kTvSlots) ADJACENT
   // lanes of one wave ("chain"), the last of which owns the vertex.
@@ -77,11 +68,11 @@ struct PackedLayout {
   std::vector<uint32_t> tv_meta;  // [tv_waves*64] nslots | chain_idx<<4 | owner_lane<<10 | owner<<16 | valid<<17
   std::vector<uint32_t> tv_wave;  // [tv_waves] passes | has_chain<<8 | slots used in pass 0 <<16 | in later passes <<20
   // connected components (= frames of a batch) are contiguous in packed order and never share a wave of
-  // (C)/(D): a batch too large to be resident at once is run group of components by group
+  // (D) / a patch of (E): a batch too large to be resident at once is run group of components by group
   std::vector<int32_t> comp_start;     // [n_comp+1] first packed vertex of each component
-  std::vector<int32_t> comp_he_wave;   // [n_comp+1] first (C) wave of each component
   std::vector<int32_t> comp_tv_wave;   // [n_comp+1] first (D) wave of each component
-  // (E) patch-per-wave rows of the persistent run (k_persistent_pv): the half-edge lanes of (C), one wave = one compact
+  // (E) patch-per-wave rows of the persistent run (k_persistent_pv): one LANE per half-edge, the lanes of a vertex contiguous (ascending edge id) inside ONE wave
+  // (isolated vertices get one idle lane), one wave = one compact
   // Morton patch of vertices.  Inside the patch the exchange goes through LDS; only the DISTINCT vertices of other
   // patches that the patch touches are fetched from memory (one lane each, sorted by record id), and only vertices
   // with a neighbour in another patch publish.  Records are numbered in walk order (rid), so a patch's records are
@@ -126,8 +117,7 @@ inline uint32_t morton_spread16(uint32_t v) {
 }
 
 // Where the next vertex of the walk goes in the current wave: lanes back to back, or -- row-packed (see PackedLayout::
-// wg_rowpack) -- first fit into the wave's four 16-lane rows, a vertex's lanes contiguous inside one row.  Shared by the
-// walks of (C) and (E), which must cut the same waves.
+// wg_rowpack) -- first fit into the wave's four 16-lane rows, a vertex's lanes contiguous inside one row.
 struct WaveFit {
   bool rowpack = false;                                  // the layout is row-packed wherever the degrees allow
   bool rows = false;                                     // ... and so is the current wave
@@ -172,62 +162,8 @@ struct WaveFit {
 };
 
 // Returns FLAME_NLTGV2_OK or FLAME_NLTGV2_ERR_INVALID_ARG.
-// ---- (C): needs (B)'s header (iperm, pdeg, slice_row), comp_start and order_m.  Built on demand: only the lane-per-half-edge
-// persistent form reads it.
-inline void build_he_rows(PackedLayout* L) {
-  const int32_t V = L->V, maxdeg = L->max_degree;
-  const std::vector<int32_t>& order_m = L->order_m;
-  // ---- (C) wave-aligned half-edge rows -------------------------------------------------------------
-  L->he_ok = (maxdeg <= kWave);
-  L->he_waves = 0;
-  L->he_max_chain = 0;
-  L->he_slot.clear(), L->he_vid.clear(), L->he_meta.clear(), L->he_wave_chain.clear();
-  L->comp_he_wave.clear();
-  if (L->he_ok && V > 0) {
-    WaveFit fit;  // (starts full: forces a new wave for the first vertex)
-    fit.rowpack = L->wg_rowpack;
-    size_t next_comp = 0;
-    for (int32_t i = 0; i < V; ++i) {
-      const int32_t s = L->iperm[order_m[i]];  // packed index of the i-th vertex in Morton order
-      const int32_t d = L->pdeg[s];
-      const int32_t need = std::max(d, 1);
-      const bool comp_begin = next_comp < L->comp_start.size() && L->comp_start[next_comp] == i;
-      if (comp_begin) {
-        L->comp_he_wave.push_back(L->he_waves);
-        ++next_comp;
-      }
-      int32_t fill = comp_begin ? -1 : fit.place(need);
-      if (fill < 0) {
-        L->he_slot.resize(L->he_slot.size() + kWave, -1);
-        L->he_vid.resize(L->he_vid.size() + kWave, -1);
-        L->he_meta.resize(L->he_meta.size() + kWave, 0u);
-        L->he_wave_chain.push_back(1);
-        L->he_waves++;
-        fit.open(need);
-        fill = fit.place(need);
-      }
-      const size_t base = static_cast<size_t>(L->he_waves - 1) * kWave + fill;
-      const int32_t tail_lane = fill + need - 1;
-      const int64_t row0 = L->slice_row[s / kWave];
-      for (int32_t k = 0; k < need; ++k) {
-        uint32_t m = static_cast<uint32_t>(k) | (static_cast<uint32_t>(tail_lane) << 6) | kHeValid;
-        if (k == need - 1) m |= kHeTail;
-        if (k < d) {
-          m |= kHeActive;
-          L->he_slot[base + k] = static_cast<int32_t>((row0 + k) * kWave + (s % kWave));
-        }
-        L->he_vid[base + k] = s;
-        L->he_meta[base + k] = m;
-      }
-      L->he_wave_chain.back() = std::max(L->he_wave_chain.back(), need);
-      L->he_max_chain = std::max(L->he_max_chain, need);
-    }
-    L->comp_he_wave.push_back(L->he_waves);
-  }
-
-}
-
-// ---- (D): as (C); only the vertex-per-lane persistent form reads it.
+// ---- (D): needs (B)'s header (iperm, pdeg, slice_row), comp_start and order_m.  Built on demand: only the vertex-per-lane persistent
+// form reads it.
 inline void build_tv_rows(PackedLayout* L) {
   const int32_t V = L->V, maxdeg = L->max_degree;
   const std::vector<int32_t>& order_m = L->order_m;
@@ -305,7 +241,7 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
   if (L->max_degree > kWave || V <= 0) return;
   L->wg_vfirst.resize(static_cast<size_t>(V));
   L->wg_info.reserve(((static_cast<size_t>(2) * L->E + V) * 9 / 8 / T + L->comp_start.size() + 2) * 4);
-  // pass 1 (host, per vertex): the greedy walk of (C) -- a vertex's lanes never straddle two waves, a component begins a
+  // pass 1 (host, per vertex): the greedy walk -- a vertex's lanes never straddle two waves, a component begins a
   // new wave.  A vertex's record id is its position in the walk (L->rid_of).  Per patch: first record id, vertex count,
   // slab stride (its largest degree rounded up to 4, at least 8).
   int32_t n_local = 0, max_deg = 1;
@@ -412,7 +348,7 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
 }
 
 // host_expand = false: only what needs the host (per-vertex tables: (A), the walk order, (B)'s slice table, (E)'s patch
-// walk); the per-slot / per-lane arrays of (B) and (E) are then produced on the device (nltgv2_layout.hip) and (C), (D)
+// walk); the per-slot / per-lane arrays of (B) and (E) are then produced on the device (nltgv2_layout.hip) and (D)
 // on demand.  host_expand = true: everything here -- the reference the device expansion is checked against, and what the
 // CPU test-suite looks at.
 inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L, bool host_expand = true, bool rowpack = true,
@@ -508,7 +444,7 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L, bool host_
       order.swap(tmp);
     }
   }
-  // The persistent layouts (C)/(D) walk the vertices in this pure Morton order: a wave then holds a compact
+  // The persistent layouts (D)/(E) walk the vertices in this pure Morton order: a wave then holds a compact
   // patch, so its graph neighbours sit in few other waves (fewer producers to wait for, better L2 locality).
   // Only the SELL-64 slices of the per-step sweep want the degree-sorted order below (uniform slice widths).
   L->order_m = order;
@@ -595,7 +531,6 @@ inline int build_layout(const flame_nltgv2_graph* g, PackedLayout* L, bool host_
   PROF_T(3);
   build_patch_rows(g, L, order_m, host_expand, rowpack, rowpack_max_patches);
   PROF_T(4);
-  if (host_expand) build_he_rows(L);  // (after (E): the two walks cut the same waves, row-packed or not -- L->wg_rowpack)
   PROF_T(5);
   if (host_expand) build_tv_rows(L);
   PROF_T(6);

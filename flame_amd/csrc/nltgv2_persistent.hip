@@ -1,6 +1,6 @@
 // nltgv2_persistent.hip -- the persistent single-launch kernels of the NLTGV2-L1 solver for gfx950 (MI355X, CDNA4): n steps in ONE
-// launch as pure dataflow between resident waves -- k_persistent_he (a lane per half-edge), k_persistent_pv (a patch per wave,
-// the dominant kernel of the bench), k_persistent_tv (a vertex per lane) -- their launcher and the residency rule.
+// launch as pure dataflow between resident waves -- k_persistent_pv (a patch per wave, a lane per half-edge: the dominant kernel
+// of the bench); k_persistent_tv (a vertex per lane) is in nltgv2_persistent_tv.hip -- their launcher and the residency rule.
 // Arithmetic and its citations: nltgv2_device.hpp; compiled with -ffp-contract=off like nltgv2_kernels.hip.
 #include "nltgv2_device.hpp"
 
@@ -9,300 +9,39 @@ namespace flame_hip {
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-// Persistent run: ONE launch == n_iters reference step()s, for graphs whose half-edges all fit on
-// the chip at once (one LANE per half-edge, the host admits <= 24 waves per CU).
+// Persistent run: ONE launch == n_iters reference step()s, as pure dataflow between resident waves.
 //
-// Why: a dependent kernel boundary costs ~3.5 us on this part (measured: trivial dependent kernels
-// replay at that period) while one step of a 640x480 graph is < 1 us of work, so one-launch-per-step
-// is launch bound.  Inside one launch the only thing a step needs from other waves is the
-// (x_bar,w1_bar,w2_bar) of graph neighbours, and a 16-byte write-through record crosses the chip
-// in ~0.45-0.55 us (tools/hop_bench.hip) -- so the steps are run as pure DATAFLOW:
+// Why: a dependent kernel boundary costs ~3.5 us on this part (measured: trivial dependent kernels replay at that period) while
+// one step of a 640x480 graph is < 1 us of work, so one-launch-per-step is launch bound.  Inside one launch the only thing a
+// step needs from other waves is the (x_bar, w1_bar, w2_bar) of graph neighbours, and a 16-byte write-through record crosses
+// the chip in ~0.45-0.55 us (tools/hop_bench.hip).  The protocol (both persistent kernels, this one and k_persistent_tv):
 //
-//   * lane <-> half-edge; the lanes of a vertex are contiguous (ascending edge id) inside one wave
-//     and its last lane ("tail") owns the vertex.  Records, weights and the private (q1,q2,q3) copy
-//     of every half-edge stay in REGISTERS for the whole run (loaded once from the SELL arrays).
-//   * every vertex publishes ONE naturally aligned 16-byte record {x_bar, w1_bar, w2_bar, tag =
-//     step number} with ONE write-through (sc1) dwordx4 store; every half-edge lane re-reads its
-//     neighbour's record (L1-bypassing sc1 dwordx4 load) until the tag equals the step it needs.
-//     The data is its own flag: no fences, no flag words, no grid barrier.  (A lane's aligned
-//     16-byte access is a single request inside one cache line; tearing between value and tag has
-//     not been observed on gfx950 and would show up as a bit mismatch in the parity tests, which
-//     compare every run of this kernel with the CPU checker exactly.)
-//   * two record buffers alternate by step parity: a vertex can only overwrite its step-s record
-//     with step s+2 after ALL its neighbours published s+1, i.e. after they consumed s.  Tags grow
-//     monotonically over the context's lifetime and every launch starts from a fresh tag, so stale
-//     records never match.
-//   * the primal accumulation of a vertex must follow the reference's edge order exactly, so the
-//     per-half-edge contributions are combined by an ORDERED segmented chain: step j moves the
-//     running sums one lane up (DPP wave_shr:1, no LDS) and the lane at position j adds its
-//     contribution; after max-degree steps the tail lane holds bit-exactly what the reference's
-//     sequential scatter (cc:120-142) produces.  Identity contributions are -0.0f (x + -0.0f == x
-//     for every x, including both zeros).
+//   * the records, weights and the private (q1, q2, q3) copy of every half-edge stay in REGISTERS for the whole run (loaded
+//     once from the SELL arrays);
+//   * every vertex that another wave reads publishes ONE naturally aligned 16-byte record {x_bar, w1_bar, w2_bar, tag = step
+//     number} with ONE write-through (sc1) dwordx4 store; a consumer re-reads the record (L1-bypassing sc1 access) until the
+//     tag equals the step it needs.  The data is its own flag: no fences, no flag words, no grid barrier.  (A lane's aligned
+//     16-byte access is a single request inside one cache line; tearing between value and tag has not been observed on gfx950,
+//     would show up as a bit mismatch in the parity tests, and FLAME_NLTGV2_OPT_VERIFY_RECORDS checks for it at run time.)
+//   * two record buffers alternate by step parity: a vertex can only overwrite its step-s record with step s+2 after ALL its
+//     neighbours published s+1, i.e. after they consumed s.  Tags grow monotonically over the context's lifetime and every
+//     launch starts from a fresh tag, so stale records never match.  Each buffer holds a remote copy (write-through) and a copy
+//     for readers on the same XCD (their L2), chosen per record from the true XCC ids the waves publish at the start.
+//   * the primal accumulation of a vertex follows the reference's edge order exactly (cc:120-142): an ORDERED sum, identity
+//     contributions are -0.0f (x + -0.0f == x for every x, including both zeros).
 //
-// All waves must be resident (cooperative launch: the runtime checks the grid); every wait is
-// bounded and reports through `err`.  The run is transactional: it reads hq/vstate/bar_in and writes hq_out/
-// vstate_out/bar_out (the other copies), so the host can take a timed-out run back and redo it per step.
+// All waves must be resident (the first launch of a topology is cooperative: the runtime checks the grid; the planner knows
+// what a CU really holds); every wait is bounded and reports through `err`.  The run is transactional: it reads hq / vstate /
+// bar_in and writes hq_out / vstate_out / bar_out (the other copies), so the host can take an expired run back and redo it per
+// step.  (Round 1's first form, one lane per half-edge with every lane polling its own neighbour from memory -- k_persistent_he
+// -- was retired in round 3: the patch-per-wave form below runs everything it ran, faster)
 // ------------------------------------------------------------------------------------------------
 
-constexpr unsigned kHeTailBit = 1u << 12, kHeActiveBit = 1u << 13, kHeValidBit = 1u << 14;
-
-__global__ void __launch_bounds__(256)
-k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd, const int32_t* __restrict__ he_slot,
-                const int32_t* __restrict__ he_vid, const uint32_t* __restrict__ he_meta,
-                const int32_t* __restrict__ he_wave_chain, const int4* hrec, const float4* hq, const float4* vstate,
-                float4* hq_out, float4* vstate_out, const float2* vaux, const float4* bar_in, float4* bar_out,
-                float4* vprev, void* xbuf, const int rec_bytes, const int dual_arg, const unsigned tag0, const int n_iters,
-                const unsigned max_spins_arg, const int presleep, const SolverParams p, int* __restrict__ err,
-                int* __restrict__ abort_flag, const int32_t* __restrict__ perm, const RunTail* __restrict__ tail) {
-  const unsigned max_spins = max_spins_arg & 0x7fffffffu;
-  const int dual = dual_arg & 1;       // bit 0: same-XCD exchange through L2
-  const int verify = dual_arg >> 1;    // bit 1: re-read every record after its tag matched and compare all four dwords
-                                       // (FLAME_NLTGV2_OPT_VERIFY_RECORDS); bit 2: test hook, corrupts one re-read
-  const int lane = threadIdx.x & 63;
-  const int wpb = blockDim.x >> 6;
-  const int b = blockIdx.x;
-  const int xcd = b & 7;
-  const int idx = (b >> 3) * wpb + (threadIdx.x >> 6);
-  if (idx >= waves_per_xcd) return;
-  if (xcd * waves_per_xcd + idx >= n_waves) return;
-  const int w = wave_begin + xcd * waves_per_xcd + idx;  // this launch covers waves [wave_begin, +n_waves)
-
-  const size_t hl = (size_t)w * 64 + lane;
-  const unsigned meta = he_meta[hl];
-  const int slot = he_slot[hl];
-  const int pv = he_vid[hl];
-  const int chain = __builtin_amdgcn_readfirstlane(he_wave_chain[w]);
-  const int pos = (int)(meta & 63u);
-  const int tail_lane = (int)((meta >> 6) & 63u);
-  const bool is_tail = (meta & kHeTailBit) != 0u;
-  const bool active = (meta & kHeActiveBit) != 0u;
-  const bool valid = (meta & kHeValidBit) != 0u;
-
-  int4 rec = make_int4(0, 0, 0, 0);
-  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (active) {
-    rec = hrec[slot];
-    q = hq[slot];
-  }
-  const bool is_target = rec.x < 0;
-  const int nbr_off = (int)(((unsigned)rec.x & 0x07ffffffu) << 4);
-  const float alpha = __int_as_float(rec.y), dx = __int_as_float(rec.z), dy = __int_as_float(rec.w);
-  const float beta = q.w;
-  float q1 = q.x, q2 = q.y, q3 = q.z;
-
-  float4 st = make_float4(0.f, 0.f, 0.f, 0.f), bs = make_float4(0.f, 0.f, 0.f, 0.f);
-  float2 aux = make_float2(0.f, 0.f);
-  if (valid) {  // every lane of a vertex reads the same words (broadcast load)
-    st = vstate[pv];
-    aux = vaux[pv];
-    bs = bar_in[pv];
-  }
-  const float data = st.w;
-  const float lam_w = p.data_factor * aux.x;
-  float x = st.x, w1 = st.y, w2 = st.z;         // invariant: every lane holds its vertex's state
-  float xb = bs.x, w1b = bs.y, w2b = bs.z;
-  float x_prev = x, w1_prev = w1, w2_prev = w2;
-  bool ok = true;
-  bool timed_out = false, torn = false;
-  const int ps = presleep;  // x64 cycles between publishing and the first poll (fixed per launch)
-
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(xbuf);
-  const int my_off = pv << 4;
-  const int S = rec_bytes, par = 2 * rec_bytes;
-  int poll_off = nbr_off;  // remote copy by default
-
-  if (dual) {  // one-time XCC exchange: which neighbours run on my XCD?
-    const unsigned my_xcc = read_xcc_id();
-    const unsigned want = (tag0 & 0x0fffffffu) << 4;
-    if (is_tail) __builtin_amdgcn_raw_buffer_store_b32((int)(want | my_xcc), rx, 4 * S + (pv << 2), 0, kAuxSc1);
-    bool pend = active;
-    unsigned spins = 0;
-    unsigned got = 0;
-    for (;;) {
-      if (pend) {
-        int o = 4 * S + (nbr_off >> 2);
-        asm volatile("" : "+v"(o)::"memory");
-        got = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, kAuxSc1);
-        pend = ((got & ~15u) != want);
-      }
-      if (!__any(pend)) break;
-      if (++spins > max_spins) {
-        timed_out = true;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-    if (active && !timed_out && (got & 15u) == my_xcc) poll_off = nbr_off + S;
-  }
-
-  // test hook (FLAME_NLTGV2_OPT_FAULT_INJECT): the first wave of the launch never publishes its first record, its
-  // neighbours' waits expire and the run is reported as timed out
-  const bool mute = (max_spins_arg >> 31) != 0u && w == wave_begin;
-  if (is_tail && !timed_out && !mute) {  // publish bar(tag0); tag0 is fresh, leftovers of earlier runs cannot match
-    v4i_t o;
-    o.x = __float_as_int(xb), o.y = __float_as_int(w1b), o.z = __float_as_int(w2b), o.w = (int)tag0;
-    const int so = (tag0 & 1u) ? par : 0;
-    __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
-    if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
-  }
-
-  for (int it = 0; it < n_iters && !timed_out; ++it) {
-    const unsigned s = tag0 + (unsigned)it;
-    // ---- wait for the neighbour's bar(s) ---------------------------------------------------------
-    // ONE poll in flight per wave, and none before the record can plausibly be there: polling is
-    // not free on this chip -- every sc1 load of a written-through line is a trip to the memory side,
-    // and thousands of them in flight slow down the very stores they are waiting for (measured: a
-    // 4-deep poll ring made the step 45 % slower).  So: sleep `ps` x 64 cycles after publishing (the
-    // neighbours publish at about the same time; their records need ~0.45 us to become visible),
-    // then poll, pausing 64 cycles between misses.  `ps` is fixed per launch (the host picks it from the
-    // number of waves per CU; a per-wave adaptive rule -- lengthen on a miss, shorten on a clean step --
-    // drifted late and measured 3-17 % slower than the best fixed value).  The offset goes through an opaque copy
-    // so the compiler re-issues the load (it would otherwise hoist it out of the spin).
-    v4i_t g = {0, 0, 0, 0};
-    bool pend = active;
-    unsigned spins = 0;
-    const int so_in = (s & 1u) ? par : 0;
-    for (int z = 0; z < ps; ++z) __builtin_amdgcn_s_sleep(1);
-    for (;;) {
-      if (pend) {
-        int o = poll_off;
-        asm volatile("" : "+v"(o)::"memory");
-        g = __builtin_amdgcn_raw_buffer_load_b128(rx, o, so_in, kAuxSc1);
-        pend = ((unsigned)g.w != s);
-      }
-      if (!__any(pend)) break;
-      ++spins;
-      if ((spins & 63u) == 0u) {
-        const int ab = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ab != 0 || spins > max_spins) {
-          timed_out = true;
-          break;
-        }
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    if (timed_out) break;
-    if (verify) {  // the record is final once its tag is visible: a second read must return the same 16 bytes
-      int o = poll_off;
-      asm volatile("" : "+v"(o)::"memory");
-      v4i_t g2 = __builtin_amdgcn_raw_buffer_load_b128(rx, o, so_in, kAuxSc1);
-      if ((verify & 2) && it == 2 && w == wave_begin && lane == 0) g2.x ^= 0x00400000;
-      if (__any(active && (g2.x != g.x || g2.y != g.y || g2.z != g.z || g2.w != g.w))) {
-        torn = true;
-        break;
-      }
-    }
-
-    __builtin_amdgcn_s_setprio(3);  // from the records' arrival to the publish this wave goes before the polling ones (k_persistent_pv)
-    // ---- dual update of this half-edge's private q copy (cc:99-110) ------------------------------
-    const float nxb = __int_as_float(g.x), nw1b = __int_as_float(g.y), nw2b = __int_as_float(g.z);
-    const float xbi = is_target ? nxb : xb, xbj = is_target ? xb : nxb;
-    const float w1bi = is_target ? nw1b : w1b, w1bj = is_target ? w1b : nw1b;
-    const float w2bi = is_target ? nw2b : w2b, w2bj = is_target ? w2b : nw2b;
-    bool okq = true;
-    const EdgeOut e = edge_dual(p, alpha, beta, dx, dy, q1, q2, q3, xbi, w1bi, w2bi, xbj, w1bj, w2bj, okq);
-    // ---- this endpoint's share of the primal scatter (cc:126-141) as ordered contributions -------
-    const float t1 = e.q1 * p.step_x * alpha;
-    const float t2 = e.q2 * p.step_x * beta;
-    const float t3 = e.q3 * p.step_x * beta;
-    float cx = is_target ? t1 : -t1;                 // x_j += t1        | x_i -= t1
-    float a1 = is_target ? t2 : t1 * dx;             // w1_j += t2       | w1_i += t1*dx
-    float b1 = is_target ? -0.0f : -t2;              //                  | w1_i -= t2
-    float a2 = is_target ? t3 : t1 * dy;
-    float b2 = is_target ? -0.0f : -t3;
-    if (active) {
-      q1 = e.q1, q2 = e.q2, q3 = e.q3;
-      ok = ok && okq;
-    } else {
-      cx = a1 = b1 = a2 = b2 = -0.0f;
-    }
-    // ---- ordered segmented chain: after `chain` steps the tail lane holds the vertex sums --------
-    float X = x, W1 = w1, W2 = w2;
-    {
-      const float Xn = X + cx, W1n = (W1 + a1) + b1, W2n = (W2 + a2) + b2;
-      if (pos == 0) X = Xn, W1 = W1n, W2 = W2n;
-    }
-    for (int j = 1; j < chain; ++j) {
-      // Xn = X[lane-1] + cx etc. with the lane shift folded into the add (v_add_f32_dpp wave_shr:1).
-      // Hand-written because hipcc emits v_mov + v_mov_dpp + v_pk_add here (17 instructions per
-      // chain step instead of 12).  s_nop 4: VALU-write -> DPP-read (2) and EXEC-write -> DPP (5)
-      // wait states, which the compiler cannot see into an asm statement.  Lane 0 has no source
-      // lane and keeps an undefined Xn: it is always at position 0 and never selects it.
-      float Xn, W1n, W2n;
-      asm volatile(
-          "s_nop 4\n\t"
-          "v_add_f32_dpp %0, %3, %6 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-          "v_add_f32_dpp %1, %4, %7 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-          "v_add_f32_dpp %2, %5, %8 wave_shr:1 row_mask:0xf bank_mask:0xf"
-          : "=&v"(Xn), "=&v"(W1n), "=&v"(W2n)
-          : "v"(X), "v"(W1), "v"(W2), "v"(cx), "v"(a1), "v"(a2));
-      W1n = W1n + b1;
-      W2n = W2n + b2;
-      if (pos == j) X = Xn, W1 = W1n, W2 = W2n;
-    }
-    // ---- vertex update at the tail lane: proxL1 (cc:147-151), extragradient (cc:160-171) ---------
-    const float xn = prox_l1(p.x_min, p.x_max, p.step_x, lam_w, X, data);
-    float nb = xn + p.theta * (xn - x);
-    nb = (nb < p.x_min) ? p.x_min : nb;
-    nb = (nb > p.x_max) ? p.x_max : nb;
-    const float w1bn = W1 + p.theta * (W1 - w1);
-    const float w2bn = W2 + p.theta * (W2 - w2);
-    if (is_tail) {
-      v4i_t o;
-      o.x = __float_as_int(nb), o.y = __float_as_int(w1bn), o.z = __float_as_int(w2bn), o.w = (int)(s + 1u);
-      const int so = ((s + 1u) & 1u) ? par : 0;
-      __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
-      if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    // ---- hand the vertex's new state back to all of its lanes -------------------------------------
-    x_prev = x, w1_prev = w1, w2_prev = w2;  // step()'s prev copy, cc:37-42
-    x = __shfl(xn, tail_lane, 64);
-    w1 = __shfl(W1, tail_lane, 64);
-    w2 = __shfl(W2, tail_lane, 64);
-    xb = __shfl(nb, tail_lane, 64);
-    w1b = __shfl(w1bn, tail_lane, 64);
-    w2b = __shfl(w2bn, tail_lane, 64);
-  }
-
-  if (timed_out || torn) {
-    if (lane == 0) {
-      __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      atomicOr(err, torn ? 4 : 2);
-    }
-    return;  // the run is reported as failed; the host takes it back
-  }
-
-  // The results go to the OTHER copies of the state arrays (the host swaps the roles only when the whole run
-  // succeeded): a run that timed out leaves the state it started from untouched.
-  if (is_tail) {
-    vstate_out[pv] = make_float4(x, w1, w2, data);
-    bar_out[pv] = make_float4(xb, w1b, w2b, 0.0f);
-    vprev[pv] = make_float4(x_prev, w1_prev, w2_prev, 0.0f);
-    // Standing outputs of a run (kept in device memory rather than in the argument list: they are read once, here).
-    float* const export_out = tail->export_out;
-    float* const photo_err = tail->photo.err;
-    if (export_out || photo_err) {
-      const int o = perm[pv];  // the caller's vertex index
-      // flame_nltgv2_set_export_target: x * graph_scale in the caller's vertex order (flame.cc:372-380)
-      if (o >= 0 && export_out) export_out[o] = x * tail->export_scale;
-      // flame_nltgv2_photo_fuse: the photometric residual of the final x, in the same launch (config 5)
-      if (o >= 0 && photo_err) {
-        const PhotoFuse& photo = tail->photo;
-        photo_err[o] = photo_residual_at(photo.pos[o], x * photo.graph_scale, photo.geo, photo.ref, photo.cmp, photo.rows,
-                                         photo.cols, photo.step, photo.border);
-      }
-    }
-  }
-  if (active) hq_out[slot] = make_float4(q1, q2, q3, beta);
-  if (!ok) atomicOr(err, 1);
-}
-
 // ------------------------------------------------------------------------------------------------
-// Persistent run, patch-per-wave form ("pv"): the lane-per-half-edge arithmetic of k_persistent_he, reorganised around
+// Persistent run, patch-per-wave form ("pv"): a lane per half-edge, organised around
 // what the in-kernel probes of round 2 measured (profiles/r02_persistent/):
 //   * a lone wave issues one instruction every ~4.5 cycles and an LDS round trip costs ~120: a step costs what the
-//     instructions and LDS trips BETWEEN a record arriving and the next one leaving cost (k_persistent_he: ~1400 cycles,
+//     instructions and LDS trips BETWEEN a record arriving and the next one leaving cost (round 1's k_persistent_he: ~1400 cycles,
 //     of which the DPP ripple 750; here ~850);
 //   * a hand-off costs a store, a load round trip, and however much later than the arrival the consumer looks; one
 //     record per half-edge polled with blocking loads made that ~2200 cycles per step;
@@ -333,7 +72,7 @@ k_persistent_he(const int wave_begin, const int n_waves, const int waves_per_xcd
 //              verification is a template flag, the wait is one statement whose common exit falls through (DESIGN.md 4,
 //              "The hand-off path").
 // Protocol (tags, two parity buffers, remote / XCD-local copies chosen from the true XCC ids, bounded waits,
-// transactional outputs) is that of k_persistent_he.
+// transactional outputs): see above.
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned kWgActiveBit = 1u << 25, kWgValidBit = 1u << 26, kWgPublishBit = 1u << 27, kWgHeadBit = 1u << 28;
 typedef float v2f_t __attribute__((ext_vector_type(2)));
@@ -378,7 +117,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   extern __shared__ float4 lds[];
   constexpr int T = 64;
   const unsigned max_spins = max_spins_arg & 0x7fffffffu;
-  const int dual = dual_arg & 1, verify = VERIFY ? dual_arg >> 1 : 0;  // as in k_persistent_he (VERIFY: compiled in only where asked for)
+  const int dual = dual_arg & 1, verify = VERIFY ? dual_arg >> 1 : 0;  // (bit 0: same-XCD exchange through L2; bits 1..: record verification, compiled in only where asked for)
   const int poll_gap = poll_gap_arg & 255, pv_presleep = (poll_gap_arg >> 8) & 255;
   const int lane = (int)threadIdx.x;
   int b = blockIdx.x;
@@ -931,7 +670,7 @@ int pv_patches_per_cu(const FusedArgs& a, bool verify) {
   return n < 4 * pv_real_waves_per_simd(verify) ? n : 4 * pv_real_waves_per_simd(verify);
 }
 
-// Persistent run (single launch).  form 1 = lane per half-edge (k_persistent_he), form 2 = vertex per
+// Persistent run (single launch).  form 2 = vertex per
 // lane (k_persistent_tv), form 3 = patch per wave (k_persistent_pv).  Returns the hipError_t unchanged (e.g. hipErrorCooperativeLaunchTooLarge)
 // so the caller can fall back to per-step launches.
 int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, int wave_begin, int n_waves,
@@ -945,10 +684,11 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
   int wpx = (n_waves + xcds - 1) / xcds;
   const int bpx = (wpx + waves_per_block - 1) / waves_per_block;
   const dim3 grid((unsigned)(bpx * 8)), block((unsigned)(64 * waves_per_block));
-  const int32_t* i0 = (form == 2) ? a.tv_slot : a.he_slot;
-  const int32_t* i1 = (form == 2) ? a.tv_vid : a.he_vid;
-  const uint32_t* i2 = (form == 2) ? a.tv_meta : a.he_meta;
-  const void* i3 = (form == 2) ? (const void*)a.tv_wave : (const void*)a.he_wave_chain;
+  if (form != 2 && form != 3) return (int)hipErrorInvalidValue;
+  const int32_t* i0 = a.tv_slot;
+  const int32_t* i1 = a.tv_vid;
+  const uint32_t* i2 = a.tv_meta;
+  const void* i3 = (const void*)a.tv_wave;
   const int4* hrec = a.hrec;
   const float4* hq = a.hq;
   const float4* vstate = a.vstate;
@@ -990,7 +730,7 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
     return (int)hipLaunchKernel(fv, gv, bv, vargs, ldsv, stream);
   }
   unsigned lds_bytes = 0u;
-  const void* fn = form == 2 ? persistent_tv_kernel(tv_static_in_lds != 0, waves_per_block, &lds_bytes) : (const void*)k_persistent_he;
+  const void* fn = persistent_tv_kernel(tv_static_in_lds != 0, waves_per_block, &lds_bytes);
   // The first launch of a topology is cooperative: the runtime verifies that the whole grid is
   // resident (hipErrorCooperativeLaunchTooLarge otherwise).  The same grid is then launched plainly
   // (identical residency, ~15 us less launch overhead per call).

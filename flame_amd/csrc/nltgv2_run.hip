@@ -48,24 +48,17 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
   }
   const bool crowded = ctx->topo < ctx->crowded_until_topo && ctx->opt_persistent == 1;  // (a form asked for by name is run as asked)
   const int wg_cap = (crowded ? std::min(ctx->pv_occ, kCrowdedWavesPerCu) : ctx->pv_occ) * cus;  // patch-per-wave form, in patches
-  const int he_cap = (ctx->opt_persistent == 2 ? kHeWavesPerCuReal : crowded ? kCrowdedWavesPerCu : kHeWavesPerCu) * cus;
-  // The lane-per-half-edge rows (C) come from the same greedy walk as the patches (E): as many waves, possible under the
-  // same condition (no vertex of more than 64 incident edges).  They, and the vertex-per-lane rows (D), are built only
-  // when their form is actually chosen.
+  // The vertex-per-lane rows (D) are built only when that form is actually chosen.
   const bool pv_fits = L.wg_ok && L.wg_rowpack && L.wg_count > 0 && L.wg_count <= wg_cap;  // (the kernel runs row-packed patches)
-  const bool he_possible = L.wg_ok && L.wg_count > 0;
   int form = 0;
   if (ctx->opt_persistent == 4) form = (L.wg_ok && L.wg_rowpack) ? 3 : 0;
-  else if (ctx->opt_persistent == 2) form = he_possible ? 1 : 0;
   else if (ctx->opt_persistent == 3) form = 2;
-  else if (pv_fits) form = 3;  // lowest latency wherever all patches are resident: 320x240 ... 1280x720 single frames
-  else if (he_possible && L.wg_count <= he_cap) form = 1;
+  else if (pv_fits) form = 3;  // lowest latency wherever all patches are resident: 320x240 ... 1920x1080 single frames, 2-7 frames of 640x480
   else form = 2;               // too big for that: vertex-per-lane, in groups of whole components if need be
-  if (form == 1 || form == 2) {
+  if (form == 2) {
     if (ensure_form_rows(ctx, form) != 0) return 0;
-    if (form == 2 && !L.tv_ok) {
-      form = he_possible ? 1 : 0;
-      if (form == 1 && ensure_form_rows(ctx, 1) != 0) return 0;
+    if (!L.tv_ok) {  // (a vertex of more than 512 edges: the per-step sweep, unless the patch form can run it in groups)
+      form = (L.wg_ok && L.wg_rowpack && L.wg_count > 0) ? 3 : 0;
     }
   }
   // vertex-per-lane form: slot constants in registers (8 waves/CU, fastest per wave) while the graph is resident
@@ -74,14 +67,14 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
   const int tv_cap = (tv_lds ? kTvLdsWavesPerCu : kTvWavesPerCu) * cus;
   if (use_tv_lds) *use_tv_lds = tv_lds ? 1 : 0;
   if (form == 0) return 0;
-  const int total = form == 3 ? L.wg_count : form == 2 ? L.tv_waves : L.he_waves;
-  const int cap = form == 3 ? wg_cap : form == 2 ? tv_cap : he_cap;
+  const int total = form == 3 ? L.wg_count : L.tv_waves;
+  const int cap = form == 3 ? wg_cap : tv_cap;
   if (total <= 0) return 0;
   if (total <= cap) {
     groups->push_back(WaveGroup{0, total});
     return form;
   }
-  const std::vector<int32_t>& cw = form == 3 ? L.comp_wg : form == 2 ? L.comp_tv_wave : L.comp_he_wave;
+  const std::vector<int32_t>& cw = form == 3 ? L.comp_wg : L.comp_tv_wave;
   if (cw.size() < 3) return 0;  // one component that does not fit: stream it
   // Groups of about equal size (the per-step time of a group grows with its waves, and a small last group would run
   // at low occupancy): cut at the component boundaries nearest to k * total / n_groups, never beyond what the chip
@@ -383,19 +376,12 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       // (measured per step: 640x480 -16 %, 1280x720 -23 %, 1080p -18 %, 7-frame batch -20 %, 15 frames -19 %)
       const int dual = (ctx->opt_dual == 2 || (ctx->opt_dual == 1 && gr.count > kDualMinWavesPerCu * ctx->prop.multiProcessorCount) ? 1 : 0) |
                        (ctx->opt_verify == 2 ? 6 : ctx->opt_verify == 1 ? 2 : 0);  // bits 1, 2: record verification, its test hook
-      // A graph of <= 8 lane-per-half-edge waves per CU of ONE XCD (32 CUs) runs there entirely: every exchange
-      // stays in that XCD's L2 (measured 320x240: 1.23 instead of 1.47 us per step; at 640x480 the 26 waves per CU
-      // this would need cost more than the shorter hop saves).
+      // A graph small enough runs on ONE XCD (32 CUs) entirely: every exchange stays in that XCD's L2 -- while its CUs get at
+      // most two patches each (measured: 48 patches 0.98 against 1.21 us per step on all eight, 208 patches 1.53 against 1.33)
       const int cus_per_xcd = ctx->prop.multiProcessorCount / 8;
-      // (patch-per-wave form: one XCD while its CUs get at most two patches each -- measured: 48 patches 0.98 against
-      // 1.21 us per step on all eight, 208 patches 1.53 against 1.33)
-      const bool one_xcd = form == 3 ? gr.count <= 2 * cus_per_xcd : (form == 1 && gr.count <= 8 * cus_per_xcd);
+      const bool one_xcd = form == 3 && gr.count <= 2 * cus_per_xcd;
       const int xcds = ctx->opt_xcds > 0 ? ctx->opt_xcds : one_xcd ? 1 : 8;
-      const int presleep = ctx->opt_presleep > 0 ? ctx->opt_presleep - 1
-                           : form == 2                ? kPreSleepTv
-                           : xcds == 1                ? kPreSleepHeOneXcd
-                           : gr.count > 12 * ctx->prop.multiProcessorCount ? kPreSleepHeDense
-                                                                            : kPreSleepHe;
+      const int presleep = ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : kPreSleepTv;  // (the patch form has its own, below)
       const unsigned spins_arg = ctx->opt_fault > 0 ? (0x80000000u | (unsigned)ctx->opt_fault) : kMaxSpins;
       if (form == 3) {
         // pacing: none where a CU holds few patches (a poll costs nothing there and a pause only delays the hand-off); at
@@ -457,7 +443,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       ctx->buf_gen ^= 1;
       refresh_args(ctx);
       ctx->coop_checked_key = key;
-      ctx->last_run_path = form == 3 ? 6 : form == 2 ? 5 : 1;
+      ctx->last_run_path = form == 3 ? 6 : 5;
       ctx->last_run_groups = (int)groups.size();
       ctx->last_run_waves_per_cu = 0;
       for (const WaveGroup& gr : groups) ctx->last_run_waves_per_cu = std::max(ctx->last_run_waves_per_cu, (gr.count + ctx->prop.multiProcessorCount - 1) / ctx->prop.multiProcessorCount);

@@ -202,7 +202,7 @@ int main() {
       for (size_t i = 0; i < f.src.size(); ++i) b.add_edge(f.src[i] + off, f.dst[i] + off);
     }
     check_layout(b, "batch of 3 frames");
-    HostGraph star;  // one hub of 70 edges (> 64: no lane-per-half-edge rows), a hub of 20, isolated vertices, parallel edges
+    HostGraph star;  // one hub of 70 edges (> 64: no patch rows), a hub of 20, isolated vertices, parallel edges
     for (int i = 0; i < 120; ++i) star.add_vertex(10.f * u01(seed), 10.f * u01(seed));
     for (int i = 1; i <= 70; ++i) star.add_edge(0, i);
     for (int i = 71; i <= 90; ++i) star.add_edge(i, 71 == i ? 72 : 71);

@@ -124,3 +124,4 @@ def test_pv_residency_table_matches_the_build(tmp_path):
         assert real >= want, f"instance probe={probe} verify={verify}: {vg} VGPRs / {sg} SGPRs keep {real} waves per SIMD, the planner assumes {want}"
     # the instance the bench runs (no probe, no verification) must not spill
     assert found[(0, 0)][2] == 0
+

@@ -74,7 +74,7 @@ def test_config_parity(env, config, n):
     g = synth.make_graph(config, seed=4242)
     ref, bad = cpu_run(oracle, g, n)
     assert bad == 0
-    for persistent in (1, 2, 3, 4, 0):  # auto, lane-per-half-edge, vertex-per-lane, patch-per-wave, one launch per step
+    for persistent in (1, 3, 4, 0):  # auto, vertex-per-lane, patch-per-wave, one launch per step
         out = gpu_run(flame_amd, g, n, options=[(5, persistent)], expect_path=None if persistent else 2)
         assert rms(out["x"], ref["x"]) <= TOL_RMS
         assert_state_equal(out, ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"{config} p={persistent}")
@@ -109,10 +109,11 @@ def test_four_kernel_path_matches_fused_and_checker(env):
     g = synth.make_graph("320x240", seed=11)
     ref, _ = cpu_run(oracle, g, 37)
     persistent = gpu_run(flame_amd, g, 37, expect_path=6)  # auto: the patch-per-wave form
-    persistent_he = gpu_run(flame_amd, g, 37, options=[(5, 2)], expect_path=1)
-    assert_state_equal(persistent_he, ref, what="persistent lane-per-half-edge")
     persistent_tv = gpu_run(flame_amd, g, 37, options=[(5, 3)], expect_path=5)
     assert_state_equal(persistent_tv, ref, what="persistent vertex-per-lane")
+    with flame_amd.Regularizer(0) as reg:  # (2 named round 1's lane-per-half-edge form, retired in round 3)
+        with pytest.raises(flame_amd.NLTGV2Error):
+            reg.set_option(5, 2)
     fused = gpu_run(flame_amd, g, 37, options=[(5, 0)], expect_path=2)
     canon = gpu_run(flame_amd, g, 37, options=[(flame_amd.regularizer.OPT_SOLVER, 1)], expect_path=4)
     assert_state_equal(persistent, ref, what="persistent")
@@ -155,10 +156,8 @@ def _opt_sets():
         # one launch per step: waves per workgroup x slot chunk, hipGraph off
         [(P, 0), (BW, 1), (U, 4)], [(P, 0), (BW, 1), (U, 16)], [(P, 0), (BW, 4), (U, 8)], [(P, 0), (HG, 0)],
         [(P, 1)],  # automatic choice
-        # lane per half-edge
-        [(P, 2)], [(P, 2), (DUAL, 0)], [(P, 2), (XCDS, 1)], [(P, 2), (XCDS, 4)], [(P, 2), (PRE, 21)],
         # vertex per lane
-        [(P, 3)], [(P, 3), (DUAL, 0)], [(P, 3), (TVLDS, 2)], [(P, 3), (TVLDS, 0)], [(P, 3), (XCDS, 1)],
+        [(P, 3)], [(P, 3), (DUAL, 0)], [(P, 3), (TVLDS, 2)], [(P, 3), (TVLDS, 0)], [(P, 3), (XCDS, 1)], [(P, 3), (XCDS, 4)], [(P, 3), (PRE, 21)],
         # patch per wave
         [(P, 4)], [(P, 4), (DUAL, 0)], [(P, 4), (DUAL, 2)], [(P, 4), (XCDS, 1)], [(P, 4), (XCDS, 8)], [(P, 4), (GAP, 1)], [(P, 4), (GAP, 2)],
         [(P, 4), (GAP, 4)], [(P, 4), (PRE, 9), (GAP, 4)], [(P, 4), (PROBE, 1)], [(P, 4), (PLACE, 0)], [(P, 4), (PLACE, 0), (DUAL, 0)],
@@ -169,7 +168,7 @@ def _opt_sets():
 @pytest.mark.parametrize("opts", _opt_sets(), ids=lambda o: "-".join(f"{k}={v}" for k, v in o))
 def test_launch_configurations_are_bit_identical(env, opts):
     """Every launch configuration computes the same bits: the one-launch-per-step sweep (waves per workgroup, slot chunk,
-    hipGraph on / off), the automatic choice and the three persistent forms with their knobs -- same-XCD exchange through L2
+    hipGraph on / off), the automatic choice and the two persistent forms with their knobs -- same-XCD exchange through L2
     on / off, slot constants in LDS, the pre-poll pause, the XCDs a launch is spread over, the poll pacing, the cycle probe,
     the placement of the records read across XCDs and the record verification."""
     flame_amd, oracle = env
@@ -242,8 +241,8 @@ def test_star_graph_high_degree(env):
     for unroll in (4, 16):  # one launch per step
         out = gpu_run(flame_amd, g, 25, options=[(5, 0), (flame_amd.regularizer.OPT_UNROLL, unroll)], expect_path=2)
         assert_state_equal(out, ref, what=f"star U={unroll}")
-    # degree 999 > 64 lanes: the lane-per-half-edge form cannot hold it, the vertex-per-lane form
-    # cannot either (999 > 8*64) -> automatic fall back to per-step launches
+    # degree 999 > 64 lanes: no patch can hold it, and the vertex-per-lane form cannot either (999 > 8*64) -> automatic
+    # fall back to per-step launches
     out = gpu_run(flame_amd, g, 25, expect_path=2)
     assert_state_equal(out, ref, what="star auto")
     # a hub of degree 300: 38 chained lanes in the vertex-per-lane form
@@ -260,7 +259,7 @@ def test_star_graph_high_degree(env):
 def test_vertices_of_more_than_sixteen_edges_in_the_patch_kernel(env, hub_degrees):
     """k_persistent_pv adds a vertex's contributions up across the lanes of a 16-lane row; a vertex of 17..64 edges fills two
     to four rows of its patch and its sum runs row after row (the running sums handed from the first lane of one row to the
-    next).  Hubs at every row boundary, both edge orientations, odd and even run lengths: all three persistent forms and the
+    next).  Hubs at every row boundary, both edge orientations, odd and even run lengths: both persistent forms and the
     per-step path agree with the checker bit for bit."""
     flame_amd, oracle = env
     rng = np.random.default_rng(sum(hub_degrees))
@@ -284,7 +283,7 @@ def test_vertices_of_more_than_sixteen_edges_in_the_patch_kernel(env, hub_degree
     for n in (1, 2, 37):
         ref, bad = cpu_run(oracle, g, n)
         assert bad == 0
-        for form, path in ((4, 6), (2, 1), (3, 5)):
+        for form, path in ((4, 6), (3, 5)):
             out = gpu_run(flame_amd, g, n, options=[(5, form)], expect_path=path if n >= 4 else None)
             assert_state_equal(out, ref, what=f"hubs {hub_degrees}, form {form}, {n} steps")
     out = gpu_run(flame_amd, g, 37, options=[(5, 0)], expect_path=2)
@@ -320,7 +319,7 @@ def test_batch_of_frames_equals_individual_frames(env):
     frames = [synth.make_graph("320x240", seed=100 + i) for i in range(5)]
     union = synth.concat_graphs(frames)
     refs = [cpu_run(oracle, f, 40)[0] for f in frames]
-    for opts in ([], [(5, 4)], [(5, 2)]):  # auto; patch-per-wave form; lane-per-half-edge form
+    for opts in ([], [(5, 4)], [(5, 3)]):  # auto; patch-per-wave form; vertex-per-lane form
         out = gpu_run(flame_amd, union, 40, options=opts)
         vo = eo = 0
         for f, ref in zip(frames, refs):
@@ -434,7 +433,7 @@ def test_nan_is_reported_not_fatal(env):
         st = reg.download_state(("x", "q1"))
         assert st["x"].shape[0] == g["V"] and np.abs(st["q1"]).max() <= 1.0
         reg.costs(flame_amd.Params())
-        for opt in (2, 3, 4, 0):  # ... and every persistent form reports it the same way
+        for opt in (3, 4, 0):  # ... and every persistent form reports it the same way
             reg.set_option(5, opt)
             reg.upload_graph(bad)
             with pytest.raises(flame_amd.NLTGV2Error) as ei:
@@ -452,7 +451,7 @@ def test_nan_is_reported_not_fatal(env):
             reg.run(flame_amd.Params(), 1)
 
 
-@pytest.mark.parametrize("form", [2, 3, 4])
+@pytest.mark.parametrize("form", [3, 4])
 def test_persistent_timeout_is_rolled_back_and_redone(env, form):
     """A persistent run whose neighbour wait expires (fault injection: one wave withholds its first record) must
     leave the state it started from untouched; run() then does the same steps with one launch per step."""
@@ -465,7 +464,7 @@ def test_persistent_timeout_is_rolled_back_and_redone(env, form):
         reg.upload_graph(g)
         reg.run(p, 30)                       # a normal persistent run first (odd/even parity both follow)
         oracle.run(ref, 30)
-        assert reg.info()["last_run_path"] in (1, 5, 6)
+        assert reg.info()["last_run_path"] in (5, 6)
         reg.set_option(flame_amd.regularizer.OPT_FAULT_INJECT, 200)
         reg.run(p, 41)                       # times out inside, recovered
         oracle.run(ref, 41)
@@ -478,7 +477,7 @@ def test_persistent_timeout_is_rolled_back_and_redone(env, form):
         reg.set_option(flame_amd.regularizer.OPT_FAULT_INJECT, 0)  # fault off: persistent runs again
         reg.run(p, 25)
         oracle.run(ref, 25)
-        assert reg.info()["last_run_path"] in (1, 5, 6)
+        assert reg.info()["last_run_path"] in (5, 6)
         assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="after the fault")
         # chained asynchronous runs (run_async back to back, an asynchronous export in between, a short per-step run):
         # the chain's starting state was copied aside, the whole chain is replayed on the per-step path
@@ -510,7 +509,7 @@ def test_persistent_timeout_is_rolled_back_and_redone(env, form):
         assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="after a clean chain")
 
 
-@pytest.mark.parametrize("form", [2, 3, 4])
+@pytest.mark.parametrize("form", [3, 4])
 def test_record_verification_detects_a_corrupted_read_and_recovers(env, form):
     """FLAME_NLTGV2_OPT_VERIFY_RECORDS: the persistent kernels re-read every neighbour record after its tag matched and
     compare all four dwords -- the run-time guard of the one hardware property the exchange relies on (an aligned 16-byte
@@ -527,7 +526,7 @@ def test_record_verification_detects_a_corrupted_read_and_recovers(env, form):
         reg.run(p, 60)
         oracle.run(ref, 60)
         info = reg.info()
-        assert info["torn_records_detected"] == 0 and info["timeouts_recovered"] == 0 and info["last_run_path"] in (1, 5, 6)
+        assert info["torn_records_detected"] == 0 and info["timeouts_recovered"] == 0 and info["last_run_path"] in (5, 6)
         assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="verified run")
         reg.set_option(14, 2)  # the hook corrupts one re-read in step 2 of the next persistent run
         reg.run(p, 33)
@@ -538,7 +537,7 @@ def test_record_verification_detects_a_corrupted_read_and_recovers(env, form):
         reg.set_option(14, 1)
         reg.run(p, 20)
         oracle.run(ref, 20)
-        assert reg.info()["last_run_path"] in (1, 5, 6) and reg.info()["torn_records_detected"] == 1
+        assert reg.info()["last_run_path"] in (5, 6) and reg.info()["torn_records_detected"] == 1
         assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="verified again")
 
 
@@ -602,7 +601,7 @@ def test_export_idepth_device_and_stream(env):
         reg.set_stream(None)
 
 
-@pytest.mark.parametrize("form", [0, 2, 3, 4])
+@pytest.mark.parametrize("form", [0, 3, 4])
 def test_standing_export_target(env, form):
     """flame_nltgv2_set_export_target: every run leaves scale * x in the caller's vertex order, on all paths."""
     import torch
@@ -662,7 +661,7 @@ def test_randomized_run_sequences(env, trial):
         reg.upload_graph(g)
         reg.set_export_target(buf.data_ptr(), 2.0)
         for step in range(12):
-            form = int(rng.choice([0, 1, 2, 3, 4]))
+            form = int(rng.choice([0, 1, 3, 4, 4]))
             reg.set_option(5, form)
             reg.set_option(1, int(rng.random() < 0.15))      # canonical four-sweep path now and then
             reg.set_option(flame_amd.regularizer.OPT_DUAL_PUBLISH, int(rng.choice([0, 1, 2])))

@@ -115,9 +115,9 @@ def test_device_expanded_layout_matches_host_builders(built, config):
         assert reg.layout_selftest() == 0
         reg.run(flame_amd.Params(), 16)
         assert reg.layout_selftest() == 0
-        reg.set_option(flame_amd.regularizer.OPT_PERSISTENT, 2)  # the lane-per-half-edge rows: converted on the device
+        reg.set_option(flame_amd.regularizer.OPT_PERSISTENT, 3)  # the vertex-per-lane rows: built on demand
         reg.run(flame_amd.Params(), 16)
-        assert reg.info()["last_run_path"] == 1 and reg.layout_selftest() == 0
+        assert reg.info()["last_run_path"] == 5 and reg.layout_selftest() == 0
 
 
 def test_sync_behind_an_unchecked_chain_and_with_growing_graphs(built):

@@ -19,7 +19,7 @@ prof() {  # prof TAG "command": kernel stats + FETCH + WRITE + SQ counters, each
 }
 B="python bench.py --steps 20 --warmup 2 --no-extras --no-cpu-baseline"
 prof bench $B                                   # the bench line's own command: 640x480, default path (k_persistent_pv)
-prof bench_he $B --persistent 2                 # the lane-per-half-edge kernel on the same workload
+prof bench_tv $B --persistent 3                 # the vertex-per-lane kernel on the same workload
 prof bench_step $B --persistent 0               # one launch per step
 prof cfg3 python tools/profile_case.py single:1280x720
 prof cfg5 python tools/profile_case.py single:1920x1080

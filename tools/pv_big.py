@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/pv_big.py -- the patch-per-wave persistent kernel on graphs beyond 12 patches per CU (GPU box).
 
-For each (config, frames) case: the automatic path, the lane-per-half-edge kernel and the patch-per-wave kernel, timed
+For each (config, frames) case: the automatic path, the vertex-per-lane kernel and the patch-per-wave kernel, timed
 (mean of the launches after the first) and bit-compared.  Environment of the experiment: FLAME_NLTGV2_DEBUG_PV_CAP /
 FLAME_NLTGV2_DEBUG_ROWPACK_MAX (residency cap per CU, row-packing up to that many patches per CU)."""
 import json
@@ -49,8 +49,8 @@ def main():
         frames = [synth.make_graph(cfg, seed=1234 + i) for i in range(nf)]
         g = frames[0] if nf == 1 else synth.concat_graphs(frames)
         row = {"case": c, "V": int(g["V"]), "E": int(g["E"])}
-        he, want = timed(g, [(OPT_PERSISTENT, 2)])
-        row["he"] = he
+        tv, want = timed(g, [(OPT_PERSISTENT, 3)])  # the vertex-per-lane kernel: the other persistent form, and the bit reference
+        row["tv"] = tv
         pv, _ = timed(g, [(OPT_PERSISTENT, 4)], want=want)
         row["pv"] = pv
         for spec in [s for s in os.environ.get("PV_VARIANTS", "").split(";") if s]:  # e.g. "13=4,8=9;13=4,8=17"

@@ -72,8 +72,8 @@ def main():
     results = []
     for cfg in cfgs:
         g = synth.make_graph(cfg, seed=5000)
-        us_he, path_he, want, _ = timed(g, [(OPT_PERSISTENT, 2)])
-        row = {"config": cfg, "V": int(g["V"]), "E": int(g["E"]), "lane_per_half_edge_us_per_iter": round(us_he, 3)}
+        us_tv, path_tv, want, _ = timed(g, [(OPT_PERSISTENT, 3)])
+        row = {"config": cfg, "V": int(g["V"]), "E": int(g["E"]), "vertex_per_lane_us_per_iter": round(us_tv, 3)}
         for gap in (1, 2):
             us, path, _, same = timed(g, [(OPT_PERSISTENT, 4), (OPT_POLL_GAP, gap)], want=want)
             row[f"patch_per_wave_us_per_iter_gap{gap - 1}"] = round(us, 3) if path == "persistent-pv" else path

@@ -45,8 +45,8 @@ for cfg, seed in cases:
     oracle.run(ref, ITERS)
     cpu_s = time.time() - t0
     # (form, same-XCD exchange, tv constants in LDS, record verification, record placement)
-    for form, dual, lds, verify, place in ((4, 2, 0, 0, 1), (4, 2, 0, 1, 1), (4, 2, 0, 1, 0), (4, 0, 0, 1, 1), (2, 0, 0, 0, 1),
-                                          (2, 2, 0, 1, 1), (3, 0, 0, 1, 1), (3, 2, 0, 0, 1), (3, 2, 2, 1, 1)):
+    for form, dual, lds, verify, place in ((4, 2, 0, 0, 1), (4, 2, 0, 1, 1), (4, 2, 0, 1, 0), (4, 0, 0, 1, 1), (4, 0, 0, 0, 0),
+                                          (3, 0, 0, 1, 1), (3, 2, 0, 0, 1), (3, 2, 2, 1, 1), (3, 2, 2, 0, 1)):
         with flame_amd.Regularizer(0) as reg:
             reg.set_option(OPT_PERSISTENT, form)
             reg.set_option(OPT_DUAL_PUBLISH, dual)

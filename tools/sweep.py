@@ -15,7 +15,7 @@ for cfg, nf in cases:
     frames = [synth.make_graph(cfg, seed=5000 + i) for i in range(nf)]
     g = synth.concat_graphs(frames) if nf > 1 else frames[0]
     row = {}
-    for form, dual, lds in ((2, 2, 0), (3, 2, 0), (3, 2, 2), (0, 0, 0)):
+    for form, dual, lds in ((4, 2, 0), (3, 2, 0), (3, 2, 2), (0, 0, 0)):
         r = flame_amd.Regularizer(0)
         r.set_option(OPT_PERSISTENT, form)
         r.set_option(OPT_DUAL_PUBLISH, dual)
