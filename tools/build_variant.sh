@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/_build_variant.sh NAME "-DFLAGS" -- experimental build of the library with other flags for nltgv2_persistent.hip (build/ab/libNAME.so)
+# tools/build_variant.sh NAME "-DFLAGS" -- experimental build of the library with other flags for nltgv2_persistent.hip (build/ab/libNAME.so)
 set -e
 R=/root/repo; FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I$R/include -I$R/flame_amd/csrc -Wall -Wno-unused-result"
 mkdir -p $R/build/obj $R/build/ab

@@ -1,3 +1,5 @@
+"""tools/probe_dense.py CASE.. -- in-kernel probe of k_persistent_pv by load: wait / compute cycles over the patches (percentiles), period,
+poll rounds; PV_VARIANTS="113=1;108=9,113=4" = option settings to compare (GPU box).  CASE = SIZE:FRAMES, e.g. 640x480:4."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -2,8 +2,7 @@
 """tools/pv_big.py -- the patch-per-wave persistent kernel on graphs beyond 12 patches per CU (GPU box).
 
 For each (config, frames) case: the automatic path, the vertex-per-lane kernel and the patch-per-wave kernel, timed
-(mean of the launches after the first) and bit-compared.  Environment of the experiment: FLAME_NLTGV2_DEBUG_PV_CAP /
-FLAME_NLTGV2_DEBUG_ROWPACK_MAX (residency cap per CU, row-packing up to that many patches per CU)."""
+(mean of the launches after the first) and bit-compared.  PV_VARIANTS="113=4,108=9;..." adds columns with option settings."""
 import json
 import os
 import sys

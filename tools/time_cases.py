@@ -1,4 +1,4 @@
-"""tools/_time_cases.py CASE.. -- us per iteration of the automatic path (mean / min of 10 launches of 200 iterations), with a state hash."""
+"""tools/time_cases.py CASE.. -- us per iteration of the automatic path (mean / min of 10 launches of 200 iterations), with a state hash."""
 import hashlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,4 +1,4 @@
-"""tools/_uncoupled.py -- period of 8 DISJOINT graphs (one per XCD: no record crosses an XCD) against coupled graphs of the same total size."""
+"""tools/uncoupled.py -- period of 8 DISJOINT graphs (one per XCD: no record crosses an XCD) against coupled graphs of the same total size."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
