@@ -525,6 +525,29 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
             oc[cfg]["photometric_residual"] = {"fused_into_the_solver_launch": True,
                                                "defined_on_fraction_of_vertices": round(float(_np2.isfinite(res).mean()), 3)}
         r.close()
+    try:  # 1280x720 against its own floor: eight DISJOINT graphs of the same total size, one per XCD (no record crosses an XCD), same kernel
+        def small(w, h, seed):
+            pos = synth.make_points(w, h, 6, seed)
+            return synth.assemble_graph(pos, synth.make_data_term(pos, w, h, seed), synth.delaunay_edges_native(pos))
+
+        g8 = synth.concat_graphs([small(334, 250, 300 + k) for k in range(8)])
+        r = flame_amd.Regularizer(0)
+        r.set_option(flame_amd.regularizer.OPT_PERSISTENT, 4)
+        r.upload_graph(g8)
+        r.run(params, 200)
+        ms8, _ = timed_launches(r, params, 200, 5)
+        i8 = r.info()
+        r.close()
+        B720 = oc["1280x720"]["algorithmic_bytes_per_launch"] / 200
+        oc["1280x720"]["floor"] = {
+            "uncoupled_period_us": round(ms8 * 1e3 / 200, 3), "uncoupled_graphs": f"8 disjoint Delaunay graphs, V={g8['V']} E={g8['E']} in total, one per XCD",
+            "uncoupled_run_path": flame_amd.regularizer.RUN_PATHS.get(i8["last_run_path"], "?"),
+            "measured_period_us": round(1e6 / oc["1280x720"]["iters_per_s"], 3),
+            "frac_of_hbm_at_uncoupled_period": round(B720 / (ms8 * 1e-3 / 200) / 1e9 / HBM_PEAK_GBPS, 4),
+            "note": "what this frame would show if none of its records crossed an XCD: the period of a graph of this size is set by the patches a CU "
+                    "holds (8 per CU here: two waves per SIMD), not by bandwidth and not by the crossings (DESIGN.md section 4, 'What the period depends on')"}
+    except Exception as e:  # the extras never take the line down
+        oc["1280x720"]["floor"] = f"{type(e).__name__}: {e}"
     out["other_configs"] = oc
     # (3) what the boundary costs when the host hands over fresh buffers every frame (PCIe-inclusive;
     #     never part of `value`): upload = host pack + H2D + device pack, download = unpack + D2H
