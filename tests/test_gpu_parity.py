@@ -353,6 +353,29 @@ def test_large_batch_as_groups_of_patches(env):
         eo += f["E"]
 
 
+def test_seven_frames_in_one_patch_per_wave_launch(env):
+    """Seven frames of 640x480 are 26 patches per CU: with 28 really resident (the kernel is capped at 92 SGPRs) the planner runs
+    them in ONE patch-per-wave launch -- the highest residency it uses; every frame equals the frame solved alone."""
+    flame_amd, oracle = env
+    frames = [synth.make_graph("640x480", seed=700 + i) for i in range(7)]
+    union = synth.concat_graphs(frames)
+    with flame_amd.Regularizer(0) as reg:
+        reg.upload_graph(union)
+        reg.run(flame_amd.Params(), 33)
+        info = reg.info()
+        out = reg.download_state(("x", "w1", "x_bar", "q2"))
+    assert info["last_run_path"] == 6 and info["last_run_groups"] == 1 and info["patches"] > 25 * 256, info
+    vo = eo = 0
+    for i, f in enumerate(frames):
+        if i in (0, 3, 6):
+            ref, _ = cpu_run(oracle, f, 33)
+            for k in ("x", "w1", "x_bar"):
+                assert np.array_equal(out[k][vo:vo + f["V"]], ref[k]), (i, k)
+            assert np.array_equal(out["q2"][eo:eo + f["E"]], ref["q2"]), i
+        vo += f["V"]
+        eo += f["E"]
+
+
 def test_large_batch_runs_as_groups_of_resident_frames(env):
     """40 frames do not fit the chip at once: the persistent run is split into groups of whole frames
     (connected components), which is the same computation because frames are independent."""
