@@ -402,7 +402,7 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
     case FLAME_NLTGV2_OPT_VERIFY_RECORDS:
       if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_verify = value;
-      if (value != 2) ctx->persist_refused_topo = ~0ull;  // hook off: let the persistent path be tried again
+      if (value != 2) ctx->persist_refused_topo = ctx->persist_backoff_topo = ~0ull;  // hook off: let the persistent path be tried again
       return 0;
     case FLAME_NLTGV2_OPT_PROBE:
       ctx->opt_probe = value ? 1 : 0;
@@ -414,7 +414,7 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
     case FLAME_NLTGV2_OPT_FAULT_INJECT:
       if (value < 0 || value > (1 << 24)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_fault = value;
-      if (value == 0) ctx->persist_refused_topo = ~0ull;  // let the persistent path be tried again
+      if (value == 0) ctx->persist_refused_topo = ctx->persist_backoff_topo = ~0ull;  // let the persistent path be tried again
       return 0;
     case FLAME_NLTGV2_OPT_XCDS:
       if (value < 0 || value > 8) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);

@@ -175,6 +175,12 @@ struct flame_nltgv2_ctx {
   uint32_t tag_next = 1;  // persistent run: tag of the current bar values (monotonic)
   int last_run_path = 0, last_run_groups = 0;
   uint64_t persist_refused_topo = ~0ull;  // topology for which the runtime refused the persistent grid
+  // ... and after an EXPIRED run of a topology the persistent path is not tried for its next `persist_backoff_left` runs: 4 after the
+  // first expired run in a row, doubling up to 1024 (a stall that passes does not leave a static graph on the per-step path for good;
+  // a GPU that stays full costs one expired run per 1024).  flame_nltgv2_info::timeouts_recovered counts them.
+  uint64_t persist_backoff_topo = ~0ull;
+  int persist_backoff_left = 0, persist_timeout_streak = 0;
+  bool replaying = false;  // finish() is redoing an expired chain: one launch per step, whatever the planner would say
   // A persistent run that needs most of the chip's wave slots (a 1080p frame: 25 of the 28 a CU really holds) only starts
   // whole when nothing else keeps slots busy; when such a run expires beside other kernels (the tracker's, the rasteriser's:
   // tools/soak_pipeline.py at 1080p), the next kCrowdedTopologies topologies are planned for at most kCrowdedWavesPerCu waves per

@@ -31,7 +31,11 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
   groups->clear();
   if (use_tv_lds) *use_tv_lds = 0;
   if (!ctx->opt_persistent || n < 4 || n > (1 << 24) || !ctx->prop.cooperativeLaunch) return 0;
-  if (ctx->persist_refused_topo == ctx->topo) return 0;
+  if (ctx->persist_refused_topo == ctx->topo || ctx->replaying) return 0;
+  if (ctx->persist_backoff_topo == ctx->topo && (ctx->persist_backoff_left > 0 || ctx->opt_fault > 0)) {  // (the test hook's fault does not pass)
+    if (ctx->persist_backoff_left > 0) --ctx->persist_backoff_left;
+    return 0;
+  }
   PackedLayout& L = ctx->L;
   const int cus = ctx->prop.multiProcessorCount;
   // ask once per (topology, kernel instance): the LDS use varies with the layout, the registers with the instance
@@ -564,23 +568,31 @@ int finish(flame_nltgv2_ctx* ctx) {
     ctx->parity = run.parity_before;
     ctx->have_prev = run.have_prev_before;
     ctx->fused_valid = true, ctx->canon_valid = false;
-    ctx->persist_refused_topo = ctx->topo;
+    ctx->persist_timeout_streak = (ctx->persist_backoff_topo == ctx->topo) ? std::min(ctx->persist_timeout_streak + 1, 9) : 1;
+    ctx->persist_backoff_topo = ctx->topo;
+    ctx->persist_backoff_left = 4 << (ctx->persist_timeout_streak - 1);
     if (!(*ctx->h_err & 4)) {
       ctx->timeouts_recovered++;
       if (ctx->last_run_waves_per_cu > kCrowdedWavesPerCu) ctx->crowded_until_topo = ctx->topo + 1 + kCrowdedTopologies;
     }
     HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, kErrBytes, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->abort_flag.p, 0, sizeof(int), ctx->stream));
+    ctx->replaying = true;
+    int replay_rc = 0;
     for (const flame_nltgv2_ctx::PendingOp& op : run.ops) {
       if (op.kind == 0) {
-        const int rc = enqueue_run(ctx, &op.params, op.n);
-        if (rc) return rc;
+        replay_rc = enqueue_run(ctx, &op.params, op.n);
       } else {
-        LAUNCHCHK(ctx, launch_export(ctx->c, ctx->f, true, op.scale, op.dst, ctx->stream));
+        const int e = launch_export(ctx->c, ctx->f, true, op.scale, op.dst, ctx->stream);
+        if (e) ctx->last_hip = e, ctx->last_error = FLAME_NLTGV2_ERR_HIP, replay_rc = FLAME_NLTGV2_ERR_HIP;
       }
+      if (replay_rc) break;
     }
+    ctx->replaying = false;
+    if (replay_rc) return replay_rc;
     return finish(ctx);
   }
+  if (run.active && ctx->last_run_path >= 5) ctx->persist_timeout_streak = 0;  // (a persistent run went through: the next expired one starts over)
   if (*ctx->h_err != 0) {
     // NaN/Inf in a dual variable (the reference's FLAME_ASSERT h:174): reported once; the state stays readable
     // (download_state, costs) and the solve can go on or be re-initialised -- q was clamped to +-1 where it happened

@@ -494,8 +494,9 @@ def test_persistent_timeout_is_rolled_back_and_redone(env, form):
         info = reg.info()
         assert info["timeouts_recovered"] == 1 and info["last_run_path"] in (2, 3)
         assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="after recovery")
-        reg.run(p, 10)                       # the topology stays on the per-step path while the fault is on
-        oracle.run(ref, 10)
+        for _ in range(6):                   # the topology stays on the per-step path while the fault is on (and for a few runs after an
+            reg.run(p, 10)                   # expired run in any case: 4, then 8, ... up to 1024 -- a stall that passes is tried again)
+            oracle.run(ref, 10)
         assert reg.info()["timeouts_recovered"] == 1
         reg.set_option(flame_amd.regularizer.OPT_FAULT_INJECT, 0)  # fault off: persistent runs again
         reg.run(p, 25)
@@ -735,6 +736,37 @@ def test_record_placement_is_bit_identical_and_well_formed(env, config):
                 assert reg.layout_selftest() == 0
             else:
                 assert pi["state"] == 0 and pi["placed_records"] == 0, pi
+
+
+@pytest.mark.gpu
+def test_after_an_expired_run_the_persistent_path_is_tried_again(env):
+    """An expired run does not leave a static graph on the per-step path for good: the next 4 runs of the topology go per step, then
+    the persistent launch is tried again (8 after a second expired run in a row, ... 1024 at most)."""
+    flame_amd, oracle = env
+    from flame_amd.regularizer import OPT_FAULT_INJECT, OPT_VERIFY_RECORDS
+
+    g = synth.make_graph("320x240", seed=77)
+    p = flame_amd.Params()
+    ref = synth.copy_graph(g)
+    with flame_amd.Regularizer(0) as reg:
+        reg.upload_graph(g)
+        reg.set_option(OPT_VERIFY_RECORDS, 2)   # test hook: one corrupted re-read in the next persistent run -> taken back like an expired run
+        reg.run(p, 12)
+        oracle.run(ref, 12)
+        assert reg.info()["torn_records_detected"] == 1 and reg.info()["last_run_path"] in (2, 3)
+        paths = []
+        for _ in range(6):
+            reg.run(p, 12)
+            oracle.run(ref, 12)
+            paths.append(reg.info()["last_run_path"])
+        # four runs per step, then the persistent launch again -- where the hook fires once more (8 runs of back-off now)
+        assert paths[:4] == [paths[0]] * 4 and paths[0] in (2, 3), paths
+        assert reg.info()["torn_records_detected"] == 2, (paths, reg.info()["torn_records_detected"])
+        reg.set_option(OPT_VERIFY_RECORDS, 0)
+        reg.run(p, 12)
+        oracle.run(ref, 12)
+        assert reg.info()["last_run_path"] == 6
+        assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS, what="after the back-off")
 
 
 @pytest.mark.gpu
