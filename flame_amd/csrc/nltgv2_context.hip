@@ -209,7 +209,7 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
     if (rc) return rc;
   }
   ctx->topo++;
-  ctx->tv_built = false;
+  ctx->tv_built = ctx->wg2_built = false;
   drop_graphs(ctx);
   refresh_args(ctx);
 
@@ -263,6 +263,28 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
 // frames run in the patch-per-wave form and never need them).
 int ensure_form_rows(flame_nltgv2_ctx* ctx, int form) {
   PackedLayout& L = ctx->L;
+  if (form == 4 && !ctx->wg2_built) {
+    build_patch_rows2(&L);
+    ctx->pv2_args = Pv2Args{};
+    if (L.wg2_ok) {
+      struct { DevBuf* b; const void* src; size_t bytes; } cp[] = {
+          {&ctx->wg2_slot, L.wg2_slot.data(), sizeof(int32_t) * L.wg2_slot.size()}, {&ctx->wg2_vid, L.wg2_vid.data(), sizeof(int32_t) * L.wg2_vid.size()},
+          {&ctx->wg2_meta, L.wg2_meta.data(), sizeof(uint32_t) * L.wg2_meta.size()}, {&ctx->wg2_nbr, L.wg2_nbr.data(), sizeof(int32_t) * L.wg2_nbr.size()},
+          {&ctx->wg2_fetch, L.wg2_fetch.data(), sizeof(int32_t) * L.wg2_fetch.size()}, {&ctx->wg2_info, L.wg2_info.data(), sizeof(int32_t) * L.wg2_info.size()}};
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      for (auto& c : cp) {
+        int rc = ensure(ctx, *c.b, c.bytes);
+        if (!rc) rc = h2d(ctx, *c.b, c.src, c.bytes);
+        if (rc) return rc;
+      }
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      ctx->pv2_args.slot = (const int32_t*)ctx->wg2_slot.p, ctx->pv2_args.vid = (const int32_t*)ctx->wg2_vid.p, ctx->pv2_args.meta = (const uint32_t*)ctx->wg2_meta.p;
+      ctx->pv2_args.nbr = (const int32_t*)ctx->wg2_nbr.p, ctx->pv2_args.fetch = (const int32_t*)ctx->wg2_fetch.p, ctx->pv2_args.info = (const int32_t*)ctx->wg2_info.p;
+      ctx->pv2_args.count = L.wg2_count, ctx->pv2_args.lcap = L.wg2_lcap;
+      ctx->pv2_occ = pv2_patches_per_cu(L.wg2_lcap);
+    }
+    ctx->wg2_built = true;
+  }
   if (form == 2 && !ctx->tv_built) {
     build_tv_rows(&L);
     struct { DevBuf* b; const void* src; size_t bytes; } cp[] = {
@@ -336,7 +358,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
               &ctx->w2p, &ctx->data, &ctx->weight, &ctx->src, &ctx->dst, &ctx->alpha, &ctx->beta, &ctx->q1,
               &ctx->q2, &ctx->q3, &ctx->row_ptr, &ctx->half, &ctx->slice_row, &ctx->perm, &ctx->pdeg,
               &ctx->rec_nbr, &ctx->rec_edge, &ctx->edge_src_slot, &ctx->hrec, &ctx->hq, &ctx->vstate, &ctx->hq_alt, &ctx->vstate_alt, &ctx->cost_terms, &ctx->run_tail,
-              &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->xbuf, &ctx->abort_flag, &ctx->tv_slot, &ctx->tv_vid, &ctx->tv_meta, &ctx->tv_wave, &ctx->err,
+              &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->xbuf, &ctx->abort_flag, &ctx->tv_slot, &ctx->tv_vid, &ctx->tv_meta, &ctx->tv_wave, &ctx->wg2_slot, &ctx->wg2_vid, &ctx->wg2_meta, &ctx->wg2_nbr, &ctx->wg2_fetch, &ctx->wg2_info, &ctx->err,
               &ctx->cost_out, &ctx->img_ref, &ctx->img_cmp, &ctx->photo_err, &ctx->r_tris, &ctx->r_valid, &ctx->r_keys,
               &ctx->r_img, &ctx->r_cov, &ctx->r_vtx, &ctx->r_val, &ctx->wg_slot, &ctx->wg_vid, &ctx->wg_meta, &ctx->wg_nbr,
               &ctx->wg_fetch, &ctx->wg_info, &ctx->wg_v0, &ctx->probe, &ctx->snap_hq, &ctx->snap_vstate, &ctx->snap_bar, &ctx->iperm,
@@ -388,7 +410,7 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
       ctx->opt_block_waves = value;
       return 0;
     case FLAME_NLTGV2_OPT_PERSISTENT:
-      if (value < 0 || value > 4 || value == 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // (2: the retired lane-per-half-edge form)
+      if (value < 0 || value > 6 || value == 2 || value == 5) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // (2: the retired lane-per-half-edge form; 6: experimental)
       ctx->opt_persistent = value;
       return 0;
     case FLAME_NLTGV2_OPT_PLACEMENT:

@@ -224,6 +224,9 @@ struct flame_nltgv2_ctx {
   DevBuf snap_hq, snap_vstate, snap_bar;
   DevBuf iperm, order_m, rid_of;   // per-vertex tables the device-side layout expansion reads (nltgv2_layout.hip)
   bool tv_built = false;  // layout (D) exists for the current topology (built on demand)
+  bool wg2_built = false; // ... and layout (E2) (two half-edges per lane; experimental)
+  Pv2Args pv2_args;
+  int pv2_occ = 0;
   void* h_stage = nullptr;         // pinned staging buffer of the uploads
   DevBuf d_stage;                 // ... and its device-side landing area (one copy; k_scatter distributes)
   size_t stage_cap = 0;
@@ -243,7 +246,7 @@ struct flame_nltgv2_ctx {
   bool tail_valid = false;
   std::vector<float> h_terms;
   DevBuf hq_alt, vstate_alt;  // the other copies of hq / vstate: a persistent run writes there, success swaps the roles
-  DevBuf xbuf, abort_flag, tv_slot, tv_vid, tv_meta, tv_wave;
+  DevBuf xbuf, abort_flag, tv_slot, tv_vid, tv_meta, tv_wave, wg2_slot, wg2_vid, wg2_meta, wg2_nbr, wg2_fetch, wg2_info;
   DevBuf wg_slot, wg_vid, wg_meta, wg_nbr, wg_fetch, wg_info, wg_v0, wg_vfirst, probe, progress;
   // misc
   DevBuf err, cost_out, img_ref, img_cmp, photo_err, r_tris, r_valid, r_keys, r_img, r_cov, r_vtx, r_val;

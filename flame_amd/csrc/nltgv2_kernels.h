@@ -157,6 +157,19 @@ struct SyncArgs {
 };
 int launch_sync_state(const SyncArgs& a, hipStream_t s);
 int pv_patches_per_cu(const FusedArgs& a, bool verify);
+// layout (E2) on the device (nltgv2_persistent_pv2.hip: two half-edges per lane; experimental)
+struct Pv2Args {
+  const int32_t* slot = nullptr;   // [count*2*64]
+  const int32_t* vid = nullptr;    // [count*64]
+  const uint32_t* meta = nullptr;  // [count*64]
+  const int32_t* nbr = nullptr;    // [count*2*64]
+  const int32_t* fetch = nullptr;  // [count*64]
+  const int32_t* info = nullptr;   // [count*4]
+  int count = 0, lcap = 0;
+};
+int pv2_patches_per_cu(int lcap);
+int launch_persistent_pv2(const FusedArgs& a, const Pv2Args& w, const SolverParams& p, int wg_begin, int n_wgs, int parity_in, unsigned tag0,
+                          int n_iters, unsigned max_spins, int poll_gap, int dual, const RunTail* tail, bool cooperative, hipStream_t stream);
 int pv_real_waves_per_simd(bool verify_or_probe);
 const void* persistent_tv_kernel(bool static_in_lds, int waves_per_block, unsigned* lds_bytes);  // nltgv2_persistent_tv.hip
 // device-side expansion of the layout arrays (nltgv2_layout.hip)

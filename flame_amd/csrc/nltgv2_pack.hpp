@@ -96,6 +96,19 @@ struct PackedLayout {
   bool wg_rowpack = false;
   std::vector<uint8_t> wg_vfirst;
   std::vector<int32_t> comp_wg;        // [n_comp+1] first patch of each component
+  // (E2) patch-per-wave rows with TWO half-edges per lane (k_persistent_pv2): the same walk and record ids, a vertex of d edges
+  // takes max(1, ceil(d / 2)) consecutive lanes of one 16-lane row (more than 8 lanes: a row to itself; the form is not
+  // built for a graph with a vertex of more than 32 edges); lane first + j holds half-edges 2j (slot 0) and 2j + 1 (slot 1)
+  // of the vertex in ascending edge id.  Half as many waves as (E) for the same graph.
+  bool wg2_ok = false;
+  int32_t wg2_count = 0, wg2_lcap = 0, wg2_rcap = 0;
+  std::vector<int32_t> wg2_slot;       // [wg2_count*2*64] (patch, slot s, lane) -> SELL slot of the half-edge, -1 idle
+  std::vector<int32_t> wg2_nbr;        // [wg2_count*2*64] neighbour of that half-edge: local index, or 0x80000000 | fetch index
+  std::vector<int32_t> wg2_vid;        // [wg2_count*64] packed vertex owning the lane, -1 unused lane
+  std::vector<uint32_t> wg2_meta;      // [wg2_count*64] first lane | lanes of the vertex<<6 | local index<<13 | flags<<24 (kWgActive: slot 0 is a half-edge)
+  std::vector<int32_t> wg2_fetch;      // [wg2_count*64] record id fetched by this lane, -1 none
+  std::vector<int32_t> wg2_info;       // [wg2_count*4] first record id, fetched records, local vertices, most lanes of a vertex
+  std::vector<int32_t> comp_wg2;       // [n_comp+1] first patch of each component
   int32_t n_rec = 0;                   // record ids in use (= V: a record's id is its vertex's position in the walk)
   std::vector<int32_t> wg_v0;          // [wg_count] walk position of the patch's first vertex (= its first record id)
 };
@@ -345,6 +358,107 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
     }
   }
   L->wg_ok = true;  // (a patch has at most 64 half-edges, hence at most 64 distinct foreign records: one per lane)
+}
+
+// ---- (E2) two half-edges per lane (host only; built on demand) -------------------------------------------------------
+inline void build_patch_rows2(PackedLayout* L) {
+  const int32_t V = L->V;
+  constexpr int32_t T = kWave;
+  const std::vector<int32_t>& order_m = L->order_m;
+  L->wg2_ok = false;
+  L->wg2_count = 0, L->wg2_lcap = 0, L->wg2_rcap = 0;
+  L->wg2_slot.clear(), L->wg2_nbr.clear(), L->wg2_vid.clear(), L->wg2_meta.clear(), L->wg2_fetch.clear(), L->wg2_info.clear();
+  L->comp_wg2.clear();
+  if (V <= 0 || L->max_degree > 32) return;
+  std::vector<uint8_t> vfirst(static_cast<size_t>(V));
+  std::vector<int32_t> v0s;
+  int32_t n_local = 0, max_l = 1;
+  WaveFit fit;
+  fit.rowpack = true;
+  size_t next_comp = 0;
+  for (int32_t i = 0; i < V; ++i) {
+    const int32_t o = order_m[i];
+    const int32_t d = L->row_ptr[o + 1] - L->row_ptr[o];
+    const int32_t need = std::max((d + 1) / 2, 1);
+    const bool comp_begin = next_comp < L->comp_start.size() && L->comp_start[next_comp] == i;
+    if (comp_begin) ++next_comp;
+    int32_t fill = comp_begin ? -1 : fit.place(need);
+    if (fill < 0) {
+      if (L->wg2_count > 0) L->wg2_info[static_cast<size_t>(L->wg2_count - 1) * 4 + 3] = max_l;
+      if (comp_begin) L->comp_wg2.push_back(L->wg2_count);
+      L->wg2_info.resize(L->wg2_info.size() + 4, 0);
+      L->wg2_info[static_cast<size_t>(L->wg2_count) * 4] = i;
+      v0s.push_back(i);
+      L->wg2_count++;
+      n_local = 0, max_l = 1;
+      fit.open(need);
+      fill = fit.place(need);
+    }
+    max_l = std::max(max_l, need);
+    L->wg2_info[static_cast<size_t>(L->wg2_count - 1) * 4 + 2] = ++n_local;
+    L->wg2_lcap = std::max(L->wg2_lcap, n_local);
+    vfirst[static_cast<size_t>(i)] = static_cast<uint8_t>(fill);
+  }
+  if (L->wg2_count > 0) L->wg2_info[static_cast<size_t>(L->wg2_count - 1) * 4 + 3] = max_l;
+  L->comp_wg2.push_back(L->wg2_count);
+  const size_t lanes = static_cast<size_t>(L->wg2_count) * T;
+  L->wg2_slot.assign(2 * lanes, -1), L->wg2_nbr.assign(2 * lanes, 0), L->wg2_vid.assign(lanes, -1), L->wg2_meta.assign(lanes, 0u);
+  L->wg2_fetch.assign(lanes, -1);
+  std::vector<int32_t> want;
+  const int32_t* rid = L->rid_of.data();
+  for (int32_t wg = 0; wg < L->wg2_count; ++wg) {
+    const size_t b = static_cast<size_t>(wg) * T, b2 = static_cast<size_t>(wg) * 2 * T;
+    const int32_t r0 = L->wg2_info[static_cast<size_t>(wg) * 4];
+    const int32_t n_loc = L->wg2_info[static_cast<size_t>(wg) * 4 + 2], r1 = r0 + n_loc;
+    const int32_t v0 = v0s[static_cast<size_t>(wg)];
+    want.clear();
+    for (int32_t i = 0; i < n_loc; ++i) {
+      const int32_t o = order_m[v0 + i];
+      for (int32_t h = L->row_ptr[o]; h < L->row_ptr[o + 1]; ++h) {
+        const int32_t r = rid[L->half_nbr[h]];
+        if (r < r0 || r >= r1) want.push_back(r);
+      }
+    }
+    std::sort(want.begin(), want.end());
+    want.erase(std::unique(want.begin(), want.end()), want.end());
+    const int32_t n_want = static_cast<int32_t>(want.size());
+    if (n_want > T) return;  // (more distinct foreign records than lanes: the form cannot run this graph; wg2_ok stays false)
+    for (int32_t k = 0; k < n_want; ++k) L->wg2_fetch[b + k] = want[static_cast<size_t>(k)];
+    L->wg2_info[static_cast<size_t>(wg) * 4 + 1] = n_want;
+    L->wg2_rcap = std::max(L->wg2_rcap, n_want);
+    for (int32_t i = 0; i < n_loc; ++i) {
+      const int32_t o = order_m[v0 + i];
+      const int32_t s = L->iperm[o];
+      const int32_t d = L->row_ptr[o + 1] - L->row_ptr[o], need = std::max((d + 1) / 2, 1);
+      const int32_t lane = vfirst[static_cast<size_t>(v0 + i)];
+      const int64_t row0 = L->slice_row[s / kWave];
+      bool publishes = false;
+      for (int32_t j = 0; j < need; ++j) {
+        uint32_t m = static_cast<uint32_t>(lane) | (static_cast<uint32_t>(need) << 6) | (static_cast<uint32_t>(i) << 13) | kWgValid;
+        if (j == need - 1) m |= kWgTail;
+        if (j == 0) m |= kWgHead;
+        for (int32_t sl = 0; sl < 2; ++sl) {
+          const int32_t k = 2 * j + sl;
+          if (k >= d) continue;
+          if (sl == 0) m |= kWgActive;
+          L->wg2_slot[b2 + static_cast<size_t>(sl) * T + lane + j] = static_cast<int32_t>((row0 + k) * kWave + (s % kWave));
+          const int32_t r = rid[L->half_nbr[L->row_ptr[o] + k]];
+          if (r >= r0 && r < r1) {
+            L->wg2_nbr[b2 + static_cast<size_t>(sl) * T + lane + j] = r - r0;
+          } else {
+            const int32_t fi = static_cast<int32_t>(std::lower_bound(want.begin(), want.end(), r) - want.begin());
+            L->wg2_nbr[b2 + static_cast<size_t>(sl) * T + lane + j] = static_cast<int32_t>(0x80000000u | static_cast<uint32_t>(fi));
+            publishes = true;
+          }
+        }
+        L->wg2_vid[b + lane + j] = s;
+        L->wg2_meta[b + lane + j] = m;
+      }
+      if (publishes)
+        for (int32_t j = 0; j < need; ++j) L->wg2_meta[b + lane + j] |= kWgPublish;
+    }
+  }
+  L->wg2_ok = true;
 }
 
 // host_expand = false: only what needs the host (per-vertex tables: (A), the walk order, (B)'s slice table, (E)'s patch

@@ -56,7 +56,10 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
   const bool pv_fits = L.wg_ok && L.wg_rowpack && L.wg_count > 0 && L.wg_count <= wg_cap;  // (the kernel runs row-packed patches)
   int form = 0;
   if (ctx->opt_persistent == 4) form = (L.wg_ok && L.wg_rowpack) ? 3 : 0;
-  else if (ctx->opt_persistent == 3) form = 2;
+  else if (ctx->opt_persistent == 6) {  // two half-edges per lane (experimental, by name only)
+    if (ensure_form_rows(ctx, 4) != 0) return 0;
+    form = (L.wg2_ok && ctx->pv2_occ > 0) ? 4 : 0;
+  } else if (ctx->opt_persistent == 3) form = 2;
   else if (pv_fits) form = 3;  // lowest latency wherever all patches are resident: 320x240 ... 1920x1080 single frames, 2-7 frames of 640x480
   else form = 2;               // too big for that: vertex-per-lane, in groups of whole components if need be
   if (form == 2) {
@@ -71,14 +74,14 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
   const int tv_cap = (tv_lds ? kTvLdsWavesPerCu : kTvWavesPerCu) * cus;
   if (use_tv_lds) *use_tv_lds = tv_lds ? 1 : 0;
   if (form == 0) return 0;
-  const int total = form == 3 ? L.wg_count : L.tv_waves;
-  const int cap = form == 3 ? wg_cap : tv_cap;
+  const int total = form == 4 ? L.wg2_count : form == 3 ? L.wg_count : L.tv_waves;
+  const int cap = form == 4 ? std::max(1, ctx->pv2_occ - 1) * cus : form == 3 ? wg_cap : tv_cap;
   if (total <= 0) return 0;
   if (total <= cap) {
     groups->push_back(WaveGroup{0, total});
     return form;
   }
-  const std::vector<int32_t>& cw = form == 3 ? L.comp_wg : L.comp_tv_wave;
+  const std::vector<int32_t>& cw = form == 4 ? L.comp_wg2 : form == 3 ? L.comp_wg : L.comp_tv_wave;
   if (cw.size() < 3) return 0;  // one component that does not fit: stream it
   // Groups of about equal size (the per-step time of a group grows with its waves, and a small last group would run
   // at low occupancy): cut at the component boundaries nearest to k * total / n_groups, never beyond what the chip
@@ -424,6 +427,15 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
           HIPCHK(ctx, hipMemsetAsync(ctx->probe.p, 0, words * sizeof(unsigned), ctx->stream));  // (idle instances write nothing)
         }
       }
+      if (form == 4) {  // two half-edges per lane: the pacing of the one-half-edge form at the same number of waves per CU
+        const bool dense = gr.count > kPvPaceAbovePerCu * ctx->prop.multiProcessorCount;
+        const int gap = ctx->opt_poll_gap > 0 ? ctx->opt_poll_gap - 1 : dense ? (3 | ((kPvDenseGap - 1) << 4)) : kPvPollGap;
+        const int poll_gap = gap | ((ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : dense ? kPvDensePreSleep : kPvPreSleep) << 8);
+        e = launch_persistent_pv2(ctx->f, ctx->pv2_args, to_sp(p), gr.begin, gr.count, ctx->parity, tag0, n, spins_arg, poll_gap, dual & 1,
+                                  (const RunTail*)ctx->run_tail.p, ctx->coop_checked_key != key, ctx->stream);
+        if (e != 0) break;
+        continue;
+      }
       e = launch_persistent_run(ctx->f, to_sp(p), form, gr.begin, gr.count, ctx->parity, tag0, n, pw, spins_arg, presleep, dual,
                                 tv_lds, xcds, (const RunTail*)ctx->run_tail.p, ctx->coop_checked_key != key, ctx->stream);
       if (e != 0) break;
@@ -447,7 +459,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       ctx->buf_gen ^= 1;
       refresh_args(ctx);
       ctx->coop_checked_key = key;
-      ctx->last_run_path = form == 3 ? 6 : 5;
+      ctx->last_run_path = form == 4 ? 7 : form == 3 ? 6 : 5;
       ctx->last_run_groups = (int)groups.size();
       ctx->last_run_waves_per_cu = 0;
       for (const WaveGroup& gr : groups) ctx->last_run_waves_per_cu = std::max(ctx->last_run_waves_per_cu, (gr.count + ctx->prop.multiProcessorCount - 1) / ctx->prop.multiProcessorCount);

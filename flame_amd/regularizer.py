@@ -31,7 +31,7 @@ OPT_SOLVER, OPT_USE_HIPGRAPH, OPT_PERSISTENT, OPT_PROBE, OPT_VERIFY_RECORDS, OPT
 # ... and the experimental range (tuning knobs / test hooks of the current kernels; tools/ and the tests use them)
 OPT_BLOCK_WAVES, OPT_UNROLL, OPT_DUAL_PUBLISH, OPT_TV_LDS, OPT_PRESLEEP, OPT_XCDS, OPT_FAULT_INJECT, OPT_POLL_GAP = 103, 104, 106, 107, 108, 109, 110, 113
 RUN_PATHS = {0: "none", 1: "persistent (the lane-per-half-edge form, retired in round 3)", 2: "per-step hipGraph", 3: "per-step eager", 4: "canonical 4-sweep",
-             5: "persistent-tv", 6: "persistent-pv"}
+             5: "persistent-tv", 6: "persistent-pv", 7: "persistent-pv2"}
 ERR_NAN = -5
 
 VERTEX_STATE = ("x", "w1", "w2", "x_bar", "w1_bar", "w2_bar", "x_prev", "w1_prev", "w2_prev")

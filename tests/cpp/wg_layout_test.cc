@@ -291,6 +291,171 @@ static int replay(HostGraph& hg, int n_iters, const nltgv2_params& p, bool rowpa
   return 0;
 }
 
+// The same replay for layout (E2): two half-edges per lane (slot 0 = half-edge 2j, slot 1 = 2j + 1 of the vertex whose j-th lane this is).
+static int replay2(HostGraph& hg, int n_iters, const nltgv2_params& p) {
+  flame_nltgv2_graph g = hg.view();
+  PackedLayout L;
+  if (build_layout(&g, &L, true, true) != 0) return 1;
+  build_patch_rows2(&L);
+  if (!L.wg2_ok) return 2;
+  const int T = 64, V = g.V;
+  std::vector<int> seen(L.n_slices * 64, 0);
+  for (int wg = 0; wg < L.wg2_count; ++wg) {
+    for (int t = 0; t < T; ++t) {
+      const size_t hl = (size_t)wg * T + t;
+      const uint32_t m = L.wg2_meta[hl];
+      if (!(m & kWgValid)) {
+        if (L.wg2_slot[(size_t)wg * 2 * T + t] >= 0 || L.wg2_slot[(size_t)wg * 2 * T + T + t] >= 0) return 3;
+        continue;
+      }
+      const int first = m & 63, need = (m >> 6) & 127;
+      if (need < 1 || first + need > 64 || first / 16 != (first + need - 1) / 16) return 4;
+      if (need > 8 && first % 16 != 0) return 5;
+      const int j = t - first;
+      if (j < 0 || j >= need) return 6;
+      if (((m & kWgHead) != 0) != (j == 0) || ((m & kWgTail) != 0) != (j == need - 1)) return 7;
+      if (((m & kWgActive) != 0) != (L.wg2_slot[(size_t)wg * 2 * T + t] >= 0)) return 8;
+      if (L.wg2_slot[(size_t)wg * 2 * T + T + t] >= 0 && !(m & kWgActive)) return 9;  // slot 1 only behind a slot 0
+      if (m & kWgTail) seen[L.wg2_vid[hl]]++;
+      if ((int)((m >> 13) & 2047) >= L.wg2_info[4 * wg + 2] || L.wg2_info[4 * wg + 2] > L.wg2_lcap) return 10;
+      if (need > L.wg2_info[4 * wg + 3]) return 11;
+    }
+    if (L.wg2_info[4 * wg + 1] > L.wg2_rcap || L.wg2_info[4 * wg + 1] > T) return 12;
+    for (int i = 1; i < L.wg2_info[4 * wg + 1]; ++i)
+      if (L.wg2_fetch[(size_t)wg * T + i] <= L.wg2_fetch[(size_t)wg * T + i - 1]) return 13;
+  }
+  for (int v = 0; v < V; ++v)
+    if (seen[L.iperm[v]] != 1) return 14;
+  const size_t NL = (size_t)L.wg2_count * T;
+  struct Lane { float x, w1, w2, xb, w1b, w2b, xp, w1p, w2p, q[2][3]; };
+  std::vector<Lane> ln(NL);
+  std::vector<Rec> glob[2] = {std::vector<Rec>(L.n_rec, Rec{0, 0, 0, 0}), std::vector<Rec>(L.n_rec, Rec{0, 0, 0, 0})};
+  const int stride = L.wg2_lcap + L.wg2_rcap;
+  std::vector<Rec> area[2] = {std::vector<Rec>((size_t)L.wg2_count * stride), std::vector<Rec>((size_t)L.wg2_count * stride)};
+  auto slot_of = [&](size_t hl, int sl) { return L.wg2_slot[(hl / T) * 2 * T + (size_t)sl * T + (hl % T)]; };
+  auto nbr_of = [&](size_t hl, int sl) { return L.wg2_nbr[(hl / T) * 2 * T + (size_t)sl * T + (hl % T)]; };
+  const unsigned tag0 = 5;
+  for (size_t hl = 0; hl < NL; ++hl) {
+    const uint32_t m = L.wg2_meta[hl];
+    if (!(m & kWgValid)) continue;
+    const int o = L.perm[L.wg2_vid[hl]];
+    Lane& a = ln[hl];
+    a.x = hg.x[o], a.w1 = hg.w1[o], a.w2 = hg.w2[o], a.xb = hg.xb[o], a.w1b = hg.w1b[o], a.w2b = hg.w2b[o];
+    a.xp = a.x, a.w1p = a.w1, a.w2p = a.w2;
+    for (int sl = 0; sl < 2; ++sl)
+      if (slot_of(hl, sl) >= 0) {
+        const int e = L.rec_edge[slot_of(hl, sl)];
+        a.q[sl][0] = hg.q1[e], a.q[sl][1] = hg.q2[e], a.q[sl][2] = hg.q3[e];
+      }
+    if (m & kWgHead) {
+      const int wg = (int)(hl / T), loc = (m >> 13) & 2047;
+      area[tag0 & 1][(size_t)wg * stride + loc] = Rec{a.xb, a.w1b, a.w2b, tag0};
+      if (m & kWgPublish) glob[tag0 & 1][L.wg2_info[4 * wg] + loc] = Rec{a.xb, a.w1b, a.w2b, tag0};
+    }
+  }
+  std::vector<float> c(NL * 2 * 5, -0.0f);  // per lane and slot: cx, a1, a2, b1, b2 (idle slots add -0.0)
+  for (int it = 0; it < n_iters; ++it) {
+    const unsigned s = tag0 + it;
+    const int par = s & 1;
+    for (int wg = 0; wg < L.wg2_count; ++wg)
+      for (int i = 0; i < L.wg2_info[4 * wg + 1]; ++i) {
+        const Rec r = glob[par][L.wg2_fetch[(size_t)wg * T + i]];
+        if (r.tag != s) return 15;
+        area[par][(size_t)wg * stride + L.wg2_lcap + i] = r;
+      }
+    for (size_t hl = 0; hl < NL; ++hl)
+      for (int sl = 0; sl < 2; ++sl) {
+        float* cc = &c[(hl * 2 + sl) * 5];
+        cc[0] = cc[1] = cc[2] = cc[3] = cc[4] = -0.0f;
+        const int slot = slot_of(hl, sl);
+        if (slot < 0) continue;
+        const int wg = (int)(hl / T), e = L.rec_edge[slot];
+        const bool is_target = (L.rec_nbr[slot] & kRoleBit) != 0;
+        const int code = nbr_of(hl, sl);
+        const int idx = code < 0 ? L.wg2_lcap + (code & 0x7fffffff) : code;
+        const Rec nb = area[par][(size_t)wg * stride + idx];
+        if (nb.tag != s) return 16;
+        // the lane's own (x_bar, w_bar): its vertex's record of this step (the head wrote it)
+        const uint32_t m = L.wg2_meta[hl];
+        const Rec own = area[par][(size_t)wg * stride + ((m >> 13) & 2047)];
+        if (own.tag != s) return 17;
+        Lane& a = ln[hl];
+        const float alpha = hg.alpha[e], beta = hg.beta[e];
+        const int si = hg.src[e], di = hg.dst[e];
+        const float dx = hg.pos[2 * si] - hg.pos[2 * di], dy = hg.pos[2 * si + 1] - hg.pos[2 * di + 1];
+        const float xbi = is_target ? nb.xb : own.xb, xbj = is_target ? own.xb : nb.xb;
+        const float w1bi = is_target ? nb.w1b : own.w1b, w1bj = is_target ? own.w1b : nb.w1b;
+        const float w2bi = is_target ? nb.w2b : own.w2b, w2bj = is_target ? own.w2b : nb.w2b;
+        float K1 = alpha * (xbi - xbj);
+        K1 -= alpha * dx * w1bi;
+        K1 -= alpha * dy * w2bi;
+        a.q[sl][0] = clampq(a.q[sl][0] + p.step_q * K1);
+        a.q[sl][1] = clampq(a.q[sl][1] + p.step_q * (beta * (w1bi - w1bj)));
+        a.q[sl][2] = clampq(a.q[sl][2] + p.step_q * (beta * (w2bi - w2bj)));
+        const float t1 = a.q[sl][0] * p.step_x * alpha, t2 = a.q[sl][1] * p.step_x * beta, t3 = a.q[sl][2] * p.step_x * beta;
+        cc[0] = is_target ? t1 : -t1;
+        cc[1] = is_target ? t2 : t1 * dx;
+        cc[2] = is_target ? t3 : t1 * dy;
+        cc[3] = is_target ? -0.0f : -t2;
+        cc[4] = is_target ? -0.0f : -t3;
+      }
+    for (size_t hl = 0; hl < NL; ++hl) {  // the head of every vertex: own slots first, then lane first + 1, ... in order
+      const uint32_t m = L.wg2_meta[hl];
+      if (!(m & kWgHead)) continue;
+      const int wg = (int)(hl / T), need = (m >> 6) & 127, loc = (m >> 13) & 2047;
+      Lane& a = ln[hl];
+      float X = a.x, W1 = a.w1, W2 = a.w2;
+      for (int j = 0; j < need; ++j)
+        for (int sl = 0; sl < 2; ++sl) {
+          const float* cc = &c[((hl + j) * 2 + sl) * 5];
+          X = X + cc[0];
+          W1 = (W1 + cc[1]) + cc[3];
+          W2 = (W2 + cc[2]) + cc[4];
+        }
+      const int o = L.perm[L.wg2_vid[hl]];
+      const float xn = prox_l1(p.x_min, p.x_max, p.step_x, p.data_factor * hg.weight[o], X, hg.data[o]);
+      float nb = xn + p.theta * (xn - a.x);
+      nb = nb < p.x_min ? p.x_min : nb;
+      nb = nb > p.x_max ? p.x_max : nb;
+      const float w1bn = W1 + p.theta * (W1 - a.w1), w2bn = W2 + p.theta * (W2 - a.w2);
+      area[par ^ 1][(size_t)wg * stride + loc] = Rec{nb, w1bn, w2bn, s + 1};
+      if (m & kWgPublish) glob[par ^ 1][L.wg2_info[4 * wg] + loc] = Rec{nb, w1bn, w2bn, s + 1};
+      a.xp = a.x, a.w1p = a.w1, a.w2p = a.w2;
+      a.x = xn, a.w1 = W1, a.w2 = W2, a.xb = nb, a.w1b = w1bn, a.w2b = w2bn;
+    }
+  }
+  HostGraph ref = hg;
+  flame_nltgv2_graph rg = ref.view();
+  nltgv2_oracle_run(&p, &rg, n_iters);
+  long bad = 0;
+  for (size_t hl = 0; hl < NL; ++hl) {
+    const uint32_t m = L.wg2_meta[hl];
+    if (!(m & kWgValid)) continue;
+    const Lane& a = ln[hl];
+    if (m & kWgHead) {
+      const int o = L.perm[L.wg2_vid[hl]];
+      const float got[9] = {a.x, a.w1, a.w2, a.xb, a.w1b, a.w2b, a.xp, a.w1p, a.w2p};
+      const float want[9] = {ref.x[o], ref.w1[o], ref.w2[o], ref.xb[o], ref.w1b[o], ref.w2b[o], ref.xp[o], ref.w1p[o], ref.w2p[o]};
+      if (std::memcmp(got, want, sizeof got) != 0) ++bad;
+    }
+    for (int sl = 0; sl < 2; ++sl)
+      if (slot_of(hl, sl) >= 0) {
+        const int e = L.rec_edge[slot_of(hl, sl)];
+        const float wq[3] = {ref.q1[e], ref.q2[e], ref.q3[e]};
+        if (std::memcmp(a.q[sl], wq, sizeof wq) != 0) ++bad;
+      }
+  }
+  if (bad) {
+    std::printf("(E2) %ld lanes differ from the checker\n", bad);
+    return 18;
+  }
+  long fetch = 0;
+  for (int wg = 0; wg < L.wg2_count; ++wg) fetch += L.wg2_info[4 * wg + 1];
+  std::printf("(E2) V=%d E=%d patches=%d (one half-edge per lane: %d) lcap=%d rcap=%d fetched/step=%ld ok\n", V, g.E, L.wg2_count, L.wg_count,
+              L.wg2_lcap, L.wg2_rcap, fetch);
+  return 0;
+}
+
 int main() {
   const nltgv2_params p = {0.1f, 0.001f, 125.0f, 0.25f, 0.0f, 10.0f};
   for (int frames : {1, 3})
@@ -303,6 +468,14 @@ int main() {
           return 1;
         }
       }
+  for (int frames : {1, 3}) {  // two half-edges per lane (no vertex of more than 32 edges)
+    HostGraph g = make_graph(61, 47, frames, 4321 + frames, false);
+    const int rc = replay2(g, 6, p);
+    if (rc) {
+      std::printf("FAILED (E2) frames=%d rc=%d\n", frames, rc);
+      return 1;
+    }
+  }
   std::printf("all ok\n");
   return 0;
 }
