@@ -182,6 +182,19 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
     rc = build_layout(g, &ctx->L, /*host_expand=*/false, /*rowpack=*/false, 0);
     if (rc) return fail(ctx, rc);
   }
+  // Layout (E2), two half-edges per lane: where the one-half-edge patches would fill the CUs (kPv2FromPerCu per CU and more), or
+  // where it is asked for by name.  Pass 1 (per vertex) here, the lanes on the device below.
+  bool want_e2 = false;
+  {
+    const int cus = ctx->prop.multiProcessorCount;
+    const int64_t est_patches = ctx->L.wg_rowpack ? (int64_t)ctx->L.wg_count : ((static_cast<int64_t>(2) * E + V / 32) / 54 + 1);
+    want_e2 = ctx->L.wg_ok && ctx->L.max_degree <= 32 && ctx->opt_verify == 0 && ctx->opt_probe == 0 &&
+              (ctx->opt_persistent == 6 || (ctx->opt_persistent == 1 && est_patches > (int64_t)kPv2FromPerCu * cus));
+    if (want_e2) {
+      build_patch_walk2(&ctx->L);
+      want_e2 = ctx->L.wg2_ok && ctx->L.wg2_count <= kPv2WavesPerCu * cus * 4;  // (beyond four groups the vertex-per-lane form it is)
+    }
+  }
   const PackedLayout& L = ctx->L;
   const size_t n_slots = (size_t)(L.rows + kRowPad) * kWave;
   if (n_slots > (size_t)0x7fffffff) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
@@ -208,6 +221,17 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
     rc = ensure(ctx, *r.b, r.bytes);
     if (rc) return rc;
   }
+  const size_t lanes2 = want_e2 ? (size_t)L.wg2_count * kWave : 0;
+  if (want_e2) {
+    struct { DevBuf* b; size_t bytes; } req2[] = {
+        {&ctx->wg2_info, sizeof(int32_t) * L.wg2_info.size()}, {&ctx->wg2_vfirst, L.wg2_vfirst.size() + 16}, {&ctx->wg2_rmax, 64},
+        {&ctx->wg2_slot, sizeof(int32_t) * 2 * lanes2}, {&ctx->wg2_nbr, sizeof(int32_t) * 2 * lanes2}, {&ctx->wg2_vid, sizeof(int32_t) * lanes2},
+        {&ctx->wg2_meta, sizeof(uint32_t) * lanes2}, {&ctx->wg2_fetch, sizeof(int32_t) * lanes2}};
+    for (auto& r : req2) {
+      rc = ensure(ctx, *r.b, r.bytes);
+      if (rc) return rc;
+    }
+  }
   ctx->topo++;
   ctx->tv_built = ctx->wg2_built = false;
   drop_graphs(ctx);
@@ -222,6 +246,10 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
       {&ctx->wg_info, L.wg_info.data(), sizeof(int32_t) * L.wg_info.size()},
       {&ctx->wg_v0, L.wg_v0.data(), sizeof(int32_t) * L.wg_v0.size()},
       {&ctx->wg_vfirst, L.wg_vfirst.data(), L.wg_vfirst.size()}};
+  if (want_e2) {
+    cp.push_back(StageCopy{&ctx->wg2_info, L.wg2_info.data(), sizeof(int32_t) * L.wg2_info.size()});
+    cp.push_back(StageCopy{&ctx->wg2_vfirst, L.wg2_vfirst.data(), L.wg2_vfirst.size()});
+  }
   cp.insert(cp.end(), extra, extra + n_extra);
   std::vector<StageFill> fills = {
       {ctx->err.p, kErrBytes, 0u}, {ctx->abort_flag.p, sizeof(int), 0u}, {ctx->xbuf.p, kXbufBytesPerVertex * records_capacity(L) + 64, 0u},
@@ -231,6 +259,7 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
       {(char*)ctx->rec_edge.p + sizeof(int32_t) * (size_t)L.rows * kWave, sizeof(int32_t) * kRowPad * kWave, 0xffffffffu},
       {(char*)ctx->rec_nbr.p + sizeof(uint32_t) * (size_t)L.rows * kWave, sizeof(uint32_t) * kRowPad * kWave, 0u}};
   // (the tags start over below: no record of an earlier topology may survive, in the placement pool either)
+  if (want_e2) fills.push_back(StageFill{ctx->wg2_rmax.p, 64, 0u});
   if (ctx->place_base) {
     fills.push_back(StageFill{ctx->place_base, (size_t)2 * kPlacePages * 4096, 0u});
     fills.push_back(StageFill{(int*)ctx->place_fill.p + 2 * kPlacePages, 64, 0u});
@@ -242,6 +271,20 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
     LAUNCHCHK(ctx, launch_build_patches(ctx->c, ctx->f, (const int32_t*)ctx->wg_v0.p, (const int32_t*)ctx->order_m.p,
                                         (const int32_t*)ctx->rid_of.p, (const uint8_t*)ctx->wg_vfirst.p,
                                         (const int32_t*)ctx->iperm.p, ctx->stream));
+  ctx->pv2_args = Pv2Args{};
+  ctx->wg2_usable = false;
+  if (want_e2) {
+    LAUNCHCHK(ctx, launch_build_patches2(ctx->c, ctx->f, L.wg2_count, (int32_t*)ctx->wg2_info.p, (const int32_t*)ctx->order_m.p,
+                                         (const int32_t*)ctx->rid_of.p, (const uint8_t*)ctx->wg2_vfirst.p, (const int32_t*)ctx->iperm.p,
+                                         (int32_t*)ctx->wg2_slot.p, (int32_t*)ctx->wg2_vid.p, (uint32_t*)ctx->wg2_meta.p,
+                                         (int32_t*)ctx->wg2_nbr.p, (int32_t*)ctx->wg2_fetch.p, (int*)ctx->wg2_rmax.p, ctx->stream));
+    ctx->pv2_args.slot = (const int32_t*)ctx->wg2_slot.p, ctx->pv2_args.vid = (const int32_t*)ctx->wg2_vid.p;
+    ctx->pv2_args.meta = (const uint32_t*)ctx->wg2_meta.p, ctx->pv2_args.nbr = (const int32_t*)ctx->wg2_nbr.p;
+    ctx->pv2_args.fetch = (const int32_t*)ctx->wg2_fetch.p, ctx->pv2_args.info = (const int32_t*)ctx->wg2_info.p;
+    ctx->pv2_args.count = L.wg2_count, ctx->pv2_args.lcap = L.wg2_lcap;
+    if (ctx->pv2_occ == 0) ctx->pv2_occ = pv2_patches_per_cu(L.wg2_lcap);
+    ctx->wg2_built = true;  // (on the device; whether every patch can fetch its records the first plan reads from wg2_rmax)
+  }
   // where the records that cross XCDs go (if the pages have been timed already; otherwise the first run does both): on
   // the stream behind the layout kernels, nobody waits for it
   if (L.wg_ok && ctx->place_state == 1 && ctx->opt_place && L.wg_count > 2 * (ctx->prop.multiProcessorCount / 8) &&
@@ -284,6 +327,7 @@ int ensure_form_rows(flame_nltgv2_ctx* ctx, int form) {
       ctx->pv2_occ = pv2_patches_per_cu(L.wg2_lcap);
     }
     ctx->wg2_built = true;
+    ctx->wg2_usable = L.wg2_ok, ctx->wg2_checked_topo = ctx->topo;  // (the host builder knows)
   }
   if (form == 2 && !ctx->tv_built) {
     build_tv_rows(&L);
@@ -358,7 +402,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
               &ctx->w2p, &ctx->data, &ctx->weight, &ctx->src, &ctx->dst, &ctx->alpha, &ctx->beta, &ctx->q1,
               &ctx->q2, &ctx->q3, &ctx->row_ptr, &ctx->half, &ctx->slice_row, &ctx->perm, &ctx->pdeg,
               &ctx->rec_nbr, &ctx->rec_edge, &ctx->edge_src_slot, &ctx->hrec, &ctx->hq, &ctx->vstate, &ctx->hq_alt, &ctx->vstate_alt, &ctx->cost_terms, &ctx->run_tail,
-              &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->xbuf, &ctx->abort_flag, &ctx->tv_slot, &ctx->tv_vid, &ctx->tv_meta, &ctx->tv_wave, &ctx->wg2_slot, &ctx->wg2_vid, &ctx->wg2_meta, &ctx->wg2_nbr, &ctx->wg2_fetch, &ctx->wg2_info, &ctx->err,
+              &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->xbuf, &ctx->abort_flag, &ctx->tv_slot, &ctx->tv_vid, &ctx->tv_meta, &ctx->tv_wave, &ctx->wg2_slot, &ctx->wg2_vid, &ctx->wg2_meta, &ctx->wg2_nbr, &ctx->wg2_fetch, &ctx->wg2_info, &ctx->wg2_vfirst, &ctx->wg2_rmax, &ctx->err,
               &ctx->cost_out, &ctx->img_ref, &ctx->img_cmp, &ctx->photo_err, &ctx->r_tris, &ctx->r_valid, &ctx->r_keys,
               &ctx->r_img, &ctx->r_cov, &ctx->r_vtx, &ctx->r_val, &ctx->wg_slot, &ctx->wg_vid, &ctx->wg_meta, &ctx->wg_nbr,
               &ctx->wg_fetch, &ctx->wg_info, &ctx->wg_v0, &ctx->probe, &ctx->snap_hq, &ctx->snap_vstate, &ctx->snap_bar, &ctx->iperm,
@@ -550,6 +594,16 @@ int flame_nltgv2_layout_selftest(flame_nltgv2_ctx* ctx, int64_t* mismatches) {
       e |= cmp(ctx->wg_slot, H.wg_slot.data(), 4 * lanes) | cmp(ctx->wg_vid, H.wg_vid.data(), 4 * lanes) |
            cmp(ctx->wg_meta, H.wg_meta.data(), 4 * lanes) | cmp(ctx->wg_nbr, H.wg_nbr.data(), 4 * lanes) |
            cmp(ctx->wg_fetch, H.wg_fetch.data(), 4 * lanes) | cmp(ctx->wg_info, H.wg_info.data(), 4 * H.wg_info.size());
+    if (ctx->wg2_built) {  // (E2), two half-edges per lane: the device expansion against the host builder
+      build_patch_rows2(&H);
+      bad += (H.wg2_ok != L.wg2_ok) + (H.wg2_count != L.wg2_count) + (H.wg2_lcap != L.wg2_lcap) + (H.wg2_vfirst != L.wg2_vfirst);
+      if (bad == 0 && H.wg2_ok) {
+        const size_t lanes2 = (size_t)H.wg2_count * kWave;
+        e |= cmp(ctx->wg2_slot, H.wg2_slot.data(), 8 * lanes2) | cmp(ctx->wg2_nbr, H.wg2_nbr.data(), 8 * lanes2) |
+             cmp(ctx->wg2_vid, H.wg2_vid.data(), 4 * lanes2) | cmp(ctx->wg2_meta, H.wg2_meta.data(), 4 * lanes2) |
+             cmp(ctx->wg2_fetch, H.wg2_fetch.data(), 4 * lanes2) | cmp(ctx->wg2_info, H.wg2_info.data(), 4 * H.wg2_info.size());
+      }
+    }
     if (e) return fail(ctx, FLAME_NLTGV2_ERR_HIP);
   }
   if (bad == 0 && ctx->place_state == 1 && ctx->place_topo == ctx->topo && L.wg_ok) {

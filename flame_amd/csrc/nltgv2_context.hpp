@@ -38,6 +38,8 @@ constexpr int kMaxCachedGraphs = 6;
 constexpr int kTvLdsWavesPerCu = 16;   // ... with the slot constants in LDS (<= 128 VGPRs -> 4 waves per SIMD; 10 KB LDS per wave = all 160 KB)
 constexpr size_t kXbufBytesPerVertex = 8 * 16 + 4;  // exchange buffers: up to four step buffers x (remote + same-XCD copy) of
                                                     // 16-byte records (the patch-per-wave form; the others use two) + the XCC table
+constexpr int kPv2FromPerCu = 14;       // from this many one-half-edge patches per CU on, the two-half-edges-per-lane form (k_persistent_pv2) runs the graph
+constexpr int kPv2WavesPerCu = 19;     // ... up to this many of ITS waves per CU (20 really resident: 91 VGPRs)
 constexpr int kCrowdedWavesPerCu = 16, kCrowdedTopologies = 64;  // (see flame_nltgv2_ctx::crowded_until_topo)
 constexpr int kPvDensePerCu = 27;      // k_persistent_pv is used up to this many patches per CU (28 are resident: 7 waves per SIMD at <= 96 SGPRs)
 constexpr int kPvPaceAbovePerCu = 13;  // ... and above this many its polls are paced (kPvDensePreSleep, kPvDenseGap)
@@ -227,6 +229,8 @@ struct flame_nltgv2_ctx {
   bool wg2_built = false; // ... and layout (E2) (two half-edges per lane; experimental)
   Pv2Args pv2_args;
   int pv2_occ = 0;
+  uint64_t wg2_checked_topo = ~0ull;  // the device expansion's verdict (no patch with more than 64 foreign records) was read for this topology
+  bool wg2_usable = false;
   void* h_stage = nullptr;         // pinned staging buffer of the uploads
   DevBuf d_stage;                 // ... and its device-side landing area (one copy; k_scatter distributes)
   size_t stage_cap = 0;
@@ -246,7 +250,7 @@ struct flame_nltgv2_ctx {
   bool tail_valid = false;
   std::vector<float> h_terms;
   DevBuf hq_alt, vstate_alt;  // the other copies of hq / vstate: a persistent run writes there, success swaps the roles
-  DevBuf xbuf, abort_flag, tv_slot, tv_vid, tv_meta, tv_wave, wg2_slot, wg2_vid, wg2_meta, wg2_nbr, wg2_fetch, wg2_info;
+  DevBuf xbuf, abort_flag, tv_slot, tv_vid, tv_meta, tv_wave, wg2_slot, wg2_vid, wg2_meta, wg2_nbr, wg2_fetch, wg2_info, wg2_vfirst, wg2_rmax;
   DevBuf wg_slot, wg_vid, wg_meta, wg_nbr, wg_fetch, wg_info, wg_v0, wg_vfirst, probe, progress;
   // misc
   DevBuf err, cost_out, img_ref, img_cmp, photo_err, r_tris, r_valid, r_keys, r_img, r_cov, r_vtx, r_val;

@@ -152,6 +152,124 @@ k_build_patch(const int n_patches, int32_t* __restrict__ wg_info, const int32_t*
   if (lane == 0) wg_info[4 * p + 1] = n_fetch;
 }
 
+// (E2) lanes, two half-edges per lane (k_persistent_pv2): one wave per patch, as k_build_patch.  Host input per patch:
+// wg_info[4p] = its first record id (= the walk position of its first vertex), wg_info[4p+2] = its vertex count; vfirst = the
+// first lane of every vertex of the walk.  A vertex of d edges owns max(1, ceil(d / 2)) lanes; lane first + j holds its half-edges
+// 2j (slot 0) and 2j + 1 (slot 1).  Output: wg_slot / wg_nbr [patch][slot][lane], wg_vid, wg_meta, the fetch list (the DISTINCT
+// records of other patches, ascending) and wg_info[4p+1] = their number -- more than 64 cannot be fetched by 64 lanes: the
+// number is left there (the kernel refuses such a patch) and *rmax tells the host.
+__global__ void __launch_bounds__(64)
+k_build_patch2(const int n_patches, int32_t* __restrict__ wg_info, const int32_t* __restrict__ order_m, const int32_t* __restrict__ rid_of,
+               const uint8_t* __restrict__ vfirst, const int32_t* __restrict__ iperm, const int32_t* __restrict__ slice_row,
+               const int32_t* __restrict__ row_ptr, const uint32_t* __restrict__ half, const int32_t* __restrict__ src,
+               const int32_t* __restrict__ dst, int32_t* __restrict__ wg_slot, int32_t* __restrict__ wg_vid, uint32_t* __restrict__ wg_meta,
+               int32_t* __restrict__ wg_nbr, int32_t* __restrict__ wg_fetch, int* __restrict__ rmax) {
+  __shared__ int s_first[64], s_o[64], s_vtx_of_lane[64], s_pub[64], s_list[64];
+  const int p = blockIdx.x;
+  if (p >= n_patches) return;
+  const int lane = threadIdx.x;
+  const int r0 = wg_info[4 * p], n_local = wg_info[4 * p + 2] & 0xffff, v0 = r0;
+  int o = -1, need = 0;
+  if (lane < n_local) {
+    o = order_m[v0 + lane];
+    const int deg = row_ptr[o + 1] - row_ptr[o];
+    need = deg > 1 ? (deg + 1) >> 1 : 1;
+  }
+  const int first = lane < n_local ? (int)vfirst[v0 + lane] : 0;
+  s_vtx_of_lane[lane] = -1;
+  s_pub[lane] = 0;
+  __syncthreads();
+  if (lane < n_local) {
+    s_first[lane] = first, s_o[lane] = o;
+    for (int k = 0; k < need; ++k) s_vtx_of_lane[first + k] = lane;
+  }
+  __syncthreads();
+  const int j = s_vtx_of_lane[lane];
+  int slot[2] = {-1, -1}, nbr[2] = {0, 0}, cand[2] = {0x7fffffff, 0x7fffffff};
+  int vid = -1;
+  uint32_t meta = 0u;
+  if (j >= 0) {
+    const int oj = s_o[j], fj = s_first[j];
+    const int dj = row_ptr[oj + 1] - row_ptr[oj], needj = dj > 1 ? (dj + 1) >> 1 : 1;
+    const int jj = lane - fj;
+    const int sp = iperm[oj];
+    vid = sp;
+    meta = (uint32_t)fj | ((uint32_t)needj << 6) | ((uint32_t)j << 13) | kWgValid;
+    if (jj == needj - 1) meta |= kWgTail;
+    if (jj == 0) meta |= kWgHead;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      const int k = 2 * jj + sl;
+      if (k < dj) {
+        if (sl == 0) meta |= kWgActive;
+        slot[sl] = (slice_row[sp >> 6] + k) * 64 + (sp & 63);
+        const uint32_t h = half[row_ptr[oj] + k];
+        const int e = (int)(h & ~kRole);
+        const int other = (h & kRole) ? src[e] : dst[e];
+        const int r = rid_of[other];
+        if (r >= r0 && r < r0 + n_local) {
+          nbr[sl] = r - r0;
+        } else {
+          cand[sl] = r;
+          s_pub[j] = 1;
+        }
+      }
+    }
+  }
+  // the DISTINCT foreign records, ascending: bitonic sort of the 128 candidates (element lane of slot 0, element 64 + lane of
+  // slot 1), drop repeats, compact
+  int a = cand[0], b = cand[1];
+#pragma unroll
+  for (int k = 2; k <= 128; k <<= 1) {
+#pragma unroll
+    for (int d = k >> 1; d > 0; d >>= 1) {
+      if (d == 64) {
+        const int lo = a < b ? a : b, hi = a < b ? b : a;
+        a = lo, b = hi;
+      } else {
+        const int ua = __shfl_xor(a, d, 64), ub = __shfl_xor(b, d, 64);
+        const bool lower = (lane & d) == 0;
+        const bool up_a = (lane & k) == 0, up_b = ((lane + 64) & k) == 0;
+        a = (lower == up_a) ? (a < ua ? a : ua) : (a > ua ? a : ua);
+        b = (lower == up_b) ? (b < ub ? b : ub) : (b > ub ? b : ub);
+      }
+    }
+  }
+  const int prev_a = __shfl_up(a, 1, 64), a_last = __shfl(a, 63, 64), prev_b0 = __shfl_up(b, 1, 64);
+  const int prev_b = lane == 0 ? a_last : prev_b0;
+  const bool keep_a = a != 0x7fffffff && (lane == 0 || a != prev_a);
+  const bool keep_b = b != 0x7fffffff && b != prev_b;
+  const unsigned long long ka = __ballot(keep_a), kb = __ballot(keep_b);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const int rank_a = __popcll(ka & below), rank_b = __popcll(ka) + __popcll(kb & below);
+  const int n_fetch = __popcll(ka) + __popcll(kb);
+  if (keep_a && rank_a < 64) s_list[rank_a] = a;
+  if (keep_b && rank_b < 64) s_list[rank_b] = b;
+  __syncthreads();
+  const int n_list = n_fetch < 64 ? n_fetch : 64;
+  const size_t hl = (size_t)p * 64 + lane, hl2 = (size_t)p * 128 + lane;
+  wg_fetch[hl] = lane < n_list ? s_list[lane] : -1;
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    if (cand[sl] != 0x7fffffff) {
+      int lo = 0, hi = n_list - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (s_list[mid] < cand[sl]) lo = mid + 1; else hi = mid;
+      }
+      nbr[sl] = (int)(0x80000000u | (unsigned)lo);
+    }
+    wg_slot[hl2 + (size_t)sl * 64] = slot[sl];
+    wg_nbr[hl2 + (size_t)sl * 64] = nbr[sl];
+  }
+  if (j >= 0 && s_pub[j]) meta |= kWgPublish;
+  wg_vid[hl] = vid, wg_meta[hl] = meta;
+  if (lane == 0) {
+    wg_info[4 * p + 1] = n_fetch;
+    if (n_fetch > 64) atomicMax(rmax, n_fetch);
+  }
+}
+
 // ---- record placement -------------------------------------------------------------------------------------------------
 // The hand-off of a 16-byte record from one XCD to another goes through the memory channel the record's address belongs
 // to, and how long that takes depends on where that channel sits relative to the two XCDs: measured on MI355X
@@ -335,6 +453,15 @@ int launch_place_records(const CanonArgs& c, const FusedArgs& a, int per_xcd, co
                      patch_of_rec, cls);
   hipLaunchKernelGGL(k_place_assign, grid1d(a.wg_count, 64), dim3(64), 0, s, a.wg_count, a.wg_info, cls, ranking, n_pages, fill, rec_off,
                      stride);
+  return (int)hipGetLastError();
+}
+
+int launch_build_patches2(const CanonArgs& c, const FusedArgs& a, int n_patches, int32_t* wg_info, const int32_t* order_m, const int32_t* rid_tab,
+                          const uint8_t* vfirst, const int32_t* iperm, int32_t* wg_slot, int32_t* wg_vid, uint32_t* wg_meta, int32_t* wg_nbr,
+                          int32_t* wg_fetch, int* rmax, hipStream_t s) {
+  if (n_patches <= 0) return 0;
+  hipLaunchKernelGGL(k_build_patch2, dim3((unsigned)n_patches), dim3(64), 0, s, n_patches, wg_info, order_m, rid_tab, vfirst, iperm,
+                     a.slice_row, c.row_ptr, c.half, c.src, c.dst, wg_slot, wg_vid, wg_meta, wg_nbr, wg_fetch, rmax);
   return (int)hipGetLastError();
 }
 

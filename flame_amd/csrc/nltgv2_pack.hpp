@@ -109,6 +109,9 @@ struct PackedLayout {
   std::vector<int32_t> wg2_fetch;      // [wg2_count*64] record id fetched by this lane, -1 none
   std::vector<int32_t> wg2_info;       // [wg2_count*4] first record id, fetched records, local vertices, most lanes of a vertex
   std::vector<int32_t> comp_wg2;       // [n_comp+1] first patch of each component
+  std::vector<uint8_t> wg2_vfirst;     // [V] first lane, within its patch, of the i-th vertex of the walk
+  std::vector<int32_t> wg2_v0;         // [wg2_count] walk position of the patch's first vertex
+  bool wg2_walked = false;             // the walk (pass 1) was done for this topology
   int32_t n_rec = 0;                   // record ids in use (= V: a record's id is its vertex's position in the walk)
   std::vector<int32_t> wg_v0;          // [wg_count] walk position of the patch's first vertex (= its first record id)
 };
@@ -360,18 +363,21 @@ inline void build_patch_rows(const flame_nltgv2_graph* g, PackedLayout* L, const
   L->wg_ok = true;  // (a patch has at most 64 half-edges, hence at most 64 distinct foreign records: one per lane)
 }
 
-// ---- (E2) two half-edges per lane (host only; built on demand) -------------------------------------------------------
-inline void build_patch_rows2(PackedLayout* L) {
+// ---- (E2) two half-edges per lane: pass 1 (host, per vertex) -- the greedy walk; the lanes are expanded on the device
+// (nltgv2_layout.hip: k_build_patch2) or, for the CPU tests and the selftest, by build_patch_rows2 below
+inline void build_patch_walk2(PackedLayout* L) {
   const int32_t V = L->V;
-  constexpr int32_t T = kWave;
   const std::vector<int32_t>& order_m = L->order_m;
   L->wg2_ok = false;
   L->wg2_count = 0, L->wg2_lcap = 0, L->wg2_rcap = 0;
   L->wg2_slot.clear(), L->wg2_nbr.clear(), L->wg2_vid.clear(), L->wg2_meta.clear(), L->wg2_fetch.clear(), L->wg2_info.clear();
   L->comp_wg2.clear();
+  L->wg2_vfirst.clear(), L->wg2_v0.clear();
+  L->wg2_walked = true;
   if (V <= 0 || L->max_degree > 32) return;
-  std::vector<uint8_t> vfirst(static_cast<size_t>(V));
-  std::vector<int32_t> v0s;
+  std::vector<uint8_t>& vfirst = L->wg2_vfirst;
+  std::vector<int32_t>& v0s = L->wg2_v0;
+  vfirst.assign(static_cast<size_t>(V), 0);
   int32_t n_local = 0, max_l = 1;
   WaveFit fit;
   fit.rowpack = true;
@@ -401,6 +407,18 @@ inline void build_patch_rows2(PackedLayout* L) {
   }
   if (L->wg2_count > 0) L->wg2_info[static_cast<size_t>(L->wg2_count - 1) * 4 + 3] = max_l;
   L->comp_wg2.push_back(L->wg2_count);
+  L->wg2_ok = L->wg2_count > 0;  // (unless a patch turns out to read more than 64 distinct foreign records: the expansion says)
+}
+
+// pass 2 on the host: the 64 lanes of every patch and its fetch list (the reference of the device expansion)
+inline void build_patch_rows2(PackedLayout* L) {
+  constexpr int32_t T = kWave;
+  const std::vector<int32_t>& order_m = L->order_m;
+  build_patch_walk2(L);
+  if (!L->wg2_ok) return;
+  L->wg2_ok = false;
+  const std::vector<uint8_t>& vfirst = L->wg2_vfirst;
+  const std::vector<int32_t>& v0s = L->wg2_v0;
   const size_t lanes = static_cast<size_t>(L->wg2_count) * T;
   L->wg2_slot.assign(2 * lanes, -1), L->wg2_nbr.assign(2 * lanes, 0), L->wg2_vid.assign(lanes, -1), L->wg2_meta.assign(lanes, 0u);
   L->wg2_fetch.assign(lanes, -1);

@@ -56,10 +56,31 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
   const bool pv_fits = L.wg_ok && L.wg_rowpack && L.wg_count > 0 && L.wg_count <= wg_cap;  // (the kernel runs row-packed patches)
   int form = 0;
   if (ctx->opt_persistent == 4) form = (L.wg_ok && L.wg_rowpack) ? 3 : 0;
-  else if (ctx->opt_persistent == 6) {  // two half-edges per lane (experimental, by name only)
-    if (ensure_form_rows(ctx, 4) != 0) return 0;
-    form = (L.wg2_ok && ctx->pv2_occ > 0) ? 4 : 0;
+  // The two-half-edges-per-lane form: half the waves for the same graph.  Its lanes were expanded on the device at upload where
+  // the graph is large enough (upload_topology); whether every patch can fetch its records (<= 64 distinct foreign ones) the
+  // expansion left in a word that is read here, once per topology.
+  auto pv2_usable = [&]() -> bool {
+    if (!ctx->wg2_built) return false;
+    if (ctx->wg2_checked_topo != ctx->topo) {
+      int rmax = 0;
+      if (hipMemcpyAsync(&rmax, ctx->wg2_rmax.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+      }
+      ctx->wg2_usable = rmax <= 64 && L.wg2_ok && ctx->pv2_occ > 1;
+      ctx->wg2_checked_topo = ctx->topo;
+    }
+    return ctx->wg2_usable;
+  };
+  const int wg2_cap = std::min(crowded ? kCrowdedWavesPerCu : kPv2WavesPerCu, std::max(1, ctx->pv2_occ - 1)) * cus;
+  if (ctx->opt_persistent == 4) form = (L.wg_ok && L.wg_rowpack) ? 3 : 0;
+  else if (ctx->opt_persistent == 6) {  // ... by name
+    if (!ctx->wg2_built && ensure_form_rows(ctx, 4) != 0) return 0;
+    form = pv2_usable() ? 4 : 0;
   } else if (ctx->opt_persistent == 3) form = 2;
+  else if (ctx->opt_verify == 0 && ctx->opt_probe == 0 && ctx->wg2_built && L.wg2_count <= wg2_cap &&
+           (!pv_fits || L.wg_count > kPv2FromPerCu * cus) && pv2_usable()) form = 4;
   else if (pv_fits) form = 3;  // lowest latency wherever all patches are resident: 320x240 ... 1920x1080 single frames, 2-7 frames of 640x480
   else form = 2;               // too big for that: vertex-per-lane, in groups of whole components if need be
   if (form == 2) {
@@ -75,7 +96,7 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
   if (use_tv_lds) *use_tv_lds = tv_lds ? 1 : 0;
   if (form == 0) return 0;
   const int total = form == 4 ? L.wg2_count : form == 3 ? L.wg_count : L.tv_waves;
-  const int cap = form == 4 ? std::max(1, ctx->pv2_occ - 1) * cus : form == 3 ? wg_cap : tv_cap;
+  const int cap = form == 4 ? wg2_cap : form == 3 ? wg_cap : tv_cap;
   if (total <= 0) return 0;
   if (total <= cap) {
     groups->push_back(WaveGroup{0, total});
