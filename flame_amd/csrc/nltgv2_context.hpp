@@ -39,6 +39,7 @@ constexpr int kTvLdsWavesPerCu = 16;   // ... with the slot constants in LDS (<=
 constexpr size_t kXbufBytesPerVertex = 8 * 16 + 4;  // exchange buffers: up to four step buffers x (remote + same-XCD copy) of
                                                     // 16-byte records (the patch-per-wave form; the others use two) + the XCC table
 constexpr int kPv2FromPerCu = 14;       // from this many one-half-edge patches per CU on, the two-half-edges-per-lane form (k_persistent_pv2) runs the graph
+constexpr int kPv2PaceAbovePerCu = 10, kPv2DensePreSleep = 2, kPv2DenseGap = 2;  // its polls are paced from this many of its waves per CU (x64 cycles before the first poll / between rounds)
 constexpr int kPv2WavesPerCu = 19;     // ... up to this many of ITS waves per CU (20 really resident: 91 VGPRs)
 constexpr int kCrowdedWavesPerCu = 16, kCrowdedTopologies = 64;  // (see flame_nltgv2_ctx::crowded_until_topo)
 constexpr int kPvDensePerCu = 27;      // k_persistent_pv is used up to this many patches per CU (28 are resident: 7 waves per SIMD at <= 96 SGPRs)

@@ -75,8 +75,8 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
   };
   const int wg2_cap = std::min(crowded ? kCrowdedWavesPerCu : kPv2WavesPerCu, std::max(1, ctx->pv2_occ - 1)) * cus;
   if (ctx->opt_persistent == 4) form = (L.wg_ok && L.wg_rowpack) ? 3 : 0;
-  else if (ctx->opt_persistent == 6) {  // ... by name
-    if (!ctx->wg2_built && ensure_form_rows(ctx, 4) != 0) return 0;
+  else if (ctx->opt_persistent == 6 && ctx->opt_verify == 0 && ctx->opt_probe == 0) {  // ... by name (it has no record verification and no probe:
+    if (!ctx->wg2_built && ensure_form_rows(ctx, 4) != 0) return 0;                     //  with those on, the one-half-edge form or the sweep)
     form = pv2_usable() ? 4 : 0;
   } else if (ctx->opt_persistent == 3) form = 2;
   else if (ctx->opt_verify == 0 && ctx->opt_probe == 0 && ctx->wg2_built && L.wg2_count <= wg2_cap &&
@@ -448,10 +448,10 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
           HIPCHK(ctx, hipMemsetAsync(ctx->probe.p, 0, words * sizeof(unsigned), ctx->stream));  // (idle instances write nothing)
         }
       }
-      if (form == 4) {  // two half-edges per lane: the pacing of the one-half-edge form at the same number of waves per CU
-        const bool dense = gr.count > kPvPaceAbovePerCu * ctx->prop.multiProcessorCount;
-        const int gap = ctx->opt_poll_gap > 0 ? ctx->opt_poll_gap - 1 : dense ? (3 | ((kPvDenseGap - 1) << 4)) : kPvPollGap;
-        const int poll_gap = gap | ((ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : dense ? kPvDensePreSleep : kPvPreSleep) << 8);
+      if (form == 4) {  // two half-edges per lane: its own pacing (swept: profiles/r03_pv2.txt)
+        const bool dense = gr.count > kPv2PaceAbovePerCu * ctx->prop.multiProcessorCount;
+        const int gap = ctx->opt_poll_gap > 0 ? ctx->opt_poll_gap - 1 : dense ? (3 | ((kPv2DenseGap - 1) << 4)) : kPvPollGap;
+        const int poll_gap = gap | ((ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : dense ? kPv2DensePreSleep : kPvPreSleep) << 8);
         e = launch_persistent_pv2(ctx->f, ctx->pv2_args, to_sp(p), gr.begin, gr.count, ctx->parity, tag0, n, spins_arg, poll_gap, dual & 1,
                                   (const RunTail*)ctx->run_tail.p, ctx->coop_checked_key != key, ctx->stream);
         if (e != 0) break;

@@ -74,7 +74,7 @@ def test_config_parity(env, config, n):
     g = synth.make_graph(config, seed=4242)
     ref, bad = cpu_run(oracle, g, n)
     assert bad == 0
-    for persistent in (1, 3, 4, 0):  # auto, vertex-per-lane, patch-per-wave, one launch per step
+    for persistent in (1, 3, 4, 6, 0):  # auto, vertex-per-lane, patch-per-wave (one / two half-edges per lane), one launch per step
         out = gpu_run(flame_amd, g, n, options=[(5, persistent)], expect_path=None if persistent else 2)
         assert rms(out["x"], ref["x"]) <= TOL_RMS
         assert_state_equal(out, ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"{config} p={persistent}")
@@ -162,13 +162,15 @@ def _opt_sets():
         [(P, 4)], [(P, 4), (DUAL, 0)], [(P, 4), (DUAL, 2)], [(P, 4), (XCDS, 1)], [(P, 4), (XCDS, 8)], [(P, 4), (GAP, 1)], [(P, 4), (GAP, 2)],
         [(P, 4), (GAP, 4)], [(P, 4), (PRE, 9), (GAP, 4)], [(P, 4), (PROBE, 1)], [(P, 4), (PLACE, 0)], [(P, 4), (PLACE, 0), (DUAL, 0)],
         [(P, 4), (PLACE, 1), (VERIFY, 1)],
+        # patch per wave, two half-edges per lane
+        [(P, 6)], [(P, 6), (DUAL, 0)], [(P, 6), (GAP, 4)], [(P, 6), (PRE, 9), (GAP, 4)],
     ]
 
 
 @pytest.mark.parametrize("opts", _opt_sets(), ids=lambda o: "-".join(f"{k}={v}" for k, v in o))
 def test_launch_configurations_are_bit_identical(env, opts):
     """Every launch configuration computes the same bits: the one-launch-per-step sweep (waves per workgroup, slot chunk,
-    hipGraph on / off), the automatic choice and the two persistent forms with their knobs -- same-XCD exchange through L2
+    hipGraph on / off), the automatic choice and the persistent forms with their knobs -- same-XCD exchange through L2
     on / off, slot constants in LDS, the pre-poll pause, the XCDs a launch is spread over, the poll pacing, the cycle probe,
     the placement of the records read across XCDs and the record verification."""
     flame_amd, oracle = env
@@ -283,7 +285,7 @@ def test_vertices_of_more_than_sixteen_edges_in_the_patch_kernel(env, hub_degree
     for n in (1, 2, 37):
         ref, bad = cpu_run(oracle, g, n)
         assert bad == 0
-        for form, path in ((4, 6), (3, 5)):
+        for form, path in ((4, 6), (3, 5)) + (((6, 7),) if max(hub_degrees) <= 32 else ()):
             out = gpu_run(flame_amd, g, n, options=[(5, form)], expect_path=path if n >= 4 else None)
             assert_state_equal(out, ref, what=f"hubs {hub_degrees}, form {form}, {n} steps")
     out = gpu_run(flame_amd, g, 37, options=[(5, 0)], expect_path=2)
@@ -354,26 +356,29 @@ def test_large_batch_as_groups_of_patches(env):
 
 
 def test_seven_frames_in_one_patch_per_wave_launch(env):
-    """Seven frames of 640x480 are 26 patches per CU: with 28 really resident (the kernel is capped at 92 SGPRs) the planner runs
-    them in ONE patch-per-wave launch -- the highest residency it uses; every frame equals the frame solved alone."""
+    """Seven frames of 640x480 would be 26 one-half-edge patches per CU; the planner runs them in ONE launch of the
+    two-half-edges-per-lane form (13 waves per CU), and -- by name -- in one launch of the one-half-edge form (28 patches per CU are
+    really resident: the kernel is capped at 92 SGPRs); every frame equals the frame solved alone."""
     flame_amd, oracle = env
     frames = [synth.make_graph("640x480", seed=700 + i) for i in range(7)]
     union = synth.concat_graphs(frames)
-    with flame_amd.Regularizer(0) as reg:
-        reg.upload_graph(union)
-        reg.run(flame_amd.Params(), 33)
-        info = reg.info()
-        out = reg.download_state(("x", "w1", "x_bar", "q2"))
-    assert info["last_run_path"] == 6 and info["last_run_groups"] == 1 and info["patches"] > 25 * 256, info
-    vo = eo = 0
-    for i, f in enumerate(frames):
-        if i in (0, 3, 6):
-            ref, _ = cpu_run(oracle, f, 33)
-            for k in ("x", "w1", "x_bar"):
-                assert np.array_equal(out[k][vo:vo + f["V"]], ref[k]), (i, k)
-            assert np.array_equal(out["q2"][eo:eo + f["E"]], ref["q2"]), i
-        vo += f["V"]
-        eo += f["E"]
+    refs = {i: cpu_run(oracle, frames[i], 33)[0] for i in (0, 3, 6)}
+    for form, path in ((1, 7), (4, 6)):
+        with flame_amd.Regularizer(0) as reg:
+            reg.set_option(5, form)
+            reg.upload_graph(union)
+            reg.run(flame_amd.Params(), 33)
+            info = reg.info()
+            out = reg.download_state(("x", "w1", "x_bar", "q2"))
+        assert info["last_run_path"] == path and info["last_run_groups"] == 1 and info["patches"] > 25 * 256, info
+        vo = eo = 0
+        for i, f in enumerate(frames):
+            if i in refs:
+                for k in ("x", "w1", "x_bar"):
+                    assert np.array_equal(out[k][vo:vo + f["V"]], refs[i][k]), (form, i, k)
+                assert np.array_equal(out["q2"][eo:eo + f["E"]], refs[i]["q2"]), (form, i)
+            vo += f["V"]
+            eo += f["E"]
 
 
 def test_large_batch_runs_as_groups_of_resident_frames(env):
@@ -474,7 +479,7 @@ def test_nan_is_reported_not_fatal(env):
             reg.run(flame_amd.Params(), 1)
 
 
-@pytest.mark.parametrize("form", [3, 4])
+@pytest.mark.parametrize("form", [3, 4, 6])
 def test_persistent_timeout_is_rolled_back_and_redone(env, form):
     """A persistent run whose neighbour wait expires (fault injection: one wave withholds its first record) must
     leave the state it started from untouched; run() then does the same steps with one launch per step."""
@@ -487,7 +492,7 @@ def test_persistent_timeout_is_rolled_back_and_redone(env, form):
         reg.upload_graph(g)
         reg.run(p, 30)                       # a normal persistent run first (odd/even parity both follow)
         oracle.run(ref, 30)
-        assert reg.info()["last_run_path"] in (5, 6)
+        assert reg.info()["last_run_path"] in (5, 6, 7)
         reg.set_option(flame_amd.regularizer.OPT_FAULT_INJECT, 200)
         reg.run(p, 41)                       # times out inside, recovered
         oracle.run(ref, 41)
@@ -501,7 +506,7 @@ def test_persistent_timeout_is_rolled_back_and_redone(env, form):
         reg.set_option(flame_amd.regularizer.OPT_FAULT_INJECT, 0)  # fault off: persistent runs again
         reg.run(p, 25)
         oracle.run(ref, 25)
-        assert reg.info()["last_run_path"] in (5, 6)
+        assert reg.info()["last_run_path"] in (5, 6, 7)
         assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="after the fault")
         # chained asynchronous runs (run_async back to back, an asynchronous export in between, a short per-step run):
         # the chain's starting state was copied aside, the whole chain is replayed on the per-step path
@@ -550,7 +555,7 @@ def test_record_verification_detects_a_corrupted_read_and_recovers(env, form):
         reg.run(p, 60)
         oracle.run(ref, 60)
         info = reg.info()
-        assert info["torn_records_detected"] == 0 and info["timeouts_recovered"] == 0 and info["last_run_path"] in (5, 6)
+        assert info["torn_records_detected"] == 0 and info["timeouts_recovered"] == 0 and info["last_run_path"] in (5, 6, 7)
         assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="verified run")
         reg.set_option(14, 2)  # the hook corrupts one re-read in step 2 of the next persistent run
         reg.run(p, 33)
@@ -561,7 +566,7 @@ def test_record_verification_detects_a_corrupted_read_and_recovers(env, form):
         reg.set_option(14, 1)
         reg.run(p, 20)
         oracle.run(ref, 20)
-        assert reg.info()["last_run_path"] in (5, 6) and reg.info()["torn_records_detected"] == 1
+        assert reg.info()["last_run_path"] in (5, 6, 7) and reg.info()["torn_records_detected"] == 1
         assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="verified again")
 
 
@@ -625,7 +630,7 @@ def test_export_idepth_device_and_stream(env):
         reg.set_stream(None)
 
 
-@pytest.mark.parametrize("form", [0, 3, 4])
+@pytest.mark.parametrize("form", [0, 3, 4, 6])
 def test_standing_export_target(env, form):
     """flame_nltgv2_set_export_target: every run leaves scale * x in the caller's vertex order, on all paths."""
     import torch
@@ -685,7 +690,7 @@ def test_randomized_run_sequences(env, trial):
         reg.upload_graph(g)
         reg.set_export_target(buf.data_ptr(), 2.0)
         for step in range(12):
-            form = int(rng.choice([0, 1, 3, 4, 4]))
+            form = int(rng.choice([0, 1, 3, 4, 6]))
             reg.set_option(5, form)
             reg.set_option(1, int(rng.random() < 0.15))      # canonical four-sweep path now and then
             reg.set_option(flame_amd.regularizer.OPT_DUAL_PUBLISH, int(rng.choice([0, 1, 2])))
@@ -771,27 +776,27 @@ def test_after_an_expired_run_the_persistent_path_is_tried_again(env):
 
 @pytest.mark.gpu
 def test_an_expired_run_at_high_residency_makes_the_planner_leave_room(env):
-    """A 1080p frame takes 25 of the 28 wave slots a CU really holds in the patch-per-wave form.  When such a run expires
-    (here: fault injection; in a pipeline: other kernels keeping slots busy), the following topologies are planned for at most
-    16 waves per CU -- the vertex-per-lane form for this graph -- instead of trying the same launch frame after frame; a small
-    graph is not affected.  Everything stays bit-identical to the checker."""
+    """Ten frames of 640x480 take 18.6 of the 20 wave slots a CU really holds for the two-half-edges-per-lane form.  When such a run
+    expires (here: fault injection; in a pipeline: other kernels keeping slots busy), the following topologies are planned for at
+    most 16 waves per CU -- the vertex-per-lane form for this graph -- instead of trying the same launch frame after frame; a
+    1080p frame (12.6 waves per CU) and a small graph are not affected.  Everything stays bit-identical to the checker."""
     flame_amd, oracle = env
     from flame_amd.regularizer import OPT_FAULT_INJECT
 
-    g = synth.make_graph("1920x1080", seed=12)
+    g = synth.concat_graphs([synth.make_graph("640x480", seed=12 + i) for i in range(10)])
     p = flame_amd.Params()
     ref = synth.copy_graph(g)
     with flame_amd.Regularizer(0) as reg:
         reg.upload_graph(g)
         reg.run(p, 20)
         oracle.run(ref, 20)
-        assert reg.info()["last_run_path"] == 6 and reg.info()["patches"] > 20 * 256
+        assert reg.info()["last_run_path"] == 7 and reg.info()["last_run_groups"] == 1
         reg.set_option(OPT_FAULT_INJECT, 200)
         reg.run(p, 21)                       # expires, taken back, redone per step
         oracle.run(ref, 21)
         assert reg.info()["timeouts_recovered"] == 1 and reg.info()["last_run_path"] in (2, 3)
         reg.set_option(OPT_FAULT_INJECT, 0)
-        for k in range(3):                   # new topologies (the same graph uploaded again): planned with room to spare
+        for k in range(2):                   # new topologies (the same graph uploaded again): planned with room to spare
             st = reg.download_state()
             g2 = synth.copy_graph(g)
             g2.update({key: st[key] for key in st})
@@ -801,6 +806,16 @@ def test_an_expired_run_at_high_residency_makes_the_planner_leave_room(env):
             assert reg.info()["last_run_path"] == 5, reg.info()["last_run_path"]
         assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS, what="after the crowded topologies")
         assert reg.info()["timeouts_recovered"] == 1
+    big = synth.make_graph("1920x1080", seed=12)
+    with flame_amd.Regularizer(0) as reg:    # 12.6 waves per CU: an expired run changes nothing for the next topology
+        reg.upload_graph(big)
+        reg.set_option(OPT_FAULT_INJECT, 200)
+        reg.run(p, 20)
+        assert reg.info()["timeouts_recovered"] == 1
+        reg.set_option(OPT_FAULT_INJECT, 0)
+        reg.upload_graph(big)
+        reg.run(p, 20)
+        assert reg.info()["last_run_path"] == 7
     small = synth.make_graph("640x480", seed=12)
     with flame_amd.Regularizer(0) as reg:    # 4 patches per CU: an expired run changes nothing for the next topology
         reg.upload_graph(small)

@@ -98,7 +98,7 @@ def test_gpu_residual_matches_checker_on_1080p(built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("config,form", [("1920x1080", 1), ("1920x1080", 3), ("640x480", 4), ("640x480", 3), ("640x480", 0)])
+@pytest.mark.parametrize("config,form", [("1920x1080", 1), ("1920x1080", 4), ("1920x1080", 3), ("640x480", 6), ("640x480", 3), ("640x480", 0)])
 def test_gpu_residual_fused_into_the_run(built, config, form):
     """BASELINE config 5: the residual of the run's final x produced by the solver's own launch (epilogue of the
     persistent kernels; one appended sweep on the per-step path) equals the stand-alone sweep and the checker."""
@@ -127,9 +127,11 @@ def test_gpu_residual_fused_into_the_run(built, config, form):
             sweep = reg.photo_residual(KRKinv, Kt, graph_scale=1.1, border=4)
             assert np.array_equal(np.nan_to_num(sweep, nan=-1.0), np.nan_to_num(fused, nan=-1.0))
         path = reg.info()["last_run_path"]
-        assert (path in (5, 6)) == (form != 0)  # (a persistent form: vertex per lane, patch per wave)
+        assert (path in (5, 6, 7)) == (form != 0)  # (a persistent form: vertex per lane, patch per wave with one / two half-edges per lane)
         if config == "1920x1080" and form == 1:
-            assert path == 6  # BASELINE config 5 runs in the patch-per-wave kernel since 28 patches per CU are resident
+            assert path == 7  # BASELINE config 5 runs in the two-half-edges-per-lane patch kernel (12.6 waves per CU)
+        if form == 4:
+            assert path == 6
         reg.photo_fuse(enable=False)
         with pytest.raises(flame_amd.NLTGV2Error):
             reg.photo_residual_last()
