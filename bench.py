@@ -172,7 +172,7 @@ def main():
         # bytes per launch = iters * (64V + 40E) and the launch duration is the HIP-event time of the step (events
         # recorded on the solver's stream right around the launch).  Per-step path: one k_fused_step launch per
         # iteration; the event time divided by the launches then includes the ~3.5 us dependent-launch gaps.
-        kernel = {"persistent-pv": "k_persistent_pv", "persistent-tv": "k_persistent_tv"}.get(run_path, "k_fused_step")
+        kernel = {"persistent-pv": "k_persistent_pv", "persistent-pv2": "k_persistent_pv2", "persistent-tv": "k_persistent_tv"}.get(run_path, "k_fused_step")
         persistent = run_path.startswith("persistent")
         launches_per_step = 1 if persistent else a.iters
         launch_us = ev_ms * 1e3 / (a.steps * launches_per_step)

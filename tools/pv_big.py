@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/pv_big.py -- the patch-per-wave persistent kernel on graphs beyond 12 patches per CU (GPU box).
 
-For each (config, frames) case: the automatic path, the vertex-per-lane kernel and the patch-per-wave kernel, timed
+For each (config, frames) case: the automatic path, the vertex-per-lane kernel and the patch-per-wave kernels (one / two half-edges per lane), timed
 (mean of the launches after the first) and bit-compared.  PV_VARIANTS="113=4,108=9;..." adds columns with option settings."""
 import json
 import os
@@ -52,13 +52,15 @@ def main():
         row["tv"] = tv
         pv, _ = timed(g, [(OPT_PERSISTENT, 4)], want=want)
         row["pv"] = pv
+        pv2, _ = timed(g, [(OPT_PERSISTENT, 6)], want=want)  # two half-edges per lane
+        row["pv2"] = pv2
         for spec in [s for s in os.environ.get("PV_VARIANTS", "").split(";") if s]:  # e.g. "13=4,8=9;13=4,8=17"
             opts = [(OPT_PERSISTENT, 4)] + [tuple(int(t) for t in kv.split("=")) for kv in spec.split(",")]
             row["pv[" + spec + "]"], _ = timed(g, opts, want=want)
         auto, _ = timed(g, [], want=want)
         row["auto"] = auto
         B = 64 * g["V"] + 40 * g["E"]
-        row["pv_frac_of_8TBps"] = round(B / (pv["us_per_iter_mean"] * 1e-6) / 8e12, 3)
+        row["auto_frac_of_8TBps"] = round(B / (auto["us_per_iter_mean"] * 1e-6) / 8e12, 3)
         print(json.dumps(row), flush=True)
 
 
