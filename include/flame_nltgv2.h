@@ -260,9 +260,9 @@ enum {
   FLAME_NLTGV2_OPT_USE_HIPGRAPH = 2, /* 1 (default) = the one-launch-per-step path replays its launches from a hipGraph */
   FLAME_NLTGV2_OPT_PERSISTENT = 5,   /* 1 (default) = run() uses ONE persistent launch for all n_iters steps when the graph
                                         fits on the chip, picking the form by size; 3 = the vertex-per-lane form by name,
-                                        4 = the patch-per-wave form by name (each only if it fits); 0 = always one launch
-                                        per step.  (2 was round 1's lane-per-half-edge form, retired in round 3: invalid
-                                        argument) */
+                                        4 = the patch-per-wave form by name, 6 = the patch-per-wave form with two half-edges
+                                        per lane by name (each only if it fits); 0 = always one launch per step.  (2 was
+                                        round 1's lane-per-half-edge form, retired in round 3; 2 and 5: invalid argument) */
   FLAME_NLTGV2_OPT_PROBE = 12,       /* 1 = the patch-per-wave kernel records a per-patch, per-step cycle probe (8 words:
                                         HW id, XCC id, wait cycles, compute cycles, poll rounds, step start, 100 MHz clock,
                                         0), read with flame_nltgv2_read_probe; 0 (default) = off */
@@ -312,7 +312,8 @@ typedef struct flame_nltgv2_info {
   char gcn_arch[32];
   int32_t last_run_path; /* 0 none, 1 persistent launch (lane per half-edge), 2 one launch per step
                             (hipGraph), 3 one launch per step (eager), 4 four canonical sweeps per step,
-                            5 persistent launch (vertex per lane), 6 persistent launch (patch per wave) */
+                            5 persistent launch (vertex per lane), 6 persistent launch (patch per wave),
+                            7 persistent launch (patch per wave, two half-edges per lane) */
   int32_t he_waves;      /* always 0 (the lane-per-half-edge form, retired in round 3; kept for the layout of the struct) */
   int32_t tv_waves;      /* waves of the vertex-per-lane persistent form (0: not applicable) */
   int32_t tv_wave_capacity; /* vertex-per-lane waves the device keeps resident */
