@@ -125,6 +125,14 @@ static void check_layout(HostGraph& h, const char* name) {
         if (rc != 0) continue;
         if (host_expand) {
           build_tv_rows(&L);
+          build_patch_rows2(&L);  // (E2): two half-edges per lane (not for a graph with a vertex of more than 32 edges)
+          EXPECT(L.wg2_walked, "the second patch walk ran");
+          if (L.wg2_ok) {
+            EXPECT(L.wg2_meta.size() == (size_t)L.wg2_count * kWave && L.wg2_slot.size() == 2 * L.wg2_meta.size(), "two-half-edge rows sized");
+            EXPECT(L.wg2_count <= L.wg_count || !L.wg_rowpack, "two half-edges per lane need no more waves than one");
+          } else {
+            EXPECT(L.max_degree > 32 || g.V == 0, "the two-half-edge form refuses only hubs of more than 32 edges (or nothing)");
+          }
           // every edge occupies exactly two slots of the SELL rows (one per endpoint)
           std::vector<int> seen((size_t)g.E, 0);
           for (size_t i = 0; i < L.rec_edge.size(); ++i)
