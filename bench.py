@@ -454,7 +454,8 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
     #     "large": a.batch frames -- more than fit at once: run as groups of resident frames, one
     #     persistent launch per group (frames are independent, so this is the same computation)
     out["batched"] = {}
-    for label, nf, iters in (("resident", None, 200), ("large", a.batch, 100)):
+    #     "ten": ten frames in ONE launch of the patch-per-wave kernel with two half-edges per lane (18.6 waves per CU)
+    for label, nf, iters in (("ten", 10, 200), ("resident", None, 200), ("large", a.batch, 100)):
         if label == "resident":  # as many frames as the register-resident persistent kernel holds
             nf = max(1, info["tv_wave_capacity"] // max(1, info["tv_waves"] + 1))
         if not nf:
