@@ -37,16 +37,23 @@ if LOAD:
 
     th = threading.Thread(target=hog, daemon=True)
     th.start()
-cases = [("640x480", 1), ("1280x720", 2), ("320x240", 3)]
-for cfg, seed in cases:
-    g = synth.make_graph(cfg, seed=seed)
+# (config, seed, iterations); the 1080p frame and the 7-frame batch run in the two-half-edges-per-lane form (and fewer iterations: the
+# CPU checker of a 1080p frame does ~300 iterations per second)
+cases = [("640x480", 1, ITERS), ("1280x720", 2, ITERS), ("320x240", 3, ITERS), ("1920x1080", 4, max(200, ITERS // 10)), ("640x480:7", 5, max(200, ITERS // 10))]
+ALL_FORMS = ((4, 2, 0, 0, 1), (4, 2, 0, 1, 1), (4, 2, 0, 1, 0), (4, 0, 0, 1, 1), (4, 0, 0, 0, 0), (6, 2, 0, 0, 1), (6, 0, 0, 0, 1),
+             (3, 0, 0, 1, 1), (3, 2, 0, 0, 1), (3, 2, 2, 1, 1), (3, 2, 2, 0, 1))
+for cfg, seed, ITERS in cases:
+    if ":" in cfg:
+        g = synth.concat_graphs([synth.make_graph(cfg.split(":")[0], seed=seed + 10 * k) for k in range(int(cfg.split(":")[1]))])
+    else:
+        g = synth.make_graph(cfg, seed=seed)
     ref = synth.copy_graph(g)
     t0 = time.time()
     oracle.run(ref, ITERS)
     cpu_s = time.time() - t0
+    big = g["V"] > 40000
     # (form, same-XCD exchange, tv constants in LDS, record verification, record placement)
-    for form, dual, lds, verify, place in ((4, 2, 0, 0, 1), (4, 2, 0, 1, 1), (4, 2, 0, 1, 0), (4, 0, 0, 1, 1), (4, 0, 0, 0, 0),
-                                          (3, 0, 0, 1, 1), (3, 2, 0, 0, 1), (3, 2, 2, 1, 1), (3, 2, 2, 0, 1)):
+    for form, dual, lds, verify, place in (((1, 2, 0, 0, 1), (6, 2, 0, 0, 1), (6, 0, 0, 0, 1), (4, 2, 0, 1, 1)) if big else ALL_FORMS):
         with flame_amd.Regularizer(0) as reg:
             reg.set_option(OPT_PERSISTENT, form)
             reg.set_option(OPT_DUAL_PUBLISH, dual)
