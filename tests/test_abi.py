@@ -124,4 +124,14 @@ def test_pv_residency_table_matches_the_build(tmp_path):
         assert real >= want, f"instance probe={probe} verify={verify}: {vg} VGPRs / {sg} SGPRs keep {real} waves per SIMD, the planner assumes {want}"
     # the instance the bench runs (no probe, no verification) must not spill
     assert found[(0, 0)][2] == 0
+    # k_persistent_pv2 (two half-edges per lane): the planner counts on five waves per SIMD (pv2_patches_per_cu: 20 per CU)
+    src2 = os.path.join(ROOT, "flame_amd", "csrc", "nltgv2_persistent_pv2.hip")
+    cmd2 = [c if c != src else src2 for c in cmd]
+    rep2 = subprocess.run(cmd2, capture_output=True, text=True, check=True).stderr
+    m = re.search(r"Function Name: \S*k_persistent_pv2\S*.*?TotalSGPRs: (\d+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)", rep2, flags=re.S)
+    assert m, "k_persistent_pv2 not found in the resource report"
+    sg, vg, scratch = int(m.group(1)), int(m.group(2)), int(m.group(3))
+    real = min(512 // ((vg + 7) // 8 * 8), 800 // ((sg + 15) // 16 * 16 + 16), 8)
+    assert real >= 5 and scratch == 0, f"k_persistent_pv2: {vg} VGPRs / {sg} SGPRs keep {real} waves per SIMD, the planner assumes 5"
+    assert "return n < 20 ? n : 20;" in open(src2).read()
 
