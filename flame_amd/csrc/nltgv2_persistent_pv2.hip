@@ -318,10 +318,19 @@ k_persistent_pv2(const int wg_begin, const int n_wgs, const int wgs_per_xcd, con
                    PV2_RM(1, m1)
                    "s_cmp_le_u32 %[md], 2\n\t"
                    "s_cbranch_scc1 9f\n\t"
-                   PV2_RM(2, m2) PV2_RM(3, m3)
+                   PV2_RM(2, m2)
+                   "s_cmp_le_u32 %[md], 3\n\t"
+                   "s_cbranch_scc1 9f\n\t"
+                   PV2_RM(3, m3)
                    "s_cmp_le_u32 %[md], 4\n\t"
                    "s_cbranch_scc1 9f\n\t"
-                   PV2_RM(4, m4) PV2_RM(5, m5) PV2_RM(6, m6) PV2_RM(7, m7)
+                   PV2_RM(4, m4)
+                   "s_cmp_le_u32 %[md], 5\n\t"
+                   "s_cbranch_scc1 9f\n\t"
+                   PV2_RM(5, m5)
+                   "s_cmp_le_u32 %[md], 6\n\t"
+                   "s_cbranch_scc1 9f\n\t"
+                   PV2_RM(6, m6) PV2_RM(7, m7)
                    "s_cmp_le_u32 %[md], 8\n\t"
                    "s_cbranch_scc1 9f\n\t"
                    PV2_RM(8, m8) PV2_ADDS(9) PV2_ADDS(10) PV2_ADDS(11) PV2_ADDS(12) PV2_ADDS(13) PV2_ADDS(14) PV2_ADDS(15)
