@@ -188,7 +188,7 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
   {
     const int cus = ctx->prop.multiProcessorCount;
     const int64_t est_patches = ctx->L.wg_rowpack ? (int64_t)ctx->L.wg_count : ((static_cast<int64_t>(2) * E + V / 32) / 54 + 1);
-    want_e2 = ctx->L.wg_ok && ctx->L.max_degree <= 32 && ctx->opt_verify == 0 && ctx->opt_probe == 0 &&
+    want_e2 = ctx->L.wg_ok && ctx->L.max_degree <= 32 && ctx->opt_probe == 0 &&
               (ctx->opt_persistent == 6 || (ctx->opt_persistent == 1 && est_patches > (int64_t)kPv2FromPerCu * cus));
     if (want_e2) {
       build_patch_walk2(&ctx->L);
@@ -282,7 +282,7 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
     ctx->pv2_args.meta = (const uint32_t*)ctx->wg2_meta.p, ctx->pv2_args.nbr = (const int32_t*)ctx->wg2_nbr.p;
     ctx->pv2_args.fetch = (const int32_t*)ctx->wg2_fetch.p, ctx->pv2_args.info = (const int32_t*)ctx->wg2_info.p;
     ctx->pv2_args.count = L.wg2_count, ctx->pv2_args.lcap = L.wg2_lcap;
-    if (ctx->pv2_occ == 0) ctx->pv2_occ = pv2_patches_per_cu(L.wg2_lcap);
+    if (ctx->pv2_occ == 0) ctx->pv2_occ = pv2_patches_per_cu(L.wg2_lcap, false), ctx->pv2_occ_verify = pv2_patches_per_cu(L.wg2_lcap, true);
     ctx->wg2_built = true;  // (on the device; whether every patch can fetch its records the first plan reads from wg2_rmax)
   }
   // where the records that cross XCDs go (if the pages have been timed already; otherwise the first run does both): on
@@ -324,7 +324,7 @@ int ensure_form_rows(flame_nltgv2_ctx* ctx, int form) {
       ctx->pv2_args.slot = (const int32_t*)ctx->wg2_slot.p, ctx->pv2_args.vid = (const int32_t*)ctx->wg2_vid.p, ctx->pv2_args.meta = (const uint32_t*)ctx->wg2_meta.p;
       ctx->pv2_args.nbr = (const int32_t*)ctx->wg2_nbr.p, ctx->pv2_args.fetch = (const int32_t*)ctx->wg2_fetch.p, ctx->pv2_args.info = (const int32_t*)ctx->wg2_info.p;
       ctx->pv2_args.count = L.wg2_count, ctx->pv2_args.lcap = L.wg2_lcap;
-      ctx->pv2_occ = pv2_patches_per_cu(L.wg2_lcap);
+      ctx->pv2_occ = pv2_patches_per_cu(L.wg2_lcap, false), ctx->pv2_occ_verify = pv2_patches_per_cu(L.wg2_lcap, true);
     }
     ctx->wg2_built = true;
     ctx->wg2_usable = L.wg2_ok, ctx->wg2_checked_topo = ctx->topo;  // (the host builder knows)

@@ -229,7 +229,7 @@ struct flame_nltgv2_ctx {
   bool tv_built = false;  // layout (D) exists for the current topology (built on demand)
   bool wg2_built = false; // ... and layout (E2) (two half-edges per lane; experimental)
   Pv2Args pv2_args;
-  int pv2_occ = 0;
+  int pv2_occ = 0, pv2_occ_verify = 0;  // patches of k_persistent_pv2 really co-resident per CU (plain / record-verifying instance)
   uint64_t wg2_checked_topo = ~0ull;  // the device expansion's verdict (no patch with more than 64 foreign records) was read for this topology
   bool wg2_usable = false;
   void* h_stage = nullptr;         // pinned staging buffer of the uploads

@@ -170,7 +170,7 @@ struct Pv2Args {
 int launch_build_patches2(const CanonArgs& c, const FusedArgs& a, int n_patches, int32_t* wg_info, const int32_t* order_m, const int32_t* rid_tab,
                           const uint8_t* vfirst, const int32_t* iperm, int32_t* wg_slot, int32_t* wg_vid, uint32_t* wg_meta, int32_t* wg_nbr,
                           int32_t* wg_fetch, int* rmax, hipStream_t s);
-int pv2_patches_per_cu(int lcap);
+int pv2_patches_per_cu(int lcap, bool verify);
 int launch_persistent_pv2(const FusedArgs& a, const Pv2Args& w, const SolverParams& p, int wg_begin, int n_wgs, int parity_in, unsigned tag0,
                           int n_iters, unsigned max_spins, int poll_gap, int dual, const RunTail* tail, bool cooperative, hipStream_t stream);
 int pv_real_waves_per_simd(bool verify_or_probe);

@@ -3,8 +3,8 @@
 // (nltgv2_persistent.hip, which documents both); a wave owns a patch of ~18 vertices instead of ~9, so a graph needs half as many
 // waves.  The period of the lock-step network grows with the waves a CU holds ("What the period depends
 // on"): this form is for graphs that fill the chip in the one-half-edge-per-lane form (a 1920x1080 frame: 25 waves per CU there,
-// 12.6 here).  EXPERIMENTAL (FLAME_NLTGV2_OPT_PERSISTENT = 6): no cycle probe, no record verification, no placed records, no
-// vertex of more than 32 edges.
+// 12.6 here).  Against k_persistent_pv it has no cycle probe, no placed records and takes no vertex of more than 32 edges (the planner
+// keeps such graphs on the other forms); the record verification (FLAME_NLTGV2_OPT_VERIFY_RECORDS) is a second instance.
 #include "nltgv2_device.hpp"
 
 namespace flame_hip {
@@ -36,6 +36,7 @@ struct SlotConst {
   v2f_t P12, C2;
 };
 
+template <bool VERIFY>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(92)))
 k_persistent_pv2(const int wg_begin, const int n_wgs, const int wgs_per_xcd, const int lcap, const int32_t* __restrict__ wg_slot,
                  const int32_t* __restrict__ wg_vid, const uint32_t* __restrict__ wg_meta, const int32_t* __restrict__ wg_nbr,
@@ -47,7 +48,7 @@ k_persistent_pv2(const int wg_begin, const int n_wgs, const int wgs_per_xcd, con
   extern __shared__ float4 lds[];
   constexpr int T = 64;
   const unsigned max_spins = max_spins_arg & 0x7fffffffu;
-  const int dual = dual_arg & 1;
+  const int dual = dual_arg & 1, verify = VERIFY ? dual_arg >> 1 : 0;  // (bits 1..: record verification and its test hook, as in k_persistent_pv)
   const int poll_gap = poll_gap_arg & 255, pv_presleep = (poll_gap_arg >> 8) & 255;
   const int lane = (int)threadIdx.x;
   const int b = blockIdx.x;
@@ -126,6 +127,7 @@ k_persistent_pv2(const int wg_begin, const int n_wgs, const int wgs_per_xcd, con
   v2f_t w_prev = w12;
   bool ok = true;
   bool timed_out = n_fetch > T;
+  bool torn = false;
 
   const int my_off = (rid_base + loc) << 4;
   const int rec_w = valid ? loc : o_ovfA + lane, rec_wstride = valid ? rec_stride : 0;
@@ -187,7 +189,7 @@ k_persistent_pv2(const int wg_begin, const int n_wgs, const int wgs_per_xcd, con
   const unsigned lds_addr0 = (unsigned)(size_t)(lds);
 
   auto step = [&](const unsigned s, const unsigned rd_n0, const unsigned rd_n1, const unsigned dst, const int wr_rec, const int it,
-                  const char* const src, char* const pub2, const int rd_rec) {
+                  const char* const src, char* const pub2, const int rd_rec, const int fetch_area) {
     float4 own = lds[rd_rec];
     const int so_out = (int)((s + 1u) & (kPar - 1)) * par;
     v4f_t nbv0, nbv1;
@@ -264,6 +266,19 @@ k_persistent_pv2(const int wg_begin, const int n_wgs, const int wgs_per_xcd, con
         }
       }
 #undef PV2_POLL
+    }
+    if (VERIFY && verify && !timed_out) {
+      // every fetch lane reads its foreign record once more, with an ordinary load, and compares all four dwords with what the
+      // LDS-DMA left in its slot (k_persistent_pv): a difference is a torn 16-byte access -- reported, the run is taken back
+      v4i_t g2 = {0, 0, 0, 0};
+      if (frid >= 0) {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g2) : "v"(src) : "memory");
+      }
+      const float4 l4 = lds[fetch_area + lane];
+      if ((verify & 2) && it == 2 && wg == wg_begin && lane == 0) g2.x ^= 0x00400000;  // test hook
+      const bool bad = frid >= 0 && (g2.x != __float_as_int(l4.x) || g2.y != __float_as_int(l4.y) || g2.z != __float_as_int(l4.z) ||
+                                     (unsigned)g2.w != s || __float_as_uint(l4.w) != s);
+      if (__any(bad)) torn = timed_out = true;
     }
     xb = own.x, wb12 = v2f_t{own.y, own.z};
     // ---- dual update of the two half-edges' private q copies (cc:99-110) and their shares of the primal scatter (cc:126-141) ----
@@ -382,17 +397,17 @@ k_persistent_pv2(const int wg_begin, const int n_wgs, const int wgs_per_xcd, con
   char* const pubB = p0 ? pa0 : pa1;
   int it = 0;
   for (; it + 1 < n_iters && !timed_out; it += 2) {
-    step(tag0 + (unsigned)it, rdA0, rdA1, dstA, wrB_rec, it, srcA, pubB, wrA_rec);
+    step(tag0 + (unsigned)it, rdA0, rdA1, dstA, wrB_rec, it, srcA, pubB, wrA_rec, areaA + lcap);
     if (timed_out) break;
-    step(tag0 + (unsigned)it + 1u, rdB0, rdB1, dstB, wrA_rec, it + 1, srcB, pubA, wrB_rec);
+    step(tag0 + (unsigned)it + 1u, rdB0, rdB1, dstB, wrA_rec, it + 1, srcB, pubA, wrB_rec, areaB + lcap);
   }
-  if (it < n_iters && !timed_out) step(tag0 + (unsigned)it, rdA0, rdA1, dstA, wrB_rec, it, srcA, pubB, wrA_rec);
+  if (it < n_iters && !timed_out) step(tag0 + (unsigned)it, rdA0, rdA1, dstA, wrB_rec, it, srcA, pubB, wrA_rec, areaA + lcap);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   if (timed_out) {
     if (lane == 0) {
       __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      atomicOr(err, 2);
+      atomicOr(err, torn ? 4 : 2);
     }
     return;
   }
@@ -420,14 +435,17 @@ k_persistent_pv2(const int wg_begin, const int n_wgs, const int wgs_per_xcd, con
 }  // namespace
 
 // Patches of k_persistent_pv2 really co-resident per CU (see pv_real_waves_per_simd in nltgv2_persistent.hip): from the kernel's
-// register counts as built -- <= 96 VGPRs, <= 96 SGPRs: five waves per SIMD.
-int pv2_patches_per_cu(int lcap) {
+// register counts as built -- <= 96 VGPRs, <= 96 SGPRs: five waves per SIMD; the instance with the record verification
+// <= 112 VGPRs: four (tests/test_abi.py re-derives both from the compiler's resource report).
+int pv2_patches_per_cu(int lcap, bool verify) {
   const size_t ldsv = 16u * (size_t)(2 * (lcap + 64) + 64);
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_persistent_pv2, 64, ldsv) != hipSuccess) {
+  const void* fn = verify ? (const void*)k_persistent_pv2<true> : (const void*)k_persistent_pv2<false>;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, ldsv) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
+  if (verify) return n < 16 ? n : 16;
   return n < 20 ? n : 20;
 }
 
@@ -457,8 +475,9 @@ int launch_persistent_pv2(const FusedArgs& a, const Pv2Args& w, const SolverPara
   const unsigned ldsv = 16u * (unsigned)(2 * (lcap + 64) + 64);
   void* vargs[] = {&wg_begin, &n_wgs, &wgx, &lcap, &w0, &w1, &w2, &w3, &w4, &w5, &hrec, &hq, &vstate, &hq_out, &vstate_out, &vaux, &bin, &bout,
                    &vprev, &xbuf, &rec_bytes, &dual, &tag0, &n_iters, &max_spins, &poll_gap, &pp, &err, &abort_flag, &perm, &tail};
-  if (cooperative) return (int)hipLaunchCooperativeKernel((const void*)k_persistent_pv2, gv, bv, vargs, ldsv, stream);
-  return (int)hipLaunchKernel((const void*)k_persistent_pv2, gv, bv, vargs, ldsv, stream);
+  const void* fn = (dual >> 1) != 0 ? (const void*)k_persistent_pv2<true> : (const void*)k_persistent_pv2<false>;
+  if (cooperative) return (int)hipLaunchCooperativeKernel(fn, gv, bv, vargs, ldsv, stream);
+  return (int)hipLaunchKernel(fn, gv, bv, vargs, ldsv, stream);
 }
 
 }  // namespace flame_hip

@@ -68,18 +68,18 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
         (void)hipGetLastError();
         return false;
       }
-      ctx->wg2_usable = rmax <= 64 && L.wg2_ok && ctx->pv2_occ > 1;
+      ctx->wg2_usable = rmax <= 64 && L.wg2_ok && ctx->pv2_occ > 1 && ctx->pv2_occ_verify > 1;
       ctx->wg2_checked_topo = ctx->topo;
     }
     return ctx->wg2_usable;
   };
-  const int wg2_cap = std::min(crowded ? kCrowdedWavesPerCu : kPv2WavesPerCu, std::max(1, ctx->pv2_occ - 1)) * cus;
+  const int wg2_cap = std::min(crowded ? kCrowdedWavesPerCu : kPv2WavesPerCu, std::max(1, (ctx->opt_verify ? ctx->pv2_occ_verify : ctx->pv2_occ) - 1)) * cus;
   if (ctx->opt_persistent == 4) form = (L.wg_ok && L.wg_rowpack) ? 3 : 0;
-  else if (ctx->opt_persistent == 6 && ctx->opt_verify == 0 && ctx->opt_probe == 0) {  // ... by name (it has no record verification and no probe:
-    if (!ctx->wg2_built && ensure_form_rows(ctx, 4) != 0) return 0;                     //  with those on, the one-half-edge form or the sweep)
+  else if (ctx->opt_persistent == 6 && ctx->opt_probe == 0) {  // ... by name (it has no cycle probe: with that on, the one-half-edge form or the sweep)
+    if (!ctx->wg2_built && ensure_form_rows(ctx, 4) != 0) return 0;
     form = pv2_usable() ? 4 : 0;
   } else if (ctx->opt_persistent == 3) form = 2;
-  else if (ctx->opt_verify == 0 && ctx->opt_probe == 0 && ctx->wg2_built && L.wg2_count <= wg2_cap &&
+  else if (ctx->opt_probe == 0 && ctx->wg2_built && L.wg2_count <= wg2_cap &&
            (!pv_fits || L.wg_count > kPv2FromPerCu * cus) && pv2_usable()) form = 4;
   else if (pv_fits) form = 3;  // lowest latency wherever all patches are resident: 320x240 ... 1920x1080 single frames, 2-7 frames of 640x480
   else form = 2;               // too big for that: vertex-per-lane, in groups of whole components if need be
@@ -452,7 +452,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
         const bool dense = gr.count > kPv2PaceAbovePerCu * ctx->prop.multiProcessorCount;
         const int gap = ctx->opt_poll_gap > 0 ? ctx->opt_poll_gap - 1 : dense ? (3 | ((kPv2DenseGap - 1) << 4)) : kPvPollGap;
         const int poll_gap = gap | ((ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : dense ? kPv2DensePreSleep : kPvPreSleep) << 8);
-        e = launch_persistent_pv2(ctx->f, ctx->pv2_args, to_sp(p), gr.begin, gr.count, ctx->parity, tag0, n, spins_arg, poll_gap, dual & 1,
+        e = launch_persistent_pv2(ctx->f, ctx->pv2_args, to_sp(p), gr.begin, gr.count, ctx->parity, tag0, n, spins_arg, poll_gap, dual,
                                   (const RunTail*)ctx->run_tail.p, ctx->coop_checked_key != key, ctx->stream);
         if (e != 0) break;
         continue;

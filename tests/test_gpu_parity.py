@@ -163,7 +163,7 @@ def _opt_sets():
         [(P, 4), (GAP, 4)], [(P, 4), (PRE, 9), (GAP, 4)], [(P, 4), (PROBE, 1)], [(P, 4), (PLACE, 0)], [(P, 4), (PLACE, 0), (DUAL, 0)],
         [(P, 4), (PLACE, 1), (VERIFY, 1)],
         # patch per wave, two half-edges per lane
-        [(P, 6)], [(P, 6), (DUAL, 0)], [(P, 6), (GAP, 4)], [(P, 6), (PRE, 9), (GAP, 4)],
+        [(P, 6)], [(P, 6), (DUAL, 0)], [(P, 6), (GAP, 4)], [(P, 6), (PRE, 9), (GAP, 4)], [(P, 6), (VERIFY, 1)],
     ]
 
 
@@ -538,7 +538,7 @@ def test_persistent_timeout_is_rolled_back_and_redone(env, form):
         assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="after a clean chain")
 
 
-@pytest.mark.parametrize("form", [3, 4])
+@pytest.mark.parametrize("form", [3, 4, 6])
 def test_record_verification_detects_a_corrupted_read_and_recovers(env, form):
     """FLAME_NLTGV2_OPT_VERIFY_RECORDS: the persistent kernels re-read every neighbour record after its tag matched and
     compare all four dwords -- the run-time guard of the one hardware property the exchange relies on (an aligned 16-byte
