@@ -473,10 +473,15 @@ void run_strip(const Input& in, const std::vector<int>& by_bin, const std::vecto
     out->certified = false;
     return;
   }
-  const double bw = ((double)in.maxx - (double)in.minx) / kBins;
-  const double xlo = lo == 0 ? -1e300 : (double)in.minx + bw * lo, xhi = hi == kBins ? 1e300 : (double)in.minx + bw * hi;
-  // what this strip has NOT looked at: the boxes left and right of its x range, between the bands (shrunk by nothing:
-  // a point exactly on a bin edge belongs to the higher bin, the boxes are closed -- conservative)
+  // Bin b holds the points whose quantised x, floor((x - minx) * 65535 / W), lies in [64 b, 64 b + 63] (triangulate_strips): the
+  // points this strip has NOT looked at have x < minx + 64 lo / sx on the left and x >= minx + 64 hi / sx on the right.  Both box
+  // edges come from that same quantisation, widened by one quantum (the product is rounded before the floor) -- W / 1024 per bin,
+  // as used before, is smaller than a bin by 1 / 65536 of its width per bin index and left points of bin lo - 1 outside the box.
+  const double inv_sx = ((double)in.maxx - (double)in.minx) / 65535.0;
+  const double xlo = lo == 0 ? -1e300 : (double)in.minx + (64.0 * lo + 1.0) * inv_sx;
+  const double xhi = hi == kBins ? 1e300 : (double)in.minx + (64.0 * hi - 1.0) * inv_sx;
+  // what this strip has NOT looked at: the boxes left and right of its x range, between the bands (the boxes are closed and one
+  // quantum wider than the excluded bins -- conservative)
   const Rect left = {(double)in.minx, xlo, (double)in.miny + band, (double)in.maxy - band};
   const Rect right = {xhi, (double)in.maxx, (double)in.miny + band, (double)in.maxy - band};
   std::vector<char> in_tri(ids.size(), 0);

@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -31,15 +32,20 @@ class Workers {
       for (int i = 0; i < n; ++i) job(i);
       return;
     }
+    // Every region has its own state {job, n, next, pending}; a worker takes the pointer under the lock when it wakes up, so a
+    // worker that was preempted between two regions only ever sees the (finished) region it belongs to: its next index is
+    // >= that region's n and it goes back to sleep without touching the new region's job or counters.
+    auto region = std::make_shared<Region>();
+    region->job = &job, region->n = n, region->pending = n;
     {
       std::lock_guard<std::mutex> lk(mtx_);
-      job_ = &job, n_jobs_ = n, next_.store(0), pending_ = n, ++generation_;
+      region_ = region, ++generation_;
     }
     cv_.notify_all();
-    work();
+    work(*region);
     std::unique_lock<std::mutex> lk(mtx_);
-    done_cv_.wait(lk, [&] { return pending_ == 0; });
-    job_ = nullptr;
+    done_cv_.wait(lk, [&] { return region->pending == 0; });
+    region_.reset();
   }
 
  private:
@@ -57,33 +63,40 @@ class Workers {
     cv_.notify_all();
     for (auto& t : pool_) t.join();
   }
-  void work() {
+  struct Region {
+    const std::function<void(int)>* job = nullptr;
+    int n = 0;
+    std::atomic<int> next{0};
+    int pending = 0;  // under mtx_
+  };
+  void work(Region& r) {
     for (;;) {
-      const int i = next_.fetch_add(1);
-      if (i >= n_jobs_) return;
-      (*job_)(i);
+      const int i = r.next.fetch_add(1);
+      if (i >= r.n) return;  // (r.job is only dereferenced for an index that was still outstanding: run() is still waiting)
+      (*r.job)(i);
       std::lock_guard<std::mutex> lk(mtx_);
-      if (--pending_ == 0) done_cv_.notify_all();
+      if (--r.pending == 0) done_cv_.notify_all();
     }
   }
   void loop() {
     uint64_t seen = 0;
     for (;;) {
+      std::shared_ptr<Region> r;
       {
         std::unique_lock<std::mutex> lk(mtx_);
         cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
         if (stop_) return;
         seen = generation_;
+        r = region_;
       }
-      work();
+      if (r) work(*r);
     }
   }
   std::mutex call_mtx_, mtx_;
   std::condition_variable cv_, done_cv_;
   std::vector<std::thread> pool_;
-  const std::function<void(int)>* job_ = nullptr;
-  std::atomic<int> next_{0};
-  int n_jobs_ = 0, pending_ = 0, n_threads_ = 1;
+  std::shared_ptr<Region> region_;  // the region in flight (under mtx_)
+  int n_threads_ = 1;
   uint64_t generation_ = 0;
   bool stop_ = false;
 };

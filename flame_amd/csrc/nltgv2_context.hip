@@ -282,7 +282,8 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
     ctx->pv2_args.meta = (const uint32_t*)ctx->wg2_meta.p, ctx->pv2_args.nbr = (const int32_t*)ctx->wg2_nbr.p;
     ctx->pv2_args.fetch = (const int32_t*)ctx->wg2_fetch.p, ctx->pv2_args.info = (const int32_t*)ctx->wg2_info.p;
     ctx->pv2_args.count = L.wg2_count, ctx->pv2_args.lcap = L.wg2_lcap;
-    if (ctx->pv2_occ == 0) ctx->pv2_occ = pv2_patches_per_cu(L.wg2_lcap, false), ctx->pv2_occ_verify = pv2_patches_per_cu(L.wg2_lcap, true);
+    if (ctx->pv2_occ == 0 || ctx->pv2_occ_lcap != L.wg2_lcap)  // (the kernel's LDS grows with lcap: asked once per value, not once per context)
+      ctx->pv2_occ = pv2_patches_per_cu(L.wg2_lcap, false), ctx->pv2_occ_verify = pv2_patches_per_cu(L.wg2_lcap, true), ctx->pv2_occ_lcap = L.wg2_lcap;
     ctx->wg2_built = true;  // (on the device; whether every patch can fetch its records the first plan reads from wg2_rmax)
   }
   // where the records that cross XCDs go (if the pages have been timed already; otherwise the first run does both): on
@@ -324,7 +325,7 @@ int ensure_form_rows(flame_nltgv2_ctx* ctx, int form) {
       ctx->pv2_args.slot = (const int32_t*)ctx->wg2_slot.p, ctx->pv2_args.vid = (const int32_t*)ctx->wg2_vid.p, ctx->pv2_args.meta = (const uint32_t*)ctx->wg2_meta.p;
       ctx->pv2_args.nbr = (const int32_t*)ctx->wg2_nbr.p, ctx->pv2_args.fetch = (const int32_t*)ctx->wg2_fetch.p, ctx->pv2_args.info = (const int32_t*)ctx->wg2_info.p;
       ctx->pv2_args.count = L.wg2_count, ctx->pv2_args.lcap = L.wg2_lcap;
-      ctx->pv2_occ = pv2_patches_per_cu(L.wg2_lcap, false), ctx->pv2_occ_verify = pv2_patches_per_cu(L.wg2_lcap, true);
+      ctx->pv2_occ = pv2_patches_per_cu(L.wg2_lcap, false), ctx->pv2_occ_verify = pv2_patches_per_cu(L.wg2_lcap, true), ctx->pv2_occ_lcap = L.wg2_lcap;
     }
     ctx->wg2_built = true;
     ctx->wg2_usable = L.wg2_ok, ctx->wg2_checked_topo = ctx->topo;  // (the host builder knows)

@@ -214,7 +214,7 @@ struct flame_nltgv2_ctx {
     int kind = 0;  // 0 run, 1 explicit export of x * scale
     flame_nltgv2_params params{};
     int n = 0;
-    float* dst = nullptr;
+    float* dst = nullptr;  // kind 1: where to; kind 0: the standing export target the run was enqueued with (NULL: none)
     float scale = 1.0f;
   };
   struct PendingRun {
@@ -229,6 +229,7 @@ struct flame_nltgv2_ctx {
   bool tv_built = false;  // layout (D) exists for the current topology (built on demand)
   bool wg2_built = false; // ... and layout (E2) (two half-edges per lane; experimental)
   Pv2Args pv2_args;
+  int pv2_occ_lcap = -1;  // the wg2_lcap (LDS sizing) the two numbers below were derived for
   int pv2_occ = 0, pv2_occ_verify = 0;  // patches of k_persistent_pv2 really co-resident per CU (plain / record-verifying instance)
   uint64_t wg2_checked_topo = ~0ull;  // the device expansion's verdict (no patch with more than 64 foreign records) was read for this topology
   bool wg2_usable = false;

@@ -27,13 +27,15 @@ struct WaveGroup {
 // so running them one after the other for all n steps is exactly the same computation.
 int ensure_form_rows(flame_nltgv2_ctx* ctx, int form);
 
-int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups, int* use_tv_lds = nullptr) {
+// `consume`: the call plans a run that is about to be enqueued (enqueue_run) -- only then does a planned-around run count against
+// the back-off after an expired wait; a query (persistent_eligible, prepare_run) leaves the bookkeeping alone.
+int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups, int* use_tv_lds = nullptr, bool consume = false) {
   groups->clear();
   if (use_tv_lds) *use_tv_lds = 0;
   if (!ctx->opt_persistent || n < 4 || n > (1 << 24) || !ctx->prop.cooperativeLaunch) return 0;
   if (ctx->persist_refused_topo == ctx->topo || ctx->replaying) return 0;
   if (ctx->persist_backoff_topo == ctx->topo && (ctx->persist_backoff_left > 0 || ctx->opt_fault > 0)) {  // (the test hook's fault does not pass)
-    if (ctx->persist_backoff_left > 0) --ctx->persist_backoff_left;
+    if (consume && ctx->persist_backoff_left > 0) --ctx->persist_backoff_left;
     return 0;
   }
   PackedLayout& L = ctx->L;
@@ -55,7 +57,6 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
   // The vertex-per-lane rows (D) are built only when that form is actually chosen.
   const bool pv_fits = L.wg_ok && L.wg_rowpack && L.wg_count > 0 && L.wg_count <= wg_cap;  // (the kernel runs row-packed patches)
   int form = 0;
-  if (ctx->opt_persistent == 4) form = (L.wg_ok && L.wg_rowpack) ? 3 : 0;
   // The two-half-edges-per-lane form: half the waves for the same graph.  Its lanes were expanded on the device at upload where
   // the graph is large enough (upload_topology); whether every patch can fetch its records (<= 64 distinct foreign ones) the
   // expansion left in a word that is read here, once per topology.
@@ -356,7 +357,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   pick_config(ctx, &unroll, &wpb);
   std::vector<WaveGroup> groups;
   int tv_lds = 0;
-  const int form = plan_persistent(ctx, n, &groups, &tv_lds);
+  const int form = plan_persistent(ctx, n, &groups, &tv_lds, /*consume=*/true);
   if (form != 0) {
     // tags must stay unique: clear the record buffers long before the 28-bit tag of the XCC table wraps -- and when the
     // form changes (the forms lay the buffers out differently: one's XCC table is another's record area)
@@ -473,6 +474,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       {
         flame_nltgv2_ctx::PendingOp op;
         op.kind = 0, op.params = *p, op.n = n;
+        op.dst = ctx->export_ptr, op.scale = ctx->export_scale;  // the standing export target THIS run was enqueued with
         ctx->pending.ops.push_back(op);
       }
       std::swap(ctx->hq, ctx->hq_alt);
@@ -505,6 +507,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   if (ctx->pending.active) {
     flame_nltgv2_ctx::PendingOp op;
     op.kind = 0, op.params = *p, op.n = n;
+    op.dst = ctx->export_ptr, op.scale = ctx->export_scale;
     ctx->pending.ops.push_back(op);
   }
   int left = n;
@@ -612,9 +615,15 @@ int finish(flame_nltgv2_ctx* ctx) {
     HIPCHK(ctx, hipMemsetAsync(ctx->abort_flag.p, 0, sizeof(int), ctx->stream));
     ctx->replaying = true;
     int replay_rc = 0;
+    // every run is redone with the standing export target it was enqueued with (the caller may have switched the target in the
+    // middle of the chain -- the double-buffered rows of a result gather: run k exports to row A, run k + 1 to row B)
+    float* const export_now = ctx->export_ptr;
+    const float export_scale_now = ctx->export_scale;
     for (const flame_nltgv2_ctx::PendingOp& op : run.ops) {
       if (op.kind == 0) {
+        ctx->export_ptr = op.dst, ctx->export_scale = op.scale;
         replay_rc = enqueue_run(ctx, &op.params, op.n);
+        ctx->export_ptr = export_now, ctx->export_scale = export_scale_now;
       } else {
         const int e = launch_export(ctx->c, ctx->f, true, op.scale, op.dst, ctx->stream);
         if (e) ctx->last_hip = e, ctx->last_error = FLAME_NLTGV2_ERR_HIP, replay_rc = FLAME_NLTGV2_ERR_HIP;

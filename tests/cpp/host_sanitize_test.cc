@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "flame_hip/nltgv2_l1_graph_regularizer.hpp"
+#include "host_workers.hpp"
 #include "nltgv2_pack.hpp"
 
 using namespace flame_hip;
@@ -154,6 +155,21 @@ static void check_layout(HostGraph& h, const char* name) {
 
 int main() {
   unsigned long long seed = 42;
+  // ---- worker pool: regions of different sizes back to back (a worker that wakes up late must never run a job of the
+  // NEXT region, and no job may be counted twice: every region has its own state, host_workers.hpp) ---------------------
+  {
+    long long total = 0, expect = 0;
+    bool once = true;
+    for (int r = 0; r < 4000; ++r) {
+      const int n = 1 + (int)(sm(seed) % 33);
+      std::vector<int> hit((size_t)n, 0);  // (dies at the end of the iteration: a stale worker writing here is a use after free)
+      flame_hip::Workers::get().run(n, [&](int i) { __atomic_add_fetch(&hit[(size_t)i], 1, __ATOMIC_RELAXED); });
+      for (int i = 0; i < n; ++i) once = once && hit[(size_t)i] == 1, total += hit[(size_t)i];
+      expect += n;
+    }
+    EXPECT(once && total == expect, "worker pool: every job of every region ran exactly once");
+    std::printf("workers  %d threads, 4000 regions of 1..33 jobs                  %s\n", flame_hip::Workers::get().threads(), once && total == expect ? "ok" : "FAIL");
+  }
   // ---- Delaunay ---------------------------------------------------------------------------------------------
   {
     std::vector<float> xy;

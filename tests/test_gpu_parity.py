@@ -656,6 +656,49 @@ def test_standing_export_target(env, form):
         assert float(buf.max()) == -7.0
 
 
+@pytest.mark.parametrize("form", [3, 4, 6])
+def test_export_target_switched_inside_a_replayed_chain(env, form):
+    """Double-buffered gather rows: run k exports into row A, the target moves to row B, run k + 1 chains on.  If the chain
+    is replayed (an expired wait), every run must be redone with the target IT was enqueued with -- row A gets run k's
+    x * scale, not the previous frame's (advisor, round 3: PendingOp now records the target)."""
+    import torch
+
+    flame_amd, oracle = env
+    g = synth.make_graph("320x240", seed=29)
+    ref = synth.copy_graph(g)
+    p = flame_amd.Params()
+    rows = torch.full((2, g["V"]), -3.0, dtype=torch.float32, device="cuda")
+    with flame_amd.Regularizer(0) as reg:
+        reg.set_option(5, form)
+        reg.upload_graph(g)
+        reg.run(p, 10)
+        oracle.run(ref, 10)
+        reg.set_option(flame_amd.regularizer.OPT_FAULT_INJECT, 200)
+        before = reg.info()["timeouts_recovered"]
+        reg.set_export_target(rows[0].data_ptr(), 2.0)
+        reg.run_async(p, 9)
+        reg.set_export_target(rows[1].data_ptr(), 0.5)
+        reg.run_async(p, 7)
+        reg.sync()
+        oracle.run(ref, 9)
+        want_a = ref["x"] * np.float32(2.0)
+        oracle.run(ref, 7)
+        want_b = ref["x"] * np.float32(0.5)
+        torch.cuda.synchronize()
+        assert reg.info()["timeouts_recovered"] == before + 1
+        got = rows.cpu().numpy()
+        assert np.array_equal(got[0], want_a), "row A must hold the FIRST run's result after the replay"
+        assert np.array_equal(got[1], want_b)
+        assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS, what="after the replayed chain")
+        # the target in force after the replay is the caller's latest one
+        reg.set_option(flame_amd.regularizer.OPT_FAULT_INJECT, 0)
+        reg.run(p, 6)
+        oracle.run(ref, 6)
+        torch.cuda.synchronize()
+        assert np.array_equal(rows[1].cpu().numpy(), ref["x"] * np.float32(0.5))
+        assert np.array_equal(rows[0].cpu().numpy(), want_a)
+
+
 def test_run_timed_and_info(env):
     flame_amd, _ = env
     g = synth.make_graph("640x480", seed=1)
