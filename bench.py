@@ -93,13 +93,21 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    # Dry-run aids (never set by the driver): FLAME_BENCH_BACKEND=gloo runs the N > 1 code path where RCCL cannot (two ranks on
+    # ONE device: tests/test_frames_world2_gpu.py), FLAME_BENCH_DEVICE=<ordinal> puts every rank on that device.
+    backend = os.environ.get("FLAME_BENCH_BACKEND", "nccl")
+    if os.environ.get("FLAME_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["FLAME_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("FLAME_BENCH_FORCE_DIST"):
         # launched by torch.distributed.run (also with a single rank: exercises the RCCL path)
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     def barrier():
         if dist is not None:
@@ -159,7 +167,7 @@ def main():
         gather_us = (time.perf_counter() - t0) / 20 * 1e6
     run_path = flame_amd.regularizer.RUN_PATHS.get(reg.info()["last_run_path"], "?")
     if dist is not None:
-        t = torch.tensor([wall], device="cuda", dtype=torch.float64)
+        t = torch.tensor([wall], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     total_iters = world * a.steps * a.iters
@@ -225,7 +233,7 @@ def main():
             "run_path": run_path,
         }
         if gather_us is not None:
-            out["result_gather"] = {"all_gather_us": round(gather_us, 1), "bytes_per_rank": int(g["V"]) * 4, "ranks": world,
+            out["result_gather"] = {"all_gather_us": round(gather_us, 1), "bytes_per_rank": int(g["V"]) * 4, "ranks": world, "backend": backend,
                                     "last_row_matches_state": gather_ok, "regathered_after_replay": int(regathered),
                                     "note": "blocking all_gather_into_tensor of x*graph_scale incl. host launch + sync; in the "
                                             "step loop it is asynchronous and overlaps the next solve"}

@@ -43,9 +43,15 @@ class IdepthGather:
         self.my_frames = shard_frames(n_frames, self.world, self.rank)
         if len(sizes_local) != len(self.my_frames):
             raise ValueError("one size per local frame expected")
+        # Staged mode: the send rows live on a GPU but the backend moves host memory only (gloo has no device all_gather).
+        # gather() then copies the local rows to pinned host memory behind the solver's run, the collective runs on the host
+        # copies and `gathered` / frame() are host tensors.  This is how two ranks drive real solvers on ONE device (RCCL refuses
+        # two ranks per device): tests/test_frames_world2_gpu.py, bench.py with FLAME_BENCH_BACKEND=gloo.
+        self._staged = torch.device(device).type == "cuda" and str(dist.get_backend()) == "gloo"
+        cdev = torch.device("cpu") if self._staged else device
         # agree on vmax and publish every frame's true length
-        sizes = torch.zeros(self.world * max(self.slots, 1), dtype=torch.int64, device=device)
-        mine = torch.zeros(max(self.slots, 1), dtype=torch.int64, device=device)
+        sizes = torch.zeros(self.world * max(self.slots, 1), dtype=torch.int64, device=cdev)
+        mine = torch.zeros(max(self.slots, 1), dtype=torch.int64, device=cdev)
         for i, v in enumerate(sizes_local):
             mine[i] = int(v)
         dist.all_gather_into_tensor(sizes, mine)
@@ -56,7 +62,8 @@ class IdepthGather:
         shape_l = (max(self.slots, 1), max(self.vmax, 1))
         shape_g = (self.world * max(self.slots, 1), max(self.vmax, 1))
         self._local = [torch.zeros(shape_l, dtype=torch.float32, device=device) for _ in range(2)]
-        self._gathered = [torch.empty(shape_g, dtype=torch.float32, device=device) for _ in range(2)]
+        self._gathered = [torch.empty(shape_g, dtype=torch.float32, device=cdev) for _ in range(2)]
+        self._h_local = [torch.zeros(shape_l, dtype=torch.float32).pin_memory() for _ in range(2)] if self._staged else None
         self._work = [None, None]
         self._cur = 0
         self.local = self._local[0]
@@ -84,7 +91,12 @@ class IdepthGather:
         for settle()."""
         k = self._cur
         self._replays_at_gather = self._replays(regs) if regs is not None else None
-        w = self.dist.all_gather_into_tensor(self._gathered[k], self._local[k], async_op=async_op)
+        send = self._local[k]
+        if self._staged:  # device rows -> pinned host rows, ordered behind the solver on the current stream, then a host collective
+            self._h_local[k].copy_(self._local[k], non_blocking=True)
+            torch.cuda.current_stream(self._local[k].device).synchronize()
+            send = self._h_local[k]
+        w = self.dist.all_gather_into_tensor(self._gathered[k], send, async_op=async_op)
         self._work[k] = w if async_op else None
         self.gathered = self._gathered[k]
         self._last = k
@@ -105,7 +117,7 @@ class IdepthGather:
         self._replays_at_gather = None
         self.wait()
         if self.world > 1:
-            t = torch.tensor([redo], dtype=torch.int32, device=self._local[0].device)
+            t = torch.tensor([redo], dtype=torch.int32, device="cpu" if self._staged else self._local[0].device)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             redo = int(t.item())
         if redo:
