@@ -165,37 +165,13 @@ int staged_h2d(flame_nltgv2_ctx* ctx, const StageCopy* cp, size_t n, const Stage
   return 0;
 }
 
-// Layout + topology arrays of `g` (V, E, pos, src, dst) onto the device; the caller adds the state.  On return the
-// stream still holds the copies: the caller synchronises before the staging buffer or `g`'s arrays may change.
-int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const StageCopy* extra, size_t n_extra, bool long_lived) {
-  const int32_t V = g->V, E = g->E;
-  (void)long_lived;
-  int rc = build_layout(g, &ctx->L, /*host_expand=*/false, /*rowpack=*/true,
-                        /*rowpack_max_patches=*/ctx->opt_persistent == 4 ? 0x7fffffff : kPvDensePerCu * ctx->prop.multiProcessorCount);
-  if (rc) return fail(ctx, rc);
-  // Row packing costs ~15 % more waves than lanes back to back.  It pays where the patch-per-wave kernel runs them; a layout
-  // that turns out too large for that kernel (more patches than the estimate) is better off back to back, for the
-  // lane-per-half-edge form.
-  // (FLAME_NLTGV2_OPT_PERSISTENT 4 -- the patch-per-wave form asked for by name -- keeps the row-packed layout whatever the
-  //  size: the kernel then runs it as groups of whole components)
-  if (ctx->L.wg_ok && ctx->L.wg_rowpack && ctx->opt_persistent != 4 && ctx->L.wg_count > kPvDensePerCu * ctx->prop.multiProcessorCount) {
-    rc = build_layout(g, &ctx->L, /*host_expand=*/false, /*rowpack=*/false, 0);
-    if (rc) return fail(ctx, rc);
-  }
-  // Layout (E2), two half-edges per lane: where the one-half-edge patches would fill the CUs (kPv2FromPerCu per CU and more), or
-  // where it is asked for by name.  Pass 1 (per vertex) here, the lanes on the device below.
-  bool want_e2 = false;
-  {
-    const int cus = ctx->prop.multiProcessorCount;
-    const int64_t est_patches = ctx->L.wg_rowpack ? (int64_t)ctx->L.wg_count : ((static_cast<int64_t>(2) * E + V / 32) / 54 + 1);
-    want_e2 = ctx->L.wg_ok && ctx->L.max_degree <= 32 && ctx->opt_probe == 0 &&
-              (ctx->opt_persistent == 6 || (ctx->opt_persistent == 1 && est_patches > (int64_t)kPv2FromPerCu * cus));
-    if (want_e2) {
-      build_patch_walk2(&ctx->L);
-      want_e2 = ctx->L.wg2_ok && ctx->L.wg2_count <= kPv2WavesPerCu * cus * 4;  // (beyond four groups the vertex-per-lane form it is)
-    }
-  }
+// Sizes every buffer of the packed forms for the layout whose scalars stand in ctx->L (V, E, n_slices, rows, wg_count, wg2_count)
+// and starts the bookkeeping of a new topology.  Table sizes are passed explicitly: the host builders know them from their
+// vectors, the device builder (nltgv2_topo_capi.hip) sizes them by their upper bounds before it runs.
+int topology_buffers(flame_nltgv2_ctx* ctx, bool want_e2, size_t n_wg_info, size_t n_wg_v0, size_t n_wg_vfirst, size_t n_wg2_info,
+                     size_t n_wg2_vfirst) {
   const PackedLayout& L = ctx->L;
+  const int32_t V = L.V, E = L.E;
   const size_t n_slots = (size_t)(L.rows + kRowPad) * kWave;
   if (n_slots > (size_t)0x7fffffff) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
   const size_t n_packed = (size_t)L.n_slices * kWave;
@@ -212,23 +188,23 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
       {&ctx->hq_alt, sizeof(float4) * n_slots}, {&ctx->vstate_alt, sizeof(float4) * n_packed}, {&ctx->photo_err, fV},
       {&ctx->bar0, sizeof(float4) * n_packed}, {&ctx->bar1, sizeof(float4) * n_packed},
       {&ctx->vprev, sizeof(float4) * n_packed}, {&ctx->xbuf, kXbufBytesPerVertex * records_capacity(L) + 64},
-      {&ctx->wg_v0, sizeof(int32_t) * L.wg_v0.size()},
-      {&ctx->wg_vfirst, L.wg_vfirst.size() + 16}, {&ctx->abort_flag, sizeof(int)}, {&ctx->err, kErrBytes}, {&ctx->cost_out, 2 * sizeof(float)},
+      {&ctx->wg_v0, sizeof(int32_t) * n_wg_v0},
+      {&ctx->wg_vfirst, n_wg_vfirst + 16}, {&ctx->abort_flag, sizeof(int)}, {&ctx->err, kErrBytes}, {&ctx->cost_out, 2 * sizeof(float)},
       {&ctx->wg_slot, sizeof(int32_t) * lanes}, {&ctx->wg_vid, sizeof(int32_t) * lanes}, {&ctx->wg_meta, sizeof(uint32_t) * lanes},
       {&ctx->wg_nbr, sizeof(int32_t) * lanes}, {&ctx->wg_fetch, sizeof(int32_t) * lanes},
-      {&ctx->wg_info, sizeof(int32_t) * L.wg_info.size()}};
+      {&ctx->wg_info, sizeof(int32_t) * n_wg_info}};
   for (auto& r : req) {
-    rc = ensure(ctx, *r.b, r.bytes);
+    const int rc = ensure(ctx, *r.b, r.bytes);
     if (rc) return rc;
   }
-  const size_t lanes2 = want_e2 ? (size_t)L.wg2_count * kWave : 0;
   if (want_e2) {
+    const size_t lanes2 = (size_t)L.wg2_count * kWave;
     struct { DevBuf* b; size_t bytes; } req2[] = {
-        {&ctx->wg2_info, sizeof(int32_t) * L.wg2_info.size()}, {&ctx->wg2_vfirst, L.wg2_vfirst.size() + 16}, {&ctx->wg2_rmax, 64},
+        {&ctx->wg2_info, sizeof(int32_t) * n_wg2_info}, {&ctx->wg2_vfirst, n_wg2_vfirst + 16}, {&ctx->wg2_rmax, 64},
         {&ctx->wg2_slot, sizeof(int32_t) * 2 * lanes2}, {&ctx->wg2_nbr, sizeof(int32_t) * 2 * lanes2}, {&ctx->wg2_vid, sizeof(int32_t) * lanes2},
         {&ctx->wg2_meta, sizeof(uint32_t) * lanes2}, {&ctx->wg2_fetch, sizeof(int32_t) * lanes2}};
     for (auto& r : req2) {
-      rc = ensure(ctx, *r.b, r.bytes);
+      const int rc = ensure(ctx, *r.b, r.bytes);
       if (rc) return rc;
     }
   }
@@ -236,36 +212,33 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
   ctx->tv_built = ctx->wg2_built = false;
   drop_graphs(ctx);
   refresh_args(ctx);
+  return 0;
+}
 
-  std::vector<StageCopy> cp = {
-      {&ctx->pos, g->pos, 2 * fV}, {&ctx->src, g->src, fE}, {&ctx->dst, g->dst, fE},
-      {&ctx->row_ptr, L.row_ptr.data(), sizeof(int32_t) * ((size_t)V + 1)}, {&ctx->half, L.half.data(), 2 * fE},
-      {&ctx->slice_row, L.slice_row.data(), sizeof(int32_t) * ((size_t)L.n_slices + 1)},
-      {&ctx->perm, L.perm.data(), sizeof(int32_t) * n_packed}, {&ctx->pdeg, L.pdeg.data(), sizeof(int32_t) * n_packed},
-      {&ctx->iperm, L.iperm.data(), iV}, {&ctx->order_m, L.order_m.data(), iV}, {&ctx->rid_of, L.rid_of.data(), iV},
-      {&ctx->wg_info, L.wg_info.data(), sizeof(int32_t) * L.wg_info.size()},
-      {&ctx->wg_v0, L.wg_v0.data(), sizeof(int32_t) * L.wg_v0.size()},
-      {&ctx->wg_vfirst, L.wg_vfirst.data(), L.wg_vfirst.size()}};
-  if (want_e2) {
-    cp.push_back(StageCopy{&ctx->wg2_info, L.wg2_info.data(), sizeof(int32_t) * L.wg2_info.size()});
-    cp.push_back(StageCopy{&ctx->wg2_vfirst, L.wg2_vfirst.data(), L.wg2_vfirst.size()});
-  }
-  cp.insert(cp.end(), extra, extra + n_extra);
-  std::vector<StageFill> fills = {
+// The clears every new topology needs (no record or flag of an earlier topology may survive).
+void topology_fills(flame_nltgv2_ctx* ctx, bool want_e2, std::vector<StageFill>* fills) {
+  const PackedLayout& L = ctx->L;
+  const size_t n_slots = (size_t)(L.rows + kRowPad) * kWave, n_packed = (size_t)L.n_slices * kWave;
+  const StageFill base[] = {
       {ctx->err.p, kErrBytes, 0u}, {ctx->abort_flag.p, sizeof(int), 0u}, {ctx->xbuf.p, kXbufBytesPerVertex * records_capacity(L) + 64, 0u},
       // empty slots / padding vertices of the second copies: zero, as the packing kernels write them in the first
       {ctx->hq_alt.p, sizeof(float4) * n_slots, 0u}, {ctx->vstate_alt.p, sizeof(float4) * n_packed, 0u},
       // the spare rows behind the last slice: no edge, neighbour 0 (what the unrolled sweeps may read past a slice's end)
       {(char*)ctx->rec_edge.p + sizeof(int32_t) * (size_t)L.rows * kWave, sizeof(int32_t) * kRowPad * kWave, 0xffffffffu},
       {(char*)ctx->rec_nbr.p + sizeof(uint32_t) * (size_t)L.rows * kWave, sizeof(uint32_t) * kRowPad * kWave, 0u}};
-  // (the tags start over below: no record of an earlier topology may survive, in the placement pool either)
-  if (want_e2) fills.push_back(StageFill{ctx->wg2_rmax.p, 64, 0u});
+  fills->insert(fills->end(), base, base + sizeof(base) / sizeof(base[0]));
+  // (the tags start over: no record of an earlier topology may survive, in the placement pool either)
+  if (want_e2) fills->push_back(StageFill{ctx->wg2_rmax.p, 64, 0u});
   if (ctx->place_base) {
-    fills.push_back(StageFill{ctx->place_base, (size_t)2 * kPlacePages * 4096, 0u});
-    fills.push_back(StageFill{(int*)ctx->place_fill.p + 2 * kPlacePages, 64, 0u});
+    fills->push_back(StageFill{ctx->place_base, (size_t)2 * kPlacePages * 4096, 0u});
+    fills->push_back(StageFill{(int*)ctx->place_fill.p + 2 * kPlacePages, 64, 0u});
   }
-  rc = staged_h2d(ctx, cp.data(), cp.size(), fills.data(), fills.size());
-  if (rc) return rc;
+}
+
+// Per-slot and per-lane arrays from the per-vertex tables that stand on the device (nltgv2_layout.hip), record placement, and the
+// run-side bookkeeping of a new topology.
+int topology_expand(flame_nltgv2_ctx* ctx, bool want_e2) {
+  const PackedLayout& L = ctx->L;
   LAUNCHCHK(ctx, launch_build_sell(ctx->c, ctx->f, (const int32_t*)ctx->iperm.p, ctx->stream));
   if (L.wg_ok)
     LAUNCHCHK(ctx, launch_build_patches(ctx->c, ctx->f, (const int32_t*)ctx->wg_v0.p, (const int32_t*)ctx->order_m.p,
@@ -291,15 +264,79 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
   if (L.wg_ok && ctx->place_state == 1 && ctx->opt_place && L.wg_count > 2 * (ctx->prop.multiProcessorCount / 8) &&
       (ctx->opt_xcds == 0 || ctx->opt_xcds == 8)) {
     refresh_args(ctx);
-    rc = place_records(ctx, (L.wg_count + 7) / 8);
+    const int rc = place_records(ctx, (L.wg_count + 7) / 8);
     if (rc) return rc;
   }
   ctx->pending = flame_nltgv2_ctx::PendingRun{};
   ctx->tag_next = 1;
   ctx->xbuf_form = 0;
   ctx->static_stale = false;
+  return 0;
+}
+
+// Whether the new topology also gets layout (E2), two half-edges per lane: where the one-half-edge patches would fill the CUs
+// (kPv2FromPerCu per CU and more), or where it is asked for by name.
+bool wants_e2(const flame_nltgv2_ctx* ctx) {
+  const PackedLayout& L = ctx->L;
+  const int cus = ctx->prop.multiProcessorCount;
+  const int64_t est_patches = L.wg_rowpack ? (int64_t)L.wg_count : ((static_cast<int64_t>(2) * L.E + L.V / 32) / 54 + 1);
+  return L.wg_ok && L.max_degree <= 32 && ctx->opt_probe == 0 &&
+         (ctx->opt_persistent == 6 || (ctx->opt_persistent == 1 && est_patches > (int64_t)kPv2FromPerCu * cus));
+}
+
+// Layout + topology arrays of `g` (V, E, pos, src, dst) onto the device, the per-vertex tables by the HOST builders
+// (nltgv2_pack.hpp); the caller adds the state.  On return the stream still holds the copies: the caller synchronises before the
+// staging buffer or `g`'s arrays may change.
+int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const StageCopy* extra, size_t n_extra, bool long_lived) {
+  const int32_t V = g->V, E = g->E;
+  (void)long_lived;
+  int rc = build_layout(g, &ctx->L, /*host_expand=*/false, /*rowpack=*/true,
+                        /*rowpack_max_patches=*/ctx->opt_persistent == 4 ? 0x7fffffff : kPvDensePerCu * ctx->prop.multiProcessorCount);
+  if (rc) return fail(ctx, rc);
+  // Row packing costs ~15 % more waves than lanes back to back.  It pays where the patch-per-wave kernel runs them; a layout
+  // that turns out too large for that kernel (more patches than the estimate) is better off back to back, for the
+  // vertex-per-lane form.
+  // (FLAME_NLTGV2_OPT_PERSISTENT 4 -- the patch-per-wave form asked for by name -- keeps the row-packed layout whatever the
+  //  size: the kernel then runs it as groups of whole components)
+  if (ctx->L.wg_ok && ctx->L.wg_rowpack && ctx->opt_persistent != 4 && ctx->L.wg_count > kPvDensePerCu * ctx->prop.multiProcessorCount) {
+    rc = build_layout(g, &ctx->L, /*host_expand=*/false, /*rowpack=*/false, 0);
+    if (rc) return fail(ctx, rc);
+  }
+  // Layout (E2): pass 1 (per vertex) here, the lanes on the device below.
+  bool want_e2 = wants_e2(ctx);
+  if (want_e2) {
+    build_patch_walk2(&ctx->L);
+    want_e2 = ctx->L.wg2_ok && ctx->L.wg2_count <= kPv2WavesPerCu * ctx->prop.multiProcessorCount * 4;  // (beyond four groups the vertex-per-lane form it is)
+  }
+  const PackedLayout& L = ctx->L;
+  rc = topology_buffers(ctx, want_e2, L.wg_info.size(), L.wg_v0.size(), L.wg_vfirst.size(), L.wg2_info.size(), L.wg2_vfirst.size());
+  if (rc) return rc;
+  const size_t n_packed = (size_t)L.n_slices * kWave;
+  const size_t fV = sizeof(float) * (size_t)V, fE = sizeof(float) * (size_t)E, iV = sizeof(int32_t) * (size_t)V;
+  std::vector<StageCopy> cp = {
+      {&ctx->pos, g->pos, 2 * fV}, {&ctx->src, g->src, fE}, {&ctx->dst, g->dst, fE},
+      {&ctx->row_ptr, L.row_ptr.data(), sizeof(int32_t) * ((size_t)V + 1)}, {&ctx->half, L.half.data(), 2 * fE},
+      {&ctx->slice_row, L.slice_row.data(), sizeof(int32_t) * ((size_t)L.n_slices + 1)},
+      {&ctx->perm, L.perm.data(), sizeof(int32_t) * n_packed}, {&ctx->pdeg, L.pdeg.data(), sizeof(int32_t) * n_packed},
+      {&ctx->iperm, L.iperm.data(), iV}, {&ctx->order_m, L.order_m.data(), iV}, {&ctx->rid_of, L.rid_of.data(), iV},
+      {&ctx->wg_info, L.wg_info.data(), sizeof(int32_t) * L.wg_info.size()},
+      {&ctx->wg_v0, L.wg_v0.data(), sizeof(int32_t) * L.wg_v0.size()},
+      {&ctx->wg_vfirst, L.wg_vfirst.data(), L.wg_vfirst.size()}};
+  if (want_e2) {
+    cp.push_back(StageCopy{&ctx->wg2_info, L.wg2_info.data(), sizeof(int32_t) * L.wg2_info.size()});
+    cp.push_back(StageCopy{&ctx->wg2_vfirst, L.wg2_vfirst.data(), L.wg2_vfirst.size()});
+  }
+  cp.insert(cp.end(), extra, extra + n_extra);
+  std::vector<StageFill> fills;
+  topology_fills(ctx, want_e2, &fills);
+  rc = staged_h2d(ctx, cp.data(), cp.size(), fills.data(), fills.size());
+  if (rc) return rc;
+  rc = topology_expand(ctx, want_e2);
+  if (rc) return rc;
   ctx->h_src.assign(g->src, g->src + E);
   ctx->h_dst.assign(g->dst, g->dst + E);
+  ctx->host_layout_valid = true;
+  ctx->feat_dev_valid = false;  // (the device's feature table describes the previous graph)
   return 0;
 }
 
@@ -307,6 +344,10 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
 // frames run in the patch-per-wave form and never need them).
 int ensure_form_rows(flame_nltgv2_ctx* ctx, int form) {
   PackedLayout& L = ctx->L;
+  if ((form == 4 && !ctx->wg2_built) || (form == 2 && !ctx->tv_built)) {  // (the host builders read the host image of the tables)
+    const int rc = ensure_host_layout(ctx);
+    if (rc) return rc;
+  }
   if (form == 4 && !ctx->wg2_built) {
     build_patch_rows2(&L);
     ctx->pv2_args = Pv2Args{};
@@ -409,6 +450,8 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
               &ctx->wg_fetch, &ctx->wg_info, &ctx->wg_v0, &ctx->probe, &ctx->snap_hq, &ctx->snap_vstate, &ctx->snap_bar, &ctx->iperm,
               &ctx->order_m, &ctx->rid_of, &ctx->d_stage, &ctx->sync_init, &ctx->sync_vmap, &ctx->sync_emap, &ctx->sync_need,
               &ctx->wg_vfirst, &ctx->place_pool, &ctx->place_rank, &ctx->place_fill, &ctx->place_rec_off, &ctx->place_patch, &ctx->place_meas, &ctx->progress};
+  for (DevBuf* b : {&ctx->feat_stamp_d, &ctx->feat_val_d, &ctx->topo_scratch, &ctx->nx_pos, &ctx->nx_src, &ctx->nx_dst, &ctx->nx_row_ptr, &ctx->nx_half, &ctx->topo_dims})
+    ctx->all.push_back(b);
   for (auto& b : ctx->sp_v) ctx->all.push_back(&b);
   for (auto& b : ctx->sp_q) ctx->all.push_back(&b);
   *out = ctx;
@@ -425,6 +468,7 @@ int flame_nltgv2_destroy(flame_nltgv2_ctx* ctx) {
   if (ctx->h_err) (void)hipHostFree(ctx->h_err);
   if (ctx->h_cost) (void)hipHostFree(ctx->h_cost);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  if (ctx->h_dims) (void)hipHostFree(ctx->h_dims);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -496,6 +540,10 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
       if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_tv_lds = value;
       return 0;
+    case FLAME_NLTGV2_OPT_SYNC_PATH:
+      if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_sync_path = value;
+      return 0;
     case FLAME_NLTGV2_OPT_UNROLL:
       if (value != 0 && value != 4 && value != 8 && value != 16) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_unroll = value;
@@ -522,9 +570,14 @@ int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info) {
   std::snprintf(info->gcn_arch, sizeof(info->gcn_arch), "%s", ctx->prop.gcnArchName);
   info->last_run_path = ctx->last_run_path;
   info->he_waves = 0;  // (the lane-per-half-edge form was retired in round 3; the field stays for the ABI)
-  if (ctx->have_graph && !ctx->tv_built) {  // the vertex-per-lane rows are built on demand; a caller sizing a batch asks here
-    ctx->L.tv_waves = 0;
-    build_tv_rows(&ctx->L);  // host table only; the upload happens when the form is first used
+  if (ctx->have_graph && !ctx->tv_built && ctx->tv_counted_topo != ctx->topo) {
+    // the vertex-per-lane rows are built on demand; a caller sizing a batch asks here (host table only, once per topology; the
+    // upload happens when the form is first used)
+    if (ensure_host_layout(ctx) == 0) {
+      ctx->L.tv_waves = 0;
+      build_tv_rows(&ctx->L);
+      ctx->tv_counted_topo = ctx->topo;
+    }
   }
   info->tv_waves = ctx->L.tv_ok ? ctx->L.tv_waves : 0;
   info->patches = ctx->L.wg_ok ? ctx->L.wg_count : 0;
@@ -532,6 +585,7 @@ int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info) {
   info->last_run_groups = ctx->last_run_groups;
   info->timeouts_recovered = ctx->timeouts_recovered;
   info->torn_records_detected = ctx->torn_records_detected;
+  info->last_sync_path = ctx->last_sync_path;
   return FLAME_NLTGV2_OK;
 }
 
@@ -563,6 +617,7 @@ int flame_nltgv2_layout_selftest(flame_nltgv2_ctx* ctx, int64_t* mismatches) {
   if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
   if (!mismatches) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
   rc = ensure_canon(ctx);
+  if (!rc) rc = ensure_host_layout(ctx);
   if (rc) return rc;
   const int32_t V = ctx->L.V, E = ctx->L.E;
   std::vector<float> pos(2 * (size_t)V);
@@ -586,6 +641,18 @@ int flame_nltgv2_layout_selftest(flame_nltgv2_ctx* ctx, int64_t* mismatches) {
   bad += (H.rows != L.rows) + (H.n_slices != L.n_slices) + (H.wg_ok != L.wg_ok) + (H.wg_count != L.wg_count) +
          (H.wg_lcap != L.wg_lcap) + (H.wg_slab_slots != L.wg_slab_slots) + (H.n_rec != L.n_rec) +
          (H.wg_v0 != L.wg_v0) + (H.wg_vfirst != L.wg_vfirst) + (H.wg_rowpack != L.wg_rowpack);
+  if (bad == 0) {  // the per-vertex tables as they stand on the device (sent up by the host path, or built there: nltgv2_topo.hip)
+    const size_t iV = 4 * (size_t)V;
+    int e = cmp(ctx->row_ptr, H.row_ptr.data(), iV + 4) | cmp(ctx->half, H.half.data(), 8 * (size_t)E) | cmp(ctx->order_m, H.order_m.data(), iV) |
+            cmp(ctx->rid_of, H.rid_of.data(), iV) | cmp(ctx->iperm, H.iperm.data(), iV) | cmp(ctx->pdeg, H.pdeg.data(), 4 * H.pdeg.size()) |
+            cmp(ctx->wg_v0, H.wg_v0.data(), 4 * H.wg_v0.size()) | cmp(ctx->wg_vfirst, H.wg_vfirst.data(), H.wg_vfirst.size() & ~size_t(3));
+    if (e) return fail(ctx, FLAME_NLTGV2_ERR_HIP);
+    std::vector<int32_t> hs(ctx->h_src.size()), hd(ctx->h_dst.size());  // (and the host image of the edge list is the device's)
+    if (E && (hipMemcpy(hs.data(), ctx->src.p, 4 * (size_t)E, hipMemcpyDeviceToHost) != hipSuccess ||
+              hipMemcpy(hd.data(), ctx->dst.p, 4 * (size_t)E, hipMemcpyDeviceToHost) != hipSuccess))
+      return fail(ctx, FLAME_NLTGV2_ERR_HIP);
+    bad += (hs != ctx->h_src) + (hd != ctx->h_dst);
+  }
   if (bad == 0) {
     const size_t n = (size_t)L.rows * kWave, lanes = (size_t)L.wg_count * kWave;
     int e = cmp(ctx->rec_nbr, H.rec_nbr.data(), 4 * n) | cmp(ctx->rec_edge, H.rec_edge.data(), 4 * n) |

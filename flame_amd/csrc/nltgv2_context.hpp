@@ -239,6 +239,19 @@ struct flame_nltgv2_ctx {
 
   PackedLayout L;
   std::vector<int32_t> h_src, h_dst, h_feat;  // host image of the current topology (for sync_graph)
+  // After a device-side build (nltgv2_topo_capi.hip) only L's scalars and h_feat are current; the vectors of L and h_src / h_dst are
+  // brought up to date on demand (ensure_host_layout: the host sync path, layouts built on the host on demand, get_topology, the
+  // self-test).
+  bool host_layout_valid = true;
+  uint64_t tv_counted_topo = ~0ull;  // get_info counted the vertex-per-lane waves of this topology
+  int opt_sync_path = 0;          // 0 auto (device where it applies), 1 host index maps + host tables, 2 device or error
+  int last_sync_path = 0;         // 1 host, 2 device
+  // the device's feature table: id -> vertex of the current graph where feat_stamp_d[id] == feat_gen (nltgv2_topo.hip)
+  DevBuf feat_stamp_d, feat_val_d, topo_scratch, nx_pos, nx_src, nx_dst, nx_row_ptr, nx_half, topo_dims;
+  int feat_tab_size_d = 0;
+  uint32_t feat_gen = 0;
+  bool feat_dev_valid = false;
+  TopoDims* h_dims = nullptr;     // pinned
   CanonArgs c;
   FusedArgs f;
   std::vector<DevBuf*> all;
@@ -311,6 +324,14 @@ struct StageFill {
 };
 int staged_h2d(flame_nltgv2_ctx* ctx, const StageCopy* cp, size_t n, const StageFill* fills = nullptr, size_t n_fills = 0);
 int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const StageCopy* extra, size_t n_extra, bool long_lived);
+int topology_buffers(flame_nltgv2_ctx* ctx, bool want_e2, size_t n_wg_info, size_t n_wg_v0, size_t n_wg_vfirst, size_t n_wg2_info,
+                     size_t n_wg2_vfirst);
+void topology_fills(flame_nltgv2_ctx* ctx, bool want_e2, std::vector<StageFill>* fills);
+int topology_expand(flame_nltgv2_ctx* ctx, bool want_e2);
+bool wants_e2(const flame_nltgv2_ctx* ctx);
+int ensure_host_layout(flame_nltgv2_ctx* ctx);  // the host image of the topology (ctx->L's vectors, h_src, h_dst) after a device build
+// ---- nltgv2_topo_capi.hip: the per-frame sync with the topology built on the device
+int sync_graph_device(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, bool* done);
 int ensure_form_rows(flame_nltgv2_ctx* ctx, int form);
 
 // ---- nltgv2_run.hip ----------------------------------------------------------------------------------------------------

@@ -94,9 +94,20 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
 
   const bool trace = std::getenv("FLAME_NLTGV2_TRACE") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
-  // The previous state stays on the device: the canonical arrays are brought up to date (a kernel, enqueued) while the
-  // host works out the index maps below.
+  // The device path (round 4, nltgv2_topo_capi.hip): index maps AND the new graph's layout tables by kernels over the resident
+  // previous topology.  It takes the pipeline's case -- the triangulator's duplicate-free edge list (edges_unique), small feature
+  // ids -- and declines the rest (a hub of more than 64 edges, ...), which goes the host way below.
+  if (ctx->opt_sync_path != 1) {
+    bool done = false;
+    rc = sync_graph_device(ctx, in, &done);
+    if (rc) return rc;
+    if (done) return FLAME_NLTGV2_OK;
+    if (ctx->opt_sync_path == 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // (asked for by name and not applicable)
+  }
+  // The host path.  The previous state stays on the device: the canonical arrays are brought up to date (a kernel, enqueued)
+  // while the host works out the index maps below, from its image of the previous topology.
   rc = ensure_canon(ctx);
+  if (!rc) rc = ensure_host_layout(ctx);
   if (rc) return rc;
   const int32_t Vo = ctx->L.V, Eo = ctx->L.E;
 
@@ -331,6 +342,7 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
   ctx->parity = 0;
   ctx->have_graph = true;
   ctx->last_error = 0;
+  ctx->last_sync_path = 1;
   return FLAME_NLTGV2_OK;
 }
 
@@ -396,9 +408,22 @@ int flame_nltgv2_set_feature_ids(flame_nltgv2_ctx* ctx, const int32_t* feat_id) 
 int flame_nltgv2_get_topology(flame_nltgv2_ctx* ctx, int32_t* src, int32_t* dst, int32_t* feat_id) {
   if (!ctx) return FLAME_NLTGV2_ERR_INVALID_ARG;
   if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if ((src || dst) && !ctx->host_layout_valid) {  // (after a device-side build the edge list comes down on demand)
+    int rc = enter(ctx);
+    if (!rc) rc = ensure_host_layout(ctx);
+    if (rc) return rc;
+  }
   if (src) std::copy(ctx->h_src.begin(), ctx->h_src.end(), src);
   if (dst) std::copy(ctx->h_dst.begin(), ctx->h_dst.end(), dst);
   if (feat_id) std::copy(ctx->h_feat.begin(), ctx->h_feat.end(), feat_id);
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_graph_size(flame_nltgv2_ctx* ctx, int32_t* V, int32_t* E) {
+  if (!ctx) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (V) *V = ctx->L.V;
+  if (E) *E = ctx->L.E;
   return FLAME_NLTGV2_OK;
 }
 

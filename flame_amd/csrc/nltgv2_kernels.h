@@ -179,6 +179,71 @@ const void* persistent_tv_kernel(bool static_in_lds, int waves_per_block, unsign
 int launch_build_sell(const CanonArgs& c, const FusedArgs& a, const int32_t* iperm, hipStream_t s);
 int launch_build_patches(const CanonArgs& c, const FusedArgs& a, const int32_t* wg_v0, const int32_t* order_m,
                          const int32_t* rid_tab, const uint8_t* vfirst, const int32_t* iperm, hipStream_t s);
+// ---- the per-VERTEX layout tables built on the device (nltgv2_topo.hip) ---------------------------------------------------
+// What the host reads back once the device has built a topology.
+struct TopoDims {
+  int32_t n_edges;            // edges of the new graph
+  int32_t n_keep;             // sync: edges that survived from the previous graph
+  int32_t rows;               // 64-wide rows of the SELL-64 layout (B)
+  int32_t max_degree;
+  int32_t wg_count, wg_lcap;  // (E): patches, most vertices of one patch
+  int32_t wg2_count, wg2_lcap;  // (E2)
+  int32_t flags;              // kTopoBad*: the device build cannot stand, the host builders take over
+  int32_t pad_[7];
+};
+constexpr int32_t kTopoBadDegree = 1;  // a vertex of more than 64 edges
+constexpr int32_t kTopoBadEdges = 2;   // sync: the new edge list is not the triangulator's (a vertex pair listed twice)
+constexpr int kTopoInf = 0x7f7f7f7f;
+// Everything the builder reads and writes (device pointers; scratch is carved out of one buffer by the host).
+struct TopoBuild {
+  int V = 0, E = 0;    // the new graph; sync: E = triangulator edges, every one of which becomes an edge
+  int Vo = 0, Eo = 0;  // sync: the previous graph
+  int n_slices = 0;
+  // inputs
+  const int32_t* fid = nullptr;        // sync: [V] feature ids of the new vertices
+  const float2* pos = nullptr;         // [V]
+  const int32_t* tri_edges = nullptr;  // sync: [2E] vertex pairs in triangulator order
+  float minx = 0, miny = 0, sx = 0, sy = 0;  // Morton quantisation of pos (nltgv2_pack.hpp: build_layout)
+  // sync: the previous topology and the feature table (id -> vertex of the graph of generation gen_prev)
+  const int32_t* o_row_ptr = nullptr;
+  const uint32_t* o_half = nullptr;
+  const int32_t *o_src = nullptr, *o_dst = nullptr;
+  uint32_t* feat_stamp = nullptr;
+  int32_t* feat_val = nullptr;
+  int tab_size = 0;
+  uint32_t gen_prev = 0, gen_new = 0;
+  // scratch
+  int32_t *old_edge = nullptr, *first_k = nullptr;  // [E]: previous edge | orientation bit 31, -1 none; [Eo]: first triangulator edge keeping it
+  int32_t* scan = nullptr;                           // [Eo + E + V + 1]: exclusive sums of [survivor flags | new-edge flags | degrees | 0]
+  int32_t *deg = nullptr, *cur = nullptr;            // [V]
+  int cc_bits = 1;                                   // 2^cc_bits >= V: the priority space of the union-find (nltgv2_topo.hip: cc_mix)
+  int32_t *parent = nullptr, *minid = nullptr;       // [2^cc_bits] indexed by priority: parent, smallest vertex id of the tree rooted there
+  uint32_t* morton = nullptr;                        // [V]
+  uint64_t* key_out = nullptr;                       // [V] sorted (component label << 32) | Morton code
+  int32_t* width = nullptr;                          // [n_slices]
+  uint8_t* wflag = nullptr;                          // [V up to 16384] walk input: degree | component begins << 7
+  uint8_t* vf[2] = {nullptr, nullptr};               // [V up to 16384] walk output of (E) / (E2): first lane | patch begins << 7
+  int32_t* seg_count[2] = {nullptr, nullptr};        // [segments] patches per walk segment
+  void* sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  int* counters = nullptr;                           // [4] "last block" tickets
+  // outputs: the new topology
+  int32_t* old_of_new = nullptr;       // sync: [V] previous vertex or -1
+  int32_t* old_of_new_edge = nullptr;  // sync: [E] previous edge or -1
+  int32_t *src = nullptr, *dst = nullptr;  // sync: written; upload: given
+  int32_t* row_ptr = nullptr;
+  uint32_t* half = nullptr;
+  int32_t *order_m = nullptr, *rid_of = nullptr, *perm = nullptr, *iperm = nullptr, *pdeg = nullptr, *slice_row = nullptr;
+  int32_t *wg_info = nullptr, *wg_v0 = nullptr, *wg2_info = nullptr, *wg2_v0 = nullptr;
+  uint8_t *wg_vfirst = nullptr, *wg2_vfirst = nullptr;
+  TopoDims* dims = nullptr;
+};
+size_t topo_sort_temp_bytes(int V, int n_scan);
+int launch_topo_feat_build(const int32_t* feat, int V, uint32_t* stamp, int32_t* val, int tab_size, uint32_t gen, hipStream_t s);
+int launch_topo_sync_front(const TopoBuild& t, hipStream_t s);
+int launch_topo_upload_front(const TopoBuild& t, hipStream_t s);
+int launch_topo_back(const TopoBuild& t, hipStream_t s);
+
 int launch_save_prev(const CanonArgs& c, hipStream_t s);
 int launch_dual(const CanonArgs& c, const SolverParams& p, hipStream_t s);
 int launch_primal(const CanonArgs& c, const SolverParams& p, hipStream_t s);

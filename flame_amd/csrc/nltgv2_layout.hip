@@ -357,6 +357,7 @@ k_place_patch_of_record(const int n_patches, const int32_t* __restrict__ wg_info
                         int32_t* __restrict__ rec_off, const int stride, int* __restrict__ fill, const int n_fill) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < n_fill) fill[p] = 0;
+  if (p < 128) fill[n_fill + 16 + p] = 0;  // the cursors of k_place_assign (behind the page counters and the rotation word's line)
   if (p >= n_patches) return;
   const int r0 = wg_info[4 * p], n = wg_info[4 * p + 2] & 0xffff;
   for (int i = 0; i < n; ++i) patch_of_rec[r0 + i] = p, rec_off[r0 + i] = -1, rec_off[stride + r0 + i] = -1;
@@ -384,42 +385,45 @@ k_place_classify(const int V, const int per_xcd, const int32_t* __restrict__ ord
   cls[r] = (int8_t)c;
 }
 
-// Step 3, one thread per patch (<= 64 vertices, ~10): per parity and class a run of slots on the first page of the class's
-// ranking that has room (pages hold 256 records; the counters may overshoot, a page that refused a run simply stays a
-// little emptier).
+// Step 3, one WAVE per patch, lane i = its i-th record (<= 64, ~10): per parity and class a run of slots on the first page of the
+// class's ranking that has room (pages hold 256 records; the counters may overshoot, a page that refused a run simply stays a little
+// emptier).  (Round 4: one THREAD per patch kept the classes in a register array indexed at run time -- 118 us per topology at
+// 640x480, in front of the frame's first run; the lanes hold them now and a ballot finds the members of a class.)
 __global__ void __launch_bounds__(64)
 k_place_assign(const int n_patches, const int32_t* __restrict__ wg_info, const int8_t* __restrict__ cls_of_rec,
                const uint16_t* __restrict__ ranking, const int n_pages, int* __restrict__ fill, int32_t* __restrict__ rec_off,
                const int stride) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = blockIdx.x, lane = threadIdx.x;
   if (p >= n_patches) return;
-  const int r0 = wg_info[4 * p], n = wg_info[4 * p + 2] & 0xffff;
-  signed char cls[64];
-  bool any = false;
-  for (int i = 0; i < n && i < 64; ++i) cls[i] = cls_of_rec[r0 + i], any |= cls[i] >= 0;
-  if (!any) return;
-  for (int par = 0; par < 2; ++par) {
-    unsigned long long done = 0ull;
-    for (int i = 0; i < n && i < 64; ++i) {
-      const int c = cls[i];
-      if (c < 0 || ((done >> i) & 1ull)) continue;
-      int m = 0;
-      for (int k = i; k < n && k < 64; ++k) m += cls[k] == c;
-      const uint16_t* const rk = ranking + ((size_t)par * 64 + c) * n_pages;
+  const int r0 = wg_info[4 * p], n = min(wg_info[4 * p + 2] & 0xffff, 64);
+  const int c_mine = lane < n ? (int)cls_of_rec[r0 + lane] : -1;
+  unsigned long long todo = __ballot(c_mine >= 0);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int c = __shfl(c_mine, leader, 64);
+    const unsigned long long members = __ballot(c_mine == c);
+    todo &= ~members;
+    const int m = __popcll(members);
+    // (a run starts on a 128-byte line of its own: the records of one patch are written by one instruction; lines shared
+    //  with another patch's records would be invalidated under the reader at that patch's pace as well)
+    const int m8 = (m + 7) & ~7;
+    for (int par = 0; par < 2; ++par) {
       int base = -1;
-      // (a run starts on a 128-byte line of its own: the records of one patch are written by one instruction; lines shared
-      //  with another patch's records would be invalidated under the reader at that patch's pace as well)
-      const int m8 = (m + 7) & ~7;
-      for (int t = 0; t < n_pages && base < 0; ++t) {
-        const int pg = rk[t];
-        const int s0 = atomicAdd(&fill[par * n_pages + pg], m8);
-        if (s0 + m8 <= 256) base = (par * n_pages + pg) * 4096 + s0 * 16;
+      if (lane == leader) {
+        // every patch of a class wants the same best page: the walk through the ranking starts at the first page that has not
+        // yet refused a run of this class (a cursor per parity and class)
+        const uint16_t* const rk = ranking + ((size_t)par * 64 + c) * n_pages;
+        int* const cursor = fill + 2 * n_pages + 16 + par * 64 + c;
+        for (int t = __hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); t < n_pages && base < 0; ++t) {
+          const int pg = rk[t];
+          const int s0 = atomicAdd(&fill[par * n_pages + pg], m8);
+          if (s0 + m8 <= 256) base = (par * n_pages + pg) * 4096 + s0 * 16;
+          else atomicMax(cursor, t + 1);
+        }
       }
-      for (int k = i; k < n && k < 64; ++k) {
-        if (cls[k] != c) continue;
-        done |= 1ull << k;
-        if (base >= 0) rec_off[(size_t)par * stride + r0 + k] = base, base += 16;
-      }
+      base = __shfl(base, leader, 64);
+      if (c_mine == c && base >= 0)
+        rec_off[(size_t)par * stride + r0 + lane] = base + 16 * __popcll(members & ((1ull << lane) - 1ull));
     }
   }
 }
@@ -451,7 +455,7 @@ int launch_place_records(const CanonArgs& c, const FusedArgs& a, int per_xcd, co
                      2 * n_pages);
   hipLaunchKernelGGL(k_place_classify, grid1d(c.V), dim3(256), 0, s, c.V, per_xcd, order_m, rid_of, c.row_ptr, c.half, c.src, c.dst,
                      patch_of_rec, cls);
-  hipLaunchKernelGGL(k_place_assign, grid1d(a.wg_count, 64), dim3(64), 0, s, a.wg_count, a.wg_info, cls, ranking, n_pages, fill, rec_off,
+  hipLaunchKernelGGL(k_place_assign, dim3((unsigned)a.wg_count), dim3(64), 0, s, a.wg_count, a.wg_info, cls, ranking, n_pages, fill, rec_off,
                      stride);
   return (int)hipGetLastError();
 }

@@ -103,6 +103,7 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
     groups->push_back(WaveGroup{0, total});
     return form;
   }
+  if (ensure_host_layout(ctx) != 0) return 0;  // (the component tables live in the host image of the layout)
   const std::vector<int32_t>& cw = form == 4 ? L.comp_wg2 : form == 3 ? L.comp_wg : L.comp_tv_wave;
   if (cw.size() < 3) return 0;  // one component that does not fit: stream it
   // Groups of about equal size (the per-step time of a group grows with its waves, and a small last group would run
@@ -257,7 +258,7 @@ int place_calibrate(flame_nltgv2_ctx* ctx) {
   int rc = ensure(ctx, ctx->place_pool, pool_bytes + 4096);
   if (!rc) rc = ensure(ctx, ctx->place_meas, sizeof(unsigned) * 64 * 2 * P + sizeof(int) * 64 + sizeof(int));
   if (!rc) rc = ensure(ctx, ctx->place_rank, sizeof(uint16_t) * 2 * 64 * P);
-  if (!rc) rc = ensure(ctx, ctx->place_fill, sizeof(int) * (2 * P + 16));  // (+ the rotation word of the launches)
+  if (!rc) rc = ensure(ctx, ctx->place_fill, sizeof(int) * (2 * P + 16 + 128));  // (+ the rotation word of the launches, + k_place_assign's cursors)
   if (rc) return rc;
   ctx->place_base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ctx->place_pool.p) + 4095) & ~uintptr_t(4095));
   unsigned* d_out = (unsigned*)ctx->place_meas.p;
@@ -265,7 +266,7 @@ int place_calibrate(flame_nltgv2_ctx* ctx) {
   int* d_fail = d_xcc + 64;
   HIPCHK(ctx, hipMemsetAsync(ctx->place_base, 0, pool_bytes, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->place_meas.p, 0, sizeof(unsigned) * 64 * 2 * P + sizeof(int) * 65, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(ctx->place_fill.p, 0, sizeof(int) * (2 * P + 16), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->place_fill.p, 0, sizeof(int) * (2 * P + 16 + 128), ctx->stream));
   LAUNCHCHK(ctx, launch_place_calibrate(ctx->place_base, 2 * P, kIters, d_out, d_xcc, d_fail, ctx->stream));
   std::vector<unsigned> out((size_t)64 * 2 * P);
   int xcc[65];

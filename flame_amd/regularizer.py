@@ -27,7 +27,7 @@ _FP = C.POINTER(C.c_float)
 _IP = C.POINTER(C.c_int32)
 
 # stable options (include/flame_nltgv2.h) ...
-OPT_SOLVER, OPT_USE_HIPGRAPH, OPT_PERSISTENT, OPT_PROBE, OPT_VERIFY_RECORDS, OPT_PLACEMENT = 1, 2, 5, 12, 14, 16
+OPT_SOLVER, OPT_USE_HIPGRAPH, OPT_PERSISTENT, OPT_PROBE, OPT_VERIFY_RECORDS, OPT_PLACEMENT, OPT_SYNC_PATH = 1, 2, 5, 12, 14, 16, 17
 # ... and the experimental range (tuning knobs / test hooks of the current kernels; tools/ and the tests use them)
 OPT_BLOCK_WAVES, OPT_UNROLL, OPT_DUAL_PUBLISH, OPT_TV_LDS, OPT_PRESLEEP, OPT_XCDS, OPT_FAULT_INJECT, OPT_POLL_GAP = 103, 104, 106, 107, 108, 109, 110, 113
 RUN_PATHS = {0: "none", 1: "persistent (the lane-per-half-edge form, retired in round 3)", 2: "per-step hipGraph", 3: "per-step eager", 4: "canonical 4-sweep",
@@ -81,7 +81,7 @@ class _Info(C.Structure):
         ("device_bytes", C.c_int64), ("algorithmic_bytes_per_iter", C.c_int64), ("compute_units", C.c_int32),
         ("device_name", C.c_char * 64), ("gcn_arch", C.c_char * 32), ("last_run_path", C.c_int32), ("he_waves", C.c_int32), ("tv_waves", C.c_int32),
         ("tv_wave_capacity", C.c_int32), ("last_run_groups", C.c_int32), ("timeouts_recovered", C.c_int32),
-        ("patches", C.c_int32), ("torn_records_detected", C.c_int32),
+        ("patches", C.c_int32), ("torn_records_detected", C.c_int32), ("last_sync_path", C.c_int32),
     ]
 
 
@@ -102,7 +102,7 @@ ABI_SYMBOLS = (
     "flame_nltgv2_status_string", "flame_nltgv2_abi_version", "flame_nltgv2_pack_probe", "flame_nltgv2_read_probe", "flame_nltgv2_layout_selftest", "flame_nltgv2_placement_info",
     "flame_nltgv2_photo_set_images", "flame_nltgv2_photo_residual", "flame_nltgv2_photo_fuse",
     "flame_nltgv2_photo_residual_last", "flame_nltgv2_sync_graph",
-    "flame_nltgv2_get_topology", "flame_nltgv2_set_feature_ids", "flame_nltgv2_interpolate_mesh",
+    "flame_nltgv2_get_topology", "flame_nltgv2_graph_size", "flame_nltgv2_set_feature_ids", "flame_nltgv2_interpolate_mesh",
     "flame_nltgv2_interpolate_mesh_arrays", "flame_nltgv2_project_graph", "flame_nltgv2_rescale_data",
     "flame_delaunay_triangulate",
 )
@@ -158,6 +158,7 @@ def load_library():
         "flame_nltgv2_photo_residual_last": (C.c_int, [ctx, _FP]),
         "flame_nltgv2_sync_graph": (C.c_int, [ctx, C.POINTER(_SyncInput)]),
         "flame_nltgv2_get_topology": (C.c_int, [ctx, _IP, _IP, _IP]),
+        "flame_nltgv2_graph_size": (C.c_int, [ctx, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "flame_nltgv2_set_feature_ids": (C.c_int, [ctx, _IP]),
         "flame_delaunay_triangulate": (C.c_int, [_FP, C.c_int32, _IP, C.c_int32, _IP, _IP, C.c_int32, _IP]),
         "flame_nltgv2_project_graph": (C.c_int, [ctx, C.POINTER(_Projection), C.c_float, C.POINTER(C.c_uint8), _FP]),
@@ -307,8 +308,9 @@ class Regularizer:
         si.init_graph_scale = float(init_graph_scale)
         si.edges_unique = 1 if edges_unique else 0  # (the caller vouches: e.g. the edges of flame_amd.delaunay)
         self._chk(self._L.flame_nltgv2_sync_graph(self._ctx, C.byref(si)), "sync_graph")
-        info = self.info()
-        self.V, self.E = info["V"], info["E"]
+        nv, ne = C.c_int32(0), C.c_int32(0)
+        self._chk(self._L.flame_nltgv2_graph_size(self._ctx, C.byref(nv), C.byref(ne)), "graph_size")
+        self.V, self.E = int(nv.value), int(ne.value)
 
     def placement_info(self) -> dict:
         """Record placement of the patch-per-wave form (FLAME_NLTGV2_OPT_PLACEMENT): state (1 in use, 0 not yet, -1

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FLAME_NLTGV2_ABI_VERSION 3
+#define FLAME_NLTGV2_ABI_VERSION 4
 
 typedef struct flame_nltgv2_ctx flame_nltgv2_ctx;
 
@@ -134,6 +134,8 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
 int flame_nltgv2_set_feature_ids(flame_nltgv2_ctx* ctx, const int32_t* feat_id);
 /* Current edge list / feature ids (E, E, V ints; any pointer may be NULL). */
 int flame_nltgv2_get_topology(flame_nltgv2_ctx* ctx, int32_t* src, int32_t* dst, int32_t* feat_id);
+/* Vertex and edge count of the current graph (after a sync: V as passed, E = surviving + new edges). */
+int flame_nltgv2_graph_size(flame_nltgv2_ctx* ctx, int32_t* V, int32_t* E);
 
 /* Flame::projectGraph (flame.cc:1888-1905) on the device state: every vertex is re-projected into the new
  * frame with EpipolarGeometry::project(pos, x*graph_scale, &u_new, &idepth_new)
@@ -278,6 +280,11 @@ enum {
                                         the first such run), 0 = every record at its linear place.  Addresses only: results
                                         are bit-identical either way */
 
+  FLAME_NLTGV2_OPT_SYNC_PATH = 17,   /* flame_nltgv2_sync_graph: 0 (default) = index maps and the new graph's layout tables are built on the
+                                        device wherever that applies (a duplicate-free edge list -- edges_unique --, feature ids below 4 M, no
+                                        vertex of more than 64 edges), on the host otherwise; 1 = always on the host; 2 = on the device or
+                                        FLAME_NLTGV2_ERR_INVALID_ARG.  Same result either way */
+
   FLAME_NLTGV2_OPT_EXPERIMENTAL = 100, /* ---- not part of the stable surface from here on ---- */
   FLAME_NLTGV2_OPT_BLOCK_WAVES = 103,  /* waves per workgroup of the fused sweep: 0 = auto, 1,2,4 */
   FLAME_NLTGV2_OPT_UNROLL = 104,       /* half-edge slots per load chunk of the fused sweep: 0 = auto, 4,8,16 */
@@ -322,6 +329,7 @@ typedef struct flame_nltgv2_info {
   int32_t patches;       /* waves (patches of ~10 vertices) of the patch-per-wave persistent form (0: not applicable) */
   int32_t torn_records_detected; /* persistent runs stopped by FLAME_NLTGV2_OPT_VERIFY_RECORDS (a record whose second
                                     read differed from the first): rolled back and redone the same way */
+  int32_t last_sync_path; /* flame_nltgv2_sync_graph: 0 none yet, 1 index maps + layout tables on the host, 2 on the device */
 } flame_nltgv2_info;
 int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info);
 

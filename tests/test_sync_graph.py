@@ -30,7 +30,19 @@ def next_frame(rng, feat_id, pos, data, next_id, width, height):
     return feat_id.astype(np.int32), np.ascontiguousarray(pos), np.ascontiguousarray(data), next_id + n_new
 
 
-def test_frame_sequence_matches_syncgraph_restatement(built):
+SYNC_MODES = ["host", "device"]  # index maps + layout tables on the host (rounds 1-3) / by kernels over the resident topology (round 4)
+
+
+def _mode(reg, mode):
+    """-> keyword arguments of sync_graph for the mode; the device path is asked for BY NAME, so a silent fall-back fails the test."""
+    import flame_amd
+
+    reg.set_option(flame_amd.regularizer.OPT_SYNC_PATH, 2 if mode == "device" else 1)
+    return {"edges_unique": mode == "device"}
+
+
+@pytest.mark.parametrize("mode", SYNC_MODES)
+def test_frame_sequence_matches_syncgraph_restatement(built, mode):
     import torch  # noqa: F401
 
     import flame_amd
@@ -46,6 +58,7 @@ def test_frame_sequence_matches_syncgraph_restatement(built):
     with flame_amd.Regularizer(0) as reg:
         reg.upload_graph(g0)
         reg.set_feature_ids(feat_id)
+        kw = _mode(reg, mode)
         for frame in range(5):
             # solve a little on both sides
             flat = sync_oracle.flatten(ref, feat_id)
@@ -72,7 +85,9 @@ def test_frame_sequence_matches_syncgraph_restatement(built):
                 weight[rng.random(len(feat_id)) < 0.1] = 0.0  # ... over the neighbours with a data weight
                 gs = 1.7
             reg.sync_graph(feat_id, pos, data, weight, edges, init_x=init_x, check_sticky_obstacles=sticky,
-                           sticky_threshold=0.02, init_graph_scale=gs)
+                           sticky_threshold=0.02, init_graph_scale=gs, **kw)
+            assert reg.info()["last_sync_path"] == (2 if mode == "device" else 1)
+            assert reg.layout_selftest() == 0, f"frame {frame}: device tables differ from the host builders'"
             sync_oracle.sync(ref, feat_id, pos, data, weight, edges, init_x=init_x, check_sticky=sticky, thr=0.02,
                              init_graph_scale=gs)
         flat = sync_oracle.flatten(ref, feat_id)
@@ -96,8 +111,9 @@ def test_sync_rejects_bad_input(built):
                            np.array([[0, g["V"]]], np.int32))
 
 
+@pytest.mark.parametrize("mode", SYNC_MODES)
 @pytest.mark.parametrize("config", ["320x240", "640x480", "1280x720", "1920x1080"])
-def test_device_expanded_layout_matches_host_builders(built, config):
+def test_device_expanded_layout_matches_host_builders(built, config, mode):
     """Per-slot (B) and per-lane (E) layout arrays are expanded on the device (nltgv2_layout.hip): word for word what the
     host builders of nltgv2_pack.hpp make of the same topology -- after an upload and after a frame sync."""
     import torch  # noqa: F401
@@ -111,7 +127,8 @@ def test_device_expanded_layout_matches_host_builders(built, config):
         rng = np.random.default_rng(5)
         w, h = (int(s) for s in config.split("x"))
         fid, pos, data, _ = next_frame(rng, np.arange(g["V"], dtype=np.int32), g["pos"].copy(), g["data_term"].copy(), g["V"], w, h)
-        reg.sync_graph(fid, pos, data, np.ones(len(fid), np.float32), synth.delaunay_edges_scipy(pos))
+        reg.sync_graph(fid, pos, data, np.ones(len(fid), np.float32), synth.delaunay_edges_scipy(pos), **_mode(reg, mode))
+        assert reg.info()["last_sync_path"] == (2 if mode == "device" else 1)
         assert reg.layout_selftest() == 0
         reg.run(flame_amd.Params(), 16)
         assert reg.layout_selftest() == 0
@@ -120,7 +137,8 @@ def test_device_expanded_layout_matches_host_builders(built, config):
         assert reg.info()["last_run_path"] == 5 and reg.layout_selftest() == 0
 
 
-def test_sync_behind_an_unchecked_chain_and_with_growing_graphs(built):
+@pytest.mark.parametrize("mode", SYNC_MODES)
+def test_sync_behind_an_unchecked_chain_and_with_growing_graphs(built, mode):
     """sync_graph settles a chain of asynchronous runs first; consecutive syncs without a run in between; the graph grows
     past every buffer's capacity and shrinks again; a rejected sync leaves the previous graph intact."""
     import torch  # noqa: F401
@@ -143,6 +161,7 @@ def test_sync_behind_an_unchecked_chain_and_with_growing_graphs(built):
         reg.upload_graph(g0)
         reg.set_feature_ids(feat_id)
         pos, data, next_id = g0["pos"].copy(), g0["data_term"].copy(), g0["V"]
+        kw = _mode(reg, mode)
         both_run(reg, 12, asynchronous=True)
         both_run(reg, 9, asynchronous=True)   # a chain: the second run sits behind an unchecked persistent run
         for frame, (w, h) in enumerate([(320, 240), (640, 480), (640, 480), (320, 240)]):
@@ -154,18 +173,18 @@ def test_sync_behind_an_unchecked_chain_and_with_growing_graphs(built):
                 feat_id, pos, data, next_id = next_frame(rng, feat_id, pos, data, next_id, w, h)
             weight = np.ones(len(feat_id), np.float32)
             edges = synth.delaunay_edges_scipy(pos)
-            reg.sync_graph(feat_id, pos, data, weight, edges)
+            reg.sync_graph(feat_id, pos, data, weight, edges, **kw)
             sync_oracle.sync(ref, feat_id, pos, data, weight, edges)
             if frame == 2:   # twice in a row, nothing run in between (the state is in the canonical arrays)
                 feat_id, pos, data, next_id = next_frame(rng, feat_id, pos, data, next_id, w, h)
                 weight = np.ones(len(feat_id), np.float32)
                 edges = synth.delaunay_edges_scipy(pos)
-                reg.sync_graph(feat_id, pos, data, weight, edges)
+                reg.sync_graph(feat_id, pos, data, weight, edges, **kw)
                 sync_oracle.sync(ref, feat_id, pos, data, weight, edges)
             bad = feat_id.copy()
             bad[1] = bad[0]
             with pytest.raises(flame_amd.NLTGV2Error):
-                reg.sync_graph(bad, pos, data, weight, edges)  # refused: the graph of this frame stays
+                reg.sync_graph(bad, pos, data, weight, edges, **kw)  # refused: the graph of this frame stays
             both_run(reg, 20)
             assert_state_equal(reg.download_state(), sync_oracle.flatten(ref, feat_id),
                                keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"frame {frame}")
@@ -202,8 +221,9 @@ def test_sync_to_empty_edgeless_and_single_vertex_frames(built):
         assert r.download_state()["x"].shape == (1,)
 
 
+@pytest.mark.parametrize("mode", SYNC_MODES)
 @pytest.mark.parametrize("seed", [1, 2])
-def test_randomized_frame_sequences(built, seed):
+def test_randomized_frame_sequences(built, seed, mode):
     """Thirty frames of random churn (0-60 % of the vertices replaced), random triangulator orientation, zero data weights,
     missing predictions (neighbour-mean init), sticky obstacles, random run lengths, synchronous and chained asynchronous
     runs: every state array and the edge list equal the syncGraph restatement's after every frame."""
@@ -221,6 +241,7 @@ def test_randomized_frame_sequences(built, seed):
     with flame_amd.Regularizer(0) as reg:
         reg.upload_graph(g0)
         reg.set_feature_ids(feat_id)
+        kw = _mode(reg, mode)
         for frame in range(30):
             flat = sync_oracle.flatten(ref, feat_id)
             n_total = 0
@@ -253,7 +274,7 @@ def test_randomized_frame_sequences(built, seed):
                 gs = float(0.5 + rng.random() * 2)
             sticky = bool(rng.random() < 0.5)
             reg.sync_graph(feat_id, pos, data, weight, edges, init_x=init_x, check_sticky_obstacles=sticky, sticky_threshold=0.03,
-                           init_graph_scale=gs)
+                           init_graph_scale=gs, **kw)
             sync_oracle.sync(ref, feat_id, pos, data, weight, edges, init_x=init_x, check_sticky=sticky, thr=0.03, init_graph_scale=gs)
             flat = sync_oracle.flatten(ref, feat_id)
             src, dst, fid = reg.topology()
