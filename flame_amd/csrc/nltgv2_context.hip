@@ -102,6 +102,10 @@ int ensure_canon(flame_nltgv2_ctx* ctx) {
     if (rc) return rc;
   }
   if (ctx->canon_valid) return 0;
+  if (ctx->raster_inflight) {  // (interpolate_mesh_begin's side stream may still read the canonical arrays this is about to rewrite)
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_raster_done, 0));
+    ctx->raster_inflight = false;
+  }
   LAUNCHCHK(ctx, launch_unpack_state(ctx->c, ctx->f, ctx->parity, ctx->have_prev, ctx->stream));
   ctx->canon_valid = true;
   return 0;
@@ -129,21 +133,24 @@ int ensure_fused(flame_nltgv2_ctx* ctx) {
 // distributes the pieces to their buffers and does the clears of `fills` (k_scatter).  The caller's arrays are free when
 // this returns (they were copied into the staging buffer); the staging buffer itself is reused by the next upload, which
 // synchronises the stream first.
-int staged_h2d(flame_nltgv2_ctx* ctx, const StageCopy* cp, size_t n, const StageFill* fills, size_t n_fills) {
+int staged_h2d(flame_nltgv2_ctx* ctx, const StageCopy* cp, size_t n, const StageFill* fills, size_t n_fills, int slot, hipStream_t stream,
+               size_t* host_off) {
+  if (!stream) stream = ctx->stream;
+  flame_nltgv2_ctx::StageSlot& st = ctx->stage[slot];
   size_t total = 0;
   for (size_t i = 0; i < n; ++i) total += (cp[i].bytes + 255) & ~size_t(255);
   if (total >= (size_t)0xffffff00u) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-  if (total > ctx->stage_cap) {
-    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-    ctx->h_stage = nullptr, ctx->stage_cap = 0;
+  if (total > st.cap) {
+    if (st.h) (void)hipHostFree(st.h);
+    st.h = nullptr, st.cap = 0;
     const size_t want = total + total / 2;
-    if (hipHostMalloc(&ctx->h_stage, want, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(&st.h, want, hipHostMallocDefault) != hipSuccess) {
       (void)hipGetLastError();
       return fail(ctx, FLAME_NLTGV2_ERR_OOM);
     }
-    ctx->stage_cap = want;
+    st.cap = want;
   }
-  int rc = ensure(ctx, ctx->d_stage, ctx->stage_cap);
+  int rc = ensure(ctx, st.d, st.cap);
   if (rc) return rc;
   std::vector<ScatterTable> tables(1);
   auto push = [&](const ScatterEntry& e) {
@@ -153,15 +160,16 @@ int staged_h2d(flame_nltgv2_ctx* ctx, const StageCopy* cp, size_t n, const Stage
   };
   size_t off = 0;
   for (size_t i = 0; i < n; ++i) {
+    if (host_off) host_off[i] = off;
     if (cp[i].bytes == 0) continue;
-    std::memcpy(static_cast<char*>(ctx->h_stage) + off, cp[i].src, cp[i].bytes);
+    std::memcpy(static_cast<char*>(st.h) + off, cp[i].src, cp[i].bytes);
     push(ScatterEntry{cp[i].b->p, (uint32_t)off, 0u, cp[i].bytes});
     off += (cp[i].bytes + 255) & ~size_t(255);
   }
   for (size_t i = 0; i < n_fills; ++i)
     if (fills[i].bytes) push(ScatterEntry{fills[i].dst, kScatterFill, fills[i].word, fills[i].bytes});
-  if (off) HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage.p, ctx->h_stage, off, hipMemcpyHostToDevice, ctx->stream));
-  for (const ScatterTable& t : tables) LAUNCHCHK(ctx, launch_scatter(t, ctx->d_stage.p, ctx->stream));
+  if (off) HIPCHK(ctx, hipMemcpyAsync(st.d.p, st.h, off, hipMemcpyHostToDevice, stream));
+  for (const ScatterTable& t : tables) LAUNCHCHK(ctx, launch_scatter(t, st.d.p, stream));
   return 0;
 }
 
@@ -290,7 +298,9 @@ bool wants_e2(const flame_nltgv2_ctx* ctx) {
 int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const StageCopy* extra, size_t n_extra, bool long_lived) {
   const int32_t V = g->V, E = g->E;
   (void)long_lived;
-  int rc = build_layout(g, &ctx->L, /*host_expand=*/false, /*rowpack=*/true,
+  int rc = cancel_prepared(ctx);  // (a builder on the side stream reads the topology this is about to replace)
+  if (rc) return rc;
+  rc = build_layout(g, &ctx->L, /*host_expand=*/false, /*rowpack=*/true,
                         /*rowpack_max_patches=*/ctx->opt_persistent == 4 ? 0x7fffffff : kPvDensePerCu * ctx->prop.multiProcessorCount);
   if (rc) return fail(ctx, rc);
   // Row packing costs ~15 % more waves than lanes back to back.  It pays where the patch-per-wave kernel runs them; a layout
@@ -337,6 +347,7 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
   ctx->h_dst.assign(g->dst, g->dst + E);
   ctx->host_layout_valid = true;
   ctx->feat_dev_valid = false;  // (the device's feature table describes the previous graph)
+  HIPCHK(ctx, hipEventRecord(ctx->ev_topo_ready, ctx->stream));
   return 0;
 }
 
@@ -432,6 +443,11 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
   ok = ok && hipGetDeviceProperties(&ctx->prop, device) == hipSuccess;
   ok = ok && hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&ctx->topo_stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&ctx->raster_stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&ctx->ev_canon, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&ctx->ev_raster_done, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&ctx->ev_topo_ready, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->h_err, kErrBytes, hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->h_cost, 2 * sizeof(float), hipHostMallocDefault) == hipSuccess;
   if (!ok) {
@@ -448,10 +464,10 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
               &ctx->cost_out, &ctx->img_ref, &ctx->img_cmp, &ctx->photo_err, &ctx->r_tris, &ctx->r_valid, &ctx->r_keys,
               &ctx->r_img, &ctx->r_cov, &ctx->r_vtx, &ctx->r_val, &ctx->wg_slot, &ctx->wg_vid, &ctx->wg_meta, &ctx->wg_nbr,
               &ctx->wg_fetch, &ctx->wg_info, &ctx->wg_v0, &ctx->probe, &ctx->snap_hq, &ctx->snap_vstate, &ctx->snap_bar, &ctx->iperm,
-              &ctx->order_m, &ctx->rid_of, &ctx->d_stage, &ctx->sync_init, &ctx->sync_vmap, &ctx->sync_emap, &ctx->sync_need,
+              &ctx->order_m, &ctx->rid_of, &ctx->stage[0].d, &ctx->stage[1].d, &ctx->sync_init, &ctx->sync_vmap, &ctx->sync_emap, &ctx->sync_need,
               &ctx->wg_vfirst, &ctx->place_pool, &ctx->place_rank, &ctx->place_fill, &ctx->place_rec_off, &ctx->place_patch, &ctx->place_meas, &ctx->progress};
-  for (DevBuf* b : {&ctx->feat_stamp_d, &ctx->feat_val_d, &ctx->topo_scratch, &ctx->nx_pos, &ctx->nx_src, &ctx->nx_dst, &ctx->nx_row_ptr, &ctx->nx_half, &ctx->topo_dims})
-    ctx->all.push_back(b);
+  for (DevBuf* b : {&ctx->feat_stamp_d, &ctx->feat_val_d, &ctx->topo_scratch, &ctx->topo_dims}) ctx->all.push_back(b);
+  for (auto& b : ctx->nx) ctx->all.push_back(&b);
   for (auto& b : ctx->sp_v) ctx->all.push_back(&b);
   for (auto& b : ctx->sp_q) ctx->all.push_back(&b);
   *out = ctx;
@@ -467,7 +483,14 @@ int flame_nltgv2_destroy(flame_nltgv2_ctx* ctx) {
     if (b->p) (void)hipFree(b->p);
   if (ctx->h_err) (void)hipHostFree(ctx->h_err);
   if (ctx->h_cost) (void)hipHostFree(ctx->h_cost);
-  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  for (auto& st : ctx->stage)
+    if (st.h) (void)hipHostFree(st.h);
+  if (ctx->topo_stream) (void)hipStreamSynchronize(ctx->topo_stream), (void)hipStreamDestroy(ctx->topo_stream);
+  if (ctx->ev_topo_ready) (void)hipEventDestroy(ctx->ev_topo_ready);
+  if (ctx->raster_stream) (void)hipStreamSynchronize(ctx->raster_stream), (void)hipStreamDestroy(ctx->raster_stream);
+  if (ctx->ev_canon) (void)hipEventDestroy(ctx->ev_canon);
+  if (ctx->ev_raster_done) (void)hipEventDestroy(ctx->ev_raster_done);
+  if (ctx->h_img) (void)hipHostFree(ctx->h_img);
   if (ctx->h_dims) (void)hipHostFree(ctx->h_dims);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

@@ -233,9 +233,13 @@ struct flame_nltgv2_ctx {
   int pv2_occ = 0, pv2_occ_verify = 0;  // patches of k_persistent_pv2 really co-resident per CU (plain / record-verifying instance)
   uint64_t wg2_checked_topo = ~0ull;  // the device expansion's verdict (no patch with more than 64 foreign records) was read for this topology
   bool wg2_usable = false;
-  void* h_stage = nullptr;         // pinned staging buffer of the uploads
-  DevBuf d_stage;                 // ... and its device-side landing area (one copy; k_scatter distributes)
-  size_t stage_cap = 0;
+  // pinned staging buffers of the uploads and their device-side landing areas (one copy; k_scatter distributes): [0] the context's
+  // stream, [1] the side stream on which a frame sync is prepared while the solver runs (nltgv2_topo_capi.hip)
+  struct StageSlot {
+    void* h = nullptr;
+    size_t cap = 0;
+    DevBuf d;
+  } stage[2];
 
   PackedLayout L;
   std::vector<int32_t> h_src, h_dst, h_feat;  // host image of the current topology (for sync_graph)
@@ -247,7 +251,37 @@ struct flame_nltgv2_ctx {
   int opt_sync_path = 0;          // 0 auto (device where it applies), 1 host index maps + host tables, 2 device or error
   int last_sync_path = 0;         // 1 host, 2 device
   // the device's feature table: id -> vertex of the current graph where feat_stamp_d[id] == feat_gen (nltgv2_topo.hip)
-  DevBuf feat_stamp_d, feat_val_d, topo_scratch, nx_pos, nx_src, nx_dst, nx_row_ptr, nx_half, topo_dims;
+  DevBuf feat_stamp_d, feat_val_d, topo_scratch, topo_dims;
+  // A frame sync is PREPARED beside the running solver (flame_nltgv2_sync_prepare): the builder reads the live topology and writes
+  // the next one into these; flame_nltgv2_sync_commit swaps them with their live counterparts (nx_live) once the solver has stopped.
+  enum { NX_POS, NX_SRC, NX_DST, NX_ROW_PTR, NX_HALF, NX_ORDER_M, NX_RID_OF, NX_PERM, NX_IPERM, NX_PDEG, NX_SLICE_ROW, NX_WG_INFO, NX_WG_V0,
+         NX_WG_VFIRST, NX_WG2_INFO, NX_WG2_VFIRST, NX_DATA, NX_WEIGHT, NX_COUNT };
+  DevBuf nx[NX_COUNT];
+  DevBuf* nx_live(int i) {
+    DevBuf* const live[NX_COUNT] = {&pos, &src, &dst, &row_ptr, &half, &order_m, &rid_of, &perm, &iperm, &pdeg, &slice_row, &wg_info, &wg_v0,
+                                    &wg_vfirst, &wg2_info, &wg2_vfirst, &data, &weight};
+    return live[i];
+  }
+  std::vector<char> prep_host;      // inputs of a prepared sync that will go the host way at commit
+  const void *prep_vmap = nullptr, *prep_emap = nullptr, *prep_init = nullptr;  // (in topo_scratch) index maps / init values of the prepared sync
+  hipStream_t raster_stream = nullptr;  // the side stream of interpolate_mesh_begin / _end
+  hipEvent_t ev_canon = nullptr, ev_raster_done = nullptr;
+  bool raster_inflight = false;       // the side stream still reads the canonical pos / x: the next unpack waits for ev_raster_done
+  float* h_img = nullptr;             // pinned: the map of the last interpolate_mesh_begin (+ the coverage count behind it)
+  size_t h_img_cap = 0;
+  int map_rows = 0, map_cols = 0;     // the dense map resident in r_img (0: none)
+  hipStream_t topo_stream = nullptr;  // the side stream of a prepared sync
+  hipEvent_t ev_topo_ready = nullptr; // recorded on the context's stream when a topology stands (upload, commit): the next builder waits for it
+  struct PreparedSync {
+    bool active = false, device = false;
+    uint64_t topo = 0;               // the topology it was prepared against
+    int32_t V = 0, E = 0;
+    bool has_init = false;
+    int32_t check_sticky = 0, edges_unique = 0, init_from_map = 0;
+    float sticky_threshold = 0.0f, init_graph_scale = 0.0f;
+    size_t off[6] = {};              // the inputs in stage[1].h: feat_id, edges, pos, data_term, data_weight, init_x
+    std::chrono::steady_clock::time_point t_begin, t_enqueued;
+  } prepared;
   int feat_tab_size_d = 0;
   uint32_t feat_gen = 0;
   bool feat_dev_valid = false;
@@ -322,7 +356,9 @@ struct StageFill {
   size_t bytes;
   uint32_t word;
 };
-int staged_h2d(flame_nltgv2_ctx* ctx, const StageCopy* cp, size_t n, const StageFill* fills = nullptr, size_t n_fills = 0);
+// slot 0 on the context's stream by default; host_off (optional): where each piece lies in the slot's pinned buffer
+int staged_h2d(flame_nltgv2_ctx* ctx, const StageCopy* cp, size_t n, const StageFill* fills = nullptr, size_t n_fills = 0, int slot = 0,
+               hipStream_t stream = nullptr, size_t* host_off = nullptr);
 int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const StageCopy* extra, size_t n_extra, bool long_lived);
 int topology_buffers(flame_nltgv2_ctx* ctx, bool want_e2, size_t n_wg_info, size_t n_wg_v0, size_t n_wg_vfirst, size_t n_wg2_info,
                      size_t n_wg2_vfirst);
@@ -331,7 +367,11 @@ int topology_expand(flame_nltgv2_ctx* ctx, bool want_e2);
 bool wants_e2(const flame_nltgv2_ctx* ctx);
 int ensure_host_layout(flame_nltgv2_ctx* ctx);  // the host image of the topology (ctx->L's vectors, h_src, h_dst) after a device build
 // ---- nltgv2_topo_capi.hip: the per-frame sync with the topology built on the device
-int sync_graph_device(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, bool* done);
+int topo_prepare(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, bool* applicable);  // builder enqueued on the side stream
+int topo_commit(flame_nltgv2_ctx* ctx, bool* done);                                             // solver stopped, sets swapped, state gathered
+int cancel_prepared(flame_nltgv2_ctx* ctx);  // before anything else changes the topology: waits for an in-flight builder, forgets it
+int sync_graph_host(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in);
+void set_init_map(flame_nltgv2_ctx* ctx, bool on, SyncArgs* sa);  // nltgv2_graph_capi.hip: index maps + tables on the host
 int ensure_form_rows(flame_nltgv2_ctx* ctx, int form);
 
 // ---- nltgv2_run.hip ----------------------------------------------------------------------------------------------------

@@ -40,6 +40,67 @@ static int interpolate_common(flame_nltgv2_ctx* ctx, const int32_t* triangles, i
   return FLAME_NLTGV2_OK;
 }
 
+// interpolate_mesh on the side stream (see flame_nltgv2.h): the canonical pos / x are read there while the solver already runs again
+// on its packed state; the next unpack waits for ev_raster_done (ensure_canon), so do the kernels of a prepared sync that reuse them.
+int flame_nltgv2_interpolate_mesh_begin(flame_nltgv2_ctx* ctx, const int32_t* triangles, int32_t T, const uint8_t* tri_valid,
+                                        int rows, int cols, float graph_scale) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_interpolate_mesh_begin");
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  const int32_t V = ctx->L.V;
+  if (T < 0 || rows <= 0 || cols <= 0 || (T > 0 && !triangles)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  for (int32_t t = 0; t < 3 * T; ++t)
+    if (triangles[t] < 0 || triangles[t] >= V) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  const size_t n = (size_t)rows * (size_t)cols;
+  hipStream_t rs = ctx->raster_stream;
+  HIPCHK(ctx, hipStreamSynchronize(rs));  // (a begin without its end: the pinned map and the device buffers are about to be reused)
+  if (ctx->h_img_cap < n + 16) {
+    if (ctx->h_img) (void)hipHostFree(ctx->h_img);
+    ctx->h_img = nullptr, ctx->h_img_cap = 0;
+    if (hipHostMalloc((void**)&ctx->h_img, sizeof(float) * (n + 16), hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(ctx, FLAME_NLTGV2_ERR_OOM);
+    }
+    ctx->h_img_cap = n + 16;
+  }
+  rc = ensure_canon(ctx);  // the solver stops here ...
+  if (!rc) rc = ensure(ctx, ctx->r_tris, sizeof(int32_t) * 3 * (size_t)T);
+  if (!rc) rc = ensure(ctx, ctx->r_valid, (size_t)T + (size_t)V + 16);
+  if (!rc) rc = ensure(ctx, ctx->r_keys, sizeof(unsigned long long) * n);
+  if (!rc) rc = ensure(ctx, ctx->r_img, sizeof(float) * n);
+  if (!rc) rc = ensure(ctx, ctx->r_cov, sizeof(int));
+  if (rc) return rc;
+  HIPCHK(ctx, hipEventRecord(ctx->ev_canon, ctx->stream));
+  HIPCHK(ctx, hipStreamWaitEvent(rs, ctx->ev_canon, 0));  // ... and may go on as soon as the caller enqueues the next run
+  if (T > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->r_tris.p, triangles, sizeof(int32_t) * 3 * (size_t)T, hipMemcpyHostToDevice, rs));
+  uint8_t* d_tv = nullptr;
+  if (tri_valid && T > 0) {
+    d_tv = (uint8_t*)ctx->r_valid.p;
+    HIPCHK(ctx, hipMemcpyAsync(d_tv, tri_valid, (size_t)T, hipMemcpyHostToDevice, rs));
+  }
+  LAUNCHCHK(ctx, launch_interpolate_mesh(T, (const int32_t*)ctx->r_tris.p, ctx->c.pos, ctx->c.x, graph_scale, nullptr, d_tv,
+                                         (unsigned long long*)ctx->r_keys.p, (float*)ctx->r_img.p, (int*)ctx->r_cov.p, rows, cols, rs));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_img, ctx->r_img.p, sizeof(float) * n, hipMemcpyDeviceToHost, rs));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_img + n, ctx->r_cov.p, sizeof(int), hipMemcpyDeviceToHost, rs));
+  HIPCHK(ctx, hipEventRecord(ctx->ev_raster_done, rs));
+  ctx->raster_inflight = true;
+  ctx->map_rows = rows, ctx->map_cols = cols;
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_interpolate_mesh_end(flame_nltgv2_ctx* ctx, const float** map_out, int32_t* coverage_out) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_interpolate_mesh_end");
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!ctx->h_img || ctx->map_rows == 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->raster_stream));
+  const size_t n = (size_t)ctx->map_rows * (size_t)ctx->map_cols;
+  if (map_out) *map_out = ctx->h_img;
+  if (coverage_out) std::memcpy(coverage_out, ctx->h_img + n, sizeof(int32_t));
+  return FLAME_NLTGV2_OK;
+}
+
 int flame_nltgv2_interpolate_mesh(flame_nltgv2_ctx* ctx, const int32_t* triangles, int32_t T, const uint8_t* tri_valid,
                                   int rows, int cols, float graph_scale, float* idepthmap_out, int32_t* coverage_out) {
   flame_hip::RoctxRange roctx_range_("flame_nltgv2_interpolate_mesh");
@@ -48,8 +109,11 @@ int flame_nltgv2_interpolate_mesh(flame_nltgv2_ctx* ctx, const int32_t* triangle
   if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
   rc = ensure_canon(ctx);
   if (rc) return rc;
-  return interpolate_common(ctx, triangles, T, ctx->L.V, nullptr, tri_valid, ctx->c.pos, ctx->c.x, graph_scale, rows,
-                            cols, idepthmap_out, coverage_out);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->raster_stream));  // (r_img may still be on its way out for an interpolate_mesh_begin)
+  rc = interpolate_common(ctx, triangles, T, ctx->L.V, nullptr, tri_valid, ctx->c.pos, ctx->c.x, graph_scale, rows,
+                          cols, idepthmap_out, coverage_out);
+  if (!rc) ctx->map_rows = rows, ctx->map_cols = cols;  // (the map stays on the device: flame_nltgv2_sync_input.init_from_map)
+  return rc;
 }
 
 int flame_nltgv2_interpolate_mesh_arrays(flame_nltgv2_ctx* ctx, const int32_t* triangles, int32_t T, const float* vertices_xy,
@@ -67,6 +131,8 @@ int flame_nltgv2_interpolate_mesh_arrays(flame_nltgv2_ctx* ctx, const int32_t* t
     HIPCHK(ctx, hipMemcpyAsync(ctx->r_vtx.p, vertices_xy, sizeof(float) * 2 * (size_t)V, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->r_val.p, values, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, ctx->stream));
   }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->raster_stream));
+  ctx->map_rows = ctx->map_cols = 0;  // (r_img will hold an image of the caller's arrays, not the graph's map)
   return interpolate_common(ctx, triangles, T, V, vtx_valid, tri_valid, (const float2*)ctx->r_vtx.p,
                             (const float*)ctx->r_val.p, 1.0f, rows, cols, img_out, coverage_out);
 }

@@ -82,31 +82,40 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
 //   * every edge gets alpha = 1/||pos_a - pos_b|| from the NEW positions and beta = 1 (flame.cc:2087-2103);
 //   * resulting edge order = surviving edges in their previous relative order, then the new edges in
 //     triangulator order (boost::edges() walks a std::list: erase keeps order, add_edge appends).
-int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in) {
-  flame_hip::RoctxRange roctx_range_("flame_nltgv2_sync_graph");
-  int rc = enter(ctx);
-  if (rc) return rc;
+}  // extern "C"
+
+namespace flame_hip {
+namespace host {
+
+// init_with_prediction on the device: the gather reads the dense map the last interpolate_mesh left in r_img (behind the
+// rasteriser if that is still running on its side stream); no map yet = a 0 x 0 map: every look-up is outside, i.e. NaN.
+void set_init_map(flame_nltgv2_ctx* ctx, bool on, SyncArgs* sa) {
+  if (!on) return;
+  if (ctx->raster_inflight) (void)hipStreamWaitEvent(ctx->stream, ctx->ev_raster_done, 0);
+  const bool have = ctx->map_rows > 0 && ctx->r_img.p;
+  sa->init_map = have ? (const float*)ctx->r_img.p : (const float*)ctx->data.p;
+  sa->map_rows = have ? ctx->map_rows : 0, sa->map_cols = have ? ctx->map_cols : 0;
+}
+
+static int sync_input_ok(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in) {
   if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
   if (!in || in->V < 0 || in->E < 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-  const int32_t V = in->V, E = in->E;
-  if (V > 0 && (!in->feat_id || !in->pos || !in->data_term || !in->data_weight)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-  if (E > 0 && !in->edges) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  if (in->V > 0 && (!in->feat_id || !in->pos || !in->data_term || !in->data_weight)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  if (in->E > 0 && !in->edges) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  if (in->init_from_map && (in->init_x || !(in->init_graph_scale > 0.0f))) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  return 0;
+}
 
+// The host path of the per-frame sync (rounds 1-3): index maps from the host image of the previous topology, the new graph's
+// per-vertex tables by the host builders; the state moves on the device.
+int sync_graph_host(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in) {
+  const int32_t V = in->V, E = in->E;
   const bool trace = std::getenv("FLAME_NLTGV2_TRACE") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
-  // The device path (round 4, nltgv2_topo_capi.hip): index maps AND the new graph's layout tables by kernels over the resident
-  // previous topology.  It takes the pipeline's case -- the triangulator's duplicate-free edge list (edges_unique), small feature
-  // ids -- and declines the rest (a hub of more than 64 edges, ...), which goes the host way below.
-  if (ctx->opt_sync_path != 1) {
-    bool done = false;
-    rc = sync_graph_device(ctx, in, &done);
-    if (rc) return rc;
-    if (done) return FLAME_NLTGV2_OK;
-    if (ctx->opt_sync_path == 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // (asked for by name and not applicable)
-  }
-  // The host path.  The previous state stays on the device: the canonical arrays are brought up to date (a kernel, enqueued)
-  // while the host works out the index maps below, from its image of the previous topology.
-  rc = ensure_canon(ctx);
+  // The previous state stays on the device: the canonical arrays are brought up to date (a kernel, enqueued) while the host works
+  // out the index maps below, from its image of the previous topology.
+  int rc = cancel_prepared(ctx);
+  if (!rc) rc = ensure_canon(ctx);
   if (!rc) rc = ensure_host_layout(ctx);
   if (rc) return rc;
   const int32_t Vo = ctx->L.V, Eo = ctx->L.E;
@@ -309,6 +318,7 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
   sa.old_of_new = (const int32_t*)ctx->sync_vmap.p, sa.old_of_new_edge = (const int32_t*)ctx->sync_emap.p;
   sa.data = (const float*)ctx->data.p, sa.weight = (const float*)ctx->weight.p;
   sa.init_x = in->init_x ? (const float*)ctx->sync_init.p : nullptr;
+  set_init_map(ctx, in->init_from_map != 0, &sa);
   sa.check_sticky = in->check_sticky_obstacles ? 1 : 0, sa.sticky_threshold = in->sticky_threshold;
   sa.graph_scale = in->init_graph_scale;
   for (int i = 0; i < 9; ++i) sa.o[i] = (const float*)cur_v[i]->p, sa.n[i] = (float*)ctx->sp_v[i].p;
@@ -344,6 +354,94 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
   ctx->last_error = 0;
   ctx->last_sync_path = 1;
   return FLAME_NLTGV2_OK;
+}
+
+}  // namespace host
+}  // namespace flame_hip
+
+extern "C" {
+
+// The sync in one call: the device path (round 4, nltgv2_topo_capi.hip) -- index maps AND the new graph's layout tables by kernels
+// over the resident previous topology -- takes the pipeline's case, the triangulator's duplicate-free edge list (edges_unique) with
+// small feature ids, and declines the rest (a hub of more than 64 edges, ...), which goes the host way.
+int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_sync_graph");
+  int rc = enter(ctx);
+  if (!rc) rc = sync_input_ok(ctx, in);
+  if (rc) return rc;
+  if (ctx->opt_sync_path != 1) {
+    bool applicable = false, done = false;
+    rc = topo_prepare(ctx, in, &applicable);
+    if (!rc && applicable) rc = topo_commit(ctx, &done);
+    if (rc) return rc;
+    if (done) return FLAME_NLTGV2_OK;
+    if (ctx->opt_sync_path == 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // (asked for by name and not applicable)
+  }
+  return sync_graph_host(ctx, in);
+}
+
+// The same in two halves, for a caller whose solver keeps iterating (run_async) while the frame's graph is prepared -- the reference
+// holds graph_mtx_ through all of Flame::syncGraph, its solver thread stands still (flame.cc:103, 309-318).  prepare: checks, one
+// staged copy, the builder enqueued on a side stream; returns at once.  Between the two only runs (run / run_async / sync) and
+// read-outs are allowed; anything that changes the topology cancels the prepared sync.  commit: waits for the builder, settles the
+// runs, swaps the new topology in, gathers the state.  Where the device path does not apply the inputs are kept and commit does the
+// whole sync the host way: the caller's code is the same either way.
+int flame_nltgv2_sync_prepare(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_sync_prepare");
+  int rc = enter(ctx);
+  if (!rc) rc = sync_input_ok(ctx, in);
+  if (rc) return rc;
+  bool applicable = false;
+  if (ctx->opt_sync_path != 1) {
+    rc = topo_prepare(ctx, in, &applicable);
+    if (rc) return rc;
+    if (!applicable && ctx->opt_sync_path == 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  }
+  if (!applicable) {  // keep the inputs (pinned, like the staged ones) for the host path at commit
+    rc = cancel_prepared(ctx);
+    if (rc) return rc;
+    flame_nltgv2_ctx::PreparedSync& P = ctx->prepared;
+    const size_t fV = sizeof(float) * (size_t)in->V;
+    DevBuf none{};
+    const StageCopy cp[] = {{&none, in->feat_id, sizeof(int32_t) * (size_t)in->V}, {&none, in->edges, sizeof(int32_t) * 2 * (size_t)in->E},
+                            {&none, in->pos, 2 * fV}, {&none, in->data_term, fV}, {&none, in->data_weight, fV}, {&none, in->init_x, in->init_x ? fV : 0}};
+    size_t total = 0;
+    for (const StageCopy& c : cp) total += (c.bytes + 255) & ~size_t(255);
+    ctx->prep_host.resize(total + 256);
+    size_t off = 0;
+    for (int i = 0; i < 6; ++i) {
+      P.off[i] = off;
+      if (cp[i].bytes) std::memcpy(ctx->prep_host.data() + off, cp[i].src, cp[i].bytes);
+      off += (cp[i].bytes + 255) & ~size_t(255);
+    }
+    P.active = true, P.device = false, P.topo = ctx->topo, P.V = in->V, P.E = in->E, P.has_init = in->init_x != nullptr;
+    P.check_sticky = in->check_sticky_obstacles, P.sticky_threshold = in->sticky_threshold, P.init_graph_scale = in->init_graph_scale;
+    P.edges_unique = in->edges_unique, P.init_from_map = in->init_from_map;
+  }
+  return FLAME_NLTGV2_OK;
+}
+
+int flame_nltgv2_sync_commit(flame_nltgv2_ctx* ctx) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_sync_commit");
+  int rc = enter(ctx);
+  if (rc) return rc;
+  flame_nltgv2_ctx::PreparedSync& P = ctx->prepared;
+  if (!P.active || P.topo != ctx->topo || !ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // nothing prepared (or cancelled)
+  const char* base = P.device ? static_cast<const char*>(ctx->stage[1].h) : ctx->prep_host.data();
+  if (P.device) {
+    bool done = false;
+    rc = topo_commit(ctx, &done);
+    if (rc || done) return rc;
+  }
+  P.active = false;
+  flame_nltgv2_sync_input in{};  // the host way, from the kept inputs
+  in.V = P.V, in.E = P.E;
+  in.feat_id = reinterpret_cast<const int32_t*>(base + P.off[0]), in.edges = reinterpret_cast<const int32_t*>(base + P.off[1]);
+  in.pos = reinterpret_cast<const float*>(base + P.off[2]), in.data_term = reinterpret_cast<const float*>(base + P.off[3]);
+  in.data_weight = reinterpret_cast<const float*>(base + P.off[4]), in.init_x = P.has_init ? reinterpret_cast<const float*>(base + P.off[5]) : nullptr;
+  in.check_sticky_obstacles = P.check_sticky, in.sticky_threshold = P.sticky_threshold, in.init_graph_scale = P.init_graph_scale;
+  in.edges_unique = P.edges_unique, in.init_from_map = P.init_from_map;
+  return sync_graph_host(ctx, &in);
 }
 
 int flame_nltgv2_project_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_projection* pr, float graph_scale,
@@ -400,8 +498,9 @@ int flame_nltgv2_set_feature_ids(flame_nltgv2_ctx* ctx, const int32_t* feat_id) 
   FlatMap seen((size_t)ctx->L.V);
   for (int32_t v = 0; v < ctx->L.V; ++v)
     if (feat_id[v] < 0 || !seen.emplace((uint64_t)(uint32_t)feat_id[v], v).second) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  if (cancel_prepared(ctx) != 0) return ctx->last_error;  // (a prepared sync looked the old ids up)
   ctx->h_feat.assign(feat_id, feat_id + ctx->L.V);
-  ctx->feat_map_valid = false, ctx->feat_tab_valid = false;
+  ctx->feat_map_valid = false, ctx->feat_tab_valid = false, ctx->feat_dev_valid = false;
   return FLAME_NLTGV2_OK;
 }
 

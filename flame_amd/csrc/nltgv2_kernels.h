@@ -142,6 +142,8 @@ struct SyncArgs {
   const float* data = nullptr;               // [V] new data terms, weights
   const float* weight = nullptr;
   const float* init_x = nullptr;             // [V] or nullptr
+  const float* init_map = nullptr;           // or: the dense inverse-depth map of the last interpolate_mesh (device), rows x cols --
+  int map_rows = 0, map_cols = 0;            // init = map(int(pos.y + 0.5), int(pos.x + 0.5)) / graph_scale (flame.cc:2131), NaN outside
   int check_sticky = 0;
   float sticky_threshold = 0.0f;
   float graph_scale = 0.0f;                  // > 0: a NaN init value is replaced by the neighbours' mean (flame.cc:2133-2158)

@@ -400,20 +400,33 @@ k_raster_triangles(int T, const int32_t* __restrict__ tris, const float2* __rest
   }
 }
 
+constexpr int kResolvePerThread = 8;
 __global__ void __launch_bounds__(256)
 k_raster_resolve(long n, const unsigned long long* __restrict__ keys, float* __restrict__ img,
                  int* __restrict__ coverage) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  bool covered = false;
-  if (i < n) {
-    const unsigned long long k = keys[i];
-    covered = (k >> 32) != 0ull;
-    const float v = __uint_as_float((unsigned)k);
-    img[i] = covered ? v : __builtin_nanf("");
-    covered = covered && !(v != v);  // flame.cc:431: counts !isnan
+  // kResolvePerThread pixels per thread and ONE atomic per workgroup: an atomic per wave -- 32 k of them on the same word at
+  // 1920x1080 -- completed at ~11 ns each and made this kernel 364 us (round 4: 2 M pixels are 24 MB of traffic, microseconds).
+  __shared__ int s_count;
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
+  int count = 0;
+  const long base = (long)blockIdx.x * blockDim.x * kResolvePerThread + threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < kResolvePerThread; ++j) {
+    const long i = base + (long)j * blockDim.x;
+    bool covered = false;
+    if (i < n) {
+      const unsigned long long k = keys[i];
+      covered = (k >> 32) != 0ull;
+      const float v = __uint_as_float((unsigned)k);
+      img[i] = covered ? v : __builtin_nanf("");
+      covered = covered && !(v != v);  // flame.cc:431: counts !isnan
+    }
+    count += __popcll(__ballot(covered));
   }
-  const unsigned long long m = __ballot(covered);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(coverage, __popcll(m));
+  if ((threadIdx.x & 63) == 0 && count) atomicAdd(&s_count, count);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_count) atomicAdd(coverage, s_count);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -616,7 +629,7 @@ int launch_interpolate_mesh(int T, const int32_t* tris, const float2* vtx, const
     hipLaunchKernelGGL(k_raster_triangles, dim3((unsigned)T), dim3(64), 0, s, T, tris, vtx, values, value_scale,
                        vtx_valid, tri_valid, keys, rows, cols);
   }
-  hipLaunchKernelGGL(k_raster_resolve, grid1d(n), dim3(256), 0, s, n, keys, img, coverage);
+  hipLaunchKernelGGL(k_raster_resolve, grid1d((n + kResolvePerThread - 1) / kResolvePerThread), dim3(256), 0, s, n, keys, img, coverage);
   return (int)hipGetLastError();
 }
 

@@ -531,7 +531,8 @@ namespace {
 // marks a new vertex whose init value is NaN and is to be replaced by the mean of its neighbours (k_sync_init_from_neighbours).
 __global__ void __launch_bounds__(256)
 k_sync_vertices(const int V, const int32_t* __restrict__ old_of_new, const float* __restrict__ data, const float* __restrict__ init_x,
-                const int check_sticky, const float sticky_threshold, const int nbr_fallback, const float* __restrict__ ox,
+                const float* __restrict__ init_map, const int map_rows, const int map_cols, const float2* __restrict__ pos,
+                const float graph_scale, const int check_sticky, const float sticky_threshold, const int nbr_fallback, const float* __restrict__ ox,
                 const float* __restrict__ ow1, const float* __restrict__ ow2, const float* __restrict__ oxb,
                 const float* __restrict__ ow1b, const float* __restrict__ ow2b, const float* __restrict__ oxp,
                 const float* __restrict__ ow1p, const float* __restrict__ ow2p, float* __restrict__ x, float* __restrict__ w1,
@@ -549,6 +550,11 @@ k_sync_vertices(const int V, const int32_t* __restrict__ old_of_new, const float
     xp[v] = oxp[o], w1p[v] = ow1p[o], w2p[v] = ow2p[o];
   } else {
     float xi = init_x ? init_x[v] : data[v];
+    if (init_map) {  // init_with_prediction, flame.cc:2131: idepthmap(pos.y + 0.5f, pos.x + 0.5f) -- float -> int truncates --, / graph_scale
+      const float2 p = pos[v];
+      const int iy = (int)(p.y + 0.5f), ix = (int)(p.x + 0.5f);
+      xi = (iy >= 0 && iy < map_rows && ix >= 0 && ix < map_cols) ? init_map[(size_t)iy * map_cols + ix] / graph_scale : __builtin_nanf("");
+    }
     if (nbr_fallback && xi != xi) {
       xi = data[v];  // what the vertex holds (flame.cc:2046-2048) while its neighbours' means are formed
       need = 1;
@@ -613,7 +619,8 @@ k_sync_init_commit(const int V, const uint8_t* __restrict__ need_nbr, float* __r
 
 int launch_sync_state(const SyncArgs& a, hipStream_t s) {
   if (a.V > 0) {
-    hipLaunchKernelGGL(k_sync_vertices, grid1d(a.V), dim3(256), 0, s, a.V, a.old_of_new, a.data, a.init_x, a.check_sticky,
+    hipLaunchKernelGGL(k_sync_vertices, grid1d(a.V), dim3(256), 0, s, a.V, a.old_of_new, a.data, a.init_x, a.init_map, a.map_rows, a.map_cols,
+                       a.pos, a.graph_scale, a.check_sticky,
                        a.sticky_threshold, a.graph_scale > 0.0f ? 1 : 0, a.o[0], a.o[1], a.o[2], a.o[3], a.o[4], a.o[5], a.o[6], a.o[7],
                        a.o[8], a.n[0], a.n[1], a.n[2], a.n[3], a.n[4], a.n[5], a.n[6], a.n[7], a.n[8], a.need_nbr);
   }

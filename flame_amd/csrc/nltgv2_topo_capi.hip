@@ -3,8 +3,11 @@
 // without host layout tables, and the host image of a device-built topology on demand.
 //
 // What the host still does per frame: check the inputs the way the C-ABI promises (ids unique and >= 0, edges in range, positions
-// finite: three streaming passes), stage the frame's arrays into ONE pinned blob, enqueue the builder, read 64 bytes of dimensions
-// back (rows, patches, largest degree), size the slot / lane arrays and enqueue their expansion and the state gather.
+// finite: three streaming passes), stage the frame's arrays into ONE pinned blob, enqueue the builder on a side stream (prepare);
+// then (commit) read 64 bytes of dimensions back (rows, patches, largest degree), stop the solver, swap the next topology in, size
+// the slot / lane arrays and enqueue their expansion and the state gather.  The reference holds graph_mtx_ -- the solver stands
+// still -- through all of Flame::syncGraph including the triangulation (flame.cc:309-318, 2052-2071); here it stands still for
+// the commit only.
 #include "nltgv2_context.hpp"
 
 namespace flame_hip {
@@ -52,16 +55,32 @@ int ensure_host_layout(flame_nltgv2_ctx* ctx) {
   return 0;
 }
 
-// The per-frame sync with the topology built on the device.  *done = false: the case is one the device path does not take
-// (the caller goes on with the host path; nothing has been changed).  Preconditions checked here: the caller vouches for a
-// duplicate-free edge list (edges_unique), ids fit the direct table, at least one edge.
-int sync_graph_device(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, bool* done) {
-  *done = false;
+int cancel_prepared(flame_nltgv2_ctx* ctx) {
+  if (!ctx->prepared.active) return 0;
+  if (ctx->prepared.device) HIPCHK(ctx, hipStreamSynchronize(ctx->topo_stream));
+  ctx->prepared.active = false;
+  return 0;
+}
+
+// The per-frame sync with the topology built on the device, in two halves.
+//
+// topo_prepare: the checks the C-ABI promises, the frame's arrays staged into ONE pinned blob, the builder enqueued on the SIDE
+// stream -- it reads the live topology (CSR, edge list) and the feature table and writes the next topology into buffers of its own
+// (ctx->nx), so the solver may keep iterating on the context's stream meanwhile (run_async); nothing the solver reads is touched.
+// *applicable = false: a case the device path does not take (no duplicate-free edge list vouched for, ids beyond the direct table,
+// fewer than two vertices or no edge); nothing has been done.
+//
+// topo_commit: waits for the builder's 64 bytes of dimensions, stops the solver (settles the chain of runs, state to the canonical
+// arrays), swaps the next topology in, expands the slot / lane arrays and gathers the state.  *done = false: the builder declined
+// (a hub of more than 64 edges, a pair listed twice, a graph beyond the row-packed patch form): the previous graph is whole, the
+// caller goes the host way with the staged inputs.
+int topo_prepare(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, bool* applicable) {
+  *applicable = false;
   const int32_t V = in->V, E = in->E;
   const int32_t Vo = ctx->L.V, Eo = ctx->L.E;
   if (!in->edges_unique || V < 2 || E < 1 || V > (1 << 22) || (int64_t)Eo + E + V + 1 > 0x7fff0000ll) return 0;
-  const bool trace = std::getenv("FLAME_NLTGV2_TRACE") != nullptr;
-  const auto t0 = std::chrono::steady_clock::now();
+  flame_nltgv2_ctx::PreparedSync& P = ctx->prepared;
+  P.t_begin = std::chrono::steady_clock::now();
   // ---- the checks the C-ABI promises (INVALID_ARG before anything is changed) -------------------------------------------------
   int32_t max_id = -1;
   for (int32_t v = 0; v < V; ++v) {
@@ -95,12 +114,12 @@ int sync_graph_device(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, 
     minx = std::min(minx, px), maxx = std::max(maxx, px);
     miny = std::min(miny, py), maxy = std::max(maxy, py);
   }
-  const auto t1 = std::chrono::steady_clock::now();
-
-  // ---- previous state to its canonical arrays (a kernel, enqueued); buffers ------------------------------------------------------
-  int rc = ensure_canon(ctx);
+  int rc = cancel_prepared(ctx);  // (a sync prepared earlier and never committed)
   if (rc) return rc;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // nothing in flight uses buffers that may be reallocated below (or the staging blob)
+
+  // ---- buffers: scratch and the next topology.  Nothing here belongs to the live graph: growing one of them frees memory the
+  // solver does not use (a hipFree still waits for the device: buffers grow geometrically, so a steady stream of frames stops growing)
+  hipStream_t ts = ctx->topo_stream;
   const int n_slices = (V + kWave - 1) / kWave;
   const size_t n_packed = (size_t)n_slices * kWave;
   const size_t fV = sizeof(float) * (size_t)V, fE = sizeof(float) * (size_t)E, iV = sizeof(int32_t) * (size_t)V;
@@ -108,31 +127,31 @@ int sync_graph_device(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, 
   const int n_seg = (V + 255) / 256;
   const int n_scan = Eo + E + V + 1;
   const size_t sort_bytes = topo_sort_temp_bytes(V, n_scan);
-  Carve cv;
-  const size_t o_fid = cv.take(iV), o_edges = cv.take(2 * fE), o_old_edge = cv.take(fE), o_first_k = cv.take(sizeof(int32_t) * (size_t)std::max(Eo, 1));
   int cc_bits = 1;
   while ((1 << cc_bits) < V) ++cc_bits;
   const size_t iM = sizeof(int32_t) << cc_bits;
+  Carve cv;
+  const size_t o_fid = cv.take(iV), o_edges = cv.take(2 * fE), o_init = cv.take(fV), o_old_edge = cv.take(fE), o_first_k = cv.take(sizeof(int32_t) * (size_t)std::max(Eo, 1));
   const size_t o_scan = cv.take(sizeof(int32_t) * (size_t)n_scan), o_deg = cv.take(iV), o_cur = cv.take(iV), o_parent = cv.take(iM), o_minid = cv.take(iM), o_morton = cv.take(iV);
   const size_t o_key_out = cv.take(8 * (size_t)V), o_width = cv.take(sizeof(int32_t) * (size_t)n_slices);
   const size_t o_wflag = cv.take(vpad), o_vf0 = cv.take(vpad), o_vf1 = cv.take(vpad), o_seg0 = cv.take(sizeof(int32_t) * (size_t)n_seg), o_seg1 = cv.take(sizeof(int32_t) * (size_t)n_seg);
-  const size_t o_counters = cv.take(64), o_wg2_v0 = cv.take(iV), o_sort = cv.take(sort_bytes);
+  const size_t o_counters = cv.take(64), o_wg2_v0 = cv.take(iV), o_vmap = cv.take(iV), o_emap = cv.take(fE), o_old_feat = cv.take(sizeof(int32_t) * (size_t)std::max(Vo, 1)), o_sort = cv.take(sort_bytes);
+  const size_t nx_bytes[flame_nltgv2_ctx::NX_COUNT] = {
+      2 * fV, fE, fE, sizeof(int32_t) * ((size_t)V + 1), 2 * fE, iV, iV, sizeof(int32_t) * n_packed, iV, sizeof(int32_t) * n_packed,
+      sizeof(int32_t) * ((size_t)n_slices + 1), 4 * iV, iV, vpad, 4 * iV, vpad, fV, fV};  // (patch tables by their upper bound: a patch holds at least one vertex)
+  // (the previous commit's kernels may still read the scratch maps and write what this builder reads: it starts behind them)
+  HIPCHK(ctx, hipStreamWaitEvent(ts, ctx->ev_topo_ready, 0));
+  if (ctx->raster_inflight) HIPCHK(ctx, hipStreamWaitEvent(ts, ctx->ev_raster_done, 0));  // (it may read a position buffer that was swapped out)
+  if (ctx->topo_scratch.cap < cv.off) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (growing the scratch under the previous commit's state gather)
   rc = ensure(ctx, ctx->topo_scratch, cv.off);
-  DevBuf* cur_v[9] = {&ctx->x, &ctx->w1, &ctx->w2, &ctx->xb, &ctx->w1b, &ctx->w2b, &ctx->xp, &ctx->w1p, &ctx->w2p};
-  DevBuf* cur_q[3] = {&ctx->q1, &ctx->q2, &ctx->q3};
-  for (int i = 0; i < 9 && !rc; ++i) rc = ensure(ctx, ctx->sp_v[i], fV);
-  for (int i = 0; i < 3 && !rc; ++i) rc = ensure(ctx, ctx->sp_q[i], fE);
-  struct { DevBuf* b; size_t bytes; } req[] = {
-      {&ctx->data, fV}, {&ctx->weight, fV}, {&ctx->alpha, fE}, {&ctx->beta, fE}, {&ctx->sync_init, fV}, {&ctx->sync_vmap, iV},
-      {&ctx->sync_emap, fE}, {&ctx->sync_need, (size_t)V}, {&ctx->nx_pos, 2 * fV}, {&ctx->nx_src, fE}, {&ctx->nx_dst, fE},
-      {&ctx->nx_row_ptr, sizeof(int32_t) * ((size_t)V + 1)}, {&ctx->nx_half, 2 * fE}, {&ctx->topo_dims, sizeof(TopoDims)},
-      // the tables the builder writes, sized by their upper bounds (a patch holds at least one vertex)
-      {&ctx->slice_row, sizeof(int32_t) * ((size_t)n_slices + 1)}, {&ctx->perm, sizeof(int32_t) * n_packed}, {&ctx->pdeg, sizeof(int32_t) * n_packed},
-      {&ctx->iperm, iV}, {&ctx->order_m, iV}, {&ctx->rid_of, iV}, {&ctx->wg_info, 4 * iV}, {&ctx->wg_v0, iV}, {&ctx->wg_vfirst, vpad},
-      {&ctx->wg2_info, 4 * iV}, {&ctx->wg2_vfirst, vpad}};
-  for (auto& r : req)
-    if (!rc) rc = ensure(ctx, *r.b, r.bytes);
+  for (int i = 0; i < flame_nltgv2_ctx::NX_COUNT && !rc; ++i) rc = ensure(ctx, ctx->nx[i], nx_bytes[i]);
+  if (!rc) rc = ensure(ctx, ctx->topo_dims, sizeof(TopoDims));
   if (rc) return rc;
+  if (!ctx->h_dims && hipHostMalloc((void**)&ctx->h_dims, sizeof(TopoDims), hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(ctx, FLAME_NLTGV2_ERR_OOM);
+  }
+  char* const sc = static_cast<char*>(ctx->topo_scratch.p);
   // the device's feature table follows the ids (grown: its content is rebuilt from the current graph's ids)
   if (ctx->feat_tab_size_d <= max_id) {
     const size_t want = (size_t)max_id + 1 + (size_t)max_id / 2;
@@ -142,34 +161,30 @@ int sync_graph_device(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, 
     ctx->feat_tab_size_d = (int)std::min(ctx->feat_stamp_d.cap / sizeof(uint32_t), ctx->feat_val_d.cap / sizeof(int32_t));
     ctx->feat_dev_valid = false;
   }
-  char* const sc = static_cast<char*>(ctx->topo_scratch.p);
-  if (!ctx->feat_dev_valid || ctx->feat_gen >= 0xfffffff0u) {
-    HIPCHK(ctx, hipMemsetAsync(ctx->feat_stamp_d.p, 0, sizeof(uint32_t) * (size_t)ctx->feat_tab_size_d, ctx->stream));
+  const bool rebuild_table = !ctx->feat_dev_valid || ctx->feat_gen >= 0xfffffff0u;
+  if (rebuild_table) {
+    HIPCHK(ctx, hipMemsetAsync(ctx->feat_stamp_d.p, 0, sizeof(uint32_t) * (size_t)ctx->feat_tab_size_d, ts));
     ctx->feat_gen = 1;
-    if (Vo > 0) {  // (the previous graph's ids travel through the scratch area the frame's ids will use next; ordered on the stream)
-      rc = ensure(ctx, ctx->sync_need, std::max((size_t)V, sizeof(int32_t) * (size_t)Vo));
-      if (rc) return rc;
-      HIPCHK(ctx, hipMemcpyAsync(ctx->sync_need.p, ctx->h_feat.data(), sizeof(int32_t) * (size_t)Vo, hipMemcpyHostToDevice, ctx->stream));
-      LAUNCHCHK(ctx, launch_topo_feat_build((const int32_t*)ctx->sync_need.p, Vo, (uint32_t*)ctx->feat_stamp_d.p, (int32_t*)ctx->feat_val_d.p,
-                                            ctx->feat_tab_size_d, ctx->feat_gen, ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (h_feat is pageable and about to change)
-    }
-    ctx->feat_dev_valid = true;
   }
 
-  // ---- one blob up: the frame's inputs ----------------------------------------------------------------------------------------------
-  DevBuf b_fid{sc + o_fid, iV}, b_edges{sc + o_edges, 2 * fE};
-  const StageCopy cp[] = {{&b_fid, in->feat_id, iV}, {&b_edges, in->edges, 2 * fE}, {&ctx->nx_pos, in->pos, 2 * fV},
-                          {&ctx->data, in->data_term, fV}, {&ctx->weight, in->data_weight, fV},
-                          {&ctx->sync_init, in->init_x, in->init_x ? fV : 0}};
-  rc = staged_h2d(ctx, cp, sizeof(cp) / sizeof(cp[0]));
+  // ---- one blob up: the frame's inputs (and, when the table is rebuilt, the live graph's ids) -----------------------------------------
+  DevBuf b_fid{sc + o_fid, iV}, b_edges{sc + o_edges, 2 * fE}, b_init{sc + o_init, fV}, b_old{sc + o_old_feat, sizeof(int32_t) * (size_t)std::max(Vo, 1)};
+  const StageCopy cp[] = {{&b_fid, in->feat_id, iV}, {&b_edges, in->edges, 2 * fE}, {&ctx->nx[flame_nltgv2_ctx::NX_POS], in->pos, 2 * fV},
+                          {&ctx->nx[flame_nltgv2_ctx::NX_DATA], in->data_term, fV}, {&ctx->nx[flame_nltgv2_ctx::NX_WEIGHT], in->data_weight, fV},
+                          {&b_init, in->init_x, in->init_x ? fV : 0},
+                          {&b_old, ctx->h_feat.data(), rebuild_table ? sizeof(int32_t) * (size_t)Vo : 0}};
+  size_t hoff[7];
+  rc = staged_h2d(ctx, cp, sizeof(cp) / sizeof(cp[0]), nullptr, 0, /*slot=*/1, ts, hoff);
   if (rc) return rc;
-  const auto t2 = std::chrono::steady_clock::now();
+  if (rebuild_table && Vo > 0)
+    LAUNCHCHK(ctx, launch_topo_feat_build((const int32_t*)(sc + o_old_feat), Vo, (uint32_t*)ctx->feat_stamp_d.p, (int32_t*)ctx->feat_val_d.p,
+                                          ctx->feat_tab_size_d, ctx->feat_gen, ts));
 
   // ---- the builder ------------------------------------------------------------------------------------------------------------------
+  using C = flame_nltgv2_ctx;
   TopoBuild t;
   t.V = V, t.E = E, t.Vo = Vo, t.Eo = Eo, t.n_slices = n_slices;
-  t.fid = (const int32_t*)(sc + o_fid), t.pos = (const float2*)ctx->nx_pos.p, t.tri_edges = (const int32_t*)(sc + o_edges);
+  t.fid = (const int32_t*)(sc + o_fid), t.pos = (const float2*)ctx->nx[C::NX_POS].p, t.tri_edges = (const int32_t*)(sc + o_edges);
   t.minx = minx, t.miny = miny;
   t.sx = (maxx > minx) ? 65535.0f / (maxx - minx) : 0.0f, t.sy = (maxy > miny) ? 65535.0f / (maxy - miny) : 0.0f;
   t.o_row_ptr = (const int32_t*)ctx->row_ptr.p, t.o_half = (const uint32_t*)ctx->half.p;
@@ -183,44 +198,76 @@ int sync_graph_device(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, 
   t.wflag = (uint8_t*)(sc + o_wflag), t.vf[0] = (uint8_t*)(sc + o_vf0), t.vf[1] = (uint8_t*)(sc + o_vf1);
   t.seg_count[0] = (int32_t*)(sc + o_seg0), t.seg_count[1] = (int32_t*)(sc + o_seg1);
   t.sort_tmp = sc + o_sort, t.sort_tmp_bytes = sort_bytes, t.counters = (int*)(sc + o_counters);
-  t.old_of_new = (int32_t*)ctx->sync_vmap.p, t.old_of_new_edge = (int32_t*)ctx->sync_emap.p;
-  t.src = (int32_t*)ctx->nx_src.p, t.dst = (int32_t*)ctx->nx_dst.p, t.row_ptr = (int32_t*)ctx->nx_row_ptr.p, t.half = (uint32_t*)ctx->nx_half.p;
-  t.order_m = (int32_t*)ctx->order_m.p, t.rid_of = (int32_t*)ctx->rid_of.p, t.perm = (int32_t*)ctx->perm.p, t.iperm = (int32_t*)ctx->iperm.p;
-  t.pdeg = (int32_t*)ctx->pdeg.p, t.slice_row = (int32_t*)ctx->slice_row.p;
-  t.wg_info = (int32_t*)ctx->wg_info.p, t.wg_v0 = (int32_t*)ctx->wg_v0.p, t.wg_vfirst = (uint8_t*)ctx->wg_vfirst.p;
-  t.wg2_info = (int32_t*)ctx->wg2_info.p, t.wg2_v0 = (int32_t*)(sc + o_wg2_v0), t.wg2_vfirst = (uint8_t*)ctx->wg2_vfirst.p;
+  t.old_of_new = (int32_t*)(sc + o_vmap), t.old_of_new_edge = (int32_t*)(sc + o_emap);
+  t.src = (int32_t*)ctx->nx[C::NX_SRC].p, t.dst = (int32_t*)ctx->nx[C::NX_DST].p;
+  t.row_ptr = (int32_t*)ctx->nx[C::NX_ROW_PTR].p, t.half = (uint32_t*)ctx->nx[C::NX_HALF].p;
+  t.order_m = (int32_t*)ctx->nx[C::NX_ORDER_M].p, t.rid_of = (int32_t*)ctx->nx[C::NX_RID_OF].p, t.perm = (int32_t*)ctx->nx[C::NX_PERM].p;
+  t.iperm = (int32_t*)ctx->nx[C::NX_IPERM].p, t.pdeg = (int32_t*)ctx->nx[C::NX_PDEG].p, t.slice_row = (int32_t*)ctx->nx[C::NX_SLICE_ROW].p;
+  t.wg_info = (int32_t*)ctx->nx[C::NX_WG_INFO].p, t.wg_v0 = (int32_t*)ctx->nx[C::NX_WG_V0].p, t.wg_vfirst = (uint8_t*)ctx->nx[C::NX_WG_VFIRST].p;
+  t.wg2_info = (int32_t*)ctx->nx[C::NX_WG2_INFO].p, t.wg2_v0 = (int32_t*)(sc + o_wg2_v0), t.wg2_vfirst = (uint8_t*)ctx->nx[C::NX_WG2_VFIRST].p;
   t.dims = (TopoDims*)ctx->topo_dims.p;
-  ctx->have_graph = false;  // (until the new graph stands)
-  ctx->feat_dev_valid = false;  // (the table is being moved on to the new graph: valid again once that graph stands)
-  LAUNCHCHK(ctx, launch_topo_sync_front(t, ctx->stream));
-  LAUNCHCHK(ctx, launch_topo_back(t, ctx->stream));
-  if (!ctx->h_dims && hipHostMalloc((void**)&ctx->h_dims, sizeof(TopoDims), hipHostMallocDefault) != hipSuccess) {
-    (void)hipGetLastError();
-    return fail(ctx, FLAME_NLTGV2_ERR_OOM);
-  }
-  HIPCHK(ctx, hipMemcpyAsync(ctx->h_dims, ctx->topo_dims.p, sizeof(TopoDims), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  const auto t3 = std::chrono::steady_clock::now();
+  ctx->feat_dev_valid = false;  // (the table moves on to the new graph: valid again once that graph stands)
+  LAUNCHCHK(ctx, launch_topo_sync_front(t, ts));
+  LAUNCHCHK(ctx, launch_topo_back(t, ts));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_dims, ctx->topo_dims.p, sizeof(TopoDims), hipMemcpyDeviceToHost, ts));
+  P.active = true, P.device = true, P.topo = ctx->topo, P.V = V, P.E = E, P.has_init = in->init_x != nullptr;
+  P.check_sticky = in->check_sticky_obstacles ? 1 : 0, P.sticky_threshold = in->sticky_threshold, P.init_graph_scale = in->init_graph_scale;
+  P.edges_unique = in->edges_unique, P.init_from_map = in->init_from_map;
+  for (int i = 0; i < 6; ++i) P.off[i] = hoff[i];
+  ctx->prep_vmap = sc + o_vmap, ctx->prep_emap = sc + o_emap, ctx->prep_init = sc + o_init;
+  P.t_enqueued = std::chrono::steady_clock::now();
+  *applicable = true;
+  return 0;
+}
+
+int topo_commit(flame_nltgv2_ctx* ctx, bool* done) {
+  *done = false;
+  using C = flame_nltgv2_ctx;
+  C::PreparedSync& P = ctx->prepared;
+  if (!P.active || !P.device || P.topo != ctx->topo) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  const bool trace = std::getenv("FLAME_NLTGV2_TRACE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  HIPCHK(ctx, hipStreamSynchronize(ctx->topo_stream));  // the solver is still iterating on the context's stream meanwhile
+  const auto t1 = std::chrono::steady_clock::now();
+  P.active = false;
+  const int32_t V = P.V, E = P.E;
   const TopoDims dm = *ctx->h_dims;
   const int cus = ctx->prop.multiProcessorCount;
   const bool rowpack = ctx->opt_persistent == 4 || (static_cast<int64_t>(2) * E + V / 32) / 54 + 1 <= (int64_t)kPvDensePerCu * cus;
   if (dm.flags != 0 || dm.n_edges != E || !rowpack || (ctx->opt_persistent != 4 && dm.wg_count > kPvDensePerCu * cus)) {
-    // A case for the host builders (a hub of more than 64 edges, a pair listed twice, a graph beyond the row-packed patch form).
-    // The previous graph is still whole -- its topology and state were only read -- except for the feature table, which has moved
-    // on: it is rebuilt from the previous graph's ids when the device path is next taken.
-    ctx->have_graph = true;
+    // A case for the host builders.  The live graph is whole -- its topology and state were only read -- except for the feature
+    // table, which has moved on: it is rebuilt from the live graph's ids when the device path is next taken.
     if (trace) std::fprintf(stderr, "[flame_nltgv2] sync_graph: device build declined (flags %d, edges %d of %d, patches %d), host path\n", dm.flags, dm.n_edges, E, dm.wg_count);
     return 0;
   }
-  // ---- the new graph stands: sizes, slot / lane arrays, state ------------------------------------------------------------------------
+  // ---- the solver stops here: the chain of runs is settled, the state goes to its canonical arrays ---------------------------------------
+  int rc = ensure_canon(ctx);
+  if (rc) return rc;
+  const auto t2 = std::chrono::steady_clock::now();
+  const int n_slices = (V + kWave - 1) / kWave;
+  const size_t fV = sizeof(float) * (size_t)V, fE = sizeof(float) * (size_t)E;
+  DevBuf* cur_v[9] = {&ctx->x, &ctx->w1, &ctx->w2, &ctx->xb, &ctx->w1b, &ctx->w2b, &ctx->xp, &ctx->w1p, &ctx->w2p};
+  DevBuf* cur_q[3] = {&ctx->q1, &ctx->q2, &ctx->q3};
+  bool grow = false;  // (growing a buffer frees it: nothing in flight may use it)
+  for (int i = 0; i < 9; ++i) grow = grow || ctx->sp_v[i].cap < fV;
+  for (int i = 0; i < 3; ++i) grow = grow || ctx->sp_q[i].cap < fE;
+  grow = grow || ctx->alpha.cap < fE || ctx->beta.cap < fE || ctx->sync_need.cap < (size_t)V;
+  if (grow) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 9 && !rc; ++i) rc = ensure(ctx, ctx->sp_v[i], fV);
+  for (int i = 0; i < 3 && !rc; ++i) rc = ensure(ctx, ctx->sp_q[i], fE);
+  if (!rc) rc = ensure(ctx, ctx->alpha, fE);
+  if (!rc) rc = ensure(ctx, ctx->beta, fE);
+  if (!rc) rc = ensure(ctx, ctx->sync_need, (size_t)V);
+  if (rc) return rc;
+  ctx->have_graph = false;  // (until the new graph stands)
   PackedLayout& L = ctx->L;
   L.V = V, L.E = E, L.n_slices = n_slices, L.rows = dm.rows, L.max_degree = dm.max_degree;
   L.wg_ok = true, L.wg_rowpack = true, L.wg_count = dm.wg_count, L.wg_lcap = dm.wg_lcap, L.wg_slab_slots = 0, L.n_rec = V;
   L.wg2_walked = true, L.wg2_ok = dm.max_degree <= 32 && dm.wg2_count > 0, L.wg2_count = dm.wg2_count, L.wg2_lcap = dm.wg2_lcap;
   L.tv_ok = false, L.tv_waves = 0;
   ctx->host_layout_valid = false;
-  bool want_e2 = wants_e2(ctx) && L.wg2_ok && L.wg2_count <= kPv2WavesPerCu * cus * 4;
-  std::swap(ctx->pos, ctx->nx_pos), std::swap(ctx->src, ctx->nx_src), std::swap(ctx->dst, ctx->nx_dst), std::swap(ctx->row_ptr, ctx->nx_row_ptr), std::swap(ctx->half, ctx->nx_half);
+  const bool want_e2 = wants_e2(ctx) && L.wg2_ok && L.wg2_count <= kPv2WavesPerCu * cus * 4;
+  for (int i = 0; i < C::NX_COUNT; ++i) std::swap(*ctx->nx_live(i), ctx->nx[i]);  // the next topology becomes the live one
   rc = topology_buffers(ctx, want_e2, 4 * (size_t)L.wg_count, (size_t)L.wg_count, (size_t)V, 4 * (size_t)L.wg2_count, (size_t)V);
   if (rc) return rc;
   std::vector<StageFill> fills;
@@ -231,11 +278,12 @@ int sync_graph_device(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, 
   if (rc) return rc;
   SyncArgs sa;
   sa.V = V, sa.E = E;
-  sa.old_of_new = (const int32_t*)ctx->sync_vmap.p, sa.old_of_new_edge = (const int32_t*)ctx->sync_emap.p;
+  sa.old_of_new = (const int32_t*)ctx->prep_vmap, sa.old_of_new_edge = (const int32_t*)ctx->prep_emap;
   sa.data = (const float*)ctx->data.p, sa.weight = (const float*)ctx->weight.p;
-  sa.init_x = in->init_x ? (const float*)ctx->sync_init.p : nullptr;
-  sa.check_sticky = in->check_sticky_obstacles ? 1 : 0, sa.sticky_threshold = in->sticky_threshold;
-  sa.graph_scale = in->init_graph_scale;
+  sa.init_x = P.has_init ? (const float*)ctx->prep_init : nullptr;
+  set_init_map(ctx, P.init_from_map != 0, &sa);
+  sa.check_sticky = P.check_sticky, sa.sticky_threshold = P.sticky_threshold;
+  sa.graph_scale = P.init_graph_scale;
   for (int i = 0; i < 9; ++i) sa.o[i] = (const float*)cur_v[i]->p, sa.n[i] = (float*)ctx->sp_v[i].p;
   for (int i = 0; i < 3; ++i) sa.oq[i] = (const float*)cur_q[i]->p, sa.nq[i] = (float*)ctx->sp_q[i].p;
   sa.src = (const int32_t*)ctx->src.p, sa.dst = (const int32_t*)ctx->dst.p, sa.row_ptr = (const int32_t*)ctx->row_ptr.p;
@@ -246,19 +294,21 @@ int sync_graph_device(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, 
   for (int i = 0; i < 3; ++i) std::swap(*cur_q[i], ctx->sp_q[i]);
   refresh_args(ctx);
   LAUNCHCHK(ctx, launch_pack_static(ctx->c, ctx->f, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(ctx->ev_topo_ready, ctx->stream));
   ctx->feat_gen += 1, ctx->feat_dev_valid = true;
-  ctx->h_feat.assign(in->feat_id, in->feat_id + V);
+  const int32_t* const fid = reinterpret_cast<const int32_t*>(static_cast<const char*>(ctx->stage[1].h) + P.off[0]);
+  ctx->h_feat.assign(fid, fid + V);
   ctx->feat_map_valid = false, ctx->feat_tab_valid = false;  // (the host path's maps describe an earlier graph)
   ctx->canon_valid = true, ctx->fused_valid = false, ctx->have_prev = false, ctx->parity = 0;
   ctx->have_graph = true, ctx->last_error = 0, ctx->last_sync_path = 2;
   *done = true;
   if (trace) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    const auto t4 = std::chrono::steady_clock::now();
+    const auto t3 = std::chrono::steady_clock::now();
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    std::fprintf(stderr, "[flame_nltgv2] sync_graph (device): checks %.3f, settle + buffers + staging %.3f, builder until the dimensions are back %.3f, "
-                 "expansion + state gather %.3f ms (V=%d E=%d: %d kept, %d patches, %d two-half-edge patches)\n",
-                 ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), V, E, dm.n_keep, dm.wg_count, dm.wg2_count);
+    std::fprintf(stderr, "[flame_nltgv2] sync_graph (device): prepare (checks, staging, builder enqueued) %.3f ms; commit: builder awaited %.3f, "
+                 "solver settled %.3f, expansion + state gather %.3f ms (V=%d E=%d: %d kept, %d patches, %d two-half-edge patches)\n",
+                 ms(P.t_begin, P.t_enqueued), ms(t0, t1), ms(t1, t2), ms(t2, t3), V, E, dm.n_keep, dm.wg_count, dm.wg2_count);
   }
   return 0;
 }

@@ -65,7 +65,8 @@ class _Graph(C.Structure):
 class _SyncInput(C.Structure):
     _fields_ = [("V", C.c_int32), ("feat_id", _IP), ("pos", _FP), ("data_term", _FP), ("data_weight", _FP),
                 ("init_x", _FP), ("E", C.c_int32), ("edges", _IP), ("check_sticky_obstacles", C.c_int32),
-                ("sticky_threshold", C.c_float), ("init_graph_scale", C.c_float), ("edges_unique", C.c_int32)]
+                ("sticky_threshold", C.c_float), ("init_graph_scale", C.c_float), ("edges_unique", C.c_int32),
+                ("init_from_map", C.c_int32)]
 
 
 class _Projection(C.Structure):
@@ -101,8 +102,9 @@ ABI_SYMBOLS = (
     "flame_nltgv2_set_option", "flame_nltgv2_get_info", "flame_nltgv2_last_error", "flame_nltgv2_last_hip_error",
     "flame_nltgv2_status_string", "flame_nltgv2_abi_version", "flame_nltgv2_pack_probe", "flame_nltgv2_read_probe", "flame_nltgv2_layout_selftest", "flame_nltgv2_placement_info",
     "flame_nltgv2_photo_set_images", "flame_nltgv2_photo_residual", "flame_nltgv2_photo_fuse",
-    "flame_nltgv2_photo_residual_last", "flame_nltgv2_sync_graph",
+    "flame_nltgv2_photo_residual_last", "flame_nltgv2_sync_graph", "flame_nltgv2_sync_prepare", "flame_nltgv2_sync_commit",
     "flame_nltgv2_get_topology", "flame_nltgv2_graph_size", "flame_nltgv2_set_feature_ids", "flame_nltgv2_interpolate_mesh",
+    "flame_nltgv2_interpolate_mesh_begin", "flame_nltgv2_interpolate_mesh_end",
     "flame_nltgv2_interpolate_mesh_arrays", "flame_nltgv2_project_graph", "flame_nltgv2_rescale_data",
     "flame_delaunay_triangulate",
 )
@@ -157,6 +159,8 @@ def load_library():
         "flame_nltgv2_photo_fuse": (C.c_int, [ctx, _FP, _FP, C.c_float, C.c_int, C.c_int]),
         "flame_nltgv2_photo_residual_last": (C.c_int, [ctx, _FP]),
         "flame_nltgv2_sync_graph": (C.c_int, [ctx, C.POINTER(_SyncInput)]),
+        "flame_nltgv2_sync_prepare": (C.c_int, [ctx, C.POINTER(_SyncInput)]),
+        "flame_nltgv2_sync_commit": (C.c_int, [ctx]),
         "flame_nltgv2_get_topology": (C.c_int, [ctx, _IP, _IP, _IP]),
         "flame_nltgv2_graph_size": (C.c_int, [ctx, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "flame_nltgv2_set_feature_ids": (C.c_int, [ctx, _IP]),
@@ -165,6 +169,8 @@ def load_library():
         "flame_nltgv2_rescale_data": (C.c_int, [ctx, C.c_float, _FP, PP]),
         "flame_nltgv2_interpolate_mesh": (C.c_int, [ctx, _IP, C.c_int32, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_float,
                                                     _FP, _IP]),
+        "flame_nltgv2_interpolate_mesh_begin": (C.c_int, [ctx, _IP, C.c_int32, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_float]),
+        "flame_nltgv2_interpolate_mesh_end": (C.c_int, [ctx, C.POINTER(_FP), _IP]),
         "flame_nltgv2_interpolate_mesh_arrays": (C.c_int, [ctx, _IP, C.c_int32, _FP, _FP, C.c_int32, C.POINTER(C.c_uint8),
                                                            C.POINTER(C.c_uint8), C.c_int, C.c_int, _FP, _IP]),
     }
@@ -282,12 +288,31 @@ class Regularizer:
         self._chk(self._L.flame_nltgv2_upload_graph(self._ctx, C.byref(cg)), "upload_graph")
         self.V, self.E = int(g["V"]), int(g["E"])
 
-    def sync_graph(self, feat_id, pos, data_term, data_weight, edges, init_x=None, check_sticky_obstacles=False,
-                   sticky_threshold=0.25, init_graph_scale=0.0, edges_unique=False):
+    def sync_prepare(self, *args, **kw):
+        """First half of sync_graph (same arguments): checks, one staged copy, the new topology's construction enqueued on a side
+        stream -- the solver may keep iterating (run_async) until sync_commit()."""
+        self._sync(self._L.flame_nltgv2_sync_prepare, "sync_prepare", *args, **kw)
+
+    def sync_commit(self):
+        """Second half: waits for the construction, settles the runs, swaps the new topology in, moves the state."""
+        self._chk(self._L.flame_nltgv2_sync_commit(self._ctx), "sync_commit")
+        self._refresh_size()
+
+    def _refresh_size(self):
+        nv, ne = C.c_int32(0), C.c_int32(0)
+        self._chk(self._L.flame_nltgv2_graph_size(self._ctx, C.byref(nv), C.byref(ne)), "graph_size")
+        self.V, self.E = int(nv.value), int(ne.value)
+
+    def sync_graph(self, *args, **kw):
         """Per-frame warm-start synchronisation (Flame::syncGraph's graph edits, flame.cc:1985-2121).
 
         init_graph_scale > 0: new vertices whose init_x is NaN start at their neighbours' mean
         (init_with_prediction's fallback, flame.cc:2133-2158)."""
+        self._sync(self._L.flame_nltgv2_sync_graph, "sync_graph", *args, **kw)
+        self._refresh_size()
+
+    def _sync(self, fn, what, feat_id, pos, data_term, data_weight, edges, init_x=None, check_sticky_obstacles=False,
+              sticky_threshold=0.25, init_graph_scale=0.0, edges_unique=False, init_from_map=False):
         V = int(len(feat_id))
         fid = _as(feat_id, np.int32, V, "feat_id")
         p = _as(pos, np.float32, 2 * V, "pos")
@@ -307,10 +332,8 @@ class Regularizer:
         si.sticky_threshold = sticky_threshold
         si.init_graph_scale = float(init_graph_scale)
         si.edges_unique = 1 if edges_unique else 0  # (the caller vouches: e.g. the edges of flame_amd.delaunay)
-        self._chk(self._L.flame_nltgv2_sync_graph(self._ctx, C.byref(si)), "sync_graph")
-        nv, ne = C.c_int32(0), C.c_int32(0)
-        self._chk(self._L.flame_nltgv2_graph_size(self._ctx, C.byref(nv), C.byref(ne)), "graph_size")
-        self.V, self.E = int(nv.value), int(ne.value)
+        si.init_from_map = 1 if init_from_map else 0  # new vertices start at the device-resident dense map's prediction (flame.cc:2131)
+        self._chk(fn(self._ctx, C.byref(si)), what)
 
     def placement_info(self) -> dict:
         """Record placement of the patch-per-wave form (FLAME_NLTGV2_OPT_PLACEMENT): state (1 in use, 0 not yet, -1
@@ -444,6 +467,25 @@ class Regularizer:
                                                         C.c_float(graph_scale), img.ctypes.data_as(_FP), C.byref(cov)),
                   "interpolate_mesh")
         return img, int(cov.value)
+
+    def interpolate_mesh_begin(self, triangles, rows, cols, graph_scale=1.0, tri_valid=None):
+        """interpolate_mesh in two halves: settles the runs, enqueues rasteriser + copy-out on a side stream and returns; the
+        solver may iterate (run_async) until interpolate_mesh_end() fetches the map."""
+        tr = np.ascontiguousarray(triangles, np.int32).reshape(-1, 3)
+        U8 = C.POINTER(C.c_uint8)
+        tv = None if tri_valid is None else np.ascontiguousarray(tri_valid, np.uint8)
+        self._chk(self._L.flame_nltgv2_interpolate_mesh_begin(self._ctx, tr.ctypes.data_as(_IP), tr.shape[0],
+                                                              None if tv is None else tv.ctypes.data_as(U8), rows, cols,
+                                                              C.c_float(graph_scale)), "interpolate_mesh_begin")
+        self._map_shape = (rows, cols)
+
+    def interpolate_mesh_end(self, copy=True):
+        """-> (idepthmap, coverage); copy=False: a view of the context's pinned buffer, valid until the next begin."""
+        p, cov = _FP(), C.c_int32(0)
+        self._chk(self._L.flame_nltgv2_interpolate_mesh_end(self._ctx, C.byref(p), C.byref(cov)), "interpolate_mesh_end")
+        rows, cols = self._map_shape
+        img = np.ctypeslib.as_array(p, shape=(rows, cols))
+        return (img.copy() if copy else img), int(cov.value)
 
     def interpolate_mesh_arrays(self, triangles, vertices, values, rows, cols, vtx_valid=None, tri_valid=None):
         tr = np.ascontiguousarray(triangles, np.int32).reshape(-1, 3)

@@ -127,8 +127,23 @@ typedef struct flame_nltgv2_sync_input {
                                    * flame_delaunay_triangulate -- and the reference's Triangle -- return): the search for
                                    * duplicates among the new edges is skipped.  0 (default): pairs that repeat are dropped as
                                    * boost::edge() / add_edge do it in the reference (flame.cc:2094-2100), the first one stays */
+  int32_t init_from_map;          /* != 0 (init_x must be NULL, init_graph_scale > 0): a NEW vertex starts at the prediction the
+                                   * reference reads from its dense map, idepthmap(pos.y + 0.5f, pos.x + 0.5f) / graph_scale
+                                   * (init_with_prediction, flame.cc:2131) -- looked up ON THE DEVICE in the map the context's last
+                                   * flame_nltgv2_interpolate_mesh[_begin] left there (no map yet, or a position outside it: NaN, i.e.
+                                   * the neighbours' mean as above).  Saves the host gather and the upload of init_x every frame */
 } flame_nltgv2_sync_input;
 int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in);
+/* The same sync in two halves, so that the solver keeps iterating while the frame's graph is prepared (the reference's solver thread
+ * stands still through all of Flame::syncGraph: it holds graph_mtx_, flame.cc:103, 309-318):
+ *   prepare  checks the inputs (same errors as sync_graph), copies them, and enqueues the construction of the new topology on a
+ *            side stream -- it only READS the live graph; returns at once.  The caller's arrays are free on return.
+ *   commit   waits for that construction, settles the runs enqueued meanwhile, swaps the new topology in and moves the state
+ *            (what sync_graph does after its index maps).  sync_graph == prepare; commit.
+ * Between the two only run / run_async / sync and read-outs (download_state, export, get_info) may be called; upload_graph,
+ * sync_graph, set_feature_ids or another prepare cancel the prepared sync (commit then returns FLAME_NLTGV2_ERR_INVALID_ARG). */
+int flame_nltgv2_sync_prepare(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in);
+int flame_nltgv2_sync_commit(flame_nltgv2_ctx* ctx);
 /* Declares the feature ids of the vertices of a graph brought in with flame_nltgv2_upload_graph (V ints,
  * unique): Flame::vtx_to_feat_ (flame.h:542-543). */
 int flame_nltgv2_set_feature_ids(flame_nltgv2_ctx* ctx, const int32_t* feat_id);
@@ -218,6 +233,13 @@ int flame_nltgv2_set_export_target(flame_nltgv2_ctx* ctx, void* dst_device, floa
  *   interpolate_mesh_arrays  the reference signature: explicit vertices / values / validity arrays */
 int flame_nltgv2_interpolate_mesh(flame_nltgv2_ctx* ctx, const int32_t* triangles, int32_t T, const uint8_t* tri_valid,
                                   int rows, int cols, float graph_scale, float* idepthmap_out, int32_t* coverage_out);
+/* interpolate_mesh in two halves, so that the solver iterates while the map is rasterised and copied out: begin settles the runs,
+ * brings the state to its canonical arrays and enqueues rasteriser + device-to-host copy on a side stream, returning at once (the
+ * caller goes on with run_async); end waits for that stream.  *map_out points at the context's pinned rows*cols floats (valid
+ * until the next begin); the map also stays on the device for flame_nltgv2_sync_input.init_from_map. */
+int flame_nltgv2_interpolate_mesh_begin(flame_nltgv2_ctx* ctx, const int32_t* triangles, int32_t T, const uint8_t* tri_valid,
+                                        int rows, int cols, float graph_scale);
+int flame_nltgv2_interpolate_mesh_end(flame_nltgv2_ctx* ctx, const float** map_out, int32_t* coverage_out);
 int flame_nltgv2_interpolate_mesh_arrays(flame_nltgv2_ctx* ctx, const int32_t* triangles, int32_t T,
                                          const float* vertices_xy, const float* values, int32_t V,
                                          const uint8_t* vtx_valid, const uint8_t* tri_valid, int rows, int cols,

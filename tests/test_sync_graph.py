@@ -307,3 +307,162 @@ def test_edges_unique_flag_skips_nothing_but_the_search(built):
     (ta, sa), (tb, sb) = outs
     assert all(np.array_equal(x, y) for x, y in zip(ta, tb))
     assert_state_equal(sa, sb, keys=OUT_KEYS, what="edges_unique")
+
+
+@pytest.mark.parametrize("config", ["320x240", "640x480"])
+def test_prepared_sync_beside_a_running_solver(built, config):
+    """flame_nltgv2_sync_prepare / _commit: the new frame's graph is built on a side stream while the solver keeps iterating on the
+    old one (run_async between the two halves); commit moves the state as it stands THEN.  Eight frames, every state array and the
+    edge list equal the syncGraph restatement's (which solves first, then syncs) -- plus the cases in which a prepared sync goes the
+    host way or is cancelled."""
+    import torch  # noqa: F401
+
+    import flame_amd
+
+    w, h = (int(s) for s in config.split("x"))
+    rng = np.random.default_rng(21)
+    g0 = synth.make_graph(config, seed=8)
+    feat_id = np.arange(g0["V"], dtype=np.int32) * 2 + 1
+    pos, data = g0["pos"].copy(), g0["data_term"].copy()
+    next_id = int(feat_id.max()) + 1
+    params = flame_amd.Params()
+    ref = sync_oracle.RefGraph.from_flat(g0, feat_id)
+
+    def ref_run(ids, n):
+        flat = sync_oracle.flatten(ref, ids)
+        assert oracle.run(flat, n) == 0
+        sync_oracle.absorb(ref, flat, ids)
+
+    with flame_amd.Regularizer(0) as reg:
+        reg.upload_graph(g0)
+        reg.set_feature_ids(feat_id)
+        reg.run(params, 20)
+        ref_run(feat_id, 20)
+        for frame in range(8):
+            old_ids = feat_id
+            feat_id, pos, data, next_id = next_frame(rng, feat_id, pos, data, next_id, w, h)
+            weight = (0.5 + rng.random(len(feat_id))).astype(np.float32)
+            edges = synth.delaunay_edges_scipy(pos)
+            init_x = (data * np.float32(1.01)).astype(np.float32)
+            gs = 0.0
+            if frame % 3 == 1:
+                init_x[rng.random(len(feat_id)) < 0.3] = np.nan
+                gs = 1.3
+            unique = frame != 5           # frame 5: no vouched-for edge list -> the host way at commit
+            fid_arg, pos_arg = feat_id.copy(), pos.copy()
+            reg.sync_prepare(fid_arg, pos_arg, data, weight, edges, init_x=init_x, check_sticky_obstacles=frame % 2 == 0,
+                             sticky_threshold=0.02, init_graph_scale=gs, edges_unique=unique)
+            fid_arg[:] = -7               # the caller's arrays are free once prepare returns
+            pos_arg[:] = np.nan
+            n_between = 0
+            for n in (17, 30, 8)[: 1 + frame % 3]:   # the solver keeps iterating on the OLD graph meanwhile
+                reg.run_async(params, n)
+                n_between += n
+            reg.sync_commit()
+            assert reg.info()["last_sync_path"] == (2 if unique else 1), frame
+            ref_run(old_ids, n_between)
+            sync_oracle.sync(ref, feat_id, pos, data, weight, edges, init_x=init_x, check_sticky=frame % 2 == 0, thr=0.02, init_graph_scale=gs)
+            flat = sync_oracle.flatten(ref, feat_id)
+            src, dst, fid = reg.topology()
+            assert np.array_equal(src, flat["src"]) and np.array_equal(dst, flat["dst"]) and np.array_equal(fid, feat_id), frame
+            assert_state_equal(reg.download_state(), flat, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"frame {frame} after commit")
+            assert reg.layout_selftest() == 0
+            reg.run(params, 25)
+            ref_run(feat_id, 25)
+            assert_state_equal(reg.download_state(), sync_oracle.flatten(ref, feat_id), keys=OUT_KEYS, what=f"frame {frame} after 25 steps")
+        # a commit with nothing prepared, and a prepared sync cancelled by an upload
+        with pytest.raises(flame_amd.NLTGV2Error):
+            reg.sync_commit()
+        f2, p2, d2, _ = next_frame(rng, feat_id, pos, data, next_id, w, h)
+        reg.sync_prepare(f2, p2, d2, np.ones(len(f2), np.float32), synth.delaunay_edges_scipy(p2), edges_unique=True)
+        reg.upload_graph(g0)
+        with pytest.raises(flame_amd.NLTGV2Error):
+            reg.sync_commit()
+        reg.run(params, 10)
+        chk = synth.copy_graph(g0)
+        assert oracle.run(chk, 10) == 0
+        assert_state_equal(reg.download_state(), chk, keys=OUT_KEYS, what="after the cancelled sync")
+        # a frame the builder declines (a hub of 70 edges): prepared on the device, committed the host way
+        hub_pos = np.concatenate([g0["pos"], np.array([[w / 2 + 0.37, h / 2 + 0.21]], np.float32)])
+        hub = len(hub_pos) - 1
+        e_all = synth.delaunay_edges_scipy(hub_pos)
+        have = {tuple(sorted(e)) for e in e_all.tolist()}
+        extra = [(int(v), hub) for v in rng.permutation(g0["V"])[:200] if tuple(sorted((int(v), hub))) not in have][:70]
+        e_hub = np.concatenate([e_all, np.array(extra, np.int32)])
+        fid_h = np.arange(len(hub_pos), dtype=np.int32)
+        data_h = np.concatenate([g0["data_term"], [1.0]]).astype(np.float32)
+        reg.set_feature_ids(np.arange(g0["V"], dtype=np.int32))
+        ref2 = sync_oracle.RefGraph.from_flat(chk, np.arange(g0["V"], dtype=np.int32))
+        reg.sync_prepare(fid_h, hub_pos, data_h, np.ones(len(fid_h), np.float32), e_hub, edges_unique=True)
+        reg.sync_commit()
+        assert reg.info()["last_sync_path"] == 1 and reg.info()["max_degree"] > 64
+        sync_oracle.sync(ref2, fid_h, hub_pos, data_h, np.ones(len(fid_h), np.float32), e_hub)
+        assert_state_equal(reg.download_state(), sync_oracle.flatten(ref2, fid_h), keys=OUT_KEYS, what="declined build, host way")
+
+
+@pytest.mark.parametrize("mode", SYNC_MODES + ["prepared"])
+def test_new_vertices_start_at_the_resident_dense_map(built, mode):
+    """flame_nltgv2_sync_input.init_from_map (init_with_prediction, flame.cc:2131): the prediction of a new vertex is read ON THE
+    DEVICE from the dense map the last interpolate_mesh left there -- idepthmap(pos.y + 0.5f, pos.x + 0.5f) / graph_scale, NaN (the
+    neighbours' mean) where no triangle covered the pixel -- and equals what the host gather of rounds 1-3 fed in as init_x.  The
+    map comes from interpolate_mesh_begin / _end with the solver iterating in between."""
+    import torch  # noqa: F401
+
+    import flame_amd
+
+    w, h = 320, 240
+    rng = np.random.default_rng(33)
+    g0 = synth.make_graph("320x240", seed=14)
+    feat_id = np.arange(g0["V"], dtype=np.int32)
+    pos, data = g0["pos"].copy(), g0["data_term"].copy()
+    next_id = g0["V"]
+    params = flame_amd.Params()
+    gs = np.float32(1.25)
+    ref = sync_oracle.RefGraph.from_flat(g0, feat_id)
+    with flame_amd.Regularizer(0) as reg:
+        reg.upload_graph(g0)
+        kw = _mode(reg, "device" if mode == "prepared" else mode)
+        tris = synth.delaunay_native(pos)[0]
+        for frame in range(4):
+            ids_now = feat_id
+            reg.run(params, 30)
+            # the dense map of this frame: two halves, the solver iterating in between
+            reg.interpolate_mesh_begin(tris, h, w, graph_scale=float(gs))
+            reg.run_async(params, 12)
+            dense, cov = reg.interpolate_mesh_end()
+            flat = sync_oracle.flatten(ref, ids_now)
+            assert oracle.run(flat, 30) == 0
+            assert oracle.run(flat, 12) == 0
+            sync_oracle.absorb(ref, flat, ids_now)
+            if frame == 0:  # the two-halves form against the one-call form on the same state
+                reg.sync()
+                chk = flame_amd.Regularizer(0)
+                chk.upload_graph(g0)
+                chk.run(params, 30)
+                one, cov1 = chk.interpolate_mesh(tris, h, w, graph_scale=float(gs))
+                chk.close()
+                assert np.array_equal(one, dense, equal_nan=True) and cov1 == cov
+            # next frame; the predictions the host would gather from the map
+            feat_id, pos, data, next_id = next_frame(rng, feat_id, pos, data, next_id, w, h)
+            weight = np.ones(len(feat_id), np.float32)
+            edges = synth.delaunay_edges_scipy(pos)
+            iy = (pos[:, 1] + np.float32(0.5)).astype(np.int32)
+            ix = (pos[:, 0] + np.float32(0.5)).astype(np.int32)
+            inside = (iy >= 0) & (iy < h) & (ix >= 0) & (ix < w)
+            init_x = np.full(len(feat_id), np.nan, np.float32)
+            init_x[inside] = dense[iy[inside], ix[inside]] / gs
+            assert np.isnan(init_x).any() and (~np.isnan(init_x)).any()
+            if mode == "prepared":
+                reg.sync_prepare(feat_id, pos, data, weight, edges, init_graph_scale=float(gs), init_from_map=True, **kw)
+                reg.run_async(params, 9)
+                flat = sync_oracle.flatten(ref, ids_now)
+                assert oracle.run(flat, 9) == 0
+                sync_oracle.absorb(ref, flat, ids_now)
+                reg.sync_commit()
+            else:
+                reg.sync_graph(feat_id, pos, data, weight, edges, init_graph_scale=float(gs), init_from_map=True, **kw)
+            sync_oracle.sync(ref, feat_id, pos, data, weight, edges, init_x=init_x, init_graph_scale=float(gs))
+            assert_state_equal(reg.download_state(), sync_oracle.flatten(ref, feat_id), keys=OUT_KEYS + ("x_prev",), what=f"frame {frame}")
+            tris = synth.delaunay_native(pos)[0]
+        with pytest.raises(flame_amd.NLTGV2Error):  # init_from_map needs the scale and excludes init_x
+            reg.sync_graph(feat_id, pos, data, weight, edges, init_from_map=True)
