@@ -1,6 +1,14 @@
-"""Per-frame stage timings of the chained rows (the frame loop of tests/test_pipeline.py at BASELINE sizes):
-Frame::create -> updateFeatureIDepths -> [projectFeatures scaffolding] -> Delaunay -> projectGraph -> syncGraph ->
-N NLTGV2 steps -> interpolateMesh, on the GPU through the C-ABI; `--cpu` also times the CPU checkers per stage."""
+"""The chained rows at BASELINE sizes (the frame loop of tests/test_pipeline.py): Frame::create -> updateFeatureIDepths ->
+[projectFeatures scaffolding] -> projectGraph -> Delaunay -> syncGraph -> NLTGV2 steps -> interpolateMesh, on the GPU through the C-ABI.
+
+  default        one stage after the other, each timed (what profiles/r0N_frame_loop_*.txt held up to round 3); `--cpu` also times
+                 the CPU checkers per stage
+  --pipelined    the loop as Flame::update() would drive it with the solver free-running (flame.cc:99-112): the solver iterates in
+                 chunks of --iters on its own stream the whole time; projectGraph, the commit of the frame's sync and the start of
+                 interpolateMesh are the only points at which it is settled.  Delaunay runs on the host, the sync's builder and the
+                 rasteriser on side streams, beside it.  Reported per frame: wall time, solver busy time (HIP events around every
+                 chunk), idle = wall - busy, iterations done.
+"""
 import argparse
 import os
 import sys
@@ -8,7 +16,7 @@ import time
 
 sys.path.insert(0, os.getcwd())
 import numpy as np
-import torch  # noqa: F401
+import torch
 
 import flame_amd
 from flame_amd import synth
@@ -20,6 +28,8 @@ ap.add_argument("--size", default="640x480")
 ap.add_argument("--iters", type=int, default=200)
 ap.add_argument("--frames", type=int, default=6)
 ap.add_argument("--cpu", action="store_true")
+ap.add_argument("--pipelined", action="store_true")
+ap.add_argument("--host-sync", action="store_true", help="index maps + layout tables on the host (rounds 1-3), for comparison")
 a = ap.parse_args()
 W, H = [int(v) for v in a.size.split("x")]
 sc = ss.PlaneScene(W, H, seed=21, normal=(0.2, -0.1, 1.0), distance=2.2)
@@ -57,39 +67,149 @@ def project_features(feats, k):  # vectorised scaffolding (float64), not a timed
     return np.concatenate(ids).astype(np.int32), np.concatenate(pos).astype(np.float32), np.concatenate(idp).astype(np.float32)
 
 
+def projection(prev, k):
+    q, t = sc.relative(prev, k)
+    R = (sc.cams[k][0] @ sc.cams[prev][0].T).astype(np.float32)
+    return (sc.K32 @ R @ sc.Kinv32).astype(np.float32), q, t
+
+
 P, SP = flame_amd.Params(), StereoParams()
 reg = flame_amd.Regularizer(0)
+if a.host_sync:
+    reg.set_option(flame_amd.regularizer.OPT_SYNC_PATH, 1)
 tr = FeatureTracker(sc.K32, sc.Kinv32, W, H)
 tr.add_frame(10, imgs[10]), tr.add_frame(11, imgs[11])
-prev = None
-for k in news:
-    t0 = time.perf_counter(); tr.add_frame(k, imgs[k]); tick("Frame::create (upload + pad + gradients)", t0)
-    poses = ss.poses_for(sc, [10, 11], k, 11)
-    t0 = time.perf_counter(); _, st = tr.update_feature_idepths(SP, k, 11, poses, feats); tick("updateFeatureIDepths (host records)", t0)
-    fid, pos, idp = project_features(feats, k)
-    t0 = time.perf_counter(); tris, edges = flame_amd.delaunay(pos); tick("Delaunay (host)", t0)
-    if prev is None:
-        g = synth.assemble_graph(pos, idp, edges)
-        t0 = time.perf_counter(); reg.upload_graph(g); reg.set_feature_ids(fid); tick("upload_graph (first frame)", t0)
-    else:
-        q, t = sc.relative(prev, k)
-        R = (sc.cams[k][0] @ sc.cams[prev][0].T).astype(np.float32)
-        KRKinv = (sc.K32 @ R @ sc.Kinv32).astype(np.float32)
-        t0 = time.perf_counter(); reg.project_graph(sc.K32, sc.Kinv32, KRKinv, q, t, (M, M, W - 2 * M, H - 2 * M)); tick("projectGraph", t0)
-        t0 = time.perf_counter(); reg.sync_graph(fid, pos, idp, np.ones(len(fid), np.float32), edges, edges_unique=True); tick("syncGraph", t0)
-    t0 = time.perf_counter(); reg.run(P, a.iters); tick("%d NLTGV2 steps" % a.iters, t0)
-    t0 = time.perf_counter(); dense, cov = reg.interpolate_mesh(tris, H, W); tick("interpolateMesh (+ D2H of the map)", t0)
-    tr.drop_frame(k)
-    prev = k
-print("%s: %d features, graph V=%d E=%d, %d updated in the last frame, coverage %.2f" % (a.size, len(feats), reg.V, reg.E, st["num_idepth_updates"], cov / (W * H)))
-tot = 0.0
-for name, v in T.items():
-    med = float(np.median(v[1:] if len(v) > 2 else v))
-    if "first frame" not in name:
-        tot += med
-    print("  %-42s %8.3f ms (median of %d)" % (name, med, len(v)))
-print("  %-42s %8.3f ms" % ("steady-state frame total", tot))
-if a.cpu:
+REGION = (M, M, W - 2 * M, H - 2 * M)
+
+if not a.pipelined:
+    prev = None
+    for k in news:
+        t0 = time.perf_counter(); tr.add_frame(k, imgs[k]); tick("Frame::create (upload + pad + gradients)", t0)
+        poses = ss.poses_for(sc, [10, 11], k, 11)
+        t0 = time.perf_counter(); _, st = tr.update_feature_idepths(SP, k, 11, poses, feats); tick("updateFeatureIDepths (host records)", t0)
+        fid, pos, idp = project_features(feats, k)
+        t0 = time.perf_counter(); tris, edges = flame_amd.delaunay(pos); tick("Delaunay (host)", t0)
+        if prev is None:
+            g = synth.assemble_graph(pos, idp, edges)
+            t0 = time.perf_counter(); reg.upload_graph(g); reg.set_feature_ids(fid); tick("upload_graph (first frame)", t0)
+        else:
+            KRKinv, q, t = projection(prev, k)
+            t0 = time.perf_counter(); reg.project_graph(sc.K32, sc.Kinv32, KRKinv, q, t, REGION); tick("projectGraph", t0)
+            t0 = time.perf_counter(); reg.sync_graph(fid, pos, idp, np.ones(len(fid), np.float32), edges, edges_unique=True); tick("syncGraph", t0)
+        t0 = time.perf_counter(); reg.run(P, a.iters); tick("%d NLTGV2 steps" % a.iters, t0)
+        t0 = time.perf_counter(); dense, cov = reg.interpolate_mesh(tris, H, W); tick("interpolateMesh (+ D2H of the map)", t0)
+        tr.drop_frame(k)
+        prev = k
+    print("%s: %d features, graph V=%d E=%d, %d updated in the last frame, coverage %.2f, sync path %s" % (
+        a.size, len(feats), reg.V, reg.E, st["num_idepth_updates"], cov / (W * H), {1: "host", 2: "device"}.get(reg.info()["last_sync_path"], "-")))
+    tot = 0.0
+    for name, v in T.items():
+        med = float(np.median(v[1:] if len(v) > 2 else v))
+        if "first frame" not in name:
+            tot += med
+        print("  %-42s %8.3f ms (median of %d)" % (name, med, len(v)))
+    print("  %-42s %8.3f ms" % ("steady-state frame total", tot))
+else:
+    # pass 1 (untimed): what the tracker and the scaffolding give every frame, so that the timed loop holds library calls only
+    plan, f1 = [], feats.copy()
+    for k in news:
+        tr.add_frame(k, imgs[k])
+        tr.update_feature_idepths(SP, k, 11, ss.poses_for(sc, [10, 11], k, 11), f1)
+        plan.append(project_features(f1, k))
+        tr.drop_frame(k)
+    stream = torch.cuda.Stream(priority=-1)
+    reg.set_stream(stream.cuda_stream)
+    events, rows = [], []
+
+    labels = []
+
+    iters_done = []
+
+    def solve(ms, label=""):  # one launch of about `ms` of iterations; label: what stood between the previous launch and this one
+        n = max(a.iters // 4, int(round(ms / chunk_ms * a.iters / 50.0)) * 50)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        reg.run_async(P, n)
+        e1.record(stream)
+        events.append((e0, e1))
+        labels.append(label)
+        iters_done.append(n)
+
+    tr.add_frame(news[0], imgs[news[0]])
+    tr.update_feature_idepths(SP, news[0], 11, ss.poses_for(sc, [10, 11], news[0], 11), feats)
+    tr.drop_frame(news[0])
+    fid, pos, idp = plan[0]
+    tris, edges = flame_amd.delaunay(pos)
+    reg.upload_graph(synth.assemble_graph(pos, idp, edges))
+    reg.set_feature_ids(fid)
+    reg.run(P, a.iters)
+    reg.interpolate_mesh_begin(tris, H, W)
+    reg.interpolate_mesh_end(copy=False)
+    torch.cuda.synchronize()
+    chunk_ms = 1.0
+    for _ in range(3):
+        solve(0.0)
+    torch.cuda.synchronize()
+    chunk_ms = min(e0.elapsed_time(e1) for e0, e1 in events) * 4  # --iters iterations on this graph, in ms (the probe ran iters / 4)
+    events.clear(), labels.clear(), iters_done.clear()
+    track_ms, host_ms, build_ms, rast_ms, prev = 0.3, 1.0, 0.3, 0.3, news[0]
+    for k, (fid, pos, idp) in zip(news[1:], plan[1:]):
+        ones = np.ones(len(fid), np.float32)
+        poses = ss.poses_for(sc, [10, 11], k, 11)
+        KRKinv, q, t = projection(prev, k)
+        n_ev = len(events)
+        t_frame = time.perf_counter()
+        solve(track_ms, "interpolate_mesh_end -> next frame")
+        t0 = time.perf_counter()
+        tr.add_frame(k, imgs[k])                                      # Frame::create
+        tr.update_feature_idepths(SP, k, 11, poses, feats)            # updateFeatureIDepths
+        track_ms = 0.9 * (time.perf_counter() - t0) * 1e3
+        reg.project_graph(sc.K32, sc.Kinv32, KRKinv, q, t, REGION)    # settles the solver
+        solve(1.08 * host_ms, "Frame::create + updateFeatureIDepths + projectGraph")  # ... which iterates on while the host triangulates
+        t0 = time.perf_counter()
+        tris, edges = flame_amd.delaunay(pos)
+        reg.sync_prepare(fid, pos, idp, ones, edges, edges_unique=True, init_from_map=True, init_graph_scale=1.0)
+        host_ms = (time.perf_counter() - t0) * 1e3
+        solve(build_ms, "Delaunay + sync_prepare (host)")  # ... and while the builder runs on its side stream
+        t0 = time.perf_counter()
+        reg.sync_commit()                                             # settles the solver: swap + state gather
+        t_commit = (time.perf_counter() - t0) * 1e3
+        solve(chunk_ms, "sync_commit")
+        reg.interpolate_mesh_begin(tris, H, W)                        # settles the solver; rasteriser + copy-out on a side stream
+        solve(max(chunk_ms, 1.05 * rast_ms), "interpolate_mesh_begin")
+        t0 = time.perf_counter()
+        dense, cov = reg.interpolate_mesh_end(copy=False)
+        rast_ms = 0.7 * rast_ms + 0.3 * (rast_ms + (time.perf_counter() - t0) * 1e3 - 0.02)
+        tr.drop_frame(k)
+        wall = (time.perf_counter() - t_frame) * 1e3
+        rows.append((wall, n_ev, len(events), host_ms, t_commit))
+        prev = k
+    reg.sync()
+    torch.cuda.synchronize()
+    print("%s pipelined: graph V=%d E=%d, coverage %.2f, sync path %s, %d iterations take %.3f ms" % (
+        a.size, reg.V, reg.E, cov / (W * H), {1: "host", 2: "device"}.get(reg.info()["last_sync_path"], "-"), a.iters, chunk_ms))
+    print("  frame   wall ms   solver busy ms   idle ms   idle %   iterations   Delaunay + prepare ms   commit call ms")
+    tot = []
+    for i, (wall, e_a, e_b, host, commit) in enumerate(rows):
+        busy = sum(e0.elapsed_time(e1) for e0, e1 in events[e_a:e_b])
+        idle = max(0.0, wall - busy)
+        n_it = sum(iters_done[e_a:e_b])
+        print("  %5d  %8.3f  %15.3f  %8.3f  %7.1f  %11d  %22.3f  %14.3f" % (i + 1, wall, busy, idle, 100 * idle / wall, n_it, host, commit))
+        if i >= 1:
+            tot.append((wall, busy, idle, n_it))
+    if tot:
+        w, b, idl, it = (float(np.median([r[j] for r in tot])) for j in range(4))
+        print("  steady state (median, first frame dropped): frame %.3f ms, solver busy %.3f ms, idle %.3f ms = %.1f %%, %d iterations per frame"
+              % (w, b, idl, 100 * idl / w, int(it)))
+    # where the solver stood still: the gap in front of every chunk (end of the previous chunk -> start of this one, on the device)
+    gaps = {}
+    first = rows[1][1] if len(rows) > 1 else 0
+    for i in range(max(first, 1), len(events)):
+        gaps.setdefault(labels[i], []).append(events[i - 1][1].elapsed_time(events[i][0]))
+    print("  solver idle by cause (device time between two launches, median over the frames): " +
+          ", ".join("%s %.3f ms" % (kk, float(np.median(v))) for kk, v in sorted(gaps.items(), key=lambda kv: -float(np.median(kv[1])))))
+    print("  recovered timeouts: %d" % reg.info()["timeouts_recovered"])
+if a.cpu and not a.pipelined:
     from oracle import capi as oracle
     from oracle import stereo_capi as so
 
