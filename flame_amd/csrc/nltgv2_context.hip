@@ -217,6 +217,7 @@ int topology_buffers(flame_nltgv2_ctx* ctx, bool want_e2, size_t n_wg_info, size
     }
   }
   ctx->topo++;
+  ctx->layout_pos_saved = false;  // (the positions that are about to stand ARE the layout's)
   ctx->tv_built = ctx->wg2_built = false;
   drop_graphs(ctx);
   refresh_args(ctx);
@@ -466,7 +467,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
               &ctx->wg_fetch, &ctx->wg_info, &ctx->wg_v0, &ctx->probe, &ctx->snap_hq, &ctx->snap_vstate, &ctx->snap_bar, &ctx->iperm,
               &ctx->order_m, &ctx->rid_of, &ctx->stage[0].d, &ctx->stage[1].d, &ctx->sync_init, &ctx->sync_vmap, &ctx->sync_emap, &ctx->sync_need,
               &ctx->wg_vfirst, &ctx->place_pool, &ctx->place_rank, &ctx->place_fill, &ctx->place_rec_off, &ctx->place_patch, &ctx->place_meas, &ctx->progress};
-  for (DevBuf* b : {&ctx->feat_stamp_d, &ctx->feat_val_d, &ctx->topo_scratch, &ctx->topo_dims}) ctx->all.push_back(b);
+  for (DevBuf* b : {&ctx->feat_stamp_d, &ctx->feat_val_d, &ctx->topo_scratch, &ctx->topo_dims, &ctx->layout_pos}) ctx->all.push_back(b);
   for (auto& b : ctx->nx) ctx->all.push_back(&b);
   for (auto& b : ctx->sp_v) ctx->all.push_back(&b);
   for (auto& b : ctx->sp_q) ctx->all.push_back(&b);
@@ -644,7 +645,7 @@ int flame_nltgv2_layout_selftest(flame_nltgv2_ctx* ctx, int64_t* mismatches) {
   if (rc) return rc;
   const int32_t V = ctx->L.V, E = ctx->L.E;
   std::vector<float> pos(2 * (size_t)V);
-  HIPCHK(ctx, hipMemcpyAsync(pos.data(), ctx->pos.p, sizeof(float) * pos.size(), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(pos.data(), ctx->layout_pos_saved ? ctx->layout_pos.p : ctx->pos.p, sizeof(float) * pos.size(), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   flame_nltgv2_graph g{};
   g.V = V, g.E = E, g.pos = pos.data(), g.src = ctx->h_src.data(), g.dst = ctx->h_dst.data();

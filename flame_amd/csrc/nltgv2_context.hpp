@@ -246,6 +246,11 @@ struct flame_nltgv2_ctx {
   // After a device-side build (nltgv2_topo_capi.hip) only L's scalars and h_feat are current; the vectors of L and h_src / h_dst are
   // brought up to date on demand (ensure_host_layout: the host sync path, layouts built on the host on demand, get_topology, the
   // self-test).
+  // The layout is a function of the positions it was built from (Morton walk).  Flame::projectGraph moves the positions between a
+  // build and the next sync: it then first copies them aside (layout_pos), so that the host image of the layout -- and the self-test --
+  // can be formed from what the device builder saw.
+  DevBuf layout_pos;
+  bool layout_pos_saved = false;
   bool host_layout_valid = true;
   uint64_t tv_counted_topo = ~0ull;  // get_info counted the vertex-per-lane waves of this topology
   int opt_sync_path = 0;          // 0 auto (device where it applies), 1 host index maps + host tables, 2 device or error
@@ -368,6 +373,7 @@ bool wants_e2(const flame_nltgv2_ctx* ctx);
 int ensure_host_layout(flame_nltgv2_ctx* ctx);  // the host image of the topology (ctx->L's vectors, h_src, h_dst) after a device build
 // ---- nltgv2_topo_capi.hip: the per-frame sync with the topology built on the device
 int topo_prepare(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, bool* applicable);  // builder enqueued on the side stream
+int topo_upload(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const StageCopy* extra, size_t n_extra, bool* done);  // upload_graph that way
 int topo_commit(flame_nltgv2_ctx* ctx, bool* done);                                             // solver stopped, sets swapped, state gathered
 int cancel_prepared(flame_nltgv2_ctx* ctx);  // before anything else changes the topology: waits for an in-flight builder, forgets it
 int sync_graph_host(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in);

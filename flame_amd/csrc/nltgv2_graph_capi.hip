@@ -41,7 +41,9 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
       {&ctx->w2p, g->w2_prev ? g->w2_prev : g->w2, fV}, {&ctx->data, g->data_term, fV},
       {&ctx->weight, g->data_weight, fV}, {&ctx->alpha, g->alpha, fE}, {&ctx->beta, g->beta, fE}, {&ctx->q1, g->q1, fE},
       {&ctx->q2, g->q2, fE}, {&ctx->q3, g->q3, fE}};
-  rc = upload_topology(ctx, g, state, sizeof(state) / sizeof(state[0]), /*long_lived=*/true);
+  bool on_device = false;  // the per-vertex layout tables by kernels (nltgv2_topo.hip) where that applies, else by the host builders
+  rc = topo_upload(ctx, g, state, sizeof(state) / sizeof(state[0]), &on_device);
+  if (!rc && !on_device) rc = upload_topology(ctx, g, state, sizeof(state) / sizeof(state[0]), /*long_lived=*/true);
   if (rc) return rc;
   const auto t_packed = std::chrono::steady_clock::now();
   LAUNCHCHK(ctx, launch_pack_static(ctx->c, ctx->f, ctx->stream));
@@ -463,6 +465,12 @@ int flame_nltgv2_project_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_project
   std::memcpy(geo.q, pr->q_ref_to_cmp, sizeof(geo.q));
   std::memcpy(geo.t, pr->t_ref_to_cmp, sizeof(geo.t));
   geo.rx = pr->region_x, geo.ry = pr->region_y, geo.rw = pr->region_w, geo.rh = pr->region_h;
+  if (!ctx->layout_pos_saved && V) {  // the layout was built from the positions as they stand: keep them (nltgv2_context.hpp: layout_pos)
+    rc = ensure(ctx, ctx->layout_pos, sizeof(float) * 2 * V);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->layout_pos.p, ctx->pos.p, sizeof(float) * 2 * V, hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->layout_pos_saved = true;
+  }
   LAUNCHCHK(ctx, launch_project_graph(ctx->c, graph_scale, geo, (uint8_t*)ctx->r_valid.p, ctx->stream));
   if (V) HIPCHK(ctx, hipMemcpyAsync(keep_out, ctx->r_valid.p, V, hipMemcpyDeviceToHost, ctx->stream));
   if (V && pos_out) HIPCHK(ctx, hipMemcpyAsync(pos_out, ctx->pos.p, sizeof(float) * 2 * V, hipMemcpyDeviceToHost, ctx->stream));

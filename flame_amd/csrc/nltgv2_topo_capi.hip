@@ -26,6 +26,46 @@ struct Carve {
 
 constexpr size_t kWalkPad = 256 * 64;  // k_topo_walk stages whole workgroups of 64 segments
 
+// Where the builder's scratch arrays lie in ctx->topo_scratch (sync: + the frame's ids / edges / init values and the index maps).
+struct ScratchMap {
+  size_t fid, edges, init, old_edge, first_k, scan, deg, cur, parent, minid, morton, key_out, width, wflag, vf0, vf1, seg0, seg1, counters, wg2_v0, vmap,
+      emap, old_feat, sort, total, sort_bytes, vpad;
+  int cc_bits, n_slices;
+};
+ScratchMap make_scratch(int32_t V, int32_t E, int32_t Vo, int32_t Eo, bool sync) {
+  ScratchMap m{};
+  const size_t fV = sizeof(float) * (size_t)V, fE = sizeof(float) * (size_t)E, iV = sizeof(int32_t) * (size_t)V;
+  m.n_slices = (V + kWave - 1) / kWave;
+  m.vpad = ((size_t)V + kWalkPad - 1) / kWalkPad * kWalkPad;
+  const int n_seg = (V + 255) / 256;
+  const int n_scan = (sync ? Eo + E : 0) + V + 1;
+  m.sort_bytes = topo_sort_temp_bytes(V, n_scan);
+  m.cc_bits = 1;
+  while ((1 << m.cc_bits) < V) ++m.cc_bits;
+  const size_t iM = sizeof(int32_t) << m.cc_bits;
+  Carve cv;
+  m.fid = cv.take(sync ? iV : 0), m.edges = cv.take(sync ? 2 * fE : 0), m.init = cv.take(sync ? fV : 0), m.old_edge = cv.take(sync ? fE : 0);
+  m.first_k = cv.take(sizeof(int32_t) * (size_t)std::max(sync ? Eo : 0, 1));
+  m.scan = cv.take(sizeof(int32_t) * (size_t)n_scan), m.deg = cv.take(iV), m.cur = cv.take(iV), m.parent = cv.take(iM), m.minid = cv.take(iM), m.morton = cv.take(iV);
+  m.key_out = cv.take(8 * (size_t)V), m.width = cv.take(sizeof(int32_t) * (size_t)m.n_slices);
+  m.wflag = cv.take(m.vpad), m.vf0 = cv.take(m.vpad), m.vf1 = cv.take(m.vpad), m.seg0 = cv.take(sizeof(int32_t) * (size_t)n_seg), m.seg1 = cv.take(sizeof(int32_t) * (size_t)n_seg);
+  m.counters = cv.take(64), m.wg2_v0 = cv.take(iV), m.vmap = cv.take(sync ? iV : 0), m.emap = cv.take(sync ? fE : 0);
+  m.old_feat = cv.take(sizeof(int32_t) * (size_t)std::max(sync ? Vo : 0, 1)), m.sort = cv.take(m.sort_bytes);
+  m.total = cv.off;
+  return m;
+}
+void bind_scratch(TopoBuild* t, char* sc, const ScratchMap& m) {
+  t->n_slices = m.n_slices;
+  t->old_edge = (int32_t*)(sc + m.old_edge), t->first_k = (int32_t*)(sc + m.first_k), t->scan = (int32_t*)(sc + m.scan);
+  t->deg = (int32_t*)(sc + m.deg), t->cur = (int32_t*)(sc + m.cur), t->parent = (int32_t*)(sc + m.parent), t->morton = (uint32_t*)(sc + m.morton);
+  t->cc_bits = m.cc_bits, t->minid = (int32_t*)(sc + m.minid);
+  t->key_out = (uint64_t*)(sc + m.key_out), t->width = (int32_t*)(sc + m.width);
+  t->wflag = (uint8_t*)(sc + m.wflag), t->vf[0] = (uint8_t*)(sc + m.vf0), t->vf[1] = (uint8_t*)(sc + m.vf1);
+  t->seg_count[0] = (int32_t*)(sc + m.seg0), t->seg_count[1] = (int32_t*)(sc + m.seg1);
+  t->sort_tmp = sc + m.sort, t->sort_tmp_bytes = m.sort_bytes, t->counters = (int*)(sc + m.counters);
+  t->wg2_v0 = (int32_t*)(sc + m.wg2_v0);
+}
+
 }  // namespace
 
 // Brings the host image of the current topology up to date after a device-side build: the edge list comes down, the host
@@ -35,7 +75,7 @@ int ensure_host_layout(flame_nltgv2_ctx* ctx) {
   const int32_t V = ctx->L.V, E = ctx->L.E;
   std::vector<float> pos(2 * (size_t)V);
   ctx->h_src.resize((size_t)E), ctx->h_dst.resize((size_t)E);
-  if (V) HIPCHK(ctx, hipMemcpyAsync(pos.data(), ctx->pos.p, sizeof(float) * pos.size(), hipMemcpyDeviceToHost, ctx->stream));
+  if (V) HIPCHK(ctx, hipMemcpyAsync(pos.data(), ctx->layout_pos_saved ? ctx->layout_pos.p : ctx->pos.p, sizeof(float) * pos.size(), hipMemcpyDeviceToHost, ctx->stream));
   if (E) HIPCHK(ctx, hipMemcpyAsync(ctx->h_src.data(), ctx->src.p, sizeof(int32_t) * (size_t)E, hipMemcpyDeviceToHost, ctx->stream));
   if (E) HIPCHK(ctx, hipMemcpyAsync(ctx->h_dst.data(), ctx->dst.p, sizeof(int32_t) * (size_t)E, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -49,8 +89,15 @@ int ensure_host_layout(flame_nltgv2_ctx* ctx) {
   L.tv_ok = dev.tv_ok, L.tv_waves = dev.tv_waves;
   const bool same = L.rows == dev.rows && L.n_slices == dev.n_slices && L.max_degree == dev.max_degree && L.wg_count == dev.wg_count &&
                     L.wg_lcap == dev.wg_lcap && L.wg_rowpack == dev.wg_rowpack &&
-                    (!dev.wg2_walked || (L.wg2_count == dev.wg2_count && L.wg2_lcap == dev.wg2_lcap));
-  if (!same) return fail(ctx, FLAME_NLTGV2_ERR_HIP);  // the device tables and the host builders disagree: a bug, never silent
+                    (!dev.wg2_ok || (L.wg2_ok && L.wg2_count == dev.wg2_count && L.wg2_lcap == dev.wg2_lcap));  // (the device walks (E2) always, the
+                                                                                                                 //  host only up to 32 edges per vertex)
+  if (!same) {  // the device tables and the host builders disagree: a bug, never silent
+    std::fprintf(stderr, "[flame_nltgv2] host image of a device-built layout differs: rows %ld / %ld, slices %d / %d, max degree %d / %d, patches %d / %d, "
+                 "lcap %d / %d, rowpack %d / %d, (E2) ok %d / %d patches %d / %d lcap %d / %d (host / device)\n", (long)L.rows, (long)dev.rows, L.n_slices, dev.n_slices,
+                 L.max_degree, dev.max_degree, L.wg_count, dev.wg_count, L.wg_lcap, dev.wg_lcap, (int)L.wg_rowpack, (int)dev.wg_rowpack, (int)L.wg2_ok,
+                 (int)dev.wg2_ok, L.wg2_count, dev.wg2_count, L.wg2_lcap, dev.wg2_lcap);
+    return fail(ctx, FLAME_NLTGV2_ERR_HIP);
+  }
   ctx->host_layout_valid = true;
   return 0;
 }
@@ -120,22 +167,13 @@ int topo_prepare(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, bool*
   // ---- buffers: scratch and the next topology.  Nothing here belongs to the live graph: growing one of them frees memory the
   // solver does not use (a hipFree still waits for the device: buffers grow geometrically, so a steady stream of frames stops growing)
   hipStream_t ts = ctx->topo_stream;
-  const int n_slices = (V + kWave - 1) / kWave;
+  const ScratchMap sm = make_scratch(V, E, Vo, Eo, /*sync=*/true);
+  const int n_slices = sm.n_slices;
   const size_t n_packed = (size_t)n_slices * kWave;
   const size_t fV = sizeof(float) * (size_t)V, fE = sizeof(float) * (size_t)E, iV = sizeof(int32_t) * (size_t)V;
-  const size_t vpad = ((size_t)V + kWalkPad - 1) / kWalkPad * kWalkPad;
-  const int n_seg = (V + 255) / 256;
-  const int n_scan = Eo + E + V + 1;
-  const size_t sort_bytes = topo_sort_temp_bytes(V, n_scan);
-  int cc_bits = 1;
-  while ((1 << cc_bits) < V) ++cc_bits;
-  const size_t iM = sizeof(int32_t) << cc_bits;
-  Carve cv;
-  const size_t o_fid = cv.take(iV), o_edges = cv.take(2 * fE), o_init = cv.take(fV), o_old_edge = cv.take(fE), o_first_k = cv.take(sizeof(int32_t) * (size_t)std::max(Eo, 1));
-  const size_t o_scan = cv.take(sizeof(int32_t) * (size_t)n_scan), o_deg = cv.take(iV), o_cur = cv.take(iV), o_parent = cv.take(iM), o_minid = cv.take(iM), o_morton = cv.take(iV);
-  const size_t o_key_out = cv.take(8 * (size_t)V), o_width = cv.take(sizeof(int32_t) * (size_t)n_slices);
-  const size_t o_wflag = cv.take(vpad), o_vf0 = cv.take(vpad), o_vf1 = cv.take(vpad), o_seg0 = cv.take(sizeof(int32_t) * (size_t)n_seg), o_seg1 = cv.take(sizeof(int32_t) * (size_t)n_seg);
-  const size_t o_counters = cv.take(64), o_wg2_v0 = cv.take(iV), o_vmap = cv.take(iV), o_emap = cv.take(fE), o_old_feat = cv.take(sizeof(int32_t) * (size_t)std::max(Vo, 1)), o_sort = cv.take(sort_bytes);
+  const size_t vpad = sm.vpad;
+  const size_t o_fid = sm.fid, o_edges = sm.edges, o_init = sm.init, o_vmap = sm.vmap, o_emap = sm.emap, o_old_feat = sm.old_feat;
+  struct { size_t off; } cv{sm.total};
   const size_t nx_bytes[flame_nltgv2_ctx::NX_COUNT] = {
       2 * fV, fE, fE, sizeof(int32_t) * ((size_t)V + 1), 2 * fE, iV, iV, sizeof(int32_t) * n_packed, iV, sizeof(int32_t) * n_packed,
       sizeof(int32_t) * ((size_t)n_slices + 1), 4 * iV, iV, vpad, 4 * iV, vpad, fV, fV};  // (patch tables by their upper bound: a patch holds at least one vertex)
@@ -183,7 +221,7 @@ int topo_prepare(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, bool*
   // ---- the builder ------------------------------------------------------------------------------------------------------------------
   using C = flame_nltgv2_ctx;
   TopoBuild t;
-  t.V = V, t.E = E, t.Vo = Vo, t.Eo = Eo, t.n_slices = n_slices;
+  t.V = V, t.E = E, t.Vo = Vo, t.Eo = Eo;
   t.fid = (const int32_t*)(sc + o_fid), t.pos = (const float2*)ctx->nx[C::NX_POS].p, t.tri_edges = (const int32_t*)(sc + o_edges);
   t.minx = minx, t.miny = miny;
   t.sx = (maxx > minx) ? 65535.0f / (maxx - minx) : 0.0f, t.sy = (maxy > miny) ? 65535.0f / (maxy - miny) : 0.0f;
@@ -191,20 +229,14 @@ int topo_prepare(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, bool*
   t.o_src = (const int32_t*)ctx->src.p, t.o_dst = (const int32_t*)ctx->dst.p;
   t.feat_stamp = (uint32_t*)ctx->feat_stamp_d.p, t.feat_val = (int32_t*)ctx->feat_val_d.p, t.tab_size = ctx->feat_tab_size_d;
   t.gen_prev = ctx->feat_gen, t.gen_new = ctx->feat_gen + 1;
-  t.old_edge = (int32_t*)(sc + o_old_edge), t.first_k = (int32_t*)(sc + o_first_k), t.scan = (int32_t*)(sc + o_scan);
-  t.deg = (int32_t*)(sc + o_deg), t.cur = (int32_t*)(sc + o_cur), t.parent = (int32_t*)(sc + o_parent), t.morton = (uint32_t*)(sc + o_morton);
-  t.cc_bits = cc_bits, t.minid = (int32_t*)(sc + o_minid);
-  t.key_out = (uint64_t*)(sc + o_key_out), t.width = (int32_t*)(sc + o_width);
-  t.wflag = (uint8_t*)(sc + o_wflag), t.vf[0] = (uint8_t*)(sc + o_vf0), t.vf[1] = (uint8_t*)(sc + o_vf1);
-  t.seg_count[0] = (int32_t*)(sc + o_seg0), t.seg_count[1] = (int32_t*)(sc + o_seg1);
-  t.sort_tmp = sc + o_sort, t.sort_tmp_bytes = sort_bytes, t.counters = (int*)(sc + o_counters);
+  bind_scratch(&t, sc, sm);
   t.old_of_new = (int32_t*)(sc + o_vmap), t.old_of_new_edge = (int32_t*)(sc + o_emap);
   t.src = (int32_t*)ctx->nx[C::NX_SRC].p, t.dst = (int32_t*)ctx->nx[C::NX_DST].p;
   t.row_ptr = (int32_t*)ctx->nx[C::NX_ROW_PTR].p, t.half = (uint32_t*)ctx->nx[C::NX_HALF].p;
   t.order_m = (int32_t*)ctx->nx[C::NX_ORDER_M].p, t.rid_of = (int32_t*)ctx->nx[C::NX_RID_OF].p, t.perm = (int32_t*)ctx->nx[C::NX_PERM].p;
   t.iperm = (int32_t*)ctx->nx[C::NX_IPERM].p, t.pdeg = (int32_t*)ctx->nx[C::NX_PDEG].p, t.slice_row = (int32_t*)ctx->nx[C::NX_SLICE_ROW].p;
   t.wg_info = (int32_t*)ctx->nx[C::NX_WG_INFO].p, t.wg_v0 = (int32_t*)ctx->nx[C::NX_WG_V0].p, t.wg_vfirst = (uint8_t*)ctx->nx[C::NX_WG_VFIRST].p;
-  t.wg2_info = (int32_t*)ctx->nx[C::NX_WG2_INFO].p, t.wg2_v0 = (int32_t*)(sc + o_wg2_v0), t.wg2_vfirst = (uint8_t*)ctx->nx[C::NX_WG2_VFIRST].p;
+  t.wg2_info = (int32_t*)ctx->nx[C::NX_WG2_INFO].p, t.wg2_vfirst = (uint8_t*)ctx->nx[C::NX_WG2_VFIRST].p;
   t.dims = (TopoDims*)ctx->topo_dims.p;
   ctx->feat_dev_valid = false;  // (the table moves on to the new graph: valid again once that graph stands)
   LAUNCHCHK(ctx, launch_topo_sync_front(t, ts));
@@ -217,6 +249,94 @@ int topo_prepare(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, bool*
   ctx->prep_vmap = sc + o_vmap, ctx->prep_emap = sc + o_emap, ctx->prep_init = sc + o_init;
   P.t_enqueued = std::chrono::steady_clock::now();
   *applicable = true;
+  return 0;
+}
+
+// upload_graph with the per-vertex tables built on the device: the caller's (pos, src, dst) go up in the one staged copy together
+// with the state, the builder runs on the context's stream in front of the slot / lane expansion.  *done = false: not a case for
+// the device builder (fewer than two vertices, no edge, a hub of more than 64 edges, a graph beyond the row-packed patch form,
+// FLAME_NLTGV2_OPT_SYNC_PATH = 1): the caller goes on with upload_topology, the host builders.
+int topo_upload(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const StageCopy* extra, size_t n_extra, bool* done) {
+  *done = false;
+  const int32_t V = g->V, E = g->E;
+  const int cus = ctx->prop.multiProcessorCount;
+  const bool rowpack = ctx->opt_persistent == 4 || (static_cast<int64_t>(2) * E + V / 32) / 54 + 1 <= (int64_t)kPvDensePerCu * cus;
+  if (ctx->opt_sync_path == 1 || !rowpack || V < 2 || E < 1 || V > (1 << 22) || (int64_t)E + V + 1 > 0x7fff0000ll) return 0;
+  {
+    uint32_t bad = 0;
+    for (int32_t k = 0; k < E; ++k) {
+      const uint32_t a = (uint32_t)g->src[k], b = (uint32_t)g->dst[k];
+      bad |= (a >= (uint32_t)V) | (b >= (uint32_t)V) | (a == b);
+    }
+    if (bad) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  }
+  float minx = g->pos[0], maxx = minx, miny = g->pos[1], maxy = miny;
+  for (int32_t v = 0; v < V; ++v) {
+    const float px = g->pos[2 * v], py = g->pos[2 * v + 1];
+    if (!std::isfinite(px) || !std::isfinite(py)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+    minx = std::min(minx, px), maxx = std::max(maxx, px);
+    miny = std::min(miny, py), maxy = std::max(maxy, py);
+  }
+  int rc = cancel_prepared(ctx);
+  if (rc) return rc;
+  const ScratchMap sm = make_scratch(V, E, 0, 0, /*sync=*/false);
+  const size_t n_packed = (size_t)sm.n_slices * kWave;
+  const size_t fV = sizeof(float) * (size_t)V, fE = sizeof(float) * (size_t)E, iV = sizeof(int32_t) * (size_t)V;
+  struct { DevBuf* b; size_t bytes; } req[] = {
+      {&ctx->topo_scratch, sm.total}, {&ctx->topo_dims, sizeof(TopoDims)}, {&ctx->pos, 2 * fV}, {&ctx->src, fE}, {&ctx->dst, fE},
+      {&ctx->row_ptr, sizeof(int32_t) * ((size_t)V + 1)}, {&ctx->half, 2 * fE}, {&ctx->slice_row, sizeof(int32_t) * ((size_t)sm.n_slices + 1)},
+      {&ctx->perm, sizeof(int32_t) * n_packed}, {&ctx->pdeg, sizeof(int32_t) * n_packed}, {&ctx->iperm, iV}, {&ctx->order_m, iV}, {&ctx->rid_of, iV},
+      {&ctx->wg_info, 4 * iV}, {&ctx->wg_v0, iV}, {&ctx->wg_vfirst, sm.vpad}, {&ctx->wg2_info, 4 * iV}, {&ctx->wg2_vfirst, sm.vpad}};
+  for (auto& r : req) {
+    rc = ensure(ctx, *r.b, r.bytes);
+    if (rc) return rc;
+  }
+  if (!ctx->h_dims && hipHostMalloc((void**)&ctx->h_dims, sizeof(TopoDims), hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(ctx, FLAME_NLTGV2_ERR_OOM);
+  }
+  if (ctx->raster_inflight) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_raster_done, 0));  // (it reads the positions this replaces)
+  std::vector<StageCopy> cp = {{&ctx->pos, g->pos, 2 * fV}, {&ctx->src, g->src, fE}, {&ctx->dst, g->dst, fE}};
+  cp.insert(cp.end(), extra, extra + n_extra);
+  rc = staged_h2d(ctx, cp.data(), cp.size());
+  if (rc) return rc;
+  char* const sc = static_cast<char*>(ctx->topo_scratch.p);
+  TopoBuild t;
+  t.V = V, t.E = E;
+  t.pos = (const float2*)ctx->pos.p;
+  t.minx = minx, t.miny = miny;
+  t.sx = (maxx > minx) ? 65535.0f / (maxx - minx) : 0.0f, t.sy = (maxy > miny) ? 65535.0f / (maxy - miny) : 0.0f;
+  bind_scratch(&t, sc, sm);
+  t.src = (int32_t*)ctx->src.p, t.dst = (int32_t*)ctx->dst.p, t.row_ptr = (int32_t*)ctx->row_ptr.p, t.half = (uint32_t*)ctx->half.p;
+  t.order_m = (int32_t*)ctx->order_m.p, t.rid_of = (int32_t*)ctx->rid_of.p, t.perm = (int32_t*)ctx->perm.p, t.iperm = (int32_t*)ctx->iperm.p;
+  t.pdeg = (int32_t*)ctx->pdeg.p, t.slice_row = (int32_t*)ctx->slice_row.p;
+  t.wg_info = (int32_t*)ctx->wg_info.p, t.wg_v0 = (int32_t*)ctx->wg_v0.p, t.wg_vfirst = (uint8_t*)ctx->wg_vfirst.p;
+  t.wg2_info = (int32_t*)ctx->wg2_info.p, t.wg2_vfirst = (uint8_t*)ctx->wg2_vfirst.p;
+  t.dims = (TopoDims*)ctx->topo_dims.p;
+  LAUNCHCHK(ctx, launch_topo_upload_front(t, ctx->stream));
+  LAUNCHCHK(ctx, launch_topo_back(t, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_dims, ctx->topo_dims.p, sizeof(TopoDims), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const TopoDims dm = *ctx->h_dims;
+  if (dm.flags != 0 || (ctx->opt_persistent != 4 && dm.wg_count > kPvDensePerCu * cus)) return 0;  // the host builders take over
+  PackedLayout& L = ctx->L;
+  L.V = V, L.E = E, L.n_slices = sm.n_slices, L.rows = dm.rows, L.max_degree = dm.max_degree;
+  L.wg_ok = true, L.wg_rowpack = true, L.wg_count = dm.wg_count, L.wg_lcap = dm.wg_lcap, L.wg_slab_slots = 0, L.n_rec = V;
+  L.wg2_walked = true, L.wg2_ok = dm.max_degree <= 32 && dm.wg2_count > 0, L.wg2_count = dm.wg2_count, L.wg2_lcap = dm.wg2_lcap;
+  L.tv_ok = false, L.tv_waves = 0;
+  ctx->host_layout_valid = false;
+  const bool want_e2 = wants_e2(ctx) && L.wg2_ok && L.wg2_count <= kPv2WavesPerCu * cus * 4;
+  rc = topology_buffers(ctx, want_e2, 4 * (size_t)L.wg_count, (size_t)L.wg_count, (size_t)V, 4 * (size_t)L.wg2_count, (size_t)V);
+  if (rc) return rc;
+  std::vector<StageFill> fills;
+  topology_fills(ctx, want_e2, &fills);
+  rc = staged_h2d(ctx, nullptr, 0, fills.data(), fills.size());
+  if (rc) return rc;
+  rc = topology_expand(ctx, want_e2);
+  if (rc) return rc;
+  ctx->feat_dev_valid = false;  // (the device's feature table describes the previous graph)
+  HIPCHK(ctx, hipEventRecord(ctx->ev_topo_ready, ctx->stream));
+  *done = true;
   return 0;
 }
 
