@@ -564,6 +564,10 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
       if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_tv_lds = value;
       return 0;
+    case FLAME_NLTGV2_OPT_COST_SUM:
+      if (value < 0 || value > 1) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_cost_sum = value;
+      return 0;
     case FLAME_NLTGV2_OPT_SYNC_PATH:
       if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_sync_path = value;

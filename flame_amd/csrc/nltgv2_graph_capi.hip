@@ -591,8 +591,18 @@ int flame_nltgv2_costs(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, floa
   const size_t E = (size_t)ctx->L.E, V = (size_t)ctx->L.V, n = 2 * E + V;
   rc = ensure(ctx, ctx->cost_terms, sizeof(float) * n);
   if (rc) return rc;
-  ctx->h_terms.resize(n);
   LAUNCHCHK(ctx, launch_cost_terms(ctx->c, (float*)ctx->cost_terms.p, ctx->stream));
+  if (ctx->opt_cost_sum == 1) {
+    // FLAME_NLTGV2_OPT_COST_SUM = 1: both sums by k_block_sum on the device, 8 bytes come back (the statistics of a frame loop,
+    // flame.cc:2172-2173: ~10 us instead of a 2E + V float copy and as many dependent additions on the host)
+    LAUNCHCHK(ctx, launch_cost_sums(ctx->c, (const float*)ctx->cost_terms.p, (float*)ctx->cost_out.p, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_cost, ctx->cost_out.p, 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (smoothness) *smoothness = p->data_factor * ctx->h_cost[0];
+    if (data) *data = ctx->h_cost[1];
+    return FLAME_NLTGV2_OK;
+  }
+  ctx->h_terms.resize(n);
   if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->h_terms.data(), ctx->cost_terms.p, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   float cost = 0.0f;

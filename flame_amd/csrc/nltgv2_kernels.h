@@ -264,5 +264,6 @@ int launch_photo_residual(const CanonArgs& c, float graph_scale, const PhotoGeom
                           const uint8_t* cmp, int rows, int cols, int step, int border, float* err, hipStream_t s);
 int launch_photo_residual_packed(const FusedArgs& a, const PhotoFuse& photo, hipStream_t s);
 int launch_cost_terms(const CanonArgs& c, float* terms, hipStream_t s);
+int launch_cost_sums(const CanonArgs& c, const float* terms, float* out2, hipStream_t s);
 
 }  // namespace flame_hip

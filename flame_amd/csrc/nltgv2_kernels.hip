@@ -437,8 +437,8 @@ k_raster_resolve(long n, const unsigned long long* __restrict__ keys, float* __r
 //                     vector: uv = q.vec x v; uv += uv; v + w*uv + q.vec x uv), write pos and
 //                     x = idepth_new / scale back, and report which vertices stay
 //                     (cv::Rect_<float>::contains, idepth_new >= 0).
-//   k_rescale_*       the rescale_data block, flame.cc:328-351; the mean of data_term*scale is summed
-//                     sequentially in vertex order by one lane (the reference's order is BGL hash order).
+//   k_rescale_*       the rescale_data block, flame.cc:328-351; the mean of data_term*scale by k_block_sum (the reference's
+//                     order is BGL hash order, i.e. unspecified: a fixed strided / pairwise order here).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_project_graph(int V, float2* __restrict__ pos, float* __restrict__ x, float graph_scale, ProjectGeometry geo,
@@ -480,11 +480,25 @@ k_project_graph(int V, float2* __restrict__ pos, float* __restrict__ x, float gr
   keep[v] = (inside && !(nid < 0.0f)) ? 1 : 0;
 }
 
-__global__ void k_rescale_mean(int V, const float* __restrict__ data, float graph_scale, float* __restrict__ out2) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// Sum of in[i] * scale over i < n in a FIXED order (so that a CPU restatement reproduces it bit for bit: oracle/photometric_oracle.c
+// strided_tree_sum): thread t of one 1024-thread workgroup adds up the elements t, t + 1024, t + 2048, ... sequentially; the 1024
+// partial sums are combined pairwise, p[t] += p[t + s] for s = 512, 256, ..., 1.  Used where the reference's own order is
+// unspecified -- its vertex loops walk a hash set (flame.cc:328-351, nltgv2...cc:73-85) -- : one lane adding 57 k terms one after
+// the other took milliseconds for an order that buys no parity.  *out = sum / divisor.
+constexpr int kSumThreads = 1024;
+__global__ void __launch_bounds__(kSumThreads)
+k_block_sum(const int n, const float* __restrict__ in, const float scale, const float divisor, float* __restrict__ out) {
+  __shared__ float p[kSumThreads];
+  const int t = threadIdx.x;
   float sum = 0.0f;
-  for (int v = 0; v < V; ++v) sum += data[v] * graph_scale;
-  out2[0] = sum / V;  // new_scale
+  for (int i = t; i < n; i += kSumThreads) sum += in[i] * scale;
+  p[t] = sum;
+  __syncthreads();
+  for (int s = kSumThreads / 2; s > 0; s >>= 1) {
+    if (t < s) p[t] += p[t + s];
+    __syncthreads();
+  }
+  if (t == 0) *out = p[0] / divisor;
 }
 
 __global__ void __launch_bounds__(256)
@@ -612,7 +626,7 @@ int launch_project_graph(const CanonArgs& c, float graph_scale, const ProjectGeo
 
 int launch_rescale(const CanonArgs& c, float graph_scale, float* new_scale_dev, hipStream_t s) {
   if (c.V <= 0) return 0;
-  hipLaunchKernelGGL(k_rescale_mean, dim3(1), dim3(64), 0, s, c.V, c.data, graph_scale, new_scale_dev);
+  hipLaunchKernelGGL(k_block_sum, dim3(1), dim3(kSumThreads), 0, s, c.V, c.data, graph_scale, (float)c.V, new_scale_dev);  // new_scale = mean
   hipLaunchKernelGGL(k_rescale_apply, grid1d(c.V), dim3(256), 0, s, c.V, c.x, c.xb, c.xp, c.data, graph_scale,
                      new_scale_dev);
   return (int)hipGetLastError();
@@ -674,6 +688,13 @@ k_cost_terms(int E, int V, const int32_t* __restrict__ src, const int32_t* __res
     diff = (diff > 0) ? diff : -diff;
     terms[2 * (size_t)E + v] = diff;
   }
+}
+
+// both cost sums on the device (FLAME_NLTGV2_OPT_COST_SUM = 1): out2[0] = sum of the 2E smoothness addends, out2[1] = of the V data addends
+int launch_cost_sums(const CanonArgs& c, const float* terms, float* out2, hipStream_t s) {
+  hipLaunchKernelGGL(k_block_sum, dim3(1), dim3(kSumThreads), 0, s, 2 * c.E, terms, 1.0f, 1.0f, out2);
+  hipLaunchKernelGGL(k_block_sum, dim3(1), dim3(kSumThreads), 0, s, c.V, terms + 2 * (size_t)c.E, 1.0f, 1.0f, out2 + 1);
+  return (int)hipGetLastError();
 }
 
 int launch_cost_terms(const CanonArgs& c, float* terms, hipStream_t s) {

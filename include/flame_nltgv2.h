@@ -169,7 +169,9 @@ typedef struct flame_nltgv2_projection {
 int flame_nltgv2_project_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_projection* pr, float graph_scale,
                                uint8_t* keep_out, float* pos_out);
 /* The rescale_data block of Flame::update (flame.cc:328-351): new_scale = mean(data_term*graph_scale);
- * x, x_bar, x_prev, data_term *= graph_scale/new_scale; params->data_factor *= new_scale/graph_scale. */
+ * x, x_bar, x_prev, data_term *= graph_scale/new_scale; params->data_factor *= new_scale/graph_scale.
+ * (The reference forms the mean over a hash set, i.e. in an unspecified order; here in a fixed order -- 1024 strided partial sums
+ * combined pairwise -- that the checker restates: oracle/photometric_oracle.c strided_tree_sum.) */
 int flame_nltgv2_rescale_data(flame_nltgv2_ctx* ctx, float graph_scale, float* new_graph_scale, flame_nltgv2_params* params);
 
 /* Per-frame refresh of data_term/data_weight for an unchanged topology (flame.cc:1985-2018). */
@@ -306,6 +308,11 @@ enum {
                                         device wherever that applies (a duplicate-free edge list -- edges_unique --, feature ids below 4 M, no
                                         vertex of more than 64 edges), on the host otherwise; 1 = always on the host; 2 = on the device or
                                         FLAME_NLTGV2_ERR_INVALID_ARG.  Same result either way */
+
+  FLAME_NLTGV2_OPT_COST_SUM = 18,    /* flame_nltgv2_costs: 0 (default) = the addends are summed sequentially in float, in the reference's edge
+                                        order and the caller's vertex order, on the host: smoothnessCost equals the reference's to the last
+                                        bit; 1 = both sums on the device in a fixed strided / pairwise order (a few microseconds, no copy of
+                                        2E + V floats; agrees with the sequential sums to ~1e-6 relative) */
 
   FLAME_NLTGV2_OPT_EXPERIMENTAL = 100, /* ---- not part of the stable surface from here on ---- */
   FLAME_NLTGV2_OPT_BLOCK_WAVES = 103,  /* waves per workgroup of the fused sweep: 0 = auto, 1,2,4 */

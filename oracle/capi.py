@@ -84,6 +84,8 @@ def lib():
         L.graph_project.restype = None
         L.graph_rescale.argtypes = [C.c_int, _FP, _FP, _FP, _FP, C.c_float, _FP]
         L.graph_rescale.restype = C.c_float
+        L.strided_tree_sum.argtypes = [C.c_int, _FP, C.c_float]
+        L.strided_tree_sum.restype = C.c_float
         L.raster_triangle_barycentric.argtypes = [C.c_int] * 6 + [C.c_float] * 3 + [_FP, C.c_int, C.c_int]
         L.raster_triangle_barycentric.restype = None
         L.raster_interpolate_mesh.argtypes = [C.c_int, _IP, _FP, _FP, U8, U8, _FP, C.c_int, C.c_int]
@@ -245,6 +247,12 @@ def graph_project(pos, x, graph_scale, K, Kinv, q, t, KRKinv, region):
                         ki.ctypes.data_as(_FP), qq.ctypes.data_as(_FP), tt.ctypes.data_as(_FP), kr.ctypes.data_as(_FP),
                         region[0], region[1], region[2], region[3], keep.ctypes.data_as(C.POINTER(C.c_uint8)))
     return keep
+
+
+def strided_tree_sum(values, scale=1.0):
+    """Sum in the fixed order of the device's k_block_sum (1024 strided partial sums, combined pairwise)."""
+    v = np.ascontiguousarray(values, np.float32)
+    return float(lib().strided_tree_sum(int(v.size), v.ctypes.data_as(_FP), C.c_float(scale)))
 
 
 def graph_rescale(g, graph_scale, data_factor):

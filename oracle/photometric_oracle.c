@@ -132,11 +132,25 @@ void graph_project(int V, float* pos, float* x, float graph_scale, const float* 
   }
 }
 
-/* flame.cc:328-351; the sum runs in the caller's vertex order (the reference's is BGL hash order). */
+/* The fixed summation order of the device's k_block_sum (flame_amd/csrc/nltgv2_kernels.hip): 1024 partial sums over the elements
+ * t, t + 1024, ..., each sequential in float, combined pairwise p[t] += p[t + s], s = 512 ... 1.  Used where the reference's own
+ * order is unspecified (it walks a hash set). */
+float strided_tree_sum(int n, const float* in, float scale) {
+  float p[1024];
+  for (int t = 0; t < 1024; ++t) {
+    float sum = 0.0f;
+    for (int i = t; i < n; i += 1024) sum += in[i] * scale;
+    p[t] = sum;
+  }
+  for (int s = 512; s > 0; s >>= 1)
+    for (int t = 0; t < s; ++t) p[t] += p[t + s];
+  return p[0];
+}
+
+/* flame.cc:328-351; the reference sums over BGL's hash order (unspecified): here in the order of strided_tree_sum. */
 float graph_rescale(int V, float* x, float* x_bar, float* x_prev, float* data_term, float graph_scale,
                     float* data_factor) {
-  float idepth_sum = 0.0f;
-  for (int v = 0; v < V; ++v) idepth_sum += data_term[v] * graph_scale;
+  const float idepth_sum = strided_tree_sum(V, data_term, graph_scale);
   const float new_scale = idepth_sum / V;
   for (int v = 0; v < V; ++v) {
     x[v] = x[v] * graph_scale / new_scale;

@@ -699,6 +699,37 @@ def test_export_target_switched_inside_a_replayed_chain(env, form):
         assert np.array_equal(rows[0].cpu().numpy(), want_a)
 
 
+def test_costs_summed_on_the_device_in_a_fixed_order(env):
+    """FLAME_NLTGV2_OPT_COST_SUM = 1: smoothnessCost / dataCost (cc:51-85) with both sums formed on the device by k_block_sum -- 1024
+    strided partial sums combined pairwise.  Bit-equal to the CPU restatement of that order over the reference's addends, and within
+    1e-5 of the sequential sums of the default path (which stay bit-equal to the checker's)."""
+    flame_amd, oracle = env
+    for config in ("320x240", "1920x1080"):
+        g = synth.make_graph(config, seed=4)
+        p = flame_amd.Params()
+        with flame_amd.Regularizer(0) as reg:
+            reg.upload_graph(g)
+            reg.run(p, 40)
+            exact = reg.costs(p)
+            reg.set_option(flame_amd.regularizer.OPT_COST_SUM, 1)
+            fast = reg.costs(p)
+            st = reg.download_state()
+        ref = synth.copy_graph(g)
+        oracle.run(ref, 40)
+        assert exact == oracle.costs(ref)
+        f = np.float32
+        i, j = g["src"], g["dst"]
+        dx, dy = g["pos"][i, 0] - g["pos"][j, 0], g["pos"][i, 1] - g["pos"][j, 1]
+        a = np.abs(((st["x"][i] - st["x"][j]) - st["w1"][i] * dx) - st["w2"][i] * dy)
+        terms = np.empty(2 * g["E"], f)
+        terms[0::2] = g["alpha"] * a
+        terms[1::2] = g["beta"] * np.abs(st["w1"][i] - st["w1"][j]) + g["beta"] * np.abs(st["w2"][i] - st["w2"][j])
+        dterms = np.abs((st["x"] - g["data_term"]) * g["data_weight"]).astype(f)
+        assert f(fast[0]) == f(p.data_factor) * f(oracle.strided_tree_sum(terms)), config
+        assert f(fast[1]) == f(oracle.strided_tree_sum(dterms)), config
+        assert abs(fast[0] - exact[0]) <= 1e-5 * abs(exact[0]) and abs(fast[1] - exact[1]) <= 1e-5 * abs(exact[1])
+
+
 def test_run_timed_and_info(env):
     flame_amd, _ = env
     g = synth.make_graph("640x480", seed=1)
