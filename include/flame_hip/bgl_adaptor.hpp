@@ -4,9 +4,11 @@
 //
 // Include this header AFTER the reference's nltgv2_l1_graph_regularizer.h inside the FLaME tree.  It needs
 // Boost.Graph and the reference's VertexData/EdgeData; Boost is absent from the build image of this repository, so here
-// it is compiled and run only against tests/cpp/mock_boost/ -- a test-only look-alike of the dozen BGL calls it makes
-// (not the reference, not Boost: a compile check of the call shapes, stated as such in DESIGN.md) -- and against real
-// Boost only inside the FLaME tree.
+// it is compiled and run only against tests/cpp/mock_boost/ -- a test-only model of the interface Boost 1.58 documents for
+// adjacency_list<hash_setS, hash_setS, undirectedS>: void* vertex descriptors, value-type edge descriptors, graph_traits,
+// node-based edge list, no parallel edges, clear_vertex / remove_vertex (not the reference, not Boost: a check of the call
+// shapes and of the behaviour the adaptor relies on, stated as such in DESIGN.md) -- and against real Boost only inside
+// the FLaME tree.
 //
 // Order and orientation are taken exactly as the reference's loops see them:
 //   vertices: boost::vertices(graph) order               (cc:35-42, 145-151, 158-171)
@@ -17,6 +19,7 @@
 #define FLAME_HIP_BGL_ADAPTOR_HPP_
 
 #include <boost/graph/adjacency_list.hpp>
+#include <cstdint>
 #include <unordered_map>
 
 #include "flame_hip/nltgv2_l1_graph_regularizer.hpp"
@@ -56,6 +59,24 @@ struct GraphAccess<boost::adjacency_list<OutEdgeS, VertexS, DirS, VP, EP, GP, Ed
   }
 
   static void size(const Graph& g, size_t* V, size_t* E) { *V = boost::num_vertices(g), *E = boost::num_edges(g); }
+
+  // Which vertex and edge objects stand at which position of vertices() / edges(): the descriptors of a hash_setS graph are the
+  // addresses of its nodes (void*; an edge descriptor carries the address of its property), so a running hash over them in walk
+  // order changes with every add_ / remove_ that moves an object to another position -- also one that leaves both counts alone.
+  static uint64_t identity(const Graph& g) {
+    uint64_t h = 0x243f6a8885a308d3ull;
+    typename Graph::vertex_iterator vit, vend;
+    boost::tie(vit, vend) = boost::vertices(g);
+    for (; vit != vend; ++vit) h = mix_identity(h, (uint64_t)(uintptr_t)(const void*)*vit);
+    typename Graph::edge_iterator eit, eend;
+    boost::tie(eit, eend) = boost::edges(g);
+    for (; eit != eend; ++eit) {
+      h = mix_identity(h, (uint64_t)(uintptr_t)(const void*)boost::source(*eit, g));
+      h = mix_identity(h, (uint64_t)(uintptr_t)(const void*)boost::target(*eit, g));
+      h = mix_identity(h, (uint64_t)(uintptr_t)(const void*)&g[*eit]);
+    }
+    return h;
+  }
 
   // By position in vertices()/edges() order: DeviceGraph::download() only calls this for a graph with the vertex and
   // edge counts (and, where the caller tracks it, the edit generation) of the one that was packed.

@@ -68,8 +68,19 @@ struct FlatArrays {
 //   static void pack(const Graph&, FlatArrays*)      vertices()/edges() order; (src,dst) = (source,target)
 //   static void unpack(const FlatArrays&, Graph*)    writes x,w,x_bar,w_bar,x_prev,w_prev,q back
 //   static void size(const Graph&, size_t* V, size_t* E)
+//   static uint64_t identity(const Graph&)           a hash of WHICH objects stand at which position of vertices()/edges()
+//                                                    (0 where positions are stable by construction): download() refuses a graph
+//                                                    whose identity differs from the uploaded one's -- an edit that leaves the
+//                                                    counts alone (remove_edge + add_edge) still moves objects to other positions
 template <class Graph>
 struct GraphAccess;
+
+inline uint64_t mix_identity(uint64_t h, uint64_t v) {  // (splitmix64 step: order-sensitive running hash)
+  h += 0x9e3779b97f4a7c15ull + v;
+  h = (h ^ (h >> 30)) * 0xbf58476d1ce4e5b9ull;
+  h = (h ^ (h >> 27)) * 0x94d049bb133111ebull;
+  return h ^ (h >> 31);
+}
 
 // Dependency-free graph container with the reference's VertexData/EdgeData field names (h:74-102).
 struct VertexData {
@@ -110,6 +121,7 @@ struct GraphAccess<FlatGraph> {
     }
   }
   static void size(const FlatGraph& g, size_t* V, size_t* E) { *V = g.vertices.size(), *E = g.edges.size(); }
+  static uint64_t identity(const FlatGraph&) { return 0; }  // (vector positions: stable by construction)
   static void unpack(const FlatArrays& f, FlatGraph* g) {
     for (size_t v = 0; v < g->vertices.size(); ++v) {
       VertexData& d = g->vertices[v];
@@ -184,6 +196,7 @@ class DeviceGraph {
     flame_nltgv2_graph v = flat_.view();
     check(flame_nltgv2_upload_graph(ctx_, &v), "upload_graph");
     uploaded_v_ = flat_.x.size(), uploaded_e_ = flat_.src.size(), generation_ = generation, uploaded_ = true;
+    identity_ = flame_hip::GraphAccess<Graph>::identity(graph);
   }
   // Before Flame::update reads x, w1, w2 (flame.cc:372-380) or edits the graph.  Values go back to the objects they
   // came from BY POSITION in vertices()/edges() order, so the graph must be the one that was uploaded: a graph whose
@@ -200,7 +213,8 @@ class DeviceGraph {
   bool matches(const Graph& graph, uint64_t generation = 0) const {
     size_t V = 0, E = 0;
     flame_hip::GraphAccess<Graph>::size(graph, &V, &E);
-    return uploaded_ && V == uploaded_v_ && E == uploaded_e_ && generation == generation_;
+    return uploaded_ && V == uploaded_v_ && E == uploaded_e_ && generation == generation_ &&
+           flame_hip::GraphAccess<Graph>::identity(graph) == identity_;
   }
   uint64_t generation() const { return generation_; }
 
@@ -221,6 +235,37 @@ class DeviceGraph {
     in.check_sticky_obstacles = check_sticky_obstacles ? 1 : 0;
     in.sticky_threshold = 0.25f;  // flame.cc:2011
     check(flame_nltgv2_sync_graph(ctx_, &in), "sync_graph");
+  }
+
+  // The same sync in two halves (flame_nltgv2_sync_prepare / _commit): prepare under graph_mtx_ right after the triangulation --
+  // it only reads the device image, the solver thread goes on stepping --, commit under graph_mtx_ when Flame::update would have
+  // left syncGraph.  init_from_map: new vertices start at the prediction of the dense map the last interpolateMesh left on the
+  // device (init_with_prediction, flame.cc:2131) instead of a host gather into init_x.
+  void syncPrepare(const std::vector<int32_t>& feat_id, const std::vector<float>& pos_xy, const std::vector<float>& data_term,
+                   const std::vector<float>& data_weight, const std::vector<int32_t>& edges, bool check_sticky_obstacles = false,
+                   const float* init_x = nullptr, float init_graph_scale = 0.0f, bool edges_unique = false, bool init_from_map = false) {
+    flame_nltgv2_sync_input in{};
+    in.init_graph_scale = init_graph_scale, in.edges_unique = edges_unique ? 1 : 0, in.init_from_map = init_from_map ? 1 : 0;
+    in.V = static_cast<int32_t>(feat_id.size());
+    in.feat_id = feat_id.data(), in.pos = pos_xy.data();
+    in.data_term = data_term.data(), in.data_weight = data_weight.data();
+    in.init_x = init_x;
+    in.E = static_cast<int32_t>(edges.size() / 2);
+    in.edges = edges.data();
+    in.check_sticky_obstacles = check_sticky_obstacles ? 1 : 0;
+    in.sticky_threshold = 0.25f;  // flame.cc:2011
+    check(flame_nltgv2_sync_prepare(ctx_, &in), "sync_prepare");
+  }
+  void syncCommit() { check(flame_nltgv2_sync_commit(ctx_), "sync_commit"); }
+  // interpolateMesh in two halves: the rasteriser and the copy-out run on a side stream while the solver steps again.
+  void interpolateMeshBegin(const std::vector<int32_t>& triangles, int rows, int cols, float graph_scale, const uint8_t* tri_validity = nullptr) {
+    check(flame_nltgv2_interpolate_mesh_begin(ctx_, triangles.data(), static_cast<int32_t>(triangles.size() / 3), tri_validity, rows, cols,
+                                              graph_scale), "interpolate_mesh_begin");
+  }
+  int interpolateMeshEnd(const float** idepthmap) {
+    int32_t coverage = 0;
+    check(flame_nltgv2_interpolate_mesh_end(ctx_, idepthmap, &coverage), "interpolate_mesh_end");
+    return coverage;
   }
 
   // utils::interpolateMesh (utils/image_utils.cc:373-396) at its call site flame.cc:409-415: rasterises
@@ -280,7 +325,7 @@ class DeviceGraph {
   flame_nltgv2_ctx* ctx_;
   flame_hip::FlatArrays flat_;
   size_t uploaded_v_ = 0, uploaded_e_ = 0;
-  uint64_t generation_ = 0;
+  uint64_t generation_ = 0, identity_ = 0;
   bool uploaded_ = false;
 };
 

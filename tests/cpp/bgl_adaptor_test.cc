@@ -84,5 +84,58 @@ int main() {
            std::memcmp(&got.w2_bar[v], &ref.w2_bar[v], 4) != 0 || std::memcmp(&got.x_prev[v], &ref.x_prev[v], 4) != 0;
   for (size_t e = 0; e < got.q1.size(); ++e) bad += std::memcmp(&got.q1[e], &ref.q1[e], 4) != 0 || std::memcmp(&got.q3[e], &ref.q3[e], 4) != 0;
   std::printf("bgl adaptor: V=%zu E=%zu, %d mismatching elements -> %s\n", got.x.size(), got.q1.size(), bad, bad ? "FAIL" : "ok");
-  return bad ? 1 : 0;
+
+  // ---- edits between upload() and download(): values go back BY POSITION, so every edit must be refused -------------------
+  // (a) an edge removed: the count differs; (b) removed and added again: both counts as uploaded, but the edge now stands at
+  // the END of edges() -- the adaptor's identity hash sees it; (c) a vertex removed the way Flame::syncGraph does it
+  // (clear_vertex + remove_vertex, flame.cc:2021-2023) and another added; (d) the untouched graph is accepted again after a
+  // fresh upload.  Also: graph_traits / edge(u, v) / add_edge on an existing pair behave as Boost documents.
+  int refuse_bad = 0;
+  auto refused = [&](const char* what) {
+    bool threw = false;
+    try {
+      dev.download(&graph);
+    } catch (const flame_hip::Error& e) {
+      threw = e.status == FLAME_NLTGV2_ERR_INVALID_ARG;
+    }
+    if (!threw) std::printf("FAIL: download() accepted a graph after %s\n", what), ++refuse_bad;
+  };
+  typedef boost::graph_traits<Graph>::edge_descriptor Edge;
+  typedef boost::graph_traits<Graph>::vertex_descriptor Vertex;
+  dev.upload(graph);
+  Graph::edge_iterator e0, e1;
+  boost::tie(e0, e1) = boost::edges(graph);
+  ++e0, ++e0;
+  const Edge victim = *e0;
+  const Vertex vs = boost::source(victim, graph), vt = boost::target(victim, graph);
+  const EdgeData kept = graph[victim];
+  if (!boost::edge(vt, vs, graph).second || boost::add_edge(vt, vs, EdgeData(), graph).second) std::printf("FAIL: edge() / add_edge on an existing pair\n"), ++refuse_bad;
+  boost::remove_edge(victim, graph);
+  refused("remove_edge");
+  boost::add_edge(vs, vt, kept, graph);
+  if (boost::num_edges(graph) != got.q1.size()) ++refuse_bad;
+  refused("remove_edge + add_edge (same counts, the edge moved to the end of edges())");
+  dev.upload(graph);
+  dev.download(&graph);  // a fresh upload is accepted
+  const Vertex gone = vh[5];
+  boost::clear_vertex(gone, graph);
+  boost::remove_vertex(gone, graph);
+  VertexData nv;
+  nv.pos = {1.5f, 2.5f};
+  const Vertex fresh = boost::add_vertex(nv, graph);
+  EdgeData ne;
+  boost::add_edge(fresh, vh[0], ne, graph), boost::add_edge(fresh, vh[1], ne, graph);
+  refused("clear_vertex + remove_vertex + add_vertex");
+  dev.upload(graph);
+  dev.run(params, 5);
+  dev.download(&graph);
+  size_t deg_sum = 0;
+  Graph::vertex_iterator v0, v1;
+  for (boost::tie(v0, v1) = boost::vertices(graph); v0 != v1; ++v0) {
+    Graph::adjacency_iterator a0, a1;
+    for (boost::tie(a0, a1) = boost::adjacent_vertices(*v0, graph); a0 != a1; ++a0) ++deg_sum;
+  }
+  if (deg_sum != 2 * boost::num_edges(graph)) std::printf("FAIL: adjacent_vertices\n"), ++refuse_bad;
+  std::printf("bgl adaptor: edits between upload and download refused, fresh uploads accepted -> %s\n", refuse_bad ? "FAIL" : "ok");
+  return (bad || refuse_bad) ? 1 : 0;
 }
