@@ -49,7 +49,7 @@ constexpr int kWalkSegment = 256;     // == nltgv2_pack.hpp kWalkSegment
 constexpr int kWindow = 512;          // == nltgv2_pack.hpp kDegreeWindow
 constexpr int kWalkLanes = 64;        // segments per workgroup of k_topo_walk
 constexpr int kWalkStride = 65;       // dwords per LDS row of k_topo_walk: the transposing accesses then touch 64 different banks
-constexpr int kCcRounds = 4;          // synchronous hooking rounds of the connected components before the asynchronous last one
+constexpr int kCcRounds = 3;          // synchronous hooking rounds of the connected components before the asynchronous last one
 
 inline dim3 grid1d(long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(256) k_topo_rows(const TopoBuild t, const int 
 // wins, parent < self holds (no cycle can form), and a root that was hooked a moment ago merely gets a smaller parent -- the link it
 // loses is found again over its edge in the next round.  A round divides the number of trees by ~7 (a tree survives as a root only
 // if no neighbouring tree has a smaller one): 52 k vertices -> 7.5 k trees after k_topo_rows -> ~1 k -> ~150 -> ...; measured, a
-// 1080p Delaunay graph is one tree after three rounds (the fourth and the asynchronous last one find nothing left to do).
+// 1080p Delaunay graph is one tree after three rounds (the asynchronous last one finds nothing left to do).
 // Every thread finds its two roots itself and leaves its vertices directly under them (any ancestor is a valid parent).
 __device__ __forceinline__ int cc_find_plain(int* parent, const int p) {
   int r = parent[p];
@@ -306,11 +306,6 @@ __global__ void __launch_bounds__(256) k_topo_hook_min(const TopoBuild t) {
     todo &= ~__ballot(mine);
   }
 }
-__global__ void __launch_bounds__(256) k_topo_compress(const TopoBuild t) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= t.V) return;
-  (void)cc_find_plain(t.parent, (int)cc_mix((uint32_t)v, t.cc_bits));
-}
 // The last round, asynchronous: the few trees left are joined over the edges that still cross between them by lock-free hooking
 // (above).  Running ALL edges through it from the start made every one of them read the nodes under the final root from L2 --
 // one hot cache line, and the failed compare-and-swaps on it serialise: 0.09 ms at 640x480 and 0.56 ms at 1080p; after the
@@ -321,7 +316,7 @@ __global__ void __launch_bounds__(256) k_topo_hook(const TopoBuild t) {
   const int a = t.src[e], b = t.dst[e];
   if ((unsigned)a >= (unsigned)t.V || (unsigned)b >= (unsigned)t.V) return;
   const int pa = (int)cc_mix((uint32_t)a, t.cc_bits), pb = (int)cc_mix((uint32_t)b, t.cc_bits);
-  if (t.parent[pa] == t.parent[pb]) return;  // (under the same root since the last compression)
+  if (cc_find_plain(t.parent, pa) == cc_find_plain(t.parent, pb)) return;  // (one tree already, as of this kernel's start)
   cc_hook(t.parent, pa, pb);
 }
 
@@ -585,7 +580,6 @@ int launch_topo_back(const TopoBuild& t, hipStream_t s) {
   hipLaunchKernelGGL(k_topo_rows, grid1d(t.V), dim3(256), 0, s, t, off);
   if (t.E > 0) {
     for (int round = 0; round < kCcRounds; ++round) hipLaunchKernelGGL(k_topo_hook_min, grid1d(t.E), dim3(256), 0, s, t);
-    hipLaunchKernelGGL(k_topo_compress, grid1d(t.V), dim3(256), 0, s, t);
     hipLaunchKernelGGL(k_topo_hook, grid1d(t.E), dim3(256), 0, s, t);
   }
   hipLaunchKernelGGL(k_topo_roots, grid1d(t.V), dim3(256), 0, s, t);
