@@ -332,13 +332,21 @@ def pv_step_cycles(flame_amd, g, params, iters, device):
     period = float((np.diff(p[0, :, 5]) & 0xffffffff).mean())
     us = float((np.diff(p[0, :, 6]) & 0xffffffff).mean()) / 100.0
     crit = int(np.argmin(wait))
+    slow = int(np.argmax(comp))
+    deg = p[:, 0, 7] & 0xff  # (probe word 7: the patch's largest vertex degree = the length of its ordered-sum chain | fetch lanes << 8)
     return {"period": round(period, 0), "period_us": round(us, 3), "shader_clock_GHz": round(period / (us * 1e3), 3),
             "compute_median": round(float(np.median(comp)), 0), "compute_max": round(float(comp.max()), 0),
+            "compute_max_over_median": round(float(comp.max() / np.median(comp)), 3),
+            "slowest_patch_largest_degree": int(deg[slow]), "median_patch_largest_degree": int(np.median(deg)),
+            "compute_by_largest_degree": {str(int(d)): round(float(comp[deg == d].mean()), 0) for d in sorted(set(deg.tolist()))},
             "wait_median": round(float(np.median(wait)), 0), "wait_min": round(float(wait.min()), 0),
             "least_slack_patch": {"compute": round(float(comp[crit]), 0), "wait": round(float(wait[crit]), 0)},
             "poll_rounds_per_step": round(float(p[:, :, 4].mean()), 2), "patches": int(info["he_waves"]),
             "instances": int(p.shape[0]),
-            "note": "cycles per step with the probe compiled in (+3-5 %); the lock-step network runs at the pace of its least-slack patches: period = their compute + their wait (one hand-off)"}
+            "note": "cycles per step with the probe compiled in (+3-5 %); the lock-step network runs at the pace of its least-slack patches: period = their "
+                    "compute + their wait (one hand-off).  A patch's compute is the chain of its largest vertex: 2 x degree dependent additions in the "
+                    "reference's edge order (`compute_by_largest_degree`) -- the slowest patch is the one that holds the graph's largest vertex, which no "
+                    "packing can shorten; polling faster or slower than one load per LDS round trip lengthens the wait (profiles/r04_poll_variants.txt)"}
 
 
 def latency_floor(flame_amd, synth, params, iters, device, B_iter, roofline):
@@ -390,6 +398,9 @@ def latency_floor(flame_amd, synth, params, iters, device, B_iter, roofline):
     rp = roofline.get("record_placement")
     if isinstance(rp, dict):
         out["cross_xcd_handoff_us"] = rp["cross_xcd_handoff_us_by_page"]
+    sc = roofline.get("step_cycles")
+    if isinstance(sc, dict):  # what the coupled frame's least-slack wait holds beyond a same-XCD hand-off: the crossing + later detection
+        out["wait_min_minus_same_xcd_handoff_cycles"] = round(sc["wait_min"] - float(wait.min()), 0)
     out["frac_of_hbm_at_uncoupled_period"] = round(out["hbm_period_us"] / uncoupled_us, 4)
     out["note"] = ("one small frame cannot iterate faster than one hand-off plus the ~600 cycles of dependent instructions behind it; "
                    "`frac_of_hbm_at_uncoupled_period` is the roofline fraction this frame would show if none of its records crossed an XCD")
@@ -492,6 +503,14 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
         out["batched"][label]["traffic"] = measured_counters(key).get("hbm_bytes_per_launch")
         out["batched"][label]["algorithmic_bytes_per_launch"] = int(bi["algorithmic_bytes_per_iter"] * iters / groups)
         out["batched"][label]["valu"] = valu_roofline(key, ms * 1e-3 / groups)
+        oc = measured_counters(key).get("on_chip")
+        if oc:  # rocprofv3 SQ counters of the same command (profiles/r04_counters.json): which on-chip resource the resident kernel keeps busy
+            out["batched"][label]["on_chip"] = dict(oc, source="profiles/traffic.json", note="fractions of wave-cycles with an instruction of the class in flight "
+                                                    "(LDS / VALU / VMEM / scalar), LDS bank-conflict share, LDS pipe busy fraction of the chip")
+            v = out["batched"][label]["valu"]
+            out["batched"][label]["roofline"] = {"bound": "valu-issue", "frac": v["frac"] if v else None,
+                                                 "note": "the state is register / LDS resident: `frac` above counts algorithmic bytes against the HBM peak and may pass 1; "
+                                                         "the resource that binds is instruction issue (this fraction), then the neighbour exchange"}
         b.close()
     # (2) the other single-GPU BASELINE configs, 200 iterations each
     oc = {}
@@ -625,10 +644,45 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
     r.run(params, 50)
     r.sync_graph(fid, pos2, data2, ones2, edges2)
     r.run(params, 50)
+    path_name = {1: "host", 2: "device"}
     out["frame_sync"] = {"sync_graph_ms": round(sorted(sync_done)[2], 3), "sync_graph_call_ms": round(sorted(sync_call)[2], 3),
+                         "path": path_name.get(r.info()["last_sync_path"], "?"),
                          "churn": "8 % of vertices replaced, re-triangulated", "V": int(len(fid)), "E": int(r.info()["E"]),
-                         "note": "median of 5; sync_graph_ms = until the device holds the new frame (call + stream sync), "
-                                 "call_ms = until the call returns (index maps, tables, one staged copy, kernels enqueued)"}
+                         "note": "median of 5; sync_graph_ms = until the device holds the new frame (call + stream sync), call_ms = until the call returns.  "
+                                 "Round 4: index maps AND the new graph's layout tables are built by kernels over the resident previous topology "
+                                 "(flame_amd/csrc/nltgv2_topo.hip); `host_path` = the same sync with both on the host (rounds 1-3); `two_halves` = "
+                                 "sync_prepare (builder on a side stream, returns at once) / sync_commit (the solver stands still for this call only)"}
+    # the same sync the host way, and in two halves with the solver iterating in between
+    from flame_amd.regularizer import OPT_SYNC_PATH
+
+    def timed_sync(prep_commit):
+        calls = []
+        for _ in range(5):
+            r.run(params, 50)
+            if prep_commit:
+                t4 = _t.perf_counter()
+                r.sync_prepare(fid, pos2, data2, ones2, edges2, edges_unique=True)
+                t5 = _t.perf_counter()
+                r.run_async(params, 400)   # the solver keeps iterating on the old graph
+                _t.sleep(0.0005)           # (the builder runs on its side stream meanwhile)
+                t6 = _t.perf_counter()
+                r.sync_commit()
+                calls.append(((t5 - t4) * 1e3, (_t.perf_counter() - t6) * 1e3))
+            else:
+                t4 = _t.perf_counter()
+                r.sync_graph(fid, pos2, data2, ones2, edges2, edges_unique=True)
+                r.sync()
+                calls.append(((_t.perf_counter() - t4) * 1e3, 0.0))
+            r.run(params, 50)
+            r.sync_graph(fid0, g["pos"], g["data_term"], g["data_weight"], edges0)
+        calls.sort()
+        return calls[2]
+    r.set_option(OPT_SYNC_PATH, 1)
+    out["frame_sync"]["host_path"] = {"sync_graph_ms": round(timed_sync(False)[0], 3)}
+    r.set_option(OPT_SYNC_PATH, 0)
+    pc = timed_sync(True)
+    out["frame_sync"]["two_halves"] = {"sync_prepare_call_ms": round(pc[0], 3), "sync_commit_call_ms": round(pc[1], 3),
+                                       "note": "commit includes settling the 400 iterations enqueued between the halves"}
     # mesh -> dense idepthmap (utils::interpolateMesh, next row 8(f)-2), incl. the D2H copy of the map
     tris = tris2
     r.interpolate_mesh(tris, h_, w_)

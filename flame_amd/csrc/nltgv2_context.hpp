@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "flame_nltgv2.h"
+#include "flame_nltgv2_test_options.h"
 #include "nltgv2_kernels.h"
 #include "nltgv2_pack.hpp"
 #include "roctx_ranges.hpp"

@@ -199,6 +199,36 @@ k_persistent_pv2(const int wg_begin, const int n_wgs, const int wgs_per_xcd, con
       unsigned long long pnarrow, exec_saved, waiting;
       const unsigned own_slot = dst + 16u * (unsigned)lane;
       const unsigned f_sleep = (poll_gap & 1) ? 1u + (((unsigned)poll_gap >> 4) & 15u) : 0u, f_narrow = (unsigned)((poll_gap >> 1) & 1);
+// What a poll round reads from LDS.  Round 4 (profiles/r04_counters.json: cfg5 / batch10 kept the chip's LDS pipes 62-72 % busy, 61 % of
+// that on bank conflicts): every lane's two neighbour tags and both 16-byte neighbour records, round after round -- 11 dwords per lane,
+// the records gathered from scattered slots -- is what the polling waves of a CU load its LDS pipe with.  All a round has to find out
+// is whether the patch's FOREIGN records have arrived (the local ones were written by this wave before the wait, in program order):
+// one tag word per lane from its own fetch slot; the neighbour records are read once, when the last of them is in.
+#ifdef FLAME_PV2_FULL_POLL
+#define PV2_ROUND_READS                                                                                  \
+               "ds_read_b32 %[ta], %[ra] offset:12\n\t"                                                 \
+               "ds_read_b32 %[tb], %[rb] offset:12\n\t"                                                 \
+               "ds_read_b32 %[t2], %[fa] offset:12\n\t"                                                 \
+               "ds_read_b128 %[na], %[ra]\n\t"                                                          \
+               "ds_read_b128 %[nb], %[rb]\n\t"
+#define PV2_ROUND_PENDING                                                                                \
+               "v_cmp_ne_u32_e32 vcc, %[tag], %[ta]\n\t"                                                \
+               "s_mov_b64 %[wt], vcc\n\t"                                                               \
+               "v_cmp_ne_u32_e32 vcc, %[tag], %[tb]\n\t"                                                \
+               "s_or_b64 %[wt], %[wt], vcc\n\t"
+#define PV2_AFTER_WAIT
+#else
+#define PV2_ROUND_READS                                                                                  \
+               "ds_read_b32 %[t2], %[fa] offset:12\n\t"
+#define PV2_ROUND_PENDING                                                                                \
+               "s_mov_b64 %[wt], %[pn]\n\t"
+#define PV2_AFTER_WAIT                                                                                   \
+               "ds_read_b128 %[na], %[ra]\n\t"                                                          \
+               "ds_read_b128 %[nb], %[rb]\n\t"                                                          \
+               "v_mov_b32 %[ta], %[tag]\n\t"                                                            \
+               "v_mov_b32 %[tb], %[tag]\n\t"                                                            \
+               "s_waitcnt lgkmcnt(0)\n\t"
+#endif
 #define PV2_POLL                                                                                          \
   asm volatile("s_setprio 0\n\t"                                                                        \
                "s_mov_b64 %[ex], exec\n\t"                                                             \
@@ -218,27 +248,21 @@ k_persistent_pv2(const int wg_begin, const int n_wgs, const int wgs_per_xcd, con
                "s_sub_u32 %[k], %[k], 1\n\t"                                                            \
                "s_branch 4b\n\t"                                                                        \
                "3:\n\t"                                                                                 \
-               "ds_read_b32 %[ta], %[ra] offset:12\n\t"                                                 \
-               "ds_read_b32 %[tb], %[rb] offset:12\n\t"                                                 \
-               "ds_read_b32 %[t2], %[fa] offset:12\n\t"                                                 \
-               "ds_read_b128 %[na], %[ra]\n\t"                                                          \
-               "ds_read_b128 %[nb], %[rb]\n\t"                                                          \
+               PV2_ROUND_READS                                                                          \
                "s_add_u32 %[cnt], %[cnt], 1\n\t"                                                        \
                "s_waitcnt lgkmcnt(0)\n\t"                                                               \
                "v_cmp_ne_u32_e32 vcc, %[tag], %[t2]\n\t"                                                \
                "s_and_b64 %[pn], vcc, %[fm]\n\t"                                                        \
+               PV2_ROUND_PENDING                                                                        \
                "s_cmp_eq_u32 %[fn], 0\n\t"                                                              \
                "s_cselect_b64 %[pn], %[fm], %[pn]\n\t"                                                  \
-               "v_cmp_ne_u32_e32 vcc, %[tag], %[ta]\n\t"                                                \
-               "s_mov_b64 %[wt], vcc\n\t"                                                               \
-               "v_cmp_ne_u32_e32 vcc, %[tag], %[tb]\n\t"                                                \
-               "s_or_b64 %[wt], %[wt], vcc\n\t"                                                         \
                "s_cmp_eq_u64 %[wt], 0\n\t"                                                              \
                "s_cbranch_scc1 2f\n\t"                                                                  \
                "s_cmp_lt_u32 %[cnt], 64\n\t"                                                            \
                "s_cbranch_scc1 1b\n\t"                                                                  \
                "2:\n\t"                                                                                 \
                "s_setprio 3\n\t"                                                                        \
+               PV2_AFTER_WAIT                                                                           \
                "s_mov_b32 m0, %[keep]"                                                                   \
                : [keep] "=&s"(keep), [cnt] "=&s"(cnt), [na] "=&v"(nbv0), [nb] "=&v"(nbv1), [ta] "=&v"(tag_a), [tb] "=&v"(tag_b),   \
                  [t2] "=&v"(tagf), [pn] "=&s"(pnarrow), [k] "=&s"(gapk), [ex] "=&s"(exec_saved), [wt] "=&s"(waiting)                \
@@ -253,7 +277,7 @@ k_persistent_pv2(const int wg_begin, const int n_wgs, const int wgs_per_xcd, con
           if (ab != 0 || ++outer > (max_spins >> 4)) {
             timed_out = true;
             if (ab == 0) {
-              const unsigned long long pm = __ballot(tag_a != s || tag_b != s);
+              const unsigned long long pm = __ballot(tag_a != s || tag_b != s || (frid >= 0 && tagf != s));
               const int fl = __ffsll((long long)pm) - 1;
               const unsigned gs = (unsigned)__shfl((int)tag_a, fl, 64);
               if (lane == 0) report_expired2(err, 3, wg, it, pm, -1, gs, s);

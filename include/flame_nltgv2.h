@@ -277,9 +277,8 @@ int flame_nltgv2_photo_fuse(flame_nltgv2_ctx* ctx, const float* KRKinv, const fl
                             int enable);
 int flame_nltgv2_photo_residual_last(flame_nltgv2_ctx* ctx, float* err_out);
 
-/* Options (flame_nltgv2_set_option).  The values below 100 are the stable surface; FLAME_NLTGV2_OPT_EXPERIMENTAL and above
- * are tuning knobs and test hooks of the current kernels (what DESIGN.md's A/B tables were measured with): they may change or
- * go with any release and a caller never needs them -- every default is the measured best. */
+/* Options (flame_nltgv2_set_option).  These are the stable surface; a caller never needs any of them -- every default is the
+ * measured best.  (Tuning knobs and test hooks of the current kernels, numbers 100 and up, live in a test-only header.) */
 enum {
   FLAME_NLTGV2_OPT_SOLVER = 1,       /* 0 = fused / persistent kernels (default), 1 = the reference's four loops one by one
                                         (save_prev / dual / primal / extragradient sweeps on the canonical arrays) */
@@ -314,23 +313,8 @@ enum {
                                         bit; 1 = both sums on the device in a fixed strided / pairwise order (a few microseconds, no copy of
                                         2E + V floats; agrees with the sequential sums to ~1e-6 relative) */
 
-  FLAME_NLTGV2_OPT_EXPERIMENTAL = 100, /* ---- not part of the stable surface from here on ---- */
-  FLAME_NLTGV2_OPT_BLOCK_WAVES = 103,  /* waves per workgroup of the fused sweep: 0 = auto, 1,2,4 */
-  FLAME_NLTGV2_OPT_UNROLL = 104,       /* half-edge slots per load chunk of the fused sweep: 0 = auto, 4,8,16 */
-  FLAME_NLTGV2_OPT_DUAL_PUBLISH = 106, /* persistent run: neighbours on the same XCD exchange through that XCD's L2 (plain store
-                                          + local record copy): 1 (default) and 2 = on, 0 = write-through records only */
-  FLAME_NLTGV2_OPT_TV_LDS = 107,       /* vertex-per-lane form: per-slot constants in LDS instead of registers: 2 = always,
-                                          1 (default) = when the register form is not resident in one launch, 0 = never */
-  FLAME_NLTGV2_OPT_PRESLEEP = 108,     /* persistent run, pause between a step's publish and its first poll: 0 (default) =
-                                          chosen from the waves per CU; n in 1..256 = (n-1) x 64 cycles */
-  FLAME_NLTGV2_OPT_XCDS = 109,         /* persistent run: XCDs (of 8) the waves are spread over: 0 (default) = one XCD for
-                                          graphs small enough to run there, else all eight; 1..8 */
-  FLAME_NLTGV2_OPT_FAULT_INJECT = 110, /* test hook: n > 0 = one wave of every persistent run withholds its first record, so the
-                                          run times out after n polls and the recovery path (state rolled back, steps redone
-                                          with one launch per step) is exercised; 0 (default) = off */
-  FLAME_NLTGV2_OPT_POLL_GAP = 113      /* patch-per-wave form: 0 (default) = chosen from the patches per CU, 1 = no pause between
-                                          the poll rounds of a wait, 2 = one s_sleep (64 cycles); 3 / 4 = the same with the polls
-                                          narrowed to the records that have not arrived yet */
+  FLAME_NLTGV2_OPT_EXPERIMENTAL = 100 /* option numbers from here on are tuning knobs and test hooks of the current kernels: declared in
+                                         flame_amd/csrc/flame_nltgv2_test_options.h (tests and tools only), not part of this surface */
 };
 int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value);
 

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "flame_hip/frame_gather.hpp"
+#include "../../flame_amd/csrc/flame_nltgv2_test_options.h"  // (test hook: FLAME_NLTGV2_OPT_FAULT_INJECT)
 
 namespace dgraph = flame::optimizers::nltgv2_l1_graph_regularizer::hip;
 

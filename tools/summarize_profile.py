@@ -14,7 +14,7 @@ import os
 import shutil
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{R}")
 DST = os.path.join(ROOT, "profiles")
@@ -52,7 +52,7 @@ def last_json(path):
 # tag -> (dominant kernel, traffic.json key or None)
 CASES = {"bench": ("k_persistent_pv", "640x480:persistent-pv"), "bench_tv": ("k_persistent_tv", "640x480:persistent-tv"),
          "bench_step": ("k_fused_step", "640x480:per-step hipGraph"), "cfg3": ("k_persistent_pv", "1280x720:persistent-pv"),
-         "cfg5": ("k_persistent_pv2", "1920x1080:persistent-pv2"), "batch5": ("k_persistent_pv2", "640x480x5:persistent-pv2"), "batch30": ("k_persistent_tv", "640x480x30:persistent-tv"),
+         "cfg5": ("k_persistent_pv2", "1920x1080:persistent-pv2"), "batch5": ("k_persistent_pv2", "640x480x5:persistent-pv2"), "batch10": ("k_persistent_pv2", "640x480x10:persistent-pv2"), "batch30": ("k_persistent_tv", "640x480x30:persistent-tv"),
          "batch64": ("k_persistent_tv", "640x480x64:persistent-tv"), "stream64": ("k_fused_step", None),
          "stereo": ("k_update_feature_idepths", None)}
 out, traffic = {}, {}
@@ -66,7 +66,8 @@ for tag, (kernel, key) in CASES.items():
         w = entry["workload"]
         entry["workload"] = {"value": w["value"], "ms_per_step": w["ms_per_step"], "run_path": w.get("run_path"), "roofline": w["roofline"]}
     c = {}
-    for d, f in ((f"fetch_{tag}", "f_counter_collection.csv"), (f"write_{tag}", "w_counter_collection.csv"), (f"sq_{tag}", "s_counter_collection.csv")):
+    for d, f in ((f"fetch_{tag}", "f_counter_collection.csv"), (f"write_{tag}", "w_counter_collection.csv"), (f"sq_{tag}", "s_counter_collection.csv"),
+                 (f"lds_{tag}", "l_counter_collection.csv"), (f"act_{tag}", "a_counter_collection.csv")):
         p = os.path.join(SRC, d, f)
         if os.path.exists(p):
             c.update(counters(p, kernel))
@@ -89,6 +90,24 @@ for tag, (kernel, key) in CASES.items():
         entry["wait_any_over_wave_cycles"] = round(c["SQ_WAIT_ANY"]["mean"] / c["SQ_WAVE_CYCLES"]["mean"], 4)
         if "SQ_ACTIVE_INST_ANY" in c:
             entry["active_inst_over_wave_cycles"] = round(c["SQ_ACTIVE_INST_ANY"]["mean"] / c["SQ_WAVE_CYCLES"]["mean"], 4)
+    if "SQ_ACTIVE_INST_LDS" in c and "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"]["mean"] > 0:
+        # the on-chip side of a resident kernel (tools/profile.sh prof_onchip): per wave-cycle, how much of the time an instruction of
+        # each class is in flight, and the LDS pipe's own counters.  SQ_ACTIVE_INST_* / SQ_WAIT_* / SQ_WAVE_CYCLES count quad-cycles
+        # summed over waves; SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE count LDS-pipe cycles (conflict share = their ratio).
+        wc = c["SQ_WAVE_CYCLES"]["mean"]
+        oc = {k.lower().replace("sq_", "") + "_over_wave_cycles": round(c[k]["mean"] / wc, 4)
+              for k in ("SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_SCA") if k in c}
+        if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE", {}).get("mean", 0) > 0:
+            oc["lds_bank_conflict_share_of_lds_active"] = round(c["SQ_LDS_BANK_CONFLICT"]["mean"] / c["SQ_LDS_IDX_ACTIVE"]["mean"], 4)
+        if entry["kernel_stats"]:
+            secs = entry["kernel_stats"]["avg_ns"] * 1e-9
+            for k in ("SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SALU"):
+                if k in c:
+                    oc[k.lower().replace("sq_", "") + "_per_s"] = c[k]["mean"] / secs
+            if "SQ_LDS_IDX_ACTIVE" in c:  # LDS pipe busy: cycles the LDS index stage is active, per CU-cycle available (256 CUs x 2.4 GHz)
+                oc["lds_pipe_busy_frac"] = round(c["SQ_LDS_IDX_ACTIVE"]["mean"] / (secs * 256 * 2.4e9), 4)
+        entry["on_chip"] = oc
+        t["on_chip"] = oc
     if key:
         traffic[key] = t
     out[tag] = entry
