@@ -218,8 +218,11 @@ k_persistent_pv2(const int wg_begin, const int n_wgs, const int wgs_per_xcd, con
                "s_or_b64 %[wt], %[wt], vcc\n\t"
 #define PV2_AFTER_WAIT
 #else
+// (only the fetch lanes that still wait read -- a lane that has seen its record keeps the matching tag in its register: -1 % more)
 #define PV2_ROUND_READS                                                                                  \
-               "ds_read_b32 %[t2], %[fa] offset:12\n\t"
+               "s_mov_b64 exec, %[pn]\n\t"                                                              \
+               "ds_read_b32 %[t2], %[fa] offset:12\n\t"                                                 \
+               "s_mov_b64 exec, %[ex]\n\t"
 #define PV2_ROUND_PENDING                                                                                \
                "s_mov_b64 %[wt], %[pn]\n\t"
 #define PV2_AFTER_WAIT                                                                                   \
