@@ -12,8 +12,6 @@ enum {
   FLAME_NLTGV2_OPT_UNROLL = 104,       /* half-edge slots per load chunk of the fused sweep: 0 = auto, 4,8,16 */
   FLAME_NLTGV2_OPT_DUAL_PUBLISH = 106, /* persistent run: neighbours on the same XCD exchange through that XCD's L2 (plain store
                                           + local record copy): 1 (default) and 2 = on, 0 = write-through records only */
-  FLAME_NLTGV2_OPT_TV_LDS = 107,       /* vertex-per-lane form: per-slot constants in LDS instead of registers: 2 = always,
-                                          1 (default) = when the register form is not resident in one launch, 0 = never */
   FLAME_NLTGV2_OPT_PRESLEEP = 108,     /* persistent run, pause between a step's publish and its first poll: 0 (default) =
                                           chosen from the waves per CU; n in 1..256 = (n-1) x 64 cycles */
   FLAME_NLTGV2_OPT_XCDS = 109,         /* persistent run: XCDs (of 8) the waves are spread over: 0 (default) = one XCD for

@@ -560,10 +560,6 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
       if (value < 0 || value > 256) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_presleep = value;
       return 0;
-    case FLAME_NLTGV2_OPT_TV_LDS:
-      if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-      ctx->opt_tv_lds = value;
-      return 0;
     case FLAME_NLTGV2_OPT_COST_SUM:
       if (value < 0 || value > 1) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_cost_sum = value;
@@ -609,7 +605,7 @@ int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info) {
   }
   info->tv_waves = ctx->L.tv_ok ? ctx->L.tv_waves : 0;
   info->patches = ctx->L.wg_ok ? ctx->L.wg_count : 0;
-  info->tv_wave_capacity = (ctx->opt_tv_lds ? kTvLdsWavesPerCu : kTvWavesPerCu) * ctx->prop.multiProcessorCount;
+  info->tv_wave_capacity = kTvLdsWavesPerCu * ctx->prop.multiProcessorCount;
   info->last_run_groups = ctx->last_run_groups;
   info->timeouts_recovered = ctx->timeouts_recovered;
   info->torn_records_detected = ctx->torn_records_detected;

@@ -41,6 +41,7 @@ constexpr size_t kXbufBytesPerVertex = 8 * 16 + 4;  // exchange buffers: up to f
                                                     // 16-byte records (the patch-per-wave form; the others use two) + the XCC table
 constexpr int kPv2FromPerCu = 14;       // from this many one-half-edge patches per CU on, the two-half-edges-per-lane form (k_persistent_pv2) runs the graph
 constexpr int kPv2PaceAbovePerCu = 10, kPv2DensePreSleep = 2, kPv2DenseGap = 2;  // its polls are paced from this many of its waves per CU (x64 cycles before the first poll / between rounds)
+constexpr int kPv2MaxGroups = 2;        // ... in at most this many launch groups of whole frames (11-20 frames of 640x480: 9-18 % faster than the vertex-per-lane form)
 constexpr int kPv2WavesPerCu = 19;     // ... up to this many of ITS waves per CU (20 really resident: 91 VGPRs)
 constexpr int kCrowdedWavesPerCu = 16, kCrowdedTopologies = 64;  // (see flame_nltgv2_ctx::crowded_until_topo)
 constexpr int kPvDensePerCu = 27;      // k_persistent_pv is used up to this many patches per CU (28 are resident: 7 waves per SIMD at <= 96 SGPRs)
@@ -53,7 +54,6 @@ constexpr int kPvPreSleep = 0;         // k_persistent_pv: x64 cycles between a 
 constexpr int kPvPollGap = 2;          // k_persistent_pv polls: re-loading only the fetch entries still waiting, no pause between
                                        // rounds (with the round-2 first form of the kernel an s_sleep between rounds won by 1-3 %;
                                        // with the shorter hand-off path of its final form no pause wins by 3-4 % at 640x480)
-constexpr int kTvWavesPerCu = 8;       // residency of k_persistent_tv (<= 256 VGPRs -> 2 waves per SIMD)
 constexpr int kDualMinWavesPerCu = 0;  // auto: exchange through the XCD's L2 when more waves than this share a CU
 // x64-cycle sleep between publishing and the first neighbour poll of k_persistent_tv (insensitive, shortest wins)
 constexpr int kPreSleepTv = 2;
@@ -175,7 +175,6 @@ struct flame_nltgv2_ctx {
   mutable uint64_t pv_occ_topo = ~0ull;
   int opt_probe = 0;     // > 0: k_persistent_pv records a per-patch, per-step cycle probe (flame_nltgv2_read_probe)
   size_t probe_words = 0;
-  int opt_tv_lds = 1;  // 0 registers, 1 auto (LDS when the register form is not resident in one launch), 2 LDS
   uint32_t tag_next = 1;  // persistent run: tag of the current bar values (monotonic)
   int last_run_path = 0, last_run_groups = 0;
   uint64_t persist_refused_topo = ~0ull;  // topology for which the runtime refused the persistent grid

@@ -318,10 +318,13 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
 
 }  // namespace
 
-// The kernel instance (slot constants in registers or in LDS) and its dynamic LDS bytes per workgroup.
+// The kernel instance and its dynamic LDS bytes per workgroup.  Since round 4 only the instance with the per-slot constants in LDS is
+// built (the register instance, LDS_STATIC = false, ran 11-15 frame batches 9 % faster per wave at half the residency; those batches
+// now run as two groups of k_persistent_pv2, 9-18 % faster still: profiles/r04_large_batches.txt).
 const void* persistent_tv_kernel(bool static_in_lds, int waves_per_block, unsigned* lds_bytes) {
-  *lds_bytes = static_in_lds ? (unsigned)(waves_per_block * 5 * kTvS * 64 * sizeof(int)) : 0u;
-  return static_in_lds ? (const void*)k_persistent_tv<true> : (const void*)k_persistent_tv<false>;
+  (void)static_in_lds;
+  *lds_bytes = (unsigned)(waves_per_block * 5 * kTvS * 64 * sizeof(int));
+  return (const void*)k_persistent_tv<true>;
 }
 
 }  // namespace flame_hip

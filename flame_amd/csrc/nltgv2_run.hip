@@ -26,6 +26,7 @@ struct WaveGroup {
 // group of connected components by group, each group resident on its own: the components are independent,
 // so running them one after the other for all n steps is exactly the same computation.
 int ensure_form_rows(flame_nltgv2_ctx* ctx, int form);
+int plan_groups(flame_nltgv2_ctx* ctx, int form, int total, int cap, const std::vector<int32_t>& cw, std::vector<WaveGroup>* groups);
 
 // `consume`: the call plans a run that is about to be enqueued (enqueue_run) -- only then does a planned-around run count against
 // the back-off after an expired wait; a query (persistent_eligible, prepare_run) leaves the bookkeeping alone.
@@ -80,8 +81,8 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
     if (!ctx->wg2_built && ensure_form_rows(ctx, 4) != 0) return 0;
     form = pv2_usable() ? 4 : 0;
   } else if (ctx->opt_persistent == 3) form = 2;
-  else if (ctx->opt_probe == 0 && ctx->wg2_built && L.wg2_count <= wg2_cap &&
-           (!pv_fits || L.wg_count > kPv2FromPerCu * cus) && pv2_usable()) form = 4;
+  else if (ctx->opt_probe == 0 && ctx->wg2_built && L.wg2_count <= kPv2MaxGroups * wg2_cap &&
+           (!pv_fits || L.wg_count > kPv2FromPerCu * cus) && pv2_usable()) form = 4;  // (beyond one launch: as two groups of whole frames, below)
   else if (pv_fits) form = 3;  // lowest latency wherever all patches are resident: 320x240 ... 1920x1080 single frames, 2-7 frames of 640x480
   else form = 2;               // too big for that: vertex-per-lane, in groups of whole components if need be
   if (form == 2) {
@@ -90,10 +91,11 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
       form = (L.wg_ok && L.wg_rowpack && L.wg_count > 0) ? 3 : 0;
     }
   }
-  // vertex-per-lane form: slot constants in registers (8 waves/CU, fastest per wave) while the graph is resident
-  // that way, else in LDS (16 waves/CU: 30 frames of 640x480 resident in one launch)
-  const bool tv_lds = form == 2 && (ctx->opt_tv_lds == 2 || (ctx->opt_tv_lds == 1 && L.tv_waves > kTvWavesPerCu * cus));
-  const int tv_cap = (tv_lds ? kTvLdsWavesPerCu : kTvWavesPerCu) * cus;
+  // vertex-per-lane form: the per-slot constants in LDS (16 waves per CU: 30 frames of 640x480 resident in one launch).  (The
+  // instance that kept them in registers -- 8 waves per CU, 9 % faster per wave -- was retired in round 4: the batches it ran, 11 to
+  // 15 frames, are faster as two groups of the two-half-edges patch form: profiles/r04_large_batches.txt.)
+  const bool tv_lds = form == 2;
+  const int tv_cap = kTvLdsWavesPerCu * cus;
   if (use_tv_lds) *use_tv_lds = tv_lds ? 1 : 0;
   if (form == 0) return 0;
   const int total = form == 4 ? L.wg2_count : form == 3 ? L.wg_count : L.tv_waves;
@@ -104,7 +106,28 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
     return form;
   }
   if (ensure_host_layout(ctx) != 0) return 0;  // (the component tables live in the host image of the layout)
+  if (form == 4 && ctx->opt_persistent == 1) {  // groups of the two-half-edges form only where whole frames make them up
+    const std::vector<int32_t>& c2 = L.comp_wg2;
+    bool ok2 = c2.size() >= 3;
+    for (size_t c = 0; ok2 && c + 1 < c2.size(); ++c) ok2 = c2[c + 1] - c2[c] <= cap;
+    if (!ok2) {
+      if (ensure_form_rows(ctx, 2) != 0 || !L.tv_ok) return 0;
+      if (use_tv_lds) *use_tv_lds = 1;
+      groups->clear();
+      return plan_groups(ctx, 2, L.tv_waves, kTvLdsWavesPerCu * cus, L.comp_tv_wave, groups);
+    }
+  }
   const std::vector<int32_t>& cw = form == 4 ? L.comp_wg2 : form == 3 ? L.comp_wg : L.comp_tv_wave;
+  return plan_groups(ctx, form, total, cap, cw, groups);
+}
+
+// `total` waves of `form` over groups of whole components (cw: first wave of every component), each at most `cap` waves.
+int plan_groups(flame_nltgv2_ctx* ctx, int form, int total, int cap, const std::vector<int32_t>& cw, std::vector<WaveGroup>* groups) {
+  (void)ctx;
+  if (total <= cap) {
+    groups->push_back(WaveGroup{0, total});
+    return form;
+  }
   if (cw.size() < 3) return 0;  // one component that does not fit: stream it
   // Groups of about equal size (the per-step time of a group grows with its waves, and a small last group would run
   // at low occupancy): cut at the component boundaries nearest to k * total / n_groups, never beyond what the chip

@@ -150,14 +150,14 @@ def test_internal_steps_individually(env):
 
 def _opt_sets():
     from flame_amd.regularizer import (OPT_BLOCK_WAVES as BW, OPT_DUAL_PUBLISH as DUAL, OPT_PERSISTENT as P, OPT_PLACEMENT as PLACE,
-                                       OPT_POLL_GAP as GAP, OPT_PRESLEEP as PRE, OPT_PROBE as PROBE, OPT_TV_LDS as TVLDS, OPT_UNROLL as U,
+                                       OPT_POLL_GAP as GAP, OPT_PRESLEEP as PRE, OPT_PROBE as PROBE, OPT_UNROLL as U,
                                        OPT_USE_HIPGRAPH as HG, OPT_VERIFY_RECORDS as VERIFY, OPT_XCDS as XCDS)
     return [
         # one launch per step: waves per workgroup x slot chunk, hipGraph off
         [(P, 0), (BW, 1), (U, 4)], [(P, 0), (BW, 1), (U, 16)], [(P, 0), (BW, 4), (U, 8)], [(P, 0), (HG, 0)],
         [(P, 1)],  # automatic choice
         # vertex per lane
-        [(P, 3)], [(P, 3), (DUAL, 0)], [(P, 3), (TVLDS, 2)], [(P, 3), (TVLDS, 0)], [(P, 3), (XCDS, 1)], [(P, 3), (XCDS, 4)], [(P, 3), (PRE, 21)],
+        [(P, 3)], [(P, 3), (DUAL, 0)], [(P, 3), (XCDS, 1)], [(P, 3), (XCDS, 4)], [(P, 3), (PRE, 21)],
         # patch per wave
         [(P, 4)], [(P, 4), (DUAL, 0)], [(P, 4), (DUAL, 2)], [(P, 4), (XCDS, 1)], [(P, 4), (XCDS, 8)], [(P, 4), (GAP, 1)], [(P, 4), (GAP, 2)],
         [(P, 4), (GAP, 4)], [(P, 4), (PRE, 9), (GAP, 4)], [(P, 4), (PROBE, 1)], [(P, 4), (PLACE, 0)], [(P, 4), (PLACE, 0), (DUAL, 0)],
@@ -768,7 +768,6 @@ def test_randomized_run_sequences(env, trial):
             reg.set_option(5, form)
             reg.set_option(1, int(rng.random() < 0.15))      # canonical four-sweep path now and then
             reg.set_option(flame_amd.regularizer.OPT_DUAL_PUBLISH, int(rng.choice([0, 1, 2])))
-            reg.set_option(flame_amd.regularizer.OPT_TV_LDS, int(rng.choice([0, 1, 2])))
             n = int(rng.choice([1, 2, 3, 5, 8, 13, 40, 120]))
             reg.run(p, n)
             assert oracle.run(ref, n, rp) == 0
@@ -852,7 +851,7 @@ def test_after_an_expired_run_the_persistent_path_is_tried_again(env):
 def test_an_expired_run_at_high_residency_makes_the_planner_leave_room(env):
     """Ten frames of 640x480 take 18.6 of the 20 wave slots a CU really holds for the two-half-edges-per-lane form.  When such a run
     expires (here: fault injection; in a pipeline: other kernels keeping slots busy), the following topologies are planned for at
-    most 16 waves per CU -- the vertex-per-lane form for this graph -- instead of trying the same launch frame after frame; a
+    most 16 waves per CU -- the same form in two groups of five frames for this graph -- instead of trying the same launch frame after frame; a
     1080p frame (12.6 waves per CU) and a small graph are not affected.  Everything stays bit-identical to the checker."""
     flame_amd, oracle = env
     from flame_amd.regularizer import OPT_FAULT_INJECT
@@ -877,7 +876,7 @@ def test_an_expired_run_at_high_residency_makes_the_planner_leave_room(env):
             reg.upload_graph(g2)
             reg.run(p, 10 + k)
             oracle.run(ref, 10 + k)
-            assert reg.info()["last_run_path"] == 5, reg.info()["last_run_path"]
+            assert reg.info()["last_run_path"] == 7 and reg.info()["last_run_groups"] == 2, reg.info()
         assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS, what="after the crowded topologies")
         assert reg.info()["timeouts_recovered"] == 1
     big = synth.make_graph("1920x1080", seed=12)

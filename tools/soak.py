@@ -11,7 +11,7 @@ import numpy as np
 import torch  # noqa
 import flame_amd
 from flame_amd import synth
-from flame_amd.regularizer import OPT_DUAL_PUBLISH, OPT_PERSISTENT, OPT_PLACEMENT, OPT_TV_LDS, OPT_VERIFY_RECORDS
+from flame_amd.regularizer import OPT_DUAL_PUBLISH, OPT_PERSISTENT, OPT_PLACEMENT, OPT_VERIFY_RECORDS
 from oracle import capi as oracle
 
 ITERS = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
@@ -57,7 +57,7 @@ for cfg, seed, ITERS in cases:
         with flame_amd.Regularizer(0) as reg:
             reg.set_option(OPT_PERSISTENT, form)
             reg.set_option(OPT_DUAL_PUBLISH, dual)
-            reg.set_option(OPT_TV_LDS, lds)
+            reg.set_option(lds)
             reg.set_option(OPT_VERIFY_RECORDS, verify)
             reg.set_option(OPT_PLACEMENT, place)
             reg.upload_graph(g)

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa
 import flame_amd
 from flame_amd import synth
-from flame_amd.regularizer import OPT_PERSISTENT, OPT_DUAL_PUBLISH, OPT_TV_LDS, RUN_PATHS
+from flame_amd.regularizer import OPT_PERSISTENT, OPT_DUAL_PUBLISH, RUN_PATHS
 
 params = flame_amd.Params()
 cases = [("640x480", 1), ("1280x720", 1), ("1920x1080", 1), ("640x480", 4), ("640x480", 7), ("640x480", 12), ("640x480", 15), ("640x480", 30)]
@@ -19,7 +19,7 @@ for cfg, nf in cases:
         r = flame_amd.Regularizer(0)
         r.set_option(OPT_PERSISTENT, form)
         r.set_option(OPT_DUAL_PUBLISH, dual)
-        r.set_option(OPT_TV_LDS, lds)
+        r.set_option(lds)
         r.upload_graph(g)
         iters = 200 if form else 50
         try:
