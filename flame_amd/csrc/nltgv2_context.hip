@@ -67,9 +67,6 @@ void refresh_args(flame_nltgv2_ctx* ctx) {
   f.edge_src_slot = (int32_t*)ctx->edge_src_slot.p;
   f.hrec = (int4*)ctx->hrec.p, f.hq = (float4*)ctx->hq.p;
   f.vstate = (float4*)ctx->vstate.p, f.vaux = (float2*)ctx->vaux.p;
-  f.hidx = (int2*)ctx->hidx.p, f.erec = (float4*)ctx->erec.p, f.eq[0] = (float*)ctx->eq0.p, f.eq[1] = (float*)ctx->eq1.p;
-  f.n_edge_rows = ctx->L.E;
-  f.edge_row = (int32_t*)ctx->edge_row.p, f.slice_edges = (int32_t*)ctx->slice_edges.p;
   f.hq_out = (float4*)ctx->hq_alt.p, f.vstate_out = (float4*)ctx->vstate_alt.p;
   f.bar[0] = (float4*)ctx->bar0.p, f.bar[1] = (float4*)ctx->bar1.p;
   f.vprev = (float4*)ctx->vprev.p;
@@ -357,27 +354,6 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
 
 // (D) rows: built and uploaded when the vertex-per-lane persistent form is first wanted for the current topology (single
 // frames run in the patch-per-wave form and never need them).
-// Edge rows of the per-step sweep: built on the device from the slot tables of the SELL rows, once per topology, when that sweep first
-// runs it (a fallback: most topologies never need them).
-int ensure_edge_rows(flame_nltgv2_ctx* ctx) {
-  if (ctx->edge_rows_topo == ctx->topo) return 0;
-  const size_t n_slots = (size_t)(ctx->L.rows + kRowPad) * kWave, E1 = (size_t)ctx->c.E + 1;
-  struct { DevBuf* b; size_t bytes; } need[] = {{&ctx->hidx, sizeof(int2) * n_slots}, {&ctx->erec, sizeof(float4) * E1}, {&ctx->eq0, 12 * E1},
-                                                {&ctx->eq1, 12 * E1}, {&ctx->edge_row, sizeof(int32_t) * E1},
-                                                {&ctx->slice_edges, sizeof(int32_t) * ((size_t)ctx->L.n_slices + 1)}};
-  for (auto& n : need) {
-    const int rc = ensure(ctx, *n.b, n.bytes);
-    if (rc) return rc;
-  }
-  refresh_args(ctx);
-  HIPCHK(ctx, hipMemsetAsync((char*)ctx->erec.p + sizeof(float4) * (E1 - 1), 0, sizeof(float4), ctx->stream));  // the spare row
-  HIPCHK(ctx, hipMemsetAsync((char*)ctx->eq0.p + 12 * (E1 - 1), 0, 12, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync((char*)ctx->eq1.p + 12 * (E1 - 1), 0, 12, ctx->stream));
-  LAUNCHCHK(ctx, launch_edge_rows_build(ctx->c, ctx->f, ctx->stream));
-  ctx->edge_rows_topo = ctx->topo;
-  return 0;
-}
-
 int ensure_form_rows(flame_nltgv2_ctx* ctx, int form) {
   PackedLayout& L = ctx->L;
   if ((form == 4 && !ctx->wg2_built) || (form == 2 && !ctx->tv_built)) {  // (the host builders read the host image of the tables)

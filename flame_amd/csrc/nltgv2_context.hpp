@@ -304,9 +304,6 @@ struct flame_nltgv2_ctx {
   RunTail tail_sent{};        // what run_tail currently holds
   bool tail_valid = false;
   std::vector<float> h_terms;
-  DevBuf hidx, erec, eq0, eq1, edge_row, slice_edges;  // edge rows of the per-step sweep (nltgv2_edge_step.hip), built at its first run
-  uint64_t edge_rows_topo = ~0ull;                     // ... of a topology
-  bool step_private = std::getenv("FLAME_NLTGV2_STEP_EDGE_ROWS") == nullptr;  // experiment (profiles/r04_edge_step.txt): unset = private duals per half-edge
   DevBuf hq_alt, vstate_alt;  // the other copies of hq / vstate: a persistent run writes there, success swaps the roles
   DevBuf xbuf, abort_flag, tv_slot, tv_vid, tv_meta, tv_wave, wg2_slot, wg2_vid, wg2_meta, wg2_nbr, wg2_fetch, wg2_info, wg2_vfirst, wg2_rmax;
   DevBuf wg_slot, wg_vid, wg_meta, wg_nbr, wg_fetch, wg_info, wg_v0, wg_vfirst, probe, progress;
@@ -352,7 +349,6 @@ int enter(flame_nltgv2_ctx* ctx);
 void refresh_args(flame_nltgv2_ctx* ctx);                     // kernel argument blocks from the current buffers
 int h2d(flame_nltgv2_ctx* ctx, DevBuf& b, const void* src, size_t bytes);
 size_t records_capacity(const PackedLayout& L);
-int ensure_edge_rows(flame_nltgv2_ctx* ctx);                  // the edge rows of the per-step sweep for the current topology
 int ensure_canon(flame_nltgv2_ctx* ctx);                      // settles a pending run, unpacks the state if needed
 int ensure_fused(flame_nltgv2_ctx* ctx);
 bool params_ok(const flame_nltgv2_params* p);

@@ -76,13 +76,6 @@ struct FusedArgs {
   int4* hrec = nullptr;     // [n_slots] {nbr|role, alpha, dx, dy}
   float4* hq = nullptr;     // [n_slots] {q1,q2,q3,beta}
   float4* vstate = nullptr; // [n_slices*64] {x,w1,w2,data}
-  // the per-step sweep on one copy of the duals (nltgv2_edge_step.hip): edge rows owned by the source endpoint
-  int2* hidx = nullptr;             // [n_slots] {nbr|role, edge row}
-  float4* erec = nullptr;           // [E+1] {alpha, beta, dx, dy}   (row E: the spare row unused slots name)
-  float* eq[2] = {nullptr, nullptr};  // [E+1][3] ping-pong {q1,q2,q3}
-  int32_t* edge_row = nullptr;      // [E] edge id -> edge row
-  int n_edge_rows = 0;              // = E: the spare row
-  int32_t* slice_edges = nullptr;   // [n_slices+1] first edge row of every slice
   float4* hq_out = nullptr;     // the other copies: a persistent run writes its results there and the host swaps
   float4* vstate_out = nullptr; // the roles once the run is known to have succeeded
   float2* vaux = nullptr;   // [n_slices*64] {data_weight, degree bits}
@@ -116,11 +109,6 @@ struct FusedArgs {
 
 int launch_fused_step(const FusedArgs& a, const SolverParams& p, int parity, bool write_prev, int unroll,
                       int waves_per_block, hipStream_t stream);
-int launch_edge_rows_build(const CanonArgs& c, const FusedArgs& a, hipStream_t s);
-int launch_q_to_edge_rows(const FusedArgs& a, int parity, hipStream_t s);    // hq -> eq[parity]
-int launch_q_from_edge_rows(const FusedArgs& a, int parity, hipStream_t s);  // eq[parity] -> hq (both endpoints' copies)
-int launch_edge_step(const FusedArgs& a, const SolverParams& p, int parity, bool write_prev, int unroll, int waves_per_block,
-                     hipStream_t stream);
 int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, int wave_begin, int n_waves,
                           int parity_in, unsigned tag0, int n_iters, int waves_per_block, unsigned max_spins,
                           int presleep, int dual, int tv_static_in_lds, int xcds, const RunTail* tail, bool cooperative,

@@ -178,11 +178,8 @@ int enqueue_fused_eager(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int
                         int wpb, bool prev_on_last) {
   const SolverParams sp = to_sp(p);
   for (int it = 0; it < n; ++it) {
-    if (ctx->step_private) {
-      LAUNCHCHK(ctx, launch_fused_step(ctx->f, sp, parity ^ (it & 1), prev_on_last && it == n - 1, unroll, wpb, ctx->stream));
-    } else {
-      LAUNCHCHK(ctx, launch_edge_step(ctx->f, sp, parity ^ (it & 1), prev_on_last && it == n - 1, unroll, wpb, ctx->stream));
-    }
+    LAUNCHCHK(ctx, launch_fused_step(ctx->f, sp, parity ^ (it & 1), prev_on_last && it == n - 1, unroll, wpb,
+                                     ctx->stream));
   }
   return 0;
 }
@@ -230,10 +227,6 @@ int get_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n, int pa
 // graph instantiation out of timed regions.
 int prepare_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   if (ctx->opt_solver != 0 || !ctx->opt_use_graph || persistent_eligible(ctx, n)) return 0;
-  if (!ctx->step_private) {
-    const int rc = ensure_edge_rows(ctx);
-    if (rc) return rc;
-  }
   int unroll, wpb;
   pick_config(ctx, &unroll, &wpb);
   int parity = ctx->parity;
@@ -541,12 +534,6 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
     op.dst = ctx->export_ptr, op.scale = ctx->export_scale;
     ctx->pending.ops.push_back(op);
   }
-  // The per-step sweep keeps ONE copy of the duals, in edge rows (nltgv2_edge_step.hip): hq -> rows, n steps, rows -> hq.
-  if (!ctx->step_private) {
-    rc = ensure_edge_rows(ctx);
-    if (rc) return rc;
-    LAUNCHCHK(ctx, launch_q_to_edge_rows(ctx->f, ctx->parity, ctx->stream));
-  }
   int left = n;
   while (left > 0) {
     const int chunk = left >= kGraphChunk ? kGraphChunk : left;
@@ -564,7 +551,6 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
     ctx->parity ^= (chunk & 1);
     left -= chunk;
   }
-  if (!ctx->step_private) LAUNCHCHK(ctx, launch_q_from_edge_rows(ctx->f, ctx->parity, ctx->stream));
   ctx->have_prev = true;
   ctx->canon_valid = false;
   if (ctx->export_ptr) LAUNCHCHK(ctx, launch_export(ctx->c, ctx->f, true, ctx->export_scale, ctx->export_ptr, ctx->stream));
