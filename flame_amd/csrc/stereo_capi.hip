@@ -35,6 +35,8 @@ struct flame_stereo_ctx {
   bool have_camera = false;
   StereoCamera cam{};
   std::unordered_map<uint32_t, Frame> frames;
+  std::vector<Frame> spare;  // buffers of dropped frames, reused by the next add_frame: hipFree waits for every stream of the device, also
+                             // for a solver that runs beside the tracker (tools/frame_loop.py --pipelined: 0.5 ms per frame)
   uint8_t* d_raw = nullptr;  // staging of the unpadded upload
   size_t raw_cap = 0;
   StereoPoseEntry* d_poses = nullptr;
@@ -78,6 +80,8 @@ void free_frame(Frame& f) {
 void drop_all_frames(flame_stereo_ctx* ctx) {
   for (auto& kv : ctx->frames) free_frame(kv.second);
   ctx->frames.clear();
+  for (Frame& f : ctx->spare) free_frame(f);  // (the camera changes: another padded size)
+  ctx->spare.clear();
 }
 
 size_t padded_pixels(const StereoCamera& c) { return (size_t)(c.width + 2 * c.border) * (size_t)(c.height + 2 * c.border); }
@@ -272,6 +276,10 @@ int flame_stereo_add_frame(flame_stereo_ctx* ctx, uint32_t frame_id, const uint8
   if (int rc = grow(ctx, &ctx->d_raw, &ctx->raw_cap, (size_t)w * h)) return rc;
   Frame& f = ctx->frames[frame_id];
   const size_t px = padded_pixels(ctx->cam);
+  if (!f.img_pad && !ctx->spare.empty()) {
+    f = ctx->spare.back();
+    ctx->spare.pop_back();
+  }
   if (!f.img_pad) {
     hipError_t e = hipMalloc((void**)&f.img_pad, px);
     if (e == hipSuccess) e = hipMalloc((void**)&f.gx_pad, px * sizeof(float));
@@ -296,7 +304,8 @@ int flame_stereo_drop_frame(flame_stereo_ctx* ctx, uint32_t frame_id) {
   auto it = ctx->frames.find(frame_id);
   if (it == ctx->frames.end()) return FLAME_NLTGV2_ERR_INVALID_ARG;
   SCHK(ctx, hipStreamSynchronize(ctx->stream));
-  free_frame(it->second);
+  constexpr size_t kSpareFrames = 4;
+  if (ctx->spare.size() < kSpareFrames) ctx->spare.push_back(it->second); else free_frame(it->second);
   ctx->frames.erase(it);
   return 0;
 }

@@ -227,7 +227,7 @@ def delaunay(pos):
                                       edg.ctypes.data_as(_IP), edg.shape[0], C.byref(ne))
     if rc != 0:
         raise NLTGV2Error(rc, "flame_delaunay_triangulate")
-    return tri[: nt.value].copy(), edg[: ne.value].copy()
+    return tri[: nt.value], edg[: ne.value]  # (views of the over-allocated arrays: no second copy)
 
 
 def pack_probe(g: dict):

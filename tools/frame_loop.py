@@ -29,6 +29,7 @@ ap.add_argument("--iters", type=int, default=200)
 ap.add_argument("--frames", type=int, default=6)
 ap.add_argument("--cpu", action="store_true")
 ap.add_argument("--pipelined", action="store_true")
+ap.add_argument("--cover", type=float, default=1.25, help="--pipelined: the chunk enqueued before Delaunay + sync_prepare covers this many times their last duration")
 ap.add_argument("--host-sync", action="store_true", help="index maps + layout tables on the host (rounds 1-3), for comparison")
 a = ap.parse_args()
 W, H = [int(v) for v in a.size.split("x")]
@@ -165,7 +166,7 @@ else:
         tr.update_feature_idepths(SP, k, 11, poses, feats)            # updateFeatureIDepths
         track_ms = 0.9 * (time.perf_counter() - t0) * 1e3
         reg.project_graph(sc.K32, sc.Kinv32, KRKinv, q, t, REGION)    # settles the solver
-        solve(1.08 * host_ms, "Frame::create + updateFeatureIDepths + projectGraph")  # ... which iterates on while the host triangulates
+        solve(a.cover * host_ms, "Frame::create + updateFeatureIDepths + projectGraph")  # ... which iterates on while the host triangulates
         t0 = time.perf_counter()
         tris, edges = flame_amd.delaunay(pos)
         reg.sync_prepare(fid, pos, idp, ones, edges, edges_unique=True, init_from_map=True, init_graph_scale=1.0)
