@@ -19,6 +19,7 @@ namespace {
 // accumulation still follows ascending edge id exactly.  The last lane of a chain owns the vertex:
 // it applies proxL1 / extragradient, publishes the record and hands the state back to its chain.
 // ------------------------------------------------------------------------------------------------
+typedef float v2f_t __attribute__((ext_vector_type(2)));
 constexpr int kTvS = 8;
 constexpr unsigned kTvOwnerBit = 1u << 16, kTvValidBit = 1u << 17;
 
@@ -26,11 +27,18 @@ __device__ __forceinline__ float dpp_shr1(float v) {  // lane l <- lane l-1; lan
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
 }
 
-// LDS_STATIC: the per-slot constants (neighbour offset, alpha, dx, dy, beta: 40 dwords per lane) live in LDS
-// (10 KB per wave) instead of registers: <= 128 VGPRs, four waves per SIMD (16 per CU, which is also all of the
-// CU's 160 KB of LDS): bigger resident batches and 4K-sized single graphs.  The duals stay in registers.
+// The per-slot constants (40 dwords per lane) live in LDS, 10 KB per wave: <= 128 VGPRs, four waves per SIMD (16 per CU, which is also
+// all of the CU's 160 KB of LDS): 30 frames of 640x480 resident, 4K-sized single graphs.  The duals stay in registers.
+//
+// Per slot: neighbour offset | role, as = +-alpha (source +, target -), bs = +-beta, dx, dy.  With the signs folded into the constants
+// both roles run ONE instruction sequence (k_persistent_pv2's, same IEEE results: a - b == -(b - a), (-a) * b == -(a * b)), and the pair
+// (w1, w2) / (q2, q3) is packed arithmetic (v_pk_mul_f32 / v_pk_add_f32): ~36 instead of ~45 vector instructions per slot for the duals
+// and 3 instead of 12 per slot and pass for the ordered accumulation -- at 16 waves per CU this kernel is bound by VALU issue
+// (profiles/r04_counters.json: SQ_ACTIVE_INST_VALU = 0.24 of every wave's cycles, four waves per SIMD).  An unused slot holds
+// (as, bs, dx, dy) = (+0, +0, -0, -0) and reads a zero record: every contribution of it then is exactly -0.0, and x + (-0.0) == x
+// for every x -- no predicate in the accumulation.
 template <bool LDS_STATIC>
-__global__ void __launch_bounds__(256, LDS_STATIC ? 4 : 2)
+__global__ void __launch_bounds__(256, 4)
 k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd, const int32_t* __restrict__ tv_slot,
                 const int32_t* __restrict__ tv_vid, const uint32_t* __restrict__ tv_meta,
                 const uint32_t* __restrict__ tv_wave, const int4* hrec, const float4* hq, const float4* vstate,
@@ -38,6 +46,7 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
                 float4* vprev, void* xbuf, const int rec_bytes, const int dual_arg, const unsigned tag0, const int n_iters,
                 const unsigned max_spins_arg, const int presleep, const SolverParams p, int* __restrict__ err,
                 int* __restrict__ abort_flag, const int32_t* __restrict__ perm, const RunTail* __restrict__ tail) {
+  static_assert(LDS_STATIC, "the register instance was retired in round 4");
   const unsigned max_spins = max_spins_arg & 0x7fffffffu;
   const int dual = dual_arg & 1, verify = dual_arg >> 1;  // as in k_persistent_he
   const int lane = threadIdx.x & 63;
@@ -62,15 +71,14 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
 
   extern __shared__ __attribute__((aligned(16))) int tv_smem[];
   int* const s_base = tv_smem + (threadIdx.x >> 6) * (5 * kTvS * 64) + lane;  // [field][slot][lane] per wave
-  int r_nbr[LDS_STATIC ? 1 : kTvS];
-  float r_alpha[LDS_STATIC ? 1 : kTvS], r_dx[LDS_STATIC ? 1 : kTvS], r_dy[LDS_STATIC ? 1 : kTvS], r_beta[LDS_STATIC ? 1 : kTvS];
 #define TV_I(field, k) s_base[((field) * kTvS + (k)) * 64]
-#define NBR(k) (*(LDS_STATIC ? &TV_I(0, k) : &r_nbr[LDS_STATIC ? 0 : (k)]))
-#define ALPHA(k) (*(LDS_STATIC ? (float*)&TV_I(1, k) : &r_alpha[LDS_STATIC ? 0 : (k)]))
-#define DX(k) (*(LDS_STATIC ? (float*)&TV_I(2, k) : &r_dx[LDS_STATIC ? 0 : (k)]))
-#define DY(k) (*(LDS_STATIC ? (float*)&TV_I(3, k) : &r_dy[LDS_STATIC ? 0 : (k)]))
-#define BETA(k) (*(LDS_STATIC ? (float*)&TV_I(4, k) : &r_beta[LDS_STATIC ? 0 : (k)]))
-  float q1[kTvS], q2[kTvS], q3[kTvS];
+#define NBR(k) TV_I(0, k)
+#define AS(k) (*(float*)&TV_I(1, k))
+#define BS(k) (*(float*)&TV_I(2, k))
+#define DX(k) (*(float*)&TV_I(3, k))
+#define DY(k) (*(float*)&TV_I(4, k))
+  float q1[kTvS];
+  v2f_t q23[kTvS];
 #pragma unroll
   for (int k = 0; k < kTvS; ++k) {
     const int sl = tv_slot[((size_t)w * kTvS + k) * 64 + lane];
@@ -80,9 +88,33 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
       r = hrec[sl];
       q = hq[sl];
     }
+    const bool tgt = r.x < 0;
+    const float alpha = __int_as_float(r.y);
     NBR(k) = (int)(((unsigned)r.x & 0x80000000u) | (((unsigned)r.x & 0x07ffffffu) << 4));
-    ALPHA(k) = __int_as_float(r.y), DX(k) = __int_as_float(r.z), DY(k) = __int_as_float(r.w);
-    q1[k] = q.x, q2[k] = q.y, q3[k] = q.z, BETA(k) = q.w;
+    AS(k) = tgt ? -alpha : alpha, BS(k) = tgt ? -q.w : q.w;
+    DX(k) = sl >= 0 ? __int_as_float(r.z) : -0.0f, DY(k) = sl >= 0 ? __int_as_float(r.w) : -0.0f;
+    q1[k] = q.x, q23[k] = v2f_t{q.y, q.z};
+  }
+  // Neighbours that live in this very wave (a wave holds 64 vertices along the Morton curve: ~85 % of the half-edges) are not fetched
+  // through L2 at all: their bars are the registers of another lane, read with ds_bpermute at the start of every step -- always
+  // current, nothing to wait for.  NBR(k) of such a slot: role | lane << 4 | 1.  (Every lane of a chain holds its vertex' bars.)
+  unsigned sw_mask = 0u;
+  {
+    int nv[kTvS];
+#pragma unroll
+    for (int k = 0; k < kTvS; ++k) nv[k] = (k < (int)(meta & 15u)) ? (NBR(k) & 0x7fffffff) >> 4 : -2;
+    const int mine = (meta & kTvValidBit) ? pv : -1;
+    for (int l = 0; l < 64; ++l) {
+      const int vid_l = __builtin_amdgcn_readlane(mine, l);
+#pragma unroll
+      for (int k = 0; k < kTvS; ++k) {
+        if (nv[k] == vid_l) {
+          NBR(k) = (int)(((unsigned)NBR(k) & 0x80000000u) | ((unsigned)l << 4) | 1u);
+          sw_mask |= 1u << k;
+          nv[k] = -2;
+        }
+      }
+    }
   }
 
   float4 st = make_float4(0.f, 0.f, 0.f, 0.f), bs = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -94,9 +126,12 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
   }
   const float data = st.w;
   const float lam_w = p.data_factor * aux.x;
-  float x = st.x, w1 = st.y, w2 = st.z;  // invariant: every lane of a chain holds the vertex state
-  float xb = bs.x, w1b = bs.y, w2b = bs.z;
-  float x_prev = x, w1_prev = w1, w2_prev = w2;
+  float x = st.x;  // invariant: every lane of a chain holds the vertex state
+  v2f_t w12 = {st.y, st.z};
+  float xb = bs.x;
+  v2f_t wb12 = {bs.y, bs.z};
+  float x_prev = x;
+  v2f_t w_prev = w12;
   bool ok = true;
   bool timed_out = false, torn = false;
   const int ps = presleep;
@@ -104,7 +139,7 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(xbuf);
   const int my_off = pv << 4;
   const int S = rec_bytes, par = 2 * rec_bytes;
-  const unsigned all_mask = (1u << nslots) - 1u;
+  const unsigned all_mask = ((1u << nslots) - 1u) & ~sw_mask;  // the slots that are fetched
 
   if (dual) {  // one-time XCC exchange: which neighbours run on my XCD?  (bit 30 of nbr[k] := same XCD)
     const unsigned my_xcc = read_xcc_id();
@@ -141,17 +176,32 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
   const bool mute = (max_spins_arg >> 31) != 0u && w == wave_begin;  // test hook, see k_persistent_he
   if (is_owner && !timed_out && !mute) {
     v4i_t o;
-    o.x = __float_as_int(xb), o.y = __float_as_int(w1b), o.z = __float_as_int(w2b), o.w = (int)tag0;
+    o.x = __float_as_int(xb), o.y = __float_as_int(wb12.x), o.z = __float_as_int(wb12.y), o.w = (int)tag0;
     const int so = (tag0 & 1u) ? par : 0;
     __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off, so, kAuxSc1);
     if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
   }
 
+  // the neighbour records of a step, then its contributions.  An unused slot is never fetched: it reads zeros in the first step and its
+  // own contributions (-0.0) afterwards -- finite either way, which is all its arithmetic needs to stay at -0.0.
+  v4i_t g[kTvS];
+#pragma unroll
+  for (int k = 0; k < kTvS; ++k) g[k] = v4i_t{0, 0, 0, 0};
   for (int it = 0; it < n_iters && !timed_out; ++it) {
     const unsigned s = tag0 + (unsigned)it;
     const int so_in = (s & 1u) ? par : 0;
-    // ---- wait for all neighbours' bar(s): one round of loads in flight, only pending slots re-polled
-    v4i_t g[kTvS];
+    {  // same-wave neighbours: all lane indices first, then all 24 permutes back to back, one wait.  Every lane takes what it gets -- a
+       // fetching slot overwrites it below, an unused slot only needs something finite.
+      int from[kTvS];
+#pragma unroll
+      for (int k = 0; k < kTvS; ++k) from[k] = (NBR(k) >> 2) & 0xfc;  // lane * 4
+#pragma unroll
+      for (int k = 0; k < kTvS; ++k) {
+        g[k].x = __builtin_amdgcn_ds_bpermute(from[k], __float_as_int(xb));
+        g[k].y = __builtin_amdgcn_ds_bpermute(from[k], __float_as_int(wb12.x));
+        g[k].z = __builtin_amdgcn_ds_bpermute(from[k], __float_as_int(wb12.y));
+      }
+    }
     unsigned pending = all_mask;
     unsigned spins = 0;
     for (int z = 0; z < ps; ++z) __builtin_amdgcn_s_sleep(1);
@@ -177,7 +227,10 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
           break;
         }
       }
-      __builtin_amdgcn_s_sleep(1);
+#ifndef TV_SPIN_SLEEP
+#define TV_SPIN_SLEEP 1
+#endif
+      __builtin_amdgcn_s_sleep(TV_SPIN_SLEEP);
     }
     if (timed_out) break;
     if (verify) {  // a record is final once its tag is visible: a second read must return the same 16 bytes
@@ -188,7 +241,7 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
           int o = NBR(k) & 0x7fffffff;
           asm volatile("" : "+v"(o)::"memory");
           v4i_t g2 = __builtin_amdgcn_raw_buffer_load_b128(rx, o, so_in, kAuxSc1);
-          if ((verify & 2) && it == 2 && w == wave_begin && lane == 0 && k == 0) g2.x ^= 0x00400000;  // test hook
+          if ((verify & 2) && it == 2 && w == wave_begin && k == __ffs((int)all_mask) - 1) g2.x ^= 0x00400000;  // test hook: every lane's first fetched slot
           bad = bad || g2.x != g[k].x || g2.y != g[k].y || g2.z != g[k].z || g2.w != g[k].w;
         }
       }
@@ -199,66 +252,70 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
     }
 
     __builtin_amdgcn_s_setprio(3);  // from the records' arrival to the publish this wave goes before the polling ones (k_persistent_pv)
-    // ---- phase A, every lane at once: dual update of each slot's private q copy (cc:99-110) and the three
-    // step-scaled values its primal scatter needs (cc:126-141).  They overwrite the neighbour record of the slot
-    // (dead from here on), so the ordered accumulation below costs no registers.
+    // ---- phase A, every lane at once: dual update of each slot's private q copy (cc:99-110) and its three contributions to the
+    // primal scatter (cc:126-141), signs folded in: X += cx, W += A, W += B reproduces
+    //   source: x - t1,  (w + t1 * d) - (t2, t3)        target: x + t1,  w + (t2, t3)     with t1 = q1 step_x alpha, (t2, t3) = q23 step_x beta
+    // (A, B) overwrite the neighbour record of the slot, dead by then: the accumulation costs eight registers (cx), not forty.
+    float cx[kTvS];
 #pragma unroll
     for (int k = 0; k < kTvS; ++k) {
       const bool is_target = NBR(k) < 0;
-      const float alpha_k = ALPHA(k), beta_k = BETA(k), dx_k = DX(k), dy_k = DY(k);
-      const float nxb = __int_as_float(g[k].x), nw1b = __int_as_float(g[k].y), nw2b = __int_as_float(g[k].z);
-      const float xbi = is_target ? nxb : xb, xbj = is_target ? xb : nxb;
-      const float w1bi = is_target ? nw1b : w1b, w1bj = is_target ? w1b : nw1b;
-      const float w2bi = is_target ? nw2b : w2b, w2bj = is_target ? w2b : nw2b;
-      bool okq = true;
-      const EdgeOut e = edge_dual(p, alpha_k, beta_k, dx_k, dy_k, q1[k], q2[k], q3[k], xbi, w1bi, w2bi,
-                                  xbj, w1bj, w2bj, okq);
-      g[k].x = __float_as_int(e.q1 * p.step_x * alpha_k);
-      g[k].y = __float_as_int(e.q2 * p.step_x * beta_k);
-      g[k].z = __float_as_int(e.q3 * p.step_x * beta_k);
-      if (k < nslots) {
-        q1[k] = e.q1, q2[k] = e.q2, q3[k] = e.q3;
-        ok = ok && okq;
-      }
+      const float as = AS(k), bs_k = BS(k);
+      const v2f_t d = {DX(k), DY(k)};
+      const v2f_t nbw = {__int_as_float(g[k].y), __int_as_float(g[k].z)};
+      const float d0 = xb - __int_as_float(g[k].x);
+      const v2f_t d12 = wb12 - nbw;
+      const v2f_t wbi = is_target ? nbw : wb12;
+      float K1 = as * d0;
+      const float alpha = __builtin_fabsf(as);
+      const v2f_t P12 = {alpha * d.x, alpha * d.y};
+      const v2f_t m12 = P12 * wbi;
+      K1 -= m12.x;
+      K1 -= m12.y;
+      const v2f_t K23 = bs_k * d12;
+      const float q1r = q1[k] + p.step_q * K1;
+      const v2f_t q23r = q23[k] + p.step_q * K23;
+      ok = ok && (__builtin_fabsf(q1r) <= 3.402823466e+38f) && (__builtin_fabsf(q23r.x) <= 3.402823466e+38f) &&
+           (__builtin_fabsf(q23r.y) <= 3.402823466e+38f);  // (an unused slot: zeros, finite)
+      q1[k] = __builtin_fminf(__builtin_fmaxf(q1r, -1.0f), 1.0f);
+      q23[k].x = __builtin_fminf(__builtin_fmaxf(q23r.x, -1.0f), 1.0f);
+      q23[k].y = __builtin_fminf(__builtin_fmaxf(q23r.y, -1.0f), 1.0f);
+      const float u1 = q1[k] * p.step_x;
+      const v2f_t u23 = q23[k] * p.step_x;
+      cx[k] = u1 * -as;                   // source: -t1, target: +t1
+      const v2f_t v = u23 * -bs_k;        // source: -(t2, t3), target: +(t2, t3)
+      const v2f_t a_src = cx[k] * -d;     // source: t1 * (dx, dy)
+      const v2f_t Ak = is_target ? v : a_src, Bk = is_target ? v2f_t{-0.0f, -0.0f} : v;
+      g[k] = v4i_t{__float_as_int(Ak.x), __float_as_int(Ak.y), __float_as_int(Bk.x), __float_as_int(Bk.y)};
     }
     // ---- phase B, ordered accumulation in ascending edge id: pass 0 for the first lane of every vertex, pass c
     // for the c-th continuation lane of vertices with more than eight edges (it first takes over the running sums
-    // of the lane before it).  A Delaunay wave contains such a vertex more often than not; with the duals already
-    // done a further pass is 13 instead of ~60 instructions per slot.
-    float X = x, W1 = w1, W2 = w2;
+    // of the lane before it).  A Delaunay wave contains such a vertex more often than not; every lane accumulates in
+    // exactly one pass.
+    float X = x;
+    v2f_t Wv = w12;
     for (int pass = 0; pass < passes; ++pass) {
       if (pass > 0) {
-        const float Xs = dpp_shr1(X), W1s = dpp_shr1(W1), W2s = dpp_shr1(W2);
-        if (cidx == pass) X = Xs, W1 = W1s, W2 = W2s;
+        const float Xs = dpp_shr1(X), W1s = dpp_shr1(Wv.x), W2s = dpp_shr1(Wv.y);
+        if (cidx == pass) X = Xs, Wv = v2f_t{W1s, W2s};
       }
-      const bool live = (cidx == pass);
+      if (cidx == pass) {
 #pragma unroll
-      for (int k = 0; k < kTvS; ++k) {
-        const bool act = live && (k < nslots);
-        const bool is_target = NBR(k) < 0;
-        const float t1 = __int_as_float(g[k].x), t2 = __int_as_float(g[k].y), t3 = __int_as_float(g[k].z);
-        float nx, nw1, nw2;
-        if (is_target) {
-          nx = X + t1;
-          nw1 = W1 + t2;
-          nw2 = W2 + t3;
-        } else {
-          nx = X - t1;
-          nw1 = W1 + t1 * DX(k);
-          nw2 = W2 + t1 * DY(k);
-          nw1 = nw1 - t2;
-          nw2 = nw2 - t3;
+        for (int k = 0; k < kTvS; ++k) {
+          X = X + cx[k];
+          Wv = Wv + v2f_t{__int_as_float(g[k].x), __int_as_float(g[k].y)};
+          Wv = Wv + v2f_t{__int_as_float(g[k].z), __int_as_float(g[k].w)};
         }
-        if (act) X = nx, W1 = nw1, W2 = nw2;
       }
     }
+    const float W1 = Wv.x, W2 = Wv.y;
     // ---- vertex update at the owner lane ----------------------------------------------------------
     const float xn = prox_l1(p.x_min, p.x_max, p.step_x, lam_w, X, data);
     float nb = xn + p.theta * (xn - x);
     nb = (nb < p.x_min) ? p.x_min : nb;
     nb = (nb > p.x_max) ? p.x_max : nb;
-    const float w1bn = W1 + p.theta * (W1 - w1);
-    const float w2bn = W2 + p.theta * (W2 - w2);
+    const float w1bn = W1 + p.theta * (W1 - w12.x);
+    const float w2bn = W2 + p.theta * (W2 - w12.y);
     if (is_owner) {
       v4i_t o;
       o.x = __float_as_int(nb), o.y = __float_as_int(w1bn), o.z = __float_as_int(w2bn), o.w = (int)(s + 1u);
@@ -267,16 +324,14 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
       if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
     }
     __builtin_amdgcn_s_setprio(0);
-    x_prev = x, w1_prev = w1, w2_prev = w2;
+    x_prev = x, w_prev = w12;
     if (has_chain) {  // wave-uniform: hand the owner's new state back to every lane of its chain
       x = __shfl(xn, owner_lane, 64);
-      w1 = __shfl(W1, owner_lane, 64);
-      w2 = __shfl(W2, owner_lane, 64);
+      w12 = v2f_t{__shfl(W1, owner_lane, 64), __shfl(W2, owner_lane, 64)};
       xb = __shfl(nb, owner_lane, 64);
-      w1b = __shfl(w1bn, owner_lane, 64);
-      w2b = __shfl(w2bn, owner_lane, 64);
+      wb12 = v2f_t{__shfl(w1bn, owner_lane, 64), __shfl(w2bn, owner_lane, 64)};
     } else {
-      x = xn, w1 = W1, w2 = W2, xb = nb, w1b = w1bn, w2b = w2bn;
+      x = xn, w12 = Wv, xb = nb, wb12 = v2f_t{w1bn, w2bn};
     }
   }
 
@@ -288,9 +343,9 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
     return;
   }
   if (is_owner) {  // into the other copies of the state arrays, see k_persistent_he
-    vstate_out[pv] = make_float4(x, w1, w2, data);
-    bar_out[pv] = make_float4(xb, w1b, w2b, 0.0f);
-    vprev[pv] = make_float4(x_prev, w1_prev, w2_prev, 0.0f);
+    vstate_out[pv] = make_float4(x, w12.x, w12.y, data);
+    bar_out[pv] = make_float4(xb, wb12.x, wb12.y, 0.0f);
+    vprev[pv] = make_float4(x_prev, w_prev.x, w_prev.y, 0.0f);
     float* const export_out = tail->export_out;
     float* const photo_err = tail->photo.err;
     if (export_out || photo_err) {
@@ -305,14 +360,14 @@ k_persistent_tv(const int wave_begin, const int n_waves, const int waves_per_xcd
   }
 #pragma unroll
   for (int k = 0; k < kTvS; ++k) {
-    if (k < nslots) hq_out[tv_slot[((size_t)w * kTvS + k) * 64 + lane]] = make_float4(q1[k], q2[k], q3[k], BETA(k));
+    if (k < nslots) hq_out[tv_slot[((size_t)w * kTvS + k) * 64 + lane]] = make_float4(q1[k], q23[k].x, q23[k].y, __builtin_fabsf(BS(k)));
   }
   if (!ok) atomicOr(err, 1);
 #undef NBR
-#undef ALPHA
+#undef AS
+#undef BS
 #undef DX
 #undef DY
-#undef BETA
 #undef TV_I
 }
 
