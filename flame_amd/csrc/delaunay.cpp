@@ -662,9 +662,9 @@ extern "C" int flame_delaunay_triangulate(const float* xy, int32_t n, int32_t* t
   }
 
   // ---- large inputs: strips in parallel (same triangulation; the order of the output is the strips') ------------------
-  // (16 strips would be ~0.15 ms faster at 8 k points on a 256-core host; the count stays: it fixes the order of the output edges,
-  // which the committed fixtures of the synthetic graphs pin)
-  int n_strips = n < 4096 ? 1 : std::min(32, n / 1024);
+  // (measured on a 256-core host: 8 480 points 0.83 / 0.65 / 0.64 ms with 8 / 16 / 32 strips, 57 600 points 5.1 / 3.9 / 3.5 ms.  The count fixes
+  // the ORDER of the output edges: flame_amd/synth.py pins the former min(32, n / 1024) for the synthetic graphs the fixtures hold)
+  int n_strips = n < 4096 ? 1 : std::min(32, n / 512);
   if (const char* e = std::getenv("FLAME_DELAUNAY_STRIPS")) n_strips = std::max(1, std::min(std::atoi(e), std::min(64, n / 64 + 1)));  // (tests)
   if (std::getenv("FLAME_DELAUNAY_PROFILE"))
     std::fprintf(stderr, "[delaunay] prep %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_enter);
