@@ -573,7 +573,7 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
             "measured_period_us": round(1e6 / oc["1280x720"]["iters_per_s"], 3),
             "frac_of_hbm_at_uncoupled_period": round(B720 / (ms8 * 1e-3 / 200) / 1e9 / HBM_PEAK_GBPS, 4),
             "note": "what this frame would show if none of its records crossed an XCD: the period of a graph of this size is set by the patches a CU "
-                    "holds (8 per CU here: two waves per SIMD), not by bandwidth and not by the crossings (DESIGN.md section 4, 'What the period depends on')"}
+                    "holds (8 per CU here: two waves per SIMD), not by bandwidth and not by the crossings (DESIGN.md section 4, 'What the period depends on'; docs/DESIGN_r3.md for the measurements)"}
     except Exception as e:  # the extras never take the line down
         oc["1280x720"]["floor"] = f"{type(e).__name__}: {e}"
     out["other_configs"] = oc

@@ -34,12 +34,12 @@ namespace {
 // what a CU really holds); every wait is bounded and reports through `err`.  The run is transactional: it reads hq / vstate /
 // bar_in and writes hq_out / vstate_out / bar_out (the other copies), so the host can take an expired run back and redo it per
 // step.  (Round 1's first form, one lane per half-edge with every lane polling its own neighbour from memory -- k_persistent_he
-// -- was retired in round 3: the patch-per-wave form below runs everything it ran, faster)
+// -- was retired in round 3: the patch-per-wave form below runs everything it ran, faster; docs/DESIGN_r3.md section 4.)
 // ------------------------------------------------------------------------------------------------
 
 // ------------------------------------------------------------------------------------------------
 // Persistent run, patch-per-wave form ("pv"): a lane per half-edge, organised around
-// what the in-kernel probes of round 2 measured (profiles/r02_persistent/):
+// what the in-kernel probes of round 2 measured (profiles/r02_persistent/, docs/DESIGN_r3.md section 4):
 //   * a lone wave issues one instruction every ~4.5 cycles and an LDS round trip costs ~120: a step costs what the
 //     instructions and LDS trips BETWEEN a record arriving and the next one leaving cost (round 1's k_persistent_he: ~1400 cycles,
 //     of which the DPP ripple 750; here ~850);
@@ -99,7 +99,7 @@ __device__ __forceinline__ void report_expired(int* err, int which, int wg, int 
 }
 
 // amdgpu_num_sgpr(92): 90 SGPRs as built -> 96 + the trap handler's 16 = 112 per wave, SEVEN waves per SIMD really resident (at the
-// compiler's own choice, 106, it is six: "Round 3" in DESIGN.md section 4); the scalar spills this costs stay outside the hand-off path
+// compiler's own choice, 106, it is six: "Round 3" in docs/DESIGN_r3.md section 4); the scalar spills this costs stay outside the hand-off path
 // (640x480: 0.962 against 0.962 us per iteration, profiles/r03_priority.txt (7)) and a 1080p frame's 25 patches per CU fit one launch.
 template <bool PROBE, bool VERIFY>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(92)))

@@ -1,7 +1,7 @@
 // nltgv2_persistent_pv2.hip -- k_persistent_pv2: the patch-per-wave persistent kernel with TWO half-edges per lane (layout (E2)
 // of nltgv2_pack.hpp).  Same protocol, same arithmetic, same order of every vertex's accumulation as k_persistent_pv
 // (nltgv2_persistent.hip, which documents both); a wave owns a patch of ~18 vertices instead of ~9, so a graph needs half as many
-// waves.  The period of the lock-step network grows with the waves a CU holds ("What the period depends
+// waves.  The period of the lock-step network grows with the waves a CU holds (docs/DESIGN_r3.md section 4, "What the period depends
 // on"): this form is for graphs that fill the chip in the one-half-edge-per-lane form (a 1920x1080 frame: 25 waves per CU there,
 // 12.6 here).  Against k_persistent_pv it has no cycle probe, no placed records and takes no vertex of more than 32 edges (the planner
 // keeps such graphs on the other forms); the record verification (FLAME_NLTGV2_OPT_VERIFY_RECORDS) is a second instance.
