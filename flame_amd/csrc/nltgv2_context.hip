@@ -467,7 +467,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
               &ctx->wg_fetch, &ctx->wg_info, &ctx->wg_v0, &ctx->probe, &ctx->snap_hq, &ctx->snap_vstate, &ctx->snap_bar, &ctx->iperm,
               &ctx->order_m, &ctx->rid_of, &ctx->stage[0].d, &ctx->stage[1].d, &ctx->sync_init, &ctx->sync_vmap, &ctx->sync_emap, &ctx->sync_need,
               &ctx->wg_vfirst, &ctx->place_pool, &ctx->place_rank, &ctx->place_fill, &ctx->place_rec_off, &ctx->place_patch, &ctx->place_meas, &ctx->progress};
-  for (DevBuf* b : {&ctx->feat_stamp_d, &ctx->feat_val_d, &ctx->topo_scratch, &ctx->topo_dims, &ctx->layout_pos}) ctx->all.push_back(b);
+  for (DevBuf* b : {&ctx->feat_stamp_d, &ctx->feat_key_d, &ctx->feat_val_d, &ctx->topo_scratch, &ctx->topo_dims, &ctx->layout_pos}) ctx->all.push_back(b);
   for (auto& b : ctx->nx) ctx->all.push_back(&b);
   for (auto& b : ctx->sp_v) ctx->all.push_back(&b);
   for (auto& b : ctx->sp_q) ctx->all.push_back(&b);

@@ -256,8 +256,11 @@ struct flame_nltgv2_ctx {
   int opt_cost_sum = 0;           // flame_nltgv2_costs: 0 sequential sums in the reference's edge / the caller's vertex order (host), 1 k_block_sum
   int opt_sync_path = 0;          // 0 auto (device where it applies), 1 host index maps + host tables, 2 device or error
   int last_sync_path = 0;         // 1 host, 2 device
-  // the device's feature table: id -> vertex of the current graph where feat_stamp_d[id] == feat_gen (nltgv2_topo.hip)
-  DevBuf feat_stamp_d, feat_val_d, topo_scratch, topo_dims;
+  // the device's feature tables: id -> vertex of the graph of generation feat_gen in table feat_gen & 1 (nltgv2_topo.hip: feat_insert / feat_lookup)
+  DevBuf feat_stamp_d, feat_key_d, feat_val_d, topo_scratch, topo_dims;
+  std::vector<int32_t> dup_key;      // prepared sync: duplicate check of the caller's feature ids (a stamped hash set)
+  std::vector<uint32_t> dup_stamp;
+  uint32_t dup_now = 0;
   // A frame sync is PREPARED beside the running solver (flame_nltgv2_sync_prepare): the builder reads the live topology and writes
   // the next one into these; flame_nltgv2_sync_commit swaps them with their live counterparts (nx_live) once the solver has stopped.
   enum { NX_POS, NX_SRC, NX_DST, NX_ROW_PTR, NX_HALF, NX_ORDER_M, NX_RID_OF, NX_PERM, NX_IPERM, NX_PDEG, NX_SLICE_ROW, NX_WG_INFO, NX_WG_V0,
@@ -288,7 +291,7 @@ struct flame_nltgv2_ctx {
     size_t off[6] = {};              // the inputs in stage[1].h: feat_id, edges, pos, data_term, data_weight, init_x
     std::chrono::steady_clock::time_point t_begin, t_enqueued;
   } prepared;
-  int feat_tab_size_d = 0;
+  int feat_tab_bits_d = 0;
   uint32_t feat_gen = 0;
   bool feat_dev_valid = false;
   TopoDims* h_dims = nullptr;     // pinned

@@ -210,9 +210,12 @@ struct TopoBuild {
   const int32_t* o_row_ptr = nullptr;
   const uint32_t* o_half = nullptr;
   const int32_t *o_src = nullptr, *o_dst = nullptr;
-  uint32_t* feat_stamp = nullptr;
+  // two open-addressing tables of 2^tab_bits slots each (>= 4 slots per vertex), table g & 1 holds the graph of generation g: a slot
+  // is live iff its stamp equals that generation -- nothing is ever cleared, feature ids may be any non-negative int32
+  uint32_t* feat_stamp = nullptr;  // [2 << tab_bits]
+  int32_t* feat_key = nullptr;
   int32_t* feat_val = nullptr;
-  int tab_size = 0;
+  int tab_bits = 0;
   uint32_t gen_prev = 0, gen_new = 0;
   // scratch
   int32_t *old_edge = nullptr, *first_k = nullptr;  // [E]: previous edge | orientation bit 31, -1 none; [Eo]: first triangulator edge keeping it
@@ -241,7 +244,7 @@ struct TopoBuild {
   TopoDims* dims = nullptr;
 };
 size_t topo_sort_temp_bytes(int V, int n_scan);
-int launch_topo_feat_build(const int32_t* feat, int V, uint32_t* stamp, int32_t* val, int tab_size, uint32_t gen, hipStream_t s);
+int launch_topo_feat_build(const int32_t* feat, int V, uint32_t* stamp, int32_t* key, int32_t* val, int tab_bits, uint32_t gen, hipStream_t s);
 int launch_topo_sync_front(const TopoBuild& t, hipStream_t s);
 int launch_topo_upload_front(const TopoBuild& t, hipStream_t s);
 int launch_topo_back(const TopoBuild& t, hipStream_t s);

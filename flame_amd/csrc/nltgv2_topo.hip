@@ -108,15 +108,37 @@ __device__ void cc_hook(int* parent, const int a, const int b) {
   }
 }
 
-// Stamped feature table: entry id is live for the graph of generation g iff stamp[id] == g.  Ids are unique within a frame, so
-// only the thread of that vertex touches an entry: the look-up of the previous graph and the entry of the new one are one pass.
+// Feature table: feature id -> vertex, as two open-addressing hash tables with generation stamps (TopoBuild).  The graph of
+// generation g lives in table g & 1; a sync looks its ids up in the previous generation's table and enters them into the other one,
+// whose slots all carry older stamps -- so nothing is cleared between frames and ids may grow without bound (the reference's feature
+// ids grow by one per detection for the whole session).  Linear probing, at most a quarter full.
+__device__ __forceinline__ uint32_t feat_slot(int id, int bits) { return ((uint32_t)id * 0x9E3779B1u) >> (32 - bits); }
+
+__device__ __forceinline__ void feat_insert(uint32_t* stamp, int32_t* key, int32_t* val, int bits, uint32_t gen, int id, int v) {
+  const uint32_t base = (gen & 1u) << bits, mask = (1u << bits) - 1u;
+  for (uint32_t h = feat_slot(id, bits);; h = (h + 1u) & mask) {
+    const uint32_t seen = __hip_atomic_load(&stamp[base + h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (seen != gen && atomicCAS(&stamp[base + h], seen, gen) == seen) {  // (a slot of an older generation: taken)
+      key[base + h] = id, val[base + h] = v;
+      return;
+    }
+  }
+}
+
+__device__ __forceinline__ int feat_lookup(const uint32_t* stamp, const int32_t* key, const int32_t* val, int bits, uint32_t gen, int id) {
+  const uint32_t base = (gen & 1u) << bits, mask = (1u << bits) - 1u;
+  for (uint32_t h = feat_slot(id, bits);; h = (h + 1u) & mask) {
+    if (stamp[base + h] != gen) return -1;  // (the entries of a generation are never removed: the first free slot ends the probe)
+    if (key[base + h] == id) return val[base + h];
+  }
+}
+
 __global__ void __launch_bounds__(256)
-k_topo_feat_build(const int32_t* __restrict__ feat, const int V, uint32_t* __restrict__ stamp, int32_t* __restrict__ val,
-                  const int tab_size, const uint32_t gen) {
+k_topo_feat_build(const int32_t* __restrict__ feat, const int V, uint32_t* __restrict__ stamp, int32_t* __restrict__ key,
+                  int32_t* __restrict__ val, const int tab_bits, const uint32_t gen) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
-  const int id = feat[v];
-  if ((unsigned)id < (unsigned)tab_size) stamp[id] = gen, val[id] = v;
+  feat_insert(stamp, key, val, tab_bits, gen, feat[v], v);
 }
 
 __global__ void __launch_bounds__(256) k_topo_init(const TopoBuild t) {
@@ -132,12 +154,8 @@ __global__ void __launch_bounds__(256) k_topo_init(const TopoBuild t) {
   if (i >= t.V) return;
   if (t.fid) {
     const int id = t.fid[i];
-    int o = -1;
-    if ((unsigned)id < (unsigned)t.tab_size) {
-      if (t.feat_stamp[id] == t.gen_prev) o = t.feat_val[id];
-      t.feat_stamp[id] = t.gen_new, t.feat_val[id] = i;
-    }
-    t.old_of_new[i] = o;
+    t.old_of_new[i] = feat_lookup(t.feat_stamp, t.feat_key, t.feat_val, t.tab_bits, t.gen_prev, id);
+    feat_insert(t.feat_stamp, t.feat_key, t.feat_val, t.tab_bits, t.gen_new, id, i);
   }
   t.deg[i] = 0, t.cur[i] = 0;
   const float2 p = t.pos[i];
@@ -543,9 +561,9 @@ size_t topo_sort_temp_bytes(int V, int n_scan) {
   return std::max(a, b) + 256;
 }
 
-int launch_topo_feat_build(const int32_t* feat, int V, uint32_t* stamp, int32_t* val, int tab_size, uint32_t gen, hipStream_t s) {
+int launch_topo_feat_build(const int32_t* feat, int V, uint32_t* stamp, int32_t* key, int32_t* val, int tab_bits, uint32_t gen, hipStream_t s) {
   if (V <= 0) return 0;
-  hipLaunchKernelGGL(k_topo_feat_build, grid1d(V), dim3(256), 0, s, feat, V, stamp, val, tab_size, gen);
+  hipLaunchKernelGGL(k_topo_feat_build, grid1d(V), dim3(256), 0, s, feat, V, stamp, key, val, tab_bits, gen);
   return (int)hipGetLastError();
 }
 

@@ -129,21 +129,22 @@ int topo_prepare(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, bool*
   flame_nltgv2_ctx::PreparedSync& P = ctx->prepared;
   P.t_begin = std::chrono::steady_clock::now();
   // ---- the checks the C-ABI promises (INVALID_ARG before anything is changed) -------------------------------------------------
-  int32_t max_id = -1;
-  for (int32_t v = 0; v < V; ++v) {
+  for (int32_t v = 0; v < V; ++v)
     if (in->feat_id[v] < 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-    max_id = std::max(max_id, in->feat_id[v]);
-  }
-  for (int32_t id : ctx->h_feat) max_id = std::max(max_id, id);
-  if (max_id >= kFeatDirectMax) return 0;
-  if (ctx->feat_stamp.size() <= (size_t)max_id) ctx->feat_stamp.resize((size_t)max_id + 1 + (size_t)max_id / 2, 0u);
-  {
-    const uint32_t stamp = ++ctx->feat_stamp_now;
-    if (stamp == 0u) std::fill(ctx->feat_stamp.begin(), ctx->feat_stamp.end(), 0u), ctx->feat_stamp_now = 1u;
+  {  // duplicate ids: a stamped open-addressing set of 4 V slots (the ids themselves may be anything up to 2^31 - 1)
+    size_t cap = 1024;
+    while (cap < 4 * (size_t)V) cap <<= 1;
+    if (ctx->dup_key.size() != cap) ctx->dup_key.assign(cap, 0), ctx->dup_stamp.assign(cap, 0u), ctx->dup_now = 0u;
+    if (++ctx->dup_now == 0u) std::fill(ctx->dup_stamp.begin(), ctx->dup_stamp.end(), 0u), ctx->dup_now = 1u;
+    const size_t mask = cap - 1;
     for (int32_t v = 0; v < V; ++v) {
-      uint32_t& st = ctx->feat_stamp[(size_t)in->feat_id[v]];
-      if (st == ctx->feat_stamp_now) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // duplicate id
-      st = ctx->feat_stamp_now;
+      const int32_t id = in->feat_id[v];
+      size_t h = ((uint32_t)id * 0x9E3779B1u) & mask;
+      while (ctx->dup_stamp[h] == ctx->dup_now) {
+        if (ctx->dup_key[h] == id) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // duplicate id
+        h = (h + 1) & mask;
+      }
+      ctx->dup_stamp[h] = ctx->dup_now, ctx->dup_key[h] = id;
     }
   }
   {
@@ -190,18 +191,23 @@ int topo_prepare(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, bool*
     return fail(ctx, FLAME_NLTGV2_ERR_OOM);
   }
   char* const sc = static_cast<char*>(ctx->topo_scratch.p);
-  // the device's feature table follows the ids (grown: its content is rebuilt from the current graph's ids)
-  if (ctx->feat_tab_size_d <= max_id) {
-    const size_t want = (size_t)max_id + 1 + (size_t)max_id / 2;
-    rc = ensure(ctx, ctx->feat_stamp_d, sizeof(uint32_t) * want);
-    if (!rc) rc = ensure(ctx, ctx->feat_val_d, sizeof(int32_t) * want);
-    if (rc) return rc;
-    ctx->feat_tab_size_d = (int)std::min(ctx->feat_stamp_d.cap / sizeof(uint32_t), ctx->feat_val_d.cap / sizeof(int32_t));
-    ctx->feat_dev_valid = false;
+  // the device's feature tables: two of 2^bits slots, at least four per vertex (grown: rebuilt from the current graph's ids)
+  {
+    int bits = 12;
+    while (((size_t)1 << bits) < 4 * (size_t)std::max(V, Vo)) ++bits;
+    if (bits > ctx->feat_tab_bits_d) {
+      const size_t want = (size_t)2 << bits;
+      rc = ensure(ctx, ctx->feat_stamp_d, sizeof(uint32_t) * want);
+      if (!rc) rc = ensure(ctx, ctx->feat_key_d, sizeof(int32_t) * want);
+      if (!rc) rc = ensure(ctx, ctx->feat_val_d, sizeof(int32_t) * want);
+      if (rc) return rc;
+      ctx->feat_tab_bits_d = bits;
+      ctx->feat_dev_valid = false;
+    }
   }
   const bool rebuild_table = !ctx->feat_dev_valid || ctx->feat_gen >= 0xfffffff0u;
   if (rebuild_table) {
-    HIPCHK(ctx, hipMemsetAsync(ctx->feat_stamp_d.p, 0, sizeof(uint32_t) * (size_t)ctx->feat_tab_size_d, ts));
+    HIPCHK(ctx, hipMemsetAsync(ctx->feat_stamp_d.p, 0, sizeof(uint32_t) * ((size_t)2 << ctx->feat_tab_bits_d), ts));
     ctx->feat_gen = 1;
   }
 
@@ -215,8 +221,8 @@ int topo_prepare(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, bool*
   rc = staged_h2d(ctx, cp, sizeof(cp) / sizeof(cp[0]), nullptr, 0, /*slot=*/1, ts, hoff);
   if (rc) return rc;
   if (rebuild_table && Vo > 0)
-    LAUNCHCHK(ctx, launch_topo_feat_build((const int32_t*)(sc + o_old_feat), Vo, (uint32_t*)ctx->feat_stamp_d.p, (int32_t*)ctx->feat_val_d.p,
-                                          ctx->feat_tab_size_d, ctx->feat_gen, ts));
+    LAUNCHCHK(ctx, launch_topo_feat_build((const int32_t*)(sc + o_old_feat), Vo, (uint32_t*)ctx->feat_stamp_d.p, (int32_t*)ctx->feat_key_d.p,
+                                          (int32_t*)ctx->feat_val_d.p, ctx->feat_tab_bits_d, ctx->feat_gen, ts));
 
   // ---- the builder ------------------------------------------------------------------------------------------------------------------
   using C = flame_nltgv2_ctx;
@@ -227,7 +233,7 @@ int topo_prepare(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, bool*
   t.sx = (maxx > minx) ? 65535.0f / (maxx - minx) : 0.0f, t.sy = (maxy > miny) ? 65535.0f / (maxy - miny) : 0.0f;
   t.o_row_ptr = (const int32_t*)ctx->row_ptr.p, t.o_half = (const uint32_t*)ctx->half.p;
   t.o_src = (const int32_t*)ctx->src.p, t.o_dst = (const int32_t*)ctx->dst.p;
-  t.feat_stamp = (uint32_t*)ctx->feat_stamp_d.p, t.feat_val = (int32_t*)ctx->feat_val_d.p, t.tab_size = ctx->feat_tab_size_d;
+  t.feat_stamp = (uint32_t*)ctx->feat_stamp_d.p, t.feat_key = (int32_t*)ctx->feat_key_d.p, t.feat_val = (int32_t*)ctx->feat_val_d.p, t.tab_bits = ctx->feat_tab_bits_d;
   t.gen_prev = ctx->feat_gen, t.gen_new = ctx->feat_gen + 1;
   bind_scratch(&t, sc, sm);
   t.old_of_new = (int32_t*)(sc + o_vmap), t.old_of_new_edge = (int32_t*)(sc + o_emap);

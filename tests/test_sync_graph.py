@@ -94,6 +94,58 @@ def test_frame_sequence_matches_syncgraph_restatement(built, mode):
         assert_state_equal(reg.download_state(), flat, keys=OUT_KEYS + ("x_prev",), what="after last sync")
 
 
+@pytest.mark.parametrize("mode", SYNC_MODES)
+def test_feature_ids_anywhere_in_int32(built, mode):
+    """The reference's feature ids grow by one per detection for the whole session (millions within minutes); the sync must not
+    depend on their magnitude.  Ids scattered over [0, 2^31): a few small ones, most beyond any direct table, new ones up to
+    INT32_MAX -- the device path keeps them in two stamped hash tables (nltgv2_topo.hip: feat_insert / feat_lookup) and stays the
+    path taken; every frame equal to the restatement."""
+    import torch  # noqa: F401
+
+    import flame_amd
+
+    rng = np.random.default_rng(77)
+    g0 = synth.make_graph("320x240", seed=13)
+    V = g0["V"]
+    feat_id = rng.choice(np.arange(5_000_000, 2_147_000_000, 997, dtype=np.int64), size=V, replace=False).astype(np.int32)
+    feat_id[:16] = np.arange(16, dtype=np.int32) * 7  # (and some small ones)
+    pos, data = g0["pos"].copy(), g0["data_term"].copy()
+    params = flame_amd.Params()
+    ref = sync_oracle.RefGraph.from_flat(g0, feat_id)
+    with flame_amd.Regularizer(0) as reg:
+        reg.upload_graph(g0)
+        reg.set_feature_ids(feat_id)
+        kw = _mode(reg, mode)
+        for frame in range(4):
+            flat = sync_oracle.flatten(ref, feat_id)
+            reg.run(params, 20)
+            assert oracle.run(flat, 20) == 0
+            assert_state_equal(reg.download_state(), flat, keys=OUT_KEYS, what=f"frame {frame}")
+            sync_oracle.absorb(ref, flat, feat_id)
+            keep = rng.random(len(feat_id)) > 0.1
+            n_new = int((~keep).sum())
+            new_id = np.setdiff1d(rng.choice(np.arange(1000, 2_147_483_647, 1013, dtype=np.int64), size=2 * n_new, replace=False), feat_id)[:n_new]
+            if frame == 2:
+                new_id[0] = 2_147_483_647  # INT32_MAX itself
+            order = rng.permutation(len(feat_id))
+            feat_id = np.concatenate([feat_id[keep], new_id]).astype(np.int32)[order]
+            pos = np.concatenate([pos[keep] + rng.normal(0, 0.3, (int(keep.sum()), 2)).astype(np.float32),
+                                  np.stack([rng.random(n_new) * 312 + 4, rng.random(n_new) * 232 + 4], 1).astype(np.float32)])[order]
+            data = np.concatenate([data[keep], (0.5 + rng.random(n_new)).astype(np.float32)])[order]
+            pos, data = np.ascontiguousarray(pos, np.float32), np.ascontiguousarray(data, np.float32)
+            weight = np.ones(len(feat_id), np.float32)
+            edges = synth.delaunay_edges_scipy(pos)
+            reg.sync_graph(feat_id, pos, data, weight, edges, **kw)
+            assert reg.info()["last_sync_path"] == (2 if mode == "device" else 1)
+            sync_oracle.sync(ref, feat_id, pos, data, weight, edges)
+        flat = sync_oracle.flatten(ref, feat_id)
+        assert_state_equal(reg.download_state(), flat, keys=OUT_KEYS, what="after the last sync")
+        dup = feat_id.copy()
+        dup[3] = dup[9]
+        with pytest.raises(flame_amd.NLTGV2Error):  # a duplicate id is still an invalid argument, whatever its magnitude
+            reg.sync_graph(dup, pos, data, weight, edges, **kw)
+
+
 def test_sync_rejects_bad_input(built):
     import torch  # noqa: F401
 

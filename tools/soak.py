@@ -57,7 +57,6 @@ for cfg, seed, ITERS in cases:
         with flame_amd.Regularizer(0) as reg:
             reg.set_option(OPT_PERSISTENT, form)
             reg.set_option(OPT_DUAL_PUBLISH, dual)
-            reg.set_option(lds)
             reg.set_option(OPT_VERIFY_RECORDS, verify)
             reg.set_option(OPT_PLACEMENT, place)
             reg.upload_graph(g)

@@ -119,7 +119,7 @@ def main():
     threads = [threading.Thread(target=t, daemon=True) for t in (tracker_load, raster_load, solver_thread)]
     for t in threads:
         t.start()
-    mismatches, checker_mismatches, paths = [], [], {}
+    mismatches, checker_mismatches, paths, syncs = [], [], {}, {}
     t0 = time.time()
     tris = synth.delaunay_native(pos)[0]
     for frame in range(FRAMES):
@@ -140,11 +140,24 @@ def main():
                     checker_mismatches.append(frame)
                 sync_oracle.absorb(ref, flat, feat_id)
             A.interpolate_mesh(tris, H, W)      # the read-back of the frame (flame.cc:372-437)
+            feat_prev = feat_id
             feat_id, pos, data, next_id = next_frame(rng, feat_id, pos, data, next_id)
             tris, edges = synth.delaunay_native(pos)
             ones = np.ones(len(feat_id), np.float32)
-            for r in (A, B):
-                r.sync_graph(feat_id, pos, data, ones, edges)
+            if frame & 1:  # round 4: the sync in two halves -- the builder on its side stream while the solver does 50 more iterations on the old graph
+                A.sync_prepare(feat_id, pos, data, ones, edges, edges_unique=True)
+                A.run_async(P, 50)
+                A.sync_commit()
+                B.run(P, 50)
+                B.sync_graph(feat_id, pos, data, ones, edges, edges_unique=True)
+                if frame < CHECK:
+                    flat = sync_oracle.flatten(ref, feat_prev)
+                    oracle.run(flat, 50)
+                    sync_oracle.absorb(ref, flat, feat_prev)
+            else:
+                for r in (A, B):
+                    r.sync_graph(feat_id, pos, data, ones, edges, edges_unique=True)  # (the triangulator's own list: the device builder takes it)
+            syncs[{1: "host", 2: "device"}.get(A.info()["last_sync_path"], "?")] = syncs.get({1: "host", 2: "device"}.get(A.info()["last_sync_path"], "?"), 0) + 1
             if frame < CHECK:
                 sync_oracle.sync(ref, feat_id, pos, data, ones, edges)
             if (frame + 1) % max(1, FRAMES // 10) == 0:  # (under the lock: a context is one thread's at a time)
@@ -159,7 +172,7 @@ def main():
         t.join(timeout=10)
     ia = A.info()
     out = {"frames": FRAMES, "size": SIZE, "V_last": int(len(feat_id)), "iterations_per_frame": ITERS, "solver_iterations": budget["done"],
-           "solver_run_paths": paths, "frames_mismatching_the_per_step_reference": len(mismatches), "first_mismatches": mismatches[:5],
+           "solver_run_paths": paths, "sync_paths_of_A": syncs, "every_other_sync": "sync_prepare + 50 iterations beside the builder + sync_commit", "frames_mismatching_the_per_step_reference": len(mismatches), "first_mismatches": mismatches[:5],
            "frames_checked_against_the_chained_cpu_checkers": CHECK, "of_those_mismatching": len(checker_mismatches),
            "timeouts_recovered": int(ia["timeouts_recovered"]), "torn_records_detected": int(ia["torn_records_detected"]),
            "concurrent_load": load, "seconds": round(time.time() - t0, 1),

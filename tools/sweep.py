@@ -19,7 +19,6 @@ for cfg, nf in cases:
         r = flame_amd.Regularizer(0)
         r.set_option(OPT_PERSISTENT, form)
         r.set_option(OPT_DUAL_PUBLISH, dual)
-        r.set_option(lds)
         r.upload_graph(g)
         iters = 200 if form else 50
         try:
