@@ -26,6 +26,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Before the HIP runtime starts: every stream of this process gets a hardware queue of its own.  The runtime multiplexes HIP streams
+# onto GPU_MAX_HW_QUEUES (default 4) in-order hardware queues; two streams that land on one queue execute in submission order --
+# when RCCL's stream shared a queue with the solver's, every result gather ran between two runs instead of beside the next one
+# (0.35 instead of 0.21 ms per step under torch.distributed.run; tools/gather_chain.py).  A runtime setting, like NCCL's own.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
