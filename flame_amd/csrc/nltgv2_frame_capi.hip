@@ -64,21 +64,23 @@ int flame_nltgv2_interpolate_mesh_begin(flame_nltgv2_ctx* ctx, const int32_t* tr
     }
     ctx->h_img_cap = n + 16;
   }
-  rc = ensure_canon(ctx);  // the solver stops here ...
-  if (!rc) rc = ensure(ctx, ctx->r_tris, sizeof(int32_t) * 3 * (size_t)T);
+  // the caller's triangles go up first (pageable memory: the copy holds the host), while the solver still runs ...
+  rc = ensure(ctx, ctx->r_tris, sizeof(int32_t) * 3 * (size_t)T);
   if (!rc) rc = ensure(ctx, ctx->r_valid, (size_t)T + (size_t)V + 16);
   if (!rc) rc = ensure(ctx, ctx->r_keys, sizeof(unsigned long long) * n);
   if (!rc) rc = ensure(ctx, ctx->r_img, sizeof(float) * n);
   if (!rc) rc = ensure(ctx, ctx->r_cov, sizeof(int));
   if (rc) return rc;
-  HIPCHK(ctx, hipEventRecord(ctx->ev_canon, ctx->stream));
-  HIPCHK(ctx, hipStreamWaitEvent(rs, ctx->ev_canon, 0));  // ... and may go on as soon as the caller enqueues the next run
   if (T > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->r_tris.p, triangles, sizeof(int32_t) * 3 * (size_t)T, hipMemcpyHostToDevice, rs));
   uint8_t* d_tv = nullptr;
   if (tri_valid && T > 0) {
     d_tv = (uint8_t*)ctx->r_valid.p;
     HIPCHK(ctx, hipMemcpyAsync(d_tv, tri_valid, (size_t)T, hipMemcpyHostToDevice, rs));
   }
+  rc = ensure_canon(ctx);  // ... it stops here ...
+  if (rc) return rc;
+  HIPCHK(ctx, hipEventRecord(ctx->ev_canon, ctx->stream));
+  HIPCHK(ctx, hipStreamWaitEvent(rs, ctx->ev_canon, 0));  // ... and may go on as soon as the caller enqueues the next run
   LAUNCHCHK(ctx, launch_interpolate_mesh(T, (const int32_t*)ctx->r_tris.p, ctx->c.pos, ctx->c.x, graph_scale, nullptr, d_tv,
                                          (unsigned long long*)ctx->r_keys.p, (float*)ctx->r_img.p, (int*)ctx->r_cov.p, rows, cols, rs));
   HIPCHK(ctx, hipMemcpyAsync(ctx->h_img, ctx->r_img.p, sizeof(float) * n, hipMemcpyDeviceToHost, rs));
