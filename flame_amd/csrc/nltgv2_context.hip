@@ -113,11 +113,9 @@ int ensure_canon(flame_nltgv2_ctx* ctx) {
 
 int ensure_fused(flame_nltgv2_ctx* ctx) {
   if (ctx->fused_valid) return 0;
-  if (ctx->static_stale) {  // positions moved: dx, dy of the packed records follow (alpha stays the caller's)
-    LAUNCHCHK(ctx, launch_pack_static(ctx->c, ctx->f, ctx->stream));
-    ctx->static_stale = false;
-  }
-  LAUNCHCHK(ctx, launch_pack_state(ctx->c, ctx->f, ctx->parity, ctx->stream));
+  // (static_stale: the positions moved, or the topology is new: dx, dy, alpha of the packed records follow in the same launch)
+  LAUNCHCHK(ctx, launch_pack_state(ctx->c, ctx->f, ctx->parity, ctx->static_stale, ctx->stream));
+  ctx->static_stale = false;
   ctx->fused_valid = true;
   ctx->have_prev = false;
   return 0;

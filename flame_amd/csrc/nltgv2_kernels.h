@@ -254,7 +254,7 @@ int launch_dual(const CanonArgs& c, const SolverParams& p, hipStream_t s);
 int launch_primal(const CanonArgs& c, const SolverParams& p, hipStream_t s);
 int launch_extragradient(const CanonArgs& c, const SolverParams& p, hipStream_t s);
 int launch_pack_static(const CanonArgs& c, const FusedArgs& a, hipStream_t s);
-int launch_pack_state(const CanonArgs& c, const FusedArgs& a, int parity, hipStream_t s);
+int launch_pack_state(const CanonArgs& c, const FusedArgs& a, int parity, bool with_static, hipStream_t s);  // (+ the records when asked)
 int launch_unpack_state(const CanonArgs& c, const FusedArgs& a, int parity, bool have_prev, hipStream_t s);
 int launch_export(const CanonArgs& c, const FusedArgs& a, bool packed_current, float scale, float* dst,
                   hipStream_t s);

@@ -248,63 +248,74 @@ k_pack_static(int64_t n_slots, const int32_t* __restrict__ rec_edge, const uint3
   hrec[s] = r;
 }
 
+// ensure_fused in ONE launch: the records (when the positions moved or the topology is new), the duals and the vertex state of the
+// packed form, and the zero fill of the other ping-pong half -- thread i does slot i and packed vertex i.  (Four launches between two
+// runs cost the free-running solver ~15 us of idle time at every settle point: tools/frame_loop.py --pipelined.)
 __global__ void __launch_bounds__(256)
-k_pack_edge_state(int64_t n_slots, const int32_t* __restrict__ rec_edge, const float* __restrict__ q1,
-                  const float* __restrict__ q2, const float* __restrict__ q3,
-                  const float* __restrict__ beta, float4* __restrict__ hq) {
+k_pack_all(int64_t n_slots, int n_packed, int with_static, const int32_t* __restrict__ rec_edge, const uint32_t* __restrict__ rec_nbr,
+           const int32_t* __restrict__ src, const int32_t* __restrict__ dst, const float* __restrict__ alpha, const float* __restrict__ beta,
+           const float2* __restrict__ pos, const float* __restrict__ q1, const float* __restrict__ q2, const float* __restrict__ q3,
+           int4* __restrict__ hrec, float4* __restrict__ hq, const int32_t* __restrict__ perm, const int32_t* __restrict__ pdeg,
+           const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ xb,
+           const float* __restrict__ w1b, const float* __restrict__ w2b, const float* __restrict__ data, const float* __restrict__ weight,
+           float4* __restrict__ vstate, float2* __restrict__ vaux, float4* __restrict__ bar, float4* __restrict__ bar_other) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_slots) return;
-  const int e = rec_edge[s];
-  hq[s] = (e >= 0) ? make_float4(q1[e], q2[e], q3[e], beta[e]) : make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
-__global__ void __launch_bounds__(256)
-k_pack_vertex_state(int n_packed, const int32_t* __restrict__ perm, const int32_t* __restrict__ pdeg,
-                    const float* __restrict__ x, const float* __restrict__ w1,
-                    const float* __restrict__ w2, const float* __restrict__ xb,
-                    const float* __restrict__ w1b, const float* __restrict__ w2b,
-                    const float* __restrict__ data, const float* __restrict__ weight,
-                    float4* __restrict__ vstate, float2* __restrict__ vaux, float4* __restrict__ bar) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_packed) return;
-  const int o = perm[s];
-  if (o >= 0) {
-    vstate[s] = make_float4(x[o], w1[o], w2[o], data[o]);
-    vaux[s] = make_float2(weight[o], __int_as_float(pdeg[s]));
-    bar[s] = make_float4(xb[o], w1b[o], w2b[o], 0.f);
-  } else {
-    vstate[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-    vaux[s] = make_float2(0.f, __int_as_float(0));
-    bar[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (s < n_slots) {
+    const int e = rec_edge[s];
+    if (with_static) {
+      int4 r;
+      r.x = (int)rec_nbr[s];
+      if (e >= 0) {
+        const float2 pi = pos[src[e]], pj = pos[dst[e]];
+        r.y = __float_as_int(alpha[e]);
+        r.z = __float_as_int(pi.x - pj.x);
+        r.w = __float_as_int(pi.y - pj.y);
+      } else {
+        r.y = r.z = r.w = 0;
+      }
+      hrec[s] = r;
+    }
+    hq[s] = (e >= 0) ? make_float4(q1[e], q2[e], q3[e], beta[e]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (s < n_packed) {
+    const int o = perm[s];
+    if (o >= 0) {
+      vstate[s] = make_float4(x[o], w1[o], w2[o], data[o]);
+      vaux[s] = make_float2(weight[o], __int_as_float(pdeg[s]));
+      bar[s] = make_float4(xb[o], w1b[o], w2b[o], 0.f);
+    } else {
+      vstate[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+      vaux[s] = make_float2(0.f, __int_as_float(0));
+      bar[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    bar_other[s] = make_float4(0.f, 0.f, 0.f, 0.f);  // the other ping-pong half must hold valid (zero) values in padding lanes too
   }
 }
 
+// ensure_canon in ONE launch: thread i unpacks packed vertex i and edge i.
 __global__ void __launch_bounds__(256)
-k_unpack_vertex_state(int n_packed, const int32_t* __restrict__ perm, const float4* __restrict__ vstate,
-                      const float4* __restrict__ bar, const float4* __restrict__ vprev, int have_prev,
-                      float* __restrict__ x, float* __restrict__ w1, float* __restrict__ w2,
-                      float* __restrict__ xb, float* __restrict__ w1b, float* __restrict__ w2b,
-                      float* __restrict__ xp, float* __restrict__ w1p, float* __restrict__ w2p) {
+k_unpack_all(int n_packed, int E, const int32_t* __restrict__ perm, const float4* __restrict__ vstate, const float4* __restrict__ bar,
+             const float4* __restrict__ vprev, int have_prev, float* __restrict__ x, float* __restrict__ w1, float* __restrict__ w2,
+             float* __restrict__ xb, float* __restrict__ w1b, float* __restrict__ w2b, float* __restrict__ xp, float* __restrict__ w1p,
+             float* __restrict__ w2p, const int32_t* __restrict__ edge_src_slot, const float4* __restrict__ hq, float* __restrict__ q1,
+             float* __restrict__ q2, float* __restrict__ q3) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_packed) return;
-  const int o = perm[s];
-  if (o < 0) return;
-  const float4 st = vstate[s], b = bar[s];
-  x[o] = st.x, w1[o] = st.y, w2[o] = st.z;
-  xb[o] = b.x, w1b[o] = b.y, w2b[o] = b.z;
-  if (have_prev) {
-    const float4 pv = vprev[s];
-    xp[o] = pv.x, w1p[o] = pv.y, w2p[o] = pv.z;
+  if (s < n_packed) {
+    const int o = perm[s];
+    if (o >= 0) {
+      const float4 st = vstate[s], b = bar[s];
+      x[o] = st.x, w1[o] = st.y, w2[o] = st.z;
+      xb[o] = b.x, w1b[o] = b.y, w2b[o] = b.z;
+      if (have_prev) {
+        const float4 pv = vprev[s];
+        xp[o] = pv.x, w1p[o] = pv.y, w2p[o] = pv.z;
+      }
+    }
   }
-}
-
-__global__ void __launch_bounds__(256)
-k_unpack_edge_state(int E, const int32_t* __restrict__ edge_src_slot, const float4* __restrict__ hq,
-                    float* __restrict__ q1, float* __restrict__ q2, float* __restrict__ q3) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  const float4 q = hq[edge_src_slot[e]];
-  q1[e] = q.x, q2[e] = q.y, q3[e] = q.z;
+  if (s < E) {
+    const float4 q = hq[edge_src_slot[s]];
+    q1[s] = q.x, q2[s] = q.y, q3[s] = q.z;
+  }
 }
 
 // x * graph_scale in original order (flame.cc:377), from whichever layout is current.
@@ -576,33 +587,22 @@ int launch_pack_static(const CanonArgs& c, const FusedArgs& a, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
-int launch_pack_state(const CanonArgs& c, const FusedArgs& a, int parity, hipStream_t s) {
-  if (a.n_slots > 0) {
-    hipLaunchKernelGGL(k_pack_edge_state, grid1d(a.n_slots), dim3(256), 0, s, a.n_slots, a.rec_edge, c.q1,
-                       c.q2, c.q3, c.beta, a.hq);
-  }
+int launch_pack_state(const CanonArgs& c, const FusedArgs& a, int parity, bool with_static, hipStream_t s) {
   const int n_packed = a.n_slices * 64;
-  if (n_packed > 0) {
-    hipLaunchKernelGGL(k_pack_vertex_state, grid1d(n_packed), dim3(256), 0, s, n_packed, a.perm, a.pdeg,
-                       c.x, c.w1, c.w2, c.xb, c.w1b, c.w2b, c.data, c.weight, a.vstate, a.vaux,
-                       a.bar[parity]);
-    // the other ping-pong half must hold valid (zero) values in padding lanes too
-    (void)hipMemsetAsync(a.bar[parity ^ 1], 0, sizeof(float4) * (size_t)n_packed, s);
-  }
+  const int64_t n = std::max<int64_t>(a.n_slots, n_packed);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_pack_all, grid1d(n), dim3(256), 0, s, a.n_slots, n_packed, with_static ? 1 : 0, a.rec_edge, a.rec_nbr, c.src, c.dst,
+                     c.alpha, c.beta, c.pos, c.q1, c.q2, c.q3, a.hrec, a.hq, a.perm, a.pdeg, c.x, c.w1, c.w2, c.xb, c.w1b, c.w2b, c.data,
+                     c.weight, a.vstate, a.vaux, a.bar[parity], a.bar[parity ^ 1]);
   return (int)hipGetLastError();
 }
 
 int launch_unpack_state(const CanonArgs& c, const FusedArgs& a, int parity, bool have_prev, hipStream_t s) {
   const int n_packed = a.n_slices * 64;
-  if (n_packed > 0) {
-    hipLaunchKernelGGL(k_unpack_vertex_state, grid1d(n_packed), dim3(256), 0, s, n_packed, a.perm, a.vstate,
-                       a.bar[parity], a.vprev, have_prev ? 1 : 0, c.x, c.w1, c.w2, c.xb, c.w1b, c.w2b,
-                       c.xp, c.w1p, c.w2p);
-  }
-  if (c.E > 0) {
-    hipLaunchKernelGGL(k_unpack_edge_state, grid1d(c.E), dim3(256), 0, s, c.E, a.edge_src_slot, a.hq, c.q1,
-                       c.q2, c.q3);
-  }
+  const int n = std::max(n_packed, c.E);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_unpack_all, grid1d(n), dim3(256), 0, s, n_packed, c.E, a.perm, a.vstate, a.bar[parity], a.vprev, have_prev ? 1 : 0,
+                     c.x, c.w1, c.w2, c.xb, c.w1b, c.w2b, c.xp, c.w1p, c.w2p, a.edge_src_slot, a.hq, c.q1, c.q2, c.q3);
   return (int)hipGetLastError();
 }
 

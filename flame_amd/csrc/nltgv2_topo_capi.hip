@@ -419,7 +419,7 @@ int topo_commit(flame_nltgv2_ctx* ctx, bool* done) {
   for (int i = 0; i < 9; ++i) std::swap(*cur_v[i], ctx->sp_v[i]);
   for (int i = 0; i < 3; ++i) std::swap(*cur_q[i], ctx->sp_q[i]);
   refresh_args(ctx);
-  LAUNCHCHK(ctx, launch_pack_static(ctx->c, ctx->f, ctx->stream));
+  ctx->static_stale = true;  // (the records of the packed form: with the state, in the one launch of the next run's ensure_fused)
   HIPCHK(ctx, hipEventRecord(ctx->ev_topo_ready, ctx->stream));
   ctx->feat_gen += 1, ctx->feat_dev_valid = true;
   const int32_t* const fid = reinterpret_cast<const int32_t*>(static_cast<const char*>(ctx->stage[1].h) + P.off[0]);
