@@ -15,7 +15,7 @@ for cfg, nf in cases:
     frames = [synth.make_graph(cfg, seed=5000 + i) for i in range(nf)]
     g = synth.concat_graphs(frames) if nf > 1 else frames[0]
     row = {}
-    for form, dual, lds in ((4, 2, 0), (3, 2, 0), (3, 2, 2), (0, 0, 0)):
+    for form, dual, lds in ((4, 2, 0), (6, 2, 0), (3, 2, 0), (0, 0, 0)):  # patch per wave (one / two half-edges per lane), vertex per lane, one launch per step
         r = flame_amd.Regularizer(0)
         r.set_option(OPT_PERSISTENT, form)
         r.set_option(OPT_DUAL_PUBLISH, dual)
@@ -28,7 +28,7 @@ for cfg, nf in cases:
             path = RUN_PATHS[info["last_run_path"]]
             us = ms * 1e3 / iters
             gbps = info["algorithmic_bytes_per_iter"] / (us * 1e-6) / 1e9
-            row[path + ("+L2" if dual else "") + ("+lds" if lds else "")] = f"{us:7.2f} us/it {nf / (us * 1e-6) / 1e6:6.2f} Mfi/s frac {gbps / 8000:5.3f}"
+            row[path + ("+L2" if dual else "")] = f"{us:7.2f} us/it {nf / (us * 1e-6) / 1e6:6.2f} Mfi/s frac {gbps / 8000:5.3f}"
         except Exception as e:
             row[f"form{form}{lds}"] = f"ERR {e}"
         r.close()
