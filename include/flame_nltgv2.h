@@ -304,8 +304,8 @@ enum {
                                         are bit-identical either way */
 
   FLAME_NLTGV2_OPT_SYNC_PATH = 17,   /* flame_nltgv2_sync_graph: 0 (default) = index maps and the new graph's layout tables are built on the
-                                        device wherever that applies (a duplicate-free edge list -- edges_unique --, feature ids below 4 M, no
-                                        vertex of more than 64 edges), on the host otherwise; 1 = always on the host; 2 = on the device or
+                                        device wherever that applies (a duplicate-free edge list -- edges_unique --, no vertex of more than 64
+                                        edges; feature ids of any magnitude), on the host otherwise; 1 = always on the host; 2 = on the device or
                                         FLAME_NLTGV2_ERR_INVALID_ARG.  Same result either way */
 
   FLAME_NLTGV2_OPT_COST_SUM = 18,    /* flame_nltgv2_costs: 0 (default) = the addends are summed sequentially in float, in the reference's edge
