@@ -327,6 +327,19 @@ int place_calibrate(flame_nltgv2_ctx* ctx) {
       for (int t = 0; t < P; ++t) m += l[t];
       best += l[r[0]], worst += l[r[P - 1]], mean += m / P;
     }
+  if (std::getenv("FLAME_NLTGV2_TRACE")) {  // the best page of every ordered pair of XCDs, in us (parity 0)
+    for (int a = 0; a < 8; ++a) {
+      std::fprintf(stderr, "[flame_nltgv2] hand-off from XCD %d to 0..7, best page (us):", a);
+      for (int b = 0; b < 8; ++b) {
+        if (a == b) { std::fprintf(stderr, "   -  "); continue; }
+        const unsigned* l = &lat[(size_t)(a * 8 + b) * 2 * P];
+        unsigned best_t = ~0u, worst_t = 0u;
+        for (int t = 0; t < P; ++t) best_t = std::min(best_t, l[t]), worst_t = std::max(worst_t, l[t]);
+        std::fprintf(stderr, " %.3f/%.3f", best_t / (100.0 * kIters), worst_t / (100.0 * kIters));
+      }
+      std::fprintf(stderr, "\n");
+    }
+  }
   const double to_us = 1.0 / (100.0 * kIters) / (2.0 * 56.0);  // 100 MHz ticks of kIters hand-offs; mean of 2 x 56 classes
   ctx->place_best_us = (float)(best * to_us), ctx->place_mean_us = (float)(mean * to_us), ctx->place_worst_us = (float)(worst * to_us);
   HIPCHK(ctx, hipMemcpyAsync(ctx->place_rank.p, rank.data(), sizeof(uint16_t) * rank.size(), hipMemcpyHostToDevice, ctx->stream));
