@@ -19,6 +19,9 @@ enum {
   FLAME_NLTGV2_OPT_FAULT_INJECT = 110, /* test hook: n > 0 = one wave of every persistent run withholds its first record, so the
                                           run times out after n polls and the recovery path (state rolled back, steps redone
                                           with one launch per step) is exercised; 0 (default) = off */
+  FLAME_NLTGV2_OPT_RG_DEPTH = 114,     /* region-per-workgroup form: steps per block = depth of the recomputed ghost ring: 0 (default) =
+                                          the library's choice, 1..6 */
+  FLAME_NLTGV2_OPT_RG_REGIONS = 115,   /* ... regions the graph is cut into: 0 (default) = one per compute unit, else 1..4096 */
   FLAME_NLTGV2_OPT_POLL_GAP = 113      /* patch-per-wave form: 0 (default) = chosen from the patches per CU, 1 = no pause between
                                           the poll rounds of a wait, 2 = one s_sleep (64 cycles); 3 / 4 = the same with the polls
                                           narrowed to the records that have not arrived yet */

@@ -29,6 +29,7 @@
 #include "flame_nltgv2_test_options.h"
 #include "nltgv2_kernels.h"
 #include "nltgv2_pack.hpp"
+#include "nltgv2_regions.hpp"
 #include "roctx_ranges.hpp"
 
 namespace flame_hip {
@@ -45,6 +46,8 @@ constexpr int kPv2MaxGroups = 2;        // ... in at most this many launch group
 constexpr int kPv2WavesPerCu = 19;     // ... up to this many of ITS waves per CU (20 really resident: 91 VGPRs)
 constexpr int kCrowdedWavesPerCu = 16, kCrowdedTopologies = 64;  // (see flame_nltgv2_ctx::crowded_until_topo)
 constexpr int kPvDensePerCu = 27;      // k_persistent_pv is used up to this many patches per CU (28 are resident: 7 waves per SIMD at <= 96 SGPRs)
+constexpr int kRgPreSleep = 0, kRgPollGap = 0;  // ... x 64 cycles between a block's end and its first poll / between two poll rounds
+constexpr int kRgDepth = 2;            // region-per-workgroup form: steps per block (depth of the recomputed ghost ring)
 constexpr int kPvPaceAbovePerCu = 13;  // ... and above this many its polls are paced (kPvDensePreSleep, kPvDenseGap)
 constexpr int kPvDensePreSleep = 3, kPvDenseGap = 2;  // x64 cycles before the first poll of a step / between poll rounds (re-swept
                                                       // with the issue priorities in: 8 / 4 before them; profiles/r03_priority.txt)
@@ -229,6 +232,15 @@ struct flame_nltgv2_ctx {
   bool tv_built = false;  // layout (D) exists for the current topology (built on demand)
   bool wg2_built = false; // ... and layout (E2) (two half-edges per lane; experimental)
   Pv2Args pv2_args;
+  // layout (R), the region-per-workgroup form (nltgv2_regions.hpp): built on the host when the form is first wanted for a topology
+  bool rg_built = false;        // ... with rg_depth_built / rg_regions_built
+  int rg_depth_built = 0, rg_regions_built = 0;
+  bool rg_usable = false;       // the layout stands, its workgroups are all resident at once
+  RegionLayout RG;
+  RgArgs rg_args;
+  DevBuf rg_tab[14], rg_xbuf;
+  int opt_rg_depth = 0;         // steps per block (ghost ring depth): 0 = default (kRgDepth)
+  int opt_rg_regions = 0;       // regions: 0 = one per CU
   int pv2_occ_lcap = -1;  // the wg2_lcap (LDS sizing) the two numbers below were derived for
   int pv2_occ = 0, pv2_occ_verify = 0;  // patches of k_persistent_pv2 really co-resident per CU (plain / record-verifying instance)
   uint64_t wg2_checked_topo = ~0ull;  // the device expansion's verdict (no patch with more than 64 foreign records) was read for this topology

@@ -41,6 +41,11 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
   }
   PackedLayout& L = ctx->L;
   const int cus = ctx->prop.multiProcessorCount;
+  if (ctx->opt_persistent == 7) {  // the region-per-workgroup form by name: layout (R) on demand, all regions in one launch
+    if (ensure_form_rows(ctx, 5) != 0 || !ctx->rg_usable) return 0;
+    groups->push_back(WaveGroup{0, ctx->RG.n_regions});
+    return 5;
+  }
   // ask once per (topology, kernel instance): the LDS use varies with the layout, the registers with the instance
   const uint64_t occ_key = ctx->topo * 4 + (ctx->opt_verify != 0 ? 1 : 0) + (ctx->opt_probe != 0 ? 2 : 0);
   if (L.wg_ok && ctx->pv_occ_topo != occ_key) {
@@ -401,6 +406,8 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
     if ((uint64_t)ctx->tag_next + (uint64_t)n >= 0x07ff0000ull || (ctx->xbuf_form != 0 && ctx->xbuf_form != form)) {
       const size_t bytes = kXbufBytesPerVertex * records_capacity(ctx->L);
       HIPCHK(ctx, hipMemsetAsync(ctx->xbuf.p, 0, bytes, ctx->stream));
+      if (ctx->rg_built && ctx->rg_args.xbuf)
+        HIPCHK(ctx, hipMemsetAsync(ctx->rg_xbuf.p, 0, (size_t)4 * ctx->RG.n_rec * 16 + sizeof(unsigned) * (size_t)ctx->RG.n_regions, ctx->stream));
       if (ctx->place_base) {
         HIPCHK(ctx, hipMemsetAsync(ctx->place_base, 0, (size_t)2 * kPlacePages * 4096, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync((int*)ctx->place_fill.p + 2 * kPlacePages, 0, 64, ctx->stream));
@@ -412,8 +419,9 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
     // by per-step launches or host uploads) can never satisfy a wait of this one
     const uint32_t tag0 = ctx->tag_next + 2;
     // (topology, form, kernel instance): a new instance -- other registers, other LDS -- gets a cooperative first launch
-    const uint64_t key = ctx->topo * 256 + (uint64_t)form * 64 + (uint64_t)tv_lds * 32 + (ctx->opt_verify != 0 ? 16 : 0) + (ctx->opt_probe != 0 ? 8 : 0) +
-                         (ctx->opt_dual == 2 ? 4 : ctx->opt_dual == 1 ? 2 : 0) + (ctx->opt_xcds > 0 ? 1 : 0);
+    const uint64_t key = ctx->topo * 1024 + (uint64_t)form * 64 + (uint64_t)tv_lds * 32 + (ctx->opt_verify != 0 ? 16 : 0) + (ctx->opt_probe != 0 ? 8 : 0) +
+                         (ctx->opt_dual == 2 ? 4 : ctx->opt_dual == 1 ? 2 : 0) + (ctx->opt_xcds > 0 ? 1 : 0) +
+                         (form == 5 ? ((uint64_t)ctx->rg_depth_built << 40) + ((uint64_t)ctx->rg_regions_built << 44) : 0);
     {  // standing outputs: (re)send the small block the kernels read in their epilogue when it changed
       RunTail want;
       std::memset(static_cast<void*>(&want), 0, sizeof want);
@@ -486,6 +494,24 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
           HIPCHK(ctx, hipMemsetAsync(ctx->probe.p, 0, words * sizeof(unsigned), ctx->stream));  // (idle instances write nothing)
         }
       }
+      if (form == 5) {  // a region per workgroup, a block of k steps per hand-off
+        unsigned* probe = nullptr;
+        if (ctx->opt_probe) {  // [region][block][16 words]
+          const int k = ctx->rg_args.depth;
+          const size_t words = (size_t)ctx->RG.n_regions * (size_t)((n + k - 1) / k) * kRgProbeWords;
+          rc = ensure(ctx, ctx->probe, words * sizeof(unsigned));
+          if (rc) return rc;
+          probe = (unsigned*)ctx->probe.p;
+          ctx->probe_words = words;
+          HIPCHK(ctx, hipMemsetAsync(ctx->probe.p, 0, words * sizeof(unsigned), ctx->stream));
+        }
+        e = launch_persistent_rg(ctx->f, ctx->rg_args, to_sp(p), ctx->parity, tag0, n, spins_arg, (dual & 1) | (std::getenv("FLAME_RG_VARIANT") ? std::atoi(std::getenv("FLAME_RG_VARIANT")) << 8 : 0) |
+                                     ((ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : kRgPreSleep) << 16) | ((ctx->opt_poll_gap > 0 ? (ctx->opt_poll_gap - 1) & 15 : kRgPollGap) << 24),
+                                 (const RunTail*)ctx->run_tail.p, probe,
+                                 ctx->coop_checked_key != key, ctx->stream);
+        if (e != 0) break;
+        continue;
+      }
       if (form == 4) {  // two half-edges per lane: its own pacing (swept: profiles/r03_pv2.txt)
         const bool dense = gr.count > kPv2PaceAbovePerCu * ctx->prop.multiProcessorCount;
         const int gap = ctx->opt_poll_gap > 0 ? ctx->opt_poll_gap - 1 : dense ? (3 | ((kPv2DenseGap - 1) << 4)) : kPvPollGap;
@@ -519,10 +545,11 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       ctx->buf_gen ^= 1;
       refresh_args(ctx);
       ctx->coop_checked_key = key;
-      ctx->last_run_path = form == 4 ? 7 : form == 3 ? 6 : 5;
+      ctx->last_run_path = form == 5 ? 8 : form == 4 ? 7 : form == 3 ? 6 : 5;
       ctx->last_run_groups = (int)groups.size();
       ctx->last_run_waves_per_cu = 0;
       for (const WaveGroup& gr : groups) ctx->last_run_waves_per_cu = std::max(ctx->last_run_waves_per_cu, (gr.count + ctx->prop.multiProcessorCount - 1) / ctx->prop.multiProcessorCount);
+      if (form == 5) ctx->last_run_waves_per_cu = ctx->rg_args.block_threads / 64 * ((ctx->RG.n_regions + ctx->prop.multiProcessorCount - 1) / ctx->prop.multiProcessorCount);
       ctx->parity ^= 1;
       ctx->have_prev = true;
       ctx->canon_valid = false;

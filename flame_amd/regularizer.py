@@ -30,8 +30,9 @@ _IP = C.POINTER(C.c_int32)
 OPT_SOLVER, OPT_USE_HIPGRAPH, OPT_PERSISTENT, OPT_PROBE, OPT_VERIFY_RECORDS, OPT_PLACEMENT, OPT_SYNC_PATH, OPT_COST_SUM = 1, 2, 5, 12, 14, 16, 17, 18
 # ... and the experimental range (tuning knobs / test hooks of the current kernels; tools/ and the tests use them)
 OPT_BLOCK_WAVES, OPT_UNROLL, OPT_DUAL_PUBLISH, OPT_PRESLEEP, OPT_XCDS, OPT_FAULT_INJECT, OPT_POLL_GAP = 103, 104, 106, 108, 109, 110, 113
+OPT_RG_DEPTH, OPT_RG_REGIONS = 114, 115
 RUN_PATHS = {0: "none", 1: "persistent (the lane-per-half-edge form, retired in round 3)", 2: "per-step hipGraph", 3: "per-step eager", 4: "canonical 4-sweep",
-             5: "persistent-tv", 6: "persistent-pv", 7: "persistent-pv2"}
+             5: "persistent-tv", 6: "persistent-pv", 7: "persistent-pv2", 8: "persistent-rg"}
 ERR_NAN = -5
 
 VERTEX_STATE = ("x", "w1", "w2", "x_bar", "w1_bar", "w2_bar", "x_prev", "w1_prev", "w2_prev")

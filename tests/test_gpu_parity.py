@@ -74,7 +74,7 @@ def test_config_parity(env, config, n):
     g = synth.make_graph(config, seed=4242)
     ref, bad = cpu_run(oracle, g, n)
     assert bad == 0
-    for persistent in (1, 3, 4, 6, 0):  # auto, vertex-per-lane, patch-per-wave (one / two half-edges per lane), one launch per step
+    for persistent in (1, 3, 4, 6, 7, 0):  # auto, vertex-per-lane, patch-per-wave (one / two half-edges per lane), region-per-workgroup, one launch per step
         out = gpu_run(flame_amd, g, n, options=[(5, persistent)], expect_path=None if persistent else 2)
         assert rms(out["x"], ref["x"]) <= TOL_RMS
         assert_state_equal(out, ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"{config} p={persistent}")
@@ -479,7 +479,7 @@ def test_nan_is_reported_not_fatal(env):
             reg.run(flame_amd.Params(), 1)
 
 
-@pytest.mark.parametrize("form", [3, 4, 6])
+@pytest.mark.parametrize("form", [3, 4, 6, 7])
 def test_persistent_timeout_is_rolled_back_and_redone(env, form):
     """A persistent run whose neighbour wait expires (fault injection: one wave withholds its first record) must
     leave the state it started from untouched; run() then does the same steps with one launch per step."""
@@ -492,7 +492,7 @@ def test_persistent_timeout_is_rolled_back_and_redone(env, form):
         reg.upload_graph(g)
         reg.run(p, 30)                       # a normal persistent run first (odd/even parity both follow)
         oracle.run(ref, 30)
-        assert reg.info()["last_run_path"] in (5, 6, 7)
+        assert reg.info()["last_run_path"] in (5, 6, 7, 8)
         reg.set_option(flame_amd.regularizer.OPT_FAULT_INJECT, 200)
         reg.run(p, 41)                       # times out inside, recovered
         oracle.run(ref, 41)
@@ -506,7 +506,7 @@ def test_persistent_timeout_is_rolled_back_and_redone(env, form):
         reg.set_option(flame_amd.regularizer.OPT_FAULT_INJECT, 0)  # fault off: persistent runs again
         reg.run(p, 25)
         oracle.run(ref, 25)
-        assert reg.info()["last_run_path"] in (5, 6, 7)
+        assert reg.info()["last_run_path"] in (5, 6, 7, 8)
         assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="after the fault")
         # chained asynchronous runs (run_async back to back, an asynchronous export in between, a short per-step run):
         # the chain's starting state was copied aside, the whole chain is replayed on the per-step path
@@ -630,7 +630,7 @@ def test_export_idepth_device_and_stream(env):
         reg.set_stream(None)
 
 
-@pytest.mark.parametrize("form", [0, 3, 4, 6])
+@pytest.mark.parametrize("form", [0, 3, 4, 6, 7])
 def test_standing_export_target(env, form):
     """flame_nltgv2_set_export_target: every run leaves scale * x in the caller's vertex order, on all paths."""
     import torch
@@ -656,7 +656,7 @@ def test_standing_export_target(env, form):
         assert float(buf.max()) == -7.0
 
 
-@pytest.mark.parametrize("form", [3, 4, 6])
+@pytest.mark.parametrize("form", [3, 4, 6, 7])
 def test_export_target_switched_inside_a_replayed_chain(env, form):
     """Double-buffered gather rows: run k exports into row A, the target moves to row B, run k + 1 chains on.  If the chain
     is replayed (an expired wait), every run must be redone with the target IT was enqueued with -- row A gets run k's
@@ -898,3 +898,56 @@ def test_an_expired_run_at_high_residency_makes_the_planner_leave_room(env):
         reg.upload_graph(small)
         reg.run(p, 20)
         assert reg.info()["last_run_path"] == 6
+
+
+# ---- the region-per-workgroup form (k_persistent_rg, layout (R)): a ghost ring of depth k, one L2 hand-off per block of k steps ---------
+@pytest.mark.parametrize("config,depth,regions", [("320x240", 1, 0), ("320x240", 2, 0), ("320x240", 3, 40), ("320x240", 4, 0), ("640x480", 2, 0), ("640x480", 3, 0),
+                                                  ("640x480", 4, 0), ("640x480", 2, 512), ("1280x720", 2, 0), ("1280x720", 3, 0)])
+def test_region_per_workgroup_form(env, config, depth, regions):
+    """Every state array bit-identical to the checker for run lengths that are and are not multiples of the block length, chained
+    runs (the ring is re-read from the packed arrays at every launch), non-default parameters and weights."""
+    from flame_amd.regularizer import OPT_PERSISTENT, OPT_RG_DEPTH, OPT_RG_REGIONS
+
+    flame_amd, oracle = env
+    g = synth.make_graph(config, seed=77 + depth)
+    rng = np.random.default_rng(depth)
+    g["data_weight"] = (0.5 + rng.random(g["V"])).astype(np.float32)
+    ref = synth.copy_graph(g)
+    pk = dict(data_factor=0.25, step_x=0.002, step_q=60.0, theta=0.5, x_min=0.05, x_max=4.0)
+    with flame_amd.Regularizer(0) as reg:
+        reg.set_option(OPT_PERSISTENT, 7)
+        reg.set_option(OPT_RG_DEPTH, depth)
+        reg.set_option(OPT_RG_REGIONS, regions)
+        reg.upload_graph(g)
+        for n, params in ((4 * depth, None), (57, pk), (1, None), (depth + 1, pk), (200, None)):
+            p = flame_amd.Params(**params) if params else flame_amd.Params()
+            reg.run(p, n)
+            bad = oracle.run(ref, n, oracle.make_params(**(params or {})))
+            assert bad == 0
+            if n >= 4:
+                assert reg.info()["last_run_path"] == 8, (config, depth, regions, n)
+            assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"{config} k={depth} n={n}")
+        assert reg.info()["timeouts_recovered"] == 0
+        sm, dc = reg.costs(flame_amd.Params())
+        assert [np.float32(sm), np.float32(dc)] == [np.float32(v) for v in oracle.costs(ref)]
+
+
+def test_region_form_declines_what_it_cannot_run(env):
+    """A vertex of more than 32 edges, or a graph too small for regions: the form asked for by name does not apply, the steps are done on
+    another path, the result is the same."""
+    from flame_amd.regularizer import OPT_PERSISTENT
+
+    flame_amd, oracle = env
+    g0 = synth.make_graph("320x240", seed=5)
+    hub, far = 1000, np.arange(0, 2000, 50, dtype=np.int32)  # a vertex of ~46 edges
+    have = set(zip(g0["src"].tolist(), g0["dst"].tolist())) | set(zip(g0["dst"].tolist(), g0["src"].tolist()))
+    extra = np.array([(hub, int(v)) for v in far if v != hub and (hub, int(v)) not in have], dtype=np.int32)
+    g = synth.assemble_graph(g0["pos"], g0["data_term"], np.concatenate([np.stack([g0["src"], g0["dst"]], axis=1), extra]))
+    ref, bad = cpu_run(oracle, g, 30)
+    assert bad == 0
+    with flame_amd.Regularizer(0) as reg:
+        reg.set_option(OPT_PERSISTENT, 7)
+        reg.upload_graph(g)
+        reg.run(flame_amd.Params(), 30)
+        assert reg.info()["last_run_path"] != 8
+        assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS, what="hub graph")
