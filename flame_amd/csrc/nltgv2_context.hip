@@ -96,16 +96,25 @@ size_t records_capacity(const PackedLayout& L) {
   return std::max(n_packed, n_rec);
 }
 
+int wait_raster(flame_nltgv2_ctx* ctx) {
+  if (ctx->raster_inflight) {
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_raster_done, 0));
+    ctx->raster_inflight = false;
+  }
+  return 0;
+}
+
 int ensure_canon(flame_nltgv2_ctx* ctx) {
   if (ctx->pending.active) {  // a persistent run is still unchecked: settle it before anything reads or edits the state
     const int rc = finish(ctx);
     if (rc) return rc;
   }
+  // interpolate_mesh_begin's side stream may still read the canonical pos / x: whoever comes through here is about to rewrite them (the
+  // unpack below, or the caller: project_graph, rescale_data, update_data, upload_state) -- also when the arrays are already current
+  // (advisor, round 4: with canon_valid set the early return skipped the wait and the caller wrote under the rasteriser)
+  int rc0 = wait_raster(ctx);
+  if (rc0) return rc0;
   if (ctx->canon_valid) return 0;
-  if (ctx->raster_inflight) {  // (interpolate_mesh_begin's side stream may still read the canonical arrays this is about to rewrite)
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_raster_done, 0));
-    ctx->raster_inflight = false;
-  }
   LAUNCHCHK(ctx, launch_unpack_state(ctx->c, ctx->f, ctx->parity, ctx->have_prev, ctx->stream));
   ctx->canon_valid = true;
   return 0;
@@ -298,6 +307,7 @@ int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const St
   const int32_t V = g->V, E = g->E;
   (void)long_lived;
   int rc = cancel_prepared(ctx);  // (a builder on the side stream reads the topology this is about to replace)
+  if (!rc) rc = wait_raster(ctx);  // (... and the rasteriser's side stream the positions)
   if (rc) return rc;
   rc = build_layout(g, &ctx->L, /*host_expand=*/false, /*rowpack=*/true,
                         /*rowpack_max_patches=*/ctx->opt_persistent == 4 ? 0x7fffffff : kPvDensePerCu * ctx->prop.multiProcessorCount);
@@ -514,7 +524,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
               &ctx->q2, &ctx->q3, &ctx->row_ptr, &ctx->half, &ctx->slice_row, &ctx->perm, &ctx->pdeg,
               &ctx->rec_nbr, &ctx->rec_edge, &ctx->edge_src_slot, &ctx->hrec, &ctx->hq, &ctx->vstate, &ctx->hq_alt, &ctx->vstate_alt, &ctx->cost_terms, &ctx->run_tail,
               &ctx->vaux, &ctx->bar0, &ctx->bar1, &ctx->vprev, &ctx->xbuf, &ctx->abort_flag, &ctx->tv_slot, &ctx->tv_vid, &ctx->tv_meta, &ctx->tv_wave, &ctx->wg2_slot, &ctx->wg2_vid, &ctx->wg2_meta, &ctx->wg2_nbr, &ctx->wg2_fetch, &ctx->wg2_info, &ctx->wg2_vfirst, &ctx->wg2_rmax, &ctx->err,
-              &ctx->cost_out, &ctx->img_ref, &ctx->img_cmp, &ctx->photo_err, &ctx->r_tris, &ctx->r_valid, &ctx->r_keys,
+              &ctx->cost_out, &ctx->img_ref, &ctx->img_cmp, &ctx->photo_err, &ctx->r_tris, &ctx->r_valid, &ctx->r_tvalid, &ctx->r_keys,
               &ctx->r_img, &ctx->r_cov, &ctx->r_vtx, &ctx->r_val, &ctx->wg_slot, &ctx->wg_vid, &ctx->wg_meta, &ctx->wg_nbr,
               &ctx->wg_fetch, &ctx->wg_info, &ctx->wg_v0, &ctx->probe, &ctx->snap_hq, &ctx->snap_vstate, &ctx->snap_bar, &ctx->iperm,
               &ctx->order_m, &ctx->rid_of, &ctx->stage[0].d, &ctx->stage[1].d, &ctx->sync_init, &ctx->sync_vmap, &ctx->sync_emap, &ctx->sync_need,

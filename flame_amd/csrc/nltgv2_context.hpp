@@ -291,6 +291,7 @@ struct flame_nltgv2_ctx {
   float* h_img = nullptr;             // pinned: the map of the last interpolate_mesh_begin (+ the coverage count behind it)
   size_t h_img_cap = 0;
   int map_rows = 0, map_cols = 0;     // the dense map resident in r_img (0: none)
+  int img_pending_rows = 0, img_pending_cols = 0;  // the map an interpolate_mesh_begin left in h_img for its _end (0: none pending)
   hipStream_t topo_stream = nullptr;  // the side stream of a prepared sync
   hipEvent_t ev_topo_ready = nullptr; // recorded on the context's stream when a topology stands (upload, commit): the next builder waits for it
   struct PreparedSync {
@@ -323,7 +324,7 @@ struct flame_nltgv2_ctx {
   DevBuf xbuf, abort_flag, tv_slot, tv_vid, tv_meta, tv_wave, wg2_slot, wg2_vid, wg2_meta, wg2_nbr, wg2_fetch, wg2_info, wg2_vfirst, wg2_rmax;
   DevBuf wg_slot, wg_vid, wg_meta, wg_nbr, wg_fetch, wg_info, wg_v0, wg_vfirst, probe, progress;
   // misc
-  DevBuf err, cost_out, img_ref, img_cmp, photo_err, r_tris, r_valid, r_keys, r_img, r_cov, r_vtx, r_val;
+  DevBuf err, cost_out, img_ref, img_cmp, photo_err, r_tris, r_valid, r_tvalid, r_keys, r_img, r_cov, r_vtx, r_val;
   int img_rows = 0, img_cols = 0, img_step = 0;
   int* h_err = nullptr;    // pinned, kErrBytes
   int last_expired[16] = {0};  // what the most recent expired wait reported (report_expired)
@@ -364,6 +365,7 @@ int enter(flame_nltgv2_ctx* ctx);
 void refresh_args(flame_nltgv2_ctx* ctx);                     // kernel argument blocks from the current buffers
 int h2d(flame_nltgv2_ctx* ctx, DevBuf& b, const void* src, size_t bytes);
 size_t records_capacity(const PackedLayout& L);
+int wait_raster(flame_nltgv2_ctx* ctx);                       // the context's stream waits for an interpolate_mesh_begin still reading pos / x
 int ensure_canon(flame_nltgv2_ctx* ctx);                      // settles a pending run, unpacks the state if needed
 int ensure_fused(flame_nltgv2_ctx* ctx);
 bool params_ok(const flame_nltgv2_params* p);

@@ -66,7 +66,7 @@ int flame_nltgv2_interpolate_mesh_begin(flame_nltgv2_ctx* ctx, const int32_t* tr
   }
   // the caller's triangles go up first (pageable memory: the copy holds the host), while the solver still runs ...
   rc = ensure(ctx, ctx->r_tris, sizeof(int32_t) * 3 * (size_t)T);
-  if (!rc) rc = ensure(ctx, ctx->r_valid, (size_t)T + (size_t)V + 16);
+  if (!rc) rc = ensure(ctx, ctx->r_tvalid, (size_t)T + 16);  // (its own buffer: project_graph writes r_valid on the context's stream)
   if (!rc) rc = ensure(ctx, ctx->r_keys, sizeof(unsigned long long) * n);
   if (!rc) rc = ensure(ctx, ctx->r_img, sizeof(float) * n);
   if (!rc) rc = ensure(ctx, ctx->r_cov, sizeof(int));
@@ -74,7 +74,7 @@ int flame_nltgv2_interpolate_mesh_begin(flame_nltgv2_ctx* ctx, const int32_t* tr
   if (T > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->r_tris.p, triangles, sizeof(int32_t) * 3 * (size_t)T, hipMemcpyHostToDevice, rs));
   uint8_t* d_tv = nullptr;
   if (tri_valid && T > 0) {
-    d_tv = (uint8_t*)ctx->r_valid.p;
+    d_tv = (uint8_t*)ctx->r_tvalid.p;
     HIPCHK(ctx, hipMemcpyAsync(d_tv, tri_valid, (size_t)T, hipMemcpyHostToDevice, rs));
   }
   rc = ensure_canon(ctx);  // ... it stops here ...
@@ -88,6 +88,7 @@ int flame_nltgv2_interpolate_mesh_begin(flame_nltgv2_ctx* ctx, const int32_t* tr
   HIPCHK(ctx, hipEventRecord(ctx->ev_raster_done, rs));
   ctx->raster_inflight = true;
   ctx->map_rows = rows, ctx->map_cols = cols;
+  ctx->img_pending_rows = rows, ctx->img_pending_cols = cols;  // (what _end describes: a synchronous interpolate_mesh in between changes map_rows)
   return FLAME_NLTGV2_OK;
 }
 
@@ -95,9 +96,9 @@ int flame_nltgv2_interpolate_mesh_end(flame_nltgv2_ctx* ctx, const float** map_o
   flame_hip::RoctxRange roctx_range_("flame_nltgv2_interpolate_mesh_end");
   int rc = enter(ctx);
   if (rc) return rc;
-  if (!ctx->h_img || ctx->map_rows == 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  if (!ctx->h_img || ctx->img_pending_rows == 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
   HIPCHK(ctx, hipStreamSynchronize(ctx->raster_stream));
-  const size_t n = (size_t)ctx->map_rows * (size_t)ctx->map_cols;
+  const size_t n = (size_t)ctx->img_pending_rows * (size_t)ctx->img_pending_cols;
   if (map_out) *map_out = ctx->h_img;
   if (coverage_out) std::memcpy(coverage_out, ctx->h_img + n, sizeof(int32_t));
   return FLAME_NLTGV2_OK;

@@ -6,7 +6,7 @@
 // slice table, the greedy patch walks) and sent them up: 0.7 ms of a 640x480 frame and 4-5 ms of a 1080p frame in which the solver
 // stood still -- ten times the 200 iterations they feed.  Here the same tables are produced by a dozen small kernels over the
 // RESIDENT previous topology and one staged copy of the frame's inputs; nltgv2_pack.hpp stays the reference they are compared with
-// word for word (flame_nltgv2_layout_selftest, tests/test_sync_graph.py, tests/test_device_topology.py).
+// word for word (flame_nltgv2_layout_selftest, tests/test_sync_graph.py, tests/test_sync_graph.py (test_device_expanded_layout_matches_host_builders, layout_selftest after every frame)).
 //
 //   front (sync)    k_topo_init      feature id -> previous vertex through a stamped table (one probe per vertex, the table follows
 //                                    the graph in the same pass), Morton codes, union-find roots

@@ -81,23 +81,25 @@ int ensure_host_layout(flame_nltgv2_ctx* ctx) {
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   flame_nltgv2_graph g{};
   g.V = V, g.E = E, g.pos = pos.data(), g.src = ctx->h_src.data(), g.dst = ctx->h_dst.data();
-  const PackedLayout dev = ctx->L;  // (scalars as the device reported them; its vectors are stale)
-  int rc = build_layout(&g, &ctx->L, /*host_expand=*/false, /*rowpack=*/dev.wg_rowpack);
+  const PackedLayout& dev = ctx->L;  // (scalars as the device reported them; its vectors are stale)
+  // built aside and committed only once it agrees with the device's tables: a mismatch leaves the context as it was (advisor, round 4)
+  PackedLayout H;
+  int rc = build_layout(&g, &H, /*host_expand=*/false, /*rowpack=*/dev.wg_rowpack);
   if (rc) return fail(ctx, rc);
-  if (dev.wg2_walked) build_patch_walk2(&ctx->L);
-  PackedLayout& L = ctx->L;
-  L.tv_ok = dev.tv_ok, L.tv_waves = dev.tv_waves;
-  const bool same = L.rows == dev.rows && L.n_slices == dev.n_slices && L.max_degree == dev.max_degree && L.wg_count == dev.wg_count &&
-                    L.wg_lcap == dev.wg_lcap && L.wg_rowpack == dev.wg_rowpack &&
-                    (!dev.wg2_ok || (L.wg2_ok && L.wg2_count == dev.wg2_count && L.wg2_lcap == dev.wg2_lcap));  // (the device walks (E2) always, the
+  if (dev.wg2_walked) build_patch_walk2(&H);
+  H.tv_ok = dev.tv_ok, H.tv_waves = dev.tv_waves;
+  const bool same = H.rows == dev.rows && H.n_slices == dev.n_slices && H.max_degree == dev.max_degree && H.wg_count == dev.wg_count &&
+                    H.wg_lcap == dev.wg_lcap && H.wg_rowpack == dev.wg_rowpack &&
+                    (!dev.wg2_ok || (H.wg2_ok && H.wg2_count == dev.wg2_count && H.wg2_lcap == dev.wg2_lcap));  // (the device walks (E2) always, the
                                                                                                                  //  host only up to 32 edges per vertex)
   if (!same) {  // the device tables and the host builders disagree: a bug, never silent
     std::fprintf(stderr, "[flame_nltgv2] host image of a device-built layout differs: rows %ld / %ld, slices %d / %d, max degree %d / %d, patches %d / %d, "
-                 "lcap %d / %d, rowpack %d / %d, (E2) ok %d / %d patches %d / %d lcap %d / %d (host / device)\n", (long)L.rows, (long)dev.rows, L.n_slices, dev.n_slices,
-                 L.max_degree, dev.max_degree, L.wg_count, dev.wg_count, L.wg_lcap, dev.wg_lcap, (int)L.wg_rowpack, (int)dev.wg_rowpack, (int)L.wg2_ok,
-                 (int)dev.wg2_ok, L.wg2_count, dev.wg2_count, L.wg2_lcap, dev.wg2_lcap);
+                 "lcap %d / %d, rowpack %d / %d, (E2) ok %d / %d patches %d / %d lcap %d / %d (host / device)\n", (long)H.rows, (long)dev.rows, H.n_slices, dev.n_slices,
+                 H.max_degree, dev.max_degree, H.wg_count, dev.wg_count, H.wg_lcap, dev.wg_lcap, (int)H.wg_rowpack, (int)dev.wg_rowpack, (int)H.wg2_ok,
+                 (int)dev.wg2_ok, H.wg2_count, dev.wg2_count, H.wg2_lcap, dev.wg2_lcap);
     return fail(ctx, FLAME_NLTGV2_ERR_HIP);
   }
+  ctx->L = std::move(H);
   ctx->host_layout_valid = true;
   return 0;
 }
@@ -177,7 +179,7 @@ int topo_prepare(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, bool*
   struct { size_t off; } cv{sm.total};
   const size_t nx_bytes[flame_nltgv2_ctx::NX_COUNT] = {
       2 * fV, fE, fE, sizeof(int32_t) * ((size_t)V + 1), 2 * fE, iV, iV, sizeof(int32_t) * n_packed, iV, sizeof(int32_t) * n_packed,
-      sizeof(int32_t) * ((size_t)n_slices + 1), 4 * iV, iV, vpad, 4 * iV, vpad, fV, fV};  // (patch tables by their upper bound: a patch holds at least one vertex)
+      sizeof(int32_t) * ((size_t)n_slices + 1), 4 * iV, iV, vpad + 16, 4 * iV, vpad + 16, fV, fV};  // (patch tables by their upper bound: a patch holds at least one vertex)
   // (the previous commit's kernels may still read the scratch maps and write what this builder reads: it starts behind them)
   HIPCHK(ctx, hipStreamWaitEvent(ts, ctx->ev_topo_ready, 0));
   if (ctx->raster_inflight) HIPCHK(ctx, hipStreamWaitEvent(ts, ctx->ev_raster_done, 0));  // (it may read a position buffer that was swapped out)
@@ -292,7 +294,7 @@ int topo_upload(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const StageC
       {&ctx->topo_scratch, sm.total}, {&ctx->topo_dims, sizeof(TopoDims)}, {&ctx->pos, 2 * fV}, {&ctx->src, fE}, {&ctx->dst, fE},
       {&ctx->row_ptr, sizeof(int32_t) * ((size_t)V + 1)}, {&ctx->half, 2 * fE}, {&ctx->slice_row, sizeof(int32_t) * ((size_t)sm.n_slices + 1)},
       {&ctx->perm, sizeof(int32_t) * n_packed}, {&ctx->pdeg, sizeof(int32_t) * n_packed}, {&ctx->iperm, iV}, {&ctx->order_m, iV}, {&ctx->rid_of, iV},
-      {&ctx->wg_info, 4 * iV}, {&ctx->wg_v0, iV}, {&ctx->wg_vfirst, sm.vpad}, {&ctx->wg2_info, 4 * iV}, {&ctx->wg2_vfirst, sm.vpad}};
+      {&ctx->wg_info, 4 * iV}, {&ctx->wg_v0, iV}, {&ctx->wg_vfirst, sm.vpad + 16}, {&ctx->wg2_info, 4 * iV}, {&ctx->wg2_vfirst, sm.vpad + 16}};
   for (auto& r : req) {
     rc = ensure(ctx, *r.b, r.bytes);
     if (rc) return rc;

@@ -518,3 +518,26 @@ def test_new_vertices_start_at_the_resident_dense_map(built, mode):
             tris = synth.delaunay_native(pos)[0]
         with pytest.raises(flame_amd.NLTGV2Error):  # init_from_map needs the scale and excludes init_x
             reg.sync_graph(feat_id, pos, data, weight, edges, init_from_map=True)
+
+
+def test_vertex_counts_at_the_walk_padding_boundary(built):
+    """Advisor, round 4: the device builder sized the per-vertex walk tables to V rounded up to 16384 bytes, topology_buffers then asked
+    for V + 16 -- a reused buffer of exactly 16384 bytes was re-allocated AFTER the build for V in 16369..16384 and the tables were
+    lost.  A context that first holds a graph of ~10.8 k vertices (buffers of 16384 bytes), then graphs of 16384 and 16383 vertices,
+    built on the device: layout word for word as the host builders', 20 steps bit-identical."""
+    import torch  # noqa: F401
+
+    import flame_amd
+
+    with flame_amd.Regularizer(0) as reg:
+        for w, h in ((104, 104), (128, 128), (127, 129), (128, 128)):
+            name = f"{6 * w}x{6 * h}"
+            synth.CONFIGS[name] = (6 * w, 6 * h, 6)
+            g = synth.make_graph(name, seed=3)
+            assert g["V"] == w * h
+            ref = synth.copy_graph(g)
+            reg.upload_graph(g)
+            assert reg.layout_selftest() == 0, name
+            reg.run(flame_amd.Params(), 20)
+            oracle.run(ref, 20)
+            assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS, what=name)
