@@ -519,6 +519,21 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
   }
   ctx->stream = ctx->own_stream;
   *ctx->h_err = 0;
+  {
+    // The first context of a process pays what would otherwise land on its first frame (tools/cold_start.py: 16 ms of code-object
+    // loading in the first upload_graph, 4 ms of record-placement calibration in the first run): the kernels' code objects are
+    // loaded here, and the page ranking of this device is measured here, once per process (later contexts take it from the cache).
+    static std::once_flag warm;
+    std::call_once(warm, [] {
+      warm_module_kernels(), warm_module_persistent(), warm_module_persistent_tv(), warm_module_persistent_pv2(), warm_module_persistent_rg();
+      warm_module_layout(), warm_module_topo();
+    });
+    if (!std::getenv("FLAME_NLTGV2_LAZY_CALIBRATION") && ctx->prop.multiProcessorCount >= 64 && place_calibrate(ctx) != 0) {
+      ctx->last_error = 0, ctx->last_hip = 0;
+      (void)hipGetLastError();
+    }
+    if (ctx->place_state < 0) ctx->place_state = 0;  // (not now: the first run that can use it tries again)
+  }
   ctx->all = {&ctx->pos, &ctx->x, &ctx->w1, &ctx->w2, &ctx->xb, &ctx->w1b, &ctx->w2b, &ctx->xp, &ctx->w1p,
               &ctx->w2p, &ctx->data, &ctx->weight, &ctx->src, &ctx->dst, &ctx->alpha, &ctx->beta, &ctx->q1,
               &ctx->q2, &ctx->q3, &ctx->row_ptr, &ctx->half, &ctx->slice_row, &ctx->perm, &ctx->pdeg,

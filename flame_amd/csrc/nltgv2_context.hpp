@@ -23,6 +23,7 @@
 #include <cmath>
 #include <new>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "flame_nltgv2.h"
@@ -408,6 +409,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n);
 int finish(flame_nltgv2_ctx* ctx);                            // reads the error word; rolls a failed persistent run back and redoes it
 int snapshot_chain_start(flame_nltgv2_ctx* ctx);
 int place_records(flame_nltgv2_ctx* ctx, int per_xcd);        // record placement, once per topology (k_place_assign)
+int place_calibrate(flame_nltgv2_ctx* ctx);                   // ... and the page ranking, once per device and process
 
 }  // namespace host
 }  // namespace flame_hip

@@ -272,6 +272,15 @@ int launch_topo_sync_front(const TopoBuild& t, hipStream_t s);
 int launch_topo_upload_front(const TopoBuild& t, hipStream_t s);
 int launch_topo_back(const TopoBuild& t, hipStream_t s);
 
+// one per translation unit with kernels: loads its code object (flame_nltgv2_create of the first context of a process)
+void warm_module_kernels();
+void warm_module_persistent();
+void warm_module_persistent_tv();
+void warm_module_persistent_pv2();
+void warm_module_persistent_rg();
+void warm_module_layout();
+void warm_module_topo();
+
 int launch_save_prev(const CanonArgs& c, hipStream_t s);
 int launch_dual(const CanonArgs& c, const SolverParams& p, hipStream_t s);
 int launch_primal(const CanonArgs& c, const SolverParams& p, hipStream_t s);

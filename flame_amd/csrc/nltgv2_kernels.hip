@@ -707,4 +707,11 @@ int launch_cost_terms(const CanonArgs& c, float* terms, hipStream_t s) {
 
 
 
+// Loads this translation unit's code object (the runtime does that at the first use of one of its kernels: several milliseconds that
+// flame_nltgv2_create takes on itself so that the first frame does not).
+void warm_module_kernels() {
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, (const void*)k_save_prev) != hipSuccess) (void)hipGetLastError();
+}
+
 }  // namespace flame_hip

@@ -636,4 +636,11 @@ int launch_sync_state(const SyncArgs& a, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+// Loads this translation unit's code object (the runtime does that at the first use of one of its kernels: several milliseconds that
+// flame_nltgv2_create takes on itself so that the first frame does not).
+void warm_module_layout() {
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, (const void*)k_scatter) != hipSuccess) (void)hipGetLastError();
+}
+
 }  // namespace flame_hip

@@ -507,4 +507,11 @@ int launch_persistent_pv2(const FusedArgs& a, const Pv2Args& w, const SolverPara
   return (int)hipLaunchKernel(fn, gv, bv, vargs, ldsv, stream);
 }
 
+// Loads this translation unit's code object (the runtime does that at the first use of one of its kernels: several milliseconds that
+// flame_nltgv2_create takes on itself so that the first frame does not).
+void warm_module_persistent_pv2() {
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, (const void*)k_persistent_pv2<false>) != hipSuccess) (void)hipGetLastError();
+}
+
 }  // namespace flame_hip

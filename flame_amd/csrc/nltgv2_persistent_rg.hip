@@ -568,4 +568,11 @@ int launch_persistent_rg(const FusedArgs& f, const RgArgs& a, const SolverParams
   return (int)hipLaunchKernel(fn, grid, block, args, a.lds_bytes, stream);
 }
 
+// Loads this translation unit's code object (the runtime does that at the first use of one of its kernels: several milliseconds that
+// flame_nltgv2_create takes on itself so that the first frame does not).
+void warm_module_persistent_rg() {
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, rg_kernel(false, 512)) != hipSuccess) (void)hipGetLastError();
+}
+
 }  // namespace flame_hip

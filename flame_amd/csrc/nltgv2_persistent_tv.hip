@@ -382,4 +382,9 @@ const void* persistent_tv_kernel(bool static_in_lds, int waves_per_block, unsign
   return (const void*)k_persistent_tv<true>;
 }
 
+void warm_module_persistent_tv() {
+  unsigned lds = 0;
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, persistent_tv_kernel(true, 4, &lds)) != hipSuccess) (void)hipGetLastError();
+}
 }  // namespace flame_hip

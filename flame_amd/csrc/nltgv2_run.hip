@@ -279,9 +279,43 @@ int enqueue_photo_sweep(flame_nltgv2_ctx* ctx, bool packed_current) {
 // ranked per pair.  ~3 ms, at the first run that can use it.  Anything unexpected (a pair missing because two blocks
 // shared an XCD, a wait that expired because the GPU is busy with someone else's work) switches placement off for this
 // context: the records then keep their linear places.
+// The page ranking is a property of the device, not of a context: the first context of a process that calibrates a device keeps the
+// ranking for the others (a fresh context's first run: 4.6 -> 0.6 ms; eight contexts of one device: 32 ms less).
+namespace {
+struct PlaceCache {
+  bool valid = false;
+  std::vector<uint16_t> rank;
+  float best = 0.f, mean = 0.f, worst = 0.f;
+};
+std::mutex g_place_mu;
+PlaceCache g_place_cache[64];
+}  // namespace
+
 int place_calibrate(flame_nltgv2_ctx* ctx) {
   ctx->place_state = -1;
   constexpr int P = kPlacePages, kIters = 12;
+  if (ctx->device >= 0 && ctx->device < 64 && !std::getenv("FLAME_NLTGV2_RECALIBRATE")) {
+    std::vector<uint16_t> rank;
+    {
+      std::lock_guard<std::mutex> lock(g_place_mu);
+      const PlaceCache& c = g_place_cache[ctx->device];
+      if (c.valid) rank = c.rank, ctx->place_best_us = c.best, ctx->place_mean_us = c.mean, ctx->place_worst_us = c.worst;
+    }
+    if (!rank.empty()) {
+      const size_t pool_bytes = (size_t)2 * P * 4096;
+      int rc = ensure(ctx, ctx->place_pool, pool_bytes + 4096);
+      if (!rc) rc = ensure(ctx, ctx->place_rank, sizeof(uint16_t) * 2 * 64 * P);
+      if (!rc) rc = ensure(ctx, ctx->place_fill, sizeof(int) * (2 * P + 16 + 128));
+      if (rc) return rc;
+      ctx->place_base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ctx->place_pool.p) + 4095) & ~uintptr_t(4095));
+      HIPCHK(ctx, hipMemsetAsync(ctx->place_base, 0, pool_bytes, ctx->stream));
+      HIPCHK(ctx, hipMemsetAsync(ctx->place_fill.p, 0, sizeof(int) * (2 * P + 16 + 128), ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->place_rank.p, rank.data(), sizeof(uint16_t) * rank.size(), hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (`rank` is pageable and leaves scope)
+      ctx->place_state = 1;
+      return 0;
+    }
+  }
   const size_t pool_bytes = (size_t)2 * P * 4096;
   int rc = ensure(ctx, ctx->place_pool, pool_bytes + 4096);
   if (!rc) rc = ensure(ctx, ctx->place_meas, sizeof(unsigned) * 64 * 2 * P + sizeof(int) * 64 + sizeof(int));
@@ -350,6 +384,11 @@ int place_calibrate(flame_nltgv2_ctx* ctx) {
   HIPCHK(ctx, hipMemcpyAsync(ctx->place_rank.p, rank.data(), sizeof(uint16_t) * rank.size(), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (`rank` is pageable and leaves scope)
   ctx->place_state = 1;
+  if (ctx->device >= 0 && ctx->device < 64) {
+    std::lock_guard<std::mutex> lock(g_place_mu);
+    PlaceCache& c = g_place_cache[ctx->device];
+    c.rank = rank, c.best = ctx->place_best_us, c.mean = ctx->place_mean_us, c.worst = ctx->place_worst_us, c.valid = true;
+  }
   return 0;
 }
 

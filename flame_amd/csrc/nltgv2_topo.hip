@@ -6,7 +6,7 @@
 // slice table, the greedy patch walks) and sent them up: 0.7 ms of a 640x480 frame and 4-5 ms of a 1080p frame in which the solver
 // stood still -- ten times the 200 iterations they feed.  Here the same tables are produced by a dozen small kernels over the
 // RESIDENT previous topology and one staged copy of the frame's inputs; nltgv2_pack.hpp stays the reference they are compared with
-// word for word (flame_nltgv2_layout_selftest, tests/test_sync_graph.py, tests/test_sync_graph.py (test_device_expanded_layout_matches_host_builders, layout_selftest after every frame)).
+// word for word (flame_nltgv2_layout_selftest; tests/test_sync_graph.py: test_device_expanded_layout_matches_host_builders and the self-test after every frame).
 //
 //   front (sync)    k_topo_init      feature id -> previous vertex through a stamped table (one probe per vertex, the table follows
 //                                    the graph in the same pass), Morton codes, union-find roots
@@ -613,6 +613,13 @@ int launch_topo_back(const TopoBuild& t, hipStream_t s) {
   hipLaunchKernelGGL(k_topo_walk, dim3((unsigned)((n_seg + kWalkLanes - 1) / kWalkLanes)), dim3(128), 0, s, t, n_seg);
   hipLaunchKernelGGL(k_topo_patches, dim3((unsigned)n_seg, 2), dim3(kWalkSegment), 0, s, t, n_seg);
   return (int)hipGetLastError();
+}
+
+// Loads this translation unit's code object (the runtime does that at the first use of one of its kernels: several milliseconds that
+// flame_nltgv2_create takes on itself so that the first frame does not).
+void warm_module_topo() {
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, (const void*)k_topo_walk) != hipSuccess) (void)hipGetLastError();
 }
 
 }  // namespace flame_hip

@@ -356,8 +356,9 @@ int flame_nltgv2_abi_version(void);
  * [patch][step][8] words; *n_words = words available.  Not part of the reference's surface. */
 int flame_nltgv2_read_probe(flame_nltgv2_ctx* ctx, uint32_t* out, int64_t max_words, int64_t* n_words);
 
-/* Measurement aid: the record placement (FLAME_NLTGV2_OPT_PLACEMENT).  *state: 1 = calibrated and in use, 0 = not yet (no
- * run has needed it), -1 = unavailable (the calibration did not complete; records keep their linear places).
+/* Measurement aid: the record placement (FLAME_NLTGV2_OPT_PLACEMENT).  *state: 1 = the page ranking of the device is known (measured
+ * once per device and process, when the first context is created), 0 = not yet (the measurement did not complete then: the first run
+ * that can use it tries again), -1 = unavailable (it did not complete then either; records keep their linear places).
  * *placed_records = records of the current topology that were given a place in the pool (per step parity);
  * us[0..2] = one-way hand-off by choice of page as the calibration measured it, mean over the XCD pairs: the best page,
  * the mean page, the worst page.  Any output pointer may be NULL.  Not part of the reference's surface. */

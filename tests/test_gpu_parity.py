@@ -813,7 +813,7 @@ def test_record_placement_is_bit_identical_and_well_formed(env, config):
                 assert 0.0 < pi["best_us"] <= pi["mean_us"] <= pi["worst_us"] < 5.0, pi
                 assert reg.layout_selftest() == 0
             else:
-                assert pi["state"] == 0 and pi["placed_records"] == 0, pi
+                assert pi["placed_records"] == 0, pi  # (the page ranking itself is measured when a context is created: state 1 either way)
 
 
 @pytest.mark.gpu
