@@ -150,6 +150,9 @@ def main():
         from flame_amd.frames import IdepthGather
 
         ig = IdepthGather(dist, [g["V"]], world, torch.device("cuda", local_rank))
+        with torch.cuda.stream(solver_stream):
+            ig.check_overlap(reg, params)  # (warns if the collective's stream shares the solver's hardware queue)
+        reg.upload_graph(g)
 
 
         def before_step():  # the solver leaves x * graph_scale in the gather's (double-buffered) send row itself
@@ -246,7 +249,7 @@ def main():
             "run_path": run_path,
         }
         if gather_us is not None:
-            out["result_gather"] = {"all_gather_us": round(gather_us, 1), "bytes_per_rank": int(g["V"]) * 4, "ranks": world, "backend": backend,
+            out["result_gather"] = {"overlap": getattr(ig, "overlap", None), "all_gather_us": round(gather_us, 1), "bytes_per_rank": int(g["V"]) * 4, "ranks": world, "backend": backend,
                                     "last_row_matches_state": gather_ok, "regathered_after_replay": int(regathered),
                                     "note": "blocking all_gather_into_tensor of x*graph_scale incl. host launch + sync; in the "
                                             "step loop it is asynchronous and overlaps the next solve"}

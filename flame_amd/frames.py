@@ -103,6 +103,58 @@ class IdepthGather:
         self._cur = 1 - k
         self.local = self._local[self._cur]
 
+    def check_overlap(self, reg, params, iters: int = 200, steps: int = 24) -> dict:
+        """Does the collective run BESIDE the solver, as the pipelined frame loop assumes?  The HIP runtime multiplexes a process's
+        streams onto GPU_MAX_HW_QUEUES (default 4) in-order hardware queues; when the collective's stream shares the solver's queue
+        every gather sits between two runs instead of beside the next one (0.35 instead of 0.21 ms per step, docs/LAB_NOTES.md round 4)
+        -- a property of the host process that a library cannot set.  This measures it on the streams the frame loop really uses:
+        `steps` frames of run_async alone, then the same with the export target set and an asynchronous gather behind every run; a step
+        that grows by more than a third means the queues collide: a RuntimeWarning says so (remedy: start the process with
+        GPU_MAX_HW_QUEUES=8) and the figures are kept in `self.overlap`.  Collective: every rank calls it (from the solver's stream
+        context).  A staged (host) backend has nothing to measure."""
+        import time
+
+        if self._staged or self.n_frames == 0:
+            self.overlap = {"measured": False}
+            return self.overlap
+        dev = self._local[0].device
+
+        def loop(with_gather: bool) -> float:
+            reg.sync()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                if with_gather:
+                    reg.set_export_target(self.local_row(0).data_ptr(), 1.0)
+                reg.run_async(params, iters)
+                if with_gather:
+                    self.gather(async_op=True, regs=[reg])
+            reg.sync()
+            self.wait()
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) / steps * 1e3
+
+        loop(True)  # (first launches, the communicator's first collective)
+        alone, beside = loop(False), loop(True)
+        reg.set_export_target(None)
+        self.overlap = self.overlap_verdict(alone, beside)
+        return self.overlap
+
+    @staticmethod
+    def overlap_verdict(step_ms_alone: float, step_ms_with_gather: float) -> dict:
+        """The figures of check_overlap and what they mean: a step that grows by more than a third with the gather behind every run is
+        a gather that waits for the runs around it (round 4 measured 0.35 against 0.21 ms when RCCL's stream shared the solver's
+        hardware queue, 0.21 against 0.19 when it did not) -- reported as a RuntimeWarning with the remedy."""
+        import warnings
+
+        ok = bool(step_ms_with_gather < 1.35 * step_ms_alone)
+        if not ok:
+            warnings.warn("flame_amd.frames: the result gather does not overlap the solver (%.3f ms per step with the gather behind every run, %.3f without): "
+                          "the collective's stream shares the solver's hardware queue; start the process with GPU_MAX_HW_QUEUES=8"
+                          % (step_ms_with_gather, step_ms_alone), RuntimeWarning)
+        return {"measured": True, "overlaps": ok, "step_ms_alone": round(step_ms_alone, 4), "step_ms_with_gather": round(step_ms_with_gather, 4),
+                "gather_tax": round(step_ms_with_gather / step_ms_alone - 1.0, 4)}
+
     def settle(self, regs) -> int:
         """Completes the gather and makes sure it carried rows of runs that really finished.  `gather()` right behind
         `run_async()` reads the export rows of unchecked runs: a persistent run whose neighbour wait expires leaves

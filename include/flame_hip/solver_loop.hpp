@@ -13,6 +13,23 @@
 //   }
 //   loop.stop();                         // or the destructor: sets the flag, wakes the thread, joins
 //
+// DEVICE MODE (round 5): a pipeline whose per-frame graph edits happen ON the device (DeviceGraph::syncPrepare / syncCommit,
+// projectGraph, interpolateMeshBegin / End) has no host graph to re-upload: construct the loop with a null graph, hand it the first
+// graph through withDevice() + deviceReady(), and do every later edit through withDevice() -- the solver thread keeps iterating on
+// whatever the device image is between two such calls (markDirty() is never needed, nothing is ever re-uploaded):
+//
+//   flame_hip::SolverLoop<flame_hip::FlatGraph> loop(nullptr, &graph_mtx_, params, /*iters_per_round=*/256);
+//   loop.start();
+//   loop.withDevice([&](DeviceGraph& d, uint64_t) { d.upload(first_graph); });  loop.deviceReady();
+//   per frame:  loop.withDevice([&](DeviceGraph& d, uint64_t iterations_so_far) { d.syncPrepare(...); });   // the solver goes on
+//               ... triangulate the next frame, track features ...
+//               loop.withDevice([&](DeviceGraph& d, uint64_t) { d.syncCommit(); });
+//               loop.withDevice([&](DeviceGraph& d, uint64_t) { d.interpolateMeshBegin(...); });  ...  interpolateMeshEnd
+//   loop.busyFraction()  -- the share of the wall time since deviceReady() the solver thread spent inside run(): the rest is the
+//                           solver standing still (callers holding the device, launches)
+// The callback's second argument is the number of iterations applied to the device image so far -- exact, read under the lock --
+// which is what lets a test replay the free-running loop on the CPU checker (tests/cpp/frame_loop_test.cc).
+//
 // Locking: the caller's mutex protects the HOST graph exactly as in the reference; the loop takes it only to upload.  An
 // internal mutex serialises the calls into the (not thread-safe) device context: the loop holds it for one round of
 // `iters_per_round` iterations (~1.3 us each at 640x480), readBack() waits for that round at most (the loop gives way to
@@ -93,6 +110,7 @@ class SolverLoop {
   // false -- and leaves the graph alone -- when the device image is not of this graph (edited since the last upload, or
   // nothing uploaded yet).
   bool readBack() {
+    if (graph_ == nullptr) return false;  // (device mode: results leave through interpolateMesh / the export target)
     CallerAccess dev_lk(this);
     uint64_t want;
     {
@@ -104,6 +122,33 @@ class SolverLoop {
     return true;
   }
   // iterations done on the device image since start(); error text of the thread, if it stopped on one
+  // Exclusive access to the device image for one call (see DEVICE MODE above): f(DeviceGraph&, iterations applied so far).
+  template <class F>
+  void withDevice(F&& f) {
+    CallerAccess dev_lk(this);
+    f(dev_, iterations_.load());
+  }
+  // Device mode: the image uploaded through withDevice() is what the loop iterates on from now on.
+  void deviceReady() {
+    {
+      std::lock_guard<std::mutex> lk(state_mtx_);
+      device_ready_ = true;
+      t_ready_ = std::chrono::steady_clock::now();
+      busy_ns_.store(0);
+    }
+    cv_.notify_all();
+  }
+  // Share of the wall time since deviceReady() / start() that the solver thread spent inside run() (device mode: what the frame loop
+  // reports as "solver busy"; 1 - this = idle: the device lock held by callers, launch gaps).
+  double busyFraction() const {
+    std::chrono::steady_clock::time_point t0;
+    {
+      std::lock_guard<std::mutex> lk(state_mtx_);
+      t0 = t_ready_;
+    }
+    const double wall = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
+    return wall > 0 ? static_cast<double>(busy_ns_.load()) / wall : 0.0;
+  }
   uint64_t iterations() const { return iterations_.load(); }
   uint64_t uploads() const { return uploads_.load(); }
   std::string error() const {
@@ -143,7 +188,14 @@ class SolverLoop {
         }
         bool have = false;
         give_way();
-        {
+        if (graph_ == nullptr) {  // device mode: nothing is ever uploaded from the host; idle until the first image stands
+          std::unique_lock<std::mutex> lk(state_mtx_);
+          if (!device_ready_) {
+            cv_.wait_for(lk, std::chrono::milliseconds(50), [&] { return stop_.load() || device_ready_; });
+            continue;
+          }
+          have = true;
+        } else {
           std::lock_guard<std::mutex> dev_lk(dev_mtx_);
           have = dev_.generation() == dirty && uploaded_once_;
         }
@@ -174,7 +226,9 @@ class SolverLoop {
           if (V == 0 || (max_rounds_ > 0 && rounds_left == 0)) {
             idle = true;
           } else {
+            const auto t0 = std::chrono::steady_clock::now();
             dev_.run(params_, iters_per_round_);
+            busy_ns_.fetch_add(static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count()));
             iterations_.fetch_add(static_cast<uint64_t>(iters_per_round_));
             if (max_rounds_ > 0) --rounds_left;
           }
@@ -208,7 +262,9 @@ class SolverLoop {
   std::condition_variable cv_;
   std::thread thread_;
   std::atomic<bool> stop_{false};
-  std::atomic<uint64_t> iterations_{0}, uploads_{0};
+  std::atomic<uint64_t> iterations_{0}, uploads_{0}, busy_ns_{0};
+  bool device_ready_ = false;                              // device mode: the first image was handed over (state_mtx_)
+  std::chrono::steady_clock::time_point t_ready_ = std::chrono::steady_clock::now();
   std::atomic<int> callers_waiting_{0};
   uint64_t dirty_generation_ = 1;  // the graph as handed to the constructor is "edit 1": uploaded by the first round
   bool uploaded_once_ = false;

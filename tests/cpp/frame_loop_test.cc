@@ -1,0 +1,220 @@
+// tests/cpp/frame_loop_test.cc -- the order of Flame::update() (/root/reference/src/flame/flame.cc:265-415) driven from C++ through
+// the facade, with the solver FREE-RUNNING beside it (flame.cc:99-112: the solver thread) -- flame_hip::SolverLoop in device mode:
+//
+//   per frame:  FeatureTracker::addFrame + updateFeatureIDepths      (flame.cc:150, 1280-1536)
+//               delaunayTriangulate                                  (utils/delaunay.cc:31-77)
+//               projectGraph                                         (flame.cc:1862-1938; C-ABI call on the loop's DeviceGraph)
+//               DeviceGraph::syncPrepare   -- the solver thread goes on iterating on the live graph --
+//               [the host's other work of a frame]
+//               DeviceGraph::syncCommit                              (flame.cc:1985-2121)
+//               DeviceGraph::interpolateMeshBegin / interpolateMeshEnd  (flame.cc:409-415)
+//
+// The program is a DRIVER: tests/test_cpp_facade.py::test_frame_loop_end_to_end writes the frames' inputs to a file (images, poses,
+// the features, and per frame the feature set that enters the graph -- produced by the chained CPU checkers), runs this program, and
+// replays its log on the checkers: the log holds, for every call that touches the device image, the number of solver iterations the
+// free-running loop had applied when the call took the device (read under the loop's lock: exact), so the CPU side can run exactly
+// those iterations between the same edits and compare every output bit for bit: the updated features, the keep mask of projectGraph,
+// the dense map and its coverage, the graph's state at the end of every frame.  It also prints what share of the wall time the solver
+// thread spent iterating (SolverLoop::busyFraction).
+//
+// usage: frame_loop_test IN OUT [iters_per_round]     exit code 0 = ran, 77 = no usable HIP device
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "flame_hip/feature_tracker.hpp"
+#include "flame_hip/solver_loop.hpp"
+
+namespace dgraph = flame::optimizers::nltgv2_l1_graph_regularizer::hip;
+
+namespace {
+
+struct Reader {
+  FILE* f;
+  template <class T>
+  T one() {
+    T v;
+    if (std::fread(&v, sizeof(T), 1, f) != 1) std::abort();
+    return v;
+  }
+  template <class T>
+  std::vector<T> many(size_t n) {
+    std::vector<T> v(n);
+    if (n && std::fread(v.data(), sizeof(T), n, f) != n) std::abort();
+    return v;
+  }
+};
+struct Writer {
+  FILE* f;
+  template <class T>
+  void one(const T& v) { std::fwrite(&v, sizeof(T), 1, f); }
+  template <class T>
+  void many(const std::vector<T>& v) {
+    if (!v.empty()) std::fwrite(v.data(), sizeof(T), v.size(), f);
+  }
+};
+
+struct Mat3 {
+  float m[9];
+  float operator()(int r, int c) const { return m[3 * r + c]; }
+};
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 3) return 2;
+  {
+    flame_nltgv2_ctx* probe = nullptr;
+    const int rc = flame_nltgv2_create(&probe, 0);
+    if (rc != 0) {
+      std::printf("%s\n", flame_nltgv2_status_string(rc));
+      return 77;
+    }
+    flame_nltgv2_destroy(probe);
+  }
+  Reader in{std::fopen(argv[1], "rb")};
+  Writer out{std::fopen(argv[2], "wb")};
+  if (!in.f || !out.f) return 2;
+  const int iters_per_round = argc > 3 ? std::atoi(argv[3]) : 200;
+  const int32_t W = in.one<int32_t>(), H = in.one<int32_t>(), pad = in.one<int32_t>();
+  const int32_t n_feats = in.one<int32_t>(), n_initial = in.one<int32_t>(), n_new = in.one<int32_t>(), host_work_us = in.one<int32_t>();
+  Mat3 K, Kinv;
+  std::memcpy(K.m, in.many<float>(9).data(), sizeof K.m);
+  std::memcpy(Kinv.m, in.many<float>(9).data(), sizeof Kinv.m);
+  try {
+    flame_hip::FeatureTracker tracker(K, Kinv, W, H, pad);
+    for (int i = 0; i < n_initial; ++i) {
+      const uint32_t id = in.one<uint32_t>();
+      const std::vector<uint8_t> img = in.many<uint8_t>((size_t)W * H);
+      tracker.addFrame(id, img.data(), W);
+    }
+    std::vector<flame_stereo_feature> feats = in.many<flame_stereo_feature>((size_t)n_feats);
+    flame_stereo_params sp;
+    flame_stereo_default_params(&sp);
+    const dgraph::Params params;
+    std::recursive_mutex graph_mtx;
+    flame_hip::SolverLoop<flame_hip::FlatGraph> loop(nullptr, &graph_mtx, params, iters_per_round);
+    loop.start();
+    bool first = true;
+    const auto t_begin = std::chrono::steady_clock::now();
+    for (int fr = 0; fr < n_new; ++fr) {
+      // ---- Frame::create + updateFeatureIDepths --------------------------------------------------------------------------
+      const uint32_t id = in.one<uint32_t>(), curr_pf = in.one<uint32_t>();
+      const std::vector<uint8_t> img = in.many<uint8_t>((size_t)W * H);
+      const int32_t n_poses = in.one<int32_t>();
+      const std::vector<flame_stereo_pose> poses = in.many<flame_stereo_pose>((size_t)n_poses);
+      tracker.addFrame(id, img.data(), W);
+      flame_stereo_stats st;
+      tracker.updateFeatureIDepths(sp, id, curr_pf, poses, feats.data(), n_feats, &st);
+      out.many(feats);
+      out.one(st);
+      // ---- the features that enter the graph (projectFeatures is scaffolding of the test, done by its Python side) ----------
+      const int32_t V = in.one<int32_t>();
+      const std::vector<int32_t> fid = in.many<int32_t>((size_t)V);
+      const std::vector<float> pos = in.many<float>((size_t)2 * V), idepth = in.many<float>((size_t)V);
+      const std::vector<float> weight((size_t)V, 1.0f);
+      std::vector<int32_t> tris, edges;
+      flame_hip::delaunayTriangulate(pos, &tris, &edges);
+      out.one<int32_t>((int32_t)(tris.size() / 3)), out.many(tris);
+      out.one<int32_t>((int32_t)(edges.size() / 2)), out.many(edges);
+      const int32_t has_projection = in.one<int32_t>();
+      flame_nltgv2_projection pr;
+      if (has_projection) pr = in.one<flame_nltgv2_projection>();
+      if (first) {
+        flame_hip::FlatGraph g;
+        g.vertices.resize((size_t)V);
+        for (int32_t v = 0; v < V; ++v) {
+          flame_hip::VertexData& d = g.vertices[(size_t)v];
+          d.pos_x = pos[2 * v], d.pos_y = pos[2 * v + 1];
+          d.data_term = d.x = d.x_bar = d.x_prev = idepth[(size_t)v];
+        }
+        for (size_t e = 0; e + 1 < edges.size(); e += 2) {
+          flame_hip::EdgeData d;
+          d.source = edges[e], d.target = edges[e + 1];
+          const float dx = pos[2 * d.source] - pos[2 * d.target], dy = pos[2 * d.source + 1] - pos[2 * d.target + 1];
+          d.alpha = 1.0f / std::sqrt(dx * dx + dy * dy);  // flame.cc:2087-2102
+          g.edges.push_back(d);
+        }
+        loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t) {
+          d.upload(g);
+          if (flame_nltgv2_set_feature_ids(d.handle(), fid.data()) != 0) throw flame_hip::Error(FLAME_NLTGV2_ERR_INVALID_ARG, "set_feature_ids");
+        });
+        loop.deviceReady();
+        out.one<uint64_t>(0);
+        first = false;
+      } else {
+        // ---- projectGraph, then the sync in two halves with the solver iterating in between ------------------------------
+        std::vector<uint8_t> keep;
+        uint64_t it_project = 0, it_commit = 0;
+        loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t it) {
+          it_project = it;
+          int32_t Vo = 0, Eo = 0;
+          if (flame_nltgv2_graph_size(d.handle(), &Vo, &Eo) != 0) throw flame_hip::Error(FLAME_NLTGV2_ERR_HIP, "graph_size");
+          keep.resize((size_t)Vo);
+          const int rc = flame_nltgv2_project_graph(d.handle(), &pr, 1.0f, keep.data(), nullptr);
+          if (rc != 0) throw flame_hip::Error(rc, "project_graph");
+        });
+        out.one(it_project), out.one<int32_t>((int32_t)keep.size()), out.many(keep);
+        loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t) {
+          d.syncPrepare(fid, pos, idepth, weight, edges, false, nullptr, 0.0f, /*edges_unique=*/true);
+        });
+        std::this_thread::sleep_for(std::chrono::microseconds(host_work_us));  // (the host's other work of a frame: the solver iterates)
+        loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t it) {
+          it_commit = it;
+          d.syncCommit();
+        });
+        out.one(it_commit);
+      }
+      // ---- interpolateMesh in two halves ----------------------------------------------------------------------------------------
+      uint64_t it_raster = 0, it_state = 0;
+      loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t it) {
+        it_raster = it;
+        d.interpolateMeshBegin(tris, H, W, 1.0f);
+      });
+      std::this_thread::sleep_for(std::chrono::microseconds(host_work_us / 2));
+      const float* map = nullptr;
+      int32_t coverage = 0;
+      std::vector<float> dense((size_t)W * H);
+      loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t) {
+        coverage = d.interpolateMeshEnd(&map);
+        std::memcpy(dense.data(), map, sizeof(float) * dense.size());
+      });
+      out.one(it_raster), out.one(coverage), out.many(dense);
+      // ---- the graph's state at the end of the frame (a read-back the reference does not need: the test's window on the solver) ------
+      flame_hip::FlatArrays a;
+      loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t it) {
+        it_state = it;
+        int32_t Vn = 0, En = 0;
+        if (flame_nltgv2_graph_size(d.handle(), &Vn, &En) != 0) throw flame_hip::Error(FLAME_NLTGV2_ERR_HIP, "graph_size");
+        a.resize((size_t)Vn, (size_t)En);
+        flame_nltgv2_graph v = a.view();
+        const int rc = flame_nltgv2_download_state(d.handle(), &v);
+        if (rc != 0) throw flame_hip::Error(rc, "download_state");
+      });
+      out.one(it_state), out.one<int32_t>((int32_t)a.x.size()), out.one<int32_t>((int32_t)a.q1.size());
+      out.many(a.x), out.many(a.w1), out.many(a.w2), out.many(a.x_bar), out.many(a.w1_bar), out.many(a.w2_bar);
+      out.many(a.q1), out.many(a.q2), out.many(a.q3);
+    }
+    const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    const double busy = loop.busyFraction();
+    const uint64_t total = loop.iterations();
+    loop.stop();
+    const std::string err = loop.error();
+    if (!err.empty()) {
+      std::printf("FAIL: the solver thread stopped: %s\n", err.c_str());
+      return 1;
+    }
+    std::printf("frame loop: %d frames in %.2f ms, %llu solver iterations beside them (%d per round), solver busy %.1f %% of the wall time since the first graph, idle %.1f %%\n",
+                n_new, wall_ms, (unsigned long long)total, iters_per_round, 100.0 * busy, 100.0 * (1.0 - busy));
+  } catch (const std::exception& e) {
+    std::printf("FAIL: %s\n", e.what());
+    return 1;
+  }
+  std::fclose(out.f);
+  std::fclose(in.f);
+  return 0;
+}

@@ -150,3 +150,18 @@ def test_world2_gloo_settle_regathers_after_a_replayed_run():
         assert v0 == [0.0, 1.0] and v2 == [20.0, 21.0]
         assert stale[0] == 10.0 and stale[1] != 11.0  # what the first gather of step 1 delivered: rank 1's row as the run found it
         assert v1 == [10.0, 11.0]       # ... and what settle() left
+
+
+def test_overlap_verdict_reports_a_gather_that_waits_for_the_runs():
+    """IdepthGather.overlap_verdict: round 4's two measurements -- 0.35 ms per step with RCCL's stream on the solver's hardware queue,
+    0.21 beside it, 0.19-0.21 without a gather -- and what the host is told."""
+    import warnings
+
+    from flame_amd.frames import IdepthGather
+
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        good = IdepthGather.overlap_verdict(0.1908, 0.2094)
+        assert good["overlaps"] and not w and abs(good["gather_tax"] - 0.0975) < 1e-3
+        bad = IdepthGather.overlap_verdict(0.21, 0.35)
+        assert not bad["overlaps"] and len(w) == 1 and "GPU_MAX_HW_QUEUES=8" in str(w[0].message)

@@ -30,7 +30,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo", one_device=True):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -38,7 +38,11 @@ def _worker(rank, world, port, q):
     import torch
     import torch.distributed as dist
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         import flame_amd
         from flame_amd import synth
@@ -46,13 +50,13 @@ def _worker(rank, world, port, q):
         from flame_amd.regularizer import OPT_FAULT_INJECT
         from oracle import capi as oracle
 
-        dev = torch.device("cuda", 0)  # both ranks: the box has one GPU
+        dev = torch.device("cuda", 0 if one_device else rank)  # (one_device: the box has one GPU, every rank uses it)
         torch.cuda.set_device(dev)
         iters = 200
         frames = [synth.make_graph("640x480", seed=1234 + r) for r in range(world)]  # bench.py's per-rank seeds
         refs = [synth.copy_graph(g) for g in frames]
         g = frames[rank]
-        reg = flame_amd.Regularizer(0)
+        reg = flame_amd.Regularizer(dev.index)
         stream = torch.cuda.Stream(device=dev, priority=-1)
         reg.set_stream(stream.cuda_stream)
         reg.upload_graph(g)
@@ -60,7 +64,7 @@ def _worker(rank, world, port, q):
         p = flame_amd.Params()
         ok, regathers, paths = True, [], []
         for step in range(4):
-            fault = step == 2 and rank == 1  # rank 1's run times out in step 2: rank 0 must learn of it and gather again too
+            fault = step == 2 and rank == world - 1  # the last rank's run times out in step 2: the others must learn of it and gather again too
             if fault:
                 reg.set_option(OPT_FAULT_INJECT, 3000)
             reg.set_export_target(ig.local_row(0).data_ptr(), 1.0)
@@ -104,9 +108,40 @@ def test_world2_real_solvers_on_one_device_gather_and_regather_across_ranks():
         assert regathers[2] == 1, (rank, regathers)       # both ranks gathered again after rank 1's replay
         assert paths[0] in (6, 7), (rank, paths)          # a persistent launch wrote the send row itself
     assert res[0][3] == res[1][3], "the ranks disagree on which steps were re-gathered"
-    assert res[1][5] >= 1                                 # rank 1 did take a run back
+    assert res[1][5] >= 1                                 # rank 1 (the last) did take a run back
     # (two processes share the GPU here: a run of either rank may also expire on its own -- it is then redone bit-identically and
     #  re-gathered, which the per-row comparison above covers; only the injected one is asserted by step)
+
+
+def test_one_rccl_rank_per_visible_device():
+    """The same exchange over RCCL with one rank per GPU, on min(visible devices, 8) ranks -- skipped on a one-GPU box (RCCL refuses
+    two ranks per device), so an 8-GPU node runs this path in the GPU test tier before the scaling bench meets it: every rank a real
+    solver on its own device, export row -> all-gather on the solver's stream -> settle(), the last rank's run made to time out in one
+    step (every rank gathers again), every gathered row on every rank against the CPU checker."""
+    import torch
+    import torch.multiprocessing as mp
+
+    world = min(torch.cuda.device_count(), 8)
+    if world < 2:
+        pytest.skip("one visible device: RCCL wants one device per rank (the two-rank gloo test covers the logic)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "nccl", False)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, ok, state_ok, regathers, paths, recovered, backend in res:
+        assert backend == "nccl"
+        assert ok, f"rank {rank}: a gathered row differs from the CPU checker"
+        assert state_ok, f"rank {rank}: solver state differs from the CPU checker"
+        assert regathers[2] == 1, (rank, regathers)
+        assert paths[0] in (6, 7, 8), (rank, paths)
+    assert all(r[3] == res[0][3] for r in res), "the ranks disagree on which steps were re-gathered"
+    assert res[-1][5] >= 1
 
 
 def test_bench_two_ranks_dry_run_with_backend_override():
