@@ -18,7 +18,9 @@ enum {
                                           graphs small enough to run there, else all eight; 1..8 */
   FLAME_NLTGV2_OPT_FAULT_INJECT = 110, /* test hook: n > 0 = one wave of every persistent run withholds its first record, so the
                                           run times out after n polls and the recovery path (state rolled back, steps redone
-                                          with one launch per step) is exercised; 0 (default) = off */
+                                          with one launch per step) is exercised; 0 (default) = off.  The chain is first replayed in a
+                                          persistent form at reduced residency, where the fault is off; 2^22 + n = the fault hits that
+                                          replay as well, so the chain ends on the one-launch-per-step path */
   FLAME_NLTGV2_OPT_RG_DEPTH = 114,     /* region-per-workgroup form: steps per block = depth of the recomputed ghost ring: 0 (default) =
                                           the library's choice, 1..6 */
   FLAME_NLTGV2_OPT_RG_REGIONS = 115,   /* ... regions the graph is cut into: 0 (default) = one per compute unit, else 1..4096 */

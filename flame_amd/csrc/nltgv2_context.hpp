@@ -187,7 +187,10 @@ struct flame_nltgv2_ctx {
   // a GPU that stays full costs one expired run per 1024).  flame_nltgv2_info::timeouts_recovered counts them.
   uint64_t persist_backoff_topo = ~0ull;
   int persist_backoff_left = 0, persist_timeout_streak = 0;
-  bool replaying = false;  // finish() is redoing an expired chain: one launch per step, whatever the planner would say
+  // finish() is redoing an expired chain: 1 = once more in a persistent form, at reduced residency (at most kCrowdedWavesPerCu waves per
+  // CU, the test hook's fault off) -- an expired wait mostly means that somebody else's kernels held wave slots for a moment, and the
+  // per-step path is 5x slower --, 2 = one launch per step, whatever the planner would say (the second attempt, which cannot expire)
+  int replaying = 0;
   // A persistent run that needs most of the chip's wave slots (a 1080p frame: 25 of the 28 a CU really holds) only starts
   // whole when nothing else keeps slots busy; when such a run expires beside other kernels (the tracker's, the rasteriser's:
   // tools/soak_pipeline.py at 1080p), the next kCrowdedTopologies topologies are planned for at most kCrowdedWavesPerCu waves per
@@ -197,7 +200,9 @@ struct flame_nltgv2_ctx {
   bool static_stale = false;  // pos changed on the device (project_graph): packed alpha/dx/dy need a re-pack
   uint64_t coop_checked_key = 0;  // (topology, form) whose persistent grid the runtime has verified as resident
   int buf_gen = 0;                // which of the two (hq, vstate) copies is current; part of the hipGraph cache key
-  int timeouts_recovered = 0;     // persistent runs that timed out and were redone on the per-step path
+  int replay_attempt = 0;         // finish(): how often the chain being settled has already been taken back (0 outside finish)
+  int replays_per_step = 0;       // ... chains whose persistent replay expired as well and that went to the per-step path
+  int timeouts_recovered = 0;     // persistent runs that timed out and were redone (persistently at reduced residency, then per step)
   int torn_records_detected = 0;  // ... that the record verification (opt_verify) stopped, redone the same way
   int opt_verify = 0;             // 1: persistent kernels re-read every record after its tag matched; 2: + test hook
   // Record placement of the patch-per-wave form (nltgv2_layout.hip): a pool of pages measured once per context, the

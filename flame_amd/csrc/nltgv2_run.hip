@@ -34,8 +34,9 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
   groups->clear();
   if (use_tv_lds) *use_tv_lds = 0;
   if (!ctx->opt_persistent || n < 4 || n > (1 << 24) || !ctx->prop.cooperativeLaunch) return 0;
-  if (ctx->persist_refused_topo == ctx->topo || ctx->replaying) return 0;
-  if (ctx->persist_backoff_topo == ctx->topo && (ctx->persist_backoff_left > 0 || ctx->opt_fault > 0)) {  // (the test hook's fault does not pass)
+  if (ctx->persist_refused_topo == ctx->topo || ctx->replaying == 2) return 0;
+  const bool retry = ctx->replaying == 1;  // the first replay of an expired chain: persistent once more, with room left on every CU
+  if (!retry && ctx->persist_backoff_topo == ctx->topo && (ctx->persist_backoff_left > 0 || ctx->opt_fault > 0)) {  // (the test hook's fault does not pass)
     if (consume && ctx->persist_backoff_left > 0) --ctx->persist_backoff_left;
     return 0;
   }
@@ -58,7 +59,7 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
                    (int)L.wg_rowpack, ctx->f.wg_slab_slots, ctx->f.wg_lcap, ctx->pv_occ);
     ctx->pv_occ_topo = occ_key;
   }
-  const bool crowded = ctx->topo < ctx->crowded_until_topo && ctx->opt_persistent == 1;  // (a form asked for by name is run as asked)
+  const bool crowded = (ctx->topo < ctx->crowded_until_topo && ctx->opt_persistent == 1) || retry;  // (a form asked for by name is run as asked)
   const int wg_cap = (crowded ? std::min(ctx->pv_occ, kCrowdedWavesPerCu) : ctx->pv_occ) * cus;  // patch-per-wave form, in patches
   // The vertex-per-lane rows (D) are built only when that form is actually chosen.
   const bool pv_fits = L.wg_ok && L.wg_rowpack && L.wg_count > 0 && L.wg_count <= wg_cap;  // (the kernel runs row-packed patches)
@@ -495,7 +496,9 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       const bool one_xcd = form == 3 && gr.count <= 2 * cus_per_xcd;
       const int xcds = ctx->opt_xcds > 0 ? ctx->opt_xcds : one_xcd ? 1 : 8;
       const int presleep = ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : kPreSleepTv;  // (the patch form has its own, below)
-      const unsigned spins_arg = ctx->opt_fault > 0 ? (0x80000000u | (unsigned)ctx->opt_fault) : kMaxSpins;
+      // (test hook: a fault of 2^22 + n also hits the persistent replay of the chain, so that the per-step rung below it is exercised)
+      const unsigned spins_arg = (ctx->opt_fault > 0 && (ctx->replaying == 0 || ctx->opt_fault >= (1 << 22)))
+                                     ? (0x80000000u | (unsigned)(ctx->opt_fault & ((1 << 22) - 1))) : kMaxSpins;
       if (form == 3) {
         // pacing: none where a CU holds few patches (a poll costs nothing there and a pause only delays the hand-off); at
         // high residency the polls of ~20 waves per CU saturate the L2s' request ports and the fabric and it is the hand-off
@@ -707,16 +710,25 @@ int finish(flame_nltgv2_ctx* ctx) {
     ctx->parity = run.parity_before;
     ctx->have_prev = run.have_prev_before;
     ctx->fused_valid = true, ctx->canon_valid = false;
-    ctx->persist_timeout_streak = (ctx->persist_backoff_topo == ctx->topo) ? std::min(ctx->persist_timeout_streak + 1, 9) : 1;
-    ctx->persist_backoff_topo = ctx->topo;
-    ctx->persist_backoff_left = 4 << (ctx->persist_timeout_streak - 1);
-    if (!(*ctx->h_err & 4)) {
-      ctx->timeouts_recovered++;
-      if (ctx->last_run_waves_per_cu > kCrowdedWavesPerCu) ctx->crowded_until_topo = ctx->topo + 1 + kCrowdedTopologies;
+    const int attempt = ctx->replay_attempt;  // 0: the chain as enqueued expired; 1: so did its persistent replay
+    if (attempt == 0) {
+      ctx->persist_timeout_streak = (ctx->persist_backoff_topo == ctx->topo) ? std::min(ctx->persist_timeout_streak + 1, 9) : 1;
+      ctx->persist_backoff_topo = ctx->topo;
+      ctx->persist_backoff_left = 4 << (ctx->persist_timeout_streak - 1);
+      if (!(*ctx->h_err & 4)) {
+        ctx->timeouts_recovered++;
+        if (ctx->last_run_waves_per_cu > kCrowdedWavesPerCu) ctx->crowded_until_topo = ctx->topo + 1 + kCrowdedTopologies;
+      }
+    } else {
+      ctx->replays_per_step++;
     }
     HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, kErrBytes, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->abort_flag.p, 0, sizeof(int), ctx->stream));
-    ctx->replaying = true;
+    // The rung between the persistent forms and the one-launch-per-step path: the chain is first redone persistently, planned for at
+    // most kCrowdedWavesPerCu waves per CU (a 1080p frame: the two-half-edges form at 12.6 per CU instead of 25 patches per CU).
+    // A torn record (verification on) goes to the per-step path at once: that is not a question of residency.
+    ctx->replaying = (attempt == 0 && !(*ctx->h_err & 4) && ctx->opt_persistent != 0 && !std::getenv("FLAME_NLTGV2_REPLAY_PER_STEP")) ? 1 : 2;
+    ctx->replay_attempt = attempt + 1;
     int replay_rc = 0;
     // every run is redone with the standing export target it was enqueued with (the caller may have switched the target in the
     // middle of the chain -- the double-buffered rows of a result gather: run k exports to row A, run k + 1 to row B)
@@ -733,9 +745,14 @@ int finish(flame_nltgv2_ctx* ctx) {
       }
       if (replay_rc) break;
     }
-    ctx->replaying = false;
-    if (replay_rc) return replay_rc;
-    return finish(ctx);
+    ctx->replaying = 0;
+    if (replay_rc) {
+      ctx->replay_attempt = 0;
+      return replay_rc;
+    }
+    const int rc2 = finish(ctx);  // (a persistent replay that expired as well comes back here once more, for the per-step path)
+    ctx->replay_attempt = 0;
+    return rc2;
   }
   if (run.active && ctx->last_run_path >= 5) ctx->persist_timeout_streak = 0;  // (a persistent run went through: the next expired one starts over)
   if (*ctx->h_err != 0) {

@@ -497,7 +497,8 @@ def test_persistent_timeout_is_rolled_back_and_redone(env, form):
         reg.run(p, 41)                       # times out inside, recovered
         oracle.run(ref, 41)
         info = reg.info()
-        assert info["timeouts_recovered"] == 1 and info["last_run_path"] in (2, 3)
+        # (taken back, then redone in a persistent form at reduced residency, where the hook's fault is off)
+        assert info["timeouts_recovered"] == 1 and info["last_run_path"] in (5, 6, 7, 8)
         assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="after recovery")
         for _ in range(6):                   # the topology stays on the per-step path while the fault is on (and for a few runs after an
             reg.run(p, 10)                   # expired run in any case: 4, then 8, ... up to 1024 -- a stall that passes is tried again)
@@ -865,9 +866,9 @@ def test_an_expired_run_at_high_residency_makes_the_planner_leave_room(env):
         oracle.run(ref, 20)
         assert reg.info()["last_run_path"] == 7 and reg.info()["last_run_groups"] == 1
         reg.set_option(OPT_FAULT_INJECT, 200)
-        reg.run(p, 21)                       # expires, taken back, redone per step
+        reg.run(p, 21)                       # expires, taken back, redone with room left on every CU: two groups of five frames
         oracle.run(ref, 21)
-        assert reg.info()["timeouts_recovered"] == 1 and reg.info()["last_run_path"] in (2, 3)
+        assert reg.info()["timeouts_recovered"] == 1 and reg.info()["last_run_path"] == 7 and reg.info()["last_run_groups"] == 2, reg.info()
         reg.set_option(OPT_FAULT_INJECT, 0)
         for k in range(2):                   # new topologies (the same graph uploaded again): planned with room to spare
             st = reg.download_state()
@@ -951,3 +952,40 @@ def test_region_form_declines_what_it_cannot_run(env):
         reg.run(flame_amd.Params(), 30)
         assert reg.info()["last_run_path"] != 8
         assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS, what="hub graph")
+
+
+@pytest.mark.parametrize("config,form", [("640x480", 1), ("1920x1080", 1), ("320x240", 7)])
+def test_an_expired_chain_is_first_redone_persistently_then_per_step(env, config, form):
+    """The rung between the persistent forms and the one-launch-per-step path (5x slower): a chain whose wait expired is taken back and
+    redone in a persistent form planned for at most 16 waves per CU (a 1080p frame: the two-half-edges form); only if THAT expires as
+    well (fault 2^22 + n: the hook hits the replay too) do the steps go one launch at a time.  Bit-identical either way."""
+    from flame_amd.regularizer import OPT_FAULT_INJECT, OPT_PERSISTENT
+
+    flame_amd, oracle = env
+    g = synth.make_graph(config, seed=31)
+    ref = synth.copy_graph(g)
+    p = flame_amd.Params()
+    with flame_amd.Regularizer(0) as reg:
+        reg.set_option(OPT_PERSISTENT, form)
+        reg.upload_graph(g)
+        reg.run(p, 20)
+        oracle.run(ref, 20)
+        clean_path = reg.info()["last_run_path"]
+        assert clean_path in (6, 7, 8)
+        reg.set_option(OPT_FAULT_INJECT, 300)
+        reg.run_async(p, 30)
+        reg.run_async(p, 11)
+        reg.sync()                             # the chain expires in its first run, is redone persistently
+        oracle.run(ref, 41)
+        info = reg.info()
+        assert info["timeouts_recovered"] == 1 and info["last_run_path"] in (6, 7, 8), info
+        assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="after the persistent replay")
+        reg.set_option(OPT_FAULT_INJECT, 0)    # (lets the next run be persistent again: the back-off is lifted with the hook)
+        reg.set_option(OPT_FAULT_INJECT, (1 << 22) + 300)
+        reg.run_async(p, 25)
+        reg.run_async(p, 7)
+        reg.sync()                             # expires, its persistent replay expires too, redone one launch per step
+        oracle.run(ref, 32)
+        info = reg.info()
+        assert info["timeouts_recovered"] == 2 and info["last_run_path"] in (2, 3), info
+        assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="after the per-step replay")
