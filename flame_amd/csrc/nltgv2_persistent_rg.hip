@@ -23,6 +23,8 @@
 //
 // The run is transactional like the other persistent forms: reads hq / vstate / bar_in, writes hq_out / vstate_out / bar_out; every
 // wait is bounded and reports through `err` (bit 1: a wait expired; the host rolls back and replays).
+#include <type_traits>
+
 #include "nltgv2_device.hpp"
 #include "nltgv2_regions.hpp"
 
@@ -100,7 +102,7 @@ k_persistent_rg(const RgArgs a, const int4* __restrict__ hrec, const float4* __r
   if (v_local) {
     const float4 bs = bar_in[pv];
     xb = bs.x, wb12 = v2f_t{bs.y, bs.z};
-    lds[t] = bs;
+    lds[t] = make_float4(bs.y, bs.z, bs.x, 0.f);  // (the order the edge lanes want: the w pair first)
   }
   // the slots the V phase of this WAVE runs over: the largest degree of its computed vertices
   int wdeg = v_comp ? (int)((vmeta >> kRgDegShift) & 255u) : 0;
@@ -191,6 +193,10 @@ k_persistent_rg(const RgArgs a, const int4* __restrict__ hrec, const float4* __r
     store_rec_sc1(base + off, o);
     if (dual & 1) *reinterpret_cast<v4i_t*>(base + S + off) = o;
   };
+  __syncthreads();
+  // the first step of EVERY block reads a ring endpoint's bar record from its poll slot: block 0 finds the initial values there
+  if (e_fbs >= 0) lds[o_poll + e_fbs] = *bi_p;
+  if (e_fbd >= 0) lds[o_poll + e_fbd] = *bj_p;
   __syncthreads();
 
   unsigned pr_t0 = 0, pr_ack = 0, pr_load = 0;
@@ -342,17 +348,24 @@ k_persistent_rg(const RgArgs a, const int4* __restrict__ hrec, const float4* __r
     char* const pub_base = xb_base + ((Tpub & 1u) ? par : 0u);
     unsigned pr_e = 0, pr_b1 = 0, pr_v = 0, pr_b2 = 0, pr_s = 0;
     if (PROBE) pr_s = (unsigned)clock64();
-    for (int s = 1; s <= kb; ++s) {
+    // One step of the block.  FIRST / LAST are compile-time: the first step of a block reads a ring endpoint's bar record from its poll
+    // slot, the last one publishes -- a lone wave issues one instruction per ~5 cycles, scalar ones included, so what a step does not
+    // need is not in its code (tools/rg_step_cost.py: the loop around two empty phases cost 416 cycles per step when it decided all
+    // that at run time).
+    auto substep = [&](const int s, auto first_tag, auto last_tag) {
+      constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
       // E phase: the edges of level <= kb + 1 - s (both endpoints exact after sub-step s - 1)
       const int lim = kb + 1 - s;
+#ifdef FLAME_RG_DIAG
+      if (!(dual & 16384))
+#endif
       if (wlevel <= lim) {
         {  // (every lane of the wave: a lane past its level, or without an edge, computes values nobody reads -- its slots belong to
            //  vertices that are not computed in this step either, or are a spare entry of its own -- and is refreshed before it counts again)
-          const bool first = fresh && s == 1;
-          const float4 bi = *(first ? bi_f : bi_p), bj = *(first ? bj_f : bj_p);
-          const v2f_t wbi = {bi.y, bi.z}, wbj = {bj.y, bj.z};
+          const float4 bi = *(FIRST ? bi_f : bi_p), bj = *(FIRST ? bj_f : bj_p);  // a bar record: {w1_bar, w2_bar, x_bar}
+          const v2f_t wbi = {bi.x, bi.y}, wbj = {bj.x, bj.y};
           // dual update, cc:99-110
-          float K1 = alpha * (bi.x - bj.x);
+          float K1 = alpha * (bi.z - bj.z);
           const v2f_t m12 = P12 * wbi;
           K1 -= m12.x;
           K1 -= m12.y;
@@ -378,7 +391,7 @@ k_persistent_rg(const RgArgs a, const int4* __restrict__ hrec, const float4* __r
             *reinterpret_cast<v2f_t*>(cd4) = v23;
             *cd1 = tt;
           }
-          if (s == kb && publishes && pubQ) publish(pub_base, offQ, q1, q23.x, q23.y, Tpub);  // q is final for this block: ahead of the V phase
+          if (LAST && publishes && pubQ) publish(pub_base, offQ, q1, q23.x, q23.y, Tpub);  // q is final for this block: ahead of the V phase
           // NaN/Inf: the reference's FLAME_ASSERT h:174 (home lanes report; they are exact in every step)
           ok = ok && (__builtin_fabsf(q1r) <= 3.402823466e+38f) && (__builtin_fabsf(q23r.x) <= 3.402823466e+38f) &&
                (__builtin_fabsf(q23r.y) <= 3.402823466e+38f);
@@ -392,6 +405,9 @@ k_persistent_rg(const RgArgs a, const int4* __restrict__ hrec, const float4* __r
       rg_barrier();
       if (PROBE) pe1 = (unsigned)clock64();
       // V phase: the vertices of depth <= kb - s
+#ifdef FLAME_RG_DIAG
+      if (!(dual & 32768))
+#endif
       if (wvdepth <= kb - s) {
         {  // (every lane of the wave, as in the E phase: a ring lane past its depth is refreshed before it counts again)
           float X = x;
@@ -424,6 +440,14 @@ k_persistent_rg(const RgArgs a, const int4* __restrict__ hrec, const float4* __r
 #ifdef FLAME_RG_DIAG
           if (dual & 1024) {
             X = X + data, W = W + v2f_t{thr, thr};
+          } else if (dual & 4096) {  // (what an X-only lane would do: the cx chain alone)
+            X = (((((((X + bp[0]) + bp[1]) + bp[2]) + bp[3]) + bp[4]) + bp[5]) + bp[6]) + bp[7];
+          } else if (dual & 8192) {  // (what a W-only lane would do)
+            const float4 c0 = cp[0], c1_ = cp[1], c2 = cp[2], c3 = cp[3], c4_ = cp[4], c5 = cp[5], c6 = cp[6], c7 = cp[7];
+            W = (W + v2f_t{c0.x, c0.y}) + v2f_t{c0.z, c0.w}, W = (W + v2f_t{c1_.x, c1_.y}) + v2f_t{c1_.z, c1_.w};
+            W = (W + v2f_t{c2.x, c2.y}) + v2f_t{c2.z, c2.w}, W = (W + v2f_t{c3.x, c3.y}) + v2f_t{c3.z, c3.w};
+            W = (W + v2f_t{c4_.x, c4_.y}) + v2f_t{c4_.z, c4_.w}, W = (W + v2f_t{c5.x, c5.y}) + v2f_t{c5.z, c5.w};
+            W = (W + v2f_t{c6.x, c6.y}) + v2f_t{c6.z, c6.w}, W = (W + v2f_t{c7.x, c7.y}) + v2f_t{c7.z, c7.w};
           } else
 #endif
           if (MAXT <= 512) {
@@ -455,9 +479,9 @@ k_persistent_rg(const RgArgs a, const int4* __restrict__ hrec, const float4* __r
           nb = (nb < p.x_min) ? p.x_min : nb;
           nb = (nb > p.x_max) ? p.x_max : nb;
           const v2f_t wbn = W + p.theta * (W - w12);
-          *bar_w = make_float4(nb, wbn.x, wbn.y, 0.f);
-          if (s == kb && publishes) {  // ahead of the barrier: the records are on their way while the workgroup gathers
-            if (pubB) publish(pub_base, offB, nb, wbn.x, wbn.y, Tpub);
+          *bar_w = make_float4(wbn.x, wbn.y, nb, 0.f);
+          if (LAST && publishes) {  // ahead of the barrier: the records are on their way while the workgroup gathers
+            if (pubB) publish(pub_base, offB, wbn.x, wbn.y, nb, Tpub);
             if (pubA) publish(pub_base, offA, xn, W.x, W.y, Tpub);
           }
           x_prev = x, w_prev = w12;  // step()'s prev copy, cc:37-42
@@ -473,6 +497,17 @@ k_persistent_rg(const RgArgs a, const int4* __restrict__ hrec, const float4* __r
       if (PROBE) {
         const unsigned pe3 = (unsigned)clock64();
         pr_e += pe0 - pr_s, pr_b1 += pe1 - pe0, pr_v += pe2 - pe1, pr_b2 += pe3 - pe2, pr_s = pe3;
+      }
+    };
+    {
+      const std::true_type yes;
+      const std::false_type no;
+      if (kb == 1) {
+        substep(1, yes, yes);
+      } else {
+        substep(1, yes, no);
+        for (int s = 2; s < kb; ++s) substep(s, no, no);
+        substep(kb, no, yes);
       }
     }
     left -= kb;

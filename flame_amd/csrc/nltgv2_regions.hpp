@@ -88,6 +88,7 @@ struct Rcb {
   std::vector<int32_t>* idx;
   std::vector<int32_t>* region_of;
   std::vector<int32_t>* first;  // [n_regions + 1] ranges of idx
+  const float* weight = nullptr;  // per vertex: a cut leaves `parts / 2` of the parts' share of the WEIGHT on its lower side (nullptr: of the count)
   int32_t next = 0;
   void cut(int32_t lo, int32_t hi, int32_t parts) {
     if (parts <= 1) {
@@ -107,13 +108,25 @@ struct Rcb {
     }
     const int axis = (mx[1] - mn[1] > mx[0] - mn[0]) ? 1 : 0;
     const int32_t pl = parts / 2;
-    const int32_t mid = lo + static_cast<int32_t>((static_cast<int64_t>(hi - lo) * pl) / parts);
+    int32_t mid = lo + static_cast<int32_t>((static_cast<int64_t>(hi - lo) * pl) / parts);
     int32_t* b = idx->data();
     const float* p = pos;
-    std::nth_element(b + lo, b + mid, b + hi, [p, axis](int32_t u, int32_t v) {
+    auto less = [p, axis](int32_t u, int32_t v) {
       const float cu = p[2 * u + axis], cv = p[2 * v + axis];
       return cu < cv || (cu == cv && u < v);
-    });
+    };
+    if (weight == nullptr) {
+      std::nth_element(b + lo, b + mid, b + hi, less);
+    } else {
+      std::sort(b + lo, b + hi, less);
+      double total = 0.0, acc = 0.0;
+      for (int32_t i = lo; i < hi; ++i) total += weight[b[i]];
+      const double want = total * pl / parts;
+      mid = lo;
+      while (mid < hi && acc + 0.5 * weight[b[mid]] < want) acc += weight[b[mid++]];
+      // (every part keeps at least one vertex)
+      mid = std::max(lo + pl, std::min(mid, hi - (parts - pl)));
+    }
     cut(lo, mid, pl);
     cut(mid, hi, parts - pl);
   }
@@ -127,7 +140,8 @@ inline int32_t rg_region_count(int32_t V, int32_t target) {
 }
 
 // Returns FLAME_NLTGV2_OK; R->ok says whether the form can run the graph (degree, size of a region's workgroup).
-inline int build_regions(const flame_nltgv2_graph* g, const PackedLayout& L, int32_t n_regions_target, int32_t depth, RegionLayout* R) {
+inline int build_regions(const flame_nltgv2_graph* g, const PackedLayout& L, int32_t n_regions_target, int32_t depth, RegionLayout* R,
+                         int balance_rounds = 3) {
   *R = RegionLayout{};
   const int32_t V = L.V, E = L.E;
   if (!g || V <= 0 || depth < 1 || depth > kRgMaxDepth || n_regions_target < 1) return FLAME_NLTGV2_OK;
@@ -147,6 +161,46 @@ inline int build_regions(const flame_nltgv2_graph* g, const PackedLayout& L, int
     rg_detail::Rcb rcb{g->pos, &idx, &R->region_of, &first};
     rcb.cut(0, V, NR);
     first[static_cast<size_t>(NR)] = V;
+  }
+  // ---- balance what a region COSTS, not what it owns: the lock-step network runs at the pace of its slowest workgroup, and a region
+  // on the hull of the triangulation (long edges, vertices of 10-19 edges) drags a ring in that is half again as large as an inner
+  // region's.  Three rounds of: the cost of every region (lanes of its ring: edges + 2 x computed vertices) -> the weight of its
+  // vertices -> the bisection again, by weight.
+  if (NR > 1 && balance_rounds > 0) {
+    std::vector<float> wgt(static_cast<size_t>(V), 1.0f);
+    std::vector<int32_t> stamp(static_cast<size_t>(V), -1), dep(static_cast<size_t>(V), 0), estamp2(static_cast<size_t>(E), -1), fr, nx;
+    for (int round = 0; round < balance_rounds; ++round) {
+      std::vector<double> cost(static_cast<size_t>(NR), 0.0);
+      double sum = 0.0;
+      for (int32_t r = 0; r < NR; ++r) {
+        fr.assign(idx.begin() + first[static_cast<size_t>(r)], idx.begin() + first[static_cast<size_t>(r) + 1]);
+        for (int32_t v : fr) stamp[static_cast<size_t>(v)] = r + NR * round, dep[static_cast<size_t>(v)] = 0;
+        int64_t n_vc = 0, n_e = 0;
+        for (int32_t d = 0; d < k; ++d) {  // the computed vertices: depth 0 .. k - 1
+          n_vc += static_cast<int64_t>(fr.size());
+          nx.clear();
+          for (int32_t v : fr)
+            for (int32_t h = L.row_ptr[v]; h < L.row_ptr[v + 1]; ++h) {
+              const int32_t e = static_cast<int32_t>(L.half[static_cast<size_t>(h)] & ~kRoleBit);
+              if (estamp2[static_cast<size_t>(e)] != r + NR * round) estamp2[static_cast<size_t>(e)] = r + NR * round, ++n_e;
+              const int32_t u = L.half_nbr[static_cast<size_t>(h)];
+              if (stamp[static_cast<size_t>(u)] != r + NR * round) stamp[static_cast<size_t>(u)] = r + NR * round, nx.push_back(u);
+            }
+          fr.swap(nx);
+        }
+        cost[static_cast<size_t>(r)] = static_cast<double>(n_e) + 2.0 * static_cast<double>(n_vc);
+        sum += cost[static_cast<size_t>(r)];
+      }
+      const double mean = sum / NR;
+      for (int32_t r = 0; r < NR; ++r) {
+        const float f = static_cast<float>(std::min(2.0, std::max(0.5, cost[static_cast<size_t>(r)] / mean)));
+        for (int32_t i = first[static_cast<size_t>(r)]; i < first[static_cast<size_t>(r) + 1]; ++i) wgt[static_cast<size_t>(idx[static_cast<size_t>(i)])] *= f;
+      }
+      for (int32_t v = 0; v < V; ++v) idx[static_cast<size_t>(v)] = v;
+      rg_detail::Rcb rcb{g->pos, &idx, &R->region_of, &first, wgt.data()};
+      rcb.cut(0, V, NR);
+      first[static_cast<size_t>(NR)] = V;
+    }
   }
   // ---- rank of every edge in its endpoints' ascending edge lists (the order of the reference's scatter, cc:120-142) ---
   std::vector<uint8_t> rank_src(static_cast<size_t>(E)), rank_dst(static_cast<size_t>(E));
@@ -172,6 +226,12 @@ inline int build_regions(const flame_nltgv2_graph* g, const PackedLayout& L, int
   std::vector<Fetch> fetch;
   std::vector<int32_t> fb_of;  // poll slot of a local vertex's bar record
   R->info.assign(static_cast<size_t>(NR) * kRgInfoWords, 0);
+  {  // (the lane tables grow region by region: room for a typical layout up front, so that they are not copied at every region)
+    const size_t guess = static_cast<size_t>(NR) * 64 + static_cast<size_t>(8 * k) * (static_cast<size_t>(V) + E);
+    for (std::vector<int32_t>* a : {&R->v_pv, &R->v_fa, &R->e_slot_src, &R->e_slot_dst, &R->e_id, &R->e_fq, &R->e_fbs, &R->e_fbd}) a->reserve(guess);
+    for (std::vector<uint32_t>* a : {&R->v_meta, &R->e_li, &R->e_meta}) a->reserve(guess);
+    R->f_src.reserve(2 * guess), R->f_prod.reserve(2 * guess);
+  }
   int64_t T = 0, FT = 0;
   bool fits = true;
   for (int32_t r = 0; r < NR; ++r) {
