@@ -558,6 +558,7 @@ int flame_nltgv2_destroy(flame_nltgv2_ctx* ctx) {
   if (!ctx) return FLAME_NLTGV2_OK;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  place_pool_release(ctx);
   drop_graphs(ctx);
   for (DevBuf* b : ctx->all)
     if (b->p) (void)hipFree(b->p);

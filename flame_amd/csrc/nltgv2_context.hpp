@@ -214,6 +214,7 @@ struct flame_nltgv2_ctx {
   char* place_base = nullptr;     // the pool, 4 KB aligned inside place_pool
   float place_best_us = 0.0f, place_mean_us = 0.0f, place_worst_us = 0.0f;  // one-way hand-off by page choice, mean over XCD pairs
   DevBuf place_pool, place_rank, place_fill, place_rec_off, place_patch, place_meas;
+  std::vector<uint16_t> place_rank_host;  // the ranking of place_pool's pages (travels with the pool: nltgv2_run.hip, place_pool_release)
   // The persistent run(s) in flight, until finish() has seen the error word: what is needed to take them back.  One
   // run is taken back by swapping the buffer roles (it wrote the other copies).  When more work is enqueued before the
   // first run has been checked (run_async back to back: the frame loop, bench.py), the state the chain started from is
@@ -414,7 +415,8 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n);
 int finish(flame_nltgv2_ctx* ctx);                            // reads the error word; rolls a failed persistent run back and redoes it
 int snapshot_chain_start(flame_nltgv2_ctx* ctx);
 int place_records(flame_nltgv2_ctx* ctx, int per_xcd);        // record placement, once per topology (k_place_assign)
-int place_calibrate(flame_nltgv2_ctx* ctx);                   // ... and the page ranking, once per device and process
+int place_calibrate(flame_nltgv2_ctx* ctx);                   // ... and the page ranking of the context's pool (measured, or taken over with a pool)
+void place_pool_release(flame_nltgv2_ctx* ctx);               // the pool and its ranking to the next context of the device
 
 }  // namespace host
 }  // namespace flame_hip

@@ -280,44 +280,68 @@ int enqueue_photo_sweep(flame_nltgv2_ctx* ctx, bool packed_current) {
 // ranked per pair.  ~3 ms, at the first run that can use it.  Anything unexpected (a pair missing because two blocks
 // shared an XCD, a wait that expired because the GPU is busy with someone else's work) switches placement off for this
 // context: the records then keep their linear places.
-// The page ranking is a property of the device, not of a context: the first context of a process that calibrates a device keeps the
-// ranking for the others (a fresh context's first run: 4.6 -> 0.6 ms; eight contexts of one device: 32 ms less).
+// The page ranking belongs to the POOL it was measured on (which page is close to which pair of XCDs is a property of the pages'
+// physical addresses: a ranking applied to another allocation is a random page choice -- 1.35 instead of 1.16 us per iteration at
+// 1280x720).  Pools therefore outlive their contexts: a context that ends hands its pool, with its ranking, to a per-device list, the
+// next context of the device takes it from there (a fresh context's first run: 4.6 -> 0.6 ms; eight contexts alive at once measure
+// eight pools, once).  A pool is cleared when it changes hands.
 namespace {
-struct PlaceCache {
-  bool valid = false;
+struct PlacePool {
+  int device = -1;
+  void* mem = nullptr;  // (2 * kPlacePages + 1) pages
   std::vector<uint16_t> rank;
   float best = 0.f, mean = 0.f, worst = 0.f;
 };
 std::mutex g_place_mu;
-PlaceCache g_place_cache[64];
+std::vector<PlacePool> g_place_free;
 }  // namespace
+
+// flame_nltgv2_destroy: the context's pool goes back to the list (its stream has been synchronised: nobody writes it any more)
+void place_pool_release(flame_nltgv2_ctx* ctx) {
+  if (!ctx->place_pool.p || ctx->place_state != 1 || ctx->place_rank_host.empty()) return;  // (an unranked pool is freed with the context)
+  PlacePool e;
+  e.device = ctx->device, e.mem = ctx->place_pool.p, e.rank.swap(ctx->place_rank_host);
+  e.best = ctx->place_best_us, e.mean = ctx->place_mean_us, e.worst = ctx->place_worst_us;
+  ctx->device_bytes -= ctx->place_pool.cap;
+  ctx->place_pool = DevBuf{};
+  ctx->place_base = nullptr, ctx->place_state = 0;
+  std::lock_guard<std::mutex> lock(g_place_mu);
+  g_place_free.push_back(std::move(e));
+}
 
 int place_calibrate(flame_nltgv2_ctx* ctx) {
   ctx->place_state = -1;
   constexpr int P = kPlacePages, kIters = 12;
-  if (ctx->device >= 0 && ctx->device < 64 && !std::getenv("FLAME_NLTGV2_RECALIBRATE")) {
-    std::vector<uint16_t> rank;
+  const size_t pool_bytes = (size_t)2 * P * 4096;
+  if (!ctx->place_pool.p && !std::getenv("FLAME_NLTGV2_RECALIBRATE")) {
+    PlacePool e;
     {
       std::lock_guard<std::mutex> lock(g_place_mu);
-      const PlaceCache& c = g_place_cache[ctx->device];
-      if (c.valid) rank = c.rank, ctx->place_best_us = c.best, ctx->place_mean_us = c.mean, ctx->place_worst_us = c.worst;
+      for (size_t i = 0; i < g_place_free.size(); ++i)
+        if (g_place_free[i].device == ctx->device) {
+          e = std::move(g_place_free[i]);
+          g_place_free.erase(g_place_free.begin() + (long)i);
+          break;
+        }
     }
-    if (!rank.empty()) {
-      const size_t pool_bytes = (size_t)2 * P * 4096;
-      int rc = ensure(ctx, ctx->place_pool, pool_bytes + 4096);
-      if (!rc) rc = ensure(ctx, ctx->place_rank, sizeof(uint16_t) * 2 * 64 * P);
+    if (e.mem) {
+      ctx->place_pool.p = e.mem, ctx->place_pool.cap = pool_bytes + 4096;
+      ctx->device_bytes += ctx->place_pool.cap;
+      ctx->place_best_us = e.best, ctx->place_mean_us = e.mean, ctx->place_worst_us = e.worst;
+      ctx->place_rank_host.swap(e.rank);
+      int rc = ensure(ctx, ctx->place_rank, sizeof(uint16_t) * 2 * 64 * P);
       if (!rc) rc = ensure(ctx, ctx->place_fill, sizeof(int) * (2 * P + 16 + 128));
       if (rc) return rc;
       ctx->place_base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ctx->place_pool.p) + 4095) & ~uintptr_t(4095));
       HIPCHK(ctx, hipMemsetAsync(ctx->place_base, 0, pool_bytes, ctx->stream));
       HIPCHK(ctx, hipMemsetAsync(ctx->place_fill.p, 0, sizeof(int) * (2 * P + 16 + 128), ctx->stream));
-      HIPCHK(ctx, hipMemcpyAsync(ctx->place_rank.p, rank.data(), sizeof(uint16_t) * rank.size(), hipMemcpyHostToDevice, ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (`rank` is pageable and leaves scope)
+      HIPCHK(ctx, hipMemcpyAsync(ctx->place_rank.p, ctx->place_rank_host.data(), sizeof(uint16_t) * ctx->place_rank_host.size(), hipMemcpyHostToDevice,
+                                 ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
       ctx->place_state = 1;
       return 0;
     }
   }
-  const size_t pool_bytes = (size_t)2 * P * 4096;
   int rc = ensure(ctx, ctx->place_pool, pool_bytes + 4096);
   if (!rc) rc = ensure(ctx, ctx->place_meas, sizeof(unsigned) * 64 * 2 * P + sizeof(int) * 64 + sizeof(int));
   if (!rc) rc = ensure(ctx, ctx->place_rank, sizeof(uint16_t) * 2 * 64 * P);
@@ -385,11 +409,7 @@ int place_calibrate(flame_nltgv2_ctx* ctx) {
   HIPCHK(ctx, hipMemcpyAsync(ctx->place_rank.p, rank.data(), sizeof(uint16_t) * rank.size(), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (`rank` is pageable and leaves scope)
   ctx->place_state = 1;
-  if (ctx->device >= 0 && ctx->device < 64) {
-    std::lock_guard<std::mutex> lock(g_place_mu);
-    PlaceCache& c = g_place_cache[ctx->device];
-    c.rank = rank, c.best = ctx->place_best_us, c.mean = ctx->place_mean_us, c.worst = ctx->place_worst_us, c.valid = true;
-  }
+  ctx->place_rank_host.swap(rank);  // (kept: the pool and its ranking go to the next context of this device, place_pool_release)
   return 0;
 }
 
