@@ -698,6 +698,10 @@ int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info) {
   info->timeouts_recovered = ctx->timeouts_recovered;
   info->torn_records_detected = ctx->torn_records_detected;
   info->last_sync_path = ctx->last_sync_path;
+  info->last_run_waves_per_cu = ctx->last_run_waves_per_cu;
+  info->regions = (ctx->rg_built && ctx->rg_usable) ? ctx->RG.n_regions : 0;
+  info->region_depth = (ctx->rg_built && ctx->rg_usable) ? ctx->RG.depth : 0;
+  info->replays_per_step = ctx->replays_per_step;
   return FLAME_NLTGV2_OK;
 }
 

@@ -84,6 +84,7 @@ class _Info(C.Structure):
         ("device_name", C.c_char * 64), ("gcn_arch", C.c_char * 32), ("last_run_path", C.c_int32), ("he_waves", C.c_int32), ("tv_waves", C.c_int32),
         ("tv_wave_capacity", C.c_int32), ("last_run_groups", C.c_int32), ("timeouts_recovered", C.c_int32),
         ("patches", C.c_int32), ("torn_records_detected", C.c_int32), ("last_sync_path", C.c_int32),
+        ("last_run_waves_per_cu", C.c_int32), ("regions", C.c_int32), ("region_depth", C.c_int32), ("replays_per_step", C.c_int32),
     ]
 
 

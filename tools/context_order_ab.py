@@ -1,5 +1,7 @@
+"""tools/context_order_ab.py -- three contexts per size, one after the other in one process: the second and third take the first one's record-placement
+pool (and its page ranking) over; with FLAME_NLTGV2_LAZY_CALIBRATION=1 the ranking is measured in the first run instead of in create()."""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import flame_amd
 from flame_amd import synth
