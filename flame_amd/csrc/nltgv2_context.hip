@@ -524,6 +524,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
     // loading in the first upload_graph, 4 ms of record-placement calibration in the first run): the kernels' code objects are
     // loaded here, and the page ranking of this device is measured here, once per process (later contexts take it from the cache).
     static std::once_flag warm;
+    if (!std::getenv("FLAME_NLTGV2_NO_WARM"))
     std::call_once(warm, [] {
       warm_module_kernels(), warm_module_persistent(), warm_module_persistent_tv(), warm_module_persistent_pv2(), warm_module_persistent_rg();
       warm_module_layout(), warm_module_topo();

@@ -292,8 +292,9 @@ struct PlacePool {
   std::vector<uint16_t> rank;
   float best = 0.f, mean = 0.f, worst = 0.f;
 };
-std::mutex g_place_mu;
-std::vector<PlacePool> g_place_free;
+// (never destroyed: a context may still be released while the process exits, after the static destructors have run)
+std::mutex& g_place_mu = *new std::mutex;
+std::vector<PlacePool>& g_place_free = *new std::vector<PlacePool>;
 }  // namespace
 
 // flame_nltgv2_destroy: the context's pool goes back to the list (its stream has been synchronised: nobody writes it any more)

@@ -55,3 +55,4 @@ print(json.dumps({"case": case, "run_path": path, "V": info["V"], "E": info["E"]
                   "launches_per_run": launches * groups, "us_per_run": round(ms * 1e3, 2), "us_per_iter": round(ms * 1e3 / iters, 3),
                   "algorithmic_bytes_per_iter": info["algorithmic_bytes_per_iter"],
                   "algorithmic_GBps": round(info["algorithmic_bytes_per_iter"] * iters / (ms * 1e-3) / 1e9, 1)}))
+r.close()
