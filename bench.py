@@ -544,7 +544,7 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
         out["batched"][label]["algorithmic_bytes_per_launch"] = int(bi["algorithmic_bytes_per_iter"] * iters / groups)
         out["batched"][label]["valu"] = valu_roofline(key, ms * 1e-3 / groups)
         oc = measured_counters(key).get("on_chip")
-        if oc:  # rocprofv3 SQ counters of the same command (profiles/r04_counters.json): which on-chip resource the resident kernel keeps busy
+        if oc:  # rocprofv3 SQ counters of the same command (profiles/r05_counters.json): which on-chip resource the resident kernel keeps busy
             out["batched"][label]["on_chip"] = dict(oc, source="profiles/traffic.json", note="fractions of wave-cycles with an instruction of the class in flight "
                                                     "(LDS / VALU / VMEM / scalar), LDS bank-conflict share, LDS pipe busy fraction of the chip")
             v = out["batched"][label]["valu"]

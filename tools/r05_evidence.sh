@@ -1,0 +1,61 @@
+#!/bin/bash
+# tools/r05_evidence.sh -- the round's measurements outside rocprofv3, on the GPU box (gpurun): every file lands in gpurun_out/r05/ and is
+# copied under profiles/ by hand.  PARTS="rg bench loops cold misc" selects.
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+O=gpurun_out/r05
+mkdir -p $O
+want() { [ -z "${PARTS:-}" ] || [[ " $PARTS " == *" $1 "* ]]; }
+run() {  # run FILE command...: the command line, then its output
+  local f=$1; shift
+  echo "== $*" >> $O/$f
+  timeout 300 "$@" >> $O/$f 2>> $O/$f.err
+  echo >> $O/$f
+}
+if want rg; then
+  rm -f $O/rg_forms.txt $O/rg_step_cost.txt
+  run rg_forms.txt python tools/rg_try.py 640x480,1280x720,1920x1080 1,2,3,4 0
+  run rg_step_cost.txt python tools/rg_step_cost.py
+fi
+if want bench; then
+  python bench.py > $O/bench_1gpu.json 2> $O/bench_1gpu.err
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29521 bench.py --gpus 1 2> $O/bench_torchrun.err | grep '"metric"' > $O/bench_torchrun_1rank.json
+  python bench.py --persistent 7 --no-extras --no-cpu-baseline > $O/bench_rg.json 2> $O/bench_rg.err
+fi
+if want loops; then
+  for s in 640x480 1280x720 1920x1080; do
+    rm -f $O/frame_loop_$s.txt
+    run frame_loop_$s.txt python tools/frame_loop.py --size $s --frames 12 --cpu
+    run frame_loop_$s.txt python tools/frame_loop.py --size $s --frames 20 --pipelined
+  done
+  rm -f $O/cpp_frame_loop.txt
+  run cpp_frame_loop.txt python -m pytest tests/test_cpp_facade.py -q -m gpu -k frame_loop_end_to_end -s
+fi
+if want cold; then
+  rm -f $O/cold_start.txt $O/replay_rung.txt
+  for s in 640x480 1920x1080; do run cold_start.txt python tools/cold_start.py $s; done
+  for s in 640x480 1920x1080; do run replay_rung.txt python tools/replay_cost.py $s; done
+fi
+if want misc; then
+  rm -f $O/gather_tax.txt $O/delaunay.txt
+  run gather_tax.txt python tools/export_tax.py
+  run gather_tax.txt bash tools/gather_tax.sh
+  FLAME_DELAUNAY_PROFILE=1 python - >> $O/delaunay.txt 2>&1 <<'PY'
+import os, time, numpy as np, sys
+sys.path.insert(0, os.getcwd())
+from flame_amd import synth
+from flame_amd.regularizer import delaunay
+for size in ("640x480", "1920x1080"):
+    pos = np.ascontiguousarray(synth.make_graph(size, seed=1234)["pos"], dtype=np.float32)
+    for strips in ("", "1", "8", "16", "32"):
+        if strips:
+            os.environ["FLAME_DELAUNAY_STRIPS"] = strips
+        else:
+            os.environ.pop("FLAME_DELAUNAY_STRIPS", None)
+        ts = []
+        for _ in range(12):
+            t = time.perf_counter(); delaunay(pos); ts.append((time.perf_counter() - t) * 1e3)
+        print(f"{size} {len(pos)} points, strips {strips or 'default'}: median {np.median(ts):.3f} min {min(ts):.3f} ms", flush=True)
+PY
+fi
+ls -la $O
