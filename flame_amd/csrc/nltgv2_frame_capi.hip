@@ -83,10 +83,12 @@ int flame_nltgv2_interpolate_mesh_begin(flame_nltgv2_ctx* ctx, const int32_t* tr
   HIPCHK(ctx, hipStreamWaitEvent(rs, ctx->ev_canon, 0));  // ... and may go on as soon as the caller enqueues the next run
   LAUNCHCHK(ctx, launch_interpolate_mesh(T, (const int32_t*)ctx->r_tris.p, ctx->c.pos, ctx->c.x, graph_scale, nullptr, d_tv,
                                          (unsigned long long*)ctx->r_keys.p, (float*)ctx->r_img.p, (int*)ctx->r_cov.p, rows, cols, rs));
-  HIPCHK(ctx, hipMemcpyAsync(ctx->h_img, ctx->r_img.p, sizeof(float) * n, hipMemcpyDeviceToHost, rs));
-  HIPCHK(ctx, hipMemcpyAsync(ctx->h_img + n, ctx->r_cov.p, sizeof(int), hipMemcpyDeviceToHost, rs));
+  // the rasteriser's kernels are the last readers of the canonical arrays (and the writers of the resident map): whoever rewrites those
+  // waits for THEM, not for the map's way out to the host (0.05 ms at 640x480, 0.3 ms at 1920x1080 -- time a commit would stand still for)
   HIPCHK(ctx, hipEventRecord(ctx->ev_raster_done, rs));
   ctx->raster_inflight = true;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_img, ctx->r_img.p, sizeof(float) * n, hipMemcpyDeviceToHost, rs));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_img + n, ctx->r_cov.p, sizeof(int), hipMemcpyDeviceToHost, rs));
   ctx->map_rows = rows, ctx->map_cols = cols;
   ctx->img_pending_rows = rows, ctx->img_pending_cols = cols;  // (what _end describes: a synchronous interpolate_mesh in between changes map_rows)
   return FLAME_NLTGV2_OK;

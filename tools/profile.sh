@@ -14,6 +14,7 @@ prof() {  # prof TAG "command": kernel stats + FETCH + WRITE + SQ counters, each
   local tag=$1; shift
   want $tag || return 0
   timeout 150 rocprofv3 --kernel-trace --stats -d $OUT/kt_$tag -o kt --output-format csv -- "$@" > $OUT/kt_$tag.log 2>&1
+  if [ -n "${KT_ONLY:-}" ]; then tail -1 $OUT/kt_$tag.log | cut -c1-400; return 0; fi   # KT_ONLY=1: the kernel statistics alone (the counters are kept)
   timeout 150 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch_$tag -o f --output-format csv -- "$@" > $OUT/fetch_$tag.log 2>&1
   timeout 150 rocprofv3 --pmc WRITE_SIZE -d $OUT/write_$tag -o w --output-format csv -- "$@" > $OUT/write_$tag.log 2>&1
   timeout 150 rocprofv3 --pmc SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/sq_$tag -o s --output-format csv -- "$@" > $OUT/sq_$tag.log 2>&1
@@ -22,6 +23,7 @@ prof() {  # prof TAG "command": kernel stats + FETCH + WRITE + SQ counters, each
 prof_onchip() {  # the on-chip side of a resident (batched) kernel: LDS and instruction-class activity, two more counter passes
   local tag=$1; shift
   want $tag || return 0
+  [ -z "${KT_ONLY:-}" ] || return 0
   timeout 150 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES -d $OUT/lds_$tag -o l --output-format csv -- "$@" > $OUT/lds_$tag.log 2>&1
   timeout 150 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VMEM_RD SQ_INSTS_SALU -d $OUT/act_$tag -o a --output-format csv -- "$@" > $OUT/act_$tag.log 2>&1
 }
@@ -43,5 +45,5 @@ prof_onchip batch30 python tools/profile_case.py batch:30:200
 prof_onchip batch64 python tools/profile_case.py batch:64:100
 want stereo || exit 0
 timeout 150 rocprofv3 --kernel-trace --stats -d $OUT/kt_stereo -o kt --output-format csv -- python tools/stereo_bench.py > $OUT/kt_stereo.log 2>&1
-timeout 150 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_INSTS_LDS -d $OUT/sq_stereo -o s --output-format csv -- python tools/stereo_bench.py > $OUT/sq_stereo.log 2>&1
+[ -z "${KT_ONLY:-}" ] && timeout 150 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_INSTS_LDS -d $OUT/sq_stereo -o s --output-format csv -- python tools/stereo_bench.py > $OUT/sq_stereo.log 2>&1
 tail -3 $OUT/kt_stereo.log
