@@ -274,7 +274,7 @@ int launch_topo_back(const TopoBuild& t, hipStream_t s);
 
 // one per translation unit with kernels: loads its code object (flame_nltgv2_create of the first context of a process)
 void warm_module_kernels();
-void warm_module_persistent();
+void warm_module_persistent(hipStream_t stream);
 void warm_module_persistent_tv();
 void warm_module_persistent_pv2();
 void warm_module_persistent_rg();

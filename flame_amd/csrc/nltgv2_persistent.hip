@@ -743,17 +743,17 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
 namespace {
 __global__ void k_warm_cooperative() {}
 }  // namespace
-void warm_module_persistent() {
+void warm_module_persistent(hipStream_t stream) {
   hipFuncAttributes fa;
   if (hipFuncGetAttributes(&fa, (const void*)k_persistent_pv<false, false>) != hipSuccess) (void)hipGetLastError();
   // ... and the runtime's one-time set-up of cooperative launches and of the occupancy query (6 ms in the first run of a process,
   // tools/cold_start.py): one empty cooperative grid -- a kernel of its own, so that a profile's statistics of the solver kernels hold
-  // solver launches only
+  // solver launches only; on the context's own (high-priority) stream, see flame_nltgv2_create
   FusedArgs a;
   a.wg_rowpack = 1, a.wg_lcap = 16;
   (void)pv_patches_per_cu(a, false);
   void* no_args[] = {nullptr};
-  if (hipLaunchCooperativeKernel((const void*)k_warm_cooperative, dim3(8), dim3(64), no_args, 0, nullptr) != hipSuccess) (void)hipGetLastError();
+  if (hipLaunchCooperativeKernel((const void*)k_warm_cooperative, dim3(8), dim3(64), no_args, 0, stream) != hipSuccess) (void)hipGetLastError();
 }
 
 }  // namespace flame_hip

@@ -15,9 +15,10 @@
 // free-running loop had applied when the call took the device (read under the loop's lock: exact), so the CPU side can run exactly
 // those iterations between the same edits and compare every output bit for bit: the updated features, the keep mask of projectGraph,
 // the dense map and its coverage, the graph's state at the end of every frame.  It also prints what share of the wall time the solver
-// thread spent iterating (SolverLoop::busyFraction).
+// thread spent iterating (SolverLoop::busyFraction).  With `lean` the window of the test is closed -- no read-back of the graph's state,
+// the dense map is not copied while the device is held -- and the printed share is that of the loop as FLaME would drive it.
 //
-// usage: frame_loop_test IN OUT [iters_per_round]     exit code 0 = ran, 77 = no usable HIP device
+// usage: frame_loop_test IN OUT [iters_per_round [lean]]     exit code 0 = ran, 77 = no usable HIP device
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -80,6 +81,7 @@ int main(int argc, char** argv) {
   Writer out{std::fopen(argv[2], "wb")};
   if (!in.f || !out.f) return 2;
   const int iters_per_round = argc > 3 ? std::atoi(argv[3]) : 200;
+  const bool lean = argc > 4 && std::atoi(argv[4]) != 0;
   const int32_t W = in.one<int32_t>(), H = in.one<int32_t>(), pad = in.one<int32_t>();
   const int32_t n_feats = in.one<int32_t>(), n_initial = in.one<int32_t>(), n_new = in.one<int32_t>(), host_work_us = in.one<int32_t>();
   Mat3 K, Kinv;
@@ -181,11 +183,13 @@ int main(int argc, char** argv) {
       std::vector<float> dense((size_t)W * H);
       loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t) {
         coverage = d.interpolateMeshEnd(&map);
-        std::memcpy(dense.data(), map, sizeof(float) * dense.size());
+        if (!lean) std::memcpy(dense.data(), map, sizeof(float) * dense.size());
       });
+      if (lean) std::memcpy(dense.data(), map, sizeof(float) * dense.size());  // (the map stays valid until the next interpolateMeshBegin)
       out.one(it_raster), out.one(coverage), out.many(dense);
       // ---- the graph's state at the end of the frame (a read-back the reference does not need: the test's window on the solver) ------
       flame_hip::FlatArrays a;
+      if (lean) continue;
       loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t it) {
         it_state = it;
         int32_t Vn = 0, En = 0;
@@ -208,8 +212,8 @@ int main(int argc, char** argv) {
       std::printf("FAIL: the solver thread stopped: %s\n", err.c_str());
       return 1;
     }
-    std::printf("frame loop: %d frames in %.2f ms, %llu solver iterations beside them (%d per round), solver busy %.1f %% of the wall time since the first graph, idle %.1f %%\n",
-                n_new, wall_ms, (unsigned long long)total, iters_per_round, 100.0 * busy, 100.0 * (1.0 - busy));
+    std::printf("frame loop%s: %d frames in %.2f ms, %llu solver iterations beside them (%d per round), solver busy %.1f %% of the wall time since the first graph, idle %.1f %%\n",
+                lean ? " (lean: no state read-back)" : "", n_new, wall_ms, (unsigned long long)total, iters_per_round, 100.0 * busy, 100.0 * (1.0 - busy));
   } catch (const std::exception& e) {
     std::printf("FAIL: %s\n", e.what());
     return 1;
