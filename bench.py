@@ -26,10 +26,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# Before the HIP runtime starts: every stream of this process gets a hardware queue of its own.  The runtime multiplexes HIP streams
-# onto GPU_MAX_HW_QUEUES (default 4) in-order hardware queues; two streams that land on one queue execute in submission order --
-# when RCCL's stream shared a queue with the solver's, every result gather ran between two runs instead of beside the next one
-# (0.35 instead of 0.21 ms per step under torch.distributed.run; tools/gather_chain.py).  A runtime setting, like NCCL's own.
+# Before the HIP runtime starts: more in-order hardware queues than the default 4, so that the streams of this process (solver, the
+# context's builder and rasteriser streams, RCCL's, torch's) do not share one.  Round 4 needed this for the result gather to overlap the
+# solve (0.35 instead of 0.21 ms per step without it); round 5 found the cause -- the gather's waits were issued on torch's DEFAULT stream
+# instead of the solver's (IdepthGather(stream=...) now orders them itself) -- and the step loop is the same with 8, 4 or 1 queue
+# (tools/overlap_probe.py, profiles/r05_gather_overlap.txt).  Kept as the roomier setting; nothing depends on it any more.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -52,8 +53,9 @@ def parse():
 
 def measure(reg, params, iters, steps, warmup, sync, barrier, stream, before_step=None, after_step=None):
     """warmup, then EXACTLY `steps` steps bracketed by barrier+synchronize.  The steps are enqueued back to back
-    (no host round trip between them; run_async), each launch bracketed by a HIP event pair recorded on the
-    solver's stream.  Returns (wall seconds, device ms summed over the steps' event regions)."""
+    (no host round trip between them; run_async); ONE HIP event pair on the solver's stream brackets the `steps` launches
+    (a pair around every launch put two more packets between two kernels of the solver's in-order queue: +10 us per step,
+    tools/overlap_probe.py -- 5 % of what it measured).  Returns (wall seconds, device ms between the two events)."""
     import torch
 
     for _ in range(warmup):
@@ -64,21 +66,21 @@ def measure(reg, params, iters, steps, warmup, sync, barrier, stream, before_ste
             after_step()
     barrier()
     sync()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    for e0, e1 in ev:
+    e0.record(stream)
+    for _ in range(steps):
         if before_step:
             before_step()
-        e0.record(stream)
         reg.run_async(params, iters)
-        e1.record(stream)
         if after_step:
             after_step()
+    e1.record(stream)
     reg.sync()  # also checks the solver's error word
     sync()
     barrier()
     t1 = time.perf_counter()
-    return t1 - t0, sum(e0.elapsed_time(e1) for e0, e1 in ev)
+    return t1 - t0, e0.elapsed_time(e1)
 
 
 def main():
@@ -149,9 +151,8 @@ def main():
         # all_gather per step; no collective on the solve path
         from flame_amd.frames import IdepthGather
 
-        ig = IdepthGather(dist, [g["V"]], world, torch.device("cuda", local_rank))
-        with torch.cuda.stream(solver_stream):
-            ig.check_overlap(reg, params)  # (warns if the collective's stream shares the solver's hardware queue)
+        ig = IdepthGather(dist, [g["V"]], world, torch.device("cuda", local_rank), stream=solver_stream)
+        ig.check_overlap(reg, params)  # (warns if the collective does not run beside the solver)
         reg.upload_graph(g)
 
 
@@ -159,11 +160,10 @@ def main():
             reg.set_export_target(ig.local_row(0).data_ptr(), 1.0)
 
         def after_step():
-            with torch.cuda.stream(solver_stream):
-                # overlaps the next step's solve; completed before the buffer is reused.  (The gather reads the row of a run
-                # nobody has checked yet: a consumer of the gathered block calls ig.settle([reg]) first, which re-gathers if the
-                # run had to be taken back and redone -- done once below, after the timed region.)
-                ig.gather(async_op=True, regs=[reg])
+            # overlaps the next step's solve; completed before the buffer is reused.  (The gather reads the row of a run
+            # nobody has checked yet: a consumer of the gathered block calls ig.settle([reg]) first, which re-gathers if the
+            # run had to be taken back and redone -- done once below, after the timed region.)
+            ig.gather(async_op=True, regs=[reg])
 
     wall, ev_ms = measure(reg, params, a.iters, a.steps, a.warmup, sync, barrier, solver_stream, before_step, after_step)
     gather_us = None
@@ -193,8 +193,8 @@ def main():
     if rank == 0:
         B_iter = info["algorithmic_bytes_per_iter"]
         # Dominant kernel.  Persistent paths: ONE launch per step covers all `iters` primal-dual iterations, so algorithmic
-        # bytes per launch = iters * (64V + 40E) and the launch duration is the HIP-event time of the step (events
-        # recorded on the solver's stream right around the launch).  Per-step path: one k_fused_step launch per
+        # bytes per launch = iters * (64V + 40E) and the average launch duration is the time between two HIP events on the
+        # solver's stream around the K back-to-back launches, divided by K (it includes the gap between two launches).  Per-step path: one k_fused_step launch per
         # iteration; the event time divided by the launches then includes the ~3.5 us dependent-launch gaps.
         kernel = {"persistent-pv": "k_persistent_pv", "persistent-pv2": "k_persistent_pv2", "persistent-tv": "k_persistent_tv", "persistent-rg": "k_persistent_rg"}.get(run_path, "k_fused_step")
         persistent = run_path.startswith("persistent")

@@ -34,8 +34,14 @@ class IdepthGather:
     everything -- at ~34 KB per 640x480 frame this is a pure-latency collective, one call per step.
     """
 
-    def __init__(self, dist, sizes_local: Sequence[int], n_frames: int, device):
+    def __init__(self, dist, sizes_local: Sequence[int], n_frames: int, device, stream=None):
+        """`stream`: the torch stream the local solvers run on (what Regularizer.set_stream was given).  The waits of local_row() and the
+        collective of gather() are then ordered against THAT stream whatever torch's current stream is when they are called.  Without
+        it they are ordered against torch's current stream -- the caller's job to make that the solver's: a wait that lands on the
+        default stream orders nothing the solver does, and its barrier packets occupy one more of the process's hardware queues
+        (4 by default: a step of 0.28-0.35 instead of 0.20 ms at 640x480, tools/overlap_probe.py)."""
         self.dist = dist
+        self.stream = stream
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
         self.n_frames = n_frames
@@ -69,11 +75,17 @@ class IdepthGather:
         self.local = self._local[0]
         self.gathered = self._gathered[0]
 
+    def _on_stream(self):
+        import contextlib
+
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
     def local_row(self, i: int) -> torch.Tensor:
         """Device row the solver of local frame i writes its x*scale into (first V entries).  Valid until
-        the next gather(); waits for the collective that last read this buffer."""
+        the next gather(); the solver's stream waits for the collective that last read this buffer."""
         if self._work[self._cur] is not None:
-            self._work[self._cur].wait()
+            with self._on_stream():
+                self._work[self._cur].wait()
             self._work[self._cur] = None
         return self._local[self._cur][i]
 
@@ -93,10 +105,12 @@ class IdepthGather:
         self._replays_at_gather = self._replays(regs) if regs is not None else None
         send = self._local[k]
         if self._staged:  # device rows -> pinned host rows, ordered behind the solver on the current stream, then a host collective
-            self._h_local[k].copy_(self._local[k], non_blocking=True)
-            torch.cuda.current_stream(self._local[k].device).synchronize()
+            with self._on_stream():
+                self._h_local[k].copy_(self._local[k], non_blocking=True)
+                torch.cuda.current_stream(self._local[k].device).synchronize()
             send = self._h_local[k]
-        w = self.dist.all_gather_into_tensor(self._gathered[k], send, async_op=async_op)
+        with self._on_stream():  # (the collective starts behind what the solver's stream holds now: the run that exports the rows)
+            w = self.dist.all_gather_into_tensor(self._gathered[k], send, async_op=async_op)
         self._work[k] = w if async_op else None
         self.gathered = self._gathered[k]
         self._last = k
@@ -104,14 +118,16 @@ class IdepthGather:
         self.local = self._local[self._cur]
 
     def check_overlap(self, reg, params, iters: int = 200, steps: int = 24) -> dict:
-        """Does the collective run BESIDE the solver, as the pipelined frame loop assumes?  The HIP runtime multiplexes a process's
-        streams onto GPU_MAX_HW_QUEUES (default 4) in-order hardware queues; when the collective's stream shares the solver's queue
-        every gather sits between two runs instead of beside the next one (0.35 instead of 0.21 ms per step, docs/LAB_NOTES.md round 4)
-        -- a property of the host process that a library cannot set.  This measures it on the streams the frame loop really uses:
-        `steps` frames of run_async alone, then the same with the export target set and an asynchronous gather behind every run; a step
-        that grows by more than a third means the queues collide: a RuntimeWarning says so (remedy: start the process with
-        GPU_MAX_HW_QUEUES=8) and the figures are kept in `self.overlap`.  Collective: every rank calls it (from the solver's stream
-        context).  A staged (host) backend has nothing to measure."""
+        """Does the collective run BESIDE the solver, as the pipelined frame loop assumes?  Measured on the streams the frame loop really
+        uses: `steps` frames of run_async alone, then the same with the export target set and an asynchronous gather behind every run; a
+        step that grows by more than a third means the gather waits for the runs around it: a RuntimeWarning says so and the figures are
+        kept in `self.overlap`.  Two ways to get there, both met: (1) the gather's waits (local_row) issued on a stream that is not the
+        solver's -- torch's default stream, when neither `stream=` was given nor the caller is inside the solver's stream context: the
+        waits order nothing and their packets take a hardware queue of their own (rounds 4-5: 0.28-0.35 instead of 0.20 ms per step with
+        the runtime's default of 4 queues); (2) the collective's stream sharing the solver's in-order hardware queue (the runtime
+        multiplexes a process's streams onto GPU_MAX_HW_QUEUES queues per priority level; a high-priority solver stream, as the context's
+        own is, has a pool to itself).  Collective: every rank calls it (from the solver's stream context, or with the gather's `stream`
+        set).  A staged (host) backend has nothing to measure."""
         import time
 
         if self._staged or self.n_frames == 0:
@@ -143,14 +159,16 @@ class IdepthGather:
     @staticmethod
     def overlap_verdict(step_ms_alone: float, step_ms_with_gather: float) -> dict:
         """The figures of check_overlap and what they mean: a step that grows by more than a third with the gather behind every run is
-        a gather that waits for the runs around it (round 4 measured 0.35 against 0.21 ms when RCCL's stream shared the solver's
-        hardware queue, 0.21 against 0.19 when it did not) -- reported as a RuntimeWarning with the remedy."""
+        a gather that waits for the runs around it (measured: 0.35 against 0.21 ms when its waits sat on torch's default stream with
+        four hardware queues, 0.20 against 0.185 when they were ordered on the solver's stream) -- reported as a RuntimeWarning with the
+        remedies."""
         import warnings
 
         ok = bool(step_ms_with_gather < 1.35 * step_ms_alone)
         if not ok:
             warnings.warn("flame_amd.frames: the result gather does not overlap the solver (%.3f ms per step with the gather behind every run, %.3f without): "
-                          "the collective's stream shares the solver's hardware queue; start the process with GPU_MAX_HW_QUEUES=8"
+                          "give IdepthGather the solver's stream (stream=...), and if it has it, the collective's stream shares the solver's hardware queue: "
+                          "use a high-priority solver stream or start the process with GPU_MAX_HW_QUEUES=8"
                           % (step_ms_with_gather, step_ms_alone), RuntimeWarning)
         return {"measured": True, "overlaps": ok, "step_ms_alone": round(step_ms_alone, 4), "step_ms_with_gather": round(step_ms_with_gather, 4),
                 "gather_tax": round(step_ms_with_gather / step_ms_alone - 1.0, 4)}
@@ -180,7 +198,8 @@ class IdepthGather:
     def wait(self) -> None:
         for k in (0, 1):
             if self._work[k] is not None:
-                self._work[k].wait()
+                with self._on_stream():
+                    self._work[k].wait()
                 self._work[k] = None
 
     def frame(self, frame_id: int) -> torch.Tensor:

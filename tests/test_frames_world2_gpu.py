@@ -60,7 +60,7 @@ def _worker(rank, world, port, q, backend="gloo", one_device=True):
         stream = torch.cuda.Stream(device=dev, priority=-1)
         reg.set_stream(stream.cuda_stream)
         reg.upload_graph(g)
-        ig = IdepthGather(dist, [g["V"]], world, dev)
+        ig = IdepthGather(dist, [g["V"]], world, dev, stream=stream)
         p = flame_amd.Params()
         ok, regathers, paths = True, [], []
         for step in range(4):

@@ -27,7 +27,7 @@ else:
     stream = torch.cuda.Stream(device=dev, priority=-1)
 reg.set_stream(stream.cuda_stream)
 reg.upload_graph(g)
-ig = IdepthGather(dist, [g["V"]], 1, dev)
+ig = IdepthGather(dist, [g["V"]], 1, dev, stream=None if os.environ.get("GATHER_NO_STREAM") else stream)
 p = flame_amd.Params()
 rows = torch.zeros((2, g["V"]), dtype=torch.float32, device=dev)
 def loop(mode, steps=200):
