@@ -37,8 +37,11 @@ if want cold; then
   for s in 640x480 1920x1080; do run replay_rung.txt python tools/replay_cost.py $s; done
 fi
 if want misc; then
-  rm -f $O/gather_tax.txt $O/delaunay.txt
+  rm -f $O/gather_tax.txt $O/delaunay.txt $O/gather_overlap.txt
   run gather_tax.txt python tools/export_tax.py
+  run gather_tax.txt env FREE_CUS_PER_XCD=1 python tools/export_tax.py   # (the solver's stream leaves one / two compute units per XCD to the collective)
+  run gather_tax.txt env FREE_CUS_PER_XCD=2 python tools/export_tax.py
+  for q in 4 8 1; do run gather_overlap.txt env GPU_MAX_HW_QUEUES=$q python tools/overlap_probe.py; done
   run gather_tax.txt bash tools/gather_tax.sh
   FLAME_DELAUNAY_PROFILE=1 python - >> $O/delaunay.txt 2>&1 <<'PY'
 import os, time, numpy as np, sys
