@@ -43,6 +43,7 @@ SolverParams to_sp(const flame_nltgv2_params* p) {
 int enter(flame_nltgv2_ctx* ctx) {
   if (!ctx) return FLAME_NLTGV2_ERR_INVALID_ARG;
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  ++ctx->call_seq;
   return 0;
 }
 
@@ -519,6 +520,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
   ok = ok && hipEventCreateWithFlags(&ctx->ev_canon, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&ctx->ev_raster_done, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&ctx->ev_topo_ready, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&ctx->ev_run_done, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->h_err, kErrBytes, hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->h_cost, 2 * sizeof(float), hipHostMallocDefault) == hipSuccess;
   if (!ok) {
@@ -580,6 +582,7 @@ int flame_nltgv2_destroy(flame_nltgv2_ctx* ctx) {
   if (ctx->raster_stream) (void)hipStreamSynchronize(ctx->raster_stream), (void)hipStreamDestroy(ctx->raster_stream);
   if (ctx->ev_canon) (void)hipEventDestroy(ctx->ev_canon);
   if (ctx->ev_raster_done) (void)hipEventDestroy(ctx->ev_raster_done);
+  if (ctx->ev_run_done) (void)hipEventDestroy(ctx->ev_run_done);
   if (ctx->h_img) (void)hipHostFree(ctx->h_img);
   if (ctx->h_dims) (void)hipHostFree(ctx->h_dims);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

@@ -323,9 +323,18 @@ struct flame_nltgv2_ctx {
   // packed
   DevBuf slice_row, perm, pdeg, rec_nbr, rec_edge, edge_src_slot, hrec, hq, vstate, vaux, bar0, bar1, vprev;
   DevBuf cost_terms;          // addends of smoothnessCost / dataCost
-  DevBuf run_tail;            // RunTail of the persistent kernels (standing export / photometric targets)
-  RunTail tail_sent{};        // what run_tail currently holds
-  bool tail_valid = false;
+  // RunTail of the persistent kernels (standing export / photometric targets): kTailSlots copies on the device, a launch takes the one
+  // that holds what it needs -- a target alternating between two rows (the double-buffered gather) costs no copy per step
+  static constexpr int kTailSlots = 4;
+  DevBuf run_tail;
+  RunTail tail_sent[kTailSlots]{};
+  bool tail_valid[kTailSlots] = {false, false, false, false};
+  int tail_next = 0;          // the slot the next unseen RunTail overwrites
+  // flame_nltgv2_stream_wait_run: the last plain persistent launch of a run carries this event as its own completion signal
+  // (hipExtLaunchKernel's stop event: no operation of its own on the solver's in-order queue)
+  hipEvent_t ev_run_done = nullptr;
+  bool run_event_bound = false;  // ev_run_done stands for the last enqueued run ...
+  uint64_t call_seq = 0, run_event_seq = 0;  // ... as long as no other call into the context followed it (enter() counts the calls)
   std::vector<float> h_terms;
   DevBuf hq_alt, vstate_alt;  // the other copies of hq / vstate: a persistent run writes there, success swaps the roles
   DevBuf xbuf, abort_flag, tv_slot, tv_vid, tv_meta, tv_wave, wg2_slot, wg2_vid, wg2_meta, wg2_nbr, wg2_fetch, wg2_info, wg2_vfirst, wg2_rmax;

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace flame_hip {
@@ -65,6 +66,7 @@ struct CanonArgs {
 
 // Packed SELL-64 layout of the fused sweep (device pointers).
 struct FusedArgs {
+  hipEvent_t stop_event = nullptr;  // a plain (not cooperative) persistent launch carries it as its completion signal (nltgv2_run.hip)
   int n_slices = 0;
   int64_t n_slots = 0;  // (rows + kRowPad) * 64
   int32_t* slice_row = nullptr;

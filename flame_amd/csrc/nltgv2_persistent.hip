@@ -727,7 +727,7 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
     const void* fv = probe ? (const void*)k_persistent_pv<true, true>
                            : vr ? (const void*)k_persistent_pv<false, true> : (const void*)k_persistent_pv<false, false>;
     if (cooperative) return (int)hipLaunchCooperativeKernel(fv, gv, bv, vargs, ldsv, stream);
-    return (int)hipLaunchKernel(fv, gv, bv, vargs, ldsv, stream);
+    return (int)hipExtLaunchKernel(fv, gv, bv, vargs, ldsv, stream, nullptr, a.stop_event, 0);
   }
   unsigned lds_bytes = 0u;
   const void* fn = persistent_tv_kernel(tv_static_in_lds != 0, waves_per_block, &lds_bytes);
@@ -735,7 +735,7 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
   // resident (hipErrorCooperativeLaunchTooLarge otherwise).  The same grid is then launched plainly
   // (identical residency, ~15 us less launch overhead per call).
   if (cooperative) return (int)hipLaunchCooperativeKernel(fn, grid, block, args, lds_bytes, stream);
-  return (int)hipLaunchKernel(fn, grid, block, args, lds_bytes, stream);
+  return (int)hipExtLaunchKernel(fn, grid, block, args, lds_bytes, stream, nullptr, a.stop_event, 0);
 }
 
 // Loads this translation unit's code object (the runtime does that at the first use of one of its kernels: several milliseconds that

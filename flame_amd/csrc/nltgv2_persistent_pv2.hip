@@ -504,7 +504,7 @@ int launch_persistent_pv2(const FusedArgs& a, const Pv2Args& w, const SolverPara
                    &vprev, &xbuf, &rec_bytes, &dual, &tag0, &n_iters, &max_spins, &poll_gap, &pp, &err, &abort_flag, &perm, &tail};
   const void* fn = (dual >> 1) != 0 ? (const void*)k_persistent_pv2<true> : (const void*)k_persistent_pv2<false>;
   if (cooperative) return (int)hipLaunchCooperativeKernel(fn, gv, bv, vargs, ldsv, stream);
-  return (int)hipLaunchKernel(fn, gv, bv, vargs, ldsv, stream);
+  return (int)hipExtLaunchKernel(fn, gv, bv, vargs, ldsv, stream, nullptr, a.stop_event, 0);
 }
 
 // Loads this translation unit's code object (the runtime does that at the first use of one of its kernels: several milliseconds that

@@ -600,7 +600,7 @@ int launch_persistent_rg(const FusedArgs& f, const RgArgs& a, const SolverParams
     }
   }
   if (cooperative) return (int)hipLaunchCooperativeKernel(fn, grid, block, args, a.lds_bytes, stream);
-  return (int)hipLaunchKernel(fn, grid, block, args, a.lds_bytes, stream);
+  return (int)hipExtLaunchKernel(fn, grid, block, args, a.lds_bytes, stream, nullptr, f.stop_event, 0);
 }
 
 // Loads this translation unit's code object (the runtime does that at the first use of one of its kernels: several milliseconds that

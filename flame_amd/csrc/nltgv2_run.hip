@@ -483,7 +483,8 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
     const uint64_t key = ctx->topo * 1024 + (uint64_t)form * 64 + (uint64_t)tv_lds * 32 + (ctx->opt_verify != 0 ? 16 : 0) + (ctx->opt_probe != 0 ? 8 : 0) +
                          (ctx->opt_dual == 2 ? 4 : ctx->opt_dual == 1 ? 2 : 0) + (ctx->opt_xcds > 0 ? 1 : 0) +
                          (form == 5 ? ((uint64_t)ctx->rg_depth_built << 40) + ((uint64_t)ctx->rg_regions_built << 44) : 0);
-    {  // standing outputs: (re)send the small block the kernels read in their epilogue when it changed
+    const RunTail* tail_dev = nullptr;
+    {  // standing outputs: the small block the kernels read in their epilogue, (re)sent when no slot holds it
       RunTail want;
       std::memset(static_cast<void*>(&want), 0, sizeof want);
       want.export_out = ctx->export_ptr, want.export_scale = ctx->export_scale;
@@ -495,17 +496,28 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
         HIPCHK(ctx, hipMemsetAsync(ctx->progress.p, 0, 2 * sizeof(unsigned) * (size_t)ctx->L.wg_count, ctx->stream));
         want.progress = (unsigned*)ctx->progress.p;
       }
-      rc = ensure(ctx, ctx->run_tail, sizeof(RunTail));
+      constexpr size_t kTailStride = (sizeof(RunTail) + 255) / 256 * 256;
+      rc = ensure(ctx, ctx->run_tail, kTailStride * flame_nltgv2_ctx::kTailSlots);
       if (rc) return rc;
-      if (!ctx->tail_valid || std::memcmp(&want, &ctx->tail_sent, sizeof(RunTail)) != 0) {
+      int slot = -1;
+      for (int i = 0; i < flame_nltgv2_ctx::kTailSlots && slot < 0; ++i)
+        if (ctx->tail_valid[i] && std::memcmp(&want, &ctx->tail_sent[i], sizeof(RunTail)) == 0) slot = i;
+      if (slot < 0) {  // (ordered on the solver's stream behind every launch that still reads the slot)
+        slot = ctx->tail_next, ctx->tail_next = (ctx->tail_next + 1) % flame_nltgv2_ctx::kTailSlots;
         // pageable source: the runtime stages it during the call, so `want` may go out of scope
-        HIPCHK(ctx, hipMemcpyAsync(ctx->run_tail.p, &want, sizeof(RunTail), hipMemcpyHostToDevice, ctx->stream));
-        ctx->tail_sent = want;
-        ctx->tail_valid = true;
+        HIPCHK(ctx, hipMemcpyAsync((char*)ctx->run_tail.p + kTailStride * (size_t)slot, &want, sizeof(RunTail), hipMemcpyHostToDevice, ctx->stream));
+        ctx->tail_sent[slot] = want;
+        ctx->tail_valid[slot] = true;
       }
+      tail_dev = (const RunTail*)((const char*)ctx->run_tail.p + kTailStride * (size_t)slot);
     }
     int e = 0;
+    ctx->run_event_bound = false;
     for (const WaveGroup& gr : groups) {
+      // the run's last launch carries ev_run_done as its own completion signal (flame_nltgv2_stream_wait_run); a cooperative launch
+      // (the first of a topology) cannot: the wait then records the event behind it
+      const bool carries = &gr == &groups.back() && ctx->coop_checked_key == key && ctx->ev_run_done != nullptr;
+      ctx->f.stop_event = carries ? ctx->ev_run_done : nullptr;
       const int pw = gr.count <= 4 * ctx->prop.multiProcessorCount ? 1 : 4;  // waves per workgroup
       // same-XCD exchange through L2: with the waves laid out along the Morton curve it wins at every size
       // (measured per step: 640x480 -16 %, 1280x720 -23 %, 1080p -18 %, 7-frame batch -20 %, 15 frames -19 %)
@@ -570,7 +582,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
         }
         e = launch_persistent_rg(ctx->f, ctx->rg_args, to_sp(p), ctx->parity, tag0, n, spins_arg, (dual & 1) | (std::getenv("FLAME_RG_VARIANT") ? std::atoi(std::getenv("FLAME_RG_VARIANT")) << 8 : 0) |
                                      ((ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : kRgPreSleep) << 16) | ((ctx->opt_poll_gap > 0 ? (ctx->opt_poll_gap - 1) & 15 : kRgPollGap) << 24),
-                                 (const RunTail*)ctx->run_tail.p, probe,
+                                 tail_dev, probe,
                                  ctx->coop_checked_key != key, ctx->stream);
         if (e != 0) break;
         continue;
@@ -580,14 +592,17 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
         const int gap = ctx->opt_poll_gap > 0 ? ctx->opt_poll_gap - 1 : dense ? (3 | ((kPv2DenseGap - 1) << 4)) : kPvPollGap;
         const int poll_gap = gap | ((ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : dense ? kPv2DensePreSleep : kPvPreSleep) << 8);
         e = launch_persistent_pv2(ctx->f, ctx->pv2_args, to_sp(p), gr.begin, gr.count, ctx->parity, tag0, n, spins_arg, poll_gap, dual,
-                                  (const RunTail*)ctx->run_tail.p, ctx->coop_checked_key != key, ctx->stream);
+                                  tail_dev, ctx->coop_checked_key != key, ctx->stream);
         if (e != 0) break;
         continue;
       }
       e = launch_persistent_run(ctx->f, to_sp(p), form, gr.begin, gr.count, ctx->parity, tag0, n, pw, spins_arg, presleep, dual,
-                                tv_lds, xcds, (const RunTail*)ctx->run_tail.p, ctx->coop_checked_key != key, ctx->stream);
+                                tv_lds, xcds, tail_dev, ctx->coop_checked_key != key, ctx->stream);
       if (e != 0) break;
     }
+    ctx->run_event_bound = e == 0 && ctx->f.stop_event != nullptr;
+    ctx->run_event_seq = ctx->call_seq;
+    ctx->f.stop_event = nullptr;
     ctx->tag_next = tag0 + (uint32_t)n;
     if (e == 0) {
       // The kernels wrote (will write) hq / vstate / bar into the other copies: make those current.  finish() takes
@@ -815,6 +830,18 @@ int flame_nltgv2_run_async(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, 
   if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
   if (!params_ok(p) || n_iters < 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
   return enqueue_run(ctx, p, n_iters);
+}
+
+int flame_nltgv2_stream_wait_run(flame_nltgv2_ctx* ctx, void* hip_stream) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_stream_wait_run");
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!hip_stream || (hipStream_t)hip_stream == ctx->stream) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  // the run enqueued by the call right before this one carries the event itself; anything else is recorded now
+  if (!(ctx->run_event_bound && ctx->call_seq == ctx->run_event_seq + 1)) HIPCHK(ctx, hipEventRecord(ctx->ev_run_done, ctx->stream));
+  ctx->run_event_bound = false;
+  HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)hip_stream, ctx->ev_run_done, 0));
+  return 0;
 }
 
 int flame_nltgv2_sync(flame_nltgv2_ctx* ctx) {

@@ -42,6 +42,7 @@ class IdepthGather:
         (4 by default: a step of 0.28-0.35 instead of 0.20 ms at 640x480, tools/overlap_probe.py)."""
         self.dist = dist
         self.stream = stream
+        self._side = None  # (set below: the stream the collective is issued from when the solvers hand their runs over themselves)
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
         self.n_frames = n_frames
@@ -71,7 +72,16 @@ class IdepthGather:
         self._gathered = [torch.empty(shape_g, dtype=torch.float32, device=cdev) for _ in range(2)]
         self._h_local = [torch.zeros(shape_l, dtype=torch.float32).pin_memory() for _ in range(2)] if self._staged else None
         self._work = [None, None]
+        self._done = [None, None]  # side-stream mode: the event behind the collective that used buffer k
         self._cur = 0
+        # Side-stream mode (round 5): with the solvers' stream known and a device backend, gather(regs=...) issues the collective from a
+        # stream of its own that waits for the solvers' runs through Regularizer.stream_wait_run -- the run's launch carries that event --
+        # and the rows are given back to the solvers by a HOST wait for the collective two steps back.  The solver's in-order queue
+        # then holds its launches only: the event torch records for the collective and the wait before a row is reused were two
+        # operations per step between two solver launches, 10 us of a 185 us step.
+        if stream is not None and not self._staged and torch.device(device).type == "cuda":
+            self._side = torch.cuda.Stream(device=device)
+            self._done_ev = [torch.cuda.Event(), torch.cuda.Event()]
         self.local = self._local[0]
         self.gathered = self._gathered[0]
 
@@ -83,6 +93,9 @@ class IdepthGather:
     def local_row(self, i: int) -> torch.Tensor:
         """Device row the solver of local frame i writes its x*scale into (first V entries).  Valid until
         the next gather(); the solver's stream waits for the collective that last read this buffer."""
+        if self._done[self._cur] is not None:  # (the host waits: the row is free before the next run is even enqueued)
+            self._done[self._cur].synchronize()
+            self._done[self._cur] = None
         if self._work[self._cur] is not None:
             with self._on_stream():
                 self._work[self._cur].wait()
@@ -109,9 +122,22 @@ class IdepthGather:
                 self._h_local[k].copy_(self._local[k], non_blocking=True)
                 torch.cuda.current_stream(self._local[k].device).synchronize()
             send = self._h_local[k]
-        with self._on_stream():  # (the collective starts behind what the solver's stream holds now: the run that exports the rows)
-            w = self.dist.all_gather_into_tensor(self._gathered[k], send, async_op=async_op)
-        self._work[k] = w if async_op else None
+        if self._side is not None and regs is not None and not self._staged:
+            for r in regs:  # the side stream waits for every solver's run (at no cost to the solvers' streams)
+                r.stream_wait_run(self._side.cuda_stream)
+            with torch.cuda.stream(self._side):
+                w = self.dist.all_gather_into_tensor(self._gathered[k], send, async_op=True)
+                w.wait()  # (the side stream waits for the collective's own stream ...)
+                self._done_ev[k].record(self._side)  # (... and says when it is over)
+            self._done[k] = self._done_ev[k]
+            self._work[k] = None
+            if not async_op:
+                self._done[k].synchronize()
+                self._done[k] = None
+        else:
+            with self._on_stream():  # (the collective starts behind what the solver's stream holds now: the run that exports the rows)
+                w = self.dist.all_gather_into_tensor(self._gathered[k], send, async_op=async_op)
+            self._work[k] = w if async_op else None
         self.gathered = self._gathered[k]
         self._last = k
         self._cur = 1 - k
@@ -197,6 +223,9 @@ class IdepthGather:
 
     def wait(self) -> None:
         for k in (0, 1):
+            if self._done[k] is not None:
+                self._done[k].synchronize()
+                self._done[k] = None
             if self._work[k] is not None:
                 with self._on_stream():
                     self._work[k].wait()

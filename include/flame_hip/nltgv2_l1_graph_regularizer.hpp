@@ -308,6 +308,9 @@ class DeviceGraph {
     check(flame_nltgv2_run_async(ctx_, &c, n_iters), "run_async");
   }
   void sync() { check(flame_nltgv2_sync(ctx_), "sync"); }
+  // Another stream of the caller waits for the runs enqueued so far (a consumer of the export row: a collective, a copy); right behind
+  // runAsync() it costs the solver's stream nothing -- the launch carries the event.
+  void streamWaitRun(void* other_hip_stream) { check(flame_nltgv2_stream_wait_run(ctx_, other_hip_stream), "stream_wait_run"); }
   // Asynchronous runs that sync() had to take back and redo (an expired neighbour wait or a torn record: the state is
   // right again when sync() returns, but anything that consumed the export row BEFORE sync() -- a gather enqueued right
   // behind runAsync() -- read the previous frame's values).  A caller compares this before and after its sync().

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FLAME_NLTGV2_ABI_VERSION 5 /* 5: flame_nltgv2_info grew (last_run_waves_per_cu, regions, region_depth, replays_per_step); FLAME_NLTGV2_OPT_PERSISTENT = 7 */
+#define FLAME_NLTGV2_ABI_VERSION 5 /* 5: flame_nltgv2_info grew (last_run_waves_per_cu, regions, region_depth, replays_per_step); FLAME_NLTGV2_OPT_PERSISTENT = 7; flame_nltgv2_stream_wait_run */
 
 typedef struct flame_nltgv2_ctx flame_nltgv2_ctx;
 
@@ -223,6 +223,12 @@ int flame_nltgv2_export_idepth_device_async(flame_nltgv2_ctx* ctx, void* dst_dev
  * scale * x[v] there (V floats, original vertex order) as part of the same launch -- the persistent kernels write
  * it in their epilogue, so a per-step result gather needs no extra kernel between two runs. */
 int flame_nltgv2_set_export_target(flame_nltgv2_ctx* ctx, void* dst_device, float scale);
+/* Makes another stream of the caller (`hip_stream`, a hipStream_t; not the context's own) wait for everything enqueued on the context's
+ * stream so far -- the consumer side of the standing export target: a collective on `hip_stream` then reads the finished row.  No
+ * host wait.  Called right behind run_async() it costs the solver's stream nothing: the run's launch carries the event as its own
+ * completion signal, where an event recorded by the caller is one more operation between two solver launches on an in-order queue
+ * (5 us each at 640x480).  FLAME_NLTGV2_ERR_INVALID_ARG for a null stream or the context's own. */
+int flame_nltgv2_stream_wait_run(flame_nltgv2_ctx* ctx, void* hip_stream);
 
 /* Mesh -> dense inverse-depth map, the step right after the solver each frame:
  * utils::interpolateMesh (utils/image_utils.cc:373-396) over utils::DrawShadedTriangleBarycentric

@@ -657,6 +657,50 @@ def test_standing_export_target(env, form):
         assert float(buf.max()) == -7.0
 
 
+@pytest.mark.parametrize("form", [0, 1, 3, 4, 7])
+def test_another_stream_waits_for_the_run_through_the_launch_own_event(env, form):
+    """flame_nltgv2_stream_wait_run: a consumer stream of the caller's is ordered behind the runs enqueued so far -- with the event the
+    run's own launch carries (called right behind run_async), or with one recorded on the spot (the first launch of a topology is
+    cooperative; another call came in between; the per-step path).  The consumer copies the export rows of alternating targets (more
+    than the context's four epilogue-argument slots) and must always see the finished row; the solver's stream is never waited for
+    by the host in between."""
+    import torch
+
+    flame_amd, oracle = env
+    g = synth.make_graph("320x240", seed=33)
+    ref = synth.copy_graph(g)
+    p = flame_amd.Params()
+    n_rows = 6
+    rows = torch.full((n_rows, g["V"]), -5.0, dtype=torch.float32, device="cuda")
+    seen = torch.zeros((2 * n_rows, g["V"]), dtype=torch.float32, device="cuda")
+    solver, side = torch.cuda.Stream(priority=-1), torch.cuda.Stream()
+    want = []
+    with flame_amd.Regularizer(0) as reg:
+        reg.set_option(5, form)
+        reg.set_stream(solver.cuda_stream)
+        reg.upload_graph(g)
+        with pytest.raises(flame_amd.NLTGV2Error):
+            reg.stream_wait_run(solver.cuda_stream)  # (the context's own stream)
+        with pytest.raises(flame_amd.NLTGV2Error):
+            reg.stream_wait_run(0)
+        for k in range(2 * n_rows):
+            reg.set_export_target(rows[k % n_rows].data_ptr(), 1.0 + k)
+            reg.run_async(p, 7 + k)
+            if k % 3 == 2:
+                reg.info()  # (a call between the run and the wait: the event is recorded instead)
+            reg.stream_wait_run(side.cuda_stream)
+            with torch.cuda.stream(side):
+                seen[k].copy_(rows[k % n_rows], non_blocking=True)
+            oracle.run(ref, 7 + k)
+            want.append(ref["x"] * np.float32(1.0 + k))
+        side.synchronize()
+        got = seen.cpu().numpy()
+        for k in range(2 * n_rows):
+            assert np.array_equal(got[k], want[k]), (form, k)
+        reg.sync()
+        assert reg.info()["timeouts_recovered"] == 0
+
+
 @pytest.mark.parametrize("form", [3, 4, 6, 7])
 def test_export_target_switched_inside_a_replayed_chain(env, form):
     """Double-buffered gather rows: run k exports into row A, the target moves to row B, run k + 1 chains on.  If the chain
