@@ -520,7 +520,8 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
   ok = ok && hipEventCreateWithFlags(&ctx->ev_canon, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&ctx->ev_raster_done, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&ctx->ev_topo_ready, hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&ctx->ev_run_done, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&ctx->ev_run[0], hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&ctx->ev_run[1], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->h_err, kErrBytes, hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->h_cost, 2 * sizeof(float), hipHostMallocDefault) == hipSuccess;
   if (!ok) {
@@ -582,7 +583,8 @@ int flame_nltgv2_destroy(flame_nltgv2_ctx* ctx) {
   if (ctx->raster_stream) (void)hipStreamSynchronize(ctx->raster_stream), (void)hipStreamDestroy(ctx->raster_stream);
   if (ctx->ev_canon) (void)hipEventDestroy(ctx->ev_canon);
   if (ctx->ev_raster_done) (void)hipEventDestroy(ctx->ev_raster_done);
-  if (ctx->ev_run_done) (void)hipEventDestroy(ctx->ev_run_done);
+  for (hipEvent_t e : ctx->ev_run)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->h_img) (void)hipHostFree(ctx->h_img);
   if (ctx->h_dims) (void)hipHostFree(ctx->h_dims);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

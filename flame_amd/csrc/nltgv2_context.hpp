@@ -330,10 +330,13 @@ struct flame_nltgv2_ctx {
   RunTail tail_sent[kTailSlots]{};
   bool tail_valid[kTailSlots] = {false, false, false, false};
   int tail_next = 0;          // the slot the next unseen RunTail overwrites
-  // flame_nltgv2_stream_wait_run: the last plain persistent launch of a run carries this event as its own completion signal
-  // (hipExtLaunchKernel's stop event: no operation of its own on the solver's in-order queue)
-  hipEvent_t ev_run_done = nullptr;
-  bool run_event_bound = false;  // ev_run_done stands for the last enqueued run ...
+  // flame_nltgv2_stream_wait_run / _runs_in_flight: the last plain persistent launch of a run carries one of these two events (in turn) as
+  // its own completion signal (hipExtLaunchKernel's stop event: no operation of its own on the solver's in-order queue)
+  hipEvent_t ev_run[2] = {nullptr, nullptr};
+  int run_ev_pick = 0, run_ev_last = 0;          // the event the run being enqueued may bind / the one of the last enqueued run
+  bool run_ev_valid[2] = {false, false};         // the event stands for a run (bound to its launch, or recorded behind it)
+  bool track_runs = false;                       // somebody asks runs_in_flight: a run whose launch cannot carry the event gets it recorded
+  bool run_event_bound = false;  // ev_run[run_ev_last] was carried by the last enqueued run's own launch ...
   uint64_t call_seq = 0, run_event_seq = 0;  // ... as long as no other call into the context followed it (enter() counts the calls)
   std::vector<float> h_terms;
   DevBuf hq_alt, vstate_alt;  // the other copies of hq / vstate: a persistent run writes there, success swaps the roles

@@ -512,12 +512,11 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       tail_dev = (const RunTail*)((const char*)ctx->run_tail.p + kTailStride * (size_t)slot);
     }
     int e = 0;
-    ctx->run_event_bound = false;
     for (const WaveGroup& gr : groups) {
-      // the run's last launch carries ev_run_done as its own completion signal (flame_nltgv2_stream_wait_run); a cooperative launch
+      // the run's last launch carries an event as its own completion signal (flame_nltgv2_stream_wait_run, _runs_in_flight); a cooperative launch
       // (the first of a topology) cannot: the wait then records the event behind it
-      const bool carries = &gr == &groups.back() && ctx->coop_checked_key == key && ctx->ev_run_done != nullptr;
-      ctx->f.stop_event = carries ? ctx->ev_run_done : nullptr;
+      const bool carries = &gr == &groups.back() && ctx->coop_checked_key == key && ctx->ev_run[ctx->run_ev_pick] != nullptr;
+      ctx->f.stop_event = carries ? ctx->ev_run[ctx->run_ev_pick] : nullptr;
       const int pw = gr.count <= 4 * ctx->prop.multiProcessorCount ? 1 : 4;  // waves per workgroup
       // same-XCD exchange through L2: with the waves laid out along the Morton curve it wins at every size
       // (measured per step: 640x480 -16 %, 1280x720 -23 %, 1080p -18 %, 7-frame batch -20 %, 15 frames -19 %)
@@ -601,7 +600,6 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       if (e != 0) break;
     }
     ctx->run_event_bound = e == 0 && ctx->f.stop_event != nullptr;
-    ctx->run_event_seq = ctx->call_seq;
     ctx->f.stop_event = nullptr;
     ctx->tag_next = tag0 + (uint32_t)n;
     if (e == 0) {
@@ -829,7 +827,20 @@ int flame_nltgv2_run_async(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, 
   if (rc) return rc;
   if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
   if (!params_ok(p) || n_iters < 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-  return enqueue_run(ctx, p, n_iters);
+  const int idx = ctx->run_ev_last ^ 1;  // the two events take turns: the last two runs can be told apart
+  ctx->run_ev_pick = idx;
+  ctx->run_event_bound = false;
+  rc = enqueue_run(ctx, p, n_iters);
+  if (rc) return rc;
+  bool stands = ctx->run_event_bound;
+  if (!stands && ctx->track_runs) {  // (a cooperative first launch, the per-step path: recorded behind it)
+    HIPCHK(ctx, hipEventRecord(ctx->ev_run[idx], ctx->stream));
+    stands = true;
+  }
+  ctx->run_ev_valid[idx] = stands;
+  ctx->run_ev_last = idx;
+  ctx->run_event_seq = ctx->call_seq;
+  return 0;
 }
 
 int flame_nltgv2_stream_wait_run(flame_nltgv2_ctx* ctx, void* hip_stream) {
@@ -837,10 +848,37 @@ int flame_nltgv2_stream_wait_run(flame_nltgv2_ctx* ctx, void* hip_stream) {
   int rc = enter(ctx);
   if (rc) return rc;
   if (!hip_stream || (hipStream_t)hip_stream == ctx->stream) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-  // the run enqueued by the call right before this one carries the event itself; anything else is recorded now
-  if (!(ctx->run_event_bound && ctx->call_seq == ctx->run_event_seq + 1)) HIPCHK(ctx, hipEventRecord(ctx->ev_run_done, ctx->stream));
-  ctx->run_event_bound = false;
-  HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)hip_stream, ctx->ev_run_done, 0));
+  // the run enqueued by the call right before this one carries (or was followed by) its event; anything else is recorded now
+  const int idx = ctx->run_ev_last;
+  if (!(ctx->run_ev_valid[idx] && ctx->call_seq == ctx->run_event_seq + 1)) {
+    HIPCHK(ctx, hipEventRecord(ctx->ev_run[idx], ctx->stream));
+    ctx->run_ev_valid[idx] = true;
+  }
+  HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)hip_stream, ctx->ev_run[idx], 0));
+  return 0;
+}
+
+int flame_nltgv2_runs_in_flight(flame_nltgv2_ctx* ctx, int32_t* n_out) {
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (!n_out) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  ctx->track_runs = true;
+  if (ctx->pending.active && !ctx->run_ev_valid[ctx->run_ev_last]) {  // a run enqueued before anybody asked: marked now
+    HIPCHK(ctx, hipEventRecord(ctx->ev_run[ctx->run_ev_last], ctx->stream));
+    ctx->run_ev_valid[ctx->run_ev_last] = true;
+  }
+  int n = 0;
+  for (int i = 0; i < 2; ++i) {
+    if (!ctx->run_ev_valid[i]) continue;
+    const hipError_t q = hipEventQuery(ctx->ev_run[i]);
+    if (q == hipErrorNotReady) {
+      (void)hipGetLastError();
+      ++n;
+    } else if (q != hipSuccess) {
+      HIPCHK(ctx, q);
+    }
+  }
+  *n_out = n;
   return 0;
 }
 

@@ -95,7 +95,7 @@ def library_path() -> str:
 
 # every symbol include/flame_nltgv2.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
-    "flame_nltgv2_default_params", "flame_nltgv2_create", "flame_nltgv2_destroy", "flame_nltgv2_set_stream", "flame_nltgv2_stream_wait_run",
+    "flame_nltgv2_default_params", "flame_nltgv2_create", "flame_nltgv2_destroy", "flame_nltgv2_set_stream", "flame_nltgv2_stream_wait_run", "flame_nltgv2_runs_in_flight",
     "flame_nltgv2_upload_graph", "flame_nltgv2_update_data", "flame_nltgv2_upload_state", "flame_nltgv2_run",
     "flame_nltgv2_run_async", "flame_nltgv2_sync", "flame_nltgv2_run_timed", "flame_nltgv2_save_prev",
     "flame_nltgv2_dual_step", "flame_nltgv2_primal_step", "flame_nltgv2_extragradient_step", "flame_nltgv2_step",
@@ -130,6 +130,7 @@ def load_library():
         "flame_nltgv2_destroy": (C.c_int, [ctx]),
         "flame_nltgv2_set_stream": (C.c_int, [ctx, C.c_void_p]),
         "flame_nltgv2_stream_wait_run": (C.c_int, [ctx, C.c_void_p]),
+        "flame_nltgv2_runs_in_flight": (C.c_int, [ctx, C.POINTER(C.c_int32)]),
         "flame_nltgv2_upload_graph": (C.c_int, [ctx, GP]),
         "flame_nltgv2_update_data": (C.c_int, [ctx, _FP, _FP]),
         "flame_nltgv2_upload_state": (C.c_int, [ctx, GP]),
@@ -542,6 +543,12 @@ class Regularizer:
 
     def set_stream(self, hip_stream_ptr: int | None):
         self._chk(self._L.flame_nltgv2_set_stream(self._ctx, C.c_void_p(hip_stream_ptr or 0)), "set_stream")
+
+    def runs_in_flight(self) -> int:
+        """How many of the last two run_async() runs the device has not finished yet (non-blocking)."""
+        n = C.c_int32(0)
+        self._chk(self._L.flame_nltgv2_runs_in_flight(self._ctx, C.byref(n)), "runs_in_flight")
+        return int(n.value)
 
     def stream_wait_run(self, hip_stream_ptr: int):
         """Another stream of the caller waits for everything enqueued on the solver's stream so far (right behind run_async: at no cost to

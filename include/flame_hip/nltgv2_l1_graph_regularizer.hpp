@@ -311,6 +311,12 @@ class DeviceGraph {
   // Another stream of the caller waits for the runs enqueued so far (a consumer of the export row: a collective, a copy); right behind
   // runAsync() it costs the solver's stream nothing -- the launch carries the event.
   void streamWaitRun(void* other_hip_stream) { check(flame_nltgv2_stream_wait_run(ctx_, other_hip_stream), "stream_wait_run"); }
+  // How many of the last two runAsync() runs the device has not finished yet (0..2; no wait, no check of their results).
+  int runsInFlight() {
+    int32_t n = 0;
+    check(flame_nltgv2_runs_in_flight(ctx_, &n), "runs_in_flight");
+    return static_cast<int>(n);
+  }
   // Asynchronous runs that sync() had to take back and redo (an expired neighbour wait or a torn record: the state is
   // right again when sync() returns, but anything that consumed the export row BEFORE sync() -- a gather enqueued right
   // behind runAsync() -- read the previous frame's values).  A caller compares this before and after its sync().

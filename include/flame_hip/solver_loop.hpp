@@ -25,9 +25,15 @@
 //               ... triangulate the next frame, track features ...
 //               loop.withDevice([&](DeviceGraph& d, uint64_t) { d.syncCommit(); });
 //               loop.withDevice([&](DeviceGraph& d, uint64_t) { d.interpolateMeshBegin(...); });  ...  interpolateMeshEnd
-//   loop.busyFraction()  -- the share of the wall time since deviceReady() the solver thread spent inside run(): the rest is the
-//                           solver standing still (callers holding the device, launches)
-// The callback's second argument is the number of iterations applied to the device image so far -- exact, read under the lock --
+//   loop.utilization(r)  -- iterations per second since deviceReady() over r, the rate of the solver alone on such a graph: the share
+//                           of the time the device spent iterating (the rest: the frame thread's calls that settle the solver)
+// In device mode the loop never blocks in the context: it ENQUEUES rounds (DeviceGraph::runAsync) and keeps two in flight
+// (DeviceGraph::runsInFlight, a non-blocking query), so the device goes from one round to the next without waiting for the host, and
+// the host part of the frame thread's calls (validation, staging, the triangles' upload) overlaps the rounds already enqueued; a
+// call that needs the settled state waits for them inside the library.  Results are checked every kRoundsPerCheck rounds at the
+// latest (sync(): an expired run is redone there).
+// The callback's second argument is the number of iterations applied to the device image once the calls before it have settled --
+// exact: rounds are counted when they are enqueued, under the lock, and every call that reads or edits the state settles them first --
 // which is what lets a test replay the free-running loop on the CPU checker (tests/cpp/frame_loop_test.cc).
 //
 // Locking: the caller's mutex protects the HOST graph exactly as in the reference; the loop takes it only to upload.  An
@@ -127,6 +133,14 @@ class SolverLoop {
   void withDevice(F&& f) {
     CallerAccess dev_lk(this);
     f(dev_, iterations_.load());
+    // device mode: a call that settled the solver leaves the queue empty -- the caller, who holds the device anyway, fills it again
+    // before it lets go (the solver thread would need a wake-up for it: ~0.1 ms of a standing solver per call)
+    bool ready;
+    {
+      std::lock_guard<std::mutex> lk(state_mtx_);
+      ready = device_ready_ && !stop_.load();
+    }
+    if (graph_ == nullptr && ready) top_up();
   }
   // Device mode: the image uploaded through withDevice() is what the loop iterates on from now on.
   void deviceReady() {
@@ -135,11 +149,12 @@ class SolverLoop {
       device_ready_ = true;
       t_ready_ = std::chrono::steady_clock::now();
       busy_ns_.store(0);
+      iterations_at_ready_.store(iterations_.load());
     }
     cv_.notify_all();
   }
-  // Share of the wall time since deviceReady() / start() that the solver thread spent inside run() (device mode: what the frame loop
-  // reports as "solver busy"; 1 - this = idle: the device lock held by callers, launch gaps).
+  // Host mode: share of the wall time since start() that the solver thread spent inside its blocking rounds.  (Device mode enqueues
+  // its rounds and never blocks: see utilization().)
   double busyFraction() const {
     std::chrono::steady_clock::time_point t0;
     {
@@ -148,6 +163,18 @@ class SolverLoop {
     }
     const double wall = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
     return wall > 0 ? static_cast<double>(busy_ns_.load()) / wall : 0.0;
+  }
+  // Device mode: the share of the time since deviceReady() the device spent on solver iterations, given the solver's own rate on such a
+  // graph (iterations per second of an undisturbed run, measured by the caller).
+  double utilization(double free_running_iters_per_s) const {
+    std::chrono::steady_clock::time_point t0;
+    {
+      std::lock_guard<std::mutex> lk(state_mtx_);
+      t0 = t_ready_;
+    }
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const double done = static_cast<double>(iterations_.load() - iterations_at_ready_.load());
+    return wall > 0 && free_running_iters_per_s > 0 ? done / wall / free_running_iters_per_s : 0.0;
   }
   uint64_t iterations() const { return iterations_.load(); }
   uint64_t uploads() const { return uploads_.load(); }
@@ -189,12 +216,21 @@ class SolverLoop {
         bool have = false;
         give_way();
         if (graph_ == nullptr) {  // device mode: nothing is ever uploaded from the host; idle until the first image stands
-          std::unique_lock<std::mutex> lk(state_mtx_);
-          if (!device_ready_) {
-            cv_.wait_for(lk, std::chrono::milliseconds(50), [&] { return stop_.load() || device_ready_; });
-            continue;
+          {
+            std::unique_lock<std::mutex> lk(state_mtx_);
+            if (!device_ready_) {
+              cv_.wait_for(lk, std::chrono::milliseconds(50), [&] { return stop_.load() || device_ready_; });
+              continue;
+            }
           }
-          have = true;
+          // rounds are enqueued, two in flight; the thread holds the device for microseconds at a time
+          bool enqueued;
+          {
+            std::lock_guard<std::mutex> dev_lk(dev_mtx_);
+            enqueued = top_up();
+          }
+          if (!enqueued) std::this_thread::sleep_for(std::chrono::microseconds(20));
+          continue;
         } else {
           std::lock_guard<std::mutex> dev_lk(dev_mtx_);
           have = dev_.generation() == dirty && uploaded_once_;
@@ -239,6 +275,10 @@ class SolverLoop {
           cv_.wait_for(lk, std::chrono::milliseconds(50), [&] { return stop_.load() || dirty_generation_ != dirty; });
         }
       }
+      if (graph_ == nullptr) {  // device mode: the rounds still in flight are checked before the thread leaves
+        std::lock_guard<std::mutex> dev_lk(dev_mtx_);
+        if (dev_vertices() > 0) dev_.sync();
+      }
     } catch (const std::exception& e) {
       std::lock_guard<std::mutex> lk(state_mtx_);
       error_ = e.what();
@@ -246,6 +286,21 @@ class SolverLoop {
     }
     std::lock_guard<std::mutex> lk(state_mtx_);
     exited_ = true;
+  }
+  // (dev_mtx_ held) device mode: enqueues rounds until two are in flight; true if it enqueued any
+  bool top_up() {
+    bool any = false;
+    if (dev_vertices() == 0) return false;
+    while (dev_.runsInFlight() < 2) {
+      dev_.runAsync(params_, iters_per_round_);
+      iterations_.fetch_add(static_cast<uint64_t>(iters_per_round_));
+      any = true;
+      if (++rounds_unchecked_ >= kRoundsPerCheck) {
+        dev_.sync();
+        rounds_unchecked_ = 0;
+      }
+    }
+    return any;
   }
   size_t dev_vertices() {
     flame_nltgv2_info info;
@@ -256,13 +311,15 @@ class SolverLoop {
   GraphMutex* graph_mtx_;
   Params params_;
   const int iters_per_round_, max_rounds_;
+  static constexpr int kRoundsPerCheck = 64;
+  int rounds_unchecked_ = 0;
   DeviceGraph dev_;
   std::mutex dev_mtx_;            // serialises calls into dev_ (the context is not thread-safe)
   mutable std::mutex state_mtx_;  // dirty_generation_, error_, thread_ start/stop
   std::condition_variable cv_;
   std::thread thread_;
   std::atomic<bool> stop_{false};
-  std::atomic<uint64_t> iterations_{0}, uploads_{0}, busy_ns_{0};
+  std::atomic<uint64_t> iterations_{0}, uploads_{0}, busy_ns_{0}, iterations_at_ready_{0};
   bool device_ready_ = false;                              // device mode: the first image was handed over (state_mtx_)
   std::chrono::steady_clock::time_point t_ready_ = std::chrono::steady_clock::now();
   std::atomic<int> callers_waiting_{0};

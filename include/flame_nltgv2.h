@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FLAME_NLTGV2_ABI_VERSION 5 /* 5: flame_nltgv2_info grew (last_run_waves_per_cu, regions, region_depth, replays_per_step); FLAME_NLTGV2_OPT_PERSISTENT = 7; flame_nltgv2_stream_wait_run */
+#define FLAME_NLTGV2_ABI_VERSION 5 /* 5: flame_nltgv2_info grew (last_run_waves_per_cu, regions, region_depth, replays_per_step); FLAME_NLTGV2_OPT_PERSISTENT = 7; flame_nltgv2_stream_wait_run, _runs_in_flight */
 
 typedef struct flame_nltgv2_ctx flame_nltgv2_ctx;
 
@@ -229,6 +229,11 @@ int flame_nltgv2_set_export_target(flame_nltgv2_ctx* ctx, void* dst_device, floa
  * completion signal, where an event recorded by the caller is one more operation between two solver launches on an in-order queue
  * (5 us each at 640x480).  FLAME_NLTGV2_ERR_INVALID_ARG for a null stream or the context's own. */
 int flame_nltgv2_stream_wait_run(flame_nltgv2_ctx* ctx, void* hip_stream);
+/* How many of the last two runs enqueued with run_async() the device has not finished yet (0, 1 or 2): what a free-running solver
+ * thread paces itself by -- it keeps two runs in flight, so that the device never waits for the host between two of them, without ever
+ * blocking in the context (include/flame_hip/solver_loop.hpp, device mode).  Does not wait, does not check the runs' results (sync()
+ * does), and costs the solver's stream nothing where the launch carries the event. */
+int flame_nltgv2_runs_in_flight(flame_nltgv2_ctx* ctx, int32_t* n_out);
 
 /* Mesh -> dense inverse-depth map, the step right after the solver each frame:
  * utils::interpolateMesh (utils/image_utils.cc:373-396) over utils::DrawShadedTriangleBarycentric
