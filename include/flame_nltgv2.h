@@ -224,13 +224,14 @@ int flame_nltgv2_export_idepth_device_async(flame_nltgv2_ctx* ctx, void* dst_dev
  * it in their epilogue, so a per-step result gather needs no extra kernel between two runs. */
 int flame_nltgv2_set_export_target(flame_nltgv2_ctx* ctx, void* dst_device, float scale);
 /* Makes another stream of the caller (`hip_stream`, a hipStream_t; not the context's own) wait for everything enqueued on the context's
- * stream so far -- the consumer side of the standing export target: a collective on `hip_stream` then reads the finished row.  No
+ * stream so far -- the consumer side of the standing export target (the read-back of flame.cc:372-380 left on the device): a collective
+ * on `hip_stream` then reads the finished row.  No
  * host wait.  Called right behind run_async() it costs the solver's stream nothing: the run's launch carries the event as its own
  * completion signal, where an event recorded by the caller is one more operation between two solver launches on an in-order queue
  * (5 us each at 640x480).  FLAME_NLTGV2_ERR_INVALID_ARG for a null stream or the context's own. */
 int flame_nltgv2_stream_wait_run(flame_nltgv2_ctx* ctx, void* hip_stream);
 /* How many of the last two runs enqueued with run_async() the device has not finished yet (0, 1 or 2): what a free-running solver
- * thread paces itself by -- it keeps two runs in flight, so that the device never waits for the host between two of them, without ever
+ * thread (flame.cc:99-112) paces itself by -- it keeps two runs in flight, so that the device never waits for the host between two of them, without ever
  * blocking in the context (include/flame_hip/solver_loop.hpp, device mode).  Does not wait, does not check the runs' results (sync()
  * does), and costs the solver's stream nothing where the launch carries the event. */
 int flame_nltgv2_runs_in_flight(flame_nltgv2_ctx* ctx, int32_t* n_out);
