@@ -3,6 +3,7 @@
 #include "nltgv2_context.hpp"
 
 #include <atomic>
+#include <unordered_set>
 
 #include "host_workers.hpp"
 
@@ -400,6 +401,18 @@ int flame_nltgv2_sync_prepare(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_inp
     if (!applicable && ctx->opt_sync_path == 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
   }
   if (!applicable) {  // keep the inputs (pinned, like the staged ones) for the host path at commit
+    // ... after the value checks sync_graph's host path makes (the header: prepare reports the same errors as sync_graph; advisor,
+    // round 4: a bad id or edge used to surface at commit, indistinguishable from "nothing prepared")
+    {
+      std::unordered_set<int32_t> ids;
+      ids.reserve((size_t)in->V * 2);
+      for (int32_t v = 0; v < in->V; ++v)
+        if (in->feat_id[v] < 0 || !ids.insert(in->feat_id[v]).second) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      for (int32_t k = 0; k < in->E; ++k) {
+        const int32_t a = in->edges[2 * k], b = in->edges[2 * k + 1];
+        if (a < 0 || a >= in->V || b < 0 || b >= in->V || a == b) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      }
+    }
     rc = cancel_prepared(ctx);
     if (rc) return rc;
     flame_nltgv2_ctx::PreparedSync& P = ctx->prepared;

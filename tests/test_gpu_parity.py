@@ -701,6 +701,38 @@ def test_another_stream_waits_for_the_run_through_the_launch_own_event(env, form
         assert reg.info()["timeouts_recovered"] == 0
 
 
+@pytest.mark.parametrize("form", [0, 1, 7])
+def test_runs_in_flight_counts_the_last_two_runs_without_waiting(env, form):
+    """flame_nltgv2_runs_in_flight: 0 on an idle context, at most 2, falls back to 0 once the device has finished the runs (no sync by
+    the caller), and the runs it watched are as good as any: the state equals the checker's."""
+    import time
+
+    flame_amd, oracle = env
+    g = synth.make_graph("640x480", seed=41)
+    ref = synth.copy_graph(g)
+    p = flame_amd.Params()
+    with flame_amd.Regularizer(0) as reg:
+        reg.set_option(5, form)
+        reg.upload_graph(g)
+        assert reg.runs_in_flight() == 0
+        seen, total = set(), 0
+        for k in range(6):
+            reg.run_async(p, 400)
+            total += 400
+            n = reg.runs_in_flight()
+            assert 0 <= n <= 2
+            seen.add(n)
+        assert max(seen) >= 1  # (2 400 iterations take > 2 ms: the query returned long before)
+        t0 = time.perf_counter()
+        while reg.runs_in_flight() != 0:
+            assert time.perf_counter() - t0 < 10.0
+            time.sleep(0.0005)
+        reg.sync()
+        oracle.run(ref, total)
+        out = reg.download_state()
+        assert all(np.array_equal(out[key], ref[key]) for key in ("x", "w1", "w2", "q1", "q2", "q3"))
+
+
 @pytest.mark.parametrize("form", [3, 4, 6, 7])
 def test_export_target_switched_inside_a_replayed_chain(env, form):
     """Double-buffered gather rows: run k exports into row A, the target moves to row B, run k + 1 chains on.  If the chain

@@ -425,6 +425,22 @@ def test_prepared_sync_beside_a_running_solver(built, config):
         # a commit with nothing prepared, and a prepared sync cancelled by an upload
         with pytest.raises(flame_amd.NLTGV2Error):
             reg.sync_commit()
+        # bad inputs on the HOST way (no vouched-for edge list) are reported by prepare itself, as sync_graph reports them: a
+        # duplicate feature id, an edge out of range, a self-loop -- and the graph is left as it was
+        fb, pb, db, _ = next_frame(rng, feat_id, pos, data, next_id, w, h)
+        eb = synth.delaunay_edges_scipy(pb)
+        for what in ("duplicate id", "edge out of range", "self-loop"):
+            f_bad, e_bad = fb.copy(), eb.copy()
+            if what == "duplicate id":
+                f_bad[3] = f_bad[2]
+            elif what == "edge out of range":
+                e_bad[5, 1] = len(fb)
+            else:
+                e_bad[7, 1] = e_bad[7, 0]
+            with pytest.raises(flame_amd.NLTGV2Error):
+                reg.sync_prepare(f_bad, pb, db, np.ones(len(fb), np.float32), e_bad, edges_unique=False)
+        src, dst, fid = reg.topology()
+        assert np.array_equal(fid, feat_id)
         f2, p2, d2, _ = next_frame(rng, feat_id, pos, data, next_id, w, h)
         reg.sync_prepare(f2, p2, d2, np.ones(len(f2), np.float32), synth.delaunay_edges_scipy(p2), edges_unique=True)
         reg.upload_graph(g0)
