@@ -329,20 +329,24 @@ bool triangulate_subset(const Input& in, const int* ids, int m, Triangulator& T)
   // ---- insertion order: Morton curve (consecutive points are close: short walks).  The keys are quantised over the
   // bounding box of the WHOLE input, and ties keep the order of `ids`: two points are inserted in the same relative order
   // in every subset that holds both (what breaks co-circular ties the same way in neighbouring strips)
-  std::vector<int> order((size_t)m);
+  // (scratch kept per thread between calls: a strip's ~150 KB of fresh vectors every frame were an mmap, its page faults and a munmap each)
+  static thread_local std::vector<int> order, tmp;
+  static thread_local std::vector<uint32_t> key, count;
+  static thread_local std::vector<char> used;
+  order.resize((size_t)m);
   std::iota(order.begin(), order.end(), 0);
   {
     const double sx = in.maxx > in.minx ? 65535.0 / ((double)in.maxx - in.minx) : 0.0;
     const double sy = in.maxy > in.miny ? 65535.0 / ((double)in.maxy - in.miny) : 0.0;
-    std::vector<uint32_t> key((size_t)m);
+    key.resize((size_t)m);
     for (int k = 0; k < m; ++k) {
       const int i = ids[k];
       const uint32_t qx = (uint32_t)(((double)xy[2 * i] - in.minx) * sx), qy = (uint32_t)(((double)xy[2 * i + 1] - in.miny) * sy);
       key[(size_t)k] = spread16(qx) | (spread16(qy) << 1);
     }
     // stable LSD radix sort by key (3 passes of 11 bits)
-    std::vector<int> tmp((size_t)m);
-    std::vector<uint32_t> count(2049);
+    tmp.resize((size_t)m);
+    count.resize(2049);
     for (int pass = 0; pass < 3; ++pass) {
       const int shift = 11 * pass;
       std::fill(count.begin(), count.end(), 0u);
@@ -366,6 +370,7 @@ bool triangulate_subset(const Input& in, const int* ids, int m, Triangulator& T)
   int v0 = a, v1 = b, v2 = c;
   if (T.orient(v0, v1, v2) < 0) std::swap(v1, v2);
   T.t.clear();
+  T.free_.clear();
   T.t.reserve((size_t)m * 4 + 16);
   const int t0 = T.new_tri(v0, v1, v2);
   // ghosts: across edge opposite v[i] of t0, i.e. edge (v[i+1], v[i+2]); the ghost holds it reversed
@@ -382,7 +387,7 @@ bool triangulate_subset(const Input& in, const int* ids, int m, Triangulator& T)
     T.t[g[i]].n[1] = g[(i + 1) % 3];
   }
 
-  std::vector<char> used((size_t)m, 0);
+  used.assign((size_t)m, 0);
   used[(size_t)v0] = used[(size_t)v1] = used[(size_t)v2] = 1;
   int last = t0;
   for (size_t k = 0; k < order.size(); ++k) {
@@ -461,7 +466,8 @@ constexpr int kBins = 1024;
 void run_strip(const Input& in, const std::vector<int>& by_bin, const std::vector<int>& bin_start, const std::vector<int>& band_pts,
                const std::vector<uint16_t>& bin_of, int core0, int core1, int halo, double band, StripResult* out) {
   const int lo = std::max(0, core0 - halo), hi = std::min(kBins, core1 + halo);
-  std::vector<int> ids(by_bin.begin() + bin_start[(size_t)lo], by_bin.begin() + bin_start[(size_t)hi]);
+  static thread_local std::vector<int> ids;
+  ids.assign(by_bin.begin() + bin_start[(size_t)lo], by_bin.begin() + bin_start[(size_t)hi]);
   const size_t n_block = ids.size();
   for (int i : band_pts)
     if (bin_of[(size_t)i] < lo || bin_of[(size_t)i] >= hi) ids.push_back(i);
@@ -469,7 +475,7 @@ void run_strip(const Input& in, const std::vector<int>& by_bin, const std::vecto
   // block point's: another x bin) -- the relative order of equal keys is that of the whole input
   (void)n_block;
   out->tris.clear(), out->edges.clear(), out->hull_edges = 0, out->vertices = 0, out->certified = true;
-  Triangulator T;
+  static thread_local Triangulator T;
   if (!triangulate_subset(in, ids.data(), (int)ids.size(), T)) {
     out->certified = false;
     return;
@@ -485,7 +491,8 @@ void run_strip(const Input& in, const std::vector<int>& by_bin, const std::vecto
   // quantum wider than the excluded bins -- conservative)
   const Rect left = {(double)in.minx, xlo, (double)in.miny + band, (double)in.maxy - band};
   const Rect right = {xhi, (double)in.maxx, (double)in.miny + band, (double)in.maxy - band};
-  std::vector<char> in_tri(ids.size(), 0);
+  static thread_local std::vector<char> in_tri;
+  in_tri.assign(ids.size(), 0);
   auto own = [&](int v) { return bin_of[(size_t)ids[(size_t)v]] >= core0 && bin_of[(size_t)ids[(size_t)v]] < core1; };
   for (size_t ti = 0; ti < T.t.size(); ++ti) {
     const Tri& tr = T.t[ti];
@@ -676,7 +683,7 @@ extern "C" int flame_delaunay_triangulate(const float* xy, int32_t n, int32_t* t
   }
 
   // ---- sequential: one triangulation of everything ------------------------------------------------------------------
-  Triangulator T;
+  static thread_local Triangulator T;
   std::vector<int> all((size_t)n);
   std::iota(all.begin(), all.end(), 0);
   if (!triangulate_subset(in, all.data(), n, T)) return FLAME_NLTGV2_OK;
