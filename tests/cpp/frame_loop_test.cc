@@ -14,8 +14,8 @@
 // replays its log on the checkers: the log holds, for every call that touches the device image, the number of solver iterations the
 // free-running loop had applied when the call took the device (read under the loop's lock: exact), so the CPU side can run exactly
 // those iterations between the same edits and compare every output bit for bit: the updated features, the keep mask of projectGraph,
-// the dense map and its coverage, the graph's state at the end of every frame.  It also prints what share of the wall time the solver
-// thread spent iterating (SolverLoop::busyFraction).  With `lean` the window of the test is closed -- no read-back of the graph's state,
+// the dense map and its coverage, the graph's state at the end of every frame.  It also prints what share of the time the device spent
+// on solver iterations (SolverLoop::utilization: iterations per second in the loop over the rate of an undisturbed run).  With `lean` the window of the test is closed -- no read-back of the graph's state,
 // the dense map is not copied while the device is held -- and the printed share is that of the loop as FLaME would drive it.
 //
 // usage: frame_loop_test IN OUT [iters_per_round [lean]]     exit code 0 = ran, 77 = no usable HIP device
