@@ -429,6 +429,16 @@ int place_records(flame_nltgv2_ctx* ctx, int per_xcd) {
   return 0;
 }
 
+// (diagnostic builds of k_persistent_rg only -- make variant VARIANT_FLAGS=-DFLAME_RG_DIAG: which parts of a step are left out, by name)
+static int rg_diag_bits() {
+#ifdef FLAME_RG_DIAG
+  const char* e = std::getenv("FLAME_RG_VARIANT");
+  return e ? std::atoi(e) << 8 : 0;
+#else
+  return 0;
+#endif
+}
+
 int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   if (n <= 0) return 0;
   if (ctx->opt_solver == 1) {  // canonical 4-sweep path
@@ -579,7 +589,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
           ctx->probe_words = words;
           HIPCHK(ctx, hipMemsetAsync(ctx->probe.p, 0, words * sizeof(unsigned), ctx->stream));
         }
-        e = launch_persistent_rg(ctx->f, ctx->rg_args, to_sp(p), ctx->parity, tag0, n, spins_arg, (dual & 1) | (std::getenv("FLAME_RG_VARIANT") ? std::atoi(std::getenv("FLAME_RG_VARIANT")) << 8 : 0) |
+        e = launch_persistent_rg(ctx->f, ctx->rg_args, to_sp(p), ctx->parity, tag0, n, spins_arg, (dual & 1) | rg_diag_bits() |
                                      ((ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : kRgPreSleep) << 16) | ((ctx->opt_poll_gap > 0 ? (ctx->opt_poll_gap - 1) & 15 : kRgPollGap) << 24),
                                  tail_dev, probe,
                                  ctx->coop_checked_key != key, ctx->stream);
