@@ -613,6 +613,361 @@ bool triangulate_strips(const Input& in, int n_strips, int32_t* tris, int32_t tr
   return true;
 }
 
+
+// ---- divide and conquer (round 5) -----------------------------------------------------------------------------------------
+// The certified strips above make every strip triangulate ~5 x its own share (halo + bands).  Here a strip triangulates its OWN
+// points only, and neighbouring parts are merged along their seam, pair by pair, in a tree:
+//   * the lower common tangent of the two convex hulls (the parts are separated by a vertical line: their x ranges are disjoint bins);
+//   * a zipper up the two hull chains that face each other: every hull edge of the chains has a ghost triangle (edge + the vertex at
+//     infinity) -- it BECOMES the real triangle (edge + the opposite end of the current base) by getting that vertex for its ghost
+//     vertex, so nothing is allocated but the two ghosts of the tangent edges;
+//   * Lawson flips, started from the zipper's triangles, with the exact in-circle predicate: the result is the Delaunay triangulation
+//     of the union (unique in general position).
+// Everything lives in one arena of triangles with GLOBAL vertex ids, a slot range per strip; merges of one level touch disjoint parts.
+// The team of threads goes through all phases behind spin barriers (host_workers.hpp).  Any surprise -- a strip without a triangle,
+// a degenerate tangent, a guard that trips -- gives up and the caller takes the certified strips.
+struct Merger {
+  Triangulator G;  // p: all points by global id; t: the arena
+  bool ok = true;
+
+  int ghost_from(int g) const { return G.t[(size_t)g].v[0]; }
+  int ghost_to(int g) const { return G.t[(size_t)g].v[1]; }
+  // hull vertex handles are their OUTGOING ghosts (v, cw-next, GHOST): n[0] = the ghost that starts at cw-next, n[1] = the one that ends at v
+  int cw(int go) const { return G.t[(size_t)go].n[0]; }
+
+  void flip(int A, int i, int B, int j, std::vector<int>& stack) {
+    Tri& ta = G.t[(size_t)A];
+    Tri& tb = G.t[(size_t)B];
+    const int a = ta.v[i], b = ta.v[(i + 1) % 3], c = ta.v[(i + 2) % 3], d = tb.v[j];
+    const int n_ab = ta.n[(i + 2) % 3], n_ca = ta.n[(i + 1) % 3];  // across a-b (opposite c), across c-a (opposite b)
+    // in B = (d, c, b) rotated: across b-d is opposite c, across d-c is opposite b
+    int jc = -1, jb = -1;
+    for (int k = 0; k < 3; ++k) {
+      if (tb.v[k] == c) jc = k;
+      if (tb.v[k] == b) jb = k;
+    }
+    const int n_bd = tb.n[jc], n_dc = tb.n[jb];
+    // A' = (a, b, d), B' = (a, d, c)
+    ta.v[0] = a, ta.v[1] = b, ta.v[2] = d;
+    ta.n[0] = n_bd, ta.n[1] = B, ta.n[2] = n_ab;
+    tb.v[0] = a, tb.v[1] = d, tb.v[2] = c;
+    tb.n[0] = n_dc, tb.n[1] = n_ca, tb.n[2] = A;
+    auto relink = [&](int outer, int was, int now) {
+      if (outer < 0) return;
+      Tri& o = G.t[(size_t)outer];
+      for (int k = 0; k < 3; ++k)
+        if (o.n[k] == was) o.n[k] = now;
+    };
+    relink(n_bd, B, A);   // (n_ab stays with A, n_dc with B)
+    relink(n_ca, A, B);
+    // the four outer edges of the pair are to be looked at again (entries are triangle * 4 + edge; the new diagonal is Delaunay)
+    stack.push_back(4 * A + 0), stack.push_back(4 * A + 2), stack.push_back(4 * B + 0), stack.push_back(4 * B + 1);
+  }
+
+  // Merges the parts whose hulls hold the ghosts gl (left part) and gr (right part); ghost slots s0, s1 are free for the two tangent
+  // edges.  Returns a ghost of the merged hull, or -1.
+  int merge(int gl, int gr, int s0, int s1, std::vector<int>& stack) {
+    const size_t guard_hull = G.t.size() + 16;
+    // rightmost vertex of the left hull, leftmost of the right hull (by their outgoing ghosts)
+    int a = gl, b = gr;
+    {
+      size_t steps = 0;
+      for (int g = cw(gl); g != gl; g = cw(g)) {
+        if (G.p[(size_t)ghost_from(g)].x > G.p[(size_t)ghost_from(a)].x) a = g;
+        if (++steps > guard_hull) return -1;
+      }
+      steps = 0;
+      for (int g = cw(gr); g != gr; g = cw(g)) {
+        if (G.p[(size_t)ghost_from(g)].x < G.p[(size_t)ghost_from(b)].x) b = g;
+        if (++steps > guard_hull) return -1;
+      }
+    }
+    // lower common tangent: a walks down the left hull (clockwise), b down the right hull (counter-clockwise)
+    for (size_t steps = 0;; ++steps) {
+      if (steps > 2 * guard_hull) return -1;
+      const int va = ghost_from(a), vb = ghost_from(b);
+      const int pa = cw(a), vp = ghost_from(pa);
+      int o = G.orient(va, vb, vp);
+      if (o < 0 || (o == 0 && G.p[(size_t)vp].x > G.p[(size_t)va].x)) {
+        a = pa;
+        continue;
+      }
+      const int qb = G.t[(size_t)b].n[1];  // the ghost that ends at vb = the outgoing ghost of its ccw-next
+      const int vq = ghost_from(qb);
+      o = G.orient(va, vb, vq);
+      if (o < 0 || (o == 0 && G.p[(size_t)vq].x < G.p[(size_t)vb].x)) {
+        b = qb;
+        continue;
+      }
+      break;
+    }
+    int bl = ghost_from(a), br = ghost_from(b);
+    int gL = G.t[(size_t)a].n[1];  // (nl, bl, GHOST): the left hull's edge that goes UP from bl
+    int gR = b;                    // (br, nr, GHOST): the right hull's edge that goes UP from br
+    // the ghost of the lower tangent (hull edge bl -> br counter-clockwise: the ghost holds it reversed)
+    const int GB = s0, GT = s1;
+    {
+      Tri& t = G.t[(size_t)GB];
+      t.v[0] = br, t.v[1] = bl, t.v[2] = GHOST;
+      t.alive = 1, t.ghost = 1, t.in_cavity = 0;
+      t.n[0] = a;                       // starts at bl
+      t.n[1] = G.t[(size_t)b].n[1];     // ends at br
+      t.n[2] = -1;
+      G.t[(size_t)a].n[1] = GB;
+      G.t[(size_t)t.n[1]].n[0] = GB;
+    }
+    const size_t first_new = stack.size();
+    int prev = GB, prev_slot = 2, made = 0;
+    for (size_t steps = 0;; ++steps) {
+      if (steps > 2 * guard_hull) return -1;
+      const int nl = ghost_from(gL), nr = ghost_to(gR);
+      if (ghost_to(gL) != bl || ghost_from(gR) != br) return -1;
+      const bool lvis = G.orient(bl, nl, br) < 0, rvis = G.orient(br, nr, bl) > 0;
+      if (!lvis && !rvis) break;
+      bool take_left = lvis;
+      if (lvis && rvis) {
+        take_left = !(G.incircle(bl, br, nl, nr) > 0);
+        if (take_left && !(G.orient(br, nr, nl) > 0)) take_left = false;       // (its new base must not cut the other chain)
+        else if (!take_left && !(G.orient(bl, nl, nr) < 0)) take_left = true;
+      }
+      if (take_left) {
+        if (!(G.orient(bl, br, nl) > 0)) return -1;
+        Tri& t = G.t[(size_t)gL];  // (nl, bl, GHOST) -> (nl, bl, br)
+        const int next_gL = t.n[1];
+        t.v[2] = br, t.ghost = 0;
+        t.n[0] = prev, G.t[(size_t)prev].n[prev_slot] = gL;  // across bl-br: the old base
+        t.n[1] = -1;
+        stack.push_back(4 * gL), stack.push_back(4 * gL + 1), stack.push_back(4 * gL + 2);
+        prev = gL, prev_slot = 1;  // across br-nl: the new base
+        bl = nl, gL = next_gL;
+      } else {
+        if (!(G.orient(bl, br, nr) > 0)) return -1;
+        Tri& t = G.t[(size_t)gR];  // (br, nr, GHOST) -> (br, nr, bl)
+        const int next_gR = t.n[0];
+        t.v[2] = bl, t.ghost = 0;
+        t.n[1] = prev, G.t[(size_t)prev].n[prev_slot] = gR;  // across bl-br
+        t.n[0] = -1;
+        stack.push_back(4 * gR), stack.push_back(4 * gR + 1), stack.push_back(4 * gR + 2);
+        prev = gR, prev_slot = 0;  // across nr-bl
+        br = nr, gR = next_gR;
+      }
+      ++made;
+    }
+    if (made == 0) return -1;
+    {  // the ghost of the upper tangent (hull edge br -> bl counter-clockwise)
+      Tri& t = G.t[(size_t)GT];
+      t.v[0] = bl, t.v[1] = br, t.v[2] = GHOST;
+      t.alive = 1, t.ghost = 1, t.in_cavity = 0;
+      t.n[0] = gR, t.n[1] = gL, t.n[2] = prev;
+      G.t[(size_t)prev].n[prev_slot] = GT;
+      G.t[(size_t)gR].n[1] = GT;
+      G.t[(size_t)gL].n[0] = GT;
+    }
+    // Lawson flips from the zipper's triangles
+    size_t flips = 0;
+    const size_t guard_flips = 64 * G.t.size() + 1024;
+    while (stack.size() > first_new) {
+      const int A = stack.back() >> 2, i = stack.back() & 3;
+      stack.pop_back();
+      const Tri& ta = G.t[(size_t)A];
+      if (!ta.alive || ta.ghost) continue;
+      const int B = ta.n[i];
+      if (B < 0) return -1;
+      const Tri& tb = G.t[(size_t)B];
+      if (tb.ghost) continue;
+      int j = -1;
+      for (int k = 0; k < 3; ++k)
+        if (tb.n[k] == A) j = k;
+      if (j < 0) return -1;
+      if (G.incircle(ta.v[0], ta.v[1], ta.v[2], tb.v[j]) > 0) {
+        if (++flips > guard_flips) return -1;
+        flip(A, i, B, j, stack);
+      }
+    }
+    if (std::getenv("FLAME_DELAUNAY_TRACE")) std::fprintf(stderr, "[delaunay] merge: %d zipper triangles, %zu flips\n", made, flips);
+    return GB;
+  }
+};
+
+bool triangulate_merge(const Input& in, int n_strips, int32_t* tris, int32_t tri_capacity, int32_t* n_tris, int32_t* edges,
+                       int32_t edge_capacity, int32_t* n_edges, bool* fits) {
+  const int32_t n = in.n;
+  const bool prof = std::getenv("FLAME_DELAUNAY_PROFILE") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
+  if (!in.filter_ok || !(in.maxx > in.minx) || !(in.maxy > in.miny) || n_strips < 2) return false;
+  flame_hip::Workers& W = flame_hip::Workers::get();
+  const int team = std::max(1, std::min(W.threads(), n_strips));  // (one thread does the same work in the same order: the output does not
+                                                                  //  depend on the machine)
+  // x bins as in triangulate_strips (equal keys share a bin), counting sort by bin
+  // (scratch of the CALLING thread, kept between calls; the team reaches it through these references -- a thread_local name inside
+  //  the team's lambda would be the worker's own, empty, copy)
+  static thread_local std::vector<uint16_t> tl_bin_of;
+  static thread_local std::vector<int> tl_bin_start, tl_by_bin;
+  std::vector<uint16_t>& bin_of = tl_bin_of;
+  std::vector<int>&bin_start = tl_bin_start, &by_bin = tl_by_bin;
+  bin_of.resize((size_t)n), by_bin.resize((size_t)n);
+  bin_start.assign(kBins + 1, 0);
+  const double sx = 65535.0 / ((double)in.maxx - in.minx);
+  for (int32_t i = 0; i < n; ++i) {
+    bin_of[(size_t)i] = (uint16_t)((uint32_t)(((double)in.xy[2 * i] - in.minx) * sx) >> 6);
+    bin_start[(size_t)bin_of[(size_t)i] + 1]++;
+  }
+  for (int b = 0; b < kBins; ++b) bin_start[(size_t)b + 1] += bin_start[(size_t)b];
+  {
+    std::vector<int> at(bin_start.begin(), bin_start.end() - 1);
+    for (int32_t i = 0; i < n; ++i) by_bin[(size_t)at[bin_of[(size_t)i]]++] = i;
+  }
+  std::vector<int> cut((size_t)n_strips + 1, 0);
+  cut[(size_t)n_strips] = kBins;
+  for (int s = 1; s < n_strips; ++s) {
+    const int want = (int)((int64_t)n * s / n_strips);
+    cut[(size_t)s] = (int)(std::upper_bound(bin_start.begin(), bin_start.end(), want) - bin_start.begin()) - 1;
+    cut[(size_t)s] = std::max(cut[(size_t)s], cut[(size_t)s - 1] + 1);
+    if (cut[(size_t)s] >= kBins) return false;
+  }
+  // the arena: a slot range per strip (a triangulation of m points never holds more than 2 m + 2 triangles, ghosts included), then two
+  // ghosts per merge
+  static thread_local Merger tl_merger;
+  Merger& M = tl_merger;
+  M.ok = true;
+  Triangulator& G = M.G;
+  G.filter_ok = in.filter_ok, G.ori_static = in.ori_static, G.icc_static = in.icc_static;
+  G.p.resize((size_t)n);
+  std::vector<int> base((size_t)n_strips + 1, 0), comp((size_t)n_strips, -1);
+  for (int s = 0; s < n_strips; ++s) {
+    const int m = bin_start[(size_t)cut[(size_t)s + 1]] - bin_start[(size_t)cut[(size_t)s]];
+    if (m < 3) return false;
+    base[(size_t)s + 1] = base[(size_t)s] + 2 * m + 8;
+  }
+  const int ghost_base = base[(size_t)n_strips];
+  G.t.resize((size_t)ghost_base + 2 * (size_t)n_strips);
+  for (size_t i = (size_t)ghost_base; i < G.t.size(); ++i) G.t[i].alive = 0, G.t[i].ghost = 0;
+  // output ranges: the strips' slot ranges and the tangent ghosts' (a tangent edge of one merge may face the seam of a later one and
+  // become a real triangle there)
+  const int n_ranges = n_strips + 1;
+  base.push_back((int)G.t.size());
+  std::atomic<int> failed{0};
+  flame_hip::SpinBarrier barrier(team);
+  // per output range (one per strip + the tangent ghosts hold no real triangle): counts, then offsets
+  std::vector<int64_t> cnt_t((size_t)n_strips + 1, 0), cnt_e((size_t)n_strips + 1, 0), at_t((size_t)n_strips + 1, 0), at_e((size_t)n_strips + 1, 0);
+  int64_t total_t = 0, total_e = 0;
+  double t_strips = 0, t_merged = 0;
+  const bool ran = W.run_team(team, [&](int rank) {
+    // ---- phase 0: the strips, each into its slot range ----------------------------------------------------------------------
+    static thread_local Triangulator T;
+    static thread_local std::vector<int> ids;
+    static thread_local std::vector<int> stack;
+    for (int s = rank; s < n_strips; s += team) {
+      ids.assign(by_bin.begin() + bin_start[(size_t)cut[(size_t)s]], by_bin.begin() + bin_start[(size_t)cut[(size_t)s + 1]]);
+      if (!triangulate_subset(in, ids.data(), (int)ids.size(), T) || (int)T.t.size() > base[(size_t)s + 1] - base[(size_t)s]) {
+        failed.store(1);
+        continue;
+      }
+      const int b0 = base[(size_t)s];
+      for (size_t k = 0; k < ids.size(); ++k) G.p[(size_t)ids[k]] = T.p[k];
+      int ghost = -1;
+      for (size_t i = 0; i < T.t.size(); ++i) {
+        Tri t = T.t[i];
+        for (int k = 0; k < 3; ++k) {
+          if (t.v[k] != GHOST) t.v[k] = ids[(size_t)t.v[k]];
+          if (t.n[k] >= 0) t.n[k] += b0;
+        }
+        if (t.alive && t.ghost) {  // (rotated so that the ghost vertex is the last: what the merge reads)
+          while (t.v[2] != GHOST) {
+            const int v0 = t.v[0], n0 = t.n[0];
+            t.v[0] = t.v[1], t.v[1] = t.v[2], t.v[2] = v0;
+            t.n[0] = t.n[1], t.n[1] = t.n[2], t.n[2] = n0;
+          }
+          ghost = b0 + (int)i;
+        }
+        G.t[(size_t)b0 + i] = t;
+      }
+      for (int i = b0 + (int)T.t.size(); i < base[(size_t)s + 1]; ++i) G.t[(size_t)i].alive = 0, G.t[(size_t)i].ghost = 0;
+      comp[(size_t)s] = ghost;
+      if (ghost < 0) failed.store(1);
+    }
+    barrier.wait();
+    if (rank == 0 && prof) t_strips = now();
+    // ---- the merge tree: parts [i, i + w) and [i + w, i + 2 w) ---------------------------------------------------------------
+    int merge_no = 0;
+    for (int w = 1; w < n_strips; w *= 2) {
+      int pair = 0;
+      for (int i = 0; i + w < n_strips; i += 2 * w, ++pair) {
+        const int slot = ghost_base + 2 * (merge_no + pair);
+        if (pair % team == rank && !failed.load()) {
+          stack.clear();
+          const int g = M.merge(comp[(size_t)i], comp[(size_t)i + w], slot, slot + 1, stack);
+          if (g < 0) failed.store(1);
+          comp[(size_t)i] = g;
+        }
+      }
+      merge_no += pair;
+      barrier.wait();
+    }
+    if (rank == 0 && prof) t_merged = now();
+    if (failed.load()) return;
+    // ---- output: real triangles in slot order; an edge by the triangle with the smaller slot (or its only one) -------------------
+    for (int s = rank; s < n_ranges; s += team) {
+      int64_t ct = 0, ce = 0;
+      for (int ti = base[(size_t)s]; ti < base[(size_t)s + 1]; ++ti) {
+        const Tri& tr = G.t[(size_t)ti];
+        if (!tr.alive || tr.ghost) continue;
+        ++ct;
+        for (int i = 0; i < 3; ++i) {
+          const int nb = tr.n[(i + 2) % 3];
+          if (nb < 0 || G.t[(size_t)nb].ghost || nb > ti) ++ce;
+        }
+      }
+      cnt_t[(size_t)s] = ct, cnt_e[(size_t)s] = ce;
+    }
+    barrier.wait();
+    if (rank == 0) {
+      for (int s = 0; s < n_ranges; ++s) at_t[(size_t)s] = total_t, at_e[(size_t)s] = total_e, total_t += cnt_t[(size_t)s], total_e += cnt_e[(size_t)s];
+      *n_tris = (int32_t)total_t, *n_edges = (int32_t)total_e;
+      *fits = (!tris || tri_capacity >= total_t) && (!edges || edge_capacity >= total_e);
+    }
+    barrier.wait();
+    if (!*fits || (!tris && !edges)) return;
+    for (int s = rank; s < n_ranges; s += team) {
+      int64_t kt = at_t[(size_t)s], ke = at_e[(size_t)s];
+      for (int ti = base[(size_t)s]; ti < base[(size_t)s + 1]; ++ti) {
+        const Tri& tr = G.t[(size_t)ti];
+        if (!tr.alive || tr.ghost) continue;
+        if (tris) tris[3 * kt] = tr.v[0], tris[3 * kt + 1] = tr.v[1], tris[3 * kt + 2] = tr.v[2];
+        ++kt;
+        if (!edges) continue;
+        for (int i = 0; i < 3; ++i) {
+          const int nb = tr.n[(i + 2) % 3];
+          if (nb < 0 || G.t[(size_t)nb].ghost || nb > ti) edges[2 * ke] = tr.v[i], edges[2 * ke + 1] = tr.v[(i + 1) % 3], ++ke;
+        }
+      }
+    }
+  });
+  if (!ran || failed.load()) {
+    if (std::getenv("FLAME_DELAUNAY_TRACE")) std::fprintf(stderr, "[delaunay] merge of %d strips gave up\n", n_strips);
+    return false;
+  }
+  // Euler, over what went in: every point of the input is a vertex unless it duplicates another (those are not counted: the check is
+  // triangles against edges, 3 T = 2 E - H with the hull's H from the ghosts -- cheap enough to keep)
+  {
+    int64_t hull = 0;
+    const int g0 = comp[0];
+    int g = g0;
+    do {
+      ++hull, g = G.t[(size_t)g].n[0];
+    } while (g != g0 && hull <= (int64_t)G.t.size());
+    if (3 * total_t != 2 * total_e - hull) {
+      if (std::getenv("FLAME_DELAUNAY_TRACE"))
+        std::fprintf(stderr, "[delaunay] merged strips do not add up: %lld triangles, %lld edges, %lld hull edges\n", (long long)total_t, (long long)total_e, (long long)hull);
+      return false;
+    }
+  }
+  if (prof) std::fprintf(stderr, "[delaunay] %d points, %d strips merged: bins %.3f ms, strips %.3f ms, merges %.3f ms, output %.3f ms\n", n, n_strips,
+                         0.0, t_strips - t0, t_merged - t_strips, now() - t_merged);
+  return true;
+}
+
 }  // namespace
 
 extern "C" int flame_delaunay_triangulate(const float* xy, int32_t n, int32_t* triangles, int32_t tri_capacity,
@@ -671,12 +1026,20 @@ extern "C" int flame_delaunay_triangulate(const float* xy, int32_t n, int32_t* t
   // ---- large inputs: strips in parallel (same triangulation; the order of the output is the strips') ------------------
   // (measured on a 256-core host: 8 480 points 0.83 / 0.65 / 0.64 ms with 8 / 16 / 32 strips, 57 600 points 5.1 / 3.9 / 3.5 ms.  The count fixes
   // the ORDER of the output edges: flame_amd/synth.py pins the former min(32, n / 1024) for the synthetic graphs the fixtures hold)
-  int n_strips = n < 4096 ? 1 : std::min(32, n / 512);
+  int n_strips = n < 4096 ? 1 : std::min(32, n / 256);  // (round 5: merged strips are cheapest at 32 from 8 k points; 16 until round 4)
   if (const char* e = std::getenv("FLAME_DELAUNAY_STRIPS")) n_strips = std::max(1, std::min(std::atoi(e), std::min(64, n / 64 + 1)));  // (tests)
   if (std::getenv("FLAME_DELAUNAY_PROFILE"))
     std::fprintf(stderr, "[delaunay] prep %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_enter);
   if (n_strips > 1) {
     bool fits = true;
+    // round 5: strips of their own points merged along their seams; the certified strips (whose output ORDER the fixtures' synthetic
+    // graphs pin: FLAME_DELAUNAY_MERGE=0, flame_amd/synth.py) when that gives up
+    const char* merge_env = std::getenv("FLAME_DELAUNAY_MERGE");
+    if (!(merge_env && std::atoi(merge_env) == 0)) {
+      if (triangulate_merge(in, n_strips, triangles, tri_capacity, n_triangles, edges, edge_capacity, n_edges, &fits))
+        return fits ? FLAME_NLTGV2_OK : FLAME_NLTGV2_ERR_INVALID_ARG;
+      *n_triangles = 0, *n_edges = 0, fits = true;
+    }
     if (triangulate_strips(in, n_strips, triangles, tri_capacity, n_triangles, edges, edge_capacity, n_edges, &fits))
       return fits ? FLAME_NLTGV2_OK : FLAME_NLTGV2_ERR_INVALID_ARG;
     *n_triangles = 0, *n_edges = 0;

@@ -100,22 +100,24 @@ def delaunay_native(pos: np.ndarray):
     """(triangles, edges) from the library's own triangulator (flame_delaunay_triangulate: host code, exact
     predicates).  The ORDER of the edges depends on how many strips the triangulator cuts the input into; the synthetic
     graphs (and the committed fixtures of them, tests/golden/config_hashes.json) are defined with the strip count of rounds
-    1-3, min(32, n / 1024) from 4096 points -- pinned here, whatever the library's default has become since."""
+    1-3, min(32, n / 1024) from 4096 points, certified strips -- pinned here, whatever the library's default has become since."""
     import os
 
     from .regularizer import delaunay
 
     n = int(np.asarray(pos).reshape(-1, 2).shape[0])
     legacy = 1 if n < 4096 else min(32, n // 1024)
-    before = os.environ.get("FLAME_DELAUNAY_STRIPS")
-    os.environ["FLAME_DELAUNAY_STRIPS"] = str(legacy)
+    pins = {"FLAME_DELAUNAY_STRIPS": str(legacy), "FLAME_DELAUNAY_MERGE": "0"}  # (round 5's merged strips order the output differently too)
+    before = {k: os.environ.get(k) for k in pins}
+    os.environ.update(pins)
     try:
         return delaunay(pos)
     finally:
-        if before is None:
-            del os.environ["FLAME_DELAUNAY_STRIPS"]
-        else:
-            os.environ["FLAME_DELAUNAY_STRIPS"] = before
+        for k, v in before.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
 
 
 def delaunay_edges_native(pos: np.ndarray) -> np.ndarray:
