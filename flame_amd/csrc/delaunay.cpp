@@ -848,17 +848,42 @@ bool triangulate_merge(const Input& in, int n_strips, int32_t* tris, int32_t tri
   const int n_ranges = n_strips + 1;
   base.push_back((int)G.t.size());
   std::atomic<int> failed{0};
-  flame_hip::SpinBarrier barrier(team);
-  // per output range (one per strip + the tangent ghosts hold no real triangle): counts, then offsets
-  std::vector<int64_t> cnt_t((size_t)n_strips + 1, 0), cnt_e((size_t)n_strips + 1, 0), at_t((size_t)n_strips + 1, 0), at_e((size_t)n_strips + 1, 0);
-  int64_t total_t = 0, total_e = 0;
+  // The phases are separated by WORK counters, not by thread barriers: a phase is over when its items are done, whoever did them.  A
+  // thread that wakes late (a pool asleep for a frame: the slowest of 31 wake-ups used to decide when phase 0 ended) finds the items
+  // taken, the counters full, and walks through.
+  struct Phase {
+    std::atomic<int> next{0}, done{0};
+    int total = 0;
+    int take() { return next.fetch_add(1, std::memory_order_relaxed); }
+    void finished() { done.fetch_add(1, std::memory_order_release); }
+    void wait() const {
+      for (int spins = 0; done.load(std::memory_order_acquire) < total; ++spins)
+        if (spins > 4000) std::this_thread::yield();
+    }
+  };
+  // the merge tree: parts [i, i + w) and [i + w, i + 2 w), level by level
+  struct Pair { int left, right, slot; };
+  std::vector<std::vector<Pair>> levels;
+  {
+    int merge_no = 0;
+    for (int w = 1; w < n_strips; w *= 2) {
+      levels.emplace_back();
+      for (int i = 0; i + w < n_strips; i += 2 * w) levels.back().push_back(Pair{i, i + w, ghost_base + 2 * merge_no++});
+    }
+  }
+  std::vector<Phase> merge_phase(levels.size());
+  for (size_t l = 0; l < levels.size(); ++l) merge_phase[l].total = (int)levels[l].size();
+  Phase strips_phase, count_phase, write_phase;
+  strips_phase.total = n_strips, count_phase.total = n_ranges, write_phase.total = n_ranges;
+  // per output range (the strips' slot ranges + the tangent ghosts'): counts, then offsets
+  std::vector<int64_t> cnt_t((size_t)n_ranges, 0), cnt_e((size_t)n_ranges, 0);
   double t_strips = 0, t_merged = 0;
-  const bool ran = W.run_team(team, [&](int rank) {
-    // ---- phase 0: the strips, each into its slot range ----------------------------------------------------------------------
+  W.run(team, [&](int) {
     static thread_local Triangulator T;
     static thread_local std::vector<int> ids;
     static thread_local std::vector<int> stack;
-    for (int s = rank; s < n_strips; s += team) {
+    // ---- phase 0: the strips, each into its slot range ----------------------------------------------------------------------
+    for (int s; (s = strips_phase.take()) < n_strips; strips_phase.finished()) {
       ids.assign(by_bin.begin() + bin_start[(size_t)cut[(size_t)s]], by_bin.begin() + bin_start[(size_t)cut[(size_t)s + 1]]);
       if (!triangulate_subset(in, ids.data(), (int)ids.size(), T) || (int)T.t.size() > base[(size_t)s + 1] - base[(size_t)s]) {
         failed.store(1);
@@ -887,28 +912,25 @@ bool triangulate_merge(const Input& in, int n_strips, int32_t* tris, int32_t tri
       comp[(size_t)s] = ghost;
       if (ghost < 0) failed.store(1);
     }
-    barrier.wait();
-    if (rank == 0 && prof) t_strips = now();
-    // ---- the merge tree: parts [i, i + w) and [i + w, i + 2 w) ---------------------------------------------------------------
-    int merge_no = 0;
-    for (int w = 1; w < n_strips; w *= 2) {
-      int pair = 0;
-      for (int i = 0; i + w < n_strips; i += 2 * w, ++pair) {
-        const int slot = ghost_base + 2 * (merge_no + pair);
-        if (pair % team == rank && !failed.load()) {
-          stack.clear();
-          const int g = M.merge(comp[(size_t)i], comp[(size_t)i + w], slot, slot + 1, stack);
-          if (g < 0) failed.store(1);
-          comp[(size_t)i] = g;
-        }
+    strips_phase.wait();
+    if (prof && t_strips == 0) t_strips = now();
+    // ---- the merge tree ----------------------------------------------------------------------------------------------------
+    for (size_t l = 0; l < levels.size(); ++l) {
+      Phase& ph = merge_phase[l];
+      for (int k; (k = ph.take()) < ph.total; ph.finished()) {
+        if (failed.load()) continue;
+        const Pair& pr = levels[l][(size_t)k];
+        stack.clear();
+        const int g = M.merge(comp[(size_t)pr.left], comp[(size_t)pr.right], pr.slot, pr.slot + 1, stack);
+        if (g < 0) failed.store(1);
+        comp[(size_t)pr.left] = g;
       }
-      merge_no += pair;
-      barrier.wait();
+      ph.wait();
     }
-    if (rank == 0 && prof) t_merged = now();
+    if (prof && t_merged == 0) t_merged = now();
     if (failed.load()) return;
     // ---- output: real triangles in slot order; an edge by the triangle with the smaller slot (or its only one) -------------------
-    for (int s = rank; s < n_ranges; s += team) {
+    for (int s; (s = count_phase.take()) < n_ranges; count_phase.finished()) {
       int64_t ct = 0, ce = 0;
       for (int ti = base[(size_t)s]; ti < base[(size_t)s + 1]; ++ti) {
         const Tri& tr = G.t[(size_t)ti];
@@ -921,16 +943,13 @@ bool triangulate_merge(const Input& in, int n_strips, int32_t* tris, int32_t tri
       }
       cnt_t[(size_t)s] = ct, cnt_e[(size_t)s] = ce;
     }
-    barrier.wait();
-    if (rank == 0) {
-      for (int s = 0; s < n_ranges; ++s) at_t[(size_t)s] = total_t, at_e[(size_t)s] = total_e, total_t += cnt_t[(size_t)s], total_e += cnt_e[(size_t)s];
-      *n_tris = (int32_t)total_t, *n_edges = (int32_t)total_e;
-      *fits = (!tris || tri_capacity >= total_t) && (!edges || edge_capacity >= total_e);
-    }
-    barrier.wait();
-    if (!*fits || (!tris && !edges)) return;
-    for (int s = rank; s < n_ranges; s += team) {
-      int64_t kt = at_t[(size_t)s], ke = at_e[(size_t)s];
+    count_phase.wait();
+    int64_t sum_t = 0, sum_e = 0;  // (every thread forms the same offsets for itself: 33 additions)
+    for (int s = 0; s < n_ranges; ++s) sum_t += cnt_t[(size_t)s], sum_e += cnt_e[(size_t)s];
+    if (!((!tris || tri_capacity >= sum_t) && (!edges || edge_capacity >= sum_e)) || (!tris && !edges)) return;
+    for (int s; (s = write_phase.take()) < n_ranges; write_phase.finished()) {
+      int64_t kt = 0, ke = 0;
+      for (int r = 0; r < s; ++r) kt += cnt_t[(size_t)r], ke += cnt_e[(size_t)r];
       for (int ti = base[(size_t)s]; ti < base[(size_t)s + 1]; ++ti) {
         const Tri& tr = G.t[(size_t)ti];
         if (!tr.alive || tr.ghost) continue;
@@ -944,7 +963,13 @@ bool triangulate_merge(const Input& in, int n_strips, int32_t* tris, int32_t tri
       }
     }
   });
-  if (!ran || failed.load()) {
+  int64_t total_t = 0, total_e = 0;
+  for (int s = 0; s < n_ranges; ++s) total_t += cnt_t[(size_t)s], total_e += cnt_e[(size_t)s];
+  if (!failed.load()) {
+    *n_tris = (int32_t)total_t, *n_edges = (int32_t)total_e;
+    *fits = (!tris || tri_capacity >= total_t) && (!edges || edge_capacity >= total_e);
+  }
+  if (failed.load()) {
     if (std::getenv("FLAME_DELAUNAY_TRACE")) std::fprintf(stderr, "[delaunay] merge of %d strips gave up\n", n_strips);
     return false;
   }

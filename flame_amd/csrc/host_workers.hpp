@@ -26,18 +26,7 @@ class Workers {
   }
   int threads() const { return n_threads_; }
   // runs job(0) .. job(n - 1), the calling thread included; returns when all are done
-  void run(int n, const std::function<void(int)>& job) { run_region(n, job, false); }
-  // the same with every job on a thread of ITS OWN, all at the same time (n <= threads(), else false and nothing runs): the jobs may
-  // wait for each other -- a team that goes through several phases separated by a SpinBarrier pays the wake-up of the pool once, not
-  // once per phase (~30 us each on a condition variable)
-  bool run_team(int n, const std::function<void(int)>& job) {
-    if (n > n_threads_) return false;
-    run_region(n, job, true);
-    return true;
-  }
-
- private:
-  void run_region(int n, const std::function<void(int)>& job, bool one_each) {
+  void run(int n, const std::function<void(int)>& job) {
     std::unique_lock<std::mutex> call(call_mtx_);  // one parallel region at a time
     if (n_threads_ <= 1 || n <= 1) {
       for (int i = 0; i < n; ++i) job(i);
@@ -47,7 +36,7 @@ class Workers {
     // worker that was preempted between two regions only ever sees the (finished) region it belongs to: its next index is
     // >= that region's n and it goes back to sleep without touching the new region's job or counters.
     auto region = std::make_shared<Region>();
-    region->job = &job, region->n = n, region->pending = n, region->one_each = one_each;
+    region->job = &job, region->n = n, region->pending = n;
     {
       std::lock_guard<std::mutex> lk(mtx_);
       region_ = region, ++generation_;
@@ -59,6 +48,7 @@ class Workers {
     region_.reset();
   }
 
+ private:
   Workers() {
     int want = (int)std::thread::hardware_concurrency();
     if (const char* e = std::getenv("FLAME_DELAUNAY_THREADS")) want = std::atoi(e);
@@ -78,7 +68,6 @@ class Workers {
     int n = 0;
     std::atomic<int> next{0};
     int pending = 0;  // under mtx_
-    bool one_each = false;
   };
   void work(Region& r) {
     for (;;) {
@@ -87,7 +76,6 @@ class Workers {
       (*r.job)(i);
       std::lock_guard<std::mutex> lk(mtx_);
       if (--r.pending == 0) done_cv_.notify_all();
-      if (r.one_each) return;  // (a team: this thread's job may have waited for the others -- it must not hold a second one back)
     }
   }
   void loop() {
@@ -113,27 +101,6 @@ class Workers {
   bool stop_ = false;
 };
 
-
-// A barrier for the jobs of Workers::run_team: spins (the phases it separates are microseconds long), yields when the wait gets long
-// (an oversubscribed host).
-class SpinBarrier {
- public:
-  explicit SpinBarrier(int n) : n_(n) {}
-  void wait() {
-    const int g = gen_.load(std::memory_order_acquire);
-    if (count_.fetch_add(1, std::memory_order_acq_rel) + 1 == n_) {
-      count_.store(0, std::memory_order_relaxed);
-      gen_.fetch_add(1, std::memory_order_release);
-      return;
-    }
-    for (int spins = 0; gen_.load(std::memory_order_acquire) == g; ++spins)
-      if (spins > 4000) std::this_thread::yield();
-  }
-
- private:
-  const int n_;
-  std::atomic<int> count_{0}, gen_{0};
-};
 
 // job(begin, end) over [0, n) in `parts` contiguous chunks
 inline void parallel_chunks(int64_t n, int parts, const std::function<void(int64_t, int64_t)>& job) {
