@@ -184,3 +184,65 @@ def test_parallel_strips_equal_the_sequential_triangulation(built, case):
         a, b, c = p[tris[:, 0]], p[tris[:, 1]], p[tris[:, 2]]
         assert np.all((b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0]) > 0)
         assert len(_sets(tris, edges)[1]) == len(edges)
+
+
+def _locally_delaunay_exact(pos, tris):
+    """Every interior edge of the triangulation passes the in-circle test with the vertex across it -- in exact integer arithmetic
+    (the coordinates are small integers)."""
+    p = np.asarray(pos, dtype=np.int64)
+    t = np.asarray(tris, dtype=np.int64)
+    owner = {}
+    for ti, (a, b, c) in enumerate(t.tolist()):
+        for u, v, w in ((a, b, c), (b, c, a), (c, a, b)):
+            owner[(u, v)] = (ti, w)
+    bad = 0
+    for (u, v), (ti, w) in owner.items():
+        other = owner.get((v, u))
+        if other is None:
+            continue
+        d = other[1]
+        ax, ay = (p[u] - p[d]).tolist()
+        bx, by = (p[v] - p[d]).tolist()
+        cx, cy = (p[w] - p[d]).tolist()
+        det = (ax * ax + ay * ay) * (bx * cy - cx * by) + (bx * bx + by * by) * (cx * ay - ax * cy) + (cx * cx + cy * cy) * (ax * by - bx * ay)
+        bad += det > 0  # d strictly inside the circle through u, v, w (counter-clockwise)
+    return bad == 0
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_merged_strips_on_degenerate_inputs_are_delaunay(built, seed):
+    """Round 5: strips of their own points merged along their seams (lower tangent, zipper over the hulls' ghost triangles, Lawson
+    flips).  Integer pixel positions -- collinear runs on the hulls and along the seams, co-circular quadruples everywhere -- have
+    many Delaunay triangulations: whatever the merge returns must BE one (exact in-circle test across every interior edge, every
+    triangle counter-clockwise, Euler), with the counts of the sequential build; for 2 ... 32 strips."""
+    from flame_amd.regularizer import delaunay
+
+    rng = np.random.default_rng(seed)
+    n = (5000, 7000, 4500, 9000)[seed - 1]
+    w, h = ((640, 480), (400, 300), (1280, 96), (320, 240))[seed - 1]   # (seed 3: strips much taller than wide would be; seed 4: dense)
+    pos = np.unique(rng.integers(0, [w, h], (n, 2)), axis=0).astype(np.float32)
+    if seed == 2:  # plus full rows and columns: long collinear runs across every seam
+        rows = np.stack([np.arange(w, dtype=np.float32), np.full(w, 150.0, np.float32)], 1)
+        cols = np.stack([np.full(h, 200.0, np.float32), np.arange(h, dtype=np.float32)], 1)
+        pos = np.unique(np.concatenate([pos, rows, cols]), axis=0).astype(np.float32)
+    if len(pos) < 4096:
+        pos = np.unique(np.concatenate([pos, rng.integers(0, [w, h], (6000, 2)).astype(np.float32)]), axis=0)
+    old = {k: os.environ.get(k) for k in ("FLAME_DELAUNAY_STRIPS", "FLAME_DELAUNAY_MERGE")}
+    try:
+        os.environ["FLAME_DELAUNAY_STRIPS"] = "1"
+        t_seq, e_seq = delaunay(pos)
+        for strips in (2, 7, 16, 32):
+            os.environ["FLAME_DELAUNAY_STRIPS"], os.environ["FLAME_DELAUNAY_MERGE"] = str(strips), "1"
+            t, e = delaunay(pos)
+            assert len(t) == len(t_seq) and len(e) == len(e_seq), (strips, len(t), len(t_seq))
+            p = pos.astype(np.float64)
+            a, b, c = p[t[:, 0]], p[t[:, 1]], p[t[:, 2]]
+            assert np.all((b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0]) > 0)
+            assert len({(min(u, v), max(u, v)) for u, v in e.tolist()}) == len(e)
+            assert _locally_delaunay_exact(pos, t), strips
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
