@@ -43,22 +43,6 @@ if want misc; then
   run gather_tax.txt env FREE_CUS_PER_XCD=2 python tools/export_tax.py
   for q in 4 8 1; do run gather_overlap.txt env GPU_MAX_HW_QUEUES=$q python tools/overlap_probe.py; done
   run gather_tax.txt bash tools/gather_tax.sh
-  FLAME_DELAUNAY_PROFILE=1 python - >> $O/delaunay.txt 2>&1 <<'PY'
-import os, time, numpy as np, sys
-sys.path.insert(0, os.getcwd())
-from flame_amd import synth
-from flame_amd.regularizer import delaunay
-for size in ("640x480", "1920x1080"):
-    pos = np.ascontiguousarray(synth.make_graph(size, seed=1234)["pos"], dtype=np.float32)
-    for strips in ("", "1", "8", "16", "32"):
-        if strips:
-            os.environ["FLAME_DELAUNAY_STRIPS"] = strips
-        else:
-            os.environ.pop("FLAME_DELAUNAY_STRIPS", None)
-        ts = []
-        for _ in range(12):
-            t = time.perf_counter(); delaunay(pos); ts.append((time.perf_counter() - t) * 1e3)
-        print(f"{size} {len(pos)} points, strips {strips or 'default'}: median {np.median(ts):.3f} min {min(ts):.3f} ms", flush=True)
-PY
+  run delaunay.txt python tools/delaunay_probe.py
 fi
 ls -la $O
