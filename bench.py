@@ -696,10 +696,12 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
                             .astype(_np.float32)])
     fid = _np.concatenate([fid, _np.arange(g["V"], g["V"] + n_new, dtype=_np.int32)])
     data2 = _np.concatenate([g["data_term"][keep], _np.ones(n_new, _np.float32)])
-    t_d0 = _t.perf_counter()
-    tris2, edges2 = flame_amd.delaunay(pos2)  # (the library's default strip count; the synthetic graphs pin their own: synth.delaunay_native)
-    t_d1 = _t.perf_counter()
-    out["delaunay"] = {"triangulate_ms": round((t_d1 - t_d0) * 1e3, 3), "points": int(len(pos2)), "triangles": int(len(tris2)),
+    t_tri = []
+    for _ in range(7):  # (the library's default: merged strips; the synthetic graphs pin their own order: synth.delaunay_native)
+        t_d0 = _t.perf_counter()
+        tris2, edges2 = flame_amd.delaunay(pos2)
+        t_tri.append((_t.perf_counter() - t_d0) * 1e3)
+    out["delaunay"] = {"triangulate_ms": round(sorted(t_tri)[len(t_tri) // 2], 3), "first_call_ms": round(t_tri[0], 3), "points": int(len(pos2)), "triangles": int(len(tris2)),
                        "note": "host code (the reference's Triangle is host code too), exact predicates"}
     r.upload_graph(g)
     r.run(params, 50)
