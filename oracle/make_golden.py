@@ -71,8 +71,51 @@ def make_delaunay_fixture():
     print("delaunay_ref_triangle", {k: v.shape for k, v in out.items() if k.endswith("triangles")}, os.path.getsize(path) // 1024, "KiB")
 
 
+def canonical_digests(tris, edges):
+    """SHA-256 of the sorted triangle set (each triangle rotated to start at its smallest vertex: the winding is kept) and of the sorted
+    undirected edge set."""
+    import hashlib
+
+    t = np.asarray(tris, dtype=np.int64).reshape(-1, 3)
+    k = np.argmin(t, axis=1)
+    t = np.take_along_axis(t, (np.arange(3)[None, :] + k[:, None]) % 3, 1)
+    t = t[np.lexsort((t[:, 2], t[:, 1], t[:, 0]))]
+    e = np.sort(np.asarray(edges, dtype=np.int64).reshape(-1, 2), axis=1)
+    e = e[np.lexsort((e[:, 1], e[:, 0]))]
+    return hashlib.sha256(t.astype("<i4").tobytes()).hexdigest(), hashlib.sha256(e.astype("<i4").tobytes()).hexdigest()
+
+
+def large_delaunay_sets():
+    """Point sets of more than 4096 points -- what flame_delaunay_triangulate cuts into strips -- regenerated from their seeds."""
+    rng = np.random.default_rng(4096)
+    return {
+        "jittered_640x480": synth.make_points(640, 480, 6, 7),
+        "uniform_6000": (rng.random((6000, 2)) * [640, 480]).astype(np.float32),
+        "clustered_5400": np.concatenate([rng.normal(c, s, (1800, 2)) for c, s in (((120, 100), 25.0), ((330, 260), 60.0), ((520, 380), 12.0))]).astype(np.float32),
+    }
+
+
+def make_large_delaunay_fixture():
+    """Digests of what the REFERENCE's vendored Triangle (oracle/_ref) makes of the large sets: they pin the strip paths of the
+    triangulator (merged strips, certified strips) the way delaunay_ref_triangle.npz pins the sequential one."""
+    import json
+
+    out = {}
+    for name, pts in large_delaunay_sets().items():
+        t, e = ref_triangle.delaunay_triangles(pts), ref_triangle.delaunay_edges(pts)
+        ht, he = canonical_digests(t, e)
+        out[name] = {"points": int(len(pts)), "triangles": int(len(t)), "edges": int(len(e)), "triangles_sha256": ht, "edges_sha256": he}
+    path = os.path.join(OUT, "delaunay_ref_triangle_large.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("delaunay_ref_triangle_large", {k: (v["points"], v["triangles"]) for k, v in out.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    make_large_delaunay_fixture()
+    if os.environ.get("GOLDEN_ONLY_DELAUNAY_LARGE"):
+        return
     make_delaunay_fixture()
     if os.environ.get("GOLDEN_ONLY_DELAUNAY"):
         return

@@ -246,3 +246,36 @@ def test_merged_strips_on_degenerate_inputs_are_delaunay(built, seed):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+@pytest.mark.parametrize("name", ["jittered_640x480", "uniform_6000", "clustered_5400"])
+def test_strip_paths_equal_reference_triangle_run_on_large_sets(built, name):
+    """The strip paths (>= 4096 points: merged strips, the default since round 5; certified strips) against the REFERENCE's Triangle run
+    here (oracle/make_golden.py: make_large_delaunay_fixture, oracle/_ref): the sorted triangle set and the sorted edge set, by their
+    SHA-256 -- the point sets are regenerated from their seeds."""
+    import json
+
+    from flame_amd.regularizer import delaunay
+    from oracle.make_golden import canonical_digests, large_delaunay_sets
+
+    want = json.load(open(os.path.join(GOLDEN, "delaunay_ref_triangle_large.json")))[name]
+    pts = large_delaunay_sets()[name]
+    assert len(pts) == want["points"]
+    old = {k: os.environ.get(k) for k in ("FLAME_DELAUNAY_STRIPS", "FLAME_DELAUNAY_MERGE")}
+    try:
+        for strips, merge in ((None, "1"), ("7", "1"), ("32", "1"), (None, "0"), ("1", "1")):
+            os.environ["FLAME_DELAUNAY_MERGE"] = merge
+            if strips is None:
+                os.environ.pop("FLAME_DELAUNAY_STRIPS", None)
+            else:
+                os.environ["FLAME_DELAUNAY_STRIPS"] = strips
+            t, e = delaunay(pts)
+            assert (len(t), len(e)) == (want["triangles"], want["edges"]), (strips, merge)
+            ht, he = canonical_digests(t, e)
+            assert ht == want["triangles_sha256"] and he == want["edges_sha256"], (strips, merge)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
