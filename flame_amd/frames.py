@@ -79,8 +79,10 @@ class IdepthGather:
         # and the rows are given back to the solvers by a HOST wait for the collective two steps back.  The solver's in-order queue
         # then holds its launches only: the event torch records for the collective and the wait before a row is reused were two
         # operations per step between two solver launches, 10 us of a 185 us step.
-        if stream is not None and not self._staged and torch.device(device).type == "cuda":
-            self._side = torch.cuda.Stream(device=device)
+        import os
+
+        if stream is not None and not self._staged and torch.device(device).type == "cuda" and os.environ.get("FLAME_GATHER_SIDE_STREAM", "1") != "0":
+            self._side = torch.cuda.Stream(device=device)  # (FLAME_GATHER_SIDE_STREAM=0: the collective ordered by torch's own events on the solver's stream)
             self._done_ev = [torch.cuda.Event(), torch.cuda.Event()]
         self.local = self._local[0]
         self.gathered = self._gathered[0]
