@@ -6,7 +6,8 @@
 //   flame_hip::SolverLoop<Graph> loop(&graph_, &graph_mtx_, params);   // in Flame::Flame
 //   loop.start();
 //   ...
-//   {  std::lock_guard<std::recursive_mutex> lock(graph_mtx_);          // Flame::update, as today (flame.cc:302-381)
+//   {  std::lock_guard<std::mutex> lock(graph_mtx_);                    // Flame::update, as today (flame.cc:302-381; graph_mtx_ is a
+//                                                                       //  plain std::mutex, flame.h:539 -- update_mtx_ is the recursive one)
 //      loop.readBack();                  // x, w1, w2, q of the device image -> graph_   (before reading / editing it)
 //      syncGraph(); ...                  // edit graph_
 //      loop.markDirty();                 // the loop uploads the edited graph before its next round
@@ -56,7 +57,7 @@
 
 namespace flame_hip {
 
-template <class Graph, class GraphMutex = std::recursive_mutex>
+template <class Graph, class GraphMutex = std::mutex>  // flame.h:539: `std::mutex graph_mtx_;`
 class SolverLoop {
  public:
   typedef flame::optimizers::nltgv2_l1_graph_regularizer::hip::Params Params;
@@ -135,12 +136,22 @@ class SolverLoop {
     f(dev_, iterations_.load());
     // device mode: a call that settled the solver leaves the queue empty -- the caller, who holds the device anyway, fills it again
     // before it lets go (the solver thread would need a wake-up for it: ~0.1 ms of a standing solver per call)
+    // (not after the solver thread has ended, on an error or a stop: nobody would ever check those rounds; and what top_up() throws
+    // -- its periodic sync() -- is the LOOP's error, kept in error(): f has succeeded and the frame thread's call must not fail for it)
     bool ready;
     {
       std::lock_guard<std::mutex> lk(state_mtx_);
-      ready = device_ready_ && !stop_.load();
+      ready = device_ready_ && !stop_.load() && !exited_ && error_.empty() && thread_.joinable();
     }
-    if (graph_ == nullptr && ready) top_up();
+    if (graph_ == nullptr && ready) {
+      try {
+        top_up();
+      } catch (const std::exception& e) {
+        std::lock_guard<std::mutex> lk(state_mtx_);
+        error_ = e.what();
+        stop_.store(true);
+      }
+    }
   }
   // Device mode: the image uploaded through withDevice() is what the loop iterates on from now on.
   void deviceReady() {

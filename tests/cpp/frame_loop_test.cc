@@ -98,7 +98,7 @@ int main(int argc, char** argv) {
     flame_stereo_params sp;
     flame_stereo_default_params(&sp);
     const dgraph::Params params;
-    std::recursive_mutex graph_mtx;
+    std::mutex graph_mtx;
     flame_hip::SolverLoop<flame_hip::FlatGraph> loop(nullptr, &graph_mtx, params, iters_per_round);
     loop.start();
     bool first = true;

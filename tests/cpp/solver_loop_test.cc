@@ -95,7 +95,7 @@ int main() {
   const nltgv2_params cp = {params.data_factor, params.step_x, params.step_q, params.theta, params.x_min, params.x_max};
   unsigned long long seed = 99;
   flame_hip::FlatGraph graph = make_graph(30, 22, 7), ref = graph;
-  std::recursive_mutex graph_mtx;
+  std::mutex graph_mtx;
 
   {  // ---- (1) three frames with a fixed budget: 5 rounds of 20 iterations per upload ----------------------------------
     flame_hip::SolverLoop<flame_hip::FlatGraph> loop(&graph, &graph_mtx, params, 20, 5);
@@ -107,7 +107,7 @@ int main() {
                     (unsigned long long)loop.iterations(), loop.error().c_str());
         return 1;
       }
-      std::lock_guard<std::recursive_mutex> lock(graph_mtx);
+      std::lock_guard<std::mutex> lock(graph_mtx);
       fails += !loop.readBack();
       oracle_run(&ref, cp, 100);
       char what[64];
@@ -134,7 +134,7 @@ int main() {
     }
     fails += !wait_for([&] { return loop.iterations() >= 400; }, 3000);
     {
-      std::lock_guard<std::recursive_mutex> lock(graph_mtx);
+      std::lock_guard<std::mutex> lock(graph_mtx);
       fails += !loop.readBack();
       oracle_run(&ref, cp, 100);
       fails += compare(graph, ref, "after the last frame");
@@ -152,7 +152,7 @@ int main() {
       flame_hip::SolverLoop<flame_hip::FlatGraph> loop(&graph, &graph_mtx, params, 50);
       loop.start();
       fails += !wait_for([&] { return loop.iterations() >= 2000; }, 3000);
-      std::lock_guard<std::recursive_mutex> lock(graph_mtx);
+      std::lock_guard<std::mutex> lock(graph_mtx);
       fails += !loop.readBack();
       its = loop.iterations();
     }
@@ -172,7 +172,7 @@ int main() {
     ok = ok && loop.running() && wait_for([&] { return loop.iterations() >= 50; }, 3000);
     const auto t0 = std::chrono::steady_clock::now();
     {
-      std::lock_guard<std::recursive_mutex> lock(graph_mtx);  // the caller edits ...
+      std::lock_guard<std::mutex> lock(graph_mtx);  // the caller edits ...
       graph.vertices[0].data_term += 0.01f;
       loop.markDirty();                                        // ... the loop now wants the mutex for its re-upload ...
       std::this_thread::sleep_for(std::chrono::milliseconds(20));
