@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip batched / other-config measurements")
     ap.add_argument("--cpu-iters", type=int, default=20000)
-    ap.add_argument("--persistent", type=int, default=1, help="0: one launch per step; 1: persistent single launch (form by size); 3 / 4 / 6 / 7: the vertex-per-lane / patch-per-wave / two-half-edges / region-per-workgroup form by name")
+    ap.add_argument("--persistent", type=int, default=1, help="0: one launch per step; 1: persistent single launch (form by size); 3 / 4 / 6: the vertex-per-lane / patch-per-wave / two-half-edges form by name")
     return ap.parse_args()
 
 
@@ -196,7 +196,7 @@ def main():
         # bytes per launch = iters * (64V + 40E) and the average launch duration is the time between two HIP events on the
         # solver's stream around the K back-to-back launches, divided by K (it includes the gap between two launches).  Per-step path: one k_fused_step launch per
         # iteration; the event time divided by the launches then includes the ~3.5 us dependent-launch gaps.
-        kernel = {"persistent-pv": "k_persistent_pv", "persistent-pv2": "k_persistent_pv2", "persistent-tv": "k_persistent_tv", "persistent-rg": "k_persistent_rg"}.get(run_path, "k_fused_step")
+        kernel = {"persistent-pv": "k_persistent_pv", "persistent-pv2": "k_persistent_pv2", "persistent-tv": "k_persistent_tv"}.get(run_path, "k_fused_step")
         persistent = run_path.startswith("persistent")
         launches_per_step = 1 if persistent else a.iters
         launch_us = ev_ms * 1e3 / (a.steps * launches_per_step)
@@ -491,8 +491,8 @@ def onchip_roofline(valu, oc, waves_per_cu):
     * `valu_pipe_throughput_frac` = SQ_INSTS_VALU / time / (1024 SIMD-32 x 2.4 GHz / 2): the share of the vector pipes' ISSUE SLOTS
       used (a wave64 instruction takes a SIMD-32 two cycles).  A third at 30 frames: the pipes are not the limit.
     * `wave_issue_busy_frac` = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x waves per SIMD: the share of SIMD cycles in which one of its
-      waves has a vector instruction IN FLIGHT, issue to completion.  A lone wave issues one instruction per ~5 cycles (this round's
-      diagnostics: tools/rg_step_cost.py, 5 cycles x instructions + LDS latencies reproduces the measured step), because each
+      waves has a vector instruction IN FLIGHT, issue to completion.  A lone wave issues one instruction per ~5 cycles (round 5's
+      diagnostics of the region form, profiles/r05_wg_region.txt: 5 cycles x instructions + LDS latencies reproduces the measured step), because each
       instruction of its chain waits for the one before; W waves per SIMD interleave W such chains.  When this fraction nears 1 every
       cycle of the SIMD is covered by some wave's dependent instruction: adding waves no longer adds progress, although half the issue
       slots stay empty.  THIS is the binding measure of these kernels (wave64 on SIMD-32 with dependent chains), and `frac`."""
@@ -618,29 +618,6 @@ def extras(a, reg, params, out, flame_amd, synth, sync, info):
     except Exception as e:  # the extras never take the line down
         oc["1280x720"]["floor"] = f"{type(e).__name__}: {e}"
     out["other_configs"] = oc
-    # (2b) round 5: the region-per-workgroup form (k_persistent_rg) by name on the headline graph -- a workgroup per compact region, a
-    #      recomputed ghost ring of k steps, ONE L2 hand-off per block of k steps.  Measured, bit-identical, and slower than the
-    #      patch-per-wave form: the planner never picks it (profiles/r05_wg_region.txt says where its time goes).
-    try:
-        from flame_amd.regularizer import OPT_PERSISTENT as _OP, OPT_RG_DEPTH as _OD
-
-        g = synth.make_graph(a.config, seed=1234)
-        rf = {}
-        for kk in (2, 3):
-            r = flame_amd.Regularizer(0)
-            r.set_option(_OP, 7)
-            r.set_option(_OD, kk)
-            r.upload_graph(g)
-            r.run(params, a.iters)
-            ms, ms_min = timed_launches(r, params, a.iters)
-            ri = r.info()
-            rf[f"k{kk}"] = {"run_path": flame_amd.regularizer.RUN_PATHS.get(ri["last_run_path"], "?"), "regions": ri["regions"], "steps_per_block": ri["region_depth"],
-                            "waves_per_cu": ri["last_run_waves_per_cu"], "per_iteration_us": round(ms * 1e3 / a.iters, 4),
-                            "frac": round(ri["algorithmic_bytes_per_iter"] * a.iters / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
-            r.close()
-        out["region_form"] = dict(rf, note="FLAME_NLTGV2_OPT_PERSISTENT = 7, by name only; same graph as the headline line")
-    except Exception as e:  # the extras never take the line down
-        out["region_form"] = f"{type(e).__name__}: {e}"
     # (3) what the boundary costs when the host hands over fresh buffers every frame (PCIe-inclusive;
     #     never part of `value`): upload = host pack + H2D + device pack, download = unpack + D2H
     import time as _t

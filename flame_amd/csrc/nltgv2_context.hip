@@ -226,7 +226,7 @@ int topology_buffers(flame_nltgv2_ctx* ctx, bool want_e2, size_t n_wg_info, size
   }
   ctx->topo++;
   ctx->layout_pos_saved = false;  // (the positions that are about to stand ARE the layout's)
-  ctx->tv_built = ctx->wg2_built = ctx->rg_built = false;
+  ctx->tv_built = ctx->wg2_built = false;
   drop_graphs(ctx);
   refresh_args(ctx);
   return 0;
@@ -392,60 +392,6 @@ int ensure_form_rows(flame_nltgv2_ctx* ctx, int form) {
     ctx->wg2_built = true;
     ctx->wg2_usable = L.wg2_ok, ctx->wg2_checked_topo = ctx->topo;  // (the host builder knows)
   }
-  const int rg_depth = ctx->opt_rg_depth > 0 ? ctx->opt_rg_depth : kRgDepth;
-  const int rg_regions = ctx->opt_rg_regions > 0 ? ctx->opt_rg_regions : ctx->prop.multiProcessorCount;
-  if (form == 5 && (!ctx->rg_built || ctx->rg_depth_built != rg_depth || ctx->rg_regions_built != rg_regions)) {
-    // Layout (R): regions by coordinate bisection of the positions the layout was built from, ghost rings, lanes, fetch lists --
-    // on the host (nltgv2_regions.hpp), once per topology.
-    ctx->rg_built = true, ctx->rg_usable = false;
-    ctx->rg_depth_built = rg_depth, ctx->rg_regions_built = rg_regions;
-    ctx->rg_args = RgArgs{};
-    int rc = ensure_host_layout(ctx);
-    if (rc) return rc;
-    std::vector<float> hpos(2 * (size_t)L.V);
-    if (L.V) HIPCHK(ctx, hipMemcpyAsync(hpos.data(), ctx->layout_pos_saved ? ctx->layout_pos.p : ctx->pos.p, sizeof(float) * hpos.size(), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    flame_nltgv2_graph g{};
-    g.V = L.V, g.E = L.E, g.pos = hpos.data(), g.src = ctx->h_src.data(), g.dst = ctx->h_dst.data();
-    RegionLayout& R = ctx->RG;
-    rc = build_regions(&g, L, rg_regions, rg_depth, &R);
-    if (rc) return fail(ctx, rc);
-    if (R.ok && rg_lds_bytes(R) <= 160u * 1024u) {
-      const struct { const void* src; size_t bytes; } cp[14] = {
-          {R.info.data(), sizeof(int32_t) * R.info.size()}, {R.v_pv.data(), sizeof(int32_t) * R.v_pv.size()}, {R.v_meta.data(), sizeof(uint32_t) * R.v_meta.size()},
-          {R.e_slot_src.data(), sizeof(int32_t) * R.e_slot_src.size()}, {R.e_slot_dst.data(), sizeof(int32_t) * R.e_slot_dst.size()},
-          {R.e_id.data(), sizeof(int32_t) * R.e_id.size()}, {R.e_li.data(), sizeof(uint32_t) * R.e_li.size()}, {R.e_meta.data(), sizeof(uint32_t) * R.e_meta.size()},
-          {R.f_src.data(), sizeof(int32_t) * R.f_src.size()}, {R.f_prod.data(), sizeof(int32_t) * R.f_prod.size()}, {R.v_fa.data(), sizeof(int32_t) * R.v_fa.size()},
-          {R.e_fq.data(), sizeof(int32_t) * R.e_fq.size()}, {R.e_fbs.data(), sizeof(int32_t) * R.e_fbs.size()}, {R.e_fbd.data(), sizeof(int32_t) * R.e_fbd.size()}};
-      for (int i = 0; i < 14; ++i) {
-        rc = ensure(ctx, ctx->rg_tab[i], cp[i].bytes + 16);
-        if (!rc) rc = h2d(ctx, ctx->rg_tab[i], cp[i].src, cp[i].bytes);
-        if (rc) return rc;
-      }
-      const size_t xbytes = (size_t)4 * R.n_rec * 16 + sizeof(unsigned) * (size_t)R.n_regions + 64;
-      rc = ensure(ctx, ctx->rg_xbuf, xbytes);
-      if (rc) return rc;
-      HIPCHK(ctx, hipMemsetAsync(ctx->rg_xbuf.p, 0, xbytes, ctx->stream));  // (no record or tag of an earlier topology survives)
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (the tables were copied out of pageable vectors)
-      RgArgs& a = ctx->rg_args;
-      a.info = (const int32_t*)ctx->rg_tab[0].p, a.v_pv = (const int32_t*)ctx->rg_tab[1].p, a.v_meta = (const uint32_t*)ctx->rg_tab[2].p;
-      a.e_slot_src = (const int32_t*)ctx->rg_tab[3].p, a.e_slot_dst = (const int32_t*)ctx->rg_tab[4].p, a.e_id = (const int32_t*)ctx->rg_tab[5].p;
-      a.e_li = (const uint32_t*)ctx->rg_tab[6].p, a.e_meta = (const uint32_t*)ctx->rg_tab[7].p;
-      a.f_src = (const int32_t*)ctx->rg_tab[8].p, a.f_prod = (const int32_t*)ctx->rg_tab[9].p, a.v_fa = (const int32_t*)ctx->rg_tab[10].p;
-      a.e_fq = (const int32_t*)ctx->rg_tab[11].p, a.e_fbs = (const int32_t*)ctx->rg_tab[12].p, a.e_fbd = (const int32_t*)ctx->rg_tab[13].p;
-      a.xbuf = (char*)ctx->rg_xbuf.p;
-      a.n_regions = R.n_regions, a.depth = R.depth, a.block_threads = R.block_threads, a.nb_cap = R.nb_cap, a.nc_cap = R.nc_cap;
-      a.deg_cap = R.deg_cap, a.f_cap = R.f_cap, a.n_packed = R.n_packed, a.n_rec = R.n_rec;
-      a.lds_bytes = (unsigned)rg_lds_bytes(R);
-      // all regions resident at once: what the runtime keeps of this instance per CU (LDS, registers)
-      const int per_cu = rg_blocks_per_cu(a, ctx->opt_probe != 0);
-      ctx->rg_usable = per_cu > 0 && (int64_t)per_cu * ctx->prop.multiProcessorCount >= ((R.n_regions + 7) / 8) * 8;
-      if (std::getenv("FLAME_NLTGV2_TRACE"))
-        std::fprintf(stderr, "[flame_nltgv2] rg: %d regions, depth %d, %d threads, LDS %u B, %d per CU -> %s; per region: owned %.1f computed %.1f local %.1f edges %.1f fetch %.1f\n",
-                     R.n_regions, R.depth, R.block_threads, a.lds_bytes, per_cu, ctx->rg_usable ? "usable" : "not resident", (double)R.sum_owned / R.n_regions,
-                     (double)R.sum_computed / R.n_regions, (double)R.sum_local / R.n_regions, (double)R.sum_edges / R.n_regions, (double)R.sum_fetch / R.n_regions);
-    }
-  }
   if (form == 2 && !ctx->tv_built) {
     build_tv_rows(&L);
     struct { DevBuf* b; const void* src; size_t bytes; } cp[] = {
@@ -537,10 +483,10 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
     static std::once_flag warm;
     if (!std::getenv("FLAME_NLTGV2_NO_WARM"))
     std::call_once(warm, [ctx] {
-      warm_module_kernels(), warm_module_persistent(ctx->own_stream), warm_module_persistent_tv(), warm_module_persistent_pv2(), warm_module_persistent_rg();
+      warm_module_kernels(), warm_module_persistent(ctx->own_stream, cooperative_allowed()), warm_module_persistent_tv(), warm_module_persistent_pv2();
       warm_module_layout(), warm_module_topo();
     });
-    if (!std::getenv("FLAME_NLTGV2_LAZY_CALIBRATION") && ctx->prop.multiProcessorCount >= 64 && place_calibrate(ctx) != 0) {
+    if (!std::getenv("FLAME_NLTGV2_LAZY_CALIBRATION") && ctx->prop.multiProcessorCount >= 64 && place_calibrate_at_create(device) && place_calibrate(ctx) != 0) {
       ctx->last_error = 0, ctx->last_hip = 0;
       (void)hipGetLastError();
     }
@@ -558,8 +504,6 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
               &ctx->wg_vfirst, &ctx->place_pool, &ctx->place_rank, &ctx->place_fill, &ctx->place_rec_off, &ctx->place_patch, &ctx->place_meas, &ctx->progress};
   for (DevBuf* b : {&ctx->feat_stamp_d, &ctx->feat_key_d, &ctx->feat_val_d, &ctx->topo_scratch, &ctx->topo_dims, &ctx->layout_pos}) ctx->all.push_back(b);
   for (auto& b : ctx->nx) ctx->all.push_back(&b);
-  for (auto& b : ctx->rg_tab) ctx->all.push_back(&b);
-  ctx->all.push_back(&ctx->rg_xbuf);
   for (auto& b : ctx->sp_v) ctx->all.push_back(&b);
   for (auto& b : ctx->sp_q) ctx->all.push_back(&b);
   *out = ctx;
@@ -617,16 +561,13 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
       ctx->opt_block_waves = value;
       return 0;
     case FLAME_NLTGV2_OPT_PERSISTENT:
-      if (value < 0 || value > 7 || value == 2 || value == 5) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // (2: the retired lane-per-half-edge form)
+      if (value < 0 || value > 6 || value == 2 || value == 5) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);  // (2: the retired lane-per-half-edge form; 7, the
+      // region-per-workgroup form of round 5, left the library in round 6: measured 15 % slower at every size, profiles/r05_wg_region.txt)
       ctx->opt_persistent = value;
       return 0;
-    case FLAME_NLTGV2_OPT_RG_DEPTH:
-      if (value < 0 || value > kRgMaxDepth) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-      ctx->opt_rg_depth = value;
-      return 0;
-    case FLAME_NLTGV2_OPT_RG_REGIONS:
-      if (value < 0 || value > 4096) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-      ctx->opt_rg_regions = value;
+    case FLAME_NLTGV2_OPT_FAR_ELIDE:
+      if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_far_elide = value;
       return 0;
     case FLAME_NLTGV2_OPT_PLACEMENT:
       if (value < 0 || value > 1) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
@@ -713,8 +654,7 @@ int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info) {
   info->torn_records_detected = ctx->torn_records_detected;
   info->last_sync_path = ctx->last_sync_path;
   info->last_run_waves_per_cu = ctx->last_run_waves_per_cu;
-  info->regions = (ctx->rg_built && ctx->rg_usable) ? ctx->RG.n_regions : 0;
-  info->region_depth = (ctx->rg_built && ctx->rg_usable) ? ctx->RG.depth : 0;
+  info->last_run_far_elided = ctx->last_run_far_elided, info->far_elision_switched_off = ctx->far_elide_off ? 1 : 0;
   info->replays_per_step = ctx->replays_per_step;
   return FLAME_NLTGV2_OK;
 }
@@ -824,6 +764,7 @@ int flame_nltgv2_layout_selftest(flame_nltgv2_ctx* ctx, int64_t* mismatches) {
           crosses = patch_of_rec[(size_t)H.rid_of[(size_t)H.half_nbr[(size_t)h]]] / per != a;
         const int32_t o = off[(size_t)par * stride + r];
         bad += crosses != (o >= 0);
+        bad += !crosses && o != -2;  // (a record that stays on its XCD is marked: no write-through copy)
         if (o < 0) continue;
         bad += (o & 15) != 0 || o < par * kPlacePages * 4096 || o >= (par + 1) * kPlacePages * 4096;
         used.push_back(o);

@@ -30,7 +30,6 @@
 #include "flame_nltgv2_test_options.h"
 #include "nltgv2_kernels.h"
 #include "nltgv2_pack.hpp"
-#include "nltgv2_regions.hpp"
 #include "roctx_ranges.hpp"
 
 namespace flame_hip {
@@ -47,8 +46,6 @@ constexpr int kPv2MaxGroups = 2;        // ... in at most this many launch group
 constexpr int kPv2WavesPerCu = 19;     // ... up to this many of ITS waves per CU (20 really resident: 91 VGPRs)
 constexpr int kCrowdedWavesPerCu = 16, kCrowdedTopologies = 64;  // (see flame_nltgv2_ctx::crowded_until_topo)
 constexpr int kPvDensePerCu = 27;      // k_persistent_pv is used up to this many patches per CU (28 are resident: 7 waves per SIMD at <= 96 SGPRs)
-constexpr int kRgPreSleep = 0, kRgPollGap = 0;  // ... x 64 cycles between a block's end and its first poll / between two poll rounds
-constexpr int kRgDepth = 2;            // region-per-workgroup form: steps per block (depth of the recomputed ghost ring)
 constexpr int kPvPaceAbovePerCu = 13;  // ... and above this many its polls are paced (kPvDensePreSleep, kPvDenseGap)
 constexpr int kPvDensePreSleep = 3, kPvDenseGap = 2;  // x64 cycles before the first poll of a step / between poll rounds (re-swept
                                                       // with the issue priorities in: 8 / 4 before them; profiles/r03_priority.txt)
@@ -208,6 +205,9 @@ struct flame_nltgv2_ctx {
   // Record placement of the patch-per-wave form (nltgv2_layout.hip): a pool of pages measured once per context, the
   // records read across XCDs assigned to them once per topology
   int opt_place = 1;              // 1 (default) on, 0 off
+  int opt_far_elide = 1;          // 1 (default): no write-through copy of records that no other XCD reads (patch-per-wave form), 0: both copies always
+  bool far_elide_off = false;     // ... switched off for this context by a launch whose dispatch was not a rotation (finish(), err bit 3)
+  int last_run_far_elided = 0;    // the last persistent run was launched with the elision on
   int place_state = 0;            // 0 not calibrated yet, 1 page ranking on the device, -1 unavailable (calibration failed)
   uint64_t place_topo = ~0ull;    // topology / patches per XCD the record offsets are valid for
   int place_per_xcd = 0;
@@ -239,15 +239,6 @@ struct flame_nltgv2_ctx {
   bool tv_built = false;  // layout (D) exists for the current topology (built on demand)
   bool wg2_built = false; // ... and layout (E2) (two half-edges per lane; experimental)
   Pv2Args pv2_args;
-  // layout (R), the region-per-workgroup form (nltgv2_regions.hpp): built on the host when the form is first wanted for a topology
-  bool rg_built = false;        // ... with rg_depth_built / rg_regions_built
-  int rg_depth_built = 0, rg_regions_built = 0;
-  bool rg_usable = false;       // the layout stands, its workgroups are all resident at once
-  RegionLayout RG;
-  RgArgs rg_args;
-  DevBuf rg_tab[14], rg_xbuf;
-  int opt_rg_depth = 0;         // steps per block (ghost ring depth): 0 = default (kRgDepth)
-  int opt_rg_regions = 0;       // regions: 0 = one per CU
   int pv2_occ_lcap = -1;  // the wg2_lcap (LDS sizing) the two numbers below were derived for
   int pv2_occ = 0, pv2_occ_verify = 0;  // patches of k_persistent_pv2 really co-resident per CU (plain / record-verifying instance)
   uint64_t wg2_checked_topo = ~0ull;  // the device expansion's verdict (no patch with more than 64 foreign records) was read for this topology
@@ -333,7 +324,7 @@ struct flame_nltgv2_ctx {
   // flame_nltgv2_stream_wait_run / _runs_in_flight: the last plain persistent launch of a run carries one of these two events (in turn) as
   // its own completion signal (hipExtLaunchKernel's stop event: no operation of its own on the solver's in-order queue)
   hipEvent_t ev_run[2] = {nullptr, nullptr};
-  int run_ev_pick = 0, run_ev_last = 0;          // the event the run being enqueued may bind / the one of the last enqueued run
+  int run_ev_pick = -1, run_ev_last = 0;          // the event the run being enqueued may bind / the one of the last enqueued run
   bool run_ev_valid[2] = {false, false};         // the event stands for a run (bound to its launch, or recorded behind it)
   bool track_runs = false;                       // somebody asks runs_in_flight: a run whose launch cannot carry the event gets it recorded
   bool run_event_bound = false;  // ev_run[run_ev_last] was carried by the last enqueued run's own launch ...
@@ -429,6 +420,8 @@ int snapshot_chain_start(flame_nltgv2_ctx* ctx);
 int place_records(flame_nltgv2_ctx* ctx, int per_xcd);        // record placement, once per topology (k_place_assign)
 int place_calibrate(flame_nltgv2_ctx* ctx);                   // ... and the page ranking of the context's pool (measured, or taken over with a pool)
 void place_pool_release(flame_nltgv2_ctx* ctx);               // the pool and its ranking to the next context of the device
+bool cooperative_allowed();                                   // false under rocprofiler-sdk (nltgv2_run.hip): first launches are plain ones then
+bool place_calibrate_at_create(int device);                    // flame_nltgv2_create: rank now (first context of the device, or a ranked pool is free) or at the first placed run
 
 }  // namespace host
 }  // namespace flame_hip

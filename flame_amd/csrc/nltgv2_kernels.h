@@ -101,7 +101,7 @@ struct FusedArgs {
   int n_rec = 0;                       // record ids in use (= V): sizes the exchange buffers
   int wg_poll_gap = 1;                 // 1: one s_sleep between the polls of k_persistent_pv, 0: none
   char* place_pool = nullptr;          // record placement (nltgv2_layout.hip): pool of pages for the remote copies of the
-  const int32_t* rec_off = nullptr;    // records other XCDs read; rec_off[parity * stride + record] = byte offset or -1
+  const int32_t* rec_off = nullptr;    // records other XCDs read; rec_off[parity * stride + record] = byte offset, -1 (linear place) or -2 (no other XCD reads it)
   int rec_off_stride = 0;
   unsigned* rot_word = nullptr;        // ... and the word in which block 0 of a launch says which XCD it is on
   unsigned* probe = nullptr;           // optional per-patch, per-step cycle probe of k_persistent_pv (tools/pv_probe.py)
@@ -178,29 +178,6 @@ int pv2_patches_per_cu(int lcap, bool verify);
 int launch_persistent_pv2(const FusedArgs& a, const Pv2Args& w, const SolverParams& p, int wg_begin, int n_wgs, int parity_in, unsigned tag0,
                           int n_iters, unsigned max_spins, int poll_gap, int dual, const RunTail* tail, bool cooperative, hipStream_t stream);
 int pv_real_waves_per_simd(bool verify_or_probe);
-// layout (R) on the device (nltgv2_regions.hpp; nltgv2_persistent_rg.hip: a region per workgroup, a ghost ring of `depth` steps)
-struct RgArgs {
-  const int32_t* info = nullptr;        // [n_regions * 8]
-  const int32_t* v_pv = nullptr;        // per lane, vertex role
-  const uint32_t* v_meta = nullptr;
-  const int32_t* e_slot_src = nullptr;  // per lane, edge role
-  const int32_t* e_slot_dst = nullptr;
-  const int32_t* e_id = nullptr;
-  const uint32_t* e_li = nullptr;
-  const uint32_t* e_meta = nullptr;
-  const int32_t* f_src = nullptr;       // fetch duties: the record, the region that publishes it
-  const int32_t* f_prod = nullptr;
-  const int32_t* v_fa = nullptr;        // poll slots of the records a lane consumes
-  const int32_t* e_fq = nullptr;
-  const int32_t* e_fbs = nullptr;
-  const int32_t* e_fbd = nullptr;
-  char* xbuf = nullptr;                 // [parity 0: remote | same-XCD][parity 1: ...] of n_rec 16-byte records, then one word per region
-  int n_regions = 0, depth = 0, block_threads = 0, nb_cap = 0, nc_cap = 0, deg_cap = 0, f_cap = 0, n_packed = 0, n_rec = 0;
-  unsigned lds_bytes = 0;
-};
-int rg_blocks_per_cu(const RgArgs& a, bool probe);
-int launch_persistent_rg(const FusedArgs& f, const RgArgs& a, const SolverParams& p, int parity_in, unsigned tag0, int n_iters,
-                         unsigned max_spins, int dual, const RunTail* tail, unsigned* probe, bool cooperative, hipStream_t stream);
 const void* persistent_tv_kernel(bool static_in_lds, int waves_per_block, unsigned* lds_bytes);  // nltgv2_persistent_tv.hip
 // device-side expansion of the layout arrays (nltgv2_layout.hip)
 int launch_build_sell(const CanonArgs& c, const FusedArgs& a, const int32_t* iperm, hipStream_t s);
@@ -276,10 +253,9 @@ int launch_topo_back(const TopoBuild& t, hipStream_t s);
 
 // one per translation unit with kernels: loads its code object (flame_nltgv2_create of the first context of a process)
 void warm_module_kernels();
-void warm_module_persistent(hipStream_t stream);
+void warm_module_persistent(hipStream_t stream, bool cooperative);
 void warm_module_persistent_tv();
 void warm_module_persistent_pv2();
-void warm_module_persistent_rg();
 void warm_module_layout();
 void warm_module_topo();
 

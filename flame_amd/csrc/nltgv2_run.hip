@@ -28,6 +28,28 @@ struct WaveGroup {
 int ensure_form_rows(flame_nltgv2_ctx* ctx, int form);
 int plan_groups(flame_nltgv2_ctx* ctx, int form, int total, int cap, const std::vector<int32_t>& cw, std::vector<WaveGroup>* groups);
 
+// Cooperative launches and rocprofiler-sdk do not end well together (ROCm 7.2): a process that runs under rocprofv3 and has made ONE
+// cooperative launch -- of any kernel: tools/coop_exit_repro.hip is 30 lines without this library -- dies with SIGSEGV inside
+// libhsa-runtime64 when the HIP runtime's static destructor (amd::Runtime::tearDown) takes the device's cooperative queue down after the
+// tool has finalised (profiles/r06_segv.txt: the backtrace and the bisection; rounds 2-5 logged it as "every profiled process ends with a
+// segmentation fault").  The cooperative launch is only the first launch of a (topology, form): the runtime's check that the grid is
+// resident as a whole, which the planner derives itself anyway (pv_patches_per_cu: the query over-reports), and the launch without
+// it is the one every later run of the topology makes.  So under a profiler the first launch is a plain one too.
+// FLAME_NLTGV2_NO_COOPERATIVE=1 does the same by hand, FLAME_NLTGV2_COOPERATIVE=1 keeps the cooperative launches whatever is loaded.
+bool cooperative_allowed() {
+  static const bool ok = [] {
+    if (std::getenv("FLAME_NLTGV2_NO_COOPERATIVE")) return false;
+    if (std::getenv("FLAME_NLTGV2_COOPERATIVE")) return true;
+    if (std::getenv("ROCP_TOOL_LIBRARIES")) return false;  // (what rocprofv3 exports for the process it starts)
+    if (void* h = dlopen("librocprofiler-sdk.so.1", RTLD_NOLOAD | RTLD_LAZY)) {  // a tool library is in the process
+      dlclose(h);
+      return false;
+    }
+    return true;
+  }();
+  return ok;
+}
+
 // `consume`: the call plans a run that is about to be enqueued (enqueue_run) -- only then does a planned-around run count against
 // the back-off after an expired wait; a query (persistent_eligible, prepare_run) leaves the bookkeeping alone.
 int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups, int* use_tv_lds = nullptr, bool consume = false) {
@@ -42,11 +64,6 @@ int plan_persistent(flame_nltgv2_ctx* ctx, int n, std::vector<WaveGroup>* groups
   }
   PackedLayout& L = ctx->L;
   const int cus = ctx->prop.multiProcessorCount;
-  if (ctx->opt_persistent == 7) {  // the region-per-workgroup form by name: layout (R) on demand, all regions in one launch
-    if (ensure_form_rows(ctx, 5) != 0 || !ctx->rg_usable) return 0;
-    groups->push_back(WaveGroup{0, ctx->RG.n_regions});
-    return 5;
-  }
   // ask once per (topology, kernel instance): the LDS use varies with the layout, the registers with the instance
   const uint64_t occ_key = ctx->topo * 4 + (ctx->opt_verify != 0 ? 1 : 0) + (ctx->opt_probe != 0 ? 2 : 0);
   if (L.wg_ok && ctx->pv_occ_topo != occ_key) {
@@ -295,7 +312,23 @@ struct PlacePool {
 // (never destroyed: a context may still be released while the process exits, after the static destructors have run)
 std::mutex& g_place_mu = *new std::mutex;
 std::vector<PlacePool>& g_place_free = *new std::vector<PlacePool>;
+std::vector<int>& g_place_seen = *new std::vector<int>;  // devices whose first context has been created
 }  // namespace
+
+// flame_nltgv2_create: is NOW the time to rank this context's pages?  Yes for the first context of a device (the process's warm-up is
+// paid there anyway) and whenever a ranked pool waits to be taken over (no measurement at all).  A later context beside live ones
+// ranks lazily, at its first run that can use placement: the measurement is ~3 ms of cross-XCD spin kernels that would compete for
+// wave slots with another context's free-running solver (a SolverLoop in device mode) -- and a context that never runs a placed form
+// never pays it.  (Pools, 512 KB of device memory each, are kept until the process exits: at most as many as contexts were alive at once.)
+bool place_calibrate_at_create(int device) {
+  std::lock_guard<std::mutex> lock(g_place_mu);
+  bool first = true;
+  for (int d : g_place_seen) first = first && d != device;
+  if (first) g_place_seen.push_back(device);
+  for (const PlacePool& e : g_place_free)
+    if (e.device == device) return true;
+  return first;
+}
 
 // flame_nltgv2_destroy: the context's pool goes back to the list (its stream has been synchronised: nobody writes it any more)
 void place_pool_release(flame_nltgv2_ctx* ctx) {
@@ -429,16 +462,6 @@ int place_records(flame_nltgv2_ctx* ctx, int per_xcd) {
   return 0;
 }
 
-// (diagnostic builds of k_persistent_rg only -- make variant VARIANT_FLAGS=-DFLAME_RG_DIAG: which parts of a step are left out, by name)
-static int rg_diag_bits() {
-#ifdef FLAME_RG_DIAG
-  const char* e = std::getenv("FLAME_RG_VARIANT");
-  return e ? std::atoi(e) << 8 : 0;
-#else
-  return 0;
-#endif
-}
-
 int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   if (n <= 0) return 0;
   if (ctx->opt_solver == 1) {  // canonical 4-sweep path
@@ -477,8 +500,6 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
     if ((uint64_t)ctx->tag_next + (uint64_t)n >= 0x07ff0000ull || (ctx->xbuf_form != 0 && ctx->xbuf_form != form)) {
       const size_t bytes = kXbufBytesPerVertex * records_capacity(ctx->L);
       HIPCHK(ctx, hipMemsetAsync(ctx->xbuf.p, 0, bytes, ctx->stream));
-      if (ctx->rg_built && ctx->rg_args.xbuf)
-        HIPCHK(ctx, hipMemsetAsync(ctx->rg_xbuf.p, 0, (size_t)4 * ctx->RG.n_rec * 16 + sizeof(unsigned) * (size_t)ctx->RG.n_regions, ctx->stream));
       if (ctx->place_base) {
         HIPCHK(ctx, hipMemsetAsync(ctx->place_base, 0, (size_t)2 * kPlacePages * 4096, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync((int*)ctx->place_fill.p + 2 * kPlacePages, 0, 64, ctx->stream));
@@ -491,8 +512,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
     const uint32_t tag0 = ctx->tag_next + 2;
     // (topology, form, kernel instance): a new instance -- other registers, other LDS -- gets a cooperative first launch
     const uint64_t key = ctx->topo * 1024 + (uint64_t)form * 64 + (uint64_t)tv_lds * 32 + (ctx->opt_verify != 0 ? 16 : 0) + (ctx->opt_probe != 0 ? 8 : 0) +
-                         (ctx->opt_dual == 2 ? 4 : ctx->opt_dual == 1 ? 2 : 0) + (ctx->opt_xcds > 0 ? 1 : 0) +
-                         (form == 5 ? ((uint64_t)ctx->rg_depth_built << 40) + ((uint64_t)ctx->rg_regions_built << 44) : 0);
+                         (ctx->opt_dual == 2 ? 4 : ctx->opt_dual == 1 ? 2 : 0) + (ctx->opt_xcds > 0 ? 1 : 0);
     const RunTail* tail_dev = nullptr;
     {  // standing outputs: the small block the kernels read in their epilogue, (re)sent when no slot holds it
       RunTail want;
@@ -525,7 +545,9 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
     for (const WaveGroup& gr : groups) {
       // the run's last launch carries an event as its own completion signal (flame_nltgv2_stream_wait_run, _runs_in_flight); a cooperative launch
       // (the first of a topology) cannot: the wait then records the event behind it
-      const bool carries = &gr == &groups.back() && ctx->coop_checked_key == key && ctx->ev_run[ctx->run_ev_pick] != nullptr;
+      // (only a run enqueued by flame_nltgv2_run_async binds one: run_ev_pick < 0 for the blocking run(), finish()'s replays, the warm-up --
+      //  their launches must not re-arm an event that still stands for an earlier run in flight)
+      const bool carries = &gr == &groups.back() && ctx->coop_checked_key == key && ctx->run_ev_pick >= 0 && ctx->ev_run[ctx->run_ev_pick] != nullptr;
       ctx->f.stop_event = carries ? ctx->ev_run[ctx->run_ev_pick] : nullptr;
       const int pw = gr.count <= 4 * ctx->prop.multiProcessorCount ? 1 : 4;  // waves per workgroup
       // same-XCD exchange through L2: with the waves laid out along the Morton curve it wins at every size
@@ -578,35 +600,27 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
           HIPCHK(ctx, hipMemsetAsync(ctx->probe.p, 0, words * sizeof(unsigned), ctx->stream));  // (idle instances write nothing)
         }
       }
-      if (form == 5) {  // a region per workgroup, a block of k steps per hand-off
-        unsigned* probe = nullptr;
-        if (ctx->opt_probe) {  // [region][block][16 words]
-          const int k = ctx->rg_args.depth;
-          const size_t words = (size_t)ctx->RG.n_regions * (size_t)((n + k - 1) / k) * kRgProbeWords;
-          rc = ensure(ctx, ctx->probe, words * sizeof(unsigned));
-          if (rc) return rc;
-          probe = (unsigned*)ctx->probe.p;
-          ctx->probe_words = words;
-          HIPCHK(ctx, hipMemsetAsync(ctx->probe.p, 0, words * sizeof(unsigned), ctx->stream));
-        }
-        e = launch_persistent_rg(ctx->f, ctx->rg_args, to_sp(p), ctx->parity, tag0, n, spins_arg, (dual & 1) | rg_diag_bits() |
-                                     ((ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : kRgPreSleep) << 16) | ((ctx->opt_poll_gap > 0 ? (ctx->opt_poll_gap - 1) & 15 : kRgPollGap) << 24),
-                                 tail_dev, probe,
-                                 ctx->coop_checked_key != key, ctx->stream);
-        if (e != 0) break;
-        continue;
-      }
       if (form == 4) {  // two half-edges per lane: its own pacing (swept: profiles/r03_pv2.txt)
         const bool dense = gr.count > kPv2PaceAbovePerCu * ctx->prop.multiProcessorCount;
         const int gap = ctx->opt_poll_gap > 0 ? ctx->opt_poll_gap - 1 : dense ? (3 | ((kPv2DenseGap - 1) << 4)) : kPvPollGap;
         const int poll_gap = gap | ((ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : dense ? kPv2DensePreSleep : kPvPreSleep) << 8);
         e = launch_persistent_pv2(ctx->f, ctx->pv2_args, to_sp(p), gr.begin, gr.count, ctx->parity, tag0, n, spins_arg, poll_gap, dual,
-                                  tail_dev, ctx->coop_checked_key != key, ctx->stream);
+                                  tail_dev, cooperative_allowed() && ctx->coop_checked_key != key, ctx->stream);
         if (e != 0) break;
         continue;
       }
-      e = launch_persistent_run(ctx->f, to_sp(p), form, gr.begin, gr.count, ctx->parity, tag0, n, pw, spins_arg, presleep, dual,
-                                tv_lds, xcds, tail_dev, ctx->coop_checked_key != key, ctx->stream);
+      // Patch-per-wave form: records that no other XCD reads get no write-through copy (k_persistent_pv, `elide`): by the placement
+      // tables' static XCD groups (1), or all of them when the run keeps to one XCD (2) -- unless an earlier launch of this context met
+      // a dispatch that was not the rotation the tables assume (far_elide_off, finish()).
+      int dual_pv = dual;
+      ctx->last_run_far_elided = 0;
+      if (form == 3 && (dual & 1) && ctx->opt_far_elide && !ctx->far_elide_off) {
+        const int mode = xcds == 1 ? 2 : (ctx->f.place_pool && gr.begin == 0) ? 1 : 0;
+        dual_pv |= (mode << 3) | (ctx->opt_far_elide == 2 ? 32 : 0);
+        ctx->last_run_far_elided = mode != 0;
+      }
+      e = launch_persistent_run(ctx->f, to_sp(p), form, gr.begin, gr.count, ctx->parity, tag0, n, pw, spins_arg, presleep, form == 3 ? dual_pv : dual,
+                                tv_lds, xcds, tail_dev, cooperative_allowed() && ctx->coop_checked_key != key, ctx->stream);
       if (e != 0) break;
     }
     ctx->run_event_bound = e == 0 && ctx->f.stop_event != nullptr;
@@ -631,11 +645,10 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       ctx->buf_gen ^= 1;
       refresh_args(ctx);
       ctx->coop_checked_key = key;
-      ctx->last_run_path = form == 5 ? 8 : form == 4 ? 7 : form == 3 ? 6 : 5;
+      ctx->last_run_path = form == 4 ? 7 : form == 3 ? 6 : 5;
       ctx->last_run_groups = (int)groups.size();
       ctx->last_run_waves_per_cu = 0;
       for (const WaveGroup& gr : groups) ctx->last_run_waves_per_cu = std::max(ctx->last_run_waves_per_cu, (gr.count + ctx->prop.multiProcessorCount - 1) / ctx->prop.multiProcessorCount);
-      if (form == 5) ctx->last_run_waves_per_cu = ctx->rg_args.block_threads / 64 * ((ctx->RG.n_regions + ctx->prop.multiProcessorCount - 1) / ctx->prop.multiProcessorCount);
       ctx->parity ^= 1;
       ctx->have_prev = true;
       ctx->canon_valid = false;
@@ -730,6 +743,13 @@ int finish(flame_nltgv2_ctx* ctx) {
   std::swap(run, ctx->pending);  // (ctx->pending is now inactive and empty)
   if (*ctx->h_err & 6) {
     if (*ctx->h_err & 4) ctx->torn_records_detected++;  // the record verification found a second read that differed
+    if (*ctx->h_err & 8) {
+      // a patch found itself on another XCD than the writer of a record that was to stay in its XCD's L2 (no write-through copy): the
+      // dispatch of that launch was not a rotation of the static groups.  Nothing was lost (the run left before its first publish); from
+      // here on this context writes both copies of every record, as rounds 1-5 did.
+      ctx->far_elide_off = true;
+      if (std::getenv("FLAME_NLTGV2_TRACE")) std::fprintf(stderr, "[flame_nltgv2] a launch's workgroups were not dealt to the XCDs in rotation: write-through copies for every record from now on\n");
+    }
     std::memcpy(ctx->last_expired, ctx->h_err, kErrBytes);
     if (std::getenv("FLAME_NLTGV2_TRACE")) trace_expired_wait(ctx);
     // A neighbour wait of a persistent run expired (its waves were not all resident: the GPU is shared with
@@ -837,10 +857,12 @@ int flame_nltgv2_run_async(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, 
   if (rc) return rc;
   if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
   if (!params_ok(p) || n_iters < 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  if (n_iters == 0) return 0;  // nothing is enqueued: the two events keep standing for the runs they stand for
   const int idx = ctx->run_ev_last ^ 1;  // the two events take turns: the last two runs can be told apart
   ctx->run_ev_pick = idx;
   ctx->run_event_bound = false;
   rc = enqueue_run(ctx, p, n_iters);
+  ctx->run_ev_pick = -1;
   if (rc) return rc;
   bool stands = ctx->run_event_bound;
   if (!stands && ctx->track_runs) {  // (a cooperative first launch, the per-step path: recorded behind it)

@@ -92,6 +92,16 @@ class IdepthGather:
 
         return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
+    def _wait_work(self, w) -> None:
+        """Orders a collective's result for its two readers: the SOLVER's stream (which re-uses the rows) and the CALLER's current
+        stream (which reads `gathered` / frame()).  Work.wait() blocks only the stream that is current when it is called; with
+        `stream=` set that used to be the solver's alone, and a `frame(i).cpu()` on the default stream was ordered behind the
+        collective by timing only (advisor, round 5)."""
+        w.wait()  # the caller's current stream (a host backend: the host)
+        if self.stream is not None and not self._staged and torch.cuda.current_stream(self.stream.device) != self.stream:
+            with torch.cuda.stream(self.stream):
+                w.wait()
+
     def local_row(self, i: int) -> torch.Tensor:
         """Device row the solver of local frame i writes its x*scale into (first V entries).  Valid until
         the next gather(); the solver's stream waits for the collective that last read this buffer."""
@@ -138,8 +148,11 @@ class IdepthGather:
                 self._done[k] = None
         else:
             with self._on_stream():  # (the collective starts behind what the solver's stream holds now: the run that exports the rows)
-                w = self.dist.all_gather_into_tensor(self._gathered[k], send, async_op=async_op)
-            self._work[k] = w if async_op else None
+                w = self.dist.all_gather_into_tensor(self._gathered[k], send, async_op=True)
+            self._work[k] = w
+            if not async_op:  # complete for the solver's stream AND for the stream the caller reads `gathered` on
+                self._wait_work(w)
+                self._work[k] = None
         self.gathered = self._gathered[k]
         self._last = k
         self._cur = 1 - k
@@ -224,17 +237,19 @@ class IdepthGather:
         return redo
 
     def wait(self) -> None:
+        """Completes the outstanding collectives for the caller's current stream and for the solver's stream (see frame())."""
         for k in (0, 1):
             if self._done[k] is not None:
                 self._done[k].synchronize()
                 self._done[k] = None
             if self._work[k] is not None:
-                with self._on_stream():
-                    self._work[k].wait()
+                self._wait_work(self._work[k])
                 self._work[k] = None
 
     def frame(self, frame_id: int) -> torch.Tensor:
-        """x*scale of global frame `frame_id` from the most recent gather()."""
+        """x*scale of global frame `frame_id` from the most recent gather().  The returned view is valid on the stream that is CURRENT
+        when frame() is called (and on the solver's stream): wait() orders both behind the collective -- by a host wait in side-stream
+        mode, by Work.wait() on each of the two streams otherwise.  A third stream must wait for one of them itself."""
         self.wait()
         counts = frames_per_rank(self.n_frames, self.world)
         r, acc = 0, 0

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FLAME_NLTGV2_ABI_VERSION 5 /* 5: flame_nltgv2_info grew (last_run_waves_per_cu, regions, region_depth, replays_per_step); FLAME_NLTGV2_OPT_PERSISTENT = 7; flame_nltgv2_stream_wait_run, _runs_in_flight */
+#define FLAME_NLTGV2_ABI_VERSION 6 /* 6: the region-per-workgroup form left the library (FLAME_NLTGV2_OPT_PERSISTENT = 7 is an invalid argument, last_run_path 8 never occurs, the two info words it used now report the write-through elision: last_run_far_elided, far_elision_switched_off; the struct's layout is unchanged); 5: flame_nltgv2_info grew (last_run_waves_per_cu, ..., replays_per_step); flame_nltgv2_stream_wait_run, _runs_in_flight */
 
 typedef struct flame_nltgv2_ctx flame_nltgv2_ctx;
 
@@ -298,12 +298,10 @@ enum {
   FLAME_NLTGV2_OPT_PERSISTENT = 5,   /* 1 (default) = run() uses ONE persistent launch for all n_iters steps when the graph
                                         fits on the chip, picking the form by size; 3 = the vertex-per-lane form by name,
                                         4 = the patch-per-wave form by name, 6 = the patch-per-wave form with two half-edges
-                                        per lane by name, 7 = the region-per-workgroup form by name (a workgroup owns a compact
-                                        region plus a recomputed ghost ring and pays the L2 hand-off once per block of steps; built
-                                        on the host from the graph's host image; measured slower than the patch-per-wave form at every
-                                        BASELINE size, so the planner never picks it by itself) -- each only if it fits; 0 = always
-                                        one launch per step.  (2 was round 1's lane-per-half-edge form, retired in round 3; 2 and
-                                        5: invalid argument) */
+                                        per lane by name -- each only if it fits; 0 = always one launch per step.  (2 was round 1's
+                                        lane-per-half-edge form, retired in round 3; 7 was round 5's region-per-workgroup form, measured
+                                        15 % slower than the patch-per-wave form at every BASELINE size -- profiles/r05_wg_region.txt --
+                                        and taken out in round 6; 2, 5 and 7: invalid argument) */
   FLAME_NLTGV2_OPT_PROBE = 12,       /* 1 = the patch-per-wave kernel records a per-patch, per-step cycle probe (8 words:
                                         HW id, XCC id, wait cycles, compute cycles, poll rounds, step start, 100 MHz clock,
                                         0), read with flame_nltgv2_read_probe; 0 (default) = off */
@@ -349,8 +347,8 @@ typedef struct flame_nltgv2_info {
   int32_t last_run_path; /* 0 none, 1 persistent launch (lane per half-edge), 2 one launch per step
                             (hipGraph), 3 one launch per step (eager), 4 four canonical sweeps per step,
                             5 persistent launch (vertex per lane), 6 persistent launch (patch per wave),
-                            7 persistent launch (patch per wave, two half-edges per lane),
-                            8 persistent launch (region per workgroup, one L2 hand-off per block of steps) */
+                            7 persistent launch (patch per wave, two half-edges per lane)  (8 was the region-per-workgroup
+                            form of ABI 5) */
   int32_t he_waves;      /* always 0 (the lane-per-half-edge form, retired in round 3; kept for the layout of the struct) */
   int32_t tv_waves;      /* waves of the vertex-per-lane persistent form (0: not applicable) */
   int32_t tv_wave_capacity; /* vertex-per-lane waves the device keeps resident */
@@ -361,8 +359,12 @@ typedef struct flame_nltgv2_info {
                                     read differed from the first): rolled back and redone the same way */
   int32_t last_sync_path; /* flame_nltgv2_sync_graph: 0 none yet, 1 index maps + layout tables on the host, 2 on the device */
   int32_t last_run_waves_per_cu; /* waves per compute unit of the last persistent run's largest launch (0: none) */
-  int32_t regions;        /* workgroups of the region-per-workgroup form for the current topology (0: not built / not applicable) */
-  int32_t region_depth;   /* ... and its steps per block = depth of the recomputed ghost ring */
+  int32_t last_run_far_elided;   /* 1: the last persistent run (patch-per-wave form) wrote no write-through copy of the records that no
+                                    other XCD reads -- they stay in their XCD's L2; 0: both copies of every record.  (ABI 5 kept the
+                                    region form's `regions` here) */
+  int32_t far_elision_switched_off; /* 1: a launch of this context was not dealt to the XCDs in rotation (a reader found itself on
+                                    another XCD than the writer of such a record): the run was taken back and redone, and the
+                                    context writes both copies from then on.  (ABI 5: `region_depth`) */
   int32_t replays_per_step; /* expired chains whose persistent replay (reduced residency) expired too: redone one launch per step */
 } flame_nltgv2_info;
 int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info);

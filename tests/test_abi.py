@@ -59,7 +59,7 @@ def test_defaults_and_status_strings(built):
     import flame_amd
 
     lib = flame_amd.load_library()
-    assert lib.flame_nltgv2_abi_version() == 5
+    assert lib.flame_nltgv2_abi_version() == 6
     p = flame_amd.Params(0, 0, 0, 0, 0, 0)
     lib.flame_nltgv2_default_params(C.byref(p))
     # == nltgv2_l1_graph_regularizer.h:121-129

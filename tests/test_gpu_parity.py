@@ -74,7 +74,7 @@ def test_config_parity(env, config, n):
     g = synth.make_graph(config, seed=4242)
     ref, bad = cpu_run(oracle, g, n)
     assert bad == 0
-    for persistent in (1, 3, 4, 6, 7, 0):  # auto, vertex-per-lane, patch-per-wave (one / two half-edges per lane), region-per-workgroup, one launch per step
+    for persistent in (1, 3, 4, 6, 0):  # auto, vertex-per-lane, patch-per-wave (one / two half-edges per lane), one launch per step
         out = gpu_run(flame_amd, g, n, options=[(5, persistent)], expect_path=None if persistent else 2)
         assert rms(out["x"], ref["x"]) <= TOL_RMS
         assert_state_equal(out, ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"{config} p={persistent}")
@@ -479,7 +479,7 @@ def test_nan_is_reported_not_fatal(env):
             reg.run(flame_amd.Params(), 1)
 
 
-@pytest.mark.parametrize("form", [3, 4, 6, 7])
+@pytest.mark.parametrize("form", [3, 4, 6])
 def test_persistent_timeout_is_rolled_back_and_redone(env, form):
     """A persistent run whose neighbour wait expires (fault injection: one wave withholds its first record) must
     leave the state it started from untouched; run() then does the same steps with one launch per step."""
@@ -492,13 +492,13 @@ def test_persistent_timeout_is_rolled_back_and_redone(env, form):
         reg.upload_graph(g)
         reg.run(p, 30)                       # a normal persistent run first (odd/even parity both follow)
         oracle.run(ref, 30)
-        assert reg.info()["last_run_path"] in (5, 6, 7, 8)
+        assert reg.info()["last_run_path"] in (5, 6, 7)
         reg.set_option(flame_amd.regularizer.OPT_FAULT_INJECT, 200)
         reg.run(p, 41)                       # times out inside, recovered
         oracle.run(ref, 41)
         info = reg.info()
         # (taken back, then redone in a persistent form at reduced residency, where the hook's fault is off)
-        assert info["timeouts_recovered"] == 1 and info["last_run_path"] in (5, 6, 7, 8)
+        assert info["timeouts_recovered"] == 1 and info["last_run_path"] in (5, 6, 7)
         assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="after recovery")
         for _ in range(6):                   # the topology stays on the per-step path while the fault is on (and for a few runs after an
             reg.run(p, 10)                   # expired run in any case: 4, then 8, ... up to 1024 -- a stall that passes is tried again)
@@ -507,7 +507,7 @@ def test_persistent_timeout_is_rolled_back_and_redone(env, form):
         reg.set_option(flame_amd.regularizer.OPT_FAULT_INJECT, 0)  # fault off: persistent runs again
         reg.run(p, 25)
         oracle.run(ref, 25)
-        assert reg.info()["last_run_path"] in (5, 6, 7, 8)
+        assert reg.info()["last_run_path"] in (5, 6, 7)
         assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="after the fault")
         # chained asynchronous runs (run_async back to back, an asynchronous export in between, a short per-step run):
         # the chain's starting state was copied aside, the whole chain is replayed on the per-step path
@@ -631,7 +631,7 @@ def test_export_idepth_device_and_stream(env):
         reg.set_stream(None)
 
 
-@pytest.mark.parametrize("form", [0, 3, 4, 6, 7])
+@pytest.mark.parametrize("form", [0, 3, 4, 6])
 def test_standing_export_target(env, form):
     """flame_nltgv2_set_export_target: every run leaves scale * x in the caller's vertex order, on all paths."""
     import torch
@@ -657,7 +657,7 @@ def test_standing_export_target(env, form):
         assert float(buf.max()) == -7.0
 
 
-@pytest.mark.parametrize("form", [0, 1, 3, 4, 7])
+@pytest.mark.parametrize("form", [0, 1, 3, 4, 6])
 def test_another_stream_waits_for_the_run_through_the_launch_own_event(env, form):
     """flame_nltgv2_stream_wait_run: a consumer stream of the caller's is ordered behind the runs enqueued so far -- with the event the
     run's own launch carries (called right behind run_async), or with one recorded on the spot (the first launch of a topology is
@@ -701,7 +701,7 @@ def test_another_stream_waits_for_the_run_through_the_launch_own_event(env, form
         assert reg.info()["timeouts_recovered"] == 0
 
 
-@pytest.mark.parametrize("form", [0, 1, 7])
+@pytest.mark.parametrize("form", [0, 1, 6])
 def test_runs_in_flight_counts_the_last_two_runs_without_waiting(env, form):
     """flame_nltgv2_runs_in_flight: 0 on an idle context, at most 2, falls back to 0 once the device has finished the runs (no sync by
     the caller), and the runs it watched are as good as any: the state equals the checker's."""
@@ -733,7 +733,7 @@ def test_runs_in_flight_counts_the_last_two_runs_without_waiting(env, form):
         assert all(np.array_equal(out[key], ref[key]) for key in ("x", "w1", "w2", "q1", "q2", "q3"))
 
 
-@pytest.mark.parametrize("form", [3, 4, 6, 7])
+@pytest.mark.parametrize("form", [3, 4, 6])
 def test_export_target_switched_inside_a_replayed_chain(env, form):
     """Double-buffered gather rows: run k exports into row A, the target moves to row B, run k + 1 chains on.  If the chain
     is replayed (an expired wait), every run must be redone with the target IT was enqueued with -- row A gets run k's
@@ -894,6 +894,64 @@ def test_record_placement_is_bit_identical_and_well_formed(env, config):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("config", ["320x240", "640x480", "1280x720"])
+def test_records_that_stay_on_their_xcd_get_no_write_through_copy(env, config):
+    """Round 6 (profiles/r06_handoff.txt): a record that no patch on another XCD reads is published with the plain store alone -- by the
+    placement tables' static XCD groups at 640x480 / 1280x720, all of them at 320x240 (the run keeps to one XCD).  Same bits as with both
+    copies and as the checker; the info words say what the last run did; with the record verification on as well."""
+    flame_amd, oracle = env
+    from flame_amd.regularizer import OPT_FAR_ELIDE, OPT_PERSISTENT, OPT_VERIFY_RECORDS
+    g = synth.make_graph(config, seed=23)
+    ref, _ = cpu_run(oracle, g, 90)
+    for elide, verify in ((1, 0), (0, 0), (1, 1)):
+        with flame_amd.Regularizer(0) as reg:
+            reg.set_option(OPT_PERSISTENT, 4)
+            reg.set_option(OPT_FAR_ELIDE, elide)
+            reg.set_option(OPT_VERIFY_RECORDS, verify)
+            reg.upload_graph(g)
+            for n in (30, 1, 59):
+                reg.run(flame_amd.Params(), n)
+            assert_state_equal(reg.download_state(), ref, what=f"{config} elide {elide} verify {verify}")
+            info = reg.info()
+            assert info["last_run_path"] == 6 and info["timeouts_recovered"] == 0 and info["torn_records_detected"] == 0, info
+            assert info["last_run_far_elided"] == elide and info["far_elision_switched_off"] == 0, info
+            if elide and config != "320x240":
+                assert reg.layout_selftest() == 0  # (-2 exactly on the records whose readers all share their XCD group)
+
+
+@pytest.mark.gpu
+def test_a_launch_that_was_not_dealt_in_rotation_switches_the_elision_off(env):
+    """The elision trusts the static XCD groups of the placement tables; every reader checks it against the TRUE XCC ids at the start of
+    a launch.  Test hook (FLAME_NLTGV2_OPT_FAR_ELIDE = 2): the first patch claims that a record it reads was written on another XCD
+    without a write-through copy -> the run leaves before anything was published, is taken back and redone with both copies, and the
+    context keeps writing both.  Bit-identical throughout, also inside a chain of asynchronous runs."""
+    flame_amd, oracle = env
+    from flame_amd.regularizer import OPT_FAR_ELIDE, OPT_PERSISTENT
+    g = synth.make_graph("640x480", seed=29)
+    ref = synth.copy_graph(g)
+    p = flame_amd.Params()
+    with flame_amd.Regularizer(0) as reg:
+        reg.set_option(OPT_PERSISTENT, 4)
+        reg.upload_graph(g)
+        reg.run(p, 20)
+        oracle.run(ref, 20)
+        assert reg.info()["last_run_far_elided"] == 1
+        reg.set_option(OPT_FAR_ELIDE, 2)
+        for n in (25, 8, 40):
+            reg.run_async(p, n)
+            oracle.run(ref, n)
+        reg.sync()
+        info = reg.info()
+        assert info["far_elision_switched_off"] == 1 and info["timeouts_recovered"] == 1 and info["last_run_far_elided"] == 0, info
+        assert_state_equal(reg.download_state(), ref, what="after the switch-off")
+        reg.run(p, 30)
+        oracle.run(ref, 30)
+        info = reg.info()
+        assert info["last_run_path"] == 6 and info["timeouts_recovered"] == 1, info
+        assert_state_equal(reg.download_state(), ref, what="both copies from then on")
+
+
+@pytest.mark.gpu
 def test_after_an_expired_run_the_persistent_path_is_tried_again(env):
     """An expired run does not leave a static graph on the per-step path for good: the next 4 runs of the topology go per step, then
     the persistent launch is tried again (8 after a second expired run in a row, ... 1024 at most)."""
@@ -977,60 +1035,7 @@ def test_an_expired_run_at_high_residency_makes_the_planner_leave_room(env):
         assert reg.info()["last_run_path"] == 6
 
 
-# ---- the region-per-workgroup form (k_persistent_rg, layout (R)): a ghost ring of depth k, one L2 hand-off per block of k steps ---------
-@pytest.mark.parametrize("config,depth,regions", [("320x240", 1, 0), ("320x240", 2, 0), ("320x240", 3, 40), ("320x240", 4, 0), ("640x480", 2, 0), ("640x480", 3, 0),
-                                                  ("640x480", 4, 0), ("640x480", 2, 512), ("1280x720", 2, 0), ("640x480", 1, 0)])
-def test_region_per_workgroup_form(env, config, depth, regions):
-    """Every state array bit-identical to the checker for run lengths that are and are not multiples of the block length, chained
-    runs (the ring is re-read from the packed arrays at every launch), non-default parameters and weights."""
-    from flame_amd.regularizer import OPT_PERSISTENT, OPT_RG_DEPTH, OPT_RG_REGIONS
-
-    flame_amd, oracle = env
-    g = synth.make_graph(config, seed=77 + depth)
-    rng = np.random.default_rng(depth)
-    g["data_weight"] = (0.5 + rng.random(g["V"])).astype(np.float32)
-    ref = synth.copy_graph(g)
-    pk = dict(data_factor=0.25, step_x=0.002, step_q=60.0, theta=0.5, x_min=0.05, x_max=4.0)
-    with flame_amd.Regularizer(0) as reg:
-        reg.set_option(OPT_PERSISTENT, 7)
-        reg.set_option(OPT_RG_DEPTH, depth)
-        reg.set_option(OPT_RG_REGIONS, regions)
-        reg.upload_graph(g)
-        for n, params in ((4 * depth, None), (57, pk), (1, None), (depth + 1, pk), (200, None)):
-            p = flame_amd.Params(**params) if params else flame_amd.Params()
-            reg.run(p, n)
-            bad = oracle.run(ref, n, oracle.make_params(**(params or {})))
-            assert bad == 0
-            if n >= 4:
-                assert reg.info()["last_run_path"] == 8, (config, depth, regions, n)
-            assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what=f"{config} k={depth} n={n}")
-        assert reg.info()["timeouts_recovered"] == 0
-        sm, dc = reg.costs(flame_amd.Params())
-        assert [np.float32(sm), np.float32(dc)] == [np.float32(v) for v in oracle.costs(ref)]
-
-
-def test_region_form_declines_what_it_cannot_run(env):
-    """A vertex of more than 32 edges, or a graph too small for regions: the form asked for by name does not apply, the steps are done on
-    another path, the result is the same."""
-    from flame_amd.regularizer import OPT_PERSISTENT
-
-    flame_amd, oracle = env
-    g0 = synth.make_graph("320x240", seed=5)
-    hub, far = 1000, np.arange(0, 2000, 50, dtype=np.int32)  # a vertex of ~46 edges
-    have = set(zip(g0["src"].tolist(), g0["dst"].tolist())) | set(zip(g0["dst"].tolist(), g0["src"].tolist()))
-    extra = np.array([(hub, int(v)) for v in far if v != hub and (hub, int(v)) not in have], dtype=np.int32)
-    g = synth.assemble_graph(g0["pos"], g0["data_term"], np.concatenate([np.stack([g0["src"], g0["dst"]], axis=1), extra]))
-    ref, bad = cpu_run(oracle, g, 30)
-    assert bad == 0
-    with flame_amd.Regularizer(0) as reg:
-        reg.set_option(OPT_PERSISTENT, 7)
-        reg.upload_graph(g)
-        reg.run(flame_amd.Params(), 30)
-        assert reg.info()["last_run_path"] != 8
-        assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS, what="hub graph")
-
-
-@pytest.mark.parametrize("config,form", [("640x480", 1), ("1920x1080", 1), ("320x240", 7)])
+@pytest.mark.parametrize("config,form", [("640x480", 1), ("1920x1080", 1), ("320x240", 4)])
 def test_an_expired_chain_is_first_redone_persistently_then_per_step(env, config, form):
     """The rung between the persistent forms and the one-launch-per-step path (5x slower): a chain whose wait expired is taken back and
     redone in a persistent form planned for at most 16 waves per CU (a 1080p frame: the two-half-edges form); only if THAT expires as
@@ -1047,14 +1052,14 @@ def test_an_expired_chain_is_first_redone_persistently_then_per_step(env, config
         reg.run(p, 20)
         oracle.run(ref, 20)
         clean_path = reg.info()["last_run_path"]
-        assert clean_path in (6, 7, 8)
+        assert clean_path in (6, 7)
         reg.set_option(OPT_FAULT_INJECT, 300)
         reg.run_async(p, 30)
         reg.run_async(p, 11)
         reg.sync()                             # the chain expires in its first run, is redone persistently
         oracle.run(ref, 41)
         info = reg.info()
-        assert info["timeouts_recovered"] == 1 and info["last_run_path"] in (6, 7, 8), info
+        assert info["timeouts_recovered"] == 1 and info["last_run_path"] in (6, 7), info
         assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="after the persistent replay")
         reg.set_option(OPT_FAULT_INJECT, 0)    # (lets the next run be persistent again: the back-off is lifted with the hook)
         reg.set_option(OPT_FAULT_INJECT, (1 << 22) + 300)

@@ -4,7 +4,7 @@
 # tracing), as /opt/skills/guides prescribe.  Output: gpurun_out/prof_<ROUND>/ ; summarise with
 # tools/summarize_profile.py and commit the summaries under profiles/.
 set -u
-R=${1:-r05}
+R=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/prof_$R
@@ -31,7 +31,6 @@ B="python bench.py --steps 20 --warmup 2 --no-extras --no-cpu-baseline"
 prof bench $B                                   # the bench line's own command: 640x480, default path (k_persistent_pv)
 prof bench_tv $B --persistent 3                 # the vertex-per-lane kernel on the same workload
 prof bench_step $B --persistent 0               # one launch per step
-prof bench_rg $B --persistent 7                 # the region-per-workgroup form (round 5: a ghost ring of two steps per L2 hand-off)
 prof cfg3 python tools/profile_case.py single:1280x720
 prof cfg5 python tools/profile_case.py single:1920x1080
 prof batch5 python tools/profile_case.py batch:5:200     # five frames in the patch-per-wave kernel (19 patches per CU; round 3's planner)

@@ -51,7 +51,7 @@ def last_json(path):
 
 # tag -> (dominant kernel, traffic.json key or None)
 CASES = {"bench": ("k_persistent_pv", "640x480:persistent-pv"), "bench_tv": ("k_persistent_tv", "640x480:persistent-tv"),
-         "bench_step": ("k_fused_step", "640x480:per-step hipGraph"), "bench_rg": ("k_persistent_rg", "640x480:persistent-rg"), "cfg3": ("k_persistent_pv", "1280x720:persistent-pv"),
+         "bench_step": ("k_fused_step", "640x480:per-step hipGraph"), "cfg3": ("k_persistent_pv", "1280x720:persistent-pv"),
          "cfg5": ("k_persistent_pv2", "1920x1080:persistent-pv2"), "batch5": ("k_persistent_pv2", "640x480x5:persistent-pv2"), "batch10": ("k_persistent_pv2", "640x480x10:persistent-pv2"), "batch30": ("k_persistent_tv", "640x480x30:persistent-tv"),
          "batch64": ("k_persistent_tv", "640x480x64:persistent-tv"), "stream64": ("k_fused_step", None),
          "stereo": ("k_update_feature_idepths", None)}
