@@ -21,9 +21,6 @@ enum {
                                           with one launch per step) is exercised; 0 (default) = off.  The chain is first replayed in a
                                           persistent form at reduced residency, where the fault is off; 2^22 + n = the fault hits that
                                           replay as well, so the chain ends on the one-launch-per-step path */
-  FLAME_NLTGV2_OPT_FAR_ELIDE = 116,    /* patch-per-wave form: 1 (default) = a record that no patch on another XCD reads gets no write-through copy,
-                                          0 = every published record is written twice (rounds 1-5); 2 = test hook: on, and the first patch of the next launch
-                                          claims that a record it reads has no write-through copy -- the run is taken back, the context goes on with 0 */
   FLAME_NLTGV2_OPT_POLL_GAP = 113      /* patch-per-wave form: 0 (default) = chosen from the patches per CU, 1 = no pause between
                                           the poll rounds of a wait, 2 = one s_sleep (64 cycles); 3 / 4 = the same with the polls
                                           narrowed to the records that have not arrived yet */

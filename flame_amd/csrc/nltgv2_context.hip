@@ -565,10 +565,6 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
       // region-per-workgroup form of round 5, left the library in round 6: measured 15 % slower at every size, profiles/r05_wg_region.txt)
       ctx->opt_persistent = value;
       return 0;
-    case FLAME_NLTGV2_OPT_FAR_ELIDE:
-      if (value < 0 || value > 2) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-      ctx->opt_far_elide = value;
-      return 0;
     case FLAME_NLTGV2_OPT_PLACEMENT:
       if (value < 0 || value > 1) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_place = value;
@@ -654,7 +650,7 @@ int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info) {
   info->torn_records_detected = ctx->torn_records_detected;
   info->last_sync_path = ctx->last_sync_path;
   info->last_run_waves_per_cu = ctx->last_run_waves_per_cu;
-  info->last_run_far_elided = ctx->last_run_far_elided, info->far_elision_switched_off = ctx->far_elide_off ? 1 : 0;
+  info->reserved0 = 0, info->reserved1 = 0;
   info->replays_per_step = ctx->replays_per_step;
   return FLAME_NLTGV2_OK;
 }
@@ -764,7 +760,6 @@ int flame_nltgv2_layout_selftest(flame_nltgv2_ctx* ctx, int64_t* mismatches) {
           crosses = patch_of_rec[(size_t)H.rid_of[(size_t)H.half_nbr[(size_t)h]]] / per != a;
         const int32_t o = off[(size_t)par * stride + r];
         bad += crosses != (o >= 0);
-        bad += !crosses && o != -2;  // (a record that stays on its XCD is marked: no write-through copy)
         if (o < 0) continue;
         bad += (o & 15) != 0 || o < par * kPlacePages * 4096 || o >= (par + 1) * kPlacePages * 4096;
         used.push_back(o);

@@ -205,9 +205,6 @@ struct flame_nltgv2_ctx {
   // Record placement of the patch-per-wave form (nltgv2_layout.hip): a pool of pages measured once per context, the
   // records read across XCDs assigned to them once per topology
   int opt_place = 1;              // 1 (default) on, 0 off
-  int opt_far_elide = 1;          // 1 (default): no write-through copy of records that no other XCD reads (patch-per-wave form), 0: both copies always
-  bool far_elide_off = false;     // ... switched off for this context by a launch whose dispatch was not a rotation (finish(), err bit 3)
-  int last_run_far_elided = 0;    // the last persistent run was launched with the elision on
   int place_state = 0;            // 0 not calibrated yet, 1 page ranking on the device, -1 unavailable (calibration failed)
   uint64_t place_topo = ~0ull;    // topology / patches per XCD the record offsets are valid for
   int place_per_xcd = 0;

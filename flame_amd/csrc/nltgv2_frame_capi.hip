@@ -1,5 +1,8 @@
 // nltgv2_frame_capi.hip -- the rows around the solver that work on its device state: mesh -> dense inverse-depth map, photometric
 // residual (see nltgv2_context.hpp).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include "nltgv2_context.hpp"
 
 extern "C" {
@@ -54,6 +57,10 @@ int flame_nltgv2_interpolate_mesh_begin(flame_nltgv2_ctx* ctx, const int32_t* tr
     if (triangles[t] < 0 || triangles[t] >= V) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
   const size_t n = (size_t)rows * (size_t)cols;
   hipStream_t rs = ctx->raster_stream;
+  const bool trace = std::getenv("FLAME_NLTGV2_TRACE") != nullptr;
+  const auto tr0 = std::chrono::steady_clock::now();
+  auto tr_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count(); };
+  double tr_a = 0, tr_b = 0, tr_c = 0, tr_d = 0;
   HIPCHK(ctx, hipStreamSynchronize(rs));  // (a begin without its end: the pinned map and the device buffers are about to be reused)
   if (ctx->h_img_cap < n + 16) {
     if (ctx->h_img) (void)hipHostFree(ctx->h_img);
@@ -77,20 +84,27 @@ int flame_nltgv2_interpolate_mesh_begin(flame_nltgv2_ctx* ctx, const int32_t* tr
     d_tv = (uint8_t*)ctx->r_tvalid.p;
     HIPCHK(ctx, hipMemcpyAsync(d_tv, tri_valid, (size_t)T, hipMemcpyHostToDevice, rs));
   }
+  tr_a = tr_us();
   rc = ensure_canon(ctx);  // ... it stops here ...
   if (rc) return rc;
+  tr_b = tr_us();
   HIPCHK(ctx, hipEventRecord(ctx->ev_canon, ctx->stream));
   HIPCHK(ctx, hipStreamWaitEvent(rs, ctx->ev_canon, 0));  // ... and may go on as soon as the caller enqueues the next run
   LAUNCHCHK(ctx, launch_interpolate_mesh(T, (const int32_t*)ctx->r_tris.p, ctx->c.pos, ctx->c.x, graph_scale, nullptr, d_tv,
                                          (unsigned long long*)ctx->r_keys.p, (float*)ctx->r_img.p, (int*)ctx->r_cov.p, rows, cols, rs));
   // the rasteriser's kernels are the last readers of the canonical arrays (and the writers of the resident map): whoever rewrites those
   // waits for THEM, not for the map's way out to the host (0.05 ms at 640x480, 0.3 ms at 1920x1080 -- time a commit would stand still for)
+  tr_c = tr_us();
   HIPCHK(ctx, hipEventRecord(ctx->ev_raster_done, rs));
   ctx->raster_inflight = true;
   HIPCHK(ctx, hipMemcpyAsync(ctx->h_img, ctx->r_img.p, sizeof(float) * n, hipMemcpyDeviceToHost, rs));
   HIPCHK(ctx, hipMemcpyAsync(ctx->h_img + n, ctx->r_cov.p, sizeof(int), hipMemcpyDeviceToHost, rs));
   ctx->map_rows = rows, ctx->map_cols = cols;
   ctx->img_pending_rows = rows, ctx->img_pending_cols = cols;  // (what _end describes: a synchronous interpolate_mesh in between changes map_rows)
+  tr_d = tr_us();
+  if (trace)
+    std::fprintf(stderr, "[flame_nltgv2] interpolate_mesh_begin: checks + triangles up %.1f us, solver settled + unpack enqueued %.1f, rasteriser enqueued %.1f, copies out enqueued %.1f\n",
+                 tr_a, tr_b - tr_a, tr_c - tr_b, tr_d - tr_c);
   return FLAME_NLTGV2_OK;
 }
 

@@ -101,7 +101,7 @@ struct FusedArgs {
   int n_rec = 0;                       // record ids in use (= V): sizes the exchange buffers
   int wg_poll_gap = 1;                 // 1: one s_sleep between the polls of k_persistent_pv, 0: none
   char* place_pool = nullptr;          // record placement (nltgv2_layout.hip): pool of pages for the remote copies of the
-  const int32_t* rec_off = nullptr;    // records other XCDs read; rec_off[parity * stride + record] = byte offset, -1 (linear place) or -2 (no other XCD reads it)
+  const int32_t* rec_off = nullptr;    // records other XCDs read; rec_off[parity * stride + record] = byte offset or -1
   int rec_off_stride = 0;
   unsigned* rot_word = nullptr;        // ... and the word in which block 0 of a launch says which XCD it is on
   unsigned* probe = nullptr;           // optional per-patch, per-step cycle probe of k_persistent_pv (tools/pv_probe.py)

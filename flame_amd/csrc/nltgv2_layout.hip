@@ -282,8 +282,7 @@ k_build_patch2(const int n_patches, int32_t* __restrict__ wg_info, const int32_t
 //     and direction;
 //   * k_place_assign gives, per topology, every record that a patch on another XCD reads a slot on the best page of its
 //     (producer XCD, consumer XCD) pair that still has room -- a patch's records of one pair stay contiguous, as they are
-//     in the linear buffer -- and leaves -1 for those that found no room (they keep their linear place) and -2 for the records
-//     that no other XCD reads (round 6: those get no write-through copy at all).
+//     in the linear buffer -- and leaves -1 for the others (they keep their linear place).
 // Only addresses change: which XCD a patch really runs on is still found out at run time (the XCC table), a wrong guess
 // here costs time, not correctness.
 __device__ __forceinline__ unsigned place_xcc_id() {
@@ -398,9 +397,6 @@ k_place_assign(const int n_patches, const int32_t* __restrict__ wg_info, const i
   if (p >= n_patches) return;
   const int r0 = wg_info[4 * p], n = min(wg_info[4 * p + 2] & 0xffff, 64);
   const int c_mine = lane < n ? (int)cls_of_rec[r0 + lane] : -1;
-  // -2: every reader of the record is on the record's own XCD (by these static groups) -- k_persistent_pv writes no write-through copy
-  // of it; -1 stays for a record that another XCD reads and that found no room on a page (it keeps its linear place, both copies)
-  if (lane < n && c_mine < 0) rec_off[r0 + lane] = -2, rec_off[(size_t)stride + r0 + lane] = -2;
   unsigned long long todo = __ballot(c_mine >= 0);
   while (todo) {
     const int leader = __ffsll((long long)todo) - 1;

@@ -117,14 +117,7 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   extern __shared__ float4 lds[];
   constexpr int T = 64;
   const unsigned max_spins = max_spins_arg & 0x7fffffffu;
-  const int dual = dual_arg & 1, verify = VERIFY ? (dual_arg >> 1) & 3 : 0;  // (bit 0: same-XCD exchange through L2; bits 1, 2: record verification, compiled in only where asked for)
-  // bits 3, 4: which records get NO write-through copy (round 6, profiles/r06_handoff.txt: a write-through store in front of a wave's
-  // plain store and polls costs the same-XCD hand-off ~200 cycles, and four records of five are read on their own XCD only):
-  // 1 = those the placement tables mark -2 (no patch of another XCD group reads them), 2 = all (the run keeps to one XCD).  Whether
-  // that holds is checked below from the TRUE XCC ids; a reader that finds itself on another XCD than an elided record's writer
-  // takes the run back (err bit 3) and the context goes on with both copies.
-  const int elide = dual ? (dual_arg >> 3) & 3 : 0;
-  const bool elide_hook = ((dual_arg >> 5) & 1) != 0;  // test hook (FLAME_NLTGV2_OPT_FAR_ELIDE = 2): the first patch claims to be stranded
+  const int dual = dual_arg & 1, verify = VERIFY ? dual_arg >> 1 : 0;  // (bit 0: same-XCD exchange through L2; bits 1..: record verification, compiled in only where asked for)
   const int poll_gap = poll_gap_arg & 255, pv_presleep = (poll_gap_arg >> 8) & 255;
   const int lane = (int)threadIdx.x;
   int b = blockIdx.x;
@@ -288,36 +281,21 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   int pub0 = -1, pub1 = -1;
   const char* src0 = xb_base + off0;
   const char* src1 = xb_base + off0 + par;
-  bool far_pub = pub_lane && elide != 2;  // this lane's record also goes out as a write-through copy
-  bool stranded = elide == 2 && fetch_remote;  // this lane would poll a write-through copy that nobody writes
   if (placed) {
-    if (pub_lane) {
-      pub0 = rec_off[rid_base + loc], pub1 = rec_off[rec_off_stride + rid_base + loc];
-      if (elide == 1 && pub0 == -2) far_pub = false;
-    }
+    if (pub_lane) pub0 = rec_off[rid_base + loc], pub1 = rec_off[rec_off_stride + rid_base + loc];
     if (fetch_remote) {
       const int o0 = rec_off[frid], o1 = rec_off[rec_off_stride + frid];
       if (o0 >= 0) src0 = place_pool + o0;
       if (o1 >= 0) src1 = place_pool + o1;
-      stranded = stranded || (elide == 1 && o0 == -2);
     }
   }
-  if (elide && elide_hook && wg == wg_begin) stranded = true;
-  if (elide && __any(stranded)) {  // the dispatch was not the rotation the tables were built for: nothing was published yet, leave
-    if (lane == 0) {
-      __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      atomicOr(err, 2 | 8);
-    }
-    return;
-  }
-  const bool wave_far = __any(far_pub);  // (wave-uniform: a patch none of whose records leaves its XCD issues no write-through store at all)
   // where the remote copy of this lane's record goes, by parity: its place in the pool, or the linear one (two buffers:
   // one address per parity, no decision left for the step)
   char* const xb_w = static_cast<char*>(xbuf);
   char* const pa0 = pub0 >= 0 ? place_pool + pub0 : xb_w + my_off;
   char* const pa1 = pub1 >= 0 ? place_pool + pub1 : xb_w + my_off + par;
-  auto publish = [&](const v4i_t o, char* pa, const int so) {  // (pub lanes only; a border patch writes all its records through)
-    if (wave_far) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(pa), "v"(o) : "memory");
+  auto publish = [&](const v4i_t o, char* pa, const int so) {  // (pub lanes only)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(pa), "v"(o) : "memory");
     if (dual) __builtin_amdgcn_raw_buffer_store_b128(o, rx, my_off + S, so, 0);
   };
   {

@@ -609,17 +609,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
         if (e != 0) break;
         continue;
       }
-      // Patch-per-wave form: records that no other XCD reads get no write-through copy (k_persistent_pv, `elide`): by the placement
-      // tables' static XCD groups (1), or all of them when the run keeps to one XCD (2) -- unless an earlier launch of this context met
-      // a dispatch that was not the rotation the tables assume (far_elide_off, finish()).
-      int dual_pv = dual;
-      ctx->last_run_far_elided = 0;
-      if (form == 3 && (dual & 1) && ctx->opt_far_elide && !ctx->far_elide_off) {
-        const int mode = xcds == 1 ? 2 : (ctx->f.place_pool && gr.begin == 0) ? 1 : 0;
-        dual_pv |= (mode << 3) | (ctx->opt_far_elide == 2 ? 32 : 0);
-        ctx->last_run_far_elided = mode != 0;
-      }
-      e = launch_persistent_run(ctx->f, to_sp(p), form, gr.begin, gr.count, ctx->parity, tag0, n, pw, spins_arg, presleep, form == 3 ? dual_pv : dual,
+      e = launch_persistent_run(ctx->f, to_sp(p), form, gr.begin, gr.count, ctx->parity, tag0, n, pw, spins_arg, presleep, dual,
                                 tv_lds, xcds, tail_dev, cooperative_allowed() && ctx->coop_checked_key != key, ctx->stream);
       if (e != 0) break;
     }
@@ -743,13 +733,6 @@ int finish(flame_nltgv2_ctx* ctx) {
   std::swap(run, ctx->pending);  // (ctx->pending is now inactive and empty)
   if (*ctx->h_err & 6) {
     if (*ctx->h_err & 4) ctx->torn_records_detected++;  // the record verification found a second read that differed
-    if (*ctx->h_err & 8) {
-      // a patch found itself on another XCD than the writer of a record that was to stay in its XCD's L2 (no write-through copy): the
-      // dispatch of that launch was not a rotation of the static groups.  Nothing was lost (the run left before its first publish); from
-      // here on this context writes both copies of every record, as rounds 1-5 did.
-      ctx->far_elide_off = true;
-      if (std::getenv("FLAME_NLTGV2_TRACE")) std::fprintf(stderr, "[flame_nltgv2] a launch's workgroups were not dealt to the XCDs in rotation: write-through copies for every record from now on\n");
-    }
     std::memcpy(ctx->last_expired, ctx->h_err, kErrBytes);
     if (std::getenv("FLAME_NLTGV2_TRACE")) trace_expired_wait(ctx);
     // A neighbour wait of a persistent run expired (its waves were not all resident: the GPU is shared with

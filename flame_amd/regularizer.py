@@ -29,7 +29,7 @@ _IP = C.POINTER(C.c_int32)
 # stable options (include/flame_nltgv2.h) ...
 OPT_SOLVER, OPT_USE_HIPGRAPH, OPT_PERSISTENT, OPT_PROBE, OPT_VERIFY_RECORDS, OPT_PLACEMENT, OPT_SYNC_PATH, OPT_COST_SUM = 1, 2, 5, 12, 14, 16, 17, 18
 # ... and the experimental range (tuning knobs / test hooks of the current kernels; tools/ and the tests use them)
-OPT_BLOCK_WAVES, OPT_UNROLL, OPT_DUAL_PUBLISH, OPT_PRESLEEP, OPT_XCDS, OPT_FAULT_INJECT, OPT_POLL_GAP, OPT_FAR_ELIDE = 103, 104, 106, 108, 109, 110, 113, 116
+OPT_BLOCK_WAVES, OPT_UNROLL, OPT_DUAL_PUBLISH, OPT_PRESLEEP, OPT_XCDS, OPT_FAULT_INJECT, OPT_POLL_GAP = 103, 104, 106, 108, 109, 110, 113
 RUN_PATHS = {0: "none", 1: "persistent (the lane-per-half-edge form, retired in round 3)", 2: "per-step hipGraph", 3: "per-step eager", 4: "canonical 4-sweep",
              5: "persistent-tv", 6: "persistent-pv", 7: "persistent-pv2"}
 ERR_NAN = -5
@@ -83,7 +83,7 @@ class _Info(C.Structure):
         ("device_name", C.c_char * 64), ("gcn_arch", C.c_char * 32), ("last_run_path", C.c_int32), ("he_waves", C.c_int32), ("tv_waves", C.c_int32),
         ("tv_wave_capacity", C.c_int32), ("last_run_groups", C.c_int32), ("timeouts_recovered", C.c_int32),
         ("patches", C.c_int32), ("torn_records_detected", C.c_int32), ("last_sync_path", C.c_int32),
-        ("last_run_waves_per_cu", C.c_int32), ("last_run_far_elided", C.c_int32), ("far_elision_switched_off", C.c_int32), ("replays_per_step", C.c_int32),
+        ("last_run_waves_per_cu", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32), ("replays_per_step", C.c_int32),
     ]
 
 

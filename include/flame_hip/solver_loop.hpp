@@ -313,9 +313,12 @@ class SolverLoop {
     }
     return any;
   }
+  // (flame_nltgv2_graph_size, not _get_info: the latter also counts the vertex-per-lane rows, once per topology, from a host image of the
+  //  layout it first has to fetch -- 0.56 ms at 640x480, which the loop paid after every syncCommit with the solver standing still:
+  //  profiles/r06_cpp_frame_loop.txt)
   size_t dev_vertices() {
-    flame_nltgv2_info info;
-    return flame_nltgv2_get_info(dev_.handle(), &info) == 0 ? static_cast<size_t>(info.V) : 0;
+    int32_t V = 0, E = 0;
+    return flame_nltgv2_graph_size(dev_.handle(), &V, &E) == 0 ? static_cast<size_t>(V) : 0;
   }
 
   Graph* graph_;

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FLAME_NLTGV2_ABI_VERSION 6 /* 6: the region-per-workgroup form left the library (FLAME_NLTGV2_OPT_PERSISTENT = 7 is an invalid argument, last_run_path 8 never occurs, the two info words it used now report the write-through elision: last_run_far_elided, far_elision_switched_off; the struct's layout is unchanged); 5: flame_nltgv2_info grew (last_run_waves_per_cu, ..., replays_per_step); flame_nltgv2_stream_wait_run, _runs_in_flight */
+#define FLAME_NLTGV2_ABI_VERSION 6 /* 6: the region-per-workgroup form left the library (FLAME_NLTGV2_OPT_PERSISTENT = 7 is an invalid argument, last_run_path 8 never occurs, the two info words it used are reserved; the struct's layout is unchanged); 5: flame_nltgv2_info grew (last_run_waves_per_cu, ..., replays_per_step); flame_nltgv2_stream_wait_run, _runs_in_flight */
 
 typedef struct flame_nltgv2_ctx flame_nltgv2_ctx;
 
@@ -359,12 +359,7 @@ typedef struct flame_nltgv2_info {
                                     read differed from the first): rolled back and redone the same way */
   int32_t last_sync_path; /* flame_nltgv2_sync_graph: 0 none yet, 1 index maps + layout tables on the host, 2 on the device */
   int32_t last_run_waves_per_cu; /* waves per compute unit of the last persistent run's largest launch (0: none) */
-  int32_t last_run_far_elided;   /* 1: the last persistent run (patch-per-wave form) wrote no write-through copy of the records that no
-                                    other XCD reads -- they stay in their XCD's L2; 0: both copies of every record.  (ABI 5 kept the
-                                    region form's `regions` here) */
-  int32_t far_elision_switched_off; /* 1: a launch of this context was not dealt to the XCDs in rotation (a reader found itself on
-                                    another XCD than the writer of such a record): the run was taken back and redone, and the
-                                    context writes both copies from then on.  (ABI 5: `region_depth`) */
+  int32_t reserved0, reserved1; /* always 0 (ABI 5: regions, region_depth of the region-per-workgroup form; kept for the layout of the struct) */
   int32_t replays_per_step; /* expired chains whose persistent replay (reduced residency) expired too: redone one launch per step */
 } flame_nltgv2_info;
 int flame_nltgv2_get_info(flame_nltgv2_ctx* ctx, flame_nltgv2_info* info);

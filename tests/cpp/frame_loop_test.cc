@@ -19,6 +19,7 @@
 // the dense map is not copied while the device is held -- and the printed share is that of the loop as FLaME would drive it.
 //
 // usage: frame_loop_test IN OUT [iters_per_round [lean]]     exit code 0 = ran, 77 = no usable HIP device
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -34,28 +35,55 @@ namespace dgraph = flame::optimizers::nltgv2_l1_graph_regularizer::hip;
 
 namespace {
 
+// (the whole input is read before the loop starts and the log is written after it ends: the loop's time holds no file I/O)
 struct Reader {
-  FILE* f;
+  std::vector<char> buf;
+  size_t at = 0;
+  bool load(const char* path) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END);
+    const long n = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    buf.resize(n > 0 ? (size_t)n : 0);
+    const bool ok = buf.empty() || std::fread(buf.data(), 1, buf.size(), f) == buf.size();
+    std::fclose(f);
+    return ok;
+  }
   template <class T>
   T one() {
     T v;
-    if (std::fread(&v, sizeof(T), 1, f) != 1) std::abort();
+    if (at + sizeof(T) > buf.size()) std::abort();
+    std::memcpy(&v, buf.data() + at, sizeof(T));
+    at += sizeof(T);
     return v;
   }
   template <class T>
   std::vector<T> many(size_t n) {
     std::vector<T> v(n);
-    if (n && std::fread(v.data(), sizeof(T), n, f) != n) std::abort();
+    if (at + n * sizeof(T) > buf.size()) std::abort();
+    if (n) std::memcpy(v.data(), buf.data() + at, n * sizeof(T));
+    at += n * sizeof(T);
     return v;
   }
 };
 struct Writer {
-  FILE* f;
+  std::vector<char> buf;
   template <class T>
-  void one(const T& v) { std::fwrite(&v, sizeof(T), 1, f); }
+  void one(const T& v) {
+    const char* p = reinterpret_cast<const char*>(&v);
+    buf.insert(buf.end(), p, p + sizeof(T));
+  }
   template <class T>
   void many(const std::vector<T>& v) {
-    if (!v.empty()) std::fwrite(v.data(), sizeof(T), v.size(), f);
+    const char* p = reinterpret_cast<const char*>(v.data());
+    buf.insert(buf.end(), p, p + v.size() * sizeof(T));
+  }
+  bool save(const char* path) const {
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return false;
+    const bool ok = buf.empty() || std::fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+    return std::fclose(f) == 0 && ok;
   }
 };
 
@@ -77,9 +105,11 @@ int main(int argc, char** argv) {
     }
     flame_nltgv2_destroy(probe);
   }
-  Reader in{std::fopen(argv[1], "rb")};
-  Writer out{std::fopen(argv[2], "wb")};
-  if (!in.f || !out.f) return 2;
+  Reader in;
+  Writer out;
+  if (!in.load(argv[1])) return 2;
+  out.buf.assign(in.buf.size() * 2 + (64u << 20), 0);  // (touched now: the loop appends into mapped pages)
+  out.buf.clear();
   const int iters_per_round = argc > 3 ? std::atoi(argv[3]) : 200;
   const bool lean = argc > 4 && std::atoi(argv[4]) != 0;
   const int32_t W = in.one<int32_t>(), H = in.one<int32_t>(), pad = in.one<int32_t>();
@@ -102,27 +132,49 @@ int main(int argc, char** argv) {
     flame_hip::SolverLoop<flame_hip::FlatGraph> loop(nullptr, &graph_mtx, params, iters_per_round);
     loop.start();
     bool first = true;
+    // per-stage wall time of the frame thread (printed as medians: what a frame's time is made of)
+    static const char* const kStage[] = {"addFrame", "updateFeatureIDepths", "delaunayTriangulate", "projectGraph", "syncPrepare", "other host work",
+                                         "syncCommit", "interpolateMeshBegin", "other host work (2)", "interpolateMeshEnd"};
+    std::vector<std::vector<double> > stage_ms(10);
+    auto t_stage = std::chrono::steady_clock::now();
+    auto lap = [&](int k) {
+      const auto now = std::chrono::steady_clock::now();
+      stage_ms[(size_t)k].push_back(std::chrono::duration<double, std::milli>(now - t_stage).count());
+      t_stage = now;
+    };
     const auto t_begin = std::chrono::steady_clock::now();
+    std::vector<double> frame_ms;
+    auto t_steady = t_begin;        // steady state: from the third frame on (the first two hold the first upload, the first launches of every
+    uint64_t it_steady = 0;         // kernel, the first sync's buffer growth)
     for (int fr = 0; fr < n_new; ++fr) {
+      const auto t_frame = std::chrono::steady_clock::now();
+      if (fr == 2) t_steady = t_frame, it_steady = loop.iterations();
       // ---- Frame::create + updateFeatureIDepths --------------------------------------------------------------------------
       const uint32_t id = in.one<uint32_t>(), curr_pf = in.one<uint32_t>();
       const std::vector<uint8_t> img = in.many<uint8_t>((size_t)W * H);
       const int32_t n_poses = in.one<int32_t>();
       const std::vector<flame_stereo_pose> poses = in.many<flame_stereo_pose>((size_t)n_poses);
+      t_stage = std::chrono::steady_clock::now();
       tracker.addFrame(id, img.data(), W);
+      lap(0);
       flame_stereo_stats st;
       tracker.updateFeatureIDepths(sp, id, curr_pf, poses, feats.data(), n_feats, &st);
-      out.many(feats);
-      out.one(st);
+      lap(1);
+      if (!lean) out.many(feats), out.one(st);  // (lean: the log is not replayed; the loop's time holds the pipeline's calls only)
       // ---- the features that enter the graph (projectFeatures is scaffolding of the test, done by its Python side) ----------
       const int32_t V = in.one<int32_t>();
       const std::vector<int32_t> fid = in.many<int32_t>((size_t)V);
       const std::vector<float> pos = in.many<float>((size_t)2 * V), idepth = in.many<float>((size_t)V);
       const std::vector<float> weight((size_t)V, 1.0f);
       std::vector<int32_t> tris, edges;
+      t_stage = std::chrono::steady_clock::now();
       flame_hip::delaunayTriangulate(pos, &tris, &edges);
-      out.one<int32_t>((int32_t)(tris.size() / 3)), out.many(tris);
-      out.one<int32_t>((int32_t)(edges.size() / 2)), out.many(edges);
+      lap(2);
+      if (!lean) {
+        out.one<int32_t>((int32_t)(tris.size() / 3)), out.many(tris);
+        out.one<int32_t>((int32_t)(edges.size() / 2)), out.many(edges);
+      }
+      uint64_t it_commit = 0, it_raster = 0, it_state = 0;
       const int32_t has_projection = in.one<int32_t>();
       flame_nltgv2_projection pr;
       if (has_projection) pr = in.one<flame_nltgv2_projection>();
@@ -151,7 +203,8 @@ int main(int argc, char** argv) {
       } else {
         // ---- projectGraph, then the sync in two halves with the solver iterating in between ------------------------------
         std::vector<uint8_t> keep;
-        uint64_t it_project = 0, it_commit = 0;
+        uint64_t it_project = 0;
+        t_stage = std::chrono::steady_clock::now();
         loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t it) {
           it_project = it;
           int32_t Vo = 0, Eo = 0;
@@ -160,33 +213,49 @@ int main(int argc, char** argv) {
           const int rc = flame_nltgv2_project_graph(d.handle(), &pr, 1.0f, keep.data(), nullptr);
           if (rc != 0) throw flame_hip::Error(rc, "project_graph");
         });
-        out.one(it_project), out.one<int32_t>((int32_t)keep.size()), out.many(keep);
+        lap(3);
+        if (!lean) out.one(it_project), out.one<int32_t>((int32_t)keep.size()), out.many(keep);
+        t_stage = std::chrono::steady_clock::now();
         loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t) {
           d.syncPrepare(fid, pos, idepth, weight, edges, false, nullptr, 0.0f, /*edges_unique=*/true);
         });
+        lap(4);
         std::this_thread::sleep_for(std::chrono::microseconds(host_work_us));  // (the host's other work of a frame: the solver iterates)
+        lap(5);
+        // syncCommit and the start of interpolateMesh follow each other in Flame::update() (flame.cc:307-319, 409-415): ONE hold of the
+        // device for both -- the solver is settled once, the rasteriser reads the canonical arrays the commit has just written (no
+        // unpack), and no freshly enqueued round has to be waited for in between (round 6: two holds cost 0.4 ms of waiting and a
+        // second 0.1 ms gap per frame, profiles/r06_cpp_frame_loop.txt)
         loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t it) {
-          it_commit = it;
+          it_commit = it_raster = it;
           d.syncCommit();
+          lap(6);
+          d.interpolateMeshBegin(tris, H, W, 1.0f);
         });
-        out.one(it_commit);
+        lap(7);
+        if (!lean) out.one(it_commit);
       }
       // ---- interpolateMesh in two halves ----------------------------------------------------------------------------------------
-      uint64_t it_raster = 0, it_state = 0;
-      loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t it) {
-        it_raster = it;
-        d.interpolateMeshBegin(tris, H, W, 1.0f);
-      });
+      if (it_raster == 0 && it_commit == 0) {  // (the first frame: no sync, the map of the uploaded graph)
+        t_stage = std::chrono::steady_clock::now();
+        loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t it) {
+          it_raster = it;
+          d.interpolateMeshBegin(tris, H, W, 1.0f);
+        });
+        lap(7);
+      }
       std::this_thread::sleep_for(std::chrono::microseconds(host_work_us / 2));
+      lap(8);
       const float* map = nullptr;
       int32_t coverage = 0;
-      std::vector<float> dense((size_t)W * H);
+      std::vector<float> dense(lean ? 0 : (size_t)W * H);
       loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t) {
-        coverage = d.interpolateMeshEnd(&map);
+        coverage = d.interpolateMeshEnd(&map);  // (the pinned map stays valid until the next interpolateMeshBegin: FLaME reads it in place)
         if (!lean) std::memcpy(dense.data(), map, sizeof(float) * dense.size());
       });
-      if (lean) std::memcpy(dense.data(), map, sizeof(float) * dense.size());  // (the map stays valid until the next interpolateMeshBegin)
-      out.one(it_raster), out.one(coverage), out.many(dense);
+      lap(9);
+      if (lean) frame_ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_frame).count());
+      if (!lean) out.one(it_raster), out.one(coverage), out.many(dense);
       // ---- the graph's state at the end of the frame (a read-back the reference does not need: the test's window on the solver) ------
       flame_hip::FlatArrays a;
       if (lean) continue;
@@ -203,8 +272,10 @@ int main(int argc, char** argv) {
       out.many(a.x), out.many(a.w1), out.many(a.w2), out.many(a.x_bar), out.many(a.w1_bar), out.many(a.w2_bar);
       out.many(a.q1), out.many(a.q2), out.many(a.q3);
     }
-    const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    const auto t_end = std::chrono::steady_clock::now();
+    const double wall_ms = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
     const uint64_t total = loop.iterations();
+    const double steady_rate = n_new > 2 ? (double)(total - it_steady) / std::chrono::duration<double>(t_end - t_steady).count() : 0.0;
     // the solver's own rate on the last frame's graph: an undisturbed run through the same context, after the loop has stopped
     double free_rate = 0.0;
     const double util_at_stop_per_rate = loop.utilization(1.0);  // iterations per second achieved in the loop
@@ -221,14 +292,28 @@ int main(int argc, char** argv) {
       std::printf("FAIL: the solver thread stopped: %s\n", err.c_str());
       return 1;
     }
-    std::printf("frame loop%s: %d frames in %.2f ms, %llu solver iterations beside them (%d per round, two rounds in flight), %.0f iterations/s in the loop against %.0f undisturbed: "
+    std::printf("frame loop%s: %d frames in %.2f ms (%.2f ms per frame), %llu solver iterations beside them (%d per round, two rounds in flight), %.0f iterations/s in the loop against %.0f undisturbed: "
                 "solver busy %.1f %% of the time since the first graph, idle %.1f %%\n",
-                lean ? " (lean: no state read-back)" : "", n_new, wall_ms, (unsigned long long)total, iters_per_round, util_at_stop_per_rate, free_rate, 100.0 * busy, 100.0 * (1.0 - busy));
+                lean ? " (lean: no state read-back)" : "", n_new, wall_ms, wall_ms / n_new, (unsigned long long)total, iters_per_round, util_at_stop_per_rate, free_rate, 100.0 * busy, 100.0 * (1.0 - busy));
+    if (lean) {
+      std::sort(frame_ms.begin() + std::min<size_t>(2, frame_ms.size()), frame_ms.end());
+      const double med = frame_ms.size() > 2 ? frame_ms[2 + (frame_ms.size() - 2) / 2] : 0.0;
+      std::printf("  steady state (from the third frame on): frame %.2f ms (median), %.0f iterations/s in the loop = solver busy %.1f %%\n", med, steady_rate,
+                  free_rate > 0 ? 100.0 * steady_rate / free_rate : 0.0);
+      std::printf("  the frame thread's stages, median ms:");
+      double sum = 0.0;
+      for (size_t k = 0; k < stage_ms.size(); ++k) {
+        std::vector<double>& v = stage_ms[k];
+        if (v.empty()) continue;
+        std::sort(v.begin(), v.end());
+        std::printf(" %s %.3f;", kStage[k], v[v.size() / 2]);
+        sum += v[v.size() / 2];
+      }
+      std::printf(" sum %.3f\n", sum);
+    }
   } catch (const std::exception& e) {
     std::printf("FAIL: %s\n", e.what());
     return 1;
   }
-  std::fclose(out.f);
-  std::fclose(in.f);
-  return 0;
+  return out.save(argv[2]) ? 0 : 2;
 }

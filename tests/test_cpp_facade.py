@@ -268,6 +268,12 @@ def test_frame_loop_end_to_end(built, tmp_path):
     with open(fin, "wb") as fh:
         fh.write(b"".join(blob))
     exe = build_frame_loop_program(tmp_path)
+    keep = os.environ.get("FLAME_KEEP_FRAME_LOOP")  # (tools/r06_frame_loop_gaps.sh: the program and its input, for a profiler)
+    if keep:
+        import shutil
+
+        os.makedirs(keep, exist_ok=True)
+        shutil.copy(exe, os.path.join(keep, "frame_loop_test")), shutil.copy(fin, os.path.join(keep, "frames.bin"))
     r = subprocess.run([exe, fin, fout, "200"], capture_output=True, text=True, timeout=600)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "FAIL" not in r.stdout and "solver busy" in r.stdout, r.stdout + r.stderr

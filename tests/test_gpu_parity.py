@@ -894,64 +894,6 @@ def test_record_placement_is_bit_identical_and_well_formed(env, config):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("config", ["320x240", "640x480", "1280x720"])
-def test_records_that_stay_on_their_xcd_get_no_write_through_copy(env, config):
-    """Round 6 (profiles/r06_handoff.txt): a record that no patch on another XCD reads is published with the plain store alone -- by the
-    placement tables' static XCD groups at 640x480 / 1280x720, all of them at 320x240 (the run keeps to one XCD).  Same bits as with both
-    copies and as the checker; the info words say what the last run did; with the record verification on as well."""
-    flame_amd, oracle = env
-    from flame_amd.regularizer import OPT_FAR_ELIDE, OPT_PERSISTENT, OPT_VERIFY_RECORDS
-    g = synth.make_graph(config, seed=23)
-    ref, _ = cpu_run(oracle, g, 90)
-    for elide, verify in ((1, 0), (0, 0), (1, 1)):
-        with flame_amd.Regularizer(0) as reg:
-            reg.set_option(OPT_PERSISTENT, 4)
-            reg.set_option(OPT_FAR_ELIDE, elide)
-            reg.set_option(OPT_VERIFY_RECORDS, verify)
-            reg.upload_graph(g)
-            for n in (30, 1, 59):
-                reg.run(flame_amd.Params(), n)
-            assert_state_equal(reg.download_state(), ref, what=f"{config} elide {elide} verify {verify}")
-            info = reg.info()
-            assert info["last_run_path"] == 6 and info["timeouts_recovered"] == 0 and info["torn_records_detected"] == 0, info
-            assert info["last_run_far_elided"] == elide and info["far_elision_switched_off"] == 0, info
-            if elide and config != "320x240":
-                assert reg.layout_selftest() == 0  # (-2 exactly on the records whose readers all share their XCD group)
-
-
-@pytest.mark.gpu
-def test_a_launch_that_was_not_dealt_in_rotation_switches_the_elision_off(env):
-    """The elision trusts the static XCD groups of the placement tables; every reader checks it against the TRUE XCC ids at the start of
-    a launch.  Test hook (FLAME_NLTGV2_OPT_FAR_ELIDE = 2): the first patch claims that a record it reads was written on another XCD
-    without a write-through copy -> the run leaves before anything was published, is taken back and redone with both copies, and the
-    context keeps writing both.  Bit-identical throughout, also inside a chain of asynchronous runs."""
-    flame_amd, oracle = env
-    from flame_amd.regularizer import OPT_FAR_ELIDE, OPT_PERSISTENT
-    g = synth.make_graph("640x480", seed=29)
-    ref = synth.copy_graph(g)
-    p = flame_amd.Params()
-    with flame_amd.Regularizer(0) as reg:
-        reg.set_option(OPT_PERSISTENT, 4)
-        reg.upload_graph(g)
-        reg.run(p, 20)
-        oracle.run(ref, 20)
-        assert reg.info()["last_run_far_elided"] == 1
-        reg.set_option(OPT_FAR_ELIDE, 2)
-        for n in (25, 8, 40):
-            reg.run_async(p, n)
-            oracle.run(ref, n)
-        reg.sync()
-        info = reg.info()
-        assert info["far_elision_switched_off"] == 1 and info["timeouts_recovered"] == 1 and info["last_run_far_elided"] == 0, info
-        assert_state_equal(reg.download_state(), ref, what="after the switch-off")
-        reg.run(p, 30)
-        oracle.run(ref, 30)
-        info = reg.info()
-        assert info["last_run_path"] == 6 and info["timeouts_recovered"] == 1, info
-        assert_state_equal(reg.download_state(), ref, what="both copies from then on")
-
-
-@pytest.mark.gpu
 def test_after_an_expired_run_the_persistent_path_is_tried_again(env):
     """An expired run does not leave a static graph on the per-step path for good: the next 4 runs of the topology go per step, then
     the persistent launch is tried again (8 after a second expired run in a row, ... 1024 at most)."""

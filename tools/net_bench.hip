@@ -254,10 +254,126 @@ __global__ void __launch_bounds__(64) k_net(const Args a) {
   if (acc == 12345.678f && lane == 0) a.wall[patch] = 0;
 }
 
+
+// ---- trace mode (trace=1): the product's poll statement with a stamp per round and, per fetch lane, the round in which its slot first
+// showed the step's tag (6 more instructions per round, ~12 % longer rounds: an account, not a timing).  Log per patch and step, 88 words:
+// {t_enter, t_exit, t_pub (s_memtime of this CU), rounds, w_enter, w_exit, w_pub (100 MHz clock), 0}, seen[64], round stamps[16].
+constexpr int kTraceW = 88;
+__global__ void __launch_bounds__(64) k_trace(const Args a) {
+  __shared__ v4f lds[2 * 64];
+  __shared__ unsigned long long rt[64];
+  const int lane = threadIdx.x;
+  const unsigned xcc = xcc_id();
+  int idx = 0;
+  if (lane == 0) idx = atomicAdd(&a.xcd_count[xcc & 7], 1);
+  idx = __builtin_amdgcn_readfirstlane(idx);
+  if (idx >= a.per_xcd) return;
+  const int patch = a.tile_patch[(xcc & 7) * a.per_xcd + idx];
+  if (patch < 0) return;
+  if (lane == 0) a.where[patch] = (int)xcc;
+  const size_t hl = (size_t)patch * 64 + lane;
+  const int so = a.src_off[hl];
+  const int pf = a.pub_far[hl];
+  const int pn0 = a.pub_near[hl * RMAX];
+  const int nf = a.n_fetch[patch];
+  const int chain_n = a.chain[patch];
+  const unsigned long long fetch_mask = __ballot(so >= 0);
+  const char* const src0 = a.base + (so >= 0 ? so : 0);
+  const char* const src1 = src0 + a.par;
+  lds[lane] = v4f{0.f, 0.f, 0.f, 0.f};
+  lds[64 + lane] = v4f{0.f, 0.f, 0.f, 0.f};
+  rt[lane] = 0;
+  const unsigned lds0 = (unsigned)(size_t)lds, rt0 = (unsigned)(size_t)rt;
+  const int look = nf > 0 ? lane % nf : 0;
+  const unsigned tag0 = a.tag0, p0 = tag0 & 1u;
+  float acc = (float)lane;
+  auto publish = [&](float v, unsigned tag, int parity) {
+    v4i o;
+    o.x = __float_as_int(v), o.y = lane, o.z = patch, o.w = (int)tag;
+    char* const pb = a.base + parity * a.par;
+    if (pf >= 0) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(pb + pf), "v"(o) : "memory");
+    if (pn0 >= 0) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(pb + pn0), "v"(o) : "memory");
+  };
+  publish(acc, tag0, (int)p0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  long long w0 = 0;
+  bool expired = false;
+  if (nf == 0) return;  // (the trace net is made of patches that wait)
+  for (int it = 0; it < a.steps && !expired; ++it) {
+    const unsigned s = tag0 + (unsigned)it;
+    const int area = (int)(s & 1u);
+    if (it == 1) w0 = wall_clock64();
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + 16u * (unsigned)(area * 64));
+    const unsigned rd = lds0 + 16u * (unsigned)(area * 64 + look);
+    const unsigned own_slot = dst + 16u * (unsigned)lane;
+    const char* const src = area ? src1 : src0;
+    const unsigned w_enter = 0, t_enter = 0;
+    unsigned cnt, keep, pend_lo, tagv, tagf, tmpv, seen = 0xffffu, rta = rt0, cntv = 0;
+    unsigned long long pnarrow, exec_saved, tm, tv;
+    const unsigned inf = 0xffffu, rtmax = rt0 + 8u * 63u;
+    v4f nbv;
+    asm volatile("s_setprio 0\n\t"
+                 "s_mov_b64 %[ex], exec\n\t"
+                 "s_mov_b32 %[keep], m0\n\t"
+                 "s_mov_b32 m0, %[dst]\n\t"
+                 "s_mov_b32 %[cnt], 0\n\t"
+                 "s_mov_b64 %[pn], %[fm]\n\t"
+                 "1:\n\t"
+                 "s_memtime %[tm]\n\t"
+                 "s_mov_b64 exec, %[pn]\n\t"
+                 "global_load_lds_dwordx4 %[src], off sc1\n\t"
+                 "s_mov_b64 exec, %[ex]\n\t"
+                 "ds_read_b32 %[t], %[ra] offset:12\n\t"
+                 "ds_read_b32 %[t2], %[fa] offset:12\n\t"
+                 "ds_read_b128 %[nb], %[ra]\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_mov_b64 %[tv], %[tm]\n\t"
+                 "ds_write_b64 %[rta], %[tv]\n\t"
+                 "v_add_u32 %[rta], 8, %[rta]\n\t"
+                 "v_min_u32 %[rta], %[rta], %[rtmax]\n\t"
+                 "v_cmp_ne_u32_e32 vcc, %[tag], %[t2]\n\t"
+                 "v_cndmask_b32_e32 %[tmp], %[cntv], %[inf], vcc\n\t"
+                 "v_min_u32 %[seen], %[seen], %[tmp]\n\t"
+                 "v_add_u32 %[cntv], 1, %[cntv]\n\t"
+                 "s_and_b64 %[pn], vcc, %[fm]\n\t"
+                 "v_cmp_ne_u32_e32 vcc, %[tag], %[t]\n\t"
+                 "s_add_u32 %[cnt], %[cnt], 1\n\t"
+                 "s_cmp_lt_u32 %[cnt], 60000\n\t"
+                 "s_cbranch_vccz 2f\n\t"
+                 "s_cbranch_scc1 1b\n\t"
+                 "2:\n\t"
+                 "s_setprio 3\n\t"
+                 "s_or_b32 %[pl], vcc_lo, vcc_hi\n\t"
+                 "s_mov_b32 m0, %[keep]"
+                 : [keep] "=&s"(keep), [cnt] "=&s"(cnt), [pl] "=&s"(pend_lo), [nb] "=&v"(nbv), [t] "=&v"(tagv), [t2] "=&v"(tagf), [pn] "=&s"(pnarrow),
+                   [ex] "=&s"(exec_saved), [tm] "=&s"(tm), [tmp] "=&v"(tmpv), [tv] "=&v"(tv), [seen] "+v"(seen), [rta] "+v"(rta), [cntv] "+v"(cntv)
+                 : [src] "v"(src), [dst] "s"(dst), [ra] "v"(rd), [fa] "v"(own_slot), [tag] "s"(s), [fm] "s"(fetch_mask), [inf] "v"(inf), [rtmax] "v"(rtmax)
+                 : "vcc", "scc", "memory");
+    if (pend_lo != 0u) expired = true;  // (60 000 rounds were not enough: the net is broken, leave)
+    acc += nbv.x;
+    const unsigned t_exit = (unsigned)clock64(), w_exit = (unsigned)wall_clock64();
+    for (int k = 0; k < chain_n; ++k)
+      asm volatile("v_add_f32 %0, 1.0, %0\n\tv_add_f32 %0, 1.0, %0\n\tv_add_f32 %0, 1.0, %0\n\tv_add_f32 %0, 1.0, %0\n\t"
+                   "v_add_f32 %0, 1.0, %0\n\tv_add_f32 %0, 1.0, %0\n\tv_add_f32 %0, 1.0, %0\n\tv_add_f32 %0, 1.0, %0\n\t"
+                   "v_add_f32 %0, 1.0, %0\n\tv_add_f32 %0, 1.0, %0\n\tv_add_f32 %0, 1.0, %0\n\tv_add_f32 %0, 1.0, %0\n\t"
+                   "v_add_f32 %0, 1.0, %0\n\tv_add_f32 %0, 1.0, %0\n\tv_add_f32 %0, 1.0, %0\n\tv_add_f32 %0, 1.0, %0" : "+v"(acc));
+    const unsigned t_pub = 0, w_pub = (unsigned)wall_clock64();
+    publish(acc, s + 1u, (int)((s + 1u) & 1u));
+    __builtin_amdgcn_s_setprio(0);
+    unsigned* o = a.log + ((size_t)patch * a.steps + it) * kTraceW;
+    if (lane == 0) o[0] = t_enter, o[1] = t_exit, o[2] = t_pub, o[3] = cnt, o[4] = w_enter, o[5] = w_exit, o[6] = w_pub;
+    o[8 + lane] = seen;
+    if (lane < 16) o[72 + lane] = (unsigned)rt[lane];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) a.wall[patch] = expired ? -1 : wall_clock64() - w0;
+  if (acc == 12345.678f && lane == 0) a.wall[patch] = 0;
+}
+
 struct Cfg {
   std::map<std::string, int> kv = {{"px", 28}, {"py", 28}, {"steps", 400}, {"chain", 7}, {"jitter", 3}, {"coupled", 1}, {"nbrs", 8},
                                    {"redge", 3}, {"rcorner", 2}, {"layout", 0}, {"order", 0}, {"far_store", 1}, {"poll", 0}, {"narrow", 1},
-                                   {"gap", 0}, {"stamp", 1}, {"pubs", 8}, {"seed", 1}, {"spad", 0}};
+                                   {"gap", 0}, {"stamp", 1}, {"pubs", 8}, {"seed", 1}, {"spad", 0}, {"trace", 0}};
   int operator[](const char* k) const { return kv.at(k); }
 };
 
@@ -377,7 +493,7 @@ int run(const Cfg& c, const char* label) {
   CHECK(hipMemset(a.base, 0, 2 * (size_t)par));
   a.par = par, a.steps = steps;
   std::vector<unsigned> logh;
-  CHECK(hipMalloc(&a.log, (size_t)P * steps * 32));
+  CHECK(hipMalloc(&a.log, (size_t)P * steps * 4 * kTraceW));
   std::vector<long long> wall(P, 0);
   a.wall = to_dev(wall);
   std::vector<int> where(P, -1);
@@ -387,7 +503,7 @@ int run(const Cfg& c, const char* label) {
   auto go = [&](bool stamp) -> double {  // one launch; the period in us by the device-wide clock (mean over the patches)
     CHECK(hipMemset(a.base, 0, 2 * (size_t)par));
     CHECK(hipMemset(a.xcd_count, 0, 8 * sizeof(int)));
-    CHECK(hipMemset(a.log, 0, (size_t)P * steps * 32));
+    CHECK(hipMemset(a.log, 0, (size_t)P * steps * 4 * kTraceW));
     a.tag0 = 1000u + 2u * (unsigned)(rnd() & 0xffff);
     const dim3 g(8 * per_xcd);
     if (c["order"] == 0) { if (stamp) launch<0, true>(c["poll"], g, a); else launch<0, false>(c["poll"], g, a); }
@@ -404,6 +520,77 @@ int run(const Cfg& c, const char* label) {
     return ticks / P / 100.0 / (steps - 1);
   };
   go(false);  // (warm: code object, pages)
+  if (c["trace"]) {
+    // ---- the account of one wait: stamps per round, per record the round that first saw it --------------------------------------
+    CHECK(hipMemset(a.base, 0, 2 * (size_t)par));
+    CHECK(hipMemset(a.xcd_count, 0, 8 * sizeof(int)));
+    CHECK(hipMemset(a.log, 0, (size_t)P * steps * 4 * kTraceW));
+    a.tag0 = 1000u + 2u * (unsigned)(rnd() & 0xffff);
+    hipLaunchKernelGGL(k_trace, dim3(8 * per_xcd), dim3(64), 0, 0, a);
+    CHECK(hipGetLastError());
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemcpy(wall.data(), a.wall, P * sizeof(long long), hipMemcpyDeviceToHost));
+    double ticks = 0;
+    int nbad = 0;
+    for (int p = 0; p < P; ++p) nbad += wall[p] <= 0, ticks += (double)wall[p];
+    const double us = ticks / P / 100.0 / (steps - 1);
+    printf("%-40s TRACE period %.4f us%s\n", label, us, nbad ? "  ** EXPIRED **" : "");
+    if (!nbad) {
+      std::vector<unsigned> lg((size_t)P * steps * kTraceW);
+      CHECK(hipMemcpy(lg.data(), a.log, lg.size() * 4, hipMemcpyDeviceToHost));
+      auto L = [&](int p, int it, int k) { return lg[((size_t)p * steps + it) * kTraceW + k]; };
+      const int i0 = steps / 4, i1 = steps - 1;
+      const double cyc = (double)(unsigned)(L(0, i1, 1) - L(0, i0, 1)) / (i1 - i0), cpt = cyc / (us * 100.0);  // cycles per step, per 100 MHz tick
+      std::vector<double> first_poll, round_len, rounds, near_d, far_d, first_seen, last_seen, spread, exit_after_last, hop_last, arith;
+      long last_is_far = 0, steps_n = 0;
+      for (int p = 0; p < P; ++p) {
+        for (int it = i0; it < i1; ++it) {
+          const unsigned nr = L(p, it, 3);
+          if (nr == 0 || nr > 16 || it < 1) continue;
+          // this CU's s_memtime -> the device-wide clock, in cycles: anchored at this step's exit
+          const double off = (double)L(p, it, 5) * cpt - (double)L(p, it, 1);
+          auto wallc = [&](unsigned t_local) { return (double)(int)(t_local - L(p, it, 1)) + (double)L(p, it, 5) * cpt; };
+          (void)off;
+          const double own_pub = (double)L(p, it - 1, 6) * cpt;  // own publish of the step before (100 MHz clock)
+          first_poll.push_back(wallc(L(p, it, 72)) - own_pub);
+          for (unsigned r = 1; r < nr; ++r) round_len.push_back((double)(unsigned)(L(p, it, 72 + r) - L(p, it, 72 + r - 1)));
+          rounds.push_back((double)nr);
+          arith.push_back((double)(int)(L(p, it, 6) - L(p, it, 5)) * cpt);
+          double lo = 1e18, hi = -1e18, hop = 0;
+          bool hi_far = false;
+          for (int l = 0; l < n_fetch[p]; ++l) {
+            const unsigned sr = L(p, it, 8 + l);
+            if (sr >= nr) continue;
+            const int off_b = src_off[(size_t)p * 64 + l];
+            const bool far = src_far[(size_t)p * 64 + l] != 0;
+            int q;  // the producer: from the record's address
+            if (far) q = off_b / 256; else if (off_b >= mbox0) q = -1; else q = (off_b - S) / 256;
+            if (q < 0) continue;
+            const double t_seen = wallc(L(p, it, 72 + sr));
+            const double d = t_seen - (double)L(q, it - 1, 6) * cpt;
+            (far ? far_d : near_d).push_back(d);
+            const double rel = t_seen - own_pub;
+            if (rel < lo) lo = rel;
+            if (rel > hi) hi = rel, hi_far = far, hop = d;
+          }
+          if (hi > -1e17) {
+            first_seen.push_back(lo), last_seen.push_back(hi), spread.push_back(hi - lo), hop_last.push_back(hop);
+            exit_after_last.push_back((double)L(p, it, 5) * cpt - (hi + own_pub));
+            last_is_far += hi_far, ++steps_n;
+          }
+        }
+      }
+      printf("    %.0f cycles per step (%.3f GHz).  Times in shader cycles; a record's clock crossing is good to +-24 (the 100 MHz clock).\n", cyc, cyc / (us * 1000.0));
+      printf("    own publish -> first poll load issued %.0f | a poll round %.0f (p10 %.0f p90 %.0f), %.1f rounds per wait | exit stamp -> publish stamp (the arithmetic) %.0f\n",
+             pct(first_poll, 0.5), pct(round_len, 0.5), pct(round_len, 0.1), pct(round_len, 0.9), pct(rounds, 0.5), pct(arith, 0.5));
+      printf("    producer's publish stamp -> the round that first sees the record: same XCD p10 %.0f p50 %.0f p90 %.0f", pct(near_d, 0.1), pct(near_d, 0.5), pct(near_d, 0.9));
+      if (!far_d.empty()) printf(" | other XCD p10 %.0f p50 %.0f p90 %.0f", pct(far_d, 0.1), pct(far_d, 0.5), pct(far_d, 0.9));
+      printf("\n    per wait, after the patch's own publish: first record seen %.0f, last %.0f (spread %.0f; the last one is another XCD's in %.0f %% of the waits); its hop %.0f (p10 %.0f p90 %.0f); "
+             "that round's start -> exit stamp %.0f\n",
+             pct(first_seen, 0.5), pct(last_seen, 0.5), pct(spread, 0.5), 100.0 * last_is_far / std::max(1l, steps_n), pct(hop_last, 0.5), pct(hop_last, 0.1), pct(hop_last, 0.9),
+             pct(exit_after_last, 0.5));
+    }
+  }
   std::vector<double> per;
   for (int rep = 0; rep < 5 && !bad; ++rep) per.push_back(go(false));
   const double period_us = bad ? 0.0 : pct(per, 0.5);

@@ -1,5 +1,6 @@
 """tools/r06_probe_patches.py -- which patches pace the lock-step network of k_persistent_pv: per patch the probe's compute and wait, its
-fetch-list length and largest degree; the least-slack patches; with and without the write-through elision.  GPU box."""
+fetch-list length and largest degree; the least-slack patches.  GPU box.  (profiles/r06_probe_patches.txt was taken with the
+write-through elision of commit b4516bc beside it: the `elision 0 / 1` lines.)"""
 import os
 import sys
 
@@ -9,7 +10,7 @@ import torch  # noqa: F401
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import flame_amd  # noqa: E402
 from flame_amd import synth  # noqa: E402
-from flame_amd.regularizer import OPT_FAR_ELIDE, OPT_PERSISTENT, OPT_PROBE  # noqa: E402
+from flame_amd.regularizer import OPT_PERSISTENT, OPT_PROBE  # noqa: E402
 
 P = flame_amd.Params()
 N = 200
@@ -23,10 +24,9 @@ def small(w, h, seed):
 cases = [("640x480 s1234 (coupled)", synth.make_graph("640x480", seed=1234)),
          ("8 x 228x168 (uncoupled)", synth.concat_graphs([small(228, 168, 100 + k) for k in range(8)]))]
 for name, g in cases:
-    for el in (0, 1):
+    for el in (0,):
         with flame_amd.Regularizer(0) as reg:
             reg.set_option(OPT_PERSISTENT, 4)
-            reg.set_option(OPT_FAR_ELIDE, el)
             reg.upload_graph(g)
             reg.run(P, N)
             plain = min(reg.run_timed(P, 2000) for _ in range(5)) * 1e3 / 2000
@@ -39,7 +39,7 @@ for name, g in cases:
         nf, deg, xcc = (p[:, 0, 7] >> 8) & 0xff, p[:, 0, 7] & 0xff, p[:, 0, 1]
         period = float((np.diff(p[0, :, 5]) & 0xffffffff).mean())
         rounds = p[:, :, 4].mean(axis=1)
-        print(f"== {name}, elision {el}: {plain:.4f} us/iter unprobed; probed {ms * 1e3 / N:.4f} us = {period:.0f} cycles; {p.shape[0]} patches, "
+        print(f"== {name}: {plain:.4f} us/iter unprobed; probed {ms * 1e3 / N:.4f} us = {period:.0f} cycles; {p.shape[0]} patches, "
               f"fetch list mean {nf.mean():.1f} max {nf.max()}, compute median {np.median(comp):.0f} max {comp.max():.0f}, wait median {np.median(wait):.0f} min {wait.min():.0f}")
         order = np.argsort(wait)[:10]
         print("   least-slack patches (wait, compute, sum, fetch list, largest degree, xcc, poll rounds): " +
