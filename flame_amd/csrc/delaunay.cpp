@@ -861,32 +861,69 @@ bool triangulate_merge(const Input& in, int n_strips, int32_t* tris, int32_t tri
         if (spins > 4000) std::this_thread::yield();
     }
   };
-  // the merge tree: parts [i, i + w) and [i + w, i + 2 w), level by level
+  // The merge tree: parts [i, i + w) and [i + w, i + 2 w), w = 1, 2, 4 ...  A merge needs its two parts and nothing else, so it runs as
+  // soon as the second of them stands -- done by the thread that has just finished that part (its triangles are in that core's
+  // cache) -- and not when a whole level of the tree has been merged (round 5: five level barriers at ~45 us each were half of the
+  // triangulation's time, the seams themselves 12 us apiece).  The thread that arrives first at a merge leaves it to the other.
   struct Pair { int left, right, slot; };
-  std::vector<std::vector<Pair>> levels;
-  {
-    int merge_no = 0;
-    for (int w = 1; w < n_strips; w *= 2) {
-      levels.emplace_back();
-      for (int i = 0; i + w < n_strips; i += 2 * w) levels.back().push_back(Pair{i, i + w, ghost_base + 2 * merge_no++});
+  std::vector<Pair> pairs;
+  std::vector<std::vector<int>> as_left((size_t)n_strips);  // the merges in which part r is the left side, in tree order
+  std::vector<int> as_right((size_t)n_strips, -1);           // ... and the one that absorbs it
+  for (int w = 1; w < n_strips; w *= 2)
+    for (int i = 0; i + w < n_strips; i += 2 * w) {
+      as_left[(size_t)i].push_back((int)pairs.size()), as_right[(size_t)(i + w)] = (int)pairs.size();
+      pairs.push_back(Pair{i, i + w, ghost_base + 2 * (int)pairs.size()});
     }
-  }
-  std::vector<Phase> merge_phase(levels.size());
-  for (size_t l = 0; l < levels.size(); ++l) merge_phase[l].total = (int)levels[l].size();
+  std::vector<std::atomic<int>> arrived(pairs.size());
+  for (auto& a : arrived) a.store(0, std::memory_order_relaxed);
+  std::atomic<int> merged{pairs.empty() ? 1 : 0};
+  // (FLAME_DELAUNAY_PROFILE: when every strip and every merge began and ended, and on which member of the team)
+  std::vector<double> pf_strip(prof ? 3 * (size_t)n_strips : 0, 0.0), pf_merge(prof ? 3 * pairs.size() : 0, 0.0);
   Phase strips_phase, count_phase, write_phase;
   strips_phase.total = n_strips, count_phase.total = n_ranges, write_phase.total = n_ranges;
   // per output range (the strips' slot ranges + the tangent ghosts'): counts, then offsets
   std::vector<int64_t> cnt_t((size_t)n_ranges, 0), cnt_e((size_t)n_ranges, 0);
   double t_strips = 0, t_merged = 0;
-  W.run(team, [&](int) {
+  const double t_call = now();
+  W.run(team, [&](int member) {
     static thread_local Triangulator T;
     static thread_local std::vector<int> ids;
     static thread_local std::vector<int> stack;
+    // part `r` (a strip, or what has been merged into it so far) stands: go up the tree as long as this thread is the second to arrive
+    auto climb = [&](int r, int member) {
+      size_t stage = 0;  // merges of part r as the left side that are done
+      for (;;) {
+        const int pi = stage < as_left[(size_t)r].size() ? as_left[(size_t)r][stage] : as_right[(size_t)r];
+        if (pi < 0) {  // part 0 after its last merge: the triangulation stands
+          merged.store(1, std::memory_order_release);
+          return;
+        }
+        if (arrived[(size_t)pi].fetch_add(1, std::memory_order_acq_rel) == 0) return;  // the other side is not there yet: its thread merges
+        const Pair& pr = pairs[(size_t)pi];
+        if (!failed.load()) {
+          stack.clear();
+          if (prof) pf_merge[3 * (size_t)pi] = now(), pf_merge[3 * (size_t)pi + 2] = member;
+          const int g = M.merge(comp[(size_t)pr.left], comp[(size_t)pr.right], pr.slot, pr.slot + 1, stack);
+          if (prof) pf_merge[3 * (size_t)pi + 1] = now();
+          if (g < 0) failed.store(1);
+          comp[(size_t)pr.left] = g;
+        }
+        // the merged part is rooted at pr.left and has done one more merge as the left side than pr.left had before
+        if (r != pr.left) {
+          r = pr.left;
+          stage = 0;
+          while (stage < as_left[(size_t)r].size() && as_left[(size_t)r][stage] != pi) ++stage;
+        }
+        ++stage;
+      }
+    };
     // ---- phase 0: the strips, each into its slot range ----------------------------------------------------------------------
     for (int s; (s = strips_phase.take()) < n_strips; strips_phase.finished()) {
+      if (prof) pf_strip[3 * (size_t)s] = now(), pf_strip[3 * (size_t)s + 2] = member;
       ids.assign(by_bin.begin() + bin_start[(size_t)cut[(size_t)s]], by_bin.begin() + bin_start[(size_t)cut[(size_t)s + 1]]);
       if (!triangulate_subset(in, ids.data(), (int)ids.size(), T) || (int)T.t.size() > base[(size_t)s + 1] - base[(size_t)s]) {
         failed.store(1);
+        climb(s, member);  // (nothing is merged any more, but every merge still hears from both sides: nobody waits for ever)
         continue;
       }
       const int b0 = base[(size_t)s];
@@ -911,22 +948,16 @@ bool triangulate_merge(const Input& in, int n_strips, int32_t* tris, int32_t tri
       for (int i = b0 + (int)T.t.size(); i < base[(size_t)s + 1]; ++i) G.t[(size_t)i].alive = 0, G.t[(size_t)i].ghost = 0;
       comp[(size_t)s] = ghost;
       if (ghost < 0) failed.store(1);
+      if (prof) pf_strip[3 * (size_t)s + 1] = now();
+      climb(s, member);
     }
-    strips_phase.wait();
-    if (prof && t_strips == 0) t_strips = now();
-    // ---- the merge tree ----------------------------------------------------------------------------------------------------
-    for (size_t l = 0; l < levels.size(); ++l) {
-      Phase& ph = merge_phase[l];
-      for (int k; (k = ph.take()) < ph.total; ph.finished()) {
-        if (failed.load()) continue;
-        const Pair& pr = levels[l][(size_t)k];
-        stack.clear();
-        const int g = M.merge(comp[(size_t)pr.left], comp[(size_t)pr.right], pr.slot, pr.slot + 1, stack);
-        if (g < 0) failed.store(1);
-        comp[(size_t)pr.left] = g;
-      }
-      ph.wait();
+    if (prof) {
+      strips_phase.wait();
+      if (t_strips == 0) t_strips = now();
     }
+    // ---- the merge tree: see above; entered from phase 0 by whoever finishes a strip -----------------------------------------------
+    for (int spins = 0; merged.load(std::memory_order_acquire) == 0; ++spins)
+      if (spins > 4000) std::this_thread::yield();
     if (prof && t_merged == 0) t_merged = now();
     if (failed.load()) return;
     // ---- output: real triangles in slot order; an edge by the triangle with the smaller slot (or its only one) -------------------
@@ -988,8 +1019,22 @@ bool triangulate_merge(const Input& in, int n_strips, int32_t* tris, int32_t tri
       return false;
     }
   }
-  if (prof) std::fprintf(stderr, "[delaunay] %d points, %d strips merged: bins %.3f ms, strips %.3f ms, merges %.3f ms, output %.3f ms\n", n, n_strips,
-                         0.0, t_strips - t0, t_merged - t_strips, now() - t_merged);
+  if (prof) {
+    double first = 1e300, last_start = 0, last_end = 0, dur_max = 0, dur_sum = 0;
+    for (int k = 0; k < n_strips; ++k) {
+      first = std::min(first, pf_strip[3 * (size_t)k]), last_start = std::max(last_start, pf_strip[3 * (size_t)k]);
+      last_end = std::max(last_end, pf_strip[3 * (size_t)k + 1]);
+      dur_max = std::max(dur_max, pf_strip[3 * (size_t)k + 1] - pf_strip[3 * (size_t)k]), dur_sum += pf_strip[3 * (size_t)k + 1] - pf_strip[3 * (size_t)k];
+    }
+    std::fprintf(stderr, "[delaunay]   bins + set-up until the team is called %.3f ms; strips: first starts at %.3f, last starts at %.3f, last ends at %.3f (a strip: mean %.3f, longest %.3f ms);"
+                 " merges (start, duration us, member):", t_call - t0, first - t0, last_start - t0, last_end - t0, dur_sum / n_strips, dur_max);
+    for (size_t k = 0; k < pairs.size(); ++k)
+      if (pairs[k].right - pairs[k].left >= n_strips / 8 || k + 1 == pairs.size())  // (the upper levels: the critical path)
+        std::fprintf(stderr, " [%d+%d: %.3f, %.0f, %d]", pairs[k].left, pairs[k].right, pf_merge[3 * k] - t0, 1e3 * (pf_merge[3 * k + 1] - pf_merge[3 * k]), (int)pf_merge[3 * k + 2]);
+    std::fprintf(stderr, "\n");
+  }
+  if (prof) std::fprintf(stderr, "[delaunay] %d points, %d strips merged: all strips triangulated after %.3f ms, the tree merged after %.3f ms (merges start as their "
+                         "parts stand), output %.3f ms\n", n, n_strips, t_strips - t0, t_merged - t0, now() - t_merged);
   return true;
 }
 

@@ -217,15 +217,20 @@ def _graph_view(g: dict, keep: list, need_all=True) -> _Graph:
     return cg
 
 
-def delaunay(pos):
+def delaunay(pos, out=None):
     """Delaunay triangulation of float32 points with the library's own triangulator (host code, exact
-    predicates).  Returns (triangles (T,3) int32 counter-clockwise, edges (E,2) int32)."""
+    predicates).  Returns (triangles (T,3) int32 counter-clockwise, edges (E,2) int32).  `out` = (triangles, edges) arrays of at least
+    (2 n, 3) and (3 n, 2) int32 to write into -- what a frame loop keeps between frames, as the C++ facade's vectors do (fresh arrays
+    of this size are fresh pages: the library's writers fault them in)."""
     L = load_library()
     p = np.ascontiguousarray(pos, np.float32).reshape(-1, 2)
     n = p.shape[0]
     nt, ne = C.c_int32(0), C.c_int32(0)
-    tri = np.empty((max(2 * n, 1), 3), np.int32)
-    edg = np.empty((max(3 * n, 1), 2), np.int32)
+    if out is not None and out[0].shape[0] >= 2 * n and out[1].shape[0] >= 3 * n and out[0].dtype == np.int32 and out[1].dtype == np.int32:
+        tri, edg = out
+    else:
+        tri = np.empty((max(2 * n, 1), 3), np.int32)
+        edg = np.empty((max(3 * n, 1), 2), np.int32)
     rc = L.flame_delaunay_triangulate(p.ctypes.data_as(_FP), n, tri.ctypes.data_as(_IP), tri.shape[0], C.byref(nt),
                                       edg.ctypes.data_as(_IP), edg.shape[0], C.byref(ne))
     if rc != 0:

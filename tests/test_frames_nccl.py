@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker_cfg4(port, q):
+def _worker_cfg4(port, q, side_stream="1"):
     """BASELINE configs[3] at FULL size on one device: 8 different 640x480 frames, one solver context each (as 8 ranks would
     hold one each), 200 iterations per step, every solver exporting x * graph_scale into its row of the gather from its own
     launch, one RCCL all_gather_into_tensor per step, every gathered row against the checker.  What only an 8-GPU node adds
@@ -31,6 +31,7 @@ def _worker_cfg4(port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["FLAME_GATHER_SIDE_STREAM"] = side_stream
     import torch
     import torch.distributed as dist
 
@@ -145,12 +146,15 @@ def test_nccl_world1_solver_export_and_gather_on_the_device():
 
 
 @pytest.mark.gpu
-def test_cfg4_eight_full_size_frames_on_one_device_with_rccl_gather():
+@pytest.mark.parametrize("side_stream", ["1", "0"])
+def test_cfg4_eight_full_size_frames_on_one_device_with_rccl_gather(side_stream):
+    """(FLAME_GATHER_SIDE_STREAM = 1: the collective issued from a side stream behind the runs' own events, the default; 0: ordered by
+    torch's events on the solver's stream -- both with the caller reading `frame()` on ITS current stream.)"""
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    proc = ctx.Process(target=_worker_cfg4, args=(_free_port(), q))
+    proc = ctx.Process(target=_worker_cfg4, args=(_free_port(), q, side_stream))
     proc.start()
     ok, regathers, recovered, paths, backend = q.get(timeout=600)
     proc.join(timeout=60)

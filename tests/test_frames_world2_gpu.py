@@ -30,10 +30,11 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, backend="gloo", one_device=True):
+def _worker(rank, world, port, q, backend="gloo", one_device=True, side_stream="1"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["FLAME_GATHER_SIDE_STREAM"] = side_stream  # (read by IdepthGather: the collective from a side stream, or by torch's own events)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
@@ -113,8 +114,9 @@ def test_world2_real_solvers_on_one_device_gather_and_regather_across_ranks():
     #  re-gathered, which the per-row comparison above covers; only the injected one is asserted by step)
 
 
-def test_one_rccl_rank_per_visible_device():
-    """The same exchange over RCCL with one rank per GPU, on min(visible devices, 8) ranks -- skipped on a one-GPU box (RCCL refuses
+@pytest.mark.parametrize("side_stream", ["1", "0"])
+def test_one_rccl_rank_per_visible_device(side_stream):
+    """(Both ways of issuing the collective: FLAME_GATHER_SIDE_STREAM = 1, the default, and 0.)  The same exchange over RCCL with one rank per GPU, on min(visible devices, 8) ranks -- skipped on a one-GPU box (RCCL refuses
     two ranks per device), so an 8-GPU node runs this path in the GPU test tier before the scaling bench meets it: every rank a real
     solver on its own device, export row -> all-gather on the solver's stream -> settle(), the last rank's run made to time out in one
     step (every rank gathers again), every gathered row on every rank against the CPU checker."""
@@ -127,7 +129,7 @@ def test_one_rccl_rank_per_visible_device():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "nccl", False)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "nccl", False, side_stream)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=900) for _ in procs)
@@ -139,7 +141,7 @@ def test_one_rccl_rank_per_visible_device():
         assert ok, f"rank {rank}: a gathered row differs from the CPU checker"
         assert state_ok, f"rank {rank}: solver state differs from the CPU checker"
         assert regathers[2] == 1, (rank, regathers)
-        assert paths[0] in (6, 7, 8), (rank, paths)
+        assert paths[0] in (6, 7), (rank, paths)
     assert all(r[3] == res[0][3] for r in res), "the ranks disagree on which steps were re-gathered"
     assert res[-1][5] >= 1
 
@@ -162,8 +164,40 @@ def test_bench_two_ranks_dry_run_with_backend_override():
     assert abs(out["value"] - 2 * 6 * iters / (out["ms_per_step"] * 6e-3)) / out["value"] < 1e-3
     rg = out["result_gather"]
     assert rg["ranks"] == 2 and rg["last_row_matches_state"] is True and rg["backend"] == "gloo"
+    # the N > 1 line carries a roofline that can be checked rank by rank: every rank's device time of a step and its fraction
+    rf = out["roofline"]
+    assert len(rf["per_rank_step_us"]) == 2 and all(u > 0 for u in rf["per_rank_step_us"]) and len(rf["per_rank_frac"]) == 2
+    assert abs(rf["per_rank_step_us"][0] - rf["avg_launch_us"] * rf["launches_per_step"]) / rf["per_rank_step_us"][0] < 1e-3
+    # (two processes share ONE device here: each rank's step is longer than alone; what is checked is that the whole-job value is the
+    #  sum of what the ranks really did in the max-over-ranks wall time)
+    assert out["value"] <= 2 * iters / (min(rf["per_rank_step_us"]) * 1e-6) * 1.001
     assert "cpu_baseline" not in out                                # reported at N = 1 only
     assert out["parity"]["bit_identical"] and out["parity"]["timed_context_bit_identical"]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "r05_bench_torchrun_2ranks_gloo_one_device.json"), "w") as f:
         f.write(lines[0] + "\n")
+
+
+def _bench_line(cmd, env, timeout=900):
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_one_rccl_rank_under_torchrun_is_as_fast_as_the_plain_line():
+    """What the result gather costs before a node shows it: bench.py under torch.distributed.run with ONE rank (RCCL world 1: a real
+    collective kernel per step, the export row, the double-buffered rows, the side stream) against the plain N = 1 line of the same
+    box, same steps -- whole-job value within 5 % (round 5 measured 1.00; a gather that lands on the solver's queue again, or waits
+    for the runs around it, shows up here as 0.9 or less)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "30", "--warmup", "4", "--no-extras", "--no-cpu-baseline"]
+    plain = max(_bench_line([sys.executable] + args, env)["value"] for _ in range(2))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + args
+    outs = [_bench_line(cmd, env) for _ in range(2)]
+    best = max(o["value"] for o in outs)
+    assert outs[0]["result_gather"]["backend"] == "nccl" and outs[0]["result_gather"]["last_row_matches_state"] is True
+    assert outs[0]["roofline"]["per_rank_step_us"][0] > 0
+    assert best >= 0.95 * plain, (best, plain, outs[0]["result_gather"])
