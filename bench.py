@@ -370,7 +370,7 @@ def pv_step_cycles(flame_amd, g, params, iters, device):
             "least_slack_patch": {"compute": round(float(comp[crit]), 0), "wait": round(float(wait[crit]), 0)},
             "poll_rounds_per_step": round(float(p[:, :, 4].mean()), 2), "patches": int(info["he_waves"]),
             "instances": int(p.shape[0]),
-            "note": "cycles per step with the probe compiled in (+3-5 %); the lock-step network runs at the pace of its least-slack patches: period = their "
+            "note": "cycles per step with the probe compiled in (+7-9 %: floor.probe_overhead_us); the lock-step network runs at the pace of its least-slack patches: period = their "
                     "compute + their wait (one hand-off).  A patch's compute is the chain of its largest vertex: 2 x degree dependent additions in the "
                     "reference's edge order (`compute_by_largest_degree`) -- the slowest patch is the one that holds the graph's largest vertex, which no "
                     "packing can shorten; polling faster or slower than one load per LDS round trip lengthens the wait (profiles/r04_poll_variants.txt)"}
@@ -400,6 +400,7 @@ def latency_floor(flame_amd, synth, params, iters, device, B_iter, roofline):
         r.upload_graph(g8)
         r.run(params, iters)
         ms, _ = timed_launches(r, params, iters, 5)
+        ms_long, _ = timed_launches(r, params, 10 * iters, 3)  # (ten times the iterations per launch: the launch's fixed part amortised)
         path = flame_amd.regularizer.RUN_PATHS.get(r.info()["last_run_path"], "?")
     finally:
         r.close()
@@ -417,9 +418,14 @@ def latency_floor(flame_amd, synth, params, iters, device, B_iter, roofline):
     wait = p[:, :, 2].mean(axis=1)
     ghz = float((np.diff(p[0, :, 5]) & 0xffffffff).mean()) / (float((np.diff(p[0, :, 6]) & 0xffffffff).mean()) * 10.0)
     uncoupled_us = ms * 1e3 / iters
+    probed_us = float((np.diff(p[0, :, 6]) & 0xffffffff).mean()) / 100.0  # the probed instance's own period in steady state, by the 100 MHz clock
+    steady_us = ms_long * 1e3 / (10 * iters)                             # the plain instance's, with the launch's fixed part amortised
+    probe_overhead_us = max(0.0, probed_us - steady_us)
     out = {"uncoupled_period_us": round(uncoupled_us, 3), "uncoupled_run_path": path,
            "uncoupled_graphs": f"8 disjoint Delaunay graphs, V={g8['V']} E={g8['E']} in total, one per XCD",
            "same_xcd_handoff_us": round(float(wait.min()) / (ghz * 1e3), 3),
+           "uncoupled_steady_period_us": round(steady_us, 3), "probed_period_us": round(probed_us, 3), "probe_overhead_us": round(probe_overhead_us, 3),
+           "same_xcd_handoff_less_probe_us": round(max(0.0, float(wait.min()) / (ghz * 1e3) - probe_overhead_us), 3),
            "hbm_period_us": round(B_iter / (HBM_PEAK_GBPS * 1e9) * 1e6, 3),
            "measured_period_us": roofline["per_iteration_us"]}
     rp = roofline.get("record_placement")
@@ -430,7 +436,12 @@ def latency_floor(flame_amd, synth, params, iters, device, B_iter, roofline):
         out["wait_min_minus_same_xcd_handoff_cycles"] = round(sc["wait_min"] - float(wait.min()), 0)
     out["frac_of_hbm_at_uncoupled_period"] = round(out["hbm_period_us"] / uncoupled_us, 4)
     out["note"] = ("one small frame cannot iterate faster than one hand-off plus the ~600 cycles of dependent instructions behind it; "
-                   "`frac_of_hbm_at_uncoupled_period` is the roofline fraction this frame would show if none of its records crossed an XCD")
+                   "`frac_of_hbm_at_uncoupled_period` is the roofline fraction this frame would show if none of its records crossed an XCD.  "
+                   "`same_xcd_handoff_us` is the least-slack patch's wait as the PROBED instance sees it; the probe's own stamps and log store sit "
+                   "inside that wait (`probe_overhead_us` = its steady period minus the plain instance's at ten times the iterations per launch, round 6: "
+                   "profiles/r06_handoff.txt section 5), "
+                   "`same_xcd_handoff_less_probe_us` takes them out; tools/hop_bench hands ONE record over in 0.26-0.29 us, the lock-step network of "
+                   "tools/net_bench.hip (19 records of 7.6 producers, the same poll statement and stores) in 0.32 us")
     return out
 
 

@@ -279,3 +279,35 @@ def test_strip_paths_equal_reference_triangle_run_on_large_sets(built, name):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_the_library_own_delaunay_check_accepts_the_merged_strips(built):
+    """FLAME_DELAUNAY_VERIFY=1 (advisor, round 5): the library itself runs the exact in-circle predicate across every interior edge of a
+    merged triangulation and falls back to the certified strips if one fails.  On the jittered 640x480 set and on a co-circular
+    integer grid the merged result passes -- no fall-back line -- and is the same set of triangles as without the switch."""
+    import subprocess
+    import sys
+
+    code = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+from flame_amd import synth
+from flame_amd.regularizer import delaunay
+pos = np.ascontiguousarray(synth.make_graph("640x480", seed=3)["pos"], np.float32)
+grid = np.stack(np.meshgrid(np.arange(90, dtype=np.float32), np.arange(60, dtype=np.float32)), -1).reshape(-1, 2)
+for name, p in (("jittered", pos), ("grid", grid)):
+    os.environ.pop("FLAME_DELAUNAY_VERIFY", None)
+    t0, e0 = delaunay(p)
+    os.environ["FLAME_DELAUNAY_VERIFY"] = "1"
+    t1, e1 = delaunay(p)
+    same = sorted(map(tuple, np.sort(t0, 1).tolist())) == sorted(map(tuple, np.sort(t1, 1).tolist()))
+    print(name, len(p), len(t1), len(e1), "same" if same and len(e0) == len(e1) else "DIFFERENT")
+"""
+    from tests.conftest import ROOT
+
+    env = dict(os.environ, FLAME_DELAUNAY_TRACE="1")
+    r = subprocess.run([sys.executable, "-c", code.format(root=ROOT)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.count("same") == 2 and "DIFFERENT" not in r.stdout, r.stdout
+    assert "falling back" not in r.stderr and "gave up" not in r.stderr, r.stderr[-2000:]

@@ -174,7 +174,7 @@ def test_bench_two_ranks_dry_run_with_backend_override():
     assert "cpu_baseline" not in out                                # reported at N = 1 only
     assert out["parity"]["bit_identical"] and out["parity"]["timed_context_bit_identical"]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r05_bench_torchrun_2ranks_gloo_one_device.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r06_bench_torchrun_2ranks_gloo_one_device.json"), "w") as f:
         f.write(lines[0] + "\n")
 
 
