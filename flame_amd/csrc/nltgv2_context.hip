@@ -464,6 +464,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
   ok = ok && hipStreamCreateWithFlags(&ctx->topo_stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipStreamCreateWithFlags(&ctx->raster_stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&ctx->ev_canon, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&ctx->ev_snap, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&ctx->ev_raster_done, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&ctx->ev_topo_ready, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&ctx->ev_run[0], hipEventDisableTiming) == hipSuccess;
@@ -526,6 +527,7 @@ int flame_nltgv2_destroy(flame_nltgv2_ctx* ctx) {
   if (ctx->ev_topo_ready) (void)hipEventDestroy(ctx->ev_topo_ready);
   if (ctx->raster_stream) (void)hipStreamSynchronize(ctx->raster_stream), (void)hipStreamDestroy(ctx->raster_stream);
   if (ctx->ev_canon) (void)hipEventDestroy(ctx->ev_canon);
+  if (ctx->ev_snap) (void)hipEventDestroy(ctx->ev_snap);
   if (ctx->ev_raster_done) (void)hipEventDestroy(ctx->ev_raster_done);
   for (hipEvent_t e : ctx->ev_run)
     if (e) (void)hipEventDestroy(e);
@@ -598,6 +600,10 @@ int flame_nltgv2_set_option(flame_nltgv2_ctx* ctx, int option, int value) {
     case FLAME_NLTGV2_OPT_PRESLEEP:
       if (value < 0 || value > 256) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
       ctx->opt_presleep = value;
+      return 0;
+    case FLAME_NLTGV2_OPT_MESH_STATE:
+      if (value < 0 || value > 1) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+      ctx->opt_mesh_state = value;
       return 0;
     case FLAME_NLTGV2_OPT_COST_SUM:
       if (value < 0 || value > 1) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);

@@ -260,6 +260,9 @@ struct flame_nltgv2_ctx {
   bool layout_pos_saved = false;
   bool host_layout_valid = true;
   uint64_t tv_counted_topo = ~0ull;  // get_info counted the vertex-per-lane waves of this topology
+  int opt_mesh_state = 0;         // interpolate_mesh_begin beside runs in flight: 0 settles them, 1 reads the canonical arrays as the last settle left them
+  uint64_t snap_topo = ~0ull;     // ev_snap was recorded for this topology (enqueue_run, when the first run after a settle goes out)
+  hipEvent_t ev_snap = nullptr;
   int opt_cost_sum = 0;           // flame_nltgv2_costs: 0 sequential sums in the reference's edge / the caller's vertex order (host), 1 k_block_sum
   int opt_sync_path = 0;          // 0 auto (device where it applies), 1 host index maps + host tables, 2 device or error
   int last_sync_path = 0;         // 1 host, 2 device

@@ -85,11 +85,18 @@ int flame_nltgv2_interpolate_mesh_begin(flame_nltgv2_ctx* ctx, const int32_t* tr
     HIPCHK(ctx, hipMemcpyAsync(d_tv, tri_valid, (size_t)T, hipMemcpyHostToDevice, rs));
   }
   tr_a = tr_us();
-  rc = ensure_canon(ctx);  // ... it stops here ...
-  if (rc) return rc;
-  tr_b = tr_us();
-  HIPCHK(ctx, hipEventRecord(ctx->ev_canon, ctx->stream));
-  HIPCHK(ctx, hipStreamWaitEvent(rs, ctx->ev_canon, 0));  // ... and may go on as soon as the caller enqueues the next run
+  if (ctx->opt_mesh_state == 1 && !ctx->canon_valid && ctx->snap_topo == ctx->topo) {
+    // FLAME_NLTGV2_OPT_MESH_STATE = 1 and runs enqueued since the last settle: the map is of the state that settle left, which the
+    // canonical arrays still hold (enqueue_run recorded ev_snap behind their last writer); the runs in flight are not waited for
+    tr_b = tr_us();
+    HIPCHK(ctx, hipStreamWaitEvent(rs, ctx->ev_snap, 0));
+  } else {
+    rc = ensure_canon(ctx);  // ... it stops here ...
+    if (rc) return rc;
+    tr_b = tr_us();
+    HIPCHK(ctx, hipEventRecord(ctx->ev_canon, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(rs, ctx->ev_canon, 0));  // ... and may go on as soon as the caller enqueues the next run
+  }
   LAUNCHCHK(ctx, launch_interpolate_mesh(T, (const int32_t*)ctx->r_tris.p, ctx->c.pos, ctx->c.x, graph_scale, nullptr, d_tv,
                                          (unsigned long long*)ctx->r_keys.p, (float*)ctx->r_img.p, (int*)ctx->r_cov.p, rows, cols, rs));
   // the rasteriser's kernels are the last readers of the canonical arrays (and the writers of the resident map): whoever rewrites those

@@ -479,6 +479,12 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
     if (ctx->export_ptr) LAUNCHCHK(ctx, launch_export(ctx->c, ctx->f, false, ctx->export_scale, ctx->export_ptr, ctx->stream));
     return enqueue_photo_sweep(ctx, false);
   }
+  if (ctx->opt_mesh_state == 1 && ctx->canon_valid) {
+    // FLAME_NLTGV2_OPT_MESH_STATE = 1: the canonical arrays stand as they are until the next unpack (the runs work on the packed
+    // copies); interpolate_mesh_begin may read them beside the runs once everything enqueued so far -- their writers -- is through
+    HIPCHK(ctx, hipEventRecord(ctx->ev_snap, ctx->stream));
+    ctx->snap_topo = ctx->topo;
+  }
   int rc = ensure_fused(ctx);
   if (rc) return rc;
   if (ctx->pending.active) {  // chaining onto an unchecked persistent run

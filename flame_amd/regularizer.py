@@ -27,7 +27,7 @@ _FP = C.POINTER(C.c_float)
 _IP = C.POINTER(C.c_int32)
 
 # stable options (include/flame_nltgv2.h) ...
-OPT_SOLVER, OPT_USE_HIPGRAPH, OPT_PERSISTENT, OPT_PROBE, OPT_VERIFY_RECORDS, OPT_PLACEMENT, OPT_SYNC_PATH, OPT_COST_SUM = 1, 2, 5, 12, 14, 16, 17, 18
+OPT_SOLVER, OPT_USE_HIPGRAPH, OPT_PERSISTENT, OPT_PROBE, OPT_VERIFY_RECORDS, OPT_PLACEMENT, OPT_SYNC_PATH, OPT_COST_SUM, OPT_MESH_STATE = 1, 2, 5, 12, 14, 16, 17, 18, 19
 # ... and the experimental range (tuning knobs / test hooks of the current kernels; tools/ and the tests use them)
 OPT_BLOCK_WAVES, OPT_UNROLL, OPT_DUAL_PUBLISH, OPT_PRESLEEP, OPT_XCDS, OPT_FAULT_INJECT, OPT_POLL_GAP = 103, 104, 106, 108, 109, 110, 113
 RUN_PATHS = {0: "none", 1: "persistent (the lane-per-half-edge form, retired in round 3)", 2: "per-step hipGraph", 3: "per-step eager", 4: "canonical 4-sweep",

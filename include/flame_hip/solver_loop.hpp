@@ -134,24 +134,24 @@ class SolverLoop {
   void withDevice(F&& f) {
     CallerAccess dev_lk(this);
     f(dev_, iterations_.load());
-    // device mode: a call that settled the solver leaves the queue empty -- the caller, who holds the device anyway, fills it again
-    // before it lets go (the solver thread would need a wake-up for it: ~0.1 ms of a standing solver per call)
-    // (not after the solver thread has ended, on an error or a stop: nobody would ever check those rounds; and what top_up() throws
-    // -- its periodic sync() -- is the LOOP's error, kept in error(): f has succeeded and the frame thread's call must not fail for it)
-    bool ready;
-    {
-      std::lock_guard<std::mutex> lk(state_mtx_);
-      ready = device_ready_ && !stop_.load() && !exited_ && error_.empty() && thread_.joinable();
-    }
-    if (graph_ == nullptr && ready) {
-      try {
-        top_up();
-      } catch (const std::exception& e) {
-        std::lock_guard<std::mutex> lk(state_mtx_);
-        error_ = e.what();
-        stop_.store(true);
-      }
-    }
+    refill();
+  }
+  // The same with a second part that does not need the solver stopped: f runs on the settled device image, the queue is filled
+  // again, THEN g runs (still with exclusive access to the context) beside the rounds just enqueued.  Made for
+  //     loop.withDevice([&](DeviceGraph& d, uint64_t it) { d.syncCommit(); },
+  //                     [&](DeviceGraph& d, uint64_t it) { d.interpolateMeshBegin(tris, rows, cols, scale); });
+  // with FLAME_NLTGV2_OPT_MESH_STATE = 1 on the context: the mesh is of the state f left (both callbacks get that state's iteration
+  // count), and the host time of its preparation -- the triangles' upload, the rasteriser's launches: ~65 us at 640x480 -- no longer
+  // stands between the commit and the solver's next round.  A g that settles the solver after all (any call that reads or edits the
+  // state does) is correct, just not faster: the queue is filled once more behind it.
+  template <class F, class G>
+  void withDevice(F&& f, G&& g) {
+    CallerAccess dev_lk(this);
+    const uint64_t it = iterations_.load();
+    f(dev_, it);
+    refill();
+    g(dev_, it);
+    refill();
   }
   // Device mode: the image uploaded through withDevice() is what the loop iterates on from now on.
   void deviceReady() {
@@ -297,6 +297,25 @@ class SolverLoop {
     }
     std::lock_guard<std::mutex> lk(state_mtx_);
     exited_ = true;
+  }
+  // (dev_mtx_ held) device mode: a call that settled the solver leaves the queue empty -- the caller, who holds the device anyway, fills
+  // it again before it lets go (the solver thread would need a wake-up for it: ~0.1 ms of a standing solver per call).  Not after the
+  // solver thread has ended, on an error or a stop: nobody would ever check those rounds; and what top_up() throws -- its periodic
+  // sync() -- is the LOOP's error, kept in error(): the caller's own call has succeeded and must not fail for it.
+  void refill() {
+    bool ready;
+    {
+      std::lock_guard<std::mutex> lk(state_mtx_);
+      ready = device_ready_ && !stop_.load() && !exited_ && error_.empty() && thread_.joinable();
+    }
+    if (graph_ != nullptr || !ready) return;
+    try {
+      top_up();
+    } catch (const std::exception& e) {
+      std::lock_guard<std::mutex> lk(state_mtx_);
+      error_ = e.what();
+      stop_.store(true);
+    }
   }
   // (dev_mtx_ held) device mode: enqueues rounds until two are in flight; true if it enqueued any
   bool top_up() {

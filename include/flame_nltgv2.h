@@ -327,6 +327,14 @@ enum {
                                         bit; 1 = both sums on the device in a fixed strided / pairwise order (a few microseconds, no copy of
                                         2E + V floats; agrees with the sequential sums to ~1e-6 relative) */
 
+  FLAME_NLTGV2_OPT_MESH_STATE = 19,  /* flame_nltgv2_interpolate_mesh_begin with runs enqueued since the last call that settled the solver:
+                                        0 (default) = waits for them and rasterises the state they leave; 1 = rasterises the state that
+                                        call left (the canonical arrays as they have stood since: a run works on its packed copies) and
+                                        waits for nothing -- the runs in flight go on beside the rasteriser.  The reference's
+                                        interpolateMesh reads whatever iterate its solver thread has reached (flame.cc:372-380 under
+                                        graph_mtx_): the state right after syncGraph is one of them.  What a frame loop gains: it can
+                                        enqueue the next round BEFORE it prepares the mesh (SolverLoop::withDevice(f, g)) */
+
   FLAME_NLTGV2_OPT_EXPERIMENTAL = 100 /* option numbers from here on are tuning knobs and test hooks of the current kernels: declared in
                                          flame_amd/csrc/flame_nltgv2_test_options.h (tests and tools only), not part of this surface */
 };

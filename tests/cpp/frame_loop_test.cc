@@ -112,6 +112,7 @@ int main(int argc, char** argv) {
   out.buf.clear();
   const int iters_per_round = argc > 3 ? std::atoi(argv[3]) : 200;
   const bool lean = argc > 4 && std::atoi(argv[4]) != 0;
+  const bool one_part = std::getenv("FRAME_LOOP_ONE_PART") != nullptr;  // syncCommit + interpolateMeshBegin with the solver stopped for both
   const int32_t W = in.one<int32_t>(), H = in.one<int32_t>(), pad = in.one<int32_t>();
   const int32_t n_feats = in.one<int32_t>(), n_initial = in.one<int32_t>(), n_new = in.one<int32_t>(), host_work_us = in.one<int32_t>();
   Mat3 K, Kinv;
@@ -226,12 +227,25 @@ int main(int argc, char** argv) {
         // device for both -- the solver is settled once, the rasteriser reads the canonical arrays the commit has just written (no
         // unpack), and no freshly enqueued round has to be waited for in between (round 6: two holds cost 0.4 ms of waiting and a
         // second 0.1 ms gap per frame, profiles/r06_cpp_frame_loop.txt)
-        loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t it) {
-          it_commit = it_raster = it;
-          d.syncCommit();
-          lap(6);
-          d.interpolateMeshBegin(tris, H, W, 1.0f);
-        });
+        // Round 6, second step: the mesh does not need the solver stopped either -- with FLAME_NLTGV2_OPT_MESH_STATE = 1 it is of the
+        // state the commit left, read from the canonical arrays beside the next rounds, which withDevice(f, g) enqueues BEFORE the
+        // mesh's host work (FRAME_LOOP_ONE_PART=1: the one-part hold, for comparison)
+        if (one_part) {
+          loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t it) {
+            it_commit = it_raster = it;
+            d.syncCommit();
+            lap(6);
+            d.interpolateMeshBegin(tris, H, W, 1.0f);
+          });
+        } else {
+          loop.withDevice(
+              [&](dgraph::DeviceGraph& d, uint64_t it) {
+                it_commit = it_raster = it;
+                d.syncCommit();
+                lap(6);
+              },
+              [&](dgraph::DeviceGraph& d, uint64_t) { d.interpolateMeshBegin(tris, H, W, 1.0f); });
+        }
         lap(7);
         if (!lean) out.one(it_commit);
       }
@@ -240,7 +254,9 @@ int main(int argc, char** argv) {
         t_stage = std::chrono::steady_clock::now();
         loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t it) {
           it_raster = it;
-          d.interpolateMeshBegin(tris, H, W, 1.0f);
+          d.interpolateMeshBegin(tris, H, W, 1.0f);  // (this one settles the rounds in flight: the option is set behind it)
+          if (!one_part && flame_nltgv2_set_option(d.handle(), FLAME_NLTGV2_OPT_MESH_STATE, 1) != 0)
+            throw flame_hip::Error(FLAME_NLTGV2_ERR_INVALID_ARG, "set_option");
         });
         lap(7);
       }

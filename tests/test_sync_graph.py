@@ -536,6 +536,84 @@ def test_new_vertices_start_at_the_resident_dense_map(built, mode):
             reg.sync_graph(feat_id, pos, data, weight, edges, init_from_map=True)
 
 
+def test_mesh_of_the_state_the_last_settle_left_beside_runs_in_flight(built):
+    """FLAME_NLTGV2_OPT_MESH_STATE = 1: with runs enqueued since the last call that settled the solver, interpolate_mesh_begin rasterises
+    the state THAT call left (the canonical arrays, which a run does not touch) and does not wait for the runs; 0 (default): it settles
+    them and shows what they leave.  Both against the one-call form on a second context; after a sync_commit (the frame loop's use:
+    commit, next round out, then the mesh) the map is the committed graph's, the state then moves on by exactly the enqueued runs."""
+    import torch  # noqa: F401
+
+    import flame_amd
+    from flame_amd.regularizer import OPT_MESH_STATE
+
+    w, h = 320, 240
+    rng = np.random.default_rng(5)
+    g0 = synth.make_graph("320x240", seed=15)
+    feat_id = np.arange(g0["V"], dtype=np.int32)
+    params = flame_amd.Params()
+    tris = synth.delaunay_native(g0["pos"])[0]
+
+    def one_call(n):
+        with flame_amd.Regularizer(0) as chk:
+            chk.upload_graph(g0)
+            chk.run(params, n)
+            return chk.interpolate_mesh(tris, h, w, graph_scale=1.5)
+
+    with flame_amd.Regularizer(0) as reg:
+        with pytest.raises(flame_amd.NLTGV2Error):
+            reg.set_option(OPT_MESH_STATE, 2)
+        reg.upload_graph(g0)
+        reg.run(params, 40)
+        reg.download_state()  # (a call that reads the state: the canonical arrays hold iteration 40 from here on)
+        reg.set_option(OPT_MESH_STATE, 1)
+        reg.run_async(params, 25)
+        reg.run_async(params, 25)
+        reg.interpolate_mesh_begin(tris, h, w, graph_scale=1.5)
+        assert reg.runs_in_flight() >= 0  # (a query, not a wait)
+        at40, cov40 = reg.interpolate_mesh_end()
+        ref40, rcov40 = one_call(40)
+        assert np.array_equal(at40, ref40, equal_nan=True) and cov40 == rcov40
+        # the default waits for the runs and shows iteration 90
+        reg.set_option(OPT_MESH_STATE, 0)
+        reg.interpolate_mesh_begin(tris, h, w, graph_scale=1.5)
+        at90, cov90 = reg.interpolate_mesh_end()
+        ref90, rcov90 = one_call(90)
+        assert np.array_equal(at90, ref90, equal_nan=True) and cov90 == rcov90
+        assert not np.array_equal(at40, at90, equal_nan=True)
+        # with the state canonical and nothing enqueued the option changes nothing
+        reg.set_option(OPT_MESH_STATE, 1)
+        reg.interpolate_mesh_begin(tris, h, w, graph_scale=1.5)
+        again, _ = reg.interpolate_mesh_end()
+        assert np.array_equal(again, at90, equal_nan=True)
+        # the frame loop's order: prepare, iterate, commit, next round out, mesh of the committed graph
+        ref = sync_oracle.RefGraph.from_flat(g0, feat_id)
+        flat = sync_oracle.flatten(ref, feat_id)
+        assert oracle.run(flat, 90) == 0
+        sync_oracle.absorb(ref, flat, feat_id)
+        ids_now = feat_id
+        feat_id2, pos2, data2, _ = next_frame(rng, feat_id, g0["pos"].copy(), g0["data_term"].copy(), g0["V"], w, h)
+        weight2 = np.ones(len(feat_id2), np.float32)
+        edges2 = synth.delaunay_edges_scipy(pos2)
+        tris2 = synth.delaunay_native(pos2)[0]
+        reg.sync_prepare(feat_id2, pos2, data2, weight2, edges2)
+        reg.run_async(params, 11)
+        flat = sync_oracle.flatten(ref, ids_now)
+        assert oracle.run(flat, 11) == 0
+        sync_oracle.absorb(ref, flat, ids_now)
+        reg.sync_commit()
+        reg.run_async(params, 30)  # (the round a frame loop enqueues before it prepares the mesh)
+        reg.interpolate_mesh_begin(tris2, h, w, graph_scale=1.5)
+        committed, ccov = reg.interpolate_mesh_end()
+        sync_oracle.sync(ref, feat_id2, pos2, data2, weight2, edges2)
+        at_commit = sync_oracle.flatten(ref, feat_id2)
+        with flame_amd.Regularizer(0) as chk:
+            chk.upload_graph(at_commit)
+            want, wcov = chk.interpolate_mesh(tris2, h, w, graph_scale=1.5)
+        assert np.array_equal(committed, want, equal_nan=True) and ccov == wcov
+        assert oracle.run(at_commit, 30) == 0
+        assert_state_equal(reg.download_state(), at_commit, keys=OUT_KEYS, what="30 iterations behind the commit")
+
+
 def test_vertex_counts_at_the_walk_padding_boundary(built):
     """Advisor, round 4: the device builder sized the per-vertex walk tables to V rounded up to 16384 bytes, topology_buffers then asked
     for V + 16 -- a reused buffer of exactly 16384 bytes was re-allocated AFTER the build for V in 16369..16384 and the tables were

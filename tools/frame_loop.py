@@ -31,6 +31,7 @@ ap.add_argument("--cpu", action="store_true")
 ap.add_argument("--pipelined", action="store_true")
 ap.add_argument("--cover", type=float, default=1.25, help="--pipelined: the chunk enqueued before Delaunay + sync_prepare covers this many times their last duration")
 ap.add_argument("--host-sync", action="store_true", help="index maps + layout tables on the host (rounds 1-3), for comparison")
+ap.add_argument("--mesh-state", type=int, default=1, help="--pipelined: FLAME_NLTGV2_OPT_MESH_STATE; 1 = the mesh of a frame is of the state sync_commit left, begun beside the chunk enqueued behind the commit (0: it settles that chunk first)")
 a = ap.parse_args()
 W, H = [int(v) for v in a.size.split("x")]
 sc = ss.PlaneScene(W, H, seed=21, normal=(0.2, -0.1, 1.0), distance=2.2)
@@ -152,6 +153,7 @@ else:
         solve(0.0)
     torch.cuda.synchronize()
     chunk_ms = min(e0.elapsed_time(e1) for e0, e1 in events) * 4  # --iters iterations on this graph, in ms (the probe ran iters / 4)
+    reg.set_option(flame_amd.regularizer.OPT_MESH_STATE, a.mesh_state)
     events.clear(), labels.clear(), iters_done.clear()
     track_ms, host_ms, build_ms, rast_ms, prev = 0.3, 1.0, 0.3, 0.3, news[0]
     for k, (fid, pos, idp) in zip(news[1:], plan[1:]):
@@ -176,7 +178,8 @@ else:
         reg.sync_commit()                                             # settles the solver: swap + state gather
         t_commit = (time.perf_counter() - t0) * 1e3
         solve(chunk_ms, "sync_commit")
-        reg.interpolate_mesh_begin(tris, H, W)                        # settles the solver; rasteriser + copy-out on a side stream
+        # --mesh-state 0: settles the solver; 1: beside the chunk just enqueued, the state the commit left.  Rasteriser + copy-out on a side stream
+        reg.interpolate_mesh_begin(tris, H, W)
         solve(max(chunk_ms, 1.05 * rast_ms), "interpolate_mesh_begin")
         t0 = time.perf_counter()
         dense, cov = reg.interpolate_mesh_end(copy=False)
