@@ -233,41 +233,72 @@ int topology_buffers(flame_nltgv2_ctx* ctx, bool want_e2, size_t n_wg_info, size
 }
 
 // The clears every new topology needs (no record or flag of an earlier topology may survive).
-void topology_fills(flame_nltgv2_ctx* ctx, bool want_e2, std::vector<StageFill>* fills) {
+void expansion_fills(const PackedLayout& L, void* rec_edge, void* rec_nbr, void* wg2_rmax, std::vector<StageFill>* fills) {
+  // the spare rows behind the last slice: no edge, neighbour 0 (what the unrolled sweeps may read past a slice's end)
+  fills->push_back(StageFill{(char*)rec_edge + sizeof(int32_t) * (size_t)L.rows * kWave, sizeof(int32_t) * kRowPad * kWave, 0xffffffffu});
+  fills->push_back(StageFill{(char*)rec_nbr + sizeof(uint32_t) * (size_t)L.rows * kWave, sizeof(uint32_t) * kRowPad * kWave, 0u});
+  if (wg2_rmax) fills->push_back(StageFill{wg2_rmax, 64, 0u});
+}
+
+void topology_fills(flame_nltgv2_ctx* ctx, bool want_e2, std::vector<StageFill>* fills, bool early) {
   const PackedLayout& L = ctx->L;
   const size_t n_slots = (size_t)(L.rows + kRowPad) * kWave, n_packed = (size_t)L.n_slices * kWave;
   const StageFill base[] = {
       {ctx->err.p, kErrBytes, 0u}, {ctx->abort_flag.p, sizeof(int), 0u}, {ctx->xbuf.p, kXbufBytesPerVertex * records_capacity(L) + 64, 0u},
       // empty slots / padding vertices of the second copies: zero, as the packing kernels write them in the first
-      {ctx->hq_alt.p, sizeof(float4) * n_slots, 0u}, {ctx->vstate_alt.p, sizeof(float4) * n_packed, 0u},
-      // the spare rows behind the last slice: no edge, neighbour 0 (what the unrolled sweeps may read past a slice's end)
-      {(char*)ctx->rec_edge.p + sizeof(int32_t) * (size_t)L.rows * kWave, sizeof(int32_t) * kRowPad * kWave, 0xffffffffu},
-      {(char*)ctx->rec_nbr.p + sizeof(uint32_t) * (size_t)L.rows * kWave, sizeof(uint32_t) * kRowPad * kWave, 0u}};
+      {ctx->hq_alt.p, sizeof(float4) * n_slots, 0u}, {ctx->vstate_alt.p, sizeof(float4) * n_packed, 0u}};
   fills->insert(fills->end(), base, base + sizeof(base) / sizeof(base[0]));
+  if (!early) expansion_fills(L, ctx->rec_edge.p, ctx->rec_nbr.p, want_e2 ? ctx->wg2_rmax.p : nullptr, fills);
   // (the tags start over: no record of an earlier topology may survive, in the placement pool either)
-  if (want_e2) fills->push_back(StageFill{ctx->wg2_rmax.p, 64, 0u});
   if (ctx->place_base) {
     fills->push_back(StageFill{ctx->place_base, (size_t)2 * kPlacePages * 4096, 0u});
     fills->push_back(StageFill{(int*)ctx->place_fill.p + 2 * kPlacePages, 64, 0u});
   }
 }
 
-// Per-slot and per-lane arrays from the per-vertex tables that stand on the device (nltgv2_layout.hip), record placement, and the
-// run-side bookkeeping of a new topology.
-int topology_expand(flame_nltgv2_ctx* ctx, bool want_e2) {
+// Where the records that cross XCDs go (if the pages have been timed already; otherwise the first run does both).
+bool placement_applies(const flame_nltgv2_ctx* ctx, const PackedLayout& L) {
+  return L.wg_ok && ctx->place_state == 1 && ctx->opt_place && L.wg_count > 2 * (ctx->prop.multiProcessorCount / 8) &&
+         (ctx->opt_xcds == 0 || ctx->opt_xcds == 8);
+}
+
+// The live tables as an expansion's operands (after refresh_args).
+ExpandTables live_tables(flame_nltgv2_ctx* ctx) {
+  ExpandTables t;
+  t.c = ctx->c, t.f = ctx->f;
+  t.iperm = (const int32_t*)ctx->iperm.p, t.wg_v0 = (const int32_t*)ctx->wg_v0.p, t.order_m = (const int32_t*)ctx->order_m.p;
+  t.rid_of = (const int32_t*)ctx->rid_of.p, t.wg_vfirst = (const uint8_t*)ctx->wg_vfirst.p;
+  t.wg2_info = (int32_t*)ctx->wg2_info.p, t.wg2_vfirst = (const uint8_t*)ctx->wg2_vfirst.p;
+  t.wg2_slot = (int32_t*)ctx->wg2_slot.p, t.wg2_vid = (int32_t*)ctx->wg2_vid.p, t.wg2_nbr = (int32_t*)ctx->wg2_nbr.p;
+  t.wg2_fetch = (int32_t*)ctx->wg2_fetch.p, t.wg2_meta = (uint32_t*)ctx->wg2_meta.p, t.wg2_rmax = (int*)ctx->wg2_rmax.p;
+  return t;
+}
+
+// Per-slot and per-lane arrays from the per-vertex tables that stand on the device (nltgv2_layout.hip) and the records' places: the
+// launches, on the tables `t` names.
+int expand_launches(flame_nltgv2_ctx* ctx, const PackedLayout& L, const ExpandTables& t, bool want_e2, hipStream_t stream) {
+  LAUNCHCHK(ctx, launch_build_sell(t.c, t.f, t.iperm, stream));
+  if (L.wg_ok) LAUNCHCHK(ctx, launch_build_patches(t.c, t.f, t.wg_v0, t.order_m, t.rid_of, t.wg_vfirst, t.iperm, stream));
+  if (want_e2)
+    LAUNCHCHK(ctx, launch_build_patches2(t.c, t.f, L.wg2_count, t.wg2_info, t.order_m, t.rid_of, t.wg2_vfirst, t.iperm, t.wg2_slot, t.wg2_vid,
+                                         t.wg2_meta, t.wg2_nbr, t.wg2_fetch, t.wg2_rmax, stream));
+  if (t.rec_off)
+    LAUNCHCHK(ctx, launch_place_records(t.c, t.f, t.per_xcd, t.order_m, t.rid_of, t.place_patch, (int8_t*)(t.place_patch + t.stride),
+                                        (const uint16_t*)ctx->place_rank.p, kPlacePages, t.place_fill, t.rec_off, (int)t.stride, stream));
+  return 0;
+}
+
+// The expansion of the live tables (unless topo_commit has had it done on them while they were the spare set) and the run-side
+// bookkeeping of a new topology.
+int topology_expand(flame_nltgv2_ctx* ctx, bool want_e2, bool launched) {
   const PackedLayout& L = ctx->L;
-  LAUNCHCHK(ctx, launch_build_sell(ctx->c, ctx->f, (const int32_t*)ctx->iperm.p, ctx->stream));
-  if (L.wg_ok)
-    LAUNCHCHK(ctx, launch_build_patches(ctx->c, ctx->f, (const int32_t*)ctx->wg_v0.p, (const int32_t*)ctx->order_m.p,
-                                        (const int32_t*)ctx->rid_of.p, (const uint8_t*)ctx->wg_vfirst.p,
-                                        (const int32_t*)ctx->iperm.p, ctx->stream));
+  if (!launched) {
+    const int rc = expand_launches(ctx, L, live_tables(ctx), want_e2, ctx->stream);
+    if (rc) return rc;
+  }
   ctx->pv2_args = Pv2Args{};
   ctx->wg2_usable = false;
   if (want_e2) {
-    LAUNCHCHK(ctx, launch_build_patches2(ctx->c, ctx->f, L.wg2_count, (int32_t*)ctx->wg2_info.p, (const int32_t*)ctx->order_m.p,
-                                         (const int32_t*)ctx->rid_of.p, (const uint8_t*)ctx->wg2_vfirst.p, (const int32_t*)ctx->iperm.p,
-                                         (int32_t*)ctx->wg2_slot.p, (int32_t*)ctx->wg2_vid.p, (uint32_t*)ctx->wg2_meta.p,
-                                         (int32_t*)ctx->wg2_nbr.p, (int32_t*)ctx->wg2_fetch.p, (int*)ctx->wg2_rmax.p, ctx->stream));
     ctx->pv2_args.slot = (const int32_t*)ctx->wg2_slot.p, ctx->pv2_args.vid = (const int32_t*)ctx->wg2_vid.p;
     ctx->pv2_args.meta = (const uint32_t*)ctx->wg2_meta.p, ctx->pv2_args.nbr = (const int32_t*)ctx->wg2_nbr.p;
     ctx->pv2_args.fetch = (const int32_t*)ctx->wg2_fetch.p, ctx->pv2_args.info = (const int32_t*)ctx->wg2_info.p;
@@ -276,10 +307,8 @@ int topology_expand(flame_nltgv2_ctx* ctx, bool want_e2) {
       ctx->pv2_occ = pv2_patches_per_cu(L.wg2_lcap, false), ctx->pv2_occ_verify = pv2_patches_per_cu(L.wg2_lcap, true), ctx->pv2_occ_lcap = L.wg2_lcap;
     ctx->wg2_built = true;  // (on the device; whether every patch can fetch its records the first plan reads from wg2_rmax)
   }
-  // where the records that cross XCDs go (if the pages have been timed already; otherwise the first run does both): on
-  // the stream behind the layout kernels, nobody waits for it
-  if (L.wg_ok && ctx->place_state == 1 && ctx->opt_place && L.wg_count > 2 * (ctx->prop.multiProcessorCount / 8) &&
-      (ctx->opt_xcds == 0 || ctx->opt_xcds == 8)) {
+  // the records' places: on the stream behind the layout kernels, nobody waits for it
+  if (!launched && placement_applies(ctx, L)) {
     refresh_args(ctx);
     const int rc = place_records(ctx, (L.wg_count + 7) / 8);
     if (rc) return rc;
@@ -293,8 +322,8 @@ int topology_expand(flame_nltgv2_ctx* ctx, bool want_e2) {
 
 // Whether the new topology also gets layout (E2), two half-edges per lane: where the one-half-edge patches would fill the CUs
 // (kPv2FromPerCu per CU and more), or where it is asked for by name.
-bool wants_e2(const flame_nltgv2_ctx* ctx) {
-  const PackedLayout& L = ctx->L;
+bool wants_e2(const flame_nltgv2_ctx* ctx) { return wants_e2(ctx, ctx->L); }
+bool wants_e2(const flame_nltgv2_ctx* ctx, const PackedLayout& L) {
   const int cus = ctx->prop.multiProcessorCount;
   const int64_t est_patches = L.wg_rowpack ? (int64_t)L.wg_count : ((static_cast<int64_t>(2) * L.E + L.V / 32) / 54 + 1);
   return L.wg_ok && L.max_degree <= 32 && ctx->opt_probe == 0 &&
@@ -467,6 +496,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
   ok = ok && hipEventCreateWithFlags(&ctx->ev_snap, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&ctx->ev_raster_done, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&ctx->ev_topo_ready, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&ctx->ev_expanded, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&ctx->ev_run[0], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&ctx->ev_run[1], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->h_err, kErrBytes, hipHostMallocDefault) == hipSuccess;
@@ -505,6 +535,8 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
               &ctx->wg_vfirst, &ctx->place_pool, &ctx->place_rank, &ctx->place_fill, &ctx->place_rec_off, &ctx->place_patch, &ctx->place_meas, &ctx->progress};
   for (DevBuf* b : {&ctx->feat_stamp_d, &ctx->feat_key_d, &ctx->feat_val_d, &ctx->topo_scratch, &ctx->topo_dims, &ctx->layout_pos}) ctx->all.push_back(b);
   for (auto& b : ctx->nx) ctx->all.push_back(&b);
+  for (auto& b : ctx->ex) ctx->all.push_back(&b);
+  ctx->all.push_back(&ctx->place_patch_nx), ctx->all.push_back(&ctx->place_fill_nx);
   for (auto& b : ctx->sp_v) ctx->all.push_back(&b);
   for (auto& b : ctx->sp_q) ctx->all.push_back(&b);
   *out = ctx;
@@ -525,6 +557,7 @@ int flame_nltgv2_destroy(flame_nltgv2_ctx* ctx) {
     if (st.h) (void)hipHostFree(st.h);
   if (ctx->topo_stream) (void)hipStreamSynchronize(ctx->topo_stream), (void)hipStreamDestroy(ctx->topo_stream);
   if (ctx->ev_topo_ready) (void)hipEventDestroy(ctx->ev_topo_ready);
+  if (ctx->ev_expanded) (void)hipEventDestroy(ctx->ev_expanded);
   if (ctx->raster_stream) (void)hipStreamSynchronize(ctx->raster_stream), (void)hipStreamDestroy(ctx->raster_stream);
   if (ctx->ev_canon) (void)hipEventDestroy(ctx->ev_canon);
   if (ctx->ev_snap) (void)hipEventDestroy(ctx->ev_snap);

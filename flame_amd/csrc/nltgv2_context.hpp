@@ -281,6 +281,18 @@ struct flame_nltgv2_ctx {
                                     &wg_vfirst, &wg2_info, &wg2_vfirst, &data, &weight};
     return live[i];
   }
+  // ... and the tables the EXPANSION of that topology writes (per slot, per lane, the records' places): filled on the side stream at
+  // commit while the solver's last rounds still run on the live ones, swapped (ex_live) together with nx once the solver has stopped.
+  enum { EX_REC_NBR, EX_REC_EDGE, EX_EDGE_SRC_SLOT, EX_WG_SLOT, EX_WG_VID, EX_WG_META, EX_WG_NBR, EX_WG_FETCH, EX_WG2_SLOT, EX_WG2_NBR,
+         EX_WG2_VID, EX_WG2_META, EX_WG2_FETCH, EX_WG2_RMAX, EX_PLACE_REC_OFF, EX_COUNT };
+  DevBuf ex[EX_COUNT];
+  DevBuf* ex_live(int i) {
+    DevBuf* const live[EX_COUNT] = {&rec_nbr, &rec_edge, &edge_src_slot, &wg_slot, &wg_vid, &wg_meta, &wg_nbr, &wg_fetch, &wg2_slot, &wg2_nbr,
+                                    &wg2_vid, &wg2_meta, &wg2_fetch, &wg2_rmax, &place_rec_off};
+    return live[i];
+  }
+  DevBuf place_patch_nx, place_fill_nx;  // placement scratch of that expansion (place_patch / place_fill's counters may be a run's own placement's)
+  hipEvent_t ev_expanded = nullptr;      // recorded on the side stream behind it: the context's stream waits for it after the swap
   std::vector<char> prep_host;      // inputs of a prepared sync that will go the host way at commit
   const void *prep_vmap = nullptr, *prep_emap = nullptr, *prep_init = nullptr;  // (in topo_scratch) index maps / init values of the prepared sync
   hipStream_t raster_stream = nullptr;  // the side stream of interpolate_mesh_begin / _end
@@ -395,9 +407,34 @@ int staged_h2d(flame_nltgv2_ctx* ctx, const StageCopy* cp, size_t n, const Stage
 int upload_topology(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const StageCopy* extra, size_t n_extra, bool long_lived);
 int topology_buffers(flame_nltgv2_ctx* ctx, bool want_e2, size_t n_wg_info, size_t n_wg_v0, size_t n_wg_vfirst, size_t n_wg2_info,
                      size_t n_wg2_vfirst);
-void topology_fills(flame_nltgv2_ctx* ctx, bool want_e2, std::vector<StageFill>* fills);
-int topology_expand(flame_nltgv2_ctx* ctx, bool want_e2);
+// The tables an expansion reads (per vertex, per patch) and writes (per slot, per lane, the records' places): the live ones, or the spare
+// sets of a prepared sync (nx / ex).
+struct ExpandTables {
+  CanonArgs c;   // V, E, row_ptr, half, src, dst
+  FusedArgs f;   // n_slices, slice_row, perm, rec_nbr, rec_edge, edge_src_slot, wg_count, wg_info, wg_slot .. wg_fetch
+  const int32_t *iperm = nullptr, *wg_v0 = nullptr, *order_m = nullptr, *rid_of = nullptr;
+  const uint8_t* wg_vfirst = nullptr;
+  int32_t* wg2_info = nullptr;
+  const uint8_t* wg2_vfirst = nullptr;
+  int32_t *wg2_slot = nullptr, *wg2_vid = nullptr, *wg2_nbr = nullptr, *wg2_fetch = nullptr;
+  uint32_t* wg2_meta = nullptr;
+  int* wg2_rmax = nullptr;
+  int32_t* rec_off = nullptr;      // placement: [2 * stride] record offsets (nullptr: no placement)
+  int32_t* place_patch = nullptr;  // ... its scratch: [stride] patch of a record + [stride] class bytes
+  int* place_fill = nullptr;       // ... the page counters and cursors
+  int per_xcd = 0;
+  size_t stride = 0;
+};
+ExpandTables live_tables(flame_nltgv2_ctx* ctx);
+bool placement_applies(const flame_nltgv2_ctx* ctx, const PackedLayout& L);
+// early = true: the clears of the tables an expansion writes (the spare rows of rec_*, the patches' fetch maximum) are left out -- they
+// were done on the spare set in front of the expansion (topo_commit)
+void topology_fills(flame_nltgv2_ctx* ctx, bool want_e2, std::vector<StageFill>* fills, bool early = false);
+void expansion_fills(const PackedLayout& L, void* rec_edge, void* rec_nbr, void* wg2_rmax, std::vector<StageFill>* fills);
+int expand_launches(flame_nltgv2_ctx* ctx, const PackedLayout& L, const ExpandTables& t, bool want_e2, hipStream_t stream);
+int topology_expand(flame_nltgv2_ctx* ctx, bool want_e2, bool launched = false);  // launched: by expand_launches on the tables now live
 bool wants_e2(const flame_nltgv2_ctx* ctx);
+bool wants_e2(const flame_nltgv2_ctx* ctx, const PackedLayout& L);
 int ensure_host_layout(flame_nltgv2_ctx* ctx);  // the host image of the topology (ctx->L's vectors, h_src, h_dst) after a device build
 // ---- nltgv2_topo_capi.hip: the per-frame sync with the topology built on the device
 int topo_prepare(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, bool* applicable);  // builder enqueued on the side stream

@@ -353,6 +353,7 @@ int topo_commit(flame_nltgv2_ctx* ctx, bool* done) {
   using C = flame_nltgv2_ctx;
   C::PreparedSync& P = ctx->prepared;
   if (!P.active || !P.device || P.topo != ctx->topo) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  hipStream_t ts = ctx->topo_stream;
   const bool trace = std::getenv("FLAME_NLTGV2_TRACE") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
   HIPCHK(ctx, hipStreamSynchronize(ctx->topo_stream));  // the solver is still iterating on the context's stream meanwhile
@@ -368,11 +369,78 @@ int topo_commit(flame_nltgv2_ctx* ctx, bool* done) {
     if (trace) std::fprintf(stderr, "[flame_nltgv2] sync_graph: device build declined (flags %d, edges %d of %d, patches %d), host path\n", dm.flags, dm.n_edges, E, dm.wg_count);
     return 0;
   }
+  // ---- the next topology's expansion: into the spare tables, on the side stream, while the solver's last rounds still run ---------------
+  // (round 6: these six kernels and their launches stood between the settled solver and its next round, ~60 us of a 130 us stop)
+  if (std::getenv("FLAME_NLTGV2_LATE_EXPAND")) {  // (for comparison: the solver is settled first, as through round 5)
+    const int rc0 = ensure_canon(ctx);
+    if (rc0) return rc0;
+  }
+  const int n_slices = (V + kWave - 1) / kWave;
+  PackedLayout Ln;  // (scalars only: the tables stand on the device)
+  Ln.V = V, Ln.E = E, Ln.n_slices = n_slices, Ln.rows = dm.rows, Ln.max_degree = dm.max_degree;
+  Ln.wg_ok = true, Ln.wg_rowpack = true, Ln.wg_count = dm.wg_count, Ln.wg_lcap = dm.wg_lcap, Ln.wg_slab_slots = 0, Ln.n_rec = V;
+  Ln.wg2_walked = true, Ln.wg2_ok = dm.max_degree <= 32 && dm.wg2_count > 0, Ln.wg2_count = dm.wg2_count, Ln.wg2_lcap = dm.wg2_lcap;
+  Ln.tv_ok = false, Ln.tv_waves = 0;
+  const bool want_e2 = wants_e2(ctx, Ln) && Ln.wg2_ok && Ln.wg2_count <= kPv2WavesPerCu * cus * 4;
+  const bool placed = placement_applies(ctx, Ln);
+  int rc = 0;
+  {
+    const size_t n_slots = (size_t)(Ln.rows + kRowPad) * kWave, lanes = (size_t)Ln.wg_count * kWave, lanes2 = (size_t)Ln.wg2_count * kWave;
+    if (n_slots > (size_t)0x7fffffff) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+    const size_t stride = records_capacity(Ln);
+    struct { int i; size_t bytes; } req[] = {
+        {C::EX_REC_NBR, sizeof(uint32_t) * n_slots}, {C::EX_REC_EDGE, sizeof(int32_t) * n_slots}, {C::EX_EDGE_SRC_SLOT, sizeof(int32_t) * (size_t)E},
+        {C::EX_WG_SLOT, sizeof(int32_t) * lanes}, {C::EX_WG_VID, sizeof(int32_t) * lanes}, {C::EX_WG_META, sizeof(uint32_t) * lanes},
+        {C::EX_WG_NBR, sizeof(int32_t) * lanes}, {C::EX_WG_FETCH, sizeof(int32_t) * lanes},
+        {C::EX_WG2_SLOT, want_e2 ? sizeof(int32_t) * 2 * lanes2 : 0}, {C::EX_WG2_NBR, want_e2 ? sizeof(int32_t) * 2 * lanes2 : 0},
+        {C::EX_WG2_VID, want_e2 ? sizeof(int32_t) * lanes2 : 0}, {C::EX_WG2_META, want_e2 ? sizeof(uint32_t) * lanes2 : 0},
+        {C::EX_WG2_FETCH, want_e2 ? sizeof(int32_t) * lanes2 : 0}, {C::EX_WG2_RMAX, want_e2 ? (size_t)64 : 0},
+        {C::EX_PLACE_REC_OFF, placed ? sizeof(int32_t) * 2 * stride : 0}};
+    for (auto& r : req)
+      if (r.bytes && (rc = ensure(ctx, ctx->ex[r.i], r.bytes)) != 0) return rc;
+    if (placed) {
+      rc = ensure(ctx, ctx->place_patch_nx, sizeof(int32_t) * stride + stride);
+      if (!rc && ctx->place_fill_nx.cap == 0) {
+        rc = ensure(ctx, ctx->place_fill_nx, sizeof(int) * (2 * kPlacePages + 16 + 128));
+        if (!rc) HIPCHK(ctx, hipMemsetAsync(ctx->place_fill_nx.p, 0, sizeof(int) * (2 * kPlacePages + 16 + 128), ts));
+      }
+      if (rc) return rc;
+    }
+    ExpandTables t;
+    t.c = ctx->c, t.f = ctx->f;  // (every pointer the expansion touches is replaced below; the rest is not read)
+    t.c.V = V, t.c.E = E;
+    t.c.src = (int32_t*)ctx->nx[C::NX_SRC].p, t.c.dst = (int32_t*)ctx->nx[C::NX_DST].p;
+    t.c.row_ptr = (int32_t*)ctx->nx[C::NX_ROW_PTR].p, t.c.half = (uint32_t*)ctx->nx[C::NX_HALF].p;
+    t.f.n_slices = n_slices, t.f.n_slots = (int)n_slots;
+    t.f.slice_row = (int32_t*)ctx->nx[C::NX_SLICE_ROW].p, t.f.perm = (int32_t*)ctx->nx[C::NX_PERM].p, t.f.pdeg = (int32_t*)ctx->nx[C::NX_PDEG].p;
+    t.f.rec_nbr = (uint32_t*)ctx->ex[C::EX_REC_NBR].p, t.f.rec_edge = (int32_t*)ctx->ex[C::EX_REC_EDGE].p;
+    t.f.edge_src_slot = (int32_t*)ctx->ex[C::EX_EDGE_SRC_SLOT].p;
+    t.f.wg_count = Ln.wg_count, t.f.n_rec = Ln.n_rec, t.f.wg_lcap = Ln.wg_lcap, t.f.wg_slab_slots = 0, t.f.wg_rowpack = 1;
+    t.f.wg_slot = (int32_t*)ctx->ex[C::EX_WG_SLOT].p, t.f.wg_vid = (int32_t*)ctx->ex[C::EX_WG_VID].p, t.f.wg_meta = (uint32_t*)ctx->ex[C::EX_WG_META].p;
+    t.f.wg_nbr = (int32_t*)ctx->ex[C::EX_WG_NBR].p, t.f.wg_fetch = (int32_t*)ctx->ex[C::EX_WG_FETCH].p;
+    t.f.wg_info = (int32_t*)ctx->nx[C::NX_WG_INFO].p;
+    t.iperm = (const int32_t*)ctx->nx[C::NX_IPERM].p, t.wg_v0 = (const int32_t*)ctx->nx[C::NX_WG_V0].p;
+    t.order_m = (const int32_t*)ctx->nx[C::NX_ORDER_M].p, t.rid_of = (const int32_t*)ctx->nx[C::NX_RID_OF].p;
+    t.wg_vfirst = (const uint8_t*)ctx->nx[C::NX_WG_VFIRST].p;
+    t.wg2_info = (int32_t*)ctx->nx[C::NX_WG2_INFO].p, t.wg2_vfirst = (const uint8_t*)ctx->nx[C::NX_WG2_VFIRST].p;
+    t.wg2_slot = (int32_t*)ctx->ex[C::EX_WG2_SLOT].p, t.wg2_vid = (int32_t*)ctx->ex[C::EX_WG2_VID].p, t.wg2_nbr = (int32_t*)ctx->ex[C::EX_WG2_NBR].p;
+    t.wg2_fetch = (int32_t*)ctx->ex[C::EX_WG2_FETCH].p, t.wg2_meta = (uint32_t*)ctx->ex[C::EX_WG2_META].p, t.wg2_rmax = (int*)ctx->ex[C::EX_WG2_RMAX].p;
+    if (placed) {
+      t.rec_off = (int32_t*)ctx->ex[C::EX_PLACE_REC_OFF].p, t.place_patch = (int32_t*)ctx->place_patch_nx.p, t.place_fill = (int*)ctx->place_fill_nx.p;
+      t.per_xcd = (Ln.wg_count + 7) / 8, t.stride = stride;
+    }
+    std::vector<StageFill> fills;
+    expansion_fills(Ln, t.f.rec_edge, t.f.rec_nbr, want_e2 ? t.wg2_rmax : nullptr, &fills);
+    rc = staged_h2d(ctx, nullptr, 0, fills.data(), fills.size(), 0, ts);
+    if (!rc) rc = expand_launches(ctx, Ln, t, want_e2, ts);
+    if (rc) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_expanded, ts));
+  }
+  const auto t1b = std::chrono::steady_clock::now();
   // ---- the solver stops here: the chain of runs is settled, the state goes to its canonical arrays ---------------------------------------
-  int rc = ensure_canon(ctx);
+  rc = ensure_canon(ctx);
   if (rc) return rc;
   const auto t2 = std::chrono::steady_clock::now();
-  const int n_slices = (V + kWave - 1) / kWave;
   const size_t fV = sizeof(float) * (size_t)V, fE = sizeof(float) * (size_t)E;
   DevBuf* cur_v[9] = {&ctx->x, &ctx->w1, &ctx->w2, &ctx->xb, &ctx->w1b, &ctx->w2b, &ctx->xp, &ctx->w1p, &ctx->w2p};
   DevBuf* cur_q[3] = {&ctx->q1, &ctx->q2, &ctx->q3};
@@ -391,19 +459,20 @@ int topo_commit(flame_nltgv2_ctx* ctx, bool* done) {
   PackedLayout& L = ctx->L;
   L.V = V, L.E = E, L.n_slices = n_slices, L.rows = dm.rows, L.max_degree = dm.max_degree;
   L.wg_ok = true, L.wg_rowpack = true, L.wg_count = dm.wg_count, L.wg_lcap = dm.wg_lcap, L.wg_slab_slots = 0, L.n_rec = V;
-  L.wg2_walked = true, L.wg2_ok = dm.max_degree <= 32 && dm.wg2_count > 0, L.wg2_count = dm.wg2_count, L.wg2_lcap = dm.wg2_lcap;
+  L.wg2_walked = true, L.wg2_ok = Ln.wg2_ok, L.wg2_count = dm.wg2_count, L.wg2_lcap = dm.wg2_lcap;
   L.tv_ok = false, L.tv_waves = 0;
   ctx->host_layout_valid = false;
-  const bool want_e2 = wants_e2(ctx) && L.wg2_ok && L.wg2_count <= kPv2WavesPerCu * cus * 4;
   for (int i = 0; i < C::NX_COUNT; ++i) std::swap(*ctx->nx_live(i), ctx->nx[i]);  // the next topology becomes the live one
+  for (int i = 0; i < C::EX_COUNT; ++i) std::swap(*ctx->ex_live(i), ctx->ex[i]);  // ... with its expansion
   rc = topology_buffers(ctx, want_e2, 4 * (size_t)L.wg_count, (size_t)L.wg_count, (size_t)V, 4 * (size_t)L.wg2_count, (size_t)V);
   if (rc) return rc;
   std::vector<StageFill> fills;
-  topology_fills(ctx, want_e2, &fills);
+  topology_fills(ctx, want_e2, &fills, /*early=*/true);
   rc = staged_h2d(ctx, nullptr, 0, fills.data(), fills.size());
   if (rc) return rc;
-  rc = topology_expand(ctx, want_e2);
+  rc = topology_expand(ctx, want_e2, /*launched=*/true);
   if (rc) return rc;
+  if (placed) ctx->place_topo = ctx->topo, ctx->place_per_xcd = (L.wg_count + 7) / 8;
   SyncArgs sa;
   sa.V = V, sa.E = E;
   sa.old_of_new = (const int32_t*)ctx->prep_vmap, sa.old_of_new_edge = (const int32_t*)ctx->prep_emap;
@@ -418,6 +487,7 @@ int topo_commit(flame_nltgv2_ctx* ctx, bool* done) {
   sa.half = (const uint32_t*)ctx->half.p, sa.pos = (const float2*)ctx->pos.p;
   sa.alpha = (float*)ctx->alpha.p, sa.beta = (float*)ctx->beta.p, sa.need_nbr = (uint8_t*)ctx->sync_need.p;
   LAUNCHCHK(ctx, launch_sync_state(sa, ctx->stream));
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_expanded, 0));  // (the state gather reads per-vertex tables only; what follows reads the expansion)
   for (int i = 0; i < 9; ++i) std::swap(*cur_v[i], ctx->sp_v[i]);
   for (int i = 0; i < 3; ++i) std::swap(*cur_q[i], ctx->sp_q[i]);
   refresh_args(ctx);
@@ -435,8 +505,8 @@ int topo_commit(flame_nltgv2_ctx* ctx, bool* done) {
     const auto t3 = std::chrono::steady_clock::now();
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     std::fprintf(stderr, "[flame_nltgv2] sync_graph (device): prepare (checks, staging, builder enqueued) %.3f ms; commit: builder awaited %.3f, "
-                 "solver settled %.3f, expansion + state gather %.3f ms (V=%d E=%d: %d kept, %d patches, %d two-half-edge patches)\n",
-                 ms(P.t_begin, P.t_enqueued), ms(t0, t1), ms(t1, t2), ms(t2, t3), V, E, dm.n_keep, dm.wg_count, dm.wg2_count);
+                 "expansion enqueued beside the solver %.3f, solver settled %.3f, swap + state gather %.3f ms (V=%d E=%d: %d kept, %d patches, %d two-half-edge patches)\n",
+                 ms(P.t_begin, P.t_enqueued), ms(t0, t1), ms(t1, t1b), ms(t1b, t2), ms(t2, t3), V, E, dm.n_keep, dm.wg_count, dm.wg2_count);
   }
   return 0;
 }
