@@ -106,9 +106,13 @@ int wait_raster(flame_nltgv2_ctx* ctx) {
 }
 
 int ensure_canon(flame_nltgv2_ctx* ctx) {
+  bool unpacked = false;
   if (ctx->pending.active) {  // a persistent run is still unchecked: settle it before anything reads or edits the state
-    const int rc = finish(ctx);
-    if (rc) return rc;
+    const int rc = finish(ctx, /*unpack_behind=*/true, &unpacked);
+    if (rc) {
+      if (unpacked) ctx->canon_valid = true;
+      return rc;
+    }
   }
   // interpolate_mesh_begin's side stream may still read the canonical pos / x: whoever comes through here is about to rewrite them (the
   // unpack below, or the caller: project_graph, rescale_data, update_data, upload_state) -- also when the arrays are already current
@@ -116,7 +120,7 @@ int ensure_canon(flame_nltgv2_ctx* ctx) {
   int rc0 = wait_raster(ctx);
   if (rc0) return rc0;
   if (ctx->canon_valid) return 0;
-  LAUNCHCHK(ctx, launch_unpack_state(ctx->c, ctx->f, ctx->parity, ctx->have_prev, ctx->stream));
+  if (!unpacked) LAUNCHCHK(ctx, launch_unpack_state(ctx->c, ctx->f, ctx->parity, ctx->have_prev, ctx->stream));
   ctx->canon_valid = true;
   return 0;
 }
@@ -553,6 +557,7 @@ int flame_nltgv2_destroy(flame_nltgv2_ctx* ctx) {
     if (b->p) (void)hipFree(b->p);
   if (ctx->h_err) (void)hipHostFree(ctx->h_err);
   if (ctx->h_cost) (void)hipHostFree(ctx->h_cost);
+  if (ctx->h_keep) (void)hipHostFree(ctx->h_keep);
   for (auto& st : ctx->stage)
     if (st.h) (void)hipHostFree(st.h);
   if (ctx->topo_stream) (void)hipStreamSynchronize(ctx->topo_stream), (void)hipStreamDestroy(ctx->topo_stream);

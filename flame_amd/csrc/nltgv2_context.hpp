@@ -351,6 +351,8 @@ struct flame_nltgv2_ctx {
   int* h_err = nullptr;    // pinned, kErrBytes
   int last_expired[16] = {0};  // what the most recent expired wait reported (report_expired)
   float* h_cost = nullptr; // pinned
+  uint8_t* h_keep = nullptr;  // pinned: project_graph's keep mask, written by its kernel
+  size_t h_keep_cap = 0;
   std::vector<CachedGraph> graphs;
   size_t device_bytes = 0;
 };
@@ -452,7 +454,9 @@ int prepare_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n);
 PhotoFuse photo_target(const flame_nltgv2_ctx* ctx);
 int enqueue_photo_sweep(flame_nltgv2_ctx* ctx, bool packed_current);
 int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n);
-int finish(flame_nltgv2_ctx* ctx);                            // reads the error word; rolls a failed persistent run back and redoes it
+// reads the error word; rolls a failed persistent run back and redoes it.  unpack_behind: the unpack of the state is enqueued before the
+// host waits (*unpacked: it was, and the runs went through -- the canonical arrays are current)
+int finish(flame_nltgv2_ctx* ctx, bool unpack_behind = false, bool* unpacked = nullptr);
 int snapshot_chain_start(flame_nltgv2_ctx* ctx);
 int place_records(flame_nltgv2_ctx* ctx, int per_xcd);        // record placement, once per topology (k_place_assign)
 int place_calibrate(flame_nltgv2_ctx* ctx);                   // ... and the page ranking of the context's pool (measured, or taken over with a pool)

@@ -469,8 +469,20 @@ int flame_nltgv2_project_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_project
   rc = ensure_canon(ctx);
   if (rc) return rc;
   const size_t V = (size_t)ctx->L.V;
-  rc = ensure(ctx, ctx->r_valid, V + 16);
-  if (rc) return rc;
+  // the keep mask is written by the kernel straight into pinned host memory, the positions the layout was built from are kept by the
+  // same kernel (round 6: as a device-to-device copy, the kernel and a copy out to the caller's pageable array this call was three
+  // more trips through the runtime, 10-16 us each, with the solver standing still: profiles/r06_cpp_frame_loop.txt)
+  if (ctx->h_keep_cap < V + 16) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_keep) (void)hipHostFree(ctx->h_keep);
+    ctx->h_keep = nullptr, ctx->h_keep_cap = 0;
+    const size_t want = (V + 16) + (V + 16) / 2;
+    if (hipHostMalloc((void**)&ctx->h_keep, want, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(ctx, FLAME_NLTGV2_ERR_OOM);
+    }
+    ctx->h_keep_cap = want;
+  }
   ProjectGeometry geo;
   std::memcpy(geo.K, pr->K, sizeof(geo.K));
   std::memcpy(geo.Kinv, pr->Kinv, sizeof(geo.Kinv));
@@ -478,16 +490,17 @@ int flame_nltgv2_project_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_project
   std::memcpy(geo.q, pr->q_ref_to_cmp, sizeof(geo.q));
   std::memcpy(geo.t, pr->t_ref_to_cmp, sizeof(geo.t));
   geo.rx = pr->region_x, geo.ry = pr->region_y, geo.rw = pr->region_w, geo.rh = pr->region_h;
+  float2* pos_before = nullptr;
   if (!ctx->layout_pos_saved && V) {  // the layout was built from the positions as they stand: keep them (nltgv2_context.hpp: layout_pos)
     rc = ensure(ctx, ctx->layout_pos, sizeof(float) * 2 * V);
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->layout_pos.p, ctx->pos.p, sizeof(float) * 2 * V, hipMemcpyDeviceToDevice, ctx->stream));
+    pos_before = (float2*)ctx->layout_pos.p;
     ctx->layout_pos_saved = true;
   }
-  LAUNCHCHK(ctx, launch_project_graph(ctx->c, graph_scale, geo, (uint8_t*)ctx->r_valid.p, ctx->stream));
-  if (V) HIPCHK(ctx, hipMemcpyAsync(keep_out, ctx->r_valid.p, V, hipMemcpyDeviceToHost, ctx->stream));
+  LAUNCHCHK(ctx, launch_project_graph(ctx->c, graph_scale, geo, ctx->h_keep, pos_before, ctx->stream));
   if (V && pos_out) HIPCHK(ctx, hipMemcpyAsync(pos_out, ctx->pos.p, sizeof(float) * 2 * V, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (V) std::memcpy(keep_out, ctx->h_keep, V);
   ctx->fused_valid = false;  // x changed; pos changed: alpha/dx/dy of the packed records are stale until the next
                              // sync_graph / upload_graph re-derives them (the reference re-triangulates right after)
   ctx->static_stale = true;

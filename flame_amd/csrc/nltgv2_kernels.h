@@ -268,7 +268,8 @@ int launch_pack_state(const CanonArgs& c, const FusedArgs& a, int parity, bool w
 int launch_unpack_state(const CanonArgs& c, const FusedArgs& a, int parity, bool have_prev, hipStream_t s);
 int launch_export(const CanonArgs& c, const FusedArgs& a, bool packed_current, float scale, float* dst,
                   hipStream_t s);
-int launch_project_graph(const CanonArgs& c, float graph_scale, const ProjectGeometry& geo, uint8_t* keep, hipStream_t s);
+// keep: one byte per vertex (device memory, or pinned host memory the kernel writes straight into); pos_before (optional): the positions as they stood
+int launch_project_graph(const CanonArgs& c, float graph_scale, const ProjectGeometry& geo, uint8_t* keep, float2* pos_before, hipStream_t s);
 int launch_rescale(const CanonArgs& c, float graph_scale, float* new_scale_dev, hipStream_t s);
 int launch_interpolate_mesh(int T, const int32_t* tris, const float2* vtx, const float* values, float value_scale,
                             const uint8_t* vtx_valid, const uint8_t* tri_valid, unsigned long long* keys, float* img,

@@ -453,10 +453,11 @@ k_raster_resolve(long n, const unsigned long long* __restrict__ keys, float* __r
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_project_graph(int V, float2* __restrict__ pos, float* __restrict__ x, float graph_scale, ProjectGeometry geo,
-                uint8_t* __restrict__ keep) {
+                uint8_t* __restrict__ keep, float2* __restrict__ pos_before) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
   const float2 u = pos[v];
+  if (pos_before) pos_before[v] = u;  // (the positions the layout was built from, kept for its host image: nltgv2_context.hpp layout_pos)
   const float idepth = x[v] * graph_scale;
   float nx, ny, nid;
   if (idepth == 0.0f) {
@@ -618,9 +619,9 @@ int launch_export(const CanonArgs& c, const FusedArgs& a, bool packed_current, f
   return (int)hipGetLastError();
 }
 
-int launch_project_graph(const CanonArgs& c, float graph_scale, const ProjectGeometry& geo, uint8_t* keep, hipStream_t s) {
+int launch_project_graph(const CanonArgs& c, float graph_scale, const ProjectGeometry& geo, uint8_t* keep, float2* pos_before, hipStream_t s) {
   if (c.V <= 0) return 0;
-  hipLaunchKernelGGL(k_project_graph, grid1d(c.V), dim3(256), 0, s, c.V, c.pos, c.x, graph_scale, geo, keep);
+  hipLaunchKernelGGL(k_project_graph, grid1d(c.V), dim3(256), 0, s, c.V, c.pos, c.x, graph_scale, geo, keep, pos_before);
   return (int)hipGetLastError();
 }
 

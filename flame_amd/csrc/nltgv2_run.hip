@@ -732,8 +732,19 @@ void trace_expired_wait(flame_nltgv2_ctx* ctx) {
                left, left ? lo - 1 : 0, left ? hi - 1 : 0, silent, first_silent);
 }
 
-int finish(flame_nltgv2_ctx* ctx) {
+int finish(flame_nltgv2_ctx* ctx, bool unpack_behind, bool* unpacked) {
   HIPCHK(ctx, hipMemcpyAsync(ctx->h_err, ctx->err.p, kErrBytes, hipMemcpyDeviceToHost, ctx->stream));
+  bool behind = false;
+  if (unpack_behind && ctx->pending.active && !ctx->canon_valid && !ctx->replaying) {
+    // The caller wants the state in its canonical arrays (ensure_canon): the unpack goes out BEHIND the runs, before the host has seen
+    // how they ended -- between the error word's arrival and a kernel launched after it the solver's stream stood empty for 25-30 us,
+    // in every call of a frame loop that settles the solver (profiles/r06_cpp_frame_loop.txt).  If the runs did expire the canonical
+    // arrays now hold rubbish: the chain is redone below, canon_valid stays false and the caller unpacks once more.
+    const int rc = wait_raster(ctx);
+    if (rc) return rc;
+    LAUNCHCHK(ctx, launch_unpack_state(ctx->c, ctx->f, ctx->parity, ctx->have_prev, ctx->stream));
+    behind = true;
+  }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   flame_nltgv2_ctx::PendingRun run;
   std::swap(run, ctx->pending);  // (ctx->pending is now inactive and empty)
@@ -812,8 +823,10 @@ int finish(flame_nltgv2_ctx* ctx) {
     // NaN/Inf in a dual variable (the reference's FLAME_ASSERT h:174): reported once; the state stays readable
     // (download_state, costs) and the solve can go on or be re-initialised -- q was clamped to +-1 where it happened
     HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, kErrBytes, ctx->stream));
+    if (unpacked) *unpacked = behind;  // (the state stays readable)
     return fail(ctx, FLAME_NLTGV2_ERR_NAN);
   }
+  if (unpacked) *unpacked = behind;
   return 0;
 }
 
