@@ -614,6 +614,64 @@ def test_mesh_of_the_state_the_last_settle_left_beside_runs_in_flight(built):
         assert_state_equal(reg.download_state(), at_commit, keys=OUT_KEYS, what="30 iterations behind the commit")
 
 
+def test_commit_and_projection_behind_rounds_that_expire(built):
+    """What a frame loop's holds enqueue behind rounds still in flight -- the next topology's expansion into the spare tables (beside the
+    solver), the unpack of the state (behind the runs, before the host has seen how they ended) -- with rounds that EXPIRE
+    (FLAME_NLTGV2_OPT_FAULT_INJECT: every wait gives up): the chain is redone on the per-step path, the state unpacked once more, the
+    commit / the projection work on what the oracle has after the same iterations.  Three frames; then the same with healthy rounds."""
+    import torch  # noqa: F401
+
+    import flame_amd
+    from flame_amd.regularizer import OPT_FAULT_INJECT
+
+    w, h = 320, 240
+    rng = np.random.default_rng(77)
+    g0 = synth.make_graph("320x240", seed=16)
+    feat_id = np.arange(g0["V"], dtype=np.int32)
+    pos, data = g0["pos"].copy(), g0["data_term"].copy()
+    next_id = g0["V"]
+    params = flame_amd.Params()
+    ref = sync_oracle.RefGraph.from_flat(g0, feat_id)
+    with flame_amd.Regularizer(0) as reg:
+        reg.upload_graph(g0)
+        reg.set_feature_ids(feat_id)
+        for frame in range(6):
+            faulty, faulty_read = frame < 3, frame == 3  # (an expired run sends its topology to the per-step path for a few runs: one fault per topology)
+            ids_now = feat_id
+            feat_id, pos, data, next_id = next_frame(rng, feat_id, pos, data, next_id, w, h)
+            weight = np.ones(len(feat_id), np.float32)
+            edges = synth.delaunay_edges_scipy(pos)
+            reg.sync_prepare(feat_id, pos, data, weight, edges)
+            before = reg.info()["timeouts_recovered"]
+            if faulty:
+                reg.set_option(OPT_FAULT_INJECT, 200)
+            reg.run_async(params, 30)
+            reg.run_async(params, 20)
+            reg.sync_commit()  # (the expansion goes out, the runs are found expired and redone, then the swap)
+            if faulty:
+                assert reg.info()["timeouts_recovered"] > before
+                reg.set_option(OPT_FAULT_INJECT, 0)
+            flat = sync_oracle.flatten(ref, ids_now)
+            assert oracle.run(flat, 50) == 0
+            sync_oracle.absorb(ref, flat, ids_now)
+            sync_oracle.sync(ref, feat_id, pos, data, weight, edges)
+            flat = sync_oracle.flatten(ref, feat_id)
+            # rounds on the new graph, a call that reads the state behind them
+            if faulty_read:
+                reg.set_option(OPT_FAULT_INJECT, 200)
+            before = reg.info()["timeouts_recovered"]
+            reg.run_async(params, 25)
+            got = reg.download_state()
+            if faulty_read:
+                assert reg.info()["timeouts_recovered"] > before
+                reg.set_option(OPT_FAULT_INJECT, 0)
+            assert oracle.run(flat, 25) == 0
+            sync_oracle.absorb(ref, flat, feat_id)
+            assert_state_equal(got, flat, keys=OUT_KEYS + ("x_prev",), what=f"frame {frame} ({'expired' if faulty else 'healthy'} rounds)")
+            src, dst, fid = reg.topology()
+            assert np.array_equal(src, flat["src"]) and np.array_equal(dst, flat["dst"]) and np.array_equal(fid, feat_id)
+
+
 def test_vertex_counts_at_the_walk_padding_boundary(built):
     """Advisor, round 4: the device builder sized the per-vertex walk tables to V rounded up to 16384 bytes, topology_buffers then asked
     for V + 16 -- a reused buffer of exactly 16384 bytes was re-allocated AFTER the build for V in 16369..16384 and the tables were
