@@ -105,10 +105,12 @@ int wait_raster(flame_nltgv2_ctx* ctx) {
   return 0;
 }
 
-int ensure_canon(flame_nltgv2_ctx* ctx) {
-  bool unpacked = false;
+int ensure_canon(flame_nltgv2_ctx* ctx, const std::function<int()>* behind, int* behind_state) {
+  bool unpacked = false, launched = false;
+  if (behind_state) *behind_state = kBehindNotLaunched;
   if (ctx->pending.active) {  // a persistent run is still unchecked: settle it before anything reads or edits the state
-    const int rc = finish(ctx, /*unpack_behind=*/true, &unpacked);
+    const int rc = finish(ctx, /*unpack_behind=*/true, &unpacked, behind, &launched);
+    if (behind_state && launched) *behind_state = unpacked ? kBehindDone : kBehindSpoiled;
     if (rc) {
       if (unpacked) ctx->canon_valid = true;
       return rc;
@@ -540,6 +542,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
   for (DevBuf* b : {&ctx->feat_stamp_d, &ctx->feat_key_d, &ctx->feat_val_d, &ctx->topo_scratch, &ctx->topo_dims, &ctx->layout_pos}) ctx->all.push_back(b);
   for (auto& b : ctx->nx) ctx->all.push_back(&b);
   for (auto& b : ctx->ex) ctx->all.push_back(&b);
+  ctx->all.push_back(&ctx->pos_undo);
   ctx->all.push_back(&ctx->place_patch_nx), ctx->all.push_back(&ctx->place_fill_nx);
   for (auto& b : ctx->sp_v) ctx->all.push_back(&b);
   for (auto& b : ctx->sp_q) ctx->all.push_back(&b);

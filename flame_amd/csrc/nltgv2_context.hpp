@@ -24,6 +24,7 @@
 #include <new>
 #include <memory>
 #include <mutex>
+#include <functional>
 #include <vector>
 
 #include "flame_nltgv2.h"
@@ -352,6 +353,7 @@ struct flame_nltgv2_ctx {
   int last_expired[16] = {0};  // what the most recent expired wait reported (report_expired)
   float* h_cost = nullptr; // pinned
   uint8_t* h_keep = nullptr;  // pinned: project_graph's keep mask, written by its kernel
+  DevBuf pos_undo;            // project_graph: the positions as they stood (when layout_pos already holds older ones), to take a projection back
   size_t h_keep_cap = 0;
   std::vector<CachedGraph> graphs;
   size_t device_bytes = 0;
@@ -390,7 +392,13 @@ void refresh_args(flame_nltgv2_ctx* ctx);                     // kernel argument
 int h2d(flame_nltgv2_ctx* ctx, DevBuf& b, const void* src, size_t bytes);
 size_t records_capacity(const PackedLayout& L);
 int wait_raster(flame_nltgv2_ctx* ctx);                       // the context's stream waits for an interpolate_mesh_begin still reading pos / x
-int ensure_canon(flame_nltgv2_ctx* ctx);                      // settles a pending run, unpacks the state if needed
+// settles a pending run, unpacks the state if needed.  `behind` (optional): launches of the caller that only read / edit the canonical arrays
+// and can be REDONE -- they go out right behind the unpack, before the host has seen how the runs ended (one wait of the host instead of
+// two with the solver standing still).  *behind_state: 0 = not launched (nothing was in flight: the caller launches them now), 1 = launched
+// and the runs went through (done), 2 = launched but the runs expired and were redone: the canonical STATE has been unpacked again, what
+// else the launches wrote the caller puts right before it launches them once more.
+enum { kBehindNotLaunched = 0, kBehindDone = 1, kBehindSpoiled = 2 };
+int ensure_canon(flame_nltgv2_ctx* ctx, const std::function<int()>* behind = nullptr, int* behind_state = nullptr);
 int ensure_fused(flame_nltgv2_ctx* ctx);
 bool params_ok(const flame_nltgv2_params* p);
 struct StageCopy {
@@ -456,7 +464,8 @@ int enqueue_photo_sweep(flame_nltgv2_ctx* ctx, bool packed_current);
 int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n);
 // reads the error word; rolls a failed persistent run back and redoes it.  unpack_behind: the unpack of the state is enqueued before the
 // host waits (*unpacked: it was, and the runs went through -- the canonical arrays are current)
-int finish(flame_nltgv2_ctx* ctx, bool unpack_behind = false, bool* unpacked = nullptr);
+int finish(flame_nltgv2_ctx* ctx, bool unpack_behind = false, bool* unpacked = nullptr, const std::function<int()>* behind = nullptr,
+           bool* behind_launched = nullptr);
 int snapshot_chain_start(flame_nltgv2_ctx* ctx);
 int place_records(flame_nltgv2_ctx* ctx, int per_xcd);        // record placement, once per topology (k_place_assign)
 int place_calibrate(flame_nltgv2_ctx* ctx);                   // ... and the page ranking of the context's pool (measured, or taken over with a pool)

@@ -466,12 +466,10 @@ int flame_nltgv2_project_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_project
   if (rc) return rc;
   if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
   if (!pr || !(graph_scale > 0.0f) || (ctx->L.V > 0 && !keep_out)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-  rc = ensure_canon(ctx);
-  if (rc) return rc;
   const size_t V = (size_t)ctx->L.V;
-  // the keep mask is written by the kernel straight into pinned host memory, the positions the layout was built from are kept by the
-  // same kernel (round 6: as a device-to-device copy, the kernel and a copy out to the caller's pageable array this call was three
-  // more trips through the runtime, 10-16 us each, with the solver standing still: profiles/r06_cpp_frame_loop.txt)
+  // the keep mask is written by the kernel straight into pinned host memory, the positions as they stood are kept by the same kernel
+  // (round 6: as a device-to-device copy, the kernel and a copy out to the caller's pageable array this call was three more trips
+  // through the runtime, 10-16 us each, with the solver standing still: profiles/r06_holds.txt)
   if (ctx->h_keep_cap < V + 16) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->h_keep) (void)hipHostFree(ctx->h_keep);
@@ -490,16 +488,30 @@ int flame_nltgv2_project_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_project
   std::memcpy(geo.q, pr->q_ref_to_cmp, sizeof(geo.q));
   std::memcpy(geo.t, pr->t_ref_to_cmp, sizeof(geo.t));
   geo.rx = pr->region_x, geo.ry = pr->region_y, geo.rw = pr->region_w, geo.rh = pr->region_h;
-  float2* pos_before = nullptr;
-  if (!ctx->layout_pos_saved && V) {  // the layout was built from the positions as they stand: keep them (nltgv2_context.hpp: layout_pos)
-    rc = ensure(ctx, ctx->layout_pos, sizeof(float) * 2 * V);
+  // the old positions go to layout_pos if the layout was built from them (nltgv2_context.hpp: kept for its host image), to pos_undo
+  // otherwise: either way the projection can be taken back
+  const bool first_since_layout = !ctx->layout_pos_saved;
+  DevBuf& save = first_since_layout ? ctx->layout_pos : ctx->pos_undo;
+  rc = ensure(ctx, save, sizeof(float) * 2 * V);
+  if (rc) return rc;
+  const std::function<int()> project = [&]() -> int {
+    LAUNCHCHK(ctx, launch_project_graph(ctx->c, graph_scale, geo, ctx->h_keep, (float2*)save.p, ctx->stream));
+    return 0;
+  };
+  // The kernel goes out BEHIND the rounds in flight and the unpack of their state, before the host has seen how they ended: one wait of
+  // the host with the solver standing still instead of two (~29 us each).  If the rounds expired the projection worked on rubbish: the
+  // state has been unpacked again by the time ensure_canon returns, the positions come back from `save`, the kernel runs once more.
+  int behind = kBehindNotLaunched;
+  rc = ensure_canon(ctx, &project, &behind);
+  if (behind == kBehindSpoiled && V) HIPCHK(ctx, hipMemcpyAsync(ctx->pos.p, save.p, sizeof(float) * 2 * V, hipMemcpyDeviceToDevice, ctx->stream));
+  if (rc) return rc;
+  if (behind != kBehindDone) {
+    rc = project();
     if (rc) return rc;
-    pos_before = (float2*)ctx->layout_pos.p;
-    ctx->layout_pos_saved = true;
   }
-  LAUNCHCHK(ctx, launch_project_graph(ctx->c, graph_scale, geo, ctx->h_keep, pos_before, ctx->stream));
+  if (first_since_layout && V) ctx->layout_pos_saved = true;
   if (V && pos_out) HIPCHK(ctx, hipMemcpyAsync(pos_out, ctx->pos.p, sizeof(float) * 2 * V, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (behind != kBehindDone || (V && pos_out)) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (V) std::memcpy(keep_out, ctx->h_keep, V);
   ctx->fused_valid = false;  // x changed; pos changed: alpha/dx/dy of the packed records are stale until the next
                              // sync_graph / upload_graph re-derives them (the reference re-triangulates right after)

@@ -732,7 +732,7 @@ void trace_expired_wait(flame_nltgv2_ctx* ctx) {
                left, left ? lo - 1 : 0, left ? hi - 1 : 0, silent, first_silent);
 }
 
-int finish(flame_nltgv2_ctx* ctx, bool unpack_behind, bool* unpacked) {
+int finish(flame_nltgv2_ctx* ctx, bool unpack_behind, bool* unpacked, const std::function<int()>* behind_fn, bool* behind_launched) {
   HIPCHK(ctx, hipMemcpyAsync(ctx->h_err, ctx->err.p, kErrBytes, hipMemcpyDeviceToHost, ctx->stream));
   bool behind = false;
   if (unpack_behind && ctx->pending.active && !ctx->canon_valid && !ctx->replaying) {
@@ -744,6 +744,11 @@ int finish(flame_nltgv2_ctx* ctx, bool unpack_behind, bool* unpacked) {
     if (rc) return rc;
     LAUNCHCHK(ctx, launch_unpack_state(ctx->c, ctx->f, ctx->parity, ctx->have_prev, ctx->stream));
     behind = true;
+    if (behind_fn) {  // (the caller's own launches on the canonical arrays: see ensure_canon)
+      const int rc2 = (*behind_fn)();
+      if (rc2) return rc2;
+      if (behind_launched) *behind_launched = true;
+    }
   }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   flame_nltgv2_ctx::PendingRun run;
@@ -823,7 +828,8 @@ int finish(flame_nltgv2_ctx* ctx, bool unpack_behind, bool* unpacked) {
     // NaN/Inf in a dual variable (the reference's FLAME_ASSERT h:174): reported once; the state stays readable
     // (download_state, costs) and the solve can go on or be re-initialised -- q was clamped to +-1 where it happened
     HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, kErrBytes, ctx->stream));
-    if (unpacked) *unpacked = behind;  // (the state stays readable)
+    // (the state stays readable; launches of the caller that went out behind the unpack count as spoiled: the call fails, they are taken back)
+    if (unpacked) *unpacked = behind && !(behind_launched && *behind_launched);
     return fail(ctx, FLAME_NLTGV2_ERR_NAN);
   }
   if (unpacked) *unpacked = behind;

@@ -65,3 +65,50 @@ def test_project_then_rescale_then_solve(built):
         reg.run(params, 15)
         oracle.run(ref, 15, ref_p)
         assert_state_equal(reg.download_state(), ref, what="steps after rescale")
+
+
+def test_projection_behind_rounds_in_flight_healthy_and_expired(built):
+    """flame_nltgv2_project_graph with rounds still in flight: its kernel goes out behind them and the unpack of their state, before the
+    host has seen how they ended.  Healthy rounds: one wait, the result of the oracle's projection after the same iterations.  Rounds
+    that EXPIRE (FLAME_NLTGV2_OPT_FAULT_INJECT): the projection worked on rubbish -- the chain is redone, the state unpacked again, the
+    positions come back from where the kernel kept them and it runs once more.  Two projections per case: the first keeps the old
+    positions as the layout's (layout_pos), the second in pos_undo.  Solver steps in between show the packed records follow."""
+    import torch  # noqa: F401
+
+    import flame_amd
+    from flame_amd.regularizer import OPT_FAULT_INJECT
+
+    K = np.array([[525.0, 0, 320.0], [0, 525.0, 240.0], [0, 0, 1]], np.float64)
+    K32, Kinv32 = K.astype(np.float32), np.linalg.inv(K).astype(np.float32)
+    region = (8.0, 8.0, 640.0 - 16.0, 480.0 - 16.0)
+    scale = np.float32(1.1)
+    params = flame_amd.Params()
+    for faulty in (False, True):
+        g = synth.make_graph("640x480", seed=23)
+        ref = synth.copy_graph(g)
+        with flame_amd.Regularizer(0) as reg:
+            reg.upload_graph(g)
+            reg.run(params, 20)
+            oracle.run(ref, 20)
+            for k, angle in enumerate((0.015, -0.01)):
+                R = _rot_y(angle)
+                t = np.array([0.02, -0.01, 0.01], np.float32)
+                KRKinv = (K32 @ R.astype(np.float32) @ Kinv32).astype(np.float32)
+                q = quat_wxyz_from_rot(R)
+                before = reg.info()["timeouts_recovered"]
+                if faulty and k == 0:
+                    reg.set_option(OPT_FAULT_INJECT, 200)
+                reg.run_async(params, 17)
+                reg.run_async(params, 9)
+                keep, pos = reg.project_graph(K32, Kinv32, KRKinv, q, t, region, graph_scale=float(scale))
+                if faulty and k == 0:
+                    assert reg.info()["timeouts_recovered"] > before
+                    reg.set_option(OPT_FAULT_INJECT, 0)
+                oracle.run(ref, 26)
+                rkeep = oracle.graph_project(ref["pos"], ref["x"], float(scale), K32, Kinv32, q, t, KRKinv, region)
+                assert np.array_equal(keep, rkeep), (faulty, k)
+                assert np.array_equal(pos, ref["pos"]), (faulty, k)
+                assert_state_equal(reg.download_state(), ref, what=f"after projection {k} (expired rounds: {faulty})")
+                reg.run(params, 8)
+                oracle.run(ref, 8)
+                assert_state_equal(reg.download_state(), ref, what=f"steps after projection {k} (expired rounds: {faulty})")
