@@ -546,6 +546,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
   ctx->all.push_back(&ctx->place_patch_nx), ctx->all.push_back(&ctx->place_fill_nx);
   for (auto& b : ctx->sp_v) ctx->all.push_back(&b);
   for (auto& b : ctx->sp_q) ctx->all.push_back(&b);
+  for (auto& b : ctx->sp_ab) ctx->all.push_back(&b);
   *out = ctx;
   return FLAME_NLTGV2_OK;
 }

@@ -150,6 +150,7 @@ struct flame_nltgv2_ctx {
   bool have_graph = false;
   bool canon_valid = false, fused_valid = false, have_prev = false;
   DevBuf sp_v[9], sp_q[3], sync_init, sync_vmap, sync_emap, sync_need;  // sync_graph: spare state arrays, inputs, index maps
+  DevBuf sp_ab[2];  // ... and spare alpha / beta (the device path's commit writes them before the solver has stopped)
   std::vector<int32_t> h_old_of_new, h_old_of_new_edge, h_old_edge_of_pair, h_first_pair_of_old, h_bucket_start, h_bucket_item, h_bucket_at;
   FlatMap feat_maps[3];     // [cur]: feature id -> vertex of the CURRENT graph (h_feat), kept from one sync to the next; the
   int feat_cur = 0;         // next sync fills the other one; [2]: scratch of a sync (new edges' duplicates)

@@ -436,25 +436,45 @@ int topo_commit(flame_nltgv2_ctx* ctx, bool* done) {
     if (rc) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_expanded, ts));
   }
-  const auto t1b = std::chrono::steady_clock::now();
-  // ---- the solver stops here: the chain of runs is settled, the state goes to its canonical arrays ---------------------------------------
-  rc = ensure_canon(ctx);
-  if (rc) return rc;
-  const auto t2 = std::chrono::steady_clock::now();
+  // ---- the state gather: old state -> the new graph's arrays through the index maps, new vertices initialised.  It reads the canonical
+  // arrays of the OLD graph and the per-vertex tables of the new one and writes spare arrays only: it can be redone, so it goes out
+  // behind the rounds in flight and the unpack of their state (ensure_canon's `behind`), before the host has seen how they ended.
   const size_t fV = sizeof(float) * (size_t)V, fE = sizeof(float) * (size_t)E;
   DevBuf* cur_v[9] = {&ctx->x, &ctx->w1, &ctx->w2, &ctx->xb, &ctx->w1b, &ctx->w2b, &ctx->xp, &ctx->w1p, &ctx->w2p};
   DevBuf* cur_q[3] = {&ctx->q1, &ctx->q2, &ctx->q3};
-  bool grow = false;  // (growing a buffer frees it: nothing in flight may use it)
-  for (int i = 0; i < 9; ++i) grow = grow || ctx->sp_v[i].cap < fV;
-  for (int i = 0; i < 3; ++i) grow = grow || ctx->sp_q[i].cap < fE;
-  grow = grow || ctx->alpha.cap < fE || ctx->beta.cap < fE || ctx->sync_need.cap < (size_t)V;
-  if (grow) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  for (int i = 0; i < 9 && !rc; ++i) rc = ensure(ctx, ctx->sp_v[i], fV);
+  for (int i = 0; i < 9 && !rc; ++i) rc = ensure(ctx, ctx->sp_v[i], fV);  // (spares: nothing in flight uses them)
   for (int i = 0; i < 3 && !rc; ++i) rc = ensure(ctx, ctx->sp_q[i], fE);
-  if (!rc) rc = ensure(ctx, ctx->alpha, fE);
-  if (!rc) rc = ensure(ctx, ctx->beta, fE);
+  for (int i = 0; i < 2 && !rc; ++i) rc = ensure(ctx, ctx->sp_ab[i], fE);
   if (!rc) rc = ensure(ctx, ctx->sync_need, (size_t)V);
   if (rc) return rc;
+  SyncArgs sa;
+  sa.V = V, sa.E = E;
+  sa.old_of_new = (const int32_t*)ctx->prep_vmap, sa.old_of_new_edge = (const int32_t*)ctx->prep_emap;
+  sa.data = (const float*)ctx->nx[C::NX_DATA].p, sa.weight = (const float*)ctx->nx[C::NX_WEIGHT].p;
+  sa.init_x = P.has_init ? (const float*)ctx->prep_init : nullptr;
+  set_init_map(ctx, P.init_from_map != 0, &sa);
+  if (P.init_from_map != 0 && sa.map_rows == 0) sa.init_map = sa.data;  // (no resident map: set_init_map named the LIVE data terms)
+  sa.check_sticky = P.check_sticky, sa.sticky_threshold = P.sticky_threshold;
+  sa.graph_scale = P.init_graph_scale;
+  for (int i = 0; i < 9; ++i) sa.o[i] = (const float*)cur_v[i]->p, sa.n[i] = (float*)ctx->sp_v[i].p;
+  for (int i = 0; i < 3; ++i) sa.oq[i] = (const float*)cur_q[i]->p, sa.nq[i] = (float*)ctx->sp_q[i].p;
+  sa.src = (const int32_t*)ctx->nx[C::NX_SRC].p, sa.dst = (const int32_t*)ctx->nx[C::NX_DST].p, sa.row_ptr = (const int32_t*)ctx->nx[C::NX_ROW_PTR].p;
+  sa.half = (const uint32_t*)ctx->nx[C::NX_HALF].p, sa.pos = (const float2*)ctx->nx[C::NX_POS].p;
+  sa.alpha = (float*)ctx->sp_ab[0].p, sa.beta = (float*)ctx->sp_ab[1].p, sa.need_nbr = (uint8_t*)ctx->sync_need.p;
+  const std::function<int()> gather = [&]() -> int {
+    LAUNCHCHK(ctx, launch_sync_state(sa, ctx->stream));
+    return 0;
+  };
+  const auto t1b = std::chrono::steady_clock::now();
+  // ---- the solver stops here: the chain of runs is settled, the state goes to its canonical arrays ---------------------------------------
+  int behind = kBehindNotLaunched;
+  rc = ensure_canon(ctx, &gather, &behind);
+  if (rc) return rc;  // (what the gather wrote, if it went out: spare arrays)
+  if (behind != kBehindDone) {  // (nothing was in flight, or the rounds expired and the state has been unpacked again)
+    rc = gather();
+    if (rc) return rc;
+  }
+  const auto t2 = std::chrono::steady_clock::now();
   ctx->have_graph = false;  // (until the new graph stands)
   PackedLayout& L = ctx->L;
   L.V = V, L.E = E, L.n_slices = n_slices, L.rows = dm.rows, L.max_degree = dm.max_degree;
@@ -473,23 +493,10 @@ int topo_commit(flame_nltgv2_ctx* ctx, bool* done) {
   rc = topology_expand(ctx, want_e2, /*launched=*/true);
   if (rc) return rc;
   if (placed) ctx->place_topo = ctx->topo, ctx->place_per_xcd = (L.wg_count + 7) / 8;
-  SyncArgs sa;
-  sa.V = V, sa.E = E;
-  sa.old_of_new = (const int32_t*)ctx->prep_vmap, sa.old_of_new_edge = (const int32_t*)ctx->prep_emap;
-  sa.data = (const float*)ctx->data.p, sa.weight = (const float*)ctx->weight.p;
-  sa.init_x = P.has_init ? (const float*)ctx->prep_init : nullptr;
-  set_init_map(ctx, P.init_from_map != 0, &sa);
-  sa.check_sticky = P.check_sticky, sa.sticky_threshold = P.sticky_threshold;
-  sa.graph_scale = P.init_graph_scale;
-  for (int i = 0; i < 9; ++i) sa.o[i] = (const float*)cur_v[i]->p, sa.n[i] = (float*)ctx->sp_v[i].p;
-  for (int i = 0; i < 3; ++i) sa.oq[i] = (const float*)cur_q[i]->p, sa.nq[i] = (float*)ctx->sp_q[i].p;
-  sa.src = (const int32_t*)ctx->src.p, sa.dst = (const int32_t*)ctx->dst.p, sa.row_ptr = (const int32_t*)ctx->row_ptr.p;
-  sa.half = (const uint32_t*)ctx->half.p, sa.pos = (const float2*)ctx->pos.p;
-  sa.alpha = (float*)ctx->alpha.p, sa.beta = (float*)ctx->beta.p, sa.need_nbr = (uint8_t*)ctx->sync_need.p;
-  LAUNCHCHK(ctx, launch_sync_state(sa, ctx->stream));
-  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_expanded, 0));  // (the state gather reads per-vertex tables only; what follows reads the expansion)
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_expanded, 0));  // (what follows reads the expansion)
   for (int i = 0; i < 9; ++i) std::swap(*cur_v[i], ctx->sp_v[i]);
   for (int i = 0; i < 3; ++i) std::swap(*cur_q[i], ctx->sp_q[i]);
+  std::swap(ctx->alpha, ctx->sp_ab[0]), std::swap(ctx->beta, ctx->sp_ab[1]);
   refresh_args(ctx);
   ctx->static_stale = true;  // (the records of the packed form: with the state, in the one launch of the next run's ensure_fused)
   HIPCHK(ctx, hipEventRecord(ctx->ev_topo_ready, ctx->stream));
