@@ -139,7 +139,10 @@ int flame_nltgv2_sync_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input
  *   prepare  checks the inputs (same errors as sync_graph), copies them, and enqueues the construction of the new topology on a
  *            side stream -- it only READS the live graph; returns at once.  The caller's arrays are free on return.
  *   commit   waits for that construction, settles the runs enqueued meanwhile, swaps the new topology in and moves the state
- *            (what sync_graph does after its index maps).  sync_graph == prepare; commit.
+ *            (what sync_graph does after its index maps).  sync_graph == prepare; commit.  Whatever of this does not need the solver
+ *            stopped is enqueued beside or behind the runs still in flight (the new graph's per-slot and per-lane tables on the side
+ *            stream into spare buffers; the state's unpack and its gather into spare arrays behind the runs): the solver's stream
+ *            stands empty for ~50 us at 640x480.
  * Between the two only run / run_async / sync and read-outs (download_state, export, get_info) may be called; upload_graph,
  * sync_graph, set_feature_ids or another prepare cancel the prepared sync (commit then returns FLAME_NLTGV2_ERR_INVALID_ARG). */
 int flame_nltgv2_sync_prepare(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in);
