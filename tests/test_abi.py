@@ -142,3 +142,19 @@ def test_pv_residency_table_matches_the_build(tmp_path):
     txt2 = open(src2).read()
     assert "return n < 20 ? n : 20;" in txt2 and "if (verify) return n < 16 ? n : 16;" in txt2
 
+
+
+def test_option_numbers_of_the_python_mirror_match_the_header():
+    """flame_amd/regularizer.py names the stable options of include/flame_nltgv2.h (and a few of the experimental range of
+    flame_amd/csrc/flame_nltgv2_test_options.h) by number: every OPT_* constant of the mirror must be the header's value."""
+    import re
+
+    from flame_amd import regularizer
+
+    text = open(os.path.join(ROOT, "include", "flame_nltgv2.h")).read()
+    text += open(os.path.join(ROOT, "flame_amd", "csrc", "flame_nltgv2_test_options.h")).read()
+    header = {m.group(1): int(m.group(2)) for m in re.finditer(r"FLAME_NLTGV2_(OPT_[A-Z0-9_]+)\s*=\s*(\d+)", text)}
+    mirror = {k: v for k, v in vars(regularizer).items() if k.startswith("OPT_") and isinstance(v, int)}
+    assert len(mirror) >= 9 and "OPT_MESH_STATE" in mirror
+    for name, value in mirror.items():
+        assert header.get(name) == value, (name, value, header.get(name))
