@@ -136,6 +136,13 @@ struct ScatterTable {
   ScatterEntry e[kScatterMax];
 };
 int launch_scatter(const ScatterTable& t, const void* blob, hipStream_t s);
+// Up to four device-to-device copies of whole float4 arrays in ONE launch (the start-of-chain snapshot: three memcpy calls were three
+// copy kernels and 19 us of the solver's queue between the first and the second round after every hold of a frame loop)
+struct CopyTable {
+  int n = 0;
+  struct { void* dst; const void* src; size_t bytes; } e[4];  // bytes: multiples of 16
+};
+int launch_copy_arrays(const CopyTable& t, hipStream_t s);
 // flame_nltgv2_sync_graph on the device: index maps in, state gathered from the previous arrays (o / oq) into new ones (n / nq)
 struct SyncArgs {
   int V = 0, E = 0;

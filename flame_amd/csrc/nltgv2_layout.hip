@@ -510,6 +510,25 @@ __global__ void __launch_bounds__(256) k_scatter(const ScatterTable t, const uin
 }
 }  // namespace
 
+namespace {
+__global__ void __launch_bounds__(256) k_copy_arrays(const CopyTable t) {
+  const uint4* __restrict__ src = static_cast<const uint4*>(t.e[blockIdx.y].src);
+  uint4* __restrict__ dst = static_cast<uint4*>(t.e[blockIdx.y].dst);
+  const size_t n16 = t.e[blockIdx.y].bytes >> 4, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+}  // namespace
+
+int launch_copy_arrays(const CopyTable& t, hipStream_t s) {
+  if (t.n <= 0) return 0;
+  size_t mx = 0;
+  for (int i = 0; i < t.n; ++i) mx = t.e[i].bytes > mx ? t.e[i].bytes : mx;
+  unsigned gx = (unsigned)((mx / 16 + 4 * 256 - 1) / (4 * 256));
+  gx = gx < 1 ? 1 : (gx > 512 ? 512 : gx);
+  hipLaunchKernelGGL(k_copy_arrays, dim3(gx, (unsigned)t.n), dim3(256), 0, s, t);
+  return (int)hipGetLastError();
+}
+
 int launch_scatter(const ScatterTable& t, const void* blob, hipStream_t s) {
   if (t.n <= 0) return 0;
   size_t mx = 0;

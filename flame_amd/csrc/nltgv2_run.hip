@@ -846,10 +846,12 @@ int snapshot_chain_start(flame_nltgv2_ctx* ctx) {
   if (!rc) rc = ensure(ctx, ctx->snap_vstate, sizeof(float4) * n_packed);
   if (!rc) rc = ensure(ctx, ctx->snap_bar, sizeof(float4) * n_packed);
   if (rc) return rc;
-  HIPCHK(ctx, hipMemcpyAsync(ctx->snap_hq.p, ctx->hq_alt.p, sizeof(float4) * n_slots, hipMemcpyDeviceToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(ctx->snap_vstate.p, ctx->vstate_alt.p, sizeof(float4) * n_packed, hipMemcpyDeviceToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(ctx->snap_bar.p, ctx->f.bar[ctx->pending.parity_before], sizeof(float4) * n_packed, hipMemcpyDeviceToDevice,
-                             ctx->stream));
+  CopyTable t;  // (one launch: as three memcpy calls this was 19 us between the first and the second round of every chain)
+  t.n = 3;
+  t.e[0] = {ctx->snap_hq.p, ctx->hq_alt.p, sizeof(float4) * n_slots};
+  t.e[1] = {ctx->snap_vstate.p, ctx->vstate_alt.p, sizeof(float4) * n_packed};
+  t.e[2] = {ctx->snap_bar.p, ctx->f.bar[ctx->pending.parity_before], sizeof(float4) * n_packed};
+  LAUNCHCHK(ctx, launch_copy_arrays(t, ctx->stream));
   ctx->pending.snapshotted = true;
   return 0;
 }

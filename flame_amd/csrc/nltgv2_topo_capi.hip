@@ -508,12 +508,14 @@ int topo_commit(flame_nltgv2_ctx* ctx, bool* done) {
   ctx->have_graph = true, ctx->last_error = 0, ctx->last_sync_path = 2;
   *done = true;
   if (trace) {
+    const auto t2b = std::chrono::steady_clock::now();
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const auto t3 = std::chrono::steady_clock::now();
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     std::fprintf(stderr, "[flame_nltgv2] sync_graph (device): prepare (checks, staging, builder enqueued) %.3f ms; commit: builder awaited %.3f, "
-                 "expansion enqueued beside the solver %.3f, solver settled %.3f, swap + state gather %.3f ms (V=%d E=%d: %d kept, %d patches, %d two-half-edge patches)\n",
-                 ms(P.t_begin, P.t_enqueued), ms(t0, t1), ms(t1, t1b), ms(t1b, t2), ms(t2, t3), V, E, dm.n_keep, dm.wg_count, dm.wg2_count);
+                 "expansion enqueued beside the solver %.3f, solver settled (unpack + state gather behind it) %.3f, swap + clears enqueued %.3f, device done %.3f ms later "
+                 "(V=%d E=%d: %d kept, %d patches, %d two-half-edge patches)\n",
+                 ms(P.t_begin, P.t_enqueued), ms(t0, t1), ms(t1, t1b), ms(t1b, t2), ms(t2, t2b), ms(t2b, t3), V, E, dm.n_keep, dm.wg_count, dm.wg2_count);
   }
   return 0;
 }
