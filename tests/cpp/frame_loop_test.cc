@@ -133,6 +133,7 @@ int main(int argc, char** argv) {
     flame_hip::SolverLoop<flame_hip::FlatGraph> loop(nullptr, &graph_mtx, params, iters_per_round);
     loop.start();
     bool first = true;
+    int meshes_begun = 0, meshes_beside_rounds = 0;  // two-part holds: the meshes begun, those with rounds still in flight behind the call
     // per-stage wall time of the frame thread (printed as medians: what a frame's time is made of)
     static const char* const kStage[] = {"addFrame", "updateFeatureIDepths", "delaunayTriangulate", "projectGraph", "syncPrepare", "other host work",
                                          "syncCommit", "interpolateMeshBegin", "other host work (2)", "interpolateMeshEnd"};
@@ -244,7 +245,11 @@ int main(int argc, char** argv) {
                 d.syncCommit();
                 lap(6);
               },
-              [&](dgraph::DeviceGraph& d, uint64_t) { d.interpolateMeshBegin(tris, H, W, 1.0f); });
+              [&](dgraph::DeviceGraph& d, uint64_t) {
+                d.interpolateMeshBegin(tris, H, W, 1.0f);
+                ++meshes_begun;
+                if (d.runsInFlight() > 0) ++meshes_beside_rounds;  // (it did not settle the rounds withDevice has just enqueued)
+              });
         }
         lap(7);
         if (!lean) out.one(it_commit);
@@ -311,6 +316,7 @@ int main(int argc, char** argv) {
     std::printf("frame loop%s: %d frames in %.2f ms (%.2f ms per frame), %llu solver iterations beside them (%d per round, two rounds in flight), %.0f iterations/s in the loop against %.0f undisturbed: "
                 "solver busy %.1f %% of the time since the first graph, idle %.1f %%\n",
                 lean ? " (lean: no state read-back)" : "", n_new, wall_ms, wall_ms / n_new, (unsigned long long)total, iters_per_round, util_at_stop_per_rate, free_rate, 100.0 * busy, 100.0 * (1.0 - busy));
+    if (!one_part) std::printf("  meshes begun beside the next rounds: %d of %d\n", meshes_beside_rounds, meshes_begun);
     if (lean) {
       std::sort(frame_ms.begin() + std::min<size_t>(2, frame_ms.size()), frame_ms.end());
       const double med = frame_ms.size() > 2 ? frame_ms[2 + (frame_ms.size() - 2) / 2] : 0.0;

@@ -2,6 +2,7 @@
 C-ABI).  CPU part: it compiles as plain C++11 with g++ and links against the in-tree library.  GPU
 part: the built program runs step()/run()/costs through the facade and compares with the checker."""
 import os
+import re
 import subprocess
 
 import pytest
@@ -282,6 +283,11 @@ def test_frame_loop_end_to_end(built, tmp_path):
     r2 = subprocess.run([exe, fin, str(tmp_path / "log_lean.bin"), "200", "1"], capture_output=True, text=True, timeout=600)
     print(r2.stdout, r2.stderr)
     assert r2.returncode == 0 and "FAIL" not in r2.stdout and "solver busy" in r2.stdout, r2.stdout + r2.stderr
+    # (the mesh of a frame is begun in the second part of a two-part hold -- SolverLoop::withDevice(f, g), FLAME_NLTGV2_OPT_MESH_STATE = 1 --
+    #  and must not have settled the rounds enqueued between the parts: counted by the program, at least half the frames of both runs)
+    for out in (r.stdout, r2.stdout):
+        m = re.search(r"meshes begun beside the next rounds: (\d+) of (\d+)", out)
+        assert m and int(m.group(2)) >= 10 and 2 * int(m.group(1)) >= int(m.group(2)), out  # (a short round may have ended by itself)
     # ---- pass 2: the program's log replayed on the chained checkers ------------------------------------------------------------------
     log = open(fout, "rb").read()
     at = [0]
