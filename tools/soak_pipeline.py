@@ -30,7 +30,7 @@ import torch  # noqa: F401  (first: one HIP runtime per process)
 import flame_amd
 from flame_amd import synth
 from flame_amd import synth_stereo as ss
-from flame_amd.regularizer import OPT_PERSISTENT, OPT_VERIFY_RECORDS, RUN_PATHS
+from flame_amd.regularizer import OPT_MESH_STATE, OPT_PERSISTENT, OPT_VERIFY_RECORDS, RUN_PATHS
 from flame_amd.stereo import FEATURE_DTYPE, FeatureTracker, StereoParams
 from oracle import capi as oracle
 from oracle import sync_oracle
@@ -43,6 +43,19 @@ W, H, _ = synth.CONFIGS[SIZE]
 KEYS = ("x", "w1", "w2", "x_bar", "w1_bar", "w2_bar", "x_prev", "w1_prev", "w2_prev", "q1", "q2", "q3")
 P = flame_amd.Params()
 stop = threading.Event()
+
+
+def _projection():  # a small camera motion (flame.cc:1888-1905): almost every vertex stays inside the region
+    K = np.array([[0.82 * W, 0, W / 2.0], [0, 0.82 * W, H / 2.0], [0, 0, 1]], np.float64)
+    a = 0.004
+    R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    K32, Kinv32 = K.astype(np.float32), np.linalg.inv(K).astype(np.float32)
+    KRKinv = (K32 @ R.astype(np.float32) @ Kinv32).astype(np.float32)
+    q = np.array([np.cos(a / 2), 0.0, np.sin(a / 2), 0.0], np.float32)
+    return K32, Kinv32, KRKinv, q, np.array([0.01, -0.004, 0.006], np.float32), (4.0, 4.0, W - 8.0, H - 8.0)
+
+
+PROJ = _projection()
 load = {"tracker_updates": 0, "raster_calls": 0}
 
 
@@ -145,13 +158,32 @@ def main():
             tris, edges = synth.delaunay_native(pos)
             ones = np.ones(len(feat_id), np.float32)
             if frame & 1:  # round 4: the sync in two halves -- the builder on its side stream while the solver does 50 more iterations on the old graph
+                # round 6: what a frame loop's holds enqueue beside / behind rounds in flight -- projectGraph's kernel behind 30 iterations,
+                # the commit's expansion beside and its unpack + state gather behind 50 more, the mesh of the committed state beside 10
+                A.run_async(P, 30)
+                keep_a, _ = A.project_graph(*PROJ, graph_scale=1.0)
+                B.run(P, 30)
+                keep_b, _ = B.project_graph(*PROJ, graph_scale=1.0)
+                if not np.array_equal(keep_a, keep_b):
+                    mismatches.append(frame)
                 A.sync_prepare(feat_id, pos, data, ones, edges, edges_unique=True)
                 A.run_async(P, 50)
                 A.sync_commit()
+                A.set_option(OPT_MESH_STATE, 1)
+                A.run_async(P, 10)
+                A.interpolate_mesh_begin(tris, H, W)
+                map_a, cov_a = A.interpolate_mesh_end()
+                A.set_option(OPT_MESH_STATE, 0)
                 B.run(P, 50)
                 B.sync_graph(feat_id, pos, data, ones, edges, edges_unique=True)
+                map_b, cov_b = B.interpolate_mesh(tris, H, W)
+                B.run(P, 10)
+                if cov_a != cov_b or not np.array_equal(map_a, map_b, equal_nan=True):
+                    mismatches.append(frame)
                 if frame < CHECK:
                     flat = sync_oracle.flatten(ref, feat_prev)
+                    oracle.run(flat, 30)
+                    oracle.graph_project(flat["pos"], flat["x"], 1.0, PROJ[0], PROJ[1], PROJ[3], PROJ[4], PROJ[2], PROJ[5])
                     oracle.run(flat, 50)
                     sync_oracle.absorb(ref, flat, feat_prev)
             else:
@@ -160,6 +192,10 @@ def main():
             syncs[{1: "host", 2: "device"}.get(A.info()["last_sync_path"], "?")] = syncs.get({1: "host", 2: "device"}.get(A.info()["last_sync_path"], "?"), 0) + 1
             if frame < CHECK:
                 sync_oracle.sync(ref, feat_id, pos, data, ones, edges)
+                if frame & 1:  # (the 10 iterations beside the mesh)
+                    flat = sync_oracle.flatten(ref, feat_id)
+                    oracle.run(flat, 10)
+                    sync_oracle.absorb(ref, flat, feat_id)
             if (frame + 1) % max(1, FRAMES // 10) == 0:  # (under the lock: a context is one thread's at a time)
                 print(f"frame {frame + 1}: {len(mismatches)} mismatching, A recovered {A.info()['timeouts_recovered']} timeouts, "
                       f"{time.time() - t0:.0f} s", flush=True)
@@ -172,7 +208,7 @@ def main():
         t.join(timeout=10)
     ia = A.info()
     out = {"frames": FRAMES, "size": SIZE, "V_last": int(len(feat_id)), "iterations_per_frame": ITERS, "solver_iterations": budget["done"],
-           "solver_run_paths": paths, "sync_paths_of_A": syncs, "every_other_sync": "sync_prepare + 50 iterations beside the builder + sync_commit", "frames_mismatching_the_per_step_reference": len(mismatches), "first_mismatches": mismatches[:5],
+           "solver_run_paths": paths, "sync_paths_of_A": syncs, "every_other_sync": "30 iterations + projectGraph behind them, sync_prepare + 50 iterations beside the builder + sync_commit (expansion beside, unpack + gather behind), 10 iterations + the mesh of the committed state beside them", "frames_mismatching_the_per_step_reference": len(mismatches), "first_mismatches": mismatches[:5],
            "frames_checked_against_the_chained_cpu_checkers": CHECK, "of_those_mismatching": len(checker_mismatches),
            "timeouts_recovered": int(ia["timeouts_recovered"]), "torn_records_detected": int(ia["torn_records_detected"]),
            "concurrent_load": load, "seconds": round(time.time() - t0, 1),
