@@ -9,9 +9,24 @@ int fail(flame_nltgv2_ctx* ctx, int status) {
   return status;
 }
 
+// An open run in flight ends when it is asked to.  Whoever is about to wait for the device without going through finish() -- a buffer
+// that grows: hipFree and the allocators wait for every stream -- asks first (the request is sent once; finish() does the checking later).
+void request_open_stop(flame_nltgv2_ctx* ctx) {
+  if (!ctx->open_inflight || ctx->open_stop_sent || !ctx->stop_dev.p || !ctx->ctl_stream) return;
+  if (hipMemcpyAsync(ctx->stop_dev.p, ctx->h_stop, sizeof(unsigned), hipMemcpyHostToDevice, ctx->ctl_stream) != hipSuccess) (void)hipGetLastError();
+  ctx->open_stop_sent = true;
+}
+
+// The host waits for the solver's stream: an open run in flight is asked to stop first (it would go on to its bound).
+hipError_t wait_solver_stream(flame_nltgv2_ctx* ctx) {
+  request_open_stop(ctx);
+  return hipStreamSynchronize(ctx->stream);
+}
+
 int ensure(flame_nltgv2_ctx* ctx, DevBuf& b, size_t bytes) {
   if (bytes == 0) bytes = 16;
   if (b.cap >= bytes) return 0;
+  request_open_stop(ctx);
   size_t want = bytes + bytes / 2;  // geometric growth, reused across frames
   want = (want + 255) & ~size_t(255);
   if (b.p) {
@@ -155,6 +170,7 @@ int staged_h2d(flame_nltgv2_ctx* ctx, const StageCopy* cp, size_t n, const Stage
   for (size_t i = 0; i < n; ++i) total += (cp[i].bytes + 255) & ~size_t(255);
   if (total >= (size_t)0xffffff00u) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
   if (total > st.cap) {
+    request_open_stop(ctx);  // (the pinned allocator waits for the device)
     if (st.h) (void)hipHostFree(st.h);
     st.h = nullptr, st.cap = 0;
     const size_t want = total + total / 2;
@@ -412,13 +428,13 @@ int ensure_form_rows(flame_nltgv2_ctx* ctx, int form) {
           {&ctx->wg2_slot, L.wg2_slot.data(), sizeof(int32_t) * L.wg2_slot.size()}, {&ctx->wg2_vid, L.wg2_vid.data(), sizeof(int32_t) * L.wg2_vid.size()},
           {&ctx->wg2_meta, L.wg2_meta.data(), sizeof(uint32_t) * L.wg2_meta.size()}, {&ctx->wg2_nbr, L.wg2_nbr.data(), sizeof(int32_t) * L.wg2_nbr.size()},
           {&ctx->wg2_fetch, L.wg2_fetch.data(), sizeof(int32_t) * L.wg2_fetch.size()}, {&ctx->wg2_info, L.wg2_info.data(), sizeof(int32_t) * L.wg2_info.size()}};
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      HIPCHK(ctx, wait_solver_stream(ctx));
       for (auto& c : cp) {
         int rc = ensure(ctx, *c.b, c.bytes);
         if (!rc) rc = h2d(ctx, *c.b, c.src, c.bytes);
         if (rc) return rc;
       }
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      HIPCHK(ctx, wait_solver_stream(ctx));
       ctx->pv2_args.slot = (const int32_t*)ctx->wg2_slot.p, ctx->pv2_args.vid = (const int32_t*)ctx->wg2_vid.p, ctx->pv2_args.meta = (const uint32_t*)ctx->wg2_meta.p;
       ctx->pv2_args.nbr = (const int32_t*)ctx->wg2_nbr.p, ctx->pv2_args.fetch = (const int32_t*)ctx->wg2_fetch.p, ctx->pv2_args.info = (const int32_t*)ctx->wg2_info.p;
       ctx->pv2_args.count = L.wg2_count, ctx->pv2_args.lcap = L.wg2_lcap;
@@ -432,13 +448,13 @@ int ensure_form_rows(flame_nltgv2_ctx* ctx, int form) {
     struct { DevBuf* b; const void* src; size_t bytes; } cp[] = {
         {&ctx->tv_slot, L.tv_slot.data(), sizeof(int32_t) * L.tv_slot.size()}, {&ctx->tv_vid, L.tv_vid.data(), sizeof(int32_t) * L.tv_vid.size()},
         {&ctx->tv_meta, L.tv_meta.data(), sizeof(uint32_t) * L.tv_meta.size()}, {&ctx->tv_wave, L.tv_wave.data(), sizeof(uint32_t) * L.tv_wave.size()}};
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, wait_solver_stream(ctx));
     for (auto& c : cp) {
       int rc = ensure(ctx, *c.b, c.bytes);
       if (!rc) rc = h2d(ctx, *c.b, c.src, c.bytes);
       if (rc) return rc;
     }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, wait_solver_stream(ctx));
     ctx->tv_built = true;
     refresh_args(ctx);
   }
@@ -507,6 +523,9 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
   ok = ok && hipEventCreateWithFlags(&ctx->ev_run[1], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->h_err, kErrBytes, hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->h_cost, 2 * sizeof(float), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&ctx->h_stop, 64, hipHostMallocDefault) == hipSuccess;
+  if (ctx->h_stop) *ctx->h_stop = 1u;
+  ok = ok && hipStreamCreateWithPriority(&ctx->ctl_stream, hipStreamNonBlocking, -1) == hipSuccess;
   if (!ok) {
     flame_nltgv2_destroy(ctx);
     return FLAME_NLTGV2_ERR_HIP;
@@ -543,6 +562,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
   for (auto& b : ctx->nx) ctx->all.push_back(&b);
   for (auto& b : ctx->ex) ctx->all.push_back(&b);
   ctx->all.push_back(&ctx->pos_undo);
+  ctx->all.push_back(&ctx->stop_dev);
   ctx->all.push_back(&ctx->place_patch_nx), ctx->all.push_back(&ctx->place_fill_nx);
   for (auto& b : ctx->sp_v) ctx->all.push_back(&b);
   for (auto& b : ctx->sp_q) ctx->all.push_back(&b);
@@ -554,6 +574,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
 int flame_nltgv2_destroy(flame_nltgv2_ctx* ctx) {
   if (!ctx) return FLAME_NLTGV2_OK;
   (void)hipSetDevice(ctx->device);
+  request_open_stop(ctx);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   place_pool_release(ctx);
   drop_graphs(ctx);
@@ -562,6 +583,8 @@ int flame_nltgv2_destroy(flame_nltgv2_ctx* ctx) {
   if (ctx->h_err) (void)hipHostFree(ctx->h_err);
   if (ctx->h_cost) (void)hipHostFree(ctx->h_cost);
   if (ctx->h_keep) (void)hipHostFree(ctx->h_keep);
+  if (ctx->h_stop) (void)hipHostFree(ctx->h_stop);
+  if (ctx->ctl_stream) (void)hipStreamSynchronize(ctx->ctl_stream), (void)hipStreamDestroy(ctx->ctl_stream);
   for (auto& st : ctx->stage)
     if (st.h) (void)hipHostFree(st.h);
   if (ctx->topo_stream) (void)hipStreamSynchronize(ctx->topo_stream), (void)hipStreamDestroy(ctx->topo_stream);
@@ -585,7 +608,7 @@ int flame_nltgv2_destroy(flame_nltgv2_ctx* ctx) {
 int flame_nltgv2_set_stream(flame_nltgv2_ctx* ctx, void* hip_stream) {
   int rc = enter(ctx);
   if (rc) return rc;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, wait_solver_stream(ctx));
   ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
   return FLAME_NLTGV2_OK;
 }
@@ -713,7 +736,7 @@ int flame_nltgv2_read_probe(flame_nltgv2_ctx* ctx, uint32_t* out, int64_t max_wo
     rc = finish(ctx);
     if (rc) return rc;
   }
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, wait_solver_stream(ctx));
   const int64_t have = (int64_t)ctx->probe_words;
   if (n_words) *n_words = have;
   if (out && ctx->probe.p) {
@@ -736,7 +759,7 @@ int flame_nltgv2_layout_selftest(flame_nltgv2_ctx* ctx, int64_t* mismatches) {
   const int32_t V = ctx->L.V, E = ctx->L.E;
   std::vector<float> pos(2 * (size_t)V);
   HIPCHK(ctx, hipMemcpyAsync(pos.data(), ctx->layout_pos_saved ? ctx->layout_pos.p : ctx->pos.p, sizeof(float) * pos.size(), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, wait_solver_stream(ctx));
   flame_nltgv2_graph g{};
   g.V = V, g.E = E, g.pos = pos.data(), g.src = ctx->h_src.data(), g.dst = ctx->h_dst.data();
   PackedLayout H;
@@ -830,7 +853,7 @@ int flame_nltgv2_placement_info(flame_nltgv2_ctx* ctx, int32_t* state, int32_t* 
     if (ctx->have_graph && ctx->place_state == 1 && ctx->place_topo == ctx->topo) {
       std::vector<int32_t> off((size_t)ctx->L.V);  // (parity 0; the walk's records)
       HIPCHK(ctx, hipMemcpyAsync(off.data(), ctx->place_rec_off.p, sizeof(int32_t) * off.size(), hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      HIPCHK(ctx, wait_solver_stream(ctx));
       for (int32_t o : off) *placed_records += o >= 0;
     }
   }

@@ -223,6 +223,8 @@ struct flame_nltgv2_ctx {
     int kind = 0;  // 0 run, 1 explicit export of x * scale
     flame_nltgv2_params params{};
     int n = 0;
+    bool open = false;      // an open run (flame_nltgv2_run_open): n is its upper bound until finish() has read how far it went
+    uint32_t tag0 = 0;      // ... its first tag: err[12] / err[13] of the run count from it
     float* dst = nullptr;  // kind 1: where to; kind 0: the standing export target the run was enqueued with (NULL: none)
     float scale = 1.0f;
   };
@@ -354,6 +356,15 @@ struct flame_nltgv2_ctx {
   int last_expired[16] = {0};  // what the most recent expired wait reported (report_expired)
   float* h_cost = nullptr; // pinned
   uint8_t* h_keep = nullptr;  // pinned: project_graph's keep mask, written by its kernel
+  unsigned* h_stop = nullptr; // pinned: the constant 1 that finish() copies into stop_dev when the host wants the state of an open run
+  DevBuf stop_dev;            // the word an open run's deciding patch looks at (device memory: a word in host memory cost that patch -- and with it
+                              // the whole lock-step network -- a PCIe round trip per two steps: 1.38 against 0.95 us per iteration)
+  hipStream_t ctl_stream = nullptr;  // ... the stream of that 4-byte copy
+  bool open_inflight = false; // an open run is enqueued and unchecked (the last op of ctx->pending)
+  bool open_stop_sent = false; // ... and has been asked to stop (request_open_stop)
+  int want_open = 0;          // enqueue_run: the run being enqueued is to be an open one (flame_nltgv2_run_open sets it for its call)
+  int last_open_iters = 0;    // how far the last open run went
+  int64_t iters_total = 0;    // iterations applied to the state by every run since create (open runs: counted when they are settled)
   DevBuf pos_undo;            // project_graph: the positions as they stood (when layout_pos already holds older ones), to take a projection back
   size_t h_keep_cap = 0;
   std::vector<CachedGraph> graphs;
@@ -400,6 +411,8 @@ int wait_raster(flame_nltgv2_ctx* ctx);                       // the context's s
 // else the launches wrote the caller puts right before it launches them once more.
 enum { kBehindNotLaunched = 0, kBehindDone = 1, kBehindSpoiled = 2 };
 int ensure_canon(flame_nltgv2_ctx* ctx, const std::function<int()>* behind = nullptr, int* behind_state = nullptr);
+void request_open_stop(flame_nltgv2_ctx* ctx);  // an open run in flight is asked to stop (once); see ensure()
+hipError_t wait_solver_stream(flame_nltgv2_ctx* ctx);  // hipStreamSynchronize(ctx->stream) behind such a request
 int ensure_fused(flame_nltgv2_ctx* ctx);
 bool params_ok(const flame_nltgv2_params* p);
 struct StageCopy {

@@ -38,7 +38,7 @@ static int interpolate_common(flame_nltgv2_ctx* ctx, const int32_t* triangles, i
   HIPCHK(ctx, hipMemcpyAsync(out, ctx->r_img.p, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
   int cov = 0;
   HIPCHK(ctx, hipMemcpyAsync(&cov, ctx->r_cov.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, wait_solver_stream(ctx));
   if (coverage) *coverage = cov;
   return FLAME_NLTGV2_OK;
 }
@@ -63,6 +63,7 @@ int flame_nltgv2_interpolate_mesh_begin(flame_nltgv2_ctx* ctx, const int32_t* tr
   double tr_a = 0, tr_b = 0, tr_c = 0, tr_d = 0;
   HIPCHK(ctx, hipStreamSynchronize(rs));  // (a begin without its end: the pinned map and the device buffers are about to be reused)
   if (ctx->h_img_cap < n + 16) {
+    request_open_stop(ctx);  // (the pinned allocator waits for the device)
     if (ctx->h_img) (void)hipHostFree(ctx->h_img);
     ctx->h_img = nullptr, ctx->h_img_cap = 0;
     if (hipHostMalloc((void**)&ctx->h_img, sizeof(float) * (n + 16), hipHostMallocDefault) != hipSuccess) {
@@ -169,13 +170,13 @@ int flame_nltgv2_photo_set_images(flame_nltgv2_ctx* ctx, const uint8_t* ref, con
   if (rc) return rc;
   if (!ref || !cmp || rows < 2 || cols < 2 || step_bytes < cols) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
   const size_t bytes = (size_t)rows * (size_t)step_bytes;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, wait_solver_stream(ctx));
   rc = ensure(ctx, ctx->img_ref, bytes + 16);
   if (!rc) rc = ensure(ctx, ctx->img_cmp, bytes + 16);
   if (rc) return rc;
   HIPCHK(ctx, hipMemcpyAsync(ctx->img_ref.p, ref, bytes, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(ctx->img_cmp.p, cmp, bytes, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, wait_solver_stream(ctx));
   ctx->img_rows = rows, ctx->img_cols = cols, ctx->img_step = step_bytes;
   return FLAME_NLTGV2_OK;
 }
@@ -198,7 +199,7 @@ int flame_nltgv2_photo_residual(flame_nltgv2_ctx* ctx, const float* KRKinv, cons
                                        (const uint8_t*)ctx->img_cmp.p, ctx->img_rows, ctx->img_cols, ctx->img_step,
                                        border, (float*)ctx->photo_err.p, ctx->stream));
   if (fV) HIPCHK(ctx, hipMemcpyAsync(err_out, ctx->photo_err.p, fV, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, wait_solver_stream(ctx));
   return FLAME_NLTGV2_OK;
 }
 
@@ -212,7 +213,7 @@ int flame_nltgv2_photo_fuse(flame_nltgv2_ctx* ctx, const float* KRKinv, const fl
   }
   if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
   if (!KRKinv || !Kt || border < 1 || ctx->img_rows == 0) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, wait_solver_stream(ctx));
   rc = ensure(ctx, ctx->photo_err, sizeof(float) * (size_t)ctx->L.V);
   if (rc) return rc;
   std::memcpy(ctx->photo_geo.KRKinv, KRKinv, sizeof(ctx->photo_geo.KRKinv));
@@ -233,7 +234,7 @@ int flame_nltgv2_photo_residual_last(flame_nltgv2_ctx* ctx, float* err_out) {
   }
   const size_t fV = sizeof(float) * (size_t)ctx->L.V;
   if (fV) HIPCHK(ctx, hipMemcpyAsync(err_out, ctx->photo_err.p, fV, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, wait_solver_stream(ctx));
   return FLAME_NLTGV2_OK;
 }
 

@@ -25,7 +25,7 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
   const bool trace = std::getenv("FLAME_NLTGV2_TRACE") != nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
   // Make sure nothing in flight still uses buffers we may reallocate (or the staging buffer).
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, wait_solver_stream(ctx));
   const size_t fV = sizeof(float) * (size_t)V, fE = sizeof(float) * (size_t)E;
   struct { DevBuf* b; size_t bytes; } req[] = {
       {&ctx->x, fV}, {&ctx->w1, fV}, {&ctx->w2, fV}, {&ctx->xb, fV}, {&ctx->w1b, fV}, {&ctx->w2b, fV}, {&ctx->xp, fV},
@@ -51,7 +51,7 @@ int flame_nltgv2_upload_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g
   // No wait here: the caller's arrays were copied into the staging buffer, the device work is ordered on the stream in
   // front of whatever comes next (a run, an export), and the next upload synchronises before it reuses the staging buffer.
   if (trace) {
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, wait_solver_stream(ctx));
     const auto t_end = std::chrono::steady_clock::now();
     std::fprintf(stderr, "[flame_nltgv2] upload_graph V=%d E=%d: host tables + enqueue %.3f ms, device %.3f ms\n", V, E,
                  std::chrono::duration<double, std::milli>(t_packed - t_begin).count(),
@@ -290,7 +290,7 @@ int sync_graph_host(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in) {
   // New topology + the frame's inputs up, state gathered on the device out of the previous arrays into spare ones,
   // which then take their place.
   ctx->have_graph = false;  // (until the new graph stands)
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // nothing in flight uses buffers that may be reallocated below
+  HIPCHK(ctx, wait_solver_stream(ctx));  // nothing in flight uses buffers that may be reallocated below
   const size_t fV = sizeof(float) * (size_t)V, fE = sizeof(float) * (size_t)En;
   DevBuf* cur_v[9] = {&ctx->x, &ctx->w1, &ctx->w2, &ctx->xb, &ctx->w1b, &ctx->w2b, &ctx->xp, &ctx->w1p, &ctx->w2p};
   DevBuf* cur_q[3] = {&ctx->q1, &ctx->q2, &ctx->q3};
@@ -335,7 +335,7 @@ int sync_graph_host(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in) {
   refresh_args(ctx);
   LAUNCHCHK(ctx, launch_pack_static(ctx->c, ctx->f, ctx->stream));
   if (trace) {  // (no wait otherwise: see flame_nltgv2_upload_graph)
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, wait_solver_stream(ctx));
     const auto t2 = std::chrono::steady_clock::now();
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     std::fprintf(stderr, "[flame_nltgv2] sync_graph: index maps %.3f ms, tables + upload + device gather %.3f ms\n", ms(t0, t1), ms(t1, t2));
@@ -471,7 +471,7 @@ int flame_nltgv2_project_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_project
   // (round 6: as a device-to-device copy, the kernel and a copy out to the caller's pageable array this call was three more trips
   // through the runtime, 10-16 us each, with the solver standing still: profiles/r06_holds.txt)
   if (ctx->h_keep_cap < V + 16) {
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    request_open_stop(ctx);  // (the pinned allocator waits for the device)
     if (ctx->h_keep) (void)hipHostFree(ctx->h_keep);
     ctx->h_keep = nullptr, ctx->h_keep_cap = 0;
     const size_t want = (V + 16) + (V + 16) / 2;
@@ -511,7 +511,7 @@ int flame_nltgv2_project_graph(flame_nltgv2_ctx* ctx, const flame_nltgv2_project
   }
   if (first_since_layout && V) ctx->layout_pos_saved = true;
   if (V && pos_out) HIPCHK(ctx, hipMemcpyAsync(pos_out, ctx->pos.p, sizeof(float) * 2 * V, hipMemcpyDeviceToHost, ctx->stream));
-  if (behind != kBehindDone || (V && pos_out)) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (behind != kBehindDone || (V && pos_out)) HIPCHK(ctx, wait_solver_stream(ctx));
   if (V) std::memcpy(keep_out, ctx->h_keep, V);
   ctx->fused_valid = false;  // x changed; pos changed: alpha/dx/dy of the packed records are stale until the next
                              // sync_graph / upload_graph re-derives them (the reference re-triangulates right after)
@@ -529,7 +529,7 @@ int flame_nltgv2_rescale_data(flame_nltgv2_ctx* ctx, float graph_scale, float* n
   if (rc) return rc;
   LAUNCHCHK(ctx, launch_rescale(ctx->c, graph_scale, (float*)ctx->cost_out.p, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(ctx->h_cost, ctx->cost_out.p, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, wait_solver_stream(ctx));
   const float ns = ctx->h_cost[0];
   p->data_factor *= ns / graph_scale;  // flame.cc:349
   *new_graph_scale = ns;
@@ -584,7 +584,7 @@ int flame_nltgv2_update_data(flame_nltgv2_ctx* ctx, const float* data_term, cons
   rc = h2d(ctx, ctx->data, data_term, fV);
   if (!rc) rc = h2d(ctx, ctx->weight, data_weight, fV);
   if (rc) return rc;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, wait_solver_stream(ctx));
   ctx->fused_valid = false;
   return FLAME_NLTGV2_OK;
 }
@@ -608,7 +608,7 @@ int flame_nltgv2_upload_state(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* s
     if (rc) return rc;
   }
   HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, kErrBytes, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, wait_solver_stream(ctx));
   ctx->fused_valid = false;
   ctx->last_error = 0;
   return FLAME_NLTGV2_OK;
@@ -635,14 +635,14 @@ int flame_nltgv2_costs(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, floa
     // flame.cc:2172-2173: ~10 us instead of a 2E + V float copy and as many dependent additions on the host)
     LAUNCHCHK(ctx, launch_cost_sums(ctx->c, (const float*)ctx->cost_terms.p, (float*)ctx->cost_out.p, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_cost, ctx->cost_out.p, 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, wait_solver_stream(ctx));
     if (smoothness) *smoothness = p->data_factor * ctx->h_cost[0];
     if (data) *data = ctx->h_cost[1];
     return FLAME_NLTGV2_OK;
   }
   ctx->h_terms.resize(n);
   if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->h_terms.data(), ctx->cost_terms.p, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, wait_solver_stream(ctx));
   float cost = 0.0f;
   for (size_t k = 0; k < 2 * E; ++k) cost += ctx->h_terms[k];
   float dcost = 0.0f;
@@ -682,7 +682,7 @@ static int export_idepth(flame_nltgv2_ctx* ctx, void* dst_device, float scale, b
   if (ctx->pending.active) {
     // an unchecked persistent run is in flight: the waiting form settles it first (so that what it copies out is the
     // checked result), the asynchronous form joins the chain and is redone should the chain have to be replayed
-    if (wait) {
+    if (wait || ctx->open_inflight) {  // (nothing is chained behind an open run)
       rc = finish(ctx);
     } else {
       rc = snapshot_chain_start(ctx);
@@ -696,7 +696,7 @@ static int export_idepth(flame_nltgv2_ctx* ctx, void* dst_device, float scale, b
   }
   const bool packed = !ctx->canon_valid;
   LAUNCHCHK(ctx, launch_export(ctx->c, ctx->f, packed, scale, (float*)dst_device, ctx->stream));
-  if (wait) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (wait) HIPCHK(ctx, wait_solver_stream(ctx));
   return FLAME_NLTGV2_OK;
 }
 

@@ -37,6 +37,7 @@ struct RunTail {
   int reserved_ = 0;
   PhotoFuse photo;              // flame_nltgv2_photo_fuse (photo.err == nullptr: off)
   unsigned* progress = nullptr; // FLAME_NLTGV2_TRACE: where a patch that leaves a run through an expired wait says how far it got
+  const unsigned* stop_req = nullptr;  // an open run (flame_nltgv2_run_open): the device word that asks it to stop (the host copies a 1 into it)
 };
 
 // Everything EpipolarGeometry::project(u, idepth, &u_new, &idepth_new) reads (stereo/epipolar_geometry.h:152-180)
@@ -67,6 +68,7 @@ struct CanonArgs {
 // Packed SELL-64 layout of the fused sweep (device pointers).
 struct FusedArgs {
   hipEvent_t stop_event = nullptr;  // a plain (not cooperative) persistent launch carries it as its completion signal (nltgv2_run.hip)
+  int open_run = 0;                 // the patch-per-wave kernel's OPEN instance: the run ends when the host asks (RunTail::stop_req), n_iters at the latest
   int n_slices = 0;
   int64_t n_slots = 0;  // (rows + kRowPad) * 64
   int32_t* slice_row = nullptr;

@@ -101,7 +101,15 @@ __device__ __forceinline__ void report_expired(int* err, int which, int wg, int 
 // amdgpu_num_sgpr(92): 90 SGPRs as built -> 96 + the trap handler's 16 = 112 per wave, SEVEN waves per SIMD really resident (at the
 // compiler's own choice, 106, it is six: "Round 3" in docs/DESIGN_r3.md section 4); the scalar spills this costs stay outside the hand-off path
 // (640x480: 0.962 against 0.962 us per iteration, profiles/r03_priority.txt (7)) and a 1080p frame's 25 patches per CU fit one launch.
-template <bool PROBE, bool VERIFY>
+// OPEN (round 6): a run that goes on until the host needs the state.  n_iters is then an upper bound; ONE patch (the middle one of the
+// launch) looks at a word the host sets (a 4-byte copy on a stream of its own) every kOpenCheck iterations and, when it is set, publishes the iteration every
+// patch leaves at -- its own plus kOpenMargin, more than any patch can be ahead of it (a patch is ahead of another by at most their
+// distance in the patch graph) -- in err[12] as tag0 + iteration (tags grow from run to run: a stale word of an earlier run is below
+// this run's tag0 and means nothing).  Every patch reads that word every kOpenCheck iterations.  A patch that saw the word too late has no neighbours left to wait for: its
+// wait expires and the run is taken back and redone like any other (nltgv2_run.hip finish()).  The patch that decides leaves the
+// number of iterations done in err[13] (tag0 + n) on its way out.
+constexpr unsigned kOpenMargin = 128u, kOpenCheck = 64u;  // (both even: an open run does an even number of iterations)
+template <bool PROBE, bool VERIFY, bool OPEN = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(92)))
 k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, const int lcap, const int slab_slots,
                 const int32_t* __restrict__ wg_slot, const int32_t* __restrict__ wg_vid,
@@ -601,12 +609,41 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
   char* const pubA = p0 ? pa1 : pa0;
   char* const pubB = p0 ? pa0 : pa1;
   int it = 0;
-  for (; it + 1 < n_iters && !timed_out; it += 2) {
-    step(tag0 + (unsigned)it, rdA_nbr, dstA, wrB_rec, areaA + lcap, it, srcA, pubB, wrA_rec);
-    if (timed_out) break;
-    step(tag0 + (unsigned)it + 1u, rdB_nbr, dstB, wrA_rec, areaB + lcap, it + 1, srcB, pubA, wrB_rec);
+  if (OPEN) {
+    const bool decides = wg == wg_begin + n_wgs / 2;
+    const unsigned* const stop_req = tail->stop_req;  // (device memory: the host's copy lands there)
+    unsigned* const stop_word = reinterpret_cast<unsigned*>(err) + 12;
+    unsigned stop_at = 0u;  // tag0 + the iteration to leave at, once known
+    for (; it + 1 < n_iters && !timed_out; it += 2) {
+      // Every kOpenCheck iterations -- all patches at the same ones: the network runs in lock step, so the ~0.5 us this load takes are
+      // spent by everybody at once, 1-2 % of the time -- the word is looked at; the deciding patch first looks at the host's request.
+      // (Asked for every trip and looked at a trip later it cost 17 %: the compiler waits for the publish stores in front of the
+      //  load, and the step's polls never wait for vmcnt, so nothing hides it.)
+      if (((unsigned)it & (kOpenCheck - 1u)) == 0u) {
+        if (decides && stop_at == 0u && stop_req &&
+            __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(stop_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) {
+          stop_at = tag0 + (unsigned)it + kOpenMargin;
+          if (lane == 0) __hip_atomic_store(stop_word, stop_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (stop_at == 0u) {
+          const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(stop_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          if (w > tag0 && w - tag0 <= (unsigned)n_iters + kOpenMargin) stop_at = w;  // (a word of an earlier run is below this run's tag0)
+        }
+      }
+      if (stop_at != 0u && stop_at - tag0 <= (unsigned)it) break;
+      step(tag0 + (unsigned)it, rdA_nbr, dstA, wrB_rec, areaA + lcap, it, srcA, pubB, wrA_rec);
+      if (timed_out) break;
+      step(tag0 + (unsigned)it + 1u, rdB_nbr, dstB, wrA_rec, areaB + lcap, it + 1, srcB, pubA, wrB_rec);
+    }
+    if (decides && lane == 0 && !timed_out) reinterpret_cast<unsigned*>(err)[13] = tag0 + (unsigned)it;
+  } else {
+    for (; it + 1 < n_iters && !timed_out; it += 2) {
+      step(tag0 + (unsigned)it, rdA_nbr, dstA, wrB_rec, areaA + lcap, it, srcA, pubB, wrA_rec);
+      if (timed_out) break;
+      step(tag0 + (unsigned)it + 1u, rdB_nbr, dstB, wrA_rec, areaB + lcap, it + 1, srcB, pubA, wrB_rec);
+    }
+    if (it < n_iters && !timed_out) step(tag0 + (unsigned)it, rdA_nbr, dstA, wrB_rec, areaA + lcap, it, srcA, pubB, wrA_rec);
   }
-  if (it < n_iters && !timed_out) step(tag0 + (unsigned)it, rdA_nbr, dstA, wrB_rec, areaA + lcap, it, srcA, pubB, wrA_rec);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA in flight when the wave ends
 
   if (timed_out) {
@@ -725,7 +762,8 @@ int launch_persistent_run(const FusedArgs& a, const SolverParams& p, int form, i
     const bool vr = (dual >> 1) != 0;  // record verification asked for
     if (!a.wg_rowpack) return (int)hipErrorInvalidConfiguration;  // (the planner never asks: the kernel runs row-packed patches)
     const void* fv = probe ? (const void*)k_persistent_pv<true, true>
-                           : vr ? (const void*)k_persistent_pv<false, true> : (const void*)k_persistent_pv<false, false>;
+                           : vr ? (const void*)k_persistent_pv<false, true>
+                                : a.open_run ? (const void*)k_persistent_pv<false, false, true> : (const void*)k_persistent_pv<false, false>;
     if (cooperative) return (int)hipLaunchCooperativeKernel(fv, gv, bv, vargs, ldsv, stream);
     return (int)hipExtLaunchKernel(fv, gv, bv, vargs, ldsv, stream, nullptr, a.stop_event, 0);
   }

@@ -371,7 +371,7 @@ int place_calibrate(flame_nltgv2_ctx* ctx) {
       HIPCHK(ctx, hipMemsetAsync(ctx->place_fill.p, 0, sizeof(int) * (2 * P + 16 + 128), ctx->stream));
       HIPCHK(ctx, hipMemcpyAsync(ctx->place_rank.p, ctx->place_rank_host.data(), sizeof(uint16_t) * ctx->place_rank_host.size(), hipMemcpyHostToDevice,
                                  ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      HIPCHK(ctx, wait_solver_stream(ctx));
       ctx->place_state = 1;
       return 0;
     }
@@ -393,7 +393,7 @@ int place_calibrate(flame_nltgv2_ctx* ctx) {
   int xcc[65];
   HIPCHK(ctx, hipMemcpyAsync(out.data(), d_out, sizeof(unsigned) * out.size(), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(xcc, d_xcc, sizeof(int) * 65, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, wait_solver_stream(ctx));
   HIPCHK(ctx, hipMemsetAsync(ctx->place_base, 0, pool_bytes, ctx->stream));  // (tags of the calibration: gone)
   if (xcc[64] != 0) return 0;  // a wait expired
   std::vector<unsigned> lat((size_t)64 * 2 * P, 0u);  // [8 a + b][page]: a record written on XCD a, seen on XCD b
@@ -441,7 +441,7 @@ int place_calibrate(flame_nltgv2_ctx* ctx) {
   const double to_us = 1.0 / (100.0 * kIters) / (2.0 * 56.0);  // 100 MHz ticks of kIters hand-offs; mean of 2 x 56 classes
   ctx->place_best_us = (float)(best * to_us), ctx->place_mean_us = (float)(mean * to_us), ctx->place_worst_us = (float)(worst * to_us);
   HIPCHK(ctx, hipMemcpyAsync(ctx->place_rank.p, rank.data(), sizeof(uint16_t) * rank.size(), hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (`rank` is pageable and leaves scope)
+  HIPCHK(ctx, wait_solver_stream(ctx));  // (`rank` is pageable and leaves scope)
   ctx->place_state = 1;
   ctx->place_rank_host.swap(rank);  // (kept: the pool and its ranking go to the next context of this device, place_pool_release)
   return 0;
@@ -464,6 +464,10 @@ int place_records(flame_nltgv2_ctx* ctx, int per_xcd) {
 
 int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   if (n <= 0) return 0;
+  if (ctx->open_inflight) {  // nothing is chained behind an open run: it would wait for the run's upper bound
+    const int rc0 = finish(ctx);
+    if (rc0) return rc0;
+  }
   if (ctx->opt_solver == 1) {  // canonical 4-sweep path
     int rc = ensure_canon(ctx);  // (settles a pending persistent run first)
     if (rc) return rc;
@@ -476,6 +480,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
     }
     ctx->fused_valid = false;
     ctx->last_run_path = 4;
+    if (ctx->replaying == 0) ctx->iters_total += n;
     if (ctx->export_ptr) LAUNCHCHK(ctx, launch_export(ctx->c, ctx->f, false, ctx->export_scale, ctx->export_ptr, ctx->stream));
     return enqueue_photo_sweep(ctx, false);
   }
@@ -500,6 +505,15 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   std::vector<WaveGroup> groups;
   int tv_lds = 0;
   const int form = plan_persistent(ctx, n, &groups, &tv_lds, /*consume=*/true);
+  // an open run: the patch-per-wave form as ONE launch of its plain instance, the first run of a chain -- anything else is run as asked
+  // for (n iterations), the caller sees that from flame_nltgv2_run_open's `opened`
+  // (its kernel instance keeps 24 patches per CU resident, not 28: tests/test_abi.py; an open run is for graphs of at most 20)
+  const bool open_run = ctx->want_open != 0 && form == 3 && groups.size() == 1 && groups[0].count <= 20 * ctx->prop.multiProcessorCount && !ctx->pending.active && ctx->opt_probe == 0 &&
+                        ctx->opt_verify == 0 && ctx->replaying == 0 && (n & 1) == 0 && ctx->h_stop != nullptr && ctx->ctl_stream != nullptr;
+  if (ctx->want_open != 0 && !open_run) {  // flame_nltgv2_run_open on a graph / a configuration it does not apply to: nothing is run
+    ctx->want_open = 0;
+    return 0;
+  }
   if (form != 0) {
     // tags must stay unique: clear the record buffers long before the 28-bit tag of the XCC table wraps -- and when the
     // form changes (the forms lay the buffers out differently: one's XCC table is another's record area)
@@ -510,6 +524,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
         HIPCHK(ctx, hipMemsetAsync(ctx->place_base, 0, (size_t)2 * kPlacePages * 4096, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync((int*)ctx->place_fill.p + 2 * kPlacePages, 0, 64, ctx->stream));
       }
+      HIPCHK(ctx, hipMemsetAsync((int*)ctx->err.p + 12, 0, 2 * sizeof(int), ctx->stream));  // (an open run's words count from its tag0)
       ctx->tag_next = 1;
     }
     ctx->xbuf_form = form;
@@ -524,6 +539,12 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       RunTail want;
       std::memset(static_cast<void*>(&want), 0, sizeof want);
       want.export_out = ctx->export_ptr, want.export_scale = ctx->export_scale;
+      if (open_run) {  // the request word: device memory, cleared on the solver's stream in front of the launch
+        rc = ensure(ctx, ctx->stop_dev, 64);
+        if (rc) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->stop_dev.p, 0, sizeof(unsigned), ctx->stream));
+      }
+      want.stop_req = open_run ? (const unsigned*)ctx->stop_dev.p : nullptr;
       const PhotoFuse pf = photo_target(ctx);
       std::memcpy(static_cast<void*>(&want.photo), &pf, sizeof pf);
       if (form == 3 && std::getenv("FLAME_NLTGV2_TRACE")) {
@@ -615,8 +636,10 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
         if (e != 0) break;
         continue;
       }
+      ctx->f.open_run = open_run ? 1 : 0;
       e = launch_persistent_run(ctx->f, to_sp(p), form, gr.begin, gr.count, ctx->parity, tag0, n, pw, spins_arg, presleep, dual,
                                 tv_lds, xcds, tail_dev, cooperative_allowed() && ctx->coop_checked_key != key, ctx->stream);
+      ctx->f.open_run = 0;
       if (e != 0) break;
     }
     ctx->run_event_bound = e == 0 && ctx->f.stop_event != nullptr;
@@ -633,9 +656,13 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       {
         flame_nltgv2_ctx::PendingOp op;
         op.kind = 0, op.params = *p, op.n = n;
+        op.open = open_run, op.tag0 = tag0;
         op.dst = ctx->export_ptr, op.scale = ctx->export_scale;  // the standing export target THIS run was enqueued with
         ctx->pending.ops.push_back(op);
       }
+      ctx->open_inflight = open_run, ctx->open_stop_sent = false;
+      if (open_run) ctx->want_open = 2;
+      if (!open_run && ctx->replaying == 0) ctx->iters_total += n;  // (an open run: counted by finish(), which learns how far it went)
       std::swap(ctx->hq, ctx->hq_alt);
       std::swap(ctx->vstate, ctx->vstate_alt);
       ctx->buf_gen ^= 1;
@@ -658,7 +685,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
     ctx->persist_refused_topo = ctx->topo;  // do not try again for this topology
     if (groups.size() > 1 && !ctx->pending.active) {
       HIPCHK(ctx, hipMemsetAsync(ctx->abort_flag.p, 0xff, sizeof(int), ctx->stream));  // tells them to leave at once
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      HIPCHK(ctx, wait_solver_stream(ctx));
       HIPCHK(ctx, hipMemsetAsync(ctx->err.p, 0, kErrBytes, ctx->stream));
       HIPCHK(ctx, hipMemsetAsync(ctx->abort_flag.p, 0, sizeof(int), ctx->stream));
     }
@@ -688,6 +715,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   }
   ctx->have_prev = true;
   ctx->canon_valid = false;
+  if (ctx->replaying == 0) ctx->iters_total += n;
   if (ctx->export_ptr) LAUNCHCHK(ctx, launch_export(ctx->c, ctx->f, true, ctx->export_scale, ctx->export_ptr, ctx->stream));
   return enqueue_photo_sweep(ctx, true);
 }
@@ -733,6 +761,11 @@ void trace_expired_wait(flame_nltgv2_ctx* ctx) {
 }
 
 int finish(flame_nltgv2_ctx* ctx, bool unpack_behind, bool* unpacked, const std::function<int()>* behind_fn, bool* behind_launched) {
+  const bool open_run = ctx->open_inflight;
+  if (open_run) {  // an open run ends when it is asked to: its deciding patch looks at this word every kOpenCheck iterations
+    request_open_stop(ctx);
+    ctx->open_inflight = false, ctx->open_stop_sent = false;
+  }
   HIPCHK(ctx, hipMemcpyAsync(ctx->h_err, ctx->err.p, kErrBytes, hipMemcpyDeviceToHost, ctx->stream));
   bool behind = false;
   if (unpack_behind && ctx->pending.active && !ctx->canon_valid && !ctx->replaying) {
@@ -750,9 +783,27 @@ int finish(flame_nltgv2_ctx* ctx, bool unpack_behind, bool* unpacked, const std:
       if (behind_launched) *behind_launched = true;
     }
   }
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, wait_solver_stream(ctx));
+  if (open_run) HIPCHK(ctx, hipStreamSynchronize(ctx->ctl_stream));  // (a run that reached its bound first: the request must not land in the NEXT open run's word)
   flame_nltgv2_ctx::PendingRun run;
   std::swap(run, ctx->pending);  // (ctx->pending is now inactive and empty)
+  if (open_run && !run.ops.empty() && run.ops.back().open) {
+    // How far the open run went: its deciding patch left tag0 + n in err[13] on its way out (n = the iteration all patches left at, or
+    // the upper bound).  A run that expired has no such number: its replay does the iterations up to the decision if one was made
+    // (err[12]), the smallest chunk otherwise -- any number is a legal one for a solver that runs until it is stopped, as long as the
+    // caller is told the truth (flame_nltgv2_iterations).
+    flame_nltgv2_ctx::PendingOp& op = run.ops.back();
+    const uint32_t done = (uint32_t)ctx->h_err[13], decided = (uint32_t)ctx->h_err[12];
+    int n_done = op.n;
+    if (!(*ctx->h_err & 6)) {
+      if (done > op.tag0 && done - op.tag0 <= (uint32_t)op.n) n_done = (int)(done - op.tag0);
+    } else {
+      n_done = (decided > op.tag0 && decided - op.tag0 <= (uint32_t)op.n) ? (int)(decided - op.tag0) : std::min(op.n, 256);
+    }
+    op.n = n_done, op.open = false;
+    ctx->iters_total += n_done;
+    ctx->last_open_iters = n_done;
+  }
   if (*ctx->h_err & 6) {
     if (*ctx->h_err & 4) ctx->torn_records_detected++;  // the record verification found a second read that differed
     std::memcpy(ctx->last_expired, ctx->h_err, kErrBytes);
@@ -885,6 +936,46 @@ int flame_nltgv2_run_async(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, 
   return 0;
 }
 
+int flame_nltgv2_run_open(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int max_iters, int32_t* opened) {
+  flame_hip::RoctxRange roctx_range_("flame_nltgv2_run_open");
+  int rc = enter(ctx);
+  if (rc) return rc;
+  if (opened) *opened = 0;
+  if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
+  if (!params_ok(p) || max_iters < 0 || (max_iters & 1)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
+  if (max_iters == 0) return 0;
+  if (ctx->pending.active) {  // an open run is the first of its chain
+    rc = finish(ctx);
+    if (rc) return rc;
+  }
+  const int idx = ctx->run_ev_last ^ 1;
+  ctx->run_ev_pick = idx;
+  ctx->run_event_bound = false;
+  ctx->want_open = 1;
+  rc = enqueue_run(ctx, p, max_iters);
+  const bool was_open = ctx->want_open == 2;
+  ctx->want_open = 0;
+  ctx->run_ev_pick = -1;
+  if (rc) return rc;
+  bool stands = ctx->run_event_bound;
+  if (!stands && ctx->track_runs) {
+    HIPCHK(ctx, hipEventRecord(ctx->ev_run[idx], ctx->stream));
+    stands = true;
+  }
+  ctx->run_ev_valid[idx] = stands;
+  ctx->run_ev_last = idx;
+  ctx->run_event_seq = ctx->call_seq;
+  if (opened) *opened = was_open ? 1 : 0;
+  return 0;
+}
+
+int flame_nltgv2_iterations(flame_nltgv2_ctx* ctx, int64_t* total, int32_t* open_in_flight) {
+  if (!ctx || !total) return FLAME_NLTGV2_ERR_INVALID_ARG;
+  *total = ctx->iters_total;
+  if (open_in_flight) *open_in_flight = ctx->open_inflight ? 1 : 0;
+  return 0;
+}
+
 int flame_nltgv2_stream_wait_run(flame_nltgv2_ctx* ctx, void* hip_stream) {
   flame_hip::RoctxRange roctx_range_("flame_nltgv2_stream_wait_run");
   int rc = enter(ctx);
@@ -929,7 +1020,7 @@ int flame_nltgv2_sync(flame_nltgv2_ctx* ctx) {
   int rc = enter(ctx);
   if (rc) return rc;
   if (!ctx->have_graph) {
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, wait_solver_stream(ctx));
     return 0;
   }
   return finish(ctx);

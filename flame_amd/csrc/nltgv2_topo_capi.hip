@@ -78,7 +78,7 @@ int ensure_host_layout(flame_nltgv2_ctx* ctx) {
   if (V) HIPCHK(ctx, hipMemcpyAsync(pos.data(), ctx->layout_pos_saved ? ctx->layout_pos.p : ctx->pos.p, sizeof(float) * pos.size(), hipMemcpyDeviceToHost, ctx->stream));
   if (E) HIPCHK(ctx, hipMemcpyAsync(ctx->h_src.data(), ctx->src.p, sizeof(int32_t) * (size_t)E, hipMemcpyDeviceToHost, ctx->stream));
   if (E) HIPCHK(ctx, hipMemcpyAsync(ctx->h_dst.data(), ctx->dst.p, sizeof(int32_t) * (size_t)E, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, wait_solver_stream(ctx));
   flame_nltgv2_graph g{};
   g.V = V, g.E = E, g.pos = pos.data(), g.src = ctx->h_src.data(), g.dst = ctx->h_dst.data();
   const PackedLayout& dev = ctx->L;  // (scalars as the device reported them; its vectors are stale)
@@ -183,11 +183,12 @@ int topo_prepare(flame_nltgv2_ctx* ctx, const flame_nltgv2_sync_input* in, bool*
   // (the previous commit's kernels may still read the scratch maps and write what this builder reads: it starts behind them)
   HIPCHK(ctx, hipStreamWaitEvent(ts, ctx->ev_topo_ready, 0));
   if (ctx->raster_inflight) HIPCHK(ctx, hipStreamWaitEvent(ts, ctx->ev_raster_done, 0));  // (it may read a position buffer that was swapped out)
-  if (ctx->topo_scratch.cap < cv.off) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (growing the scratch under the previous commit's state gather)
+  if (ctx->topo_scratch.cap < cv.off) HIPCHK(ctx, wait_solver_stream(ctx));  // (growing the scratch under the previous commit's state gather)
   rc = ensure(ctx, ctx->topo_scratch, cv.off);
   for (int i = 0; i < flame_nltgv2_ctx::NX_COUNT && !rc; ++i) rc = ensure(ctx, ctx->nx[i], nx_bytes[i]);
   if (!rc) rc = ensure(ctx, ctx->topo_dims, sizeof(TopoDims));
   if (rc) return rc;
+  if (!ctx->h_dims) request_open_stop(ctx);
   if (!ctx->h_dims && hipHostMalloc((void**)&ctx->h_dims, sizeof(TopoDims), hipHostMallocDefault) != hipSuccess) {
     (void)hipGetLastError();
     return fail(ctx, FLAME_NLTGV2_ERR_OOM);
@@ -299,6 +300,7 @@ int topo_upload(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const StageC
     rc = ensure(ctx, *r.b, r.bytes);
     if (rc) return rc;
   }
+  if (!ctx->h_dims) request_open_stop(ctx);
   if (!ctx->h_dims && hipHostMalloc((void**)&ctx->h_dims, sizeof(TopoDims), hipHostMallocDefault) != hipSuccess) {
     (void)hipGetLastError();
     return fail(ctx, FLAME_NLTGV2_ERR_OOM);
@@ -324,7 +326,7 @@ int topo_upload(flame_nltgv2_ctx* ctx, const flame_nltgv2_graph* g, const StageC
   LAUNCHCHK(ctx, launch_topo_upload_front(t, ctx->stream));
   LAUNCHCHK(ctx, launch_topo_back(t, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(ctx->h_dims, ctx->topo_dims.p, sizeof(TopoDims), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, wait_solver_stream(ctx));
   const TopoDims dm = *ctx->h_dims;
   if (dm.flags != 0 || (ctx->opt_persistent != 4 && dm.wg_count > kPvDensePerCu * cus)) return 0;  // the host builders take over
   PackedLayout& L = ctx->L;
@@ -509,7 +511,7 @@ int topo_commit(flame_nltgv2_ctx* ctx, bool* done) {
   *done = true;
   if (trace) {
     const auto t2b = std::chrono::steady_clock::now();
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, wait_solver_stream(ctx));
     const auto t3 = std::chrono::steady_clock::now();
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     std::fprintf(stderr, "[flame_nltgv2] sync_graph (device): prepare (checks, staging, builder enqueued) %.3f ms; commit: builder awaited %.3f, "

@@ -94,7 +94,7 @@ def library_path() -> str:
 
 # every symbol include/flame_nltgv2.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
-    "flame_nltgv2_default_params", "flame_nltgv2_create", "flame_nltgv2_destroy", "flame_nltgv2_set_stream", "flame_nltgv2_stream_wait_run", "flame_nltgv2_runs_in_flight",
+    "flame_nltgv2_default_params", "flame_nltgv2_create", "flame_nltgv2_destroy", "flame_nltgv2_set_stream", "flame_nltgv2_stream_wait_run", "flame_nltgv2_runs_in_flight", "flame_nltgv2_run_open", "flame_nltgv2_iterations",
     "flame_nltgv2_upload_graph", "flame_nltgv2_update_data", "flame_nltgv2_upload_state", "flame_nltgv2_run",
     "flame_nltgv2_run_async", "flame_nltgv2_sync", "flame_nltgv2_run_timed", "flame_nltgv2_save_prev",
     "flame_nltgv2_dual_step", "flame_nltgv2_primal_step", "flame_nltgv2_extragradient_step", "flame_nltgv2_step",
@@ -130,6 +130,8 @@ def load_library():
         "flame_nltgv2_set_stream": (C.c_int, [ctx, C.c_void_p]),
         "flame_nltgv2_stream_wait_run": (C.c_int, [ctx, C.c_void_p]),
         "flame_nltgv2_runs_in_flight": (C.c_int, [ctx, C.POINTER(C.c_int32)]),
+        "flame_nltgv2_run_open": (C.c_int, [ctx, C.POINTER(Params), C.c_int, C.POINTER(C.c_int32)]),
+        "flame_nltgv2_iterations": (C.c_int, [ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
         "flame_nltgv2_upload_graph": (C.c_int, [ctx, GP]),
         "flame_nltgv2_update_data": (C.c_int, [ctx, _FP, _FP]),
         "flame_nltgv2_upload_state": (C.c_int, [ctx, GP]),
@@ -553,6 +555,19 @@ class Regularizer:
         n = C.c_int32(0)
         self._chk(self._L.flame_nltgv2_runs_in_flight(self._ctx, C.byref(n)), "runs_in_flight")
         return int(n.value)
+
+    def run_open(self, params: Params, max_iters: int) -> bool:
+        """A run that goes on (at most max_iters, even) until the next call that needs the solver settled asks it to stop.  False: not
+        applicable to this graph / configuration -- nothing was enqueued, use run_async."""
+        opened = C.c_int32(0)
+        self._chk(self._L.flame_nltgv2_run_open(self._ctx, C.byref(params), int(max_iters), C.byref(opened)), "run_open")
+        return bool(opened.value)
+
+    def iterations(self):
+        """(iterations applied by all runs so far, whether an open run is in flight and not yet counted); never waits."""
+        total, open_ = C.c_int64(0), C.c_int32(0)
+        self._chk(self._L.flame_nltgv2_iterations(self._ctx, C.byref(total), C.byref(open_)), "iterations")
+        return int(total.value), bool(open_.value)
 
     def stream_wait_run(self, hip_stream_ptr: int):
         """Another stream of the caller waits for everything enqueued on the solver's stream so far (right behind run_async: at no cost to

@@ -308,6 +308,24 @@ class DeviceGraph {
     check(flame_nltgv2_run_async(ctx_, &c, n_iters), "run_async");
   }
   void sync() { check(flame_nltgv2_sync(ctx_), "sync"); }
+  // A run that goes on until the next call that needs the solver settled asks it to stop (flame_nltgv2_run_open: the reference's solver
+  // thread is `while (true) step()`, flame.cc:99-112); at most max_iters (even) iterations.  false: not applicable to this graph or
+  // configuration -- nothing was enqueued, use runAsync.
+  bool runOpen(const Params& p, int max_iters) {
+    const flame_nltgv2_params c = to_c(p);
+    int32_t opened = 0;
+    check(flame_nltgv2_run_open(ctx_, &c, max_iters, &opened), "run_open");
+    return opened != 0;
+  }
+  // Iterations applied to the state by all runs so far; an open run is counted when it has been settled (*open_in_flight: one is not yet).
+  // Never waits: right after a call that settled the solver this is the exact number the state has seen.
+  uint64_t iterations(bool* open_in_flight = nullptr) {
+    int64_t total = 0;
+    int32_t open_ = 0;
+    check(flame_nltgv2_iterations(ctx_, &total, &open_), "iterations");
+    if (open_in_flight) *open_in_flight = open_ != 0;
+    return static_cast<uint64_t>(total);
+  }
   // Another stream of the caller waits for the runs enqueued so far (a consumer of the export row: a collective, a copy); right behind
   // runAsync() it costs the solver's stream nothing -- the launch carries the event.
   void streamWaitRun(void* other_hip_stream) { check(flame_nltgv2_stream_wait_run(ctx_, other_hip_stream), "stream_wait_run"); }

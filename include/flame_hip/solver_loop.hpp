@@ -100,6 +100,13 @@ class SolverLoop {
     cv_.notify_all();
     if (t.joinable()) t.join();
   }
+  // Device mode, before start(): instead of rounds of iters_per_round iterations, two in flight, the loop keeps ONE open run going
+  // (DeviceGraph::runOpen: it ends when a withDevice() call needs the solver settled, at most max_iters iterations) -- no start-up and no
+  // gap between rounds (12 us per round at 640x480), and a call waits ~0.15 ms for the solver instead of for up to two rounds.  Where
+  // an open run is not applicable (DeviceGraph::runOpen says so) the loop enqueues rounds as before.  The callbacks' iteration count
+  // then LAGS behind (an open run is counted once it is settled): a callback that needs the exact number asks DeviceGraph::iterations()
+  // after its first call that settled the solver.
+  void useOpenRuns(int max_iters = 1 << 15) { open_max_ = max_iters > 0 ? (max_iters & ~1) : 0; }
   bool running() const {
     std::lock_guard<std::mutex> lk(state_mtx_);
     return thread_.joinable() && !exited_ && !stop_.load();
@@ -134,6 +141,7 @@ class SolverLoop {
   void withDevice(F&& f) {
     CallerAccess dev_lk(this);
     f(dev_, iterations_.load());
+    count();
     refill();
   }
   // The same with a second part that does not need the solver stopped: f runs on the settled device image, the queue is filled
@@ -149,8 +157,10 @@ class SolverLoop {
     CallerAccess dev_lk(this);
     const uint64_t it = iterations_.load();
     f(dev_, it);
+    count();
     refill();
-    g(dev_, it);
+    g(dev_, open_max_ > 0 ? iterations_.load() : it);
+    count();
     refill();
   }
   // Device mode: the image uploaded through withDevice() is what the loop iterates on from now on.
@@ -318,9 +328,26 @@ class SolverLoop {
     }
   }
   // (dev_mtx_ held) device mode: enqueues rounds until two are in flight; true if it enqueued any
+  // (dev_mtx_ held) open runs: the library counts (an open run when it is settled); rounds are counted here, when they are enqueued
+  void count() {
+    if (open_max_ > 0 && graph_ == nullptr) iterations_.store(count_base_ + dev_.iterations());
+  }
   bool top_up() {
     bool any = false;
     if (dev_vertices() == 0) return false;
+    if (open_max_ > 0) {
+      if (dev_.runsInFlight() > 0) return false;
+      const bool opened = dev_.runOpen(params_, open_max_);  // (settles -- and counts -- an open run that reached its bound by itself)
+      count();
+      if (opened) return true;
+      // not applicable to this graph: rounds, counted by the library as well
+      while (dev_.runsInFlight() < 2) {
+        dev_.runAsync(params_, iters_per_round_);
+        any = true;
+      }
+      count();
+      return any;
+    }
     while (dev_.runsInFlight() < 2) {
       dev_.runAsync(params_, iters_per_round_);
       iterations_.fetch_add(static_cast<uint64_t>(iters_per_round_));
@@ -344,6 +371,8 @@ class SolverLoop {
   GraphMutex* graph_mtx_;
   Params params_;
   const int iters_per_round_, max_rounds_;
+  int open_max_ = 0;               // device mode: > 0 = one open run of at most this many iterations instead of rounds (useOpenRuns)
+  uint64_t count_base_ = 0;        // ... iterations_ = count_base_ + the library's count
   static constexpr int kRoundsPerCheck = 64;
   int rounds_unchecked_ = 0;
   DeviceGraph dev_;

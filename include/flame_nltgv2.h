@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FLAME_NLTGV2_ABI_VERSION 6 /* 6: the region-per-workgroup form left the library (FLAME_NLTGV2_OPT_PERSISTENT = 7 is an invalid argument, last_run_path 8 never occurs, the two info words it used are reserved; the struct's layout is unchanged); 5: flame_nltgv2_info grew (last_run_waves_per_cu, ..., replays_per_step); flame_nltgv2_stream_wait_run, _runs_in_flight */
+#define FLAME_NLTGV2_ABI_VERSION 7 /* 7: flame_nltgv2_run_open, flame_nltgv2_iterations, FLAME_NLTGV2_OPT_MESH_STATE; 6: the region-per-workgroup form left the library (FLAME_NLTGV2_OPT_PERSISTENT = 7 is an invalid argument, last_run_path 8 never occurs, the two info words it used are reserved; the struct's layout is unchanged); 5: flame_nltgv2_info grew (last_run_waves_per_cu, ..., replays_per_step); flame_nltgv2_stream_wait_run, _runs_in_flight */
 
 typedef struct flame_nltgv2_ctx flame_nltgv2_ctx;
 
@@ -238,6 +238,18 @@ int flame_nltgv2_stream_wait_run(flame_nltgv2_ctx* ctx, void* hip_stream);
  * blocking in the context (include/flame_hip/solver_loop.hpp, device mode).  Does not wait, does not check the runs' results (sync()
  * does), and costs the solver's stream nothing where the launch carries the event. */
 int flame_nltgv2_runs_in_flight(flame_nltgv2_ctx* ctx, int32_t* n_out);
+/* A run that goes on until the caller needs the state -- the reference's solver thread is `while (true) step()` (flame.cc:99-112), and a
+ * frame loop that enqueues rounds of N iterations pays each round's start-up and the gap between two launches (12 us per round at 640x480)
+ * and waits for up to two rounds whenever it needs the state.  run_open enqueues ONE launch of at most max_iters (even) iterations; the next
+ * call that needs the solver settled (sync, download_state, project_graph, sync_commit, a further run, ...) asks it to stop: one patch reads the
+ * request and publishes the iteration every patch leaves at (~0.1 ms later at 640x480).  *opened = 0: not applicable here (a graph beyond the
+ * patch-per-wave form's single launch, record verification or the probe on, a persistent run still unchecked) -- NOTHING was enqueued, use
+ * run_async.  How many iterations an open run did is known once it is settled: flame_nltgv2_iterations.  An expired open run is taken back
+ * and redone like any other.  flame_nltgv2_stream_wait_run / _runs_in_flight see it like a run_async (in flight until it has been stopped). */
+int flame_nltgv2_run_open(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int max_iters, int32_t* opened);
+/* Iterations applied to the state by all runs of this context so far (run, run_async: counted when enqueued; an open run: when settled --
+ * *open_in_flight = 1 says one is not yet counted).  Never waits. */
+int flame_nltgv2_iterations(flame_nltgv2_ctx* ctx, int64_t* total, int32_t* open_in_flight);
 
 /* Mesh -> dense inverse-depth map, the step right after the solver each frame:
  * utils::interpolateMesh (utils/image_utils.cc:373-396) over utils::DrawShadedTriangleBarycentric

@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -112,6 +113,7 @@ int main(int argc, char** argv) {
   out.buf.clear();
   const int iters_per_round = argc > 3 ? std::atoi(argv[3]) : 200;
   const bool lean = argc > 4 && std::atoi(argv[4]) != 0;
+  const bool rounds = std::getenv("FRAME_LOOP_ROUNDS") != nullptr;
   const bool one_part = std::getenv("FRAME_LOOP_ONE_PART") != nullptr;  // syncCommit + interpolateMeshBegin with the solver stopped for both
   const int32_t W = in.one<int32_t>(), H = in.one<int32_t>(), pad = in.one<int32_t>();
   const int32_t n_feats = in.one<int32_t>(), n_initial = in.one<int32_t>(), n_new = in.one<int32_t>(), host_work_us = in.one<int32_t>();
@@ -131,8 +133,13 @@ int main(int argc, char** argv) {
     const dgraph::Params params;
     std::mutex graph_mtx;
     flame_hip::SolverLoop<flame_hip::FlatGraph> loop(nullptr, &graph_mtx, params, iters_per_round);
+    // Round 6, third step: ONE open run instead of rounds (DeviceGraph::runOpen: it goes on until a call needs the solver settled) --
+    // FRAME_LOOP_ROUNDS=1: rounds of iters_per_round, two in flight, for comparison.  Either way the iteration counts the log holds are
+    // the library's (DeviceGraph::iterations() right after the call that settled the solver).
+    if (!rounds) loop.useOpenRuns();
     loop.start();
     bool first = true;
+    uint64_t it_base = 0;  // the library's iteration count when the first graph stood
     int meshes_begun = 0, meshes_beside_rounds = 0;  // two-part holds: the meshes begun, those with rounds still in flight behind the call
     // per-stage wall time of the frame thread (printed as medians: what a frame's time is made of)
     static const char* const kStage[] = {"addFrame", "updateFeatureIDepths", "delaunayTriangulate", "projectGraph", "syncPrepare", "other host work",
@@ -198,6 +205,7 @@ int main(int argc, char** argv) {
         loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t) {
           d.upload(g);
           if (flame_nltgv2_set_feature_ids(d.handle(), fid.data()) != 0) throw flame_hip::Error(FLAME_NLTGV2_ERR_INVALID_ARG, "set_feature_ids");
+          it_base = d.iterations();
         });
         loop.deviceReady();
         out.one<uint64_t>(0);
@@ -207,13 +215,13 @@ int main(int argc, char** argv) {
         std::vector<uint8_t> keep;
         uint64_t it_project = 0;
         t_stage = std::chrono::steady_clock::now();
-        loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t it) {
-          it_project = it;
+        loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t) {
           int32_t Vo = 0, Eo = 0;
           if (flame_nltgv2_graph_size(d.handle(), &Vo, &Eo) != 0) throw flame_hip::Error(FLAME_NLTGV2_ERR_HIP, "graph_size");
           keep.resize((size_t)Vo);
           const int rc = flame_nltgv2_project_graph(d.handle(), &pr, 1.0f, keep.data(), nullptr);
           if (rc != 0) throw flame_hip::Error(rc, "project_graph");
+          it_project = d.iterations() - it_base;  // (the call has settled the solver: the state it projected had seen exactly this many)
         });
         lap(3);
         if (!lean) out.one(it_project), out.one<int32_t>((int32_t)keep.size()), out.many(keep);
@@ -232,17 +240,17 @@ int main(int argc, char** argv) {
         // state the commit left, read from the canonical arrays beside the next rounds, which withDevice(f, g) enqueues BEFORE the
         // mesh's host work (FRAME_LOOP_ONE_PART=1: the one-part hold, for comparison)
         if (one_part) {
-          loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t it) {
-            it_commit = it_raster = it;
+          loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t) {
             d.syncCommit();
+            it_commit = it_raster = d.iterations() - it_base;
             lap(6);
             d.interpolateMeshBegin(tris, H, W, 1.0f);
           });
         } else {
           loop.withDevice(
-              [&](dgraph::DeviceGraph& d, uint64_t it) {
-                it_commit = it_raster = it;
+              [&](dgraph::DeviceGraph& d, uint64_t) {
                 d.syncCommit();
+                it_commit = it_raster = d.iterations() - it_base;
                 lap(6);
               },
               [&](dgraph::DeviceGraph& d, uint64_t) {
@@ -257,9 +265,9 @@ int main(int argc, char** argv) {
       // ---- interpolateMesh in two halves ----------------------------------------------------------------------------------------
       if (it_raster == 0 && it_commit == 0) {  // (the first frame: no sync, the map of the uploaded graph)
         t_stage = std::chrono::steady_clock::now();
-        loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t it) {
-          it_raster = it;
+        loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t) {
           d.interpolateMeshBegin(tris, H, W, 1.0f);  // (this one settles the rounds in flight: the option is set behind it)
+          it_raster = d.iterations() - it_base;
           if (!one_part && flame_nltgv2_set_option(d.handle(), FLAME_NLTGV2_OPT_MESH_STATE, 1) != 0)
             throw flame_hip::Error(FLAME_NLTGV2_ERR_INVALID_ARG, "set_option");
         });
@@ -280,19 +288,20 @@ int main(int argc, char** argv) {
       // ---- the graph's state at the end of the frame (a read-back the reference does not need: the test's window on the solver) ------
       flame_hip::FlatArrays a;
       if (lean) continue;
-      loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t it) {
-        it_state = it;
+      loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t) {
         int32_t Vn = 0, En = 0;
         if (flame_nltgv2_graph_size(d.handle(), &Vn, &En) != 0) throw flame_hip::Error(FLAME_NLTGV2_ERR_HIP, "graph_size");
         a.resize((size_t)Vn, (size_t)En);
         flame_nltgv2_graph v = a.view();
         const int rc = flame_nltgv2_download_state(d.handle(), &v);
         if (rc != 0) throw flame_hip::Error(rc, "download_state");
+        it_state = d.iterations() - it_base;
       });
       out.one(it_state), out.one<int32_t>((int32_t)a.x.size()), out.one<int32_t>((int32_t)a.q1.size());
       out.many(a.x), out.many(a.w1), out.many(a.w2), out.many(a.x_bar), out.many(a.w1_bar), out.many(a.w2_bar);
       out.many(a.q1), out.many(a.q2), out.many(a.q3);
     }
+    loop.withDevice([&](dgraph::DeviceGraph& d, uint64_t) { d.sync(); });  // (an open run still in flight is counted once it is settled)
     const auto t_end = std::chrono::steady_clock::now();
     const double wall_ms = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
     const uint64_t total = loop.iterations();
@@ -313,9 +322,10 @@ int main(int argc, char** argv) {
       std::printf("FAIL: the solver thread stopped: %s\n", err.c_str());
       return 1;
     }
-    std::printf("frame loop%s: %d frames in %.2f ms (%.2f ms per frame), %llu solver iterations beside them (%d per round, two rounds in flight), %.0f iterations/s in the loop against %.0f undisturbed: "
+    const std::string how = rounds ? std::to_string(iters_per_round) + " per round, two rounds in flight" : std::string("one open run between two calls that need the solver settled");
+    std::printf("frame loop%s: %d frames in %.2f ms (%.2f ms per frame), %llu solver iterations beside them (%s), %.0f iterations/s in the loop against %.0f undisturbed: "
                 "solver busy %.1f %% of the time since the first graph, idle %.1f %%\n",
-                lean ? " (lean: no state read-back)" : "", n_new, wall_ms, wall_ms / n_new, (unsigned long long)total, iters_per_round, util_at_stop_per_rate, free_rate, 100.0 * busy, 100.0 * (1.0 - busy));
+                lean ? " (lean: no state read-back)" : "", n_new, wall_ms, wall_ms / n_new, (unsigned long long)total, how.c_str(), util_at_stop_per_rate, free_rate, 100.0 * busy, 100.0 * (1.0 - busy));
     if (!one_part) std::printf("  meshes begun beside the next rounds: %d of %d\n", meshes_beside_rounds, meshes_begun);
     if (lean) {
       std::sort(frame_ms.begin() + std::min<size_t>(2, frame_ms.size()), frame_ms.end());
@@ -332,6 +342,10 @@ int main(int argc, char** argv) {
         sum += v[v.size() / 2];
       }
       std::printf(" sum %.3f\n", sum);
+      std::printf("  ... their longest, ms:");
+      for (size_t k = 0; k < stage_ms.size(); ++k)
+        if (!stage_ms[k].empty()) std::printf(" %s %.3f;", kStage[k], stage_ms[k].back());
+      std::printf("\n");
     }
   } catch (const std::exception& e) {
     std::printf("FAIL: %s\n", e.what());

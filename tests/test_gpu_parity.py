@@ -1085,3 +1085,68 @@ def test_an_expired_chain_is_first_redone_persistently_then_per_step(env, config
         info = reg.info()
         assert info["timeouts_recovered"] == 2 and info["last_run_path"] in (2, 3), info
         assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="after the per-step replay")
+
+
+def test_open_run_stops_when_asked_and_says_how_far_it_went(built):
+    """flame_nltgv2_run_open: ONE launch that iterates until the next call that needs the solver settled asks it to stop -- a patch reads the
+    request and publishes the iteration every patch leaves at.  However far it went (flame_nltgv2_iterations says), the state is the
+    oracle's after exactly that many iterations: stopped after a few milliseconds, run to its bound, stopped at once, settled by a run
+    enqueued behind it, not applicable (record verification on: nothing enqueued), and expired (the test hook's fault: taken back, redone)."""
+    import time
+
+    import torch  # noqa: F401
+
+    import flame_amd
+    from flame_amd.regularizer import OPT_FAULT_INJECT, OPT_VERIFY_RECORDS
+    from oracle import capi as oracle
+
+    keys = OUT_KEYS + ("x_prev", "w1_prev", "w2_prev")
+    g = synth.make_graph("640x480", seed=3)
+    ref = synth.copy_graph(g)
+    p = flame_amd.Params()
+    with flame_amd.Regularizer(0) as reg:
+        reg.upload_graph(g)
+        reg.run(p, 10)
+        oracle.run(ref, 10)
+        assert reg.iterations() == (10, False)
+
+        def settle_and_check(what, settle, lo, hi, extra=0):
+            before = reg.iterations()[0]
+            assert reg.iterations()[1]
+            out = settle()
+            total, still_open = reg.iterations()
+            n = total - before - extra
+            assert not still_open and n % 2 == 0 and lo <= n <= hi, (what, n)
+            oracle.run(ref, n + extra)
+            assert_state_equal(out if out is not None else reg.download_state(), ref, keys=keys, what=f"{what}: {n} iterations")
+            return n
+
+        assert reg.run_open(p, 400000)
+        assert reg.runs_in_flight() >= 1
+        time.sleep(0.004)
+        n = settle_and_check("stopped after 4 ms by a read-back", lambda: reg.download_state(), 500, 40000)
+        assert reg.info()["last_run_path"] == 6
+        assert reg.run_open(p, 64)
+        time.sleep(0.002)
+        settle_and_check("run to its bound", lambda: reg.sync(), 64, 64)
+        assert reg.run_open(p, 400000)
+        n0 = settle_and_check("stopped at once", lambda: reg.sync(), 2, 4000)
+        assert reg.run_open(p, 400000)
+        time.sleep(0.001)
+        settle_and_check("settled by a run enqueued behind it", lambda: (reg.run_async(p, 30), reg.sync())[1], 2, 40000, extra=30)
+        # odd bounds are refused; with the record verification on an open run is not applicable: nothing happens
+        with pytest.raises(flame_amd.NLTGV2Error):
+            reg.run_open(p, 33)
+        reg.set_option(OPT_VERIFY_RECORDS, 1)
+        before = reg.iterations()
+        assert not reg.run_open(p, 1000) and reg.iterations() == before
+        reg.set_option(OPT_VERIFY_RECORDS, 0)
+        # an open run whose waits expire: taken back and redone
+        rec = reg.info()["timeouts_recovered"]
+        reg.set_option(OPT_FAULT_INJECT, 200)
+        assert reg.run_open(p, 400000)
+        time.sleep(0.002)
+        settle_and_check("expired, redone", lambda: reg.sync(), 2, 40000)
+        reg.set_option(OPT_FAULT_INJECT, 0)
+        assert reg.info()["timeouts_recovered"] == rec + 1
+        print(f"open runs: {n} iterations in ~4 ms, {n0} when stopped at once")

@@ -133,6 +133,7 @@ def main():
     for t in threads:
         t.start()
     mismatches, checker_mismatches, paths, syncs = [], [], {}, {}
+    opened = 0
     t0 = time.time()
     tris = synth.delaunay_native(pos)[0]
     for frame in range(FRAMES):
@@ -160,9 +161,15 @@ def main():
             if frame & 1:  # round 4: the sync in two halves -- the builder on its side stream while the solver does 50 more iterations on the old graph
                 # round 6: what a frame loop's holds enqueue beside / behind rounds in flight -- projectGraph's kernel behind 30 iterations,
                 # the commit's expansion beside and its unpack + state gather behind 50 more, the mesh of the committed state beside 10
-                A.run_async(P, 30)
+                it0 = A.iterations()[0]
+                if A.run_open(P, 1 << 14):  # an open run: it goes on until projectGraph needs the state (0.2 ms here), then says how far it went
+                    time.sleep(0.0002)
+                    opened += 1
+                else:
+                    A.run_async(P, 30)
                 keep_a, _ = A.project_graph(*PROJ, graph_scale=1.0)
-                B.run(P, 30)
+                n_open = A.iterations()[0] - it0
+                B.run(P, n_open)
                 keep_b, _ = B.project_graph(*PROJ, graph_scale=1.0)
                 if not np.array_equal(keep_a, keep_b):
                     mismatches.append(frame)
@@ -182,7 +189,7 @@ def main():
                     mismatches.append(frame)
                 if frame < CHECK:
                     flat = sync_oracle.flatten(ref, feat_prev)
-                    oracle.run(flat, 30)
+                    oracle.run(flat, n_open)
                     oracle.graph_project(flat["pos"], flat["x"], 1.0, PROJ[0], PROJ[1], PROJ[3], PROJ[4], PROJ[2], PROJ[5])
                     oracle.run(flat, 50)
                     sync_oracle.absorb(ref, flat, feat_prev)
@@ -208,7 +215,7 @@ def main():
         t.join(timeout=10)
     ia = A.info()
     out = {"frames": FRAMES, "size": SIZE, "V_last": int(len(feat_id)), "iterations_per_frame": ITERS, "solver_iterations": budget["done"],
-           "solver_run_paths": paths, "sync_paths_of_A": syncs, "every_other_sync": "30 iterations + projectGraph behind them, sync_prepare + 50 iterations beside the builder + sync_commit (expansion beside, unpack + gather behind), 10 iterations + the mesh of the committed state beside them", "frames_mismatching_the_per_step_reference": len(mismatches), "first_mismatches": mismatches[:5],
+           "solver_run_paths": paths, "sync_paths_of_A": syncs, "open_runs": opened, "every_other_sync": "an open run stopped by projectGraph (its kernel behind the run), sync_prepare + 50 iterations beside the builder + sync_commit (expansion beside, unpack + gather behind), 10 iterations + the mesh of the committed state beside them", "frames_mismatching_the_per_step_reference": len(mismatches), "first_mismatches": mismatches[:5],
            "frames_checked_against_the_chained_cpu_checkers": CHECK, "of_those_mismatching": len(checker_mismatches),
            "timeouts_recovered": int(ia["timeouts_recovered"]), "torn_records_detected": int(ia["torn_records_detected"]),
            "concurrent_load": load, "seconds": round(time.time() - t0, 1),
