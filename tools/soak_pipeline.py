@@ -6,8 +6,7 @@ without pause, and Flame::update() on another thread firing updateFeatureIDepths
 rate.  Here, for FRAMES frames:
 
   * solver thread (the SolverLoop contract: a fixed budget per frame, the context touched under one lock): context A runs its
-    per-frame budget of iterations in persistent launches (the patch-per-wave kernel; record verification on in every other
-    frame), while at the same time, on other streams of the same GPU,
+    per-frame budget of iterations in persistent launches (the patch-per-wave kernel; record verification on in two frames of four), while at the same time, on other streams of the same GPU,
   * a tracker thread keeps FeatureTracker.update_resident (the 16-lane epipolar kernel) going back to back, and
   * a raster thread keeps interpolate_mesh_arrays going on a third context;
   * every frame the main thread -- under the lock, as Flame::update does -- reads the solver's mesh out (interpolate_mesh on A),
@@ -140,7 +139,7 @@ def main():
         with frame_ready:             # Flame::update(): wait for the frame's budget, then own the graph
             while budget["left"] > 0:
                 frame_ready.wait(timeout=0.05)
-            A.set_option(OPT_VERIFY_RECORDS, frame & 1)
+            A.set_option(OPT_VERIFY_RECORDS, 1 if (frame & 3) >= 2 else 0)  # (two frames on, two off: an open run applies where it is off)
             pa = RUN_PATHS.get(A.info()["last_run_path"], "?")
             paths[pa] = paths.get(pa, 0) + 1
             B.run(P, ITERS)
