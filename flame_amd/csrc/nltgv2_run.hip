@@ -944,6 +944,14 @@ int flame_nltgv2_run_open(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, i
   if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
   if (!params_ok(p) || max_iters < 0 || (max_iters & 1)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
   if (max_iters == 0) return 0;
+  {  // applicable at all?  Asked BEFORE anything is settled: a loop that falls back to rounds must not have them waited for here
+    std::vector<WaveGroup> groups;
+    int tv_lds = 0;
+    const int form = plan_persistent(ctx, max_iters, &groups, &tv_lds, /*consume=*/false);
+    if (form != 3 || groups.size() != 1 || groups[0].count > 20 * ctx->prop.multiProcessorCount || ctx->opt_probe != 0 || ctx->opt_verify != 0 ||
+        !ctx->h_stop || !ctx->ctl_stream)
+      return 0;
+  }
   if (ctx->pending.active) {  // an open run is the first of its chain
     rc = finish(ctx);
     if (rc) return rc;

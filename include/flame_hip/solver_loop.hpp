@@ -141,7 +141,7 @@ class SolverLoop {
   void withDevice(F&& f) {
     CallerAccess dev_lk(this);
     f(dev_, iterations_.load());
-    count();
+    recount();
     refill();
   }
   // The same with a second part that does not need the solver stopped: f runs on the settled device image, the queue is filled
@@ -157,10 +157,10 @@ class SolverLoop {
     CallerAccess dev_lk(this);
     const uint64_t it = iterations_.load();
     f(dev_, it);
-    count();
+    recount();
     refill();
     g(dev_, open_max_ > 0 ? iterations_.load() : it);
-    count();
+    recount();
     refill();
   }
   // Device mode: the image uploaded through withDevice() is what the loop iterates on from now on.
@@ -332,15 +332,26 @@ class SolverLoop {
   void count() {
     if (open_max_ > 0 && graph_ == nullptr) iterations_.store(count_base_ + dev_.iterations());
   }
+  void recount() {  // (behind a caller's callback: it may have changed the graph)
+    count();
+    open_na_ = false;
+  }
   bool top_up() {
     bool any = false;
     if (dev_vertices() == 0) return false;
     if (open_max_ > 0) {
-      if (dev_.runsInFlight() > 0) return false;
-      const bool opened = dev_.runOpen(params_, open_max_);  // (settles -- and counts -- an open run that reached its bound by itself)
-      count();
-      if (opened) return true;
-      // not applicable to this graph: rounds, counted by the library as well
+      if (!open_na_) {
+        bool open_now = false;
+        dev_.iterations(&open_now);
+        if (open_now && dev_.runsInFlight() > 0) return false;  // the open run goes on
+        // (nothing open in flight -- or it reached its bound by itself: settled and counted by the call below.  Where an open run does not
+        //  apply the call returns at once, WITHOUT waiting for rounds that may be in flight)
+        const bool opened = dev_.runOpen(params_, open_max_);
+        count();
+        if (opened) return true;
+        open_na_ = true;  // not applicable to this graph (asked again after the next withDevice(): the graph may have changed)
+      }
+      // rounds, counted by the library as well
       while (dev_.runsInFlight() < 2) {
         dev_.runAsync(params_, iters_per_round_);
         any = true;
@@ -373,6 +384,7 @@ class SolverLoop {
   const int iters_per_round_, max_rounds_;
   int open_max_ = 0;               // device mode: > 0 = one open run of at most this many iterations instead of rounds (useOpenRuns)
   uint64_t count_base_ = 0;        // ... iterations_ = count_base_ + the library's count
+  bool open_na_ = false;           // ... an open run is not applicable to the graph as it stands (rounds until a callback has run)
   static constexpr int kRoundsPerCheck = 64;
   int rounds_unchecked_ = 0;
   DeviceGraph dev_;
