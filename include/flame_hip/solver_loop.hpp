@@ -199,6 +199,7 @@ class SolverLoop {
   }
   uint64_t iterations() const { return iterations_.load(); }
   uint64_t uploads() const { return uploads_.load(); }
+  uint64_t openRuns() const { return open_runs_.load(); }  // device mode with useOpenRuns(): how many open runs the loop has started
   std::string error() const {
     std::lock_guard<std::mutex> lk(state_mtx_);
     return error_;
@@ -348,7 +349,10 @@ class SolverLoop {
         //  apply the call returns at once, WITHOUT waiting for rounds that may be in flight)
         const bool opened = dev_.runOpen(params_, open_max_);
         count();
-        if (opened) return true;
+        if (opened) {
+          open_runs_.fetch_add(1);
+          return true;
+        }
         open_na_ = true;  // not applicable to this graph (asked again after the next withDevice(): the graph may have changed)
       }
       // rounds, counted by the library as well
@@ -393,7 +397,7 @@ class SolverLoop {
   std::condition_variable cv_;
   std::thread thread_;
   std::atomic<bool> stop_{false};
-  std::atomic<uint64_t> iterations_{0}, uploads_{0}, busy_ns_{0}, iterations_at_ready_{0};
+  std::atomic<uint64_t> iterations_{0}, uploads_{0}, busy_ns_{0}, iterations_at_ready_{0}, open_runs_{0};
   bool device_ready_ = false;                              // device mode: the first image was handed over (state_mtx_)
   std::chrono::steady_clock::time_point t_ready_ = std::chrono::steady_clock::now();
   std::atomic<int> callers_waiting_{0};

@@ -322,7 +322,7 @@ int main(int argc, char** argv) {
       std::printf("FAIL: the solver thread stopped: %s\n", err.c_str());
       return 1;
     }
-    const std::string how = rounds ? std::to_string(iters_per_round) + " per round, two rounds in flight" : std::string("one open run between two calls that need the solver settled");
+    const std::string how = rounds ? std::to_string(iters_per_round) + " per round, two rounds in flight" : std::to_string((unsigned long long)loop.openRuns()) + " open runs, each until a call needs the solver settled" + (loop.openRuns() < (uint64_t)n_new ? "; rounds of " + std::to_string(iters_per_round) + " where an open run does not apply" : std::string());
     std::printf("frame loop%s: %d frames in %.2f ms (%.2f ms per frame), %llu solver iterations beside them (%s), %.0f iterations/s in the loop against %.0f undisturbed: "
                 "solver busy %.1f %% of the time since the first graph, idle %.1f %%\n",
                 lean ? " (lean: no state read-back)" : "", n_new, wall_ms, wall_ms / n_new, (unsigned long long)total, how.c_str(), util_at_stop_per_rate, free_rate, 100.0 * busy, 100.0 * (1.0 - busy));
