@@ -36,7 +36,8 @@ struct SlotConst {
   v2f_t P12, C2;
 };
 
-template <bool VERIFY>
+// OPEN: the open run's instance (nltgv2_persistent.hip, k_persistent_pv: the same words of the error block, the same margin and interval)
+template <bool VERIFY, bool OPEN = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(92)))
 k_persistent_pv2(const int wg_begin, const int n_wgs, const int wgs_per_xcd, const int lcap, const int32_t* __restrict__ wg_slot,
                  const int32_t* __restrict__ wg_vid, const uint32_t* __restrict__ wg_meta, const int32_t* __restrict__ wg_nbr,
@@ -423,12 +424,38 @@ k_persistent_pv2(const int wg_begin, const int n_wgs, const int wgs_per_xcd, con
   char* const pubA = p0 ? pa1 : pa0;
   char* const pubB = p0 ? pa0 : pa1;
   int it = 0;
-  for (; it + 1 < n_iters && !timed_out; it += 2) {
-    step(tag0 + (unsigned)it, rdA0, rdA1, dstA, wrB_rec, it, srcA, pubB, wrA_rec, areaA + lcap);
-    if (timed_out) break;
-    step(tag0 + (unsigned)it + 1u, rdB0, rdB1, dstB, wrA_rec, it + 1, srcB, pubA, wrB_rec, areaB + lcap);
+  if (OPEN) {
+    constexpr unsigned kOpenMargin = 128u, kOpenCheck = 64u;  // (as in k_persistent_pv)
+    const bool decides = wg == wg_begin + n_wgs / 2;
+    const unsigned* const stop_req = tail->stop_req;
+    unsigned* const stop_word = reinterpret_cast<unsigned*>(err) + 12;
+    unsigned stop_at = 0u;
+    for (; it + 1 < n_iters && !timed_out; it += 2) {
+      if (((unsigned)it & (kOpenCheck - 1u)) == 0u) {
+        if (decides && stop_at == 0u && stop_req &&
+            __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(stop_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) {
+          stop_at = tag0 + (unsigned)it + kOpenMargin;
+          if (lane == 0) __hip_atomic_store(stop_word, stop_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (stop_at == 0u) {
+          const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(stop_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          if (w > tag0 && w - tag0 <= (unsigned)n_iters + kOpenMargin) stop_at = w;
+        }
+      }
+      if (stop_at != 0u && stop_at - tag0 <= (unsigned)it) break;
+      step(tag0 + (unsigned)it, rdA0, rdA1, dstA, wrB_rec, it, srcA, pubB, wrA_rec, areaA + lcap);
+      if (timed_out) break;
+      step(tag0 + (unsigned)it + 1u, rdB0, rdB1, dstB, wrA_rec, it + 1, srcB, pubA, wrB_rec, areaB + lcap);
+    }
+    if (decides && lane == 0 && !timed_out) reinterpret_cast<unsigned*>(err)[13] = tag0 + (unsigned)it;
+  } else {
+    for (; it + 1 < n_iters && !timed_out; it += 2) {
+      step(tag0 + (unsigned)it, rdA0, rdA1, dstA, wrB_rec, it, srcA, pubB, wrA_rec, areaA + lcap);
+      if (timed_out) break;
+      step(tag0 + (unsigned)it + 1u, rdB0, rdB1, dstB, wrA_rec, it + 1, srcB, pubA, wrB_rec, areaB + lcap);
+    }
+    if (it < n_iters && !timed_out) step(tag0 + (unsigned)it, rdA0, rdA1, dstA, wrB_rec, it, srcA, pubB, wrA_rec, areaA + lcap);
   }
-  if (it < n_iters && !timed_out) step(tag0 + (unsigned)it, rdA0, rdA1, dstA, wrB_rec, it, srcA, pubB, wrA_rec, areaA + lcap);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   if (timed_out) {
@@ -502,7 +529,7 @@ int launch_persistent_pv2(const FusedArgs& a, const Pv2Args& w, const SolverPara
   const unsigned ldsv = 16u * (unsigned)(2 * (lcap + 64) + 64);
   void* vargs[] = {&wg_begin, &n_wgs, &wgx, &lcap, &w0, &w1, &w2, &w3, &w4, &w5, &hrec, &hq, &vstate, &hq_out, &vstate_out, &vaux, &bin, &bout,
                    &vprev, &xbuf, &rec_bytes, &dual, &tag0, &n_iters, &max_spins, &poll_gap, &pp, &err, &abort_flag, &perm, &tail};
-  const void* fn = (dual >> 1) != 0 ? (const void*)k_persistent_pv2<true> : (const void*)k_persistent_pv2<false>;
+  const void* fn = (dual >> 1) != 0 ? (const void*)k_persistent_pv2<true> : a.open_run ? (const void*)k_persistent_pv2<false, true> : (const void*)k_persistent_pv2<false>;
   if (cooperative) return (int)hipLaunchCooperativeKernel(fn, gv, bv, vargs, ldsv, stream);
   return (int)hipExtLaunchKernel(fn, gv, bv, vargs, ldsv, stream, nullptr, a.stop_event, 0);
 }

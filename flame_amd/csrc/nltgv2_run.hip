@@ -462,6 +462,14 @@ int place_records(flame_nltgv2_ctx* ctx, int per_xcd) {
   return 0;
 }
 
+// An open run: ONE launch of the patch-per-wave form or of the two-half-edges form.  Their OPEN instances keep fewer patches resident than
+// the plain ones (24 instead of 28 per CU; 16 instead of 20: tests/test_abi.py): graphs of at most 20 / 14 patches per CU.
+static bool open_run_applies(const flame_nltgv2_ctx* ctx, int form, const std::vector<WaveGroup>& groups) {
+  if (groups.size() != 1) return false;
+  const int cus = ctx->prop.multiProcessorCount;
+  return (form == 3 && groups[0].count <= 20 * cus) || (form == 4 && groups[0].count <= 14 * cus);
+}
+
 int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   if (n <= 0) return 0;
   if (ctx->open_inflight) {  // nothing is chained behind an open run: it would wait for the run's upper bound
@@ -507,8 +515,7 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
   const int form = plan_persistent(ctx, n, &groups, &tv_lds, /*consume=*/true);
   // an open run: the patch-per-wave form as ONE launch of its plain instance, the first run of a chain -- anything else is run as asked
   // for (n iterations), the caller sees that from flame_nltgv2_run_open's `opened`
-  // (its kernel instance keeps 24 patches per CU resident, not 28: tests/test_abi.py; an open run is for graphs of at most 20)
-  const bool open_run = ctx->want_open != 0 && form == 3 && groups.size() == 1 && groups[0].count <= 20 * ctx->prop.multiProcessorCount && !ctx->pending.active && ctx->opt_probe == 0 &&
+  const bool open_run = ctx->want_open != 0 && open_run_applies(ctx, form, groups) && !ctx->pending.active && ctx->opt_probe == 0 &&
                         ctx->opt_verify == 0 && ctx->replaying == 0 && (n & 1) == 0 && ctx->h_stop != nullptr && ctx->ctl_stream != nullptr;
   if (ctx->want_open != 0 && !open_run) {  // flame_nltgv2_run_open on a graph / a configuration it does not apply to: nothing is run
     ctx->want_open = 0;
@@ -631,8 +638,10 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
         const bool dense = gr.count > kPv2PaceAbovePerCu * ctx->prop.multiProcessorCount;
         const int gap = ctx->opt_poll_gap > 0 ? ctx->opt_poll_gap - 1 : dense ? (3 | ((kPv2DenseGap - 1) << 4)) : kPvPollGap;
         const int poll_gap = gap | ((ctx->opt_presleep > 0 ? ctx->opt_presleep - 1 : dense ? kPv2DensePreSleep : kPvPreSleep) << 8);
+        ctx->f.open_run = open_run ? 1 : 0;
         e = launch_persistent_pv2(ctx->f, ctx->pv2_args, to_sp(p), gr.begin, gr.count, ctx->parity, tag0, n, spins_arg, poll_gap, dual,
                                   tail_dev, cooperative_allowed() && ctx->coop_checked_key != key, ctx->stream);
+        ctx->f.open_run = 0;
         if (e != 0) break;
         continue;
       }
@@ -948,9 +957,7 @@ int flame_nltgv2_run_open(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, i
     std::vector<WaveGroup> groups;
     int tv_lds = 0;
     const int form = plan_persistent(ctx, max_iters, &groups, &tv_lds, /*consume=*/false);
-    if (form != 3 || groups.size() != 1 || groups[0].count > 20 * ctx->prop.multiProcessorCount || ctx->opt_probe != 0 || ctx->opt_verify != 0 ||
-        !ctx->h_stop || !ctx->ctl_stream)
-      return 0;
+    if (!open_run_applies(ctx, form, groups) || ctx->opt_probe != 0 || ctx->opt_verify != 0 || !ctx->h_stop || !ctx->ctl_stream) return 0;
   }
   if (ctx->pending.active) {  // an open run is the first of its chain
     rc = finish(ctx);

@@ -106,7 +106,8 @@ class SolverLoop {
   // an open run is not applicable (DeviceGraph::runOpen says so) the loop enqueues rounds as before.  The callbacks' iteration count
   // then LAGS behind (an open run is counted once it is settled): a callback that needs the exact number asks DeviceGraph::iterations()
   // after its first call that settled the solver.
-  void useOpenRuns(int max_iters = 1 << 15) { open_max_ = max_iters > 0 ? (max_iters & ~1) : 0; }
+  // (max_iters: what anybody ELSE who makes the device wait -- another context's hipFree -- waits for at most: 4 096 iterations are 4-6 ms)
+  void useOpenRuns(int max_iters = 1 << 12) { open_max_ = max_iters > 0 ? (max_iters & ~1) : 0; }
   bool running() const {
     std::lock_guard<std::mutex> lk(state_mtx_);
     return thread_.joinable() && !exited_ && !stop_.load();

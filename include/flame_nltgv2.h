@@ -242,9 +242,9 @@ int flame_nltgv2_runs_in_flight(flame_nltgv2_ctx* ctx, int32_t* n_out);
  * frame loop that enqueues rounds of N iterations pays each round's start-up and the gap between two launches (12 us per round at 640x480)
  * and waits for up to two rounds whenever it needs the state.  run_open enqueues ONE launch of at most max_iters (even) iterations; the next
  * call that needs the solver settled (sync, download_state, project_graph, sync_commit, a further run, ...) asks it to stop: one patch reads the
- * request and publishes the iteration every patch leaves at (~0.1 ms later at 640x480).  *opened = 0: not applicable here (a graph beyond the
- * patch-per-wave form's single launch, record verification or the probe on, a persistent run still unchecked) -- NOTHING was enqueued, use
- * run_async.  How many iterations an open run did is known once it is settled: flame_nltgv2_iterations.  An expired open run is taken back
+ * request and publishes the iteration every patch leaves at (~0.15 ms later at 640x480).  *opened = 0: not applicable here (a graph beyond ONE
+ * launch of the patch-per-wave or the two-half-edges form at <= 20 / 14 patches per CU, record verification or the probe on) -- NOTHING was
+ * enqueued and nothing waited for, use run_async.  How many iterations an open run did is known once it is settled: flame_nltgv2_iterations.  An expired open run is taken back
  * and redone like any other.  flame_nltgv2_stream_wait_run / _runs_in_flight see it like a run_async (in flight until it has been stopped). */
 int flame_nltgv2_run_open(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int max_iters, int32_t* opened);
 /* Iterations applied to the state by all runs of this context so far (run, run_async: counted when enqueued; an open run: when settled --

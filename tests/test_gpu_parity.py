@@ -1087,7 +1087,8 @@ def test_an_expired_chain_is_first_redone_persistently_then_per_step(env, config
         assert_state_equal(reg.download_state(), ref, keys=OUT_KEYS + ("x_prev", "w1_prev", "w2_prev"), what="after the per-step replay")
 
 
-def test_open_run_stops_when_asked_and_says_how_far_it_went(built):
+@pytest.mark.parametrize("size,path", [("640x480", 6), ("1920x1080", 7)])
+def test_open_run_stops_when_asked_and_says_how_far_it_went(built, size, path):
     """flame_nltgv2_run_open: ONE launch that iterates until the next call that needs the solver settled asks it to stop -- a patch reads the
     request and publishes the iteration every patch leaves at.  However far it went (flame_nltgv2_iterations says), the state is the
     oracle's after exactly that many iterations: stopped after a few milliseconds, run to its bound, stopped at once, settled by a run
@@ -1101,7 +1102,7 @@ def test_open_run_stops_when_asked_and_says_how_far_it_went(built):
     from oracle import capi as oracle
 
     keys = OUT_KEYS + ("x_prev", "w1_prev", "w2_prev")
-    g = synth.make_graph("640x480", seed=3)
+    g = synth.make_graph(size, seed=3)  # (640x480: the patch-per-wave form; 1920x1080: two half-edges per lane)
     ref = synth.copy_graph(g)
     p = flame_amd.Params()
     with flame_amd.Regularizer(0) as reg:
@@ -1125,7 +1126,7 @@ def test_open_run_stops_when_asked_and_says_how_far_it_went(built):
         assert reg.runs_in_flight() >= 1
         time.sleep(0.004)
         n = settle_and_check("stopped after 4 ms by a read-back", lambda: reg.download_state(), 500, 40000)
-        assert reg.info()["last_run_path"] == 6
+        assert reg.info()["last_run_path"] == path
         assert reg.run_open(p, 64)
         time.sleep(0.002)
         settle_and_check("run to its bound", lambda: reg.sync(), 64, 64)
