@@ -239,12 +239,16 @@ def main():
                             "page of their pair, 128-byte aligned per producing patch"}
             except Exception as e:  # noqa: BLE001
                 roofline["record_placement"] = f"{type(e).__name__}: {e}"
+            # (--no-extras leaves both out: they launch the dominant kernel with other lengths and graphs, and the rocprofv3 statistics of that
+            #  command -- tools/profile.sh, profiles/r06_kernel_stats_bench.csv -- are to hold the headline's launches only)
             try:
-                roofline["step_cycles"] = pv_step_cycles(flame_amd, g, params, a.iters, local_rank)
+                if not a.no_extras:
+                    roofline["step_cycles"] = pv_step_cycles(flame_amd, g, params, a.iters, local_rank)
             except Exception as e:  # noqa: BLE001
                 roofline["step_cycles"] = f"{type(e).__name__}: {e}"
             try:  # what `frac` has to be read against: the physical floor of one iteration of ONE small frame, measured by this run
-                roofline["floor"] = latency_floor(flame_amd, synth, params, a.iters, local_rank, B_iter, roofline)
+                if not a.no_extras:
+                    roofline["floor"] = latency_floor(flame_amd, synth, params, a.iters, local_rank, B_iter, roofline)
             except Exception as e:  # noqa: BLE001
                 roofline["floor"] = f"{type(e).__name__}: {e}"
         out = {
