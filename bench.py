@@ -332,12 +332,57 @@ def main():
             extras(a, reg, params, out, flame_amd, synth, sync, info)
         except Exception as e:  # noqa: BLE001
             out["extras_error"] = f"{type(e).__name__}: {e}"
+        try:
+            out["open_run"] = open_run_block(reg, params, solver_stream)
+        except Exception as e:  # noqa: BLE001
+            out["open_run"] = f"{type(e).__name__}: {e}"
     reg.close()
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def open_run_block(reg, params, stream):
+    """flame_nltgv2_run_open on the bench's own graph: the open run's kernel instance against the plain one (4 000 iterations per launch, an open run
+    left to reach its bound) and how long an open run takes to stop once a call needs the state."""
+    import time as _t
+
+    import numpy as _np
+    import torch
+
+    if not reg.run_open(params, 64):
+        return {"applicable": False}
+    reg.sync()
+    per = {"plain": [], "open": []}
+    for _ in range(5):
+        for kind in ("plain", "open"):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            if kind == "plain":
+                reg.run_async(params, 4000)
+            else:
+                reg.run_open(params, 4000)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            reg.sync()
+            per[kind].append(e0.elapsed_time(e1) * 1e3 / 4000)
+    wall, its = [], []
+    for _ in range(12):
+        before = reg.iterations()[0]
+        reg.run_open(params, 1 << 18)
+        _t.sleep(0.0005)
+        t0 = _t.perf_counter()
+        reg.sync()
+        wall.append((_t.perf_counter() - t0) * 1e6)
+        its.append(reg.iterations()[0] - before)
+    return {"applicable": True, "plain_us_per_iteration": round(float(_np.median(per["plain"][1:])), 4),
+            "open_us_per_iteration": round(float(_np.median(per["open"][1:])), 4),
+            "stop_latency_us": round(float(_np.median(wall)), 1), "iterations_when_stopped_after_0.5_ms": [int(min(its)), int(max(its))],
+            "note": "one launch that iterates until a call needs the solver settled (the reference's solver thread is while(true) step()): a patch reads "
+                    "the host's request every 64 iterations and publishes the iteration all patches leave at (+128); stop_latency = sync() issued 0.5 ms "
+                    "after run_open, wall time until it returns; profiles/r06_holds.txt section 8"}
 
 
 def pv_step_cycles(flame_amd, g, params, iters, device):
