@@ -13,6 +13,7 @@ int fail(flame_nltgv2_ctx* ctx, int status) {
 // that grows: hipFree and the allocators wait for every stream -- asks first (the request is sent once; finish() does the checking later).
 void request_open_stop(flame_nltgv2_ctx* ctx) {
   if (!ctx->open_inflight || ctx->open_stop_sent || !ctx->stop_dev.p || !ctx->ctl_stream) return;
+  *ctx->h_stop = ctx->open_tag0;  // (the run it is for; a copy of an earlier request still under way would carry this one early: the same request)
   if (hipMemcpyAsync(ctx->stop_dev.p, ctx->h_stop, sizeof(unsigned), hipMemcpyHostToDevice, ctx->ctl_stream) != hipSuccess) (void)hipGetLastError();
   ctx->open_stop_sent = true;
 }
@@ -524,7 +525,7 @@ int flame_nltgv2_create(flame_nltgv2_ctx** out, int device) {
   ok = ok && hipHostMalloc((void**)&ctx->h_err, kErrBytes, hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->h_cost, 2 * sizeof(float), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->h_stop, 64, hipHostMallocDefault) == hipSuccess;
-  if (ctx->h_stop) *ctx->h_stop = 1u;
+  if (ctx->h_stop) *ctx->h_stop = 0u;
   ok = ok && hipStreamCreateWithPriority(&ctx->ctl_stream, hipStreamNonBlocking, -1) == hipSuccess;
   if (!ok) {
     flame_nltgv2_destroy(ctx);

@@ -356,12 +356,13 @@ struct flame_nltgv2_ctx {
   int last_expired[16] = {0};  // what the most recent expired wait reported (report_expired)
   float* h_cost = nullptr; // pinned
   uint8_t* h_keep = nullptr;  // pinned: project_graph's keep mask, written by its kernel
-  unsigned* h_stop = nullptr; // pinned: the constant 1 that finish() copies into stop_dev when the host wants the state of an open run
+  unsigned* h_stop = nullptr; // pinned: the open run's tag0, which request_open_stop copies into stop_dev when the host wants the state
   DevBuf stop_dev;            // the word an open run's deciding patch looks at (device memory: a word in host memory cost that patch -- and with it
                               // the whole lock-step network -- a PCIe round trip per two steps: 1.38 against 0.95 us per iteration)
   hipStream_t ctl_stream = nullptr;  // ... the stream of that 4-byte copy
   bool open_inflight = false; // an open run is enqueued and unchecked (the last op of ctx->pending)
   bool open_stop_sent = false; // ... and has been asked to stop (request_open_stop)
+  uint32_t open_tag0 = 0;      // ... its first tag: what a request to stop it says
   int want_open = 0;          // enqueue_run: the run being enqueued is to be an open one (flame_nltgv2_run_open sets it for its call)
   int last_open_iters = 0;    // how far the last open run went
   int64_t iters_total = 0;    // iterations applied to the state by every run since create (open runs: counted when they are settled)

@@ -102,7 +102,8 @@ __device__ __forceinline__ void report_expired(int* err, int which, int wg, int 
 // compiler's own choice, 106, it is six: "Round 3" in docs/DESIGN_r3.md section 4); the scalar spills this costs stay outside the hand-off path
 // (640x480: 0.962 against 0.962 us per iteration, profiles/r03_priority.txt (7)) and a 1080p frame's 25 patches per CU fit one launch.
 // OPEN (round 6): a run that goes on until the host needs the state.  n_iters is then an upper bound; ONE patch (the middle one of the
-// launch) looks at a word the host sets (a 4-byte copy on a stream of its own) every kOpenCheck iterations and, when it is set, publishes the iteration every
+// launch) looks at a word the host sets to this run's tag0 (a 4-byte copy on a stream of its own; a request for an earlier run means nothing, so the
+// word is never cleared) every kOpenCheck iterations and, when it says so, publishes the iteration every
 // patch leaves at -- its own plus kOpenMargin, more than any patch can be ahead of it (a patch is ahead of another by at most their
 // distance in the patch graph) -- in err[12] as tag0 + iteration (tags grow from run to run: a stale word of an earlier run is below
 // this run's tag0 and means nothing).  Every patch reads that word every kOpenCheck iterations.  A patch that saw the word too late has no neighbours left to wait for: its
@@ -621,9 +622,13 @@ k_persistent_pv(const int wg_begin, const int n_wgs, const int wgs_per_xcd, cons
       //  load, and the step's polls never wait for vmcnt, so nothing hides it.)
       if (((unsigned)it & (kOpenCheck - 1u)) == 0u) {
         if (decides && stop_at == 0u && stop_req &&
-            __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(stop_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) {
+            (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(stop_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == tag0) {
           stop_at = tag0 + (unsigned)it + kOpenMargin;
-          if (lane == 0) __hip_atomic_store(stop_word, stop_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0) {
+            __hip_atomic_store(stop_word, stop_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (taken: tags start over with every topology, the next graph's first run has this tag0 again)
+            __hip_atomic_store(const_cast<unsigned*>(stop_req), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
         if (stop_at == 0u) {
           const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(stop_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));

@@ -433,9 +433,13 @@ k_persistent_pv2(const int wg_begin, const int n_wgs, const int wgs_per_xcd, con
     for (; it + 1 < n_iters && !timed_out; it += 2) {
       if (((unsigned)it & (kOpenCheck - 1u)) == 0u) {
         if (decides && stop_at == 0u && stop_req &&
-            __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(stop_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) {
+            (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(stop_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == tag0) {
           stop_at = tag0 + (unsigned)it + kOpenMargin;
-          if (lane == 0) __hip_atomic_store(stop_word, stop_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0) {
+            __hip_atomic_store(stop_word, stop_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (taken: tags start over with every topology, the next graph's first run has this tag0 again)
+            __hip_atomic_store(const_cast<unsigned*>(stop_req), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
         if (stop_at == 0u) {
           const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(stop_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));

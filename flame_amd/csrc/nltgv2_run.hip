@@ -546,10 +546,12 @@ int enqueue_run(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, int n) {
       RunTail want;
       std::memset(static_cast<void*>(&want), 0, sizeof want);
       want.export_out = ctx->export_ptr, want.export_scale = ctx->export_scale;
-      if (open_run) {  // the request word: device memory, cleared on the solver's stream in front of the launch
+      if (open_run) {  // the request word: device memory; a request names the run it is for (its tag0), so the word is never cleared
+        const bool fresh = ctx->stop_dev.p == nullptr;
         rc = ensure(ctx, ctx->stop_dev, 64);
         if (rc) return rc;
-        HIPCHK(ctx, hipMemsetAsync(ctx->stop_dev.p, 0, sizeof(unsigned), ctx->stream));
+        if (fresh) HIPCHK(ctx, hipMemsetAsync(ctx->stop_dev.p, 0, 64, ctx->stream));
+        ctx->open_tag0 = tag0;
       }
       want.stop_req = open_run ? (const unsigned*)ctx->stop_dev.p : nullptr;
       const PhotoFuse pf = photo_target(ctx);
@@ -793,7 +795,6 @@ int finish(flame_nltgv2_ctx* ctx, bool unpack_behind, bool* unpacked, const std:
     }
   }
   HIPCHK(ctx, wait_solver_stream(ctx));
-  if (open_run) HIPCHK(ctx, hipStreamSynchronize(ctx->ctl_stream));  // (a run that reached its bound first: the request must not land in the NEXT open run's word)
   flame_nltgv2_ctx::PendingRun run;
   std::swap(run, ctx->pending);  // (ctx->pending is now inactive and empty)
   if (open_run && !run.ops.empty() && run.ops.back().open) {
@@ -953,7 +954,7 @@ int flame_nltgv2_run_open(flame_nltgv2_ctx* ctx, const flame_nltgv2_params* p, i
   if (!ctx->have_graph) return fail(ctx, FLAME_NLTGV2_ERR_NO_GRAPH);
   if (!params_ok(p) || max_iters < 0 || (max_iters & 1)) return fail(ctx, FLAME_NLTGV2_ERR_INVALID_ARG);
   if (max_iters == 0) return 0;
-  {  // applicable at all?  Asked BEFORE anything is settled: a loop that falls back to rounds must not have them waited for here
+  if (ctx->pending.active) {  // applicable at all?  Asked BEFORE anything is settled: a loop that falls back to rounds must not have them waited for here
     std::vector<WaveGroup> groups;
     int tv_lds = 0;
     const int form = plan_persistent(ctx, max_iters, &groups, &tv_lds, /*consume=*/false);

@@ -31,6 +31,7 @@ ap.add_argument("--cpu", action="store_true")
 ap.add_argument("--pipelined", action="store_true")
 ap.add_argument("--cover", type=float, default=1.25, help="--pipelined: the chunk enqueued before Delaunay + sync_prepare covers this many times their last duration")
 ap.add_argument("--host-sync", action="store_true", help="index maps + layout tables on the host (rounds 1-3), for comparison")
+ap.add_argument("--open-runs", type=int, default=1, help="--pipelined: 1 = the solver iterates in open runs (flame_nltgv2_run_open) between the calls that need its state; 0 = launches of a guessed length")
 ap.add_argument("--mesh-state", type=int, default=1, help="--pipelined: FLAME_NLTGV2_OPT_MESH_STATE; 1 = the mesh of a frame is of the state sync_commit left, begun beside the chunk enqueued behind the commit (0: it settles that chunk first)")
 a = ap.parse_args()
 W, H = [int(v) for v in a.size.split("x")]
@@ -127,15 +128,21 @@ else:
 
     iters_done = []
 
-    def solve(ms, label=""):  # one launch of about `ms` of iterations; label: what stood between the previous launch and this one
+    def solve(ms, label="", closed=False):  # one launch of about `ms` of iterations; label: what stood between the previous launch and this one
+        # --open-runs 1: ONE open run instead (flame_nltgv2_run_open: it iterates until the next call that needs the state asks it to stop --
+        # no guess at how long the host will take); a call while one is in flight does nothing
+        if a.open_runs and not closed and reg.iterations()[1]:
+            return
         n = max(a.iters // 4, int(round(ms / chunk_ms * a.iters / 50.0)) * 50)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        before = reg.iterations()[0]
         e0.record(stream)
-        reg.run_async(P, n)
+        if not (a.open_runs and not closed and reg.run_open(P, 1 << 13)):
+            reg.run_async(P, n)
         e1.record(stream)
         events.append((e0, e1))
         labels.append(label)
-        iters_done.append(n)
+        iters_done.append(before)  # (open runs: the library's count when the launch went out; differences are taken when the loop prints)
 
     tr.add_frame(news[0], imgs[news[0]])
     tr.update_feature_idepths(SP, news[0], 11, ss.poses_for(sc, [10, 11], news[0], 11), feats)
@@ -150,7 +157,8 @@ else:
     torch.cuda.synchronize()
     chunk_ms = 1.0
     for _ in range(3):
-        solve(0.0)
+        solve(0.0, closed=True)
+    reg.sync()
     torch.cuda.synchronize()
     chunk_ms = min(e0.elapsed_time(e1) for e0, e1 in events) * 4  # --iters iterations on this graph, in ms (the probe ran iters / 4)
     reg.set_option(flame_amd.regularizer.OPT_MESH_STATE, a.mesh_state)
@@ -197,7 +205,7 @@ else:
     for i, (wall, e_a, e_b, host, commit) in enumerate(rows):
         busy = sum(e0.elapsed_time(e1) for e0, e1 in events[e_a:e_b])
         idle = max(0.0, wall - busy)
-        n_it = sum(iters_done[e_a:e_b])
+        n_it = (iters_done[e_b] if e_b < len(iters_done) else reg.iterations()[0]) - iters_done[e_a]
         print("  %5d  %8.3f  %15.3f  %8.3f  %7.1f  %11d  %22.3f  %14.3f" % (i + 1, wall, busy, idle, 100 * idle / wall, n_it, host, commit))
         if i >= 1:
             tot.append((wall, busy, idle, n_it))
